@@ -1,0 +1,922 @@
+// C ABI of libakaze_hip.so (declared in include/akaze_hip.h): context, per-op entry points and
+// the extract_features / descriptor_match orchestration.  The host owns the evolution pyramid
+// (plan, plane addresses, ping-pong parity) and enqueues the gfx950 kernels on one HIP stream.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <type_traits>
+
+#include "akz_internal.hpp"
+
+namespace akz {
+const std::string& get_error();
+}
+using namespace akz;
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+struct akz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf scratch[6];                       // f32 plane temporaries (largest level x batch)
+    DevBuf small;                            // hmax bits / histogram / counters
+    DevBuf cand;                             // NMS candidates
+    DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
+    DevBuf match_a, match_b, match_rec, match_out;
+    std::vector<std::pair<size_t, void*>> slab_pool;  // freed pyramid slabs, reused by size
+};
+
+static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return AKZ_OK;
+    if (b.p) {
+        AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+        AKZ_HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    AKZ_HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return AKZ_OK;
+}
+static int bind(akz_ctx* c) {
+    if (!c) {
+        set_error("null context");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    return AKZ_OK;
+}
+
+extern "C" {
+
+int akz_abi_version(void) { return AKZ_ABI_VERSION; }
+const char* akz_last_error(void) { return get_error().c_str(); }
+
+void akz_config_default(akz_config* o) {
+    if (!o) return;
+    o->num_sublevels = 4;
+    o->max_octave_evolution = 4;
+    o->base_scale_offset = 1.6;
+    o->initial_contrast = 0.001;
+    o->contrast_percentile = 0.7;
+    o->contrast_factor_num_bins = 300;
+    o->derivative_factor = 1.5;
+    o->detector_threshold = 0.001;
+    o->descriptor_channels = 3;
+    o->descriptor_pattern_size = 10;
+}
+
+int akz_ctx_create(int device, void* stream, akz_ctx** out) {
+    if (!out) {
+        set_error("akz_ctx_create: null out");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device visible: the A-KAZE HIP path cannot run (there is no CPU fallback)");
+        return AKZ_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device index out of range");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    AKZ_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("libakaze_hip.so carries gfx950 code only; device is ") + prop.gcnArchName);
+        return AKZ_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<akz_ctx> c(new akz_ctx);
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    *out = c.release();
+    return AKZ_OK;
+}
+
+int akz_ctx_destroy(akz_ctx* c) {
+    if (!c) return AKZ_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
+                      &c->small, &c->cand, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
+                      &c->match_out};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& s : c->slab_pool) (void)hipFree(s.second);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return AKZ_OK;
+}
+int akz_ctx_synchronize(akz_ctx* c) {
+    AKZ_TRY(bind(c));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    return AKZ_OK;
+}
+void* akz_ctx_stream(akz_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int akz_device_malloc(akz_ctx* c, size_t bytes, void** d_out) {
+    AKZ_TRY(bind(c));
+    if (!d_out) return AKZ_ERR_INVALID_ARG;
+    AKZ_HIP_TRY(hipMalloc(d_out, bytes ? bytes : 1));
+    return AKZ_OK;
+}
+int akz_device_free(akz_ctx* c, void* d_ptr) {
+    AKZ_TRY(bind(c));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    AKZ_HIP_TRY(hipFree(d_ptr));
+    return AKZ_OK;
+}
+int akz_memcpy_h2d(akz_ctx* c, void* d_dst, const void* src, size_t bytes) {
+    AKZ_TRY(bind(c));
+    AKZ_HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    return AKZ_OK;
+}
+int akz_memcpy_d2h(akz_ctx* c, void* dst, const void* d_src, size_t bytes) {
+    AKZ_TRY(bind(c));
+    AKZ_HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    return AKZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side planning
+// ---------------------------------------------------------------------------------------------
+int akz_fed_tau_by_process_time(double T, int M, double tau_max, int reordering, double* out, uint64_t cap,
+                                uint64_t* n) {
+    if (M <= 0 || !(tau_max > 0.0)) {
+        set_error("fed_tau: M and tau_max must be positive");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    std::vector<double> tau;
+    AKZ_TRY(fed_tau_by_process_time(T, M, tau_max, reordering != 0, tau));
+    if (n) *n = tau.size();
+    if (out)
+        for (size_t i = 0; i < tau.size() && i < cap; ++i) out[i] = tau[i];
+    return AKZ_OK;
+}
+int akz_gaussian_kernel(float sigma, uint64_t kernel_size, float* out) {
+    if (!out || kernel_size == 0 || kernel_size % 2 == 0) {
+        set_error("gaussian_kernel: odd kernel_size and non-null out required");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const std::vector<float> k = gaussian_kernel(sigma, (size_t)kernel_size);
+    std::memcpy(out, k.data(), k.size() * sizeof(float));
+    return AKZ_OK;
+}
+int akz_scharr_kernels(uint32_t scale, float* main_axis, float* off_axis) {
+    if (scale == 0 || !main_axis || !off_axis) {
+        set_error("scharr_kernels: scale >= 1 and non-null outputs required");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    std::vector<float> m, o;
+    scharr_kernels(scale, m, o);
+    std::memcpy(main_axis, m.data(), m.size() * sizeof(float));
+    std::memcpy(off_axis, o.data(), o.size() * sizeof(float));
+    return AKZ_OK;
+}
+int akz_plan_num_levels(uint32_t w, uint32_t h, const akz_config* cfg, uint64_t* n_levels) {
+    if (!cfg || !n_levels) return AKZ_ERR_INVALID_ARG;
+    std::vector<LevelPlan> plan;
+    AKZ_TRY(build_plan(w, h, *cfg, plan));
+    *n_levels = plan.size();
+    return AKZ_OK;
+}
+static int level_info_out(const std::vector<LevelPlan>& plan, uint64_t level, double* etime, double* esigma,
+                          uint32_t* octave, uint32_t* sublevel, uint32_t* sigma_size, uint32_t* lw, uint32_t* lh,
+                          uint32_t* det_sigma, uint64_t* n_tau, double* tau, uint64_t tau_cap) {
+    if (level >= plan.size()) {
+        set_error("level out of range");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const LevelPlan& lv = plan[(size_t)level];
+    if (etime) *etime = lv.etime;
+    if (esigma) *esigma = lv.esigma;
+    if (octave) *octave = lv.octave;
+    if (sublevel) *sublevel = lv.sublevel;
+    if (sigma_size) *sigma_size = lv.sigma_size;
+    if (lw) *lw = lv.w;
+    if (lh) *lh = lv.h;
+    if (det_sigma) *det_sigma = lv.det_sigma;
+    if (n_tau) *n_tau = lv.tau.size();
+    if (tau)
+        for (size_t i = 0; i < lv.tau.size() && i < tau_cap; ++i) tau[i] = lv.tau[i];
+    return AKZ_OK;
+}
+int akz_plan_level_info(uint32_t w, uint32_t h, const akz_config* cfg, uint64_t level, double* etime, double* esigma,
+                        uint32_t* octave, uint32_t* sublevel, uint32_t* sigma_size, uint32_t* level_w,
+                        uint32_t* level_h, uint32_t* detector_sigma, uint64_t* n_tau, double* tau, uint64_t tau_cap) {
+    if (!cfg) return AKZ_ERR_INVALID_ARG;
+    std::vector<LevelPlan> plan;
+    AKZ_TRY(build_plan(w, h, *cfg, plan));
+    return level_info_out(plan, level, etime, esigma, octave, sublevel, sigma_size, level_w, level_h, detector_sigma,
+                          n_tau, tau, tau_cap);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// per-op entry points
+// ---------------------------------------------------------------------------------------------
+static int check_plane_args(const void* a, const void* b, uint32_t w, uint32_t h, uint32_t n, int hw) {
+    if (!a || !b || w == 0 || h == 0 || n == 0) {
+        set_error("null plane pointer or empty image");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    if ((int)w < 2 * hw + 1 || (int)h < 2 * hw + 1) {
+        set_error("image smaller than the filter kernel");
+        return AKZ_ERR_TOO_SMALL;
+    }
+    return AKZ_OK;
+}
+static size_t plane_bytes(uint32_t w, uint32_t h, uint32_t n) { return (size_t)w * h * n * sizeof(float); }
+
+template <typename T>
+static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                              float sigma) {
+    const size_t ks = gaussian_kernel_size(sigma);
+    if (ks > (size_t)kMaxTaps || !(sigma > 0.0f)) {
+        set_error("gaussian_blur: sigma must be in (0, 6]");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const std::vector<float> k = gaussian_kernel(sigma, ks);
+    Taps t;
+    AKZ_TRY(taps_from_dense(k.data(), (uint32_t)k.size(), t));
+    AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
+    AKZ_TRY(ensure(c, c->scratch[0], plane_bytes(w, h, n)));
+    float* tmp = (float*)c->scratch[0].p;
+    if constexpr (std::is_same<T, uint8_t>::value) launch::filter_h_u8(c->stream, d_in, tmp, w, h, n, t);
+    else launch::filter_h_f32(c->stream, d_in, tmp, w, h, n, t);
+    launch::filter_v_f32(c->stream, tmp, d_out, w, h, n, t);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+
+// scharr_horizontal / scharr_vertical (derivatives.rs:41-65) through scratch[0]
+static int scharr_impl(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n, bool x_order,
+                       uint32_t sigma) {
+    const Taps tm = taps_scharr_main(sigma), to = taps_scharr_off(sigma);
+    AKZ_TRY(ensure(c, c->scratch[0], plane_bytes(w, h, n)));
+    float* tmp = (float*)c->scratch[0].p;
+    launch::filter_h_f32(c->stream, d_in, tmp, w, h, n, x_order ? tm : to);
+    launch::filter_v_f32(c->stream, tmp, d_out, w, h, n, x_order ? to : tm);
+    return AKZ_OK;
+}
+
+static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile,
+                         double gscale, uint64_t nbins, double* d_k_out) {
+    if (nbins == 0 || nbins > 4096) {
+        set_error("contrast_factor: num_bins must be in 1..4096");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    if (w < 5 || h < 5) {
+        set_error("contrast_factor: image too small");
+        return AKZ_ERR_TOO_SMALL;
+    }
+    AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
+    float* blurred = (float*)c->scratch[1].p;
+    AKZ_TRY(gaussian_blur_impl<float>(c, d_in, blurred, w, h, n, (float)gscale));
+    const size_t small_bytes = (size_t)n * (8 + nbins * 4);
+    AKZ_TRY(ensure(c, c->small, small_bytes));
+    unsigned long long* d_hmax = (unsigned long long*)c->small.p;
+    uint32_t* d_hist = (uint32_t*)((char*)c->small.p + (size_t)n * 8);
+    AKZ_HIP_TRY(hipMemsetAsync(c->small.p, 0, small_bytes, c->stream));
+    launch::contrast_max(c->stream, blurred, w, h, n, d_hmax);
+    launch::contrast_hist(c->stream, blurred, w, h, n, d_hmax, (uint32_t)nbins, d_hist);
+    launch::contrast_final(c->stream, d_hmax, d_hist, (uint32_t)nbins, percentile, n, d_k_out);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+
+// calculate_step x n_tau with ping-pong between `a` and `b`; the input is in `a`.  Returns the
+// buffer holding the result through *result.
+static int fed_impl(akz_ctx* c, float* a, float* b, const float* lflow, float* lstep, uint32_t w, uint32_t h,
+                    uint32_t n, const double* taus, uint32_t n_tau, float** result) {
+    float* cur = a;
+    float* oth = b;
+    for (uint32_t j = 0; j < n_tau; ++j) {
+        const float half_tau = 0.5f * (float)taus[j];
+        launch::fed_step(c->stream, cur, lflow, oth, (j + 1 == n_tau) ? lstep : nullptr, w, h, n, half_tau);
+        std::swap(cur, oth);
+    }
+    *result = cur;
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+
+static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
+                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n) {
+    if (sigma == 0 || 2 * sigma + 1 > (uint32_t)kMaxTaps) {
+        set_error("detector_response: sigma_size must be in 1..6");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_TRY(check_plane_args(lsmooth, ldet_out, w, h, n, (int)sigma));
+    const size_t pb = plane_bytes(w, h, n);
+    if (!lxx) { AKZ_TRY(ensure(c, c->scratch[2], pb)); lxx = (float*)c->scratch[2].p; }
+    if (!lyy) { AKZ_TRY(ensure(c, c->scratch[3], pb)); lyy = (float*)c->scratch[3].p; }
+    if (!lxy) { AKZ_TRY(ensure(c, c->scratch[4], pb)); lxy = (float*)c->scratch[4].p; }
+    AKZ_TRY(scharr_impl(c, lsmooth, lx, w, h, n, true, sigma));   // Lx  = scharr(Lsmooth, x)
+    AKZ_TRY(scharr_impl(c, lsmooth, ly, w, h, n, false, sigma));  // Ly  = scharr(Lsmooth, y)
+    AKZ_TRY(scharr_impl(c, lx, lxx, w, h, n, true, sigma));       // Lxx = scharr(Lx, x)
+    AKZ_TRY(scharr_impl(c, ly, lyy, w, h, n, false, sigma));      // Lyy = scharr(Ly, y)
+    AKZ_TRY(scharr_impl(c, lx, lxy, w, h, n, false, sigma));      // Lxy = scharr(Lx, y)
+    const uint32_t quat = sigma * sigma * sigma * sigma;
+    launch::ldet(c->stream, lxx, lyy, lxy, ldet_out, (uint64_t)w * h * n, (float)quat);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+
+extern "C" {
+
+int akz_op_horizontal_filter(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                             const float* taps, uint32_t ntaps) {
+    AKZ_TRY(bind(c));
+    Taps t;
+    AKZ_TRY(taps_from_dense(taps, ntaps, t));
+    AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
+    launch::filter_h_f32(c->stream, d_in, d_out, w, h, n, t);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+int akz_op_vertical_filter(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                           const float* taps, uint32_t ntaps) {
+    AKZ_TRY(bind(c));
+    Taps t;
+    AKZ_TRY(taps_from_dense(taps, ntaps, t));
+    AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
+    launch::filter_v_f32(c->stream, d_in, d_out, w, h, n, t);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+int akz_op_gaussian_blur(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                         float sigma) {
+    AKZ_TRY(bind(c));
+    return gaussian_blur_impl<float>(c, d_in, d_out, w, h, n, sigma);
+}
+int akz_op_gaussian_blur_u8(akz_ctx* c, const uint8_t* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                            float sigma) {
+    AKZ_TRY(bind(c));
+    return gaussian_blur_impl<uint8_t>(c, d_in, d_out, w, h, n, sigma);
+}
+int akz_op_half_size(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n) {
+    AKZ_TRY(bind(c));
+    AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, 0));
+    if (w < 2 || h < 2) {
+        set_error("half_size: image smaller than 2x2");
+        return AKZ_ERR_TOO_SMALL;
+    }
+    launch::half_size(c->stream, d_in, d_out, w, h, n);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+int akz_op_scharr(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n, int x_order,
+                  int y_order, uint32_t sigma) {
+    AKZ_TRY(bind(c));
+    if ((x_order != 0) == (y_order != 0)) {
+        set_error("scharr: exactly one of x_order / y_order must be set (the pipeline never uses the others)");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    if (sigma == 0 || 2 * sigma + 1 > (uint32_t)kMaxTaps) {
+        set_error("scharr: sigma_size must be in 1..6");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, (int)sigma));
+    AKZ_TRY(scharr_impl(c, d_in, d_out, w, h, n, x_order != 0, sigma));
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+int akz_op_pm_g2(akz_ctx* c, const float* d_lx, const float* d_ly, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                 const double* d_k) {
+    AKZ_TRY(bind(c));
+    AKZ_TRY(check_plane_args(d_lx, d_out, w, h, n, 0));
+    if (!d_ly || !d_k) return AKZ_ERR_INVALID_ARG;
+    launch::pm_g2(c->stream, d_lx, d_ly, d_out, w, h, n, d_k, 0);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+int akz_op_contrast_factor(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile,
+                           double gscale, uint64_t num_bins, double* d_k_out) {
+    AKZ_TRY(bind(c));
+    if (!d_in || !d_k_out || n == 0) return AKZ_ERR_INVALID_ARG;
+    return contrast_impl(c, d_in, w, h, n, percentile, gscale, num_bins, d_k_out);
+}
+int akz_op_flow(akz_ctx* c, const float* d_lsmooth, float* d_lflow, uint32_t w, uint32_t h, uint32_t n,
+                const double* d_k, uint32_t k_scale_pow) {
+    AKZ_TRY(bind(c));
+    AKZ_TRY(check_plane_args(d_lsmooth, d_lflow, w, h, n, 1));
+    if (!d_k) return AKZ_ERR_INVALID_ARG;
+    launch::flow(c->stream, d_lsmooth, d_lflow, w, h, n, d_k, k_scale_pow);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+int akz_op_fed_steps(akz_ctx* c, float* d_lt, const float* d_lflow, float* d_lstep, uint32_t w, uint32_t h,
+                     uint32_t n, const double* taus, uint32_t n_tau) {
+    AKZ_TRY(bind(c));
+    AKZ_TRY(check_plane_args(d_lt, d_lflow, w, h, n, 1));
+    if (n_tau && !taus) return AKZ_ERR_INVALID_ARG;
+    AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(w, h, n)));
+    float* res = nullptr;
+    AKZ_TRY(fed_impl(c, d_lt, (float*)c->scratch[5].p, d_lflow, d_lstep, w, h, n, taus, n_tau, &res));
+    if (res != d_lt)
+        AKZ_HIP_TRY(hipMemcpyAsync(d_lt, res, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
+    return AKZ_OK;
+}
+int akz_op_detector_response(akz_ctx* c, const float* d_lsmooth, uint32_t sigma_size, float* d_lx, float* d_ly,
+                             float* d_lxx, float* d_lyy, float* d_lxy, float* d_ldet, uint32_t w, uint32_t h,
+                             uint32_t n) {
+    AKZ_TRY(bind(c));
+    if (!d_lx || !d_ly) return AKZ_ERR_INVALID_ARG;
+    return detector_impl(c, d_lsmooth, sigma_size, d_lx, d_ly, d_lxx, d_lyy, d_lxy, d_ldet, w, h, n);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// extract_features
+// ---------------------------------------------------------------------------------------------
+struct akz_result {
+    akz_ctx* ctx = nullptr;
+    akz_config cfg;
+    uint32_t w = 0, h = 0, n = 0, flags = 0;
+    std::vector<LevelPlan> plan;
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    float* planes[kMaxLevels][10];  // image 0 of the batch; stride = level w*h
+    double* d_k = nullptr;          // inside the slab
+    std::vector<double> k_host;
+    std::vector<std::vector<akz_keypoint>> kps;
+    std::vector<std::vector<uint8_t>> desc;  // unpadded, host
+    uint8_t* d_desc64 = nullptr;             // all images back to back, 64-byte rows
+    std::vector<uint64_t> desc_off;          // first row of each image in d_desc64
+    std::vector<uint64_t> n_extrema;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
+    for (size_t i = 0; i < c->slab_pool.size(); ++i)
+        if (c->slab_pool[i].first >= bytes && c->slab_pool[i].first <= bytes + bytes / 4) {
+            *p = c->slab_pool[i].second;
+            *got = c->slab_pool[i].first;
+            c->slab_pool.erase(c->slab_pool.begin() + (long)i);
+            return AKZ_OK;
+        }
+    AKZ_HIP_TRY(hipMalloc(p, bytes));
+    *got = bytes;
+    return AKZ_OK;
+}
+static void slab_release(akz_ctx* c, void* p, size_t bytes) {
+    if (c->slab_pool.size() >= 4) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(c->slab_pool.front().second);
+        c->slab_pool.erase(c->slab_pool.begin());
+    }
+    c->slab_pool.emplace_back(bytes, p);
+}
+
+template <typename T>
+static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
+                        uint32_t flags, akz_result** out) {
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    AKZ_TRY(bind(c));
+    if (!d_imgs || !cfgp || n == 0) {
+        set_error("extract: null image/config or empty batch");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    std::unique_ptr<akz_result> r(new akz_result);
+    r->ctx = c;
+    r->cfg = *cfgp;
+    r->w = w; r->h = h; r->n = n; r->flags = flags;
+    AKZ_TRY(build_plan(w, h, r->cfg, r->plan));
+    const akz_config& cfg = r->cfg;
+    const std::vector<LevelPlan>& plan = r->plan;
+    const size_t L = plan.size();
+    const bool keep_all = (flags & AKZ_KEEP_ALL_PLANES) != 0;
+    hipStream_t s = c->stream;
+
+    // ---- pyramid slab layout ----
+    std::memset(r->planes, 0, sizeof(r->planes));
+    size_t off = 0;
+    std::vector<std::pair<float**, size_t>> fix;  // (slot, offset)
+    auto want = [&](size_t lvl, int plane) {
+        const size_t bytes = align_up(plane_bytes(plan[lvl].w, plan[lvl].h, n), 256);
+        fix.emplace_back(&r->planes[lvl][plane], off);
+        off += bytes;
+    };
+    for (size_t l = 0; l < L; ++l) {
+        want(l, AKZ_LT);
+        if (l > 0) want(l, AKZ_LSMOOTH);  // level 0: Lsmooth is a clone of Lt (lib.rs:58) -> alias
+        want(l, AKZ_LX);
+        want(l, AKZ_LY);
+        want(l, AKZ_LDET);
+        if (l > 0) want(l, AKZ_LFLOW);
+        if (keep_all) {
+            want(l, AKZ_LXX);
+            want(l, AKZ_LYY);
+            want(l, AKZ_LXY);
+            if (l > 0) want(l, AKZ_LSTEP);
+        }
+    }
+    const size_t k_off = off;
+    off += align_up((size_t)n * sizeof(double), 256);
+    AKZ_TRY(slab_acquire(c, off, &r->slab, &r->slab_bytes));
+    for (auto& f : fix) *f.first = (float*)((char*)r->slab + f.second);
+    r->planes[0][AKZ_LSMOOTH] = r->planes[0][AKZ_LT];
+    r->d_k = (double*)((char*)r->slab + k_off);
+    auto P = [&](size_t l, int p) { return r->planes[l][p]; };
+    struct SlabGuard {  // return the slab to the pool on any early error exit
+        akz_result* r;
+        bool armed = true;
+        ~SlabGuard() {
+            if (armed && r->slab) {
+                slab_release(r->ctx, r->slab, r->slab_bytes);
+                r->slab = nullptr;
+            }
+        }
+    } guard{r.get()};
+
+    // ---- level 0: Lt0 = gaussian_blur(img, base_scale_offset); contrast factor (lib.rs:56-69) ----
+    AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));
+    AKZ_TRY(contrast_impl(c, P(0, AKZ_LSMOOTH), w, h, n, cfg.contrast_percentile, 1.0, cfg.contrast_factor_num_bins,
+                          r->d_k));
+
+    // ---- levels 1..L-1 (lib.rs:78-119) ----
+    uint32_t max_w = w, max_h = h;
+    AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(max_w, max_h, n)));
+    for (size_t i = 1; i < L; ++i) {
+        const LevelPlan& lv = plan[i];
+        const LevelPlan& pv = plan[i - 1];
+        float* A = P(i, AKZ_LT);
+        float* B = (float*)c->scratch[5].p;
+        const uint32_t n_tau = (uint32_t)lv.tau.size();
+        float* start = (n_tau % 2 == 0) ? A : B;  // so that the last step lands in the Lt plane
+        if (lv.octave > pv.octave) {
+            launch::half_size(s, P(i - 1, AKZ_LT), start, pv.w, pv.h, n);
+        } else {
+            AKZ_HIP_TRY(hipMemcpyAsync(start, P(i - 1, AKZ_LT), plane_bytes(lv.w, lv.h, n), hipMemcpyDeviceToDevice,
+                                       s));
+        }
+        AKZ_TRY(gaussian_blur_impl<float>(c, start, P(i, AKZ_LSMOOTH), lv.w, lv.h, n, 1.0f));
+        launch::flow(s, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h, n, r->d_k, lv.octave);
+        float* lstep = keep_all ? P(i, AKZ_LSTEP) : nullptr;
+        if (lstep && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep, 0, plane_bytes(lv.w, lv.h, n), s));
+        float* res = nullptr;
+        AKZ_TRY(fed_impl(c, start, start == A ? B : A, P(i, AKZ_LFLOW), lstep, lv.w, lv.h, n, lv.tau.data(), n_tau,
+                         &res));
+        if (res != A) {
+            set_error("internal: FED ping-pong parity");
+            return AKZ_ERR_HIP;
+        }
+    }
+
+    // ---- detector response (detector_response.rs:38-55) + NMS candidates ----
+    uint32_t cap = 1u << 17;
+    std::vector<std::vector<Candidate>> cands(n);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        AKZ_TRY(ensure(c, c->cand, (size_t)n * cap * sizeof(Candidate)));
+        AKZ_TRY(ensure(c, c->small, (size_t)n * sizeof(uint32_t)));
+        uint32_t* d_count = (uint32_t*)c->small.p;
+        AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)n * sizeof(uint32_t), s));
+        for (size_t l = 0; l < L; ++l) {
+            const LevelPlan& lv = plan[l];
+            if (attempt == 0)
+                AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
+                                      P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n));
+            launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l,
+                        (float)cfg.detector_threshold, border_margin(lv, cfg), (Candidate*)c->cand.p, cap, d_count);
+        }
+        AKZ_HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> counts(n);
+        AKZ_HIP_TRY(hipMemcpyAsync(counts.data(), d_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AKZ_HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t mx = *std::max_element(counts.begin(), counts.end());
+        if (mx > cap) {  // overflow: grow and redo the NMS pass only
+            cap = mx + mx / 8;
+            continue;
+        }
+        for (uint32_t img = 0; img < n; ++img) {
+            cands[img].resize(counts[img]);
+            if (counts[img])
+                AKZ_HIP_TRY(hipMemcpyAsync(cands[img].data(), (Candidate*)c->cand.p + (size_t)img * cap,
+                                           (size_t)counts[img] * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+        }
+        AKZ_HIP_TRY(hipStreamSynchronize(s));
+        cap = 0;
+        break;
+    }
+    if (cap != 0) {
+        set_error("NMS candidate buffer overflow");
+        return AKZ_ERR_OVERFLOW;
+    }
+
+    // ---- host: raster order, sequential cache logic, refinement ----
+    std::vector<std::vector<HostKeypoint>> hk(n);
+    r->n_extrema.assign(n, 0);
+    uint64_t total_kp = 0;
+    r->desc_off.assign(n + 1, 0);
+    for (uint32_t img = 0; img < n; ++img) {
+        std::sort(cands[img].begin(), cands[img].end(), [](const Candidate& a, const Candidate& b) {
+            return a.level != b.level ? a.level < b.level : a.idx < b.idx;
+        });
+        select_keypoints(cands[img], plan, cfg, hk[img], &r->n_extrema[img]);
+        r->desc_off[img] = total_kp;
+        total_kp += hk[img].size();
+    }
+    r->desc_off[n] = total_kp;
+
+    // ---- orientation (device sums + host atan2f) and M-LDB descriptors ----
+    LevelTable tab;
+    std::memset(&tab, 0, sizeof(tab));
+    for (size_t l = 0; l < L; ++l) {
+        tab.lv[l].lt = P(l, AKZ_LT);
+        tab.lv[l].lx = P(l, AKZ_LX);
+        tab.lv[l].ly = P(l, AKZ_LY);
+        tab.lv[l].w = plan[l].w;
+        tab.lv[l].h = plan[l].h;
+        tab.lv[l].stride = (uint64_t)plan[l].w * plan[l].h;
+    }
+    std::vector<KpParam> params(total_kp);
+    for (uint32_t img = 0; img < n; ++img)
+        for (size_t i = 0; i < hk[img].size(); ++i) {
+            const HostKeypoint& k = hk[img][i];
+            KpParam& p = params[r->desc_off[img] + i];
+            const float ratio = (float)(1u << k.octave);
+            p.xf = k.x / ratio;
+            p.yf = k.y / ratio;
+            p.scale = std::round(0.5f * k.size / ratio);
+            p.co = 1.0f; p.si = 0.0f;
+            p.level = k.class_id;
+            p._pad[0] = p._pad[1] = 0;
+        }
+    const uint32_t desc_bytes = (uint32_t)(((6 + 36 + 120) * cfg.descriptor_channels + 7) / 8);
+    r->kps.assign(n, {});
+    r->desc.assign(n, {});
+    AKZ_TRY(ensure(c, c->kp_in, std::max<size_t>(1, total_kp) * sizeof(KpParam)));
+    AKZ_TRY(ensure(c, c->kp_out, std::max<size_t>(1, total_kp) * std::max(sizeof(OrientOut), (size_t)64)));
+    if (total_kp) {
+        unsigned long long wmask = 0;
+        uint32_t nwin = 0;
+        orientation_windows(&wmask, &nwin);
+        KpParam* d_kp = (KpParam*)c->kp_in.p;
+        OrientOut* d_oo = (OrientOut*)c->kp_out.p;
+        AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params.data(), total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+        for (uint32_t img = 0; img < n; ++img)
+            launch::orientation(s, tab, img, d_kp + r->desc_off[img], (uint32_t)hk[img].size(), wmask, nwin,
+                                d_oo + r->desc_off[img]);
+        AKZ_HIP_TRY(hipGetLastError());
+        std::vector<OrientOut> oo(total_kp);
+        AKZ_HIP_TRY(hipMemcpyAsync(oo.data(), d_oo, total_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+        AKZ_HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t img = 0; img < n; ++img)
+            for (size_t i = 0; i < hk[img].size(); ++i) {
+                const size_t g = r->desc_off[img] + i;
+                HostKeypoint& k = hk[img][i];
+                k.angle = oo[g].found ? atan2f(oo[g].sum_y, oo[g].sum_x) : 0.0f;  // scale_space_extrema.rs:326
+                params[g].co = cosf(k.angle);                                      // descriptors.rs:55-56
+                params[g].si = sinf(k.angle);
+            }
+        AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params.data(), total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+        // descriptors live in the slab-independent buffer owned by the result
+        AKZ_HIP_TRY(hipMalloc((void**)&r->d_desc64, total_kp * 64));
+        for (uint32_t img = 0; img < n; ++img)
+            launch::mldb(s, tab, img, d_kp + r->desc_off[img], (uint32_t)hk[img].size(),
+                         (uint32_t)cfg.descriptor_channels, (uint32_t)cfg.descriptor_pattern_size,
+                         r->d_desc64 + r->desc_off[img] * 64);
+        AKZ_HIP_TRY(hipGetLastError());
+        if (!(flags & AKZ_NO_HOST_DESCRIPTORS)) {
+            std::vector<uint8_t> rows(total_kp * 64);
+            AKZ_HIP_TRY(hipMemcpyAsync(rows.data(), r->d_desc64, rows.size(), hipMemcpyDeviceToHost, s));
+            AKZ_HIP_TRY(hipStreamSynchronize(s));
+            for (uint32_t img = 0; img < n; ++img) {
+                r->desc[img].resize(hk[img].size() * desc_bytes);
+                for (size_t i = 0; i < hk[img].size(); ++i)
+                    std::memcpy(&r->desc[img][i * desc_bytes], &rows[(r->desc_off[img] + i) * 64], desc_bytes);
+            }
+        } else {
+            AKZ_HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
+    for (uint32_t img = 0; img < n; ++img) {
+        r->kps[img].resize(hk[img].size());
+        for (size_t i = 0; i < hk[img].size(); ++i) {
+            const HostKeypoint& k = hk[img][i];
+            r->kps[img][i] = akz_keypoint{k.x, k.y, k.response, k.size, k.octave, k.class_id, k.angle, 0};
+        }
+    }
+    r->k_host.assign(n, 0.0);
+    AKZ_HIP_TRY(hipMemcpyAsync(r->k_host.data(), r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    AKZ_HIP_TRY(hipStreamSynchronize(s));
+    guard.armed = false;
+    *out = r.release();
+    return AKZ_OK;
+}
+
+template <typename T>
+static int extract_host(akz_ctx* c, const T* img, uint32_t w, uint32_t h, const akz_config* cfg, uint32_t flags,
+                        akz_result** out) {
+    AKZ_TRY(bind(c));
+    if (!img || w == 0 || h == 0) {
+        set_error("extract: null or empty image");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const size_t bytes = (size_t)w * h * sizeof(T);
+    AKZ_TRY(ensure(c, c->scratch[4], bytes));
+    AKZ_HIP_TRY(hipMemcpyAsync(c->scratch[4].p, img, bytes, hipMemcpyHostToDevice, c->stream));
+    // scratch[4] is also the Lxy temporary of the detector; the frame is consumed by level 0 long
+    // before that on the same stream.
+    return extract_impl<T>(c, (const T*)c->scratch[4].p, w, h, 1, cfg, flags, out);
+}
+
+extern "C" {
+
+int akz_extract_gray_u8(akz_ctx* c, const uint8_t* img, uint32_t w, uint32_t h, const akz_config* cfg, uint32_t flags,
+                        akz_result** out) {
+    return extract_host<uint8_t>(c, img, w, h, cfg, flags, out);
+}
+int akz_extract_gray_f32(akz_ctx* c, const float* img, uint32_t w, uint32_t h, const akz_config* cfg, uint32_t flags,
+                         akz_result** out) {
+    return extract_host<float>(c, img, w, h, cfg, flags, out);
+}
+int akz_extract_device_u8(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                          const akz_config* cfg, uint32_t flags, akz_result** out) {
+    return extract_impl<uint8_t>(c, d_imgs, w, h, n, cfg, flags, out);
+}
+int akz_extract_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                           const akz_config* cfg, uint32_t flags, akz_result** out) {
+    return extract_impl<float>(c, d_imgs, w, h, n, cfg, flags, out);
+}
+
+int akz_result_free(akz_result* r) {
+    if (!r) return AKZ_OK;
+    (void)hipSetDevice(r->ctx->device);
+    if (r->d_desc64) {
+        (void)hipStreamSynchronize(r->ctx->stream);
+        (void)hipFree(r->d_desc64);
+    }
+    if (r->slab) slab_release(r->ctx, r->slab, r->slab_bytes);
+    delete r;
+    return AKZ_OK;
+}
+int akz_result_num_images(const akz_result* r, uint64_t* n) {
+    if (!r || !n) return AKZ_ERR_INVALID_ARG;
+    *n = r->n;
+    return AKZ_OK;
+}
+static int check_img(const akz_result* r, uint64_t img) {
+    if (!r || img >= r->n) {
+        set_error("null result or image index out of range");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    return AKZ_OK;
+}
+int akz_result_counts(const akz_result* r, uint64_t img, uint64_t* n_levels, uint64_t* n_keypoints,
+                      uint64_t* desc_bytes) {
+    AKZ_TRY(check_img(r, img));
+    if (n_levels) *n_levels = r->plan.size();
+    if (n_keypoints) *n_keypoints = r->kps[(size_t)img].size();
+    if (desc_bytes) *desc_bytes = ((6 + 36 + 120) * r->cfg.descriptor_channels + 7) / 8;
+    return AKZ_OK;
+}
+int akz_result_keypoints(const akz_result* r, uint64_t img, akz_keypoint* out) {
+    AKZ_TRY(check_img(r, img));
+    const auto& k = r->kps[(size_t)img];
+    if (!k.empty()) {
+        if (!out) return AKZ_ERR_INVALID_ARG;
+        std::memcpy(out, k.data(), k.size() * sizeof(akz_keypoint));
+    }
+    return AKZ_OK;
+}
+int akz_result_descriptors(const akz_result* r, uint64_t img, uint8_t* out) {
+    AKZ_TRY(check_img(r, img));
+    if (r->flags & AKZ_NO_HOST_DESCRIPTORS) {
+        set_error("descriptors were kept on the device (AKZ_NO_HOST_DESCRIPTORS)");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const auto& d = r->desc[(size_t)img];
+    if (!d.empty()) {
+        if (!out) return AKZ_ERR_INVALID_ARG;
+        std::memcpy(out, d.data(), d.size());
+    }
+    return AKZ_OK;
+}
+int akz_result_device_descriptors(const akz_result* r, uint64_t img, const uint8_t** d_desc, uint64_t* n_keypoints) {
+    AKZ_TRY(check_img(r, img));
+    if (d_desc) *d_desc = r->d_desc64 ? r->d_desc64 + r->desc_off[(size_t)img] * 64 : nullptr;
+    if (n_keypoints) *n_keypoints = r->kps[(size_t)img].size();
+    return AKZ_OK;
+}
+int akz_result_contrast(const akz_result* r, uint64_t img, double* k) {
+    AKZ_TRY(check_img(r, img));
+    if (!k) return AKZ_ERR_INVALID_ARG;
+    *k = r->k_host[(size_t)img];
+    return AKZ_OK;
+}
+int akz_result_level_info(const akz_result* r, uint64_t level, double* etime, double* esigma, uint32_t* octave,
+                          uint32_t* sublevel, uint32_t* sigma_size, uint32_t* w, uint32_t* h, uint64_t* n_tau,
+                          double* tau, uint64_t tau_cap) {
+    if (!r) return AKZ_ERR_INVALID_ARG;
+    return level_info_out(r->plan, level, etime, esigma, octave, sublevel, sigma_size, w, h, nullptr, n_tau, tau,
+                          tau_cap);
+}
+int akz_result_device_plane(const akz_result* r, uint64_t img, uint64_t level, akz_plane plane,
+                            const float** d_plane) {
+    AKZ_TRY(check_img(r, img));
+    if (level >= r->plan.size() || (int)plane < 0 || (int)plane > 9 || !d_plane) {
+        set_error("level/plane out of range");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const float* base = r->planes[(size_t)level][(int)plane];
+    const LevelPlan& lv = r->plan[(size_t)level];
+    *d_plane = base ? base + (size_t)img * lv.w * lv.h : nullptr;
+    return AKZ_OK;
+}
+int akz_fetch_plane(const akz_result* r, uint64_t img, uint64_t level, akz_plane plane, float* out, uint64_t* n_px) {
+    const float* d = nullptr;
+    AKZ_TRY(akz_result_device_plane(r, img, level, plane, &d));
+    const LevelPlan& lv = r->plan[(size_t)level];
+    const uint64_t npx = d ? (uint64_t)lv.w * lv.h : 0;
+    if (n_px) *n_px = npx;
+    if (out && npx) {
+        AKZ_TRY(bind(r->ctx));
+        AKZ_HIP_TRY(hipMemcpyAsync(out, d, npx * sizeof(float), hipMemcpyDeviceToHost, r->ctx->stream));
+        AKZ_HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    }
+    return AKZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// descriptor_match
+// ---------------------------------------------------------------------------------------------
+int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
+                                uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
+                                uint64_t* d_n_out) {
+    AKZ_TRY(bind(c));
+    if (!d_out || !d_n_out || (n0 && !d_d0) || (n1 && !d_d1) || n0 > 0x7fffffffull || n1 > 0x7fffffffull) {
+        set_error("descriptor_match: bad arguments");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const uint32_t thr = (uint32_t)std::min<uint64_t>(distance_threshold, 0x7fffffffull);
+    AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * sizeof(MatchRec)));
+    launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, (MatchRec*)c->match_rec.p);
+    launch::match_compact(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, thr, lowes_ratio * lowes_ratio,
+                          d_out, (unsigned long long*)d_n_out);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
+}
+
+int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8_t* d1, uint64_t n1,
+                         uint64_t desc_bytes, uint64_t distance_threshold, double lowes_ratio, akz_match* out,
+                         uint64_t* n_out) {
+    AKZ_TRY(bind(c));
+    if (!n_out || desc_bytes == 0 || desc_bytes > 64 || (n0 && (!d0 || !out)) || (n1 && !d1)) {
+        set_error("descriptor_match: bad arguments (desc_bytes must be 1..64)");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    *n_out = 0;
+    if (n0 == 0) return AKZ_OK;
+    auto pad = [&](const uint8_t* src, uint64_t cnt, std::vector<uint8_t>& dst) {
+        dst.assign((size_t)std::max<uint64_t>(1, cnt) * 64, 0);
+        for (uint64_t i = 0; i < cnt; ++i) std::memcpy(&dst[(size_t)i * 64], src + i * desc_bytes, desc_bytes);
+    };
+    std::vector<uint8_t> p0, p1;
+    pad(d0, n0, p0);
+    pad(d1, n1, p1);
+    AKZ_TRY(ensure(c, c->match_a, p0.size()));
+    AKZ_TRY(ensure(c, c->match_b, p1.size()));
+    AKZ_TRY(ensure(c, c->match_out, n0 * sizeof(akz_match) + 64));
+    AKZ_HIP_TRY(hipMemcpyAsync(c->match_a.p, p0.data(), p0.size(), hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP_TRY(hipMemcpyAsync(c->match_b.p, p1.data(), p1.size(), hipMemcpyHostToDevice, c->stream));
+    akz_match* d_m = (akz_match*)((char*)c->match_out.p + 64);
+    uint64_t* d_cnt = (uint64_t*)c->match_out.p;
+    AKZ_TRY(akz_descriptor_match_device(c, (const uint8_t*)c->match_a.p, n0, (const uint8_t*)c->match_b.p, n1,
+                                        distance_threshold, lowes_ratio, d_m, d_cnt));
+    uint64_t cnt = 0;
+    AKZ_HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (cnt) {
+        AKZ_HIP_TRY(hipMemcpyAsync(out, d_m, cnt * sizeof(akz_match), hipMemcpyDeviceToHost, c->stream));
+        AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    *n_out = cnt;
+    return AKZ_OK;
+}
+
+const char* akz_fed_kernel_name(void) { return "k_fed_step"; }
+
+}  // extern "C"

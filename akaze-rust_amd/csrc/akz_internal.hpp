@@ -1,0 +1,139 @@
+// Internal declarations shared by the host-side translation units of libakaze_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/akaze_hip.h"
+
+namespace akz {
+
+void set_error(const std::string& msg);
+
+#define AKZ_HIP_TRY(expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            ::akz::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));            \
+            return AKZ_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define AKZ_TRY(expr)            \
+    do {                         \
+        int _s = (expr);         \
+        if (_s != AKZ_OK) return _s; \
+    } while (0)
+
+// ---- host-side planning (akz_plan.cpp) ---------------------------------------------------
+struct LevelPlan {
+    double etime = 0, esigma = 0;
+    uint32_t octave = 0, sublevel = 0, sigma_size = 0;  // EvolutionStep scalars
+    uint32_t w = 0, h = 0;                               // plane size of the level
+    uint32_t det_sigma = 0;                              // round(esigma*derivative_factor/2^octave)
+    std::vector<double> tau;                             // fed_tau_steps
+};
+int config_validate(const akz_config& c);
+int fed_tau_by_process_time(double T, int M, double tau_max, bool reordering, std::vector<double>& tau);
+std::vector<float> gaussian_kernel(float sigma, size_t kernel_size);
+size_t gaussian_kernel_size(float sigma);
+void scharr_kernels(uint32_t scale, std::vector<float>& main_axis, std::vector<float>& off_axis);
+int build_plan(uint32_t w, uint32_t h, const akz_config& cfg, std::vector<LevelPlan>& plan);
+
+// A separable-filter pass as a sparse tap list: out = sum_i wgt[i] * in(.. + off[i]) evaluated
+// left to right starting from 0.0f.  Dense Gaussian: 2hw+1 taps; Scharr: taps at -s, 0, +s.
+constexpr int kMaxTaps = 13;
+struct Taps {
+    int n = 0;
+    int hw = 0;  // half width of the full kernel (border clamp distance)
+    int off[kMaxTaps] = {0};
+    float wgt[kMaxTaps] = {0};
+};
+int taps_from_dense(const float* k, uint32_t ntaps, Taps& t);
+Taps taps_scharr_main(uint32_t scale);
+Taps taps_scharr_off(uint32_t scale);
+
+// ---- device kernels' launch wrappers (akz_kernels.hip) -----------------------------------
+struct Candidate {  // one NMS survivor (scale_space_extrema.rs:32-42 + bounds :80-87)
+    uint32_t level;
+    uint32_t idx;  // flat index w*y + x in the level
+    float v, xp, xm, yp, ym;
+    uint32_t _pad;
+};
+struct KpParam {  // per-keypoint input of the orientation / descriptor kernels
+    float xf, yf;     // point / ratio
+    float scale;      // round(0.5*size/ratio)
+    float co, si;     // cosf/sinf(angle) from the host libm (descriptor only)
+    uint32_t level;
+    uint32_t _pad[2];
+};
+struct OrientOut {
+    float sum_x, sum_y;
+    uint32_t found;
+    uint32_t _pad;
+};
+struct MatchRec {  // per query descriptor
+    uint32_t min_d, second_d, min_j, _pad;
+};
+struct LevelPtrs {  // device addresses of the planes one kernel needs, image 0 of the batch
+    const float* lt;
+    const float* lx;
+    const float* ly;
+    uint32_t w, h;
+    uint64_t stride;  // elements between consecutive images
+};
+constexpr int kMaxLevels = 64;
+struct LevelTable {
+    LevelPtrs lv[kMaxLevels];
+};
+
+namespace launch {
+void filter_h_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t);
+void filter_h_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t);
+void filter_v_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t);
+void half_size(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n);
+void pm_g2(hipStream_t s, const float* lx, const float* ly, float* out, uint32_t w, uint32_t h, uint32_t n,
+           const double* d_k, uint32_t k_scale_pow);
+void flow(hipStream_t s, const float* lsmooth, float* lflow, uint32_t w, uint32_t h, uint32_t n, const double* d_k,
+          uint32_t k_scale_pow);
+void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
+              uint32_t h, uint32_t n, float half_tau);
+void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
+                  unsigned long long* d_hmax_bits);
+void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
+                   const unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist);
+void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const uint32_t* d_hist, uint32_t nbins,
+                    double percentile, uint32_t n, double* d_k);
+void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
+          float sigma_quat);
+void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
+         float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count);
+void orientation(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp,
+                 unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out);
+void mldb(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp, uint32_t channels,
+          uint32_t pattern, uint8_t* d_desc64);
+void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
+           MatchRec* d_out);
+void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
+                   akz_match* d_out, unsigned long long* d_n_out);
+}  // namespace launch
+
+// ---- host keypoint logic (akz_keypoints.cpp) ---------------------------------------------
+struct HostKeypoint {
+    float x, y, response, size;
+    uint32_t octave, class_id;
+    float angle;
+    // level coordinates + 4-neighbour Ldet values carried from the NMS kernel
+    uint32_t lx, ly;
+    float xp, xm, yp, ym;
+};
+// scale_space_extrema.rs:12-132 on raster-ordered candidates, then :141-178 (refinement w/o orientation)
+void select_keypoints(const std::vector<Candidate>& cands_sorted, const std::vector<LevelPlan>& plan,
+                      const akz_config& cfg, std::vector<HostKeypoint>& out, uint64_t* n_extrema);
+// which of the sliding windows of compute_main_orientation contain atan2f(a, a), a > 0
+void orientation_windows(unsigned long long* mask, uint32_t* n_windows);
+float border_margin(const LevelPlan& lv, const akz_config& cfg);  // smax * sigma_size (f32)
+
+}  // namespace akz

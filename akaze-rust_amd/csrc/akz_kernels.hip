@@ -1,0 +1,588 @@
+// gfx950 kernels of the A-KAZE hot path.  All image arithmetic is IEEE f32/f64 add/mul/div/sqrt
+// in the reference's evaluation order; the file must be compiled with -ffp-contract=off and
+// correctly rounded f32 divide/sqrt, f32 denormals on (see Makefile).  No MFMA: every kernel here
+// is a <2 flop/byte stencil, gather or popcount loop.
+#include <hip/hip_runtime.h>
+
+#include "akz_internal.hpp"
+
+namespace akz {
+namespace {
+
+constexpr int BX = 64, BY = 4;  // one wave per image row segment, 4 rows per workgroup
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ float px(const float* p, long i) { return p[i]; }
+// create_unit_float_image: f32::from(v) * 1f32 / 255f32  (akaze/src/types/image.rs:136)
+__device__ __forceinline__ float px(const uint8_t* p, long i) { return ((float)p[i] * 1.0f) / 255.0f; }
+
+// ---------------------------------------------------------------------------------------------
+// horizontal_filter / vertical_filter + fill_border  (akaze/src/types/image.rs:239-332)
+// out(x,y) = raw(clamp(x,hw,w-1-hw), clamp(y,hw,h-1-hw)); raw = ((0 + k0*I0) + k1*I1) + ...
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_filter_h(const T* __restrict__ in, float* __restrict__ out, int w, int h, Taps t) {
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    const int cx = clampi(x, t.hw, w - 1 - t.hw), cy = clampi(y, t.hw, h - 1 - t.hw);
+    const T* row = in + base + (size_t)cy * w + cx;
+    float acc = 0.0f;
+    for (int i = 0; i < t.n; ++i) acc = acc + t.wgt[i] * px(row, t.off[i]);
+    out[base + (size_t)y * w + x] = acc;
+}
+
+__global__ void k_filter_v(const float* __restrict__ in, float* __restrict__ out, int w, int h, Taps t) {
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    const int cx = clampi(x, t.hw, w - 1 - t.hw), cy = clampi(y, t.hw, h - 1 - t.hw);
+    const float* col = in + base + (size_t)cy * w + cx;
+    float acc = 0.0f;
+    for (int i = 0; i < t.n; ++i) acc = acc + t.wgt[i] * col[(long)t.off[i] * w];
+    out[base + (size_t)y * w + x] = acc;
+}
+
+// half_size (akaze/src/types/image.rs:102-118): (((0+a00)+a01)+a10)+a11)/4, a01 = (2x, 2y+1)
+__global__ void k_half_size(const float* __restrict__ in, float* __restrict__ out, int w, int h) {
+    const int ow = w / 2, oh = h / 2;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const float* src = in + (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    float v = 0.0f;
+    v = v + src[(size_t)(2 * y) * w + 2 * x];
+    v = v + src[(size_t)(2 * y + 1) * w + 2 * x];
+    v = v + src[(size_t)(2 * y) * w + 2 * x + 1];
+    v = v + src[(size_t)(2 * y + 1) * w + 2 * x + 1];
+    out[(size_t)blockIdx.z * (size_t)ow * (size_t)oh + (size_t)y * ow + x] = v / 4.0f;
+}
+
+// pm_g2 (akaze/src/lib.rs:26-41), f64 inside; the contrast factor of octave o is k*0.75*...*0.75
+// multiplied one octave at a time in f64 as lib.rs:84 does.
+__device__ __forceinline__ double octave_contrast(double k, unsigned pow) {
+    for (unsigned i = 0; i < pow; ++i) k = k * 0.75;
+    return k;
+}
+__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {
+    const double dx = (double)lx, dy = (double)ly;
+    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
+}
+__global__ void k_pm_g2(const float* __restrict__ lx, const float* __restrict__ ly, float* __restrict__ out,
+                        size_t plane, const double* __restrict__ d_k, unsigned pow) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const double k = octave_contrast(d_k[blockIdx.z], pow);
+    const double inverse_k = 1.0 / (k * k);
+    const size_t o = (size_t)blockIdx.z * plane + i;
+    out[o] = pm_g2_px(lx[o], ly[o], inverse_k);
+}
+
+// scale-1 Scharr pair evaluated from a plane with the reference's two-level border clamp
+// (derivatives.rs:41-65 over image.rs:270-332).  "lx" = V_off(H_main(I)), "ly" = V_main(H_off(I)).
+struct Scharr1 {
+    float n, wn;  // main-axis taps [n, wn, n]
+};
+__device__ __forceinline__ void scharr1_pair(const float* __restrict__ I, int w, int h, int x, int y, Scharr1 k,
+                                             float& lx, float& ly) {
+    const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
+    float hm[3], ho[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int ry = clampi(cy + r - 1, 1, h - 2);  // fill_border of the H pass
+        const float* p = I + (size_t)ry * w + cx;
+        const float a = p[-1], b = p[0], c = p[1];
+        hm[r] = ((0.0f + k.n * a) + k.wn * b) + k.n * c;
+        ho[r] = ((0.0f + -1.0f * a) + 0.0f * b) + 1.0f * c;
+    }
+    lx = ((0.0f + -1.0f * hm[0]) + 0.0f * hm[1]) + 1.0f * hm[2];
+    ly = ((0.0f + k.n * ho[0]) + k.wn * ho[1]) + k.n * ho[2];
+}
+
+// Lsmooth -> Lflow  (akaze/src/lib.rs:98-105)
+__global__ void k_flow(const float* __restrict__ ls, float* __restrict__ out, int w, int h, Scharr1 sk,
+                       const double* __restrict__ d_k, unsigned pow) {
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    float lx, ly;
+    scharr1_pair(ls + base, w, h, x, y, sk, lx, ly);
+    const double k = octave_contrast(d_k[blockIdx.z], pow);
+    out[base + (size_t)y * w + x] = pm_g2_px(lx, ly, 1.0 / (k * k));
+}
+
+// ---------------------------------------------------------------------------------------------
+// FED step, direct form (akaze/src/ops/nonlinear_diffusion.rs:15-144).  Jacobi update: reads
+// the pre-step Lt, writes Lt' (ping-pong) and optionally Lstep.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fed_step(const float* __restrict__ L, const float* __restrict__ C, float* __restrict__ Lout,
+                           float* __restrict__ Lstep, int w, int h, float half_tau) {
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t i = (size_t)blockIdx.z * (size_t)w * (size_t)h + (size_t)y * w + x;
+    const float l = L[i], c = C[i];
+    const bool hxp = x + 1 < w, hxn = x > 0, hyp = y + 1 < h, hyn = y > 0;
+    float xpos = 0.0f, xneg = 0.0f;
+    if (hxp) xpos = (c + C[i + 1]) * (L[i + 1] - l);
+    if (hxn) xneg = (C[i - 1] + c) * (l - L[i - 1]);
+    float t = hxp ? (hxn ? xpos - xneg : xpos) : -xneg;
+    if (hyp) {
+        t = t + (c + C[i + w]) * (L[i + w] - l);
+        if (hyn) t = t - (C[i - w] + c) * (l - L[i - w]);
+    } else {
+        t = t + (c + C[i - w]) * (L[i - w] - l);  // last row: y_pos taken towards y-1 (:104-119)
+    }
+    const float st = half_tau * t;
+    if (Lstep) Lstep[i] = st;
+    Lout[i] = l + st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// contrast factor (akaze/src/ops/contrast_factor.rs:18-71) on the sigma-blurred level 0
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double grad_mod(const float* I, int w, int h, int x, int y, Scharr1 sk) {
+    float lx, ly;
+    scharr1_pair(I, w, h, x, y, sk, lx, ly);
+    const double dx = (double)lx, dy = (double)ly;
+    return sqrt(dx * dx + dy * dy);
+}
+__global__ void k_contrast_max(const float* __restrict__ blurred, int w, int h, Scharr1 sk,
+                               unsigned long long* __restrict__ d_hmax_bits) {
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    double m = 0.0;
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        const double g = grad_mod(blurred + (size_t)blockIdx.z * (size_t)w * (size_t)h, w, h, x, y, sk);
+        if (g > m) m = g;
+    }
+    // non-negative doubles order like their bit patterns
+    unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(bits, o, 64);
+        bits = other > bits ? other : bits;
+    }
+    if (threadIdx.x == 0 && bits != 0ull) atomicMax(d_hmax_bits + blockIdx.z, bits);
+}
+__global__ void k_contrast_hist(const float* __restrict__ blurred, int w, int h, Scharr1 sk,
+                                const unsigned long long* __restrict__ d_hmax_bits, unsigned nbins,
+                                unsigned* __restrict__ d_hist) {
+    extern __shared__ unsigned s_hist[];
+    const int tid = threadIdx.y * BX + threadIdx.x;
+    for (unsigned b = tid; b < nbins; b += BX * BY) s_hist[b] = 0u;
+    __syncthreads();
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        const double hmax = __longlong_as_double((long long)d_hmax_bits[blockIdx.z]);
+        const double g = grad_mod(blurred + (size_t)blockIdx.z * (size_t)w * (size_t)h, w, h, x, y, sk);
+        if (g != 0.0) {
+            const double f = floor((double)nbins * (g / hmax));
+            unsigned b = f >= (double)nbins ? nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
+            atomicAdd(&s_hist[b], 1u);
+        }
+    }
+    __syncthreads();
+    for (unsigned b = tid; b < nbins; b += BX * BY)
+        if (s_hist[b]) atomicAdd(&d_hist[(size_t)blockIdx.z * nbins + b], s_hist[b]);
+}
+__global__ void k_contrast_final(const unsigned long long* __restrict__ d_hmax_bits,
+                                 const unsigned* __restrict__ d_hist, unsigned nbins, double percentile, unsigned n,
+                                 double* __restrict__ d_k) {
+    const unsigned img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= n) return;
+    const unsigned* hist = d_hist + (size_t)img * nbins;
+    const double hmax = __longlong_as_double((long long)d_hmax_bits[img]);
+    unsigned long long num_points = 0;
+    for (unsigned b = 0; b < nbins; ++b) num_points += hist[b];
+    const double tf = (double)num_points * percentile;
+    const unsigned long long threshold = tf > 0.0 ? (unsigned long long)tf : 0ull;
+    unsigned long long k = 0, num_elements = 0;
+    while (num_elements < threshold && k < nbins) {
+        num_elements += hist[k];
+        k += 1;
+    }
+    d_k[img] = num_elements >= threshold ? hmax * (double)k / (double)nbins : 0.03;
+}
+
+// Ldet = ((Lxx*Lyy) - (Lxy*Lxy)) * sigma^4   (akaze/src/ops/detector_response.rs:52)
+__global__ void k_ldet(const float* __restrict__ lxx, const float* __restrict__ lyy, const float* __restrict__ lxy,
+                       float* __restrict__ out, size_t count, float q) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    out[i] = ((lxx[i] * lyy[i]) - (lxy[i] * lxy[i])) * q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NMS candidates (akaze/src/ops/scale_space_extrema.rs:32-42) pre-filtered by the descriptor
+// border test (:80-87), which depends only on (x, y, level); out-of-border candidates never
+// touch the reference's keypoint cache.  Unordered append; the host sorts into raster order.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_nms(const float* __restrict__ ldet, int w, int h, size_t img_stride, unsigned level, float thr,
+                      float border_m, Candidate* __restrict__ cand, unsigned cap, unsigned* __restrict__ count) {
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x < 1 || x >= w || y < 1 || y >= h - 1) return;
+    const long i = (long)y * w + x;
+    if (i >= (long)w * h - w - 1) return;  // flat range (w+1) .. len-w-1 of the reference loop
+    const float* D = ldet + (size_t)blockIdx.z * img_stride;
+    const float v = D[i];
+    if (!(v > thr)) return;
+    const float xp = D[i + 1], xm = D[i - 1], ym = D[i - w], yp = D[i + w];
+    if (!(v > xp && v > xm && v > ym && v > yp)) return;
+    const float fx = (float)x, fy = (float)y;
+    const bool is_out = (roundf(fx - border_m) - 1.0f) < 0.0f || (roundf(fx + border_m) + 1.0f) >= (float)w ||
+                        (roundf(fy - border_m) - 1.0f) < 0.0f || (roundf(fy + border_m) + 1.0f) >= (float)h;
+    if (is_out) return;
+    const unsigned slot = atomicAdd(count + blockIdx.z, 1u);
+    if (slot < cap) {
+        Candidate c;
+        c.level = level;
+        c.idx = (unsigned)i;
+        c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
+        c._pad = 0;
+        cand[(size_t)blockIdx.z * cap + slot] = c;
+    }
+}
+
+// published 7x7 half-Gaussian table (sigma 2.5) of SURF/KAZE/A-KAZE
+// (akaze/src/ops/scale_space_extrema.rs:207-271)
+__constant__ float c_gauss25[7][7] = {
+    {0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+    {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+    {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+    {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+    {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+    {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+    {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
+
+// ---------------------------------------------------------------------------------------------
+// Dominant orientation, device part (akaze/src/ops/scale_space_extrema.rs:274-329).
+// angs[k] = atan2(res_y, res_y) is pi/4 for res_y > 0 and <= 0 otherwise, so a window either
+// takes every sample with res_y > 0 (in k order) or none; which windows do is a keypoint-
+// independent bit mask computed on the host with the host libm.  The running sums are never
+// reset (as in the reference).  The final atan2f is left to the host.
+// ---------------------------------------------------------------------------------------------
+constexpr int ORI_THREADS = 64;
+__global__ void k_orientation(LevelTable tab, unsigned img, const KpParam* __restrict__ kps, unsigned nkp,
+                              unsigned long long window_mask, unsigned n_windows, OrientOut* __restrict__ out) {
+    __shared__ float s_rx[109 * ORI_THREADS];
+    __shared__ float s_ry[109 * ORI_THREADS];
+    const unsigned t = threadIdx.x;
+    const unsigned i = blockIdx.x * ORI_THREADS + t;
+    if (i >= nkp) return;
+    const KpParam kp = kps[i];
+    const LevelPtrs lv = tab.lv[kp.level];
+    const float* lx = lv.lx + (size_t)img * lv.stride;
+    const float* ly = lv.ly + (size_t)img * lv.stride;
+    int idx = 0;
+    for (int a = -6; a <= 6; ++a)
+        for (int b = -6; b <= 6; ++b)
+            if (a * a + b * b < 36) {
+                const float fy = roundf(kp.yf + (float)b * kp.scale);
+                const float fx = roundf(kp.xf + (float)a * kp.scale);
+                const int iy = clampi(fy > 0.0f ? (int)fy : 0, 0, (int)lv.h - 1);
+                const int ix = clampi(fx > 0.0f ? (int)fx : 0, 0, (int)lv.w - 1);
+                const int ia = a < 0 ? -a : a, ib = b < 0 ? -b : b;
+                const float g = c_gauss25[ia][ib];
+                const size_t p = (size_t)iy * lv.w + ix;
+                s_rx[idx * ORI_THREADS + t] = g * lx[p];
+                s_ry[idx * ORI_THREADS + t] = g * ly[p];
+                ++idx;
+            }
+    float sum_x = 0.0f, sum_y = 0.0f, maxv = 0.0f, bx = 0.0f, by = 0.0f;
+    unsigned found = 0;
+    for (unsigned wdw = 0; wdw < n_windows; ++wdw) {
+        if ((window_mask >> wdw) & 1ull) {
+            for (int k = 0; k < 109; ++k) {
+                const float ry = s_ry[k * ORI_THREADS + t];
+                if (ry > 0.0f) {
+                    sum_x = sum_x + s_rx[k * ORI_THREADS + t];
+                    sum_y = sum_y + ry;
+                }
+            }
+        }
+        const float val = sum_x * sum_x + sum_y * sum_y;
+        if (val > maxv) {
+            maxv = val;
+            bx = sum_x;
+            by = sum_y;
+            found = 1;
+        }
+    }
+    OrientOut o;
+    o.sum_x = bx; o.sum_y = by; o.found = found; o._pad = 0;
+    out[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// M-LDB descriptor (akaze/src/ops/descriptors.rs:37-175): one wave per keypoint; lanes 0..28 own
+// the 4+9+16 grid cells and sum their samples sequentially in the reference order (f32 adds are
+// not associative); then all 64 lanes evaluate the 162*channels comparisons and ballot packs
+// them LSB-first into a 64-byte row.
+// ---------------------------------------------------------------------------------------------
+__constant__ unsigned char c_pair_a[162], c_pair_b[162];  // (i, j), i < j, per grid, cell ids 0..28
+
+__global__ void k_mldb(LevelTable tab, unsigned img, const KpParam* __restrict__ kps, unsigned nkp,
+                       unsigned channels, uint8_t* __restrict__ desc64) {
+    __shared__ float s_val[3][32];
+    const unsigned kpi = blockIdx.x;
+    if (kpi >= nkp) return;
+    const unsigned lane = threadIdx.x;
+    const KpParam kp = kps[kpi];
+    const LevelPtrs lv = tab.lv[kp.level];
+    const size_t ioff = (size_t)img * lv.stride;
+    const float* Lt = lv.lt + ioff;
+    const float* Lx = lv.lx + ioff;
+    const float* Ly = lv.ly + ioff;
+    if (lane < 29) {
+        int step, ng, ci;
+        if (lane < 4) { step = 10; ng = 2; ci = (int)lane; }
+        else if (lane < 13) { step = 7; ng = 3; ci = (int)lane - 4; }
+        else { step = 5; ng = 4; ci = (int)lane - 13; }
+        const int i0 = -10 + (ci / ng) * step, j0 = -10 + (ci % ng) * step;
+        const float co = kp.co, si = kp.si, scale = kp.scale;
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        for (int k = i0; k < i0 + step; ++k)
+            for (int l = j0; l < j0 + step; ++l) {
+                const float lf = (float)l + 0.5f, kf = (float)k + 0.5f;
+                const float sample_y = kp.yf + (lf * co * scale + kf * si * scale);
+                const float sample_x = kp.xf + (-lf * si * scale + kf * co * scale);
+                const int y1 = clampi((int)roundf(sample_y), 0, (int)lv.h - 1);
+                const int x1 = clampi((int)roundf(sample_x), 0, (int)lv.w - 1);
+                const size_t p = (size_t)y1 * lv.w + x1;
+                di = di + Lt[p];
+                if (channels > 1) {
+                    const float rx = Lx[p], ry = Ly[p];
+                    if (channels == 2) {
+                        dx = dx + sqrtf(rx * rx + ry * ry);
+                    } else {
+                        const float rry = rx * co + ry * si;
+                        const float rrx = -rx * si + ry * co;
+                        dx = dx + rrx;
+                        dy = dy + rry;
+                    }
+                }
+            }
+        const float ns = (float)(step * step);
+        s_val[0][lane] = di / ns;
+        s_val[1][lane] = dx / ns;
+        s_val[2][lane] = dy / ns;
+    }
+    __syncthreads();
+    // bit order: grid 0 (6 pairs), grid 1 (36), grid 2 (120); inside a grid channel-major
+    const unsigned seg0 = 6u * channels, seg1 = seg0 + 36u * channels, total = seg1 + 120u * channels;
+    unsigned long long words[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const unsigned b = (unsigned)r * 64u + lane;
+        bool bit = false;
+        if (b < total) {
+            unsigned rel, npairs, pbase;
+            if (b < seg0) { rel = b; npairs = 6; pbase = 0; }
+            else if (b < seg1) { rel = b - seg0; npairs = 36; pbase = 6; }
+            else { rel = b - seg1; npairs = 120; pbase = 42; }
+            const unsigned pos = rel / npairs, p = rel % npairs;
+            bit = s_val[pos][c_pair_a[pbase + p]] > s_val[pos][c_pair_b[pbase + p]];
+        }
+        words[r] = __ballot(bit);
+    }
+    if (lane < 8) {
+        unsigned long long wv = words[0];
+#pragma unroll
+        for (int r = 1; r < 8; ++r)
+            if (lane == (unsigned)r) wv = words[r];
+        reinterpret_cast<unsigned long long*>(desc64 + (size_t)kpi * 64)[lane] = wv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Brute-force Hamming 1-NN / 2-NN (akaze/src/ops/feature_matching.rs:37-50, :113-123).
+// The reference's bail-out only skips distances that could not update min/second, so exact
+// distances with the same update rule give identical (min, second, min_j).
+// ---------------------------------------------------------------------------------------------
+constexpr int MT = 256;  // queries per workgroup == train rows per LDS tile
+__global__ void __launch_bounds__(MT) k_match(const uint4* __restrict__ d0, unsigned n0, const uint4* __restrict__ d1,
+                                             unsigned n1, unsigned threshold, MatchRec* __restrict__ out) {
+    __shared__ uint4 s_tile[MT * 4];
+    const unsigned i = blockIdx.x * MT + threadIdx.x;
+    uint4 q[4];
+    const bool live = i < n0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = live ? d0[(size_t)i * 4 + k] : make_uint4(0, 0, 0, 0);
+    unsigned min_d = threshold, second = threshold, min_j = 0;
+    for (unsigned base = 0; base < n1; base += MT) {
+        const unsigned rows = min((unsigned)MT, n1 - base);
+        __syncthreads();
+        for (unsigned e = threadIdx.x; e < rows * 4; e += MT) s_tile[e] = d1[(size_t)base * 4 + e];
+        __syncthreads();
+        for (unsigned r = 0; r < rows; ++r) {
+            unsigned d = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 t = s_tile[r * 4 + k];
+                d += __popc(q[k].x ^ t.x) + __popc(q[k].y ^ t.y) + __popc(q[k].z ^ t.z) + __popc(q[k].w ^ t.w);
+            }
+            if (d < min_d) {
+                second = min_d;
+                min_d = d;
+                min_j = base + r;
+            } else if (d < second) {
+                second = d;
+            }
+        }
+    }
+    if (live) {
+        MatchRec m;
+        m.min_d = min_d; m.second_d = second; m.min_j = min_j; m._pad = 0;
+        out[i] = m;
+    }
+}
+
+// Lowe ratio^2 + threshold test (feature_matching.rs:61-63) and ordered compaction, one workgroup.
+__global__ void __launch_bounds__(1024) k_match_compact(const MatchRec* __restrict__ rec, unsigned n0,
+                                                        unsigned threshold, double ratio2,
+                                                        akz_match* __restrict__ out,
+                                                        unsigned long long* __restrict__ n_out) {
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_base;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (unsigned start = 0; start < n0; start += 1024) {
+        const unsigned i = start + threadIdx.x;
+        bool keep = false;
+        MatchRec m = {0, 0, 0, 0};
+        if (i < n0) {
+            m = rec[i];
+            keep = ((double)m.min_d < (double)m.second_d * ratio2) && (m.min_d < threshold);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        unsigned off = s_base;
+        for (unsigned wv = 0; wv < wave; ++wv) off += s_wave[wv];
+        if (keep) {
+            akz_match o;
+            o.index_0 = i; o.index_1 = m.min_j; o.distance = (double)m.min_d;
+            out[off + before] = o;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (unsigned wv = 0; wv < 16; ++wv) tot += s_wave[wv];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = s_base;
+}
+
+inline dim3 grid2d(uint32_t w, uint32_t h, uint32_t n) { return dim3((w + BX - 1) / BX, (h + BY - 1) / BY, n); }
+
+}  // namespace
+
+// =============================================================================================
+// launch wrappers
+// =============================================================================================
+namespace launch {
+
+static Scharr1 scharr1() {
+    const Taps m = taps_scharr_main(1);
+    return Scharr1{m.wgt[0], m.wgt[1]};
+}
+
+void filter_h_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t) {
+    hipLaunchKernelGGL(k_filter_h<float>, grid2d(w, h, n), dim3(BX, BY), 0, s, in, out, (int)w, (int)h, t);
+}
+void filter_h_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t) {
+    hipLaunchKernelGGL(k_filter_h<uint8_t>, grid2d(w, h, n), dim3(BX, BY), 0, s, in, out, (int)w, (int)h, t);
+}
+void filter_v_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t) {
+    hipLaunchKernelGGL(k_filter_v, grid2d(w, h, n), dim3(BX, BY), 0, s, in, out, (int)w, (int)h, t);
+}
+void half_size(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n) {
+    hipLaunchKernelGGL(k_half_size, grid2d(w / 2, h / 2, n), dim3(BX, BY), 0, s, in, out, (int)w, (int)h);
+}
+void pm_g2(hipStream_t s, const float* lx, const float* ly, float* out, uint32_t w, uint32_t h, uint32_t n,
+           const double* d_k, uint32_t k_scale_pow) {
+    const size_t plane = (size_t)w * h;
+    hipLaunchKernelGGL(k_pm_g2, dim3((unsigned)((plane + 255) / 256), 1, n), dim3(256), 0, s, lx, ly, out, plane, d_k,
+                       k_scale_pow);
+}
+void flow(hipStream_t s, const float* lsmooth, float* lflow, uint32_t w, uint32_t h, uint32_t n, const double* d_k,
+          uint32_t k_scale_pow) {
+    hipLaunchKernelGGL(k_flow, grid2d(w, h, n), dim3(BX, BY), 0, s, lsmooth, lflow, (int)w, (int)h, scharr1(), d_k,
+                       k_scale_pow);
+}
+void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
+              uint32_t h, uint32_t n, float half_tau) {
+    hipLaunchKernelGGL(k_fed_step, grid2d(w, h, n), dim3(BX, BY), 0, s, lt_in, lflow, lt_out, lstep, (int)w, (int)h,
+                       half_tau);
+}
+void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
+                  unsigned long long* d_hmax_bits) {
+    hipLaunchKernelGGL(k_contrast_max, grid2d(w, h, n), dim3(BX, BY), 0, s, blurred, (int)w, (int)h, scharr1(),
+                       d_hmax_bits);
+}
+void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
+                   const unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist) {
+    hipLaunchKernelGGL(k_contrast_hist, grid2d(w, h, n), dim3(BX, BY), nbins * sizeof(unsigned), s, blurred, (int)w,
+                       (int)h, scharr1(), d_hmax_bits, nbins, d_hist);
+}
+void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const uint32_t* d_hist, uint32_t nbins,
+                    double percentile, uint32_t n, double* d_k) {
+    hipLaunchKernelGGL(k_contrast_final, dim3((n + 63) / 64), dim3(64), 0, s, d_hmax_bits, d_hist, nbins, percentile,
+                       n, d_k);
+}
+void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
+          float sigma_quat) {
+    hipLaunchKernelGGL(k_ldet, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, lxx, lyy, lxy, out,
+                       (size_t)count, sigma_quat);
+}
+void nms(hipStream_t s, const float* ldet_p, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
+         float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count) {
+    hipLaunchKernelGGL(k_nms, grid2d(w, h, n), dim3(BX, BY), 0, s, ldet_p, (int)w, (int)h, (size_t)img_stride, level,
+                       thr, border_m, d_cand, cap_per_img, d_count);
+}
+void orientation(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp,
+                 unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out) {
+    if (nkp == 0) return;
+    hipLaunchKernelGGL(k_orientation, dim3((nkp + ORI_THREADS - 1) / ORI_THREADS), dim3(ORI_THREADS), 0, s, lt, img,
+                       d_kp, nkp, window_mask, n_windows, d_out);
+}
+
+static bool g_pairs_uploaded = false;
+static int upload_pairs() {
+    // pair order of mldb_binary_comparisons (descriptors.rs:161-174): for i, for j > i
+    unsigned char a[162], b[162];
+    int p = 0;
+    const int counts[3] = {4, 9, 16}, base[3] = {0, 4, 13};
+    for (int g = 0; g < 3; ++g)
+        for (int i = 0; i < counts[g]; ++i)
+            for (int j = i + 1; j < counts[g]; ++j) {
+                a[p] = (unsigned char)(base[g] + i);
+                b[p] = (unsigned char)(base[g] + j);
+                ++p;
+            }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_pair_a), a, sizeof(a)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_pair_b), b, sizeof(b)) != hipSuccess) return -1;
+    g_pairs_uploaded = true;
+    return 0;
+}
+void mldb(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp, uint32_t channels,
+          uint32_t /*pattern*/, uint8_t* d_desc64) {
+    if (nkp == 0) return;
+    if (!g_pairs_uploaded) upload_pairs();
+    hipLaunchKernelGGL(k_mldb, dim3(nkp), dim3(64), 0, s, lt, img, d_kp, nkp, channels, d_desc64);
+}
+void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
+           MatchRec* d_out) {
+    if (n0 == 0) return;
+    hipLaunchKernelGGL(k_match, dim3((n0 + MT - 1) / MT), dim3(MT), 0, s, reinterpret_cast<const uint4*>(d0), n0,
+                       reinterpret_cast<const uint4*>(d1), n1, threshold, d_out);
+}
+void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
+                   akz_match* d_out, unsigned long long* d_n_out) {
+    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, s, d_rec, n0, threshold, ratio2, d_out, d_n_out);
+}
+
+}  // namespace launch
+}  // namespace akz

@@ -1,0 +1,480 @@
+"""Python host binding of libakaze_hip.so (the C ABI in include/akaze_hip.h).
+
+Mirrors the reference crate's public interface for the hot path — same names, argument
+meaning and error behaviour (the reference panics; here an AkazeError is raised):
+
+    akaze::extract_features   (akaze/src/lib.rs:167-194)   -> extract_features()
+    akaze::match_features     (akaze/src/lib.rs:252-275)   -> match_features()  (descriptor part)
+    types::evolution::Config  (akaze/src/types/evolution.rs:8-55) -> Config
+    pub mod ops / types::image                              -> ops.* on torch CUDA tensors
+
+torch is used only as the owner of device memory and streams; all compute is in the HIP
+library.  There is no CPU fallback: if libakaze_hip.so is missing or no gfx950 GPU is
+visible, constructing a Context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libakaze_hip.so")
+
+AKZ_KEEP_ALL_PLANES = 1
+AKZ_NO_HOST_DESCRIPTORS = 2
+
+PLANES = ["Lt", "Lsmooth", "Lx", "Ly", "Lxx", "Lyy", "Lxy", "Lflow", "Lstep", "Ldet"]
+
+
+class AkazeError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"akaze_hip status {status}: {msg}")
+        self.status = status
+
+
+class Config(C.Structure):
+    """types::evolution::Config (akaze/src/types/evolution.rs:8-38); Config() == Config::default()."""
+    _fields_ = [
+        ("num_sublevels", C.c_uint32),
+        ("max_octave_evolution", C.c_uint32),
+        ("base_scale_offset", C.c_double),
+        ("initial_contrast", C.c_double),
+        ("contrast_percentile", C.c_double),
+        ("contrast_factor_num_bins", C.c_uint64),
+        ("derivative_factor", C.c_double),
+        ("detector_threshold", C.c_double),
+        ("descriptor_channels", C.c_uint64),
+        ("descriptor_pattern_size", C.c_uint64),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().akz_config_default(C.byref(self))
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+     ("octave", "<u8"), ("class_id", "<u8"), ("angle", "<f4"), ("_pad", "<u4")])
+MATCH_DTYPE = np.dtype([("index_0", "<u8"), ("index_1", "<u8"), ("distance", "<f8")])
+
+_lib = None
+
+
+def lib():
+    """Load libakaze_hip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C akaze-rust_amd). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, f64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+    pu32, pu64, pf64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+    fp = C.POINTER(C.c_float)
+    sig = {
+        "akz_abi_version": ([], i32),
+        "akz_last_error": ([], C.c_char_p),
+        "akz_config_default": ([C.POINTER(Config)], None),
+        "akz_ctx_create": ([i32, vp, C.POINTER(vp)], i32),
+        "akz_ctx_destroy": ([vp], i32),
+        "akz_ctx_synchronize": ([vp], i32),
+        "akz_ctx_stream": ([vp], vp),
+        "akz_device_malloc": ([vp, C.c_size_t, C.POINTER(vp)], i32),
+        "akz_device_free": ([vp, vp], i32),
+        "akz_memcpy_h2d": ([vp, vp, vp, C.c_size_t], i32),
+        "akz_memcpy_d2h": ([vp, vp, vp, C.c_size_t], i32),
+        "akz_fed_tau_by_process_time": ([f64, i32, f64, i32, pf64, u64, pu64], i32),
+        "akz_gaussian_kernel": ([C.c_float, u64, fp], i32),
+        "akz_scharr_kernels": ([u32, fp, fp], i32),
+        "akz_plan_num_levels": ([u32, u32, C.POINTER(Config), pu64], i32),
+        "akz_plan_level_info": ([u32, u32, C.POINTER(Config), u64, pf64, pf64, pu32, pu32, pu32, pu32, pu32, pu32,
+                                 pu64, pf64, u64], i32),
+        "akz_op_horizontal_filter": ([vp, vp, vp, u32, u32, u32, fp, u32], i32),
+        "akz_op_vertical_filter": ([vp, vp, vp, u32, u32, u32, fp, u32], i32),
+        "akz_op_gaussian_blur": ([vp, vp, vp, u32, u32, u32, C.c_float], i32),
+        "akz_op_gaussian_blur_u8": ([vp, vp, vp, u32, u32, u32, C.c_float], i32),
+        "akz_op_half_size": ([vp, vp, vp, u32, u32, u32], i32),
+        "akz_op_scharr": ([vp, vp, vp, u32, u32, u32, i32, i32, u32], i32),
+        "akz_op_pm_g2": ([vp, vp, vp, vp, u32, u32, u32, vp], i32),
+        "akz_op_contrast_factor": ([vp, vp, u32, u32, u32, f64, f64, u64, vp], i32),
+        "akz_op_flow": ([vp, vp, vp, u32, u32, u32, vp, u32], i32),
+        "akz_op_fed_steps": ([vp, vp, vp, vp, u32, u32, u32, pf64, u32], i32),
+        "akz_op_detector_response": ([vp, vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32], i32),
+        "akz_extract_gray_u8": ([vp, vp, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_gray_f32": ([vp, vp, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_device_u8": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_device_f32": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_result_free": ([vp], i32),
+        "akz_result_num_images": ([vp, pu64], i32),
+        "akz_result_counts": ([vp, u64, pu64, pu64, pu64], i32),
+        "akz_result_keypoints": ([vp, u64, vp], i32),
+        "akz_result_descriptors": ([vp, u64, vp], i32),
+        "akz_result_device_descriptors": ([vp, u64, C.POINTER(vp), pu64], i32),
+        "akz_result_contrast": ([vp, u64, pf64], i32),
+        "akz_result_level_info": ([vp, u64, pf64, pf64, pu32, pu32, pu32, pu32, pu32, pu64, pf64, u64], i32),
+        "akz_fetch_plane": ([vp, u64, u64, i32, vp, pu64], i32),
+        "akz_result_device_plane": ([vp, u64, u64, i32, C.POINTER(vp)], i32),
+        "akz_descriptor_match": ([vp, vp, u64, vp, u64, u64, u64, f64, vp, pu64], i32),
+        "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
+        "akz_fed_kernel_name": ([], C.c_char_p),
+        "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)  # AttributeError here == a symbol of include/akaze_hip.h is missing
+        fn.argtypes = args
+        fn.restype = res
+    L._declared = sorted(sig)
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != 0:
+        raise AkazeError(status, lib().akz_last_error().decode("utf-8", "replace"))
+
+
+# ------------------------------------------------------------------------------------------
+# host-side planning helpers (no GPU needed)
+# ------------------------------------------------------------------------------------------
+def fed_tau_by_process_time(T, M=1, tau_max=0.25, reordering=True):
+    """ops::fed_tau::fed_tau_by_process_time (akaze/src/ops/fed_tau.rs:27-30)."""
+    n = C.c_uint64()
+    _check(lib().akz_fed_tau_by_process_time(T, M, tau_max, int(reordering), None, 0, C.byref(n)))
+    out = np.zeros(n.value, np.float64)
+    _check(lib().akz_fed_tau_by_process_time(T, M, tau_max, int(reordering),
+                                             out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)))
+    return out
+
+
+def gaussian_kernel(sigma, kernel_size):
+    out = np.zeros(kernel_size, np.float32)
+    _check(lib().akz_gaussian_kernel(sigma, kernel_size, out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def scharr_kernels(scale):
+    n = 2 * scale + 1
+    m, o = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    fp = C.POINTER(C.c_float)
+    _check(lib().akz_scharr_kernels(scale, m.ctypes.data_as(fp), o.ctypes.data_as(fp)))
+    return m, o
+
+
+def plan_levels(w, h, cfg=None):
+    """types::evolution::allocate_evolutions (akaze/src/types/evolution.rs:135-161) + level sizes."""
+    cfg = cfg or Config()
+    n = C.c_uint64()
+    _check(lib().akz_plan_num_levels(w, h, C.byref(cfg), C.byref(n)))
+    out = []
+    for lvl in range(n.value):
+        et, es = C.c_double(), C.c_double()
+        o, s, ss, lw, lh, ds = (C.c_uint32() for _ in range(6))
+        nt = C.c_uint64()
+        tau = np.zeros(8192, np.float64)
+        _check(lib().akz_plan_level_info(w, h, C.byref(cfg), lvl, C.byref(et), C.byref(es), C.byref(o), C.byref(s),
+                                         C.byref(ss), C.byref(lw), C.byref(lh), C.byref(ds), C.byref(nt),
+                                         tau.ctypes.data_as(C.POINTER(C.c_double)), len(tau)))
+        out.append(dict(etime=et.value, esigma=es.value, octave=o.value, sublevel=s.value, sigma_size=ss.value,
+                        w=lw.value, h=lh.value, det_sigma=ds.value, tau=tau[:nt.value].copy()))
+    return out
+
+
+def synth_frame(w, h, frame_index=0, shift=(0, 0)):
+    """Deterministic synthetic 8-bit luma frame; host utility."""
+    out = np.empty((h, w), np.uint8)
+    _check(lib().akz_synth_frame_u8(out.ctypes.data_as(C.c_void_p), w, h, frame_index, shift[0], shift[1]))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# GPU context
+# ------------------------------------------------------------------------------------------
+class Context:
+    """One GPU + one HIP stream.  Not thread-safe; one per host thread / per rank."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().akz_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().akz_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().akz_ctx_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return lib().akz_ctx_stream(self._h)
+
+    # ---- the hot path --------------------------------------------------------------------
+    def extract_features(self, image, options=None, keep_all_planes=True, host_descriptors=True):
+        """akaze::extract_features on an in-memory luma image (2-D uint8 or float32 numpy array, or a
+        torch CUDA tensor of shape [H, W] or [N, H, W]).  Returns an ExtractResult."""
+        options = options or Config()
+        flags = (AKZ_KEEP_ALL_PLANES if keep_all_planes else 0) | (0 if host_descriptors else AKZ_NO_HOST_DESCRIPTORS)
+        res = C.c_void_p()
+        L = lib()
+        if isinstance(image, np.ndarray):
+            img = np.ascontiguousarray(image)
+            if img.ndim != 2:
+                raise ValueError("host images must be 2-D (one luma plane)")
+            h, w = img.shape
+            if img.dtype == np.uint8:
+                _check(L.akz_extract_gray_u8(self._h, img.ctypes.data_as(C.c_void_p), w, h, C.byref(options), flags,
+                                             C.byref(res)))
+            else:
+                img = img.astype(np.float32, copy=False)
+                _check(L.akz_extract_gray_f32(self._h, img.ctypes.data_as(C.c_void_p), w, h, C.byref(options), flags,
+                                              C.byref(res)))
+        else:  # torch CUDA tensor
+            import torch
+            t = image
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+                raise ValueError("device images must be contiguous torch CUDA tensors")
+            if t.dim() == 2:
+                t = t.unsqueeze(0)
+            n, h, w = t.shape
+            if t.dtype == torch.uint8:
+                fn = L.akz_extract_device_u8
+            elif t.dtype == torch.float32:
+                fn = L.akz_extract_device_f32
+            else:
+                raise ValueError("uint8 or float32 images only")
+            _check(fn(self._h, C.c_void_p(t.data_ptr()), w, h, n, C.byref(options), flags, C.byref(res)))
+        return ExtractResult(self, res)
+
+    def descriptor_match(self, d0, d1, distance_threshold=10000, lowes_ratio=0.86):
+        """ops::feature_matching::descriptor_match (akaze/src/ops/feature_matching.rs:23-94)."""
+        d0 = np.ascontiguousarray(d0, np.uint8)
+        d1 = np.ascontiguousarray(d1, np.uint8)
+        nb = d0.shape[1] if d0.ndim == 2 and d0.shape[0] else (d1.shape[1] if d1.ndim == 2 else 61)
+        n0 = d0.shape[0] if d0.ndim == 2 else 0
+        n1 = d1.shape[0] if d1.ndim == 2 else 0
+        out = np.zeros(max(n0, 1), MATCH_DTYPE)
+        n = C.c_uint64()
+        _check(lib().akz_descriptor_match(self._h, d0.ctypes.data_as(C.c_void_p), n0, d1.ctypes.data_as(C.c_void_p),
+                                          n1, nb, distance_threshold, lowes_ratio, out.ctypes.data_as(C.c_void_p),
+                                          C.byref(n)))
+        return out[:n.value].copy()
+
+    def descriptor_match_device(self, d0, d1, distance_threshold=10000, lowes_ratio=0.86):
+        """Same on torch CUDA uint8 tensors of 64-byte descriptor rows; returns (matches tensor view, count)."""
+        import torch
+        n0, n1 = d0.shape[0], d1.shape[0]
+        out = torch.empty((max(n0, 1), 24), dtype=torch.uint8, device=d0.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=d0.device)
+        _check(lib().akz_descriptor_match_device(self._h, C.c_void_p(d0.data_ptr()), n0, C.c_void_p(d1.data_ptr()),
+                                                 n1, distance_threshold, lowes_ratio, C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(cnt.data_ptr())))
+        return out, cnt
+
+    # ---- per-op entry points on torch CUDA float32 tensors [N, H, W] or [H, W] -----------
+    def _nhw(self, t):
+        if t.dim() == 2:
+            return 1, t.shape[0], t.shape[1]
+        return t.shape[0], t.shape[1], t.shape[2]
+
+    def _taps(self, taps):
+        taps = np.ascontiguousarray(taps, np.float32)
+        return taps, taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps)
+
+    def horizontal_filter(self, img, taps):
+        import torch
+        n, h, w = self._nhw(img)
+        out = torch.empty_like(img)
+        k, pk, nk = self._taps(taps)
+        _check(lib().akz_op_horizontal_filter(self._h, img.data_ptr(), out.data_ptr(), w, h, n, pk, nk))
+        return out
+
+    def vertical_filter(self, img, taps):
+        import torch
+        n, h, w = self._nhw(img)
+        out = torch.empty_like(img)
+        k, pk, nk = self._taps(taps)
+        _check(lib().akz_op_vertical_filter(self._h, img.data_ptr(), out.data_ptr(), w, h, n, pk, nk))
+        return out
+
+    def gaussian_blur(self, img, sigma):
+        import torch
+        n, h, w = self._nhw(img)
+        out = torch.empty(img.shape, dtype=torch.float32, device=img.device)
+        fn = lib().akz_op_gaussian_blur_u8 if img.dtype == torch.uint8 else lib().akz_op_gaussian_blur
+        _check(fn(self._h, img.data_ptr(), out.data_ptr(), w, h, n, sigma))
+        return out
+
+    def half_size(self, img):
+        import torch
+        n, h, w = self._nhw(img)
+        shape = (h // 2, w // 2) if img.dim() == 2 else (n, h // 2, w // 2)
+        out = torch.empty(shape, dtype=torch.float32, device=img.device)
+        _check(lib().akz_op_half_size(self._h, img.data_ptr(), out.data_ptr(), w, h, n))
+        return out
+
+    def scharr(self, img, x_order, y_order, sigma_size):
+        import torch
+        n, h, w = self._nhw(img)
+        out = torch.empty_like(img)
+        _check(lib().akz_op_scharr(self._h, img.data_ptr(), out.data_ptr(), w, h, n, int(x_order), int(y_order),
+                                   sigma_size))
+        return out
+
+    def pm_g2(self, lx, ly, k):
+        """k: python float or a torch CUDA float64 tensor with one value per image."""
+        import torch
+        n, h, w = self._nhw(lx)
+        out = torch.empty_like(lx)
+        kt = k if isinstance(k, torch.Tensor) else torch.full((n,), float(k), dtype=torch.float64, device=lx.device)
+        _check(lib().akz_op_pm_g2(self._h, lx.data_ptr(), ly.data_ptr(), out.data_ptr(), w, h, n, kt.data_ptr()))
+        return out
+
+    def contrast_factor(self, img, percentile=0.7, gscale=1.0, nbins=300):
+        import torch
+        n, h, w = self._nhw(img)
+        out = torch.zeros(n, dtype=torch.float64, device=img.device)
+        _check(lib().akz_op_contrast_factor(self._h, img.data_ptr(), w, h, n, percentile, gscale, nbins,
+                                            out.data_ptr()))
+        return out
+
+    def flow(self, lsmooth, k, k_scale_pow=0):
+        import torch
+        n, h, w = self._nhw(lsmooth)
+        out = torch.empty_like(lsmooth)
+        kt = k if isinstance(k, torch.Tensor) else torch.full((n,), float(k), dtype=torch.float64,
+                                                              device=lsmooth.device)
+        _check(lib().akz_op_flow(self._h, lsmooth.data_ptr(), out.data_ptr(), w, h, n, kt.data_ptr(), k_scale_pow))
+        return out
+
+    def fed_steps(self, lt, lflow, taus, want_lstep=False):
+        """calculate_step for each tau, in place on `lt` (as the reference mutates evolution.Lt)."""
+        import torch
+        n, h, w = self._nhw(lt)
+        taus = np.ascontiguousarray(taus, np.float64)
+        lstep = torch.zeros_like(lt) if want_lstep else None
+        _check(lib().akz_op_fed_steps(self._h, lt.data_ptr(), lflow.data_ptr(), lstep.data_ptr() if want_lstep else None,
+                                      w, h, n, taus.ctypes.data_as(C.POINTER(C.c_double)), len(taus)))
+        return lstep
+
+    def detector_response(self, lsmooth, sigma_size, keep_second=True):
+        import torch
+        n, h, w = self._nhw(lsmooth)
+        names = ["Lx", "Ly", "Lxx", "Lyy", "Lxy", "Ldet"]
+        outs = {k: torch.empty_like(lsmooth) for k in names if keep_second or k in ("Lx", "Ly", "Ldet")}
+        p = lambda k: outs[k].data_ptr() if k in outs else None
+        _check(lib().akz_op_detector_response(self._h, lsmooth.data_ptr(), sigma_size, p("Lx"), p("Ly"), p("Lxx"),
+                                              p("Lyy"), p("Lxy"), p("Ldet"), w, h, n))
+        return outs
+
+
+class ExtractResult:
+    """(Vec<EvolutionStep>, Vec<Keypoint>, Vec<Descriptor>) of akaze::extract_features, per image of the
+    batch; EvolutionStep images stay on the GPU and are fetched lazily."""
+
+    def __init__(self, ctx, handle):
+        self._ctx = ctx
+        self._h = handle
+        n = C.c_uint64()
+        _check(lib().akz_result_num_images(handle, C.byref(n)))
+        self.num_images = n.value
+
+    def close(self):
+        if self._h:
+            lib().akz_result_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self, img=0):
+        nl, nk, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().akz_result_counts(self._h, img, C.byref(nl), C.byref(nk), C.byref(nb)))
+        return nl.value, nk.value, nb.value
+
+    def keypoints(self, img=0):
+        _, nk, _ = self.counts(img)
+        out = np.zeros(nk, KEYPOINT_DTYPE)
+        _check(lib().akz_result_keypoints(self._h, img, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def descriptors(self, img=0):
+        _, nk, nb = self.counts(img)
+        out = np.zeros((nk, nb), np.uint8)
+        _check(lib().akz_result_descriptors(self._h, img, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def device_descriptors(self, img=0):
+        """(device address, rows) of the 64-byte descriptor rows of image `img`."""
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(lib().akz_result_device_descriptors(self._h, img, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def contrast(self, img=0):
+        k = C.c_double()
+        _check(lib().akz_result_contrast(self._h, img, C.byref(k)))
+        return k.value
+
+    def level_info(self, lvl):
+        et, es = C.c_double(), C.c_double()
+        o, s, ss, w, h = (C.c_uint32() for _ in range(5))
+        nt = C.c_uint64()
+        tau = np.zeros(8192, np.float64)
+        _check(lib().akz_result_level_info(self._h, lvl, C.byref(et), C.byref(es), C.byref(o), C.byref(s),
+                                           C.byref(ss), C.byref(w), C.byref(h), C.byref(nt),
+                                           tau.ctypes.data_as(C.POINTER(C.c_double)), len(tau)))
+        return dict(etime=et.value, esigma=es.value, octave=o.value, sublevel=s.value, sigma_size=ss.value,
+                    w=w.value, h=h.value, tau=tau[:nt.value].copy())
+
+    def plane(self, lvl, name, img=0):
+        pid = PLANES.index(name) if isinstance(name, str) else int(name)
+        n = C.c_uint64()
+        _check(lib().akz_fetch_plane(self._h, img, lvl, pid, None, C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 0), np.float32)
+        info = self.level_info(lvl)
+        out = np.empty((info["h"], info["w"]), np.float32)
+        _check(lib().akz_fetch_plane(self._h, img, lvl, pid, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# module-level mirror of the reference's free functions
+# ------------------------------------------------------------------------------------------
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def extract_features(image, options=None, ctx=None):
+    """akaze::extract_features(image, options) -> (evolutions, keypoints, descriptors).
+    `evolutions` is the ExtractResult (planes fetched lazily), keypoints a structured array,
+    descriptors an [n, 61] uint8 array."""
+    r = (ctx or default_context()).extract_features(image, options)
+    return r, r.keypoints(0), r.descriptors(0)
+
+
+def match_features(keypoints_0, descriptors_0, keypoints_1, descriptors_1, lowes_ratio, ctx=None):
+    """Descriptor stage of akaze::match_features (lib.rs:261-266): descriptor_match(d0, d1, 10000, ratio).
+    The RANSAC post-filter (lib.rs:267-274) is host code outside the GPU path."""
+    return (ctx or default_context()).descriptor_match(descriptors_0, descriptors_1, 10000, lowes_ratio)

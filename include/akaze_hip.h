@@ -1,0 +1,234 @@
+/* akaze_hip.h — C ABI of the MI355X-native A-KAZE hot path (libakaze_hip.so).
+ *
+ * The reference crate (indianajohn/akaze-rust) has no FFI/plugin boundary; its
+ * drop-in boundary is the public Rust API.  Every entry point below names the
+ * reference item it replaces (paths relative to the reference repository root).
+ * A Rust shim that re-exports the reference signatures over these symbols is in
+ * akaze-rust_amd/rust/ and described in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns AKZ_OK (0) or a negative akz_status; nothing throws
+ *     or aborts across the ABI.  akz_last_error() gives a thread-local message.
+ *   - an akz_ctx is bound to one GPU and one HIP stream and is NOT thread-safe;
+ *     use one context per host thread / per GPU.
+ *   - images are row-major, contiguous, index = w*y + x, exactly like
+ *     GrayFloatImage (akaze/src/types/image.rs:32-36).  A batch of n images of
+ *     equal size is n such planes back to back (plane stride = w*h elements).
+ *   - pointers named d_* are DEVICE pointers (hipMalloc / torch CUDA tensors);
+ *     all others are host pointers.
+ *   - "op" entry points enqueue on the context's stream and return without
+ *     synchronising unless they hand a value back to the host.
+ */
+#ifndef AKAZE_HIP_H
+#define AKAZE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AKZ_ABI_VERSION 1
+
+typedef enum akz_status {
+    AKZ_OK = 0,
+    AKZ_ERR_INVALID_ARG = -1,  /* null pointer, zero size, unsupported Config value    */
+    AKZ_ERR_HIP = -2,          /* a HIP runtime call failed (message in akz_last_error) */
+    AKZ_ERR_NO_DEVICE = -3,    /* no gfx950 device visible / extension cannot run        */
+    AKZ_ERR_TOO_SMALL = -4,    /* image smaller than the stencil supports                */
+    AKZ_ERR_OVERFLOW = -5,     /* a fixed-capacity device buffer (candidates) overflowed */
+    AKZ_ERR_UNSUPPORTED = -6,  /* reference behaviour that does not terminate / panics   */
+    AKZ_ERR_BUFFER = -7        /* caller buffer too small                                */
+} akz_status;
+
+/* types::evolution::Config — akaze/src/types/evolution.rs:8-38 (defaults :40-55). */
+typedef struct akz_config {
+    uint32_t num_sublevels;
+    uint32_t max_octave_evolution;
+    double base_scale_offset;
+    double initial_contrast; /* declared by the reference, never read */
+    double contrast_percentile;
+    uint64_t contrast_factor_num_bins;
+    double derivative_factor;
+    double detector_threshold;
+    uint64_t descriptor_channels;
+    uint64_t descriptor_pattern_size;
+} akz_config;
+
+/* types::keypoint::Keypoint — akaze/src/types/keypoint.rs:8-30 (point = (x, y)). */
+typedef struct akz_keypoint {
+    float x, y;
+    float response;
+    float size;
+    uint64_t octave;
+    uint64_t class_id;
+    float angle;
+    uint32_t _pad;
+} akz_keypoint;
+
+/* types::feature_match::Match — akaze/src/types/feature_match.rs:9-16. */
+typedef struct akz_match {
+    uint64_t index_0;
+    uint64_t index_1;
+    double distance;
+} akz_match;
+
+/* EvolutionStep image fields in declaration order — akaze/src/types/evolution.rs:71-89. */
+typedef enum akz_plane {
+    AKZ_LT = 0, AKZ_LSMOOTH = 1, AKZ_LX = 2, AKZ_LY = 3, AKZ_LXX = 4,
+    AKZ_LYY = 5, AKZ_LXY = 6, AKZ_LFLOW = 7, AKZ_LSTEP = 8, AKZ_LDET = 9
+} akz_plane;
+
+/* akz_extract_* flags */
+enum {
+    /* keep every EvolutionStep plane resident so akz_fetch_plane can return it
+       (what extract_features returns, akaze/src/lib.rs:193).  Without it only the
+       planes later stages read (Lt, Lsmooth, Lx, Ly, Lflow, Ldet) are materialised and
+       Lxx/Lyy/Lxy/Lstep are never written. */
+    AKZ_KEEP_ALL_PLANES = 1u << 0,
+    /* leave keypoints/descriptors on the device only (no D2H of descriptors) */
+    AKZ_NO_HOST_DESCRIPTORS = 1u << 1
+};
+
+typedef struct akz_ctx akz_ctx;
+typedef struct akz_result akz_result;
+
+/* ---- library ------------------------------------------------------------------------ */
+int akz_abi_version(void);
+const char* akz_last_error(void);
+/* Config::default() — akaze/src/types/evolution.rs:40-55 */
+void akz_config_default(akz_config* out);
+
+/* ---- context ------------------------------------------------------------------------ */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream),
+   or NULL to let the context create its own. */
+int akz_ctx_create(int device, void* stream, akz_ctx** out);
+int akz_ctx_destroy(akz_ctx* ctx);
+int akz_ctx_synchronize(akz_ctx* ctx);
+void* akz_ctx_stream(akz_ctx* ctx);
+
+/* plain device-memory helpers so a non-torch host (the Rust shim) needs no HIP bindings */
+int akz_device_malloc(akz_ctx* ctx, size_t bytes, void** d_out);
+int akz_device_free(akz_ctx* ctx, void* d_ptr);
+int akz_memcpy_h2d(akz_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int akz_memcpy_d2h(akz_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ---- host-side planning (scalar code the reference also runs on the CPU) ------------- */
+/* ops::fed_tau::fed_tau_by_process_time — akaze/src/ops/fed_tau.rs:27-30 (+ :43-106).
+   Writes min(*n, cap) step sizes.  AKZ_ERR_UNSUPPORTED where the reference never
+   terminates (n == 1 with reordering, fed_tau.rs:95). */
+int akz_fed_tau_by_process_time(double T, int M, double tau_max, int reordering, double* out, uint64_t cap,
+                                uint64_t* n);
+/* types::image::gaussian_kernel — akaze/src/types/image.rs:352-365 */
+int akz_gaussian_kernel(float sigma, uint64_t kernel_size, float* out);
+/* ops::derivatives::scharr_{main,off}_axis_kernel — akaze/src/ops/derivatives.rs:74-101 */
+int akz_scharr_kernels(uint32_t scale, float* main_axis, float* off_axis);
+/* types::evolution::allocate_evolutions — akaze/src/types/evolution.rs:135-161.
+   Level sizes follow the chained half_size of create_nonlinear_scale_space (lib.rs:80-90). */
+int akz_plan_num_levels(uint32_t w, uint32_t h, const akz_config* cfg, uint64_t* n_levels);
+int akz_plan_level_info(uint32_t w, uint32_t h, const akz_config* cfg, uint64_t level, double* etime, double* esigma,
+                        uint32_t* octave, uint32_t* sublevel, uint32_t* sigma_size, uint32_t* level_w,
+                        uint32_t* level_h, uint32_t* detector_sigma, uint64_t* n_tau, double* tau, uint64_t tau_cap);
+
+/* ---- per-op entry points on device planes (mirror of `pub mod ops` / `types::image`) -- */
+/* types::image::horizontal_filter / vertical_filter incl. fill_border — image.rs:239-332 */
+int akz_op_horizontal_filter(akz_ctx* ctx, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                             const float* taps, uint32_t ntaps);
+int akz_op_vertical_filter(akz_ctx* ctx, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                           const float* taps, uint32_t ntaps);
+/* types::image::gaussian_blur — image.rs:374-380 */
+int akz_op_gaussian_blur(akz_ctx* ctx, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                         float sigma);
+/* create_unit_float_image + gaussian_blur on 8-bit luma — image.rs:127-140, lib.rs:56 */
+int akz_op_gaussian_blur_u8(akz_ctx* ctx, const uint8_t* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                            float sigma);
+/* ImageFunctions::half_size — image.rs:102-118 ; out is (w/2) x (h/2) */
+int akz_op_half_size(akz_ctx* ctx, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n);
+/* ops::derivatives::scharr — derivatives.rs:112-130 (x_order xor y_order; both -> INVALID_ARG) */
+int akz_op_scharr(akz_ctx* ctx, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n, int x_order,
+                  int y_order, uint32_t sigma_size);
+/* pm_g2 — lib.rs:26-41 ; d_k: n contrast factors (double) on the device */
+int akz_op_pm_g2(akz_ctx* ctx, const float* d_lx, const float* d_ly, float* d_out, uint32_t w, uint32_t h, uint32_t n,
+                 const double* d_k);
+/* ops::contrast_factor::compute_contrast_factor — contrast_factor.rs:18-71 ; writes n doubles to d_k_out */
+int akz_op_contrast_factor(akz_ctx* ctx, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile,
+                           double gradient_histogram_scale, uint64_t num_bins, double* d_k_out);
+/* Lsmooth -> Lflow of one level: scharr(sigma 1) x2 + pm_g2 — lib.rs:98-105.
+   d_k: per-image contrast factor of octave 0; k_scale_pow = number of x0.75 octave steps (lib.rs:84). */
+int akz_op_flow(akz_ctx* ctx, const float* d_lsmooth, float* d_lflow, uint32_t w, uint32_t h, uint32_t n,
+                const double* d_k, uint32_t k_scale_pow);
+/* ops::nonlinear_diffusion::calculate_step, n_tau times — nonlinear_diffusion.rs:15-144.
+   d_lt is updated in place (as the reference does); d_lstep (may be NULL) receives the
+   last step's increment.  taus are the f64 step sizes of the level. */
+int akz_op_fed_steps(akz_ctx* ctx, float* d_lt, const float* d_lflow, float* d_lstep, uint32_t w, uint32_t h,
+                     uint32_t n, const double* taus, uint32_t n_tau);
+/* compute_multiscale_derivatives_for_evolution + Ldet — detector_response.rs:8-14, :40-54.
+   d_lxx/d_lyy/d_lxy may be NULL (not materialised). */
+int akz_op_detector_response(akz_ctx* ctx, const float* d_lsmooth, uint32_t sigma_size, float* d_lx, float* d_ly,
+                             float* d_lxx, float* d_lyy, float* d_lxy, float* d_ldet, uint32_t w, uint32_t h,
+                             uint32_t n);
+
+/* ---- the hot path: extract_features -------------------------------------------------- */
+/* akaze::extract_features — akaze/src/lib.rs:167-194, minus image::open/to_luma (ingest is
+   upstream of the path).  Host-buffer forms copy the frame(s) H2D first. */
+int akz_extract_gray_u8(akz_ctx* ctx, const uint8_t* img, uint32_t w, uint32_t h, const akz_config* cfg,
+                        uint32_t flags, akz_result** out);
+int akz_extract_gray_f32(akz_ctx* ctx, const float* img, uint32_t w, uint32_t h, const akz_config* cfg,
+                         uint32_t flags, akz_result** out);
+/* n equally sized frames already resident in HBM; one result handle for the batch */
+int akz_extract_device_u8(akz_ctx* ctx, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                          const akz_config* cfg, uint32_t flags, akz_result** out);
+int akz_extract_device_f32(akz_ctx* ctx, const float* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                           const akz_config* cfg, uint32_t flags, akz_result** out);
+
+int akz_result_free(akz_result* res);
+int akz_result_num_images(const akz_result* res, uint64_t* n_images);
+/* (Vec<EvolutionStep>.len(), Vec<Keypoint>.len(), Descriptor.vector.len()) of image `img` */
+int akz_result_counts(const akz_result* res, uint64_t img, uint64_t* n_levels, uint64_t* n_keypoints,
+                      uint64_t* desc_bytes);
+int akz_result_keypoints(const akz_result* res, uint64_t img, akz_keypoint* out /* n_keypoints */);
+/* unpadded: n_keypoints * desc_bytes bytes, Descriptor.vector of each keypoint back to back */
+int akz_result_descriptors(const akz_result* res, uint64_t img, uint8_t* out);
+/* device-resident descriptors, 64-byte rows (desc_bytes used, rest zero), for akz_match_device / RCCL gather */
+int akz_result_device_descriptors(const akz_result* res, uint64_t img, const uint8_t** d_desc, uint64_t* n_keypoints);
+/* the contrast factor compute_contrast_factor returned for image `img` (lib.rs:64-69) */
+int akz_result_contrast(const akz_result* res, uint64_t img, double* k);
+/* scalar fields of EvolutionStep — evolution.rs:59-70, :91 */
+int akz_result_level_info(const akz_result* res, uint64_t level, double* etime, double* esigma, uint32_t* octave,
+                          uint32_t* sublevel, uint32_t* sigma_size, uint32_t* w, uint32_t* h, uint64_t* n_tau,
+                          double* tau, uint64_t tau_cap);
+/* lazy D2H of one EvolutionStep image; *n_px = 0 for the 0x0 planes (level 0 Lflow/Lstep, or
+   planes not kept without AKZ_KEEP_ALL_PLANES).  out may be NULL to query the size. */
+int akz_fetch_plane(const akz_result* res, uint64_t img, uint64_t level, akz_plane plane, float* out,
+                    uint64_t* n_px);
+/* device address of a resident plane (NULL if not kept) */
+int akz_result_device_plane(const akz_result* res, uint64_t img, uint64_t level, akz_plane plane,
+                            const float** d_plane);
+
+/* ---- the hot path: match_features (descriptor part) ---------------------------------- */
+/* ops::feature_matching::descriptor_match — akaze/src/ops/feature_matching.rs:23-94.
+   d0: n0 x desc_bytes, d1: n1 x desc_bytes (host, unpadded).  out must hold n0 entries. */
+int akz_descriptor_match(akz_ctx* ctx, const uint8_t* d0, uint64_t n0, const uint8_t* d1, uint64_t n1,
+                         uint64_t desc_bytes, uint64_t distance_threshold, double lowes_ratio, akz_match* out,
+                         uint64_t* n_out);
+/* same on device-resident 64-byte descriptor rows (what akz_result_device_descriptors and the
+   RCCL gather produce).  d_out: n0 akz_match records on the device, compacted in index_0
+   order; *d_n_out (device uint64) receives the count. */
+int akz_descriptor_match_device(akz_ctx* ctx, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
+                                uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
+                                uint64_t* d_n_out);
+
+/* ---- measurement hooks --------------------------------------------------------------- */
+/* Deterministic synthetic 8-bit luma frame (integer-only, SplitMix64-seeded):
+   gradient background + w*h/2048 random rectangles/discs + +-8 noise.  (shift_x, shift_y)
+   translates the shapes, giving a second view of the same frame for match tests.  Host code. */
+int akz_synth_frame_u8(uint8_t* out, uint32_t w, uint32_t h, uint64_t frame_index, int32_t shift_x,
+                       int32_t shift_y);
+/* name of the FED kernel variant the context uses (for bench / profiles) */
+const char* akz_fed_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKAZE_HIP_H */

@@ -1,0 +1,933 @@
+// akaze_ref — CPU ORACLE for the A-KAZE hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is a C++17 restatement of the reference crate's CPU algorithm
+// (indianajohn/akaze-rust, mounted at /root/reference while developing).  It is
+// the checker that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+// leg compare the HIP path against.  Nothing in the product path
+// (akaze-rust_amd/) may include, link or call it.
+//
+// PARITY STATUS: the reference is Rust and neither rustc nor cargo exists in
+// this image, so the reference cannot be executed here.  The oracle is pinned
+// only by the numeric literals the reference's own tests hold:
+//   * gaussian_kernel(3.0, 7)            akaze/src/types/image.rs:486-502
+//   * scharr kernels at scale 1          akaze/src/ops/derivatives.rs:11-28
+// Everything downstream (scale space, Ldet, keypoints, descriptor bytes, match
+// pairs) is "parity unpinned": no golden vectors exist in the reference and
+// none can be generated from it in this container.  See DESIGN.md.
+//
+// Arithmetic rules followed throughout: f32/f64
+// exactly where the reference uses them, no FMA contraction (build with
+// -ffp-contract=off), round() = half away from zero, float->usize casts
+// saturate, transcendental functions come from the host libm with run-time
+// arguments (build with -fno-builtin so gcc cannot fold them with MPFR).
+//
+// Each function cites the reference lines it restates as  [ref: path:lines].
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace akref {
+
+// ---------------------------------------------------------------------------
+// Types                                  [ref: akaze/src/types/image.rs:32-36]
+// ---------------------------------------------------------------------------
+struct Image {
+    int w = 0, h = 0;
+    std::vector<float> px;  // row-major, index = w*y + x
+    Image() = default;
+    Image(int w_, int h_) : w(w_), h(h_), px(size_t(w_) * size_t(h_), 0.0f) {}
+    float get(int x, int y) const { return px[size_t(w) * y + x]; }
+    void put(int x, int y, float v) { px[size_t(w) * y + x] = v; }
+};
+
+// [ref: akaze/src/types/evolution.rs:8-38, defaults :40-55]
+struct Config {
+    uint32_t num_sublevels = 4;
+    uint32_t max_octave_evolution = 4;
+    double base_scale_offset = 1.6;
+    double initial_contrast = 0.001;  // declared, never read by the reference
+    double contrast_percentile = 0.7;
+    uint64_t contrast_factor_num_bins = 300;
+    double derivative_factor = 1.5;
+    double detector_threshold = 0.001;
+    uint64_t descriptor_channels = 3;
+    uint64_t descriptor_pattern_size = 10;
+};
+
+// [ref: akaze/src/types/keypoint.rs:8-30]
+struct Keypoint {
+    float x, y;
+    float response;
+    float size;
+    uint64_t octave;
+    uint64_t class_id;
+    float angle;
+};
+
+// [ref: akaze/src/types/feature_match.rs:9-16]
+struct Match {
+    uint64_t index_0, index_1;
+    double distance;
+};
+
+// [ref: akaze/src/types/evolution.rs:59-92]
+struct Evolution {
+    double etime = 0, esigma = 0;
+    uint32_t octave = 0, sublevel = 0, sigma_size = 0;
+    Image Lt, Lsmooth, Lx, Ly, Lxx, Lyy, Lxy, Lflow, Lstep, Ldet;
+    std::vector<double> fed_tau_steps;
+};
+
+static inline uint64_t sat_usize(double v) {  // Rust `as usize` from a float
+    if (!(v > 0.0)) return 0;                  // NaN and negatives -> 0
+    if (v >= 18446744073709551615.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+static inline uint32_t sat_u32(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 4294967295.0) return UINT32_MAX;
+    return (uint32_t)v;
+}
+
+// ---------------------------------------------------------------------------
+// Image primitives
+// ---------------------------------------------------------------------------
+
+// [ref: akaze/src/types/image.rs:102-118]  2x2 mean; x outer, y inner; the sum
+// starts at 0 and adds (2x,2y), (2x,2y+1), (2x+1,2y), (2x+1,2y+1) in that order.
+Image half_size(const Image& src) {
+    Image out(src.w / 2, src.h / 2);
+    for (int x = 0; x < out.w; ++x)
+        for (int y = 0; y < out.h; ++y) {
+            float val = 0.0f;
+            for (int xs = 2 * x; xs < 2 * x + 2; ++xs)
+                for (int ys = 2 * y; ys < 2 * y + 2; ++ys) val += src.get(xs, ys);
+            out.put(x, y, val / 4.0f);
+        }
+    return out;
+}
+
+// [ref: akaze/src/types/image.rs:239-260]
+void fill_border(Image& o, int hw) {
+    for (int x = 0; x < o.w; ++x) {
+        float plus = o.get(x, hw);
+        float minus = o.get(x, o.h - hw - 1);
+        for (int y = 0; y < hw; ++y) o.put(x, y, plus);
+        for (int y = o.h - hw; y < o.h; ++y) o.put(x, y, minus);
+    }
+    for (int y = 0; y < o.h; ++y) {
+        float plus = o.get(hw, y);
+        float minus = o.get(o.w - hw - 1, y);
+        for (int x = 0; x < hw; ++x) o.put(x, y, plus);
+        for (int x = o.w - hw; x < o.w; ++x) o.put(x, y, minus);
+    }
+}
+
+// [ref: akaze/src/types/image.rs:270-295]  One flat pass over the whole buffer
+// per tap (zero taps included), the image treated as a 1-D array; rows wrap
+// into each other at the left/right edges and fill_border repairs that.
+Image horizontal_filter(const Image& img, const std::vector<float>& kern) {
+    const int hw = int(kern.size() / 2);
+    const long n = long(img.w) * img.h;
+    Image out(img.w, img.h);
+    for (int k = -hw; k <= hw; ++k) {
+        const float kv = kern[size_t(k + hw)];
+        // out index runs hw .. n-hw-2 inclusive  (loop count n-2hw-1)
+        for (long i = hw; i < n - hw - 1; ++i) out.px[size_t(i)] += kv * img.px[size_t(i + k)];
+    }
+    fill_border(out, hw);
+    return out;
+}
+
+// [ref: akaze/src/types/image.rs:305-332]
+Image vertical_filter(const Image& img, const std::vector<float>& kern) {
+    const int hw = int(kern.size() / 2);
+    const long w = img.w;
+    const long n = long(img.w) * img.h;
+    Image out(img.w, img.h);
+    for (int k = -hw; k <= hw; ++k) {
+        const float kv = kern[size_t(k + hw)];
+        for (long i = hw * w; i < n - hw * w - 1; ++i)
+            out.px[size_t(i)] += kv * img.px[size_t(i + k * w)];
+    }
+    fill_border(out, hw);
+    return out;
+}
+
+// [ref: akaze/src/types/image.rs:341-343]  all f32.
+static float gaussian(float x, float r) {
+    const float pi = 3.14159265358979323846f;
+    float a = std::sqrt(2.0f * pi) * r;
+    float recip = 1.0f / a;
+    float arg = -(x * x) / (2.0f * (r * r));
+    return recip * expf(arg);
+}
+
+// [ref: akaze/src/types/image.rs:352-365]
+std::vector<float> gaussian_kernel(float r, size_t kernel_size) {
+    std::vector<float> kernel(kernel_size, 0.0f);
+    const int hw = int(kernel_size / 2);
+    float sum = 0.0f;
+    for (int i = -hw; i <= hw; ++i) {
+        float val = gaussian(float(i), r);
+        kernel[size_t(i + hw)] = val;
+        sum += val;
+    }
+    for (float& v : kernel) v /= sum;
+    return kernel;
+}
+
+// [ref: akaze/src/types/image.rs:374-380]
+Image gaussian_blur(const Image& img, float r) {
+    size_t kernel_size = size_t(sat_usize(std::ceil(r))) * 2 + 1;
+    std::vector<float> k = gaussian_kernel(r, kernel_size);
+    Image hor = horizontal_filter(img, k);
+    return vertical_filter(hor, k);
+}
+
+// ---------------------------------------------------------------------------
+// Scharr derivatives                  [ref: akaze/src/ops/derivatives.rs:41-130]
+// ---------------------------------------------------------------------------
+std::vector<float> scharr_off_axis_kernel(uint32_t scale) {  // :74-82
+    size_t size = 3 + 2 * size_t(scale - 1);
+    std::vector<float> k(size, 0.0f);
+    k[0] = -1.0f;
+    k[size / 2] = 0.0f;
+    k[size - 1] = 1.0f;
+    return k;
+}
+std::vector<float> scharr_main_axis_kernel(uint32_t scale) {  // :91-101
+    size_t size = 3 + 2 * size_t(scale - 1);
+    double w = 10.0 / 3.0;
+    double norm = 1.0 / (2.0 * double(scale) * (w + 2.0));
+    std::vector<float> k(size, 0.0f);
+    k[0] = float(norm);
+    k[size / 2] = float(w * norm);
+    k[size - 1] = float(norm);
+    return k;
+}
+// "horizontal": main-axis (smoothing) kernel in the H pass, off-axis (difference)
+// kernel in the V pass — as written in the reference (:41-47), not "fixed".
+static Image scharr_horizontal(const Image& img, uint32_t s) {
+    Image hor = horizontal_filter(img, scharr_main_axis_kernel(s));
+    return vertical_filter(hor, scharr_off_axis_kernel(s));
+}
+static Image scharr_vertical(const Image& img, uint32_t s) {  // :59-65
+    Image hor = horizontal_filter(img, scharr_off_axis_kernel(s));
+    return vertical_filter(hor, scharr_main_axis_kernel(s));
+}
+Image scharr(const Image& img, bool x_order, bool y_order, uint32_t s) {  // :112-130
+    if (x_order && y_order) {
+        Image horizontal = scharr_horizontal(img, s);
+        Image vertical = scharr_horizontal(img, s);  // sic: horizontal twice
+        for (size_t i = 0; i < vertical.px.size(); ++i) vertical.px[i] += horizontal.px[i];  // image.rs:218-231
+        return vertical;
+    } else if (x_order) {
+        return scharr_horizontal(img, s);
+    } else if (y_order) {
+        return scharr_vertical(img, s);
+    }
+    return Image(img.w, img.h);
+}
+
+// ---------------------------------------------------------------------------
+// Perona-Malik g2                              [ref: akaze/src/lib.rs:26-41]
+// ---------------------------------------------------------------------------
+Image pm_g2(const Image& Lx, const Image& Ly, double k) {
+    Image dst(Lx.w, Lx.h);
+    const double inverse_k = 1.0 / (k * k);
+    for (size_t i = 0; i < dst.px.size(); ++i) {
+        double lx = double(Lx.px[i]), ly = double(Ly.px[i]);
+        double v = 1.0 / (1.0 + inverse_k * (lx * lx + ly * ly));
+        dst.px[i] = float(v);
+    }
+    return dst;
+}
+
+// ---------------------------------------------------------------------------
+// Contrast factor              [ref: akaze/src/ops/contrast_factor.rs:18-71]
+// ---------------------------------------------------------------------------
+double compute_contrast_factor(const Image& image, double percentile, double gscale, size_t num_bins) {
+    double num_points = 0.0, hmax = 0.0;
+    std::vector<double> histogram(num_bins, 0.0);
+    Image gaussian = gaussian_blur(image, float(gscale));
+    Image Lx = scharr(gaussian, true, false, 1);
+    Image Ly = scharr(gaussian, false, true, 1);
+    for (int y = 1; y < gaussian.h - 1; ++y)
+        for (int x = 1; x < gaussian.w - 1; ++x) {
+            double lx = double(Lx.get(x, y)), ly = double(Ly.get(x, y));
+            double modg = std::sqrt(lx * lx + ly * ly);
+            if (modg > hmax) hmax = modg;
+        }
+    for (int y = 1; y < gaussian.h - 1; ++y)
+        for (int x = 1; x < gaussian.w - 1; ++x) {
+            double lx = double(Lx.get(x, y)), ly = double(Ly.get(x, y));
+            double modg = std::sqrt(lx * lx + ly * ly);
+            if (modg != 0.0) {
+                uint64_t bin = sat_usize(std::floor(double(num_bins) * (modg / hmax)));
+                if (bin == num_bins) bin -= 1;
+                histogram[size_t(bin)] += 1.0;
+                num_points += 1.0;
+            }
+        }
+    const uint64_t threshold = sat_usize(num_points * percentile);
+    uint64_t k = 0, num_elements = 0;
+    while (num_elements < threshold && k < num_bins) {
+        num_elements += sat_usize(histogram[size_t(k)]);
+        k += 1;
+    }
+    if (num_elements >= threshold) return hmax * double(k) / double(num_bins);
+    return 0.03;
+}
+
+// ---------------------------------------------------------------------------
+// FED step sizes                         [ref: akaze/src/ops/fed_tau.rs:27-106]
+// ---------------------------------------------------------------------------
+static bool is_prime(uint64_t n) {  // primal::is_prime (third-party, trivial)
+    if (n < 2) return false;
+    for (uint64_t d = 2; d * d <= n; ++d)
+        if (n % d == 0) return false;
+    return true;
+}
+// returns false for n == 1 with reordering: the reference underflows a usize
+// there (fed_tau.rs:95) and never terminates in release builds.
+bool fed_tau_internal(size_t n, double scale, double tau_max, bool reordering, std::vector<double>& tau) {
+    tau.clear();
+    if (n == 0) return true;
+    std::vector<double> tauh(reordering ? n : 0, 0.0);
+    tau.assign(n, 0.0);
+    const double pi = 3.14159265358979323846264338327950288;
+    const double c = 1.0 / (4.0 * double(n) + 2.0);
+    const double d = scale * tau_max / 2.0;
+    for (size_t k = 0; k < n; ++k) {
+        double h = cos(pi * (2.0 * double(k) + 1.0) * c);
+        if (reordering) tauh[k] = d / (h * h);
+        else tau[k] = d / (h * h);
+    }
+    if (reordering) {
+        const size_t kappa = n / 2;
+        if (kappa == 0) return false;
+        size_t prime = n + 1;
+        while (!is_prime(prime)) prime += 1;
+        size_t k = 0;
+        for (size_t t = 0; t < n; ++t) {
+            size_t index = ((k + 1) * kappa) % prime - 1;  // wraps like release-mode usize
+            while (index >= n) {
+                k += 1;
+                index = ((k + 1) * kappa) % prime - 1;
+            }
+            tau[t] = tauh[index];
+            k += 1;
+        }
+    }
+    return true;
+}
+bool fed_tau_by_process_time(double T, int M, double tau_max, bool reordering, std::vector<double>& tau) {
+    const double t = T / double(M);  // :27-30
+    // :43-49
+    const size_t n = size_t(sat_usize(std::ceil(std::sqrt(3.0 * t / tau_max + 0.25) - 0.5 - 1.0e-8) + 0.5));
+    const double scale = 3.0 * t / (tau_max * double(n * (n + 1)));
+    return fed_tau_internal(n, scale, tau_max, reordering, tau);
+}
+
+// ---------------------------------------------------------------------------
+// Evolution planning               [ref: akaze/src/types/evolution.rs:101-161]
+// ---------------------------------------------------------------------------
+bool allocate_evolutions(uint32_t width, uint32_t height, const Config& o, std::vector<Evolution>& out) {
+    out.clear();
+    for (uint32_t i = 0; i < o.max_octave_evolution; ++i) {
+        double rfactor = 1.0 / pow(2.0, double(i));
+        uint32_t level_height = sat_u32(double(height) * rfactor);
+        uint32_t level_width = sat_u32(double(width) * rfactor);
+        if ((level_width >= 80 && level_height >= 40) || i == 0) {
+            for (uint32_t j = 0; j < o.num_sublevels; ++j) {
+                Evolution e;
+                e.esigma = o.base_scale_offset * pow(2.0, double(j) / double(o.num_sublevels) + double(i));
+                e.etime = 0.5 * (e.esigma * e.esigma);
+                e.octave = i;
+                e.sublevel = j;
+                e.sigma_size = sat_u32(std::round(e.esigma));
+                out.push_back(std::move(e));
+            }
+        } else {
+            break;
+        }
+    }
+    for (size_t i = 1; i < out.size(); ++i) {
+        double ttime = out[i].etime - out[i - 1].etime;
+        if (!fed_tau_by_process_time(ttime, 1, 0.25, true, out[i].fed_tau_steps)) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// One explicit diffusion step   [ref: akaze/src/ops/nonlinear_diffusion.rs:15-173]
+// ---------------------------------------------------------------------------
+void calculate_step(Image& Ld, const Image& c, Image& Lstep, double step_size) {
+    const int w = Lstep.w, h = Lstep.h;
+    const float half_tau = 0.5f * float(step_size);
+    auto L = [&](int x, int y) { return Ld.get(x, y); };
+    auto C = [&](int x, int y) { return c.get(x, y); };
+    auto xpos = [&](int x, int y) { return (C(x, y) + C(x + 1, y)) * (L(x + 1, y) - L(x, y)); };
+    auto xneg = [&](int x, int y) { return (C(x - 1, y) + C(x, y)) * (L(x, y) - L(x - 1, y)); };
+    auto ypos = [&](int x, int y) { return (C(x, y) + C(x, y + 1)) * (L(x, y + 1) - L(x, y)); };
+    auto yneg = [&](int x, int y) { return (C(x, y - 1) + C(x, y)) * (L(x, y) - L(x, y - 1)); };
+    // "y_pos" of the last row (:105, :111, :116): offsets [0,-1,-1,0]
+    auto ypos_last = [&](int x, int y) { return (C(x, y) + C(x, y - 1)) * (L(x, y - 1) - L(x, y)); };
+    const int xend = w - 1, yend = h - 1;
+    for (int y = 1; y < h - 1; ++y)  // :30-81
+        for (int x = 1; x < w - 1; ++x)
+            Lstep.put(x, y, half_tau * (xpos(x, y) - xneg(x, y) + ypos(x, y) - yneg(x, y)));
+    for (int x = 1; x < w - 1; ++x)  // first row :83-92
+        Lstep.put(x, 0, half_tau * (xpos(x, 0) - xneg(x, 0) + ypos(x, 0)));
+    Lstep.put(0, 0, half_tau * (xpos(0, 0) + ypos(0, 0)));                       // :94-97
+    Lstep.put(xend, 0, half_tau * (-xneg(xend, 0) + ypos(xend, 0)));             // :99-102
+    for (int x = 1; x < w - 1; ++x)  // last row :104-109
+        Lstep.put(x, yend, half_tau * (xpos(x, yend) - xneg(x, yend) + ypos_last(x, yend)));
+    Lstep.put(0, yend, half_tau * (xpos(0, yend) + ypos_last(0, yend)));         // :110-114
+    Lstep.put(xend, yend, half_tau * (-xneg(xend, yend) + ypos_last(xend, yend)));  // :115-119
+    for (int y = 1; y < h - 1; ++y) {  // first / last column :121-138
+        Lstep.put(0, y, half_tau * (xpos(0, y) + ypos(0, y) - yneg(0, y)));
+        Lstep.put(xend, y, half_tau * (-xneg(xend, y) + ypos(xend, y) - yneg(xend, y)));
+    }
+    for (size_t i = 0; i < Ld.px.size(); ++i) Ld.px[i] += Lstep.px[i];  // :140-143
+}
+
+// ---------------------------------------------------------------------------
+// Nonlinear scale space                      [ref: akaze/src/lib.rs:49-120]
+// ---------------------------------------------------------------------------
+void create_nonlinear_scale_space(std::vector<Evolution>& ev, const Image& image, const Config& o,
+                                  double* contrast_out) {
+    ev[0].Lt = gaussian_blur(image, float(o.base_scale_offset));
+    ev[0].Lsmooth = ev[0].Lt;
+    double contrast = compute_contrast_factor(ev[0].Lsmooth, o.contrast_percentile, 1.0,
+                                              size_t(o.contrast_factor_num_bins));
+    if (contrast_out) *contrast_out = contrast;
+    for (size_t i = 1; i < ev.size(); ++i) {
+        if (ev[i].octave > ev[i - 1].octave) {
+            ev[i].Lt = half_size(ev[i - 1].Lt);
+            contrast *= 0.75;
+        } else {
+            ev[i].Lt = ev[i - 1].Lt;
+        }
+        ev[i].Lsmooth = gaussian_blur(ev[i].Lt, 1.0f);
+        ev[i].Lx = scharr(ev[i].Lsmooth, true, false, 1);
+        ev[i].Ly = scharr(ev[i].Lsmooth, false, true, 1);
+        ev[i].Lflow = pm_g2(ev[i].Lx, ev[i].Ly, contrast);
+        ev[i].Lstep = Image(ev[i].Lt.w, ev[i].Lt.h);
+        for (double tau : ev[i].fed_tau_steps) calculate_step(ev[i].Lt, ev[i].Lflow, ev[i].Lstep, tau);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Detector response         [ref: akaze/src/ops/detector_response.rs:8-55]
+// ---------------------------------------------------------------------------
+static uint32_t level_sigma_size(const Evolution& e, const Config& o) {  // :21-24, :41-42
+    double ratio = pow(2.0, double(e.octave));
+    return sat_u32(std::round(e.esigma * o.derivative_factor / ratio));
+}
+static void multiscale_derivatives_for(Evolution& e, uint32_t s) {  // :8-14
+    e.Lx = scharr(e.Lsmooth, true, false, s);
+    e.Ly = scharr(e.Lsmooth, false, true, s);
+    e.Lxx = scharr(e.Lx, true, false, s);
+    e.Lyy = scharr(e.Ly, false, true, s);
+    e.Lxy = scharr(e.Lx, false, true, s);
+}
+void detector_response(std::vector<Evolution>& ev, const Config& o, unsigned threads) {
+    // :16-29 — the reference runs one job per evolution on a num_cpus pool.
+    if (threads <= 1) {
+        for (auto& e : ev) multiscale_derivatives_for(e, level_sigma_size(e, o));
+    } else {
+        size_t next = 0;
+        while (next < ev.size()) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < threads && next < ev.size(); ++t, ++next) {
+                Evolution* e = &ev[next];
+                uint32_t s = level_sigma_size(*e, o);
+                pool.emplace_back([e, s] { multiscale_derivatives_for(*e, s); });
+            }
+            for (auto& th : pool) th.join();
+        }
+    }
+    for (auto& e : ev) {  // :40-54
+        uint32_t s = level_sigma_size(e, o);
+        uint32_t quat = s * s * s * s;
+        e.Ldet = Image(e.Lxx.w, e.Lxx.h);
+        const float q = float(quat);
+        for (size_t i = 0; i < e.Ldet.px.size(); ++i)
+            e.Ldet.px[i] = ((e.Lxx.px[i] * e.Lyy.px[i]) - (e.Lxy.px[i] * e.Lxy.px[i])) * q;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Scale-space extrema   [ref: akaze/src/ops/scale_space_extrema.rs:12-132]
+// ---------------------------------------------------------------------------
+std::vector<Keypoint> find_scale_space_extrema(const std::vector<Evolution>& ev, const Config& o) {
+    std::vector<Keypoint> cache;
+    const float smax = 10.0f * std::sqrt(2.0f);
+    const float thr = float(o.detector_threshold);
+    for (size_t e_id = 0; e_id < ev.size(); ++e_id) {
+        const Evolution& e = ev[e_id];
+        const long w = e.Ldet.w, h = e.Ldet.h;
+        const std::vector<float>& D = e.Ldet.px;
+        const long len = long(D.size());
+        for (long i = w + 1; i < len - w - 1; ++i) {
+            const long x = i % w, y = i / w;
+            const float v = D[size_t(i)];
+            if (x != 0 && x != w && v > thr && v > D[size_t(i + 1)] && v > D[size_t(i - 1)] &&
+                v > D[size_t(i - w)] && v > D[size_t(i + w)]) {
+                Keypoint kp;
+                kp.response = std::fabs(v);
+                kp.size = float(e.esigma * o.derivative_factor);
+                kp.octave = e.octave;
+                kp.class_id = e_id;
+                kp.x = float(x);
+                kp.y = float(y);
+                kp.angle = 0.0f;
+                const float ratio = powf(2.0f, float(e.octave));
+                const float sigma_size = std::round(kp.size / ratio);
+                size_t id_repeated = 0;
+                bool is_repeated = false, is_extremum = true;
+                for (size_t k = 0; k < cache.size(); ++k) {
+                    const Keypoint& p = cache[k];
+                    if (kp.class_id == p.class_id || (kp.class_id != 0 && kp.class_id - 1 == p.class_id)) {
+                        float dist = (kp.x * ratio - p.x) * (kp.x * ratio - p.x) +
+                                     (kp.y * ratio - p.y) * (kp.y * ratio - p.y);
+                        if (dist <= kp.size * kp.size) {
+                            if (kp.response > p.response) {
+                                id_repeated = k;
+                                is_repeated = true;
+                            } else {
+                                is_extremum = false;
+                            }
+                            break;
+                        }
+                    }
+                }
+                if (is_extremum) {
+                    float left_x = std::round(kp.x - smax * sigma_size) - 1.0f;
+                    float right_x = std::round(kp.x + smax * sigma_size) + 1.0f;
+                    float up_y = std::round(kp.y - smax * sigma_size) - 1.0f;
+                    float down_y = std::round(kp.y + smax * sigma_size) + 1.0f;
+                    bool is_out = left_x < 0.0f || right_x >= float(w) || up_y < 0.0f || down_y >= float(h);
+                    if (!is_out) {
+                        kp.x = kp.x * ratio + 0.5f * (ratio - 1.0f);
+                        kp.y = kp.y * ratio + 0.5f * (ratio - 1.0f);
+                        if (!is_repeated) cache.push_back(kp);
+                        else cache[id_repeated] = kp;
+                    }
+                }
+            }
+        }
+    }
+    std::vector<Keypoint> out;  // :109-129 filter against the upper scale
+    for (size_t i = 0; i < cache.size(); ++i) {
+        bool is_repeated = false;
+        const Keypoint kp_i = cache[i];
+        for (size_t j = i; j < cache.size(); ++j) {
+            const Keypoint& kp_j = cache[j];
+            if (kp_i.class_id + 1 == kp_j.class_id) {
+                float dist = (kp_i.x - kp_j.x) * (kp_i.x - kp_j.x) + (kp_i.y - kp_j.y) * (kp_i.y - kp_j.y);
+                if (dist <= kp_i.size * kp_i.size) {
+                    is_repeated = true;
+                    break;
+                }
+            }
+        }
+        if (!is_repeated) out.push_back(kp_i);
+    }
+    return out;
+}
+
+// published 7x7 half-Gaussian weight table (sigma 2.5) used by SURF/KAZE/A-KAZE
+// [ref: akaze/src/ops/scale_space_extrema.rs:207-271]
+static const float GAUSS25[7][7] = {
+    {0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+    {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+    {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+    {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+    {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+    {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+    {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
+
+// [ref: akaze/src/ops/scale_space_extrema.rs:274-329]  quirks kept: angs uses
+// atan2(res_y, res_y); ang1 is advanced before the window test; the sums are
+// never reset between windows.
+void compute_main_orientation(Keypoint& kp, const std::vector<Evolution>& ev) {
+    float res_x[109], res_y[109], angs[109];
+    static const int id[13] = {6, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 6};
+    const float pi = 3.14159265358979323846f;
+    const Evolution& e = ev[size_t(kp.class_id)];
+    const float ratio = float(1u << e.octave);
+    const float s = std::round(0.5f * kp.size / ratio);
+    const float xf = kp.x / ratio, yf = kp.y / ratio;
+    int idx = 0;
+    for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j)
+            if (i * i + j * j < 36) {
+                int iy = int(sat_usize(std::round(yf + float(j) * s)));
+                int ix = int(sat_usize(std::round(xf + float(i) * s)));
+                float g = GAUSS25[id[i + 6]][id[j + 6]];
+                res_x[idx] = g * e.Lx.get(ix, iy);
+                res_y[idx] = g * e.Ly.get(ix, iy);
+                angs[idx] = atan2f(res_y[idx], res_y[idx]);
+                ++idx;
+            }
+    float ang1 = 0.0f, sum_x = 0.0f, sum_y = 0.0f, max = 0.0f;
+    while (ang1 < 2.0f * pi) {
+        float ang2 = (ang1 + pi / 3.0f > 2.0f * pi) ? (ang1 - 5.0f * pi / 3.0f) : (ang1 + pi / 3.0f);
+        ang1 += 0.15f;
+        for (int k = 0; k < 109; ++k) {
+            float ang = angs[k];
+            if ((ang1 < ang2 && ang1 < ang && ang < ang2) ||
+                (ang2 < ang1 && ((ang > 0.0f && ang < ang2) || (ang > ang1 && ang < 2.0f * pi)))) {
+                sum_x += res_x[k];
+                sum_y += res_y[k];
+            }
+        }
+        float val = sum_x * sum_x + sum_y * sum_y;
+        if (val > max) {
+            max = val;
+            kp.angle = atan2f(sum_y, sum_x);
+        }
+    }
+}
+
+// [ref: akaze/src/ops/scale_space_extrema.rs:141-189]  the LU solve result is
+// discarded by the reference (:168-169), so the offset is b = (-dx, -dy).
+std::vector<Keypoint> do_subpixel_refinement(const std::vector<Keypoint>& in, const std::vector<Evolution>& ev) {
+    std::vector<Keypoint> result;
+    for (const Keypoint& kp : in) {
+        const float ratio = powf(2.0f, float(kp.octave));
+        const int x = int(sat_usize(std::round(kp.x / ratio)));
+        const int y = int(sat_usize(std::round(kp.y / ratio)));
+        const Image& D = ev[size_t(kp.class_id)].Ldet;
+        float x_p = D.get(x + 1, y), x_m = D.get(x - 1, y);
+        float y_p = D.get(x, y + 1), y_m = D.get(x, y - 1);
+        float d_x = 0.5f * (x_p - x_m);
+        float d_y = 0.5f * (y_p - y_m);
+        float b0 = -d_x, b1 = -d_y;
+        if (std::fabs(b0) <= 1.0f && std::fabs(b1) <= 1.0f) {
+            Keypoint c = kp;
+            c.x = float(x) + b0;
+            c.y = float(y) + b1;
+            c.x = c.x * ratio + 0.5f * (ratio - 1.0f);
+            c.y = c.y * ratio + 0.5f * (ratio - 1.0f);
+            result.push_back(c);
+        }
+    }
+    for (Keypoint& kp : result) compute_main_orientation(kp, ev);
+    return result;
+}
+
+// ---------------------------------------------------------------------------
+// M-LDB descriptor                 [ref: akaze/src/ops/descriptors.rs:14-175]
+// ---------------------------------------------------------------------------
+static void mldb_fill_values(float* values, size_t sample_step, const Evolution& e, float xf, float yf, float co,
+                             float si, float scale, const Config& o) {  // :87-151
+    const int pattern = int(o.descriptor_pattern_size);
+    const size_t nch = size_t(o.descriptor_channels);
+    size_t valuepos = 0;
+    for (int i = -pattern; i < pattern; i += int(sample_step))
+        for (int j = -pattern; j < pattern; j += int(sample_step)) {
+            float di = 0.0f, dx = 0.0f, dy = 0.0f;
+            size_t nsamples = 0;
+            for (int k = i; k < i + int(sample_step); ++k)
+                for (int l = j; l < j + int(sample_step); ++l) {
+                    float lf = float(l) + 0.5f;
+                    float kf = float(k) + 0.5f;
+                    float sample_y = yf + (lf * co * scale + kf * si * scale);
+                    float sample_x = xf + (-lf * si * scale + kf * co * scale);
+                    int y1 = int(std::round(sample_y));
+                    int x1 = int(std::round(sample_x));
+                    float ri = e.Lt.get(x1, y1);
+                    di += ri;
+                    if (nch > 1) {
+                        float rx = e.Lx.get(x1, y1);
+                        float ry = e.Ly.get(x1, y1);
+                        if (nch == 2) {
+                            dx += std::sqrt(rx * rx + ry * ry);
+                        } else {
+                            float rry = rx * co + ry * si;
+                            float rrx = -rx * si + ry * co;
+                            dx += rrx;
+                            dy += rry;
+                        }
+                    }
+                    nsamples += 1;
+                }
+            di /= float(nsamples);
+            dx /= float(nsamples);
+            dy /= float(nsamples);
+            values[valuepos] = di;
+            if (nch > 1) values[valuepos + 1] = dx;
+            if (nch > 2) values[valuepos + 2] = dy;
+            valuepos += nch;
+        }
+}
+static void mldb_binary_comparisons(const float* values, uint8_t* desc, size_t count, size_t& dpos, size_t nch) {
+    for (size_t pos = 0; pos < nch; ++pos)  // :154-175
+        for (size_t i = 0; i < count; ++i) {
+            float ival = values[nch * i + pos];
+            for (size_t j = i + 1; j < count; ++j) {
+                uint8_t res = ival > values[nch * j + pos] ? 1 : 0;
+                desc[dpos >> 3] |= uint8_t(res << (dpos & 7));
+                dpos += 1;
+            }
+        }
+}
+size_t descriptor_bytes(const Config& o) { return ((6 + 36 + 120) * size_t(o.descriptor_channels) + 7) / 8; }
+void get_mldb_descriptor(const Keypoint& kp, const std::vector<Evolution>& ev, const Config& o, uint8_t* out) {
+    std::memset(out, 0, descriptor_bytes(o));  // :37-83
+    float values[16 * 3] = {0};
+    const float size_mult[3] = {1.0f, 2.0f / 3.0f, 1.0f / 2.0f};
+    const float ratio = float(1u << kp.octave);
+    const float scale = std::round(0.5f * kp.size / ratio);
+    const float xf = kp.x / ratio, yf = kp.y / ratio;
+    const float co = cosf(kp.angle), si = sinf(kp.angle);
+    size_t dpos = 0;
+    const float pattern_size = float(o.descriptor_pattern_size);
+    for (size_t lvl = 0; lvl < 3; ++lvl) {
+        size_t val_count = (lvl + 2) * (lvl + 2);
+        size_t sample_size = size_t(sat_usize(std::ceil(pattern_size * size_mult[lvl])));
+        mldb_fill_values(values, sample_size, ev[size_t(kp.class_id)], xf, yf, co, si, scale, o);
+        mldb_binary_comparisons(values, out, val_count, dpos, size_t(o.descriptor_channels));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Brute-force Hamming match   [ref: akaze/src/ops/feature_matching.rs:23-123]
+// ---------------------------------------------------------------------------
+static size_t hamming_distance(const uint8_t* a, const uint8_t* b, size_t nbytes, size_t bailout) {  // :113-123
+    size_t d = 0;
+    for (size_t i = 0; i < nbytes; ++i) {
+        d += size_t(__builtin_popcount(unsigned(a[i] ^ b[i])));
+        if (d > bailout) break;
+    }
+    return d;
+}
+std::vector<Match> descriptor_match(const uint8_t* d0, size_t n0, const uint8_t* d1, size_t n1, size_t nbytes,
+                                    size_t distance_threshold, double lowes_ratio) {
+    std::vector<Match> out;
+    for (size_t i = 0; i < n0; ++i) {
+        size_t min_d = distance_threshold, min_j = 0, second = min_d;
+        for (size_t j = 0; j < n1; ++j) {
+            size_t d = hamming_distance(d0 + i * nbytes, d1 + j * nbytes, nbytes, second);
+            if (d < min_d) {
+                second = min_d;
+                min_d = d;
+                min_j = j;
+            } else if (d < second) {
+                second = d;
+            }
+        }
+        if (double(min_d) < double(second) * (lowes_ratio * lowes_ratio)) {
+            if (min_d < distance_threshold) out.push_back(Match{i, min_j, double(min_d)});
+        }
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// extract_features on an in-memory luma image [ref: akaze/src/lib.rs:167-194]
+// (image::open + to_luma are upstream of the path and out of scope)
+// ---------------------------------------------------------------------------
+struct Result {
+    Config cfg;
+    std::vector<Evolution> ev;
+    std::vector<Keypoint> kps;
+    std::vector<uint8_t> desc;
+    double contrast = 0;
+    size_t n_extrema = 0;  // before sub-pixel refinement
+};
+
+Result* extract(const Image& img, const Config& o, unsigned threads) {
+    auto* r = new Result;
+    r->cfg = o;
+    if (!allocate_evolutions(uint32_t(img.w), uint32_t(img.h), o, r->ev)) {
+        delete r;
+        return nullptr;
+    }
+    create_nonlinear_scale_space(r->ev, img, o, &r->contrast);
+    detector_response(r->ev, o, threads);                         // lib.rs:130-138
+    std::vector<Keypoint> ext = find_scale_space_extrema(r->ev, o);
+    r->n_extrema = ext.size();
+    r->kps = do_subpixel_refinement(ext, r->ev);
+    const size_t nb = descriptor_bytes(o);
+    r->desc.assign(r->kps.size() * nb, 0);
+    for (size_t i = 0; i < r->kps.size(); ++i) get_mldb_descriptor(r->kps[i], r->ev, o, &r->desc[i * nb]);
+    return r;
+}
+
+}  // namespace akref
+
+// ===========================================================================
+// C API for ctypes (tests / smoke / bench cpu_baseline only)
+// ===========================================================================
+extern "C" {
+
+struct ref_config {
+    uint32_t num_sublevels, max_octave_evolution;
+    double base_scale_offset, initial_contrast, contrast_percentile;
+    uint64_t contrast_factor_num_bins;
+    double derivative_factor, detector_threshold;
+    uint64_t descriptor_channels, descriptor_pattern_size;
+};
+struct ref_keypoint {
+    float x, y, response, size;
+    uint64_t octave, class_id;
+    float angle;
+    uint32_t _pad;
+};
+struct ref_match {
+    uint64_t index_0, index_1;
+    double distance;
+};
+
+static akref::Config to_cfg(const ref_config* c) {
+    akref::Config o;
+    if (!c) return o;
+    o.num_sublevels = c->num_sublevels;
+    o.max_octave_evolution = c->max_octave_evolution;
+    o.base_scale_offset = c->base_scale_offset;
+    o.initial_contrast = c->initial_contrast;
+    o.contrast_percentile = c->contrast_percentile;
+    o.contrast_factor_num_bins = c->contrast_factor_num_bins;
+    o.derivative_factor = c->derivative_factor;
+    o.detector_threshold = c->detector_threshold;
+    o.descriptor_channels = c->descriptor_channels;
+    o.descriptor_pattern_size = c->descriptor_pattern_size;
+    return o;
+}
+static akref::Image to_img(const float* p, int w, int h) {
+    akref::Image im(w, h);
+    std::memcpy(im.px.data(), p, sizeof(float) * size_t(w) * size_t(h));
+    return im;
+}
+static void from_img(const akref::Image& im, float* out) { std::memcpy(out, im.px.data(), sizeof(float) * im.px.size()); }
+
+void ref_config_default(ref_config* c) {
+    akref::Config o;
+    c->num_sublevels = o.num_sublevels;
+    c->max_octave_evolution = o.max_octave_evolution;
+    c->base_scale_offset = o.base_scale_offset;
+    c->initial_contrast = o.initial_contrast;
+    c->contrast_percentile = o.contrast_percentile;
+    c->contrast_factor_num_bins = o.contrast_factor_num_bins;
+    c->derivative_factor = o.derivative_factor;
+    c->detector_threshold = o.detector_threshold;
+    c->descriptor_channels = o.descriptor_channels;
+    c->descriptor_pattern_size = o.descriptor_pattern_size;
+}
+
+void ref_gaussian_kernel(float r, uint64_t size, float* out) {
+    auto k = akref::gaussian_kernel(r, size_t(size));
+    std::memcpy(out, k.data(), sizeof(float) * k.size());
+}
+void ref_scharr_kernels(uint32_t scale, float* main_axis, float* off_axis) {
+    auto m = akref::scharr_main_axis_kernel(scale);
+    auto o = akref::scharr_off_axis_kernel(scale);
+    std::memcpy(main_axis, m.data(), sizeof(float) * m.size());
+    std::memcpy(off_axis, o.data(), sizeof(float) * o.size());
+}
+void ref_horizontal_filter(const float* img, int w, int h, const float* k, int klen, float* out) {
+    from_img(akref::horizontal_filter(to_img(img, w, h), std::vector<float>(k, k + klen)), out);
+}
+void ref_vertical_filter(const float* img, int w, int h, const float* k, int klen, float* out) {
+    from_img(akref::vertical_filter(to_img(img, w, h), std::vector<float>(k, k + klen)), out);
+}
+void ref_gaussian_blur(const float* img, int w, int h, float r, float* out) {
+    from_img(akref::gaussian_blur(to_img(img, w, h), r), out);
+}
+void ref_half_size(const float* img, int w, int h, float* out) { from_img(akref::half_size(to_img(img, w, h)), out); }
+void ref_scharr(const float* img, int w, int h, int x_order, int y_order, uint32_t sigma, float* out) {
+    from_img(akref::scharr(to_img(img, w, h), x_order != 0, y_order != 0, sigma), out);
+}
+void ref_pm_g2(const float* lx, const float* ly, int w, int h, double k, float* out) {
+    from_img(akref::pm_g2(to_img(lx, w, h), to_img(ly, w, h), k), out);
+}
+double ref_contrast_factor(const float* img, int w, int h, double percentile, double gscale, uint64_t nbins) {
+    return akref::compute_contrast_factor(to_img(img, w, h), percentile, gscale, size_t(nbins));
+}
+// returns n (number of steps) or -1 where the reference would not terminate
+int64_t ref_fed_tau(double T, int M, double tau_max, int reordering, double* out, uint64_t cap) {
+    std::vector<double> tau;
+    if (!akref::fed_tau_by_process_time(T, M, tau_max, reordering != 0, tau)) return -1;
+    for (size_t i = 0; i < tau.size() && i < cap; ++i) out[i] = tau[i];
+    return int64_t(tau.size());
+}
+// in-place on lt / lstep like the reference
+void ref_fed_step(float* lt, const float* lflow, float* lstep, int w, int h, double tau) {
+    akref::Image Lt = to_img(lt, w, h), Lf = to_img(lflow, w, h), Ls = to_img(lstep, w, h);
+    akref::calculate_step(Lt, Lf, Ls, tau);
+    from_img(Lt, lt);
+    from_img(Ls, lstep);
+}
+
+typedef akref::Result ref_result;
+
+ref_result* ref_extract_f32(const float* img, int w, int h, const ref_config* cfg, uint32_t threads) {
+    return akref::extract(to_img(img, w, h), to_cfg(cfg), threads);
+}
+// [ref: akaze/src/types/image.rs:127-140]  f32::from(v) * 1f32 / 255f32
+ref_result* ref_extract_u8(const uint8_t* img, int w, int h, const ref_config* cfg, uint32_t threads) {
+    akref::Image im(w, h);
+    for (size_t i = 0; i < im.px.size(); ++i) im.px[i] = float(img[i]) * 1.0f / 255.0f;
+    return akref::extract(im, to_cfg(cfg), threads);
+}
+void ref_result_free(ref_result* r) { delete r; }
+uint64_t ref_result_num_levels(const ref_result* r) { return r->ev.size(); }
+uint64_t ref_result_num_keypoints(const ref_result* r) { return r->kps.size(); }
+uint64_t ref_result_num_extrema(const ref_result* r) { return r->n_extrema; }
+uint64_t ref_result_desc_bytes(const ref_result* r) { return akref::descriptor_bytes(r->cfg); }
+double ref_result_contrast(const ref_result* r) { return r->contrast; }
+void ref_result_keypoints(const ref_result* r, ref_keypoint* out) {
+    for (size_t i = 0; i < r->kps.size(); ++i) {
+        const auto& k = r->kps[i];
+        out[i] = ref_keypoint{k.x, k.y, k.response, k.size, k.octave, k.class_id, k.angle, 0};
+    }
+}
+void ref_result_descriptors(const ref_result* r, uint8_t* out) { std::memcpy(out, r->desc.data(), r->desc.size()); }
+int ref_result_level_info(const ref_result* r, uint64_t lvl, double* etime, double* esigma, uint32_t* octave,
+                          uint32_t* sublevel, uint32_t* sigma_size, uint32_t* w, uint32_t* h, uint64_t* n_tau,
+                          double* tau, uint64_t tau_cap) {
+    if (lvl >= r->ev.size()) return -1;
+    const auto& e = r->ev[size_t(lvl)];
+    if (etime) *etime = e.etime;
+    if (esigma) *esigma = e.esigma;
+    if (octave) *octave = e.octave;
+    if (sublevel) *sublevel = e.sublevel;
+    if (sigma_size) *sigma_size = e.sigma_size;
+    if (w) *w = uint32_t(e.Lt.w);
+    if (h) *h = uint32_t(e.Lt.h);
+    if (n_tau) *n_tau = e.fed_tau_steps.size();
+    if (tau)
+        for (size_t i = 0; i < e.fed_tau_steps.size() && i < tau_cap; ++i) tau[i] = e.fed_tau_steps[i];
+    return 0;
+}
+// plane ids follow EvolutionStep field order [ref: akaze/src/types/evolution.rs:71-89]
+// 0 Lt 1 Lsmooth 2 Lx 3 Ly 4 Lxx 5 Lyy 6 Lxy 7 Lflow 8 Lstep 9 Ldet
+// returns the number of pixels in the plane (0 for the 0x0 planes of level 0)
+int64_t ref_result_plane(const ref_result* r, uint64_t lvl, int plane, float* out) {
+    if (lvl >= r->ev.size()) return -1;
+    const auto& e = r->ev[size_t(lvl)];
+    const akref::Image* im[10] = {&e.Lt, &e.Lsmooth, &e.Lx, &e.Ly, &e.Lxx, &e.Lyy, &e.Lxy, &e.Lflow, &e.Lstep, &e.Ldet};
+    if (plane < 0 || plane > 9) return -1;
+    if (out) from_img(*im[plane], out);
+    return int64_t(im[plane]->px.size());
+}
+
+// returns number of matches written (out must hold n0 entries)
+uint64_t ref_descriptor_match(const uint8_t* d0, uint64_t n0, const uint8_t* d1, uint64_t n1, uint64_t desc_bytes,
+                              uint64_t distance_threshold, double lowes_ratio, ref_match* out) {
+    auto m = akref::descriptor_match(d0, size_t(n0), d1, size_t(n1), size_t(desc_bytes), size_t(distance_threshold),
+                                     lowes_ratio);
+    for (size_t i = 0; i < m.size(); ++i) out[i] = ref_match{m[i].index_0, m[i].index_1, m[i].distance};
+    return m.size();
+}
+
+}  // extern "C"

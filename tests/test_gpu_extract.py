@@ -1,0 +1,112 @@
+"""GPU end-to-end parity of extract_features / descriptor_match against the CPU oracle and the
+committed golden vectors.  Bar: every EvolutionStep plane, keypoint field, descriptor byte and
+match record identical."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+PLANES = ["Lt", "Lsmooth", "Lx", "Ly", "Lxx", "Lyy", "Lxy", "Lflow", "Lstep", "Ldet"]
+KP_FIELDS = ("x", "y", "response", "size", "octave", "class_id", "angle")
+
+
+def assert_same_result(res, rf, planes=True, img=0):
+    nl, nk, nb = res.counts(img)
+    assert nl == rf.num_levels and nb == rf.desc_bytes
+    assert res.contrast(img) == rf.contrast
+    if planes:
+        for lvl in range(nl):
+            info, rinfo = res.level_info(lvl), rf.level_info(lvl)
+            for f in ("etime", "esigma", "octave", "sublevel", "sigma_size", "w", "h"):
+                assert info[f] == rinfo[f], (lvl, f)
+            assert info["tau"].tobytes() == rinfo["tau"].tobytes()
+            for pl in PLANES:
+                a, b = res.plane(lvl, pl, img), rf.plane(lvl, pl)
+                assert a.shape == b.shape, (lvl, pl, a.shape, b.shape)
+                if a.size and not np.array_equal(a, b):
+                    bad = np.argwhere(a != b)
+                    raise AssertionError(f"level {lvl} plane {pl}: {len(bad)} px differ, first {bad[0]}: "
+                                         f"{a[tuple(bad[0])]!r} vs {b[tuple(bad[0])]!r}")
+    kp, rk = res.keypoints(img), rf.keypoints()
+    assert nk == rf.num_keypoints == len(kp)
+    for f in KP_FIELDS:
+        assert np.array_equal(kp[f], rk[f]), f
+    assert np.array_equal(res.descriptors(img), rf.descriptors())
+
+
+@pytest.mark.parametrize("w,h,idx", [(320, 240, 0), (640, 480, 1), (517, 389, 2)])
+def test_extract_matches_oracle_all_planes(ctx, amd, ref, w, h, idx):
+    frame = amd.synth_frame(w, h, idx)
+    res = ctx.extract_features(frame)
+    rf = ref.extract(frame)
+    assert rf.num_keypoints > 0
+    assert_same_result(res, rf)
+
+
+def test_extract_f32_input_and_lean_planes(ctx, amd, ref):
+    frame = (amd.synth_frame(400, 300, 5).astype(np.float32) * np.float32(1.0)) / np.float32(255.0)
+    res = ctx.extract_features(frame, keep_all_planes=False)
+    rf = ref.extract(frame)
+    assert_same_result(res, rf, planes=False)
+    # planes that are not kept read as 0x0, kept ones are still exact
+    assert res.plane(3, "Lxx").size == 0 and res.plane(3, "Lstep").size == 0
+    assert np.array_equal(res.plane(3, "Ldet"), rf.plane(3, "Ldet"))
+    assert res.plane(0, "Lflow").size == 0 and rf.plane(0, "Lflow").size == 0
+
+
+def test_extract_device_batch(ctx, amd, ref):
+    import torch
+    frames = np.stack([amd.synth_frame(480, 270, i) for i in range(3)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda())
+    assert res.num_images == 3
+    for i in range(3):
+        assert_same_result(res, ref.extract(frames[i]), planes=(i == 1), img=i)
+
+
+def test_extract_nondefault_config(ctx, amd, ref):
+    frame = amd.synth_frame(640, 360, 7)
+    for kw in (dict(num_sublevels=5, max_octave_evolution=5), dict(descriptor_channels=1),
+               dict(descriptor_channels=2), dict(detector_threshold=0.0005, num_sublevels=3)):
+        res = ctx.extract_features(frame, amd.Config(**kw))
+        rf = ref.extract(frame, ref.default_config(**kw))
+        assert_same_result(res, rf, planes=False)
+
+
+def test_golden_vectors(ctx, amd):
+    g = np.load(os.path.join(GOLDEN, "synthetic_small.npz"))
+    descs = {}
+    for name in ("a", "b"):
+        res = ctx.extract_features(g[f"{name}_frame"])
+        assert np.array_equal(res.keypoints().view(np.uint8), g[f"{name}_keypoints"])
+        assert np.array_equal(res.descriptors(), g[f"{name}_descriptors"])
+        assert res.contrast() == float(g[f"{name}_contrast"])
+        descs[name] = res.descriptors()
+    m = ctx.descriptor_match(descs["a"], descs["b"], 10000, 0.86)
+    assert np.array_equal(m.view(np.uint8), g["matches_ab"])
+
+
+def test_extract_and_match_pair(ctx, amd, ref):
+    """Shape of the reference's integration test (akaze/tests/integration-test.rs:73-93) on a synthetic
+    pair: extract both views, descriptor_match with ratio 0.86, compare with the oracle."""
+    f0 = amd.synth_frame(960, 540, 11)
+    f1 = amd.synth_frame(960, 540, 11, shift=(17, 9))
+    r0, r1 = ctx.extract_features(f0), ctx.extract_features(f1)
+    q0, q1 = ref.extract(f0), ref.extract(f1)
+    assert_same_result(r0, q0, planes=False)
+    assert_same_result(r1, q1, planes=False)
+    got = amd.match_features(r0.keypoints(), r0.descriptors(), r1.keypoints(), r1.descriptors(), 0.86, ctx=ctx)
+    exp = ref.descriptor_match(q0.descriptors(), q1.descriptors(), 10000, 0.86)
+    assert len(exp) > 20 and np.array_equal(got, exp)
+
+
+def test_errors(ctx, amd):
+    with pytest.raises(amd.AkazeError) as e:
+        ctx.extract_features(np.zeros((8, 8), np.uint8))
+    assert e.value.status == -4
+    with pytest.raises(amd.AkazeError):
+        ctx.extract_features(amd.synth_frame(320, 240, 0), amd.Config(descriptor_channels=4))
+    with pytest.raises(amd.AkazeError) as e:
+        ctx.extract_features(amd.synth_frame(320, 240, 0), amd.Config(num_sublevels=16))
+    assert e.value.status in (-1, -6)

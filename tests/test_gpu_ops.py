@@ -1,0 +1,160 @@
+"""GPU parity tests, one per op of the C ABI, against the CPU oracle on the same seeded inputs.
+Bar: bit-exact (f32 results compared by value so that -0.0 == +0.0, NaNs never expected)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    import torch
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def same(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert not np.isnan(a).any() and not np.isnan(b).any()
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        raise AssertionError(f"{len(bad)} of {a.size} values differ, first at {bad[0]}: {a[tuple(bad[0])]!r} vs "
+                             f"{b[tuple(bad[0])]!r}; max abs diff {np.abs(a - b).max()}")
+
+
+def rand_img(h, w, seed, lo=0.0, hi=1.0):
+    return np.random.default_rng(seed).uniform(lo, hi, (h, w)).astype(np.float32)
+
+
+SHAPES = [(37, 53), (64, 64), (135, 240), (101, 259)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("klen", [3, 5, 9, 13])
+def test_horizontal_vertical_filter(ctx, ref, shape, klen):
+    img = rand_img(*shape, seed=klen)
+    kern = np.random.default_rng(klen + 1).standard_normal(klen).astype(np.float32)
+    same(host(ctx.horizontal_filter(dev(img), kern)), ref.horizontal_filter(img, kern))
+    same(host(ctx.vertical_filter(dev(img), kern)), ref.vertical_filter(img, kern))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("sigma", [1.0, 1.6, 2.5])
+def test_gaussian_blur(ctx, ref, shape, sigma):
+    img = rand_img(*shape, seed=2)
+    same(host(ctx.gaussian_blur(dev(img), sigma)), ref.gaussian_blur(img, sigma))
+
+
+def test_gaussian_blur_u8_unit_float(ctx, ref):
+    u8 = np.random.default_rng(0).integers(0, 256, (77, 131), dtype=np.uint8)
+    unit = (u8.astype(np.float32) * np.float32(1.0)) / np.float32(255.0)  # image.rs:136
+    same(host(ctx.gaussian_blur(dev(u8), 1.6)), ref.gaussian_blur(unit, 1.6))
+
+
+def test_batch_of_planes(ctx, ref):
+    imgs = np.stack([rand_img(45, 70, s) for s in range(3)])
+    out = host(ctx.gaussian_blur(dev(imgs), 1.0))
+    for i in range(3):
+        same(out[i], ref.gaussian_blur(imgs[i], 1.0))
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (64, 64), (135, 241), (2, 2)])
+def test_half_size(ctx, ref, shape):
+    img = rand_img(*shape, seed=3)
+    same(host(ctx.half_size(dev(img))), ref.half_size(img))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("sigma", [1, 2, 3, 4])
+def test_scharr(ctx, ref, shape, sigma):
+    img = rand_img(*shape, seed=4, lo=-1.0)
+    same(host(ctx.scharr(dev(img), True, False, sigma)), ref.scharr(img, True, False, sigma))
+    same(host(ctx.scharr(dev(img), False, True, sigma)), ref.scharr(img, False, True, sigma))
+
+
+def test_scharr_rejects_unused_orders(ctx, amd):
+    with pytest.raises(amd.AkazeError):
+        ctx.scharr(dev(rand_img(20, 20, 0)), True, True, 1)
+
+
+@pytest.mark.parametrize("k", [0.0043, 0.03, 0.5])
+def test_pm_g2(ctx, ref, k):
+    lx, ly = rand_img(60, 90, 5, -0.2, 0.2), rand_img(60, 90, 6, -0.2, 0.2)
+    same(host(ctx.pm_g2(dev(lx), dev(ly), k)), ref.pm_g2(lx, ly, k))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_flow_is_scharr1_plus_pm_g2(ctx, ref, shape):
+    ls = rand_img(*shape, seed=7)
+    k = 0.0123
+    exp = ref.pm_g2(ref.scharr(ls, True, False, 1), ref.scharr(ls, False, True, 1), k)
+    same(host(ctx.flow(dev(ls), k)), exp)
+    # octave scaling: k * 0.75 * 0.75 multiplied step by step in f64 (lib.rs:84)
+    exp2 = ref.pm_g2(ref.scharr(ls, True, False, 1), ref.scharr(ls, False, True, 1), (k * 0.75) * 0.75)
+    same(host(ctx.flow(dev(ls), k, 2)), exp2)
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(270, 480)])
+def test_contrast_factor(ctx, ref, shape):
+    img = ref.gaussian_blur(rand_img(*shape, seed=8), 1.6)
+    got = float(host(ctx.contrast_factor(dev(img), 0.7, 1.0, 300))[0])
+    assert got == ref.contrast_factor(img, 0.7, 1.0, 300)
+
+
+def test_contrast_factor_flat_image(ctx, ref):
+    img = np.full((40, 50), 0.25, np.float32)
+    assert float(host(ctx.contrast_factor(dev(img)))[0]) == ref.contrast_factor(img)
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(3, 3), (5, 64), (64, 5)])
+@pytest.mark.parametrize("ntau", [1, 2, 5])
+def test_fed_steps_all_border_cases(ctx, ref, shape, ntau):
+    lt = rand_img(*shape, seed=9)
+    c = rand_img(*shape, seed=10)
+    taus = np.array([0.19623365730888334, 3.7012260958150769, 0.12604081556156974, 0.25, 1.5])[:ntau]
+    exp, step = lt.copy(), None
+    for t in taus:
+        exp, step = ref.fed_step(exp, c, t)
+    d_lt = dev(lt)
+    d_step = ctx.fed_steps(d_lt, dev(c), taus, want_lstep=True)
+    same(host(d_lt), exp)
+    same(host(d_step), step)
+
+
+@pytest.mark.parametrize("sigma", [2, 3, 4])
+def test_detector_response(ctx, ref, sigma):
+    ls = rand_img(96, 130, seed=11)
+    got = ctx.detector_response(dev(ls), sigma)
+    lx = ref.scharr(ls, True, False, sigma)
+    ly = ref.scharr(ls, False, True, sigma)
+    lxx = ref.scharr(lx, True, False, sigma)
+    lyy = ref.scharr(ly, False, True, sigma)
+    lxy = ref.scharr(lx, False, True, sigma)
+    q = np.float32(sigma ** 4)
+    ldet = ((lxx * lyy) - (lxy * lxy)) * q
+    for name, exp in (("Lx", lx), ("Ly", ly), ("Lxx", lxx), ("Lyy", lyy), ("Lxy", lxy), ("Ldet", ldet)):
+        same(host(got[name]), exp)
+    lean = ctx.detector_response(dev(ls), sigma, keep_second=False)
+    same(host(lean["Ldet"]), ldet)
+
+
+def test_descriptor_match(ctx, ref):
+    rng = np.random.default_rng(12)
+    d0 = rng.integers(0, 256, (300, 61), dtype=np.uint8)
+    d1 = rng.integers(0, 256, (517, 61), dtype=np.uint8)
+    for i in range(0, 300, 3):  # plant near-duplicates so that the ratio test passes
+        d1[(i * 7) % 517] = d0[i]
+        d1[(i * 7) % 517, i % 61] ^= 0x11
+    d1[100] = d0[4]; d1[400] = d0[4]  # exact tie
+    for ratio, thr in ((0.86, 10000), (0.5, 10000), (0.99, 40)):
+        got = ctx.descriptor_match(d0, d1, thr, ratio)
+        exp = ref.descriptor_match(d0, d1, thr, ratio)
+        assert len(got) == len(exp) and len(got) > 0
+        assert np.array_equal(got, exp)
+    assert len(ctx.descriptor_match(d0, np.zeros((0, 61), np.uint8))) == 0
+    assert np.array_equal(ctx.descriptor_match(d0[:5], d1[:1]), ref.descriptor_match(d0[:5], d1[:1]))
+    assert len(ctx.descriptor_match(np.zeros((0, 61), np.uint8), d1)) == 0

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <time.h>
 #include <type_traits>
 
 #include "akz_internal.hpp"
@@ -31,7 +32,56 @@ struct akz_ctx {
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     std::vector<std::pair<size_t, void*>> slab_pool;  // freed pyramid slabs, reused by size
+    // stage profiling (akz_ctx_set_profiling)
+    bool profiling = false;
+    akz_profile prof{};
+    struct Span { int stage; hipEvent_t a, b; };
+    std::vector<Span> spans;          // recorded, not yet resolved
+    std::vector<hipEvent_t> ev_pool;  // recycled events
 };
+
+// RAII stage timer: device stages bracket the enqueued work with two events on the stream; they
+// are resolved (hipEventElapsedTime) at the end of the extract call, after the final sync.
+struct StageTimer {
+    akz_ctx* c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(akz_ctx* c) {
+        if (!c->ev_pool.empty()) {
+            hipEvent_t e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    StageTimer(akz_ctx* ctx, int st) : c(ctx), stage(st) {
+        if (!c->profiling) return;
+        a = get(c);
+        b = get(c);
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~StageTimer() {
+        if (!c->profiling) return;
+        (void)hipEventRecord(b, c->stream);
+        c->spans.push_back({stage, a, b});
+    }
+};
+static void resolve_spans(akz_ctx* c) {
+    for (auto& sp : c->spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) c->prof.ms[sp.stage] += (double)ms;
+        c->ev_pool.push_back(sp.a);
+        c->ev_pool.push_back(sp.b);
+    }
+    c->spans.clear();
+}
+static double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
 
 static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return AKZ_OK;
@@ -118,6 +168,8 @@ int akz_ctx_destroy(akz_ctx* c) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& s : c->slab_pool) (void)hipFree(s.second);
+    for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return AKZ_OK;
@@ -313,6 +365,10 @@ static int fed_impl(akz_ctx* c, float* a, float* b, const float* lflow, float* l
         const float half_tau = 0.5f * (float)taus[j];
         launch::fed_step(c->stream, cur, lflow, oth, (j + 1 == n_tau) ? lstep : nullptr, w, h, n, half_tau);
         std::swap(cur, oth);
+    }
+    if (c->profiling) {
+        c->prof.fed_launches += n_tau;
+        c->prof.fed_px_steps += (uint64_t)w * h * n * n_tau;
     }
     *result = cur;
     AKZ_HIP_TRY(hipGetLastError());
@@ -551,10 +607,17 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         }
     } guard{r.get()};
 
+    const double t_call0 = now_ms();
     // ---- level 0: Lt0 = gaussian_blur(img, base_scale_offset); contrast factor (lib.rs:56-69) ----
-    AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));
-    AKZ_TRY(contrast_impl(c, P(0, AKZ_LSMOOTH), w, h, n, cfg.contrast_percentile, 1.0, cfg.contrast_factor_num_bins,
-                          r->d_k));
+    {
+        StageTimer st(c, AKZ_ST_BLUR0);
+        AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));
+    }
+    {
+        StageTimer st(c, AKZ_ST_CONTRAST);
+        AKZ_TRY(contrast_impl(c, P(0, AKZ_LSMOOTH), w, h, n, cfg.contrast_percentile, 1.0,
+                              cfg.contrast_factor_num_bins, r->d_k));
+    }
 
     // ---- levels 1..L-1 (lib.rs:78-119) ----
     uint32_t max_w = w, max_h = h;
@@ -566,6 +629,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         float* B = (float*)c->scratch[5].p;
         const uint32_t n_tau = (uint32_t)lv.tau.size();
         float* start = (n_tau % 2 == 0) ? A : B;  // so that the last step lands in the Lt plane
+        std::unique_ptr<StageTimer> st_prep(new StageTimer(c, AKZ_ST_PREP));
         if (lv.octave > pv.octave) {
             launch::half_size(s, P(i - 1, AKZ_LT), start, pv.w, pv.h, n);
         } else {
@@ -576,9 +640,13 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         launch::flow(s, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h, n, r->d_k, lv.octave);
         float* lstep = keep_all ? P(i, AKZ_LSTEP) : nullptr;
         if (lstep && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep, 0, plane_bytes(lv.w, lv.h, n), s));
+        st_prep.reset();
         float* res = nullptr;
-        AKZ_TRY(fed_impl(c, start, start == A ? B : A, P(i, AKZ_LFLOW), lstep, lv.w, lv.h, n, lv.tau.data(), n_tau,
-                         &res));
+        {
+            StageTimer st(c, AKZ_ST_FED);
+            AKZ_TRY(fed_impl(c, start, start == A ? B : A, P(i, AKZ_LFLOW), lstep, lv.w, lv.h, n, lv.tau.data(),
+                             n_tau, &res));
+        }
         if (res != A) {
             set_error("internal: FED ping-pong parity");
             return AKZ_ERR_HIP;
@@ -595,9 +663,12 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)n * sizeof(uint32_t), s));
         for (size_t l = 0; l < L; ++l) {
             const LevelPlan& lv = plan[l];
-            if (attempt == 0)
+            if (attempt == 0) {
+                StageTimer st(c, AKZ_ST_DETECTOR);
                 AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
                                       P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n));
+            }
+            StageTimer st(c, AKZ_ST_NMS);
             launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l,
                         (float)cfg.detector_threshold, border_margin(lv, cfg), (Candidate*)c->cand.p, cap, d_count);
         }
@@ -626,6 +697,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
     }
 
     // ---- host: raster order, sequential cache logic, refinement ----
+    const double t_host0 = now_ms();
     std::vector<std::vector<HostKeypoint>> hk(n);
     r->n_extrema.assign(n, 0);
     uint64_t total_kp = 0;
@@ -639,6 +711,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         total_kp += hk[img].size();
     }
     r->desc_off[n] = total_kp;
+    if (c->profiling) c->prof.ms[AKZ_ST_HOST_KP] += now_ms() - t_host0;
 
     // ---- orientation (device sums + host atan2f) and M-LDB descriptors ----
     LevelTable tab;
@@ -673,6 +746,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         unsigned long long wmask = 0;
         uint32_t nwin = 0;
         orientation_windows(&wmask, &nwin);
+        const double t_or0 = now_ms();
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* d_oo = (OrientOut*)c->kp_out.p;
         AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params.data(), total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
@@ -692,6 +766,8 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
                 params[g].si = sinf(k.angle);
             }
         AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params.data(), total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+        const double t_ml0 = now_ms();
+        if (c->profiling) c->prof.ms[AKZ_ST_ORIENT] += t_ml0 - t_or0;
         // descriptors live in the slab-independent buffer owned by the result
         AKZ_HIP_TRY(hipMalloc((void**)&r->d_desc64, total_kp * 64));
         for (uint32_t img = 0; img < n; ++img)
@@ -711,6 +787,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         } else {
             AKZ_HIP_TRY(hipStreamSynchronize(s));
         }
+        if (c->profiling) c->prof.ms[AKZ_ST_MLDB] += now_ms() - t_ml0;
     }
     for (uint32_t img = 0; img < n; ++img) {
         r->kps[img].resize(hk[img].size());
@@ -722,6 +799,12 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
     r->k_host.assign(n, 0.0);
     AKZ_HIP_TRY(hipMemcpyAsync(r->k_host.data(), r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     AKZ_HIP_TRY(hipStreamSynchronize(s));
+    if (c->profiling) {
+        resolve_spans(c);
+        c->prof.ms[AKZ_ST_TOTAL] += now_ms() - t_call0;
+        c->prof.calls += 1;
+        c->prof.pixels += (uint64_t)w * h * n;
+    }
     guard.armed = false;
     *out = r.release();
     return AKZ_OK;
@@ -917,6 +1000,20 @@ int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8
     return AKZ_OK;
 }
 
+int akz_ctx_set_profiling(akz_ctx* c, int on) {
+    AKZ_TRY(bind(c));
+    c->profiling = on != 0;
+    return AKZ_OK;
+}
+int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
+    AKZ_TRY(bind(c));
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    resolve_spans(c);
+    *out = c->prof;
+    if (reset) c->prof = akz_profile{};
+    return AKZ_OK;
+}
 const char* akz_fed_kernel_name(void) { return "k_fed_step"; }
 
 }  // extern "C"

@@ -56,6 +56,20 @@ class Config(C.Structure):
             setattr(self, k, v)
 
 
+STAGES = ["blur0", "contrast", "prep", "fed", "detector", "nms", "host_kp", "orient", "mldb", "total"]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 10), ("fed_launches", C.c_uint64), ("fed_px_steps", C.c_uint64),
+                ("calls", C.c_uint64), ("pixels", C.c_uint64)]
+
+    def as_dict(self):
+        d = {k: self.ms[i] for i, k in enumerate(STAGES)}
+        d.update(fed_launches=self.fed_launches, fed_px_steps=self.fed_px_steps, calls=self.calls,
+                 pixels=self.pixels)
+        return d
+
+
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "<f4"),
      ("octave", "<u8"), ("class_id", "<u8"), ("angle", "<f4"), ("_pad", "<u4")])
@@ -73,6 +87,10 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
             "g.build()' or make -C akaze-rust_amd). There is no CPU fallback.")
+    # torch bundles its own HIP runtime (libamdhip64.so.7).  Import it first so that this library's
+    # NEEDED libamdhip64.so.7 binds to the copy torch already loaded: two HIP/HSA runtimes in one
+    # process do not both see the GPU.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32, f64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
     pu32, pu64, pf64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double)
@@ -123,6 +141,8 @@ def lib():
         "akz_descriptor_match": ([vp, vp, u64, vp, u64, u64, u64, f64, vp, pu64], i32),
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
+        "akz_ctx_set_profiling": ([vp, i32], i32),
+        "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
     }
     for name, (args, res) in sig.items():
@@ -220,6 +240,14 @@ class Context:
     @property
     def stream(self):
         return lib().akz_ctx_stream(self._h)
+
+    def set_profiling(self, on=True):
+        _check(lib().akz_ctx_set_profiling(self._h, int(on)))
+
+    def get_profile(self, reset=True):
+        p = Profile()
+        _check(lib().akz_ctx_get_profile(self._h, C.byref(p), int(reset)))
+        return p.as_dict()
 
     # ---- the hot path --------------------------------------------------------------------
     def extract_features(self, image, options=None, keep_all_planes=True, host_descriptors=True):

@@ -225,6 +225,30 @@ int akz_descriptor_match_device(akz_ctx* ctx, const uint8_t* d_d0, uint64_t n0, 
    translates the shapes, giving a second view of the same frame for match tests.  Host code. */
 int akz_synth_frame_u8(uint8_t* out, uint32_t w, uint32_t h, uint64_t frame_index, int32_t shift_x,
                        int32_t shift_y);
+/* Stage timing with HIP events recorded on the context's stream (device stages) and the host
+   clock (host stages).  Off by default; when on, every extract call adds its stage times. */
+typedef enum akz_stage {
+    AKZ_ST_BLUR0 = 0,    /* level-0 Gaussian blur (lib.rs:56)                            */
+    AKZ_ST_CONTRAST = 1, /* compute_contrast_factor (lib.rs:64-69)                       */
+    AKZ_ST_PREP = 2,     /* per level: clone/half_size, Lsmooth, Lflow (lib.rs:80-105)   */
+    AKZ_ST_FED = 3,      /* per level: the calculate_step launches (lib.rs:109-118)      */
+    AKZ_ST_DETECTOR = 4, /* detector_response (detector_response.rs:38-55)               */
+    AKZ_ST_NMS = 5,      /* extrema candidates + D2H                                     */
+    AKZ_ST_HOST_KP = 6,  /* host: sort, cache logic, refinement                          */
+    AKZ_ST_ORIENT = 7,   /* orientation kernel + host atan2f/cosf/sinf                   */
+    AKZ_ST_MLDB = 8,     /* descriptor kernel + D2H                                      */
+    AKZ_ST_TOTAL = 9,    /* wall time of the whole extract call (host clock)             */
+    AKZ_STAGE_COUNT = 10
+} akz_stage;
+typedef struct akz_profile {
+    double ms[AKZ_STAGE_COUNT];
+    uint64_t fed_launches;   /* FED kernel launches inside AKZ_ST_FED                        */
+    uint64_t fed_px_steps;   /* sum over launches of pixels x steps advanced (x batch)       */
+    uint64_t calls;          /* extract calls accumulated                                     */
+    uint64_t pixels;         /* input pixels accumulated (w*h*n per call)                     */
+} akz_profile;
+int akz_ctx_set_profiling(akz_ctx* ctx, int on);
+int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
 /* name of the FED kernel variant the context uses (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
 

@@ -148,13 +148,21 @@ int akz_ctx_create(int device, void* stream, akz_ctx** out) {
     }
     std::unique_ptr<akz_ctx> c(new akz_ctx);
     c->device = device;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-    } else {
-        AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)stream;  // NULL == the default stream
     *out = c.release();
+    return AKZ_OK;
+}
+int akz_stream_create(int device, void** stream_out) {
+    if (!stream_out) return AKZ_ERR_INVALID_ARG;
+    AKZ_HIP_TRY(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    AKZ_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = (void*)s;
+    return AKZ_OK;
+}
+int akz_stream_destroy(int device, void* stream) {
+    AKZ_HIP_TRY(hipSetDevice(device));
+    if (stream) AKZ_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return AKZ_OK;
 }
 
@@ -902,6 +910,19 @@ int akz_result_device_descriptors(const akz_result* r, uint64_t img, const uint8
     AKZ_TRY(check_img(r, img));
     if (d_desc) *d_desc = r->d_desc64 ? r->d_desc64 + r->desc_off[(size_t)img] * 64 : nullptr;
     if (n_keypoints) *n_keypoints = r->kps[(size_t)img].size();
+    return AKZ_OK;
+}
+int akz_result_copy_device_descriptors(const akz_result* r, uint8_t* d_dst, uint64_t capacity_rows, uint64_t* rows) {
+    if (!r) return AKZ_ERR_INVALID_ARG;
+    const uint64_t total = r->desc_off.empty() ? 0 : r->desc_off.back();
+    if (rows) *rows = total;
+    if (total == 0) return AKZ_OK;
+    if (!d_dst || capacity_rows < total) {
+        set_error("copy_device_descriptors: destination too small");
+        return AKZ_ERR_BUFFER;
+    }
+    AKZ_TRY(bind(r->ctx));
+    AKZ_HIP_TRY(hipMemcpyAsync(d_dst, r->d_desc64, total * 64, hipMemcpyDeviceToDevice, r->ctx->stream));
     return AKZ_OK;
 }
 int akz_result_contrast(const akz_result* r, uint64_t img, double* k) {

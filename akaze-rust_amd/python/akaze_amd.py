@@ -101,6 +101,8 @@ def lib():
         "akz_config_default": ([C.POINTER(Config)], None),
         "akz_ctx_create": ([i32, vp, C.POINTER(vp)], i32),
         "akz_ctx_destroy": ([vp], i32),
+        "akz_stream_create": ([i32, C.POINTER(vp)], i32),
+        "akz_stream_destroy": ([i32, vp], i32),
         "akz_ctx_synchronize": ([vp], i32),
         "akz_ctx_stream": ([vp], vp),
         "akz_device_malloc": ([vp, C.c_size_t, C.POINTER(vp)], i32),
@@ -135,6 +137,7 @@ def lib():
         "akz_result_descriptors": ([vp, u64, vp], i32),
         "akz_result_device_descriptors": ([vp, u64, C.POINTER(vp), pu64], i32),
         "akz_result_contrast": ([vp, u64, pf64], i32),
+        "akz_result_copy_device_descriptors": ([vp, vp, u64, pu64], i32),
         "akz_result_level_info": ([vp, u64, pf64, pf64, pu32, pu32, pu32, pu32, pu32, pu64, pf64, u64], i32),
         "akz_fetch_plane": ([vp, u64, u64, i32, vp, pu64], i32),
         "akz_result_device_plane": ([vp, u64, u64, i32, C.POINTER(vp)], i32),
@@ -452,6 +455,13 @@ class ExtractResult:
         p, n = C.c_void_p(), C.c_uint64()
         _check(lib().akz_result_device_descriptors(self._h, img, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def copy_device_descriptors(self, dst):
+        """D2D copy of every image's 64-byte descriptor rows into the torch CUDA uint8 tensor dst [rows, 64]."""
+        n = C.c_uint64()
+        _check(lib().akz_result_copy_device_descriptors(self._h, C.c_void_p(dst.data_ptr()), dst.shape[0],
+                                                        C.byref(n)))
+        return n.value
 
     def contrast(self, img=0):
         k = C.c_double()

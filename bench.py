@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpix/s through extract_features (4 octaves x 4 sublevels) on synthetic
+1920x1080 frames, one process per GPU, frames sharded one-per-GPU-slot across ranks.
+
+    python bench.py --gpus N --steps K --warmup W [--frames F] [--width 1920 --height 1080]
+
+A "step" is one extract_features pass over this rank's shard of F frames that are already
+resident in HBM (uploaded before the timed region).  For N > 1 the step also runs the path's
+one exchange: an RCCL all-gather of the shard's descriptor rows (what a following brute-force
+match needs); extraction itself has no collective.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the FED diffusion kernel (the dominant kernel): algorithmic bytes (12 B per
+                pixel-step) / HIP-event time of the FED launches inside the timed
+                steps, against 8 TB/s HBM peak.  roofline.fed_4k is the same kernel measured on
+                3840x2160 planes (the north-star's quoted point), outside the timed region.
+  cpu_baseline  the CPU oracle (C++ restatement of the reference's CPU path; the Rust reference
+                cannot be built in this image) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "akaze-rust_amd", "python")]
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+FED_BYTES_PER_PX_STEP = 12.0   # read Lt + read Lflow + write Lt'  
+
+
+def pmc_traffic():
+    """HBM bytes per FED launch from the committed rocprofv3 PMC summary (profiles/), if present."""
+    p = os.path.join(ROOT, "profiles", "fed_pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fed4k", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import akaze_amd as A
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = A.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    cfg = A.Config()  # Config::default(): 4 octaves x 4 sublevels, 486-bit M-LDB
+    W, H, F = args.width, args.height, args.frames
+
+    # this rank's shard: global frame indices rank*F .. rank*F+F-1 (one image per GPU slot)
+    frames = np.stack([A.synth_frame(W, H, rank * F + i) for i in range(F)])
+    d_frames = torch.from_numpy(frames).to(dev)
+    torch.cuda.synchronize()
+
+    def gather_descriptors(res):
+        """The path's exchange step: counts, then padded 64-byte rows over RCCL."""
+        rows = sum(res.counts(i)[1] for i in range(res.num_images))
+        local = torch.zeros((max(rows, 1), 64), dtype=torch.uint8, device=dev)
+        res.copy_device_descriptors(local)
+        cnt = torch.tensor([rows], dtype=torch.int64, device=dev)
+        cnts = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(cnts, cnt)
+        cap = int(cnts.max().item())
+        padded = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
+        padded[:rows] = local[:rows]
+        allrows = torch.empty((world * cap, 64), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allrows, padded)
+        return allrows, cnts
+
+    def step():
+        res = ctx.extract_features(d_frames, cfg, keep_all_planes=not args.lean)
+        nk = sum(res.counts(i)[1] for i in range(res.num_images))
+        if world > 1:
+            gather_descriptors(res)
+        res.close()
+        return nk
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)
+    ctx.get_profile(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    nk = 0
+    for _ in range(args.steps):
+        nk = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.get_profile(reset=True)
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_px = float(W) * H * F * world * args.steps
+    value = total_px / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (FED step) inside the timed region -------------------
+    fed_s = prof["fed"] / 1e3
+    fed_bytes = FED_BYTES_PER_PX_STEP * prof["fed_px_steps"]
+    achieved = fed_bytes / fed_s / 1e9 if fed_s > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": A.lib().akz_fed_kernel_name().decode(),
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": pmc_traffic(),
+        "launches": prof["fed_launches"],
+        "avg_launch_us": round(prof["fed"] * 1e3 / max(1, prof["fed_launches"]), 2),
+        "algorithmic_bytes_per_launch": round(fed_bytes / max(1, prof["fed_launches"])),
+        "note": "all FED launches of the timed steps (levels 1..15, 1920x1080 down to 240x135, batch F)",
+    }
+
+    # ---- the same kernel on 3840x2160 planes (north-star target point), untimed leg -----------
+    if rank == 0 and not args.no_fed4k:
+        w4, h4, nst = 3840, 2160, 40
+        lt = torch.rand((h4, w4), dtype=torch.float32, device=dev)
+        lf = torch.rand((h4, w4), dtype=torch.float32, device=dev)
+        taus = np.full(nst, 0.2)
+        ctx.fed_steps(lt, lf, taus)  # warm
+        ctx.set_profiling(True)
+        ctx.get_profile(reset=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctx.fed_steps(lt, lf, taus)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        ctx.set_profiling(False)
+        per = ms / nst * 1e3
+        gbs = FED_BYTES_PER_PX_STEP * w4 * h4 / (per * 1e-6) / 1e9
+        roofline["fed_4k"] = {"avg_launch_us": round(per, 2), "achieved": round(gbs, 1),
+                              "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst}
+        del lt, lf
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import akaze_ref as R
+        cores = os.cpu_count() or 1
+        n_sample = 3
+        t1 = time.perf_counter()
+        kp_ref = 0
+        for i in range(n_sample):
+            r = R.extract(frames[i % F], threads=cores)
+            kp_ref += r.num_keypoints
+            r.close()
+        dt = time.perf_counter() - t1
+        cpu = {"value": round(W * H * n_sample / dt / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+               "sample": f"{n_sample} of the same {W}x{H} frames through the C++ restatement of the reference CPU "
+                         f"path (scale space single-threaded, detector derivatives on {cores} threads as "
+                         "detector_response.rs:16-29)",
+               "seconds": round(dt, 2)}
+
+    if rank == 0:
+        stage_ms = {k: round(prof[k] / max(1, prof["calls"]), 3) for k in A.STAGES}
+        out = {
+            "metric": "Mpix/s through extract_features (4 oct x 4 sub)",
+            "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
+                                   f"(4 octaves x 4 sublevels, 486-bit M-LDB), {F} frames per GPU per step "
+                                   "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)",
+                       "frames_per_gpu": F, "width": W, "height": H,
+                       "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
+                       "exchange": "RCCL all-gather of descriptor rows" if world > 1 else "none (1 GPU)",
+                       "keypoints_per_step_rank0": nk},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "stage_ms_per_step": stage_ms,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,9 +101,12 @@ const char* akz_last_error(void);
 void akz_config_default(akz_config* out);
 
 /* ---- context ------------------------------------------------------------------------ */
-/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream),
-   or NULL to let the context create its own. */
+/* stream: the hipStream_t every kernel and copy of this context is enqueued on, e.g.
+   torch.cuda.current_stream().cuda_stream.  NULL is the device's default (null) stream, as in
+   every HIP API.  akz_stream_create/destroy give non-torch hosts a private stream. */
 int akz_ctx_create(int device, void* stream, akz_ctx** out);
+int akz_stream_create(int device, void** stream_out);
+int akz_stream_destroy(int device, void* stream);
 int akz_ctx_destroy(akz_ctx* ctx);
 int akz_ctx_synchronize(akz_ctx* ctx);
 void* akz_ctx_stream(akz_ctx* ctx);
@@ -192,6 +195,10 @@ int akz_result_keypoints(const akz_result* res, uint64_t img, akz_keypoint* out 
 int akz_result_descriptors(const akz_result* res, uint64_t img, uint8_t* out);
 /* device-resident descriptors, 64-byte rows (desc_bytes used, rest zero), for akz_match_device / RCCL gather */
 int akz_result_device_descriptors(const akz_result* res, uint64_t img, const uint8_t** d_desc, uint64_t* n_keypoints);
+/* D2D copy of ALL images' descriptor rows (image 0 first, 64-byte rows) into a caller buffer of
+   capacity_rows rows, e.g. a torch tensor that is then all-gathered over RCCL. */
+int akz_result_copy_device_descriptors(const akz_result* res, uint8_t* d_dst, uint64_t capacity_rows,
+                                       uint64_t* rows);
 /* the contrast factor compute_contrast_factor returned for image `img` (lib.rs:64-69) */
 int akz_result_contrast(const akz_result* res, uint64_t img, double* k);
 /* scalar fields of EvolutionStep — evolution.rs:59-70, :91 */

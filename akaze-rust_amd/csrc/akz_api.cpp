@@ -33,6 +33,7 @@ struct akz_ctx {
     DevBuf match_a, match_b, match_rec, match_out;
     std::vector<std::pair<size_t, void*>> slab_pool;  // freed pyramid slabs, reused by size
     // stage profiling (akz_ctx_set_profiling)
+    int fed_mode = 1;  // 0: one k_fed_step launch per step, 1: k_fed_fused (<= 8 steps per launch)
     bool profiling = false;
     akz_profile prof{};
     struct Span { int stage; hipEvent_t a, b; };
@@ -363,19 +364,38 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
     return AKZ_OK;
 }
 
+// FED launch plan: the level's n_tau steps are cut into ceil(n_tau / 8) launches of balanced size.
+static constexpr uint32_t kFedMaxFuse = 8;
+static uint32_t fed_num_launches(const akz_ctx* c, uint32_t n_tau) {
+    if (c->fed_mode == 0) return n_tau;
+    return (n_tau + kFedMaxFuse - 1) / kFedMaxFuse;
+}
 // calculate_step x n_tau with ping-pong between `a` and `b`; the input is in `a`.  Returns the
 // buffer holding the result through *result.
 static int fed_impl(akz_ctx* c, float* a, float* b, const float* lflow, float* lstep, uint32_t w, uint32_t h,
                     uint32_t n, const double* taus, uint32_t n_tau, float** result) {
     float* cur = a;
     float* oth = b;
-    for (uint32_t j = 0; j < n_tau; ++j) {
-        const float half_tau = 0.5f * (float)taus[j];
-        launch::fed_step(c->stream, cur, lflow, oth, (j + 1 == n_tau) ? lstep : nullptr, w, h, n, half_tau);
-        std::swap(cur, oth);
+    if (c->fed_mode == 0) {
+        for (uint32_t j = 0; j < n_tau; ++j) {
+            const float half_tau = 0.5f * (float)taus[j];
+            launch::fed_step(c->stream, cur, lflow, oth, (j + 1 == n_tau) ? lstep : nullptr, w, h, n, half_tau);
+            std::swap(cur, oth);
+        }
+    } else {
+        const uint32_t launches = fed_num_launches(c, n_tau);
+        uint32_t done = 0;
+        for (uint32_t k = 0; k < launches; ++k) {
+            const uint32_t cnt = (n_tau - done + (launches - k) - 1) / (launches - k);  // balanced chunks
+            float ht[8];
+            for (uint32_t j = 0; j < cnt; ++j) ht[j] = 0.5f * (float)taus[done + j];
+            done += cnt;
+            launch::fed_fused(c->stream, cur, lflow, oth, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt);
+            std::swap(cur, oth);
+        }
     }
     if (c->profiling) {
-        c->prof.fed_launches += n_tau;
+        c->prof.fed_launches += fed_num_launches(c, n_tau);
         c->prof.fed_px_steps += (uint64_t)w * h * n * n_tau;
     }
     *result = cur;
@@ -636,7 +656,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         float* A = P(i, AKZ_LT);
         float* B = (float*)c->scratch[5].p;
         const uint32_t n_tau = (uint32_t)lv.tau.size();
-        float* start = (n_tau % 2 == 0) ? A : B;  // so that the last step lands in the Lt plane
+        float* start = (fed_num_launches(c, n_tau) % 2 == 0) ? A : B;  // the last launch must land in Lt
         std::unique_ptr<StageTimer> st_prep(new StageTimer(c, AKZ_ST_PREP));
         if (lv.octave > pv.octave) {
             launch::half_size(s, P(i - 1, AKZ_LT), start, pv.w, pv.h, n);
@@ -1035,6 +1055,12 @@ int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
     if (reset) c->prof = akz_profile{};
     return AKZ_OK;
 }
-const char* akz_fed_kernel_name(void) { return "k_fed_step"; }
+int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
+    AKZ_TRY(bind(c));
+    if (mode != 0 && mode != 1) return AKZ_ERR_INVALID_ARG;
+    c->fed_mode = mode;
+    return AKZ_OK;
+}
+const char* akz_fed_kernel_name(void) { return "k_fed_fused"; }
 
 }  // extern "C"

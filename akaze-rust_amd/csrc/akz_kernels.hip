@@ -4,6 +4,8 @@
 // is a <2 flop/byte stencil, gather or popcount loop.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "akz_internal.hpp"
 
 namespace akz {
@@ -138,6 +140,151 @@ __global__ void k_fed_step(const float* __restrict__ L, const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// FED, LDS-tiled and temporally fused: one launch advances a tile by n <= HALO explicit steps.
+// The workgroup loads its TW x TH tile plus a halo of n rows (and HALO columns, kept a multiple
+// of 4 so that every LDS/global access is a 16-byte float4) of Lt and Lflow into LDS, runs the n
+// Jacobi steps between two LDS copies of Lt, and stores only the centre.  After step s the values
+// within (n - s) pixels of the centre are exact, further out they are stale and never used, so the
+// centre after step n equals n launches of k_fed_step bit for bit.  Lflow is constant across the
+// steps of a level (lib.rs:105-118), so HBM traffic per step drops from 12 B/px to
+// (8*overfetch + 4)/n B/px.  East/west fluxes are shared between neighbours: x_neg(x) and
+// x_pos(x-1) are the same expression (nonlinear_diffusion.rs:63-64), evaluated once.
+// ---------------------------------------------------------------------------------------------
+struct FedTaus {
+    int n;
+    float half_tau[8];  // 0.5f * (tau as f32) per step (nonlinear_diffusion.rs:67)
+};
+
+template <bool INNER>
+__device__ __forceinline__ float4 fed_group(const float4 lc, const float4 cc, const float4 ln, const float4 cn,
+                                            const float4 ls, const float4 cs, float lw, float cw, float le, float ce,
+                                            int gx, int gy, int w, int h, float half_tau, float4& step) {
+    const float l[6] = {lw, lc.x, lc.y, lc.z, lc.w, le};
+    const float c[6] = {cw, cc.x, cc.y, cc.z, cc.w, ce};
+    const float lN[4] = {ln.x, ln.y, ln.z, ln.w}, cN[4] = {cn.x, cn.y, cn.z, cn.w};
+    const float lS[4] = {ls.x, ls.y, ls.z, ls.w}, cS[4] = {cs.x, cs.y, cs.z, cs.w};
+    float xf[5];  // xf[i] = flux between pixel i-1 and i of the group (i = 0 is the west neighbour)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) xf[i] = (c[i] + c[i + 1]) * (l[i + 1] - l[i]);
+    float out[4], st[4];
+    const bool hyp = INNER || (gy + 1 < h), hyn = INNER || (gy > 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lv = l[i + 1], cv = c[i + 1];
+        const bool hxp = INNER || (gx + i + 1 < w), hxn = INNER || (gx + i > 0);
+        float t = hxp ? (hxn ? xf[i + 1] - xf[i] : xf[i + 1]) : -xf[i];
+        if (hyp) {
+            t = t + (cv + cS[i]) * (lS[i] - lv);
+            if (hyn) t = t - (cN[i] + cv) * (lv - lN[i]);
+        } else {
+            t = t + (cv + cN[i]) * (lN[i] - lv);
+        }
+        st[i] = half_tau * t;
+        out[i] = lv + st[i];
+    }
+    step = make_float4(st[0], st[1], st[2], st[3]);
+    return make_float4(out[0], out[1], out[2], out[3]);
+}
+
+template <int TW, int TH, int HALO, int NT>
+__global__ void __launch_bounds__(NT)
+k_fed_fused(const float* __restrict__ L_in, const float* __restrict__ C, float* __restrict__ L_out,
+            float* __restrict__ Lstep, int w, int h, FedTaus ht) {
+    constexpr int RW = TW + 2 * HALO;    // region width in pixels (multiple of 4)
+    constexpr int XG = RW / 4;           // float4 groups per region row
+    constexpr int RP = RW + 8;           // LDS pitch: 4 pad floats on each side
+    constexpr int RHMAX = TH + 2 * HALO;
+    constexpr int PLANE = (RHMAX + 2) * RP;  // one pad row above and below
+    __shared__ __attribute__((aligned(16))) float sL[2][PLANE];
+    __shared__ __attribute__((aligned(16))) float sC[PLANE];
+    const int tid = threadIdx.x;
+    const int n = ht.n;
+    const int RH = TH + 2 * n;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    const bool vec_ok = (w & 3) == 0;
+    auto lds = [&](int ly, int lx) { return (ly + 1) * RP + 4 + lx; };
+
+    // ---- stage the region (out-of-image pixels read as 0 and are never used by in-image ones) ----
+    for (int idx = tid; idx < RH * XG; idx += NT) {
+        const int ly = idx / XG, g = idx - ly * XG;
+        const int gy = y0 - n + ly, gx = x0 - HALO + 4 * g;
+        float4 vl = make_float4(0.f, 0.f, 0.f, 0.f), vc = vl;
+        if (gy >= 0 && gy < h && gx + 3 >= 0 && gx < w) {
+            const float* pl = L_in + base + (size_t)gy * w;
+            const float* pc = C + base + (size_t)gy * w;
+            if (vec_ok && gx >= 0 && gx + 3 < w) {
+                vl = *reinterpret_cast<const float4*>(pl + gx);
+                vc = *reinterpret_cast<const float4*>(pc + gx);
+            } else {
+                float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gx + e >= 0 && gx + e < w) {
+                        a[e] = pl[gx + e];
+                        b[e] = pc[gx + e];
+                    }
+                vl = make_float4(a[0], a[1], a[2], a[3]);
+                vc = make_float4(b[0], b[1], b[2], b[3]);
+            }
+        }
+        *reinterpret_cast<float4*>(&sL[0][lds(ly, 4 * g)]) = vl;
+        *reinterpret_cast<float4*>(&sC[lds(ly, 4 * g)]) = vc;
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 1; s <= n; ++s) {
+        const int m = n - s;             // pixels beyond the centre that later steps still need
+        const int mx = (m + 3) & ~3;
+        const int ly0 = n - m, rows = TH + 2 * m;
+        const int g0 = (HALO - mx) / 4, groups = (TW + 2 * mx) / 4;
+        const bool last = s == n;
+        const float half_tau = ht.half_tau[s - 1];
+        const float* src = sL[cur];
+        float* dst = sL[cur ^ 1];
+        for (int idx = tid; idx < rows * groups; idx += NT) {
+            const int r = idx / groups, g = g0 + (idx - r * groups);
+            const int ly = ly0 + r;
+            const int gy = y0 - n + ly, gx = x0 - HALO + 4 * g;
+            if (gy < 0 || gy >= h || gx >= w || gx + 3 < 0) continue;
+            const int o = lds(ly, 4 * g);
+            const float4 lc = *reinterpret_cast<const float4*>(src + o);
+            const float4 ln = *reinterpret_cast<const float4*>(src + o - RP);
+            const float4 ls = *reinterpret_cast<const float4*>(src + o + RP);
+            const float4 cc = *reinterpret_cast<const float4*>(sC + o);
+            const float4 cn = *reinterpret_cast<const float4*>(sC + o - RP);
+            const float4 cs = *reinterpret_cast<const float4*>(sC + o + RP);
+            const float lw = src[o - 1], le = src[o + 4], cw = sC[o - 1], ce = sC[o + 4];
+            const bool inner = gy >= 1 && gy + 1 < h && gx >= 1 && gx + 4 < w;
+            float4 st;
+            const float4 res = inner ? fed_group<true>(lc, cc, ln, cn, ls, cs, lw, cw, le, ce, gx, gy, w, h, half_tau, st)
+                                     : fed_group<false>(lc, cc, ln, cn, ls, cs, lw, cw, le, ce, gx, gy, w, h, half_tau, st);
+            if (!last) {
+                *reinterpret_cast<float4*>(dst + o) = res;
+            } else {  // m == 0: exactly the centre tile -> straight to HBM
+                float* po = L_out + base + (size_t)gy * w;
+                float* ps = Lstep ? Lstep + base + (size_t)gy * w : nullptr;
+                if (vec_ok && gx >= 0 && gx + 3 < w) {
+                    *reinterpret_cast<float4*>(po + gx) = res;
+                    if (ps) *reinterpret_cast<float4*>(ps + gx) = st;
+                } else {
+                    const float rv[4] = {res.x, res.y, res.z, res.w}, sv[4] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gx + e >= 0 && gx + e < w) {
+                            po[gx + e] = rv[e];
+                            if (ps) ps[gx + e] = sv[e];
+                        }
+                }
+            }
+        }
+        if (!last) __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // contrast factor (akaze/src/ops/contrast_factor.rs:18-71) on the sigma-blurred level 0
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double grad_mod(const float* I, int w, int h, int x, int y, Scharr1 sk) {
@@ -146,42 +293,59 @@ __device__ __forceinline__ double grad_mod(const float* I, int w, int h, int x, 
     const double dx = (double)lx, dy = (double)ly;
     return sqrt(dx * dx + dy * dy);
 }
-__global__ void k_contrast_max(const float* __restrict__ blurred, int w, int h, Scharr1 sk,
-                               unsigned long long* __restrict__ d_hmax_bits) {
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+// Both passes walk the interior with a fixed number of fat workgroups per image (grid-stride over
+// rows) so that each workgroup issues ONE global atomicMax / one histogram flush.
+constexpr int CT = 256;  // threads per contrast workgroup
+__global__ void __launch_bounds__(CT)
+k_contrast_max(const float* __restrict__ blurred, int w, int h, Scharr1 sk,
+               unsigned long long* __restrict__ d_hmax_bits) {
+    __shared__ unsigned long long s_part[CT / 64];
+    const float* I = blurred + (size_t)blockIdx.z * (size_t)w * (size_t)h;
     double m = 0.0;
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-        const double g = grad_mod(blurred + (size_t)blockIdx.z * (size_t)w * (size_t)h, w, h, x, y, sk);
-        if (g > m) m = g;
-    }
+    for (int y = 1 + (int)blockIdx.x; y < h - 1; y += (int)gridDim.x)
+        for (int x = 1 + (int)threadIdx.x; x < w - 1; x += CT) {
+            const double g = grad_mod(I, w, h, x, y, sk);
+            if (g > m) m = g;
+        }
     // non-negative doubles order like their bit patterns
     unsigned long long bits = (unsigned long long)__double_as_longlong(m);
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(bits, o, 64);
         bits = other > bits ? other : bits;
     }
-    if (threadIdx.x == 0 && bits != 0ull) atomicMax(d_hmax_bits + blockIdx.z, bits);
-}
-__global__ void k_contrast_hist(const float* __restrict__ blurred, int w, int h, Scharr1 sk,
-                                const unsigned long long* __restrict__ d_hmax_bits, unsigned nbins,
-                                unsigned* __restrict__ d_hist) {
-    extern __shared__ unsigned s_hist[];
-    const int tid = threadIdx.y * BX + threadIdx.x;
-    for (unsigned b = tid; b < nbins; b += BX * BY) s_hist[b] = 0u;
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = bits;
     __syncthreads();
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-        const double hmax = __longlong_as_double((long long)d_hmax_bits[blockIdx.z]);
-        const double g = grad_mod(blurred + (size_t)blockIdx.z * (size_t)w * (size_t)h, w, h, x, y, sk);
-        if (g != 0.0) {
-            const double f = floor((double)nbins * (g / hmax));
-            unsigned b = f >= (double)nbins ? nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
-            atomicAdd(&s_hist[b], 1u);
-        }
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < CT / 64; ++i) bits = s_part[i] > bits ? s_part[i] : bits;
+        if (bits != 0ull) atomicMax(d_hmax_bits + blockIdx.z, bits);
     }
+}
+__global__ void __launch_bounds__(CT)
+k_contrast_hist(const float* __restrict__ blurred, int w, int h, Scharr1 sk,
+                const unsigned long long* __restrict__ d_hmax_bits, unsigned nbins, unsigned copies,
+                unsigned* __restrict__ d_hist) {
+    extern __shared__ unsigned s_hist[];  // `copies` private histograms (lanes spread over them)
+    const unsigned tid = threadIdx.x;
+    for (unsigned b = tid; b < nbins * copies; b += CT) s_hist[b] = 0u;
     __syncthreads();
-    for (unsigned b = tid; b < nbins; b += BX * BY)
-        if (s_hist[b]) atomicAdd(&d_hist[(size_t)blockIdx.z * nbins + b], s_hist[b]);
+    const float* I = blurred + (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    const double hmax = __longlong_as_double((long long)d_hmax_bits[blockIdx.z]);
+    unsigned* mine = s_hist + (tid & (copies - 1u)) * nbins;
+    for (int y = 1 + (int)blockIdx.x; y < h - 1; y += (int)gridDim.x)
+        for (int x = 1 + (int)tid; x < w - 1; x += CT) {
+            const double g = grad_mod(I, w, h, x, y, sk);
+            if (g != 0.0) {
+                const double f = floor((double)nbins * (g / hmax));
+                const unsigned b = f >= (double)nbins ? nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
+                atomicAdd(&mine[b], 1u);
+            }
+        }
+    __syncthreads();
+    for (unsigned b = tid; b < nbins; b += CT) {
+        unsigned v = 0;
+        for (unsigned c = 0; c < copies; ++c) v += s_hist[c * nbins + b];
+        if (v) atomicAdd(&d_hist[(size_t)blockIdx.z * nbins + b], v);
+    }
 }
 __global__ void k_contrast_final(const unsigned long long* __restrict__ d_hmax_bits,
                                  const unsigned* __restrict__ d_hist, unsigned nbins, double percentile, unsigned n,
@@ -517,15 +681,31 @@ void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_o
     hipLaunchKernelGGL(k_fed_step, grid2d(w, h, n), dim3(BX, BY), 0, s, lt_in, lflow, lt_out, lstep, (int)w, (int)h,
                        half_tau);
 }
+void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
+               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps) {
+    constexpr int TW = 64, TH = 32, NT = 256;
+    FedTaus ht;
+    ht.n = (int)n_steps;
+    for (uint32_t i = 0; i < 8; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
+    const dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
+    if (n_steps <= 4)
+        hipLaunchKernelGGL((k_fed_fused<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
+                           (int)h, ht);
+    else
+        hipLaunchKernelGGL((k_fed_fused<TW, TH, 8, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
+                           (int)h, ht);
+}
+static unsigned contrast_blocks(uint32_t h) { return h > 2 ? std::min<uint32_t>(h - 2, 128u) : 1u; }
 void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
                   unsigned long long* d_hmax_bits) {
-    hipLaunchKernelGGL(k_contrast_max, grid2d(w, h, n), dim3(BX, BY), 0, s, blurred, (int)w, (int)h, scharr1(),
-                       d_hmax_bits);
+    hipLaunchKernelGGL(k_contrast_max, dim3(contrast_blocks(h), 1, n), dim3(CT), 0, s, blurred, (int)w, (int)h,
+                       scharr1(), d_hmax_bits);
 }
 void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
                    const unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist) {
-    hipLaunchKernelGGL(k_contrast_hist, grid2d(w, h, n), dim3(BX, BY), nbins * sizeof(unsigned), s, blurred, (int)w,
-                       (int)h, scharr1(), d_hmax_bits, nbins, d_hist);
+    const unsigned copies = nbins <= 512 ? 8u : (nbins <= 2048 ? 2u : 1u);
+    hipLaunchKernelGGL(k_contrast_hist, dim3(contrast_blocks(h), 1, n), dim3(CT), nbins * copies * sizeof(unsigned), s,
+                       blurred, (int)w, (int)h, scharr1(), d_hmax_bits, nbins, copies, d_hist);
 }
 void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const uint32_t* d_hist, uint32_t nbins,
                     double percentile, uint32_t n, double* d_k) {

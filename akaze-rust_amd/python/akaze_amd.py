@@ -145,6 +145,7 @@ def lib():
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
         "akz_ctx_set_profiling": ([vp, i32], i32),
+        "akz_ctx_set_fed_mode": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
     }
@@ -243,6 +244,10 @@ class Context:
     @property
     def stream(self):
         return lib().akz_ctx_stream(self._h)
+
+    def set_fed_mode(self, mode):
+        """1 = fused LDS kernel (default), 0 = one launch per step."""
+        _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
 
     def set_profiling(self, on=True):
         _check(lib().akz_ctx_set_profiling(self._h, int(on)))

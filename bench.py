@@ -160,11 +160,14 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
+        p4 = ctx.get_profile(reset=True)
         ctx.set_profiling(False)
-        per = ms / nst * 1e3
-        gbs = FED_BYTES_PER_PX_STEP * w4 * h4 / (per * 1e-6) / 1e9
+        launches = max(1, p4["fed_launches"])
+        per = ms / launches * 1e3
+        gbs = FED_BYTES_PER_PX_STEP * w4 * h4 * nst / (ms * 1e-3) / 1e9
         roofline["fed_4k"] = {"avg_launch_us": round(per, 2), "achieved": round(gbs, 1),
-                              "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst}
+                              "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst, "launches": launches,
+                              "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * w4 * h4 * nst / launches)}
         del lt, lf
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only -------

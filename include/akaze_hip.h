@@ -256,7 +256,10 @@ typedef struct akz_profile {
 } akz_profile;
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
-/* name of the FED kernel variant the context uses (for bench / profiles) */
+/* FED kernel variant: 1 (default) = k_fed_fused, LDS-tiled, up to 8 explicit steps per launch;
+   0 = k_fed_step, one launch per step.  Results are bit-identical. */
+int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
+/* name of the default FED kernel (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
 
 #ifdef __cplusplus

@@ -110,19 +110,43 @@ def test_contrast_factor_flat_image(ctx, ref):
     assert float(host(ctx.contrast_factor(dev(img)))[0]) == ref.contrast_factor(img)
 
 
-@pytest.mark.parametrize("shape", SHAPES + [(3, 3), (5, 64), (64, 5)])
-@pytest.mark.parametrize("ntau", [1, 2, 5])
-def test_fed_steps_all_border_cases(ctx, ref, shape, ntau):
+FED_TAUS = np.array([0.19623365730888334, 3.7012260958150769, 0.12604081556156974, 0.25, 1.5, 0.07, 2.2, 0.4,
+                     0.9, 0.11, 3.1, 0.6, 0.33])
+
+
+@pytest.mark.parametrize("mode", [1, 0])  # 1: k_fed_fused (LDS, <= 8 steps per launch), 0: k_fed_step
+@pytest.mark.parametrize("shape", SHAPES + [(3, 3), (5, 64), (64, 5), (33, 130), (270, 480)])
+@pytest.mark.parametrize("ntau", [1, 2, 4, 5, 8, 13])
+def test_fed_steps_all_border_cases(ctx, ref, shape, ntau, mode):
     lt = rand_img(*shape, seed=9)
     c = rand_img(*shape, seed=10)
-    taus = np.array([0.19623365730888334, 3.7012260958150769, 0.12604081556156974, 0.25, 1.5])[:ntau]
+    taus = FED_TAUS[:ntau]
     exp, step = lt.copy(), None
     for t in taus:
         exp, step = ref.fed_step(exp, c, t)
+    ctx.set_fed_mode(mode)
+    try:
+        d_lt = dev(lt)
+        d_step = ctx.fed_steps(d_lt, dev(c), taus, want_lstep=True)
+        same(host(d_lt), exp)
+        same(host(d_step), step)
+    finally:
+        ctx.set_fed_mode(1)
+
+
+def test_fed_fused_batch_and_unaligned_width(ctx, ref):
+    """Batch of planes whose width is not a multiple of 4 (scalar load/store path of k_fed_fused)."""
+    lt = np.stack([rand_img(70, 131, s) for s in range(3)])
+    c = np.stack([rand_img(70, 131, 10 + s) for s in range(3)])
+    taus = FED_TAUS[:7]
     d_lt = dev(lt)
-    d_step = ctx.fed_steps(d_lt, dev(c), taus, want_lstep=True)
-    same(host(d_lt), exp)
-    same(host(d_step), step)
+    ctx.fed_steps(d_lt, dev(c), taus)
+    got = host(d_lt)
+    for i in range(3):
+        exp = lt[i].copy()
+        for t in taus:
+            exp, _ = ref.fed_step(exp, c[i], t)
+        same(got[i], exp)
 
 
 @pytest.mark.parametrize("sigma", [2, 3, 4])

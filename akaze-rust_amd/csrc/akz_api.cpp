@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <time.h>
 #include <type_traits>
 
@@ -31,7 +33,9 @@ struct akz_ctx {
     DevBuf cand;                             // NMS candidates
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
-    std::vector<std::pair<size_t, void*>> slab_pool;  // freed pyramid slabs, reused by size
+    DevBuf cosi;                             // (cos, sin) per keypoint
+    DevBuf pin[3];                           // pinned host staging: candidates, orientation sums, descriptor rows
+    std::vector<std::pair<size_t, void*>> slab_pool;  // freed device blocks (pyramid slabs, descriptor rows)
     // stage profiling (akz_ctx_set_profiling)
     int fed_mode = 1;  // 0: one k_fed_step launch per step, 1: k_fed_fused (<= 8 steps per launch)
     bool profiling = false;
@@ -94,6 +98,19 @@ static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
     }
     const size_t want = bytes + bytes / 8 + 256;
     AKZ_HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return AKZ_OK;
+}
+static int ensure_pinned(akz_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return AKZ_OK;
+    if (b.p) {
+        AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+        AKZ_HIP_TRY(hipHostFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    AKZ_HIP_TRY(hipHostMalloc(&b.p, want, hipHostMallocDefault));
     b.bytes = want;
     return AKZ_OK;
 }
@@ -173,9 +190,11 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
                       &c->small, &c->cand, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
-                      &c->match_out};
+                      &c->match_out, &c->cosi};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (DevBuf& b : c->pin)
+        if (b.p) (void)hipHostFree(b.p);
     for (auto& s : c->slab_pool) (void)hipFree(s.second);
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -319,6 +338,14 @@ static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t 
     Taps t;
     AKZ_TRY(taps_from_dense(k.data(), (uint32_t)k.size(), t));
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
+    if (launch::blur_fused_supported((uint32_t)k.size()) && (const void*)d_in != (const void*)d_out) {
+        if constexpr (std::is_same<T, uint8_t>::value)
+            launch::blur_fused_u8(c->stream, d_in, d_out, w, h, n, k.data(), (uint32_t)k.size());
+        else
+            launch::blur_fused_f32(c->stream, d_in, d_out, w, h, n, k.data(), (uint32_t)k.size());
+        AKZ_HIP_TRY(hipGetLastError());
+        return AKZ_OK;
+    }
     AKZ_TRY(ensure(c, c->scratch[0], plane_bytes(w, h, n)));
     float* tmp = (float*)c->scratch[0].p;
     if constexpr (std::is_same<T, uint8_t>::value) launch::filter_h_u8(c->stream, d_in, tmp, w, h, n, t);
@@ -370,35 +397,44 @@ static uint32_t fed_num_launches(const akz_ctx* c, uint32_t n_tau) {
     if (c->fed_mode == 0) return n_tau;
     return (n_tau + kFedMaxFuse - 1) / kFedMaxFuse;
 }
-// calculate_step x n_tau with ping-pong between `a` and `b`; the input is in `a`.  Returns the
-// buffer holding the result through *result.
-static int fed_impl(akz_ctx* c, float* a, float* b, const float* lflow, float* lstep, uint32_t w, uint32_t h,
-                    uint32_t n, const double* taus, uint32_t n_tau, float** result) {
-    float* cur = a;
-    float* oth = b;
-    if (c->fed_mode == 0) {
-        for (uint32_t j = 0; j < n_tau; ++j) {
-            const float half_tau = 0.5f * (float)taus[j];
-            launch::fed_step(c->stream, cur, lflow, oth, (j + 1 == n_tau) ? lstep : nullptr, w, h, n, half_tau);
-            std::swap(cur, oth);
+// calculate_step x n_tau.  The first launch reads `in` (never written), launches alternate between
+// the buffers A and B such that the LAST one writes A.  `in` may be B or a third buffer, never A
+// unless the number of launches is even (then A is rewritten only after it was consumed).
+static float* fed_dst(uint32_t launches, uint32_t k /*1-based*/, float* A, float* B) {
+    return ((launches - k) % 2 == 0) ? A : B;
+}
+static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float* lflow, float* lstep, uint32_t w,
+                    uint32_t h, uint32_t n, const double* taus, uint32_t n_tau) {
+    const uint32_t launches = fed_num_launches(c, n_tau);
+    if (launches == 0) {
+        if (in != A) AKZ_HIP_TRY(hipMemcpyAsync(A, in, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
+        return AKZ_OK;
+    }
+    const float* cur = in;
+    uint32_t done = 0;
+    for (uint32_t k = 1; k <= launches; ++k) {
+        float* dst = fed_dst(launches, k, A, B);
+        if ((const float*)dst == cur) {
+            set_error("internal: FED ping-pong aliasing");
+            return AKZ_ERR_INVALID_ARG;
         }
-    } else {
-        const uint32_t launches = fed_num_launches(c, n_tau);
-        uint32_t done = 0;
-        for (uint32_t k = 0; k < launches; ++k) {
-            const uint32_t cnt = (n_tau - done + (launches - k) - 1) / (launches - k);  // balanced chunks
+        if (c->fed_mode == 0) {
+            const float half_tau = 0.5f * (float)taus[done];
+            done += 1;
+            launch::fed_step(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, half_tau);
+        } else {
+            const uint32_t cnt = (n_tau - done + (launches - k + 1) - 1) / (launches - k + 1);  // balanced chunks
             float ht[8];
             for (uint32_t j = 0; j < cnt; ++j) ht[j] = 0.5f * (float)taus[done + j];
             done += cnt;
-            launch::fed_fused(c->stream, cur, lflow, oth, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt);
-            std::swap(cur, oth);
+            launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt);
         }
+        cur = dst;
     }
     if (c->profiling) {
-        c->prof.fed_launches += fed_num_launches(c, n_tau);
+        c->prof.fed_launches += launches;
         c->prof.fed_px_steps += (uint64_t)w * h * n * n_tau;
     }
-    *result = cur;
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
 }
@@ -410,6 +446,11 @@ static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float
         return AKZ_ERR_INVALID_ARG;
     }
     AKZ_TRY(check_plane_args(lsmooth, ldet_out, w, h, n, (int)sigma));
+    if (launch::detector_fused_supported(sigma)) {
+        launch::detector_fused(c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n);
+        AKZ_HIP_TRY(hipGetLastError());
+        return AKZ_OK;
+    }
     const size_t pb = plane_bytes(w, h, n);
     if (!lxx) { AKZ_TRY(ensure(c, c->scratch[2], pb)); lxx = (float*)c->scratch[2].p; }
     if (!lyy) { AKZ_TRY(ensure(c, c->scratch[3], pb)); lyy = (float*)c->scratch[3].p; }
@@ -513,12 +554,13 @@ int akz_op_fed_steps(akz_ctx* c, float* d_lt, const float* d_lflow, float* d_lst
     AKZ_TRY(bind(c));
     AKZ_TRY(check_plane_args(d_lt, d_lflow, w, h, n, 1));
     if (n_tau && !taus) return AKZ_ERR_INVALID_ARG;
+    // in place for the caller: copy the input aside when the launch count is odd
     AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(w, h, n)));
-    float* res = nullptr;
-    AKZ_TRY(fed_impl(c, d_lt, (float*)c->scratch[5].p, d_lflow, d_lstep, w, h, n, taus, n_tau, &res));
-    if (res != d_lt)
-        AKZ_HIP_TRY(hipMemcpyAsync(d_lt, res, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
-    return AKZ_OK;
+    AKZ_TRY(ensure(c, c->scratch[3], plane_bytes(w, h, n)));
+    float* B = (float*)c->scratch[5].p;
+    float* in = (float*)c->scratch[3].p;
+    AKZ_HIP_TRY(hipMemcpyAsync(in, d_lt, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
+    return fed_impl(c, in, d_lt, B, d_lflow, d_lstep, w, h, n, taus, n_tau);
 }
 int akz_op_detector_response(akz_ctx* c, const float* d_lsmooth, uint32_t sigma_size, float* d_lx, float* d_ly,
                              float* d_lxx, float* d_lyy, float* d_lxy, float* d_ldet, uint32_t w, uint32_t h,
@@ -546,6 +588,7 @@ struct akz_result {
     std::vector<std::vector<akz_keypoint>> kps;
     std::vector<std::vector<uint8_t>> desc;  // unpadded, host
     uint8_t* d_desc64 = nullptr;             // all images back to back, 64-byte rows
+    size_t desc_block_bytes = 0;             // pooled device block behind d_desc64
     std::vector<uint64_t> desc_off;          // first row of each image in d_desc64
     std::vector<uint64_t> n_extrema;
 };
@@ -553,19 +596,21 @@ struct akz_result {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
+    bytes = align_up(std::max<size_t>(bytes, 256), 256);
     for (size_t i = 0; i < c->slab_pool.size(); ++i)
-        if (c->slab_pool[i].first >= bytes && c->slab_pool[i].first <= bytes + bytes / 4) {
+        if (c->slab_pool[i].first >= bytes && c->slab_pool[i].first <= bytes + bytes / 4 + 65536) {
             *p = c->slab_pool[i].second;
             *got = c->slab_pool[i].first;
             c->slab_pool.erase(c->slab_pool.begin() + (long)i);
             return AKZ_OK;
         }
+    bytes += bytes / 8;  // head-room so that the next, slightly larger request can reuse the block
     AKZ_HIP_TRY(hipMalloc(p, bytes));
     *got = bytes;
     return AKZ_OK;
 }
 static void slab_release(akz_ctx* c, void* p, size_t bytes) {
-    if (c->slab_pool.size() >= 4) {
+    if (c->slab_pool.size() >= 8) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipFree(c->slab_pool.front().second);
         c->slab_pool.erase(c->slab_pool.begin());
@@ -632,6 +677,10 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
                 slab_release(r->ctx, r->slab, r->slab_bytes);
                 r->slab = nullptr;
             }
+            if (armed && r->d_desc64) {
+                slab_release(r->ctx, r->d_desc64, r->desc_block_bytes);
+                r->d_desc64 = nullptr;
+            }
         }
     } guard{r.get()};
 
@@ -648,36 +697,36 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
     }
 
     // ---- levels 1..L-1 (lib.rs:78-119) ----
-    uint32_t max_w = w, max_h = h;
-    AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(max_w, max_h, n)));
+    AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(w, h, n)));
+    AKZ_TRY(ensure(c, c->scratch[3], plane_bytes(w, h, n)));
+    const std::vector<float> g1 = gaussian_kernel(1.0f, gaussian_kernel_size(1.0f));  // Lsmooth taps (lib.rs:95)
     for (size_t i = 1; i < L; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
         float* A = P(i, AKZ_LT);
         float* B = (float*)c->scratch[5].p;
         const uint32_t n_tau = (uint32_t)lv.tau.size();
-        float* start = (fed_num_launches(c, n_tau) % 2 == 0) ? A : B;  // the last launch must land in Lt
-        std::unique_ptr<StageTimer> st_prep(new StageTimer(c, AKZ_ST_PREP));
-        if (lv.octave > pv.octave) {
-            launch::half_size(s, P(i - 1, AKZ_LT), start, pv.w, pv.h, n);
-        } else {
-            AKZ_HIP_TRY(hipMemcpyAsync(start, P(i - 1, AKZ_LT), plane_bytes(lv.w, lv.h, n), hipMemcpyDeviceToDevice,
-                                       s));
+        const bool half = lv.octave > pv.octave;
+        // FED input: the previous level's final Lt (clone, lib.rs:92, no copy needed) or its 2x2 mean
+        // (lib.rs:82) materialised by k_prep into a buffer the first FED launch does not write.
+        const float* fed_in = P(i - 1, AKZ_LT);
+        float* half_buf = nullptr;
+        if (half) {
+            const uint32_t launches = fed_num_launches(c, n_tau);
+            half_buf = launches == 0 ? A : (fed_dst(launches, 1, A, B) == A ? B : A);
+            fed_in = half_buf;
         }
-        AKZ_TRY(gaussian_blur_impl<float>(c, start, P(i, AKZ_LSMOOTH), lv.w, lv.h, n, 1.0f));
-        launch::flow(s, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h, n, r->d_k, lv.octave);
-        float* lstep = keep_all ? P(i, AKZ_LSTEP) : nullptr;
-        if (lstep && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep, 0, plane_bytes(lv.w, lv.h, n), s));
-        st_prep.reset();
-        float* res = nullptr;
+        {
+            StageTimer st(c, AKZ_ST_PREP);
+            launch::prep_fused(s, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
+                               pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
+            float* lstep0 = keep_all ? P(i, AKZ_LSTEP) : nullptr;
+            if (lstep0 && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep0, 0, plane_bytes(lv.w, lv.h, n), s));
+        }
         {
             StageTimer st(c, AKZ_ST_FED);
-            AKZ_TRY(fed_impl(c, start, start == A ? B : A, P(i, AKZ_LFLOW), lstep, lv.w, lv.h, n, lv.tau.data(),
-                             n_tau, &res));
-        }
-        if (res != A) {
-            set_error("internal: FED ping-pong parity");
-            return AKZ_ERR_HIP;
+            AKZ_TRY(fed_impl(c, fed_in, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
+                             lv.tau.data(), n_tau));
         }
     }
 
@@ -701,21 +750,35 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
                         (float)cfg.detector_threshold, border_margin(lv, cfg), (Candidate*)c->cand.p, cap, d_count);
         }
         AKZ_HIP_TRY(hipGetLastError());
-        std::vector<uint32_t> counts(n);
-        AKZ_HIP_TRY(hipMemcpyAsync(counts.data(), d_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AKZ_TRY(ensure_pinned(c, c->pin[1], (size_t)n * sizeof(uint32_t)));
+        uint32_t* counts = (uint32_t*)c->pin[1].p;
+        AKZ_HIP_TRY(hipMemcpyAsync(counts, d_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         AKZ_HIP_TRY(hipStreamSynchronize(s));
-        const uint32_t mx = *std::max_element(counts.begin(), counts.end());
+        uint32_t mx = 0;
+        size_t total_c = 0;
+        for (uint32_t img = 0; img < n; ++img) {
+            mx = std::max(mx, counts[img]);
+            total_c += counts[img];
+        }
         if (mx > cap) {  // overflow: grow and redo the NMS pass only
             cap = mx + mx / 8;
             continue;
         }
+        AKZ_TRY(ensure_pinned(c, c->pin[0], std::max<size_t>(1, total_c) * sizeof(Candidate)));
+        Candidate* hc = (Candidate*)c->pin[0].p;
+        size_t o = 0;
         for (uint32_t img = 0; img < n; ++img) {
-            cands[img].resize(counts[img]);
             if (counts[img])
-                AKZ_HIP_TRY(hipMemcpyAsync(cands[img].data(), (Candidate*)c->cand.p + (size_t)img * cap,
+                AKZ_HIP_TRY(hipMemcpyAsync(hc + o, (Candidate*)c->cand.p + (size_t)img * cap,
                                            (size_t)counts[img] * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+            o += counts[img];
         }
         AKZ_HIP_TRY(hipStreamSynchronize(s));
+        o = 0;
+        for (uint32_t img = 0; img < n; ++img) {
+            cands[img].assign(hc + o, hc + o + counts[img]);
+            o += counts[img];
+        }
         cap = 0;
         break;
     }
@@ -730,11 +793,28 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
     r->n_extrema.assign(n, 0);
     uint64_t total_kp = 0;
     r->desc_off.assign(n + 1, 0);
+    {
+        auto work = [&](uint32_t img) {
+            std::sort(cands[img].begin(), cands[img].end(), [](const Candidate& a, const Candidate& b) {
+                return a.level != b.level ? a.level < b.level : a.idx < b.idx;
+            });
+            select_keypoints(cands[img], plan, cfg, hk[img], &r->n_extrema[img]);
+        };
+        const uint32_t hw_threads = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t nthreads = std::min<uint32_t>({n, hw_threads, 32u});
+        if (nthreads <= 1) {
+            for (uint32_t img = 0; img < n; ++img) work(img);
+        } else {  // images are independent: one host thread per image (up to 32)
+            std::atomic<uint32_t> next{0};
+            std::vector<std::thread> pool;
+            for (uint32_t t = 0; t < nthreads; ++t)
+                pool.emplace_back([&] {
+                    for (uint32_t img = next.fetch_add(1); img < n; img = next.fetch_add(1)) work(img);
+                });
+            for (auto& th : pool) th.join();
+        }
+    }
     for (uint32_t img = 0; img < n; ++img) {
-        std::sort(cands[img].begin(), cands[img].end(), [](const Candidate& a, const Candidate& b) {
-            return a.level != b.level ? a.level < b.level : a.idx < b.idx;
-        });
-        select_keypoints(cands[img], plan, cfg, hk[img], &r->n_extrema[img]);
         r->desc_off[img] = total_kp;
         total_kp += hk[img].size();
     }
@@ -761,51 +841,53 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
             p.xf = k.x / ratio;
             p.yf = k.y / ratio;
             p.scale = std::round(0.5f * k.size / ratio);
-            p.co = 1.0f; p.si = 0.0f;
             p.level = k.class_id;
-            p._pad[0] = p._pad[1] = 0;
+            p.img = img;
+            p._pad[0] = p._pad[1] = p._pad[2] = 0;
         }
     const uint32_t desc_bytes = (uint32_t)(((6 + 36 + 120) * cfg.descriptor_channels + 7) / 8);
     r->kps.assign(n, {});
     r->desc.assign(n, {});
-    AKZ_TRY(ensure(c, c->kp_in, std::max<size_t>(1, total_kp) * sizeof(KpParam)));
-    AKZ_TRY(ensure(c, c->kp_out, std::max<size_t>(1, total_kp) * std::max(sizeof(OrientOut), (size_t)64)));
     if (total_kp) {
         unsigned long long wmask = 0;
         uint32_t nwin = 0;
         orientation_windows(&wmask, &nwin);
         const double t_or0 = now_ms();
+        AKZ_TRY(ensure(c, c->kp_in, total_kp * sizeof(KpParam)));
+        AKZ_TRY(ensure(c, c->kp_out, total_kp * sizeof(OrientOut)));
+        AKZ_TRY(ensure(c, c->cosi, total_kp * 2 * sizeof(float)));
+        AKZ_TRY(ensure_pinned(c, c->pin[1], total_kp * std::max(sizeof(OrientOut), 2 * sizeof(float))));
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* d_oo = (OrientOut*)c->kp_out.p;
         AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params.data(), total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
-        for (uint32_t img = 0; img < n; ++img)
-            launch::orientation(s, tab, img, d_kp + r->desc_off[img], (uint32_t)hk[img].size(), wmask, nwin,
-                                d_oo + r->desc_off[img]);
+        launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());
-        std::vector<OrientOut> oo(total_kp);
-        AKZ_HIP_TRY(hipMemcpyAsync(oo.data(), d_oo, total_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+        OrientOut* oo = (OrientOut*)c->pin[1].p;
+        AKZ_HIP_TRY(hipMemcpyAsync(oo, d_oo, total_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
         AKZ_HIP_TRY(hipStreamSynchronize(s));
+        std::vector<float> cosi(total_kp * 2);
         for (uint32_t img = 0; img < n; ++img)
             for (size_t i = 0; i < hk[img].size(); ++i) {
                 const size_t g = r->desc_off[img] + i;
                 HostKeypoint& k = hk[img][i];
                 k.angle = oo[g].found ? atan2f(oo[g].sum_y, oo[g].sum_x) : 0.0f;  // scale_space_extrema.rs:326
-                params[g].co = cosf(k.angle);                                      // descriptors.rs:55-56
-                params[g].si = sinf(k.angle);
+                cosi[2 * g] = cosf(k.angle);                                       // descriptors.rs:55-56
+                cosi[2 * g + 1] = sinf(k.angle);
             }
-        AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params.data(), total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+        AKZ_HIP_TRY(hipMemcpyAsync(c->cosi.p, cosi.data(), cosi.size() * sizeof(float), hipMemcpyHostToDevice, s));
         const double t_ml0 = now_ms();
         if (c->profiling) c->prof.ms[AKZ_ST_ORIENT] += t_ml0 - t_or0;
-        // descriptors live in the slab-independent buffer owned by the result
-        AKZ_HIP_TRY(hipMalloc((void**)&r->d_desc64, total_kp * 64));
-        for (uint32_t img = 0; img < n; ++img)
-            launch::mldb(s, tab, img, d_kp + r->desc_off[img], (uint32_t)hk[img].size(),
-                         (uint32_t)cfg.descriptor_channels, (uint32_t)cfg.descriptor_pattern_size,
-                         r->d_desc64 + r->desc_off[img] * 64);
+        // descriptor rows live in a pooled device block owned by the result
+        void* blk = nullptr;
+        AKZ_TRY(slab_acquire(c, total_kp * 64, &blk, &r->desc_block_bytes));
+        r->d_desc64 = (uint8_t*)blk;
+        launch::mldb(s, tab, d_kp, (const float*)c->cosi.p, (uint32_t)total_kp, (uint32_t)cfg.descriptor_channels,
+                     r->d_desc64);
         AKZ_HIP_TRY(hipGetLastError());
         if (!(flags & AKZ_NO_HOST_DESCRIPTORS)) {
-            std::vector<uint8_t> rows(total_kp * 64);
-            AKZ_HIP_TRY(hipMemcpyAsync(rows.data(), r->d_desc64, rows.size(), hipMemcpyDeviceToHost, s));
+            AKZ_TRY(ensure_pinned(c, c->pin[2], total_kp * 64));
+            uint8_t* rows = (uint8_t*)c->pin[2].p;
+            AKZ_HIP_TRY(hipMemcpyAsync(rows, r->d_desc64, total_kp * 64, hipMemcpyDeviceToHost, s));
             AKZ_HIP_TRY(hipStreamSynchronize(s));
             for (uint32_t img = 0; img < n; ++img) {
                 r->desc[img].resize(hk[img].size() * desc_bytes);
@@ -876,10 +958,7 @@ int akz_extract_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t
 int akz_result_free(akz_result* r) {
     if (!r) return AKZ_OK;
     (void)hipSetDevice(r->ctx->device);
-    if (r->d_desc64) {
-        (void)hipStreamSynchronize(r->ctx->stream);
-        (void)hipFree(r->d_desc64);
-    }
+    if (r->d_desc64) slab_release(r->ctx, r->d_desc64, r->desc_block_bytes);
     if (r->slab) slab_release(r->ctx, r->slab, r->slab_bytes);
     delete r;
     return AKZ_OK;
@@ -1041,6 +1120,32 @@ int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8
     return AKZ_OK;
 }
 
+// Host keypoint logic alone (no GPU): raster-ordered NMS candidates -> keypoints without angle.
+// cand: n_cand records {level, idx, v, xp, xm, yp, ym, pad} (32 bytes each, any order).
+int akz_host_select_keypoints(uint32_t w, uint32_t h, const akz_config* cfg, const void* cand, uint64_t n_cand,
+                              akz_keypoint* out, uint64_t cap, uint64_t* n_out, uint64_t* n_extrema) {
+    if (!cfg || (n_cand && !cand) || !n_out) return AKZ_ERR_INVALID_ARG;
+    std::vector<LevelPlan> plan;
+    AKZ_TRY(build_plan(w, h, *cfg, plan));
+    std::vector<Candidate> c((const Candidate*)cand, (const Candidate*)cand + n_cand);
+    for (const Candidate& x : c)
+        if (x.level >= plan.size() || x.idx >= (uint64_t)plan[x.level].w * plan[x.level].h) {
+            set_error("candidate out of range");
+            return AKZ_ERR_INVALID_ARG;
+        }
+    std::sort(c.begin(), c.end(), [](const Candidate& a, const Candidate& b) {
+        return a.level != b.level ? a.level < b.level : a.idx < b.idx;
+    });
+    std::vector<HostKeypoint> hk;
+    uint64_t ne = 0;
+    select_keypoints(c, plan, *cfg, hk, &ne);
+    *n_out = hk.size();
+    if (n_extrema) *n_extrema = ne;
+    if (out)
+        for (size_t i = 0; i < hk.size() && i < cap; ++i)
+            out[i] = akz_keypoint{hk[i].x, hk[i].y, hk[i].response, hk[i].size, hk[i].octave, hk[i].class_id, 0.0f, 0};
+    return AKZ_OK;
+}
 int akz_ctx_set_profiling(akz_ctx* c, int on) {
     AKZ_TRY(bind(c));
     c->profiling = on != 0;

@@ -65,9 +65,9 @@ struct Candidate {  // one NMS survivor (scale_space_extrema.rs:32-42 + bounds :
 struct KpParam {  // per-keypoint input of the orientation / descriptor kernels
     float xf, yf;     // point / ratio
     float scale;      // round(0.5*size/ratio)
-    float co, si;     // cosf/sinf(angle) from the host libm (descriptor only)
     uint32_t level;
-    uint32_t _pad[2];
+    uint32_t img;     // image of the batch
+    uint32_t _pad[3];
 };
 struct OrientOut {
     float sum_x, sum_y;
@@ -109,14 +109,28 @@ void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, 
                    const unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist);
 void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const uint32_t* d_hist, uint32_t nbins,
                     double percentile, uint32_t n, double* d_k);
+// ---- fused LDS stencil chains (akz_stencil.hip) ----
+bool blur_fused_supported(uint32_t ntaps);
+void blur_fused_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k,
+                    uint32_t ntaps);
+void blur_fused_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k,
+                   uint32_t ntaps);
+// prev: the previous level's final Lt (pw x ph).  half: this level starts a new octave; then the 2x2
+// mean is written to lt_out as well.  g3: the 3 Gaussian taps of sigma 1.
+void prep_fused(hipStream_t s, const float* prev, bool half, float* lt_out, float* lsmooth, float* lflow, uint32_t w,
+                uint32_t h, uint32_t pw, uint32_t ph, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow);
+bool detector_fused_supported(uint32_t sigma);
+void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
+                    float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n);
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat);
 void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
          float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count);
-void orientation(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp,
+void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint32_t nkp,
                  unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out);
-void mldb(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp, uint32_t channels,
-          uint32_t pattern, uint8_t* d_desc64);
+// d_cosi: (cosf(angle), sinf(angle)) per keypoint from the host libm (descriptors.rs:55-56)
+void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
+          uint32_t channels, uint8_t* d_desc64);
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
            MatchRec* d_out);
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,

@@ -379,29 +379,62 @@ __global__ void k_ldet(const float* __restrict__ lxx, const float* __restrict__ 
 // border test (:80-87), which depends only on (x, y, level); out-of-border candidates never
 // touch the reference's keypoint cache.  Unordered append; the host sorts into raster order.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_nms(const float* __restrict__ ldet, int w, int h, size_t img_stride, unsigned level, float thr,
-                      float border_m, Candidate* __restrict__ cand, unsigned cap, unsigned* __restrict__ count) {
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
-    if (x < 1 || x >= w || y < 1 || y >= h - 1) return;
-    const long i = (long)y * w + x;
-    if (i >= (long)w * h - w - 1) return;  // flat range (w+1) .. len-w-1 of the reference loop
-    const float* D = ldet + (size_t)blockIdx.z * img_stride;
-    const float v = D[i];
+__device__ __forceinline__ void nms_emit(float v, float xp, float xm, float yp, float ym, int x, int y, int w, int h,
+                                         unsigned level, float thr, float border_m, Candidate* __restrict__ cand,
+                                         unsigned cap, unsigned* __restrict__ count) {
     if (!(v > thr)) return;
-    const float xp = D[i + 1], xm = D[i - 1], ym = D[i - w], yp = D[i + w];
     if (!(v > xp && v > xm && v > ym && v > yp)) return;
     const float fx = (float)x, fy = (float)y;
     const bool is_out = (roundf(fx - border_m) - 1.0f) < 0.0f || (roundf(fx + border_m) + 1.0f) >= (float)w ||
                         (roundf(fy - border_m) - 1.0f) < 0.0f || (roundf(fy + border_m) + 1.0f) >= (float)h;
     if (is_out) return;
-    const unsigned slot = atomicAdd(count + blockIdx.z, 1u);
+    const unsigned slot = atomicAdd(count, 1u);
     if (slot < cap) {
         Candidate c;
         c.level = level;
-        c.idx = (unsigned)i;
+        c.idx = (unsigned)(y * w + x);
         c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
         c._pad = 0;
-        cand[(size_t)blockIdx.z * cap + slot] = c;
+        cand[slot] = c;
+    }
+}
+// one thread = 4 consecutive pixels of a row (float4 loads of the row and its two neighbours)
+__global__ void k_nms(const float* __restrict__ ldet, int w, int h, size_t img_stride, unsigned level, float thr,
+                      float border_m, Candidate* __restrict__ cand, unsigned cap, unsigned* __restrict__ count) {
+    const int x0 = (blockIdx.x * BX + threadIdx.x) * 4, y = blockIdx.y * BY + threadIdx.y;
+    if (x0 >= w || y < 1 || y >= h - 1) return;
+    const float* D = ldet + (size_t)blockIdx.z * img_stride;
+    const float* row = D + (size_t)y * w;
+    Candidate* mycand = cand + (size_t)blockIdx.z * cap;
+    unsigned* mycount = count + blockIdx.z;
+    float c[6], up[4], dn[4];
+    if ((w & 3) == 0 && x0 + 3 < w) {
+        const float4 vc = *reinterpret_cast<const float4*>(row + x0);
+        const float4 vu = *reinterpret_cast<const float4*>(row - w + x0);
+        const float4 vd = *reinterpret_cast<const float4*>(row + w + x0);
+        c[1] = vc.x; c[2] = vc.y; c[3] = vc.z; c[4] = vc.w;
+        up[0] = vu.x; up[1] = vu.y; up[2] = vu.z; up[3] = vu.w;
+        dn[0] = vd.x; dn[1] = vd.y; dn[2] = vd.z; dn[3] = vd.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = x0 + e < w;
+            c[e + 1] = in ? row[x0 + e] : 0.0f;
+            up[e] = in ? row[x0 + e - w] : 0.0f;
+            dn[e] = in ? row[x0 + e + w] : 0.0f;
+        }
+    }
+    c[0] = x0 > 0 ? row[x0 - 1] : 0.0f;
+    // the reference's "east" neighbour of x = w-1 is the next row's x = 0 (flat iteration); such a pixel
+    // always fails the border test, so any value works; read in bounds.
+    c[5] = (x0 + 4 < w) ? row[x0 + 4] : 0.0f;
+    const long last = (long)w * h - w - 1;  // flat range (w+1) .. len-w-1 of the reference loop
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        if (x < 1 || x >= w) continue;
+        if ((long)y * w + x >= last) continue;
+        nms_emit(c[e + 1], c[e + 2], c[e], dn[e], up[e], x, y, w, h, level, thr, border_m, mycand, cap, mycount);
     }
 }
 
@@ -423,56 +456,85 @@ __constant__ float c_gauss25[7][7] = {
 // independent bit mask computed on the host with the host libm.  The running sums are never
 // reset (as in the reference).  The final atan2f is left to the host.
 // ---------------------------------------------------------------------------------------------
-constexpr int ORI_THREADS = 64;
-__global__ void k_orientation(LevelTable tab, unsigned img, const KpParam* __restrict__ kps, unsigned nkp,
-                              unsigned long long window_mask, unsigned n_windows, OrientOut* __restrict__ out) {
-    __shared__ float s_rx[109 * ORI_THREADS];
-    __shared__ float s_ry[109 * ORI_THREADS];
-    const unsigned t = threadIdx.x;
-    const unsigned i = blockIdx.x * ORI_THREADS + t;
-    if (i >= nkp) return;
-    const KpParam kp = kps[i];
-    const LevelPtrs lv = tab.lv[kp.level];
-    const float* lx = lv.lx + (size_t)img * lv.stride;
-    const float* ly = lv.ly + (size_t)img * lv.stride;
+// One wave per keypoint (4 keypoints per workgroup, all images in one launch): the 64 lanes gather the
+// 109 samples in two rounds into LDS, then lanes with even/odd index replay the sequential x / y
+// running sums (f32 adds in k order, as the reference) and exchange them once per window.
+struct OriTable {
+    signed char a[112], b[112];
+};
+constexpr OriTable make_ori_table() {
+    OriTable t{};
     int idx = 0;
-    for (int a = -6; a <= 6; ++a)
-        for (int b = -6; b <= 6; ++b)
-            if (a * a + b * b < 36) {
+    for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j)
+            if (i * i + j * j < 36) {
+                t.a[idx] = (signed char)i;
+                t.b[idx] = (signed char)j;
+                ++idx;
+            }
+    for (; idx < 112; ++idx) { t.a[idx] = 0; t.b[idx] = 0; }
+    return t;
+}
+__constant__ OriTable c_ori = make_ori_table();
+
+constexpr int ORI_KPB = 4;  // keypoints (waves) per workgroup
+__global__ void __launch_bounds__(64 * ORI_KPB)
+k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, unsigned long long window_mask,
+              unsigned n_windows, OrientOut* __restrict__ out) {
+    __shared__ float s_rx[ORI_KPB][112];
+    __shared__ float s_ry[ORI_KPB][112];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned i = blockIdx.x * ORI_KPB + wv;
+    const bool live = i < nkp;
+    if (live) {
+        const KpParam kp = kps[i];
+        const LevelPtrs lv = tab.lv[kp.level];
+        const float* lx = lv.lx + (size_t)kp.img * lv.stride;
+        const float* ly = lv.ly + (size_t)kp.img * lv.stride;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned k = lane + 64u * r;
+            if (k < 109u) {
+                const int a = c_ori.a[k], b = c_ori.b[k];
                 const float fy = roundf(kp.yf + (float)b * kp.scale);
                 const float fx = roundf(kp.xf + (float)a * kp.scale);
                 const int iy = clampi(fy > 0.0f ? (int)fy : 0, 0, (int)lv.h - 1);
                 const int ix = clampi(fx > 0.0f ? (int)fx : 0, 0, (int)lv.w - 1);
-                const int ia = a < 0 ? -a : a, ib = b < 0 ? -b : b;
-                const float g = c_gauss25[ia][ib];
+                const float g = c_gauss25[a < 0 ? -a : a][b < 0 ? -b : b];
                 const size_t p = (size_t)iy * lv.w + ix;
-                s_rx[idx * ORI_THREADS + t] = g * lx[p];
-                s_ry[idx * ORI_THREADS + t] = g * ly[p];
-                ++idx;
+                s_rx[wv][k] = g * lx[p];
+                s_ry[wv][k] = g * ly[p];
             }
-    float sum_x = 0.0f, sum_y = 0.0f, maxv = 0.0f, bx = 0.0f, by = 0.0f;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const bool is_y = (lane & 1u) != 0;  // odd lanes carry sum_y, even lanes sum_x
+    float sum = 0.0f, maxv = 0.0f, bx = 0.0f, by = 0.0f;
     unsigned found = 0;
     for (unsigned wdw = 0; wdw < n_windows; ++wdw) {
         if ((window_mask >> wdw) & 1ull) {
             for (int k = 0; k < 109; ++k) {
-                const float ry = s_ry[k * ORI_THREADS + t];
-                if (ry > 0.0f) {
-                    sum_x = sum_x + s_rx[k * ORI_THREADS + t];
-                    sum_y = sum_y + ry;
-                }
+                const float ry = s_ry[wv][k];
+                const float add = is_y ? ry : s_rx[wv][k];
+                if (ry > 0.0f) sum = sum + add;
             }
         }
-        const float val = sum_x * sum_x + sum_y * sum_y;
+        const float other = __shfl_xor(sum, 1, 64);
+        const float sx = is_y ? other : sum, sy = is_y ? sum : other;
+        const float val = sx * sx + sy * sy;
         if (val > maxv) {
             maxv = val;
-            bx = sum_x;
-            by = sum_y;
+            bx = sx;
+            by = sy;
             found = 1;
         }
     }
-    OrientOut o;
-    o.sum_x = bx; o.sum_y = by; o.found = found; o._pad = 0;
-    out[i] = o;
+    if (lane == 0) {
+        OrientOut o;
+        o.sum_x = bx; o.sum_y = by; o.found = found; o._pad = 0;
+        out[i] = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,17 +543,35 @@ __global__ void k_orientation(LevelTable tab, unsigned img, const KpParam* __res
 // not associative); then all 64 lanes evaluate the 162*channels comparisons and ballot packs
 // them LSB-first into a 64-byte row.
 // ---------------------------------------------------------------------------------------------
-__constant__ unsigned char c_pair_a[162], c_pair_b[162];  // (i, j), i < j, per grid, cell ids 0..28
+// pair order of mldb_binary_comparisons (descriptors.rs:161-174): for i, for j > i, per grid; cell ids 0..28
+struct PairTable {
+    unsigned char a[162], b[162];
+};
+constexpr PairTable make_pairs() {
+    PairTable t{};
+    int p = 0;
+    const int counts[3] = {4, 9, 16}, base[3] = {0, 4, 13};
+    for (int g = 0; g < 3; ++g)
+        for (int i = 0; i < counts[g]; ++i)
+            for (int j = i + 1; j < counts[g]; ++j) {
+                t.a[p] = (unsigned char)(base[g] + i);
+                t.b[p] = (unsigned char)(base[g] + j);
+                ++p;
+            }
+    return t;
+}
+__constant__ PairTable c_pairs = make_pairs();
 
-__global__ void k_mldb(LevelTable tab, unsigned img, const KpParam* __restrict__ kps, unsigned nkp,
-                       unsigned channels, uint8_t* __restrict__ desc64) {
+__global__ void k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi,
+                       unsigned nkp, unsigned channels, uint8_t* __restrict__ desc64) {
     __shared__ float s_val[3][32];
     const unsigned kpi = blockIdx.x;
     if (kpi >= nkp) return;
     const unsigned lane = threadIdx.x;
     const KpParam kp = kps[kpi];
+    const float2 cs = cosi[kpi];
     const LevelPtrs lv = tab.lv[kp.level];
-    const size_t ioff = (size_t)img * lv.stride;
+    const size_t ioff = (size_t)kp.img * lv.stride;
     const float* Lt = lv.lt + ioff;
     const float* Lx = lv.lx + ioff;
     const float* Ly = lv.ly + ioff;
@@ -501,7 +581,7 @@ __global__ void k_mldb(LevelTable tab, unsigned img, const KpParam* __restrict__
         else if (lane < 13) { step = 7; ng = 3; ci = (int)lane - 4; }
         else { step = 5; ng = 4; ci = (int)lane - 13; }
         const int i0 = -10 + (ci / ng) * step, j0 = -10 + (ci % ng) * step;
-        const float co = kp.co, si = kp.si, scale = kp.scale;
+        const float co = cs.x, si = cs.y, scale = kp.scale;
         float di = 0.0f, dx = 0.0f, dy = 0.0f;
         for (int k = i0; k < i0 + step; ++k)
             for (int l = j0; l < j0 + step; ++l) {
@@ -543,7 +623,7 @@ __global__ void k_mldb(LevelTable tab, unsigned img, const KpParam* __restrict__
             else if (b < seg1) { rel = b - seg0; npairs = 36; pbase = 6; }
             else { rel = b - seg1; npairs = 120; pbase = 42; }
             const unsigned pos = rel / npairs, p = rel % npairs;
-            bit = s_val[pos][c_pair_a[pbase + p]] > s_val[pos][c_pair_b[pbase + p]];
+            bit = s_val[pos][c_pairs.a[pbase + p]] > s_val[pos][c_pairs.b[pbase + p]];
         }
         words[r] = __ballot(bit);
     }
@@ -719,39 +799,21 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
 }
 void nms(hipStream_t s, const float* ldet_p, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
          float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count) {
-    hipLaunchKernelGGL(k_nms, grid2d(w, h, n), dim3(BX, BY), 0, s, ldet_p, (int)w, (int)h, (size_t)img_stride, level,
-                       thr, border_m, d_cand, cap_per_img, d_count);
+    hipLaunchKernelGGL(k_nms, grid2d((w + 3) / 4, h, n), dim3(BX, BY), 0, s, ldet_p, (int)w, (int)h, (size_t)img_stride,
+                       level, thr, border_m, d_cand, cap_per_img, d_count);
 }
-void orientation(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp,
+void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint32_t nkp,
                  unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out) {
     if (nkp == 0) return;
-    hipLaunchKernelGGL(k_orientation, dim3((nkp + ORI_THREADS - 1) / ORI_THREADS), dim3(ORI_THREADS), 0, s, lt, img,
-                       d_kp, nkp, window_mask, n_windows, d_out);
+    hipLaunchKernelGGL(k_orientation, dim3((nkp + ORI_KPB - 1) / ORI_KPB), dim3(64 * ORI_KPB), 0, s, lt, d_kp, nkp,
+                       window_mask, n_windows, d_out);
 }
 
-static bool g_pairs_uploaded = false;
-static int upload_pairs() {
-    // pair order of mldb_binary_comparisons (descriptors.rs:161-174): for i, for j > i
-    unsigned char a[162], b[162];
-    int p = 0;
-    const int counts[3] = {4, 9, 16}, base[3] = {0, 4, 13};
-    for (int g = 0; g < 3; ++g)
-        for (int i = 0; i < counts[g]; ++i)
-            for (int j = i + 1; j < counts[g]; ++j) {
-                a[p] = (unsigned char)(base[g] + i);
-                b[p] = (unsigned char)(base[g] + j);
-                ++p;
-            }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_pair_a), a, sizeof(a)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_pair_b), b, sizeof(b)) != hipSuccess) return -1;
-    g_pairs_uploaded = true;
-    return 0;
-}
-void mldb(hipStream_t s, const LevelTable& lt, uint32_t img, const KpParam* d_kp, uint32_t nkp, uint32_t channels,
-          uint32_t /*pattern*/, uint8_t* d_desc64) {
+void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
+          uint32_t channels, uint8_t* d_desc64) {
     if (nkp == 0) return;
-    if (!g_pairs_uploaded) upload_pairs();
-    hipLaunchKernelGGL(k_mldb, dim3(nkp), dim3(64), 0, s, lt, img, d_kp, nkp, channels, d_desc64);
+    hipLaunchKernelGGL(k_mldb, dim3(nkp), dim3(64), 0, s, lt, d_kp, reinterpret_cast<const float2*>(d_cosi), nkp,
+                       channels, d_desc64);
 }
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
            MatchRec* d_out) {

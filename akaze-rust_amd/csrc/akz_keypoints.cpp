@@ -42,42 +42,66 @@ void orientation_windows(unsigned long long* mask, uint32_t* n_windows) {
 
 namespace {
 
-// Uniform grid over full-resolution coordinates holding cache slots; lets the "first cache
-// entry within `size` on level e or e-1" query of the reference (a linear scan, :57-76) be
-// answered from a few cells.  The answer is the MINIMUM slot index among qualifying entries,
-// which is exactly what the reference's front-to-back scan with `break` returns.
-class SlotGrid {
+// Uniform grids (one per level) over full-resolution coordinates holding cache slots as
+// intrusive singly linked lists (head per cell, next per slot; no per-cell allocation).  They let
+// the "first cache entry within `size` on level e or e-1" query of the reference (a linear scan,
+// :57-76) be answered from a few cells.  The answer is the MINIMUM slot index among qualifying
+// entries, which is exactly what the reference's front-to-back scan with `break` returns.
+class SlotGrids {
 public:
-    SlotGrid(float width, float height, float cell) : cell_(cell) {
-        nx_ = std::max(1, (int)std::ceil(width / cell) + 1);
-        ny_ = std::max(1, (int)std::ceil(height / cell) + 1);
-        cells_.resize((size_t)nx_ * ny_);
+    SlotGrids(const std::vector<LevelPlan>& plan, const akz_config& cfg, size_t max_slots) {
+        const float width = (float)plan[0].w + 16.0f, height = (float)plan[0].h + 16.0f;
+        size_t total = 0;
+        for (const LevelPlan& lv : plan) {
+            G g;
+            g.cell = std::max(8.0f, (float)(lv.esigma * cfg.derivative_factor));
+            g.nx = std::max(1, (int)std::ceil(width / g.cell) + 1);
+            g.ny = std::max(1, (int)std::ceil(height / g.cell) + 1);
+            g.base = total;
+            total += (size_t)g.nx * g.ny;
+            grids_.push_back(g);
+        }
+        head_.assign(total, -1);
+        next_.assign(max_slots, -1);
     }
-    void insert(uint32_t slot, float x, float y) { cells_[index(x, y)].push_back(slot); }
-    void remove(uint32_t slot, float x, float y) {
-        auto& v = cells_[index(x, y)];
-        for (size_t i = 0; i < v.size(); ++i)
-            if (v[i] == slot) {
-                v[i] = v.back();
-                v.pop_back();
+    void insert(uint32_t level, int32_t slot, float x, float y) {
+        int32_t& h = head_[index(level, x, y)];
+        next_[slot] = h;
+        h = slot;
+    }
+    void remove(uint32_t level, int32_t slot, float x, float y) {
+        int32_t* link = &head_[index(level, x, y)];
+        while (*link != -1) {
+            if (*link == slot) {
+                *link = next_[slot];
                 return;
             }
+            link = &next_[*link];
+        }
     }
     template <typename F>
-    void for_each_near(float x, float y, float radius, F&& f) const {
-        const int x0 = cx(x - radius), x1 = cx(x + radius), y0 = cy(y - radius), y1 = cy(y + radius);
+    void for_each_near(uint32_t level, float x, float y, float radius, F&& f) const {
+        const G& g = grids_[level];
+        const int x0 = cx(g, x - radius), x1 = cx(g, x + radius), y0 = cy(g, y - radius), y1 = cy(g, y + radius);
         for (int yy = y0; yy <= y1; ++yy)
             for (int xx = x0; xx <= x1; ++xx)
-                for (uint32_t s : cells_[(size_t)yy * nx_ + xx]) f(s);
+                for (int32_t s = head_[g.base + (size_t)yy * g.nx + xx]; s != -1; s = next_[s]) f((uint32_t)s);
     }
 
 private:
-    int cx(float x) const { return std::min(nx_ - 1, std::max(0, (int)std::floor(x / cell_))); }
-    int cy(float y) const { return std::min(ny_ - 1, std::max(0, (int)std::floor(y / cell_))); }
-    size_t index(float x, float y) const { return (size_t)cy(y) * nx_ + cx(x); }
-    float cell_;
-    int nx_, ny_;
-    std::vector<std::vector<uint32_t>> cells_;
+    struct G {
+        float cell;
+        int nx, ny;
+        size_t base;
+    };
+    static int cx(const G& g, float x) { return std::min(g.nx - 1, std::max(0, (int)std::floor(x / g.cell))); }
+    static int cy(const G& g, float y) { return std::min(g.ny - 1, std::max(0, (int)std::floor(y / g.cell))); }
+    size_t index(uint32_t level, float x, float y) const {
+        const G& g = grids_[level];
+        return g.base + (size_t)cy(g, y) * g.nx + cx(g, x);
+    }
+    std::vector<G> grids_;
+    std::vector<int32_t> head_, next_;
 };
 
 }  // namespace
@@ -91,14 +115,7 @@ void select_keypoints(const std::vector<Candidate>& cands, const std::vector<Lev
         if (n_extrema) *n_extrema = 0;
         return;
     }
-    float max_size = 1.0f;
-    for (const LevelPlan& lv : plan) max_size = std::max(max_size, (float)(lv.esigma * cfg.derivative_factor));
-    // one grid per level so that a query only walks entries of class_id e and e-1
-    std::vector<SlotGrid> grids;
-    grids.reserve(plan.size());
-    for (size_t l = 0; l < plan.size(); ++l)
-        grids.emplace_back((float)plan[0].w + 16.0f, (float)plan[0].h + 16.0f,
-                           std::max(8.0f, (float)(plan[l].esigma * cfg.derivative_factor)));
+    SlotGrids grids(plan, cfg, cands.size() + 1);
 
     // ---- first pass: scale_space_extrema.rs:43-100 ----
     for (const Candidate& c : cands) {
@@ -125,8 +142,8 @@ void select_keypoints(const std::vector<Candidate>& cands, const std::vector<Lev
             const float dist = (qx - p.x) * (qx - p.x) + (qy - p.y) * (qy - p.y);
             if (dist <= size2) hit = s;
         };
-        grids[c.level].for_each_near(qx, qy, kp.size + 1.0f, visit);
-        if (c.level > 0) grids[c.level - 1].for_each_near(qx, qy, kp.size + 1.0f, visit);
+        grids.for_each_near(c.level, qx, qy, kp.size + 1.0f, visit);
+        if (c.level > 0) grids.for_each_near(c.level - 1, qx, qy, kp.size + 1.0f, visit);
         bool is_repeated = false, is_extremum = true;
         if (hit != UINT32_MAX) {
             if (kp.response > cache[hit].response) is_repeated = true;
@@ -138,12 +155,12 @@ void select_keypoints(const std::vector<Candidate>& cands, const std::vector<Lev
         kp.y = kp.y * ratio + 0.5f * (ratio - 1.0f);
         if (!is_repeated) {
             cache.push_back(kp);
-            grids[kp.class_id].insert((uint32_t)(cache.size() - 1), kp.x, kp.y);
+            grids.insert(kp.class_id, (int32_t)(cache.size() - 1), kp.x, kp.y);
         } else {
             const HostKeypoint old = cache[hit];
-            grids[old.class_id].remove(hit, old.x, old.y);
+            grids.remove(old.class_id, (int32_t)hit, old.x, old.y);
             cache[hit] = kp;
-            grids[kp.class_id].insert(hit, kp.x, kp.y);
+            grids.insert(kp.class_id, (int32_t)hit, kp.x, kp.y);
         }
     }
 
@@ -155,7 +172,7 @@ void select_keypoints(const std::vector<Candidate>& cands, const std::vector<Lev
         bool repeated = false;
         if ((size_t)a.class_id + 1 < plan.size()) {
             const float size2 = a.size * a.size;
-            grids[a.class_id + 1].for_each_near(a.x, a.y, a.size + 1.0f, [&](uint32_t s) {
+            grids.for_each_near(a.class_id + 1, a.x, a.y, a.size + 1.0f, [&](uint32_t s) {
                 if (repeated || s < i) return;
                 const HostKeypoint& b = cache[s];
                 const float dist = (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y);

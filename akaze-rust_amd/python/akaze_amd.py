@@ -144,6 +144,7 @@ def lib():
         "akz_descriptor_match": ([vp, vp, u64, vp, u64, u64, u64, f64, vp, pu64], i32),
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
+        "akz_host_select_keypoints": ([u32, u32, C.POINTER(Config), vp, u64, vp, u64, pu64, pu64], i32),
         "akz_ctx_set_profiling": ([vp, i32], i32),
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
@@ -207,6 +208,21 @@ def plan_levels(w, h, cfg=None):
         out.append(dict(etime=et.value, esigma=es.value, octave=o.value, sublevel=s.value, sigma_size=ss.value,
                         w=lw.value, h=lh.value, det_sigma=ds.value, tau=tau[:nt.value].copy()))
     return out
+
+
+CANDIDATE_DTYPE = np.dtype([("level", "<u4"), ("idx", "<u4"), ("v", "<f4"), ("xp", "<f4"), ("xm", "<f4"),
+                            ("yp", "<f4"), ("ym", "<f4"), ("_pad", "<u4")])
+
+
+def host_select_keypoints(w, h, cfg, cands):
+    """Host part of detect_keypoints (scale_space_extrema.rs:43-178) on NMS candidates; no GPU needed.
+    Returns (keypoints without angle, number of extrema before the sub-pixel step)."""
+    cands = np.ascontiguousarray(cands, CANDIDATE_DTYPE)
+    out = np.zeros(max(1, len(cands)), KEYPOINT_DTYPE)
+    n, ne = C.c_uint64(), C.c_uint64()
+    _check(lib().akz_host_select_keypoints(w, h, C.byref(cfg), cands.ctypes.data_as(C.c_void_p), len(cands),
+                                           out.ctypes.data_as(C.c_void_p), len(out), C.byref(n), C.byref(ne)))
+    return out[:n.value].copy(), ne.value
 
 
 def synth_frame(w, h, frame_index=0, shift=(0, 0)):
@@ -521,3 +537,36 @@ def match_features(keypoints_0, descriptors_0, keypoints_1, descriptors_1, lowes
     """Descriptor stage of akaze::match_features (lib.rs:261-266): descriptor_match(d0, d1, 10000, ratio).
     The RANSAC post-filter (lib.rs:267-274) is host code outside the GPU path."""
     return (ctx or default_context()).descriptor_match(descriptors_0, descriptors_1, 10000, lowes_ratio)
+
+
+# ------------------------------------------------------------------------------------------
+# multi-GPU: per-image sharding and the one exchange step of the path
+# ------------------------------------------------------------------------------------------
+def shard_frames(num_frames, rank, world_size):
+    """Frame indices owned by `rank`: image i -> GPU i mod G; extraction needs no
+    collective."""
+    return list(range(rank, num_frames, world_size))
+
+
+def gather_descriptor_rows(local_rows, group=None):
+    """All-gather of 64-byte descriptor rows before a cross-image brute-force match: every rank
+    contributes a [n_r, 64] uint8 tensor (any n_r >= 0) and receives ([sum n_r, 64] rows in rank order,
+    counts per rank).  Two collectives: the row counts, then the rows padded to the largest shard.
+    With the "nccl" backend this is RCCL over xGMI; tensors stay on the GPU."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = local_rows.device
+    n_local = int(local_rows.shape[0])
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    cnts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    counts = [int(v) for v in cnts.tolist()]
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
+    if n_local:
+        padded[:n_local] = local_rows
+    gathered = torch.empty((world * cap, 64), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    rows = torch.cat([gathered[r * cap:r * cap + counts[r]] for r in range(world)], dim=0)
+    return rows, counts

@@ -46,12 +46,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step (C4: 256 frames / 8 GPUs)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the descriptor gather even with one rank (self-test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -67,45 +69,40 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ctx = A.Context(local_rank, torch.cuda.current_stream().cuda_stream)
     cfg = A.Config()  # Config::default(): 4 octaves x 4 sublevels, 486-bit M-LDB
     W, H, F = args.width, args.height, args.frames
 
-    # this rank's shard: global frame indices rank*F .. rank*F+F-1 (one image per GPU slot)
-    frames = np.stack([A.synth_frame(W, H, rank * F + i) for i in range(F)])
+    # this rank's shard of the world*F frames of a step: image i -> GPU i mod world (weak scaling)
+    frames = np.stack([A.synth_frame(W, H, i) for i in A.shard_frames(world * F, rank, world)])
     d_frames = torch.from_numpy(frames).to(dev)
     torch.cuda.synchronize()
 
     def gather_descriptors(res):
         """The path's exchange step: counts, then padded 64-byte rows over RCCL."""
         rows = sum(res.counts(i)[1] for i in range(res.num_images))
-        local = torch.zeros((max(rows, 1), 64), dtype=torch.uint8, device=dev)
-        res.copy_device_descriptors(local)
-        cnt = torch.tensor([rows], dtype=torch.int64, device=dev)
-        cnts = torch.zeros(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(cnts, cnt)
-        cap = int(cnts.max().item())
-        padded = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
-        padded[:rows] = local[:rows]
-        allrows = torch.empty((world * cap, 64), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(allrows, padded)
-        return allrows, cnts
+        local = torch.empty((rows, 64), dtype=torch.uint8, device=dev)
+        if rows:
+            res.copy_device_descriptors(local)
+        return A.gather_descriptor_rows(local)
 
     def step():
         res = ctx.extract_features(d_frames, cfg, keep_all_planes=not args.lean)
         nk = sum(res.counts(i)[1] for i in range(res.num_images))
-        if world > 1:
+        if use_dist:
             gather_descriptors(res)
         res.close()
         return nk
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,7 +119,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -203,14 +200,14 @@ def main():
                                    "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)",
                        "frames_per_gpu": F, "width": W, "height": H,
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
-                       "exchange": "RCCL all-gather of descriptor rows" if world > 1 else "none (1 GPU)",
+                       "exchange": "RCCL all-gather of descriptor rows" if use_dist else "none (1 GPU)",
                        "keypoints_per_step_rank0": nk},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

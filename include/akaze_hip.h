@@ -226,6 +226,14 @@ int akz_descriptor_match_device(akz_ctx* ctx, const uint8_t* d_d0, uint64_t n0, 
                                 uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
                                 uint64_t* d_n_out);
 
+/* ---- host-only pieces, callable without a GPU --------------------------------------------- */
+/* find_scale_space_extrema's order-dependent cache logic + the sub-pixel step
+   (scale_space_extrema.rs:43-178) on NMS candidates {u32 level, u32 flat_idx, f32 v, xp, xm, yp, ym,
+   u32 pad} that already passed threshold, 4-neighbour maximum and the border test.  Keypoints are
+   returned without orientation (angle = 0). */
+int akz_host_select_keypoints(uint32_t w, uint32_t h, const akz_config* cfg, const void* cand, uint64_t n_cand,
+                              akz_keypoint* out, uint64_t cap, uint64_t* n_out, uint64_t* n_extrema);
+
 /* ---- measurement hooks --------------------------------------------------------------- */
 /* Deterministic synthetic 8-bit luma frame (integer-only, SplitMix64-seeded):
    gradient background + w*h/2048 random rectangles/discs + +-8 noise.  (shift_x, shift_y)

@@ -126,8 +126,60 @@ def test_isa_has_no_contracted_fma():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_audit
     rows, bad = isa_audit.audit(os.path.join(pkg, "csrc", "akz_kernels.s"))
-    assert len(rows) >= 14 and not bad, bad
-    pure = {r[0]: r[1] for r in rows}
+    rows2, bad2 = isa_audit.audit(os.path.join(pkg, "csrc", "akz_stencil.s"))
+    assert len(rows) >= 14 and len(rows2) >= 18 and not bad and not bad2, (bad, bad2)
+    pure = {r[0]: r[1] for r in rows + rows2}
     for k, v in pure.items():
-        if k.startswith(("k_fed", "k_filter_v", "k_filter_hIf", "k_ldet", "k_nms", "k_orientation")):
+        if k.startswith(("k_fed", "k_filter_v", "k_filter_hIf", "k_ldet", "k_nms", "k_orientation", "k_deriv",
+                         "k_blurILi1EfE", "k_blurILi2EfE")):
             assert v == 0, (k, v)
+
+
+def _round_half_away(v):
+    v = np.asarray(v, np.float32)
+    return np.trunc(v + np.copysign(np.float32(0.5), v)).astype(np.float32)
+
+
+def nms_candidates_numpy(r, cfg):
+    """numpy statement of what k_nms hands to the host: threshold + strict 4-neighbour maximum
+    (scale_space_extrema.rs:32-42) + the border test (:80-87), any order."""
+    import akaze_amd
+    out = []
+    thr = np.float32(cfg.detector_threshold)
+    smax = np.float32(10.0) * np.sqrt(np.float32(2.0))
+    for lvl in range(r.num_levels):
+        info = r.level_info(lvl)
+        D = r.plane(lvl, "Ldet")
+        h, w = D.shape
+        size = np.float32(info["esigma"] * cfg.derivative_factor)
+        ratio = np.float32(2.0 ** info["octave"])
+        m = smax * _round_half_away(size / ratio)
+        c = D[1:-1, 1:-1]
+        ok = (c > thr) & (c > D[1:-1, 2:]) & (c > D[1:-1, :-2]) & (c > D[:-2, 1:-1]) & (c > D[2:, 1:-1])
+        ys, xs = np.nonzero(ok)
+        ys, xs = ys + 1, xs + 1
+        fx, fy = xs.astype(np.float32), ys.astype(np.float32)
+        is_out = ((_round_half_away(fx - m) - 1 < 0) | (_round_half_away(fx + m) + 1 >= np.float32(w)) |
+                  (_round_half_away(fy - m) - 1 < 0) | (_round_half_away(fy + m) + 1 >= np.float32(h)))
+        for x, y in zip(xs[~is_out], ys[~is_out]):
+            out.append((lvl, y * w + x, D[y, x], D[y, x + 1], D[y, x - 1], D[y + 1, x], D[y - 1, x], 0))
+    return np.array(out, akaze_amd.CANDIDATE_DTYPE)
+
+
+@pytest.mark.parametrize("w,h,idx,kw", [(640, 480, 1, {}), (960, 540, 3, {}),
+                                        (800, 600, 2, dict(detector_threshold=0.0002))])
+def test_host_keypoint_logic_matches_oracle(amd, ref, w, h, idx, kw):
+    """The order-dependent cache logic + sub-pixel step run on the host (akz_keypoints.cpp) must give the
+    oracle's keypoints when fed the candidates the NMS kernel would emit (here computed with numpy from
+    the oracle's Ldet planes, in shuffled order)."""
+    frame = amd.synth_frame(w, h, idx)
+    r = ref.extract(frame, ref.default_config(**kw))
+    cfg = amd.Config(**kw)
+    cands = nms_candidates_numpy(r, cfg)
+    assert len(cands) > 50
+    rng = np.random.default_rng(0)
+    kps, n_ext = amd.host_select_keypoints(w, h, cfg, cands[rng.permutation(len(cands))])
+    rk = r.keypoints()
+    assert n_ext == r.num_extrema and len(kps) == len(rk)
+    for f in ("x", "y", "response", "size", "octave", "class_id"):
+        assert np.array_equal(kps[f], rk[f]), f

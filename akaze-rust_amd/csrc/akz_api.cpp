@@ -34,7 +34,8 @@ struct akz_ctx {
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf cosi;                             // (cos, sin) per keypoint
-    DevBuf pin[3];                           // pinned host staging: candidates, orientation sums, descriptor rows
+    DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
+                                             // rows, keypoint params, (cos, sin), contrast factors
     std::vector<std::pair<size_t, void*>> slab_pool;  // freed device blocks (pyramid slabs, descriptor rows)
     // stage profiling (akz_ctx_set_profiling)
     int fed_mode = 1;  // 0: one k_fed_step launch per step, 1: k_fed_fused (<= 8 steps per launch)
@@ -586,7 +587,7 @@ struct akz_result {
     double* d_k = nullptr;          // inside the slab
     std::vector<double> k_host;
     std::vector<std::vector<akz_keypoint>> kps;
-    std::vector<std::vector<uint8_t>> desc;  // unpadded, host
+    std::vector<uint8_t> rows64;             // host copy of the 64-byte rows (all images)
     uint8_t* d_desc64 = nullptr;             // all images back to back, 64-byte rows
     size_t desc_block_bytes = 0;             // pooled device block behind d_desc64
     std::vector<uint64_t> desc_off;          // first row of each image in d_desc64
@@ -594,6 +595,26 @@ struct akz_result {
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// run fn(begin, end) over [0, total) on up to `max_threads` host threads
+template <typename F>
+static void parallel_chunks(size_t total, size_t min_chunk, unsigned max_threads, F&& fn) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t want = std::max<size_t>(1, total / std::max<size_t>(1, min_chunk));
+    const unsigned nt = (unsigned)std::min<size_t>({want, (size_t)hw, (size_t)max_threads});
+    if (nt <= 1) {
+        fn((size_t)0, total);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t chunk = (total + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t b = (size_t)t * chunk, e = std::min(total, b + chunk);
+        if (b >= e) break;
+        pool.emplace_back([&fn, b, e] { fn(b, e); });
+    }
+    for (auto& th : pool) th.join();
+}
 
 static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
     bytes = align_up(std::max<size_t>(bytes, 256), 256);
@@ -740,14 +761,23 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)n * sizeof(uint32_t), s));
         for (size_t l = 0; l < L; ++l) {
             const LevelPlan& lv = plan[l];
+            const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
+            if (attempt == 0 && launch::detector_nms_fused_supported(lv.det_sigma)) {
+                // derivatives, Ldet and extrema candidates in two launches (no second pass over Ldet)
+                StageTimer st(c, AKZ_ST_DETECTOR);
+                launch::detector_nms_fused(s, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY),
+                                           P(l, AKZ_LXX), P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n,
+                                           (uint32_t)l, thr, bm, (Candidate*)c->cand.p, cap, d_count);
+                continue;
+            }
             if (attempt == 0) {
                 StageTimer st(c, AKZ_ST_DETECTOR);
                 AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
                                       P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n));
             }
             StageTimer st(c, AKZ_ST_NMS);
-            launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l,
-                        (float)cfg.detector_threshold, border_margin(lv, cfg), (Candidate*)c->cand.p, cap, d_count);
+            launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l, thr, bm,
+                        (Candidate*)c->cand.p, cap, d_count);
         }
         AKZ_HIP_TRY(hipGetLastError());
         AKZ_TRY(ensure_pinned(c, c->pin[1], (size_t)n * sizeof(uint32_t)));
@@ -832,7 +862,10 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         tab.lv[l].h = plan[l].h;
         tab.lv[l].stride = (uint64_t)plan[l].w * plan[l].h;
     }
-    std::vector<KpParam> params(total_kp);
+    // keypoint parameters are built directly in pinned memory: pageable H2D copies above ~1 MiB make the
+    // runtime pin user pages in place, which serialises concurrent contexts
+    AKZ_TRY(ensure_pinned(c, c->pin[3], std::max<size_t>(1, total_kp) * sizeof(KpParam)));
+    KpParam* params = (KpParam*)c->pin[3].p;
     for (uint32_t img = 0; img < n; ++img)
         for (size_t i = 0; i < hk[img].size(); ++i) {
             const HostKeypoint& k = hk[img][i];
@@ -845,9 +878,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
             p.img = img;
             p._pad[0] = p._pad[1] = p._pad[2] = 0;
         }
-    const uint32_t desc_bytes = (uint32_t)(((6 + 36 + 120) * cfg.descriptor_channels + 7) / 8);
     r->kps.assign(n, {});
-    r->desc.assign(n, {});
     if (total_kp) {
         unsigned long long wmask = 0;
         uint32_t nwin = 0;
@@ -859,22 +890,26 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         AKZ_TRY(ensure_pinned(c, c->pin[1], total_kp * std::max(sizeof(OrientOut), 2 * sizeof(float))));
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* d_oo = (OrientOut*)c->kp_out.p;
-        AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params.data(), total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+        AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params, total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
         launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());
         OrientOut* oo = (OrientOut*)c->pin[1].p;
         AKZ_HIP_TRY(hipMemcpyAsync(oo, d_oo, total_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
         AKZ_HIP_TRY(hipStreamSynchronize(s));
-        std::vector<float> cosi(total_kp * 2);
-        for (uint32_t img = 0; img < n; ++img)
-            for (size_t i = 0; i < hk[img].size(); ++i) {
-                const size_t g = r->desc_off[img] + i;
-                HostKeypoint& k = hk[img][i];
-                k.angle = oo[g].found ? atan2f(oo[g].sum_y, oo[g].sum_x) : 0.0f;  // scale_space_extrema.rs:326
-                cosi[2 * g] = cosf(k.angle);                                       // descriptors.rs:55-56
-                cosi[2 * g + 1] = sinf(k.angle);
+        AKZ_TRY(ensure_pinned(c, c->pin[4], total_kp * 2 * sizeof(float)));
+        float* cosi = (float*)c->pin[4].p;
+        std::vector<float> angles(total_kp);
+        parallel_chunks(total_kp, 4096, 16, [&](size_t b, size_t e) {
+            for (size_t g = b; g < e; ++g) {
+                const float ang = oo[g].found ? atan2f(oo[g].sum_y, oo[g].sum_x) : 0.0f;  // scale_space_extrema.rs:326
+                angles[g] = ang;
+                cosi[2 * g] = cosf(ang);                                                  // descriptors.rs:55-56
+                cosi[2 * g + 1] = sinf(ang);
             }
-        AKZ_HIP_TRY(hipMemcpyAsync(c->cosi.p, cosi.data(), cosi.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        });
+        for (uint32_t img = 0; img < n; ++img)
+            for (size_t i = 0; i < hk[img].size(); ++i) hk[img][i].angle = angles[r->desc_off[img] + i];
+        AKZ_HIP_TRY(hipMemcpyAsync(c->cosi.p, cosi, total_kp * 2 * sizeof(float), hipMemcpyHostToDevice, s));
         const double t_ml0 = now_ms();
         if (c->profiling) c->prof.ms[AKZ_ST_ORIENT] += t_ml0 - t_or0;
         // descriptor rows live in a pooled device block owned by the result
@@ -889,11 +924,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
             uint8_t* rows = (uint8_t*)c->pin[2].p;
             AKZ_HIP_TRY(hipMemcpyAsync(rows, r->d_desc64, total_kp * 64, hipMemcpyDeviceToHost, s));
             AKZ_HIP_TRY(hipStreamSynchronize(s));
-            for (uint32_t img = 0; img < n; ++img) {
-                r->desc[img].resize(hk[img].size() * desc_bytes);
-                for (size_t i = 0; i < hk[img].size(); ++i)
-                    std::memcpy(&r->desc[img][i * desc_bytes], &rows[(r->desc_off[img] + i) * 64], desc_bytes);
-            }
+            r->rows64.assign(rows, rows + total_kp * 64);  // un-padded lazily by akz_result_descriptors
         } else {
             AKZ_HIP_TRY(hipStreamSynchronize(s));
         }
@@ -906,9 +937,10 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
             r->kps[img][i] = akz_keypoint{k.x, k.y, k.response, k.size, k.octave, k.class_id, k.angle, 0};
         }
     }
-    r->k_host.assign(n, 0.0);
-    AKZ_HIP_TRY(hipMemcpyAsync(r->k_host.data(), r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
+    AKZ_HIP_TRY(hipMemcpyAsync(c->pin[5].p, r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     AKZ_HIP_TRY(hipStreamSynchronize(s));
+    r->k_host.assign((const double*)c->pin[5].p, (const double*)c->pin[5].p + n);
     if (c->profiling) {
         resolve_spans(c);
         c->prof.ms[AKZ_ST_TOTAL] += now_ms() - t_call0;
@@ -998,10 +1030,12 @@ int akz_result_descriptors(const akz_result* r, uint64_t img, uint8_t* out) {
         set_error("descriptors were kept on the device (AKZ_NO_HOST_DESCRIPTORS)");
         return AKZ_ERR_INVALID_ARG;
     }
-    const auto& d = r->desc[(size_t)img];
-    if (!d.empty()) {
+    const size_t nk = r->kps[(size_t)img].size();
+    if (nk) {
         if (!out) return AKZ_ERR_INVALID_ARG;
-        std::memcpy(out, d.data(), d.size());
+        const size_t nb = ((6 + 36 + 120) * r->cfg.descriptor_channels + 7) / 8;
+        const uint8_t* rows = r->rows64.data() + r->desc_off[(size_t)img] * 64;
+        for (size_t i = 0; i < nk; ++i) std::memcpy(out + i * nb, rows + i * 64, nb);
     }
     return AKZ_OK;
 }

@@ -122,6 +122,11 @@ void prep_fused(hipStream_t s, const float* prev, bool half, float* lt_out, floa
 bool detector_fused_supported(uint32_t sigma);
 void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n);
+// first + second derivatives, Ldet and the extrema candidates of one level in two launches
+bool detector_nms_fused_supported(uint32_t sigma);
+void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
+                        float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
+                        float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count);
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat);
 void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,

@@ -562,54 +562,78 @@ constexpr PairTable make_pairs() {
 }
 __constant__ PairTable c_pairs = make_pairs();
 
-__global__ void k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi,
-                       unsigned nkp, unsigned channels, uint8_t* __restrict__ desc64) {
-    __shared__ float s_val[3][32];
-    const unsigned kpi = blockIdx.x;
-    if (kpi >= nkp) return;
-    const unsigned lane = threadIdx.x;
-    const KpParam kp = kps[kpi];
-    const float2 cs = cosi[kpi];
+// Four keypoints (waves) per workgroup.  Per grid, the 64 lanes of a wave first gather that grid's
+// samples in parallel (coordinates, three plane reads, rotation) into LDS in the reference's sample
+// order; then one lane per cell adds its samples sequentially in that order (f32 adds are not
+// associative), so the gathers are never on the serial path.
+constexpr int MLDB_KPB = 4;
+constexpr int MLDB_MAXS = 448;  // >= 441 samples of the 3x3 grid
+__global__ void __launch_bounds__(64 * MLDB_KPB)
+k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi, unsigned nkp,
+       unsigned channels, uint8_t* __restrict__ desc64) {
+    __shared__ float s_buf[MLDB_KPB][3][MLDB_MAXS];
+    __shared__ float s_val[MLDB_KPB][3][32];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned kpi = blockIdx.x * MLDB_KPB + wv;
+    const bool live = kpi < nkp;
+    KpParam kp = kps[live ? kpi : 0];
+    const float2 cs = cosi[live ? kpi : 0];
     const LevelPtrs lv = tab.lv[kp.level];
     const size_t ioff = (size_t)kp.img * lv.stride;
     const float* Lt = lv.lt + ioff;
     const float* Lx = lv.lx + ioff;
     const float* Ly = lv.ly + ioff;
-    if (lane < 29) {
-        int step, ng, ci;
-        if (lane < 4) { step = 10; ng = 2; ci = (int)lane; }
-        else if (lane < 13) { step = 7; ng = 3; ci = (int)lane - 4; }
-        else { step = 5; ng = 4; ci = (int)lane - 13; }
-        const int i0 = -10 + (ci / ng) * step, j0 = -10 + (ci % ng) * step;
-        const float co = cs.x, si = cs.y, scale = kp.scale;
-        float di = 0.0f, dx = 0.0f, dy = 0.0f;
-        for (int k = i0; k < i0 + step; ++k)
-            for (int l = j0; l < j0 + step; ++l) {
+    const float co = cs.x, si = cs.y, scale = kp.scale;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int step = g == 0 ? 10 : (g == 1 ? 7 : 5);
+        const int ng = g + 2;
+        const int per_cell = step * step, ncell = ng * ng, nsamp = per_cell * ncell;
+        const int cell_base = g == 0 ? 0 : (g == 1 ? 4 : 13);
+        if (live) {
+            for (int sidx = (int)lane; sidx < nsamp; sidx += 64) {
+                const int ci = sidx / per_cell, t = sidx - ci * per_cell;
+                const int i0 = -10 + (ci / ng) * step, j0 = -10 + (ci % ng) * step;
+                const int k = i0 + t / step, l = j0 + t % step;  // k outer, l inner (descriptors.rs:108-109)
                 const float lf = (float)l + 0.5f, kf = (float)k + 0.5f;
                 const float sample_y = kp.yf + (lf * co * scale + kf * si * scale);
                 const float sample_x = kp.xf + (-lf * si * scale + kf * co * scale);
                 const int y1 = clampi((int)roundf(sample_y), 0, (int)lv.h - 1);
                 const int x1 = clampi((int)roundf(sample_x), 0, (int)lv.w - 1);
                 const size_t p = (size_t)y1 * lv.w + x1;
-                di = di + Lt[p];
+                float v1 = 0.0f, v2 = 0.0f;
+                s_buf[wv][0][sidx] = Lt[p];
                 if (channels > 1) {
                     const float rx = Lx[p], ry = Ly[p];
                     if (channels == 2) {
-                        dx = dx + sqrtf(rx * rx + ry * ry);
+                        v1 = sqrtf(rx * rx + ry * ry);
                     } else {
-                        const float rry = rx * co + ry * si;
-                        const float rrx = -rx * si + ry * co;
-                        dx = dx + rrx;
-                        dy = dy + rry;
+                        v2 = rx * co + ry * si;   // rry -> dy
+                        v1 = -rx * si + ry * co;  // rrx -> dx
                     }
                 }
+                s_buf[wv][1][sidx] = v1;
+                s_buf[wv][2][sidx] = v2;
             }
-        const float ns = (float)(step * step);
-        s_val[0][lane] = di / ns;
-        s_val[1][lane] = dx / ns;
-        s_val[2][lane] = dy / ns;
+        }
+        __syncthreads();
+        if (live && (int)lane < ncell) {
+            const float* b0 = &s_buf[wv][0][lane * per_cell];
+            const float* b1 = &s_buf[wv][1][lane * per_cell];
+            const float* b2 = &s_buf[wv][2][lane * per_cell];
+            float di = 0.0f, dx = 0.0f, dy = 0.0f;
+            for (int t = 0; t < per_cell; ++t) {
+                di = di + b0[t];
+                dx = dx + b1[t];
+                dy = dy + b2[t];
+            }
+            const float ns = (float)per_cell;
+            s_val[wv][0][cell_base + lane] = di / ns;
+            s_val[wv][1][cell_base + lane] = dx / ns;
+            s_val[wv][2][cell_base + lane] = dy / ns;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // bit order: grid 0 (6 pairs), grid 1 (36), grid 2 (120); inside a grid channel-major
     const unsigned seg0 = 6u * channels, seg1 = seg0 + 36u * channels, total = seg1 + 120u * channels;
     unsigned long long words[8];
@@ -623,16 +647,16 @@ __global__ void k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const fl
             else if (b < seg1) { rel = b - seg0; npairs = 36; pbase = 6; }
             else { rel = b - seg1; npairs = 120; pbase = 42; }
             const unsigned pos = rel / npairs, p = rel % npairs;
-            bit = s_val[pos][c_pairs.a[pbase + p]] > s_val[pos][c_pairs.b[pbase + p]];
+            bit = s_val[wv][pos][c_pairs.a[pbase + p]] > s_val[wv][pos][c_pairs.b[pbase + p]];
         }
         words[r] = __ballot(bit);
     }
-    if (lane < 8) {
-        unsigned long long wv = words[0];
+    if (live && lane < 8) {
+        unsigned long long wvw = words[0];
 #pragma unroll
         for (int r = 1; r < 8; ++r)
-            if (lane == (unsigned)r) wv = words[r];
-        reinterpret_cast<unsigned long long*>(desc64 + (size_t)kpi * 64)[lane] = wv;
+            if (lane == (unsigned)r) wvw = words[r];
+        reinterpret_cast<unsigned long long*>(desc64 + (size_t)kpi * 64)[lane] = wvw;
     }
 }
 
@@ -763,7 +787,10 @@ void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_o
 }
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
                uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps) {
-    constexpr int TW = 64, TH = 32, NT = 256;
+#ifndef AKZ_FED_NT
+#define AKZ_FED_NT 512
+#endif
+    constexpr int TW = 64, TH = 32, NT = AKZ_FED_NT;
     FedTaus ht;
     ht.n = (int)n_steps;
     for (uint32_t i = 0; i < 8; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
@@ -812,8 +839,8 @@ void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint3
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64) {
     if (nkp == 0) return;
-    hipLaunchKernelGGL(k_mldb, dim3(nkp), dim3(64), 0, s, lt, d_kp, reinterpret_cast<const float2*>(d_cosi), nkp,
-                       channels, d_desc64);
+    hipLaunchKernelGGL(k_mldb, dim3((nkp + MLDB_KPB - 1) / MLDB_KPB), dim3(64 * MLDB_KPB), 0, s, lt, d_kp,
+                       reinterpret_cast<const float2*>(d_cosi), nkp, channels, d_desc64);
 }
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
            MatchRec* d_out) {

@@ -22,7 +22,10 @@
 namespace akz {
 namespace {
 
-constexpr int TW = 64, TH = 32, NT = 256;
+#ifndef AKZ_STENCIL_NT
+#define AKZ_STENCIL_NT 512
+#endif
+constexpr int TW = 64, TH = 32, NT = AKZ_STENCIL_NT;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -296,6 +299,104 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_deriv2 with the extrema test fused in: Ldet is evaluated on the tile plus a one-pixel ring
+// (kept in LDS, aliased onto the dead Lx window), so the strict 4-neighbour maximum + threshold +
+// descriptor-border test of scale_space_extrema.rs:32-42, :80-87 run without re-reading Ldet from
+// HBM.  Candidates are appended unordered; the host sorts them into raster order.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(NT)
+k_deriv2_nms(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float* __restrict__ lxx_out,
+             float* __restrict__ lyy_out, float* __restrict__ lxy_out, float* __restrict__ ldet_out, int w, int h,
+             float kn, float kwn, float quat, unsigned level, float thr, float border_m,
+             Candidate* __restrict__ cand, unsigned cap, unsigned* __restrict__ count) {
+    constexpr int DW = TW + 2, DH = TH + 2;          // Ldet window, origin (x0-1, y0-1)
+    constexpr int AW = DW, AH = DH + 2 * S;          // H windows,   origin (x0-1, y0-1-S)
+    constexpr int RW = DW + 2 * S, RH = DH + 2 * S;  // input windows, origin (x0-1-S, y0-1-S)
+    static_assert(DW * DH <= RH * RW, "Ldet window must fit in the Lx window it aliases");
+    __shared__ float sX[RH * RW];
+    __shared__ float sY[RH * RW];
+    __shared__ float sA[AH * AW];  // H_main(Lx)
+    __shared__ float sB[AH * AW];  // H_off(Ly)
+    __shared__ float sC[AH * AW];  // H_off(Lx)
+    float* sD = sX;                // Ldet window (valid after the second barrier)
+    const int tid = threadIdx.x;
+    const int x0 = tile_origin(blockIdx.x, TW, w), y0 = tile_origin(blockIdx.y, TH, h);
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    for (int idx = tid; idx < RH * RW; idx += NT) {
+        const int ly = idx / RW, lx = idx - ly * RW;
+        const int gx = x0 - 1 - S + lx, gy = y0 - 1 - S + ly;
+        const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+        const size_t g = base + (size_t)gy * w + gx;
+        sX[idx] = in ? lx_in[g] : 0.0f;
+        sY[idx] = in ? ly_in[g] : 0.0f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < AH * AW; idx += NT) {
+        const int ly = idx / AW, lx = idx - ly * AW;
+        const int x = x0 - 1 + lx, y = y0 - 1 - S + ly;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+            const int o = (cy - (y0 - 1 - S)) * RW + (cx - (x0 - 1 - S));
+            const float xa = sX[o - S], xb = sX[o], xc = sX[o + S];
+            const float ya = sY[o - S], yb = sY[o], yc = sY[o + S];
+            sA[idx] = ((0.0f + kn * xa) + kwn * xb) + kn * xc;
+            sB[idx] = ((0.0f + -1.0f * ya) + 0.0f * yb) + 1.0f * yc;
+            sC[idx] = ((0.0f + -1.0f * xa) + 0.0f * xb) + 1.0f * xc;
+        }
+    }
+    __syncthreads();  // sX / sY are dead from here on
+    for (int idx = tid; idx < DH * DW; idx += NT) {
+        const int ly = idx / DW, lx = idx - ly * DW;
+        const int x = x0 - 1 + lx, y = y0 - 1 + ly;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+            const int o = (cy - (y0 - 1 - S)) * AW + (cx - (x0 - 1));
+            const float lxx = ((0.0f + -1.0f * sA[o - S * AW]) + 0.0f * sA[o]) + 1.0f * sA[o + S * AW];
+            const float lyy = ((0.0f + kn * sB[o - S * AW]) + kwn * sB[o]) + kn * sB[o + S * AW];
+            const float lxy = ((0.0f + kn * sC[o - S * AW]) + kwn * sC[o]) + kn * sC[o + S * AW];
+            const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
+            sD[idx] = det;
+            if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) {
+                const size_t g = base + (size_t)y * w + x;
+                if (lxx_out) lxx_out[g] = lxx;
+                if (lyy_out) lyy_out[g] = lyy;
+                if (lxy_out) lxy_out[g] = lxy;
+                ldet_out[g] = det;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TH * TW; idx += NT) {
+        const int ly = idx / TW, lx = idx - ly * TW;
+        const int x = x0 + lx, y = y0 + ly;
+        // flat range (w+1) .. len-w-2 of the reference loop; x = w-1 never passes the border test
+        if (x < 1 || x > w - 2 || y < 1 || y > h - 2) continue;
+        if ((long)y * w + x >= (long)w * h - w - 1) continue;
+        const int o = (ly + 1) * DW + (lx + 1);
+        const float v = sD[o];
+        if (!(v > thr)) continue;
+        const float xp = sD[o + 1], xm = sD[o - 1], yp = sD[o + DW], ym = sD[o - DW];
+        if (!(v > xp && v > xm && v > ym && v > yp)) continue;
+        const float fx = (float)x, fy = (float)y;
+        const bool is_out = (roundf(fx - border_m) - 1.0f) < 0.0f || (roundf(fx + border_m) + 1.0f) >= (float)w ||
+                            (roundf(fy - border_m) - 1.0f) < 0.0f || (roundf(fy + border_m) + 1.0f) >= (float)h;
+        if (is_out) continue;
+        // tiles shifted inward overlap their neighbour: only the owner of a pixel reports it
+        if (x < (int)blockIdx.x * TW || y < (int)blockIdx.y * TH) continue;
+        const unsigned slot = atomicAdd(count + blockIdx.z, 1u);
+        if (slot < cap) {
+            Candidate c;
+            c.level = level;
+            c.idx = (unsigned)(y * w + x);
+            c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
+            c._pad = 0;
+            cand[(size_t)blockIdx.z * cap + slot] = c;
+        }
+    }
+}
+
 inline dim3 tiles(uint32_t w, uint32_t h, uint32_t n) { return dim3((w + TW - 1) / TW, (h + TH - 1) / TH, n); }
 
 }  // namespace
@@ -336,6 +437,28 @@ void prep_fused(hipStream_t s, const float* prev, bool half, float* lt_out, floa
 }
 
 bool detector_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <= 6; }
+bool detector_nms_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <= 4; }  // LDS <= 64 KB
+
+void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
+                        float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
+                        float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count) {
+    const Taps m = taps_scharr_main(sigma);
+    const float kn = m.wgt[0], kwn = m.wgt[1];
+    const float quat = (float)(sigma * sigma * sigma * sigma);
+    const dim3 g = tiles(w, h, n);
+#define AKZ_DETN(S)                                                                                                \
+    case S:                                                                                                        \
+        hipLaunchKernelGGL((k_deriv1<S>), g, dim3(NT), 0, s, lsmooth, lx, ly, (int)w, (int)h, kn, kwn);            \
+        hipLaunchKernelGGL((k_deriv2_nms<S>), g, dim3(NT), 0, s, (const float*)lx, (const float*)ly, lxx, lyy, lxy, \
+                           ldet_out, (int)w, (int)h, kn, kwn, quat, level, thr, border_m, d_cand, cap_per_img,     \
+                           d_count);                                                                               \
+        break;
+    switch (sigma) {
+        AKZ_DETN(1) AKZ_DETN(2) AKZ_DETN(3) AKZ_DETN(4)
+        default: break;
+    }
+#undef AKZ_DETN
+}
 
 void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n) {

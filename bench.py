@@ -50,8 +50,13 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
+    ap.add_argument("--host-threads", type=int, default=1,
+                    help="contexts per GPU: each is one host thread + one HIP stream working on its part of "
+                         "the shard, so one part's host keypoint logic overlaps the other's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record stage events in the timed region")
+    ap.add_argument("--own-streams", action="store_true", help="streams from akz_stream_create instead of torch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the descriptor gather even with one rank (self-test)")
     args = ap.parse_args()
@@ -75,29 +80,55 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    ctx = A.Context(local_rank, torch.cuda.current_stream().cuda_stream)
     cfg = A.Config()  # Config::default(): 4 octaves x 4 sublevels, 486-bit M-LDB
     W, H, F = args.width, args.height, args.frames
+    T = max(1, min(args.host_threads, F))
 
     # this rank's shard of the world*F frames of a step: image i -> GPU i mod world (weak scaling)
     frames = np.stack([A.synth_frame(W, H, i) for i in A.shard_frames(world * F, rank, world)])
     d_frames = torch.from_numpy(frames).to(dev)
     torch.cuda.synchronize()
 
-    def gather_descriptors(res):
+    # T contexts, each with its own stream and a contiguous part of the shard
+    # (never the legacy null stream when T > 1: it synchronises implicitly with every other stream)
+    if args.own_streams:
+        import ctypes
+        handles = []
+        for _ in range(T):
+            h = ctypes.c_void_p()
+            assert A.lib().akz_stream_create(local_rank, ctypes.byref(h)) == 0
+            handles.append(h.value)
+        ctxs = [A.Context(local_rank, h) for h in handles]
+    else:
+        streams = [torch.cuda.current_stream()] if T == 1 else [torch.cuda.Stream(dev) for _ in range(T)]
+        ctxs = [A.Context(local_rank, st.cuda_stream) for st in streams]
+    ctx = ctxs[0]
+    bounds = [(F * t) // T for t in range(T + 1)]
+    parts = [d_frames[bounds[t]:bounds[t + 1]] for t in range(T)]
+
+    def gather_descriptors(results):
         """The path's exchange step: counts, then padded 64-byte rows over RCCL."""
-        rows = sum(res.counts(i)[1] for i in range(res.num_images))
+        rows = sum(res.counts(i)[1] for res in results for i in range(res.num_images))
         local = torch.empty((rows, 64), dtype=torch.uint8, device=dev)
-        if rows:
-            res.copy_device_descriptors(local)
+        o = 0
+        for res in results:
+            o += res.copy_device_descriptors(local[o:])
+        torch.cuda.synchronize()
         return A.gather_descriptor_rows(local)
 
+    import concurrent.futures
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=T) if T > 1 else None
+
+    def extract_part(t):
+        return ctxs[t].extract_features(parts[t], cfg, keep_all_planes=not args.lean)
+
     def step():
-        res = ctx.extract_features(d_frames, cfg, keep_all_planes=not args.lean)
-        nk = sum(res.counts(i)[1] for i in range(res.num_images))
+        results = list(pool.map(extract_part, range(T))) if pool else [extract_part(0)]
+        nk = sum(res.counts(i)[1] for res in results for i in range(res.num_images))
         if use_dist:
-            gather_descriptors(res)
-        res.close()
+            gather_descriptors(results)
+        for res in results:
+            res.close()
         return nk
 
     def barrier():
@@ -108,8 +139,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.set_profiling(True)
-    ctx.get_profile(reset=True)
+    for c in ctxs:
+        c.set_profiling(not args.no_profile)
+        c.get_profile(reset=True)
     barrier()
     t0 = time.perf_counter()
     nk = 0
@@ -117,8 +149,10 @@ def main():
         nk = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.get_profile(reset=True)
-    ctx.set_profiling(False)
+    profs = [c.get_profile(reset=True) for c in ctxs]
+    for c in ctxs:
+        c.set_profiling(False)
+    prof = {k: sum(p[k] for p in profs) for k in profs[0]}
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -139,7 +173,8 @@ def main():
         "launches": prof["fed_launches"],
         "avg_launch_us": round(prof["fed"] * 1e3 / max(1, prof["fed_launches"]), 2),
         "algorithmic_bytes_per_launch": round(fed_bytes / max(1, prof["fed_launches"])),
-        "note": "all FED launches of the timed steps (levels 1..15, 1920x1080 down to 240x135, batch F)",
+        "note": "all FED launches of the timed steps (levels 1..15, 1920x1080 down to 240x135); time = sum of "
+                "HIP-event spans around each level's FED launches on the launching stream",
     }
 
     # ---- the same kernel on 3840x2160 planes (north-star target point), untimed leg -----------
@@ -188,7 +223,7 @@ def main():
                "seconds": round(dt, 2)}
 
     if rank == 0:
-        stage_ms = {k: round(prof[k] / max(1, prof["calls"]), 3) for k in A.STAGES}
+        stage_ms = {k: round(prof[k] / max(1, args.steps), 3) for k in A.STAGES}
         out = {
             "metric": "Mpix/s through extract_features (4 oct x 4 sub)",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -198,7 +233,7 @@ def main():
             "config": {"workload": f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
                                    f"(4 octaves x 4 sublevels, 486-bit M-LDB), {F} frames per GPU per step "
                                    "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)",
-                       "frames_per_gpu": F, "width": W, "height": H,
+                       "frames_per_gpu": F, "width": W, "height": H, "host_threads_per_gpu": T,
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
                        "exchange": "RCCL all-gather of descriptor rows" if use_dist else "none (1 GPU)",
                        "keypoints_per_step_rank0": nk},

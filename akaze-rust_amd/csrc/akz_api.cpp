@@ -37,6 +37,12 @@ struct akz_ctx {
     DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
                                              // rows, keypoint params, (cos, sin), contrast factors
     std::vector<std::pair<size_t, void*>> slab_pool;  // freed device blocks (pyramid slabs, descriptor rows)
+    // extractions in flight (akz_extract_begin_* / akz_extract_finish)
+    static constexpr int kSlots = 3;
+    DevBuf cand_slot[kSlots], count_slot[kSlots];
+    bool slot_busy[kSlots] = {false, false, false};
+    uint32_t cand_cap_hint = 1u << 15;  // grows to 1.25x the largest candidate count seen
+    hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     // stage profiling (akz_ctx_set_profiling)
     int fed_mode = 1;  // 0: one k_fed_step launch per step, 1: k_fed_fused (<= 8 steps per launch)
     bool profiling = false;
@@ -75,13 +81,18 @@ struct StageTimer {
     }
 };
 static void resolve_spans(akz_ctx* c) {
+    std::vector<akz_ctx::Span> pending;
     for (auto& sp : c->spans) {
+        if (hipEventQuery(sp.b) != hipSuccess) {  // still in flight (a later job): keep for the next call
+            pending.push_back(sp);
+            continue;
+        }
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) c->prof.ms[sp.stage] += (double)ms;
         c->ev_pool.push_back(sp.a);
         c->ev_pool.push_back(sp.b);
     }
-    c->spans.clear();
+    c->spans.swap(pending);
 }
 static double now_ms() {
     timespec ts;
@@ -93,6 +104,7 @@ static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return AKZ_OK;
     if (b.p) {
         AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->aux) AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
         AKZ_HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -196,6 +208,14 @@ int akz_ctx_destroy(akz_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
         if (b.p) (void)hipHostFree(b.p);
+    for (int i = 0; i < akz_ctx::kSlots; ++i) {
+        if (c->cand_slot[i].p) (void)hipFree(c->cand_slot[i].p);
+        if (c->count_slot[i].p) (void)hipFree(c->count_slot[i].p);
+    }
+    if (c->aux) {
+        (void)hipStreamSynchronize(c->aux);
+        (void)hipStreamDestroy(c->aux);
+    }
     for (auto& s : c->slab_pool) (void)hipFree(s.second);
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -633,15 +653,47 @@ static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
 static void slab_release(akz_ctx* c, void* p, size_t bytes) {
     if (c->slab_pool.size() >= 8) {
         (void)hipStreamSynchronize(c->stream);
+        if (c->aux) (void)hipStreamSynchronize(c->aux);
         (void)hipFree(c->slab_pool.front().second);
         c->slab_pool.erase(c->slab_pool.begin());
     }
     c->slab_pool.emplace_back(bytes, p);
 }
 
+// An extraction in flight: everything up to the NMS candidates is enqueued on the context's
+// stream by extract_begin (no host synchronisation); extract_finish picks the candidates up on
+// the auxiliary stream once `nms_done` fires and runs the host keypoint logic, orientation and
+// descriptors.  With two jobs in flight the host phase of one batch runs under the kernels of the
+// next while the scale-space kernels of both stay serialised on one stream.
+struct akz_job {
+    std::unique_ptr<akz_result> r;
+    int slot = -1;            // candidate / counter buffers used by this job
+    uint32_t cap = 0;         // candidate capacity per image
+    hipEvent_t nms_done = nullptr;
+    double t_begin_ms = 0.0;
+};
+
+static void result_release_device(akz_result* r) {
+    if (r->slab) slab_release(r->ctx, r->slab, r->slab_bytes);
+    if (r->d_desc64) slab_release(r->ctx, r->d_desc64, r->desc_block_bytes);
+    r->slab = nullptr;
+    r->d_desc64 = nullptr;
+}
+static void job_destroy(akz_job* j) {
+    if (!j) return;
+    akz_ctx* c = j->r ? j->r->ctx : nullptr;
+    if (c) {
+        (void)hipStreamSynchronize(c->stream);
+        if (j->slot >= 0) c->slot_busy[j->slot] = false;
+        if (j->nms_done) c->ev_pool.push_back(j->nms_done);
+        result_release_device(j->r.get());
+    }
+    delete j;
+}
+
 template <typename T>
-static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
-                        uint32_t flags, akz_result** out) {
+static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
+                         uint32_t flags, akz_job** out) {
     if (!out) return AKZ_ERR_INVALID_ARG;
     *out = nullptr;
     AKZ_TRY(bind(c));
@@ -649,7 +701,19 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         set_error("extract: null image/config or empty batch");
         return AKZ_ERR_INVALID_ARG;
     }
-    std::unique_ptr<akz_result> r(new akz_result);
+    int slot = -1;
+    for (int i = 0; i < akz_ctx::kSlots; ++i)
+        if (!c->slot_busy[i]) {
+            slot = i;
+            break;
+        }
+    if (slot < 0) {
+        set_error("extract_begin: too many extractions in flight on this context (finish one first)");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    std::unique_ptr<akz_job> job(new akz_job);
+    job->r.reset(new akz_result);
+    akz_result* r = job->r.get();
     r->ctx = c;
     r->cfg = *cfgp;
     r->w = w; r->h = h; r->n = n; r->flags = flags;
@@ -690,22 +754,15 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
     r->planes[0][AKZ_LSMOOTH] = r->planes[0][AKZ_LT];
     r->d_k = (double*)((char*)r->slab + k_off);
     auto P = [&](size_t l, int p) { return r->planes[l][p]; };
-    struct SlabGuard {  // return the slab to the pool on any early error exit
+    struct Guard {  // return the device blocks to the pool on any early error exit
         akz_result* r;
         bool armed = true;
-        ~SlabGuard() {
-            if (armed && r->slab) {
-                slab_release(r->ctx, r->slab, r->slab_bytes);
-                r->slab = nullptr;
-            }
-            if (armed && r->d_desc64) {
-                slab_release(r->ctx, r->d_desc64, r->desc_block_bytes);
-                r->d_desc64 = nullptr;
-            }
+        ~Guard() {
+            if (armed) result_release_device(r);
         }
-    } guard{r.get()};
+    } guard{r};
 
-    const double t_call0 = now_ms();
+    job->t_begin_ms = now_ms();
     // ---- level 0: Lt0 = gaussian_blur(img, base_scale_offset); contrast factor (lib.rs:56-69) ----
     {
         StageTimer st(c, AKZ_ST_BLUR0);
@@ -719,7 +776,6 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
 
     // ---- levels 1..L-1 (lib.rs:78-119) ----
     AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(w, h, n)));
-    AKZ_TRY(ensure(c, c->scratch[3], plane_bytes(w, h, n)));
     const std::vector<float> g1 = gaussian_kernel(1.0f, gaussian_kernel_size(1.0f));  // Lsmooth taps (lib.rs:95)
     for (size_t i = 1; i < L; ++i) {
         const LevelPlan& lv = plan[i];
@@ -751,71 +807,111 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         }
     }
 
-    // ---- detector response (detector_response.rs:38-55) + NMS candidates ----
-    uint32_t cap = 1u << 17;
+    // ---- detector response (detector_response.rs:38-55) + extrema candidates ----
+    // one append list for the whole batch (image id stored per candidate): a single D2H later
+    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint, 1u << 14),
+                                                      0x7fffffffull / sizeof(Candidate));
+    AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
+    AKZ_TRY(ensure(c, c->count_slot[slot], 256));
+    uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
+    Candidate* d_cand = (Candidate*)c->cand_slot[slot].p;
+    AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+    for (size_t l = 0; l < L; ++l) {
+        const LevelPlan& lv = plan[l];
+        const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
+        if (launch::detector_nms_fused_supported(lv.det_sigma)) {
+            // derivatives, Ldet and extrema candidates in two launches (no second pass over Ldet)
+            StageTimer st(c, AKZ_ST_DETECTOR);
+            launch::detector_nms_fused(s, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
+                                       P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr,
+                                       bm, d_cand, cap, d_count);
+            continue;
+        }
+        {
+            StageTimer st(c, AKZ_ST_DETECTOR);
+            AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
+                                  P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n));
+        }
+        StageTimer st(c, AKZ_ST_NMS);
+        launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l, thr, bm, d_cand, cap,
+                    d_count);
+    }
+    AKZ_HIP_TRY(hipGetLastError());
+    job->nms_done = StageTimer::get(c);
+    AKZ_HIP_TRY(hipEventRecord(job->nms_done, s));
+    job->slot = slot;
+    job->cap = cap;
+    c->slot_busy[slot] = true;
+    guard.armed = false;
+    *out = job.release();
+    return AKZ_OK;
+}
+
+static int extract_finish(akz_job* jobp, akz_result** out) {
+    if (!jobp || !out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::unique_ptr<akz_job, void (*)(akz_job*)> job(jobp, job_destroy);  // always consumed
+    akz_result* r = job->r.get();
+    akz_ctx* c = r->ctx;
+    AKZ_TRY(bind(c));
+    if (!c->aux) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    hipStream_t s = c->aux;  // everything below waits only for THIS job's kernels
+    const akz_config& cfg = r->cfg;
+    const std::vector<LevelPlan>& plan = r->plan;
+    const size_t L = plan.size();
+    const uint32_t n = r->n;
+    auto P = [&](size_t l, int p) { return r->planes[l][p]; };
+    AKZ_HIP_TRY(hipStreamWaitEvent(s, job->nms_done, 0));
+    const double t_fetch0 = now_ms();
+    double t_counts = t_fetch0;
+
+    // ---- candidates: the list length, then exactly the used part of the list ----
+    uint32_t cap = job->cap;
+    uint32_t* d_count = (uint32_t*)c->count_slot[job->slot].p;
     std::vector<std::vector<Candidate>> cands(n);
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        AKZ_TRY(ensure(c, c->cand, (size_t)n * cap * sizeof(Candidate)));
-        AKZ_TRY(ensure(c, c->small, (size_t)n * sizeof(uint32_t)));
-        uint32_t* d_count = (uint32_t*)c->small.p;
-        AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)n * sizeof(uint32_t), s));
-        for (size_t l = 0; l < L; ++l) {
-            const LevelPlan& lv = plan[l];
-            const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
-            if (attempt == 0 && launch::detector_nms_fused_supported(lv.det_sigma)) {
-                // derivatives, Ldet and extrema candidates in two launches (no second pass over Ldet)
-                StageTimer st(c, AKZ_ST_DETECTOR);
-                launch::detector_nms_fused(s, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY),
-                                           P(l, AKZ_LXX), P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n,
-                                           (uint32_t)l, thr, bm, (Candidate*)c->cand.p, cap, d_count);
-                continue;
-            }
-            if (attempt == 0) {
-                StageTimer st(c, AKZ_ST_DETECTOR);
-                AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
-                                      P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n));
-            }
-            StageTimer st(c, AKZ_ST_NMS);
-            launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l, thr, bm,
-                        (Candidate*)c->cand.p, cap, d_count);
-        }
-        AKZ_HIP_TRY(hipGetLastError());
-        AKZ_TRY(ensure_pinned(c, c->pin[1], (size_t)n * sizeof(uint32_t)));
-        uint32_t* counts = (uint32_t*)c->pin[1].p;
-        AKZ_HIP_TRY(hipMemcpyAsync(counts, d_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    for (int attempt = 0;; ++attempt) {
+        AKZ_TRY(ensure_pinned(c, c->pin[1], 256));
+        uint32_t* total_p = (uint32_t*)c->pin[1].p;
+        AKZ_HIP_TRY(hipMemcpyAsync(total_p, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         AKZ_HIP_TRY(hipStreamSynchronize(s));
-        uint32_t mx = 0;
-        size_t total_c = 0;
-        for (uint32_t img = 0; img < n; ++img) {
-            mx = std::max(mx, counts[img]);
-            total_c += counts[img];
-        }
-        if (mx > cap) {  // overflow: grow and redo the NMS pass only
-            cap = mx + mx / 8;
+        t_counts = now_ms();
+        const uint32_t total_c = *total_p;
+        c->cand_cap_hint = std::max(c->cand_cap_hint, (uint32_t)((uint64_t)total_c * 5 / 4 / n) + 64u);
+        if (total_c > cap) {  // overflow: grow and redo the NMS pass alone on the stored Ldet planes
+            if (attempt >= 3) {
+                set_error("NMS candidate buffer overflow");
+                return AKZ_ERR_OVERFLOW;
+            }
+            cap = total_c + total_c / 8;
+            AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+            AKZ_TRY(ensure(c, c->cand_slot[job->slot], (size_t)cap * sizeof(Candidate)));
+            AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+            for (size_t l = 0; l < L; ++l)
+                launch::nms(s, P(l, AKZ_LDET), plan[l].w, plan[l].h, n, (uint64_t)plan[l].w * plan[l].h, (uint32_t)l,
+                            (float)cfg.detector_threshold, border_margin(plan[l], cfg),
+                            (Candidate*)c->cand_slot[job->slot].p, cap, d_count);
+            AKZ_HIP_TRY(hipGetLastError());
             continue;
         }
         AKZ_TRY(ensure_pinned(c, c->pin[0], std::max<size_t>(1, total_c) * sizeof(Candidate)));
         Candidate* hc = (Candidate*)c->pin[0].p;
-        size_t o = 0;
-        for (uint32_t img = 0; img < n; ++img) {
-            if (counts[img])
-                AKZ_HIP_TRY(hipMemcpyAsync(hc + o, (Candidate*)c->cand.p + (size_t)img * cap,
-                                           (size_t)counts[img] * sizeof(Candidate), hipMemcpyDeviceToHost, s));
-            o += counts[img];
+        if (total_c) {
+            AKZ_HIP_TRY(hipMemcpyAsync(hc, c->cand_slot[job->slot].p, (size_t)total_c * sizeof(Candidate),
+                                       hipMemcpyDeviceToHost, s));
+            AKZ_HIP_TRY(hipStreamSynchronize(s));
         }
-        AKZ_HIP_TRY(hipStreamSynchronize(s));
-        o = 0;
-        for (uint32_t img = 0; img < n; ++img) {
-            cands[img].assign(hc + o, hc + o + counts[img]);
-            o += counts[img];
-        }
-        cap = 0;
+        std::vector<uint32_t> per(n, 0);
+        for (uint32_t i = 0; i < total_c; ++i)
+            if (hc[i].img < n) per[hc[i].img]++;
+        for (uint32_t img = 0; img < n; ++img) cands[img].reserve(per[img]);
+        for (uint32_t i = 0; i < total_c; ++i)
+            if (hc[i].img < n) cands[hc[i].img].push_back(hc[i]);
         break;
     }
-    if (cap != 0) {
-        set_error("NMS candidate buffer overflow");
-        return AKZ_ERR_OVERFLOW;
-    }
+    c->slot_busy[job->slot] = false;  // the candidate buffers may be reused by the next begin
+    job->slot = -1;
+    if (c->profiling) c->prof.ms[AKZ_ST_NMS] += now_ms() - t_counts;  // candidate D2H after the counts arrived
+    (void)t_fetch0;
 
     // ---- host: raster order, sequential cache logic, refinement ----
     const double t_host0 = now_ms();
@@ -919,7 +1015,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
         launch::mldb(s, tab, d_kp, (const float*)c->cosi.p, (uint32_t)total_kp, (uint32_t)cfg.descriptor_channels,
                      r->d_desc64);
         AKZ_HIP_TRY(hipGetLastError());
-        if (!(flags & AKZ_NO_HOST_DESCRIPTORS)) {
+        if (!(r->flags & AKZ_NO_HOST_DESCRIPTORS)) {
             AKZ_TRY(ensure_pinned(c, c->pin[2], total_kp * 64));
             uint8_t* rows = (uint8_t*)c->pin[2].p;
             AKZ_HIP_TRY(hipMemcpyAsync(rows, r->d_desc64, total_kp * 64, hipMemcpyDeviceToHost, s));
@@ -942,14 +1038,27 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
     AKZ_HIP_TRY(hipStreamSynchronize(s));
     r->k_host.assign((const double*)c->pin[5].p, (const double*)c->pin[5].p + n);
     if (c->profiling) {
-        resolve_spans(c);
-        c->prof.ms[AKZ_ST_TOTAL] += now_ms() - t_call0;
+        resolve_spans(c);  // only spans whose events have completed are resolved
+        c->prof.ms[AKZ_ST_TOTAL] += now_ms() - job->t_begin_ms;
         c->prof.calls += 1;
-        c->prof.pixels += (uint64_t)w * h * n;
+        c->prof.pixels += (uint64_t)r->w * r->h * n;
     }
-    guard.armed = false;
-    *out = r.release();
+    c->ev_pool.push_back(job->nms_done);
+    job->nms_done = nullptr;
+    *out = job->r.release();
+    akz_job* raw = job.release();
+    delete raw;
     return AKZ_OK;
+}
+
+template <typename T>
+static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
+                        uint32_t flags, akz_result** out) {
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    akz_job* job = nullptr;
+    AKZ_TRY(extract_begin<T>(c, d_imgs, w, h, n, cfgp, flags, &job));
+    return extract_finish(job, out);
 }
 
 template <typename T>
@@ -963,8 +1072,7 @@ static int extract_host(akz_ctx* c, const T* img, uint32_t w, uint32_t h, const 
     const size_t bytes = (size_t)w * h * sizeof(T);
     AKZ_TRY(ensure(c, c->scratch[4], bytes));
     AKZ_HIP_TRY(hipMemcpyAsync(c->scratch[4].p, img, bytes, hipMemcpyHostToDevice, c->stream));
-    // scratch[4] is also the Lxy temporary of the detector; the frame is consumed by level 0 long
-    // before that on the same stream.
+    // the frame is consumed by level 0 on the same stream before anything else touches scratch[4]
     return extract_impl<T>(c, (const T*)c->scratch[4].p, w, h, 1, cfg, flags, out);
 }
 
@@ -987,11 +1095,25 @@ int akz_extract_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t
     return extract_impl<float>(c, d_imgs, w, h, n, cfg, flags, out);
 }
 
+int akz_extract_begin_device_u8(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                                const akz_config* cfg, uint32_t flags, akz_job** out) {
+    return extract_begin<uint8_t>(c, d_imgs, w, h, n, cfg, flags, out);
+}
+int akz_extract_begin_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                                 const akz_config* cfg, uint32_t flags, akz_job** out) {
+    return extract_begin<float>(c, d_imgs, w, h, n, cfg, flags, out);
+}
+int akz_extract_finish(akz_job* job, akz_result** out) { return extract_finish(job, out); }
+int akz_job_abandon(akz_job* job) {
+    if (job && job->r) (void)hipSetDevice(job->r->ctx->device);
+    job_destroy(job);
+    return AKZ_OK;
+}
+
 int akz_result_free(akz_result* r) {
     if (!r) return AKZ_OK;
     (void)hipSetDevice(r->ctx->device);
-    if (r->d_desc64) slab_release(r->ctx, r->d_desc64, r->desc_block_bytes);
-    if (r->slab) slab_release(r->ctx, r->slab, r->slab_bytes);
+    result_release_device(r);
     delete r;
     return AKZ_OK;
 }
@@ -1055,7 +1177,12 @@ int akz_result_copy_device_descriptors(const akz_result* r, uint8_t* d_dst, uint
         return AKZ_ERR_BUFFER;
     }
     AKZ_TRY(bind(r->ctx));
-    AKZ_HIP_TRY(hipMemcpyAsync(d_dst, r->d_desc64, total * 64, hipMemcpyDeviceToDevice, r->ctx->stream));
+    // on the auxiliary stream and complete on return: the context's main stream may already be busy
+    // with the next batch, and the caller typically hands d_dst to a collective on yet another stream
+    akz_ctx* c = r->ctx;
+    if (!c->aux) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    AKZ_HIP_TRY(hipMemcpyAsync(d_dst, r->d_desc64, total * 64, hipMemcpyDeviceToDevice, c->aux));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
     return AKZ_OK;
 }
 int akz_result_contrast(const akz_result* r, uint64_t img, double* k) {

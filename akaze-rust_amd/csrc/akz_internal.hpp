@@ -60,7 +60,7 @@ struct Candidate {  // one NMS survivor (scale_space_extrema.rs:32-42 + bounds :
     uint32_t level;
     uint32_t idx;  // flat index w*y + x in the level
     float v, xp, xm, yp, ym;
-    uint32_t _pad;
+    uint32_t img;  // image of the batch
 };
 struct KpParam {  // per-keypoint input of the orientation / descriptor kernels
     float xf, yf;     // point / ratio
@@ -126,11 +126,12 @@ void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
 bool detector_nms_fused_supported(uint32_t sigma);
 void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
-                        float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count);
+                        float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat);
+// candidates of all images are appended to ONE list (d_count is a single counter, cap the list capacity)
 void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
-         float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count);
+         float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint32_t nkp,
                  unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out);
 // d_cosi: (cosf(angle), sinf(angle)) per keypoint from the host libm (descriptors.rs:55-56)

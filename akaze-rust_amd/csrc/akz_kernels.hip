@@ -380,8 +380,8 @@ __global__ void k_ldet(const float* __restrict__ lxx, const float* __restrict__ 
 // touch the reference's keypoint cache.  Unordered append; the host sorts into raster order.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void nms_emit(float v, float xp, float xm, float yp, float ym, int x, int y, int w, int h,
-                                         unsigned level, float thr, float border_m, Candidate* __restrict__ cand,
-                                         unsigned cap, unsigned* __restrict__ count) {
+                                         unsigned level, unsigned img, float thr, float border_m,
+                                         Candidate* __restrict__ cand, unsigned cap, unsigned* __restrict__ count) {
     if (!(v > thr)) return;
     if (!(v > xp && v > xm && v > ym && v > yp)) return;
     const float fx = (float)x, fy = (float)y;
@@ -394,7 +394,7 @@ __device__ __forceinline__ void nms_emit(float v, float xp, float xm, float yp, 
         c.level = level;
         c.idx = (unsigned)(y * w + x);
         c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
-        c._pad = 0;
+        c.img = img;
         cand[slot] = c;
     }
 }
@@ -405,8 +405,6 @@ __global__ void k_nms(const float* __restrict__ ldet, int w, int h, size_t img_s
     if (x0 >= w || y < 1 || y >= h - 1) return;
     const float* D = ldet + (size_t)blockIdx.z * img_stride;
     const float* row = D + (size_t)y * w;
-    Candidate* mycand = cand + (size_t)blockIdx.z * cap;
-    unsigned* mycount = count + blockIdx.z;
     float c[6], up[4], dn[4];
     if ((w & 3) == 0 && x0 + 3 < w) {
         const float4 vc = *reinterpret_cast<const float4*>(row + x0);
@@ -434,7 +432,7 @@ __global__ void k_nms(const float* __restrict__ ldet, int w, int h, size_t img_s
         const int x = x0 + e;
         if (x < 1 || x >= w) continue;
         if ((long)y * w + x >= last) continue;
-        nms_emit(c[e + 1], c[e + 2], c[e], dn[e], up[e], x, y, w, h, level, thr, border_m, mycand, cap, mycount);
+        nms_emit(c[e + 1], c[e + 2], c[e], dn[e], up[e], x, y, w, h, level, blockIdx.z, thr, border_m, cand, cap, count);
     }
 }
 
@@ -825,9 +823,9 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
                        (size_t)count, sigma_quat);
 }
 void nms(hipStream_t s, const float* ldet_p, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
-         float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count) {
+         float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
     hipLaunchKernelGGL(k_nms, grid2d((w + 3) / 4, h, n), dim3(BX, BY), 0, s, ldet_p, (int)w, (int)h, (size_t)img_stride,
-                       level, thr, border_m, d_cand, cap_per_img, d_count);
+                       level, thr, border_m, d_cand, cap, d_count);
 }
 void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint32_t nkp,
                  unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out) {

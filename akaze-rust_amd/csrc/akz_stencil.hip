@@ -385,14 +385,14 @@ k_deriv2_nms(const float* __restrict__ lx_in, const float* __restrict__ ly_in, f
         if (is_out) continue;
         // tiles shifted inward overlap their neighbour: only the owner of a pixel reports it
         if (x < (int)blockIdx.x * TW || y < (int)blockIdx.y * TH) continue;
-        const unsigned slot = atomicAdd(count + blockIdx.z, 1u);
+        const unsigned slot = atomicAdd(count, 1u);
         if (slot < cap) {
             Candidate c;
             c.level = level;
             c.idx = (unsigned)(y * w + x);
             c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
-            c._pad = 0;
-            cand[(size_t)blockIdx.z * cap + slot] = c;
+            c.img = blockIdx.z;
+            cand[slot] = c;
         }
     }
 }
@@ -441,7 +441,7 @@ bool detector_nms_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <
 
 void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
-                        float thr, float border_m, Candidate* d_cand, uint32_t cap_per_img, uint32_t* d_count) {
+                        float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
     const Taps m = taps_scharr_main(sigma);
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
@@ -450,8 +450,7 @@ void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, flo
     case S:                                                                                                        \
         hipLaunchKernelGGL((k_deriv1<S>), g, dim3(NT), 0, s, lsmooth, lx, ly, (int)w, (int)h, kn, kwn);            \
         hipLaunchKernelGGL((k_deriv2_nms<S>), g, dim3(NT), 0, s, (const float*)lx, (const float*)ly, lxx, lyy, lxy, \
-                           ldet_out, (int)w, (int)h, kn, kwn, quat, level, thr, border_m, d_cand, cap_per_img,     \
-                           d_count);                                                                               \
+                           ldet_out, (int)w, (int)h, kn, kwn, quat, level, thr, border_m, d_cand, cap, d_count);    \
         break;
     switch (sigma) {
         AKZ_DETN(1) AKZ_DETN(2) AKZ_DETN(3) AKZ_DETN(4)

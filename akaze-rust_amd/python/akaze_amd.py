@@ -130,6 +130,10 @@ def lib():
         "akz_extract_gray_f32": ([vp, vp, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
         "akz_extract_device_u8": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
         "akz_extract_device_f32": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_begin_device_u8": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_begin_device_f32": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_finish": ([vp, C.POINTER(vp)], i32),
+        "akz_job_abandon": ([vp], i32),
         "akz_result_free": ([vp], i32),
         "akz_result_num_images": ([vp, pu64], i32),
         "akz_result_counts": ([vp, u64, pu64, pu64, pu64], i32),
@@ -310,6 +314,23 @@ class Context:
             _check(fn(self._h, C.c_void_p(t.data_ptr()), w, h, n, C.byref(options), flags, C.byref(res)))
         return ExtractResult(self, res)
 
+    def extract_begin(self, frames, options=None, keep_all_planes=True, host_descriptors=True):
+        """First half of extract_features on a torch CUDA tensor [N, H, W] (uint8 or float32): enqueue the
+        GPU work up to the extrema candidates and return a Job without synchronising."""
+        import torch
+        options = options or Config()
+        flags = (AKZ_KEEP_ALL_PLANES if keep_all_planes else 0) | (0 if host_descriptors else AKZ_NO_HOST_DESCRIPTORS)
+        t = frames
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+            raise ValueError("device images must be contiguous torch CUDA tensors")
+        if t.dim() == 2:
+            t = t.unsqueeze(0)
+        n, h, w = t.shape
+        fn = lib().akz_extract_begin_device_u8 if t.dtype == torch.uint8 else lib().akz_extract_begin_device_f32
+        job = C.c_void_p()
+        _check(fn(self._h, C.c_void_p(t.data_ptr()), w, h, n, C.byref(options), flags, C.byref(job)))
+        return Job(self, job, t)
+
     def descriptor_match(self, d0, d1, distance_threshold=10000, lowes_ratio=0.86):
         """ops::feature_matching::descriptor_match (akaze/src/ops/feature_matching.rs:23-94)."""
         d0 = np.ascontiguousarray(d0, np.uint8)
@@ -432,6 +453,25 @@ class Context:
         return outs
 
 
+class Job:
+    """An extraction in flight (akz_extract_begin_*); finish() exactly once."""
+
+    def __init__(self, ctx, handle, frames):
+        self._ctx, self._h, self._frames = ctx, handle, frames  # keep the frames alive
+
+    def finish(self):
+        res = C.c_void_p()
+        h, self._h = self._h, None
+        _check(lib().akz_extract_finish(h, C.byref(res)))
+        self._frames = None
+        return ExtractResult(self._ctx, res)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().akz_job_abandon(self._h)
+            self._h = None
+
+
 class ExtractResult:
     """(Vec<EvolutionStep>, Vec<Keypoint>, Vec<Descriptor>) of akaze::extract_features, per image of the
     batch; EvolutionStep images stay on the GPU and are fetched lazily."""
@@ -548,11 +588,16 @@ def shard_frames(num_frames, rank, world_size):
     return list(range(rank, num_frames, world_size))
 
 
-def gather_descriptor_rows(local_rows, group=None):
+def gather_descriptor_rows(local_rows, group=None, cap_rows=None):
     """All-gather of 64-byte descriptor rows before a cross-image brute-force match: every rank
-    contributes a [n_r, 64] uint8 tensor (any n_r >= 0) and receives ([sum n_r, 64] rows in rank order,
-    counts per rank).  Two collectives: the row counts, then the rows padded to the largest shard.
-    With the "nccl" backend this is RCCL over xGMI; tensors stay on the GPU."""
+    contributes a [n_r, 64] uint8 tensor (any n_r >= 0).  Two collectives: the row counts, then the rows
+    padded to a common capacity.  With the "nccl" backend this is RCCL over xGMI; tensors stay on the GPU.
+
+    cap_rows=None: capacity = the largest shard (needs one host sync to read the counts); returns
+    ([sum n_r, 64] rows in rank order, counts per rank as a list).
+    cap_rows=int:  fixed capacity, NO host synchronisation — returns the padded [world, cap_rows, 64]
+    tensor and the device tensor of counts; rows beyond a rank's count are zero.  Raises if the local
+    shard does not fit."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -561,6 +606,15 @@ def gather_descriptor_rows(local_rows, group=None):
     cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
     cnts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(cnts, cnt, group=group)
+    if cap_rows is not None:
+        if n_local > cap_rows:
+            raise ValueError(f"local shard has {n_local} rows, capacity is {cap_rows}")
+        padded = torch.zeros((cap_rows, 64), dtype=torch.uint8, device=dev)
+        if n_local:
+            padded[:n_local] = local_rows
+        gathered = torch.empty((world * cap_rows, 64), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, padded, group=group)
+        return gathered.view(world, cap_rows, 64), cnts
     counts = [int(v) for v in cnts.tolist()]
     cap = max(max(counts), 1)
     padded = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)

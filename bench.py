@@ -50,13 +50,13 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
-    ap.add_argument("--host-threads", type=int, default=1,
-                    help="contexts per GPU: each is one host thread + one HIP stream working on its part of "
-                         "the shard, so one part's host keypoint logic overlaps the other's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
+    ap.add_argument("--parts", type=int, default=1,
+                    help="batches per step; batches are software-pipelined on ONE stream (begin(batch j+1) is "
+                         "enqueued before finish(batch j)), so the host keypoint phase of a batch runs under the "
+                         "kernels of the next")
     ap.add_argument("--no-profile", action="store_true", help="do not record stage events in the timed region")
-    ap.add_argument("--own-streams", action="store_true", help="streams from akz_stream_create instead of torch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the descriptor gather even with one rank (self-test)")
     args = ap.parse_args()
@@ -82,53 +82,68 @@ def main():
 
     cfg = A.Config()  # Config::default(): 4 octaves x 4 sublevels, 486-bit M-LDB
     W, H, F = args.width, args.height, args.frames
-    T = max(1, min(args.host_threads, F))
 
     # this rank's shard of the world*F frames of a step: image i -> GPU i mod world (weak scaling)
     frames = np.stack([A.synth_frame(W, H, i) for i in A.shard_frames(world * F, rank, world)])
     d_frames = torch.from_numpy(frames).to(dev)
     torch.cuda.synchronize()
 
-    # T contexts, each with its own stream and a contiguous part of the shard
-    # (never the legacy null stream when T > 1: it synchronises implicitly with every other stream)
-    if args.own_streams:
-        import ctypes
-        handles = []
-        for _ in range(T):
-            h = ctypes.c_void_p()
-            assert A.lib().akz_stream_create(local_rank, ctypes.byref(h)) == 0
-            handles.append(h.value)
-        ctxs = [A.Context(local_rank, h) for h in handles]
-    else:
-        streams = [torch.cuda.current_stream()] if T == 1 else [torch.cuda.Stream(dev) for _ in range(T)]
-        ctxs = [A.Context(local_rank, st.cuda_stream) for st in streams]
-    ctx = ctxs[0]
-    bounds = [(F * t) // T for t in range(T + 1)]
-    parts = [d_frames[bounds[t]:bounds[t + 1]] for t in range(T)]
+    # one context = one host thread + one HIP stream + an auxiliary stream.  The stream is a dedicated
+    # non-blocking one, never the legacy null stream: that one synchronises implicitly with every
+    # blocking stream in the process (RCCL has some) and would serialise the pipeline.
+    main = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(main)
+    ctx = A.Context(local_rank, main.cuda_stream)
+    NP = max(1, min(args.parts, F))
+    cut = [(F * i) // NP for i in range(NP + 1)]
+    batches = [d_frames[cut[i]:cut[i + 1]] for i in range(NP)]
+
+    side = torch.cuda.Stream(dev)  # collectives run here so that they never wait for the extraction stream
+
+    gather_ms = [0.0]
+    gather_cap = [0]  # fixed row capacity of the padded all-gather, set from the first step
 
     def gather_descriptors(results):
-        """The path's exchange step: counts, then padded 64-byte rows over RCCL."""
+        """The path's exchange step: counts, then padded 64-byte rows over RCCL (a few MB, latency-bound).
+        Fixed capacity => no host synchronisation: both collectives are only enqueued on the side stream."""
         rows = sum(res.counts(i)[1] for res in results for i in range(res.num_images))
-        local = torch.empty((rows, 64), dtype=torch.uint8, device=dev)
-        o = 0
-        for res in results:
-            o += res.copy_device_descriptors(local[o:])
-        torch.cuda.synchronize()
-        return A.gather_descriptor_rows(local)
+        if rows > gather_cap[0]:
+            gather_cap[0] = 1 << max(10, (rows + rows // 2).bit_length())
+        with torch.cuda.stream(side):
+            local = torch.empty((rows, 64), dtype=torch.uint8, device=dev)
+            side.synchronize()  # the allocation above is the only thing the aux-stream copy must wait for
+            o = 0
+            for res in results:
+                o += res.copy_device_descriptors(local[o:])  # complete on return (aux stream)
+            return A.gather_descriptor_rows(local, cap_rows=gather_cap[0])
 
-    import concurrent.futures
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=T) if T > 1 else None
+    def run_steps(k_steps):
+        """k_steps passes over the shard as one software-pipelined stream of k_steps*NP batches:
+        begin(batch j+1) is enqueued before finish(batch j), also across step boundaries, so the
+        candidate fetch + host keypoint logic of a batch run under the kernels of the next one.
+        Every step's results are complete (and, with N > 1, gathered) before run_steps returns."""
+        nk, prev, done = 0, None, []
 
-    def extract_part(t):
-        return ctxs[t].extract_features(parts[t], cfg, keep_all_planes=not args.lean)
+        def retire(res):
+            nonlocal nk, done
+            done.append(res)
+            if len(done) == NP:  # a whole step has finished
+                nk = sum(r.counts(i)[1] for r in done for i in range(r.num_images))
+                if use_dist:
+                    tg = time.perf_counter()
+                    gather_descriptors(done)
+                    gather_ms[0] += (time.perf_counter() - tg) * 1e3
+                for r in done:
+                    r.close()
+                done = []
 
-    def step():
-        results = list(pool.map(extract_part, range(T))) if pool else [extract_part(0)]
-        nk = sum(res.counts(i)[1] for res in results for i in range(res.num_images))
-        if use_dist:
-            gather_descriptors(results)
-        for res in results:
-            res.close()
+        for _ in range(k_steps):
+            for bt in batches:
+                job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean)
+                if prev is not None:
+                    retire(prev.finish())
+                prev = job
+        retire(prev.finish())
         return nk
 
     def barrier():
@@ -137,22 +152,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    for c in ctxs:
-        c.set_profiling(not args.no_profile)
-        c.get_profile(reset=True)
+    if args.warmup:
+        run_steps(args.warmup)
+    ctx.set_profiling(not args.no_profile)
+    ctx.get_profile(reset=True)
     barrier()
     t0 = time.perf_counter()
-    nk = 0
-    for _ in range(args.steps):
-        nk = step()
+    gather_ms[0] = 0.0
+    nk = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    profs = [c.get_profile(reset=True) for c in ctxs]
-    for c in ctxs:
-        c.set_profiling(False)
-    prof = {k: sum(p[k] for p in profs) for k in profs[0]}
+    prof = ctx.get_profile(reset=True)
+    ctx.set_profiling(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,10 +244,12 @@ def main():
             "config": {"workload": f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
                                    f"(4 octaves x 4 sublevels, 486-bit M-LDB), {F} frames per GPU per step "
                                    "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)",
-                       "frames_per_gpu": F, "width": W, "height": H, "host_threads_per_gpu": T,
+                       "frames_per_gpu": F, "width": W, "height": H, "batches_per_step": NP,
+                       "pipelining": "begin(batch j+1) before finish(batch j) on one stream, across steps",
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
                        "exchange": "RCCL all-gather of descriptor rows" if use_dist else "none (1 GPU)",
-                       "keypoints_per_step_rank0": nk},
+                       "keypoints_per_step_rank0": nk,
+                       "host_ms_in_gather_per_step": round(gather_ms[0] / max(1, args.steps), 3)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,

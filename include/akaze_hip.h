@@ -93,6 +93,7 @@ enum {
 
 typedef struct akz_ctx akz_ctx;
 typedef struct akz_result akz_result;
+typedef struct akz_job akz_job; /* an extraction in flight, see akz_extract_begin_* */
 
 /* ---- library ------------------------------------------------------------------------ */
 int akz_abi_version(void);
@@ -185,6 +186,19 @@ int akz_extract_device_u8(akz_ctx* ctx, const uint8_t* d_imgs, uint32_t w, uint3
 int akz_extract_device_f32(akz_ctx* ctx, const float* d_imgs, uint32_t w, uint32_t h, uint32_t n,
                            const akz_config* cfg, uint32_t flags, akz_result** out);
 
+/* Two-phase form for streaming: begin enqueues the scale space, the detector response and the extrema
+   candidates of a batch on the context's stream and returns WITHOUT synchronising; finish waits for
+   that batch only, runs the host keypoint logic, orientation and descriptors (on an auxiliary stream)
+   and hands the result over.  Begin the next batch before finishing the previous one and the host
+   phase of one runs under the kernels of the other.  Up to 3 jobs in flight per context; a job must be
+   finished (or abandoned) exactly once; the frames must stay valid until then. */
+int akz_extract_begin_device_u8(akz_ctx* ctx, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                                const akz_config* cfg, uint32_t flags, akz_job** out);
+int akz_extract_begin_device_f32(akz_ctx* ctx, const float* d_imgs, uint32_t w, uint32_t h, uint32_t n,
+                                 const akz_config* cfg, uint32_t flags, akz_job** out);
+int akz_extract_finish(akz_job* job, akz_result** out);
+int akz_job_abandon(akz_job* job);
+
 int akz_result_free(akz_result* res);
 int akz_result_num_images(const akz_result* res, uint64_t* n_images);
 /* (Vec<EvolutionStep>.len(), Vec<Keypoint>.len(), Descriptor.vector.len()) of image `img` */
@@ -196,7 +210,8 @@ int akz_result_descriptors(const akz_result* res, uint64_t img, uint8_t* out);
 /* device-resident descriptors, 64-byte rows (desc_bytes used, rest zero), for akz_match_device / RCCL gather */
 int akz_result_device_descriptors(const akz_result* res, uint64_t img, const uint8_t** d_desc, uint64_t* n_keypoints);
 /* D2D copy of ALL images' descriptor rows (image 0 first, 64-byte rows) into a caller buffer of
-   capacity_rows rows, e.g. a torch tensor that is then all-gathered over RCCL. */
+   capacity_rows rows, e.g. a torch tensor that is then all-gathered over RCCL.  Runs on the context's
+   auxiliary stream and is complete on return (it never waits for batches still in flight). */
 int akz_result_copy_device_descriptors(const akz_result* res, uint8_t* d_dst, uint64_t capacity_rows,
                                        uint64_t* rows);
 /* the contrast factor compute_contrast_factor returned for image `img` (lib.rs:64-69) */
@@ -248,7 +263,7 @@ typedef enum akz_stage {
     AKZ_ST_PREP = 2,     /* per level: clone/half_size, Lsmooth, Lflow (lib.rs:80-105)   */
     AKZ_ST_FED = 3,      /* per level: the calculate_step launches (lib.rs:109-118)      */
     AKZ_ST_DETECTOR = 4, /* detector_response (detector_response.rs:38-55)               */
-    AKZ_ST_NMS = 5,      /* extrema candidates + D2H                                     */
+    AKZ_ST_NMS = 5,      /* stand-alone NMS launches (if any) + D2H of the candidate lists */
     AKZ_ST_HOST_KP = 6,  /* host: sort, cache logic, refinement                          */
     AKZ_ST_ORIENT = 7,   /* orientation kernel + host atan2f/cosf/sinf                   */
     AKZ_ST_MLDB = 8,     /* descriptor kernel + D2H                                      */

@@ -28,6 +28,12 @@ def _worker(rank, world, port, counts, out_dir):
         rng = np.random.default_rng(100 + rank)
         local = torch.from_numpy(rng.integers(0, 256, (counts[rank], 64), dtype=np.uint8))
         rows, cnts = A.gather_descriptor_rows(local)
+        # fixed-capacity form (no host sync): same rows once the padding is stripped
+        padded, dcnt = A.gather_descriptor_rows(local, cap_rows=16)
+        assert padded.shape == (world, 16, 64) and [int(v) for v in dcnt.tolist()] == list(cnts)
+        strip = torch.cat([padded[r, :cnts[r]] for r in range(world)], dim=0)
+        assert torch.equal(strip, rows)
+        assert all(int(padded[r, cnts[r]:].sum()) == 0 for r in range(world))
         np.save(os.path.join(out_dir, f"rows_{rank}.npy"), rows.numpy())
         np.save(os.path.join(out_dir, f"cnts_{rank}.npy"), np.array(cnts))
         np.save(os.path.join(out_dir, f"local_{rank}.npy"), local.numpy())

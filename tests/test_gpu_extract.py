@@ -110,3 +110,58 @@ def test_errors(ctx, amd):
     with pytest.raises(amd.AkazeError) as e:
         ctx.extract_features(amd.synth_frame(320, 240, 0), amd.Config(num_sublevels=16))
     assert e.value.status in (-1, -6)
+
+
+def test_begin_finish_pipelined_matches_oracle(ctx, amd, ref):
+    """Two extractions in flight on one context (begin B before finishing A) give the same results as
+    the synchronous call; a third begin is accepted, a fourth is refused until one is finished."""
+    import torch
+    fa = np.stack([amd.synth_frame(480, 270, i) for i in range(2)])
+    fb = np.stack([amd.synth_frame(480, 270, 10 + i) for i in range(3)])
+    ja = ctx.extract_begin(torch.from_numpy(fa).cuda())
+    jb = ctx.extract_begin(torch.from_numpy(fb).cuda())
+    jc = ctx.extract_begin(torch.from_numpy(fa).cuda())
+    with pytest.raises(amd.AkazeError):
+        ctx.extract_begin(torch.from_numpy(fa).cuda())
+    ra = ja.finish()
+    rb = jb.finish()
+    del jc  # abandoned without finishing
+    for i in range(2):
+        assert_same_result(ra, ref.extract(fa[i]), planes=(i == 0), img=i)
+    for i in range(3):
+        assert_same_result(rb, ref.extract(fb[i]), planes=False, img=i)
+    # the context is still usable and its slots are free again
+    r = ctx.extract_features(fa[0])
+    assert_same_result(r, ref.extract(fa[0]), planes=False)
+
+
+def test_baseline_c2_1080p_frame(ctx, amd, ref):
+    """BASELINE.json configs[1]: one 1920x1080 synthetic frame, 4 octaves x 4 sublevels."""
+    frame = amd.synth_frame(1920, 1080, 0)
+    res = ctx.extract_features(frame)
+    rf = ref.extract(frame, threads=8)
+    assert rf.num_levels == 16 and rf.num_keypoints > 1000
+    assert_same_result(res, rf, planes=False)
+    for lvl, pl in ((0, "Lt"), (3, "Lflow"), (7, "Ldet"), (15, "Lt"), (15, "Ldet")):
+        assert np.array_equal(res.plane(lvl, pl), rf.plane(lvl, pl)), (lvl, pl)
+
+
+def test_baseline_c3_4k_pair_extract_and_match(ctx, amd, ref):
+    """BASELINE.json configs[2]: 3840x2160 synthetic pair, extract_features + Hamming match_features;
+    descriptor bytes and match index pairs identical to the oracle."""
+    f0 = amd.synth_frame(3840, 2160, 0)
+    f1 = amd.synth_frame(3840, 2160, 0, shift=(17, 9))
+    r0, r1 = ctx.extract_features(f0, keep_all_planes=False), ctx.extract_features(f1, keep_all_planes=False)
+    q0, q1 = ref.extract(f0, threads=8), ref.extract(f1, threads=8)
+    assert q0.num_keypoints > 4000
+    assert_same_result(r0, q0, planes=False)
+    assert_same_result(r1, q1, planes=False)
+    got = ctx.descriptor_match(r0.descriptors(), r1.descriptors(), 10000, 0.86)
+    exp = ref.descriptor_match(q0.descriptors(), q1.descriptors(), 10000, 0.86)
+    assert len(exp) > 500 and np.array_equal(got, exp)
+    # size-independent properties: matching a set against itself pairs every descriptor with itself at
+    # distance 0 unless it has an exact duplicate (then the ratio test rejects it)
+    d0 = r0.descriptors()
+    self_m = ctx.descriptor_match(d0, d0, 10000, 0.86)
+    assert np.all(self_m["index_0"] == self_m["index_1"]) and np.all(self_m["distance"] == 0)
+    assert len(self_m) >= len(d0) - 2 * (len(d0) - len(np.unique(d0, axis=0)))

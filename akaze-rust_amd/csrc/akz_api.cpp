@@ -44,7 +44,7 @@ struct akz_ctx {
     uint32_t cand_cap_hint = 1u << 15;  // grows to 1.25x the largest candidate count seen
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     // stage profiling (akz_ctx_set_profiling)
-    int fed_mode = 1;  // 0: one k_fed_step launch per step, 1: k_fed_fused (<= 8 steps per launch)
+    int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 1: k_fed_fused, 2: k_fed_own (both <= 8 steps/launch)
     bool profiling = false;
     akz_profile prof{};
     struct Span { int stage; hipEvent_t a, b; };
@@ -448,7 +448,8 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
             float ht[8];
             for (uint32_t j = 0; j < cnt; ++j) ht[j] = 0.5f * (float)taus[done + j];
             done += cnt;
-            launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt);
+            launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt,
+                              c->fed_mode);
         }
         cur = dst;
     }
@@ -1323,10 +1324,10 @@ int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
 }
 int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
-    if (mode != 0 && mode != 1) return AKZ_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
     c->fed_mode = mode;
     return AKZ_OK;
 }
-const char* akz_fed_kernel_name(void) { return "k_fed_fused"; }
+const char* akz_fed_kernel_name(void) { return "k_fed_own"; }
 
 }  // extern "C"

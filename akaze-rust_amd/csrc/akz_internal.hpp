@@ -100,9 +100,10 @@ void flow(hipStream_t s, const float* lsmooth, float* lflow, uint32_t w, uint32_
           uint32_t k_scale_pow);
 void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
               uint32_t h, uint32_t n, float half_tau);
-// n_steps <= 8 explicit steps in one launch (LDS-tiled, temporally fused)
+// n_steps <= 8 explicit steps in one launch (LDS-tiled, temporally fused).  variant 2: register
+// ownership (k_fed_own), variant 1: all values through LDS (k_fed_fused)
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
-               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps);
+               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps, int variant);
 void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
                   unsigned long long* d_hmax_bits);
 void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,

@@ -285,6 +285,206 @@ k_fed_fused(const float* __restrict__ L_in, const float* __restrict__ C, float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// FED with register ownership (the default).  Same tile / halo / bit-exactness argument as
+// k_fed_fused, different data movement: every thread OWNS two vertically adjacent float4 groups
+// of the region for all n fused steps.  Its Lt values stay in registers, the Lflow pair sums
+// (c + c_neighbour), which are constant over the steps of a level, are formed once, left/right
+// neighbours come from the adjacent lanes by shuffle, and LDS is touched only for the row above and
+// the row below (2 x b128 read + 2 x b128 write per thread and step instead of 6 x b128 + 4
+// bank-conflicted b32 reads per group).  All threads run every step on the whole region (stale
+// values further than n - s pixels from the centre are never used), so there is no divergence
+// around the shuffles.
+// ---------------------------------------------------------------------------------------------
+template <int TW, int TH, int HALO, int NT>
+__global__ void __launch_bounds__(NT)
+k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __restrict__ L_out,
+          float* __restrict__ Lstep, int w, int h, FedTaus ht) {
+    constexpr int RW = TW + 2 * HALO;    // region width in pixels (multiple of 4)
+    constexpr int XG = RW / 4;           // float4 group columns
+    constexpr int RP = RW + 8;           // LDS pitch: 4 pad floats on each side
+    constexpr int RHMAX = TH + 2 * HALO;
+    constexpr int PLANE = (RHMAX + 2) * RP;  // one pad row above and below
+    static_assert(XG * (RHMAX / 2) <= NT, "one thread per pair of region rows and group column");
+    __shared__ __attribute__((aligned(16))) float sA[PLANE];
+    __shared__ __attribute__((aligned(16))) float sB[PLANE];
+    const int tid = threadIdx.x;
+    const int n = ht.n;
+    const int RH = TH + 2 * n;  // even
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    const bool vec_ok = (w & 3) == 0;
+    auto lds = [&](int ly, int lx) { return (ly + 1) * RP + 4 + lx; };
+
+    // ---- stage Lt -> sA, Lflow -> sB (out-of-image pixels read as 0 and are never used) ----
+    for (int idx = tid; idx < RH * XG; idx += NT) {
+        const int ly = idx / XG, g = idx - ly * XG;
+        const int gy = y0 - n + ly, gx = x0 - HALO + 4 * g;
+        float4 vl = make_float4(0.f, 0.f, 0.f, 0.f), vc = vl;
+        if (gy >= 0 && gy < h && gx + 3 >= 0 && gx < w) {
+            const float* pl = L_in + base + (size_t)gy * w;
+            const float* pc = C + base + (size_t)gy * w;
+            if (vec_ok && gx >= 0 && gx + 3 < w) {
+                vl = *reinterpret_cast<const float4*>(pl + gx);
+                vc = *reinterpret_cast<const float4*>(pc + gx);
+            } else {
+                float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gx + e >= 0 && gx + e < w) {
+                        a[e] = pl[gx + e];
+                        b[e] = pc[gx + e];
+                    }
+                vl = make_float4(a[0], a[1], a[2], a[3]);
+                vc = make_float4(b[0], b[1], b[2], b[3]);
+            }
+        }
+        *reinterpret_cast<float4*>(&sA[lds(ly, 4 * g)]) = vl;
+        *reinterpret_cast<float4*>(&sB[lds(ly, 4 * g)]) = vc;
+    }
+    __syncthreads();
+
+    // ---- ownership: group column g, region rows 2p and 2p+1 ----
+    const int slot = tid < XG * (RH / 2) ? tid : 0;
+    const bool active = tid < XG * (RH / 2);
+    const int p = slot / XG, g = slot - p * XG;
+    const int lya = 2 * p, lyb = 2 * p + 1;
+    const int oa = lds(lya, 4 * g), ob = oa + RP;
+    const int gx = x0 - HALO + 4 * g, gya = y0 - n + lya, gyb = gya + 1;
+    const unsigned lane = threadIdx.x & 63u;
+
+    float la[4], lb[4];
+    float sxa[5], sxb[5], sN[4], sM[4], sS[4];  // Lflow pair sums, constant over the steps
+    {
+        const float4 va = *reinterpret_cast<const float4*>(sA + oa), vb = *reinterpret_cast<const float4*>(sA + ob);
+        la[0] = va.x; la[1] = va.y; la[2] = va.z; la[3] = va.w;
+        lb[0] = vb.x; lb[1] = vb.y; lb[2] = vb.z; lb[3] = vb.w;
+        const float4 ca4 = *reinterpret_cast<const float4*>(sB + oa), cb4 = *reinterpret_cast<const float4*>(sB + ob);
+        const float4 cn4 = *reinterpret_cast<const float4*>(sB + oa - RP);
+        const float4 cs4 = *reinterpret_cast<const float4*>(sB + ob + RP);
+        const float ca[6] = {sB[oa - 1], ca4.x, ca4.y, ca4.z, ca4.w, sB[oa + 4]};
+        const float cb[6] = {sB[ob - 1], cb4.x, cb4.y, cb4.z, cb4.w, sB[ob + 4]};
+        const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            sxa[i] = ca[i] + ca[i + 1];
+            sxb[i] = cb[i] + cb[i + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sN[i] = cn[i] + ca[i + 1];
+            sM[i] = ca[i + 1] + cb[i + 1];
+            sS[i] = cb[i + 1] + cs[i];
+        }
+    }
+    __syncthreads();  // sB is free from here on: it becomes the second Lt buffer
+
+    // image-border presence flags of the two owned rows (constant over the steps)
+    const bool inner = gya >= 1 && gyb + 1 < h && gx >= 1 && gx + 4 < w;
+    const bool a_hyn = gya > 0, a_hyp = gya + 1 < h, b_hyn = gyb > 0, b_hyp = gyb + 1 < h;
+
+    float* src = sA;
+    float* dst = sB;
+    float sta[4] = {0.f, 0.f, 0.f, 0.f}, stb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 1; s <= n; ++s) {
+        const float half_tau = ht.half_tau[s - 1];
+        // left / right neighbours from the adjacent lanes (same row pair, neighbouring group column);
+        // the first / last lane of a wave and region edges fall back to LDS (edge values are never used)
+        float lwa = __shfl_up(la[3], 1, 64), lwb = __shfl_up(lb[3], 1, 64);
+        float lea = __shfl_down(la[0], 1, 64), leb = __shfl_down(lb[0], 1, 64);
+        if (lane == 0u || g == 0) { lwa = src[oa - 1]; lwb = src[ob - 1]; }
+        if (lane == 63u || g == XG - 1) { lea = src[oa + 4]; leb = src[ob + 4]; }
+        const float4 n4 = *reinterpret_cast<const float4*>(src + oa - RP);
+        const float4 s4 = *reinterpret_cast<const float4*>(src + ob + RP);
+        const float ln[4] = {n4.x, n4.y, n4.z, n4.w}, ls[4] = {s4.x, s4.y, s4.z, s4.w};
+        const float ra[6] = {lwa, la[0], la[1], la[2], la[3], lea};
+        const float rb[6] = {lwb, lb[0], lb[1], lb[2], lb[3], leb};
+        float xfa[5], xfb[5], fN[4], fM[4], fS[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            xfa[i] = sxa[i] * (ra[i + 1] - ra[i]);
+            xfb[i] = sxb[i] * (rb[i + 1] - rb[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fN[i] = sN[i] * (la[i] - ln[i]);  // y_neg of row a
+            fM[i] = sM[i] * (lb[i] - la[i]);  // y_pos of row a == y_neg of row b
+            fS[i] = sS[i] * (ls[i] - lb[i]);  // y_pos of row b
+        }
+        float na[4], nb[4];
+        if (inner) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sta[i] = half_tau * (((xfa[i + 1] - xfa[i]) + fM[i]) - fN[i]);
+                stb[i] = half_tau * (((xfb[i + 1] - xfb[i]) + fS[i]) - fM[i]);
+                na[i] = la[i] + sta[i];
+                nb[i] = lb[i] + stb[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool hxp = gx + i + 1 < w, hxn = gx + i > 0;
+                float ta = hxp ? (hxn ? xfa[i + 1] - xfa[i] : xfa[i + 1]) : -xfa[i];
+                float tb = hxp ? (hxn ? xfb[i + 1] - xfb[i] : xfb[i + 1]) : -xfb[i];
+                if (a_hyp) {
+                    ta = ta + fM[i];
+                    if (a_hyn) ta = ta - fN[i];
+                } else {
+                    ta = ta + sN[i] * (ln[i] - la[i]);  // last image row: y_pos towards y-1 (:104-119)
+                }
+                if (b_hyp) {
+                    tb = tb + fS[i];
+                    if (b_hyn) tb = tb - fM[i];
+                } else {
+                    tb = tb + sM[i] * (la[i] - lb[i]);
+                }
+                sta[i] = half_tau * ta;
+                stb[i] = half_tau * tb;
+                na[i] = la[i] + sta[i];
+                nb[i] = lb[i] + stb[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            la[i] = na[i];
+            lb[i] = nb[i];
+        }
+        if (s < n) {
+            if (active) {
+                *reinterpret_cast<float4*>(dst + oa) = make_float4(la[0], la[1], la[2], la[3]);
+                *reinterpret_cast<float4*>(dst + ob) = make_float4(lb[0], lb[1], lb[2], lb[3]);
+            }
+            __syncthreads();
+            float* t = src;
+            src = dst;
+            dst = t;
+        }
+    }
+
+    // ---- centre groups go straight to HBM ----
+    if (!active || gx < x0 || gx >= x0 + TW) return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ly = r == 0 ? lya : lyb, gy = r == 0 ? gya : gyb;
+        if (ly < n || ly >= n + TH || gy >= h || gx >= w) continue;
+        const float* v = r == 0 ? la : lb;
+        const float* st = r == 0 ? sta : stb;
+        float* po = L_out + base + (size_t)gy * w;
+        float* ps = Lstep ? Lstep + base + (size_t)gy * w : nullptr;
+        if (vec_ok && gx + 3 < w) {
+            *reinterpret_cast<float4*>(po + gx) = make_float4(v[0], v[1], v[2], v[3]);
+            if (ps) *reinterpret_cast<float4*>(ps + gx) = make_float4(st[0], st[1], st[2], st[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (gx + e < w) {
+                    po[gx + e] = v[e];
+                    if (ps) ps[gx + e] = st[e];
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // contrast factor (akaze/src/ops/contrast_factor.rs:18-71) on the sigma-blurred level 0
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double grad_mod(const float* I, int w, int h, int x, int y, Scharr1 sk) {
@@ -784,7 +984,7 @@ void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_o
                        half_tau);
 }
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
-               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps) {
+               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps, int variant) {
 #ifndef AKZ_FED_NT
 #define AKZ_FED_NT 512
 #endif
@@ -793,6 +993,15 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
     ht.n = (int)n_steps;
     for (uint32_t i = 0; i < 8; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
     const dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
+    if (variant == 2) {
+        if (n_steps <= 4)
+            hipLaunchKernelGGL((k_fed_own<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
+                               (int)h, ht);
+        else
+            hipLaunchKernelGGL((k_fed_own<TW, TH, 8, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
+                               (int)h, ht);
+        return;
+    }
     if (n_steps <= 4)
         hipLaunchKernelGGL((k_fed_fused<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
                            (int)h, ht);

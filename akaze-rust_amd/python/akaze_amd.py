@@ -266,7 +266,7 @@ class Context:
         return lib().akz_ctx_stream(self._h)
 
     def set_fed_mode(self, mode):
-        """1 = fused LDS kernel (default), 0 = one launch per step."""
+        """2 = register-ownership fused kernel (default), 1 = LDS-only fused kernel, 0 = one launch per step."""
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
 
     def set_profiling(self, on=True):

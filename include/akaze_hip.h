@@ -279,8 +279,9 @@ typedef struct akz_profile {
 } akz_profile;
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
-/* FED kernel variant: 1 (default) = k_fed_fused, LDS-tiled, up to 8 explicit steps per launch;
-   0 = k_fed_step, one launch per step.  Results are bit-identical. */
+/* FED kernel variant: 2 (default) = k_fed_own, LDS tile + register ownership, up to 8 explicit steps
+   per launch; 1 = k_fed_fused, same tiling with all values through LDS; 0 = k_fed_step, one launch
+   per step.  Results are bit-identical. */
 int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
 /* name of the default FED kernel (for bench / profiles) */
 const char* akz_fed_kernel_name(void);

@@ -114,7 +114,7 @@ FED_TAUS = np.array([0.19623365730888334, 3.7012260958150769, 0.1260408155615697
                      0.9, 0.11, 3.1, 0.6, 0.33])
 
 
-@pytest.mark.parametrize("mode", [1, 0])  # 1: k_fed_fused (LDS, <= 8 steps per launch), 0: k_fed_step
+@pytest.mark.parametrize("mode", [2, 1, 0])  # 2: k_fed_own, 1: k_fed_fused (both <= 8 steps per launch), 0: k_fed_step
 @pytest.mark.parametrize("shape", SHAPES + [(3, 3), (5, 64), (64, 5), (33, 130), (270, 480)])
 @pytest.mark.parametrize("ntau", [1, 2, 4, 5, 8, 13])
 def test_fed_steps_all_border_cases(ctx, ref, shape, ntau, mode):
@@ -131,7 +131,7 @@ def test_fed_steps_all_border_cases(ctx, ref, shape, ntau, mode):
         same(host(d_lt), exp)
         same(host(d_step), step)
     finally:
-        ctx.set_fed_mode(1)
+        ctx.set_fed_mode(2)
 
 
 def test_fed_fused_batch_and_unaligned_width(ctx, ref):

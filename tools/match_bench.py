@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Times the brute-force Hamming matcher (k_match + k_match_compact) on device-resident descriptor rows:
+a 3840x2160 synthetic pair (BASELINE configs[2]) and a gathered multi-frame set."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "akaze-rust_amd", "python"))
+import numpy as np, torch
+import akaze_amd as A
+ctx = A.Context(0, torch.cuda.current_stream().cuda_stream)
+f0, f1 = A.synth_frame(3840, 2160, 0), A.synth_frame(3840, 2160, 0, shift=(17, 9))
+r0, r1 = ctx.extract_features(f0, keep_all_planes=False), ctx.extract_features(f1, keep_all_planes=False)
+def rows(res):
+    n = sum(res.counts(i)[1] for i in range(res.num_images))
+    t = torch.empty((n, 64), dtype=torch.uint8, device="cuda"); res.copy_device_descriptors(t); return t
+d0, d1 = rows(r0), rows(r1)
+def timeit(a, b, reps=20):
+    ctx.descriptor_match_device(a, b); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): out, cnt = ctx.descriptor_match_device(a, b)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    pairs = a.shape[0] * b.shape[0]
+    print(f"n0={a.shape[0]} n1={b.shape[0]} matches={int(cnt.item())} {ms*1e3:.1f} us  {pairs/ms/1e6:.2f} Gpairs/s "
+          f"({pairs*32/ms/1e9:.2f} T xor+popc lane-ops/s)")
+timeit(d0, d1)
+big0 = torch.cat([d0] * 8); big1 = torch.cat([d1] * 8)
+timeit(big0, big1, reps=5)

@@ -1237,8 +1237,10 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
         return AKZ_ERR_INVALID_ARG;
     }
     const uint32_t thr = (uint32_t)std::min<uint64_t>(distance_threshold, 0x7fffffffull);
-    AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * sizeof(MatchRec)));
-    launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, (MatchRec*)c->match_rec.p);
+    const uint32_t chunks = launch::match_num_chunks((uint32_t)n0, (uint32_t)n1);
+    AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * (chunks + 1) * sizeof(MatchRec)));
+    MatchRec* merged = (MatchRec*)c->match_rec.p;
+    launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, merged + n0, merged);
     launch::match_compact(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, thr, lowes_ratio * lowes_ratio,
                           d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());

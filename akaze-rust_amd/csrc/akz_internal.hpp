@@ -138,8 +138,9 @@ void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint3
 // d_cosi: (cosf(angle), sinf(angle)) per keypoint from the host libm (descriptors.rs:55-56)
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64);
+uint32_t match_num_chunks(uint32_t n0, uint32_t n1);
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
-           MatchRec* d_out);
+           MatchRec* d_part, MatchRec* d_out);
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out);
 }  // namespace launch

@@ -864,8 +864,35 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
 // distances with the same update rule give identical (min, second, min_j).
 // ---------------------------------------------------------------------------------------------
 constexpr int MT = 256;  // queries per workgroup == train rows per LDS tile
+
+__device__ __forceinline__ unsigned hamming64(const uint4 (&q)[4], const uint4* __restrict__ row) {
+    unsigned d = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 t = row[k];
+        d += __popc(q[k].x ^ t.x);
+        d += __popc(q[k].y ^ t.y);
+        d += __popc(q[k].z ^ t.z);
+        d += __popc(q[k].w ^ t.w);
+    }
+    return d;
+}
+__device__ __forceinline__ void top2_feed(unsigned d, unsigned j, unsigned& min_d, unsigned& second, unsigned& min_j) {
+    if (d < min_d) {  // the reference's update rule (feature_matching.rs:41-49)
+        second = min_d;
+        min_d = d;
+        min_j = j;
+    } else if (d < second) {
+        second = d;
+    }
+}
+// blockIdx.x: 256 queries (one per thread, in registers); blockIdx.y: a chunk of the train set, staged
+// through LDS 256 rows at a time.  Each workgroup writes the chunk-local (min, second, argmin) of its
+// queries; k_match_merge folds the chunks in index order, which reproduces the sequential scan exactly
+// (top-2 of a union = top-2 of the per-part top-2s; ties keep the lowest index).
 __global__ void __launch_bounds__(MT) k_match(const uint4* __restrict__ d0, unsigned n0, const uint4* __restrict__ d1,
-                                             unsigned n1, unsigned threshold, MatchRec* __restrict__ out) {
+                                             unsigned n1, unsigned chunk_rows, unsigned threshold,
+                                             MatchRec* __restrict__ out) {
     __shared__ uint4 s_tile[MT * 4];
     const unsigned i = blockIdx.x * MT + threadIdx.x;
     uint4 q[4];
@@ -873,32 +900,42 @@ __global__ void __launch_bounds__(MT) k_match(const uint4* __restrict__ d0, unsi
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = live ? d0[(size_t)i * 4 + k] : make_uint4(0, 0, 0, 0);
     unsigned min_d = threshold, second = threshold, min_j = 0;
-    for (unsigned base = 0; base < n1; base += MT) {
-        const unsigned rows = min((unsigned)MT, n1 - base);
+    const unsigned begin = blockIdx.y * chunk_rows, end = min(n1, begin + chunk_rows);
+    for (unsigned base = begin; base < end; base += MT) {
+        const unsigned rows = min((unsigned)MT, end - base);
         __syncthreads();
         for (unsigned e = threadIdx.x; e < rows * 4; e += MT) s_tile[e] = d1[(size_t)base * 4 + e];
         __syncthreads();
-        for (unsigned r = 0; r < rows; ++r) {
-            unsigned d = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint4 t = s_tile[r * 4 + k];
-                d += __popc(q[k].x ^ t.x) + __popc(q[k].y ^ t.y) + __popc(q[k].z ^ t.z) + __popc(q[k].w ^ t.w);
-            }
-            if (d < min_d) {
-                second = min_d;
-                min_d = d;
-                min_j = base + r;
-            } else if (d < second) {
-                second = d;
-            }
+        unsigned r = 0;
+        for (; r + 4 <= rows; r += 4) {  // four independent popcount chains per iteration
+            const unsigned da = hamming64(q, s_tile + (r + 0) * 4), db = hamming64(q, s_tile + (r + 1) * 4);
+            const unsigned dc = hamming64(q, s_tile + (r + 2) * 4), dd = hamming64(q, s_tile + (r + 3) * 4);
+            top2_feed(da, base + r + 0, min_d, second, min_j);
+            top2_feed(db, base + r + 1, min_d, second, min_j);
+            top2_feed(dc, base + r + 2, min_d, second, min_j);
+            top2_feed(dd, base + r + 3, min_d, second, min_j);
         }
+        for (; r < rows; ++r) top2_feed(hamming64(q, s_tile + r * 4), base + r, min_d, second, min_j);
     }
     if (live) {
         MatchRec m;
         m.min_d = min_d; m.second_d = second; m.min_j = min_j; m._pad = 0;
-        out[i] = m;
+        out[(size_t)blockIdx.y * n0 + i] = m;
     }
+}
+__global__ void k_match_merge(const MatchRec* __restrict__ part, unsigned n0, unsigned chunks, unsigned threshold,
+                              MatchRec* __restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n0) return;
+    unsigned min_d = threshold, second = threshold, min_j = 0;
+    for (unsigned c = 0; c < chunks; ++c) {
+        const MatchRec m = part[(size_t)c * n0 + i];
+        top2_feed(m.min_d, m.min_j, min_d, second, min_j);
+        if (m.second_d < second) second = m.second_d;  // second_d >= min_d of its chunk >= min_d
+    }
+    MatchRec o;
+    o.min_d = min_d; o.second_d = second; o.min_j = min_j; o._pad = 0;
+    out[i] = o;
 }
 
 // Lowe ratio^2 + threshold test (feature_matching.rs:61-63) and ordered compaction, one workgroup.
@@ -1049,11 +1086,24 @@ void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float*
     hipLaunchKernelGGL(k_mldb, dim3((nkp + MLDB_KPB - 1) / MLDB_KPB), dim3(64 * MLDB_KPB), 0, s, lt, d_kp,
                        reinterpret_cast<const float2*>(d_cosi), nkp, channels, d_desc64);
 }
+uint32_t match_num_chunks(uint32_t n0, uint32_t n1) {
+    const uint32_t qblocks = (n0 + MT - 1) / MT, tiles = std::max<uint32_t>(1, (n1 + MT - 1) / MT);
+    // enough workgroups to fill 256 CUs several times over, at least 4 LDS tiles per chunk
+    const uint32_t want = std::max<uint32_t>(1, 2048u / std::max<uint32_t>(1, qblocks));
+    return std::max<uint32_t>(1, std::min<uint32_t>({want, (tiles + 3) / 4, 64u}));
+}
+// d_part: chunks * n0 records of scratch; d_out: n0 merged records
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
-           MatchRec* d_out) {
+           MatchRec* d_part, MatchRec* d_out) {
     if (n0 == 0) return;
-    hipLaunchKernelGGL(k_match, dim3((n0 + MT - 1) / MT), dim3(MT), 0, s, reinterpret_cast<const uint4*>(d0), n0,
-                       reinterpret_cast<const uint4*>(d1), n1, threshold, d_out);
+    const uint32_t chunks = match_num_chunks(n0, n1);
+    const uint32_t tiles = std::max<uint32_t>(1, (n1 + MT - 1) / MT);
+    const uint32_t chunk_rows = ((tiles + chunks - 1) / chunks) * MT;
+    hipLaunchKernelGGL(k_match, dim3((n0 + MT - 1) / MT, chunks), dim3(MT), 0, s, reinterpret_cast<const uint4*>(d0), n0,
+                       reinterpret_cast<const uint4*>(d1), n1, chunk_rows, threshold, chunks > 1 ? d_part : d_out);
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_match_merge, dim3((n0 + 255) / 256), dim3(256), 0, s, (const MatchRec*)d_part, n0, chunks,
+                           threshold, d_out);
 }
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out) {

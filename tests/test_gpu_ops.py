@@ -182,3 +182,24 @@ def test_descriptor_match(ctx, ref):
     assert len(ctx.descriptor_match(d0, np.zeros((0, 61), np.uint8))) == 0
     assert np.array_equal(ctx.descriptor_match(d0[:5], d1[:1]), ref.descriptor_match(d0[:5], d1[:1]))
     assert len(ctx.descriptor_match(np.zeros((0, 61), np.uint8), d1)) == 0
+
+
+def test_descriptor_match_chunked_large(ctx, ref):
+    """Train sets large enough to be split over several workgroups (chunk merge) with planted ties across
+    chunk boundaries: result identical to the sequential scan of the oracle."""
+    rng = np.random.default_rng(21)
+    d0 = rng.integers(0, 256, (700, 61), dtype=np.uint8)
+    d1 = rng.integers(0, 256, (9001, 61), dtype=np.uint8)
+    for i in range(0, 700, 2):
+        j = (i * 13 + 5) % 9001
+        d1[j] = d0[i]
+        d1[j, i % 61] ^= 0x3
+    # exact duplicates far apart (different chunks): the tie must resolve to the lower index and the ratio
+    # test must reject them (second == min)
+    d1[100] = d0[1]; d1[8000] = d0[1]
+    d1[4097] = d0[3]; d1[4095] = d0[3]
+    for ratio, thr in ((0.86, 10000), (0.7, 10000), (0.99, 60)):
+        got = ctx.descriptor_match(d0, d1, thr, ratio)
+        exp = ref.descriptor_match(d0, d1, thr, ratio)
+        assert len(exp) > 100 and np.array_equal(got, exp)
+    assert 1 not in got["index_0"] and 3 not in got["index_0"]

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "akz_internal.hpp"
 
@@ -269,6 +270,75 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Quad helpers: the detector kernels process four consecutive pixels of a row per thread.  Window
+// origins and pitches are multiples of 4 floats, so the centre taps are one aligned float4 and
+// vertical taps are aligned float4s of other rows; horizontal taps at -S / +S are assembled from the
+// neighbouring elements.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+// a = p[-S .. -S+3], b = p[0..3], c = p[S .. S+3]; p is 16-byte aligned
+template <int S>
+__device__ __forceinline__ void h_taps(const float* p, float (&a)[4], float (&b)[4], float (&c)[4]) {
+    ld4(p, b);
+    if (S == 4) {
+        ld4(p - 4, a);
+        ld4(p + 4, c);
+    } else if (S == 2) {
+        const float2 l = *reinterpret_cast<const float2*>(p - 2), r = *reinterpret_cast<const float2*>(p + 4);
+        a[0] = l.x; a[1] = l.y; a[2] = b[0]; a[3] = b[1];
+        c[0] = b[2]; c[1] = b[3]; c[2] = r.x; c[3] = r.y;
+    } else if (S == 1) {
+        a[0] = p[-1]; a[1] = b[0]; a[2] = b[1]; a[3] = b[2];
+        c[0] = b[1]; c[1] = b[2]; c[2] = b[3]; c[3] = p[4];
+    } else if (S == 3) {
+        a[0] = p[-3]; a[1] = p[-2]; a[2] = p[-1]; a[3] = b[0];
+        c[0] = b[3]; c[1] = p[4]; c[2] = p[5]; c[3] = p[6];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = p[i - S];
+            c[i] = p[i + S];
+        }
+    }
+}
+// the two separable Scharr taps sets (derivatives.rs:74-101), evaluated left to right from 0.0f
+__device__ __forceinline__ float tap_main(float a, float b, float c, float kn, float kwn) {
+    return ((0.0f + kn * a) + kwn * b) + kn * c;
+}
+__device__ __forceinline__ float tap_off(float a, float b, float c) {
+    return ((0.0f + -1.0f * a) + 0.0f * b) + 1.0f * c;
+}
+// global load of 4 consecutive pixels of row gy starting at gx (zeros outside the image)
+__device__ __forceinline__ float4 load_quad(const float* __restrict__ plane, int gx, int gy, int w, int h, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy < 0 || gy >= h || gx + 3 < 0 || gx >= w) return v;
+    const float* row = plane + (size_t)gy * w;
+    if (vec_ok && gx >= 0 && gx + 3 < w) return *reinterpret_cast<const float4*>(row + gx);
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (gx + e >= 0 && gx + e < w) t[e] = row[gx + e];
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ void store_quad(float* __restrict__ plane, int gx, int gy, int w, bool vec_ok,
+                                           const float (&v)[4]) {
+    float* row = plane + (size_t)gy * w;
+    if (vec_ok && gx + 3 < w) {
+        *reinterpret_cast<float4*>(row + gx) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (gx + e < w) row[gx + e] = v[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Multiscale first derivatives (detector_response.rs:9-10): Lx = V_off(H_main(Ls)),
 // Ly = V_main(H_off(Ls)) at scale S: taps at -S, 0, +S (the zero taps of the dense kernel add
 // +-0 and are skipped).
@@ -277,23 +347,26 @@ template <int S>
 __global__ void __launch_bounds__(NT)
 k_deriv1(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out, int w, int h,
          TileGrid tg, float kn, float kwn) {
-    constexpr int RW = TW + 2 * S, RH = TH + 2 * S;
-    constexpr int NLOAD = (RH * RW + NT - 1) / NT;
-    __shared__ float sIn[RH * RW];
-    __shared__ float sM[RH * TW];
-    __shared__ float sO[RH * TW];
+    constexpr int HX = (S + 3) / 4 * 4;          // x halo of the input window, multiple of 4
+    constexpr int RW = TW + 2 * HX, RH = TH + 2 * S;
+    constexpr int RQ = RW / 4, TQ = TW / 4;      // quads per row
+    constexpr int NLOAD = (RH * RQ + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float sIn[RH * RW];
+    __shared__ __attribute__((aligned(16))) float sM[RH * TW];
+    __shared__ __attribute__((aligned(16))) float sO[RH * TW];
     const int tid = threadIdx.x;
     const int ntiles = tg.tx * tg.ty * tg.n;
-    float regs[NLOAD];
+    const bool vec_ok = (w & 3) == 0;
+    float4 regs[NLOAD];
     auto issue = [&](int tile) {
         const Tile tl = decode_tile(tile, tg, w, h);
         const float* src = ls + (size_t)tl.bz * (size_t)w * (size_t)h;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
-            const int idx = tid + k * NT;
-            const int ly = idx / RW, lx = idx - ly * RW;
-            const int gx = tl.x0 - S + lx, gy = tl.y0 - S + ly;
-            regs[k] = (idx < RH * RW && gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
+            const int q = tid + k * NT;
+            const int ly = q / RQ, qc = q - ly * RQ;
+            regs[k] = q < RH * RQ ? load_quad(src, tl.x0 - HX + 4 * qc, tl.y0 - S + ly, w, h, vec_ok)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     int tile = blockIdx.x;
@@ -301,36 +374,69 @@ k_deriv1(const float* __restrict__ ls, float* __restrict__ lx_out, float* __rest
     for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
-            const int idx = tid + k * NT;
-            if (idx < RH * RW) sIn[idx] = regs[k];
+            const int q = tid + k * NT;
+            if (q < RH * RQ) *reinterpret_cast<float4*>(sIn + 4 * q) = regs[k];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         const Tile tl = decode_tile(tile, tg, w, h);
         const int x0 = tl.x0, y0 = tl.y0;
-        const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
-        for (int idx = tid; idx < RH * TW; idx += NT) {
-            const int ly = idx / TW, lx = idx - ly * TW;
-            const int x = x0 + lx, y = y0 - S + ly;
-            if (x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-                const float* p = sIn + (cy - (y0 - S)) * RW + (cx - (x0 - S));
-                const float a = p[-S], b = p[0], c = p[S];
-                sM[idx] = ((0.0f + kn * a) + kwn * b) + kn * c;
-                sO[idx] = ((0.0f + -1.0f * a) + 0.0f * b) + 1.0f * c;
+        float* lxp = lx_out + (size_t)tl.bz * (size_t)w * (size_t)h;
+        float* lyp = ly_out + (size_t)tl.bz * (size_t)w * (size_t)h;
+        for (int q = tid; q < RH * TQ; q += NT) {  // H passes on window rows y0-S .. y0+TH+S
+            const int ly = q / TQ, qc = q - ly * TQ;
+            const int x = x0 + 4 * qc, y = y0 - S + ly;
+            if (y < 0 || y >= h || x >= w) continue;
+            const int cy = clampi(y, S, h - 1 - S);
+            const float* rowp = sIn + (cy - (y0 - S)) * RW + HX;  // element of column x0
+            float hm[4], ho[4];
+            if (x >= S && x + 3 <= w - 1 - S) {
+                float a[4], b[4], c[4];
+                h_taps<S>(rowp + 4 * qc, a, b, c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hm[i] = tap_main(a[i], b[i], c[i], kn, kwn);
+                    ho[i] = tap_off(a[i], b[i], c[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cx = clampi(x + i, S, w - 1 - S);
+                    const float* p = rowp + (cx - x0);
+                    hm[i] = tap_main(p[-S], p[0], p[S], kn, kwn);
+                    ho[i] = tap_off(p[-S], p[0], p[S]);
+                }
             }
+            st4(sM + 4 * q, hm);
+            st4(sO + 4 * q, ho);
         }
         __syncthreads();
-        for (int idx = tid; idx < TH * TW; idx += NT) {
-            const int ly = idx / TW, lx = idx - ly * TW;
-            const int x = x0 + lx, y = y0 + ly;
-            if (x < w && y < h) {
-                const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-                const int o = (cy - (y0 - S)) * TW + (cx - x0);
-                const size_t g = base + (size_t)y * w + x;
-                lx_out[g] = ((0.0f + -1.0f * sM[o - S * TW]) + 0.0f * sM[o]) + 1.0f * sM[o + S * TW];
-                ly_out[g] = ((0.0f + kn * sO[o - S * TW]) + kwn * sO[o]) + kn * sO[o + S * TW];
+        for (int q = tid; q < TH * TQ; q += NT) {  // V passes on the centre
+            const int ly = q / TQ, qc = q - ly * TQ;
+            const int x = x0 + 4 * qc, y = y0 + ly;
+            if (y >= h || x >= w) continue;
+            const int cy = clampi(y, S, h - 1 - S);
+            const int rowo = (cy - (y0 - S)) * TW;
+            float vx[4], vy[4];
+            if (x >= S && x + 3 <= w - 1 - S) {
+                float m0[4], m1[4], m2[4], o0[4], o1[4], o2[4];
+                ld4(sM + rowo - S * TW + 4 * qc, m0); ld4(sM + rowo + 4 * qc, m1); ld4(sM + rowo + S * TW + 4 * qc, m2);
+                ld4(sO + rowo - S * TW + 4 * qc, o0); ld4(sO + rowo + 4 * qc, o1); ld4(sO + rowo + S * TW + 4 * qc, o2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vx[i] = tap_off(m0[i], m1[i], m2[i]);
+                    vy[i] = tap_main(o0[i], o1[i], o2[i], kn, kwn);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = rowo + (clampi(x + i, S, w - 1 - S) - x0);
+                    vx[i] = tap_off(sM[o - S * TW], sM[o], sM[o + S * TW]);
+                    vy[i] = tap_main(sO[o - S * TW], sO[o], sO[o + S * TW], kn, kwn);
+                }
             }
+            store_quad(lxp, x, y, w, vec_ok, vx);
+            store_quad(lyp, x, y, w, vec_ok, vy);
         }
         __syncthreads();
     }
@@ -344,7 +450,8 @@ k_deriv1(const float* __restrict__ ls, float* __restrict__ lx_out, float* __rest
 // window), so the strict 4-neighbour maximum + threshold + descriptor-border test of
 // scale_space_extrema.rs:32-42, :80-87 run without re-reading Ldet from HBM.  Candidates are appended
 // unordered to one list; the host sorts them into raster order.  The second-derivative planes are
-// written only if the caller keeps them.
+// written only if the caller keeps them.  (One pixel per thread and stage: a float4-per-thread form
+// measured 3-4 % slower here — too few work items per phase for 512 threads.)
 // ---------------------------------------------------------------------------------------------
 struct NmsArgs {
     unsigned level;

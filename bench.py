@@ -56,6 +56,8 @@ def main():
                     help="batches per step; batches are software-pipelined on ONE stream (begin(batch j+1) is "
                          "enqueued before finish(batch j)), so the host keypoint phase of a batch runs under the "
                          "kernels of the next")
+    ap.add_argument("--sync", action="store_true",
+                    help="finish every batch right after beginning it (no software pipelining): clean per-stage times")
     ap.add_argument("--no-profile", action="store_true", help="do not record stage events in the timed region")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the descriptor gather even with one rank (self-test)")
@@ -140,10 +142,14 @@ def main():
         for _ in range(k_steps):
             for bt in batches:
                 job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean)
+                if args.sync:
+                    retire(job.finish())
+                    continue
                 if prev is not None:
                     retire(prev.finish())
                 prev = job
-        retire(prev.finish())
+        if prev is not None:
+            retire(prev.finish())
         return nk
 
     def barrier():

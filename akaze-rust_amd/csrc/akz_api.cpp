@@ -1324,6 +1324,18 @@ int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
     if (reset) c->prof = akz_profile{};
     return AKZ_OK;
 }
+int akz_remove_outliers(const akz_keypoint*, uint64_t, const akz_keypoint*, uint64_t, const akz_match*, uint64_t, uint64_t,
+                        float, float, akz_match*, uint64_t*);
+int akz_match_features(akz_ctx* c, const akz_keypoint* kp0, const uint8_t* d0, uint64_t n0, const akz_keypoint* kp1,
+                       const uint8_t* d1, uint64_t n1, uint64_t desc_bytes, double lowes_ratio, uint64_t ransac_trials,
+                       float ransac_epsilon_inliers, akz_match* out, uint64_t* n_out) {
+    if (!n_out) return AKZ_ERR_INVALID_ARG;
+    std::vector<akz_match> raw((size_t)std::max<uint64_t>(1, n0));
+    uint64_t n_raw = 0;
+    AKZ_TRY(akz_descriptor_match(c, d0, n0, d1, n1, desc_bytes, 10000, lowes_ratio, raw.data(), &n_raw));  // lib.rs:261-266
+    return akz_remove_outliers(kp0, n0, kp1, n1, raw.data(), n_raw, ransac_trials, 0.05f, ransac_epsilon_inliers, out,
+                               n_out);                                                                        // lib.rs:267-274
+}
 int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
     if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;

@@ -1,0 +1,182 @@
+// Host post-filter of match_features: 8-point fundamental matrix + RANSAC
+// (akaze/src/ops/estimate_fundamental_matrix.rs:17-165, called from akaze/src/lib.rs:267-274).
+// a tiny host step after the GPU matcher, outside the GPU path.
+//
+// Reference behaviour reproduced here, quirks included:
+//   * fewer than 8 matches: returned unchanged (:107-110);
+//   * the design matrix row is [x0*x1, x0*y1, x0, y0*x1, y0*y1, y0, x1, y1, 1] (:26-40) with (x0, y0)
+//     from keypoints_0 and (x1, y1) from keypoints_1;
+//   * nalgebra's SVD of the 8x9 matrix yields 8 singular values / right vectors; the model is the
+//     right singular vector of the SMALLEST OF THOSE 8 (:46-53) — not the null vector of the 9x9
+//     problem — accepted only if all 8 singular values exceed epsilon_model (rank == 8, :44);
+//   * F = [[v0, v3, v6], [v1, v4, v7], [v2, v5, v8]] (:55-66); error = |p_r^T F p_l| (:79-83);
+//   * a model replaces the best one only with strictly more inliers; if no trial yields a model the
+//     final model is the zero matrix, whose error is 0, so every match is kept (:112-113, :152-163);
+//   * a fresh `random::default()` source is created inside every trial (:118), so every trial draws
+//     the same 8 indices; only the HashSet iteration order (random per process) differs.
+// Not reproducible bit for bit (and not a parity target): the `random` crate's generator
+// (not in the reference tree; restated from memory as Xorshift128+ seeded [42, 69] — unverified), the
+// HashSet order, and nalgebra's f32 SVD.  Here the sample is taken in ascending index order and the
+// decomposition is a cyclic Jacobi eigen-solve of A^T A in f64.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "akz_internal.hpp"
+
+namespace akz {
+namespace {
+
+struct XorShift128Plus {  // `random::default()` of the random crate 0.12 (restated, unverified)
+    uint64_t s0 = 42, s1 = 69;
+    uint64_t next() {
+        uint64_t x = s0;
+        const uint64_t y = s1;
+        s0 = y;
+        x ^= x << 23;
+        x ^= x >> 17;
+        x ^= y ^ (y >> 26);
+        s1 = x;
+        return x + y;
+    }
+};
+
+// eigen-decomposition of the symmetric 9x9 matrix m (destroyed): eigenvalues in val, vectors in the
+// columns of vec
+void jacobi9(double m[9][9], double val[9], double vec[9][9]) {
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) vec[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < 9; ++i)
+            for (int j = i + 1; j < 9; ++j) off += m[i][j] * m[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 9; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                if (std::fabs(m[p][q]) < 1e-300) continue;
+                const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 9; ++k) {
+                    const double a = m[k][p], b = m[k][q];
+                    m[k][p] = c * a - s * b;
+                    m[k][q] = s * a + c * b;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double a = m[p][k], b = m[q][k];
+                    m[p][k] = c * a - s * b;
+                    m[q][k] = s * a + c * b;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double a = vec[k][p], b = vec[k][q];
+                    vec[k][p] = c * a - s * b;
+                    vec[k][q] = s * a + c * b;
+                }
+            }
+    }
+    for (int i = 0; i < 9; ++i) val[i] = m[i][i];
+}
+
+struct Model {
+    float f[3][3];
+};
+
+// estimate_fundamental_matrix (:17-69)
+bool estimate(const akz_keypoint* k0, const akz_keypoint* k1, const akz_match* sample, float epsilon, Model& out) {
+    float a[8][9];
+    for (int i = 0; i < 8; ++i) {
+        const float x0 = k0[sample[i].index_0].x, y0 = k0[sample[i].index_0].y;
+        const float x1 = k1[sample[i].index_1].x, y1 = k1[sample[i].index_1].y;
+        const float row[9] = {x0 * x1, x0 * y1, x0, y0 * x1, y0 * y1, y0, x1, y1, 1.0f};
+        std::memcpy(a[i], row, sizeof(row));
+    }
+    double m[9][9], val[9], vec[9][9];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) {
+            double s = 0.0;
+            for (int r = 0; r < 8; ++r) s += (double)a[r][i] * (double)a[r][j];
+            m[i][j] = s;
+        }
+    jacobi9(m, val, vec);
+    int order[9];
+    for (int i = 0; i < 9; ++i) order[i] = i;
+    std::sort(order, order + 9, [&](int x, int y) { return val[x] > val[y]; });
+    // the 8 singular values an SVD of the 8x9 matrix returns (the 9th direction is its null space)
+    int rank = 0;
+    for (int i = 0; i < 8; ++i)
+        if ((float)std::sqrt(std::max(0.0, val[order[i]])) > epsilon) ++rank;
+    if (rank != 8) return false;
+    const int mi = order[7];  // smallest of the 8
+    float v[9];
+    for (int i = 0; i < 9; ++i) v[i] = (float)vec[i][mi];
+    const float f[3][3] = {{v[0], v[3], v[6]}, {v[1], v[4], v[7]}, {v[2], v[5], v[8]}};
+    std::memcpy(out.f, f, sizeof(f));
+    return true;
+}
+
+// evaluate_model (:79-83): |p_r^T F p_l|
+float model_error(const Model& md, const akz_keypoint& k0, const akz_keypoint& k1) {
+    const float pr[3] = {k1.x, k1.y, 1.0f}, pl[3] = {k0.x, k0.y, 1.0f};
+    float row[3];
+    for (int j = 0; j < 3; ++j) row[j] = (pr[0] * md.f[0][j] + pr[1] * md.f[1][j]) + pr[2] * md.f[2][j];
+    const float s = (row[0] * pl[0] + row[1] * pl[1]) + row[2] * pl[2];
+    return std::fabs(s);
+}
+
+}  // namespace
+}  // namespace akz
+
+using namespace akz;
+
+extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1,
+                                   uint64_t n1, const akz_match* matches, uint64_t n_matches, uint64_t num_trials,
+                                   float epsilon_model, float epsilon_inlier, akz_match* out, uint64_t* n_out) {
+    if (!n_out || (n_matches && (!matches || !out))) {
+        set_error("remove_outliers: null pointer");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    for (uint64_t i = 0; i < n_matches; ++i)
+        if (matches[i].index_0 >= n0 || matches[i].index_1 >= n1 || !keypoints_0 || !keypoints_1) {
+            set_error("remove_outliers: match index out of range");
+            return AKZ_ERR_INVALID_ARG;
+        }
+    if (n_matches < 8) {  // "Not enough points to do RANSAC."
+        if (n_matches) std::memcpy(out, matches, n_matches * sizeof(akz_match));
+        *n_out = n_matches;
+        return AKZ_OK;
+    }
+    uint64_t max_inliers = 0;
+    Model final_model;
+    std::memset(&final_model, 0, sizeof(final_model));
+    // every trial re-creates the default source, so all trials draw the same 8 indices
+    std::vector<uint64_t> picked;
+    {
+        XorShift128Plus src;
+        while (picked.size() < 8) {
+            const uint64_t j = src.next() % n_matches;
+            if (std::find(picked.begin(), picked.end(), j) == picked.end()) picked.push_back(j);
+        }
+        std::sort(picked.begin(), picked.end());
+    }
+    akz_match sample[8];
+    for (int i = 0; i < 8; ++i) sample[i] = matches[picked[i]];
+    Model model;
+    if (num_trials > 0 && estimate(keypoints_0, keypoints_1, sample, epsilon_model, model)) {
+        uint64_t inl = 0;
+        for (uint64_t i = 0; i < n_matches; ++i)
+            if (model_error(model, keypoints_0[matches[i].index_0], keypoints_1[matches[i].index_1]) < epsilon_inlier)
+                ++inl;
+        if (inl > max_inliers) {
+            max_inliers = inl;
+            final_model = model;
+        }
+    }
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n_matches; ++i)
+        if (model_error(final_model, keypoints_0[matches[i].index_0], keypoints_1[matches[i].index_1]) <
+            epsilon_inlier)
+            out[k++] = matches[i];
+    *n_out = k;
+    return AKZ_OK;
+}

@@ -148,6 +148,12 @@ def lib():
         "akz_descriptor_match": ([vp, vp, u64, vp, u64, u64, u64, f64, vp, pu64], i32),
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
+        "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
+        "akz_match_features": ([vp, vp, vp, u64, vp, vp, u64, u64, f64, u64, C.c_float, vp, pu64], i32),
+        "akz_write_features": ([C.c_char_p, vp, u64, vp, u64], i32),
+        "akz_read_features": ([C.c_char_p, vp, vp, u64, u64, pu64, pu64, pu64], i32),
+        "akz_write_matches": ([C.c_char_p, vp, u64], i32),
+        "akz_read_matches": ([C.c_char_p, vp, u64, pu64], i32),
         "akz_host_select_keypoints": ([u32, u32, C.POINTER(Config), vp, u64, vp, u64, pu64, pu64], i32),
         "akz_ctx_set_profiling": ([vp, i32], i32),
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
@@ -573,10 +579,72 @@ def extract_features(image, options=None, ctx=None):
     return r, r.keypoints(0), r.descriptors(0)
 
 
-def match_features(keypoints_0, descriptors_0, keypoints_1, descriptors_1, lowes_ratio, ctx=None):
-    """Descriptor stage of akaze::match_features (lib.rs:261-266): descriptor_match(d0, d1, 10000, ratio).
-    The RANSAC post-filter (lib.rs:267-274) is host code outside the GPU path."""
-    return (ctx or default_context()).descriptor_match(descriptors_0, descriptors_1, 10000, lowes_ratio)
+def serialize_features_to_file(keypoints, descriptors, path):
+    """akaze_util::serialize_features_to_file (akaze-util/src/lib.rs:17-30): ".json" -> serde_json, else bincode."""
+    k = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE)
+    d = np.ascontiguousarray(descriptors, np.uint8).reshape(len(k), -1) if len(k) else np.zeros((0, 61), np.uint8)
+    _check(lib().akz_write_features(os.fsencode(path), k.ctypes.data_as(C.c_void_p), len(k),
+                                    d.ctypes.data_as(C.c_void_p), d.shape[1]))
+
+
+def deserialize_features_from_file(path):
+    """akaze_util::deserialize_features_from_file (lib.rs:33-42) -> (keypoints, descriptors[n, bytes])."""
+    nk, nd, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _check(lib().akz_read_features(os.fsencode(path), None, None, 0, 0, C.byref(nk), C.byref(nd), C.byref(nb)))
+    k = np.zeros(nk.value, KEYPOINT_DTYPE)
+    d = np.zeros((nd.value, nb.value), np.uint8)
+    _check(lib().akz_read_features(os.fsencode(path), k.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                   max(1, len(k)), max(1, d.size), C.byref(nk), C.byref(nd), C.byref(nb)))
+    return k, d
+
+
+def serialize_matches_to_file(matches, path):
+    """akaze_util::serialize_matches_to_file (lib.rs:44-53)."""
+    m = np.ascontiguousarray(matches, MATCH_DTYPE)
+    _check(lib().akz_write_matches(os.fsencode(path), m.ctypes.data_as(C.c_void_p), len(m)))
+
+
+def deserialize_matches_from_file(path):
+    """akaze_util::deserialize_matches_from_file (lib.rs:56-67)."""
+    n = C.c_uint64()
+    _check(lib().akz_read_matches(os.fsencode(path), None, 0, C.byref(n)))
+    m = np.zeros(n.value, MATCH_DTYPE)
+    _check(lib().akz_read_matches(os.fsencode(path), m.ctypes.data_as(C.c_void_p), max(1, len(m)), C.byref(n)))
+    return m
+
+
+def remove_outliers(keypoints_0, keypoints_1, matches, num_trials, epsilon_model, epsilon_inlier):
+    """ops::estimate_fundamental_matrix::remove_outliers (estimate_fundamental_matrix.rs:99-165); host only."""
+    k0 = np.ascontiguousarray(keypoints_0, KEYPOINT_DTYPE)
+    k1 = np.ascontiguousarray(keypoints_1, KEYPOINT_DTYPE)
+    m = np.ascontiguousarray(matches, MATCH_DTYPE)
+    out = np.zeros(max(1, len(m)), MATCH_DTYPE)
+    n = C.c_uint64()
+    _check(lib().akz_remove_outliers(k0.ctypes.data_as(C.c_void_p), len(k0), k1.ctypes.data_as(C.c_void_p), len(k1),
+                                     m.ctypes.data_as(C.c_void_p), len(m), num_trials, epsilon_model, epsilon_inlier,
+                                     out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def match_features(keypoints_0, descriptors_0, keypoints_1, descriptors_1, lowes_ratio, ransac_trials=None,
+                   ransac_epsilon_inliers=None, ctx=None):
+    """akaze::match_features (lib.rs:252-275): descriptor_match(d0, d1, 10000, ratio) on the GPU, then — when
+    ransac_trials / ransac_epsilon_inliers are given, as in the reference signature — the RANSAC
+    fundamental-matrix filter on the host.  Without them only the (bit-exact) descriptor stage runs."""
+    c = ctx or default_context()
+    if ransac_trials is None:
+        return c.descriptor_match(descriptors_0, descriptors_1, 10000, lowes_ratio)
+    k0 = np.ascontiguousarray(keypoints_0, KEYPOINT_DTYPE)
+    k1 = np.ascontiguousarray(keypoints_1, KEYPOINT_DTYPE)
+    d0 = np.ascontiguousarray(descriptors_0, np.uint8)
+    d1 = np.ascontiguousarray(descriptors_1, np.uint8)
+    out = np.zeros(max(1, len(d0)), MATCH_DTYPE)
+    n = C.c_uint64()
+    _check(lib().akz_match_features(c._h, k0.ctypes.data_as(C.c_void_p), d0.ctypes.data_as(C.c_void_p), len(d0),
+                                    k1.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p), len(d1),
+                                    d0.shape[1] if d0.ndim == 2 else 61, lowes_ratio, ransac_trials,
+                                    ransac_epsilon_inliers, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return out[:n.value].copy()
 
 
 # ------------------------------------------------------------------------------------------

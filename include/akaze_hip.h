@@ -241,6 +241,34 @@ int akz_descriptor_match_device(akz_ctx* ctx, const uint8_t* d_d0, uint64_t n0, 
                                 uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
                                 uint64_t* d_n_out);
 
+/* ---- the rest of match_features (host post-filter) -------------------- */
+/* ops::estimate_fundamental_matrix::remove_outliers — estimate_fundamental_matrix.rs:99-165: 8-point
+   fundamental matrix + RANSAC over the matches; fewer than 8 matches are returned unchanged.  Host code.
+   The reference's own output is not reproducible (HashSet order, `random` crate), so this is a
+   behavioural restatement, not a parity target.  out must hold n_matches entries. */
+int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1, uint64_t n1,
+                        const akz_match* matches, uint64_t n_matches, uint64_t num_trials, float epsilon_model,
+                        float epsilon_inlier, akz_match* out, uint64_t* n_out);
+/* akaze::match_features — akaze/src/lib.rs:252-275: descriptor_match(d0, d1, 10000, lowes_ratio) on the
+   GPU, then remove_outliers(kp0, kp1, matches, ransac_trials, 0.05, ransac_epsilon_inliers) on the host.
+   Descriptors are host arrays of n x desc_bytes; out must hold n0 entries. */
+int akz_match_features(akz_ctx* ctx, const akz_keypoint* keypoints_0, const uint8_t* descriptors_0, uint64_t n0,
+                       const akz_keypoint* keypoints_1, const uint8_t* descriptors_1, uint64_t n1, uint64_t desc_bytes,
+                       double lowes_ratio, uint64_t ransac_trials, float ransac_epsilon_inliers, akz_match* out,
+                       uint64_t* n_out);
+
+/* ---- on-disk formats of akaze-util ---------------------------------- */
+/* akaze_util::{serialize,deserialize}_{features,matches}_{to,from}_file — akaze-util/src/lib.rs:17-67.
+   A path ending in ".json" is serde_json, anything else bincode 1.x (little-endian, u64 lengths), exactly
+   as the reference chooses (lib.rs:24-28).  descriptors: n x desc_bytes.  The read functions return the
+   counts when the output pointers are NULL. */
+int akz_write_features(const char* path, const akz_keypoint* kps, uint64_t n, const uint8_t* descriptors,
+                       uint64_t desc_bytes);
+int akz_read_features(const char* path, akz_keypoint* kps, uint8_t* descriptors, uint64_t cap_keypoints,
+                      uint64_t cap_desc_bytes, uint64_t* n_keypoints, uint64_t* n_descriptors, uint64_t* desc_bytes);
+int akz_write_matches(const char* path, const akz_match* matches, uint64_t n);
+int akz_read_matches(const char* path, akz_match* out, uint64_t cap, uint64_t* n_out);
+
 /* ---- host-only pieces, callable without a GPU --------------------------------------------- */
 /* find_scale_space_extrema's order-dependent cache logic + the sub-pixel step
    (scale_space_extrema.rs:43-178) on NMS candidates {u32 level, u32 flat_idx, f32 v, xp, xm, yp, ym,

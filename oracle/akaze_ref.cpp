@@ -733,6 +733,107 @@ std::vector<Match> descriptor_match(const uint8_t* d0, size_t n0, const uint8_t*
 }
 
 // ---------------------------------------------------------------------------
+// RANSAC post-filter     [ref: akaze/src/ops/estimate_fundamental_matrix.rs:17-165]
+// Not a parity target (HashSet order and the `random` crate make the reference's own output vary);
+// restated to cross-check the product's host implementation with a DIFFERENT decomposition:
+// one-sided (Hestenes) Jacobi on the 9x8 transpose of the design matrix.
+// ---------------------------------------------------------------------------
+struct XorShift128Plus {  // random::default() of the `random` crate 0.12 — restated from memory, unverified
+    uint64_t s0 = 42, s1 = 69;
+    uint64_t next() {
+        uint64_t x = s0;
+        const uint64_t y = s1;
+        s0 = y;
+        x ^= x << 23;
+        x ^= x >> 17;
+        x ^= y ^ (y >> 26);
+        s1 = x;
+        return x + y;
+    }
+};
+static bool estimate_f(const Keypoint* k0, const Keypoint* k1, const Match* sample, float epsilon, float F[3][3]) {
+    double b[9][8];  // B = A^T, columns = the 8 correspondences (:26-40)
+    for (int i = 0; i < 8; ++i) {
+        const float x0 = k0[sample[i].index_0].x, y0 = k0[sample[i].index_0].y;
+        const float x1 = k1[sample[i].index_1].x, y1 = k1[sample[i].index_1].y;
+        const float row[9] = {x0 * x1, x0 * y1, x0, y0 * x1, y0 * y1, y0, x1, y1, 1.0f};
+        for (int r = 0; r < 9; ++r) b[r][i] = double(row[r]);
+    }
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 8; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int r = 0; r < 9; ++r) {
+                    alpha += b[r][p] * b[r][p];
+                    beta += b[r][q] * b[r][q];
+                    gamma += b[r][p] * b[r][q];
+                }
+                off = std::max(off, std::fabs(gamma) / std::sqrt(std::max(alpha * beta, 1e-300)));
+                if (std::fabs(gamma) < 1e-300) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (int r = 0; r < 9; ++r) {
+                    const double bp = b[r][p], bq = b[r][q];
+                    b[r][p] = c * bp - sn * bq;
+                    b[r][q] = sn * bp + c * bq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double sv[8];
+    int rank = 0, mi = 0;
+    for (int i = 0; i < 8; ++i) {
+        double n2 = 0;
+        for (int r = 0; r < 9; ++r) n2 += b[r][i] * b[r][i];
+        sv[i] = std::sqrt(n2);
+        if (float(sv[i]) > epsilon) ++rank;
+        if (sv[i] < sv[mi]) mi = i;
+    }
+    if (rank != 8) return false;  // :44
+    float v[9];
+    for (int r = 0; r < 9; ++r) v[r] = float(b[r][mi] / sv[mi]);
+    const float f[3][3] = {{v[0], v[3], v[6]}, {v[1], v[4], v[7]}, {v[2], v[5], v[8]}};  // :55-66
+    std::memcpy(F, f, sizeof(f));
+    return true;
+}
+static float model_error(const float F[3][3], const Keypoint& k0, const Keypoint& k1) {  // :79-83
+    const float pr[3] = {k1.x, k1.y, 1.0f}, pl[3] = {k0.x, k0.y, 1.0f};
+    float s = 0.0f;
+    for (int j = 0; j < 3; ++j) s += (pr[0] * F[0][j] + pr[1] * F[1][j] + pr[2] * F[2][j]) * pl[j];
+    return std::fabs(s);
+}
+std::vector<Match> remove_outliers(const Keypoint* k0, const Keypoint* k1, const std::vector<Match>& matches,
+                                   size_t num_trials, float eps_model, float eps_inlier) {
+    if (matches.size() < 8) return matches;  // :107-110
+    std::vector<size_t> picked;  // same 8 indices in every trial: the source is re-created per trial (:118)
+    XorShift128Plus src;
+    while (picked.size() < 8) {
+        size_t j = size_t(src.next() % matches.size());
+        if (std::find(picked.begin(), picked.end(), j) == picked.end()) picked.push_back(j);
+    }
+    std::sort(picked.begin(), picked.end());
+    Match sample[8];
+    for (int i = 0; i < 8; ++i) sample[i] = matches[picked[size_t(i)]];
+    float final_model[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, model[3][3];
+    size_t max_inliers = 0;
+    if (num_trials > 0 && estimate_f(k0, k1, sample, eps_model, model)) {
+        size_t inl = 0;
+        for (const Match& m : matches)
+            if (model_error(model, k0[m.index_0], k1[m.index_1]) < eps_inlier) ++inl;
+        if (inl > max_inliers) {
+            max_inliers = inl;
+            std::memcpy(final_model, model, sizeof(model));
+        }
+    }
+    std::vector<Match> out;
+    for (const Match& m : matches)
+        if (model_error(final_model, k0[m.index_0], k1[m.index_1]) < eps_inlier) out.push_back(m);
+    return out;
+}
+
+// ---------------------------------------------------------------------------
 // extract_features on an in-memory luma image [ref: akaze/src/lib.rs:167-194]
 // (image::open + to_luma are upstream of the path and out of scope)
 // ---------------------------------------------------------------------------
@@ -928,6 +1029,20 @@ uint64_t ref_descriptor_match(const uint8_t* d0, uint64_t n0, const uint8_t* d1,
                                      lowes_ratio);
     for (size_t i = 0; i < m.size(); ++i) out[i] = ref_match{m[i].index_0, m[i].index_1, m[i].distance};
     return m.size();
+}
+
+// kp arrays use the ref_keypoint layout; out must hold n_matches entries
+uint64_t ref_remove_outliers(const ref_keypoint* k0, uint64_t n0, const ref_keypoint* k1, uint64_t n1,
+                             const ref_match* matches, uint64_t n_matches, uint64_t num_trials, float eps_model,
+                             float eps_inlier, ref_match* out) {
+    std::vector<akref::Keypoint> a(n0), b(n1);
+    for (uint64_t i = 0; i < n0; ++i) a[i] = akref::Keypoint{k0[i].x, k0[i].y, k0[i].response, k0[i].size, k0[i].octave, k0[i].class_id, k0[i].angle};
+    for (uint64_t i = 0; i < n1; ++i) b[i] = akref::Keypoint{k1[i].x, k1[i].y, k1[i].response, k1[i].size, k1[i].octave, k1[i].class_id, k1[i].angle};
+    std::vector<akref::Match> m(n_matches);
+    for (uint64_t i = 0; i < n_matches; ++i) m[i] = akref::Match{matches[i].index_0, matches[i].index_1, matches[i].distance};
+    auto r = akref::remove_outliers(a.data(), b.data(), m, size_t(num_trials), eps_model, eps_inlier);
+    for (size_t i = 0; i < r.size(); ++i) out[i] = ref_match{r[i].index_0, r[i].index_1, r[i].distance};
+    return r.size();
 }
 
 }  // extern "C"

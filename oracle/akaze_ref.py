@@ -90,6 +90,9 @@ def lib():
     L.ref_descriptor_match.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double,
                                        C.c_void_p]
     L.ref_descriptor_match.restype = C.c_uint64
+    L.ref_remove_outliers.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                      C.c_uint64, C.c_float, C.c_float, C.c_void_p]
+    L.ref_remove_outliers.restype = C.c_uint64
     _lib = L
     return L
 
@@ -278,4 +281,15 @@ def descriptor_match(d0, d1, distance_threshold=10000, lowes_ratio=0.86):
     u8p = C.POINTER(C.c_uint8)
     n = lib().ref_descriptor_match(d0.ctypes.data_as(u8p), n0, d1.ctypes.data_as(u8p), n1, nb, distance_threshold,
                                    lowes_ratio, out.ctypes.data_as(C.c_void_p))
+    return out[:n].copy()
+
+
+def remove_outliers(keypoints_0, keypoints_1, matches, num_trials=1000, eps_model=0.05, eps_inlier=3.0):
+    k0 = np.ascontiguousarray(keypoints_0, KEYPOINT_DTYPE)
+    k1 = np.ascontiguousarray(keypoints_1, KEYPOINT_DTYPE)
+    m = np.ascontiguousarray(matches, MATCH_DTYPE)
+    out = np.zeros(max(1, len(m)), MATCH_DTYPE)
+    n = lib().ref_remove_outliers(k0.ctypes.data_as(C.c_void_p), len(k0), k1.ctypes.data_as(C.c_void_p), len(k1),
+                                  m.ctypes.data_as(C.c_void_p), len(m), num_trials, eps_model, eps_inlier,
+                                  out.ctypes.data_as(C.c_void_p))
     return out[:n].copy()

@@ -165,3 +165,18 @@ def test_baseline_c3_4k_pair_extract_and_match(ctx, amd, ref):
     self_m = ctx.descriptor_match(d0, d0, 10000, 0.86)
     assert np.all(self_m["index_0"] == self_m["index_1"]) and np.all(self_m["distance"] == 0)
     assert len(self_m) >= len(d0) - 2 * (len(d0) - len(np.unique(d0, axis=0)))
+
+
+def test_match_features_full_dropin(ctx, amd, ref):
+    """akaze::match_features with its reference signature (lib.rs:252-260): GPU descriptor_match followed by
+    the host RANSAC filter, against the oracle's descriptor_match + remove_outliers."""
+    f0 = amd.synth_frame(960, 540, 11)
+    f1 = amd.synth_frame(960, 540, 11, shift=(17, 9))
+    r0, r1 = ctx.extract_features(f0, keep_all_planes=False), ctx.extract_features(f1, keep_all_planes=False)
+    q0, q1 = ref.extract(f0), ref.extract(f1)
+    got = amd.match_features(r0.keypoints(), r0.descriptors(), r1.keypoints(), r1.descriptors(), 0.86, 1000, 3.0,
+                             ctx=ctx)
+    raw = ref.descriptor_match(q0.descriptors(), q1.descriptors(), 10000, 0.86)
+    exp = ref.remove_outliers(q0.keypoints(), q1.keypoints(), raw, 1000, 0.05, 3.0)
+    assert len(raw) >= 8 and np.array_equal(got, exp)
+    assert set(got["index_0"].tolist()) <= set(raw["index_0"].tolist())

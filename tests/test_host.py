@@ -183,3 +183,114 @@ def test_host_keypoint_logic_matches_oracle(amd, ref, w, h, idx, kw):
     assert n_ext == r.num_extrema and len(kps) == len(rk)
     for f in ("x", "y", "response", "size", "octave", "class_id"):
         assert np.array_equal(kps[f], rk[f]), f
+
+
+def _two_view_scene(n, n_outliers, seed):
+    """n points seen by two cameras (a translation + small rotation): exact epipolar geometry, plus
+    n_outliers wrong correspondences at the END of the match list."""
+    import akaze_amd
+    rng = np.random.default_rng(seed)
+    X = np.c_[rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(6, 14, n)]
+    f, cx, cy = 900.0, 960.0, 540.0
+    th = 0.05
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = np.array([0.6, 0.05, 0.1])
+    def proj(P):
+        return np.c_[f * P[:, 0] / P[:, 2] + cx, f * P[:, 1] / P[:, 2] + cy]
+    p0, p1 = proj(X), proj(X @ R.T + t)
+    k0 = np.zeros(n, akaze_amd.KEYPOINT_DTYPE); k1 = np.zeros(n, akaze_amd.KEYPOINT_DTYPE)
+    k0["x"], k0["y"] = p0[:, 0], p0[:, 1]
+    k1["x"], k1["y"] = p1[:, 0], p1[:, 1]
+    m = np.zeros(n, akaze_amd.MATCH_DTYPE)
+    m["index_0"] = np.arange(n); m["index_1"] = np.arange(n); m["distance"] = rng.integers(0, 80, n)
+    if n_outliers:
+        wrong = np.arange(n - n_outliers, n)
+        m["index_1"][wrong] = (wrong * 7 + 3) % (n - n_outliers)
+    return k0, k1, m
+
+
+def test_remove_outliers_host(amd, ref):
+    """remove_outliers (estimate_fundamental_matrix.rs:99-165) on the host: behavioural checks and
+    agreement with the oracle's restatement (different SVD method)."""
+    k0, k1, m = _two_view_scene(120, 0, 1)
+    # fewer than 8 matches: unchanged (:107-110)
+    assert np.array_equal(amd.remove_outliers(k0, k1, m[:7], 100, 0.05, 3.0), m[:7])
+    # exact geometry, no outliers.  The reference takes the right singular vector of the smallest of the
+    # EIGHT singular values nalgebra returns for the 8x9 system (:46-53) — not its null vector — so even
+    # perfect correspondences are not all inliers of "the model"; product and oracle must agree on that.
+    got = amd.remove_outliers(k0, k1, m, 1000, 0.05, 0.5)
+    assert np.array_equal(got, ref.remove_outliers(k0, k1, m, 1000, 0.05, 0.5)) and 8 <= len(got) <= len(m)
+    # a huge inlier tolerance keeps everything, zero trials leave the zero model, which also keeps everything
+    assert np.array_equal(amd.remove_outliers(k0, k1, m, 1000, 0.05, 1e9), m)
+    assert np.array_equal(amd.remove_outliers(k0, k1, m, 0, 0.05, 0.5), m)
+    # with wrong correspondences: output is an ordered subset that keeps the true matches and agrees with the oracle
+    k0, k1, m = _two_view_scene(200, 40, 2)
+    got = amd.remove_outliers(k0, k1, m, 1000, 0.05, 0.5)
+    exp = ref.remove_outliers(k0, k1, m, 1000, 0.05, 0.5)
+    assert np.array_equal(got, exp)
+    assert np.all(np.diff(got["index_0"].astype(np.int64)) > 0)
+    assert len(got) < len(m) and set(got["index_0"].tolist()) <= set(m["index_0"].tolist())
+    # degenerate sample (all points identical): rank < 8 -> no model -> zero matrix -> every match kept (:112, :152-163)
+    kz = np.zeros(20, amd.KEYPOINT_DTYPE); kz["x"] = 5; kz["y"] = 7
+    mz = np.zeros(20, amd.MATCH_DTYPE); mz["index_0"] = np.arange(20); mz["index_1"] = np.arange(20)
+    assert np.array_equal(amd.remove_outliers(kz, kz, mz, 10, 0.05, 3.0), mz)
+    # index validation instead of the reference's slice panic
+    bad = m.copy(); bad["index_1"][0] = 10**6
+    with pytest.raises(amd.AkazeError):
+        amd.remove_outliers(k0, k1, bad, 10, 0.05, 3.0)
+
+
+def test_features_and_matches_file_formats(amd, tmp_path):
+    """akaze-util's on-disk formats (akaze-util/src/lib.rs:10-67): bincode 1.x bytes checked against a
+    hand-built struct.pack image, serde_json schema checked with the json module, both round-trip."""
+    import json
+    import struct
+    kps = np.zeros(3, amd.KEYPOINT_DTYPE)
+    kps["x"] = [10.5, 699.0, 0.1]; kps["y"] = [20.25, 29.000069, 1e-7]; kps["response"] = [0.00101189, 0.5, 3.0]
+    kps["size"] = 2.4; kps["octave"] = [0, 1, 3]; kps["class_id"] = [0, 5, 15]; kps["angle"] = [2.2353425, -0.5, 0.0]
+    desc = np.random.default_rng(0).integers(0, 256, (3, 61), dtype=np.uint8)
+    p = str(tmp_path / "features.cbor")  # the reference's CLIs use this suffix for bincode (lib.rs:24-28)
+    amd.serialize_features_to_file(kps, desc, p)
+    exp = struct.pack("<Q", 3)
+    for k in kps:
+        exp += struct.pack("<ffffQQf", k["x"], k["y"], k["response"], k["size"], k["octave"], k["class_id"], k["angle"])
+    exp += struct.pack("<Q", 3)
+    for d in desc:
+        exp += struct.pack("<Q", 61) + d.tobytes()
+    assert open(p, "rb").read() == exp and len(exp) == 8 + 3 * 36 + 8 + 3 * (8 + 61)
+    k2, d2 = amd.deserialize_features_from_file(p)
+    assert k2.tobytes() == kps.tobytes() and np.array_equal(d2, desc)
+    # JSON: serde field names and nesting; floats round-trip exactly through the shortest representation
+    pj = str(tmp_path / "features.json")
+    amd.serialize_features_to_file(kps, desc, pj)
+    doc = json.load(open(pj))
+    assert list(doc) == ["keypoints", "descriptors"]
+    assert list(doc["keypoints"][0]) == ["point", "response", "size", "octave", "class_id", "angle"]
+    assert doc["keypoints"][1]["class_id"] == 5 and doc["descriptors"][2]["vector"] == desc[2].tolist()
+    assert np.float32(doc["keypoints"][2]["point"][1]) == np.float32(1e-7)
+    k3, d3 = amd.deserialize_features_from_file(pj)
+    assert k3.tobytes() == kps.tobytes() and np.array_equal(d3, desc)
+    # a file as serde_json would print it (different whitespace / field order must not matter)
+    open(pj, "w").write('{ "descriptors": [ {"vector": [1, 2, 255]} ],\n "keypoints": [ {"angle": 0.5, "class_id": 2, '
+                        '"octave": 1, "size": 4.8, "response": 0.25, "point": [3.0, 4.5]} ] }')
+    k4, d4 = amd.deserialize_features_from_file(pj)
+    assert (k4["x"][0], k4["y"][0], k4["class_id"][0], k4["octave"][0]) == (3.0, 4.5, 2, 1) and d4.tolist() == [[1, 2, 255]]
+    # matches
+    m = np.zeros(2, amd.MATCH_DTYPE)
+    m["index_0"] = [1, 7]; m["index_1"] = [3, 2**40]; m["distance"] = [17.0, 0.0]
+    pm = str(tmp_path / "matches.bin")
+    amd.serialize_matches_to_file(m, pm)
+    assert open(pm, "rb").read() == struct.pack("<Q", 2) + struct.pack("<QQd", 1, 3, 17.0) + struct.pack("<QQd", 7, 2**40, 0.0)
+    assert np.array_equal(amd.deserialize_matches_from_file(pm), m)
+    pmj = str(tmp_path / "matches.json")
+    amd.serialize_matches_to_file(m, pmj)
+    assert json.load(open(pmj)) == [{"index_0": 1, "index_1": 3, "distance": 17.0},
+                                    {"index_0": 7, "index_1": 2**40, "distance": 0.0}]
+    assert np.array_equal(amd.deserialize_matches_from_file(pmj), m)
+    # empty sets and malformed input
+    amd.serialize_features_to_file(kps[:0], desc[:0], p)
+    k5, d5 = amd.deserialize_features_from_file(p)
+    assert len(k5) == 0 and len(d5) == 0
+    open(p, "wb").write(b"\x05\x00\x00")
+    with pytest.raises(amd.AkazeError):
+        amd.deserialize_features_from_file(p)

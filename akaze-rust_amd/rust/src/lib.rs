@@ -132,8 +132,9 @@ extern "C" {
                              tau: *mut f64, tau_cap: u64) -> c_int;
     pub(crate) fn akz_fetch_plane(res: *const c_void, img: u64, level: u64, plane: c_int, out: *mut f32,
                                   n_px: *mut u64) -> c_int;
-    fn akz_descriptor_match(ctx: *mut c_void, d0: *const u8, n0: u64, d1: *const u8, n1: u64, desc_bytes: u64,
-                            distance_threshold: u64, lowes_ratio: f64, out: *mut Match, n_out: *mut u64) -> c_int;
+    fn akz_match_features(ctx: *mut c_void, kp0: *const AkzKeypoint, d0: *const u8, n0: u64, kp1: *const AkzKeypoint,
+                          d1: *const u8, n1: u64, desc_bytes: u64, lowes_ratio: f64, ransac_trials: u64,
+                          ransac_epsilon_inliers: f32, out: *mut Match, n_out: *mut u64) -> c_int;
 }
 
 pub(crate) fn check(status: c_int) {
@@ -196,24 +197,26 @@ pub fn extract_features(input_image_path: PathBuf, options: Config) -> (Vec<Evol
     (evolutions, keypoints, descriptors)
 }
 
-/// akaze::match_features (akaze/src/lib.rs:252-275).  The Hamming stage (descriptor_match with
-/// distance threshold 10000) runs on the GPU; the RANSAC filter `remove_outliers` is host code that
-/// the maintainer keeps from the reference crate (ops/estimate_fundamental_matrix.rs), unchanged.
+/// akaze::match_features (akaze/src/lib.rs:252-275): the Hamming stage (descriptor_match with distance
+/// threshold 10000) runs on the GPU, the RANSAC filter (remove_outliers, epsilon_model 0.05) on the host
+/// inside the library.
 pub fn match_features(keypoints_0: &[Keypoint], descriptors_0: &[Descriptor], keypoints_1: &[Keypoint],
                       descriptors_1: &[Descriptor], lowes_ratio: f64, ransac_trials: usize,
                       ransac_epsilon_inliers: f32) -> Vec<Match> {
     let nb = descriptors_0.first().or(descriptors_1.first()).map(|d| d.vector.len()).unwrap_or(61);
     let flat = |ds: &[Descriptor]| ds.iter().flat_map(|d| d.vector.iter().cloned()).collect::<Vec<u8>>();
-    let (d0, d1) = (flat(descriptors_0), flat(descriptors_1));
+    let raw = |ks: &[Keypoint]| ks.iter().map(|k| AkzKeypoint {
+        x: k.point.0, y: k.point.1, response: k.response, size: k.size,
+        octave: k.octave as u64, class_id: k.class_id as u64, angle: k.angle, _pad: 0,
+    }).collect::<Vec<AkzKeypoint>>();
+    let (d0, d1, k0, k1) = (flat(descriptors_0), flat(descriptors_1), raw(keypoints_0), raw(keypoints_1));
     let mut out = vec![Match { index_0: 0, index_1: 0, distance: 0.0 }; descriptors_0.len().max(1)];
     let mut n = 0u64;
     CTX.with(|ctx| check(unsafe {
-        akz_descriptor_match(*ctx, d0.as_ptr(), descriptors_0.len() as u64, d1.as_ptr(), descriptors_1.len() as u64,
-                             nb as u64, 10000, lowes_ratio, out.as_mut_ptr(), &mut n)
+        akz_match_features(*ctx, k0.as_ptr(), d0.as_ptr(), descriptors_0.len() as u64, k1.as_ptr(), d1.as_ptr(),
+                           descriptors_1.len() as u64, nb as u64, lowes_ratio, ransac_trials as u64,
+                           ransac_epsilon_inliers, out.as_mut_ptr(), &mut n)
     }));
     out.truncate(n as usize);
-    let _ = (keypoints_0, keypoints_1, ransac_trials, ransac_epsilon_inliers);
-    // -> ops::estimate_fundamental_matrix::remove_outliers(keypoints_0, keypoints_1, &out, ransac_trials, 0.05,
-    //    ransac_epsilon_inliers) from the reference crate goes here (host, out of the GPU path).
     out
 }

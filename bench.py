@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
+    ap.add_argument("--sublevels", type=int, default=4)
+    ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
     ap.add_argument("--parts", type=int, default=1,
@@ -82,7 +84,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = A.Config()  # Config::default(): 4 octaves x 4 sublevels, 486-bit M-LDB
+    cfg = A.Config(num_sublevels=args.sublevels, max_octave_evolution=args.octaves)  # default 4 x 4, 486-bit M-LDB
     W, H, F = args.width, args.height, args.frames
 
     # this rank's shard of the world*F frames of a step: image i -> GPU i mod world (weak scaling)
@@ -242,13 +244,13 @@ def main():
     if rank == 0:
         stage_ms = {k: round(prof[k] / max(1, args.steps), 3) for k in A.STAGES}
         out = {
-            "metric": "Mpix/s through extract_features (4 oct x 4 sub)",
+            "metric": f"Mpix/s through extract_features ({args.octaves} oct x {args.sublevels} sub)",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
-                                   f"(4 octaves x 4 sublevels, 486-bit M-LDB), {F} frames per GPU per step "
+                                   f"({args.octaves} octaves x {args.sublevels} sublevels, 486-bit M-LDB), {F} frames per GPU per step "
                                    "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)",
                        "frames_per_gpu": F, "width": W, "height": H, "batches_per_step": NP,
                        "pipelining": "begin(batch j+1) before finish(batch j) on one stream, across steps",

@@ -471,6 +471,8 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
     constexpr int AW = DW, AH = DH + 2 * S;                // H windows,   origin (x0-RING, y0-RING-S)
     constexpr int RW = DW + 2 * S, RH = DH + 2 * S;        // input windows, origin (x0-RING-S, y0-RING-S)
     constexpr int NLOAD = (RH * RW + NT - 1) / NT;
+    constexpr int NROWT = NT / TW;                         // thread rows of the 2-D mapping (8)
+    static_assert(TW == 64 && NT % TW == 0, "one thread per tile column");
     static_assert(DW * DH <= RH * RW, "Ldet window must fit in the Lx window it aliases");
     __shared__ float sX[RH * RW];
     __shared__ float sY[RH * RW];
@@ -479,20 +481,123 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
     __shared__ float sC[AH * AW];  // H_off(Lx)
     float* sD = sX;                // Ldet window (valid after the second barrier)
     const int tid = threadIdx.x;
+    const int tx = tid & (TW - 1), ty = tid / TW;
     const int ntiles = tg.tx * tg.ty * tg.n;
+    // window coordinates of this thread's prefetch slots do not depend on the tile: compute them once
+    int pl_y[NLOAD], pl_x[NLOAD];
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+        const int idx = tid + k * NT;
+        pl_y[k] = idx / RW;
+        pl_x[k] = idx - pl_y[k] * RW;
+    }
     float rx[NLOAD], ry[NLOAD];
     auto issue = [&](int tile) {
         const Tile tl = decode_tile(tile, tg, w, h);
         const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
-            const int idx = tid + k * NT;
-            const int ly = idx / RW, lx = idx - ly * RW;
-            const int gx = tl.x0 - RING - S + lx, gy = tl.y0 - RING - S + ly;
-            const bool in = idx < RH * RW && gx >= 0 && gx < w && gy >= 0 && gy < h;
+            const int gx = tl.x0 - RING - S + pl_x[k], gy = tl.y0 - RING - S + pl_y[k];
+            const bool in = tid + k * NT < RH * RW && gx >= 0 && gx < w && gy >= 0 && gy < h;
             const size_t g = base + (size_t)gy * w + gx;
             rx[k] = in ? lx_in[g] : 0.0f;
             ry[k] = in ? ly_in[g] : 0.0f;
+        }
+    };
+    // One H-pass position: window column wc (0..AW-1) of image column x, window row ly.
+    auto h_pos = [&](int x, int wc, int ly, int x0, int y0) {
+        const int y = y0 - RING - S + ly;
+        if (x < 0 || x >= w || y < 0 || y >= h) return;
+        const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+        const int o = (cy - (y0 - RING - S)) * RW + (cx - (x0 - RING - S));
+        const float xa = sX[o - S], xb = sX[o], xc = sX[o + S];
+        const float ya = sY[o - S], yb = sY[o], yc = sY[o + S];
+        const int q = ly * AW + wc;
+        sA[q] = ((0.0f + kn * xa) + kwn * xb) + kn * xc;
+        sB[q] = ((0.0f + -1.0f * ya) + 0.0f * yb) + 1.0f * yc;
+        sC[q] = ((0.0f + -1.0f * xa) + 0.0f * xb) + 1.0f * xc;
+    };
+    // One V-pass position: Ldet (+ second derivatives) at image (x, y); window column wc, window row ly.
+    auto v_pos = [&](int x, int wc, int ly, int x0, int y0, size_t base, bool centre) {
+        const int y = y0 - RING + ly;
+        if (x < 0 || x >= w || y < 0 || y >= h) return;
+        const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+        const int o = (cy - (y0 - RING - S)) * AW + (cx - (x0 - RING));
+        const float lxx = ((0.0f + -1.0f * sA[o - S * AW]) + 0.0f * sA[o]) + 1.0f * sA[o + S * AW];
+        const float lyy = ((0.0f + kn * sB[o - S * AW]) + kwn * sB[o]) + kn * sB[o + S * AW];
+        const float lxy = ((0.0f + kn * sC[o - S * AW]) + kwn * sC[o]) + kn * sC[o + S * AW];
+        const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
+        if (NMS) sD[ly * DW + wc] = det;
+        if (centre) {
+            const size_t g = base + (size_t)y * w + x;
+            if (lxx_out) lxx_out[g] = lxx;
+            if (lyy_out) lyy_out[g] = lyy;
+            if (lxy_out) lxy_out[g] = lxy;
+            ldet_out[g] = det;
+        }
+    };
+    // The column passes of thread (tx, ty): rows ty, ty+8, ... of tile column x0+tx, fully unrolled and
+    // split into "issue every LDS read" / "compute and store" so that the ~100-cycle ds_read latency of
+    // one position overlaps the others (only 4 waves per SIMD are resident: LDS-limited occupancy).
+    constexpr int HIT = (AH + NROWT - 1) / NROWT, VIT = (DH + NROWT - 1) / NROWT;
+    auto h_column = [&](int x0, int y0) {
+        const int x = x0 + tx;
+        const bool xin = x < w;
+        const int cxo = clampi(x, S, w - 1 - S) - (x0 - RING - S);
+        float xa[HIT], xb[HIT], xc[HIT], ya[HIT], yb[HIT], yc[HIT];
+        bool ok[HIT];
+#pragma unroll
+        for (int i = 0; i < HIT; ++i) {
+            const int ly = ty + i * NROWT, y = y0 - RING - S + ly;
+            ok[i] = xin && ly < AH && y >= 0 && y < h;
+            const int o = ok[i] ? (clampi(y, S, h - 1 - S) - (y0 - RING - S)) * RW + cxo : S;
+            xa[i] = sX[o - S]; xb[i] = sX[o]; xc[i] = sX[o + S];
+            ya[i] = sY[o - S]; yb[i] = sY[o]; yc[i] = sY[o + S];
+        }
+#pragma unroll
+        for (int i = 0; i < HIT; ++i)
+            if (ok[i]) {
+                const int q = (ty + i * NROWT) * AW + tx + RING;
+                sA[q] = ((0.0f + kn * xa[i]) + kwn * xb[i]) + kn * xc[i];
+                sB[q] = ((0.0f + -1.0f * ya[i]) + 0.0f * yb[i]) + 1.0f * yc[i];
+                sC[q] = ((0.0f + -1.0f * xa[i]) + 0.0f * xb[i]) + 1.0f * xc[i];
+            }
+    };
+    auto v_column = [&](int x0, int y0, size_t base) {
+        const int x = x0 + tx;
+        const bool xin = x < w;
+        const int cxo = clampi(x, S, w - 1 - S) - (x0 - RING);
+        float a0[VIT], a1[VIT], a2[VIT], b0[VIT], b1[VIT], b2[VIT], c0[VIT], c1[VIT], c2[VIT];
+        bool ok[VIT];
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int ly = ty + i * NROWT, y = y0 - RING + ly;
+            ok[i] = xin && ly < DH && y >= 0 && y < h;
+            const int o = ok[i] ? (clampi(y, S, h - 1 - S) - (y0 - RING - S)) * AW + cxo : S * AW;
+            a0[i] = sA[o - S * AW]; a1[i] = sA[o]; a2[i] = sA[o + S * AW];
+            b0[i] = sB[o - S * AW]; b1[i] = sB[o]; b2[i] = sB[o + S * AW];
+            c0[i] = sC[o - S * AW]; c1[i] = sC[o]; c2[i] = sC[o + S * AW];
+        }
+        float det[VIT];
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const float lxx = ((0.0f + -1.0f * a0[i]) + 0.0f * a1[i]) + 1.0f * a2[i];
+            const float lyy = ((0.0f + kn * b0[i]) + kwn * b1[i]) + kn * b2[i];
+            const float lxy = ((0.0f + kn * c0[i]) + kwn * c1[i]) + kn * c2[i];
+            det[i] = ((lxx * lyy) - (lxy * lxy)) * quat;
+            const int ly = ty + i * NROWT;
+            if (ok[i] && ly >= RING && ly < TH + RING) {
+                const size_t g = base + (size_t)(y0 - RING + ly) * w + x;
+                if (lxx_out) lxx_out[g] = lxx;
+                if (lyy_out) lyy_out[g] = lyy;
+                if (lxy_out) lxy_out[g] = lxy;
+                ldet_out[g] = det[i];
+            }
+        }
+        if (NMS) {  // sD aliases sX: every thread has finished reading sX before the barrier in front of this pass
+#pragma unroll
+            for (int i = 0; i < VIT; ++i)
+                if (ok[i]) sD[(ty + i * NROWT) * DW + tx + RING] = det[i];
         }
     };
     int tile = blockIdx.x;
@@ -511,49 +616,22 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         const Tile tl = decode_tile(tile, tg, w, h);
         const int x0 = tl.x0, y0 = tl.y0;
         const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
-        for (int idx = tid; idx < AH * AW; idx += NT) {
-            const int ly = idx / AW, lx = idx - ly * AW;
-            const int x = x0 - RING + lx, y = y0 - RING - S + ly;
-            if (x >= 0 && x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-                const int o = (cy - (y0 - RING - S)) * RW + (cx - (x0 - RING - S));
-                const float xa = sX[o - S], xb = sX[o], xc = sX[o + S];
-                const float ya = sY[o - S], yb = sY[o], yc = sY[o + S];
-                sA[idx] = ((0.0f + kn * xa) + kwn * xb) + kn * xc;
-                sB[idx] = ((0.0f + -1.0f * ya) + 0.0f * yb) + 1.0f * yc;
-                sC[idx] = ((0.0f + -1.0f * xa) + 0.0f * xb) + 1.0f * xc;
-            }
-        }
+        // ---- three H passes: thread (tx, ty) owns tile column x0+tx, window rows ty, ty+8, ... ----
+        h_column(x0, y0);
+        if (NMS && tid < 2 * AH) h_pos((tid & 1) ? x0 + TW : x0 - 1, (tid & 1) ? AW - 1 : 0, tid >> 1, x0, y0);
         __syncthreads();  // sX / sY are dead from here on
-        for (int idx = tid; idx < DH * DW; idx += NT) {
-            const int ly = idx / DW, lx = idx - ly * DW;
-            const int x = x0 - RING + lx, y = y0 - RING + ly;
-            if (x >= 0 && x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-                const int o = (cy - (y0 - RING - S)) * AW + (cx - (x0 - RING));
-                const float lxx = ((0.0f + -1.0f * sA[o - S * AW]) + 0.0f * sA[o]) + 1.0f * sA[o + S * AW];
-                const float lyy = ((0.0f + kn * sB[o - S * AW]) + kwn * sB[o]) + kn * sB[o + S * AW];
-                const float lxy = ((0.0f + kn * sC[o - S * AW]) + kwn * sC[o]) + kn * sC[o + S * AW];
-                const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
-                if (NMS) sD[idx] = det;
-                if (lx >= RING && lx < TW + RING && ly >= RING && ly < TH + RING) {
-                    const size_t g = base + (size_t)y * w + x;
-                    if (lxx_out) lxx_out[g] = lxx;
-                    if (lyy_out) lyy_out[g] = lyy;
-                    if (lxy_out) lxy_out[g] = lxy;
-                    ldet_out[g] = det;
-                }
-            }
-        }
+        // ---- three V passes + determinant ----
+        v_column(x0, y0, base);
+        if (NMS && tid < 2 * DH) v_pos((tid & 1) ? x0 + TW : x0 - 1, (tid & 1) ? DW - 1 : 0, tid >> 1, x0, y0, base, false);
         __syncthreads();
         if (NMS) {
-            for (int idx = tid; idx < TH * TW; idx += NT) {
-                const int ly = idx / TW, lx = idx - ly * TW;
-                const int x = x0 + lx, y = y0 + ly;
+            const int x = x0 + tx;
+            for (int ly = ty; ly < TH; ly += NROWT) {
+                const int y = y0 + ly;
                 // flat range (w+1) .. len-w-2 of the reference loop; x = w-1 never passes the border test
                 if (x < 1 || x > w - 2 || y < 1 || y > h - 2) continue;
                 if ((long)y * w + x >= (long)w * h - w - 1) continue;
-                const int o = (ly + 1) * DW + (lx + 1);
+                const int o = (ly + 1) * DW + (tx + 1);
                 const float v = sD[o];
                 if (!(v > nms.thr)) continue;
                 const float xp = sD[o + 1], xm = sD[o - 1], yp = sD[o + DW], ym = sD[o - DW];

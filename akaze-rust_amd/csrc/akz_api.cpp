@@ -3,6 +3,7 @@
 // (plan, plane addresses, ping-pong parity) and enqueues the gfx950 kernels on one HIP stream.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <memory>
@@ -45,7 +46,7 @@ struct akz_ctx {
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     // stage profiling (akz_ctx_set_profiling)
     int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 1: k_fed_fused, 2: k_fed_own (both <= 8 steps/launch)
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
     akz_profile prof{};
     struct Span { int stage; hipEvent_t a, b; };
     std::vector<Span> spans;          // recorded, not yet resolved
@@ -68,14 +69,16 @@ struct StageTimer {
         (void)hipEventCreate(&e);
         return e;
     }
+    bool on;
     StageTimer(akz_ctx* ctx, int st) : c(ctx), stage(st) {
-        if (!c->profiling) return;
+        on = c->profiling >= 2 || (c->profiling == 1 && st == AKZ_ST_FED);
+        if (!on) return;
         a = get(c);
         b = get(c);
         (void)hipEventRecord(a, c->stream);
     }
     ~StageTimer() {
-        if (!c->profiling) return;
+        if (!on) return;
         (void)hipEventRecord(b, c->stream);
         c->spans.push_back({stage, a, b});
     }
@@ -125,6 +128,12 @@ static int ensure_pinned(akz_ctx* c, DevBuf& b, size_t bytes) {
     const size_t want = bytes + bytes / 4 + 4096;
     AKZ_HIP_TRY(hipHostMalloc(&b.p, want, hipHostMallocDefault));
     b.bytes = want;
+    return AKZ_OK;
+}
+// The auxiliary stream carries the finish-side copies and the per-keypoint kernels.  (A lowest-priority
+// stream was measured and made no difference to the main-stream kernels, so it is a plain stream.)
+static int ensure_aux(akz_ctx* c) {
+    if (!c->aux) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     return AKZ_OK;
 }
 static int bind(akz_ctx* c) {
@@ -855,7 +864,7 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
     akz_result* r = job->r.get();
     akz_ctx* c = r->ctx;
     AKZ_TRY(bind(c));
-    if (!c->aux) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    AKZ_TRY(ensure_aux(c));
     hipStream_t s = c->aux;  // everything below waits only for THIS job's kernels
     const akz_config& cfg = r->cfg;
     const std::vector<LevelPlan>& plan = r->plan;
@@ -1181,7 +1190,7 @@ int akz_result_copy_device_descriptors(const akz_result* r, uint8_t* d_dst, uint
     // on the auxiliary stream and complete on return: the context's main stream may already be busy
     // with the next batch, and the caller typically hands d_dst to a collective on yet another stream
     akz_ctx* c = r->ctx;
-    if (!c->aux) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    AKZ_TRY(ensure_aux(c));
     AKZ_HIP_TRY(hipMemcpyAsync(d_dst, r->d_desc64, total * 64, hipMemcpyDeviceToDevice, c->aux));
     AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
     return AKZ_OK;
@@ -1312,7 +1321,8 @@ int akz_host_select_keypoints(uint32_t w, uint32_t h, const akz_config* cfg, con
 }
 int akz_ctx_set_profiling(akz_ctx* c, int on) {
     AKZ_TRY(bind(c));
-    c->profiling = on != 0;
+    if (on < 0 || on > 2) return AKZ_ERR_INVALID_ARG;
+    c->profiling = on == 1 ? 2 : on == 2 ? 1 : 0;  // API: 1 = all stages, 2 = light (FED spans only)
     return AKZ_OK;
 }
 int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {

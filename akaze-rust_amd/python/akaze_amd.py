@@ -276,6 +276,7 @@ class Context:
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
 
     def set_profiling(self, on=True):
+        """0/False off, 1/True every stage, 2 light (FED spans + host-clock stages only)."""
         _check(lib().akz_ctx_set_profiling(self._h, int(on)))
 
     def get_profile(self, reset=True):

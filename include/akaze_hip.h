@@ -305,6 +305,8 @@ typedef struct akz_profile {
     uint64_t calls;          /* extract calls accumulated                                     */
     uint64_t pixels;         /* input pixels accumulated (w*h*n per call)                     */
 } akz_profile;
+/* on: 0 = off, 1 = every stage (two HIP events per stage and level), 2 = light: only the FED spans and the
+   host-clock stages (what bench.py uses inside its timed region) */
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
 /* FED kernel variant: 2 (default) = k_fed_own, LDS tile + register ownership, up to 8 explicit steps

@@ -45,6 +45,9 @@ struct akz_ctx {
     uint32_t cand_cap_hint = 1u << 15;  // grows to 1.25x the largest candidate count seen
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     // stage profiling (akz_ctx_set_profiling)
+    uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
+    int prep_mode = 2;  // same values as det_mode, for the level-preparation kernel
+    int det_mode = 2;  // 0: tiled LDS detector kernels, 1: streaming kernels wherever supported, 2: auto
     int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 1: k_fed_fused, 2: k_fed_own (both <= 8 steps/launch)
     int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
     akz_profile prof{};
@@ -470,6 +473,16 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
     return AKZ_OK;
 }
 
+// Detector kernel family of one level.  Measured on MI355X (32 x 1080p): with the three second-derivative
+// planes written out the LDS-tiled pair is faster (3.9 vs 4.3 ms per batch), without them the streaming pair
+// is (3.4 vs 3.7 ms); small launches (single frames, coarse octaves) are latency-bound and stay tiled.
+static bool use_stream_detector(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
+                                bool keep_second, bool nms = true) {
+    if (c->det_mode == 0 || !launch::detector_stream_supported(sigma, w, h, border_m, nms)) return false;
+    if (c->det_mode == 1) return true;
+    return !keep_second && (uint64_t)w * h * n >= c->stream_min_px;
+}
+
 static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                          float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n) {
     if (sigma == 0 || 2 * sigma + 1 > (uint32_t)kMaxTaps) {
@@ -477,6 +490,12 @@ static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float
         return AKZ_ERR_INVALID_ARG;
     }
     AKZ_TRY(check_plane_args(lsmooth, ldet_out, w, h, n, (int)sigma));
+    if (use_stream_detector(c, sigma, w, h, n, 0.0f, lxx && lyy && lxy, false)) {
+        launch::detector_stream(c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, 0, 0.0f, 0.0f,
+                                nullptr, 0, nullptr);
+        AKZ_HIP_TRY(hipGetLastError());
+        return AKZ_OK;
+    }
     if (launch::detector_fused_supported(sigma)) {
         launch::detector_fused(c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n);
         AKZ_HIP_TRY(hipGetLastError());
@@ -805,8 +824,17 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         {
             StageTimer st(c, AKZ_ST_PREP);
-            launch::prep_fused(s, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
-                               pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
+            // measured on MI355X: the streaming kernel is ~2x faster for cloned levels of a batch (a single
+            // frame is launch-latency bound and stays on the tiled kernel); for the first
+            // level of an octave (2x2 mean of a 4x larger input) the two are equal, the tiled one stays
+            const bool stream_prep = c->prep_mode != 0 && launch::prep_stream_supported(lv.w, lv.h) &&
+                                     (c->prep_mode == 1 || (!half && (uint64_t)lv.w * lv.h * n >= c->stream_min_px));
+            if (stream_prep)
+                launch::prep_stream(s, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
+                                    pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
+            else
+                launch::prep_fused(s, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
+                                   pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
             float* lstep0 = keep_all ? P(i, AKZ_LSTEP) : nullptr;
             if (lstep0 && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep0, 0, plane_bytes(lv.w, lv.h, n), s));
         }
@@ -829,6 +857,13 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     for (size_t l = 0; l < L; ++l) {
         const LevelPlan& lv = plan[l];
         const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
+        if (use_stream_detector(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
+            StageTimer st(c, AKZ_ST_DETECTOR);
+            launch::detector_stream(s, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
+                                    P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr, bm,
+                                    d_cand, cap, d_count);
+            continue;
+        }
         if (launch::detector_nms_fused_supported(lv.det_sigma)) {
             // derivatives, Ldet and extrema candidates in two launches (no second pass over Ldet)
             StageTimer st(c, AKZ_ST_DETECTOR);
@@ -1346,6 +1381,18 @@ int akz_match_features(akz_ctx* c, const akz_keypoint* kp0, const uint8_t* d0, u
     return akz_remove_outliers(kp0, n0, kp1, n1, raw.data(), n_raw, ransac_trials, 0.05f, ransac_epsilon_inliers, out,
                                n_out);                                                                        // lib.rs:267-274
 }
+int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
+    c->det_mode = mode;
+    return AKZ_OK;
+}
+
+int akz_ctx_set_prep_mode(akz_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
+    c->prep_mode = mode;
+    return AKZ_OK;
+}
+
 int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
     if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;

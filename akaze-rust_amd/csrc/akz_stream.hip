@@ -1,0 +1,684 @@
+// Barrier-free streaming kernels for gfx950: the level preparation (lib.rs:80-105) and the detector
+// derivatives (detector_response.rs:8-55) as register-ring stencil chains.
+//
+// Every lane owns a column of four consecutive pixels and marches down the rows of a strip:
+//
+//   * a horizontal pass on a plane that is in HBM reads its taps (x-S, x, x+S) as dword-aligned 16-byte
+//     global loads of the input row (a wave reads 1 KiB of a row per load, the shifted loads hit L1); a
+//     horizontal pass on a row that exists only in registers (k_prep_stream) takes the neighbours of a
+//     quad from the adjacent lanes with DPP wave shifts;
+//   * the horizontal results of the last 2S+1 rows live in a REGISTER ring (the loop is unrolled by the
+//     ring length, so every ring index is static); the vertical pass combines ring rows r-2S, r-S, r and
+//     the outputs go straight to HBM as 16-byte stores;
+//   * there is no LDS and no barrier; the next row's loads are issued before the current row's arithmetic.
+//
+// fill_border (types/image.rs:239-260) is reproduced exactly: a pass result at (x, y) is the interior
+// result at (clamp(x,S,w-1-S), clamp(y,S,h-1-S)).  Columns: lanes whose four pixels are not all interior
+// ("edge lanes") evaluate every pixel at its clamped column with scalar loads.  Rows: the H pass of row v
+// reads input row clamp(v), and the wave that produces interior row S (h-1-S) also stores it to rows
+// 0..S-1 (h-S..h-1).
+//
+// Work split: one wave per (image, row band, strip), strips fastest, so that the waves running side by
+// side work on the same image rows; bands are sized to give every resident wave slot one wave (all waves
+// finish together), but never shorter than a few ring lengths (each band re-warms its ring).
+//
+// Where they are used (akz_api.cpp picks per launch; both families give identical bytes): the streaming
+// preparation kernel is ~2x faster than the LDS-tiled one for batches (4.2 vs 2.2 TB/s at 32 x 1080p); the
+// streaming detector pair wins only when Lxx/Lyy/Lxy are not written out.  A 2 reads : 4 writes kernel
+// tops out near 4.4-5.2 TB/s on MI355X even for a plain copy-like loop (tools/membw), so the detector
+// kernels are bounded by their write mix, not by their structure.
+//
+// Arithmetic is the reference's: f32 mul then add, taps left to right starting from 0.0f, no FMA.
+// The off-axis Scharr taps [-1, 0.., 0, ..0, 1] are evaluated as (0.0f - a) + c, which is
+// bit-identical to ((0.0f + -1.0f*a) + 0.0f*b) + 1.0f*c for every finite b (the zero taps add +-0
+// to an accumulator that is never -0).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "akz_internal.hpp"
+
+namespace akz {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // four pixels of a row, dword-aligned
+
+constexpr int WAVE = 64, SNT = 256;  // 4 independent waves per workgroup
+#ifndef AKZ_STREAM_PF
+#define AKZ_STREAM_PF 1
+#endif
+constexpr int PF = AKZ_STREAM_PF;     // rows of input taps in flight per wave
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ f4 tap_main(f4 a, f4 b, f4 c, float kn, float kwn) {
+    return ((0.0f + kn * a) + kwn * b) + kn * c;
+}
+__device__ __forceinline__ f4 tap_off(f4 a, f4 c) { return (0.0f - a) + c; }
+
+struct StreamGrid {
+    int nstrips;    // strips per image row
+    int nbands;     // row bands per image
+    int band_rows;  // interior rows per band
+    long waves;     // n * nbands * nstrips
+};
+
+// Column geometry of one lane inside its strip.  A quad that would cross the right image edge is
+// shifted left to end at the last column (it then overlaps its neighbour and recomputes a few of its
+// pixels with identical results), so every store is one 16-byte store.
+struct Lane {
+    int x;           // column of the lane's first pixel (halo lanes may lie outside the image)
+    int first;       // first pixel of the quad this lane OWNS (reports candidates for); 4 = none
+    bool edge;       // some pixel is evaluated at a clamped column
+    bool store;      // this lane stores its quad
+    unsigned cx[4];  // evaluation columns of the four pixels
+};
+template <int S, int HL>
+__device__ __forceinline__ Lane make_lane(int strip, int lane, int w) {
+    constexpr int SW = 4 * (WAVE - 2 * HL);
+    Lane L;
+    const int xn = strip * SW + 4 * (lane - HL);  // nominal position
+    L.store = lane >= HL && lane < WAVE - HL && xn < w;
+    L.x = L.store ? min(xn, w - 4) : xn;
+    L.first = L.store ? xn - L.x : 4;
+    L.edge = !(L.x >= S && L.x + 3 <= w - 1 - S);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L.cx[i] = (unsigned)clampi(L.x + i, S, w - 1 - S);
+    return L;
+}
+// taps a = row[cx-S], b = row[cx], c = row[cx+S] of the lane's four pixels (edge lanes only)
+template <int S, bool NEED_B>
+__device__ __forceinline__ void fetch_edge(const float* __restrict__ row, const Lane& L, f4& a, f4& b, f4& c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = row[L.cx[i] - S];
+        if (NEED_B) b[i] = row[L.cx[i]];
+        c[i] = row[L.cx[i] + S];
+    }
+}
+template <int S, bool NEED_B>
+__device__ __forceinline__ void fetch_vec(const float* __restrict__ row, const Lane& L, f4& a, f4& b, f4& c) {
+    a = *reinterpret_cast<const f4u*>(row + L.x - S);
+    if (NEED_B) b = *reinterpret_cast<const f4u*>(row + L.x);
+    c = *reinterpret_cast<const f4u*>(row + L.x + S);
+}
+// one output row of N planes; ro = offset of the row's first pixel
+template <int N>
+__device__ __forceinline__ void store_rows(float* const (&plane)[N], size_t ro, const Lane& L, const f4 (&v)[N]) {
+    if (L.store) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) *reinterpret_cast<f4u*>(plane[i] + ro + L.x) = v[i];
+    }
+}
+// interior row c of the output planes, plus (two rows per strip) the border rows that copy it
+template <int S, int N>
+__device__ __forceinline__ void store_filled(float* const (&plane)[N], const Lane& L, int w, int h, int c, const f4 (&v)[N]) {
+    store_rows<N>(plane, (size_t)c * w, L, v);
+    if (c == S || c == h - 1 - S) {  // wave-uniform
+        if (c == S) {
+#pragma nounroll
+            for (int y = 0; y < S; ++y) store_rows<N>(plane, (size_t)y * w, L, v);
+        }
+        if (c == h - 1 - S) {
+#pragma nounroll
+            for (int y = h - S; y < h; ++y) store_rows<N>(plane, (size_t)y * w, L, v);
+        }
+    }
+}
+
+// One wave per (image, band, strip), strips fastest: the waves that run side by side read and write the
+// same rows of the image, i.e. the same DRAM pages and TLB entries.  Everything here is wave-uniform and
+// stays in scalar registers.
+struct Piece {
+    int img, strip, cs, ce;  // interior rows [cs, ce), S <= cs, ce <= h-S; empty when cs >= ce
+};
+__device__ __forceinline__ Piece wave_piece(long wave, const StreamGrid& g, int S, int h) {
+    Piece p;
+    const long per = (long)g.nbands * g.nstrips;
+    p.img = (int)(wave / per);
+    const int rem = (int)(wave - (long)p.img * per);
+    const int band = rem / g.nstrips;
+    p.strip = rem - band * g.nstrips;
+    p.cs = S + band * g.band_rows;
+    p.ce = min(p.cs + g.band_rows, h - S);
+    return p;
+}
+// the wave index as a scalar: everything derived from it (pieces, row pointers, loop bounds) is then
+// provably uniform and the compiler keeps it in SGPRs with scalar branches
+__device__ __forceinline__ long wave_index() {
+    return (long)blockIdx.x * (SNT / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multiscale first derivatives (detector_response.rs:9-10): Lx = V_off(H_main(Ls)), Ly = V_main(H_off(Ls))
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(SNT, (S <= 2 ? 4 : S == 3 ? 3 : 2))  // second argument: waves per SIMD the register budget must allow
+k_deriv1_stream(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out, int w, int h,
+                StreamGrid g, float kn, float kwn) {
+    constexpr int P = 2 * S + 1;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long wave = wave_index();
+    if (wave >= g.waves) return;
+    {
+        const Piece pc = wave_piece(wave, g, S, h);
+        if (pc.cs >= pc.ce) return;
+        const Lane L = make_lane<S, 0>(pc.strip, lane, w);
+        const size_t base = (size_t)pc.img * (size_t)w * (size_t)h;
+        const float* in = ls + base;
+        float* const out[2] = {lx_out + base, ly_out + base};
+        const int v0 = pc.cs - S, T = (pc.ce - pc.cs) + 2 * S;  // H rows v0 .. v0+T-1
+        f4 rM[P], rO[P];
+        f4 qa[PF], qb[PF], qc[PF];  // taps of rows t .. t+PF-1, in flight ahead of the arithmetic
+        auto fetch = [&](int t, f4& fa, f4& fb, f4& fc) {
+            const float* row = in + (size_t)clampi(v0 + std::min(t, T - 1), S, h - 1 - S) * w;
+            if (!L.edge) fetch_vec<S, true>(row, L, fa, fb, fc);
+            else fetch_edge<S, true>(row, L, fa, fb, fc);
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) fetch(i, qa[i], qb[i], qc[i]);
+        for (int t0 = 0; t0 < T; t0 += P) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int t = t0 + k;
+                if (t < T) {
+                    f4 na, nb, nc;
+                    fetch(t + PF, na, nb, nc);
+                    const f4 a = qa[0], b = qb[0], c = qc[0];
+                    rM[k] = tap_main(a, b, c, kn, kwn);
+                    rO[k] = tap_off(a, c);
+                    if (t >= 2 * S) {
+                        const int k0 = (k + 1) % P, k1 = (k + P - S) % P;  // rows c-S, c; k = row c+S
+                        const f4 v[2] = {tap_off(rM[k0], rM[k]), tap_main(rO[k0], rO[k1], rO[k], kn, kwn)};
+                        store_filled<S, 2>(out, L, w, h, v0 + t - S, v);
+                    }
+#pragma unroll
+                    for (int i = 0; i + 1 < PF; ++i) { qa[i] = qa[i + 1]; qb[i] = qb[i + 1]; qc[i] = qc[i + 1]; }
+                    qa[PF - 1] = na; qb[PF - 1] = nb; qc[PF - 1] = nc;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second derivatives, Hessian determinant and (NMS) the extrema test of scale_space_extrema.rs:32-42,
+// :80-87: Lxx = V_off(H_main(Lx)), Lyy = V_main(H_off(Ly)), Lxy = V_main(H_off(Lx)),
+// Ldet = ((Lxx*Lyy) - (Lxy*Lxy)) * sigma^4.  A pixel is a candidate if Ldet > threshold, Ldet is
+// strictly above its 4 neighbours and the descriptor window fits in the image; the host turns the
+// last test into the rectangle [xlo,xhi] x [ylo,yhi] (same float expressions) and checks that it
+// keeps candidates at least S+2 pixels away from every edge, so only interior rows and columns are
+// ever tested.  With NMS one lane on each side of the wave is a halo lane: it computes Ldet for its
+// neighbour but neither stores nor reports.
+// ---------------------------------------------------------------------------------------------
+struct StreamNms {
+    unsigned level;
+    float thr;
+    int xlo, xhi, ylo, yhi;
+    Candidate* cand;
+    unsigned cap;
+    unsigned* count;
+};
+
+template <int S, bool NMS, bool KEEP>
+__global__ void __launch_bounds__(SNT, (S == 1 ? 3 : 2))
+k_deriv2_stream(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float* __restrict__ lxx_out,
+                float* __restrict__ lyy_out, float* __restrict__ lxy_out, float* __restrict__ ldet_out, int w, int h,
+                StreamGrid g, float kn, float kwn, float quat, StreamNms nms) {
+    constexpr int P = 2 * S + 1, HL = NMS ? 1 : 0, NOUT = KEEP ? 4 : 1;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long wave = wave_index();
+    if (wave >= g.waves) return;
+    {
+        const Piece pc = wave_piece(wave, g, S, h);
+        if (pc.cs >= pc.ce) return;
+        const Lane L = make_lane<S, HL>(pc.strip, lane, w);
+        const size_t base = (size_t)pc.img * (size_t)w * (size_t)h;
+        const float* inx = lx_in + base;
+        const float* iny = ly_in + base;
+        float* out[NOUT];
+        out[0] = ldet_out + base;
+        if (KEEP) {
+            out[1] = lxx_out + base;
+            out[2] = lyy_out + base;
+            out[3] = lxy_out + base;
+        }
+        float* const(&outc)[NOUT] = out;
+        // extrema test: rows [cs, ce) of this piece; it needs Ldet of rows cs-1 and ce as well
+        const int cb = NMS ? std::max(pc.cs - 1, S) : pc.cs;
+        const int cl = NMS ? std::min(pc.ce + 1, h - S) : pc.ce;
+        const int v0 = cb - S, T = (cl - cb) + 2 * S;
+        unsigned xok = 0;  // bit i: pixel i of this lane may be a candidate
+        if (NMS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i >= L.first && L.x + i >= nms.xlo && L.x + i <= nms.xhi) xok |= 1u << i;
+        }
+        f4 rA[P], rB[P], rC[P];
+        f4 dm2 = 0.0f, dm1 = 0.0f;  // Ldet of rows c-2, c-1
+        f4 qxa[PF], qxb[PF], qxc[PF], qya[PF], qyc[PF];  // taps of rows t .. t+PF-1, in flight ahead of the arithmetic
+        auto fetch = [&](int t, f4& fxa, f4& fxb, f4& fxc, f4& fya, f4& fyc) {
+            const size_t ro = (size_t)clampi(v0 + std::min(t, T - 1), S, h - 1 - S) * w;
+            f4 unused;
+            if (!L.edge) {
+                fetch_vec<S, true>(inx + ro, L, fxa, fxb, fxc);
+                fetch_vec<S, false>(iny + ro, L, fya, unused, fyc);
+            } else {
+                fetch_edge<S, true>(inx + ro, L, fxa, fxb, fxc);
+                fetch_edge<S, false>(iny + ro, L, fya, unused, fyc);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) fetch(i, qxa[i], qxb[i], qxc[i], qya[i], qyc[i]);
+        for (int t0 = 0; t0 < T; t0 += P) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int t = t0 + k;
+                if (t < T) {
+                    f4 nxa, nxb, nxc, nya, nyc;
+                    fetch(t + PF, nxa, nxb, nxc, nya, nyc);
+                    const f4 xa = qxa[0], xb = qxb[0], xc = qxc[0], ya = qya[0], yc = qyc[0];
+                    rA[k] = tap_main(xa, xb, xc, kn, kwn);  // H_main(Lx)
+                    rB[k] = tap_off(ya, yc);                // H_off(Ly)
+                    rC[k] = tap_off(xa, xc);                // H_off(Lx)
+                    if (t >= 2 * S) {
+                        const int k0 = (k + 1) % P, k1 = (k + P - S) % P;
+                        const int cr = v0 + t - S;
+                        f4 o[NOUT];
+                        const f4 lxx = tap_off(rA[k0], rA[k]);
+                        const f4 lyy = tap_main(rB[k0], rB[k1], rB[k], kn, kwn);
+                        const f4 lxy = tap_main(rC[k0], rC[k1], rC[k], kn, kwn);
+                        const f4 det = ((lxx * lyy) - (lxy * lxy)) * quat;
+                        o[0] = det;
+                        if (KEEP) {
+                            o[1] = lxx;
+                            o[2] = lyy;
+                            o[3] = lxy;
+                        }
+                        const f4(&oc)[NOUT] = o;
+                        if (cr >= pc.cs && cr < pc.ce) store_filled<S, NOUT>(outc, L, w, h, cr, oc);
+                        if (NMS) {
+                            const int y = cr - 1;  // row under test: dm1, between dm2 (above) and det (below)
+                            if (t >= 2 * S + 2 && y >= pc.cs && y < pc.ce && y >= nms.ylo && y <= nms.yhi) {  // uniform
+                                const float left = __shfl_up(dm1[3], 1), right = __shfl_down(dm1[0], 1);
+                                const float xm[4] = {left, dm1[0], dm1[1], dm1[2]};
+                                const float xp[4] = {dm1[1], dm1[2], dm1[3], right};
+                                unsigned m = 0;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float v = dm1[i];
+                                    const bool hit = (v > nms.thr) & (v > xp[i]) & (v > xm[i]) & (v > dm2[i]) & (v > det[i]);
+                                    m |= hit ? 1u << i : 0u;
+                                }
+                                m &= xok;
+                                while (m) {  // rare; at most two pixels of a quad can be strict maxima
+                                    const int i = __ffs(m) - 1;
+                                    m &= m - 1;
+                                    Candidate cd;
+                                    cd.level = nms.level;
+                                    cd.idx = (unsigned)(y * w + L.x + i);
+                                    cd.v = i == 0 ? dm1[0] : i == 1 ? dm1[1] : i == 2 ? dm1[2] : dm1[3];
+                                    cd.xp = i == 0 ? dm1[1] : i == 1 ? dm1[2] : i == 2 ? dm1[3] : right;
+                                    cd.xm = i == 0 ? left : i == 1 ? dm1[0] : i == 2 ? dm1[1] : dm1[2];
+                                    cd.yp = i == 0 ? det[0] : i == 1 ? det[1] : i == 2 ? det[2] : det[3];
+                                    cd.ym = i == 0 ? dm2[0] : i == 1 ? dm2[1] : i == 2 ? dm2[2] : dm2[3];
+                                    cd.img = (unsigned)pc.img;
+                                    const unsigned slot = atomicAdd(nms.count, 1u);
+                                    if (slot < nms.cap) nms.cand[slot] = cd;
+                                }
+                            }
+                            dm2 = dm1;
+                            dm1 = det;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i + 1 < PF; ++i) {
+                        qxa[i] = qxa[i + 1]; qxb[i] = qxb[i + 1]; qxc[i] = qxc[i + 1];
+                        qya[i] = qya[i + 1]; qyc[i] = qyc[i + 1];
+                    }
+                    qxa[PF - 1] = nxa; qxb[PF - 1] = nxb; qxc[PF - 1] = nxc; qya[PF - 1] = nya; qyc[PF - 1] = nyc;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One level's preparation (lib.rs:80-105), streaming: Lt_i (the previous level's Lt, or its 2x2 mean,
+// types/image.rs:102-118) -> Lsmooth_i = gaussian_blur(Lt_i, 1.0) -> scale-1 Scharr pair -> Lflow_i =
+// pm_g2.  Four passes with half width 1, chained per row in registers:
+//
+//   input row v --H_g--> G ring (3 rows) --V_g--> Lsmooth row u=v-1 --H_scharr--> HM/HO rings (3 rows)
+//               --V_scharr--> (Lx1, Ly1) of row c=v-2 --pm_g2--> Lflow row c
+//
+// The second horizontal pass works on a row that exists only in registers: the x-1 / x+1 neighbours of
+// a quad come from the adjacent lanes (DPP wave shifts), so one lane on each side of the wave is a halo
+// lane.  fill_border: columns as in the kernels above (stage 1 evaluates edge pixels at their clamped
+// column, so every lane holds the FILLED Lsmooth of its own columns; stage 2 copies the results of
+// columns 1 / w-2 to columns 0 / w-1); rows: Lsmooth row 0 (h-1) is row 1 (h-2), which the first (last)
+// band handles by entering the scharr ring slot of that row twice.
+// ---------------------------------------------------------------------------------------------
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ float from_left_lane(float v) {  // lane i receives lane i-1 (DPP wave_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right_lane(float v) {  // lane i receives lane i+1 (DPP wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ f4 tap3(f4 a, f4 b, f4 c, float k0, float k1, float k2) {
+    return ((0.0f + k0 * a) + k1 * b) + k2 * c;
+}
+__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {  // lib.rs:30-37
+    const double dx = (double)lx, dy = (double)ly;
+    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
+}
+__device__ __forceinline__ float mean4(float p00, float p01, float p10, float p11) {  // image.rs:108-114
+    float v = 0.0f;
+    v = v + p00;  // (2x,   2y)
+    v = v + p01;  // (2x,   2y+1)
+    v = v + p10;  // (2x+1, 2y)
+    v = v + p11;  // (2x+1, 2y+1)
+    return v / 4.0f;
+}
+
+struct PrepLane {
+    int x;
+    bool edge;       // some pixel is evaluated at a clamped column (or lies outside the image)
+    bool vst, sst;   // stores its quad with one 16-byte store / pixel by pixel (quad crosses the right edge)
+    bool fix0;       // holds column 0
+    int i0;          // component that holds column w-1, or -1
+    unsigned cx[4];  // evaluation columns
+};
+__device__ __forceinline__ PrepLane make_prep_lane(int strip, int lane, int w) {
+    PrepLane L;
+    L.x = strip * (4 * (WAVE - 2)) + 4 * (lane - 1);
+    L.edge = !(L.x >= 1 && L.x + 3 <= w - 2);
+    const bool owner = lane >= 1 && lane < WAVE - 1 && L.x < w;
+    L.vst = owner && L.x + 3 < w;
+    L.sst = owner && !L.vst;
+    L.fix0 = L.x == 0;
+    L.i0 = (w - 1 >= L.x && w - 1 <= L.x + 3) ? w - 1 - L.x : -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L.cx[i] = (unsigned)clampi(L.x + i, 1, w - 2);
+    return L;
+}
+__device__ __forceinline__ void prep_store(float* __restrict__ row, const PrepLane& L, int w, f4 v) {
+    if (L.vst) {
+        *reinterpret_cast<f4u*>(row + L.x) = v;
+    } else if (L.sst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (L.x + i < w) row[L.x + i] = v[i];
+    }
+}
+// row y of a filled plane; rows 1 and h-2 are also the border rows 0 and h-1
+__device__ __forceinline__ void prep_store_filled(float* __restrict__ plane, const PrepLane& L, int w, int h, int y, f4 v) {
+    prep_store(plane + (size_t)y * w, L, w, v);
+    if (y == 1) prep_store(plane, L, w, v);
+    if (y == h - 2) prep_store(plane + (size_t)(h - 1) * w, L, w, v);
+}
+
+// Stage-1 taps of level row y (0 <= y < h): a, b, c = Lt_i at columns cx-1, cx, cx+1; raw = Lt_i at the lane's
+// own columns (HALF only: that is the half-size image the level starts from).
+template <bool HALF>
+__device__ __forceinline__ void prep_fetch(const float* __restrict__ src, int pw, int w, int y, const PrepLane& L, f4& a,
+                                           f4& b, f4& c, f4& raw) {
+    if (!HALF) {
+        const float* row = src + (size_t)y * w;
+        if (!L.edge) {
+            const f4 q0 = *reinterpret_cast<const f4u*>(row + L.x - 1);
+            const f2u q1 = *reinterpret_cast<const f2u*>(row + L.x + 3);
+            a = q0;
+            b = f4{q0[1], q0[2], q0[3], q1[0]};
+            c = f4{q0[2], q0[3], q1[0], q1[1]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = row[L.cx[i] - 1];
+                b[i] = row[L.cx[i]];
+                c[i] = row[L.cx[i] + 1];
+            }
+        }
+        raw = b;
+    } else {
+        const float* r0 = src + (size_t)(2 * y) * pw;
+        const float* r1 = r0 + pw;
+        if (!L.edge) {
+            const float* p0 = r0 + 2 * L.x - 2;
+            const float* p1 = r1 + 2 * L.x - 2;
+            const f4 u0 = *reinterpret_cast<const f4u*>(p0), u1 = *reinterpret_cast<const f4u*>(p0 + 4),
+                     u2 = *reinterpret_cast<const f4u*>(p0 + 8);
+            const f4 d0 = *reinterpret_cast<const f4u*>(p1), d1 = *reinterpret_cast<const f4u*>(p1 + 4),
+                     d2 = *reinterpret_cast<const f4u*>(p1 + 8);
+            const float m0 = mean4(u0[0], d0[0], u0[1], d0[1]), m1 = mean4(u0[2], d0[2], u0[3], d0[3]);
+            const float m2 = mean4(u1[0], d1[0], u1[1], d1[1]), m3 = mean4(u1[2], d1[2], u1[3], d1[3]);
+            const float m4 = mean4(u2[0], d2[0], u2[1], d2[1]), m5 = mean4(u2[2], d2[2], u2[3], d2[3]);
+            a = f4{m0, m1, m2, m3};
+            b = f4{m1, m2, m3, m4};
+            c = f4{m2, m3, m4, m5};
+            raw = b;
+        } else {
+            auto mean_at = [&](unsigned col) { return mean4(r0[2 * col], r1[2 * col], r0[2 * col + 1], r1[2 * col + 1]); };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = mean_at(L.cx[i] - 1);
+                b[i] = mean_at(L.cx[i]);
+                c[i] = mean_at(L.cx[i] + 1);
+                raw[i] = mean_at((unsigned)clampi(L.x + i, 0, w - 1));
+            }
+        }
+    }
+}
+
+template <bool HALF>
+__global__ void __launch_bounds__(SNT, 3)
+k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float* __restrict__ lsmooth,
+              float* __restrict__ lflow, int w, int h, int pw, int ph, StreamGrid g, float g0, float g1, float g2,
+              float kn, float kwn, const double* __restrict__ d_k, unsigned k_pow) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long wave = wave_index();
+    if (wave >= g.waves) return;
+    const Piece pc = wave_piece(wave, g, 1, h);
+    if (pc.cs >= pc.ce) return;
+    const PrepLane L = make_prep_lane(pc.strip, lane, w);
+    const bool edge_strip = pc.strip == 0 || pc.strip == g.nstrips - 1;
+    const float* src = prev + (size_t)pc.img * (size_t)pw * (size_t)ph;
+    const size_t base = (size_t)pc.img * (size_t)w * (size_t)h;
+    float* ltp = HALF ? lt_out + base : nullptr;
+    float* lsp = lsmooth + base;
+    float* lfp = lflow + base;
+    double kc = d_k[pc.img];
+    for (unsigned i = 0; i < k_pow; ++i) kc = kc * 0.75;  // lib.rs:84, one octave at a time in f64
+    const double inverse_k = 1.0 / (kc * kc);
+    const int v0 = pc.cs - 2, T = (pc.ce - pc.cs) + 4;  // input rows v0 .. v0+T-1 (clamped to 1..h-2 when loaded)
+    f4 a, b, c, raw;
+    if (HALF) {  // rows 0 and h-1 of the half-size image are not on the filter path (their taps are clamped away)
+        if (pc.cs == 1) {
+            prep_fetch<true>(src, pw, w, 0, L, a, b, c, raw);
+            prep_store(ltp, L, w, raw);
+        }
+        if (pc.ce == h - 1) {
+            prep_fetch<true>(src, pw, w, h - 1, L, a, b, c, raw);
+            prep_store(ltp + (size_t)(h - 1) * w, L, w, raw);
+        }
+    }
+    f4 G[3], HM[3], HO[3];
+    prep_fetch<HALF>(src, pw, w, clampi(v0, 1, h - 2), L, a, b, c, raw);
+    for (int t0 = 0; t0 < T; t0 += 3) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int t = t0 + k;
+            if (t < T) {
+                const int km1 = (k + 2) % 3, km2 = (k + 1) % 3;
+                const int v = v0 + t;
+                f4 na, nb, nc, nraw;  // the next row's taps are in flight during this row's arithmetic
+                prep_fetch<HALF>(src, pw, w, clampi(v0 + std::min(t + 1, T - 1), 1, h - 2), L, na, nb, nc, nraw);
+                if (HALF && v >= pc.cs && v < pc.ce) prep_store(ltp + (size_t)v * w, L, w, raw);
+                G[k] = tap3(a, b, c, g0, g1, g2);
+                if (t >= 2) {
+                    const int u = v - 1;
+                    const f4 ls = tap3(G[km2], G[km1], G[k], g0, g1, g2);  // filled Lsmooth of the lane's columns
+                    if (u >= pc.cs && u < pc.ce) prep_store_filled(lsp, L, w, h, u, ls);
+                    const f4 la = f4{from_left_lane(ls[3]), ls[0], ls[1], ls[2]};
+                    const f4 lc = f4{ls[1], ls[2], ls[3], from_right_lane(ls[0])};
+                    f4 hm = tap_main(la, ls, lc, kn, kwn);
+                    f4 ho = tap_off(la, lc);
+                    if (edge_strip) {  // wave-uniform: results of columns 1 / w-2 are also those of columns 0 / w-1
+                        const float ml = from_left_lane(hm[3]), ol = from_left_lane(ho[3]);
+                        const f4 rm = hm, ro = ho;
+                        if (L.fix0) { hm[0] = rm[1]; ho[0] = ro[1]; }
+                        if (L.i0 == 0) { hm[0] = ml; ho[0] = ol; }
+                        if (L.i0 == 1) { hm[1] = rm[0]; ho[1] = ro[0]; }
+                        if (L.i0 == 2) { hm[2] = rm[1]; ho[2] = ro[1]; }
+                        if (L.i0 == 3) { hm[3] = rm[2]; ho[3] = ro[2]; }
+                    }
+                    HM[k] = hm;
+                    HO[k] = ho;
+                    if (u == 1) { HM[km1] = hm; HO[km1] = ho; }              // Lsmooth row 0 is row 1
+                    if (u == h - 1) { HM[k] = HM[km1]; HO[k] = HO[km1]; }    // Lsmooth row h-1 is row h-2
+                    if (t >= 4) {
+                        const int cr = u - 1;
+                        const f4 lx1 = tap_off(HM[km2], HM[k]);
+                        const f4 ly1 = tap_main(HO[km2], HO[km1], HO[k], kn, kwn);
+                        f4 fl;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fl[i] = pm_g2_px(lx1[i], ly1[i], inverse_k);
+                        if (cr >= pc.cs && cr < pc.ce) prep_store_filled(lfp, L, w, h, cr, fl);
+                    }
+                }
+                a = na; b = nb; c = nc; raw = nraw;
+            }
+        }
+    }
+}
+
+// Bands are sized so that one wave per resident slot covers the batch in a single round.
+template <typename K>
+inline StreamGrid plan_stream(K kernel, uint32_t w, uint32_t h, uint32_t n, int S, int HL, int min_rows, dim3* grid) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    static int per_cu = 0;  // one per kernel instantiation
+    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SNT, 0) != hipSuccess || per_cu <= 0))
+        per_cu = 2;
+    const int sw = 4 * (WAVE - 2 * HL);
+    const long slots = (long)cus * per_cu * (SNT / WAVE);
+    const int rows = (int)h - 2 * S;
+    StreamGrid g;
+    g.nstrips = (int)((w + sw - 1) / sw);
+    const long cols = (long)n * g.nstrips;
+    // enough bands to give every resident slot a wave; a band restarts the ring (warm-up rows), so bands stay
+    // at least min_rows tall even when that leaves slots idle (small levels are latency-bound either way)
+    const long nb_fill = std::max<long>(1, (slots + cols - 1) / cols);
+    g.band_rows = (int)std::max<long>((rows + nb_fill - 1) / nb_fill, std::min<long>(min_rows, rows));
+    g.nbands = (rows + g.band_rows - 1) / g.band_rows;
+    g.waves = cols * g.nbands;
+    *grid = dim3((unsigned)((g.waves + SNT / WAVE - 1) / (SNT / WAVE)));
+    return g;
+}
+
+}  // namespace
+
+namespace launch {
+
+// The candidate rectangle of scale_space_extrema.rs:32-42 (x in 1..w-2, y in 1..h-2) and :80-87 (descriptor
+// window inside the image) with the reference's float expressions; both border tests are monotone in the
+// coordinate, so the admissible coordinates form one interval.
+static void admissible(uint32_t dim, float border_m, int* lo, int* hi) {
+    auto out_lo = [&](int v) { return (roundf((float)v - border_m) - 1.0f) < 0.0f; };
+    auto out_hi = [&](int v) { return (roundf((float)v + border_m) + 1.0f) >= (float)dim; };
+    int a = 1, b = (int)dim - 2;
+    while (a <= b && out_lo(a)) ++a;
+    while (b >= a && out_hi(b)) --b;
+    *lo = a;
+    *hi = b;  // empty when lo > hi
+}
+
+bool detector_stream_supported(uint32_t sigma, uint32_t w, uint32_t h, float border_m, bool nms) {
+    if (sigma < 1 || sigma > 4) return false;
+    if (w < 4 * sigma + 8 || h < 4 * sigma + 8) return false;
+    // the extrema test reads Ldet one pixel around a candidate: keep that ring inside the interior rows/columns
+    return !nms || border_m >= (float)(sigma + 2);
+}
+
+bool prep_stream_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16; }
+static int prep_min_rows() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("AKZ_PREP_MIN_ROWS");  // tuning knob
+        v = e ? std::max(1, atoi(e)) : 8;
+    }
+    return v;
+}
+
+void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, float* lsmooth, float* lflow, uint32_t w,
+                 uint32_t h, uint32_t pw, uint32_t ph, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow) {
+    const Taps m = taps_scharr_main(1);
+    dim3 grid;
+    if (half) {
+        const StreamGrid g = plan_stream(k_prep_stream<true>, w, h, n, 1, 1, prep_min_rows(), &grid);
+        hipLaunchKernelGGL((k_prep_stream<true>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
+                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow);
+    } else {
+        const StreamGrid g = plan_stream(k_prep_stream<false>, w, h, n, 1, 1, prep_min_rows(), &grid);
+        hipLaunchKernelGGL((k_prep_stream<false>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
+                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow);
+    }
+}
+
+#define AKZ_SDET(S)                                                                                                  \
+    case S: {                                                                                                        \
+        dim3 g1, g2;                                                                                                 \
+        const StreamGrid s1 = plan_stream(k_deriv1_stream<S>, w, h, n, S, 0, 4 * (S + 1), &g1);                                   \
+        hipLaunchKernelGGL((k_deriv1_stream<S>), g1, dim3(SNT), 0, s, lsmooth, lx, ly, (int)w, (int)h, s1, kn, kwn); \
+        if (d_cand) {                                                                                                \
+            if (keep) {                                                                                              \
+                const StreamGrid s2 = plan_stream(k_deriv2_stream<S, true, true>, w, h, n, S, 1, 4 * (S + 1), &g2);               \
+                hipLaunchKernelGGL((k_deriv2_stream<S, true, true>), g2, dim3(SNT), 0, s, (const float*)lx,          \
+                                   (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na); \
+            } else {                                                                                                 \
+                const StreamGrid s2 = plan_stream(k_deriv2_stream<S, true, false>, w, h, n, S, 1, 4 * (S + 1), &g2);              \
+                hipLaunchKernelGGL((k_deriv2_stream<S, true, false>), g2, dim3(SNT), 0, s, (const float*)lx,         \
+                                   (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na); \
+            }                                                                                                        \
+        } else if (keep) {                                                                                           \
+            const StreamGrid s2 = plan_stream(k_deriv2_stream<S, false, true>, w, h, n, S, 0, 4 * (S + 1), &g2);                  \
+            hipLaunchKernelGGL((k_deriv2_stream<S, false, true>), g2, dim3(SNT), 0, s, (const float*)lx,             \
+                               (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na);    \
+        } else {                                                                                                     \
+            const StreamGrid s2 = plan_stream(k_deriv2_stream<S, false, false>, w, h, n, S, 0, 4 * (S + 1), &g2);                 \
+            hipLaunchKernelGGL((k_deriv2_stream<S, false, false>), g2, dim3(SNT), 0, s, (const float*)lx,            \
+                               (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na);    \
+        }                                                                                                            \
+    } break;
+
+// Streaming detector of one level: first derivatives, second derivatives + Ldet and, when d_cand is
+// given, the extrema candidates.  lxx/lyy/lxy may be null together (the planes are then not kept).
+void detector_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
+                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level, float thr,
+                     float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
+    const Taps m = taps_scharr_main(sigma);
+    const float kn = m.wgt[0], kwn = m.wgt[1];
+    const float quat = (float)(sigma * sigma * sigma * sigma);
+    const bool keep = lxx && lyy && lxy;
+    StreamNms na{level, thr, 0, -1, 0, -1, d_cand, cap, d_count};
+    if (d_cand) {
+        admissible(w, border_m, &na.xlo, &na.xhi);
+        admissible(h, border_m, &na.ylo, &na.yhi);
+    }
+    switch (sigma) {
+        AKZ_SDET(1) AKZ_SDET(2) AKZ_SDET(3) AKZ_SDET(4)
+        default: break;
+    }
+}
+#undef AKZ_SDET
+
+}  // namespace launch
+}  // namespace akz

@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libakaze_hip.so")
+LIB_PATH = os.environ.get("AKAZE_HIP_LIB") or os.path.join(_PKG, "libakaze_hip.so")  # override: kernel tuning A/B builds
 
 AKZ_KEEP_ALL_PLANES = 1
 AKZ_NO_HOST_DESCRIPTORS = 2
@@ -157,6 +157,8 @@ def lib():
         "akz_host_select_keypoints": ([u32, u32, C.POINTER(Config), vp, u64, vp, u64, pu64, pu64], i32),
         "akz_ctx_set_profiling": ([vp, i32], i32),
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
+        "akz_ctx_set_detector_mode": ([vp, i32], i32),
+        "akz_ctx_set_prep_mode": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
     }
@@ -274,6 +276,14 @@ class Context:
     def set_fed_mode(self, mode):
         """2 = register-ownership fused kernel (default), 1 = LDS-only fused kernel, 0 = one launch per step."""
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
+
+    def set_detector_mode(self, mode):
+        """2 = automatic (default), 1 = streaming register-ring kernels wherever supported, 0 = LDS-tiled kernels."""
+        _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
+
+    def set_prep_mode(self, mode):
+        """Level-preparation kernel: 2 = automatic (default), 1 = streaming, 0 = LDS-tiled."""
+        _check(lib().akz_ctx_set_prep_mode(self._h, int(mode)))
 
     def set_profiling(self, on=True):
         """0/False off, 1/True every stage, 2 light (FED spans + host-clock stages only)."""

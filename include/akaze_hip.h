@@ -313,6 +313,12 @@ int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
    per launch; 1 = k_fed_fused, same tiling with all values through LDS; 0 = k_fed_step, one launch
    per step.  Results are bit-identical. */
 int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
+/* Detector kernel variant: 2 (default) = automatic (streaming register-ring kernels for batches whose
+   second-derivative planes are not kept, LDS-tiled kernels otherwise); 1 = streaming wherever it is
+   supported (sigma_size <= 4); 0 = tiled only.  Results are bit-identical. */
+int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
+/* Same choice for the level-preparation kernel (Lsmooth, Lflow of a level). */
+int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
 /* name of the default FED kernel (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
 

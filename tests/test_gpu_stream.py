@@ -1,0 +1,80 @@
+"""The streaming (register-ring) kernels of akz_stream.hip against the CPU oracle and against the LDS-tiled
+kernels: every plane, keypoint and descriptor byte identical, for shapes that exercise the strip / band /
+edge-lane logic (widths that are not multiples of 4 or of the 240/248-pixel strips, several bands, batches)."""
+import numpy as np
+import pytest
+
+from test_gpu_extract import PLANES, assert_same_result
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def sctx(amd):
+    """A context with both streaming paths forced on (mode 1), so that small test images take them too."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_detector_mode(1)
+    c.set_prep_mode(1)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("w,h,idx", [(320, 240, 0), (517, 389, 2), (249, 131, 3), (1001, 300, 4)])
+def test_stream_extract_matches_oracle_all_planes(sctx, amd, ref, w, h, idx):
+    frame = amd.synth_frame(w, h, idx)
+    assert_same_result(sctx.extract_features(frame), ref.extract(frame))
+
+
+def test_stream_batch_and_nondefault_config(sctx, amd, ref):
+    import torch
+    frames = np.stack([amd.synth_frame(486, 270, i) for i in range(3)])
+    res = sctx.extract_features(torch.from_numpy(frames).cuda())
+    for i in range(3):
+        assert_same_result(res, ref.extract(frames[i]), planes=(i == 2), img=i)
+    frame = amd.synth_frame(640, 360, 7)
+    for kw in (dict(num_sublevels=5, max_octave_evolution=5), dict(detector_threshold=0.0005, num_sublevels=3)):
+        assert_same_result(sctx.extract_features(frame, amd.Config(**kw)), ref.extract(frame, ref.default_config(**kw)),
+                           planes=False)
+
+
+@pytest.mark.parametrize("sigma", [1, 2, 3, 4])
+def test_stream_detector_response_op(sctx, ref, sigma):
+    import torch
+    rng = np.random.default_rng(40 + sigma)
+    for (h, w) in ((96, 130), (70, 517)):
+        ls = rng.random((h, w), dtype=np.float32)
+        got = sctx.detector_response(torch.from_numpy(ls).cuda(), sigma)
+        lx = ref.scharr(ls, True, False, sigma)
+        ly = ref.scharr(ls, False, True, sigma)
+        exp = {"Lx": lx, "Ly": ly, "Lxx": ref.scharr(lx, True, False, sigma), "Lyy": ref.scharr(ly, False, True, sigma),
+               "Lxy": ref.scharr(lx, False, True, sigma)}
+        exp["Ldet"] = ((exp["Lxx"] * exp["Lyy"]) - (exp["Lxy"] * exp["Lxy"])) * np.float32(sigma ** 4)
+        for k, v in exp.items():
+            assert np.array_equal(got[k].cpu().numpy().reshape(h, w), v), (sigma, w, h, k)
+        lean = sctx.detector_response(torch.from_numpy(ls).cuda(), sigma, keep_second=False)
+        assert np.array_equal(lean["Ldet"].cpu().numpy().reshape(h, w), exp["Ldet"])
+
+
+def test_stream_equals_tiled_on_1080p_batch(ctx, sctx, amd):
+    """Full-size property check (the oracle would take minutes): both kernel families give the same bytes."""
+    import torch
+    frames = torch.from_numpy(np.stack([amd.synth_frame(1920, 1080, 20 + i) for i in range(4)])).cuda()
+    ctx.set_detector_mode(0)
+    ctx.set_prep_mode(0)
+    try:
+        a = ctx.extract_features(frames)
+    finally:
+        ctx.set_detector_mode(2)
+        ctx.set_prep_mode(2)
+    b = sctx.extract_features(frames)
+    d = ctx.extract_features(frames)  # the default (automatic) choice
+    for i in range(4):
+        assert a.counts(i) == b.counts(i) == d.counts(i) and a.counts(i)[1] > 1000
+        assert a.keypoints(i).tobytes() == b.keypoints(i).tobytes() == d.keypoints(i).tobytes()
+        assert np.array_equal(a.descriptors(i), b.descriptors(i)) and np.array_equal(a.descriptors(i), d.descriptors(i))
+    for lvl in (0, 1, 3, 4, 9, 15):
+        for pl in PLANES:
+            x = a.plane(lvl, pl, 1)
+            assert np.array_equal(x, b.plane(lvl, pl, 1)), (lvl, pl)
+            assert np.array_equal(x, d.plane(lvl, pl, 1)), (lvl, pl)

@@ -675,48 +675,59 @@ constexpr OriTable make_ori_table() {
 }
 __constant__ OriTable c_ori = make_ori_table();
 
-constexpr int ORI_KPB = 4;  // keypoints (waves) per workgroup
-__global__ void __launch_bounds__(64 * ORI_KPB)
+// Workgroups are numbered so that each XCD (workgroup id mod 8) walks a CONTIGUOUS range of the keypoint
+// list: neighbours in the list are neighbours in the image, and their sample windows then share lines in
+// that XCD's L2 instead of being fetched once per XCD.  nb must be a multiple of 8.
+__device__ __forceinline__ unsigned xcd_contiguous_group(unsigned b, unsigned nb) {
+    return (b & 7u) * (nb >> 3) + (b >> 3);
+}
+
+// 32 keypoints per workgroup.  Phase 1: all 256 threads gather the 32 x 109 weighted samples into LDS.
+// Phase 2: the window sums are one strictly sequential chain of f32 adds per keypoint and component (the
+// sums are never reset between windows, scale_space_extrema.rs:298-328), so the first wave runs the 64
+// chains of the workgroup side by side -- lane 2j carries sum_x of keypoint j, lane 2j+1 its sum_y --
+// instead of spending a whole wave on the two chains of one keypoint.
+constexpr int ORI_KPB = 32, ORI_NS = 109, ORI_NT = 256;
+__global__ void __launch_bounds__(ORI_NT)
 k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, unsigned long long window_mask,
               unsigned n_windows, OrientOut* __restrict__ out) {
-    __shared__ float s_rx[ORI_KPB][112];
-    __shared__ float s_ry[ORI_KPB][112];
-    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const unsigned i = blockIdx.x * ORI_KPB + wv;
-    const bool live = i < nkp;
-    if (live) {
-        const KpParam kp = kps[i];
-        const LevelPtrs lv = tab.lv[kp.level];
-        const float* lx = lv.lx + (size_t)kp.img * lv.stride;
-        const float* ly = lv.ly + (size_t)kp.img * lv.stride;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const unsigned k = lane + 64u * r;
-            if (k < 109u) {
-                const int a = c_ori.a[k], b = c_ori.b[k];
-                const float fy = roundf(kp.yf + (float)b * kp.scale);
-                const float fx = roundf(kp.xf + (float)a * kp.scale);
-                const int iy = clampi(fy > 0.0f ? (int)fy : 0, 0, (int)lv.h - 1);
-                const int ix = clampi(fx > 0.0f ? (int)fx : 0, 0, (int)lv.w - 1);
-                const float g = c_gauss25[a < 0 ? -a : a][b < 0 ? -b : b];
-                const size_t p = (size_t)iy * lv.w + ix;
-                s_rx[wv][k] = g * lx[p];
-                s_ry[wv][k] = g * ly[p];
-            }
+    __shared__ float s_rx[ORI_KPB * ORI_NS];
+    __shared__ float s_ry[ORI_KPB * ORI_NS + 16];
+    const unsigned base = xcd_contiguous_group(blockIdx.x, gridDim.x) * ORI_KPB;
+    if (base >= nkp) return;  // whole workgroup
+    for (unsigned idx = threadIdx.x; idx < ORI_KPB * ORI_NS; idx += ORI_NT) {
+        const unsigned j = idx / ORI_NS, k = idx - j * ORI_NS;
+        float rx = 0.0f, ry = 0.0f;
+        if (base + j < nkp) {
+            const KpParam kp = kps[base + j];
+            const LevelPtrs lv = tab.lv[kp.level];
+            const float* lx = lv.lx + (size_t)kp.img * lv.stride;
+            const float* ly = lv.ly + (size_t)kp.img * lv.stride;
+            const int a = c_ori.a[k], b = c_ori.b[k];
+            const float fy = roundf(kp.yf + (float)b * kp.scale);
+            const float fx = roundf(kp.xf + (float)a * kp.scale);
+            const int iy = clampi(fy > 0.0f ? (int)fy : 0, 0, (int)lv.h - 1);
+            const int ix = clampi(fx > 0.0f ? (int)fx : 0, 0, (int)lv.w - 1);
+            const float g = c_gauss25[a < 0 ? -a : a][b < 0 ? -b : b];
+            const size_t p = (size_t)iy * lv.w + ix;
+            rx = g * lx[p];
+            ry = g * ly[p];
         }
+        s_rx[idx] = rx;
+        s_ry[idx] = ry;
     }
     __syncthreads();
-    if (!live) return;
-    const bool is_y = (lane & 1u) != 0;  // odd lanes carry sum_y, even lanes sum_x
+    if (threadIdx.x >= 64) return;
+    const unsigned lane = threadIdx.x, j = lane >> 1;
+    const bool is_y = (lane & 1u) != 0;
+    const float* py = s_ry + j * ORI_NS;
+    const float* pa = is_y ? py : s_rx + j * ORI_NS;
     float sum = 0.0f, maxv = 0.0f, bx = 0.0f, by = 0.0f;
     unsigned found = 0;
     for (unsigned wdw = 0; wdw < n_windows; ++wdw) {
         if ((window_mask >> wdw) & 1ull) {
-            for (int k = 0; k < 109; ++k) {
-                const float ry = s_ry[wv][k];
-                const float add = is_y ? ry : s_rx[wv][k];
-                if (ry > 0.0f) sum = sum + add;
-            }
+            for (int k = 0; k < ORI_NS; ++k)
+                if (py[k] > 0.0f) sum = sum + pa[k];
         }
         const float other = __shfl_xor(sum, 1, 64);
         const float sx = is_y ? other : sum, sy = is_y ? sum : other;
@@ -728,10 +739,10 @@ k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, uns
             found = 1;
         }
     }
-    if (lane == 0) {
+    if (!is_y && base + j < nkp) {
         OrientOut o;
         o.sum_x = bx; o.sum_y = by; o.found = found; o._pad = 0;
-        out[i] = o;
+        out[base + j] = o;
     }
 }
 
@@ -760,19 +771,24 @@ constexpr PairTable make_pairs() {
 }
 __constant__ PairTable c_pairs = make_pairs();
 
-// Four keypoints (waves) per workgroup.  Per grid, the 64 lanes of a wave first gather that grid's
-// samples in parallel (coordinates, three plane reads, rotation) into LDS in the reference's sample
-// order; then one lane per cell adds its samples sequentially in that order (f32 adds are not
-// associative), so the gathers are never on the serial path.
+// Four keypoints (waves) per workgroup.  The three grids sample the same rotated lattice: offsets
+// k, l in [-10, 10) for the 2x2 and 4x4 grids and [-10, 11) for the 3x3 grid, and a sample's
+// coordinates depend only on (k, l).  So the 64 lanes of a wave first gather the 21 x 21 lattice
+// once (coordinates, three plane reads, rotation) into LDS -- 441 gathers instead of the 1241 of a
+// per-grid evaluation -- and then one lane per cell (4 + 9 + 16 = 29 lanes, all grids at once) adds
+// its samples sequentially in the reference order (f32 adds are not associative), so the gathers
+// are never on the serial path.
+//
+// Workgroup numbering: xcd_contiguous_group, as in k_orientation.
 constexpr int MLDB_KPB = 4;
-constexpr int MLDB_MAXS = 448;  // >= 441 samples of the 3x3 grid
+constexpr int MLDB_LAT = 21, MLDB_NS = MLDB_LAT * MLDB_LAT;
 __global__ void __launch_bounds__(64 * MLDB_KPB)
 k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi, unsigned nkp,
        unsigned channels, uint8_t* __restrict__ desc64) {
-    __shared__ float s_buf[MLDB_KPB][3][MLDB_MAXS];
+    __shared__ float s_win[MLDB_KPB][3][MLDB_NS + 7];
     __shared__ float s_val[MLDB_KPB][3][32];
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const unsigned kpi = blockIdx.x * MLDB_KPB + wv;
+    const unsigned kpi = xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB + wv;
     const bool live = kpi < nkp;
     KpParam kp = kps[live ? kpi : 0];
     const float2 cs = cosi[live ? kpi : 0];
@@ -782,56 +798,57 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
     const float* Lx = lv.lx + ioff;
     const float* Ly = lv.ly + ioff;
     const float co = cs.x, si = cs.y, scale = kp.scale;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const int step = g == 0 ? 10 : (g == 1 ? 7 : 5);
-        const int ng = g + 2;
-        const int per_cell = step * step, ncell = ng * ng, nsamp = per_cell * ncell;
-        const int cell_base = g == 0 ? 0 : (g == 1 ? 4 : 13);
-        if (live) {
-            for (int sidx = (int)lane; sidx < nsamp; sidx += 64) {
-                const int ci = sidx / per_cell, t = sidx - ci * per_cell;
-                const int i0 = -10 + (ci / ng) * step, j0 = -10 + (ci % ng) * step;
-                const int k = i0 + t / step, l = j0 + t % step;  // k outer, l inner (descriptors.rs:108-109)
-                const float lf = (float)l + 0.5f, kf = (float)k + 0.5f;
-                const float sample_y = kp.yf + (lf * co * scale + kf * si * scale);
-                const float sample_x = kp.xf + (-lf * si * scale + kf * co * scale);
-                const int y1 = clampi((int)roundf(sample_y), 0, (int)lv.h - 1);
-                const int x1 = clampi((int)roundf(sample_x), 0, (int)lv.w - 1);
-                const size_t p = (size_t)y1 * lv.w + x1;
-                float v1 = 0.0f, v2 = 0.0f;
-                s_buf[wv][0][sidx] = Lt[p];
-                if (channels > 1) {
-                    const float rx = Lx[p], ry = Ly[p];
-                    if (channels == 2) {
-                        v1 = sqrtf(rx * rx + ry * ry);
-                    } else {
-                        v2 = rx * co + ry * si;   // rry -> dy
-                        v1 = -rx * si + ry * co;  // rrx -> dx
-                    }
+    if (live) {
+        for (int sidx = (int)lane; sidx < MLDB_NS; sidx += 64) {
+            const int kk = sidx / MLDB_LAT, ll = sidx - kk * MLDB_LAT;
+            const int k = kk - 10, l = ll - 10;
+            const float lf = (float)l + 0.5f, kf = (float)k + 0.5f;
+            const float sample_y = kp.yf + (lf * co * scale + kf * si * scale);
+            const float sample_x = kp.xf + (-lf * si * scale + kf * co * scale);
+            const int y1 = clampi((int)roundf(sample_y), 0, (int)lv.h - 1);
+            const int x1 = clampi((int)roundf(sample_x), 0, (int)lv.w - 1);
+            const size_t p = (size_t)y1 * lv.w + x1;
+            float v1 = 0.0f, v2 = 0.0f;
+            s_win[wv][0][sidx] = Lt[p];
+            if (channels > 1) {
+                const float rx = Lx[p], ry = Ly[p];
+                if (channels == 2) {
+                    v1 = sqrtf(rx * rx + ry * ry);
+                } else {
+                    v2 = rx * co + ry * si;   // rry -> dy
+                    v1 = -rx * si + ry * co;  // rrx -> dx
                 }
-                s_buf[wv][1][sidx] = v1;
-                s_buf[wv][2][sidx] = v2;
             }
+            s_win[wv][1][sidx] = v1;
+            s_win[wv][2][sidx] = v2;
         }
-        __syncthreads();
-        if (live && (int)lane < ncell) {
-            const float* b0 = &s_buf[wv][0][lane * per_cell];
-            const float* b1 = &s_buf[wv][1][lane * per_cell];
-            const float* b2 = &s_buf[wv][2][lane * per_cell];
-            float di = 0.0f, dx = 0.0f, dy = 0.0f;
-            for (int t = 0; t < per_cell; ++t) {
-                di = di + b0[t];
-                dx = dx + b1[t];
-                dy = dy + b2[t];
-            }
-            const float ns = (float)per_cell;
-            s_val[wv][0][cell_base + lane] = di / ns;
-            s_val[wv][1][cell_base + lane] = dx / ns;
-            s_val[wv][2][cell_base + lane] = dy / ns;
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    if (live && lane < 29) {
+        // cell ids 0..3: 2x2 grid (step 10), 4..12: 3x3 (step 7), 13..28: 4x4 (step 5)
+        const int g = lane < 4 ? 0 : (lane < 13 ? 1 : 2);
+        const int step = g == 0 ? 10 : (g == 1 ? 7 : 5), ng = g + 2;
+        const int ci = (int)lane - (g == 0 ? 0 : (g == 1 ? 4 : 13));
+        const int kk0 = (ci / ng) * step, ll0 = (ci % ng) * step;  // lattice origin of the cell
+        const int per_cell = step * step;
+        const float* b0 = &s_win[wv][0][0];
+        const float* b1 = &s_win[wv][1][0];
+        const float* b2 = &s_win[wv][2][0];
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        int dk = 0, dl = 0;  // k outer, l inner (descriptors.rs:108-109)
+        for (int t = 0; t < per_cell; ++t) {
+            const int o = (kk0 + dk) * MLDB_LAT + ll0 + dl;
+            di = di + b0[o];
+            dx = dx + b1[o];
+            dy = dy + b2[o];
+            if (++dl == step) { dl = 0; ++dk; }
+        }
+        const float ns = (float)per_cell;
+        s_val[wv][0][lane] = di / ns;
+        s_val[wv][1][lane] = dx / ns;
+        s_val[wv][2][lane] = dy / ns;
+    }
+    __syncthreads();
     // bit order: grid 0 (6 pairs), grid 1 (36), grid 2 (120); inside a grid channel-major
     const unsigned seg0 = 6u * channels, seg1 = seg0 + 36u * channels, total = seg1 + 120u * channels;
     unsigned long long words[8];
@@ -1076,14 +1093,16 @@ void nms(hipStream_t s, const float* ldet_p, uint32_t w, uint32_t h, uint32_t n,
 void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint32_t nkp,
                  unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out) {
     if (nkp == 0) return;
-    hipLaunchKernelGGL(k_orientation, dim3((nkp + ORI_KPB - 1) / ORI_KPB), dim3(64 * ORI_KPB), 0, s, lt, d_kp, nkp,
+    const uint32_t groups = (nkp + ORI_KPB - 1) / ORI_KPB;
+    hipLaunchKernelGGL(k_orientation, dim3((groups + 7u) / 8u * 8u), dim3(ORI_NT), 0, s, lt, d_kp, nkp,
                        window_mask, n_windows, d_out);
 }
 
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64) {
     if (nkp == 0) return;
-    hipLaunchKernelGGL(k_mldb, dim3((nkp + MLDB_KPB - 1) / MLDB_KPB), dim3(64 * MLDB_KPB), 0, s, lt, d_kp,
+    const uint32_t groups = (nkp + MLDB_KPB - 1) / MLDB_KPB;
+    hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp,
                        reinterpret_cast<const float2*>(d_cosi), nkp, channels, d_desc64);
 }
 uint32_t match_num_chunks(uint32_t n0, uint32_t n1) {

@@ -479,7 +479,7 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
 static bool use_stream_detector(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
                                 bool keep_second, bool nms = true) {
     if (c->det_mode == 0 || !launch::detector_stream_supported(sigma, w, h, border_m, nms)) return false;
-    if (c->det_mode == 1) return true;
+    if (c->det_mode == 1 || c->det_mode == 3) return true;
     return !keep_second && (uint64_t)w * h * n >= c->stream_min_px;
 }
 
@@ -491,8 +491,8 @@ static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float
     }
     AKZ_TRY(check_plane_args(lsmooth, ldet_out, w, h, n, (int)sigma));
     if (use_stream_detector(c, sigma, w, h, n, 0.0f, lxx && lyy && lxy, false)) {
-        launch::detector_stream(c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, 0, 0.0f, 0.0f,
-                                nullptr, 0, nullptr);
+        (c->det_mode == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+            c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, 0, 0.0f, 0.0f, nullptr, 0, nullptr);
         AKZ_HIP_TRY(hipGetLastError());
         return AKZ_OK;
     }
@@ -859,9 +859,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
         if (use_stream_detector(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
             StageTimer st(c, AKZ_ST_DETECTOR);
-            launch::detector_stream(s, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
-                                    P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr, bm,
-                                    d_cand, cap, d_count);
+            (c->det_mode == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+                s, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX), P(l, AKZ_LYY),
+                P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr, bm, d_cand, cap, d_count);
             continue;
         }
         if (launch::detector_nms_fused_supported(lv.det_sigma)) {
@@ -1382,7 +1382,7 @@ int akz_match_features(akz_ctx* c, const akz_keypoint* kp0, const uint8_t* d0, u
                                n_out);                                                                        // lib.rs:267-274
 }
 int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
+    if (!c || mode < 0 || mode > 3) return AKZ_ERR_INVALID_ARG;
     c->det_mode = mode;
     return AKZ_OK;
 }

@@ -124,6 +124,9 @@ bool detector_fused_supported(uint32_t sigma);
 void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n);
 // first + second derivatives, Ldet and the extrema candidates of one level in two launches
+void detector_fused_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
+                           float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
+                           float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 // streaming form of prep_fused (akz_stream.hip)
 bool prep_stream_supported(uint32_t w, uint32_t h);
 void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, float* lsmooth, float* lflow, uint32_t w,

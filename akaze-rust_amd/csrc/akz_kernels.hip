@@ -654,9 +654,9 @@ __constant__ float c_gauss25[7][7] = {
 // independent bit mask computed on the host with the host libm.  The running sums are never
 // reset (as in the reference).  The final atan2f is left to the host.
 // ---------------------------------------------------------------------------------------------
-// One wave per keypoint (4 keypoints per workgroup, all images in one launch): the 64 lanes gather the
-// 109 samples in two rounds into LDS, then lanes with even/odd index replay the sequential x / y
-// running sums (f32 adds in k order, as the reference) and exchange them once per window.
+// All images in one launch; the kernel (below) gathers the 109 weighted samples of 32 keypoints into LDS
+// and then replays the sequential x / y running sums (f32 adds in k order, as the reference), two lanes
+// per keypoint, exchanging the pair once per window.
 struct OriTable {
     signed char a[112], b[112];
 };

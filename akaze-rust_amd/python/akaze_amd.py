@@ -278,7 +278,7 @@ class Context:
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
 
     def set_detector_mode(self, mode):
-        """2 = automatic (default), 1 = streaming register-ring kernels wherever supported, 0 = LDS-tiled kernels."""
+        """2 = automatic (default), 1 = streaming kernel pair, 3 = fused streaming kernel, 0 = LDS-tiled kernels."""
         _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
 
     def set_prep_mode(self, mode):

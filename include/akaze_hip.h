@@ -314,8 +314,10 @@ int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
    per step.  Results are bit-identical. */
 int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
 /* Detector kernel variant: 2 (default) = automatic (streaming register-ring kernels for batches whose
-   second-derivative planes are not kept, LDS-tiled kernels otherwise); 1 = streaming wherever it is
-   supported (sigma_size <= 4); 0 = tiled only.  Results are bit-identical. */
+   second-derivative planes are not kept, LDS-tiled kernels otherwise); 1 = streaming pair (first /
+   second derivatives) wherever it is supported (sigma_size <= 4); 3 = the single fused streaming kernel
+   (least HBM traffic, but one wave per SIMD: slower than the pair on MI355X today); 0 = tiled only.
+   Results are bit-identical. */
 int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
 /* Same choice for the level-preparation kernel (Lsmooth, Lflow of a level). */
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);

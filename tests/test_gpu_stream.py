@@ -9,12 +9,13 @@ from test_gpu_extract import PLANES, assert_same_result
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def sctx(amd):
-    """A context with both streaming paths forced on (mode 1), so that small test images take them too."""
+@pytest.fixture(params=[1, 3], ids=["pair", "fused"])
+def sctx(amd, request):
+    """A context with the streaming paths forced on (detector: the two-kernel pair or the fused kernel), so that
+    small test images take them too."""
     import torch
     c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
-    c.set_detector_mode(1)
+    c.set_detector_mode(request.param)
     c.set_prep_mode(1)
     yield c
     c.close()

@@ -1,0 +1,11 @@
+#!/bin/bash
+# The workload table of DESIGN.md 4.4: bench.py over the other BASELINE shapes (run through gpurun from the repo root).
+J='import json,sys; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print("| %s | %.0f | %.2f ms | %.2f |" % (sys.argv[1], d["value"], d["ms_per_step"], r["frac"]))'
+run() { name=$1; shift; python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fed4k "$@" 2>/dev/null | grep '^{' | python3 -c "$J" "$name"; }
+run "32 x 1920x1080 per step (bench default)"
+run "32 x 1920x1080, second-derivative / Lstep planes not kept (--lean)" --lean
+run "1 x 1920x1080 per step" --frames 1
+run "8 x 3840x2160 per step" --width 3840 --height 2160 --frames 8
+run "1 x 3840x2160 per step" --width 3840 --height 2160 --frames 1
+run "8 x 3840x2160, 5 octaves x 5 sublevels" --width 3840 --height 2160 --frames 8 --sublevels 5 --octaves 5
+run "16 x 2016x1512 (size of the reference's test-data/1.jpg)" --width 2016 --height 1512 --frames 16

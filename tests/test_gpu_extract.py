@@ -180,3 +180,43 @@ def test_match_features_full_dropin(ctx, amd, ref):
     exp = ref.remove_outliers(q0.keypoints(), q1.keypoints(), raw, 1000, 0.05, 3.0)
     assert len(raw) >= 8 and np.array_equal(got, exp)
     assert set(got["index_0"].tolist()) <= set(raw["index_0"].tolist())
+
+
+def test_baseline_c4_batch_is_independent_per_image(ctx, amd, ref):
+    """BASELINE.json configs[3] (a batch of 1080p frames sharded one image per GPU slot): a frame's result does
+    not depend on what else is in the batch or where it sits, and equals the oracle's for a sampled frame."""
+    import torch
+    frames = np.stack([amd.synth_frame(1920, 1080, 100 + i) for i in range(6)])
+    batch = ctx.extract_features(torch.from_numpy(frames).cuda(), keep_all_planes=False)
+    rev = ctx.extract_features(torch.from_numpy(frames[::-1].copy()).cuda(), keep_all_planes=False)
+    for i in range(6):
+        single = ctx.extract_features(frames[i], keep_all_planes=False)
+        for other, j in ((batch, i), (rev, 5 - i)):
+            assert single.counts(0) == other.counts(j)
+            assert single.keypoints(0).tobytes() == other.keypoints(j).tobytes()
+            assert np.array_equal(single.descriptors(0), other.descriptors(j))
+            assert single.contrast(0) == other.contrast(j)
+    assert_same_result(batch, ref.extract(frames[3], threads=8), planes=False, img=3)
+
+
+def test_baseline_c5_4k_5x5_stream_all_pairs_match(ctx, amd, ref):
+    """BASELINE.json configs[4] on one GPU: 3840x2160 frames, 5 octaves x 5 sublevels, full 486-bit M-LDB,
+    then the all-pairs Hamming match over the gathered descriptor sets; everything identical to the oracle."""
+    import torch
+    kw = dict(num_sublevels=5, max_octave_evolution=5)
+    frames = np.stack([amd.synth_frame(3840, 2160, 7, shift=(s, s // 2)) for s in (0, 12, 24)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda(), amd.Config(**kw), keep_all_planes=False)
+    refs = [ref.extract(f, ref.default_config(**kw), threads=8) for f in frames]
+    for i, rf in enumerate(refs):
+        assert rf.num_levels == 25 and rf.desc_bytes == 61 and rf.num_keypoints > 3000
+        assert_same_result(res, rf, planes=False, img=i)
+    n_matches = 0
+    for i in range(3):
+        for j in range(3):
+            if i == j:
+                continue
+            got = ctx.descriptor_match(res.descriptors(i), res.descriptors(j), 10000, 0.86)
+            exp = ref.descriptor_match(refs[i].descriptors(), refs[j].descriptors(), 10000, 0.86)
+            assert np.array_equal(got, exp), (i, j)
+            n_matches += len(exp)
+    assert n_matches > 1000

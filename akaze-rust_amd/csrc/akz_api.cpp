@@ -1381,6 +1381,50 @@ int akz_match_features(akz_ctx* c, const akz_keypoint* kp0, const uint8_t* d0, u
     return akz_remove_outliers(kp0, n0, kp1, n1, raw.data(), n_raw, ransac_trials, 0.05f, ransac_epsilon_inliers, out,
                                n_out);                                                                        // lib.rs:267-274
 }
+// akaze::extract_features(input_image_path, options) — akaze/src/lib.rs:167-194
+int akz_extract_features_file(akz_ctx* c, const char* path, const akz_config* cfg, uint32_t flags, akz_result** out) {
+    if (!c || !path || !out) {
+        set_error("akz_extract_features_file: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    uint32_t w = 0, h = 0;
+    uint8_t* luma = nullptr;
+    AKZ_TRY(akz_image_load_luma(path, &w, &h, &luma));
+    const int st = akz_extract_gray_u8(c, luma, w, h, cfg, flags, out);
+    akz_image_free(luma);
+    return st;
+}
+
+// types::evolution::write_evolutions — evolution.rs:162-218 (file names: build_path, :162-167)
+int akz_write_evolutions(const akz_result* r, uint64_t img, const char* dir) {
+    if (!r || !dir) {
+        set_error("akz_write_evolutions: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    uint64_t n_levels = 0, nk = 0, nb = 0;
+    AKZ_TRY(akz_result_counts(r, img, &n_levels, &nk, &nb));
+    static const struct { akz_plane p; const char* label; } order[10] = {
+        {AKZ_LT, "Lt_"}, {AKZ_LSMOOTH, "Lsmooth_"}, {AKZ_LX, "Lx_"}, {AKZ_LY, "Ly_"}, {AKZ_LXX, "Lxx_"},
+        {AKZ_LYY, "Lyy_"}, {AKZ_LXY, "Lxy_"}, {AKZ_LFLOW, "Lflow_"}, {AKZ_LSTEP, "Lstep_"}, {AKZ_LDET, "Ldet_"}};
+    std::vector<float> buf;
+    for (uint64_t l = 0; l < n_levels; ++l) {
+        uint32_t w = 0, h = 0;
+        AKZ_TRY(akz_result_level_info(r, l, nullptr, nullptr, nullptr, nullptr, nullptr, &w, &h, nullptr, nullptr, 0));
+        for (const auto& o : order) {
+            uint64_t n_px = 0;
+            AKZ_TRY(akz_fetch_plane(r, img, l, o.p, nullptr, &n_px));
+            if (n_px == 0) continue;  // `save` skips 0x0 images
+            buf.resize(n_px);
+            AKZ_TRY(akz_fetch_plane(r, img, l, o.p, buf.data(), &n_px));
+            char name[64];
+            snprintf(name, sizeof(name), "%s%05llu.png", o.label, (unsigned long long)l);
+            const std::string path = std::string(dir) + "/" + name;
+            AKZ_TRY(akz_image_save_plane_png(path.c_str(), buf.data(), w, h));
+        }
+    }
+    return AKZ_OK;
+}
+
 int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 3) return AKZ_ERR_INVALID_ARG;
     c->det_mode = mode;

@@ -1,0 +1,903 @@
+// Image ingest and debug output around the GPU path (host code only).
+//
+//   * decode: what `image::open(path)` followed by `to_luma()` hands to create_unit_float_image
+//     (akaze/src/lib.rs:171-172, types/image.rs:127-140): JPEG (baseline and progressive Huffman, 8 bit),
+//     PNG (non-interlaced, every colour type / bit depth) and binary PNM.  The reference delegates this to
+//     the `image` 0.21 / `jpeg-decoder` / `png` crates, whose sources are not in the reference tree:
+//     PARITY UNPINNED for lossy input — the JPEG path below follows the published baseline algorithm with
+//     an stb-style integer IDCT, triangle-filter chroma upsampling and a float YCbCr->RGB conversion (what
+//     jpeg-decoder 0.1 is believed to do), and the luma weights 0.2126 / 0.7152 / 0.0722 (f32, truncated)
+//     that `image` 0.21 is believed to use.  Lossless formats decode exactly.
+//   * debug output: `save` / `normalize` (types/image.rs:168-197), `write_evolutions`
+//     (types/evolution.rs:162-218), `draw_circle` / `draw_line` / `blend` / `random_color`
+//     (types/image.rs:385-481), `draw_keypoints_to_image` (types/keypoint.rs:52-56), `draw_matches`
+//     (types/feature_match.rs:18-82), written as PNG through zlib.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "akz_internal.hpp"
+
+namespace akz {
+namespace img {
+
+struct Image {
+    uint32_t w = 0, h = 0, ch = 0;  // ch: 1 (luma) or 3 (RGB), 8 bit
+    std::vector<uint8_t> px;
+};
+
+static bool read_file(const char* path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return false; }
+    out.resize((size_t)n);
+    const size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    return got == (size_t)n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PNM (P5 / P6, maxval <= 255)
+// ------------------------------------------------------------------------------------------------
+static int decode_pnm(const std::vector<uint8_t>& d, Image& im) {
+    size_t p = 2;
+    auto next_int = [&](long& v) {
+        for (;;) {
+            while (p < d.size() && isspace(d[p])) ++p;
+            if (p < d.size() && d[p] == '#') { while (p < d.size() && d[p] != '\n') ++p; continue; }
+            break;
+        }
+        if (p >= d.size() || !isdigit(d[p])) return false;
+        v = 0;
+        while (p < d.size() && isdigit(d[p])) { v = v * 10 + (d[p] - '0'); if (v > (1L << 30)) return false; ++p; }
+        return true;
+    };
+    long w, h, mv;
+    if (!next_int(w) || !next_int(h) || !next_int(mv) || w <= 0 || h <= 0 || mv <= 0 || mv > 255) {
+        set_error("image: malformed PNM header");
+        return AKZ_ERR_IO;
+    }
+    ++p;  // single whitespace after maxval
+    im.w = (uint32_t)w; im.h = (uint32_t)h; im.ch = d[1] == '5' ? 1 : 3;
+    const size_t n = (size_t)w * h * im.ch;
+    if (p + n > d.size()) { set_error("image: truncated PNM data"); return AKZ_ERR_IO; }
+    im.px.assign(d.begin() + p, d.begin() + p + n);
+    if (mv != 255) for (auto& v : im.px) v = (uint8_t)((unsigned)v * 255u / (unsigned)mv);
+    return AKZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PNG (non-interlaced)
+// ------------------------------------------------------------------------------------------------
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+static int decode_png(const std::vector<uint8_t>& d, Image& im) {
+    size_t p = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    bool end = false;
+    while (!end && p + 12 <= d.size()) {
+        const uint32_t len = be32(&d[p]);
+        const char* type = (const char*)&d[p + 4];
+        if (p + 12 + (size_t)len > d.size()) { set_error("image: truncated PNG chunk"); return AKZ_ERR_IO; }
+        const uint8_t* body = &d[p + 8];
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            end = true;
+        }
+        p += 12 + (size_t)len;
+    }
+    const int nch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!w || !h || !nch || w > (1u << 16) || h > (1u << 16) || (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) ||
+        (ctype == 3 && (depth == 16 || plte.size() < 3)) || ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8)) {
+        set_error("image: unsupported or malformed PNG header");
+        return AKZ_ERR_IO;
+    }
+    if (interlace) { set_error("image: interlaced PNG is not supported"); return AKZ_ERR_UNSUPPORTED; }
+    const size_t bpp_bits = (size_t)nch * depth, stride = (w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) {
+        set_error("image: PNG inflate failed");
+        return AKZ_ERR_IO;
+    }
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    im.w = w; im.h = h; im.ch = (ctype == 0 || ctype == 4) ? 1 : 3;
+    im.px.resize((size_t)w * h * im.ch);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* line = &raw[(stride + 1) * y];
+        const int ft = line[0];
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred = 0;
+            switch (ft) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: {
+                    const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                } break;
+                default: set_error("image: bad PNG filter type"); return AKZ_ERR_IO;
+            }
+            cur[i] = (uint8_t)(line[1 + i] + pred);
+        }
+        auto sample = [&](size_t idx) -> unsigned {  // idx-th sample of the row, scaled to 8 bit (palette: index)
+            if (depth == 8) return cur[idx];
+            if (depth == 16) return cur[2 * idx];
+            const unsigned per = 8 / depth, v = (cur[idx / per] >> ((per - 1 - idx % per) * depth)) & ((1u << depth) - 1);
+            return ctype == 3 ? v : v * 255u / ((1u << depth) - 1);
+        };
+        uint8_t* o = &im.px[(size_t)y * w * im.ch];
+        for (uint32_t x = 0; x < w; ++x) {
+            if (ctype == 0 || ctype == 4) {
+                o[x] = (uint8_t)sample((size_t)x * nch);
+            } else if (ctype == 3) {
+                const unsigned idx = sample(x);
+                if (3 * idx + 2 >= plte.size()) { set_error("image: PNG palette index out of range"); return AKZ_ERR_IO; }
+                o[3 * x] = plte[3 * idx]; o[3 * x + 1] = plte[3 * idx + 1]; o[3 * x + 2] = plte[3 * idx + 2];
+            } else {
+                for (int k = 0; k < 3; ++k) o[3 * x + k] = (uint8_t)sample((size_t)x * nch + k);
+            }
+        }
+        prev.swap(cur);
+    }
+    return AKZ_OK;
+}
+
+int encode_png(const char* path, const uint8_t* data, uint32_t w, uint32_t h, uint32_t ch) {
+    if (!path || !data || !w || !h || (ch != 1 && ch != 3)) { set_error("save_png: bad arguments"); return AKZ_ERR_INVALID_ARG; }
+    const size_t stride = (size_t)w * ch;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        raw[(stride + 1) * y] = 0;
+        memcpy(&raw[(stride + 1) * y + 1], data + stride * y, stride);
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { set_error("save_png: deflate failed"); return AKZ_ERR_IO; }
+    FILE* f = fopen(path, "wb");
+    if (!f) { set_error("save_png: cannot open output file"); return AKZ_ERR_IO; }
+    auto chunk = [&](const char* type, const uint8_t* body, uint32_t len) {
+        uint8_t hd[8] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len,
+                         (uint8_t)type[0], (uint8_t)type[1], (uint8_t)type[2], (uint8_t)type[3]};
+        uLong crc = crc32(0L, hd + 4, 4);
+        if (len) crc = crc32(crc, body, len);
+        const uint8_t tl[4] = {(uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+        fwrite(hd, 1, 8, f);
+        if (len) fwrite(body, 1, len, f);
+        fwrite(tl, 1, 4, f);
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    const uint8_t ihdr[13] = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w,
+                              (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h,
+                              8, (uint8_t)(ch == 1 ? 0 : 2), 0, 0, 0};
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), (uint32_t)clen);
+    chunk("IEND", nullptr, 0);
+    const bool ok = !ferror(f);
+    fclose(f);
+    if (!ok) { set_error("save_png: write failed"); return AKZ_ERR_IO; }
+    return AKZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// JPEG: baseline (SOF0/SOF1) and progressive (SOF2) Huffman, 8-bit, 1 or 3 components
+// ------------------------------------------------------------------------------------------------
+namespace jpg {
+
+static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+    bool present = false;
+    uint8_t counts[17] = {0};
+    uint8_t symbols[256] = {0};
+    int mincode[17], maxcode[18], valptr[17];
+    void build() {
+        int code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            valptr[len] = k;
+            mincode[len] = code;
+            code += counts[len];
+            k += counts[len];
+            maxcode[len] = counts[len] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        present = true;
+    }
+};
+
+struct Component {
+    int id = 0, h = 1, v = 1, tq = 0;
+    int bw = 0, bh = 0;          // blocks per row / column, padded to whole MCUs
+    int cw = 0, chh = 0;         // blocks per row / column actually covering the component (non-interleaved scans)
+    int dc_pred = 0, td = 0, ta = 0;
+    std::vector<int16_t> coef;   // bw * bh * 64, natural order
+    std::vector<uint8_t> plane;  // (bw*8) x (bh*8)
+};
+
+struct Decoder {
+    const uint8_t* d;
+    size_t n, p = 0;
+    uint16_t qt[4][64];
+    bool qt_present[4] = {false, false, false, false};
+    Huff hdc[4], hac[4];
+    std::vector<Component> comp;
+    int width = 0, height = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
+    bool progressive = false, have_frame = false;
+    int restart_interval = 0;
+    // entropy-coded segment reader
+    uint32_t bitbuf = 0;
+    int bitcnt = 0;
+    bool hit_marker = false;
+    int eobrun = 0;
+
+    int fail(const char* m) { set_error(m); return AKZ_ERR_IO; }
+
+    void reset_bits() { bitbuf = 0; bitcnt = 0; hit_marker = false; }
+    void fill() {
+        while (bitcnt <= 24) {
+            uint32_t b = 0;
+            if (!hit_marker && p < n) {
+                b = d[p];
+                if (b == 0xff) {
+                    const uint8_t nx = p + 1 < n ? d[p + 1] : 0xd9;
+                    if (nx == 0) p += 2;
+                    else { hit_marker = true; b = 0; }  // leave p on the marker; feed zeros
+                } else {
+                    ++p;
+                }
+            }
+            bitbuf |= b << (24 - bitcnt);
+            bitcnt += 8;
+        }
+    }
+    int get_bits(int k) {
+        if (k == 0) return 0;
+        if (bitcnt < k) fill();
+        const int v = (int)(bitbuf >> (32 - k));
+        bitbuf <<= k;
+        bitcnt -= k;
+        return v;
+    }
+    int get_bit() { return get_bits(1); }
+    int decode_huff(const Huff& h) {
+        if (bitcnt < 16) fill();
+        int code = 0;
+        for (int len = 1; len <= 16; ++len) {
+            code = (code << 1) | (int)(bitbuf >> 31);
+            bitbuf <<= 1;
+            --bitcnt;
+            if (h.maxcode[len] >= 0 && code <= h.maxcode[len] && code >= h.mincode[len]) return h.symbols[h.valptr[len] + code - h.mincode[len]];
+        }
+        return -1;
+    }
+    static int extend(int v, int t) { return t && v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+    int parse_dqt(size_t end) {
+        while (p < end) {
+            const int pq = d[p] >> 4, tq = d[p] & 15;
+            ++p;
+            if (tq > 3 || pq > 1 || p + (pq ? 128 : 64) > end) return fail("jpeg: bad DQT");
+            for (int i = 0; i < 64; ++i) {
+                qt[tq][kZigzag[i]] = pq ? (uint16_t)((d[p] << 8) | d[p + 1]) : d[p];
+                p += pq ? 2 : 1;
+            }
+            qt_present[tq] = true;
+        }
+        return AKZ_OK;
+    }
+    int parse_dht(size_t end) {
+        while (p < end) {
+            const int tc = d[p] >> 4, th = d[p] & 15;
+            ++p;
+            if (tc > 1 || th > 3 || p + 16 > end) return fail("jpeg: bad DHT");
+            Huff& h = tc ? hac[th] : hdc[th];
+            int total = 0;
+            h.counts[0] = 0;
+            for (int i = 1; i <= 16; ++i) { h.counts[i] = d[p + i - 1]; total += h.counts[i]; }
+            p += 16;
+            if (total > 256 || p + total > end) return fail("jpeg: bad DHT");
+            memcpy(h.symbols, d + p, total);
+            p += total;
+            h.build();
+        }
+        return AKZ_OK;
+    }
+    int parse_sof(size_t end, bool prog) {
+        if (have_frame || p + 6 > end) return fail("jpeg: bad SOF");
+        if (d[p] != 8) { set_error("jpeg: only 8-bit precision is supported"); return AKZ_ERR_UNSUPPORTED; }
+        height = (d[p + 1] << 8) | d[p + 2];
+        width = (d[p + 3] << 8) | d[p + 4];
+        const int nc = d[p + 5];
+        p += 6;
+        if (!width || !height) return fail("jpeg: zero image size");
+        if (nc != 1 && nc != 3) { set_error("jpeg: only 1- and 3-component images are supported"); return AKZ_ERR_UNSUPPORTED; }
+        if (p + 3 * (size_t)nc > end) return fail("jpeg: bad SOF");
+        comp.resize(nc);
+        for (int i = 0; i < nc; ++i) {
+            comp[i].id = d[p]; comp[i].h = d[p + 1] >> 4; comp[i].v = d[p + 1] & 15; comp[i].tq = d[p + 2];
+            p += 3;
+            if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4 || comp[i].tq > 3) return fail("jpeg: bad component");
+            hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v);
+        }
+        if (nc == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }
+        mcux = (width + 8 * hmax - 1) / (8 * hmax);
+        mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+        for (auto& c : comp) {
+            c.bw = mcux * c.h; c.bh = mcuy * c.v;
+            const int cwpx = (width * c.h + hmax - 1) / hmax, chpx = (height * c.v + vmax - 1) / vmax;
+            c.cw = (cwpx + 7) / 8; c.chh = (chpx + 7) / 8;
+            if ((size_t)c.bw * c.bh > (1u << 24)) return fail("jpeg: image too large");
+            c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+        }
+        progressive = prog;
+        have_frame = true;
+        return AKZ_OK;
+    }
+
+    // one 8x8 block of a scan
+    int block_baseline(Component& c, int16_t* blk) {
+        const int t = decode_huff(hdc[c.td]);
+        if (t < 0 || t > 11) return fail("jpeg: bad DC code");
+        c.dc_pred += extend(get_bits(t), t);
+        blk[0] = (int16_t)c.dc_pred;
+        for (int k = 1; k < 64;) {
+            const int rs = decode_huff(hac[c.ta]);
+            if (rs < 0) return fail("jpeg: bad AC code");
+            const int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (r != 15) break;
+                k += 16;
+                continue;
+            }
+            k += r;
+            if (k > 63) return fail("jpeg: AC index overflow");
+            blk[kZigzag[k]] = (int16_t)extend(get_bits(s), s);
+            ++k;
+        }
+        return AKZ_OK;
+    }
+    int block_dc_prog(Component& c, int16_t* blk, int ah, int al) {
+        if (ah == 0) {
+            const int t = decode_huff(hdc[c.td]);
+            if (t < 0 || t > 11) return fail("jpeg: bad DC code");
+            c.dc_pred += extend(get_bits(t), t);
+            blk[0] = (int16_t)(c.dc_pred * (1 << al));
+        } else if (get_bit()) {
+            blk[0] = (int16_t)(blk[0] | (1 << al));
+        }
+        return AKZ_OK;
+    }
+    int block_ac_first(Component& c, int16_t* blk, int ss, int se, int al) {
+        if (eobrun > 0) { --eobrun; return AKZ_OK; }
+        for (int k = ss; k <= se;) {
+            const int rs = decode_huff(hac[c.ta]);
+            if (rs < 0) return fail("jpeg: bad AC code");
+            const int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (r < 15) {
+                    eobrun = (1 << r) - 1;
+                    if (r) eobrun += get_bits(r);
+                    break;
+                }
+                k += 16;
+                continue;
+            }
+            k += r;
+            if (k > 63) return fail("jpeg: AC index overflow");
+            blk[kZigzag[k]] = (int16_t)(extend(get_bits(s), s) * (1 << al));
+            ++k;
+        }
+        return AKZ_OK;
+    }
+    int block_ac_refine(Component& c, int16_t* blk, int ss, int se, int al) {
+        const int p1 = 1 << al, m1 = -(1 << al);
+        int k = ss;
+        if (eobrun <= 0) {
+            for (; k <= se;) {
+                const int rs = decode_huff(hac[c.ta]);
+                if (rs < 0) return fail("jpeg: bad AC code");
+                int r = rs >> 4;
+                const int s = rs & 15;
+                int value = 0;
+                if (s == 0) {
+                    if (r < 15) {
+                        eobrun = (1 << r);
+                        if (r) eobrun += get_bits(r);
+                        break;
+                    }
+                } else {
+                    if (s != 1) return fail("jpeg: bad refinement code");
+                    value = get_bit() ? p1 : m1;
+                }
+                while (k <= se) {
+                    int16_t& co = blk[kZigzag[k]];
+                    ++k;
+                    if (co != 0) {
+                        if (get_bit() && (co & p1) == 0) co = (int16_t)(co + (co >= 0 ? p1 : m1));
+                    } else {
+                        if (r == 0) {
+                            if (value) co = (int16_t)value;
+                            break;
+                        }
+                        --r;
+                    }
+                }
+            }
+        }
+        if (eobrun > 0) {
+            for (; k <= se; ++k) {
+                int16_t& co = blk[kZigzag[k]];
+                if (co != 0 && get_bit() && (co & p1) == 0) co = (int16_t)(co + (co >= 0 ? p1 : m1));
+            }
+            --eobrun;
+        }
+        return AKZ_OK;
+    }
+
+    int handle_restart(int& count) {
+        if (!restart_interval) return AKZ_OK;
+        if (++count < restart_interval) return AKZ_OK;
+        count = 0;
+        // byte-align, expect RSTn
+        reset_bits();
+        while (p + 1 < n && !(d[p] == 0xff && d[p + 1] >= 0xd0 && d[p + 1] <= 0xd7)) {
+            if (d[p] == 0xff && d[p + 1] != 0 && d[p + 1] != 0xff) return AKZ_OK;  // some other marker: end of scan data
+            ++p;
+        }
+        if (p + 1 < n) p += 2;
+        for (auto& c : comp) c.dc_pred = 0;
+        eobrun = 0;
+        return AKZ_OK;
+    }
+
+    int parse_sos(size_t end) {
+        if (!have_frame || p >= end) return fail("jpeg: SOS before SOF");
+        const int ns = d[p++];
+        if (ns < 1 || ns > (int)comp.size() || p + 2 * (size_t)ns + 3 > end) return fail("jpeg: bad SOS");
+        std::vector<Component*> sc;
+        for (int i = 0; i < ns; ++i) {
+            Component* c = nullptr;
+            for (auto& cc : comp) if (cc.id == d[p]) c = &cc;
+            if (!c) return fail("jpeg: unknown scan component");
+            c->td = d[p + 1] >> 4; c->ta = d[p + 1] & 15;
+            if (c->td > 3 || c->ta > 3) return fail("jpeg: bad table selector");
+            sc.push_back(c);
+            p += 2;
+        }
+        const int ss = d[p], se = d[p + 1], ah = d[p + 2] >> 4, al = d[p + 2] & 15;
+        p = end;
+        if (progressive) {
+            if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) return fail("jpeg: bad progressive scan");
+        }
+        for (auto* c : sc) {
+            c->dc_pred = 0;
+            const bool need_dc = !progressive || ss == 0, need_ac = !progressive || ss > 0;
+            if ((need_dc && !(progressive && ah) && !hdc[c->td].present) || (need_ac && !hac[c->ta].present)) return fail("jpeg: missing Huffman table");
+        }
+        reset_bits();
+        eobrun = 0;
+        int rcount = 0;
+        auto do_block = [&](Component& c, int bx, int by) -> int {
+            int16_t* blk = &c.coef[((size_t)by * c.bw + bx) * 64];
+            if (!progressive) return block_baseline(c, blk);
+            if (ss == 0) return block_dc_prog(c, blk, ah, al);
+            return ah == 0 ? block_ac_first(c, blk, ss, se, al) : block_ac_refine(c, blk, ss, se, al);
+        };
+        if (ns == 1) {  // non-interleaved: the component's own block grid
+            Component& c = *sc[0];
+            for (int by = 0; by < c.chh; ++by)
+                for (int bx = 0; bx < c.cw; ++bx) {
+                    AKZ_TRY(do_block(c, bx, by));
+                    AKZ_TRY(handle_restart(rcount));
+                }
+        } else {
+            for (int my = 0; my < mcuy; ++my)
+                for (int mx = 0; mx < mcux; ++mx) {
+                    for (auto* c : sc)
+                        for (int v = 0; v < c->v; ++v)
+                            for (int h = 0; h < c->h; ++h) AKZ_TRY(do_block(*c, mx * c->h + h, my * c->v + v));
+                    AKZ_TRY(handle_restart(rcount));
+                }
+        }
+        // continue marker parsing after the entropy-coded data
+        while (p + 1 < n && !(d[p] == 0xff && d[p + 1] != 0 && d[p + 1] != 0xff && !(d[p + 1] >= 0xd0 && d[p + 1] <= 0xd7))) ++p;
+        return AKZ_OK;
+    }
+
+    // stb-style integer IDCT of one dequantised block
+    static void idct(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) {
+        auto f2f = [](double x) { return (int)(x * 4096 + 0.5); };
+        static const int c0 = f2f(0.5411961), c1 = f2f(-1.847759065), c2 = f2f(0.765366865), c3 = f2f(1.175875602),
+                         c4 = f2f(0.298631336), c5 = f2f(2.053119869), c6 = f2f(3.072711026), c7 = f2f(1.501321110),
+                         c8 = f2f(-0.899976223), c9 = f2f(-2.562915447), c10 = f2f(-1.961570560), c11 = f2f(-0.390180644);
+        int val[64];
+        auto pass = [&](int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int (&x)[4], int (&t)[4]) {
+            int p2 = s2, p3 = s6;
+            int p1 = (p2 + p3) * c0;
+            int t2 = p1 + p3 * c1, t3 = p1 + p2 * c2;
+            p2 = s0; p3 = s4;
+            int t0 = (p2 + p3) * 4096, t1 = (p2 - p3) * 4096;
+            x[0] = t0 + t3; x[3] = t0 - t3; x[1] = t1 + t2; x[2] = t1 - t2;
+            t0 = s7; t1 = s5; t2 = s3; t3 = s1;
+            p3 = t0 + t2;
+            int p4 = t1 + t3;
+            p1 = t0 + t3; p2 = t1 + t2;
+            const int p5 = (p3 + p4) * c3;
+            t0 = t0 * c4; t1 = t1 * c5; t2 = t2 * c6; t3 = t3 * c7;
+            p1 = p5 + p1 * c8; p2 = p5 + p2 * c9; p3 = p3 * c10; p4 = p4 * c11;
+            t[3] = t3 + p1 + p4; t[2] = t2 + p2 + p3; t[1] = t1 + p2 + p4; t[0] = t0 + p1 + p3;
+        };
+        int dq[64];
+        for (int i = 0; i < 64; ++i) dq[i] = in[i] * (int)q[i];
+        for (int i = 0; i < 8; ++i) {  // columns
+            const int* dcol = dq + i;
+            int* v = val + i;
+            if (!dcol[8] && !dcol[16] && !dcol[24] && !dcol[32] && !dcol[40] && !dcol[48] && !dcol[56]) {
+                const int dc = dcol[0] * 4;
+                for (int r = 0; r < 8; ++r) v[r * 8] = dc;
+                continue;
+            }
+            int x[4], t[4];
+            pass(dcol[0], dcol[8], dcol[16], dcol[24], dcol[32], dcol[40], dcol[48], dcol[56], x, t);
+            for (int k = 0; k < 4; ++k) x[k] += 512;
+            v[0] = (x[0] + t[3]) >> 10; v[56] = (x[0] - t[3]) >> 10;
+            v[8] = (x[1] + t[2]) >> 10; v[48] = (x[1] - t[2]) >> 10;
+            v[16] = (x[2] + t[1]) >> 10; v[40] = (x[2] - t[1]) >> 10;
+            v[24] = (x[3] + t[0]) >> 10; v[32] = (x[3] - t[0]) >> 10;
+        }
+        auto clamp8 = [](int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); };
+        for (int i = 0; i < 8; ++i) {  // rows
+            const int* v = val + 8 * i;
+            uint8_t* o = out + (size_t)i * stride;
+            int x[4], t[4];
+            pass(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], x, t);
+            for (int k = 0; k < 4; ++k) x[k] += 65536 + (128 << 17);
+            o[0] = clamp8((x[0] + t[3]) >> 17); o[7] = clamp8((x[0] - t[3]) >> 17);
+            o[1] = clamp8((x[1] + t[2]) >> 17); o[6] = clamp8((x[1] - t[2]) >> 17);
+            o[2] = clamp8((x[2] + t[1]) >> 17); o[5] = clamp8((x[2] - t[1]) >> 17);
+            o[3] = clamp8((x[3] + t[0]) >> 17); o[4] = clamp8((x[3] - t[0]) >> 17);
+        }
+    }
+
+    int run(Image& im) {
+        if (n < 4 || d[0] != 0xff || d[1] != 0xd8) return fail("jpeg: missing SOI");
+        p = 2;
+        bool eoi = false;
+        while (!eoi && p + 1 < n) {
+            if (d[p] != 0xff) { ++p; continue; }
+            const uint8_t m = d[p + 1];
+            if (m == 0xff) { ++p; continue; }
+            p += 2;
+            if (m == 0xd9) { eoi = true; break; }
+            if (m == 0x01 || (m >= 0xd0 && m <= 0xd7) || m == 0x00) continue;
+            if (p + 2 > n) break;
+            const size_t len = ((size_t)d[p] << 8) | d[p + 1];
+            if (len < 2 || p + len > n) return fail("jpeg: bad segment length");
+            const size_t end = p + len;
+            p += 2;
+            switch (m) {
+                case 0xdb: AKZ_TRY(parse_dqt(end)); break;
+                case 0xc4: AKZ_TRY(parse_dht(end)); break;
+                case 0xc0: case 0xc1: AKZ_TRY(parse_sof(end, false)); break;
+                case 0xc2: AKZ_TRY(parse_sof(end, true)); break;
+                case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb: case 0xcd: case 0xce: case 0xcf:
+                    set_error("jpeg: lossless / hierarchical / arithmetic coding is not supported");
+                    return AKZ_ERR_UNSUPPORTED;
+                case 0xdd:
+                    if (len < 4) return fail("jpeg: bad DRI");
+                    restart_interval = (d[p] << 8) | d[p + 1];
+                    break;
+                case 0xda: AKZ_TRY(parse_sos(end)); continue;  // p already sits on the next marker
+                default: break;
+            }
+            p = end;
+        }
+        if (!have_frame) return fail("jpeg: no frame");
+        // dequantise + IDCT into padded component planes
+        for (auto& c : comp) {
+            if (!qt_present[c.tq]) return fail("jpeg: missing quantisation table");
+            const int pw = c.bw * 8;
+            c.plane.assign((size_t)pw * c.bh * 8, 0);
+            for (int by = 0; by < c.bh; ++by)
+                for (int bx = 0; bx < c.bw; ++bx)
+                    idct(&c.coef[((size_t)by * c.bw + bx) * 64], qt[c.tq], &c.plane[(size_t)by * 8 * pw + bx * 8], pw);
+            std::vector<int16_t>().swap(c.coef);
+        }
+        im.w = (uint32_t)width; im.h = (uint32_t)height;
+        if (comp.size() == 1) {
+            im.ch = 1;
+            im.px.resize((size_t)width * height);
+            const int pw = comp[0].bw * 8;
+            for (int y = 0; y < height; ++y) memcpy(&im.px[(size_t)y * width], &comp[0].plane[(size_t)y * pw], width);
+            return AKZ_OK;
+        }
+        // chroma upsampling (triangle filter for 2x, nearest otherwise) + YCbCr -> RGB
+        im.ch = 3;
+        im.px.resize((size_t)width * height * 3);
+        std::vector<std::vector<uint8_t>> rows(3, std::vector<uint8_t>((size_t)width + 16));
+        for (int y = 0; y < height; ++y) {
+            for (int ci = 0; ci < 3; ++ci) {
+                const Component& c = comp[ci];
+                const int pw = c.bw * 8;
+                const int sh = hmax / c.h, sv = vmax / c.v;
+                const int cwpx = (width * c.h + hmax - 1) / hmax, chpx = (height * c.v + vmax - 1) / vmax;
+                uint8_t* o = rows[ci].data();
+                if (sh == 1 && sv == 1) {
+                    memcpy(o, &c.plane[(size_t)y * pw], width);
+                } else if (sh == 2 && (sv == 1 || sv == 2) && hmax % c.h == 0 && vmax % c.v == 0) {
+                    int yn = y, yf = y;
+                    if (sv == 2) {
+                        yn = y >> 1;
+                        yf = (y & 1) ? std::min(yn + 1, chpx - 1) : std::max(yn - 1, 0);
+                    }
+                    const uint8_t* near_ = &c.plane[(size_t)yn * pw];
+                    const uint8_t* far_ = &c.plane[(size_t)yf * pw];
+                    if (sv == 1) {
+                        if (cwpx == 1) { o[0] = o[1] = near_[0]; }
+                        else {
+                            o[0] = near_[0];
+                            o[1] = (uint8_t)((near_[0] * 3 + near_[1] + 2) >> 2);
+                            for (int i = 1; i < cwpx - 1; ++i) {
+                                const int s = 3 * near_[i] + 2;
+                                o[2 * i] = (uint8_t)((s + near_[i - 1]) >> 2);
+                                o[2 * i + 1] = (uint8_t)((s + near_[i + 1]) >> 2);
+                            }
+                            o[2 * (cwpx - 1)] = (uint8_t)((near_[cwpx - 1] * 3 + near_[cwpx - 2] + 2) >> 2);
+                            o[2 * (cwpx - 1) + 1] = near_[cwpx - 1];
+                        }
+                    } else {
+                        if (cwpx == 1) { o[0] = o[1] = (uint8_t)((3 * near_[0] + far_[0] + 2) >> 2); }
+                        else {
+                            int t1 = 3 * near_[0] + far_[0], t0;
+                            o[0] = (uint8_t)((t1 + 2) >> 2);
+                            for (int i = 1; i < cwpx; ++i) {
+                                t0 = t1;
+                                t1 = 3 * near_[i] + far_[i];
+                                o[2 * i - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
+                                o[2 * i] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+                            }
+                            o[2 * cwpx - 1] = (uint8_t)((t1 + 2) >> 2);
+                        }
+                    }
+                } else {
+                    const int yy = std::min(y * c.v / vmax, chpx - 1);
+                    for (int x = 0; x < width; ++x) o[x] = c.plane[(size_t)yy * pw + std::min(x * c.h / hmax, cwpx - 1)];
+                }
+            }
+            uint8_t* o = &im.px[(size_t)y * width * 3];
+            auto clamp8 = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+            for (int x = 0; x < width; ++x) {
+                const float Y = (float)rows[0][x], cb = (float)rows[1][x] - 128.0f, cr = (float)rows[2][x] - 128.0f;
+                const float r = Y + 1.40200f * cr;
+                const float g = Y - 0.34414f * cb - 0.71414f * cr;
+                const float b = Y + 1.77200f * cb;
+                o[3 * x] = clamp8((int)(r + 0.5f));
+                o[3 * x + 1] = clamp8((int)(g + 0.5f));
+                o[3 * x + 2] = clamp8((int)(b + 0.5f));
+            }
+        }
+        return AKZ_OK;
+    }
+};
+
+}  // namespace jpg
+
+static int decode_jpeg(const std::vector<uint8_t>& d, Image& im) {
+    jpg::Decoder dec;
+    dec.d = d.data();
+    dec.n = d.size();
+    memset(dec.qt, 0, sizeof(dec.qt));
+    return dec.run(im);
+}
+
+int load(const char* path, Image& im) {
+    if (!path) { set_error("image: null path"); return AKZ_ERR_INVALID_ARG; }
+    std::vector<uint8_t> d;
+    if (!read_file(path, d)) { set_error(std::string("image: cannot read ") + path); return AKZ_ERR_IO; }
+    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (d.size() >= 8 && !memcmp(d.data(), png_sig, 8)) return decode_png(d, im);
+    if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d, im);
+    if (d.size() >= 3 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, im);
+    set_error("image: unrecognised format (JPEG, PNG and binary PNM are supported)");
+    return AKZ_ERR_UNSUPPORTED;
+}
+
+// DynamicImage::to_luma of `image` 0.21 (believed: f32 weights, truncating cast)
+void to_luma(const Image& im, std::vector<uint8_t>& out) {
+    if (im.ch == 1) { out = im.px; return; }
+    out.resize((size_t)im.w * im.h);
+    for (size_t i = 0; i < out.size(); ++i) {
+        const float l = 0.2126f * (float)im.px[3 * i] + 0.7152f * (float)im.px[3 * i + 1] + 0.0722f * (float)im.px[3 * i + 2];
+        out[i] = (uint8_t)l;
+    }
+}
+void to_rgb(const Image& im, std::vector<uint8_t>& out) {
+    if (im.ch == 3) { out = im.px; return; }
+    out.resize((size_t)im.w * im.h * 3);
+    for (size_t i = 0; i < (size_t)im.w * im.h; ++i) out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = im.px[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug drawing (types/image.rs:385-481)
+// ------------------------------------------------------------------------------------------------
+struct Rgb { uint8_t r, g, b; };
+// random_color(): a FRESH random::default() source per call, so every call returns the same three bytes
+// (types/image.rs:385-392).  The generator is the restated Xorshift128+ of akz_ransac.cpp (unverified).
+Rgb random_color() {
+    uint64_t s0 = 42, s1 = 69;
+    auto next = [&]() {
+        uint64_t x = s0;
+        const uint64_t y = s1;
+        s0 = y;
+        x ^= x << 23;
+        x ^= x >> 17;
+        x ^= y ^ (y >> 26);
+        s1 = x;
+        return x + y;
+    };
+    Rgb c;
+    c.r = (uint8_t)next(); c.g = (uint8_t)next(); c.b = (uint8_t)next();
+    return c;
+}
+static uint32_t f2u_sat(float v) { return v <= 0.0f || v != v ? 0u : (v >= 4294967295.0f ? 0xffffffffu : (uint32_t)v); }  // Rust `as u32`
+static uint8_t f2u8_sat(float v) { return v <= 0.0f || v != v ? 0 : (v >= 255.0f ? 255 : (uint8_t)v); }
+
+// Pixels outside the image are skipped (the reference's get_pixel_mut would panic there).
+void draw_circle(uint8_t* rgb, uint32_t w, uint32_t h, float px, float py, Rgb col, float radius) {
+    const uint32_t cx = f2u_sat(px), cy = f2u_sat(py), r = f2u_sat(radius);
+    const uint32_t x0 = cx >= r ? cx - r : 0, x1 = cx > 0xffffffffu - r ? 0xffffffffu : cx + r;
+    const uint32_t y0 = cy >= r ? cy - r : 0, y1 = cy > 0xffffffffu - r ? 0xffffffffu : cy + r;
+    for (uint32_t x = x0; x < x1 && x < w; ++x)
+        for (uint32_t y = y0; y < y1 && y < h; ++y) {
+            const float dx = (float)x - px, dy = (float)y - py;
+            if (sqrtf(dx * dx + dy * dy) <= radius) {
+                uint8_t* p = rgb + ((size_t)y * w + x) * 3;
+                p[0] = f2u8_sat(((float)col.r + (float)p[0]) / 2.0f);
+                p[1] = f2u8_sat(((float)col.g + (float)p[1]) / 2.0f);
+                p[2] = f2u8_sat(((float)col.b + (float)p[2]) / 2.0f);
+            }
+        }
+}
+void draw_line(uint8_t* rgb, uint32_t w, uint32_t h, float x0, float y0, float x1, float y1, Rgb col, float radius) {
+    const float dx = x1 - x0, dy = y1 - y0;
+    if (fabsf(dx) <= 1.0f && fabsf(dy) <= 1.0f) {
+        draw_circle(rgb, w, h, x0, y0, col, radius);
+        return;
+    }
+    const float m = dy / dx, b = y0 - m * x0;
+    const float xa = std::min(x0, x1), xn = std::max(x0, x1);
+    const float npts = std::max(std::max(fabsf(dx), fabsf(dy)), 2.0f);
+    const float step = fabsf(dx) / npts;
+    if (!(step > 0.0f)) {  // vertical line: the reference's `while x <= x_n` never advances; draw the segment once
+        draw_circle(rgb, w, h, x0, y0, col, radius);
+        return;
+    }
+    for (float x = xa; x <= xn; x += step) draw_circle(rgb, w, h, x, m * x + b, col, radius);
+}
+
+}  // namespace img
+}  // namespace akz
+
+using namespace akz;
+
+extern "C" {
+
+int akz_image_load(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t** pixels) {
+    if (!width || !height || !channels || !pixels) { set_error("akz_image_load: null output"); return AKZ_ERR_INVALID_ARG; }
+    img::Image im;
+    AKZ_TRY(img::load(path, im));
+    uint8_t* out = (uint8_t*)malloc(im.px.size() ? im.px.size() : 1);
+    if (!out) { set_error("akz_image_load: out of memory"); return AKZ_ERR_NO_MEMORY; }
+    memcpy(out, im.px.data(), im.px.size());
+    *width = im.w; *height = im.h; *channels = im.ch; *pixels = out;
+    return AKZ_OK;
+}
+
+int akz_image_load_luma(const char* path, uint32_t* width, uint32_t* height, uint8_t** luma) {
+    if (!width || !height || !luma) { set_error("akz_image_load_luma: null output"); return AKZ_ERR_INVALID_ARG; }
+    img::Image im;
+    AKZ_TRY(img::load(path, im));
+    std::vector<uint8_t> l;
+    img::to_luma(im, l);
+    uint8_t* out = (uint8_t*)malloc(l.size() ? l.size() : 1);
+    if (!out) { set_error("akz_image_load_luma: out of memory"); return AKZ_ERR_NO_MEMORY; }
+    memcpy(out, l.data(), l.size());
+    *width = im.w; *height = im.h; *luma = out;
+    return AKZ_OK;
+}
+
+int akz_image_load_rgb(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgb) {
+    if (!width || !height || !rgb) { set_error("akz_image_load_rgb: null output"); return AKZ_ERR_INVALID_ARG; }
+    img::Image im;
+    AKZ_TRY(img::load(path, im));
+    std::vector<uint8_t> c;
+    img::to_rgb(im, c);
+    uint8_t* out = (uint8_t*)malloc(c.size() ? c.size() : 1);
+    if (!out) { set_error("akz_image_load_rgb: out of memory"); return AKZ_ERR_NO_MEMORY; }
+    memcpy(out, c.data(), c.size());
+    *width = im.w; *height = im.h; *rgb = out;
+    return AKZ_OK;
+}
+
+void akz_image_free(void* pixels) { free(pixels); }
+
+int akz_image_save_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels) {
+    return img::encode_png(path, pixels, width, height, channels);
+}
+
+int akz_image_save_plane_png(const char* path, const float* plane, uint32_t width, uint32_t height) {
+    if (!path || (!plane && width && height)) { set_error("akz_image_save_plane_png: bad arguments"); return AKZ_ERR_INVALID_ARG; }
+    if (!width || !height) return AKZ_OK;  // `save` skips empty images (types/image.rs:192)
+    const size_t n = (size_t)width * height;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;  // f32::MAX / f32::MIN
+    for (size_t i = 0; i < n; ++i) {
+        if (plane[i] > mx) mx = plane[i];
+        if (plane[i] < mn) mn = plane[i];
+    }
+    const float range = mx - mn;
+    std::vector<uint8_t> out(n);
+    for (size_t i = 0; i < n; ++i) {
+        float p = plane[i];
+        p -= mn;
+        p /= range;
+        out[i] = img::f2u8_sat(p * 255.0f);  // `(*val * 255f32) as u8` saturates, NaN -> 0
+    }
+    return img::encode_png(path, out.data(), width, height, 1);
+}
+
+int akz_draw_keypoints(uint8_t* rgb, uint32_t width, uint32_t height, const akz_keypoint* kps, uint64_t n) {
+    if ((!rgb && width && height) || (!kps && n)) { set_error("akz_draw_keypoints: null argument"); return AKZ_ERR_INVALID_ARG; }
+    for (uint64_t i = 0; i < n; ++i) img::draw_circle(rgb, width, height, kps[i].x, kps[i].y, img::random_color(), kps[i].size);
+    return AKZ_OK;
+}
+
+int akz_draw_matches(const uint8_t* rgb0, uint32_t w0, uint32_t h0, const uint8_t* rgb1, uint32_t w1, uint32_t h1,
+                     const akz_keypoint* kp0, uint64_t n0, const akz_keypoint* kp1, uint64_t n1, const akz_match* matches,
+                     uint64_t n_matches, uint32_t* out_w, uint32_t* out_h, uint8_t** out_rgb) {
+    if (!rgb0 || !rgb1 || !out_w || !out_h || !out_rgb || (!matches && n_matches)) {
+        set_error("akz_draw_matches: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const uint32_t half = std::max(w0, w1), cw = 2 * half, ch = std::max(h0, h1);
+    const size_t out_bytes = (size_t)cw * ch * 3;
+    uint8_t* out = (uint8_t*)calloc(out_bytes > 0 ? out_bytes : 1, 1);
+    if (!out) { set_error("akz_draw_matches: out of memory"); return AKZ_ERR_NO_MEMORY; }
+    for (uint32_t y = 0; y < h0; ++y) memcpy(out + (size_t)y * cw * 3, rgb0 + (size_t)y * w0 * 3, (size_t)w0 * 3);
+    for (uint32_t y = 0; y < h1; ++y) memcpy(out + ((size_t)y * cw + half) * 3, rgb1 + (size_t)y * w1 * 3, (size_t)w1 * 3);
+    for (uint64_t i = 0; i < n_matches; ++i) {
+        if (matches[i].index_0 >= n0 || matches[i].index_1 >= n1) {
+            free(out);
+            set_error("akz_draw_matches: match index out of range");
+            return AKZ_ERR_INVALID_ARG;
+        }
+        const akz_keypoint& a = kp0[matches[i].index_0];
+        const akz_keypoint& b = kp1[matches[i].index_1];
+        img::draw_line(out, cw, ch, a.x, a.y, b.x + (float)cw / 2.0f, b.y, img::random_color(), (float)ch / 500.0f);
+    }
+    *out_w = cw; *out_h = ch; *out_rgb = out;
+    return AKZ_OK;
+}
+
+}  // extern "C"

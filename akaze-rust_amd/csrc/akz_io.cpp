@@ -355,4 +355,56 @@ int akz_read_matches(const char* path, akz_match* out, uint64_t cap, uint64_t* n
     return AKZ_OK;
 }
 
+// serde_json::to_string(&Config) / from_str (akaze-util/src/bin/extract_features.rs:66-83); field order and
+// names of types::evolution::Config (evolution.rs:8-38)
+int akz_config_to_json(const akz_config* cfg, char* buf, uint64_t cap, uint64_t* len) {
+    if (!cfg || !len) return AKZ_ERR_INVALID_ARG;
+    std::string s = "{\"num_sublevels\":" + std::to_string(cfg->num_sublevels) +
+                    ",\"max_octave_evolution\":" + std::to_string(cfg->max_octave_evolution) + ",\"base_scale_offset\":";
+    num(s, cfg->base_scale_offset);
+    s += ",\"initial_contrast\":";
+    num(s, cfg->initial_contrast);
+    s += ",\"contrast_percentile\":";
+    num(s, cfg->contrast_percentile);
+    s += ",\"contrast_factor_num_bins\":" + std::to_string(cfg->contrast_factor_num_bins) + ",\"derivative_factor\":";
+    num(s, cfg->derivative_factor);
+    s += ",\"detector_threshold\":";
+    num(s, cfg->detector_threshold);
+    s += ",\"descriptor_channels\":" + std::to_string(cfg->descriptor_channels) +
+         ",\"descriptor_pattern_size\":" + std::to_string(cfg->descriptor_pattern_size) + "}";
+    *len = s.size();
+    if (!buf || cap < s.size() + 1) return AKZ_ERR_BUFFER;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return AKZ_OK;
+}
+
+int akz_config_from_json(const char* json, akz_config* cfg) {
+    if (!json || !cfg) return AKZ_ERR_INVALID_ARG;
+    const std::string s(json);
+    Json j(s);
+    j.expect('{');
+    if (!j.eat('}')) {
+        do {
+            const std::string k = j.key();
+            if (k == "num_sublevels") cfg->num_sublevels = (uint32_t)j.number();
+            else if (k == "max_octave_evolution") cfg->max_octave_evolution = (uint32_t)j.number();
+            else if (k == "base_scale_offset") cfg->base_scale_offset = j.number();
+            else if (k == "initial_contrast") cfg->initial_contrast = j.number();
+            else if (k == "contrast_percentile") cfg->contrast_percentile = j.number();
+            else if (k == "contrast_factor_num_bins") cfg->contrast_factor_num_bins = (uint64_t)j.number();
+            else if (k == "derivative_factor") cfg->derivative_factor = j.number();
+            else if (k == "detector_threshold") cfg->detector_threshold = j.number();
+            else if (k == "descriptor_channels") cfg->descriptor_channels = (uint64_t)j.number();
+            else if (k == "descriptor_pattern_size") cfg->descriptor_pattern_size = (uint64_t)j.number();
+            else j.skip();
+        } while (j.ok && j.eat(','));
+        j.expect('}');
+    }
+    if (!j.ok) {
+        set_error("akz_config_from_json: malformed JSON");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    return AKZ_OK;
+}
+
 }  // extern "C"

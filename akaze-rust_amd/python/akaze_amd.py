@@ -155,6 +155,18 @@ def lib():
         "akz_write_matches": ([C.c_char_p, vp, u64], i32),
         "akz_read_matches": ([C.c_char_p, vp, u64, pu64], i32),
         "akz_host_select_keypoints": ([u32, u32, C.POINTER(Config), vp, u64, vp, u64, pu64, pu64], i32),
+        "akz_image_load": ([C.c_char_p, pu32, pu32, pu32, C.POINTER(vp)], i32),
+        "akz_image_load_luma": ([C.c_char_p, pu32, pu32, C.POINTER(vp)], i32),
+        "akz_image_load_rgb": ([C.c_char_p, pu32, pu32, C.POINTER(vp)], i32),
+        "akz_image_free": ([vp], None),
+        "akz_extract_features_file": ([vp, C.c_char_p, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_config_to_json": ([C.POINTER(Config), C.c_char_p, u64, pu64], i32),
+        "akz_config_from_json": ([C.c_char_p, C.POINTER(Config)], i32),
+        "akz_image_save_png": ([C.c_char_p, vp, u32, u32, u32], i32),
+        "akz_image_save_plane_png": ([C.c_char_p, vp, u32, u32], i32),
+        "akz_write_evolutions": ([vp, u64, C.c_char_p], i32),
+        "akz_draw_keypoints": ([vp, u32, u32, vp, u64], i32),
+        "akz_draw_matches": ([vp, u32, u32, vp, u32, u32, vp, u64, vp, u64, vp, u64, pu32, pu32, C.POINTER(vp)], i32),
         "akz_ctx_set_profiling": ([vp, i32], i32),
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
@@ -329,6 +341,14 @@ class Context:
             else:
                 raise ValueError("uint8 or float32 images only")
             _check(fn(self._h, C.c_void_p(t.data_ptr()), w, h, n, C.byref(options), flags, C.byref(res)))
+        return ExtractResult(self, res)
+
+    def extract_features_file(self, path, options=None, keep_all_planes=True):
+        """akaze::extract_features(input_image_path, options) — akaze/src/lib.rs:167-194."""
+        cfg = options or Config()
+        res = C.c_void_p()
+        _check(lib().akz_extract_features_file(self._h, os.fsencode(path), C.byref(cfg),
+                                               AKZ_KEEP_ALL_PLANES if keep_all_planes else 0, C.byref(res)))
         return ExtractResult(self, res)
 
     def extract_begin(self, frames, options=None, keep_all_planes=True, host_descriptors=True):
@@ -541,6 +561,11 @@ class ExtractResult:
                                                         C.byref(n)))
         return n.value
 
+    def write_evolutions(self, directory, img=0):
+        """types::evolution::write_evolutions: one normalised PNG per plane and level."""
+        os.makedirs(directory, exist_ok=True)
+        _check(lib().akz_write_evolutions(self._h, img, os.fsencode(directory)))
+
     def contrast(self, img=0):
         k = C.c_double()
         _check(lib().akz_result_contrast(self._h, img, C.byref(k)))
@@ -573,6 +598,80 @@ class ExtractResult:
 # module-level mirror of the reference's free functions
 # ------------------------------------------------------------------------------------------
 _default_ctx = None
+
+
+def _take(ptr, n, dtype=np.uint8):
+    """Copy n bytes out of a buffer the library allocated, then release it."""
+    try:
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)).copy().view(dtype)
+    finally:
+        lib().akz_image_free(ptr)
+
+
+def load_image(path):
+    """image::open(path): (h, w) uint8 for luma files, (h, w, 3) for colour ones."""
+    w, h, ch, px = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_void_p()
+    _check(lib().akz_image_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(ch), C.byref(px)))
+    a = _take(px, w.value * h.value * ch.value)
+    return a.reshape(h.value, w.value) if ch.value == 1 else a.reshape(h.value, w.value, 3)
+
+
+def load_image_luma(path):
+    """image::open(path).to_luma(): (h, w) uint8 — the input of create_unit_float_image."""
+    w, h, px = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    _check(lib().akz_image_load_luma(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    return _take(px, w.value * h.value).reshape(h.value, w.value)
+
+
+def load_image_rgb(path):
+    w, h, px = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    _check(lib().akz_image_load_rgb(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    return _take(px, w.value * h.value * 3).reshape(h.value, w.value, 3)
+
+
+def save_png(path, pixels):
+    a = np.ascontiguousarray(pixels, np.uint8)
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    _check(lib().akz_image_save_png(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], ch))
+
+
+def save_plane_png(path, plane):
+    """types::image::save: min/max normalise, scale to 8 bit, write."""
+    a = np.ascontiguousarray(plane, np.float32)
+    _check(lib().akz_image_save_plane_png(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0]))
+
+
+def config_to_json(cfg=None):
+    cfg = cfg or Config()
+    n = C.c_uint64()
+    buf = C.create_string_buffer(1024)
+    _check(lib().akz_config_to_json(C.byref(cfg), buf, 1024, C.byref(n)))
+    return buf.value.decode()
+
+
+def config_from_json(text, base=None):
+    cfg = base or Config()
+    _check(lib().akz_config_from_json(text.encode(), C.byref(cfg)))
+    return cfg
+
+
+def draw_keypoints(rgb, keypoints):
+    """types::keypoint::draw_keypoints: returns a new RGB image with the keypoints blended in."""
+    out = np.ascontiguousarray(rgb, np.uint8).copy()
+    kp = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE)
+    _check(lib().akz_draw_keypoints(out.ctypes.data, out.shape[1], out.shape[0], kp.ctypes.data, len(kp)))
+    return out
+
+
+def draw_matches(rgb0, rgb1, keypoints_0, keypoints_1, matches):
+    a, b = np.ascontiguousarray(rgb0, np.uint8), np.ascontiguousarray(rgb1, np.uint8)
+    k0, k1 = np.ascontiguousarray(keypoints_0, KEYPOINT_DTYPE), np.ascontiguousarray(keypoints_1, KEYPOINT_DTYPE)
+    m = np.ascontiguousarray(matches, MATCH_DTYPE)
+    w, h, px = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    _check(lib().akz_draw_matches(a.ctypes.data, a.shape[1], a.shape[0], b.ctypes.data, b.shape[1], b.shape[0],
+                                  k0.ctypes.data, len(k0), k1.ctypes.data, len(k1), m.ctypes.data, len(m),
+                                  C.byref(w), C.byref(h), C.byref(px)))
+    return _take(px, w.value * h.value * 3).reshape(h.value, w.value, 3)
 
 
 def default_context():

@@ -39,7 +39,9 @@ typedef enum akz_status {
     AKZ_ERR_TOO_SMALL = -4,    /* image smaller than the stencil supports                */
     AKZ_ERR_OVERFLOW = -5,     /* a fixed-capacity device buffer (candidates) overflowed */
     AKZ_ERR_UNSUPPORTED = -6,  /* reference behaviour that does not terminate / panics   */
-    AKZ_ERR_BUFFER = -7        /* caller buffer too small                                */
+    AKZ_ERR_BUFFER = -7,       /* caller buffer too small                                */
+    AKZ_ERR_IO = -8,           /* an image file cannot be read / written or is malformed */
+    AKZ_ERR_NO_MEMORY = -9     /* host allocation failed                                 */
 } akz_status;
 
 /* types::evolution::Config — akaze/src/types/evolution.rs:8-38 (defaults :40-55). */
@@ -323,6 +325,49 @@ int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
 /* name of the default FED kernel (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
+
+/* ---- image ingest, options files (host code) -------------------- */
+/* What `image::open(path)` hands to the crate (akaze/src/lib.rs:171): JPEG (baseline / progressive
+   Huffman, 8 bit, 1 or 3 components), PNG (non-interlaced) and binary PNM, decoded to 8-bit luma
+   (*channels = 1) or RGB (*channels = 3) as stored.  The pixel buffers returned by the akz_image_*
+   loaders are released with akz_image_free.  Decoding of lossy formats is not bit-pinned against the
+   `image` / `jpeg-decoder` crates (their sources are not in the reference tree). */
+int akz_image_load(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t** pixels);
+/* image::open(path).to_luma() — the input of create_unit_float_image (types/image.rs:127-140) */
+int akz_image_load_luma(const char* path, uint32_t* width, uint32_t* height, uint8_t** luma);
+/* image::open(path).to_rgb() — what the debug drawings are made on (extract_features.rs:94-96) */
+int akz_image_load_rgb(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgb);
+void akz_image_free(void* pixels);
+/* akaze::extract_features(input_image_path, options) — akaze/src/lib.rs:167-194: decode, to_luma,
+   unit float image, scale space, keypoints, descriptors.  Equivalent to akz_image_load_luma +
+   akz_extract_gray_u8. */
+int akz_extract_features_file(akz_ctx* ctx, const char* path, const akz_config* cfg, uint32_t flags, akz_result** out);
+/* serde_json form of Config (what `-o options.json` reads and writes, extract_features.rs:66-83).
+   to_json: writes a NUL-terminated string, *len = its length (AKZ_ERR_BUFFER if cap is too small, *len
+   then holds the size needed).  from_json: fields that are absent keep the value already in *cfg
+   (serde itself would reject the file: every field is required there). */
+int akz_config_to_json(const akz_config* cfg, char* buf, uint64_t cap, uint64_t* len);
+int akz_config_from_json(const char* json, akz_config* cfg);
+
+/* ---- debug output (host code) ----------------------------------- */
+/* 8-bit PNG, channels = 1 (luma) or 3 (RGB) */
+int akz_image_save_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels);
+/* types::image::save — normalize to [0,1] (min/max), `(v * 255) as u8`, write (types/image.rs:168-197);
+   a 0x0 plane writes nothing */
+int akz_image_save_plane_png(const char* path, const float* plane, uint32_t width, uint32_t height);
+/* types::evolution::write_evolutions (evolution.rs:162-218): Lt_00000.png ... Ldet_000NN.png of image `img`
+   into directory `dir` (must exist).  Needs a result extracted with AKZ_KEEP_ALL_PLANES to contain every
+   plane; planes that were not kept are skipped like the reference skips 0x0 images. */
+int akz_write_evolutions(const akz_result* res, uint64_t img, const char* dir);
+/* types::keypoint::draw_keypoints_to_image (keypoint.rs:52-56): blends a disc of radius `size` at every
+   keypoint into the RGB image.  random_color() builds a fresh random source per call, so every disc has the
+   same colour (image.rs:385-392).  Pixels outside the image are skipped (the reference would panic). */
+int akz_draw_keypoints(uint8_t* rgb, uint32_t width, uint32_t height, const akz_keypoint* kps, uint64_t n);
+/* types::feature_match::draw_matches (feature_match.rs:32-82): the two images side by side (each half as wide as
+   the wider one), one line per match.  *out_rgb is released with akz_image_free. */
+int akz_draw_matches(const uint8_t* rgb0, uint32_t w0, uint32_t h0, const uint8_t* rgb1, uint32_t w1, uint32_t h1,
+                     const akz_keypoint* kp0, uint64_t n0, const akz_keypoint* kp1, uint64_t n1,
+                     const akz_match* matches, uint64_t n_matches, uint32_t* out_w, uint32_t* out_h, uint8_t** out_rgb);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -526,40 +527,42 @@ struct Decoder {
         return AKZ_OK;
     }
 
-    // stb-style integer IDCT of one dequantised block
+    // stb-style integer IDCT of one dequantised block.  64-bit intermediates: corrupt files carry coefficients that
+    // overflow the 32-bit form (identical results for every valid stream).
     static void idct(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) {
-        auto f2f = [](double x) { return (int)(x * 4096 + 0.5); };
-        static const int c0 = f2f(0.5411961), c1 = f2f(-1.847759065), c2 = f2f(0.765366865), c3 = f2f(1.175875602),
+        typedef int64_t I;
+        auto f2f = [](double x) { return (I)(x * 4096 + 0.5); };
+        static const I c0 = f2f(0.5411961), c1 = f2f(-1.847759065), c2 = f2f(0.765366865), c3 = f2f(1.175875602),
                          c4 = f2f(0.298631336), c5 = f2f(2.053119869), c6 = f2f(3.072711026), c7 = f2f(1.501321110),
                          c8 = f2f(-0.899976223), c9 = f2f(-2.562915447), c10 = f2f(-1.961570560), c11 = f2f(-0.390180644);
-        int val[64];
-        auto pass = [&](int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int (&x)[4], int (&t)[4]) {
-            int p2 = s2, p3 = s6;
-            int p1 = (p2 + p3) * c0;
-            int t2 = p1 + p3 * c1, t3 = p1 + p2 * c2;
+        I val[64];
+        auto pass = [&](I s0, I s1, I s2, I s3, I s4, I s5, I s6, I s7, I (&x)[4], I (&t)[4]) {
+            I p2 = s2, p3 = s6;
+            I p1 = (p2 + p3) * c0;
+            I t2 = p1 + p3 * c1, t3 = p1 + p2 * c2;
             p2 = s0; p3 = s4;
-            int t0 = (p2 + p3) * 4096, t1 = (p2 - p3) * 4096;
+            I t0 = (p2 + p3) * 4096, t1 = (p2 - p3) * 4096;
             x[0] = t0 + t3; x[3] = t0 - t3; x[1] = t1 + t2; x[2] = t1 - t2;
             t0 = s7; t1 = s5; t2 = s3; t3 = s1;
             p3 = t0 + t2;
-            int p4 = t1 + t3;
+            I p4 = t1 + t3;
             p1 = t0 + t3; p2 = t1 + t2;
-            const int p5 = (p3 + p4) * c3;
+            const I p5 = (p3 + p4) * c3;
             t0 = t0 * c4; t1 = t1 * c5; t2 = t2 * c6; t3 = t3 * c7;
             p1 = p5 + p1 * c8; p2 = p5 + p2 * c9; p3 = p3 * c10; p4 = p4 * c11;
             t[3] = t3 + p1 + p4; t[2] = t2 + p2 + p3; t[1] = t1 + p2 + p4; t[0] = t0 + p1 + p3;
         };
-        int dq[64];
-        for (int i = 0; i < 64; ++i) dq[i] = in[i] * (int)q[i];
+        I dq[64];
+        for (int i = 0; i < 64; ++i) dq[i] = (I)in[i] * (I)q[i];
         for (int i = 0; i < 8; ++i) {  // columns
-            const int* dcol = dq + i;
-            int* v = val + i;
+            const I* dcol = dq + i;
+            I* v = val + i;
             if (!dcol[8] && !dcol[16] && !dcol[24] && !dcol[32] && !dcol[40] && !dcol[48] && !dcol[56]) {
-                const int dc = dcol[0] * 4;
+                const I dc = dcol[0] * 4;
                 for (int r = 0; r < 8; ++r) v[r * 8] = dc;
                 continue;
             }
-            int x[4], t[4];
+            I x[4], t[4];
             pass(dcol[0], dcol[8], dcol[16], dcol[24], dcol[32], dcol[40], dcol[48], dcol[56], x, t);
             for (int k = 0; k < 4; ++k) x[k] += 512;
             v[0] = (x[0] + t[3]) >> 10; v[56] = (x[0] - t[3]) >> 10;
@@ -567,13 +570,13 @@ struct Decoder {
             v[16] = (x[2] + t[1]) >> 10; v[40] = (x[2] - t[1]) >> 10;
             v[24] = (x[3] + t[0]) >> 10; v[32] = (x[3] - t[0]) >> 10;
         }
-        auto clamp8 = [](int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); };
+        auto clamp8 = [](I x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); };
         for (int i = 0; i < 8; ++i) {  // rows
-            const int* v = val + 8 * i;
+            const I* v = val + 8 * i;
             uint8_t* o = out + (size_t)i * stride;
-            int x[4], t[4];
+            I x[4], t[4];
             pass(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], x, t);
-            for (int k = 0; k < 4; ++k) x[k] += 65536 + (128 << 17);
+            for (int k = 0; k < 4; ++k) x[k] += 65536 + ((I)128 << 17);
             o[0] = clamp8((x[0] + t[3]) >> 17); o[7] = clamp8((x[0] - t[3]) >> 17);
             o[1] = clamp8((x[1] + t[2]) >> 17); o[6] = clamp8((x[1] - t[2]) >> 17);
             o[2] = clamp8((x[2] + t[1]) >> 17); o[5] = clamp8((x[2] - t[1]) >> 17);
@@ -717,9 +720,14 @@ int load(const char* path, Image& im) {
     std::vector<uint8_t> d;
     if (!read_file(path, d)) { set_error(std::string("image: cannot read ") + path); return AKZ_ERR_IO; }
     static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (d.size() >= 8 && !memcmp(d.data(), png_sig, 8)) return decode_png(d, im);
-    if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d, im);
-    if (d.size() >= 3 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, im);
+    try {
+        if (d.size() >= 8 && !memcmp(d.data(), png_sig, 8)) return decode_png(d, im);
+        if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d, im);
+        if (d.size() >= 3 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, im);
+    } catch (const std::exception& e) {  // bad_alloc on absurd header sizes: nothing throws across the ABI
+        set_error(std::string("image: ") + e.what());
+        return AKZ_ERR_NO_MEMORY;
+    }
     set_error("image: unrecognised format (JPEG, PNG and binary PNM are supported)");
     return AKZ_ERR_UNSUPPORTED;
 }

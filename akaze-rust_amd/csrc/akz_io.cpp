@@ -133,7 +133,7 @@ int parse_features_bincode(const std::string& s, FeaturesData& f) {
     f.desc.resize((size_t)n);
     for (auto& d : f.desc) {
         uint64_t len = 0;
-        if (!get(s, pos, len) || pos + len > s.size()) goto bad;
+        if (!get(s, pos, len) || len > s.size() - pos) goto bad;  // (pos + len could wrap)
         d.assign(s.begin() + (long)pos, s.begin() + (long)(pos + len));
         pos += len;
     }
@@ -263,7 +263,12 @@ int akz_read_features(const char* path, akz_keypoint* kps, uint8_t* desc, uint64
     std::string s;
     AKZ_TRY(read_file(path, s));
     FeaturesData f;
-    AKZ_TRY(is_json(path) ? parse_features_json(s, f) : parse_features_bincode(s, f));
+    try {
+        AKZ_TRY(is_json(path) ? parse_features_json(s, f) : parse_features_bincode(s, f));
+    } catch (const std::exception& e) {  // bad_alloc / length_error on absurd element counts: nothing throws across the ABI
+        set_error(std::string("read_features: ") + e.what());
+        return AKZ_ERR_NO_MEMORY;
+    }
     const uint64_t nb = f.desc.empty() ? 0 : f.desc[0].size();
     for (const auto& d : f.desc)
         if (d.size() != nb) {
@@ -340,7 +345,7 @@ int akz_read_matches(const char* path, akz_match* out, uint64_t cap, uint64_t* n
     } else {
         size_t pos = 0;
         uint64_t n = 0;
-        if (!get(s, pos, n) || n * 24 + 8 != s.size()) {
+        if (!get(s, pos, n) || n > s.size() || n * 24 + 8 != s.size()) {
             set_error("malformed bincode matches file");
             return AKZ_ERR_INVALID_ARG;
         }

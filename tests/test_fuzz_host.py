@@ -1,0 +1,48 @@
+"""The host-side parsers (image decoders, akaze-util file readers) under AddressSanitizer + UBSan on corrupted
+inputs: they must reject or decode, never read or write out of bounds.  CPU build only (tools/fuzz/fuzz_host.cpp)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_parsers_survive_corrupted_files_under_sanitizers(amd, tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    exe = str(tmp_path / "fuzz_host")
+    csrc = os.path.join(ROOT, "akaze-rust_amd", "csrc")
+    build = subprocess.run(
+        ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+         "-I/opt/rocm/include", "-I" + csrc, os.path.join(ROOT, "tools", "fuzz", "fuzz_host.cpp"), os.path.join(csrc, "akz_image.cpp"),
+         os.path.join(csrc, "akz_io.cpp"), "-o", exe, "-lz"], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr[-2000:]
+    im = PIL.open(os.path.join(ROOT, "tests", "golden", "1.jpg")).crop((300, 200, 460, 320))
+    seeds = []
+    for name, kw in (("base.jpg", dict(quality=85, subsampling=2)), ("prog.jpg", dict(quality=85, subsampling=2, progressive=True)),
+                     ("rst.jpg", dict(quality=85, subsampling=1, restart_marker_blocks=5)), ("rgb.png", {}), ("rgb.ppm", {})):
+        p = str(tmp_path / name)
+        im.save(p, **kw)
+        seeds.append(p)
+    p = str(tmp_path / "pal.png")
+    im.convert("P").save(p)
+    seeds.append(p)
+    kp = np.zeros(20, amd.KEYPOINT_DTYPE)
+    kp["x"], kp["size"], kp["octave"] = np.arange(20), 3.5, 2
+    desc = np.random.default_rng(0).integers(0, 256, (20, 61), dtype=np.uint8)
+    m = np.zeros(7, amd.MATCH_DTYPE)
+    m["index_0"], m["distance"] = np.arange(7), 1.5
+    for ext in ("cbor", "json"):
+        amd.serialize_features_to_file(kp, desc, str(tmp_path / f"features.{ext}"))
+        amd.serialize_matches_to_file(m, str(tmp_path / f"matches.{ext}"))
+        seeds += [str(tmp_path / f"features.{ext}"), str(tmp_path / f"matches.{ext}")]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    run = subprocess.run([exe, "120", str(tmp_path)] + seeds, capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
+    assert "decoded" in run.stdout

@@ -473,14 +473,35 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
     return AKZ_OK;
 }
 
-// Detector kernel family of one level.  Measured on MI355X (32 x 1080p): with the three second-derivative
-// planes written out the LDS-tiled pair is faster (3.9 vs 4.3 ms per batch), without them the streaming pair
-// is (3.4 vs 3.7 ms); small launches (single frames, coarse octaves) are latency-bound and stay tiled.
-static bool use_stream_detector(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
-                                bool keep_second, bool nms = true) {
-    if (c->det_mode == 0 || !launch::detector_stream_supported(sigma, w, h, border_m, nms)) return false;
-    if (c->det_mode == 1 || c->det_mode == 3) return true;
-    return !keep_second && (uint64_t)w * h * n >= c->stream_min_px;
+// Detector kernel family of one level: 0 = LDS-tiled pair, 1 = streaming pair, 3 = fused streaming kernel.
+// Measured on MI355X per level of a 32-frame batch (tools/det_levels.py, microseconds, sigma_size 3):
+//                    keep Lxx/Lyy/Lxy: tiled  pair  fused      not kept: tiled  pair  fused
+//   32 x 1920x1080                      535   503    547                  425   387    443
+//   32 x  960x540                       127   139    149                  110    90    115
+//   32 x  480x270                        43    47     34                   39    44     35
+//   32 x  240x135                        20    33     29                   19    28     29
+// (the fused kernel runs one wave per SIMD and only wins where the launch is latency-bound but still fills the
+// chip; the smallest launches are cheapest on the tiled kernels).  Inside the pipelined extraction the streaming
+// pair loses its stand-alone edge at full resolution when all planes are kept (detector stage 4.2 vs 3.9 ms per
+// batch), so it is used only when Lxx/Lyy/Lxy are not written (3.3 vs 3.7 ms).  AKZ_DET_RULE=a,b,c overrides
+// the three pixel-count thresholds for experiments.
+static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
+                           bool keep_second, bool nms = true) {
+    if (c->det_mode == 0 || !launch::detector_stream_supported(sigma, w, h, border_m, nms)) return 0;
+    if (c->det_mode == 1 || c->det_mode == 3) return c->det_mode;
+    static uint64_t pair_keep = ~0ull, pair_lean = 8u << 20, fused_min = 2u << 20;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char* e = getenv("AKZ_DET_RULE")) {
+            unsigned long long a = 0, b = 0, f = 0;
+            if (sscanf(e, "%llu,%llu,%llu", &a, &b, &f) == 3) { pair_keep = a; pair_lean = b; fused_min = f; }
+        }
+    }
+    const uint64_t px = (uint64_t)w * h * n;
+    if (px >= (keep_second ? pair_keep : pair_lean)) return 1;
+    if (px >= fused_min && px < (8u << 20)) return 3;
+    return 0;
 }
 
 static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
@@ -490,8 +511,8 @@ static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float
         return AKZ_ERR_INVALID_ARG;
     }
     AKZ_TRY(check_plane_args(lsmooth, ldet_out, w, h, n, (int)sigma));
-    if (use_stream_detector(c, sigma, w, h, n, 0.0f, lxx && lyy && lxy, false)) {
-        (c->det_mode == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+    if (const int fam = detector_family(c, sigma, w, h, n, 0.0f, lxx && lyy && lxy, false)) {
+        (fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
             c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, 0, 0.0f, 0.0f, nullptr, 0, nullptr);
         AKZ_HIP_TRY(hipGetLastError());
         return AKZ_OK;
@@ -857,9 +878,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     for (size_t l = 0; l < L; ++l) {
         const LevelPlan& lv = plan[l];
         const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
-        if (use_stream_detector(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
+        if (const int fam = detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
             StageTimer st(c, AKZ_ST_DETECTOR);
-            (c->det_mode == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+            (fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
                 s, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX), P(l, AKZ_LYY),
                 P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr, bm, d_cand, cap, d_count);
             continue;

@@ -409,16 +409,25 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
         set_error("contrast_factor: image too small");
         return AKZ_ERR_TOO_SMALL;
     }
-    AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
-    float* blurred = (float*)c->scratch[1].p;
-    AKZ_TRY(gaussian_blur_impl<float>(c, d_in, blurred, w, h, n, (float)gscale));
     const size_t small_bytes = (size_t)n * (8 + nbins * 4);
     AKZ_TRY(ensure(c, c->small, small_bytes));
     unsigned long long* d_hmax = (unsigned long long*)c->small.p;
     uint32_t* d_hist = (uint32_t*)((char*)c->small.p + (size_t)n * 8);
     AKZ_HIP_TRY(hipMemsetAsync(c->small.p, 0, small_bytes, c->stream));
-    launch::contrast_max(c->stream, blurred, w, h, n, d_hmax);
-    launch::contrast_hist(c->stream, blurred, w, h, n, d_hmax, (uint32_t)nbins, d_hist);
+    const size_t ks = gaussian_kernel_size((float)gscale);
+    const bool stream = c->prep_mode != 0 && gscale > 0.0 && launch::contrast_stream_supported(w, h, (uint32_t)ks, (uint32_t)nbins) &&
+                        (c->prep_mode == 1 || (uint64_t)w * h * n >= c->stream_min_px);
+    if (stream) {
+        // both passes recompute blur + Scharr from the input in registers: no blurred plane is written or re-read
+        const std::vector<float> g3 = gaussian_kernel((float)gscale, ks);
+        launch::contrast_stream(c->stream, d_in, w, h, n, g3.data(), d_hmax, (uint32_t)nbins, d_hist);
+    } else {
+        AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
+        float* blurred = (float*)c->scratch[1].p;
+        AKZ_TRY(gaussian_blur_impl<float>(c, d_in, blurred, w, h, n, (float)gscale));
+        launch::contrast_max(c->stream, blurred, w, h, n, d_hmax);
+        launch::contrast_hist(c->stream, blurred, w, h, n, d_hmax, (uint32_t)nbins, d_hist);
+    }
     launch::contrast_final(c->stream, d_hmax, d_hist, (uint32_t)nbins, percentile, n, d_k_out);
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;

@@ -127,6 +127,10 @@ void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
 void detector_fused_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                            float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
                            float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
+// streaming contrast-factor passes (akz_stream.hip): max and histogram of the gradient of blur(in) in two launches
+bool contrast_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins);
+void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
+                     unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist);
 // streaming form of prep_fused (akz_stream.hip)
 bool prep_stream_supported(uint32_t w, uint32_t h);
 void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, float* lsmooth, float* lflow, uint32_t w,

@@ -547,20 +547,26 @@ k_contrast_hist(const float* __restrict__ blurred, int w, int h, Scharr1 sk,
         if (v) atomicAdd(&d_hist[(size_t)blockIdx.z * nbins + b], v);
     }
 }
-__global__ void k_contrast_final(const unsigned long long* __restrict__ d_hmax_bits,
-                                 const unsigned* __restrict__ d_hist, unsigned nbins, double percentile, unsigned n,
-                                 double* __restrict__ d_k) {
-    const unsigned img = blockIdx.x * blockDim.x + threadIdx.x;
+// One workgroup per image: the histogram is staged in LDS by all threads, then thread 0 replays the sequential
+// percentile scan of contrast_factor.rs:56-70 (a single thread walking the bins in global memory took 38 us).
+__global__ void __launch_bounds__(256)
+k_contrast_final(const unsigned long long* __restrict__ d_hmax_bits, const unsigned* __restrict__ d_hist,
+                 unsigned nbins, double percentile, unsigned n, double* __restrict__ d_k) {
+    extern __shared__ unsigned s_bins[];
+    const unsigned img = blockIdx.x;
     if (img >= n) return;
     const unsigned* hist = d_hist + (size_t)img * nbins;
+    for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) s_bins[b] = hist[b];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     const double hmax = __longlong_as_double((long long)d_hmax_bits[img]);
     unsigned long long num_points = 0;
-    for (unsigned b = 0; b < nbins; ++b) num_points += hist[b];
+    for (unsigned b = 0; b < nbins; ++b) num_points += s_bins[b];
     const double tf = (double)num_points * percentile;
     const unsigned long long threshold = tf > 0.0 ? (unsigned long long)tf : 0ull;
     unsigned long long k = 0, num_elements = 0;
     while (num_elements < threshold && k < nbins) {
-        num_elements += hist[k];
+        num_elements += s_bins[k];
         k += 1;
     }
     d_k[img] = num_elements >= threshold ? hmax * (double)k / (double)nbins : 0.03;
@@ -1077,7 +1083,7 @@ void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, 
 }
 void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const uint32_t* d_hist, uint32_t nbins,
                     double percentile, uint32_t n, double* d_k) {
-    hipLaunchKernelGGL(k_contrast_final, dim3((n + 63) / 64), dim3(64), 0, s, d_hmax_bits, d_hist, nbins, percentile,
+    hipLaunchKernelGGL(k_contrast_final, dim3(n), dim3(256), nbins * sizeof(unsigned), s, d_hmax_bits, d_hist, nbins, percentile,
                        n, d_k);
 }
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,

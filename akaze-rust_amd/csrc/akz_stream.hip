@@ -488,11 +488,24 @@ __device__ __forceinline__ void prep_fetch(const float* __restrict__ src, int pw
     }
 }
 
-template <bool HALF>
+// MODE 0: level preparation.  MODE 1 / 2: the two passes of compute_contrast_factor (contrast_factor.rs:18-71) on
+// the same chain — gaussian_blur(Lt0, 1.0), scale-1 Scharr pair, then over the interior pixels the maximum of
+// sqrt(Lx^2 + Ly^2) in f64 (MODE 1: one atomicMax per wave) or its histogram (MODE 2: per-wave LDS histograms,
+// flushed once) — without writing any plane.
+struct ContrastArgs {
+    unsigned long long* hmax_bits;  // per image, non-negative f64 as its bit pattern (orders like the value)
+    unsigned* hist;                 // per image, nbins counters
+    unsigned nbins;
+};
+constexpr int CHIST_COPIES = 4;  // sub-histograms per wave (lanes spread over them) against same-bin conflicts
+
+template <bool HALF, int MODE>
 __global__ void __launch_bounds__(SNT, 3)
 k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float* __restrict__ lsmooth,
               float* __restrict__ lflow, int w, int h, int pw, int ph, StreamGrid g, float g0, float g1, float g2,
-              float kn, float kwn, const double* __restrict__ d_k, unsigned k_pow) {
+              float kn, float kwn, const double* __restrict__ d_k, unsigned k_pow, ContrastArgs ca) {
+    static_assert(!(HALF && MODE != 0), "the contrast passes read the level itself");
+    extern __shared__ unsigned s_chist[];  // MODE 2: [wave][copy][bin]
     const int lane = threadIdx.x & (WAVE - 1);
     const long wave = wave_index();
     if (wave >= g.waves) return;
@@ -503,11 +516,26 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
     const float* src = prev + (size_t)pc.img * (size_t)pw * (size_t)ph;
     const size_t base = (size_t)pc.img * (size_t)w * (size_t)h;
     float* ltp = HALF ? lt_out + base : nullptr;
-    float* lsp = lsmooth + base;
-    float* lfp = lflow + base;
-    double kc = d_k[pc.img];
-    for (unsigned i = 0; i < k_pow; ++i) kc = kc * 0.75;  // lib.rs:84, one octave at a time in f64
-    const double inverse_k = 1.0 / (kc * kc);
+    float* lsp = MODE == 0 ? lsmooth + base : nullptr;
+    float* lfp = MODE == 0 ? lflow + base : nullptr;
+    double inverse_k = 0.0, hmax = 0.0, gmax = 0.0;
+    unsigned* myhist = nullptr;
+    unsigned colmask = 0;  // MODE 1/2: pixels of this lane inside the interior columns 1..w-2 (contrast_factor.rs:35)
+    if (MODE == 0) {
+        double kc = d_k[pc.img];
+        for (unsigned i = 0; i < k_pow; ++i) kc = kc * 0.75;  // lib.rs:84, one octave at a time in f64
+        inverse_k = 1.0 / (kc * kc);
+    } else {
+        if (L.vst || L.sst)
+            for (int i = 0; i < 4; ++i)
+                if (L.x + i >= 1 && L.x + i <= w - 2) colmask |= 1u << i;
+        if (MODE == 2) {
+            hmax = __longlong_as_double((long long)ca.hmax_bits[pc.img]);
+            unsigned* wh = s_chist + (size_t)(threadIdx.x >> 6) * CHIST_COPIES * ca.nbins;
+            for (unsigned b = lane; b < CHIST_COPIES * ca.nbins; b += WAVE) wh[b] = 0u;  // wave-private: no barrier
+            myhist = wh + (lane & (CHIST_COPIES - 1)) * ca.nbins;
+        }
+    }
     const int v0 = pc.cs - 2, T = (pc.ce - pc.cs) + 4;  // input rows v0 .. v0+T-1 (clamped to 1..h-2 when loaded)
     f4 a, b, c, raw;
     if (HALF) {  // rows 0 and h-1 of the half-size image are not on the filter path (their taps are clamped away)
@@ -536,12 +564,12 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
                 if (t >= 2) {
                     const int u = v - 1;
                     const f4 ls = tap3(G[km2], G[km1], G[k], g0, g1, g2);  // filled Lsmooth of the lane's columns
-                    if (u >= pc.cs && u < pc.ce) prep_store_filled(lsp, L, w, h, u, ls);
+                    if (MODE == 0 && u >= pc.cs && u < pc.ce) prep_store_filled(lsp, L, w, h, u, ls);
                     const f4 la = f4{from_left_lane(ls[3]), ls[0], ls[1], ls[2]};
                     const f4 lc = f4{ls[1], ls[2], ls[3], from_right_lane(ls[0])};
                     f4 hm = tap_main(la, ls, lc, kn, kwn);
                     f4 ho = tap_off(la, lc);
-                    if (edge_strip) {  // wave-uniform: results of columns 1 / w-2 are also those of columns 0 / w-1
+                    if (MODE == 0 && edge_strip) {  // wave-uniform: results of columns 1 / w-2 are also those of columns 0 / w-1
                         const float ml = from_left_lane(hm[3]), ol = from_left_lane(ho[3]);
                         const f4 rm = hm, ro = ho;
                         if (L.fix0) { hm[0] = rm[1]; ho[0] = ro[1]; }
@@ -558,14 +586,46 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
                         const int cr = u - 1;
                         const f4 lx1 = tap_off(HM[km2], HM[k]);
                         const f4 ly1 = tap_main(HO[km2], HO[km1], HO[k], kn, kwn);
-                        f4 fl;
+                        if (MODE == 0) {
+                            f4 fl;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) fl[i] = pm_g2_px(lx1[i], ly1[i], inverse_k);
-                        if (cr >= pc.cs && cr < pc.ce) prep_store_filled(lfp, L, w, h, cr, fl);
+                            for (int i = 0; i < 4; ++i) fl[i] = pm_g2_px(lx1[i], ly1[i], inverse_k);
+                            if (cr >= pc.cs && cr < pc.ce) prep_store_filled(lfp, L, w, h, cr, fl);
+                        } else if (cr >= pc.cs && cr < pc.ce) {  // interior rows 1..h-2 are exactly the band rows
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (!(colmask & (1u << i))) continue;
+                                const double dx = (double)lx1[i], dy = (double)ly1[i];
+                                const double gm = sqrt(dx * dx + dy * dy);
+                                if (MODE == 1) {
+                                    if (gm > gmax) gmax = gm;
+                                } else if (gm != 0.0) {
+                                    const double f = floor((double)ca.nbins * (gm / hmax));
+                                    const unsigned b = f >= (double)ca.nbins ? ca.nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
+                                    atomicAdd(&myhist[b], 1u);
+                                }
+                            }
+                        }
                     }
                 }
                 a = na; b = nb; c = nc; raw = nraw;
             }
+        }
+    }
+    if (MODE == 1) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(gmax);
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(bits, o, 64);
+            bits = other > bits ? other : bits;
+        }
+        if (lane == 0 && bits != 0ull) atomicMax(ca.hmax_bits + pc.img, bits);
+    }
+    if (MODE == 2) {
+        const unsigned* wh = s_chist + (size_t)(threadIdx.x >> 6) * CHIST_COPIES * ca.nbins;
+        for (unsigned b = lane; b < ca.nbins; b += WAVE) {
+            unsigned v = 0;
+            for (int cpy = 0; cpy < CHIST_COPIES; ++cpy) v += wh[cpy * ca.nbins + b];
+            if (v) atomicAdd(&ca.hist[(size_t)pc.img * ca.nbins + b], v);
         }
     }
 }
@@ -902,14 +962,33 @@ void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, flo
     const Taps m = taps_scharr_main(1);
     dim3 grid;
     if (half) {
-        const StreamGrid g = plan_stream(k_prep_stream<true>, w, h, n, 1, 1, prep_min_rows(), &grid);
-        hipLaunchKernelGGL((k_prep_stream<true>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
-                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow);
+        const StreamGrid g = plan_stream(k_prep_stream<true, 0>, w, h, n, 1, 1, prep_min_rows(), &grid);
+        hipLaunchKernelGGL((k_prep_stream<true, 0>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
+                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ContrastArgs{});
     } else {
-        const StreamGrid g = plan_stream(k_prep_stream<false>, w, h, n, 1, 1, prep_min_rows(), &grid);
-        hipLaunchKernelGGL((k_prep_stream<false>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
-                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow);
+        const StreamGrid g = plan_stream(k_prep_stream<false, 0>, w, h, n, 1, 1, prep_min_rows(), &grid);
+        hipLaunchKernelGGL((k_prep_stream<false, 0>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
+                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ContrastArgs{});
     }
+}
+
+// compute_contrast_factor's two passes over gaussian_blur(in, sigma with the 3 taps g3) without materialising the
+// blurred plane: maximum, then histogram (d_hmax_bits / d_hist zeroed by the caller).  nbins <= 1024.
+bool contrast_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins) {
+    return ntaps == 3 && nbins <= 1024 && prep_stream_supported(w, h);
+}
+void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
+                     unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist) {
+    const Taps m = taps_scharr_main(1);
+    const ContrastArgs ca{d_hmax_bits, d_hist, nbins};
+    dim3 grid;
+    const StreamGrid g1 = plan_stream(k_prep_stream<false, 1>, w, h, n, 1, 1, prep_min_rows(), &grid);
+    hipLaunchKernelGGL((k_prep_stream<false, 1>), grid, dim3(SNT), 0, s, in, nullptr, nullptr, nullptr, (int)w, (int)h,
+                       (int)w, (int)h, g1, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], nullptr, 0u, ca);
+    const StreamGrid g2 = plan_stream(k_prep_stream<false, 2>, w, h, n, 1, 1, prep_min_rows(), &grid);
+    hipLaunchKernelGGL((k_prep_stream<false, 2>), grid, dim3(SNT), (SNT / WAVE) * CHIST_COPIES * nbins * sizeof(unsigned), s,
+                       in, nullptr, nullptr, nullptr, (int)w, (int)h, (int)w, (int)h, g2, g3[0], g3[1], g3[2], m.wgt[0],
+                       m.wgt[1], nullptr, 0u, ca);
 }
 
 #define AKZ_FDET(S)                                                                                                   \

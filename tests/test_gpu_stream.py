@@ -79,3 +79,18 @@ def test_stream_equals_tiled_on_1080p_batch(ctx, sctx, amd):
             x = a.plane(lvl, pl, 1)
             assert np.array_equal(x, b.plane(lvl, pl, 1)), (lvl, pl)
             assert np.array_equal(x, d.plane(lvl, pl, 1)), (lvl, pl)
+
+
+@pytest.mark.parametrize("shape", [(96, 130), (131, 249), (300, 517), (64, 1001)])
+def test_stream_contrast_factor(sctx, ref, shape):
+    """compute_contrast_factor through the streaming passes (no blurred plane): identical f64 result, for several
+    bin counts / percentiles and a batch whose images have different maxima."""
+    import torch
+    rng = np.random.default_rng(shape[1])
+    imgs = np.stack([ref.gaussian_blur(rng.random(shape, dtype=np.float32) * np.float32(s), 1.6) for s in (1.0, 0.3, 0.05)])
+    for nbins, pct in ((300, 0.7), (64, 0.5), (1000, 0.9)):
+        got = sctx.contrast_factor(torch.from_numpy(imgs).cuda(), pct, 1.0, nbins).cpu().numpy()
+        for i in range(3):
+            assert float(got[i]) == ref.contrast_factor(imgs[i], pct, 1.0, nbins), (nbins, pct, i)
+    flat = np.full(shape, 0.25, np.float32)
+    assert float(sctx.contrast_factor(torch.from_numpy(flat).cuda()).cpu().numpy()[0]) == ref.contrast_factor(flat)

@@ -171,6 +171,7 @@ def lib():
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
+        "akz_ctx_set_detector_overlap": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
     }
@@ -292,6 +293,10 @@ class Context:
     def set_detector_mode(self, mode):
         """2 = automatic (default), 1 = streaming kernel pair, 3 = fused streaming kernel, 0 = LDS-tiled kernels."""
         _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
+
+    def set_detector_overlap(self, on=True):
+        """Run each level's detector on a side stream, concurrently with the diffusion of later levels (default off)."""
+        _check(lib().akz_ctx_set_detector_overlap(self._h, int(bool(on))))
 
     def set_prep_mode(self, mode):
         """Level-preparation kernel: 2 = automatic (default), 1 = streaming, 0 = LDS-tiled."""

@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 1 streaming, 0 LDS-tiled")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
+    ap.add_argument("--det-overlap", action="store_true",
+                    help="detector launches on a side stream, concurrent with the diffusion (faster, but the FED spans of the "
+                         "roofline then include the time shared with the detector kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
     ap.add_argument("--parts", type=int, default=1,
@@ -102,6 +105,7 @@ def main():
     ctx = A.Context(local_rank, main.cuda_stream)
     ctx.set_detector_mode(args.det_mode)
     ctx.set_prep_mode(args.prep_mode)
+    ctx.set_detector_overlap(args.det_overlap)
     NP = max(1, min(args.parts, F))
     cut = [(F * i) // NP for i in range(NP + 1)]
     batches = [d_frames[cut[i]:cut[i + 1]] for i in range(NP)]

@@ -94,3 +94,26 @@ def test_stream_contrast_factor(sctx, ref, shape):
             assert float(got[i]) == ref.contrast_factor(imgs[i], pct, 1.0, nbins), (nbins, pct, i)
     flat = np.full(shape, 0.25, np.float32)
     assert float(sctx.contrast_factor(torch.from_numpy(flat).cuda()).cpu().numpy()[0]) == ref.contrast_factor(flat)
+
+
+def test_detector_overlap_gives_identical_results(amd, ref):
+    """Detector launches on a side stream (concurrent with the diffusion of later levels): same bytes, also with two
+    batches in flight."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_detector_overlap(True)
+    try:
+        fa = np.stack([amd.synth_frame(486, 270, i) for i in range(3)])
+        fb = np.stack([amd.synth_frame(640, 360, 40 + i) for i in range(2)])
+        ja = c.extract_begin(torch.from_numpy(fa).cuda())
+        jb = c.extract_begin(torch.from_numpy(fb).cuda(), keep_all_planes=False)
+        ra, rb = ja.finish(), jb.finish()
+        for i in range(3):
+            assert_same_result(ra, ref.extract(fa[i]), planes=(i == 1), img=i)
+        for i in range(2):
+            assert_same_result(rb, ref.extract(fb[i]), planes=False, img=i)
+        r = c.extract_features(amd.synth_frame(517, 389, 2), amd.Config(num_sublevels=5, max_octave_evolution=5))
+        assert_same_result(r, ref.extract(amd.synth_frame(517, 389, 2), ref.default_config(num_sublevels=5, max_octave_evolution=5)),
+                           planes=False)
+    finally:
+        c.close()

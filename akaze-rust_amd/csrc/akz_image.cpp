@@ -751,22 +751,12 @@ void to_rgb(const Image& im, std::vector<uint8_t>& out) {
 // debug drawing (types/image.rs:385-481)
 // ------------------------------------------------------------------------------------------------
 struct Rgb { uint8_t r, g, b; };
-// random_color(): a FRESH random::default() source per call, so every call returns the same three bytes
-// (types/image.rs:385-392).  The generator is the restated Xorshift128+ of akz_ransac.cpp (unverified).
+// random_color() (types/image.rs:385-392): three `read::<u8>()` (the low byte of the next value) from the calling
+// thread's default source, which persists across calls: every disc / line gets its own colour.
 Rgb random_color() {
-    uint64_t s0 = 42, s1 = 69;
-    auto next = [&]() {
-        uint64_t x = s0;
-        const uint64_t y = s1;
-        s0 = y;
-        x ^= x << 23;
-        x ^= x >> 17;
-        x ^= y ^ (y >> 26);
-        s1 = x;
-        return x + y;
-    };
+    DefaultSource& src = default_source();
     Rgb c;
-    c.r = (uint8_t)next(); c.g = (uint8_t)next(); c.b = (uint8_t)next();
+    c.r = (uint8_t)src.next(); c.g = (uint8_t)src.next(); c.b = (uint8_t)src.next();
     return c;
 }
 static uint32_t f2u_sat(float v) { return v <= 0.0f || v != v ? 0u : (v >= 4294967295.0f ? 0xffffffffu : (uint32_t)v); }  // Rust `as u32`

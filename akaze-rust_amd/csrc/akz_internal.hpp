@@ -21,6 +21,22 @@ void set_error(const std::string& msg);
         }                                                                                          \
     } while (0)
 
+// The `random` crate's default source (Xorshift128+), one per thread, seeded [42, 69] (akz_ransac.cpp)
+struct DefaultSource {
+    uint64_t s0 = 42, s1 = 69;
+    uint64_t next() {
+        uint64_t x = s0;
+        const uint64_t y = s1;
+        s0 = y;
+        x ^= x << 23;
+        x ^= x >> 17;
+        x ^= y ^ (y >> 26);
+        s1 = x;
+        return x + y;
+    }
+};
+DefaultSource& default_source();
+
 #define AKZ_TRY(expr)            \
     do {                         \
         int _s = (expr);         \

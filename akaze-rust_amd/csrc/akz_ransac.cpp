@@ -12,12 +12,15 @@
 //   * F = [[v0, v3, v6], [v1, v4, v7], [v2, v5, v8]] (:55-66); error = |p_r^T F p_l| (:79-83);
 //   * a model replaces the best one only with strictly more inliers; if no trial yields a model the
 //     final model is the zero matrix, whose error is 0, so every match is kept (:112-113, :152-163);
-//   * a fresh `random::default()` source is created inside every trial (:118), so every trial draws
-//     the same 8 indices; only the HashSet iteration order (random per process) differs.
-// Not reproducible bit for bit (and not a parity target): the `random` crate's generator
-// (not in the reference tree; restated from memory as Xorshift128+ seeded [42, 69] — unverified), the
-// HashSet order, and nalgebra's f32 SVD.  Here the sample is taken in ascending index order and the
-// decomposition is a cyclic Jacobi eigen-solve of A^T A in f64.
+//   * every trial takes `random::default()` (:118).  In the `random` crate 0.12 that is a handle to a
+//     THREAD-LOCAL Xorshift128+ source seeded [42, 69], not a fresh generator: successive trials (and later
+//     calls, and the debug drawings' random_color) continue one stream.  The crate is not in the reference
+//     tree; generator, seed and the persistence are pinned by the reference's own published output
+//     test-data/keypoints-1.jpg, whose i-th keypoint disc has the colour of stream values 3i..3i+2
+//     (tests/test_reference_outputs.py).  akz_random_seed reseeds the calling thread's source.
+// Not reproducible bit for bit (and not a parity target): the HashSet iteration order of the
+// 8 sampled indices (random per process) and nalgebra's f32 SVD.  Here the sample is taken in ascending
+// index order and the decomposition is a cyclic Jacobi eigen-solve of A^T A in f64.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -26,21 +29,14 @@
 #include "akz_internal.hpp"
 
 namespace akz {
-namespace {
 
-struct XorShift128Plus {  // `random::default()` of the random crate 0.12 (restated, unverified)
-    uint64_t s0 = 42, s1 = 69;
-    uint64_t next() {
-        uint64_t x = s0;
-        const uint64_t y = s1;
-        s0 = y;
-        x ^= x << 23;
-        x ^= x >> 17;
-        x ^= y ^ (y >> 26);
-        s1 = x;
-        return x + y;
-    }
-};
+// `random::default()` of the `random` crate 0.12: one Xorshift128+ source per thread, seeded [42, 69]
+DefaultSource& default_source() {
+    static thread_local DefaultSource src;
+    return src;
+}
+
+namespace {
 
 // eigen-decomposition of the symmetric 9x9 matrix m (destroyed): eigenvalues in val, vectors in the
 // columns of vec
@@ -149,20 +145,19 @@ extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0,
     uint64_t max_inliers = 0;
     Model final_model;
     std::memset(&final_model, 0, sizeof(final_model));
-    // every trial re-creates the default source, so all trials draw the same 8 indices
+    DefaultSource& src = default_source();
     std::vector<uint64_t> picked;
-    {
-        XorShift128Plus src;
+    for (uint64_t trial = 0; trial < num_trials; ++trial) {
+        picked.clear();  // `set.insert(source.read::<usize>() % matches.len())` until 8 distinct indices (:117-121)
         while (picked.size() < 8) {
             const uint64_t j = src.next() % n_matches;
             if (std::find(picked.begin(), picked.end(), j) == picked.end()) picked.push_back(j);
         }
-        std::sort(picked.begin(), picked.end());
-    }
-    akz_match sample[8];
-    for (int i = 0; i < 8; ++i) sample[i] = matches[picked[i]];
-    Model model;
-    if (num_trials > 0 && estimate(keypoints_0, keypoints_1, sample, epsilon_model, model)) {
+        std::sort(picked.begin(), picked.end());  // the reference iterates the HashSet: arbitrary order
+        akz_match sample[8];
+        for (int i = 0; i < 8; ++i) sample[i] = matches[picked[i]];
+        Model model;
+        if (!estimate(keypoints_0, keypoints_1, sample, epsilon_model, model)) continue;
         uint64_t inl = 0;
         for (uint64_t i = 0; i < n_matches; ++i)
             if (model_error(model, keypoints_0[matches[i].index_0], keypoints_1[matches[i].index_1]) < epsilon_inlier)
@@ -178,5 +173,13 @@ extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0,
             epsilon_inlier)
             out[k++] = matches[i];
     *n_out = k;
+    return AKZ_OK;
+}
+
+// random::default().seed([s0, s1]) for the calling thread
+extern "C" int akz_random_seed(uint64_t s0, uint64_t s1) {
+    DefaultSource& src = default_source();
+    src.s0 = s0;
+    src.s1 = s1;
     return AKZ_OK;
 }

@@ -155,6 +155,7 @@ def lib():
         "akz_write_matches": ([C.c_char_p, vp, u64], i32),
         "akz_read_matches": ([C.c_char_p, vp, u64, pu64], i32),
         "akz_host_select_keypoints": ([u32, u32, C.POINTER(Config), vp, u64, vp, u64, pu64, pu64], i32),
+        "akz_random_seed": ([u64, u64], i32),
         "akz_image_load": ([C.c_char_p, pu32, pu32, pu32, C.POINTER(vp)], i32),
         "akz_image_load_luma": ([C.c_char_p, pu32, pu32, C.POINTER(vp)], i32),
         "akz_image_load_rgb": ([C.c_char_p, pu32, pu32, C.POINTER(vp)], i32),
@@ -658,6 +659,12 @@ def config_from_json(text, base=None):
     cfg = base or Config()
     _check(lib().akz_config_from_json(text.encode(), C.byref(cfg)))
     return cfg
+
+
+def random_seed(s0=42, s1=69):
+    """random::default().seed([s0, s1]) for the calling thread: restarts the stream that RANSAC sampling and the
+    drawing colours consume ([42, 69] is the state a fresh thread starts with)."""
+    _check(lib().akz_random_seed(s0, s1))
 
 
 def draw_keypoints(rgb, keypoints):

@@ -354,6 +354,12 @@ int akz_extract_features_file(akz_ctx* ctx, const char* path, const akz_config* 
 int akz_config_to_json(const akz_config* cfg, char* buf, uint64_t cap, uint64_t* len);
 int akz_config_from_json(const char* json, akz_config* cfg);
 
+/* `random::default().seed([s0, s1])`: reseeds the calling thread's default random source — one Xorshift128+
+   stream per thread, initially seeded [42, 69], shared by the RANSAC sampling of akz_remove_outliers /
+   akz_match_features (estimate_fundamental_matrix.rs:118-121) and the colours of the debug drawings
+   (types/image.rs:385-392), exactly as the `random` crate 0.12 behaves inside one process. */
+int akz_random_seed(uint64_t s0, uint64_t s1);
+
 /* ---- debug output (host code) ----------------------------------- */
 /* 8-bit PNG, channels = 1 (luma) or 3 (RGB) */
 int akz_image_save_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels);
@@ -365,8 +371,8 @@ int akz_image_save_plane_png(const char* path, const float* plane, uint32_t widt
    plane; planes that were not kept are skipped like the reference skips 0x0 images. */
 int akz_write_evolutions(const akz_result* res, uint64_t img, const char* dir);
 /* types::keypoint::draw_keypoints_to_image (keypoint.rs:52-56): blends a disc of radius `size` at every
-   keypoint into the RGB image.  random_color() builds a fresh random source per call, so every disc has the
-   same colour (image.rs:385-392).  Pixels outside the image are skipped (the reference would panic). */
+   keypoint into the RGB image, each in the next random_color() of the calling thread's default source
+   (image.rs:385-392; see akz_random_seed).  Pixels outside the image are skipped (the reference would panic). */
 int akz_draw_keypoints(uint8_t* rgb, uint32_t width, uint32_t height, const akz_keypoint* kps, uint64_t n);
 /* types::feature_match::draw_matches (feature_match.rs:32-82): the two images side by side (each half as wide as
    the wider one), one line per match.  *out_rgb is released with akz_image_free. */

@@ -284,6 +284,13 @@ def descriptor_match(d0, d1, distance_threshold=10000, lowes_ratio=0.86):
     return out[:n].copy()
 
 
+def random_seed(s0=42, s1=69):
+    """random::default().seed([s0, s1]) for the calling thread ([42, 69] is what a fresh thread starts with)."""
+    lib().ref_random_seed.argtypes = [C.c_uint64, C.c_uint64]
+    lib().ref_random_seed.restype = None
+    lib().ref_random_seed(s0, s1)
+
+
 def remove_outliers(keypoints_0, keypoints_1, matches, num_trials=1000, eps_model=0.05, eps_inlier=3.0):
     k0 = np.ascontiguousarray(keypoints_0, KEYPOINT_DTYPE)
     k1 = np.ascontiguousarray(keypoints_1, KEYPOINT_DTYPE)

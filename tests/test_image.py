@@ -165,13 +165,20 @@ def test_draw_keypoints_and_matches(amd):
     kp0["x"], kp0["y"], kp0["size"] = [20.5, 40.25, 78.0], [30.0, 10.75, 58.0], [4.8, 7.2, 3.0]
     kp1 = np.zeros(2, amd.KEYPOINT_DTYPE)
     kp1["x"], kp1["y"] = [10.0, 60.0], [20.0, 40.0]
+    # colours: three u8 reads per keypoint from the thread's persistent Xorshift128+ source (random_color, image.rs:385-392)
+    from test_reference_outputs import xorshift128plus
+    amd.random_seed(42, 69)
     drawn = amd.draw_keypoints(a, kp0)
-    col = drawn[30, 20].astype(int) * 2 - a[30, 20].astype(int)  # the one colour every disc is blended with
+    stream = xorshift128plus()
     exp = a.copy()
     for k in kp0:
-        _circle(exp, np.float32(k["x"]), np.float32(k["y"]), np.clip(col, 0, 255).astype(np.uint8), np.float32(k["size"]))
-    assert np.abs(drawn.astype(int) - exp.astype(int)).max() <= 1  # colour recovered to +-1 from a blended pixel
-    assert not np.array_equal(drawn, a)
+        col = np.array([next(stream) & 0xFF for _ in range(3)], np.uint8)
+        _circle(exp, np.float32(k["x"]), np.float32(k["y"]), col, np.float32(k["size"]))
+    assert np.array_equal(drawn, exp) and not np.array_equal(drawn, a)
+    again = amd.draw_keypoints(a, kp0)            # the stream continues: other colours
+    assert not np.array_equal(again, drawn)
+    amd.random_seed(42, 69)
+    assert np.array_equal(amd.draw_keypoints(a, kp0), drawn)
     m = np.zeros(2, amd.MATCH_DTYPE)
     m["index_0"], m["index_1"] = [0, 1], [1, 0]
     out = amd.draw_matches(a, b, kp0, kp1, m)

@@ -1,0 +1,139 @@
+"""Pinning against the reference's OWN published outputs: test-data/keypoints-1.jpg and keypoints-2.jpg are what the
+reference crate drew for test-data/1.jpg and 2.jpg (`extract_features -d`: draw_keypoints_to_image on the input image,
+akaze-util/src/bin/extract_features.rs:94-103); all four files are committed under tests/golden.
+
+The drawing blends, for keypoint i of the returned list, a disc of radius keypoint.size at keypoint.point in the colour
+random_color() returns at that moment (types/image.rs:385-444) — three u8 reads from the `random` crate's thread-local
+default source.  So the picture carries, per keypoint, its POSITION, its SIZE and — through the colour — its INDEX in the
+list.  Checked here, for the CPU oracle run on this repo's decode of the same JPEG:
+
+  * the union of the oracle's keypoint discs covers the changed pixels of the published picture (IoU > 0.95);
+  * for every keypoint whose disc does not overlap another one, the disc colour recovered from the picture equals
+    values 3i, 3i+1, 3i+2 of Xorshift128+ seeded [42, 69] at the keypoint's index i in the ORACLE's list.
+
+The second property only holds if the oracle returns the same number of keypoints in the same order, at the same places
+and sizes, as the reference did (one missing or extra keypoint would shift the colour of every later one).  It also pins
+the generator, its seed and the fact that `random::default()` is one persistent stream per thread — which is what the
+RANSAC sampling consumes (estimate_fundamental_matrix.rs:118-121).  No GPU needed; the GPU path is then tied to the
+oracle bit for bit by tests/test_gpu_*.py."""
+import os
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL.Image")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+M64 = (1 << 64) - 1
+
+
+def xorshift128plus(s0=42, s1=69):
+    while True:
+        x, y = s0, s1
+        s0 = y
+        x ^= (x << 23) & M64
+        x ^= x >> 17
+        x ^= y ^ (y >> 26)
+        s1 = x
+        yield (x + y) & M64
+
+
+def disc_cover(kp, shape):
+    """coverage count and last-writer index per pixel, with draw_circle's integer window (types/image.rs:417-444)"""
+    h, w = shape
+    cnt = np.zeros((h, w), np.int32)
+    owner = np.full((h, w), -1, np.int32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i, k in enumerate(kp):
+        cx, cy, rad = np.float32(k["x"]), np.float32(k["y"]), np.float32(k["size"])
+        x0, x1 = max(int(cx) - int(rad), 0), min(int(cx) + int(rad), w)
+        y0, y1 = max(int(cy) - int(rad), 0), min(int(cy) + int(rad), h)
+        inside = (xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2 <= rad * rad
+        cnt[y0:y1, x0:x1] += inside
+        owner[y0:y1, x0:x1][inside] = i
+    return cnt, owner
+
+
+@pytest.mark.parametrize("name", ["1", "2"])
+def test_oracle_keypoints_match_the_reference_picture(amd, ref, name):
+    src = os.path.join(GOLDEN, f"{name}.jpg")
+    base = np.asarray(PIL.open(src).convert("RGB")).astype(np.int32)
+    published = np.asarray(PIL.open(os.path.join(GOLDEN, f"keypoints-{name}.jpg")).convert("RGB")).astype(np.int32)
+    assert base.shape == published.shape == (1512, 2016, 3)
+    kp = ref.extract(amd.load_image_luma(src), threads=8).keypoints()
+    assert len(kp) > 3000
+    cnt, owner = disc_cover(kp, base.shape[:2])
+
+    changed = np.abs(published - base).sum(axis=2) > 40       # JPEG noise of the re-encoded picture stays below that
+    mine = cnt > 0
+    iou = (mine & changed).sum() / (mine | changed).sum()
+    recall = (mine & changed).sum() / changed.sum()
+    assert iou > 0.95 and recall > 0.99, (iou, recall)
+
+    stream = xorshift128plus()
+    vals = np.array([next(stream) & 0xFF for _ in range(3 * len(kp))], np.float64).reshape(-1, 3)
+    single = cnt == 1
+    checked = good = 0
+    last_checked = 0
+    for i in range(len(kp)):
+        sel = single & (owner == i)
+        if sel.sum() < 30:
+            continue
+        colour = np.median(2 * published[sel] - base[sel], axis=0)   # blend: out = (colour + pixel) / 2
+        checked += 1
+        last_checked = i
+        good += np.abs(np.clip(colour, 0, 255) - vals[i]).max() < 14
+    assert checked > 800 and last_checked > 0.98 * len(kp)
+    assert good / checked > 0.985, (good, checked)
+
+
+def test_product_drawing_reproduces_the_reference_picture(amd, ref):
+    """akz_draw_keypoints on the input image with the oracle's keypoints, from a freshly seeded source, is the published
+    picture up to its JPEG re-encoding."""
+    src = os.path.join(GOLDEN, "1.jpg")
+    kp = ref.extract(amd.load_image_luma(src), threads=8).keypoints()
+    amd.random_seed(42, 69)
+    drawn = amd.draw_keypoints(amd.load_image_rgb(src), kp).astype(np.int32)
+    published = np.asarray(PIL.open(os.path.join(GOLDEN, "keypoints-1.jpg")).convert("RGB")).astype(np.int32)
+    d = np.abs(drawn - published)
+    assert d.mean() < 3.0 and (d.max(axis=2) > 48).mean() < 0.01, (d.mean(), (d.max(axis=2) > 48).mean())
+    # the same call without reseeding continues the stream: other colours
+    again = amd.draw_keypoints(amd.load_image_rgb(src), kp).astype(np.int32)
+    assert np.abs(again - published).mean() > 2 * d.mean()
+
+
+def test_oracle_matches_are_the_lines_of_the_reference_match_picture(amd, ref):
+    """test-data/match_image.jpg is the reference's draw_matches output for 1.jpg / 2.jpg (feature_match.rs:32-82, written
+    by extract_and_match -m or the integration test): the two images side by side and one line per match that survived
+    RANSAC, from keypoint_0.point to keypoint_1.point shifted by the first image's width.  The oracle's descriptor_match
+    + remove_outliers on the same images must select (nearly) those pairs: a line is drawn along >= 97 % of the oracle's
+    inlier matches, while random keypoint pairs rarely lie on one (< 15 %; measured 7.5 %).  (RANSAC is not bit-reproducible even
+    reference-to-reference — HashSet order, SVD rounding — so the inlier sets may differ by a few matches.)  This ties
+    the descriptors and the Hamming matcher of the oracle to the reference's real output: wrong descriptor bits would
+    pair other keypoints."""
+    paths = [os.path.join(GOLDEN, n) for n in ("1.jpg", "2.jpg")]
+    base = np.concatenate([np.asarray(PIL.open(p).convert("RGB")).astype(np.int32) for p in paths], axis=1)
+    published = np.asarray(PIL.open(os.path.join(GOLDEN, "match_image.jpg")).convert("RGB")).astype(np.int32)
+    assert published.shape == base.shape == (1512, 4032, 3)
+    changed = np.abs(published - base).sum(axis=2) > 40
+    r0, r1 = (ref.extract(amd.load_image_luma(p), threads=8) for p in paths)
+    k0, k1 = r0.keypoints(), r1.keypoints()
+    matches = ref.descriptor_match(r0.descriptors(), r1.descriptors(), 10000, 0.86)
+    ref.random_seed(42, 69)
+    inliers = ref.remove_outliers(k0, k1, matches, 1000, 0.05, 3.0)
+    assert len(matches) > 300 and 0.4 * len(matches) < len(inliers) < len(matches)
+    h, w = changed.shape
+
+    def drawn(i0, i1):
+        x0, y0, x1, y1 = float(k0["x"][i0]), float(k0["y"][i0]), float(k1["x"][i1]) + w / 2, float(k1["y"][i1])
+        n = int(max(abs(x1 - x0), abs(y1 - y0), 2))
+        xs = np.linspace(x0, x1, n).astype(int).clip(0, w - 1)
+        ys = np.linspace(y0, y1, n).astype(int).clip(0, h - 1)
+        return changed[ys, xs].mean() > 0.9
+
+    on_line = np.array([drawn(int(m["index_0"]), int(m["index_1"])) for m in inliers])
+    assert on_line.mean() > 0.97, on_line.mean()
+    all_on_line = np.array([drawn(int(m["index_0"]), int(m["index_1"])) for m in matches])
+    assert 0.9 * len(inliers) < all_on_line.sum() < 1.2 * len(inliers)       # the reference kept about as many
+    rng = np.random.default_rng(3)
+    control = np.array([drawn(int(a), int(b)) for a, b in zip(rng.integers(0, len(k0), 400), rng.integers(0, len(k1), 400))])
+    assert control.mean() < 0.15, control.mean()   # the lines are nearly parallel, so a few random pairs fall onto one

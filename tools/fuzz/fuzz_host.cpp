@@ -14,9 +14,15 @@
 
 #include "../../include/akaze_hip.h"
 
-namespace akz {  // the two symbols the parsers need from the rest of the library
+#include "../../akaze-rust_amd/csrc/akz_internal.hpp"
+
+namespace akz {  // the symbols the parsers need from the rest of the library
 static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
+DefaultSource& default_source() {
+    static thread_local DefaultSource src;
+    return src;
+}
 }  // namespace akz
 extern "C" const char* akz_last_error(void) { return akz::g_err.c_str(); }
 

@@ -174,6 +174,8 @@ def test_match_features_full_dropin(ctx, amd, ref):
     f1 = amd.synth_frame(960, 540, 11, shift=(17, 9))
     r0, r1 = ctx.extract_features(f0, keep_all_planes=False), ctx.extract_features(f1, keep_all_planes=False)
     q0, q1 = ref.extract(f0), ref.extract(f1)
+    amd.random_seed(42, 69)   # product and oracle each keep one persistent random source per thread
+    ref.random_seed(42, 69)
     got = amd.match_features(r0.keypoints(), r0.descriptors(), r1.keypoints(), r1.descriptors(), 0.86, 1000, 3.0,
                              ctx=ctx)
     raw = ref.descriptor_match(q0.descriptors(), q1.descriptors(), 10000, 0.86)

@@ -148,6 +148,10 @@ static int bind(akz_ctx* c) {
         return AKZ_ERR_INVALID_ARG;
     }
     AKZ_HIP_TRY(hipSetDevice(c->device));
+    // The HIP runtime keeps ONE last-error slot per thread, shared with every other user of the runtime in the
+    // process (PyTorch probes that fail on purpose, ...): drop whatever is in it so that the hipGetLastError()
+    // checks after this entry point's launches report this entry point's errors only.
+    (void)hipGetLastError();
     return AKZ_OK;
 }
 
@@ -378,6 +382,15 @@ static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t 
     Taps t;
     AKZ_TRY(taps_from_dense(k.data(), (uint32_t)k.size(), t));
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
+    constexpr bool is_u8 = std::is_same<T, uint8_t>::value;
+    if ((const void*)d_in != (const void*)d_out && c->prep_mode != 0 &&
+        launch::blur5_stream_supported(w, h, (uint32_t)k.size(), is_u8) &&
+        (!is_u8 || ((uintptr_t)d_in & 3u) == 0) && (c->prep_mode == 1 || (uint64_t)w * h * n >= c->stream_min_px)) {
+        if constexpr (is_u8) launch::blur5_stream_u8(c->stream, d_in, d_out, w, h, n, k.data());
+        else launch::blur5_stream_f32(c->stream, d_in, d_out, w, h, n, k.data());
+        AKZ_HIP_TRY(hipGetLastError());
+        return AKZ_OK;
+    }
     if (launch::blur_fused_supported((uint32_t)k.size()) && (const void*)d_in != (const void*)d_out) {
         if constexpr (std::is_same<T, uint8_t>::value)
             launch::blur_fused_u8(c->stream, d_in, d_out, w, h, n, k.data(), (uint32_t)k.size());

@@ -143,6 +143,10 @@ void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
 void detector_fused_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                            float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
                            float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
+// streaming 5-tap gaussian_blur (akz_stream.hip)
+bool blur5_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, bool is_u8);
+void blur5_stream_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
+void blur5_stream_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
 // streaming contrast-factor passes (akz_stream.hip): max and histogram of the gradient of blur(in) in two launches
 bool contrast_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins);
 void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,

@@ -596,10 +596,13 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
                             for (int i = 0; i < 4; ++i) {
                                 if (!(colmask & (1u << i))) continue;
                                 const double dx = (double)lx1[i], dy = (double)ly1[i];
-                                const double gm = sqrt(dx * dx + dy * dy);
-                                if (MODE == 1) {
-                                    if (gm > gmax) gmax = gm;
-                                } else if (gm != 0.0) {
+                                const double ss = dx * dx + dy * dy;
+                                if (MODE == 1) {  // sqrt is monotone and correctly rounded: max sqrt(s) == sqrt(max s)
+                                    if (ss > gmax) gmax = ss;
+                                    continue;
+                                }
+                                const double gm = sqrt(ss);
+                                if (gm != 0.0) {
                                     const double f = floor((double)ca.nbins * (gm / hmax));
                                     const unsigned b = f >= (double)ca.nbins ? ca.nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
                                     atomicAdd(&myhist[b], 1u);
@@ -613,7 +616,7 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
         }
     }
     if (MODE == 1) {
-        unsigned long long bits = (unsigned long long)__double_as_longlong(gmax);
+        unsigned long long bits = (unsigned long long)__double_as_longlong(sqrt(gmax));
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(bits, o, 64);
             bits = other > bits ? other : bits;
@@ -894,6 +897,92 @@ k_detector_stream(const float* __restrict__ ls, float* __restrict__ lx_out, floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gaussian_blur with a dense 5-tap kernel (types/image.rs:374-380: V(H(in)), fill_border after each pass), the
+// level-0 blur of the pyramid (sigma 1.6).  T = uint8_t folds in create_unit_float_image (types/image.rs:136):
+// the 256 possible values of `f32::from(v) * 1f32 / 255f32` are tabulated once per workgroup with that very
+// expression, so each tap costs an LDS read instead of a correctly rounded f32 division.
+// ---------------------------------------------------------------------------------------------
+struct Taps5 {
+    float k[5];
+};
+__device__ __forceinline__ f4 tap5(const f4 (&p)[5], const Taps5& t) {
+    f4 acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * p[i];
+    return acc;
+}
+// the five taps (columns cx-2 .. cx+2) of the lane's four pixels of one input row
+template <typename T>
+__device__ __forceinline__ void blur5_fetch(const T* __restrict__ row, const Lane& L, const float* __restrict__ lut, f4 (&p)[5]) {
+    if (!L.edge) {
+        float v[8];  // columns x-2 .. x+5
+        if constexpr (sizeof(T) == 1) {
+            // x is a multiple of 4 and the caller guarantees 4-byte aligned rows: bytes x-4 .. x+7 are three dwords
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(row + L.x - 4);
+            const uint32_t a = q[0], b = q[1], c = q[2];
+            v[0] = lut[(a >> 16) & 255u]; v[1] = lut[a >> 24];
+            v[2] = lut[b & 255u]; v[3] = lut[(b >> 8) & 255u]; v[4] = lut[(b >> 16) & 255u]; v[5] = lut[b >> 24];
+            v[6] = lut[c & 255u]; v[7] = lut[(c >> 8) & 255u];
+        } else {
+            const f4 q0 = *reinterpret_cast<const f4u*>(row + L.x - 2), q1 = *reinterpret_cast<const f4u*>(row + L.x + 2);
+            v[0] = q0[0]; v[1] = q0[1]; v[2] = q0[2]; v[3] = q0[3];
+            v[4] = q1[0]; v[5] = q1[1]; v[6] = q1[2]; v[7] = q1[3];
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) p[t] = f4{v[t], v[t + 1], v[t + 2], v[t + 3]};
+    } else {
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (sizeof(T) == 1) p[t][i] = lut[row[L.cx[i] + t - 2]];
+                else p[t][i] = row[L.cx[i] + t - 2];
+            }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SNT, 4)
+k_blur5_stream(const T* __restrict__ in, float* __restrict__ out, int w, int h, StreamGrid g, Taps5 tp) {
+    constexpr int S = 2, P = 5;
+    __shared__ float s_lut[256];
+    if (sizeof(T) == 1) {
+        s_lut[threadIdx.x & 255] = ((float)(threadIdx.x & 255) * 1.0f) / 255.0f;  // SNT == 256
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long wave = wave_index();
+    if (wave >= g.waves) return;
+    const Piece pc = wave_piece(wave, g, S, h);
+    if (pc.cs >= pc.ce) return;
+    const Lane L = make_lane<S, 0>(pc.strip, lane, w);
+    const size_t base = (size_t)pc.img * (size_t)w * (size_t)h;
+    const T* src = in + base;
+    float* const dst[1] = {out + base};
+    const int v0 = pc.cs - S, T_ = (pc.ce - pc.cs) + 2 * S;
+    f4 ring[P];
+    f4 cur[5], nxt[5];
+    blur5_fetch<T>(src + (size_t)clampi(v0, S, h - 1 - S) * w, L, s_lut, cur);
+    for (int t0 = 0; t0 < T_; t0 += P) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int t = t0 + k;
+            if (t < T_) {
+                blur5_fetch<T>(src + (size_t)clampi(v0 + min(t + 1, T_ - 1), S, h - 1 - S) * w, L, s_lut, nxt);
+                ring[k] = tap5(cur, tp);
+                if (t >= 2 * S) {
+                    const f4 col[5] = {ring[(k + 1) % P], ring[(k + 2) % P], ring[(k + 3) % P], ring[(k + 4) % P], ring[k]};
+                    const f4 v[1] = {tap5(col, tp)};
+                    store_filled<S, 1>(dst, L, w, h, v0 + t - S, v);
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) cur[i] = nxt[i];
+            }
+        }
+    }
+}
+
 // Bands are sized so that one wave per resident slot covers the batch in a single round.
 template <typename K>
 inline StreamGrid plan_stream(K kernel, uint32_t w, uint32_t h, uint32_t n, int S, int HL, int min_rows, dim3* grid) {
@@ -945,6 +1034,25 @@ bool detector_stream_supported(uint32_t sigma, uint32_t w, uint32_t h, float bor
     if (w < 4 * sigma + 8 || h < 4 * sigma + 8) return false;
     // the extrema test reads Ldet one pixel around a candidate: keep that ring inside the interior rows/columns
     return !nms || border_m >= (float)(sigma + 2);
+}
+
+// 5-tap gaussian_blur as a streaming kernel; u8 input needs 4-byte aligned rows (w % 4 == 0) for its dword loads
+bool blur5_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, bool is_u8) {
+    return ntaps == 5 && w >= 16 && h >= 16 && (!is_u8 || (w & 3u) == 0);
+}
+template <typename T>
+static void blur5_stream_t(hipStream_t s, const T* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
+    Taps5 tp;
+    for (int i = 0; i < 5; ++i) tp.k[i] = k[i];
+    dim3 grid;
+    const StreamGrid g = plan_stream(k_blur5_stream<T>, w, h, n, 2, 0, 12, &grid);
+    hipLaunchKernelGGL((k_blur5_stream<T>), grid, dim3(SNT), 0, s, in, out, (int)w, (int)h, g, tp);
+}
+void blur5_stream_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
+    blur5_stream_t<uint8_t>(s, in, out, w, h, n, k);
+}
+void blur5_stream_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
+    blur5_stream_t<float>(s, in, out, w, h, n, k);
 }
 
 bool prep_stream_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16; }

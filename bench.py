@@ -257,6 +257,21 @@ def main():
     if rank == 0:
         stage_ms = {k: round(warm_prof[k], 3) for k in A.STAGES}
         stage_ms["note"] = "one untimed step with full stage profiling, un-pipelined; timed steps record FED spans only"
+        # algorithmic HBM bytes of each GPU stage of one step (SURVEY.md 8(d) model: every stage input read once, every
+        # kept plane written once) against that stage's time in the profiled step: where the path stands kernel by kernel
+        lv = A.plan_levels(W, H, cfg)
+        px = [l["w"] * l["h"] * F for l in lv]
+        half = [i > 0 and lv[i]["octave"] > lv[i - 1]["octave"] for i in range(len(lv))]
+        stage_bytes = {
+            "blur0": px[0] * (1 + 4),                                   # u8 in, f32 Lt0 out
+            "contrast": px[0] * 4 * 2,                                  # two passes over Lt0
+            "prep": sum((16 + 12 if half[i] else 4 + 8) * px[i] for i in range(1, len(lv))),  # [2x2 mean: 4 px in, Lt out] Lsmooth, Lflow out
+            "fed": sum(FED_BYTES_PER_PX_STEP * len(lv[i]["tau"]) * px[i] for i in range(1, len(lv))),
+            "detector": sum((4 + 8 + 8 + (4 if args.lean else 16)) * p for p in px),  # Lsmooth in; Lx, Ly out and in again; Ldet (+Lxx, Lyy, Lxy) out
+        }
+        stage_roofline = {k: {"algorithmic_GB": round(b / 1e9, 3), "achieved_GBps": round(b / 1e9 / (warm_prof[k] * 1e-3), 1),
+                              "frac": round(b / 1e9 / (warm_prof[k] * 1e-3) / HBM_PEAK_GBS, 3)}
+                          for k, b in stage_bytes.items() if warm_prof[k] > 0}
         out = {
             "metric": f"Mpix/s through extract_features ({args.octaves} oct x {args.sublevels} sub)",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -275,6 +290,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,
+            "stage_roofline": stage_roofline,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -117,3 +117,20 @@ def test_detector_overlap_gives_identical_results(amd, ref):
                            planes=False)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("shape", [(96, 132), (131, 248), (77, 516), (40, 1000), (300, 517)])
+def test_stream_blur5(sctx, ref, shape):
+    """The level-0 blur (sigma 1.6 -> 5 taps) through the streaming kernel: f32 input for any width, u8 input (with the
+    tabulated u8 -> unit float conversion) for 4-byte aligned rows; other cases fall back to the tiled kernel."""
+    import torch
+    rng = np.random.default_rng(shape[0])
+    f = rng.random((2,) + shape, dtype=np.float32)
+    got = sctx.gaussian_blur(torch.from_numpy(f).cuda(), 1.6).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], ref.gaussian_blur(f[i], 1.6)), i
+    u8 = rng.integers(0, 256, (2,) + shape, dtype=np.uint8)
+    unit = (u8.astype(np.float32) * np.float32(1.0)) / np.float32(255.0)  # image.rs:136
+    got = sctx.gaussian_blur(torch.from_numpy(u8).cuda(), 1.6).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], ref.gaussian_blur(unit[i], 1.6)), i

@@ -502,7 +502,10 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
     return AKZ_OK;
 }
 
-// Detector kernel family of one level: 0 = LDS-tiled pair, 1 = streaming pair, 3 = fused streaming kernel.
+// Detector kernel family of one level: 0 = LDS-tiled pair, 1 = streaming pair, 3 = fused streaming kernel,
+// 4 = one LDS-tiled kernel (k_detector_tiled: 495-545 us at 32 x 1080p with all planes kept, 122-129 at 960x540,
+// 37-41 at 480x270, 14-19 at 240x135 — ahead of the tiled pair stand-alone, level with it inside the pipelined
+// extraction of a batch, and clearly ahead for small launches and single frames, where it halves the launches).
 // Measured on MI355X per level of a 32-frame batch (tools/det_levels.py, microseconds, sigma_size 3):
 //                    keep Lxx/Lyy/Lxy: tiled  pair  fused      not kept: tiled  pair  fused
 //   32 x 1920x1080                      535   503    547                  425   387    443
@@ -516,6 +519,7 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
 // the three pixel-count thresholds for experiments.
 static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
                            bool keep_second, bool nms = true) {
+    if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;
     if (c->det_mode == 0 || !launch::detector_stream_supported(sigma, w, h, border_m, nms)) return 0;
     if (c->det_mode == 1 || c->det_mode == 3) return c->det_mode;
     static uint64_t pair_keep = ~0ull, pair_lean = 8u << 20, fused_min = 2u << 20;
@@ -530,6 +534,7 @@ static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_
     const uint64_t px = (uint64_t)w * h * n;
     if (px >= (keep_second ? pair_keep : pair_lean)) return 1;
     if (px >= fused_min && px < (8u << 20)) return 3;
+    if (px < fused_min && launch::detector_tiled_fused_supported(sigma)) return 4;  // one launch instead of two: 14 vs 20 us
     return 0;
 }
 
@@ -541,7 +546,7 @@ static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float
     }
     AKZ_TRY(check_plane_args(lsmooth, ldet_out, w, h, n, (int)sigma));
     if (const int fam = detector_family(c, sigma, w, h, n, 0.0f, lxx && lyy && lxy, false)) {
-        (fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+        (fam == 4 ? launch::detector_tiled_fused : fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
             c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, 0, 0.0f, 0.0f, nullptr, 0, nullptr);
         AKZ_HIP_TRY(hipGetLastError());
         return AKZ_OK;
@@ -866,7 +871,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
         if (const int fam = detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
             StageTimer st(c, AKZ_ST_DETECTOR, st_);
-            (fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+            (fam == 4 ? launch::detector_tiled_fused : fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
                 st_, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX), P(l, AKZ_LYY),
                 P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr, bm, d_cand, cap, d_count);
             return true;
@@ -1511,7 +1516,7 @@ int akz_write_evolutions(const akz_result* r, uint64_t img, const char* dir) {
 }
 
 int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 3) return AKZ_ERR_INVALID_ARG;
+    if (!c || mode < 0 || mode > 4) return AKZ_ERR_INVALID_ARG;
     c->det_mode = mode;
     return AKZ_OK;
 }

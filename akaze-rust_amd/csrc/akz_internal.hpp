@@ -140,6 +140,10 @@ bool detector_fused_supported(uint32_t sigma);
 void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n);
 // first + second derivatives, Ldet and the extrema candidates of one level in two launches
+bool detector_tiled_fused_supported(uint32_t sigma);
+void detector_tiled_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
+                          float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
+                          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 void detector_fused_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                            float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
                            float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);

@@ -657,6 +657,167 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole detector of a level in one LDS-tiled kernel (detector_response.rs:8-55 + the extrema test):
+// Lsmooth -> (H) Hm, Ho -> (V) Lx, Ly -> (H) A, B, C -> (V) Lxx, Lyy, Lxy, Ldet -> candidates.  Same window
+// discipline as the kernels above (every window position holds the FILLED value of its stage), four passes
+// with half width S, so the Lsmooth window is the tile grown by 2S (+1 for the extrema ring) on every side.
+// Against k_deriv1 + k_deriv2 this reads Lsmooth once instead of Lsmooth + Lx + Ly (28 instead of 36 B/px
+// with all planes kept) at the price of recomputing the first stage on the wider ring.  LDS: two buffers
+// that are reused as the stages retire (Lsmooth -> Lx,Ly -> Ldet in one, Hm,Ho -> A,B,C in the other).
+// ---------------------------------------------------------------------------------------------
+template <int S, bool NMS, bool KEEP>
+__global__ void __launch_bounds__(NT)
+k_detector_tiled(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out,
+                 float* __restrict__ lxx_out, float* __restrict__ lyy_out, float* __restrict__ lxy_out,
+                 float* __restrict__ ldet_out, int w, int h, TileGrid tg, float kn, float kwn, float quat, NmsArgs nms) {
+    constexpr int R = NMS ? 1 : 0;
+    constexpr int W0W = TW + 2 * R + 4 * S, W0H = TH + 2 * R + 4 * S;  // Lsmooth, origin (x0-R-2S, y0-R-2S)
+    constexpr int H1W = TW + 2 * R + 2 * S, H1H = W0H;                 // Hm, Ho,   origin (x0-R-S,  y0-R-2S)
+    constexpr int W2W = H1W, W2H = TH + 2 * R + 2 * S;                 // Lx, Ly,   origin (x0-R-S,  y0-R-S)
+    constexpr int H2W = TW + 2 * R, H2H = W2H;                         // A, B, C,  origin (x0-R,    y0-R-S)
+    constexpr int DW = H2W, DH = TH + 2 * R;                           // Ldet,     origin (x0-R,    y0-R)
+    constexpr int PSZ = (W0W * W0H > 2 * W2W * W2H) ? W0W * W0H : 2 * W2W * W2H;
+    constexpr int QSZ = (2 * H1W * H1H > 3 * H2W * H2H) ? 2 * H1W * H1H : 3 * H2W * H2H;
+    static_assert(DW * DH <= PSZ, "Ldet window must fit in the buffer it aliases");
+    constexpr int NLOAD = (W0W * W0H + NT - 1) / NT;
+    __shared__ float sP[PSZ];  // Lsmooth, then Lx | Ly, then Ldet
+    __shared__ float sQ[QSZ];  // Hm | Ho, then A | B | C
+    float* const s0 = sP;
+    float* const sHm = sQ;
+    float* const sHo = sQ + H1W * H1H;
+    float* const sLx = sP;
+    float* const sLy = sP + W2W * W2H;
+    float* const sA = sQ;
+    float* const sB = sQ + H2W * H2H;
+    float* const sC = sQ + 2 * H2W * H2H;
+    float* const sD = sP;
+    const int tid = threadIdx.x;
+    const int ntiles = tg.tx * tg.ty * tg.n;
+    float regs[NLOAD];
+    auto issue = [&](int tile) {
+        const Tile tl = decode_tile(tile, tg, w, h);
+        const float* src = ls + (size_t)tl.bz * (size_t)w * (size_t)h;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * NT;
+            const int wy = idx / W0W, wx = idx - wy * W0W;
+            const int gx = tl.x0 - R - 2 * S + wx, gy = tl.y0 - R - 2 * S + wy;
+            regs[k] = (idx < W0W * W0H && gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < W0W * W0H) s0[idx] = regs[k];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        const Tile tl = decode_tile(tile, tg, w, h);
+        const int x0 = tl.x0, y0 = tl.y0;
+        const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
+        // ---- stage 1, H pass: Hm = H_main(Ls), Ho = H_off(Ls) ----
+        for (int idx = tid; idx < H1W * H1H; idx += NT) {
+            const int wy = idx / H1W, wx = idx - wy * H1W;
+            const int x = x0 - R - S + wx, y = y0 - R - 2 * S + wy;
+            if (x < 0 || x >= w || y < 0 || y >= h) continue;
+            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+            const float* p = s0 + (cy - (y0 - R - 2 * S)) * W0W + (cx - (x0 - R - 2 * S));
+            const float a = p[-S], b = p[0], c = p[S];
+            sHm[idx] = tap_main(a, b, c, kn, kwn);
+            sHo[idx] = tap_off(a, b, c);
+        }
+        __syncthreads();  // the Lsmooth window is dead from here on
+        // ---- stage 1, V pass: Lx = V_off(Hm), Ly = V_main(Ho); the tile's own pixels go to HBM ----
+        for (int idx = tid; idx < W2W * W2H; idx += NT) {
+            const int wy = idx / W2W, wx = idx - wy * W2W;
+            const int x = x0 - R - S + wx, y = y0 - R - S + wy;
+            if (x < 0 || x >= w || y < 0 || y >= h) continue;
+            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+            const int o = (cy - (y0 - R - 2 * S)) * H1W + (cx - (x0 - R - S));
+            const float vx = tap_off(sHm[o - S * H1W], sHm[o], sHm[o + S * H1W]);
+            const float vy = tap_main(sHo[o - S * H1W], sHo[o], sHo[o + S * H1W], kn, kwn);
+            sLx[idx] = vx;
+            sLy[idx] = vy;
+            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + TH) {
+                const size_t gi = base + (size_t)y * w + x;
+                lx_out[gi] = vx;
+                ly_out[gi] = vy;
+            }
+        }
+        __syncthreads();  // Hm / Ho are dead from here on
+        // ---- stage 2, H pass: A = H_main(Lx), B = H_off(Ly), C = H_off(Lx) ----
+        for (int idx = tid; idx < H2W * H2H; idx += NT) {
+            const int wy = idx / H2W, wx = idx - wy * H2W;
+            const int x = x0 - R + wx, y = y0 - R - S + wy;
+            if (x < 0 || x >= w || y < 0 || y >= h) continue;
+            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+            const int o = (cy - (y0 - R - S)) * W2W + (cx - (x0 - R - S));
+            const float xa = sLx[o - S], xb = sLx[o], xc = sLx[o + S];
+            const float ya = sLy[o - S], yb = sLy[o], yc = sLy[o + S];
+            sA[idx] = tap_main(xa, xb, xc, kn, kwn);
+            sB[idx] = tap_off(ya, yb, yc);
+            sC[idx] = tap_off(xa, xb, xc);
+        }
+        __syncthreads();  // Lx / Ly windows are dead from here on (sD aliases them)
+        // ---- stage 2, V pass + determinant ----
+        for (int idx = tid; idx < DW * DH; idx += NT) {
+            const int wy = idx / DW, wx = idx - wy * DW;
+            const int x = x0 - R + wx, y = y0 - R + wy;
+            if (x < 0 || x >= w || y < 0 || y >= h) continue;
+            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
+            const int o = (cy - (y0 - R - S)) * H2W + (cx - (x0 - R));
+            const float lxx = tap_off(sA[o - S * H2W], sA[o], sA[o + S * H2W]);
+            const float lyy = tap_main(sB[o - S * H2W], sB[o], sB[o + S * H2W], kn, kwn);
+            const float lxy = tap_main(sC[o - S * H2W], sC[o], sC[o + S * H2W], kn, kwn);
+            const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
+            if (NMS) sD[idx] = det;
+            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + TH) {
+                const size_t gi = base + (size_t)y * w + x;
+                if (KEEP) {
+                    lxx_out[gi] = lxx;
+                    lyy_out[gi] = lyy;
+                    lxy_out[gi] = lxy;
+                }
+                ldet_out[gi] = det;
+            }
+        }
+        __syncthreads();
+        if (NMS) {
+            for (int idx = tid; idx < TW * TH; idx += NT) {
+                const int ly = idx / TW, lx = idx - ly * TW;
+                const int x = x0 + lx, y = y0 + ly;
+                // flat range (w+1) .. len-w-2 of the reference loop; x = w-1 never passes the border test
+                if (x < 1 || x > w - 2 || y < 1 || y > h - 2) continue;
+                if ((long)y * w + x >= (long)w * h - w - 1) continue;
+                const int o = (ly + 1) * DW + (lx + 1);
+                const float v = sD[o];
+                if (!(v > nms.thr)) continue;
+                const float xp = sD[o + 1], xm = sD[o - 1], yp = sD[o + DW], ym = sD[o - DW];
+                if (!(v > xp && v > xm && v > ym && v > yp)) continue;
+                const float fx = (float)x, fy = (float)y, bm = nms.border_m;
+                const bool is_out = (roundf(fx - bm) - 1.0f) < 0.0f || (roundf(fx + bm) + 1.0f) >= (float)w ||
+                                    (roundf(fy - bm) - 1.0f) < 0.0f || (roundf(fy + bm) + 1.0f) >= (float)h;
+                if (is_out) continue;
+                if (x < tl.bx * TW || y < tl.by * TH) continue;  // overlapping (shifted) tiles: only the owner reports
+                const unsigned slot = atomicAdd(nms.count, 1u);
+                if (slot < nms.cap) {
+                    Candidate c;
+                    c.level = nms.level;
+                    c.idx = (unsigned)(y * w + x);
+                    c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
+                    c.img = (unsigned)tl.bz;
+                    nms.cand[slot] = c;
+                }
+            }
+            __syncthreads();  // sD (= sP) is overwritten by the next iteration
+        }
+    }
+}
+
 struct Launch {
     TileGrid tg;
     dim3 grid;
@@ -747,6 +908,39 @@ void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, flo
     }
 }
 #undef AKZ_DET
+
+// One-kernel LDS-tiled detector (k_detector_tiled); d_cand == nullptr: no extrema test.  S <= 4.
+bool detector_tiled_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <= 4; }
+#define AKZ_TDET(S)                                                                                                   \
+    case S:                                                                                                           \
+        if (d_cand && keep)                                                                                           \
+            hipLaunchKernelGGL((k_detector_tiled<S, true, true>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
+                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+        else if (d_cand)                                                                                              \
+            hipLaunchKernelGGL((k_detector_tiled<S, true, false>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
+                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+        else if (keep)                                                                                                \
+            hipLaunchKernelGGL((k_detector_tiled<S, false, true>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
+                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_detector_tiled<S, false, false>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
+                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+        break;
+void detector_tiled_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
+                          float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
+                          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
+    const Taps m = taps_scharr_main(sigma);
+    const float kn = m.wgt[0], kwn = m.wgt[1];
+    const float quat = (float)(sigma * sigma * sigma * sigma);
+    const bool keep = lxx && lyy && lxy;
+    const Launch l = plan_tiles(w, h, n);
+    const NmsArgs na{level, thr, border_m, d_cand, cap, d_count};
+    switch (sigma) {
+        AKZ_TDET(1) AKZ_TDET(2) AKZ_TDET(3) AKZ_TDET(4)
+        default: break;
+    }
+}
+#undef AKZ_TDET
 
 }  // namespace launch
 }  // namespace akz

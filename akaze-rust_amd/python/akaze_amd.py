@@ -292,7 +292,8 @@ class Context:
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
 
     def set_detector_mode(self, mode):
-        """2 = automatic (default), 1 = streaming kernel pair, 3 = fused streaming kernel, 0 = LDS-tiled kernels."""
+        """2 = automatic (default), 1 = streaming kernel pair, 3 = fused streaming kernel, 4 = one LDS-tiled kernel,
+        0 = LDS-tiled kernel pair."""
         _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
 
     def set_detector_overlap(self, on=True):

@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
     ap.add_argument("--sublevels", type=int, default=4)
     ap.add_argument("--octaves", type=int, default=4)
-    ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 1 streaming, 0 LDS-tiled")
+    ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 1 streaming pair, 3 fused streaming, 4 one tiled kernel, 0 tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
     ap.add_argument("--det-overlap", action="store_true",
                     help="detector launches on a side stream, concurrent with the diffusion (faster, but the FED spans of the "

@@ -318,8 +318,9 @@ int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
 /* Detector kernel variant: 2 (default) = automatic (streaming register-ring kernels for batches whose
    second-derivative planes are not kept, LDS-tiled kernels otherwise); 1 = streaming pair (first /
    second derivatives) wherever it is supported (sigma_size <= 4); 3 = the single fused streaming kernel
-   (least HBM traffic, but one wave per SIMD: slower than the pair on MI355X today); 0 = tiled only.
-   Results are bit-identical. */
+   (least HBM traffic, but one wave per SIMD: slower than the pair on MI355X today); 4 = the single
+   LDS-tiled kernel (first and second derivatives in one pass; the automatic choice for small launches);
+   0 = tiled pair only.  Results are bit-identical. */
 int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
 /* Detector overlap (default off): launch each level's detector on a side stream as soon as its Lsmooth
    exists, concurrently with the diffusion of that and later levels.  Fills the chip during the

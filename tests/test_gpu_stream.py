@@ -9,7 +9,7 @@ from test_gpu_extract import PLANES, assert_same_result
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 3], ids=["pair", "fused"])
+@pytest.fixture(params=[1, 3, 4], ids=["pair", "fused", "tiled_fused"])
 def sctx(amd, request):
     """A context with the streaming paths forced on (detector: the two-kernel pair or the fused kernel), so that
     small test images take them too."""

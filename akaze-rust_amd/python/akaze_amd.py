@@ -815,3 +815,57 @@ def gather_descriptor_rows(local_rows, group=None, cap_rows=None):
     dist.all_gather_into_tensor(gathered, padded, group=group)
     rows = torch.cat([gathered[r * cap:r * cap + counts[r]] for r in range(world)], dim=0)
     return rows, counts
+
+
+def gather_descriptor_sets(local_sets, group=None):
+    """The exchange step of a cross-GPU all-pairs match (BASELINE configs[4]): every rank
+    contributes the descriptor rows of ITS images ([n_i, 64] uint8 tensors, in its shard order); afterwards every
+    rank holds every image's rows.  Three all-gathers (images per rank, rows per image, the rows); with the "nccl"
+    backend they are RCCL over xGMI and the tensors stay on the GPU.
+
+    Returns (sets, owners): one rows tensor per image of the whole job, rank-major, and the rank that owns it."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = local_sets[0].device if local_sets else torch.device("cpu")
+    n_img = torch.tensor([len(local_sets)], dtype=torch.int64, device=dev)
+    imgs = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(imgs, n_img, group=group)
+    imgs = [int(v) for v in imgs.tolist()]
+    cap = max(max(imgs), 1)
+    mine = torch.zeros(cap, dtype=torch.int64, device=dev)
+    if local_sets:
+        mine[:len(local_sets)] = torch.tensor([int(t.shape[0]) for t in local_sets], dtype=torch.int64, device=dev)
+    per_img = torch.zeros(world * cap, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(per_img, mine, group=group)
+    per_img = per_img.view(world, cap).tolist()
+    local = torch.cat(local_sets, dim=0) if local_sets else torch.zeros((0, 64), dtype=torch.uint8, device=dev)
+    rows, _ = gather_descriptor_rows(local, group)
+    sets, owners, pos = [], [], 0
+    for r in range(world):
+        for i in range(imgs[r]):
+            n = int(per_img[r][i])
+            sets.append(rows[pos:pos + n])
+            owners.append(r)
+            pos += n
+    return sets, owners
+
+
+def all_pairs_match(local_sets, match_fn, group=None):
+    """Cross-GPU all-pairs Hamming match: after gather_descriptor_sets every rank matches the images it OWNS (as
+    queries) against every other image of the job, i.e. 1/world of the ordered pairs each; nothing else is
+    exchanged.  match_fn(rows_i, rows_j) is Context.descriptor_match_device on the GPUs.
+
+    Returns {(i, j): matches} for this rank's share, i and j being global (rank-major) image indices."""
+    import torch.distributed as dist
+    sets, owners = gather_descriptor_sets(local_sets, group)
+    rank = dist.get_rank(group)
+    out = {}
+    for i, owner in enumerate(owners):
+        if owner != rank:
+            continue
+        for j in range(len(sets)):
+            if i != j:
+                out[(i, j)] = match_fn(sets[i], sets[j])
+    return out
+

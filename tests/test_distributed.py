@@ -69,3 +69,68 @@ def test_shard_frames_one_image_per_gpu_slot():
         assert sorted(sum(shards, [])) == list(range(256))
         assert all(len(s) == 256 // world for s in shards)
         assert all(i % world == r for r, s in enumerate(shards) for i in s)
+
+
+def _np_match(d0, d1, ratio=0.86):
+    """Plain numpy Hamming 1-NN / 2-NN with the reference's rule (feature_matching.rs:37-50, :113-123), for CPU tensors."""
+    a, b = d0.numpy(), d1.numpy()
+    out = []
+    if len(b) == 0:
+        return out
+    for i in range(len(a)):
+        dist = np.unpackbits(a[i][None, :] ^ b, axis=1).sum(axis=1).astype(np.int64)
+        order = np.argsort(dist, kind="stable")
+        best = int(order[0])
+        second = int(dist[order[1]]) if len(b) > 1 else 10 ** 9
+        if dist[best] < 10000 and float(dist[best]) ** 2 < (ratio ** 2) * float(second) ** 2:
+            out.append((i, best, int(dist[best])))
+    return out
+
+
+def _pairs_worker(rank, world, port, sizes, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "akaze-rust_amd", "python"))
+    import pickle
+    import torch
+    import torch.distributed as dist
+    import akaze_amd as A
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        everything = [torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)) for r in range(world) for n in sizes[r]]
+        first = sum(len(sizes[r]) for r in range(rank))
+        local = everything[first:first + len(sizes[rank])]
+        sets, owners = A.gather_descriptor_sets(local)
+        assert len(sets) == len(everything) and all(torch.equal(a, b) for a, b in zip(sets, everything))
+        assert owners == [r for r in range(world) for _ in sizes[r]]
+        res = A.all_pairs_match(local, _np_match)
+        with open(os.path.join(out_dir, f"pairs_{rank}.pkl"), "wb") as f:
+            pickle.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [((6, 9), (4,)), ((5,), (0, 7, 3)), ((), (8, 2))])
+def test_all_pairs_match_gloo(tmp_path, sizes):
+    """BASELINE configs[4]'s cross-GPU all-pairs match on two CPU ranks: every ordered image pair is matched exactly
+    once, by the rank that owns the query image, with the result a single process gets."""
+    import pickle
+    import torch
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_pairs_worker, args=(world, _free_port(), sizes, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(7)
+    everything = [torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)) for r in range(world) for n in sizes[r]]
+    owners = [r for r in range(world) for _ in sizes[r]]
+    seen = {}
+    for r in range(world):
+        res = pickle.load(open(tmp_path / f"pairs_{r}.pkl", "rb"))
+        assert all(owners[i] == r for (i, _j) in res)
+        assert not (set(res) & set(seen))
+        seen.update(res)
+    n = len(everything)
+    assert set(seen) == {(i, j) for i in range(n) for j in range(n) if i != j}
+    for (i, j), m in seen.items():
+        assert m == _np_match(everything[i], everything[j]), (i, j)
+

@@ -222,3 +222,43 @@ def test_baseline_c5_4k_5x5_stream_all_pairs_match(ctx, amd, ref):
             assert np.array_equal(got, exp), (i, j)
             n_matches += len(exp)
     assert n_matches > 1000
+
+
+def test_all_pairs_match_over_rccl_world1(ctx, amd, ref):
+    """The cross-GPU all-pairs path of BASELINE configs[4] with the real backend (RCCL, one rank on this box):
+    device-resident 64-byte descriptor rows are gathered with all_gather and matched on the GPU; every pair equals
+    the oracle's descriptor_match."""
+    import torch
+    import torch.distributed as dist
+    frames = np.stack([amd.synth_frame(640, 360, 60 + i, shift=(4 * i, 2 * i)) for i in range(3)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda(), keep_all_planes=False)
+    refs = [ref.extract(f) for f in frames]
+    local = []
+    for i in range(3):
+        total = res.counts(i)[1]
+        rows = torch.zeros((total, 64), dtype=torch.uint8, device="cuda")
+        rows[:, :61] = torch.from_numpy(res.descriptors(i)).cuda()
+        local.append(rows)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    def match(a, b):  # device rows in, host records out
+        out, cnt = ctx.descriptor_match_device(a, b, 10000, 0.86)
+        ctx.synchronize()
+        return out.cpu().numpy()[:int(cnt.item())].view(amd.MATCH_DTYPE).reshape(-1)
+
+    try:
+        pairs = amd.all_pairs_match(local, match)
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert set(pairs) == {(i, j) for i in range(3) for j in range(3) if i != j}
+    total = 0
+    for (i, j), got in pairs.items():
+        exp = ref.descriptor_match(refs[i].descriptors(), refs[j].descriptors(), 10000, 0.86)
+        assert np.array_equal(got, exp), (i, j)
+        total += len(exp)
+    assert total > 20

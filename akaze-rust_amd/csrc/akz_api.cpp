@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <map>
 #include <memory>
 #include <thread>
 #include <time.h>
@@ -533,8 +534,8 @@ static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_
     }
     const uint64_t px = (uint64_t)w * h * n;
     if (px >= (keep_second ? pair_keep : pair_lean)) return 1;
-    if (px >= fused_min && px < (8u << 20)) return 3;
-    if (px < fused_min && launch::detector_tiled_fused_supported(sigma)) return 4;  // one launch instead of two: 14 vs 20 us
+    // small launches: the one-kernel tiled form, which extract_begin also batches across levels of equal sigma_size
+    if (px < (8u << 20) && launch::detector_tiled_fused_supported(sigma)) return fused_min == 0 ? 3 : 4;
     return 0;
 }
 
@@ -951,10 +952,18 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     }
 
     // ---- detector levels that were not overlapped (no side stream, or kernel sizes without a fused form) ----
+    // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group
+    std::map<uint32_t, std::vector<launch::DetLevelDesc>> sets;
     for (size_t l = 0; l < L; ++l) {
         if (det_launched[l]) continue;
         const LevelPlan& lv = plan[l];
         const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
+        if (detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all) == 4) {
+            sets[lv.det_sigma].push_back(launch::DetLevelDesc{P(l, AKZ_LSMOOTH), P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
+                                                             P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h,
+                                                             (uint32_t)l, bm});
+            continue;
+        }
         if (detector_one_pass(l, s)) continue;
         {
             StageTimer st(c, AKZ_ST_DETECTOR);
@@ -964,6 +973,14 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         StageTimer st(c, AKZ_ST_NMS);
         launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l, thr, bm, d_cand, cap,
                     d_count);
+    }
+    for (auto& kv : sets) {
+        const uint32_t maxn = launch::detector_tiled_set_max();
+        for (size_t i = 0; i < kv.second.size(); i += maxn) {
+            StageTimer st(c, AKZ_ST_DETECTOR);
+            launch::detector_tiled_set(s, kv.first, kv.second.data() + i, (uint32_t)std::min<size_t>(maxn, kv.second.size() - i), n,
+                                       (float)cfg.detector_threshold, d_cand, cap, d_count);
+        }
     }
     AKZ_HIP_TRY(hipGetLastError());
     if (ds) {  // the main stream (and with it nms_done and the next batch) continues after the side stream's launches

@@ -141,6 +141,16 @@ void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n);
 // first + second derivatives, Ldet and the extrema candidates of one level in two launches
 bool detector_tiled_fused_supported(uint32_t sigma);
+// the same kernel over a set of levels that share sigma_size (one launch for several small levels)
+struct DetLevelDesc {
+    const float* lsmooth;
+    float *lx, *ly, *lxx, *lyy, *lxy, *ldet;
+    uint32_t w, h, level;
+    float border_m;
+};
+uint32_t detector_tiled_set_max();
+void detector_tiled_set(hipStream_t s, uint32_t sigma, const DetLevelDesc* levels, uint32_t nlevels, uint32_t n, float thr,
+                        Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 void detector_tiled_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                           float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
                           float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);

@@ -666,11 +666,31 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
 // with all planes kept) at the price of recomputing the first stage on the wider ring.  LDS: two buffers
 // that are reused as the stages retire (Lsmooth -> Lx,Ly -> Ldet in one, Hm,Ho -> A,B,C in the other).
 // ---------------------------------------------------------------------------------------------
+// One launch covers a SET of levels that share sigma_size S (the kernel's template parameter): every level's
+// detector depends only on its own Lsmooth, so the coarse levels of a pyramid — each too small to fill the chip —
+// go into one grid (tiles numbered level after level).
+struct DetLevel {
+    const float* ls;
+    float *lx, *ly, *lxx, *lyy, *lxy, *ldet;
+    int w, h;
+    TileGrid tg;
+    int tile0;      // index of the level's first tile in the launch
+    unsigned level;
+    float border_m;
+};
+constexpr int kDetSetMax = 16;
+struct DetSet {
+    int nlevels, ntiles;
+    float thr;
+    Candidate* cand;
+    unsigned cap;
+    unsigned* count;
+    DetLevel lv[kDetSetMax];
+};
+
 template <int S, bool NMS, bool KEEP>
 __global__ void __launch_bounds__(NT)
-k_detector_tiled(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out,
-                 float* __restrict__ lxx_out, float* __restrict__ lyy_out, float* __restrict__ lxy_out,
-                 float* __restrict__ ldet_out, int w, int h, TileGrid tg, float kn, float kwn, float quat, NmsArgs nms) {
+k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
     constexpr int R = NMS ? 1 : 0;
     constexpr int W0W = TW + 2 * R + 4 * S, W0H = TH + 2 * R + 4 * S;  // Lsmooth, origin (x0-R-2S, y0-R-2S)
     constexpr int H1W = TW + 2 * R + 2 * S, H1H = W0H;                 // Hm, Ho,   origin (x0-R-S,  y0-R-2S)
@@ -693,11 +713,18 @@ k_detector_tiled(const float* __restrict__ ls, float* __restrict__ lx_out, float
     float* const sC = sQ + 2 * H2W * H2H;
     float* const sD = sP;
     const int tid = threadIdx.x;
-    const int ntiles = tg.tx * tg.ty * tg.n;
+    const int ntiles = ds.ntiles;
+    auto level_of = [&](int tile) {  // wave-uniform
+        int li = 0;
+        while (li + 1 < ds.nlevels && tile >= ds.lv[li + 1].tile0) ++li;
+        return li;
+    };
     float regs[NLOAD];
     auto issue = [&](int tile) {
-        const Tile tl = decode_tile(tile, tg, w, h);
-        const float* src = ls + (size_t)tl.bz * (size_t)w * (size_t)h;
+        const DetLevel& dl = ds.lv[level_of(tile)];
+        const int w = dl.w, h = dl.h;
+        const Tile tl = decode_tile(tile - dl.tile0, dl.tg, w, h);
+        const float* src = dl.ls + (size_t)tl.bz * (size_t)w * (size_t)h;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             const int idx = tid + k * NT;
@@ -716,9 +743,17 @@ k_detector_tiled(const float* __restrict__ ls, float* __restrict__ lx_out, float
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
-        const Tile tl = decode_tile(tile, tg, w, h);
+        const DetLevel& dl = ds.lv[level_of(tile)];
+        const int w = dl.w, h = dl.h;
+        const Tile tl = decode_tile(tile - dl.tile0, dl.tg, w, h);
         const int x0 = tl.x0, y0 = tl.y0;
         const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
+        float* const lx_out = dl.lx;
+        float* const ly_out = dl.ly;
+        float* const lxx_out = dl.lxx;
+        float* const lyy_out = dl.lyy;
+        float* const lxy_out = dl.lxy;
+        float* const ldet_out = dl.ldet;
         // ---- stage 1, H pass: Hm = H_main(Ls), Ho = H_off(Ls) ----
         for (int idx = tid; idx < H1W * H1H; idx += NT) {
             const int wy = idx / H1W, wx = idx - wy * H1W;
@@ -795,22 +830,22 @@ k_detector_tiled(const float* __restrict__ ls, float* __restrict__ lx_out, float
                 if ((long)y * w + x >= (long)w * h - w - 1) continue;
                 const int o = (ly + 1) * DW + (lx + 1);
                 const float v = sD[o];
-                if (!(v > nms.thr)) continue;
+                if (!(v > ds.thr)) continue;
                 const float xp = sD[o + 1], xm = sD[o - 1], yp = sD[o + DW], ym = sD[o - DW];
                 if (!(v > xp && v > xm && v > ym && v > yp)) continue;
-                const float fx = (float)x, fy = (float)y, bm = nms.border_m;
+                const float fx = (float)x, fy = (float)y, bm = dl.border_m;
                 const bool is_out = (roundf(fx - bm) - 1.0f) < 0.0f || (roundf(fx + bm) + 1.0f) >= (float)w ||
                                     (roundf(fy - bm) - 1.0f) < 0.0f || (roundf(fy + bm) + 1.0f) >= (float)h;
                 if (is_out) continue;
                 if (x < tl.bx * TW || y < tl.by * TH) continue;  // overlapping (shifted) tiles: only the owner reports
-                const unsigned slot = atomicAdd(nms.count, 1u);
-                if (slot < nms.cap) {
+                const unsigned slot = atomicAdd(ds.count, 1u);
+                if (slot < ds.cap) {
                     Candidate c;
-                    c.level = nms.level;
+                    c.level = dl.level;
                     c.idx = (unsigned)(y * w + x);
                     c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
                     c.img = (unsigned)tl.bz;
-                    nms.cand[slot] = c;
+                    ds.cand[slot] = c;
                 }
             }
             __syncthreads();  // sD (= sP) is overwritten by the next iteration
@@ -909,36 +944,60 @@ void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, flo
 }
 #undef AKZ_DET
 
-// One-kernel LDS-tiled detector (k_detector_tiled); d_cand == nullptr: no extrema test.  S <= 4.
+// One-kernel LDS-tiled detector (k_detector_tiled) over a set of levels with the same sigma_size (<= 4);
+// d_cand == nullptr: no extrema test.  lxx/lyy/lxy of a level may be null together (planes not kept): `keep`
+// must then be false for the whole set.
 bool detector_tiled_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <= 4; }
 #define AKZ_TDET(S)                                                                                                   \
     case S:                                                                                                           \
         if (d_cand && keep)                                                                                           \
-            hipLaunchKernelGGL((k_detector_tiled<S, true, true>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
-                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+            hipLaunchKernelGGL((k_detector_tiled<S, true, true>), grid, dim3(NT), 0, s, ds, kn, kwn, quat);           \
         else if (d_cand)                                                                                              \
-            hipLaunchKernelGGL((k_detector_tiled<S, true, false>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
-                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+            hipLaunchKernelGGL((k_detector_tiled<S, true, false>), grid, dim3(NT), 0, s, ds, kn, kwn, quat);          \
         else if (keep)                                                                                                \
-            hipLaunchKernelGGL((k_detector_tiled<S, false, true>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
-                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+            hipLaunchKernelGGL((k_detector_tiled<S, false, true>), grid, dim3(NT), 0, s, ds, kn, kwn, quat);          \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_detector_tiled<S, false, false>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
-                               ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                                    \
+            hipLaunchKernelGGL((k_detector_tiled<S, false, false>), grid, dim3(NT), 0, s, ds, kn, kwn, quat);         \
         break;
-void detector_tiled_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
-                          float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
-                          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
+uint32_t detector_tiled_set_max() { return (uint32_t)kDetSetMax; }
+void detector_tiled_set(hipStream_t s, uint32_t sigma, const DetLevelDesc* levels, uint32_t nlevels, uint32_t n, float thr,
+                        Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
+    if (nlevels == 0 || nlevels > (uint32_t)kDetSetMax) return;
     const Taps m = taps_scharr_main(sigma);
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
-    const bool keep = lxx && lyy && lxy;
-    const Launch l = plan_tiles(w, h, n);
-    const NmsArgs na{level, thr, border_m, d_cand, cap, d_count};
+    DetSet ds;
+    ds.nlevels = (int)nlevels;
+    ds.thr = thr;
+    ds.cand = d_cand;
+    ds.cap = cap;
+    ds.count = d_count;
+    bool keep = true;
+    long total = 0;
+    for (uint32_t i = 0; i < nlevels; ++i) {
+        const DetLevelDesc& d = levels[i];
+        DetLevel& o = ds.lv[i];
+        o.ls = d.lsmooth; o.lx = d.lx; o.ly = d.ly; o.lxx = d.lxx; o.lyy = d.lyy; o.lxy = d.lxy; o.ldet = d.ldet;
+        o.w = (int)d.w; o.h = (int)d.h;
+        o.tg = plan_tiles(d.w, d.h, n).tg;
+        o.tile0 = (int)total;
+        o.level = d.level;
+        o.border_m = d.border_m;
+        total += (long)o.tg.tx * o.tg.ty * o.tg.n;
+        keep = keep && d.lxx && d.lyy && d.lxy;
+    }
+    ds.ntiles = (int)total;
+    const dim3 grid((unsigned)std::min<long>(total, AKZ_PERSIST_BLOCKS));
     switch (sigma) {
         AKZ_TDET(1) AKZ_TDET(2) AKZ_TDET(3) AKZ_TDET(4)
         default: break;
     }
+}
+void detector_tiled_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
+                          float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
+                          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
+    const DetLevelDesc d{lsmooth, lx, ly, lxx, lyy, lxy, ldet_out, w, h, level, border_m};
+    detector_tiled_set(s, sigma, &d, 1, n, thr, d_cand, cap, d_count);
 }
 #undef AKZ_TDET
 

@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--det-overlap", action="store_true",
                     help="detector launches on a side stream, concurrent with the diffusion (faster, but the FED spans of the "
                          "roofline then include the time shared with the detector kernels)")
+    ap.add_argument("--depth", type=int, default=1, choices=[1, 2],
+                    help="batches begun ahead of the one being finished (the context holds at most three in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
     ap.add_argument("--parts", type=int, default=1,
@@ -134,7 +136,7 @@ def main():
         begin(batch j+1) is enqueued before finish(batch j), also across step boundaries, so the
         candidate fetch + host keypoint logic of a batch run under the kernels of the next one.
         Every step's results are complete (and, with N > 1, gathered) before run_steps returns."""
-        nk, prev, done = 0, None, []
+        nk, inflight, done = 0, [], []
 
         def retire(res):
             nonlocal nk, done
@@ -155,11 +157,11 @@ def main():
                 if args.sync:
                     retire(job.finish())
                     continue
-                if prev is not None:
-                    retire(prev.finish())
-                prev = job
-        if prev is not None:
-            retire(prev.finish())
+                inflight.append(job)
+                if len(inflight) > args.depth:
+                    retire(inflight.pop(0).finish())
+        while inflight:
+            retire(inflight.pop(0).finish())
         return nk
 
     def barrier():

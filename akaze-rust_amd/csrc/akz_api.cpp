@@ -1313,6 +1313,88 @@ int akz_result_descriptors(const akz_result* r, uint64_t img, uint8_t* out) {
     }
     return AKZ_OK;
 }
+// ops::scale_space_extrema::compute_main_orientation (scale_space_extrema.rs:207-329) and
+// ops::descriptors::extract_descriptors (descriptors.rs:14-35) for CALLER-SUPPLIED keypoints of image `img`, on the
+// pyramid the result retains: what the reference's two public ops do when they are handed a keypoint list that did
+// not come out of detect_keypoints (re-description, externally detected points).
+int akz_result_describe_keypoints(const akz_result* r, uint64_t img, akz_keypoint* kps, uint64_t n_kp,
+                                  int compute_orientation, uint8_t* descriptors) {
+    AKZ_TRY(check_img(r, img));
+    akz_ctx* c = r->ctx;
+    AKZ_TRY(bind(c));
+    if (n_kp == 0) return AKZ_OK;
+    if (!kps || !descriptors) {
+        set_error("akz_result_describe_keypoints: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const size_t L = r->plan.size();
+    LevelTable tab;
+    std::memset(&tab, 0, sizeof(tab));
+    for (size_t l = 0; l < L; ++l) {
+        tab.lv[l].lt = r->planes[l][AKZ_LT];
+        tab.lv[l].lx = r->planes[l][AKZ_LX];
+        tab.lv[l].ly = r->planes[l][AKZ_LY];
+        tab.lv[l].w = r->plan[l].w;
+        tab.lv[l].h = r->plan[l].h;
+        tab.lv[l].stride = (uint64_t)r->plan[l].w * r->plan[l].h;
+    }
+    AKZ_TRY(ensure_aux(c));
+    hipStream_t s = c->aux;
+    AKZ_TRY(ensure_pinned(c, c->pin[3], n_kp * sizeof(KpParam)));
+    KpParam* params = (KpParam*)c->pin[3].p;
+    for (uint64_t i = 0; i < n_kp; ++i) {
+        const akz_keypoint& k = kps[i];
+        if (k.class_id >= L || k.octave > 30) {  // the reference indexes evolutions[class_id] and would panic
+            set_error("akz_result_describe_keypoints: keypoint class_id / octave out of range");
+            return AKZ_ERR_INVALID_ARG;
+        }
+        KpParam& p = params[i];
+        const float ratio = (float)(1u << k.octave);
+        p.xf = k.x / ratio;
+        p.yf = k.y / ratio;
+        p.scale = std::round(0.5f * k.size / ratio);
+        p.level = (uint32_t)k.class_id;
+        p.img = (uint32_t)img;
+        p._pad[0] = p._pad[1] = p._pad[2] = 0;
+    }
+    AKZ_TRY(ensure(c, c->kp_in, n_kp * sizeof(KpParam)));
+    AKZ_TRY(ensure(c, c->kp_out, n_kp * sizeof(OrientOut)));
+    AKZ_TRY(ensure(c, c->cosi, n_kp * 2 * sizeof(float)));
+    AKZ_TRY(ensure_pinned(c, c->pin[1], n_kp * std::max(sizeof(OrientOut), 2 * sizeof(float))));
+    KpParam* d_kp = (KpParam*)c->kp_in.p;
+    AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params, n_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+    if (compute_orientation) {
+        unsigned long long wmask = 0;
+        uint32_t nwin = 0;
+        orientation_windows(&wmask, &nwin);
+        OrientOut* d_oo = (OrientOut*)c->kp_out.p;
+        launch::orientation(s, tab, d_kp, (uint32_t)n_kp, wmask, nwin, d_oo);
+        AKZ_HIP_TRY(hipGetLastError());
+        OrientOut* oo = (OrientOut*)c->pin[1].p;
+        AKZ_HIP_TRY(hipMemcpyAsync(oo, d_oo, n_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+        AKZ_HIP_TRY(hipStreamSynchronize(s));
+        for (uint64_t i = 0; i < n_kp; ++i)  // no window sum above zero: the angle keeps its value (scale_space_extrema.rs:322-327)
+            if (oo[i].found) kps[i].angle = atan2f(oo[i].sum_y, oo[i].sum_x);
+    }
+    AKZ_TRY(ensure_pinned(c, c->pin[4], n_kp * 2 * sizeof(float)));
+    float* cosi = (float*)c->pin[4].p;
+    for (uint64_t i = 0; i < n_kp; ++i) {
+        cosi[2 * i] = cosf(kps[i].angle);  // descriptors.rs:55-56
+        cosi[2 * i + 1] = sinf(kps[i].angle);
+    }
+    AKZ_HIP_TRY(hipMemcpyAsync(c->cosi.p, cosi, n_kp * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    AKZ_TRY(ensure(c, c->match_a, n_kp * 64));
+    uint8_t* d_rows = (uint8_t*)c->match_a.p;
+    launch::mldb(s, tab, d_kp, (const float*)c->cosi.p, (uint32_t)n_kp, (uint32_t)r->cfg.descriptor_channels, d_rows);
+    AKZ_HIP_TRY(hipGetLastError());
+    AKZ_TRY(ensure_pinned(c, c->pin[2], n_kp * 64));
+    uint8_t* rows = (uint8_t*)c->pin[2].p;
+    AKZ_HIP_TRY(hipMemcpyAsync(rows, d_rows, n_kp * 64, hipMemcpyDeviceToHost, s));
+    AKZ_HIP_TRY(hipStreamSynchronize(s));
+    const size_t nb = ((6 + 36 + 120) * r->cfg.descriptor_channels + 7) / 8;
+    for (uint64_t i = 0; i < n_kp; ++i) std::memcpy(descriptors + i * nb, rows + i * 64, nb);
+    return AKZ_OK;
+}
 int akz_result_device_descriptors(const akz_result* r, uint64_t img, const uint8_t** d_desc, uint64_t* n_keypoints) {
     AKZ_TRY(check_img(r, img));
     if (d_desc) *d_desc = r->d_desc64 ? r->d_desc64 + r->desc_off[(size_t)img] * 64 : nullptr;

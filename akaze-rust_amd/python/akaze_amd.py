@@ -155,6 +155,7 @@ def lib():
         "akz_write_matches": ([C.c_char_p, vp, u64], i32),
         "akz_read_matches": ([C.c_char_p, vp, u64, pu64], i32),
         "akz_host_select_keypoints": ([u32, u32, C.POINTER(Config), vp, u64, vp, u64, pu64, pu64], i32),
+        "akz_result_describe_keypoints": ([vp, u64, vp, u64, i32, vp], i32),
         "akz_random_seed": ([u64, u64], i32),
         "akz_image_load": ([C.c_char_p, pu32, pu32, pu32, C.POINTER(vp)], i32),
         "akz_image_load_luma": ([C.c_char_p, pu32, pu32, C.POINTER(vp)], i32),
@@ -567,6 +568,16 @@ class ExtractResult:
         _check(lib().akz_result_copy_device_descriptors(self._h, C.c_void_p(dst.data_ptr()), dst.shape[0],
                                                         C.byref(n)))
         return n.value
+
+    def describe_keypoints(self, keypoints, img=0, compute_orientation=True):
+        """compute_main_orientation + extract_descriptors for caller-supplied keypoints on the retained pyramid.
+        Returns (keypoints with the angle filled in, descriptors[n, desc_bytes])."""
+        kp = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE).copy()
+        nb = self.counts(img)[2] or ((6 + 36 + 120) * 3 + 7) // 8
+        desc = np.zeros((len(kp), nb), np.uint8)
+        _check(lib().akz_result_describe_keypoints(self._h, img, kp.ctypes.data, len(kp), int(bool(compute_orientation)),
+                                                   desc.ctypes.data))
+        return kp, desc
 
     def write_evolutions(self, directory, img=0):
         """types::evolution::write_evolutions: one normalised PNG per plane and level."""

@@ -209,6 +209,13 @@ int akz_result_counts(const akz_result* res, uint64_t img, uint64_t* n_levels, u
 int akz_result_keypoints(const akz_result* res, uint64_t img, akz_keypoint* out /* n_keypoints */);
 /* unpadded: n_keypoints * desc_bytes bytes, Descriptor.vector of each keypoint back to back */
 int akz_result_descriptors(const akz_result* res, uint64_t img, uint8_t* out);
+/* ops::scale_space_extrema::compute_main_orientation (scale_space_extrema.rs:207-329) and
+   ops::descriptors::extract_descriptors (descriptors.rs:14-35) for caller-supplied keypoints of image `img` on the
+   retained pyramid: uses point, size, octave and class_id of every keypoint; with compute_orientation != 0 the
+   angle field is (re)computed and written back, otherwise the given angle is used.  descriptors: n x desc_bytes.
+   Keypoints too close to the image border are sampled with clamped coordinates (the reference would panic). */
+int akz_result_describe_keypoints(const akz_result* res, uint64_t img, akz_keypoint* kps, uint64_t n_keypoints,
+                                  int compute_orientation, uint8_t* descriptors);
 /* device-resident descriptors, 64-byte rows (desc_bytes used, rest zero), for akz_match_device / RCCL gather */
 int akz_result_device_descriptors(const akz_result* res, uint64_t img, const uint8_t** d_desc, uint64_t* n_keypoints);
 /* D2D copy of ALL images' descriptor rows (image 0 first, 64-byte rows) into a caller buffer of

@@ -1049,6 +1049,18 @@ uint64_t ref_descriptor_match(const uint8_t* d0, uint64_t n0, const uint8_t* d1,
     return m.size();
 }
 
+// compute_main_orientation (optional) + get_mldb_descriptor for caller-supplied keypoints on a result's pyramid
+// [ref: scale_space_extrema.rs:207-329, descriptors.rs:14-35].  kps: in/out (angle written when orient != 0).
+void ref_result_describe(const ref_result* r, ref_keypoint* kps, uint64_t n, int orient, uint8_t* desc) {
+    const size_t nb = akref::descriptor_bytes(r->cfg);
+    for (uint64_t i = 0; i < n; ++i) {
+        akref::Keypoint k{kps[i].x, kps[i].y, kps[i].response, kps[i].size, kps[i].octave, kps[i].class_id, kps[i].angle};
+        if (orient) akref::compute_main_orientation(k, r->ev);
+        kps[i].angle = k.angle;
+        akref::get_mldb_descriptor(k, r->ev, r->cfg, desc + i * nb);
+    }
+}
+
 // random::default().seed([s0, s1]) for the calling thread (takes effect at the next remove_outliers call)
 void ref_random_seed(uint64_t s0, uint64_t s1) {
     akref::g_seed0 = s0;

@@ -250,6 +250,16 @@ class RefResult:
         lib().ref_result_plane(self._h, lvl, pid, out.ctypes.data_as(C.POINTER(C.c_float)))
         return out
 
+    def describe(self, keypoints, compute_orientation=True):
+        """compute_main_orientation + extract_descriptors for caller-supplied keypoints on this pyramid."""
+        kp = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE).copy()
+        desc = np.zeros((len(kp), self.desc_bytes), np.uint8)
+        fn = lib().ref_result_describe
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        fn.restype = None
+        fn(self._h, kp.ctypes.data_as(C.c_void_p), len(kp), int(bool(compute_orientation)), desc.ctypes.data_as(C.c_void_p))
+        return kp, desc
+
     def close(self):
         if self._h:
             lib().ref_result_free(self._h)

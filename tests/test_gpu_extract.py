@@ -262,3 +262,35 @@ def test_all_pairs_match_over_rccl_world1(ctx, amd, ref):
         assert np.array_equal(got, exp), (i, j)
         total += len(exp)
     assert total > 20
+
+
+def test_describe_caller_supplied_keypoints(ctx, amd, ref):
+    """compute_main_orientation + extract_descriptors as stand-alone ops (scale_space_extrema.rs:207-329,
+    descriptors.rs:14-35) on keypoints the detector did not produce: the detector's own list reordered, and moved /
+    rescaled copies of it, against the oracle on its pyramid."""
+    frame = amd.synth_frame(800, 600, 21)
+    res, rf = ctx.extract_features(frame), ref.extract(frame)
+    kp = res.keypoints()
+    assert len(kp) > 100
+    # 1) the detector's own keypoints, reversed, with the stored angle: same descriptors row for row
+    k1, d1 = res.describe_keypoints(kp[::-1], compute_orientation=False)
+    assert np.array_equal(d1, res.descriptors()[::-1]) and k1.tobytes() == kp[::-1].tobytes()
+    # 2) ... and with the orientation recomputed: same angles
+    k2, d2 = res.describe_keypoints(kp[::-1], compute_orientation=True)
+    assert np.array_equal(k2["angle"], kp["angle"][::-1]) and np.array_equal(d2, d1)
+    # 3) moved and rescaled keypoints (interior ones, so that every sample stays inside the image)
+    inner = kp[(kp["x"] > 150) & (kp["x"] < 650) & (kp["y"] > 150) & (kp["y"] < 450)][:200].copy()
+    inner["x"] += np.float32(1.3)
+    inner["y"] -= np.float32(0.7)
+    inner["size"] *= np.float32(1.1)
+    inner["angle"] = np.float32(0.37)
+    for orient in (True, False):
+        got_k, got_d = res.describe_keypoints(inner, compute_orientation=orient)
+        exp_k, exp_d = rf.describe(inner, compute_orientation=orient)
+        assert np.array_equal(got_k["angle"], exp_k["angle"]), orient
+        assert np.array_equal(got_d, exp_d), orient
+    assert not np.array_equal(got_k["angle"], res.describe_keypoints(inner, compute_orientation=True)[0]["angle"])
+    bad = inner[:2].copy()
+    bad["class_id"] = 99
+    with pytest.raises(amd.AkazeError):
+        res.describe_keypoints(bad)

@@ -14,6 +14,10 @@ Extra objects on that line:
                 pixel-step) / HIP-event time of the FED launches inside the timed
                 steps, against 8 TB/s HBM peak.  roofline.fed_4k is the same kernel measured on
                 3840x2160 planes (the north-star's quoted point), outside the timed region.
+  stage_roofline  algorithmic HBM bytes of every GPU stage / its time in one un-pipelined, fully profiled step.
+  single_frame  BASELINE configs[1] taken literally — one 1920x1080 frame per extract_features call: latency of a
+                lone call and the rate of a stream of such calls (untimed extra leg; the headline workload is the
+                32-frames-per-GPU batch of configs[3], which is what the 1/2/4/8-GPU metric shards).
   cpu_baseline  the CPU oracle (C++ restatement of the reference's CPU path; the Rust reference
                 cannot be built in this image) timed on the host cores on a bounded sample.
 """
@@ -61,6 +65,7 @@ def main():
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-frame-per-call leg")
     ap.add_argument("--parts", type=int, default=1,
                     help="batches per step; batches are software-pipelined on ONE stream (begin(batch j+1) is "
                          "enqueued before finish(batch j)), so the host keypoint phase of a batch runs under the "
@@ -236,6 +241,32 @@ def main():
                               "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * w4 * h4 * nst / launches)}
         del lt, lf
 
+    # ---- BASELINE configs[1] taken literally: ONE frame per extract call (untimed extra leg, rank 0) -----------
+    single = None
+    if rank == 0 and not args.no_single:
+        ctx.set_profiling(0)
+        one = d_frames[:1]
+        for _ in range(10):
+            ctx.extract_begin(one, cfg, keep_all_planes=not args.lean).finish().close()
+        torch.cuda.synchronize()
+        reps = 100
+        t1 = time.perf_counter()
+        for _ in range(reps):                      # latency: begin + finish, nothing in flight
+            ctx.extract_begin(one, cfg, keep_all_planes=not args.lean).finish().close()
+        lat = (time.perf_counter() - t1) / reps
+        t1 = time.perf_counter()
+        prev_job = None
+        for _ in range(reps):                      # stream of single frames, the next one begun before this one is finished
+            job = ctx.extract_begin(one, cfg, keep_all_planes=not args.lean)
+            if prev_job is not None:
+                prev_job.finish().close()
+            prev_job = job
+        prev_job.finish().close()
+        thr = (time.perf_counter() - t1) / reps
+        single = {"workload": f"one {W}x{H} frame per extract_features call (BASELINE configs[1])",
+                  "latency_ms": round(lat * 1e3, 3), "stream_ms_per_frame": round(thr * 1e3, 3),
+                  "stream_Mpix_s": round(W * H / thr / 1e6, 1)}
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -293,6 +324,7 @@ def main():
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,
             "stage_roofline": stage_roofline,
+            "single_frame": single,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

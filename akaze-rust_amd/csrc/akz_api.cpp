@@ -44,6 +44,7 @@ struct akz_ctx {
     DevBuf cand_slot[kSlots], count_slot[kSlots];
     bool slot_busy[kSlots] = {false, false, false};
     uint32_t cand_cap_hint = 1u << 15;  // grows to 1.25x the largest candidate count seen
+    uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     hipStream_t det = nullptr;          // detector launches of a level, concurrent with the diffusion of later levels
     int det_overlap = 0;                // 1: detector launches on `det`, concurrent with the diffusion (akz_ctx_set_detector_overlap)
@@ -1025,9 +1026,25 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
         AKZ_TRY(ensure_pinned(c, c->pin[1], 256));
         uint32_t* total_p = (uint32_t*)c->pin[1].p;
         AKZ_HIP_TRY(hipMemcpyAsync(total_p, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        // Small jobs are bound by the latency of these round trips: fetch, with the count, as many candidates as the
+        // previous job of this context had (+25 %) and the contrast factors, so that one synchronisation serves all.
+        uint32_t spec = 0;
+        if (attempt == 0) {
+            spec = std::min<uint32_t>(cap, c->last_total_cands + c->last_total_cands / 4 + 64u);
+            if ((size_t)spec * sizeof(Candidate) > (1u << 20)) spec = 0;  // large lists: exactly the used part, below
+            AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[5].p, r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+            if (spec) {
+                AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec * sizeof(Candidate)));
+                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->cand_slot[job->slot].p, (size_t)spec * sizeof(Candidate),
+                                           hipMemcpyDeviceToHost, s));
+            }
+        }
         AKZ_HIP_TRY(hipStreamSynchronize(s));
         t_counts = now_ms();
         const uint32_t total_c = *total_p;
+        if (attempt == 0) r->k_host.assign((const double*)c->pin[5].p, (const double*)c->pin[5].p + n);
+        c->last_total_cands = total_c;
         c->cand_cap_hint = std::max(c->cand_cap_hint, (uint32_t)((uint64_t)total_c * 5 / 4 / n) + 64u);
         if (total_c > cap) {  // overflow: grow and redo the NMS pass alone on the stored Ldet planes
             if (attempt >= 3) {
@@ -1045,13 +1062,18 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             AKZ_HIP_TRY(hipGetLastError());
             continue;
         }
-        AKZ_TRY(ensure_pinned(c, c->pin[0], std::max<size_t>(1, total_c) * sizeof(Candidate)));
-        Candidate* hc = (Candidate*)c->pin[0].p;
-        if (total_c) {
-            AKZ_HIP_TRY(hipMemcpyAsync(hc, c->cand_slot[job->slot].p, (size_t)total_c * sizeof(Candidate),
-                                       hipMemcpyDeviceToHost, s));
+        const uint32_t have = std::min(spec, total_c);  // already on the host
+        if (total_c > have) {
+            std::vector<Candidate> keep;
+            if (have) keep.assign((const Candidate*)c->pin[0].p, (const Candidate*)c->pin[0].p + have);  // ensure_pinned may move the buffer
+            AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)total_c * sizeof(Candidate)));
+            if (have) std::memcpy(c->pin[0].p, keep.data(), (size_t)have * sizeof(Candidate));
+            AKZ_HIP_TRY(hipMemcpyAsync((Candidate*)c->pin[0].p + have, (const Candidate*)c->cand_slot[job->slot].p + have,
+                                       (size_t)(total_c - have) * sizeof(Candidate), hipMemcpyDeviceToHost, s));
             AKZ_HIP_TRY(hipStreamSynchronize(s));
         }
+        AKZ_TRY(ensure_pinned(c, c->pin[0], sizeof(Candidate)));
+        Candidate* hc = (Candidate*)c->pin[0].p;
         std::vector<uint32_t> per(n, 0);
         for (uint32_t i = 0; i < total_c; ++i)
             if (hc[i].img < n) per[hc[i].img]++;
@@ -1185,10 +1207,6 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             r->kps[img][i] = akz_keypoint{k.x, k.y, k.response, k.size, k.octave, k.class_id, k.angle, 0};
         }
     }
-    AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
-    AKZ_HIP_TRY(hipMemcpyAsync(c->pin[5].p, r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-    AKZ_HIP_TRY(hipStreamSynchronize(s));
-    r->k_host.assign((const double*)c->pin[5].p, (const double*)c->pin[5].p + n);
     if (c->profiling) {
         resolve_spans(c);  // only spans whose events have completed are resolved
         c->prof.ms[AKZ_ST_TOTAL] += now_ms() - job->t_begin_ms;

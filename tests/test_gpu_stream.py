@@ -134,3 +134,14 @@ def test_stream_blur5(sctx, ref, shape):
     got = sctx.gaussian_blur(torch.from_numpy(u8).cuda(), 1.6).cpu().numpy()
     for i in range(2):
         assert np.array_equal(got[i], ref.gaussian_blur(unit[i], 1.6)), i
+
+
+def test_auto_mode_odd_width_batch_matches_oracle(ctx, amd, ref):
+    """The automatic kernel choice on a batch that is large enough for the streaming kernels but has rows that are
+    not multiples of 4 pixels (u8 level-0 blur falls back to the tiled kernel, streaming preparation and the
+    grouped coarse-level detector run): every plane of one frame and all keypoints / descriptors."""
+    import torch
+    frames = np.stack([amd.synth_frame(1283, 721, 70 + i) for i in range(3)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda())
+    for i in range(3):
+        assert_same_result(res, ref.extract(frames[i], threads=8), planes=(i == 1), img=i)

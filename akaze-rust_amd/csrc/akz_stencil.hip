@@ -248,7 +248,7 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
                 const float* p = sB + (cy - (y0 - 1)) * BW + (cx - (x0 - 1));
                 const float a = p[-1], b = p[0], c = p[1];
                 sM[idx] = ((0.0f + kn * a) + kwn * b) + kn * c;
-                sO[idx] = ((0.0f + -1.0f * a) + 0.0f * b) + 1.0f * c;
+                sO[idx] = (0.0f - a) + c;
             }
         }
         __syncthreads();
@@ -260,7 +260,7 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
             if (x < w && y < h) {
                 const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
                 const int o = (cy - (y0 - 1)) * TW + (cx - x0);
-                const float lx1 = ((0.0f + -1.0f * sM[o - TW]) + 0.0f * sM[o]) + 1.0f * sM[o + TW];
+                const float lx1 = (0.0f - sM[o - TW]) + sM[o + TW];
                 const float ly1 = ((0.0f + kn * sO[o - TW]) + kwn * sO[o]) + kn * sO[o + TW];
                 lflow[base + (size_t)y * w + x] = pm_g2_px(lx1, ly1, inverse_k);
             }
@@ -311,8 +311,10 @@ __device__ __forceinline__ void h_taps(const float* p, float (&a)[4], float (&b)
 __device__ __forceinline__ float tap_main(float a, float b, float c, float kn, float kwn) {
     return ((0.0f + kn * a) + kwn * b) + kn * c;
 }
-__device__ __forceinline__ float tap_off(float a, float b, float c) {
-    return ((0.0f + -1.0f * a) + 0.0f * b) + 1.0f * c;
+// off-axis taps [-1, 0.., 0, ..0, 1]: ((0.0f + -1.0f*a) + 0.0f*b) + 1.0f*c == (0.0f - a) + c bit for bit for every
+// finite b (the zero taps add +-0 to an accumulator that is never -0); four VALU operations fewer per value
+__device__ __forceinline__ float tap_off(float a, float /*b*/, float c) {
+    return (0.0f - a) + c;
 }
 // global load of 4 consecutive pixels of row gy starting at gx (zeros outside the image)
 __device__ __forceinline__ float4 load_quad(const float* __restrict__ plane, int gx, int gy, int w, int h, bool vec_ok) {
@@ -511,11 +513,11 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
         const int o = (cy - (y0 - RING - S)) * RW + (cx - (x0 - RING - S));
         const float xa = sX[o - S], xb = sX[o], xc = sX[o + S];
-        const float ya = sY[o - S], yb = sY[o], yc = sY[o + S];
+        const float ya = sY[o - S], yc = sY[o + S];
         const int q = ly * AW + wc;
         sA[q] = ((0.0f + kn * xa) + kwn * xb) + kn * xc;
-        sB[q] = ((0.0f + -1.0f * ya) + 0.0f * yb) + 1.0f * yc;
-        sC[q] = ((0.0f + -1.0f * xa) + 0.0f * xb) + 1.0f * xc;
+        sB[q] = (0.0f - ya) + yc;
+        sC[q] = (0.0f - xa) + xc;
     };
     // One V-pass position: Ldet (+ second derivatives) at image (x, y); window column wc, window row ly.
     auto v_pos = [&](int x, int wc, int ly, int x0, int y0, size_t base, bool centre) {
@@ -523,7 +525,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         if (x < 0 || x >= w || y < 0 || y >= h) return;
         const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
         const int o = (cy - (y0 - RING - S)) * AW + (cx - (x0 - RING));
-        const float lxx = ((0.0f + -1.0f * sA[o - S * AW]) + 0.0f * sA[o]) + 1.0f * sA[o + S * AW];
+        const float lxx = (0.0f - sA[o - S * AW]) + sA[o + S * AW];
         const float lyy = ((0.0f + kn * sB[o - S * AW]) + kwn * sB[o]) + kn * sB[o + S * AW];
         const float lxy = ((0.0f + kn * sC[o - S * AW]) + kwn * sC[o]) + kn * sC[o + S * AW];
         const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
@@ -544,7 +546,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         const int x = x0 + tx;
         const bool xin = x < w;
         const int cxo = clampi(x, S, w - 1 - S) - (x0 - RING - S);
-        float xa[HIT], xb[HIT], xc[HIT], ya[HIT], yb[HIT], yc[HIT];
+        float xa[HIT], xb[HIT], xc[HIT], ya[HIT], yc[HIT];
         bool ok[HIT];
 #pragma unroll
         for (int i = 0; i < HIT; ++i) {
@@ -552,36 +554,36 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
             ok[i] = xin && ly < AH && y >= 0 && y < h;
             const int o = ok[i] ? (clampi(y, S, h - 1 - S) - (y0 - RING - S)) * RW + cxo : S;
             xa[i] = sX[o - S]; xb[i] = sX[o]; xc[i] = sX[o + S];
-            ya[i] = sY[o - S]; yb[i] = sY[o]; yc[i] = sY[o + S];
+            ya[i] = sY[o - S]; yc[i] = sY[o + S];
         }
 #pragma unroll
         for (int i = 0; i < HIT; ++i)
             if (ok[i]) {
                 const int q = (ty + i * NROWT) * AW + tx + RING;
                 sA[q] = ((0.0f + kn * xa[i]) + kwn * xb[i]) + kn * xc[i];
-                sB[q] = ((0.0f + -1.0f * ya[i]) + 0.0f * yb[i]) + 1.0f * yc[i];
-                sC[q] = ((0.0f + -1.0f * xa[i]) + 0.0f * xb[i]) + 1.0f * xc[i];
+                sB[q] = (0.0f - ya[i]) + yc[i];
+                sC[q] = (0.0f - xa[i]) + xc[i];
             }
     };
     auto v_column = [&](int x0, int y0, size_t base) {
         const int x = x0 + tx;
         const bool xin = x < w;
         const int cxo = clampi(x, S, w - 1 - S) - (x0 - RING);
-        float a0[VIT], a1[VIT], a2[VIT], b0[VIT], b1[VIT], b2[VIT], c0[VIT], c1[VIT], c2[VIT];
+        float a0[VIT], a2[VIT], b0[VIT], b1[VIT], b2[VIT], c0[VIT], c1[VIT], c2[VIT];
         bool ok[VIT];
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int ly = ty + i * NROWT, y = y0 - RING + ly;
             ok[i] = xin && ly < DH && y >= 0 && y < h;
             const int o = ok[i] ? (clampi(y, S, h - 1 - S) - (y0 - RING - S)) * AW + cxo : S * AW;
-            a0[i] = sA[o - S * AW]; a1[i] = sA[o]; a2[i] = sA[o + S * AW];
+            a0[i] = sA[o - S * AW]; a2[i] = sA[o + S * AW];
             b0[i] = sB[o - S * AW]; b1[i] = sB[o]; b2[i] = sB[o + S * AW];
             c0[i] = sC[o - S * AW]; c1[i] = sC[o]; c2[i] = sC[o + S * AW];
         }
         float det[VIT];
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
-            const float lxx = ((0.0f + -1.0f * a0[i]) + 0.0f * a1[i]) + 1.0f * a2[i];
+            const float lxx = (0.0f - a0[i]) + a2[i];
             const float lyy = ((0.0f + kn * b0[i]) + kwn * b1[i]) + kn * b2[i];
             const float lxy = ((0.0f + kn * c0[i]) + kwn * c1[i]) + kn * c2[i];
             det[i] = ((lxx * lyy) - (lxy * lxy)) * quat;

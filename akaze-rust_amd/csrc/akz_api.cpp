@@ -44,6 +44,8 @@ struct akz_ctx {
     DevBuf cand_slot[kSlots], count_slot[kSlots];
     bool slot_busy[kSlots] = {false, false, false};
     uint32_t cand_cap_hint = 1u << 15;  // grows to 1.25x the largest candidate count seen
+    int live_results = 0;               // akz_result objects (also inside jobs) that still point at this context
+    bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     hipStream_t det = nullptr;          // detector launches of a level, concurrent with the diffusion of later levels
@@ -149,6 +151,10 @@ static int bind(akz_ctx* c) {
         set_error("null context");
         return AKZ_ERR_INVALID_ARG;
     }
+    if (c->dead) {
+        set_error("the context of this object was destroyed");
+        return AKZ_ERR_INVALID_ARG;
+    }
     AKZ_HIP_TRY(hipSetDevice(c->device));
     // The HIP runtime keeps ONE last-error slot per thread, shared with every other user of the runtime in the
     // process (PyTorch probes that fail on purpose, ...): drop whatever is in it so that the hipGetLastError()
@@ -245,7 +251,12 @@ int akz_ctx_destroy(akz_ctx* c) {
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    c->slab_pool.clear();
+    c->spans.clear();
+    c->ev_pool.clear();
+    c->aux = c->det = nullptr;
+    c->dead = true;  // results that are still alive keep the (now resource-less) struct; see result_delete
+    if (c->live_results == 0) delete c;
     return AKZ_OK;
 }
 int akz_ctx_synchronize(akz_ctx* c) {
@@ -751,8 +762,11 @@ static void slab_release(akz_ctx* c, void* p, size_t bytes) {
 // the auxiliary stream once `nms_done` fires and runs the host keypoint logic, orientation and
 // descriptors.  With two jobs in flight the host phase of one batch runs under the kernels of the
 // next while the scale-space kernels of both stay serialised on one stream.
+struct ResultDeleter {
+    void operator()(akz_result* r) const;
+};
 struct akz_job {
-    std::unique_ptr<akz_result> r;
+    std::unique_ptr<akz_result, ResultDeleter> r;
     int slot = -1;            // candidate / counter buffers used by this job
     uint32_t cap = 0;         // candidate capacity per image
     hipEvent_t nms_done = nullptr;
@@ -760,11 +774,26 @@ struct akz_job {
 };
 
 static void result_release_device(akz_result* r) {
-    if (r->slab) slab_release(r->ctx, r->slab, r->slab_bytes);
-    if (r->d_desc64) slab_release(r->ctx, r->d_desc64, r->desc_block_bytes);
+    if (r->ctx && r->ctx->dead) {  // the pools went away with the context: hand the blocks back to the runtime
+        if (r->slab) (void)hipFree(r->slab);
+        if (r->d_desc64) (void)hipFree(r->d_desc64);
+    } else {
+        if (r->slab) slab_release(r->ctx, r->slab, r->slab_bytes);
+        if (r->d_desc64) slab_release(r->ctx, r->d_desc64, r->desc_block_bytes);
+    }
     r->slab = nullptr;
     r->d_desc64 = nullptr;
 }
+// Every akz_result is deleted through here: a result may outlive akz_ctx_destroy (a caller that frees in the
+// "wrong" order); the context struct itself is then released with its last result.
+static void result_delete(akz_result* r) {
+    if (!r) return;
+    akz_ctx* c = r->ctx;
+    result_release_device(r);
+    delete r;
+    if (c && --c->live_results == 0 && c->dead) delete c;
+}
+void ResultDeleter::operator()(akz_result* r) const { result_delete(r); }
 static void job_destroy(akz_job* j) {
     if (!j) return;
     akz_ctx* c = j->r ? j->r->ctx : nullptr;
@@ -801,6 +830,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     job->r.reset(new akz_result);
     akz_result* r = job->r.get();
     r->ctx = c;
+    ++c->live_results;
     r->cfg = *cfgp;
     r->w = w; r->h = h; r->n = n; r->flags = flags;
     AKZ_TRY(build_plan(w, h, r->cfg, r->plan));
@@ -1283,8 +1313,7 @@ int akz_job_abandon(akz_job* job) {
 int akz_result_free(akz_result* r) {
     if (!r) return AKZ_OK;
     (void)hipSetDevice(r->ctx->device);
-    result_release_device(r);
-    delete r;
+    result_delete(r);
     return AKZ_OK;
 }
 int akz_result_num_images(const akz_result* r, uint64_t* n) {

@@ -110,6 +110,8 @@ void akz_config_default(akz_config* out);
 int akz_ctx_create(int device, void* stream, akz_ctx** out);
 int akz_stream_create(int device, void** stream_out);
 int akz_stream_destroy(int device, void* stream);
+/* Results and jobs of the context may be freed after it (they keep their host data; device accessors then
+   return AKZ_ERR_INVALID_ARG). */
 int akz_ctx_destroy(akz_ctx* ctx);
 int akz_ctx_synchronize(akz_ctx* ctx);
 void* akz_ctx_stream(akz_ctx* ctx);

@@ -294,3 +294,55 @@ def test_describe_caller_supplied_keypoints(ctx, amd, ref):
     bad["class_id"] = 99
     with pytest.raises(amd.AkazeError):
         res.describe_keypoints(bad)
+
+
+def test_two_contexts_on_two_host_threads(amd, ref):
+    """One context per host thread (the C ABI's threading rule), two threads on the same GPU at once: results are
+    those of the oracle, nothing leaks between the contexts."""
+    import threading
+    import torch
+    frames = [np.stack([amd.synth_frame(640, 360, 80 + 10 * t + i) for i in range(2)]) for t in range(2)]
+    out, errs = [None, None], []
+
+    def work(t):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                c = amd.Context(0, stream.cuda_stream)
+                d = torch.from_numpy(frames[t]).cuda()
+                stream.synchronize()
+                last = None
+                for _ in range(6):
+                    last = c.extract_features(d, keep_all_planes=False)
+                out[t] = [(last.keypoints(i).copy(), last.descriptors(i).copy()) for i in range(2)]
+                c.close()
+        except Exception as e:  # surfaced in the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for t in range(2):
+        for i in range(2):
+            q = ref.extract(frames[t][i])
+            assert out[t][i][0].tobytes() == q.keypoints().tobytes() and np.array_equal(out[t][i][1], q.descriptors())
+
+
+def test_result_may_outlive_its_context(amd, ref):
+    """Freeing in the 'wrong' order is safe: a result keeps its host data after akz_ctx_destroy, device accessors
+    report the destroyed context instead of touching freed memory, and the result can still be freed."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    frame = amd.synth_frame(480, 270, 3)
+    res = c.extract_features(frame)
+    job = c.extract_begin(torch.from_numpy(frame[None]).cuda())
+    c.close()
+    q = ref.extract(frame)
+    assert res.keypoints().tobytes() == q.keypoints().tobytes() and np.array_equal(res.descriptors(), q.descriptors())
+    with pytest.raises(amd.AkazeError):
+        res.plane(2, "Lt")
+    with pytest.raises(amd.AkazeError):
+        job.finish()
+    res.close()
+    del job

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "akz_internal.hpp"
 
@@ -1054,10 +1055,24 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
     for (uint32_t i = 0; i < 8; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
     const dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
     if (variant == 2) {
-        if (n_steps <= 4)
-            hipLaunchKernelGGL((k_fed_own<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
-                               (int)h, ht);
-        else
+        if (n_steps <= 4) {
+            // halo 4: a 64 x 48 tile gives 18 x 27 (n = 3) or 18 x 28 (n = 4) owner threads of 512; 64 x 32 only 342 / 360
+            static const int th4 = [] {
+                const char* e = std::getenv("AKZ_FED_TH4");
+                return e ? std::atoi(e) : 48;
+            }();
+            if (th4 == 48 && h >= 48) {
+                const dim3 g48((w + TW - 1) / TW, (h + 47) / 48, n);
+                hipLaunchKernelGGL((k_fed_own<TW, 48, 4, NT>), g48, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
+                                   (int)h, ht);
+            } else if (th4 == 40 && h >= 40) {
+                const dim3 g40((w + TW - 1) / TW, (h + 39) / 40, n);
+                hipLaunchKernelGGL((k_fed_own<TW, 40, 4, NT>), g40, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
+                                   (int)h, ht);
+            } else
+                hipLaunchKernelGGL((k_fed_own<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
+                                   (int)h, ht);
+        } else
             hipLaunchKernelGGL((k_fed_own<TW, TH, 8, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
                                (int)h, ht);
         return;

@@ -455,6 +455,69 @@ k_deriv1(const float* __restrict__ ls, float* __restrict__ lx_out, float* __rest
 // written only if the caller keeps them.  (One pixel per thread and stage: a float4-per-thread form
 // measured 3-4 % slower here — too few work items per phase for 512 threads.)
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Extrema of one tile from its Ldet window in LDS (window origin one pixel up-left of the tile, pitch DW):
+// threshold + strict 4-neighbour maximum + descriptor-border test (scale_space_extrema.rs:32-42, :80-87).
+// Slots of the global candidate list are reserved ONCE PER TILE: the threads count their extrema in an LDS
+// counter, one thread adds the tile's total to the global counter (a frame with fine texture has several extrema
+// per tile, and a million same-address device atomics per batch cost 0.6 ms), then every thread writes its
+// candidates into the reserved range.  Candidates are appended unordered; the host sorts them into raster order.
+// sCnt[0] must be zero on entry (thread 0 clears it behind an earlier barrier of the tile loop); the caller
+// places a barrier after the call before the Ldet window is overwritten.
+// ---------------------------------------------------------------------------------------------
+template <int DW>
+__device__ __forceinline__ void tile_extrema(const float* sD, unsigned* sCnt, int tid, const Tile& tl, int w, int h,
+                                             float thr, float bm, unsigned level, Candidate* __restrict__ cand,
+                                             unsigned cap, unsigned* __restrict__ count) {
+    constexpr int IT = TW * TH / NT;
+    static_assert(IT * NT == TW * TH && IT <= 32, "whole number of tile pixels per thread");
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NT;
+        const int ly = idx / TW, lx = idx - ly * TW;
+        const int x = tl.x0 + lx, y = tl.y0 + ly;
+        // flat range (w+1) .. len-w-2 of the reference loop; x = w-1 never passes the border test
+        if (x < 1 || x > w - 2 || y < 1 || y > h - 2) continue;
+        if ((long)y * w + x >= (long)w * h - w - 1) continue;
+        const int o = (ly + 1) * DW + (lx + 1);
+        const float v = sD[o];
+        if (!(v > thr)) continue;
+        if (!(v > sD[o + 1] && v > sD[o - 1] && v > sD[o - DW] && v > sD[o + DW])) continue;
+        const float fx = (float)x, fy = (float)y;
+        const bool is_out = (roundf(fx - bm) - 1.0f) < 0.0f || (roundf(fx + bm) + 1.0f) >= (float)w ||
+                            (roundf(fy - bm) - 1.0f) < 0.0f || (roundf(fy + bm) + 1.0f) >= (float)h;
+        if (is_out) continue;
+        // tiles shifted inward overlap their neighbour: only the owner of a pixel reports it
+        if (x < tl.bx * TW || y < tl.by * TH) continue;
+        mask |= 1u << i;
+    }
+    const unsigned cnt = (unsigned)__popc(mask);
+    unsigned mine = 0;
+    if (cnt) mine = atomicAdd(&sCnt[0], cnt);
+    __syncthreads();
+    if (sCnt[0] == 0) return;  // uniform
+    if (tid == 0) sCnt[1] = atomicAdd(count, sCnt[0]);
+    __syncthreads();
+    unsigned slot = sCnt[1] + mine;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        if (!((mask >> i) & 1u)) continue;
+        const int idx = tid + i * NT;
+        const int ly = idx / TW, lx = idx - ly * TW;
+        const int o = (ly + 1) * DW + (lx + 1);
+        if (slot < cap) {
+            Candidate c;
+            c.level = level;
+            c.idx = (unsigned)((tl.y0 + ly) * w + tl.x0 + lx);
+            c.v = sD[o]; c.xp = sD[o + 1]; c.xm = sD[o - 1]; c.yp = sD[o + DW]; c.ym = sD[o - DW];
+            c.img = (unsigned)tl.bz;
+            cand[slot] = c;
+        }
+        ++slot;
+    }
+}
+
 struct NmsArgs {
     unsigned level;
     float thr, border_m;
@@ -481,6 +544,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
     __shared__ float sA[AH * AW];  // H_main(Lx)
     __shared__ float sB[AH * AW];  // H_off(Ly)
     __shared__ float sC[AH * AW];  // H_off(Lx)
+    __shared__ unsigned sCnt[2];   // extrema of the tile, base slot in the candidate list
     float* sD = sX;                // Ldet window (valid after the second barrier)
     const int tid = threadIdx.x;
     const int tx = tid & (TW - 1), ty = tid / TW;
@@ -614,6 +678,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
             }
         }
         __syncthreads();
+        if (NMS && tid == 0) sCnt[0] = 0;
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         const Tile tl = decode_tile(tile, tg, w, h);
         const int x0 = tl.x0, y0 = tl.y0;
@@ -627,33 +692,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         if (NMS && tid < 2 * DH) v_pos((tid & 1) ? x0 + TW : x0 - 1, (tid & 1) ? DW - 1 : 0, tid >> 1, x0, y0, base, false);
         __syncthreads();
         if (NMS) {
-            const int x = x0 + tx;
-            for (int ly = ty; ly < TH; ly += NROWT) {
-                const int y = y0 + ly;
-                // flat range (w+1) .. len-w-2 of the reference loop; x = w-1 never passes the border test
-                if (x < 1 || x > w - 2 || y < 1 || y > h - 2) continue;
-                if ((long)y * w + x >= (long)w * h - w - 1) continue;
-                const int o = (ly + 1) * DW + (tx + 1);
-                const float v = sD[o];
-                if (!(v > nms.thr)) continue;
-                const float xp = sD[o + 1], xm = sD[o - 1], yp = sD[o + DW], ym = sD[o - DW];
-                if (!(v > xp && v > xm && v > ym && v > yp)) continue;
-                const float fx = (float)x, fy = (float)y, bm = nms.border_m;
-                const bool is_out = (roundf(fx - bm) - 1.0f) < 0.0f || (roundf(fx + bm) + 1.0f) >= (float)w ||
-                                    (roundf(fy - bm) - 1.0f) < 0.0f || (roundf(fy + bm) + 1.0f) >= (float)h;
-                if (is_out) continue;
-                // tiles shifted inward overlap their neighbour: only the owner of a pixel reports it
-                if (x < tl.bx * TW || y < tl.by * TH) continue;
-                const unsigned slot = atomicAdd(nms.count, 1u);
-                if (slot < nms.cap) {
-                    Candidate c;
-                    c.level = nms.level;
-                    c.idx = (unsigned)(y * w + x);
-                    c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
-                    c.img = (unsigned)tl.bz;
-                    nms.cand[slot] = c;
-                }
-            }
+            tile_extrema<DW>(sD, sCnt, tid, tl, w, h, nms.thr, nms.border_m, nms.level, nms.cand, nms.cap, nms.count);
             __syncthreads();  // sD (= sX) is overwritten by the next iteration
         }
     }
@@ -705,6 +744,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
     constexpr int NLOAD = (W0W * W0H + NT - 1) / NT;
     __shared__ float sP[PSZ];  // Lsmooth, then Lx | Ly, then Ldet
     __shared__ float sQ[QSZ];  // Hm | Ho, then A | B | C
+    __shared__ unsigned sCnt[2];  // extrema of the tile, base slot in the candidate list
     float* const s0 = sP;
     float* const sHm = sQ;
     float* const sHo = sQ + H1W * H1H;
@@ -744,6 +784,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
             if (idx < W0W * W0H) s0[idx] = regs[k];
         }
         __syncthreads();
+        if (NMS && tid == 0) sCnt[0] = 0;
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         const DetLevel& dl = ds.lv[level_of(tile)];
         const int w = dl.w, h = dl.h;
@@ -824,32 +865,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
         }
         __syncthreads();
         if (NMS) {
-            for (int idx = tid; idx < TW * TH; idx += NT) {
-                const int ly = idx / TW, lx = idx - ly * TW;
-                const int x = x0 + lx, y = y0 + ly;
-                // flat range (w+1) .. len-w-2 of the reference loop; x = w-1 never passes the border test
-                if (x < 1 || x > w - 2 || y < 1 || y > h - 2) continue;
-                if ((long)y * w + x >= (long)w * h - w - 1) continue;
-                const int o = (ly + 1) * DW + (lx + 1);
-                const float v = sD[o];
-                if (!(v > ds.thr)) continue;
-                const float xp = sD[o + 1], xm = sD[o - 1], yp = sD[o + DW], ym = sD[o - DW];
-                if (!(v > xp && v > xm && v > ym && v > yp)) continue;
-                const float fx = (float)x, fy = (float)y, bm = dl.border_m;
-                const bool is_out = (roundf(fx - bm) - 1.0f) < 0.0f || (roundf(fx + bm) + 1.0f) >= (float)w ||
-                                    (roundf(fy - bm) - 1.0f) < 0.0f || (roundf(fy + bm) + 1.0f) >= (float)h;
-                if (is_out) continue;
-                if (x < tl.bx * TW || y < tl.by * TH) continue;  // overlapping (shifted) tiles: only the owner reports
-                const unsigned slot = atomicAdd(ds.count, 1u);
-                if (slot < ds.cap) {
-                    Candidate c;
-                    c.level = dl.level;
-                    c.idx = (unsigned)(y * w + x);
-                    c.v = v; c.xp = xp; c.xm = xm; c.yp = yp; c.ym = ym;
-                    c.img = (unsigned)tl.bz;
-                    ds.cand[slot] = c;
-                }
-            }
+            tile_extrema<DW>(sD, sCnt, tid, tl, w, h, ds.thr, dl.border_m, dl.level, ds.cand, ds.cap, ds.count);
             __syncthreads();  // sD (= sP) is overwritten by the next iteration
         }
     }
@@ -859,13 +875,22 @@ struct Launch {
     TileGrid tg;
     dim3 grid;
 };
+// workgroups of a persistent launch; AKZ_PERSIST_BLOCKS in the environment overrides the built-in value (tuning runs)
+inline long persist_blocks() {
+    static const long v = [] {
+        const char* e = std::getenv("AKZ_PERSIST_BLOCKS");
+        const long x = e ? std::atol(e) : 0;
+        return x > 0 ? x : (long)AKZ_PERSIST_BLOCKS;
+    }();
+    return v;
+}
 inline Launch plan_tiles(uint32_t w, uint32_t h, uint32_t n) {
     Launch l;
     l.tg.tx = (int)((w + TW - 1) / TW);
     l.tg.ty = (int)((h + TH - 1) / TH);
     l.tg.n = (int)n;
     const long total = (long)l.tg.tx * l.tg.ty * l.tg.n;
-    l.grid = dim3((unsigned)std::min<long>(total, AKZ_PERSIST_BLOCKS));
+    l.grid = dim3((unsigned)std::min<long>(total, persist_blocks()));
     return l;
 }
 
@@ -989,7 +1014,7 @@ void detector_tiled_set(hipStream_t s, uint32_t sigma, const DetLevelDesc* level
         keep = keep && d.lxx && d.lyy && d.lxy;
     }
     ds.ntiles = (int)total;
-    const dim3 grid((unsigned)std::min<long>(total, AKZ_PERSIST_BLOCKS));
+    const dim3 grid((unsigned)std::min<long>(total, persist_blocks()));
     switch (sigma) {
         AKZ_TDET(1) AKZ_TDET(2) AKZ_TDET(3) AKZ_TDET(4)
         default: break;

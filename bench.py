@@ -63,6 +63,8 @@ def main():
                          "roofline then include the time shared with the detector kernels)")
     ap.add_argument("--depth", type=int, default=1, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
+    ap.add_argument("--threshold", type=float, default=None,
+                    help="detector_threshold override (tuning runs: a huge value removes every extremum candidate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-frame-per-call leg")
@@ -97,6 +99,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = A.Config(num_sublevels=args.sublevels, max_octave_evolution=args.octaves)  # default 4 x 4, 486-bit M-LDB
+    if args.threshold is not None:
+        cfg.detector_threshold = args.threshold
     W, H, F = args.width, args.height, args.frames
 
     # this rank's shard of the world*F frames of a step: image i -> GPU i mod world (weak scaling)

@@ -296,8 +296,11 @@ k_fed_fused(const float* __restrict__ L_in, const float* __restrict__ C, float* 
 // values further than n - s pixels from the centre are never used), so there is no divergence
 // around the shuffles.
 // ---------------------------------------------------------------------------------------------
+#ifndef AKZ_FED_WAVES
+#define AKZ_FED_WAVES 6  // 80 VGPRs: three 512-thread workgroups per CU instead of two (+9 % on the FED launches); 8 would spill
+#endif
 template <int TW, int TH, int HALO, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(AKZ_FED_WAVES, AKZ_FED_WAVES)))
 k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __restrict__ L_out,
           float* __restrict__ Lstep, int w, int h, FedTaus ht) {
     constexpr int RW = TW + 2 * HALO;    // region width in pixels (multiple of 4)

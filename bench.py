@@ -16,7 +16,8 @@ Extra objects on that line:
                 3840x2160 planes (the north-star's quoted point), outside the timed region.
   stage_roofline  algorithmic HBM bytes of every GPU stage / its time in one un-pipelined, fully profiled step.
   single_frame  BASELINE configs[1] taken literally — one 1920x1080 frame per extract_features call: latency of a
-                lone call and the rate of a stream of such calls (untimed extra leg; the headline workload is the
+                lone call, the rate of a stream of such calls on one context, and on four contexts driven by four
+                host threads (untimed extra leg; the headline workload is the
                 32-frames-per-GPU batch of configs[3], which is what the 1/2/4/8-GPU metric shards).
   cpu_baseline  the CPU oracle (C++ restatement of the reference's CPU path; the Rust reference
                 cannot be built in this image) timed on the host cores on a bounded sample.
@@ -270,6 +271,40 @@ def main():
         single = {"workload": f"one {W}x{H} frame per extract_features call (BASELINE configs[1])",
                   "latency_ms": round(lat * 1e3, 3), "stream_ms_per_frame": round(thr * 1e3, 3),
                   "stream_Mpix_s": round(W * H / thr / 1e6, 1)}
+        # the same calls from K host threads with one context + stream each: a lone 1080p chain is launch-latency
+        # bound and leaves most of the chip idle, concurrent chains fill it (ctypes releases the GIL in the calls)
+        import threading
+        K, reps_k = 4, 60
+        wall = [0.0] * K
+        bar = threading.Barrier(K)
+
+        def single_worker(k):
+            st_k = torch.cuda.Stream(dev)
+            ctx_k = A.Context(local_rank, st_k.cuda_stream)
+            fr = d_frames[k % F: k % F + 1]
+            for _ in range(5):
+                ctx_k.extract_begin(fr, cfg, keep_all_planes=not args.lean).finish().close()
+            bar.wait()
+            t_k = time.perf_counter()
+            prev = None
+            for _ in range(reps_k):
+                job = ctx_k.extract_begin(fr, cfg, keep_all_planes=not args.lean)
+                if prev is not None:
+                    prev.finish().close()
+                prev = job
+            prev.finish().close()
+            wall[k] = time.perf_counter() - t_k
+            bar.wait()
+            ctx_k.close()
+
+        threads = [threading.Thread(target=single_worker, args=(k,)) for k in range(K)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        per = max(wall) / (K * reps_k)
+        single["multi_context"] = {"contexts": K, "ms_per_frame": round(per * 1e3, 3),
+                                   "Mpix_s": round(W * H / per / 1e6, 1)}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only -------
     cpu = None

@@ -1,0 +1,94 @@
+// HBM bandwidth of TILED plane traffic (tools only; not part of the product): every workgroup of 512 threads moves
+// TW x TH tiles of R input planes to W output planes of a batch of 1920x1080 frames with no arithmetic, in the access
+// shapes the stencil kernels use (one dword per lane and row, or one float4 per lane), one tile per workgroup or a
+// persistent grid.  What this reaches is the ceiling of a tiled kernel with that read:write mix.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+template <int R, int W, int TW, int TH, int VEC>
+__global__ void __launch_bounds__(512) k_tile(const float* __restrict__ in, float* __restrict__ out, int w, int h, int n,
+                                               size_t plane, int ntx, int nty) {
+    const int ntiles = ntx * nty * n;
+    constexpr int CW = TW / VEC;          // lanes per tile row
+    constexpr int ROWS = 512 / CW;        // tile rows covered per pass
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int bz = t / (ntx * nty), rem = t - bz * ntx * nty, by = rem / ntx, bx = rem - by * ntx;
+        const int x = bx * TW + tx * VEC;
+        const size_t base = (size_t)bz * w * h;
+#pragma unroll
+        for (int r0 = 0; r0 < TH; r0 += ROWS) {
+            const int y = by * TH + r0 + ty;
+            if (ty >= TH || y >= h || x >= w) continue;
+            const size_t g = base + (size_t)y * w + x;
+            if (VEC == 4) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 v = *reinterpret_cast<const float4*>(in + r * plane + g);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    acc.x += 1.0f;
+                    *reinterpret_cast<float4*>(out + k * plane + g) = acc;
+                }
+            } else {
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc += in[r * plane + g];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    acc += 1.0f;
+                    out[k * plane + g] = acc;
+                }
+            }
+        }
+    }
+}
+
+template <int R, int W, int TW, int TH, int VEC>
+void run(const float* in, float* out, int w, int h, int n, int blocks) {
+    const int ntx = (w + TW - 1) / TW, nty = (h + TH - 1) / TH;
+    const size_t plane = (size_t)w * h * n;
+    const int grid = blocks > 0 ? blocks : ntx * nty * n;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((k_tile<R, W, TW, TH, VEC>), dim3(grid), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
+    hipEventRecord(a);
+    const int it = 10;
+    for (int i = 0; i < it; ++i)
+        hipLaunchKernelGGL((k_tile<R, W, TW, TH, VEC>), dim3(grid), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double bytes = (double)plane * 4 * (R + W) * it;
+    printf("R%d:W%d tile %3dx%-2d vec%d grid %6d  %5.0f GB/s  (%.0f us)\n", R, W, TW, TH, VEC, grid, bytes / ms / 1e6, ms / it * 1e3);
+}
+
+template <int R, int W>
+void shapes(const float* in, float* out, int w, int h, int n) {
+    for (int blocks : {0, 1024, 768, 512}) {
+        run<R, W, 64, 32, 1>(in, out, w, h, n, blocks);
+        run<R, W, 64, 32, 4>(in, out, w, h, n, blocks);
+        run<R, W, 128, 16, 1>(in, out, w, h, n, blocks);
+        run<R, W, 128, 16, 4>(in, out, w, h, n, blocks);
+        run<R, W, 256, 8, 4>(in, out, w, h, n, blocks);
+        run<R, W, 512, 4, 4>(in, out, w, h, n, blocks);
+        run<R, W, 1920, 1, 4>(in, out, w, h, n, blocks);
+    }
+}
+
+int main() {
+    const int w = 1920, h = 1080, n = 32;
+    const size_t plane = (size_t)w * h * n;
+    float *in, *out;
+    hipMalloc(&in, plane * 4 * 2); hipMalloc(&out, plane * 4 * 6);
+    hipMemset(in, 0, plane * 4 * 2); hipMemset(out, 0, plane * 4 * 6);
+    shapes<1, 2>(in, out, w, h, n);   // k_deriv1, k_prep
+    shapes<2, 4>(in, out, w, h, n);   // k_deriv2, all planes kept
+    shapes<1, 6>(in, out, w, h, n);   // one-kernel detector
+    shapes<2, 1>(in, out, w, h, n);   // FED launch (Lt, Lflow -> Lt')
+    return 0;
+}

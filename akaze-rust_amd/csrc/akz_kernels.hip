@@ -156,6 +156,14 @@ struct FedTaus {
     float half_tau[8];  // 0.5f * (tau as f32) per step (nonlinear_diffusion.rs:67)
 };
 
+// neighbour lane exchange as a one-instruction DPP move (no LDS crossbar round trip as with ds_bpermute)
+__device__ __forceinline__ float from_left_lane(float v) {  // lane i receives lane i-1 (DPP wave_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right_lane(float v) {  // lane i receives lane i+1 (DPP wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
 template <bool INNER>
 __device__ __forceinline__ float4 fed_group(const float4 lc, const float4 cc, const float4 ln, const float4 cn,
                                             const float4 ls, const float4 cs, float lw, float cw, float le, float ce,
@@ -393,8 +401,8 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
         const float half_tau = ht.half_tau[s - 1];
         // left / right neighbours from the adjacent lanes (same row pair, neighbouring group column);
         // the first / last lane of a wave and region edges fall back to LDS (edge values are never used)
-        float lwa = __shfl_up(la[3], 1, 64), lwb = __shfl_up(lb[3], 1, 64);
-        float lea = __shfl_down(la[0], 1, 64), leb = __shfl_down(lb[0], 1, 64);
+        float lwa = from_left_lane(la[3]), lwb = from_left_lane(lb[3]);
+        float lea = from_right_lane(la[0]), leb = from_right_lane(lb[0]);
         if (lane == 0u || g == 0) { lwa = src[oa - 1]; lwb = src[ob - 1]; }
         if (lane == 63u || g == XG - 1) { lea = src[oa + 4]; leb = src[ob + 4]; }
         const float4 n4 = *reinterpret_cast<const float4*>(src + oa - RP);

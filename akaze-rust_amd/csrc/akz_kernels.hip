@@ -364,12 +364,14 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
     const int gx = x0 - HALO + 4 * g, gya = y0 - n + lya, gyb = gya + 1;
     const unsigned lane = threadIdx.x & 63u;
 
-    float la[4], lb[4];
-    float sxa[5], sxb[5], sN[4], sM[4], sS[4];  // Lflow pair sums, constant over the steps
+    // Row-pair vectors: .x belongs to owned row a, .y to owned row b, so that every flux and update below is one
+    // packed f32 operation (v_pk_add_f32 / v_pk_mul_f32: both rows per instruction, IEEE per component, no FMA).
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 L[4];                 // Lt of the two owned rows
+    v2 SX[5], SU[4], SV[4];  // Lflow pair sums, constant over the steps: x-direction | (north of a, a|b) | (a|b, south of b)
     {
         const float4 va = *reinterpret_cast<const float4*>(sA + oa), vb = *reinterpret_cast<const float4*>(sA + ob);
-        la[0] = va.x; la[1] = va.y; la[2] = va.z; la[3] = va.w;
-        lb[0] = vb.x; lb[1] = vb.y; lb[2] = vb.z; lb[3] = vb.w;
+        L[0] = v2{va.x, vb.x}; L[1] = v2{va.y, vb.y}; L[2] = v2{va.z, vb.z}; L[3] = v2{va.w, vb.w};
         const float4 ca4 = *reinterpret_cast<const float4*>(sB + oa), cb4 = *reinterpret_cast<const float4*>(sB + ob);
         const float4 cn4 = *reinterpret_cast<const float4*>(sB + oa - RP);
         const float4 cs4 = *reinterpret_cast<const float4*>(sB + ob + RP);
@@ -377,15 +379,12 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
         const float cb[6] = {sB[ob - 1], cb4.x, cb4.y, cb4.z, cb4.w, sB[ob + 4]};
         const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            sxa[i] = ca[i] + ca[i + 1];
-            sxb[i] = cb[i] + cb[i + 1];
-        }
+        for (int i = 0; i < 5; ++i) SX[i] = v2{ca[i] + ca[i + 1], cb[i] + cb[i + 1]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sN[i] = cn[i] + ca[i + 1];
-            sM[i] = ca[i + 1] + cb[i + 1];
-            sS[i] = cb[i + 1] + cs[i];
+            const float sN = cn[i] + ca[i + 1], sM = ca[i + 1] + cb[i + 1], sS = cb[i + 1] + cs[i];
+            SU[i] = v2{sN, sM};
+            SV[i] = v2{sM, sS};
         }
     }
     __syncthreads();  // sB is free from here on: it becomes the second Lt buffer
@@ -396,74 +395,60 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
 
     float* src = sA;
     float* dst = sB;
-    float sta[4] = {0.f, 0.f, 0.f, 0.f}, stb[4] = {0.f, 0.f, 0.f, 0.f};
+    v2 ST[4] = {v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}};
     for (int s = 1; s <= n; ++s) {
         const float half_tau = ht.half_tau[s - 1];
         // left / right neighbours from the adjacent lanes (same row pair, neighbouring group column);
         // the first / last lane of a wave and region edges fall back to LDS (edge values are never used)
-        float lwa = from_left_lane(la[3]), lwb = from_left_lane(lb[3]);
-        float lea = from_right_lane(la[0]), leb = from_right_lane(lb[0]);
-        if (lane == 0u || g == 0) { lwa = src[oa - 1]; lwb = src[ob - 1]; }
-        if (lane == 63u || g == XG - 1) { lea = src[oa + 4]; leb = src[ob + 4]; }
+        v2 Lw = v2{from_left_lane(L[3].x), from_left_lane(L[3].y)};
+        v2 Le = v2{from_right_lane(L[0].x), from_right_lane(L[0].y)};
+        if (lane == 0u || g == 0) Lw = v2{src[oa - 1], src[ob - 1]};
+        if (lane == 63u || g == XG - 1) Le = v2{src[oa + 4], src[ob + 4]};
         const float4 n4 = *reinterpret_cast<const float4*>(src + oa - RP);
         const float4 s4 = *reinterpret_cast<const float4*>(src + ob + RP);
         const float ln[4] = {n4.x, n4.y, n4.z, n4.w}, ls[4] = {s4.x, s4.y, s4.z, s4.w};
-        const float ra[6] = {lwa, la[0], la[1], la[2], la[3], lea};
-        const float rb[6] = {lwb, lb[0], lb[1], lb[2], lb[3], leb};
-        float xfa[5], xfb[5], fN[4], fM[4], fS[4];
+        const v2 R[6] = {Lw, L[0], L[1], L[2], L[3], Le};
+        v2 XF[5];  // x fluxes between columns i-1 and i of the group (x_neg(x) and x_pos(x-1) are one expression, :63-64)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            xfa[i] = sxa[i] * (ra[i + 1] - ra[i]);
-            xfb[i] = sxb[i] * (rb[i + 1] - rb[i]);
-        }
+        for (int i = 0; i < 5; ++i) XF[i] = SX[i] * (R[i + 1] - R[i]);
+        v2 U[4], V[4];  // (y_neg of a, y_pos of a == y_neg of b) and (y_pos of a, y_pos of b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            fN[i] = sN[i] * (la[i] - ln[i]);  // y_neg of row a
-            fM[i] = sM[i] * (lb[i] - la[i]);  // y_pos of row a == y_neg of row b
-            fS[i] = sS[i] * (ls[i] - lb[i]);  // y_pos of row b
+            U[i] = SU[i] * (L[i] - v2{ln[i], L[i].x});
+            V[i] = SV[i] * (v2{L[i].y, ls[i]} - L[i]);
         }
-        float na[4], nb[4];
         if (inner) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                sta[i] = half_tau * (((xfa[i + 1] - xfa[i]) + fM[i]) - fN[i]);
-                stb[i] = half_tau * (((xfb[i + 1] - xfb[i]) + fS[i]) - fM[i]);
-                na[i] = la[i] + sta[i];
-                nb[i] = lb[i] + stb[i];
+                ST[i] = half_tau * (((XF[i + 1] - XF[i]) + V[i]) - U[i]);
+                L[i] = L[i] + ST[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool hxp = gx + i + 1 < w, hxn = gx + i > 0;
-                float ta = hxp ? (hxn ? xfa[i + 1] - xfa[i] : xfa[i + 1]) : -xfa[i];
-                float tb = hxp ? (hxn ? xfb[i + 1] - xfb[i] : xfb[i + 1]) : -xfb[i];
+                float ta = hxp ? (hxn ? XF[i + 1].x - XF[i].x : XF[i + 1].x) : -XF[i].x;
+                float tb = hxp ? (hxn ? XF[i + 1].y - XF[i].y : XF[i + 1].y) : -XF[i].y;
                 if (a_hyp) {
-                    ta = ta + fM[i];
-                    if (a_hyn) ta = ta - fN[i];
+                    ta = ta + V[i].x;
+                    if (a_hyn) ta = ta - U[i].x;
                 } else {
-                    ta = ta + sN[i] * (ln[i] - la[i]);  // last image row: y_pos towards y-1 (:104-119)
+                    ta = ta + SU[i].x * (ln[i] - L[i].x);  // last image row: y_pos towards y-1 (:104-119)
                 }
                 if (b_hyp) {
-                    tb = tb + fS[i];
-                    if (b_hyn) tb = tb - fM[i];
+                    tb = tb + V[i].y;
+                    if (b_hyn) tb = tb - U[i].y;
                 } else {
-                    tb = tb + sM[i] * (la[i] - lb[i]);
+                    tb = tb + SU[i].y * (L[i].x - L[i].y);
                 }
-                sta[i] = half_tau * ta;
-                stb[i] = half_tau * tb;
-                na[i] = la[i] + sta[i];
-                nb[i] = lb[i] + stb[i];
+                ST[i] = v2{half_tau * ta, half_tau * tb};
+                L[i] = L[i] + ST[i];
             }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            la[i] = na[i];
-            lb[i] = nb[i];
         }
         if (s < n) {
             if (active) {
-                *reinterpret_cast<float4*>(dst + oa) = make_float4(la[0], la[1], la[2], la[3]);
-                *reinterpret_cast<float4*>(dst + ob) = make_float4(lb[0], lb[1], lb[2], lb[3]);
+                *reinterpret_cast<float4*>(dst + oa) = make_float4(L[0].x, L[1].x, L[2].x, L[3].x);
+                *reinterpret_cast<float4*>(dst + ob) = make_float4(L[0].y, L[1].y, L[2].y, L[3].y);
             }
             __syncthreads();
             float* t = src;
@@ -471,6 +456,8 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
             dst = t;
         }
     }
+    const float la[4] = {L[0].x, L[1].x, L[2].x, L[3].x}, lb[4] = {L[0].y, L[1].y, L[2].y, L[3].y};
+    const float sta[4] = {ST[0].x, ST[1].x, ST[2].x, ST[3].x}, stb[4] = {ST[0].y, ST[1].y, ST[2].y, ST[3].y};
 
     // ---- centre groups go straight to HBM ----
     if (!active || gx < x0 || gx >= x0 + TW) return;
@@ -1068,6 +1055,7 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
     if (variant == 2) {
         if (n_steps <= 4) {
             // halo 4: a 64 x 48 tile gives 18 x 27 (n = 3) or 18 x 28 (n = 4) owner threads of 512; 64 x 32 only 342 / 360
+            // (AKZ_FED_TH4=32 selects the old shape for A/B runs; 64 x 40 and 256-thread 64 x 20 tiles measured slower)
             static const int th4 = [] {
                 const char* e = std::getenv("AKZ_FED_TH4");
                 return e ? std::atoi(e) : 48;
@@ -1075,10 +1063,6 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
             if (th4 == 48 && h >= 48) {
                 const dim3 g48((w + TW - 1) / TW, (h + 47) / 48, n);
                 hipLaunchKernelGGL((k_fed_own<TW, 48, 4, NT>), g48, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
-                                   (int)h, ht);
-            } else if (th4 == 40 && h >= 40) {
-                const dim3 g40((w + TW - 1) / TW, (h + 39) / 40, n);
-                hipLaunchKernelGGL((k_fed_own<TW, 40, 4, NT>), g40, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
                                    (int)h, ht);
             } else
                 hipLaunchKernelGGL((k_fed_own<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,

@@ -49,7 +49,8 @@ struct akz_ctx {
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     hipStream_t det = nullptr;          // detector launches of a level, concurrent with the diffusion of later levels
-    int det_overlap = 0;                // 1: detector launches on `det`, concurrent with the diffusion (akz_ctx_set_detector_overlap)
+    int det_overlap = 0;                // 1: every level's detector on `det` as soon as its Lsmooth exists; 2: the fine
+                                        // octaves' detectors on `det` once the coarse octaves start (akz_ctx_set_detector_overlap)
     // stage profiling (akz_ctx_set_profiling)
     uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
     int prep_mode = 2;  // same values as det_mode, for the level-preparation kernel
@@ -895,7 +896,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
     Candidate* d_cand = (Candidate*)c->cand_slot[slot].p;
     AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
-    if (c->det_overlap && !c->det) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->det, hipStreamNonBlocking));
+    if (c->det_overlap && !c->det) {  // lowest priority: the main stream's launches are dispatched first
+        int least = 0, greatest = 0;
+        AKZ_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        AKZ_HIP_TRY(hipStreamCreateWithPriority(&c->det, hipStreamNonBlocking, least));
+    }
     hipStream_t ds = c->det_overlap ? c->det : nullptr;
     std::vector<char> det_launched(L, 0);
     // derivatives, Ldet and extrema candidates of level l in one or two launches on stream `st_`; false when the
@@ -920,8 +925,31 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         return false;
     };
     // Lsmooth of level l is complete on the main stream: hand the level to the side stream
+    // Mode 2 hands over nothing until the first level of octave `kDeferOctave` has been prepared, then all finer
+    // levels at once: their bandwidth-bound detector launches run next to the coarse octaves' sequential chain of
+    // small, latency-bound preparation / diffusion launches, which leaves most of the chip idle.  The full-size
+    // diffusion launches (90 % of the FED pixel-steps) still run alone, so their timing stays meaningful.
+    constexpr uint32_t kDeferOctave = 2;
+    size_t defer_level = L;
+    if (c->det_overlap == 2)
+        for (size_t l = 1; l < L; ++l)
+            if (plan[l].octave >= kDeferOctave && plan[l - 1].octave < kDeferOctave) defer_level = l;
+    if (c->det_overlap == 2 && (defer_level >= L || (uint64_t)w * h * n < (8u << 20))) ds = nullptr;  // nothing to hide / launch-bound
     auto overlap_detector = [&](size_t l) -> int {
         if (!ds) return AKZ_OK;
+        if (c->det_overlap == 2) {
+            if (l != defer_level) return AKZ_OK;
+            hipEvent_t ready = StageTimer::get(c);
+            AKZ_HIP_TRY(hipEventRecord(ready, s));
+            AKZ_HIP_TRY(hipStreamWaitEvent(ds, ready, 0));
+            c->ev_pool.push_back(ready);
+            // short-lived workgroups (one tile each) on the low-priority side stream: the main stream's small launches
+            // get the slots they free
+            launch::set_tile_grid_limit(1L << 40);
+            for (size_t f = 0; f < l; ++f) det_launched[f] = detector_one_pass(f, ds) ? 1 : 0;
+            launch::set_tile_grid_limit(0);
+            return AKZ_OK;
+        }
         hipEvent_t ready = StageTimer::get(c);
         AKZ_HIP_TRY(hipEventRecord(ready, s));
         AKZ_HIP_TRY(hipStreamWaitEvent(ds, ready, 0));
@@ -1671,7 +1699,7 @@ int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
 
 int akz_ctx_set_detector_overlap(akz_ctx* c, int on) {
     if (!c) return AKZ_ERR_INVALID_ARG;
-    c->det_overlap = on ? 1 : 0;
+    c->det_overlap = on < 0 ? 0 : (on > 2 ? 1 : on);
     return AKZ_OK;
 }
 

@@ -193,6 +193,9 @@ void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uin
            MatchRec* d_part, MatchRec* d_out);
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out);
+// workgroups of the following persistent tiled launches issued by this thread (0: built-in value); a huge value makes
+// every workgroup take one tile
+void set_tile_grid_limit(long blocks);
 }  // namespace launch
 
 // ---- host keypoint logic (akz_keypoints.cpp) ---------------------------------------------

@@ -297,9 +297,11 @@ class Context:
         0 = LDS-tiled kernel pair."""
         _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
 
-    def set_detector_overlap(self, on=True):
-        """Run each level's detector on a side stream, concurrently with the diffusion of later levels (default off)."""
-        _check(lib().akz_ctx_set_detector_overlap(self._h, int(bool(on))))
+    def set_detector_overlap(self, mode=1):
+        """0 = off; 1 = every level's detector on a side stream as soon as its Lsmooth exists (concurrent with the
+        diffusion of that and later levels); 2 = the fine octaves' detectors on the side stream once the coarse
+        octaves (2, 3, ...) start, so that the full-size diffusion launches still run alone."""
+        _check(lib().akz_ctx_set_detector_overlap(self._h, int(mode)))
 
     def set_prep_mode(self, mode):
         """Level-preparation kernel: 2 = automatic (default), 1 = streaming, 0 = LDS-tiled."""

@@ -59,9 +59,10 @@ def main():
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 1 streaming pair, 3 fused streaming, 4 one tiled kernel, 0 tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
-    ap.add_argument("--det-overlap", action="store_true",
-                    help="detector launches on a side stream, concurrent with the diffusion (faster, but the FED spans of the "
-                         "roofline then include the time shared with the detector kernels)")
+    ap.add_argument("--det-overlap", type=int, default=0, choices=[0, 1, 2],
+                    help="detector launches on a side stream: 1 = every level as soon as its Lsmooth exists (the FED spans of "
+                         "the roofline then include the time shared with the detector kernels), 2 = the fine octaves' "
+                         "detectors next to the coarse octaves' latency-bound chain only")
     ap.add_argument("--depth", type=int, default=1, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
     ap.add_argument("--threshold", type=float, default=None,

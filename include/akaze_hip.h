@@ -331,10 +331,12 @@ int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
    LDS-tiled kernel (first and second derivatives in one pass; the automatic choice for small launches);
    0 = tiled pair only.  Results are bit-identical. */
 int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
-/* Detector overlap (default off): launch each level's detector on a side stream as soon as its Lsmooth
-   exists, concurrently with the diffusion of that and later levels.  Fills the chip during the
-   latency-bound coarse levels (+4..11 % batch throughput on MI355X, -10 % for single frames); results
-   are identical.  Off by default because concurrently running kernels cannot be timed individually. */
+/* Detector overlap (default 0 = off).  1: launch each level's detector on a low-priority side stream as soon
+   as its Lsmooth exists, concurrently with the diffusion of that and later levels (+4..11 % batch
+   throughput on MI355X, -10 % for single frames).  2: hand the detectors of octaves 0 and 1 to the side
+   stream when the chain reaches octave 2, so that only the small, latency-bound launches of the coarse
+   octaves share the chip (+2.5 %; batches of 8 Mpx and more, otherwise as 0).  Results are identical.
+   Off by default because concurrently running kernels cannot be timed individually. */
 int akz_ctx_set_detector_overlap(akz_ctx* ctx, int on);
 /* Same choice for the level-preparation kernel (Lsmooth, Lflow of a level). */
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);

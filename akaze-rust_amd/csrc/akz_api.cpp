@@ -1188,9 +1188,7 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
         std::atomic<long> t_sort_us{0}, t_sel_us{0};
         auto work = [&](uint32_t img) {
             const double t0 = host_timing ? now_ms() : 0.0;
-            std::sort(cands[img].begin(), cands[img].end(), [](const Candidate& a, const Candidate& b) {
-                return a.level != b.level ? a.level < b.level : a.idx < b.idx;
-            });
+            sort_candidates(cands[img], plan);
             const double t1 = host_timing ? now_ms() : 0.0;
             select_keypoints(cands[img], plan, cfg, hk[img], &r->n_extrema[img]);
             if (host_timing) {
@@ -1652,9 +1650,7 @@ int akz_host_select_keypoints(uint32_t w, uint32_t h, const akz_config* cfg, con
             set_error("candidate out of range");
             return AKZ_ERR_INVALID_ARG;
         }
-    std::sort(c.begin(), c.end(), [](const Candidate& a, const Candidate& b) {
-        return a.level != b.level ? a.level < b.level : a.idx < b.idx;
-    });
+    sort_candidates(c, plan);
     std::vector<HostKeypoint> hk;
     uint64_t ne = 0;
     select_keypoints(c, plan, *cfg, hk, &ne);

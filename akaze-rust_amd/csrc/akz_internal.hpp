@@ -207,6 +207,8 @@ struct HostKeypoint {
     uint32_t lx, ly;
     float xp, xm, yp, ym;
 };
+// unordered NMS survivors of one image into the reference's scan order: level, then flat index
+void sort_candidates(std::vector<Candidate>& cands, const std::vector<LevelPlan>& plan);
 // scale_space_extrema.rs:12-132 on raster-ordered candidates, then :141-178 (refinement w/o orientation)
 void select_keypoints(const std::vector<Candidate>& cands_sorted, const std::vector<LevelPlan>& plan,
                       const akz_config& cfg, std::vector<HostKeypoint>& out, uint64_t* n_extrema);

@@ -47,27 +47,51 @@ namespace {
 // the "first cache entry within `size` on level e or e-1" query of the reference (a linear scan,
 // :57-76) be answered from a few cells.  The answer is the MINIMUM slot index among qualifying
 // entries, which is exactly what the reference's front-to-back scan with `break` returns.
+// A level's cells are twice the largest query radius it ever sees (its own entries are looked up by
+// candidates of the same and of the next level, radius = their size + 1), so a query touches at
+// most 2 x 2 cells; the grid keeps its own copy of every slot's position (8 bytes) so that the
+// distance test does not pull the 56-byte cache entries through the cache.
 class SlotGrids {
+    struct G {
+        float cell, inv;
+        int nx, ny;
+        size_t base;
+    };
+    struct P {
+        float x, y;
+    };
+
 public:
     SlotGrids(const std::vector<LevelPlan>& plan, const akz_config& cfg, size_t max_slots) {
         const float width = (float)plan[0].w + 16.0f, height = (float)plan[0].h + 16.0f;
         size_t total = 0;
-        for (const LevelPlan& lv : plan) {
+        for (size_t l = 0; l < plan.size(); ++l) {
+            const LevelPlan& up = plan[std::min(l + 1, plan.size() - 1)];
             G g;
-            g.cell = std::max(8.0f, (float)(lv.esigma * cfg.derivative_factor));
+            g.cell = std::max(16.0f, 2.0f * ((float)(up.esigma * cfg.derivative_factor) + 1.0f));
+            g.inv = 1.0f / g.cell;
             g.nx = std::max(1, (int)std::ceil(width / g.cell) + 1);
             g.ny = std::max(1, (int)std::ceil(height / g.cell) + 1);
             g.base = total;
             total += (size_t)g.nx * g.ny;
             grids_.push_back(g);
         }
-        head_.assign(total, -1);
-        next_.assign(max_slots, -1);
+        // the arrays live in per-thread buffers that keep their capacity between calls (a 4K frame needs ~2 MB of
+        // cell heads; fresh allocations of that size are page-faulted in on every call)
+        static thread_local std::vector<int32_t> head_buf, next_buf;
+        static thread_local std::vector<P> pos_buf;
+        head_buf.assign(total, -1);
+        next_buf.assign(max_slots, -1);
+        if (pos_buf.size() < max_slots) pos_buf.resize(max_slots);
+        head_ = head_buf.data();
+        next_ = next_buf.data();
+        pos_ = pos_buf.data();
     }
     void insert(uint32_t level, int32_t slot, float x, float y) {
         int32_t& h = head_[index(level, x, y)];
         next_[slot] = h;
         h = slot;
+        pos_[slot] = P{x, y};
     }
     void remove(uint32_t level, int32_t slot, float x, float y) {
         int32_t* link = &head_[index(level, x, y)];
@@ -79,32 +103,76 @@ public:
             link = &next_[*link];
         }
     }
-    template <typename F>
-    void for_each_near(uint32_t level, float x, float y, float radius, F&& f) const {
+    // lowest slot index below `best` whose position is within sqrt(d2max) of (x, y); `best` if none
+    uint32_t min_slot_within(uint32_t level, float x, float y, float radius, float d2max, uint32_t best) const {
         const G& g = grids_[level];
         const int x0 = cx(g, x - radius), x1 = cx(g, x + radius), y0 = cy(g, y - radius), y1 = cy(g, y + radius);
         for (int yy = y0; yy <= y1; ++yy)
             for (int xx = x0; xx <= x1; ++xx)
-                for (int32_t s = head_[g.base + (size_t)yy * g.nx + xx]; s != -1; s = next_[s]) f((uint32_t)s);
+                for (int32_t s = head_[g.base + (size_t)yy * g.nx + xx]; s != -1; s = next_[s]) {
+                    if ((uint32_t)s >= best) continue;
+                    const P p = pos_[s];
+                    const float dist = (x - p.x) * (x - p.x) + (y - p.y) * (y - p.y);
+                    if (dist <= d2max) best = (uint32_t)s;
+                }
+        return best;
+    }
+    // is there a slot >= from within sqrt(d2max) of (x, y)?
+    bool any_slot_from(uint32_t level, float x, float y, float radius, float d2max, uint32_t from) const {
+        const G& g = grids_[level];
+        const int x0 = cx(g, x - radius), x1 = cx(g, x + radius), y0 = cy(g, y - radius), y1 = cy(g, y + radius);
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx)
+                for (int32_t s = head_[g.base + (size_t)yy * g.nx + xx]; s != -1; s = next_[s]) {
+                    if ((uint32_t)s < from) continue;
+                    const P p = pos_[s];
+                    const float dist = (x - p.x) * (x - p.x) + (y - p.y) * (y - p.y);
+                    if (dist <= d2max) return true;
+                }
+        return false;
     }
 
 private:
-    struct G {
-        float cell;
-        int nx, ny;
-        size_t base;
-    };
-    static int cx(const G& g, float x) { return std::min(g.nx - 1, std::max(0, (int)std::floor(x / g.cell))); }
-    static int cy(const G& g, float y) { return std::min(g.ny - 1, std::max(0, (int)std::floor(y / g.cell))); }
+    // the cell of a coordinate only has to be monotone and identical for insert and query: x * (1 / cell) will do
+    static int cx(const G& g, float x) { return std::min(g.nx - 1, std::max(0, (int)(x * g.inv))); }
+    static int cy(const G& g, float y) { return std::min(g.ny - 1, std::max(0, (int)(y * g.inv))); }
     size_t index(uint32_t level, float x, float y) const {
         const G& g = grids_[level];
         return g.base + (size_t)cy(g, y) * g.nx + cx(g, x);
     }
     std::vector<G> grids_;
-    std::vector<int32_t> head_, next_;
+    int32_t *head_ = nullptr, *next_ = nullptr;
+    P* pos_ = nullptr;
 };
 
 }  // namespace
+
+// Candidates into the reference's scan order (level, then flat index w*y + x): a counting sort over (level, row)
+// buckets followed by an insertion sort inside each row, which holds a handful of candidates.  About 4x faster
+// than std::sort on the 32-byte records (levels and indices must have been validated against the plan).
+void sort_candidates(std::vector<Candidate>& c, const std::vector<LevelPlan>& plan) {
+    if (c.size() < 2) return;
+    std::vector<uint32_t> row0(plan.size() + 1, 0);
+    for (size_t l = 0; l < plan.size(); ++l) row0[l + 1] = row0[l] + plan[l].h;
+    std::vector<uint32_t> start(row0.back() + 1, 0);
+    std::vector<uint32_t> bucket(c.size());
+    for (size_t i = 0; i < c.size(); ++i) {
+        bucket[i] = row0[c[i].level] + c[i].idx / plan[c[i].level].w;
+        ++start[bucket[i] + 1];
+    }
+    for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+    std::vector<Candidate> out(c.size());
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < c.size(); ++i) out[fill[bucket[i]]++] = c[i];
+    for (size_t b = 0; b + 1 < start.size(); ++b)
+        for (uint32_t i = start[b] + 1; i < start[b + 1]; ++i) {
+            const Candidate v = out[i];
+            uint32_t j = i;
+            for (; j > start[b] && out[j - 1].idx > v.idx; --j) out[j] = out[j - 1];
+            out[j] = v;
+        }
+    c.swap(out);
+}
 
 void select_keypoints(const std::vector<Candidate>& cands, const std::vector<LevelPlan>& plan,
                       const akz_config& cfg, std::vector<HostKeypoint>& out, uint64_t* n_extrema) {
@@ -117,33 +185,34 @@ void select_keypoints(const std::vector<Candidate>& cands, const std::vector<Lev
     }
     SlotGrids grids(plan, cfg, cands.size() + 1);
 
+    // per-level constants of the loop below (the same expressions, evaluated once per level)
+    struct LevelConst {
+        float size, ratio;
+    };
+    std::vector<LevelConst> lc(plan.size());
+    for (size_t l = 0; l < plan.size(); ++l)
+        lc[l] = LevelConst{(float)(plan[l].esigma * cfg.derivative_factor), powf(2.0f, (float)plan[l].octave)};
+
     // ---- first pass: scale_space_extrema.rs:43-100 ----
     for (const Candidate& c : cands) {
         const LevelPlan& lv = plan[c.level];
         HostKeypoint kp;
-        kp.lx = c.idx % lv.w;
         kp.ly = c.idx / lv.w;
+        kp.lx = c.idx - kp.ly * lv.w;
         kp.response = std::fabs(c.v);
-        kp.size = (float)(lv.esigma * cfg.derivative_factor);
+        kp.size = lc[c.level].size;
         kp.octave = lv.octave;
         kp.class_id = c.level;
         kp.x = (float)kp.lx;
         kp.y = (float)kp.ly;
         kp.angle = 0.0f;
         kp.xp = c.xp; kp.xm = c.xm; kp.yp = c.yp; kp.ym = c.ym;
-        const float ratio = powf(2.0f, (float)lv.octave);
+        const float ratio = lc[c.level].ratio;
         const float qx = kp.x * ratio, qy = kp.y * ratio;
         const float size2 = kp.size * kp.size;
         // first (lowest-index) cache entry on this or the previous level within `size`
-        uint32_t hit = UINT32_MAX;
-        auto visit = [&](uint32_t s) {
-            if (s >= hit) return;
-            const HostKeypoint& p = cache[s];
-            const float dist = (qx - p.x) * (qx - p.x) + (qy - p.y) * (qy - p.y);
-            if (dist <= size2) hit = s;
-        };
-        grids.for_each_near(c.level, qx, qy, kp.size + 1.0f, visit);
-        if (c.level > 0) grids.for_each_near(c.level - 1, qx, qy, kp.size + 1.0f, visit);
+        uint32_t hit = grids.min_slot_within(c.level, qx, qy, kp.size + 1.0f, size2, UINT32_MAX);
+        if (c.level > 0) hit = grids.min_slot_within(c.level - 1, qx, qy, kp.size + 1.0f, size2, hit);
         bool is_repeated = false, is_extremum = true;
         if (hit != UINT32_MAX) {
             if (kp.response > cache[hit].response) is_repeated = true;
@@ -164,41 +233,30 @@ void select_keypoints(const std::vector<Candidate>& cands, const std::vector<Lev
         }
     }
 
-    // ---- second pass: drop points repeated on the next level LATER in the cache (:109-129) ----
-    std::vector<HostKeypoint> extrema;
-    extrema.reserve(cache.size());
+    // ---- second pass: drop points repeated on the next level LATER in the cache (:109-129), and on the survivors
+    // the "sub-pixel" step (:141-178; the LU solve result is discarded by the reference) ----
+    uint64_t extrema = 0;
+    out.reserve(cache.size());
     for (uint32_t i = 0; i < cache.size(); ++i) {
-        const HostKeypoint& a = cache[i];
-        bool repeated = false;
-        if ((size_t)a.class_id + 1 < plan.size()) {
-            const float size2 = a.size * a.size;
-            grids.for_each_near(a.class_id + 1, a.x, a.y, a.size + 1.0f, [&](uint32_t s) {
-                if (repeated || s < i) return;
-                const HostKeypoint& b = cache[s];
-                const float dist = (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y);
-                if (dist <= size2) repeated = true;
-            });
-        }
-        if (!repeated) extrema.push_back(a);
-    }
-    if (n_extrema) *n_extrema = extrema.size();
-
-    // ---- "sub-pixel" step (:141-178): the LU solve result is discarded by the reference ----
-    for (const HostKeypoint& k : extrema) {
-        const float ratio = powf(2.0f, (float)k.octave);
-        const float fx = std::round(k.x / ratio), fy = std::round(k.y / ratio);
-        const uint32_t x = fx > 0.0f ? (uint32_t)fx : 0u, y = fy > 0.0f ? (uint32_t)fy : 0u;
-        (void)x; (void)y;  // equal k.lx, k.ly: p*ratio + 0.5(ratio-1) rounds back to p
+        const HostKeypoint& k = cache[i];
+        const bool repeated = (size_t)k.class_id + 1 < plan.size() &&
+                              grids.any_slot_from(k.class_id + 1, k.x, k.y, k.size + 1.0f, k.size * k.size, i);
+        if (repeated) continue;
+        ++extrema;
+        // the reference re-derives the level coordinates as round(k.x / ratio): p*ratio + 0.5(ratio-1) rounds back
+        // to p, i.e. to k.lx, k.ly
+        const float ratio = lc[k.class_id].ratio;
         const float d_x = 0.5f * (k.xp - k.xm);
         const float d_y = 0.5f * (k.yp - k.ym);
         const float b0 = -d_x, b1 = -d_y;
         if (std::fabs(b0) <= 1.0f && std::fabs(b1) <= 1.0f) {
-            HostKeypoint r = k;
+            out.push_back(k);
+            HostKeypoint& r = out.back();
             r.x = ((float)k.lx + b0) * ratio + 0.5f * (ratio - 1.0f);
             r.y = ((float)k.ly + b1) * ratio + 0.5f * (ratio - 1.0f);
-            out.push_back(r);
         }
     }
+    if (n_extrema) *n_extrema = extrema;
 }
 
 }  // namespace akz

@@ -6,8 +6,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <time.h>
 #include <type_traits>
@@ -26,6 +29,89 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
 };
+
+// Host worker threads of a context, started on first use and kept for the context's lifetime: the finish half of an
+// extraction runs several short parallel phases per batch (bucketing the candidates, one selection job per image, the
+// libm calls per keypoint), and creating ~60 threads per batch cost more than some of those phases.
+// run(count, fn) calls fn(i) for every i in [0, count) on the workers and the calling thread and returns when all
+// calls have finished.  One run at a time (a context is used by one host thread).
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned workers) {
+        for (unsigned t = 0; t < workers; ++t) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto& th : threads_) th.join();
+    }
+    unsigned size() const { return (unsigned)threads_.size() + 1; }
+    template <typename F>
+    void run(size_t count, F&& fn) {
+        if (count <= 1 || threads_.empty()) {
+            for (size_t i = 0; i < count; ++i) fn(i);
+            return;
+        }
+        auto r = std::make_shared<Run>();
+        r->job = [&fn](size_t i) { fn(i); };
+        r->count = count;
+        r->pending = count;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            current_ = r;
+            ++generation_;
+        }
+        cv_.notify_all();
+        drain(*r);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return r->pending == 0; });
+        current_.reset();
+    }
+
+private:
+    struct Run {  // one run() call; workers that wake up late hold their own reference and find nothing left to do
+        std::function<void(size_t)> job;
+        size_t count = 0;
+        std::atomic<size_t> next{0};
+        size_t pending = 0;  // guarded by m_
+    };
+    void drain(Run& r) {
+        size_t finished = 0;
+        for (size_t i = r.next.fetch_add(1); i < r.count; i = r.next.fetch_add(1)) {
+            r.job(i);
+            ++finished;
+        }
+        if (finished) {
+            std::lock_guard<std::mutex> lk(m_);
+            r.pending -= finished;
+            if (r.pending == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::shared_ptr<Run> r;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return quit_ || generation_ != seen; });
+                if (quit_) return;
+                seen = generation_;
+                r = current_;
+            }
+            if (r) drain(*r);
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::shared_ptr<Run> current_;
+    uint64_t generation_ = 0;
+    bool quit_ = false;
+};
+
 struct akz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -61,6 +147,14 @@ struct akz_ctx {
     struct Span { int stage; hipEvent_t a, b; };
     std::vector<Span> spans;          // recorded, not yet resolved
     std::vector<hipEvent_t> ev_pool;  // recycled events
+    std::unique_ptr<WorkerPool> workers;  // host threads of the finish half (started on first use)
+    WorkerPool& pool() {
+        if (!workers) {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            workers.reset(new WorkerPool(std::min(hw, 16u) - 1));
+        }
+        return *workers;
+    }
 };
 
 // RAII stage timer: device stages bracket the enqueued work with two events on the stream; they
@@ -256,6 +350,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     c->spans.clear();
     c->ev_pool.clear();
     c->aux = c->det = nullptr;
+    c->workers.reset();  // joins the host worker threads
     c->dead = true;  // results that are still alive keep the (now resource-less) struct; see result_delete
     if (c->live_results == 0) delete c;
     return AKZ_OK;
@@ -716,26 +811,6 @@ struct akz_result {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// run fn(begin, end) over [0, total) on up to `max_threads` host threads
-template <typename F>
-static void parallel_chunks(size_t total, size_t min_chunk, unsigned max_threads, F&& fn) {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t want = std::max<size_t>(1, total / std::max<size_t>(1, min_chunk));
-    const unsigned nt = (unsigned)std::min<size_t>({want, (size_t)hw, (size_t)max_threads});
-    if (nt <= 1) {
-        fn((size_t)0, total);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const size_t chunk = (total + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; ++t) {
-        const size_t b = (size_t)t * chunk, e = std::min(total, b + chunk);
-        if (b >= e) break;
-        pool.emplace_back([&fn, b, e] { fn(b, e); });
-    }
-    for (auto& th : pool) th.join();
-}
-
 static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
     bytes = align_up(std::max<size_t>(bytes, 256), 256);
     for (size_t i = 0; i < c->slab_pool.size(); ++i)
@@ -1143,12 +1218,7 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             *b = (size_t)total_c * t / slices;
             *e = (size_t)total_c * (t + 1) / slices;
         };
-        auto run_slices = [&](auto&& fn) {
-            if (slices == 1) return fn(0u);
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < slices; ++t) pool.emplace_back(fn, t);
-            for (auto& th : pool) th.join();
-        };
+        auto run_slices = [&](auto&& fn) { c->pool().run(slices, [&](size_t t) { fn((unsigned)t); }); };
         run_slices([&](unsigned t) {
             size_t b, e;
             slice_range(t, &b, &e);
@@ -1196,19 +1266,7 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
                 t_sel_us += (long)((now_ms() - t1) * 1e3);
             }
         };
-        const uint32_t hw_threads = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t nthreads = std::min<uint32_t>({n, hw_threads, 32u});
-        if (nthreads <= 1) {
-            for (uint32_t img = 0; img < n; ++img) work(img);
-        } else {  // images are independent: one host thread per image (up to 32)
-            std::atomic<uint32_t> next{0};
-            std::vector<std::thread> pool;
-            for (uint32_t t = 0; t < nthreads; ++t)
-                pool.emplace_back([&] {
-                    for (uint32_t img = next.fetch_add(1); img < n; img = next.fetch_add(1)) work(img);
-                });
-            for (auto& th : pool) th.join();
-        }
+        c->pool().run(n, [&](size_t img) { work((uint32_t)img); });  // images are independent
         if (host_timing) {
             size_t tc = 0, tk = 0;
             for (uint32_t img = 0; img < n; ++img) { tc += cands[img].size(); tk += hk[img].size(); }
@@ -1272,7 +1330,9 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
         AKZ_TRY(ensure_pinned(c, c->pin[4], total_kp * 2 * sizeof(float)));
         float* cosi = (float*)c->pin[4].p;
         std::vector<float> angles(total_kp);
-        parallel_chunks(total_kp, 4096, 16, [&](size_t b, size_t e) {
+        const size_t kAngleChunk = 4096;  // keypoints per libm job
+        c->pool().run((total_kp + kAngleChunk - 1) / kAngleChunk, [&](size_t j) {
+            const size_t b = j * kAngleChunk, e = std::min<size_t>(total_kp, b + kAngleChunk);
             for (size_t g = b; g < e; ++g) {
                 const float ang = oo[g].found ? atan2f(oo[g].sum_y, oo[g].sum_x) : 0.0f;  // scale_space_extrema.rs:326
                 angles[g] = ang;

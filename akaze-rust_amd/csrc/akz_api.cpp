@@ -147,6 +147,7 @@ struct akz_ctx {
     struct Span { int stage; hipEvent_t a, b; };
     std::vector<Span> spans;          // recorded, not yet resolved
     std::vector<hipEvent_t> ev_pool;  // recycled events
+    hipEvent_t fed_done = nullptr;     // recorded by every extract_begin behind its last diffusion launch
     std::unique_ptr<WorkerPool> workers;  // host threads of the finish half (started on first use)
     WorkerPool& pool() {
         if (!workers) {
@@ -351,6 +352,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     c->ev_pool.clear();
     c->aux = c->det = nullptr;
     c->workers.reset();  // joins the host worker threads
+    if (c->fed_done) { (void)hipEventDestroy(c->fed_done); c->fed_done = nullptr; }
     c->dead = true;  // results that are still alive keep the (now resource-less) struct; see result_delete
     if (c->live_results == 0) delete c;
     return AKZ_OK;
@@ -1087,6 +1089,12 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
     }
 
+    // The keypoint kernels of the batch that is finished next (orientation, M-LDB: gather-bound, on the auxiliary
+    // stream) wait for this point: next to the VALU-bound diffusion launches they cost more than next to the
+    // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.
+    if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
+    AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+
     // ---- detector levels that were not overlapped (no side stream, or kernel sizes without a fused form) ----
     // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group
     std::map<uint32_t, std::vector<launch::DetLevelDesc>> sets;
@@ -1322,6 +1330,14 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* d_oo = (OrientOut*)c->kp_out.p;
         AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params, total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+        static const bool kp_after_fed = [] {
+            const char* e = std::getenv("AKZ_KP_AFTER_FED");  // tuning: 0 launches the keypoint kernels at once
+            return !e || std::atoi(e) != 0;
+        }();
+        // behind the diffusion of the batch begun last (no wait if that is this batch or has passed the point);
+        // small jobs are bound by the latency of this chain, not by the chip, and do not wait
+        if (kp_after_fed && c->fed_done && (uint64_t)r->w * r->h * n >= (8u << 20))
+            AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_done, 0));
         launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());
         OrientOut* oo = (OrientOut*)c->pin[1].p;

@@ -36,7 +36,10 @@ namespace {
 #ifndef AKZ_PERSIST_BLOCKS
 #define AKZ_PERSIST_BLOCKS 1024  // 256 CUs x 4 workgroups of 512 threads
 #endif
-constexpr int TW = 64, TH = 32, NT = AKZ_STENCIL_NT;
+#ifndef AKZ_STENCIL_TH
+#define AKZ_STENCIL_TH 32
+#endif
+constexpr int TW = 64, TH = AKZ_STENCIL_TH, NT = AKZ_STENCIL_NT;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

@@ -126,6 +126,7 @@ def main():
     side = torch.cuda.Stream(dev)  # collectives run here so that they never wait for the extraction stream
 
     gather_ms = [0.0]
+    host_ms = {"begin": 0.0, "finish": 0.0, "calls": 0}  # host time inside extract_begin / extract_finish
     gather_cap = [0]  # fixed row capacity of the padded all-gather, set from the first step
 
     def gather_descriptors(results):
@@ -164,13 +165,19 @@ def main():
 
         for _ in range(k_steps):
             for bt in batches:
+                tb = time.perf_counter()
                 job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean)
+                host_ms["begin"] += (time.perf_counter() - tb) * 1e3
+                host_ms["calls"] += 1
                 if args.sync:
                     retire(job.finish())
                     continue
                 inflight.append(job)
                 if len(inflight) > args.depth:
-                    retire(inflight.pop(0).finish())
+                    tf = time.perf_counter()
+                    res = inflight.pop(0).finish()
+                    host_ms["finish"] += (time.perf_counter() - tf) * 1e3
+                    retire(res)
         while inflight:
             retire(inflight.pop(0).finish())
         return nk
@@ -193,6 +200,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     gather_ms[0] = 0.0
+    host_ms.update(begin=0.0, finish=0.0, calls=0)
     nk = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -359,7 +367,9 @@ def main():
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
                        "exchange": "RCCL all-gather of descriptor rows" if use_dist else "none (1 GPU)",
                        "keypoints_per_step_rank0": nk,
-                       "host_ms_in_gather_per_step": round(gather_ms[0] / max(1, args.steps), 3)},
+                       "host_ms_in_gather_per_step": round(gather_ms[0] / max(1, args.steps), 3),
+                       "host_ms_in_begin_per_batch": round(host_ms["begin"] / max(1, host_ms["calls"]), 3),
+                       "host_ms_in_finish_per_batch": round(host_ms["finish"] / max(1, host_ms["calls"]), 3)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,

@@ -80,12 +80,40 @@ void shapes(const float* in, float* out, int w, int h, int n) {
     }
 }
 
-int main() {
+// Sustained rate: the same launch back to back for `seconds`, reported per window of 50 launches (does the rate of a
+// cold chip hold under continuous load?)
+template <int R, int W>
+void sustained(const float* in, float* out, int w, int h, int n, double seconds) {
+    constexpr int TW = 64, TH = 32;
+    const int ntx = (w + TW - 1) / TW, nty = (h + TH - 1) / TH;
+    const size_t plane = (size_t)w * h * n;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    double total_ms = 0;
+    printf("sustained R%d:W%d 64x32 vec1, one tile per workgroup:", R, W);
+    while (total_ms < seconds * 1e3) {
+        hipEventRecord(a);
+        for (int i = 0; i < 50; ++i)
+            hipLaunchKernelGGL((k_tile<R, W, TW, TH, 1>), dim3(ntx * nty * n), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        total_ms += ms;
+        printf(" %.0f", (double)plane * 4 * (R + W) * 50 / ms / 1e6);
+    }
+    printf(" GB/s\n");
+}
+
+int main(int argc, char** argv) {
     const int w = 1920, h = 1080, n = 32;
     const size_t plane = (size_t)w * h * n;
     float *in, *out;
     hipMalloc(&in, plane * 4 * 2); hipMalloc(&out, plane * 4 * 6);
     hipMemset(in, 0, plane * 4 * 2); hipMemset(out, 0, plane * 4 * 6);
+    if (argc > 1) {  // tilebw sustained
+        sustained<2, 4>(in, out, w, h, n, 4.0);
+        sustained<1, 2>(in, out, w, h, n, 4.0);
+        return 0;
+    }
     shapes<1, 2>(in, out, w, h, n);   // k_deriv1, k_prep
     shapes<2, 4>(in, out, w, h, n);   // k_deriv2, all planes kept
     shapes<1, 6>(in, out, w, h, n);   // one-kernel detector

@@ -328,30 +328,51 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
     auto lds = [&](int ly, int lx) { return (ly + 1) * RP + 4 + lx; };
 
     // ---- stage Lt -> sA, Lflow -> sB (out-of-image pixels read as 0 and are never used) ----
-    for (int idx = tid; idx < RH * XG; idx += NT) {
-        const int ly = idx / XG, g = idx - ly * XG;
-        const int gy = y0 - n + ly, gx = x0 - HALO + 4 * g;
-        float4 vl = make_float4(0.f, 0.f, 0.f, 0.f), vc = vl;
-        if (gy >= 0 && gy < h && gx + 3 >= 0 && gx < w) {
-            const float* pl = L_in + base + (size_t)gy * w;
-            const float* pc = C + base + (size_t)gy * w;
-            if (vec_ok && gx >= 0 && gx + 3 < w) {
-                vl = *reinterpret_cast<const float4*>(pl + gx);
-                vc = *reinterpret_cast<const float4*>(pc + gx);
-            } else {
-                float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    // The region has at most 2 * NT float4 groups per plane.  All four loads of a thread (two groups x two planes) are
+    // issued before the first LDS write: a workgroup's lifetime is dominated by this load phase (one fused step costs
+    // 17 us per full-resolution batch level, the launch 280), and a rolled loop would wait for the first pair of loads
+    // before issuing the second.
+    static_assert(RHMAX * XG <= 2 * NT && (TH + 2) * XG >= NT, "two staging slots per thread, the first always used");
+    if (vec_ok) {
+        const int i1 = tid + NT;
+        const int ly0 = tid / XG, g0 = tid - ly0 * XG;
+        const int ly1 = i1 / XG, g1 = i1 - ly1 * XG;
+        const int gy0 = y0 - n + ly0, gx0 = x0 - HALO + 4 * g0;
+        const int gy1 = y0 - n + ly1, gx1 = x0 - HALO + 4 * g1;
+        // with w a multiple of 4 a group is either inside or outside the image as a whole
+        const bool in0 = gy0 >= 0 && gy0 < h && gx0 >= 0 && gx0 < w;
+        const bool in1 = i1 < RH * XG && gy1 >= 0 && gy1 < h && gx1 >= 0 && gx1 < w;
+        const size_t o0 = in0 ? base + (size_t)gy0 * w + gx0 : base;
+        const size_t o1 = in1 ? base + (size_t)gy1 * w + gx1 : base;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 l0 = *reinterpret_cast<const float4*>(L_in + o0), c0 = *reinterpret_cast<const float4*>(C + o0);
+        float4 l1 = *reinterpret_cast<const float4*>(L_in + o1), c1 = *reinterpret_cast<const float4*>(C + o1);
+        if (!in0) { l0 = zero; c0 = zero; }
+        if (!in1) { l1 = zero; c1 = zero; }
+        *reinterpret_cast<float4*>(&sA[lds(ly0, 4 * g0)]) = l0;
+        *reinterpret_cast<float4*>(&sB[lds(ly0, 4 * g0)]) = c0;
+        if (i1 < RH * XG) {
+            *reinterpret_cast<float4*>(&sA[lds(ly1, 4 * g1)]) = l1;
+            *reinterpret_cast<float4*>(&sB[lds(ly1, 4 * g1)]) = c1;
+        }
+    } else {
+        for (int idx = tid; idx < RH * XG; idx += NT) {
+            const int ly = idx / XG, g = idx - ly * XG;
+            const int gy = y0 - n + ly, gx = x0 - HALO + 4 * g;
+            float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < h) {
+                const float* pl = L_in + base + (size_t)gy * w;
+                const float* pc = C + base + (size_t)gy * w;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (gx + e >= 0 && gx + e < w) {
                         a[e] = pl[gx + e];
                         b[e] = pc[gx + e];
                     }
-                vl = make_float4(a[0], a[1], a[2], a[3]);
-                vc = make_float4(b[0], b[1], b[2], b[3]);
             }
+            *reinterpret_cast<float4*>(&sA[lds(ly, 4 * g)]) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>(&sB[lds(ly, 4 * g)]) = make_float4(b[0], b[1], b[2], b[3]);
         }
-        *reinterpret_cast<float4*>(&sA[lds(ly, 4 * g)]) = vl;
-        *reinterpret_cast<float4*>(&sB[lds(ly, 4 * g)]) = vc;
     }
     __syncthreads();
 

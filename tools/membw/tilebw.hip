@@ -80,6 +80,52 @@ void shapes(const float* in, float* out, int w, int h, int n) {
     }
 }
 
+// The FED access shape: R planes read as (TW + 2*HX) x (TH + 2*HY) regions in float4 groups (HX a multiple of 4, so the
+// region starts 16 bytes before a 256-byte tile row), one plane written as TW x TH tiles.  No arithmetic.
+template <int R, int TW, int TH, int HX, int HY>
+__global__ void __launch_bounds__(512) k_halo(const float* __restrict__ in, float* __restrict__ out, int w, int h, int n,
+                                               size_t plane, int ntx, int nty) {
+    constexpr int XG = (TW + 2 * HX) / 4, RH = TH + 2 * HY;
+    const int t = blockIdx.x;
+    const int bz = t / (ntx * nty), rem = t - bz * ntx * nty, by = rem / ntx, bx = rem - by * ntx;
+    const size_t base = (size_t)bz * w * h;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int idx = threadIdx.x; idx < XG * RH; idx += 512) {
+        const int ly = idx / XG, g = idx - ly * XG;
+        const int gy = by * TH - HY + ly, gx = bx * TW - HX + 4 * g;
+        if (gy < 0 || gy >= h || gx < 0 || gx >= w) continue;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(in + r * plane + base + (size_t)gy * w + gx);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    // every thread of the first TW/4 * TH writes one centre group
+    const int cw = TW / 4;
+    for (int idx = threadIdx.x; idx < cw * TH; idx += 512) {
+        const int ly = idx / cw, g = idx - ly * cw;
+        const int gy = by * TH + ly, gx = bx * TW + 4 * g;
+        if (gy < h && gx < w) *reinterpret_cast<float4*>(out + base + (size_t)gy * w + gx) = acc;
+    }
+}
+template <int R, int TW, int TH, int HX, int HY>
+void run_halo(const float* in, float* out, int w, int h, int n) {
+    const int ntx = (w + TW - 1) / TW, nty = (h + TH - 1) / TH;
+    const size_t plane = (size_t)w * h * n;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((k_halo<R, TW, TH, HX, HY>), dim3(ntx * nty * n), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
+    hipEventRecord(a);
+    const int it = 10;
+    for (int i = 0; i < it; ++i)
+        hipLaunchKernelGGL((k_halo<R, TW, TH, HX, HY>), dim3(ntx * nty * n), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("halo R%d:W1 tile %3dx%-2d halo x%d y%d: %.0f us per launch, %.0f GB/s algorithmic (tile bytes only)\n", R, TW, TH, HX, HY,
+           ms / it * 1e3, (double)plane * 4 * (R + 1) * it / ms / 1e6);
+}
+
 // Sustained rate: the same launch back to back for `seconds`, reported per window of 50 launches (does the rate of a
 // cold chip hold under continuous load?)
 template <int R, int W>
@@ -109,6 +155,17 @@ int main(int argc, char** argv) {
     float *in, *out;
     hipMalloc(&in, plane * 4 * 2); hipMalloc(&out, plane * 4 * 6);
     hipMemset(in, 0, plane * 4 * 2); hipMemset(out, 0, plane * 4 * 6);
+    if (argc > 1 && argv[1][0] == 'h') {  // tilebw halo
+        run_halo<2, 64, 48, 0, 0>(in, out, w, h, n);
+        run_halo<2, 64, 48, 4, 0>(in, out, w, h, n);
+        run_halo<2, 64, 48, 0, 3>(in, out, w, h, n);
+        run_halo<2, 64, 48, 4, 3>(in, out, w, h, n);
+        run_halo<2, 64, 32, 8, 8>(in, out, w, h, n);
+        run_halo<2, 128, 24, 4, 3>(in, out, w, h, n);
+        run_halo<2, 256, 16, 4, 3>(in, out, w, h, n);
+        run_halo<1, 64, 48, 4, 3>(in, out, w, h, n);
+        return 0;
+    }
     if (argc > 1) {  // tilebw sustained
         sustained<2, 4>(in, out, w, h, n, 4.0);
         sustained<1, 2>(in, out, w, h, n, 4.0);

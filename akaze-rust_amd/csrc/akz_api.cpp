@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 #include <time.h>
 #include <type_traits>
 
@@ -112,6 +113,26 @@ private:
     bool quit_ = false;
 };
 
+// Host cores this process can count on: the affinity mask, cut down by the cgroup CPU quota, divided among the ranks
+// of a one-process-per-GPU job on this host (LOCAL_WORLD_SIZE, set by torchrun).
+static unsigned host_cpu_share() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0)
+            n = std::min<unsigned>(n, (unsigned)std::max(1L, atol(q) / period));
+        fclose(f);
+    }
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+        const int ranks = atoi(e);
+        if (ranks > 1) n = std::max(2u, n / (unsigned)ranks);
+    }
+    return std::max(1u, n);
+}
+
 struct akz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -150,10 +171,7 @@ struct akz_ctx {
     hipEvent_t fed_done = nullptr;     // recorded by every extract_begin behind its last diffusion launch
     std::unique_ptr<WorkerPool> workers;  // host threads of the finish half (started on first use)
     WorkerPool& pool() {
-        if (!workers) {
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            workers.reset(new WorkerPool(std::min(hw, 16u) - 1));
-        }
+        if (!workers) workers.reset(new WorkerPool(std::min(host_cpu_share(), 16u) - 1));
         return *workers;
     }
 };
@@ -1219,8 +1237,7 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
         Candidate* hc = (Candidate*)c->pin[0].p;
         // bucket the unordered list by image: slices of the list are counted and scattered by separate threads
         // (a 32-frame batch has ~2 x 10^5 candidates)
-        const unsigned slices = (unsigned)std::min<size_t>({(size_t)total_c / 16384 + 1, (size_t)16,
-                                                            (size_t)std::max(1u, std::thread::hardware_concurrency())});
+        const unsigned slices = (unsigned)std::min<size_t>((size_t)total_c / 16384 + 1, (size_t)c->pool().size());
         std::vector<std::vector<uint32_t>> at(slices, std::vector<uint32_t>(n, 0));  // counts, then write offsets
         auto slice_range = [&](unsigned t, size_t* b, size_t* e) {
             *b = (size_t)total_c * t / slices;

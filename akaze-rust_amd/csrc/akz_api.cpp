@@ -142,6 +142,8 @@ struct akz_ctx {
     DevBuf cand;                             // NMS candidates
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
+    DevBuf mm_q8, mm_t8, mm_pop;             // MFMA matcher: unpacked int8 images of the two sets, bit counts
+    int match_mode = 2;                      // 0: popcount kernel, 1: MFMA kernel, 2: MFMA from 2^22 pairs (akz_ctx_set_match_mode)
     DevBuf cosi;                             // (cos, sin) per keypoint
     DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
                                              // rows, keypoint params, (cos, sin), contrast factors
@@ -344,7 +346,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
                       &c->small, &c->cand, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
-                      &c->match_out, &c->cosi};
+                      &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
@@ -1683,10 +1685,27 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
         return AKZ_ERR_INVALID_ARG;
     }
     const uint32_t thr = (uint32_t)std::min<uint64_t>(distance_threshold, 0x7fffffffull);
-    const uint32_t chunks = launch::match_num_chunks((uint32_t)n0, (uint32_t)n1);
+    // large products go to the matrix cores (integer GEMM on the unpacked bits, identical records); the popcount
+    // kernel has no unpacking pass and wins for small sets
+    const bool mfma = n0 && n1 && (c->match_mode == 1 || (c->match_mode == 2 && n0 * n1 >= (1ull << 22)));
+    const uint32_t chunks = mfma ? launch::match_mfma_chunks((uint32_t)n0, (uint32_t)n1)
+                                 : launch::match_num_chunks((uint32_t)n0, (uint32_t)n1);
     AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * (chunks + 1) * sizeof(MatchRec)));
     MatchRec* merged = (MatchRec*)c->match_rec.p;
-    launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, merged + n0, merged);
+    if (mfma) {
+        const uint32_t q_rows = launch::match_mfma_rows((uint32_t)n0, true), t_rows = launch::match_mfma_rows((uint32_t)n1, false);
+        AKZ_TRY(ensure(c, c->mm_q8, (size_t)q_rows * 512));
+        AKZ_TRY(ensure(c, c->mm_t8, (size_t)t_rows * 512));
+        AKZ_TRY(ensure(c, c->mm_pop, ((size_t)q_rows + t_rows) * sizeof(uint32_t)));
+        uint32_t* qpop = (uint32_t*)c->mm_pop.p;
+        uint32_t* tpop = qpop + q_rows;
+        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, (uint8_t*)c->mm_q8.p, qpop);
+        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, (uint8_t*)c->mm_t8.p, tpop);
+        launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, tpop,
+                           (uint32_t)n1, thr, merged + n0, merged);
+    } else {
+        launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, merged + n0, merged);
+    }
     launch::match_compact(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, thr, lowes_ratio * lowes_ratio,
                           d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());
@@ -1843,6 +1862,12 @@ int akz_ctx_set_prep_mode(akz_ctx* c, int mode) {
     return AKZ_OK;
 }
 
+int akz_ctx_set_match_mode(akz_ctx* c, int mode) {
+    AKZ_TRY(bind(c));
+    if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
+    c->match_mode = mode;
+    return AKZ_OK;
+}
 int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
     if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;

@@ -1149,6 +1149,9 @@ uint32_t match_num_chunks(uint32_t n0, uint32_t n1) {
     return std::max<uint32_t>(1, std::min<uint32_t>({want, (tiles + 3) / 4, 64u}));
 }
 // d_part: chunks * n0 records of scratch; d_out: n0 merged records
+void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out) {
+    hipLaunchKernelGGL(k_match_merge, dim3((n0 + 255) / 256), dim3(256), 0, s, d_part, n0, chunks, threshold, d_out);
+}
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
            MatchRec* d_part, MatchRec* d_out) {
     if (n0 == 0) return;
@@ -1157,9 +1160,7 @@ void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uin
     const uint32_t chunk_rows = ((tiles + chunks - 1) / chunks) * MT;
     hipLaunchKernelGGL(k_match, dim3((n0 + MT - 1) / MT, chunks), dim3(MT), 0, s, reinterpret_cast<const uint4*>(d0), n0,
                        reinterpret_cast<const uint4*>(d1), n1, chunk_rows, threshold, chunks > 1 ? d_part : d_out);
-    if (chunks > 1)
-        hipLaunchKernelGGL(k_match_merge, dim3((n0 + 255) / 256), dim3(256), 0, s, (const MatchRec*)d_part, n0, chunks,
-                           threshold, d_out);
+    if (chunks > 1) match_merge(s, d_part, n0, chunks, threshold, d_out);
 }
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out) {

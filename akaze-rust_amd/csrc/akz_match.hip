@@ -1,0 +1,223 @@
+// Brute-force Hamming matcher on the matrix cores (gfx950).
+//
+// ops::feature_matching::descriptor_match (akaze/src/ops/feature_matching.rs:23-94) scans, for every query
+// descriptor, all train descriptors and keeps the smallest and second smallest Hamming distance (strict '<'
+// updates, :41-49: the lowest index wins among equal minima).  With the descriptor bits unpacked to int8 0/1,
+//     hamming(a, b) = |a| + |b| - 2 <a, b>,
+// and the inner products of all (train, query) pairs are one integer GEMM with K = 512: exact integer
+// arithmetic, so distances, indices and therefore the match list are identical to the popcount scan
+// (k_match in akz_kernels.hip, which stays the path for small sets), at a multiple of its rate — the popcount
+// kernel is bound by the vector ALU (16 xor + 16 bit-count-accumulate per pair), this one by
+// v_mfma_i32_32x32x32_i8.
+//
+// Layout.  k_unpack_bits writes a set as int8 [rows padded][512] (bit b of byte t -> column 8t + b; any fixed
+// order works, both operands use the same one) and the bit count of every row.  k_match_mfma: 1024 threads = 16
+// waves, four per SIMD; a wave owns 32 queries as the B operand for all 16 K-steps (64 VGPRs, loaded once); the
+// workgroup walks a chunk of the train set in LDS tiles of 32 rows (one MFMA tile) that all waves share
+// (double-buffered; row pitch 528 B so that the 16-byte operand reads of a 16-lane group fall into different
+// banks).  A/B operand of lane l (r = l & 31, h = l >> 5) at K-step s: bytes 32 s + 16 h .. + 15 of row r — the
+// same function of (l, s) for both operands, which is all the dot product needs.  The 32 x 32 result has its column
+// (query) on the lane and rows (i & 3) + 8 (i >> 2) + 4 h, i = 0..15, in the registers (cdna_hip_programming.md,
+// C/D layout): ascending train index inside a lane, so the reference's update rule applies directly; the two
+// lanes of a column are merged at the end of the chunk with the order-free form of the rule ((distance, index)
+// lexicographic minimum; second = min of the others), and the chunks by k_match_merge.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "akz_internal.hpp"
+
+namespace akz {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int KB = 512;            // int8 columns per descriptor (64 bytes x 8 bits)
+constexpr int MM_NT = 1024;        // threads per workgroup: 16 waves, four per SIMD
+constexpr int MM_QW = 32;          // queries per wave: one 32-column block, its B operand resident in 64 VGPRs
+constexpr int MM_QB = (MM_NT / 64) * MM_QW;  // queries per workgroup (512)
+constexpr int MM_SUB = 1;          // 32-row MFMA tiles per LDS tile (2 needs a second accumulator set: 128 VGPRs and spills, measured slower)
+constexpr int MM_TR = 32 * MM_SUB; // train rows per LDS tile
+constexpr int MM_PITCH = KB + 16;  // LDS row pitch in bytes
+
+// one wave per descriptor row: lane t expands byte t into 8 int8 values; the row's bit count by wave reduction
+__global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad,
+                                                     uint8_t* __restrict__ out, unsigned* __restrict__ pop) {
+    const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row >= n_pad) return;
+    const unsigned byte = row < n ? d[(size_t)row * 64 + lane] : 0u;
+    uint2 v;
+    v.x = (byte & 1u) | ((byte & 2u) << 7) | ((byte & 4u) << 14) | ((byte & 8u) << 21);
+    v.y = ((byte >> 4) & 1u) | (((byte >> 4) & 2u) << 7) | (((byte >> 4) & 4u) << 14) | (((byte >> 4) & 8u) << 21);
+    *reinterpret_cast<uint2*>(out + (size_t)row * KB + 8 * lane) = v;
+    unsigned c = __popc(byte);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) pop[row] = c;
+}
+
+__device__ __forceinline__ void top2_feed(unsigned d, unsigned j, unsigned& min_d, unsigned& second, unsigned& min_j) {
+    if (d < min_d) {  // the reference's update rule (feature_matching.rs:41-49)
+        second = min_d;
+        min_d = d;
+        min_j = j;
+    } else if (d < second) {
+        second = d;
+    }
+}
+
+// blockIdx.x: 512 queries; blockIdx.y: a chunk of `chunk_tiles` train tiles.  q8 / t8: unpacked sets, rows padded
+// to a multiple of MM_QB / MM_TR with zero rows; qpop / tpop: bit counts.  Writes (min, second, argmin) of every
+// live query over the chunk to out[chunk * n0 + query].
+__global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict__ q8, const unsigned* __restrict__ qpop,
+                                                      unsigned n0, const uint8_t* __restrict__ t8,
+                                                      const unsigned* __restrict__ tpop, unsigned n1, unsigned chunk_tiles,
+                                                      unsigned threshold, MatchRec* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH];
+    __shared__ unsigned s_pop[2][MM_TR];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const unsigned q_first = blockIdx.x * MM_QB + wave * MM_QW;  // this wave's 32 queries
+
+    // B operand: 16 K-steps of this wave's 32 queries, resident for the whole chunk
+    v4i bq[16];
+    {
+        const uint8_t* row = q8 + (size_t)(q_first + r) * KB + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bq[s] = *reinterpret_cast<const v4i*>(row + 32 * s);
+        // pin the operand here: otherwise the waits for these loads are placed at their first use inside the tile loop
+#pragma unroll
+        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bq[s]));
+    }
+    const unsigned pq = qpop[q_first + r];
+    unsigned min_d = threshold, second = threshold, min_j = 0u;
+
+    const unsigned tiles_total = (n1 + MM_TR - 1) / MM_TR;
+    const unsigned t_begin = blockIdx.y * chunk_tiles, t_end = min(tiles_total, t_begin + chunk_tiles);
+    // staging: the LDS tile (32 KiB) is moved in 16-byte pieces, SG per thread (row-major, 32 pieces per row)
+    constexpr int SG = MM_TR * KB / 16 / MM_NT;
+    uint4 stage[SG];
+    auto fetch = [&](unsigned tile) {
+#pragma unroll
+        for (int k = 0; k < SG; ++k) {
+            const unsigned piece = tid + k * MM_NT;
+            stage[k] = *reinterpret_cast<const uint4*>(t8 + ((size_t)tile * MM_TR + (piece >> 5)) * KB + (piece & 31u) * 16u);
+        }
+    };
+    auto commit = [&](unsigned tile, int buf) {
+#pragma unroll
+        for (int k = 0; k < SG; ++k) {
+            const unsigned piece = tid + k * MM_NT;
+            *reinterpret_cast<uint4*>(&s_tile[buf][(piece >> 5) * MM_PITCH + (piece & 31u) * 16u]) = stage[k];
+        }
+        if (tid < MM_TR) s_pop[buf][tid] = tpop[(size_t)tile * MM_TR + tid];
+    };
+    if (t_begin < t_end) {
+        fetch(t_begin);
+        commit(t_begin, 0);
+    }
+    __syncthreads();
+    for (unsigned tile = t_begin; tile < t_end; ++tile) {
+        const int buf = (int)((tile - t_begin) & 1u);
+        const bool more = tile + 1 < t_end;
+        if (more) fetch(tile + 1);  // in flight under the MFMA chains below
+        // the MFMA chains of all sub-tiles are issued before the first epilogue, whose vector instructions then run
+        // while the matrix pipe works on the later chains
+        v16i acc[MM_SUB];
+#pragma unroll
+        for (int sub = 0; sub < MM_SUB; ++sub) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[sub][i] = 0;
+            const uint8_t* arow = &s_tile[buf][(32 * sub + r) * MM_PITCH + 16 * h];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                acc[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(arow + 32 * s), bq[s], acc[sub], 0, 0, 0);
+        }
+        const bool partial = (tile + 1) * MM_TR > n1;  // uniform: only the last tile of the set
+#pragma unroll
+        for (int sub = 0; sub < MM_SUB; ++sub) {
+            // distances of this lane's 16 train rows of the sub-tile (ascending index) to its query
+            const unsigned j0 = tile * MM_TR + 32 * sub + 4 * h;
+            auto dist = [&](int i) {
+                const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
+                unsigned d = s_pop[buf][32 * sub + row + 4 * h] + pq - 2u * (unsigned)acc[sub][i];
+                if (partial && j0 + row >= n1) d = 0xffffffffu;  // padding rows never match
+                return d;
+            };
+            unsigned best = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) best = min(best, dist(i));
+            if (best < second) {  // rare once a few hundred rows have been seen
+#pragma unroll
+                for (int i = 0; i < 16; ++i) top2_feed(dist(i), j0 + (unsigned)((i & 3) + 8 * (i >> 2)), min_d, second, min_j);
+            }
+        }
+        if (more) commit(tile + 1, buf ^ 1);
+        __syncthreads();
+    }
+    // the two lanes of a column hold disjoint row sets: order-free merge, then one record per live query
+    {
+        const unsigned o_min = __shfl_xor(min_d, 32, 64), o_sec = __shfl_xor(second, 32, 64);
+        const unsigned o_j = __shfl_xor(min_j, 32, 64);
+        unsigned m = min_d, s2 = second, j = min_j;
+        if (o_min < m || (o_min == m && o_min < threshold && o_j < j)) {  // the other lane holds the winner
+            s2 = min(o_sec, m);
+            m = o_min;
+            j = o_j;
+        } else {
+            s2 = min(s2, o_min);
+        }
+        const unsigned q = q_first + r;
+        if (h == 0 && q < n0) {
+            MatchRec rec;
+            rec.min_d = m; rec.second_d = s2; rec.min_j = j; rec._pad = 0;
+            out[(size_t)blockIdx.y * n0 + q] = rec;
+        }
+    }
+}
+
+}  // namespace
+
+namespace launch {
+
+// rows of the unpacked image of a set of n descriptors (queries: whole workgroups; train: whole tiles)
+uint32_t match_mfma_rows(uint32_t n, bool queries) {
+    const uint32_t m = queries ? (uint32_t)MM_QB : (uint32_t)MM_TR;
+    return (std::max<uint32_t>(n, 1) + m - 1) / m * m;
+}
+uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1) {
+    const uint32_t qblocks = (std::max<uint32_t>(n0, 1) + MM_QB - 1) / MM_QB;
+    const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
+    // One workgroup per CU is resident (16 waves); a launch runs in rounds of 256 workgroups, each of which first
+    // loads its 512 queries (as much traffic as 16 train tiles) and then walks its chunk.  Pick the chunk count
+    // with the least estimated time: rounds x (tiles per chunk + 16).
+    const uint32_t cmax = std::max<uint32_t>(1, std::min<uint32_t>(tiles / 8, 128u));
+    uint32_t best = 1;
+    uint64_t best_cost = ~0ull;
+    for (uint32_t c = 1; c <= cmax; ++c) {
+        const uint64_t rounds = ((uint64_t)qblocks * c + 255) / 256;
+        const uint64_t cost = rounds * ((tiles + c - 1) / c + 16);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, uint8_t* out8, uint32_t* pop) {
+    hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, out8, pop);
+}
+// top-2 records of every query over the whole train set in d_out (d_part: chunks x n0 scratch records)
+void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
+                const uint32_t* tpop, uint32_t n1, uint32_t threshold, MatchRec* d_part, MatchRec* d_out) {
+    if (n0 == 0) return;
+    const uint32_t chunks = match_mfma_chunks(n0, n1);
+    const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
+    const uint32_t chunk_tiles = (tiles + chunks - 1) / chunks;
+    hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, tpop, n1,
+                       chunk_tiles, threshold, chunks > 1 ? d_part : d_out);
+    if (chunks > 1) match_merge(s, d_part, n0, chunks, threshold, d_out);
+}
+
+}  // namespace launch
+}  // namespace akz

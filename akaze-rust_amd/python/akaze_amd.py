@@ -171,6 +171,7 @@ def lib():
         "akz_draw_matches": ([vp, u32, u32, vp, u32, u32, vp, u64, vp, u64, vp, u64, pu32, pu32, C.POINTER(vp)], i32),
         "akz_ctx_set_profiling": ([vp, i32], i32),
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
+        "akz_ctx_set_match_mode": ([vp, i32], i32),
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
         "akz_ctx_set_detector_overlap": ([vp, i32], i32),
@@ -291,6 +292,10 @@ class Context:
     def set_fed_mode(self, mode):
         """2 = register-ownership fused kernel (default), 1 = LDS-only fused kernel, 0 = one launch per step."""
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
+
+    def set_match_mode(self, mode):
+        """2 = automatic (default), 1 = matrix-core matcher, 0 = popcount matcher."""
+        _check(lib().akz_ctx_set_match_mode(self._h, int(mode)))
 
     def set_detector_mode(self, mode):
         """2 = automatic (default), 1 = streaming kernel pair, 3 = fused streaming kernel, 4 = one LDS-tiled kernel,

@@ -324,6 +324,10 @@ int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
    per launch; 1 = k_fed_fused, same tiling with all values through LDS; 0 = k_fed_step, one launch
    per step.  Results are bit-identical. */
 int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
+/* Matcher kernel: 2 (default) = automatic (matrix-core kernel from 2^22 descriptor pairs, popcount kernel
+   below), 1 = matrix-core kernel (k_match_mfma: descriptor bits unpacked to int8, Hamming distances from
+   one integer GEMM), 0 = popcount kernel (k_match).  Results are identical. */
+int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
 /* Detector kernel variant: 2 (default) = automatic (streaming register-ring kernels for batches whose
    second-derivative planes are not kept, LDS-tiled kernels otherwise); 1 = streaming pair (first /
    second derivatives) wherever it is supported (sigma_size <= 4); 3 = the single fused streaming kernel

@@ -166,7 +166,16 @@ def test_detector_response(ctx, ref, sigma):
     same(host(lean["Ldet"]), ldet)
 
 
-def test_descriptor_match(ctx, ref):
+@pytest.fixture(params=[0, 1], ids=["popcount", "mfma"])
+def mctx(request, ctx):
+    """The context with the matcher kernel forced: 0 = popcount scan, 1 = matrix-core (integer GEMM) scan."""
+    ctx.set_match_mode(request.param)
+    yield ctx
+    ctx.set_match_mode(2)
+
+
+def test_descriptor_match(mctx, ref):
+    ctx = mctx
     rng = np.random.default_rng(12)
     d0 = rng.integers(0, 256, (300, 61), dtype=np.uint8)
     d1 = rng.integers(0, 256, (517, 61), dtype=np.uint8)
@@ -184,9 +193,10 @@ def test_descriptor_match(ctx, ref):
     assert len(ctx.descriptor_match(np.zeros((0, 61), np.uint8), d1)) == 0
 
 
-def test_descriptor_match_chunked_large(ctx, ref):
+def test_descriptor_match_chunked_large(mctx, ref):
     """Train sets large enough to be split over several workgroups (chunk merge) with planted ties across
     chunk boundaries: result identical to the sequential scan of the oracle."""
+    ctx = mctx
     rng = np.random.default_rng(21)
     d0 = rng.integers(0, 256, (700, 61), dtype=np.uint8)
     d1 = rng.integers(0, 256, (9001, 61), dtype=np.uint8)

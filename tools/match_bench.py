@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the brute-force Hamming matcher (k_match + k_match_compact) on device-resident descriptor rows:
+"""Times the brute-force Hamming matcher (popcount kernel k_match and matrix-core kernel k_match_mfma, each with
+merge + compaction) on device-resident descriptor rows:
 a 3840x2160 synthetic pair (BASELINE configs[2]) and a gathered multi-frame set."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +24,10 @@ def timeit(a, b, reps=20):
     pairs = a.shape[0] * b.shape[0]
     print(f"n0={a.shape[0]} n1={b.shape[0]} matches={int(cnt.item())} {ms*1e3:.1f} us  {pairs/ms/1e6:.2f} Gpairs/s "
           f"({pairs*32/ms/1e9:.2f} T xor+popc lane-ops/s)")
-timeit(d0, d1)
 big0 = torch.cat([d0] * 8); big1 = torch.cat([d1] * 8)
-timeit(big0, big1, reps=5)
+for mode, name in ((0, "popcount"), (1, "mfma")):
+    ctx.set_match_mode(mode)
+    print(name)
+    timeit(d0[:2000], d1[:2000])
+    timeit(d0, d1)
+    timeit(big0, big1, reps=5)

@@ -1696,13 +1696,14 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
         const uint32_t q_rows = launch::match_mfma_rows((uint32_t)n0, true), t_rows = launch::match_mfma_rows((uint32_t)n1, false);
         AKZ_TRY(ensure(c, c->mm_q8, (size_t)q_rows * 512));
         AKZ_TRY(ensure(c, c->mm_t8, (size_t)t_rows * 512));
-        AKZ_TRY(ensure(c, c->mm_pop, ((size_t)q_rows + t_rows) * sizeof(uint32_t)));
+        AKZ_TRY(ensure(c, c->mm_pop, ((size_t)2 * q_rows + t_rows) * sizeof(uint32_t)));
         uint32_t* qpop = (uint32_t*)c->mm_pop.p;
-        uint32_t* tpop = qpop + q_rows;
-        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, (uint8_t*)c->mm_q8.p, qpop);
-        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, (uint8_t*)c->mm_t8.p, tpop);
-        launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, tpop,
-                           (uint32_t)n1, thr, merged + n0, merged);
+        uint32_t* bound = qpop + q_rows;
+        uint32_t* tpop = bound + q_rows;
+        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr);
+        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0);
+        launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p,
+                           (uint32_t)n1, thr, bound, merged + n0, merged);
     } else {
         launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, merged + n0, merged);
     }

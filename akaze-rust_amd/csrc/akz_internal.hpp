@@ -196,9 +196,10 @@ void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t ch
 // GEMM; identical records.  Rows of the unpacked images are padded (match_mfma_rows).
 uint32_t match_mfma_rows(uint32_t n, bool queries);
 uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1);
-void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, uint8_t* out8, uint32_t* pop);
-void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
-                const uint32_t* tpop, uint32_t n1, uint32_t threshold, MatchRec* d_part, MatchRec* d_out);
+void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
+                 uint32_t* bound, uint32_t threshold);  // bound (queries only): per-query pruning bound, set to threshold
+void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
+                uint32_t threshold, uint32_t* bound, MatchRec* d_part, MatchRec* d_out);
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out);
 // workgroups of the following persistent tiled launches issued by this thread (0: built-in value); a huge value makes

@@ -3,7 +3,7 @@
 // ops::feature_matching::descriptor_match (akaze/src/ops/feature_matching.rs:23-94) scans, for every query
 // descriptor, all train descriptors and keeps the smallest and second smallest Hamming distance (strict '<'
 // updates, :41-49: the lowest index wins among equal minima).  With the descriptor bits unpacked to int8 0/1,
-//     hamming(a, b) = |a| + |b| - 2 <a, b>,
+//     hamming(a, b) = |a| + |b| - 2 <a, b>      (a: train row, b: query row),
 // and the inner products of all (train, query) pairs are one integer GEMM with K = 512: exact integer
 // arithmetic, so distances, indices and therefore the match list are identical to the popcount scan
 // (k_match in akz_kernels.hip, which stays the path for small sets), at a multiple of its rate — the popcount
@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 
 #include "akz_internal.hpp"
 
@@ -41,40 +42,47 @@ constexpr int MM_SUB = 1;          // 32-row MFMA tiles per LDS tile (2 needs a 
 constexpr int MM_TR = 32 * MM_SUB; // train rows per LDS tile
 constexpr int MM_PITCH = KB + 16;  // LDS row pitch in bytes
 
-// one wave per descriptor row: lane t expands byte t into 8 int8 values; the row's bit count by wave reduction
-__global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad,
-                                                     uint8_t* __restrict__ out, unsigned* __restrict__ pop) {
+// One wave per descriptor row: lane t expands byte t into 8 int8 values; the row's bit count by wave reduction.
+// A descriptor has 61 bytes (486 bits used, feature_matching.rs works on those bytes), so columns 488..511 are free.
+// They fold the train row's bit count into the product: a TRAIN row gets its bits as 0/1 and its count split over
+// columns 488..491 (each <= 127), a QUERY row gets its bits as 0/2 and -1 in those four columns, so that
+//     <train row, query row> = 2 <a, b> - |a|     and     hamming = |b| - that,
+// i.e. the kernel's epilogue is a maximum over accumulators instead of 16 additions of row counts.
+__global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, bool query,
+                                                     uint8_t* __restrict__ out, unsigned* __restrict__ pop,
+                                                     unsigned* __restrict__ bound, unsigned threshold) {
     const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (row >= n_pad) return;
-    const unsigned byte = row < n ? d[(size_t)row * 64 + lane] : 0u;
+    const unsigned byte = (row < n && lane < 61u) ? d[(size_t)row * 64 + lane] : 0u;
+    unsigned c = __popc(byte);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     uint2 v;
     v.x = (byte & 1u) | ((byte & 2u) << 7) | ((byte & 4u) << 14) | ((byte & 8u) << 21);
     v.y = ((byte >> 4) & 1u) | (((byte >> 4) & 2u) << 7) | (((byte >> 4) & 4u) << 14) | (((byte >> 4) & 8u) << 21);
+    if (query) {
+        v.x <<= 1;
+        v.y <<= 1;
+        if (lane == 61u) v.x = 0xffffffffu;  // -1 in columns 488..491
+    } else if (lane == 61u) {
+        const unsigned c0 = min(c, 127u), c1 = min(c - c0, 127u), c2 = min(c - c0 - c1, 127u), c3 = c - c0 - c1 - c2;  // c <= 488
+        v.x = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    }
     *reinterpret_cast<uint2*>(out + (size_t)row * KB + 8 * lane) = v;
-    unsigned c = __popc(byte);
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (lane == 0) pop[row] = c;
-}
-
-__device__ __forceinline__ void top2_feed(unsigned d, unsigned j, unsigned& min_d, unsigned& second, unsigned& min_j) {
-    if (d < min_d) {  // the reference's update rule (feature_matching.rs:41-49)
-        second = min_d;
-        min_d = d;
-        min_j = j;
-    } else if (d < second) {
-        second = d;
+    if (lane == 0) {
+        pop[row] = c;
+        if (bound) bound[row] = threshold;  // queries: the shared pruning bound of k_match_mfma starts at the threshold
     }
 }
 
 // blockIdx.x: 512 queries; blockIdx.y: a chunk of `chunk_tiles` train tiles.  q8 / t8: unpacked sets, rows padded
-// to a multiple of MM_QB / MM_TR with zero rows; qpop / tpop: bit counts.  Writes (min, second, argmin) of every
+// to a multiple of MM_QB / MM_TR with zero rows (k_unpack_bits, query / train form); qpop: bit counts of the queries.  Writes (min, second, argmin) of every
 // live query over the chunk to out[chunk * n0 + query].
 __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict__ q8, const unsigned* __restrict__ qpop,
                                                       unsigned n0, const uint8_t* __restrict__ t8,
-                                                      const unsigned* __restrict__ tpop, unsigned n1, unsigned chunk_tiles,
-                                                      unsigned threshold, MatchRec* __restrict__ out) {
+                                                      unsigned n1, unsigned chunk_tiles,
+                                                      unsigned threshold, unsigned* __restrict__ bound,
+                                                      MatchRec* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH];
-    __shared__ unsigned s_pop[2][MM_TR];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
     const unsigned q_first = blockIdx.x * MM_QB + wave * MM_QW;  // this wave's 32 queries
@@ -91,6 +99,16 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
     }
     const unsigned pq = qpop[q_first + r];
     unsigned min_d = threshold, second = threshold, min_j = 0u;
+    // A chunk starts without knowing anything about its queries, and while `second` is still large nearly every tile
+    // contains a row that beats it for one of the wave's queries (the slow path below then runs for the whole wave:
+    // a third of the kernel's time with 16 chunks).  All workgroups that scan for a query therefore share an upper
+    // bound of its final second-best distance: bound[q] only ever receives some chunk's current `second`, which is
+    // never below the final value, so rows with a distance ABOVE the bound cannot appear in the final (min, second,
+    // argmin) — rows AT the bound still take the exact path (they can decide a tie) — and skipping them leaves the
+    // merged result identical.  The bound is re-read every fourth tile past the L1 (agent-scope atomic load) and the
+    // value is used four tiles later, so the load is never waited for.
+    unsigned limit = threshold;  // min(second, bound[q] + 1): a tile whose best distance is >= limit changes nothing that matters
+    unsigned b_seen = threshold;  // bound[q] as last read (consumed four tiles after the load was issued: never waited for)
 
     const unsigned tiles_total = (n1 + MM_TR - 1) / MM_TR;
     const unsigned t_begin = blockIdx.y * chunk_tiles, t_end = min(tiles_total, t_begin + chunk_tiles);
@@ -110,7 +128,6 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
             const unsigned piece = tid + k * MM_NT;
             *reinterpret_cast<uint4*>(&s_tile[buf][(piece >> 5) * MM_PITCH + (piece & 31u) * 16u]) = stage[k];
         }
-        if (tid < MM_TR) s_pop[buf][tid] = tpop[(size_t)tile * MM_TR + tid];
     };
     if (t_begin < t_end) {
         fetch(t_begin);
@@ -134,22 +151,53 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
                 acc[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(arow + 32 * s), bq[s], acc[sub], 0, 0, 0);
         }
         const bool partial = (tile + 1) * MM_TR > n1;  // uniform: only the last tile of the set
+        if (((tile - t_begin) & 3u) == 0u) {  // use the value requested four tiles ago, request the next one
+            limit = min(limit, min(second, b_seen < 0xffffffffu ? b_seen + 1u : b_seen));
+            b_seen = __hip_atomic_load(bound + q_first + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
         for (int sub = 0; sub < MM_SUB; ++sub) {
             // distances of this lane's 16 train rows of the sub-tile (ascending index) to its query
             const unsigned j0 = tile * MM_TR + 32 * sub + 4 * h;
-            auto dist = [&](int i) {
-                const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
-                unsigned d = s_pop[buf][32 * sub + row + 4 * h] + pq - 2u * (unsigned)acc[sub][i];
-                if (partial && j0 + row >= n1) d = 0xffffffffu;  // padding rows never match
-                return d;
-            };
-            unsigned best = 0xffffffffu;
+            // acc[i] = 2 <a, b> - |a| (the row counts ride in the product), so hamming = |b| - acc[i]: the smallest
+            // distance of the 16 rows is pq minus the largest accumulator
+            int top = acc[sub][0];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) best = min(best, dist(i));
-            if (best < second) {  // rare once a few hundred rows have been seen
+            for (int i = 1; i < 16; ++i) top = max(top, acc[sub][i]);
+            if (partial || (int)pq - top < (int)limit) {  // rare: see `limit`
+                // exact update from the tile's two smallest distances and the first row of the smallest: keys
+                // (acc << 4 | 15 - i) order by accumulator, then by ascending row; top two keys by max3 / med3
+                int key[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) top2_feed(dist(i), j0 + (unsigned)((i & 3) + 8 * (i >> 2)), min_d, second, min_j);
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
+                    key[i] = (partial && j0 + row >= n1) ? INT_MIN : (acc[sub][i] << 4) + (15 - i);  // padding rows never match
+                }
+                int M = INT_MIN, S = INT_MIN;
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {  // five groups of three keys, then the sixteenth
+                    const int a = key[3 * g], b = key[3 * g + 1], c = key[3 * g + 2];
+                    const int gm = max(a, max(b, c)), gs = max(min(a, b), min(max(a, b), c));  // largest, median
+                    S = max(min(M, gm), max(S, gs));
+                    M = max(M, gm);
+                }
+                S = max(S, min(M, key[15]));
+                M = max(M, key[15]);
+                const int i1 = 15 - (M & 15);
+                const unsigned tb = M == INT_MIN ? 0xffffffffu : (unsigned)((int)pq - (M >> 4));
+                const unsigned ts = S == INT_MIN ? 0xffffffffu : (unsigned)((int)pq - (S >> 4));
+                const unsigned before = second;
+                if (tb < min_d) {  // rows of a lane arrive in ascending order: the sequential rule (:41-49) folded per tile
+                    second = min(min_d, ts);
+                    min_d = tb;
+                    min_j = j0 + (unsigned)((i1 & 3) + 8 * (i1 >> 2));
+                } else {
+                    second = min(second, tb);
+                }
+                if (second < before) {
+                    atomicMin(bound + q_first + r, second);
+                    limit = min(limit, second);
+                }
             }
         }
         if (more) commit(tile + 1, buf ^ 1);
@@ -204,18 +252,19 @@ uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1) {
     }
     return best;
 }
-void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, uint8_t* out8, uint32_t* pop) {
-    hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, out8, pop);
+void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
+                 uint32_t* bound, uint32_t threshold) {
+    hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, query, out8, pop, bound, threshold);
 }
 // top-2 records of every query over the whole train set in d_out (d_part: chunks x n0 scratch records)
-void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
-                const uint32_t* tpop, uint32_t n1, uint32_t threshold, MatchRec* d_part, MatchRec* d_out) {
+void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
+                uint32_t threshold, uint32_t* bound, MatchRec* d_part, MatchRec* d_out) {
     if (n0 == 0) return;
     const uint32_t chunks = match_mfma_chunks(n0, n1);
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
     const uint32_t chunk_tiles = (tiles + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, tpop, n1,
-                       chunk_tiles, threshold, chunks > 1 ? d_part : d_out);
+    hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, n1,
+                       chunk_tiles, threshold, bound, chunks > 1 ? d_part : d_out);
     if (chunks > 1) match_merge(s, d_part, n0, chunks, threshold, d_out);
 }
 

@@ -324,9 +324,9 @@ int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
    per launch; 1 = k_fed_fused, same tiling with all values through LDS; 0 = k_fed_step, one launch
    per step.  Results are bit-identical. */
 int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
-/* Matcher kernel: 2 (default) = automatic (matrix-core kernel from 2^22 descriptor pairs, popcount kernel
-   below), 1 = matrix-core kernel (k_match_mfma: descriptor bits unpacked to int8, Hamming distances from
-   one integer GEMM), 0 = popcount kernel (k_match).  Results are identical. */
+/* Matcher kernel: 2 (default) and 1 = matrix-core kernel (k_match_mfma: descriptor bits unpacked to int8,
+   Hamming distances from one integer GEMM; faster than the popcount scan from 128 x 128 descriptors up),
+   0 = popcount kernel (k_match).  Results are identical. */
 int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
 /* Detector kernel variant: 2 (default) = automatic (streaming register-ring kernels for batches whose
    second-derivative planes are not kept, LDS-tiled kernels otherwise); 1 = streaming pair (first /

@@ -19,6 +19,8 @@ Extra objects on that line:
                 lone call, the rate of a stream of such calls on one context, and on four contexts driven by four
                 host threads (untimed extra leg; the headline workload is the
                 32-frames-per-GPU batch of configs[3], which is what the 1/2/4/8-GPU metric shards).
+  match         the brute-force Hamming matcher on two descriptor sets (untimed extra leg): pairs/s and fraction of the
+                dense int8 MFMA rate (1024 operations per descriptor pair).
   cpu_baseline  the CPU oracle (C++ restatement of the reference's CPU path; the Rust reference
                 cannot be built in this image) timed on the host cores on a bounded sample.
 """
@@ -33,6 +35,7 @@ sys.path[:0] = [os.path.join(ROOT, "akaze-rust_amd", "python")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FED_BYTES_PER_PX_STEP = 12.0   # read Lt + read Lflow + write Lt'  
+MFMA_I8_PEAK_OPS = 5.0e15      # dense int8 MFMA rate: 2 x the 2.5 PFLOP/s bf16 figure (MI355X_MICROARCH.md)
 
 
 def pmc_traffic():
@@ -93,6 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fed4k", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-frame-per-call leg")
+    ap.add_argument("--no-match", action="store_true", help="skip the matcher leg")
     ap.add_argument("--parts", type=int, default=1,
                     help="batches per step; batches are software-pipelined on ONE stream (begin(batch j+1) is "
                          "enqueued before finish(batch j)), so the host keypoint phase of a batch runs under the "
@@ -278,6 +282,33 @@ def main():
                               "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * w4 * h4 * nst / launches)}
         del lt, lf
 
+    # ---- the matcher (BASELINE configs[2] / [4]: Hamming match of two descriptor sets), untimed leg, rank 0 ------
+    match_leg = None
+    if rank == 0 and not args.no_match:
+        g = torch.Generator(device=dev).manual_seed(7)
+        legs = []
+        for n_m in (11264, 65536):  # a 4K frame's keypoint count; a gathered multi-frame set
+            da = torch.randint(0, 256, (n_m, 64), dtype=torch.uint8, device=dev, generator=g)
+            db = torch.randint(0, 256, (n_m, 64), dtype=torch.uint8, device=dev, generator=g)
+            da[:, 61:] = 0
+            db[:, 61:] = 0
+            ctx.descriptor_match_device(da, db)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps_m = 10
+            e0.record()
+            for _ in range(reps_m):
+                ctx.descriptor_match_device(da, db)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_m = e0.elapsed_time(e1) / reps_m
+            pairs = float(n_m) * n_m
+            legs.append({"n0": n_m, "n1": n_m, "ms": round(ms_m, 3), "Tpairs_per_s": round(pairs / ms_m / 1e9, 3),
+                         "mfma_frac": round(pairs * 2 * 512 / (ms_m * 1e-3) / MFMA_I8_PEAK_OPS, 3)})
+        match_leg = {"kernel": "k_match_mfma (+ unpack, merge, compaction)", "bound": "mfma",
+                     "peak": "%.1f POP/s int8 dense (2 x the 2.5 PFLOP/s bf16 MFMA rate)" % (MFMA_I8_PEAK_OPS / 1e15),
+                     "ops_per_pair": 1024, "sets": legs}
+
     # ---- BASELINE configs[1] taken literally: ONE frame per extract call (untimed extra leg, rank 0) -----------
     single = None
     if rank == 0 and not args.no_single:
@@ -398,6 +429,7 @@ def main():
             "stage_ms_per_step": stage_ms,
             "stage_roofline": stage_roofline,
             "single_frame": single,
+            "match": match_leg,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The workload table of DESIGN.md 4.4: bench.py over the other BASELINE shapes (run through gpurun from the repo root).
 J='import json,sys; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print("| %s | %.0f | %.2f ms | %.2f |" % (sys.argv[1], d["value"], d["ms_per_step"], r["frac"]))'
-run() { name=$1; shift; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fed4k --no-single "$@" 2>/dev/null | grep '^{' | python3 -c "$J" "$name"; }
+run() { name=$1; shift; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fed4k --no-single --no-match "$@" 2>/dev/null | grep '^{' | python3 -c "$J" "$name"; }
 run "32 x 1920x1080 per step (bench default)"
 run "32 x 1920x1080, second-derivative / Lstep planes not kept (--lean)" --lean
 run "1 x 1920x1080 per step" --frames 1

@@ -5,5 +5,5 @@ J='import json,sys; d=json.loads(sys.stdin.readline()); r=d["roofline"]; s=d["st
 for t in "$@"; do
   rm -f akaze-rust_amd/csrc/akz_kernels.o akaze-rust_amd/csrc/akz_stencil.o akaze-rust_amd/csrc/akz_stream.o
   make -C akaze-rust_amd -j8 TUNE="$t" > /dev/null 2>&1 || { echo "build failed: $t"; continue; }
-  for i in 1 2; do python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-fed4k --no-single 2>/dev/null | grep '^{' | python3 -c "$J" "[$t]"; done
+  for i in 1 2; do python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-fed4k --no-single --no-match 2>/dev/null | grep '^{' | python3 -c "$J" "[$t]"; done
 done

@@ -193,6 +193,27 @@ def test_descriptor_match(mctx, ref):
     assert len(ctx.descriptor_match(np.zeros((0, 61), np.uint8), d1)) == 0
 
 
+@pytest.mark.parametrize("n0,n1", [(1, 1), (2, 33), (33, 31), (64, 64), (513, 1000), (700, 63), (1025, 4097)])
+def test_descriptor_match_ragged_sizes(ctx, ref, n0, n1):
+    """Set sizes around the tile sizes of the matrix-core matcher (32 train rows, 512 queries per workgroup), low-entropy
+    descriptors with many exact ties and duplicates: both matcher kernels against the oracle's sequential scan."""
+    rng = np.random.default_rng(n0 * 7919 + n1)
+    base = rng.integers(0, 256, (8, 61), dtype=np.uint8)
+    d0 = base[rng.integers(0, 8, n0)].copy()
+    d1 = base[rng.integers(0, 8, n1)].copy()
+    d0[rng.random(d0.shape) < 0.02] ^= 0x10  # a few differing bits: many equal distances, some exact duplicates
+    d1[rng.random(d1.shape) < 0.02] ^= 0x01
+    for ratio, thr in ((0.86, 10000), (1.5, 10000), (0.99, 12)):
+        exp = ref.descriptor_match(d0, d1, thr, ratio)
+        for mode in (1, 0):
+            ctx.set_match_mode(mode)
+            try:
+                got = ctx.descriptor_match(d0, d1, thr, ratio)
+            finally:
+                ctx.set_match_mode(2)
+            assert np.array_equal(got, exp), (mode, ratio, thr, len(got), len(exp))
+
+
 def test_descriptor_match_chunked_large(mctx, ref):
     """Train sets large enough to be split over several workgroups (chunk merge) with planted ties across
     chunk boundaries: result identical to the sequential scan of the oracle."""

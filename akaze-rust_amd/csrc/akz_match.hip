@@ -11,16 +11,17 @@
 // v_mfma_i32_32x32x32_i8.
 //
 // Layout.  k_unpack_bits writes a set as int8 [rows padded][512] (bit b of byte t -> column 8t + b; any fixed
-// order works, both operands use the same one) and the bit count of every row.  k_match_mfma: 1024 threads = 16
-// waves, four per SIMD; a wave owns 32 queries as the B operand for all 16 K-steps (64 VGPRs, loaded once); the
-// workgroup walks a chunk of the train set in LDS tiles of 32 rows (one MFMA tile) that all waves share
-// (double-buffered; row pitch 528 B so that the 16-byte operand reads of a 16-lane group fall into different
-// banks).  A/B operand of lane l (r = l & 31, h = l >> 5) at K-step s: bytes 32 s + 16 h .. + 15 of row r — the
-// same function of (l, s) for both operands, which is all the dot product needs.  The 32 x 32 result has its column
-// (query) on the lane and rows (i & 3) + 8 (i >> 2) + 4 h, i = 0..15, in the registers (cdna_hip_programming.md,
-// C/D layout): ascending train index inside a lane, so the reference's update rule applies directly; the two
-// lanes of a column are merged at the end of the chunk with the order-free form of the rule ((distance, index)
-// lexicographic minimum; second = min of the others), and the chunks by k_match_merge.
+// order works, both operands use the same one; the free columns 488..511 carry the train rows' bit counts, see
+// there).  k_match_mfma: 1024 threads = 16 waves, four per SIMD; a wave owns 32 queries as the B operand for all 16
+// K-steps (64 VGPRs, loaded once); the workgroup walks a chunk of the train set in LDS tiles of 128 rows (four
+// 32-row MFMA tiles per barrier) that all waves share (double-buffered; row pitch 528 B so that the 16-byte
+// operand reads of a 16-lane group fall into different banks; the next tile arrives in 32-row parts through one
+// register stage).  A/B operand of lane l (r = l & 31, h = l >> 5) at K-step s: bytes 32 s + 16 h .. + 15 of
+// row r — the same function of (l, s) for both operands, which is all the dot product needs.  The 32 x 32 result
+// has its column (query) on the lane and rows (i & 3) + 8 (i >> 2) + 4 h, i = 0..15, in the registers
+// (cdna_hip_programming.md, C/D layout): ascending train index inside a lane, so the reference's update rule
+// applies directly; the two lanes of a column are merged at the end of the chunk with the order-free form of the
+// rule ((distance, index) lexicographic minimum; second = min of the others), and the chunks by k_match_merge.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,8 +39,14 @@ constexpr int KB = 512;            // int8 columns per descriptor (64 bytes x 8 
 constexpr int MM_NT = 1024;        // threads per workgroup: 16 waves, four per SIMD
 constexpr int MM_QW = 32;          // queries per wave: one 32-column block, its B operand resident in 64 VGPRs
 constexpr int MM_QB = (MM_NT / 64) * MM_QW;  // queries per workgroup (512)
-constexpr int MM_SUB = 1;          // 32-row MFMA tiles per LDS tile (2 needs a second accumulator set: 128 VGPRs and spills, measured slower)
-constexpr int MM_TR = 32 * MM_SUB; // train rows per LDS tile
+#ifndef AKZ_MM_SUB
+#define AKZ_MM_SUB 4
+#endif
+#ifndef AKZ_MM_AHEAD
+#define AKZ_MM_AHEAD 3
+#endif
+constexpr int MM_SUB = AKZ_MM_SUB;  // 32-row MFMA tiles per LDS tile, i.e. per barrier (1: 2.91, 2: 2.97, 4: 3.07 T pairs/s)
+constexpr int MM_TR = 32 * MM_SUB;  // train rows per LDS tile
 constexpr int MM_PITCH = KB + 16;  // LDS row pitch in bytes
 
 // One wave per descriptor row: lane t expands byte t into 8 int8 values; the row's bit count by wave reduction.
@@ -112,44 +119,27 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
 
     const unsigned tiles_total = (n1 + MM_TR - 1) / MM_TR;
     const unsigned t_begin = blockIdx.y * chunk_tiles, t_end = min(tiles_total, t_begin + chunk_tiles);
-    // staging: the LDS tile (32 KiB) is moved in 16-byte pieces, SG per thread (row-major, 32 pieces per row)
-    constexpr int SG = MM_TR * KB / 16 / MM_NT;
-    uint4 stage[SG];
-    auto fetch = [&](unsigned tile) {
-#pragma unroll
-        for (int k = 0; k < SG; ++k) {
-            const unsigned piece = tid + k * MM_NT;
-            stage[k] = *reinterpret_cast<const uint4*>(t8 + ((size_t)tile * MM_TR + (piece >> 5)) * KB + (piece & 31u) * 16u);
-        }
+    // Staging: the next LDS tile is fetched one 32-row part at a time (one 16-byte piece per thread and part, 32
+    // pieces per row): part p is requested before the MFMA chain of sub-tile p of the current tile and handed to the
+    // other LDS buffer after that sub-tile's epilogue, so one register stage serves MM_SUB parts per barrier.
+    static_assert(32 * KB / 16 == MM_NT, "one 16-byte piece per thread and 32-row part");
+    const unsigned st_src = (tid >> 5) * KB + (tid & 31u) * 16u, st_dst = (tid >> 5) * MM_PITCH + (tid & 31u) * 16u;
+    uint4 stage;
+    auto fetch = [&](unsigned tile, int part) {
+        stage = *reinterpret_cast<const uint4*>(t8 + ((size_t)tile * MM_TR + 32u * part) * KB + st_src);
     };
-    auto commit = [&](unsigned tile, int buf) {
-#pragma unroll
-        for (int k = 0; k < SG; ++k) {
-            const unsigned piece = tid + k * MM_NT;
-            *reinterpret_cast<uint4*>(&s_tile[buf][(piece >> 5) * MM_PITCH + (piece & 31u) * 16u]) = stage[k];
-        }
-    };
+    auto commit = [&](int buf, int part) { *reinterpret_cast<uint4*>(&s_tile[buf][32 * part * MM_PITCH + st_dst]) = stage; };
     if (t_begin < t_end) {
-        fetch(t_begin);
-        commit(t_begin, 0);
+#pragma unroll
+        for (int part = 0; part < MM_SUB; ++part) {
+            fetch(t_begin, part);
+            commit(0, part);
+        }
     }
     __syncthreads();
     for (unsigned tile = t_begin; tile < t_end; ++tile) {
         const int buf = (int)((tile - t_begin) & 1u);
         const bool more = tile + 1 < t_end;
-        if (more) fetch(tile + 1);  // in flight under the MFMA chains below
-        // the MFMA chains of all sub-tiles are issued before the first epilogue, whose vector instructions then run
-        // while the matrix pipe works on the later chains
-        v16i acc[MM_SUB];
-#pragma unroll
-        for (int sub = 0; sub < MM_SUB; ++sub) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[sub][i] = 0;
-            const uint8_t* arow = &s_tile[buf][(32 * sub + r) * MM_PITCH + 16 * h];
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-                acc[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(arow + 32 * s), bq[s], acc[sub], 0, 0, 0);
-        }
         const bool partial = (tile + 1) * MM_TR > n1;  // uniform: only the last tile of the set
         if (((tile - t_begin) & 3u) == 0u) {  // use the value requested four tiles ago, request the next one
             limit = min(limit, min(second, b_seen < 0xffffffffu ? b_seen + 1u : b_seen));
@@ -157,13 +147,32 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
         }
 #pragma unroll
         for (int sub = 0; sub < MM_SUB; ++sub) {
+            if (more) fetch(tile + 1, sub);  // in flight under the MFMA chain below
+            v16i acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            const uint8_t* arow = &s_tile[buf][(32 * sub + r) * MM_PITCH + 16 * h];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(arow + 32 * s), bq[s], acc, 0, 0, 0);
+            // schedule: keep AKZ_MM_AHEAD operand reads in flight ahead of the MFMA that consumes them (an LDS read
+            // takes ~100 cycles, an MFMA 32; left alone the scheduler issues read, wait, MFMA, read, wait, ...)
+#if AKZ_MM_AHEAD > 0
+            __builtin_amdgcn_sched_group_barrier(0x100, AKZ_MM_AHEAD, 0);
+#pragma unroll
+            for (int s = 0; s < 16 - AKZ_MM_AHEAD; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, AKZ_MM_AHEAD, 0);
+#endif
             // distances of this lane's 16 train rows of the sub-tile (ascending index) to its query
             const unsigned j0 = tile * MM_TR + 32 * sub + 4 * h;
             // acc[i] = 2 <a, b> - |a| (the row counts ride in the product), so hamming = |b| - acc[i]: the smallest
             // distance of the 16 rows is pq minus the largest accumulator
-            int top = acc[sub][0];
+            int top = acc[0];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) top = max(top, acc[sub][i]);
+            for (int i = 1; i < 16; ++i) top = max(top, acc[i]);
             if (partial || (int)pq - top < (int)limit) {  // rare: see `limit`
                 // exact update from the tile's two smallest distances and the first row of the smallest: keys
                 // (acc << 4 | 15 - i) order by accumulator, then by ascending row; top two keys by max3 / med3
@@ -171,7 +180,7 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
-                    key[i] = (partial && j0 + row >= n1) ? INT_MIN : (acc[sub][i] << 4) + (15 - i);  // padding rows never match
+                    key[i] = (partial && j0 + row >= n1) ? INT_MIN : (acc[i] << 4) + (15 - i);  // padding rows never match
                 }
                 int M = INT_MIN, S = INT_MIN;
 #pragma unroll
@@ -199,8 +208,8 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
                     limit = min(limit, second);
                 }
             }
+            if (more) commit(buf ^ 1, sub);
         }
-        if (more) commit(tile + 1, buf ^ 1);
         __syncthreads();
     }
     // the two lanes of a column hold disjoint row sets: order-free merge, then one record per live query
@@ -237,14 +246,15 @@ uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1) {
     const uint32_t qblocks = (std::max<uint32_t>(n0, 1) + MM_QB - 1) / MM_QB;
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
     // One workgroup per CU is resident (16 waves); a launch runs in rounds of 256 workgroups, each of which first
-    // loads its 512 queries (as much traffic as 16 train tiles) and then walks its chunk.  Pick the chunk count
-    // with the least estimated time: rounds x (tiles per chunk + 16).
-    const uint32_t cmax = std::max<uint32_t>(1, std::min<uint32_t>(tiles / 8, 128u));
+    // loads its 512 queries (as much traffic as 512 train rows) and then walks its chunk.  Pick the chunk count
+    // with the least estimated time: rounds x (tiles per chunk + 512 / rows per tile).
+    constexpr uint32_t kQueryLoad = 512 / MM_TR;
+    const uint32_t cmax = std::max<uint32_t>(1, std::min<uint32_t>(tiles / (kQueryLoad / 2), 128u));
     uint32_t best = 1;
     uint64_t best_cost = ~0ull;
     for (uint32_t c = 1; c <= cmax; ++c) {
         const uint64_t rounds = ((uint64_t)qblocks * c + 255) / 256;
-        const uint64_t cost = rounds * ((tiles + c - 1) / c + 16);
+        const uint64_t cost = rounds * ((tiles + c - 1) / c + kQueryLoad);
         if (cost < best_cost) {
             best_cost = cost;
             best = c;

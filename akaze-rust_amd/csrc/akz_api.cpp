@@ -1676,9 +1676,11 @@ int akz_fetch_plane(const akz_result* r, uint64_t img, uint64_t level, akz_plane
 // ---------------------------------------------------------------------------------------------
 // descriptor_match
 // ---------------------------------------------------------------------------------------------
-int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
-                                uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
-                                uint64_t* d_n_out) {
+// rows_le_61: every row uses at most its first 61 bytes (M-LDB descriptors: 486 bits; the matrix-core kernel keeps the
+// train rows' bit counts in the K-columns of bytes 61..63 and ignores whatever those bytes hold)
+static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
+                             uint64_t distance_threshold, double lowes_ratio, akz_match* d_out, uint64_t* d_n_out,
+                             bool rows_le_61) {
     AKZ_TRY(bind(c));
     if (!d_out || !d_n_out || (n0 && !d_d0) || (n1 && !d_d1) || n0 > 0x7fffffffull || n1 > 0x7fffffffull) {
         set_error("descriptor_match: bad arguments");
@@ -1688,7 +1690,7 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
     // the scan runs on the matrix cores (integer GEMM on the unpacked bits, identical records): 24 us against 29 for the
     // popcount kernel at 128 x 128, 35 against 190 at 1024 x 1024, 3.0 ms against 9.9 at 90 K x 90 K; mode 0 keeps the
     // popcount kernel selectable
-    const bool mfma = n0 && n1 && c->match_mode != 0;
+    const bool mfma = n0 && n1 && c->match_mode != 0 && rows_le_61;
     const uint32_t chunks = mfma ? launch::match_mfma_chunks((uint32_t)n0, (uint32_t)n1)
                                  : launch::match_num_chunks((uint32_t)n0, (uint32_t)n1);
     AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * (chunks + 1) * sizeof(MatchRec)));
@@ -1712,6 +1714,12 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
                           d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
+}
+
+int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
+                                uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
+                                uint64_t* d_n_out) {
+    return match_device_impl(c, d_d0, n0, d_d1, n1, distance_threshold, lowes_ratio, d_out, d_n_out, true);
 }
 
 int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8_t* d1, uint64_t n1,
@@ -1738,8 +1746,8 @@ int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8
     AKZ_HIP_TRY(hipMemcpyAsync(c->match_b.p, p1.data(), p1.size(), hipMemcpyHostToDevice, c->stream));
     akz_match* d_m = (akz_match*)((char*)c->match_out.p + 64);
     uint64_t* d_cnt = (uint64_t*)c->match_out.p;
-    AKZ_TRY(akz_descriptor_match_device(c, (const uint8_t*)c->match_a.p, n0, (const uint8_t*)c->match_b.p, n1,
-                                        distance_threshold, lowes_ratio, d_m, d_cnt));
+    AKZ_TRY(match_device_impl(c, (const uint8_t*)c->match_a.p, n0, (const uint8_t*)c->match_b.p, n1, distance_threshold,
+                              lowes_ratio, d_m, d_cnt, desc_bytes <= 61));
     uint64_t cnt = 0;
     AKZ_HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
     AKZ_HIP_TRY(hipStreamSynchronize(c->stream));

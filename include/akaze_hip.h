@@ -246,7 +246,8 @@ int akz_descriptor_match(akz_ctx* ctx, const uint8_t* d0, uint64_t n0, const uin
                          uint64_t desc_bytes, uint64_t distance_threshold, double lowes_ratio, akz_match* out,
                          uint64_t* n_out);
 /* same on device-resident 64-byte descriptor rows (what akz_result_device_descriptors and the
-   RCCL gather produce).  d_out: n0 akz_match records on the device, compacted in index_0
+   RCCL gather produce: an M-LDB descriptor has at most 61 bytes, bytes 61..63 of a row are padding
+   and are NOT compared).  d_out: n0 akz_match records on the device, compacted in index_0
    order; *d_n_out (device uint64) receives the count. */
 int akz_descriptor_match_device(akz_ctx* ctx, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
                                 uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,

@@ -214,6 +214,20 @@ def test_descriptor_match_ragged_sizes(ctx, ref, n0, n1):
             assert np.array_equal(got, exp), (mode, ratio, thr, len(got), len(exp))
 
 
+def test_descriptor_match_full_width_rows(ctx, ref):
+    """Descriptors of 62..64 bytes use the bytes the matrix-core kernel keeps its row counts in: the host entry point
+    routes them to the popcount kernel."""
+    rng = np.random.default_rng(5)
+    for nb in (64, 62, 61, 21):
+        d0 = rng.integers(0, 256, (200, nb), dtype=np.uint8)
+        d1 = rng.integers(0, 256, (333, nb), dtype=np.uint8)
+        d1[::3] = d0[:111]
+        d1[::3, nb - 1] ^= 0x80
+        got = ctx.descriptor_match(d0, d1, 10000, 0.86)
+        exp = ref.descriptor_match(d0, d1, 10000, 0.86)
+        assert len(exp) > 50 and np.array_equal(got, exp), nb
+
+
 def test_descriptor_match_chunked_large(mctx, ref):
     """Train sets large enough to be split over several workgroups (chunk merge) with planted ties across
     chunk boundaries: result identical to the sequential scan of the oracle."""

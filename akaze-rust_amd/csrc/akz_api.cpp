@@ -142,7 +142,7 @@ struct akz_ctx {
     DevBuf cand;                             // NMS candidates
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
-    DevBuf mm_q8, mm_t8, mm_pop;             // MFMA matcher: unpacked int8 images of the two sets, bit counts
+    DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
     int match_mode = 2;                      // 0: popcount kernel, 1 / 2 (default): matrix-core kernel (akz_ctx_set_match_mode)
     DevBuf cosi;                             // (cos, sin) per keypoint
     DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
@@ -346,7 +346,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
                       &c->small, &c->cand, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
-                      &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop};
+                      &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
@@ -1703,8 +1703,8 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
         uint32_t* qpop = (uint32_t*)c->mm_pop.p;
         uint32_t* bound = qpop + q_rows;
         uint32_t* tpop = bound + q_rows;
-        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr);
-        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0);
+        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, 1, nullptr);
+        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, nullptr);
         launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p,
                            (uint32_t)n1, thr, bound, merged + n0, merged);
     } else {
@@ -1720,6 +1720,86 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
                                 uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
                                 uint64_t* d_n_out) {
     return match_device_impl(c, d_d0, n0, d_d1, n1, distance_threshold, lowes_ratio, d_out, d_n_out, true);
+}
+
+// One query set against several train sets in ONE matrix-core launch (all-pairs matching: a query image against
+// the descriptor sets of all other images).  A pair of 11 K-row sets alone runs at 1.2 T pairs/s, a launch over
+// many sets at the rate of one large product (3 T pairs/s), and every set is unpacked once per call.
+int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
+                                     const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
+                                     double lowes_ratio, akz_match* d_out, uint64_t* d_n_out) {
+    AKZ_TRY(bind(c));
+    if ((n0 && !d_out) || !d_n_out || (n_sets && !set_rows) || (n0 && !d_q) || n0 > 0x7fffffffull || n_sets > 65535) {
+        set_error("descriptor_match_sets: bad arguments");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    uint64_t total_rows = 0;
+    for (uint64_t k = 0; k < n_sets; ++k) total_rows += set_rows[k];
+    if ((total_rows && !d_train) || total_rows > 0x7fffffffull) {
+        set_error("descriptor_match_sets: bad train sets");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    if (n_sets == 0) return AKZ_OK;
+    if (n0 == 0) {
+        AKZ_HIP_TRY(hipMemsetAsync(d_n_out, 0, n_sets * sizeof(uint64_t), c->stream));
+        return AKZ_OK;
+    }
+    if (c->match_mode == 0) {  // popcount kernel: set by set
+        uint64_t off = 0;
+        for (uint64_t k = 0; k < n_sets; ++k) {
+            AKZ_TRY(match_device_impl(c, d_q, n0, d_train + off * 64, set_rows[k], distance_threshold, lowes_ratio,
+                                      d_out + k * n0, d_n_out + k, true));
+            off += set_rows[k];
+        }
+        return AKZ_OK;
+    }
+    const uint32_t thr = (uint32_t)std::min<uint64_t>(distance_threshold, 0x7fffffffull);
+    const uint32_t tr = launch::match_mfma_tile_rows();
+    const uint32_t q_rows = launch::match_mfma_rows((uint32_t)n0, true);
+    // padded train image: every set starts on a tile boundary
+    std::vector<uint32_t> tiles;  // {first source row, valid rows} per tile
+    std::vector<launch::MatchChunkHost> chunks(n_sets);
+    uint64_t src = 0;
+    for (uint64_t k = 0; k < n_sets; ++k) {
+        const uint32_t t0 = (uint32_t)(tiles.size() / 2), rows = (uint32_t)set_rows[k];
+        for (uint32_t r = 0; r < rows; r += tr) {
+            tiles.push_back((uint32_t)(src + r));
+            tiles.push_back(std::min(tr, rows - r));
+        }
+        chunks[k] = launch::MatchChunkHost{t0, (uint32_t)(tiles.size() / 2), t0 * tr, rows, (uint32_t)(k * q_rows), (uint32_t)k};
+        src += rows;
+    }
+    const uint32_t n_tiles = (uint32_t)(tiles.size() / 2), t_rows = std::max(1u, n_tiles) * tr;
+    if ((uint64_t)n_sets * q_rows > 0x7fffffffull) {
+        set_error("descriptor_match_sets: too many sets for this query set");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_TRY(ensure(c, c->mm_q8, (size_t)q_rows * 512));
+    AKZ_TRY(ensure(c, c->mm_t8, (size_t)t_rows * 512));
+    AKZ_TRY(ensure(c, c->mm_pop, ((size_t)q_rows * (1 + n_sets) + t_rows) * sizeof(uint32_t)));
+    const size_t tab_tiles = std::max<size_t>(1, tiles.size()) * sizeof(uint32_t);
+    AKZ_TRY(ensure(c, c->mm_tab, tab_tiles + n_sets * sizeof(launch::MatchChunkHost)));
+    AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * n_sets * sizeof(MatchRec)));
+    uint32_t* qpop = (uint32_t*)c->mm_pop.p;
+    uint32_t* bound = qpop + q_rows;
+    uint32_t* tpop = bound + (size_t)n_sets * q_rows;
+    uint32_t* d_tiles = (uint32_t*)c->mm_tab.p;
+    void* d_chunks = (char*)c->mm_tab.p + tab_tiles;
+    if (!tiles.empty())
+        AKZ_HIP_TRY(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), n_sets * sizeof(launch::MatchChunkHost), hipMemcpyHostToDevice,
+                               c->stream));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));  // the tables are stack / heap objects of this call
+    launch::unpack_bits(c->stream, d_q, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, (uint32_t)n_sets,
+                        nullptr);
+    if (n_tiles)
+        launch::unpack_bits(c->stream, d_train, 0, n_tiles * tr, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, d_tiles);
+    launch::match_mfma_multi(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
+                             (uint32_t)n_sets, thr, bound, (MatchRec*)c->match_rec.p);
+    launch::match_compact_sets(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, (uint32_t)n_sets, thr,
+                               lowes_ratio * lowes_ratio, d_out, (unsigned long long*)d_n_out);
+    AKZ_HIP_TRY(hipGetLastError());
+    return AKZ_OK;
 }
 
 int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8_t* d1, uint64_t n1,

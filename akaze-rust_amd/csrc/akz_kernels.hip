@@ -988,6 +988,9 @@ __global__ void __launch_bounds__(1024) k_match_compact(const MatchRec* __restri
                                                         unsigned long long* __restrict__ n_out) {
     __shared__ unsigned s_wave[16];
     __shared__ unsigned s_base;
+    rec += (size_t)blockIdx.x * n0;  // one workgroup per set of records (blockIdx.x = 0 for a single set)
+    out += (size_t)blockIdx.x * n0;
+    n_out += blockIdx.x;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
@@ -1165,6 +1168,10 @@ void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uin
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out) {
     hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, s, d_rec, n0, threshold, ratio2, d_out, d_n_out);
+}
+void match_compact_sets(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t n_sets, uint32_t threshold, double ratio2,
+                        akz_match* d_out, unsigned long long* d_n_out) {
+    hipLaunchKernelGGL(k_match_compact, dim3(n_sets), dim3(1024), 0, s, d_rec, n0, threshold, ratio2, d_out, d_n_out);
 }
 
 }  // namespace launch

@@ -55,12 +55,23 @@ constexpr int MM_PITCH = KB + 16;  // LDS row pitch in bytes
 // columns 488..491 (each <= 127), a QUERY row gets its bits as 0/2 and -1 in those four columns, so that
 //     <train row, query row> = 2 <a, b> - |a|     and     hamming = |b| - that,
 // i.e. the kernel's epilogue is a maximum over accumulators instead of 16 additions of row counts.
+// tiles (optional): for images of SEVERAL sets laid out one after the other, each padded to whole LDS tiles — entry
+// t = {first source row, number of valid rows} of padded rows t * MM_TR .. + MM_TR - 1 (n is ignored then).
 __global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, bool query,
                                                      uint8_t* __restrict__ out, unsigned* __restrict__ pop,
-                                                     unsigned* __restrict__ bound, unsigned threshold) {
+                                                     unsigned* __restrict__ bound, unsigned threshold, unsigned n_bound,
+                                                     const uint2* __restrict__ tiles) {
     const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (row >= n_pad) return;
-    const unsigned byte = (row < n && lane < 61u) ? d[(size_t)row * 64 + lane] : 0u;
+    unsigned src = row;
+    bool live = row < n;
+    if (tiles) {
+        const uint2 e = tiles[row / MM_TR];
+        const unsigned local = row % MM_TR;
+        live = local < e.y;
+        src = e.x + local;
+    }
+    const unsigned byte = (live && lane < 61u) ? d[(size_t)src * 64 + lane] : 0u;
     unsigned c = __popc(byte);
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     uint2 v;
@@ -77,18 +88,27 @@ __global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__
     *reinterpret_cast<uint2*>(out + (size_t)row * KB + 8 * lane) = v;
     if (lane == 0) {
         pop[row] = c;
-        if (bound) bound[row] = threshold;  // queries: the shared pruning bound of k_match_mfma starts at the threshold
+        // queries: the shared pruning bounds of k_match_mfma (one per train set) start at the threshold
+        if (bound)
+            for (unsigned k = 0; k < n_bound; ++k) bound[(size_t)k * n_pad + row] = threshold;
     }
 }
 
 // blockIdx.x: 512 queries; blockIdx.y: a chunk of `chunk_tiles` train tiles.  q8 / t8: unpacked sets, rows padded
 // to a multiple of MM_QB / MM_TR with zero rows (k_unpack_bits, query / train form); qpop: bit counts of the queries.  Writes (min, second, argmin) of every
 // live query over the chunk to out[chunk * n0 + query].
+// A chunk of a multi-set launch (k_match_mfma with a table): LDS tiles [t_begin, t_end) of the padded train image
+// belong to one set that starts at padded row row0 and has n_rows valid rows; records go to out[record * n0 + query]
+// with row indices relative to the set, bounds live at bound[bound_off + query].
+struct MatchChunk {
+    unsigned t_begin, t_end, row0, n_rows, bound_off, record;
+};
+
 __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict__ q8, const unsigned* __restrict__ qpop,
                                                       unsigned n0, const uint8_t* __restrict__ t8,
                                                       unsigned n1, unsigned chunk_tiles,
                                                       unsigned threshold, unsigned* __restrict__ bound,
-                                                      MatchRec* __restrict__ out) {
+                                                      MatchRec* __restrict__ out, const MatchChunk* __restrict__ table) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
@@ -117,8 +137,16 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
     unsigned limit = threshold;  // min(second, bound[q] + 1): a tile whose best distance is >= limit changes nothing that matters
     unsigned b_seen = threshold;  // bound[q] as last read (consumed four tiles after the load was issued: never waited for)
 
-    const unsigned tiles_total = (n1 + MM_TR - 1) / MM_TR;
-    const unsigned t_begin = blockIdx.y * chunk_tiles, t_end = min(tiles_total, t_begin + chunk_tiles);
+    unsigned t_begin, t_end, row0 = 0u, record = blockIdx.y;
+    if (table) {  // one train set per chunk
+        const MatchChunk ck = table[blockIdx.y];
+        t_begin = ck.t_begin; t_end = ck.t_end; row0 = ck.row0; n1 = ck.n_rows; record = ck.record;
+        bound += ck.bound_off;
+    } else {
+        const unsigned tiles_total = (n1 + MM_TR - 1) / MM_TR;
+        t_begin = blockIdx.y * chunk_tiles;
+        t_end = min(tiles_total, t_begin + chunk_tiles);
+    }
     // Staging: the next LDS tile is fetched one 32-row part at a time (one 16-byte piece per thread and part, 32
     // pieces per row): part p is requested before the MFMA chain of sub-tile p of the current tile and handed to the
     // other LDS buffer after that sub-tile's epilogue, so one register stage serves MM_SUB parts per barrier.
@@ -140,7 +168,7 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
     for (unsigned tile = t_begin; tile < t_end; ++tile) {
         const int buf = (int)((tile - t_begin) & 1u);
         const bool more = tile + 1 < t_end;
-        const bool partial = (tile + 1) * MM_TR > n1;  // uniform: only the last tile of the set
+        const bool partial = (tile + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
         if (((tile - t_begin) & 3u) == 0u) {  // use the value requested four tiles ago, request the next one
             limit = min(limit, min(second, b_seen < 0xffffffffu ? b_seen + 1u : b_seen));
             b_seen = __hip_atomic_load(bound + q_first + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -167,7 +195,7 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
             __builtin_amdgcn_sched_group_barrier(0x008, AKZ_MM_AHEAD, 0);
 #endif
             // distances of this lane's 16 train rows of the sub-tile (ascending index) to its query
-            const unsigned j0 = tile * MM_TR + 32 * sub + 4 * h;
+            const unsigned j0 = tile * MM_TR - row0 + 32 * sub + 4 * h;  // row index inside the set
             // acc[i] = 2 <a, b> - |a| (the row counts ride in the product), so hamming = |b| - acc[i]: the smallest
             // distance of the 16 rows is pq minus the largest accumulator
             int top = acc[0];
@@ -228,7 +256,7 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
         if (h == 0 && q < n0) {
             MatchRec rec;
             rec.min_d = m; rec.second_d = s2; rec.min_j = j; rec._pad = 0;
-            out[(size_t)blockIdx.y * n0 + q] = rec;
+            out[(size_t)record * n0 + q] = rec;
         }
     }
 }
@@ -263,8 +291,19 @@ uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1) {
     return best;
 }
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
-                 uint32_t* bound, uint32_t threshold) {
-    hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, query, out8, pop, bound, threshold);
+                 uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles) {
+    hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, query, out8, pop, bound, threshold,
+                       n_bound, reinterpret_cast<const uint2*>(d_tiles));
+}
+uint32_t match_mfma_tile_rows() { return MM_TR; }
+uint32_t match_mfma_query_block() { return MM_QB; }
+// One launch for a query set against SEVERAL train sets (padded image t8 as laid out by unpack_bits with a tile table):
+// chunk c of d_table describes set c (one chunk per set); record c * n0 + q = top-2 of query q over set c.
+void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
+                      const void* d_table, uint32_t n_sets, uint32_t threshold, uint32_t* bound, MatchRec* d_out) {
+    if (n0 == 0 || n_sets == 0) return;
+    hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, n_sets), dim3(MM_NT), 0, s, q8, qpop, n0, t8, 0u, 0u,
+                       threshold, bound, d_out, reinterpret_cast<const MatchChunk*>(d_table));
 }
 // top-2 records of every query over the whole train set in d_out (d_part: chunks x n0 scratch records)
 void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
@@ -274,7 +313,7 @@ void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
     const uint32_t chunk_tiles = (tiles + chunks - 1) / chunks;
     hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, n1,
-                       chunk_tiles, threshold, bound, chunks > 1 ? d_part : d_out);
+                       chunk_tiles, threshold, bound, chunks > 1 ? d_part : d_out, (const MatchChunk*)nullptr);
     if (chunks > 1) match_merge(s, d_part, n0, chunks, threshold, d_out);
 }
 

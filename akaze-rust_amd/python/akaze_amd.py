@@ -172,6 +172,7 @@ def lib():
         "akz_ctx_set_profiling": ([vp, i32], i32),
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
         "akz_ctx_set_match_mode": ([vp, i32], i32),
+        "akz_descriptor_match_sets_device": ([vp, vp, u64, vp, C.POINTER(u64), u64, u64, f64, vp, vp], i32),
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
         "akz_ctx_set_detector_overlap": ([vp, i32], i32),
@@ -396,6 +397,24 @@ class Context:
                                           n1, nb, distance_threshold, lowes_ratio, out.ctypes.data_as(C.c_void_p),
                                           C.byref(n)))
         return out[:n.value].copy()
+
+    def descriptor_match_sets_device(self, q, train, rows, distance_threshold=10000, lowes_ratio=0.86):
+        """One query set against several train sets in one launch: q [n0, 64] uint8 CUDA tensor, train the sets'
+        64-byte rows one after the other ([sum(rows), 64]), rows the row count of every set.  Returns (matches
+        [n_sets, n0, 24] uint8 — akz_match records, set k's first counts[k] are valid, index_1 relative to the
+        set — and counts [n_sets] int64), the same as one descriptor_match_device call per set."""
+        import torch
+        n0, ns = int(q.shape[0]), len(rows)
+        out = torch.empty((ns, max(n0, 1), 24), dtype=torch.uint8, device=q.device)
+        if n0 == 0:
+            out = out[:, :0]
+        cnt = torch.zeros(max(ns, 1), dtype=torch.int64, device=q.device)
+        arr = (C.c_uint64 * max(ns, 1))(*[int(r) for r in rows])
+        _check(lib().akz_descriptor_match_sets_device(self._h, C.c_void_p(q.data_ptr()) if n0 else None, n0,
+                                                      C.c_void_p(train.data_ptr()) if sum(rows) else None, arr, ns,
+                                                      distance_threshold, lowes_ratio, C.c_void_p(out.data_ptr()),
+                                                      C.c_void_p(cnt.data_ptr())))
+        return out, cnt[:ns]
 
     def descriptor_match_device(self, d0, d1, distance_threshold=10000, lowes_ratio=0.86):
         """Same on torch CUDA uint8 tensors of 64-byte descriptor rows; returns (matches tensor view, count)."""
@@ -869,18 +888,31 @@ def gather_descriptor_sets(local_sets, group=None):
     return sets, owners
 
 
-def all_pairs_match(local_sets, match_fn, group=None):
+def all_pairs_match(local_sets, match_fn, group=None, match_sets_fn=None):
     """Cross-GPU all-pairs Hamming match: after gather_descriptor_sets every rank matches the images it OWNS (as
     queries) against every other image of the job, i.e. 1/world of the ordered pairs each; nothing else is
-    exchanged.  match_fn(rows_i, rows_j) is Context.descriptor_match_device on the GPUs.
+    exchanged.  match_fn(rows_i, rows_j) is Context.descriptor_match_device on the GPUs.  With
+    match_sets_fn(rows_i, all_rows, rows_per_set) -> [matches of set 0, ...] (Context.descriptor_match_sets_device:
+    one launch per query image against the concatenated sets of all images) match_fn is not called.
 
     Returns {(i, j): matches} for this rank's share, i and j being global (rank-major) image indices."""
+    import torch
     import torch.distributed as dist
     sets, owners = gather_descriptor_sets(local_sets, group)
     rank = dist.get_rank(group)
     out = {}
+    cat = rows = None
+    if match_sets_fn is not None:
+        cat = torch.cat(sets, dim=0) if sets else None
+        rows = [int(t.shape[0]) for t in sets]
     for i, owner in enumerate(owners):
         if owner != rank:
+            continue
+        if match_sets_fn is not None:
+            per_set = match_sets_fn(sets[i], cat, rows)
+            for j in range(len(sets)):
+                if i != j:
+                    out[(i, j)] = per_set[j]
             continue
         for j in range(len(sets)):
             if i != j:

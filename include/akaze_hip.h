@@ -252,6 +252,14 @@ int akz_descriptor_match(akz_ctx* ctx, const uint8_t* d0, uint64_t n0, const uin
 int akz_descriptor_match_device(akz_ctx* ctx, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
                                 uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
                                 uint64_t* d_n_out);
+/* One query set against n_sets train sets in one launch (all-pairs matching, BASELINE configs[4]): d_train
+   holds the sets' 64-byte rows one after the other, set_rows[k] (host) the number of rows of set k.
+   Results of set k: matches at d_out + k * n0 (room for n0 each), count at d_n_out[k] (device uint64),
+   index_1 relative to the set — exactly what n_sets calls of akz_descriptor_match_device return, at the
+   rate of one large product. */
+int akz_descriptor_match_sets_device(akz_ctx* ctx, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
+                                     const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
+                                     double lowes_ratio, akz_match* d_out, uint64_t* d_n_out);
 
 /* ---- the rest of match_features (host post-filter) -------------------- */
 /* ops::estimate_fundamental_matrix::remove_outliers — estimate_fundamental_matrix.rs:99-165: 8-point

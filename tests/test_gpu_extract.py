@@ -249,17 +249,25 @@ def test_all_pairs_match_over_rccl_world1(ctx, amd, ref):
         ctx.synchronize()
         return out.cpu().numpy()[:int(cnt.item())].view(amd.MATCH_DTYPE).reshape(-1)
 
+    def match_sets(q, cat, rows):  # one launch per query image against all images' sets
+        out, cnt = ctx.descriptor_match_sets_device(q, cat, rows, 10000, 0.86)
+        ctx.synchronize()
+        out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+        return [out[k][:int(cnt[k])].copy().view(amd.MATCH_DTYPE).reshape(-1) for k in range(len(rows))]
+
     try:
         pairs = amd.all_pairs_match(local, match)
+        pairs_multi = amd.all_pairs_match(local, None, match_sets_fn=match_sets)
         torch.cuda.synchronize()
     finally:
         if created:
             dist.destroy_process_group()
-    assert set(pairs) == {(i, j) for i in range(3) for j in range(3) if i != j}
+    assert set(pairs) == {(i, j) for i in range(3) for j in range(3) if i != j} == set(pairs_multi)
     total = 0
     for (i, j), got in pairs.items():
         exp = ref.descriptor_match(refs[i].descriptors(), refs[j].descriptors(), 10000, 0.86)
         assert np.array_equal(got, exp), (i, j)
+        assert np.array_equal(pairs_multi[(i, j)], exp), (i, j)
         total += len(exp)
     assert total > 20
 

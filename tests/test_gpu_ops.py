@@ -214,6 +214,53 @@ def test_descriptor_match_ragged_sizes(ctx, ref, n0, n1):
             assert np.array_equal(got, exp), (mode, ratio, thr, len(got), len(exp))
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+def test_descriptor_match_sets(ctx, ref, mode):
+    """One query set against several train sets in one launch (sizes around the tile sizes, an empty set, duplicates
+    across sets): every set's match list equals the oracle's descriptor_match of that pair."""
+    import torch
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, (40, 61), dtype=np.uint8)
+
+    def make(n):
+        d = base[rng.integers(0, 40, n)].copy()
+        d[rng.random(d.shape) < 0.03] ^= 0x24
+        return d
+
+    q = make(700)
+    sets = [make(n) for n in (129, 0, 1, 128, 1000, 37, 2051)]
+
+    def rows64(d):
+        r = np.zeros((len(d), 64), np.uint8)
+        r[:, :61] = d
+        return r
+
+    dq = torch.from_numpy(rows64(q)).cuda()
+    cat = torch.from_numpy(np.concatenate([rows64(t) for t in sets])).cuda()
+    ctx.set_match_mode(mode)
+    try:
+        for ratio, thr in ((0.86, 10000), (1.2, 10000), (0.95, 9)):
+            out, cnt = ctx.descriptor_match_sets_device(dq, cat, [len(t) for t in sets], thr, ratio)
+            ctx.synchronize()
+            out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+            total = 0
+            for k, t in enumerate(sets):
+                got = out[k][:int(cnt[k])].copy().view(ctx_match_dtype()).reshape(-1)
+                exp = ref.descriptor_match(q, t, thr, ratio)
+                assert np.array_equal(got, exp), (mode, ratio, thr, k, len(got), len(exp))
+                total += len(exp)
+            assert total > 100
+        out, cnt = ctx.descriptor_match_sets_device(dq[:0], cat, [len(t) for t in sets])
+        assert int(cnt.sum().item()) == 0
+    finally:
+        ctx.set_match_mode(2)
+
+
+def ctx_match_dtype():
+    import akaze_amd
+    return akaze_amd.MATCH_DTYPE
+
+
 def test_descriptor_match_full_width_rows(ctx, ref):
     """Descriptors of 62..64 bytes use the bytes the matrix-core kernel keeps its row counts in: the host entry point
     routes them to the popcount kernel."""

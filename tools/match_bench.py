@@ -31,3 +31,19 @@ for mode, name in ((0, "popcount"), (1, "mfma")):
     timeit(d0[:2000], d1[:2000])
     timeit(d0, d1)
     timeit(big0, big1, reps=5)
+# one query image against 16 train images: one launch per pair vs one multi-set launch
+ctx.set_match_mode(1)
+sets = [d1] * 16
+cat, rows = torch.cat(sets), [int(s_.shape[0]) for s_ in sets]
+def time_fn(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+t_pairs = time_fn(lambda: [ctx.descriptor_match_device(d0, s_) for s_ in sets])
+t_multi = time_fn(lambda: ctx.descriptor_match_sets_device(d0, cat, rows))
+pairs = d0.shape[0] * sum(rows)
+print(f"all-pairs step, 1 x {d0.shape[0]} queries against 16 x {rows[0]} rows: 16 pair launches {t_pairs*1e3:.0f} us "
+      f"({pairs/t_pairs/1e9:.2f} T pairs/s), one multi-set launch {t_multi*1e3:.0f} us ({pairs/t_multi/1e9:.2f} T pairs/s)")

@@ -105,6 +105,12 @@ def _pairs_worker(rank, world, port, sizes, out_dir):
         assert len(sets) == len(everything) and all(torch.equal(a, b) for a, b in zip(sets, everything))
         assert owners == [r for r in range(world) for _ in sizes[r]]
         res = A.all_pairs_match(local, _np_match)
+
+        def np_match_sets(q, cat, rows):  # the multi-set form: one call per query image against all sets
+            offs = np.concatenate([[0], np.cumsum(rows)])
+            return [_np_match(q, cat[offs[k]:offs[k + 1]]) for k in range(len(rows))]
+
+        assert A.all_pairs_match(local, None, match_sets_fn=np_match_sets) == res
         with open(os.path.join(out_dir, f"pairs_{rank}.pkl"), "wb") as f:
             pickle.dump(res, f)
     finally:

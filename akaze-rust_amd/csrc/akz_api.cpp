@@ -986,7 +986,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // coarse levels' launches are latency-bound and leave most of the chip idle, the other stream fills it
     // (+4 % at 32 x 1080p, +11 % at 8 x 4K, -10 % for a single frame; off by default because kernels that share
     // the chip can no longer be timed individually, which is what bench.py's roofline does).
-    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint, 1u << 14),
+    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint, 16u),
                                                       0x7fffffffull / sizeof(Candidate));
     AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
     AKZ_TRY(ensure(c, c->count_slot[slot], 256));
@@ -1952,6 +1952,11 @@ int akz_ctx_set_prep_mode(akz_ctx* c, int mode) {
     return AKZ_OK;
 }
 
+int akz_ctx_set_candidate_hint(akz_ctx* c, uint32_t per_image) {
+    AKZ_TRY(bind(c));
+    c->cand_cap_hint = std::max<uint32_t>(per_image, 16u);
+    return AKZ_OK;
+}
 int akz_ctx_set_match_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
     if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;

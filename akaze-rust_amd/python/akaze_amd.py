@@ -172,6 +172,7 @@ def lib():
         "akz_ctx_set_profiling": ([vp, i32], i32),
         "akz_ctx_set_fed_mode": ([vp, i32], i32),
         "akz_ctx_set_match_mode": ([vp, i32], i32),
+        "akz_ctx_set_candidate_hint": ([vp, u32], i32),
         "akz_descriptor_match_sets_device": ([vp, vp, u64, vp, C.POINTER(u64), u64, u64, f64, vp, vp], i32),
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
@@ -293,6 +294,11 @@ class Context:
     def set_fed_mode(self, mode):
         """2 = register-ownership fused kernel (default), 1 = LDS-only fused kernel, 0 = one launch per step."""
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
+
+    def set_candidate_hint(self, per_image):
+        """Room for extrema candidates per image in the next extraction (a list that overflows is enlarged and the
+        extrema pass repeated by finish: same results)."""
+        _check(lib().akz_ctx_set_candidate_hint(self._h, int(per_image)))
 
     def set_match_mode(self, mode):
         """2 = automatic (default), 1 = matrix-core matcher, 0 = popcount matcher."""

@@ -333,6 +333,11 @@ int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
    per launch; 1 = k_fed_fused, same tiling with all values through LDS; 0 = k_fed_step, one launch
    per step.  Results are bit-identical. */
 int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
+/* Extrema candidates per image that the next extraction reserves room for (default 32768; it grows to 1.25x
+   the largest count seen).  A list that overflows is detected by akz_extract_finish, which enlarges it and
+   repeats the extrema pass on the stored Ldet planes — results are the same, the call is slower; the setter
+   exists so that this path can be tested and so that callers with very dense frames can skip the retry. */
+int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
 /* Matcher kernel: 2 (default) and 1 = matrix-core kernel (k_match_mfma: descriptor bits unpacked to int8,
    Hamming distances from one integer GEMM; faster than the popcount scan from 128 x 128 descriptors up),
    0 = popcount kernel (k_match).  Results are identical. */

@@ -224,6 +224,28 @@ def test_baseline_c5_4k_5x5_stream_all_pairs_match(ctx, amd, ref):
     assert n_matches > 1000
 
 
+def test_candidate_list_overflow_is_retried(amd, ref):
+    """A candidate list that is too small (16 entries per image here) overflows in the fused detector kernels; finish
+    notices, enlarges the list and repeats the extrema pass on the stored Ldet planes: same keypoints and descriptors,
+    for a single frame and for a batch, and the next extraction (hint grown) needs no retry."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        frames = np.stack([amd.synth_frame(640, 360, 70 + i) for i in range(3)])
+        refs = [ref.extract(f) for f in frames]
+        assert all(r.num_keypoints > 20 for r in refs)  # more keypoints (hence candidates) than the 16 list entries
+        c.set_candidate_hint(16)
+        assert_same_result(c.extract_features(frames[0]), refs[0], planes=False)
+        c.set_candidate_hint(16)
+        res = c.extract_features(torch.from_numpy(frames).cuda(), keep_all_planes=False)
+        for i in range(3):
+            assert_same_result(res, refs[i], planes=False, img=i)
+        res = c.extract_features(torch.from_numpy(frames).cuda())
+        assert_same_result(res, refs[1], planes=True, img=1)
+    finally:
+        c.close()
+
+
 def test_all_pairs_match_over_rccl_world1(ctx, amd, ref):
     """The cross-GPU all-pairs path of BASELINE configs[4] with the real backend (RCCL, one rank on this box):
     device-resident 64-byte descriptor rows are gathered with all_gather and matched on the GPU; every pair equals

@@ -46,3 +46,24 @@ def test_parsers_survive_corrupted_files_under_sanitizers(amd, tmp_path):
     assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
     assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
     assert "decoded" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_keypoint_selection_matches_linear_scans_under_sanitizers(tmp_path):
+    """The host keypoint selection (counting sort, uniform grids with 2 x 2-cell queries, merged second pass) on random
+    candidate sets with dense clusters and exact ties, under AddressSanitizer + UBSan, against a direct restatement of
+    the reference's linear scans (tools/fuzz/fuzz_keypoints.cpp)."""
+    exe = str(tmp_path / "fuzz_keypoints")
+    csrc = os.path.join(ROOT, "akaze-rust_amd", "csrc")
+    build = subprocess.run(
+        ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+         "-I/opt/rocm/include", "-I" + csrc, os.path.join(ROOT, "tools", "fuzz", "fuzz_keypoints.cpp"),
+         os.path.join(csrc, "akz_keypoints.cpp"), os.path.join(csrc, "akz_plan.cpp"), "-o", exe], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    run = subprocess.run([exe, "400"], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
+    assert "identical to the linear scans" in run.stdout

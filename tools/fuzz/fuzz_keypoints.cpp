@@ -1,0 +1,154 @@
+// Sanitizer + cross-check driver for the host keypoint selection (akz_keypoints.cpp): random candidate sets with dense
+// clusters, exact ties and repeated positions are put into scan order by sort_candidates and run through
+// select_keypoints (uniform grids, counting sort), and the result is compared with a direct restatement of the
+// reference's linear scans (scale_space_extrema.rs:43-129, :141-178).  CPU build only; built and run by
+// tests/test_fuzz_host.py with -fsanitize=address,undefined.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/akaze_hip.h"
+
+#include "../../akaze-rust_amd/csrc/akz_internal.hpp"
+
+using namespace akz;
+
+// the reference's two passes and the sub-pixel step with plain linear scans over the cache
+static void naive(const std::vector<Candidate>& cands, const std::vector<LevelPlan>& plan, const akz_config& cfg,
+                  std::vector<HostKeypoint>& out, uint64_t* n_extrema) {
+    std::vector<HostKeypoint> cache;
+    for (const Candidate& c : cands) {
+        const LevelPlan& lv = plan[c.level];
+        HostKeypoint kp{};
+        kp.lx = c.idx % lv.w;
+        kp.ly = c.idx / lv.w;
+        kp.response = std::fabs(c.v);
+        kp.size = (float)(lv.esigma * cfg.derivative_factor);
+        kp.octave = lv.octave;
+        kp.class_id = c.level;
+        kp.x = (float)kp.lx;
+        kp.y = (float)kp.ly;
+        kp.xp = c.xp; kp.xm = c.xm; kp.yp = c.yp; kp.ym = c.ym;
+        const float ratio = powf(2.0f, (float)lv.octave);
+        bool is_extremum = true, is_repeated = false;
+        size_t id_repeated = 0;
+        for (size_t ik = 0; ik < cache.size(); ++ik) {
+            const HostKeypoint& p = cache[ik];
+            if (kp.class_id == p.class_id || (kp.class_id > 0 && kp.class_id - 1 == p.class_id)) {
+                const float dist = (kp.x * ratio - p.x) * (kp.x * ratio - p.x) + (kp.y * ratio - p.y) * (kp.y * ratio - p.y);
+                if (dist <= kp.size * kp.size) {
+                    if (kp.response > p.response) { id_repeated = ik; is_repeated = true; }
+                    else is_extremum = false;
+                    break;
+                }
+            }
+        }
+        if (!is_extremum) continue;
+        kp.x = kp.x * ratio + 0.5f * (ratio - 1.0f);
+        kp.y = kp.y * ratio + 0.5f * (ratio - 1.0f);
+        if (!is_repeated) cache.push_back(kp);
+        else cache[id_repeated] = kp;
+    }
+    std::vector<HostKeypoint> extrema;
+    for (size_t i = 0; i < cache.size(); ++i) {
+        bool repeated = false;
+        const HostKeypoint& a = cache[i];
+        for (size_t j = i; j < cache.size(); ++j) {
+            const HostKeypoint& b = cache[j];
+            if (a.class_id + 1 == b.class_id) {
+                const float dist = (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y);
+                if (dist <= a.size * a.size) { repeated = true; break; }
+            }
+        }
+        if (!repeated) extrema.push_back(a);
+    }
+    *n_extrema = extrema.size();
+    out.clear();
+    for (const HostKeypoint& k : extrema) {
+        const float ratio = powf(2.0f, (float)k.octave);
+        const float b0 = -(0.5f * (k.xp - k.xm)), b1 = -(0.5f * (k.yp - k.ym));
+        if (std::fabs(b0) <= 1.0f && std::fabs(b1) <= 1.0f) {
+            HostKeypoint r = k;
+            r.x = ((float)k.lx + b0) * ratio + 0.5f * (ratio - 1.0f);
+            r.y = ((float)k.ly + b1) * ratio + 0.5f * (ratio - 1.0f);
+            out.push_back(r);
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 40;
+    std::mt19937 rng(20261003);
+    auto uni = [&](int lo, int hi) { return (int)(rng() % (unsigned)(hi - lo + 1)) + lo; };
+    long total_c = 0, total_k = 0;
+    for (int it = 0; it < rounds; ++it) {
+        akz_config cfg{};  // Config::default() (types/evolution.rs:40-55)
+        cfg.num_sublevels = 4; cfg.max_octave_evolution = 4; cfg.base_scale_offset = 1.6; cfg.initial_contrast = 0.001;
+        cfg.contrast_percentile = 0.7; cfg.contrast_factor_num_bins = 300; cfg.derivative_factor = 1.5;
+        cfg.detector_threshold = 0.001; cfg.descriptor_channels = 3; cfg.descriptor_pattern_size = 10;
+        if (it % 5 == 4) { cfg.num_sublevels = 5; cfg.max_octave_evolution = 5; }
+        const uint32_t w = (uint32_t)uni(64, 700), h = (uint32_t)uni(64, 500);
+        std::vector<LevelPlan> plan;
+        if (build_plan(w, h, cfg, plan) != AKZ_OK) continue;
+        // candidates: a few cluster centres in full-resolution coordinates, every level draws points around them
+        const int n_centres = uni(1, 12), per_level = uni(0, 400);
+        std::vector<std::pair<float, float>> centres;
+        for (int c = 0; c < n_centres; ++c) centres.emplace_back((float)uni(0, (int)w - 1), (float)uni(0, (int)h - 1));
+        std::vector<Candidate> cands;
+        for (size_t l = 0; l < plan.size(); ++l) {
+            const LevelPlan& lv = plan[l];
+            const float ratio = (float)(1u << lv.octave);
+            for (int k = 0; k < per_level; ++k) {
+                const auto& ce = centres[(size_t)uni(0, n_centres - 1)];
+                const int spread = uni(0, 3) == 0 ? 40 : 4;
+                const int x = std::min<int>((int)lv.w - 1, std::max(0, (int)(ce.first / ratio) + uni(-spread, spread)));
+                const int y = std::min<int>((int)lv.h - 1, std::max(0, (int)(ce.second / ratio) + uni(-spread, spread)));
+                Candidate c{};
+                c.level = (uint32_t)l;
+                c.idx = (uint32_t)(y * (int)lv.w + x);
+                c.v = (float)uni(1, 6) * 0.25f;  // few distinct responses: many exact ties
+                c.xp = (float)uni(-3, 3) * 0.5f; c.xm = (float)uni(-3, 3) * 0.5f;
+                c.yp = (float)uni(-3, 3) * 0.5f; c.ym = (float)uni(-3, 3) * 0.5f;
+                cands.push_back(c);
+            }
+        }
+        // one candidate per (level, pixel), as the extrema kernels emit them
+        std::sort(cands.begin(), cands.end(), [](const Candidate& a, const Candidate& b) {
+            return a.level != b.level ? a.level < b.level : a.idx < b.idx;
+        });
+        cands.erase(std::unique(cands.begin(), cands.end(), [](const Candidate& a, const Candidate& b) {
+            return a.level == b.level && a.idx == b.idx;
+        }), cands.end());
+        std::vector<Candidate> shuffled = cands;
+        std::shuffle(shuffled.begin(), shuffled.end(), rng);
+        sort_candidates(shuffled, plan);
+        for (size_t i = 0; i < cands.size(); ++i)
+            if (shuffled[i].level != cands[i].level || shuffled[i].idx != cands[i].idx || shuffled[i].v != cands[i].v) {
+                fprintf(stderr, "sort_candidates differs at %zu (round %d)\n", i, it);
+                return 1;
+            }
+        std::vector<HostKeypoint> got, exp;
+        uint64_t ne_got = 0, ne_exp = 0;
+        select_keypoints(shuffled, plan, cfg, got, &ne_got);
+        naive(cands, plan, cfg, exp, &ne_exp);
+        if (ne_got != ne_exp || got.size() != exp.size()) {
+            fprintf(stderr, "round %d: %zu/%llu keypoints/extrema, expected %zu/%llu\n", it, got.size(),
+                    (unsigned long long)ne_got, exp.size(), (unsigned long long)ne_exp);
+            return 1;
+        }
+        for (size_t i = 0; i < got.size(); ++i)
+            if (got[i].x != exp[i].x || got[i].y != exp[i].y || got[i].response != exp[i].response ||
+                got[i].class_id != exp[i].class_id || got[i].size != exp[i].size || got[i].octave != exp[i].octave) {
+                fprintf(stderr, "round %d: keypoint %zu differs\n", it, i);
+                return 1;
+            }
+        total_c += (long)cands.size();
+        total_k += (long)got.size();
+    }
+    printf("selected %ld keypoints from %ld candidates, identical to the linear scans\n", total_k, total_c);
+    return 0;
+}

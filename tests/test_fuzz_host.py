@@ -67,3 +67,18 @@ def test_keypoint_selection_matches_linear_scans_under_sanitizers(tmp_path):
     assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
     assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
     assert "identical to the linear scans" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_worker_pool_under_thread_sanitizer(tmp_path):
+    """The per-context host worker pool (akz_pool.hpp) under ThreadSanitizer: thousands of short runs of varying size
+    (every index exactly once), short-lived pools, two pools driven by two threads (tools/fuzz/pool_tsan.cpp)."""
+    exe = str(tmp_path / "pool_tsan")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread",
+                            os.path.join(ROOT, "tools", "fuzz", "pool_tsan.cpp"), "-o", exe], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "ThreadSanitizer" not in run.stderr and "pool ok" in run.stdout, run.stderr[-3000:]

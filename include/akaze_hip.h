@@ -342,8 +342,8 @@ int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
    Hamming distances from one integer GEMM; faster than the popcount scan from 128 x 128 descriptors up),
    0 = popcount kernel (k_match).  Results are identical. */
 int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
-/* Detector kernel variant: 2 (default) = automatic (streaming register-ring kernels for batches whose
-   second-derivative planes are not kept, LDS-tiled kernels otherwise); 1 = streaming pair (first /
+/* Detector kernel variant: 2 (default) = automatic (the LDS-tiled pair, the one-kernel tiled form for
+   launches under 8 Mpx); 1 = streaming pair (first /
    second derivatives) wherever it is supported (sigma_size <= 4); 3 = the single fused streaming kernel
    (least HBM traffic, but one wave per SIMD: slower than the pair on MI355X today); 4 = the single
    LDS-tiled kernel (first and second derivatives in one pass; the automatic choice for small launches);

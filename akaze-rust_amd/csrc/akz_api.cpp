@@ -574,19 +574,21 @@ static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_
     if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;
     if (c->det_mode == 0 || !launch::detector_stream_supported(sigma, w, h, border_m, nms)) return 0;
     if (c->det_mode == 1 || c->det_mode == 3) return c->det_mode;
-    static uint64_t pair_keep = ~0ull, pair_lean = ~0ull, fused_min = 2u << 20;
+    static uint64_t pair_keep = ~0ull, pair_lean = ~0ull, fused_min = 2u << 20, tiled1_max = 8u << 20;
     static bool init = false;
     if (!init) {
         init = true;
         if (const char* e = getenv("AKZ_DET_RULE")) {
-            unsigned long long a = 0, b = 0, f = 0;
-            if (sscanf(e, "%llu,%llu,%llu", &a, &b, &f) == 3) { pair_keep = a; pair_lean = b; fused_min = f; }
+            unsigned long long a = 0, b = 0, f = 0, t1 = 0;
+            const int got = sscanf(e, "%llu,%llu,%llu,%llu", &a, &b, &f, &t1);
+            if (got >= 3) { pair_keep = a; pair_lean = b; fused_min = f; }
+            if (got == 4) tiled1_max = t1;
         }
     }
     const uint64_t px = (uint64_t)w * h * n;
     if (px >= (keep_second ? pair_keep : pair_lean)) return 1;
     // small launches: the one-kernel tiled form, which extract_begin also batches across levels of equal sigma_size
-    if (px < (8u << 20) && launch::detector_tiled_fused_supported(sigma)) return fused_min == 0 ? 3 : 4;
+    if (px < tiled1_max && launch::detector_tiled_fused_supported(sigma)) return fused_min == 0 ? 3 : 4;
     return 0;
 }
 

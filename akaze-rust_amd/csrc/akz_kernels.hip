@@ -818,7 +818,9 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
     const bool live = kpi < nkp;
     KpParam kp = kps[live ? kpi : 0];
     const float2 cs = cosi[live ? kpi : 0];
-    const LevelPtrs lv = tab.lv[kp.level];
+    // one keypoint per wave: its level is wave-uniform, so the level's pointers come from the kernel arguments by
+    // scalar loads (a per-lane index would send the whole table through scratch memory)
+    const LevelPtrs lv = tab.lv[__builtin_amdgcn_readfirstlane(kp.level)];
     const size_t ioff = (size_t)kp.img * lv.stride;
     const float* Lt = lv.lt + ioff;
     const float* Lx = lv.lx + ioff;

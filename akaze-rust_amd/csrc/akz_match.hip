@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 #include "akz_internal.hpp"
 
@@ -271,6 +272,10 @@ uint32_t match_mfma_rows(uint32_t n, bool queries) {
     return (std::max<uint32_t>(n, 1) + m - 1) / m * m;
 }
 uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1) {
+    if (const char* e = std::getenv("AKZ_MM_CHUNKS")) {  // tuning override
+        const uint32_t tiles_e = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
+        return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::atoi(e), tiles_e));
+    }
     const uint32_t qblocks = (std::max<uint32_t>(n0, 1) + MM_QB - 1) / MM_QB;
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
     // One workgroup per CU is resident (16 waves); a launch runs in rounds of 256 workgroups, each of which first

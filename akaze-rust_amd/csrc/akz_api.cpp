@@ -565,10 +565,10 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
 // (the fused kernel runs one wave per SIMD and only wins where the launch is latency-bound but still fills the
 // chip; the smallest launches are cheapest on the tiled kernels).  Inside the pipelined extraction the streaming
 // pair loses its stand-alone edge at full resolution when all planes are kept (detector stage 4.2 vs 3.9 ms per
-// batch).  Since the tiled kernels reserve their candidate slots once per tile (tile_extrema) they are ahead with
-// real frames in both cases — the streaming kernels still append one candidate per atomic — (3.34 vs 4.26 ms kept,
-// 3.11 vs 3.00 ms not kept but 9.48 vs 9.34 Gpix/s end to end), so the streaming pair is no longer chosen
-// automatically; det_mode 1 / 3 select it.  AKZ_DET_RULE=a,b,c overrides the three pixel-count thresholds.
+// batch).  With candidate slots reserved in blocks in both families (once per tile, tile_extrema; per wave buffer of
+// 32, wave_cands_push) the tiled kernels are ahead with all planes kept (detector stage 3.34 vs 3.82 ms) and level
+// without them (3.01 vs 2.80 ms stage time, 9.94 vs 9.93 Gpix/s end to end), so the streaming pair is not chosen
+// automatically; det_mode 1 / 3 select it.  AKZ_DET_RULE=a,b,c[,d] overrides the pixel-count thresholds.
 static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
                            bool keep_second, bool nms = true) {
     if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;

@@ -237,12 +237,59 @@ struct StreamNms {
     unsigned* count;
 };
 
+// Extrema of a wave are collected in a small LDS buffer of that wave and appended to the global list in blocks: one
+// device-scope atomic per CAND_BUF candidates instead of one each (a 32-frame batch emits 1.6 x 10^5 candidates, and
+// that many atomics on one address cost 0.6 ms).  All helpers are called by the whole wave (wave-uniform control flow).
+constexpr int CAND_BUF = 32;
+__device__ __forceinline__ void wave_cands_flush(Candidate* buf, unsigned& n, const StreamNms& nms, int lane) {
+    if (n == 0) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(nms.count, n);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    const uint4* src = reinterpret_cast<const uint4*>(buf);
+    uint4* dst = reinterpret_cast<uint4*>(nms.cand);
+    for (unsigned e = (unsigned)lane; e < 2u * n; e += WAVE)  // 16-byte halves of the 32-byte records
+        if (base + (e >> 1) < nms.cap) dst[2 * (size_t)base + e] = src[e];
+    __builtin_amdgcn_wave_barrier();
+    n = 0;
+}
+// every lane offers the pixels of its quad whose bit is set in m (at most two); `make(i)` builds the record of pixel i
+template <typename F>
+__device__ __forceinline__ void wave_cands_push(Candidate* buf, unsigned& n, unsigned m, const StreamNms& nms, int lane,
+                                                F&& make) {
+    while (__ballot(m != 0u)) {  // rare
+        const bool have = m != 0u;
+        const int i = have ? __ffs(m) - 1 : 0;
+        m &= m - 1u;
+        const unsigned long long b = __ballot(have);
+        const unsigned nb = (unsigned)__popcll(b);  // <= 64 > CAND_BUF is possible: flush first, then at most 32 per round
+        if (n + nb > (unsigned)CAND_BUF) wave_cands_flush(buf, n, nms, lane);
+        const unsigned before = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+        if (nb <= (unsigned)CAND_BUF) {
+            if (have) buf[n + before] = make(i);
+            n += nb;
+        } else {  // more hits in one row of the wave than the buffer holds: two halves
+            const bool lo = before < (unsigned)CAND_BUF;
+            if (have && lo) buf[before] = make(i);
+            n = min(nb, (unsigned)CAND_BUF);
+            __builtin_amdgcn_wave_barrier();
+            wave_cands_flush(buf, n, nms, lane);
+            if (have && !lo) buf[before - CAND_BUF] = make(i);
+            n = nb - (unsigned)CAND_BUF;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int S, bool NMS, bool KEEP>
 __global__ void __launch_bounds__(SNT, (S == 1 ? 3 : 2))
 k_deriv2_stream(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float* __restrict__ lxx_out,
                 float* __restrict__ lyy_out, float* __restrict__ lxy_out, float* __restrict__ ldet_out, int w, int h,
                 StreamGrid g, float kn, float kwn, float quat, StreamNms nms) {
     constexpr int P = 2 * S + 1, HL = NMS ? 1 : 0, NOUT = KEEP ? 4 : 1;
+    __shared__ Candidate s_cands[NMS ? SNT / WAVE : 1][NMS ? CAND_BUF : 1];  // per-wave extrema buffer
+    Candidate* const cbuf = s_cands[NMS ? (threadIdx.x >> 6) : 0];
+    unsigned cnum = 0;
     const int lane = threadIdx.x & (WAVE - 1);
     const long wave = wave_index();
     if (wave >= g.waves) return;
@@ -328,9 +375,7 @@ k_deriv2_stream(const float* __restrict__ lx_in, const float* __restrict__ ly_in
                                     m |= hit ? 1u << i : 0u;
                                 }
                                 m &= xok;
-                                while (m) {  // rare; at most two pixels of a quad can be strict maxima
-                                    const int i = __ffs(m) - 1;
-                                    m &= m - 1;
+                                wave_cands_push(cbuf, cnum, m, nms, lane, [&](int i) {  // at most two pixels of a quad can be strict maxima
                                     Candidate cd;
                                     cd.level = nms.level;
                                     cd.idx = (unsigned)(y * w + L.x + i);
@@ -340,9 +385,8 @@ k_deriv2_stream(const float* __restrict__ lx_in, const float* __restrict__ ly_in
                                     cd.yp = i == 0 ? det[0] : i == 1 ? det[1] : i == 2 ? det[2] : det[3];
                                     cd.ym = i == 0 ? dm2[0] : i == 1 ? dm2[1] : i == 2 ? dm2[2] : dm2[3];
                                     cd.img = (unsigned)pc.img;
-                                    const unsigned slot = atomicAdd(nms.count, 1u);
-                                    if (slot < nms.cap) nms.cand[slot] = cd;
-                                }
+                                    return cd;
+                                });
                             }
                             dm2 = dm1;
                             dm1 = det;
@@ -358,6 +402,7 @@ k_deriv2_stream(const float* __restrict__ lx_in, const float* __restrict__ ly_in
             }
         }
     }
+    if (NMS) wave_cands_flush(cbuf, cnum, nms, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -724,8 +769,11 @@ k_detector_stream(const float* __restrict__ ls, float* __restrict__ lx_out, floa
                   StreamNms nms) {
     constexpr int P = 2 * S + 1, NOUT = KEEP ? 4 : 1;
     __shared__ f4 s_ring[SNT / WAVE][2][P][WAVE];  // stage-1 H results of the last P rows, per wave
+    __shared__ Candidate s_cands[NMS ? SNT / WAVE : 1][NMS ? CAND_BUF : 1];  // per-wave extrema buffer
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Candidate* const cbuf = s_cands[NMS ? wv : 0];
+    unsigned cnum = 0;
     const long wave = (long)blockIdx.x * (SNT / WAVE) + wv;
     if (wave >= g.waves) return;
     // (image, band, strip), strips fastest; bands split the interior rows evenly
@@ -852,9 +900,7 @@ k_detector_stream(const float* __restrict__ ls, float* __restrict__ lx_out, floa
                                     m |= hit ? 1u << i : 0u;
                                 }
                                 m &= xok;
-                                while (m) {  // rare; at most two pixels of a quad can be strict maxima
-                                    const int i = __ffs(m) - 1;
-                                    m &= m - 1;
+                                wave_cands_push(cbuf, cnum, m, nms, lane, [&](int i) {  // at most two pixels of a quad can be strict maxima
                                     Candidate cd;
                                     cd.level = nms.level;
                                     cd.idx = (unsigned)(y * w + L.x + i);
@@ -864,9 +910,8 @@ k_detector_stream(const float* __restrict__ ls, float* __restrict__ lx_out, floa
                                     cd.yp = i == 0 ? det[0] : i == 1 ? det[1] : i == 2 ? det[2] : det[3];
                                     cd.ym = i == 0 ? dm2[0] : i == 1 ? dm2[1] : i == 2 ? dm2[2] : dm2[3];
                                     cd.img = (unsigned)img;
-                                    const unsigned slot = atomicAdd(nms.count, 1u);
-                                    if (slot < nms.cap) nms.cand[slot] = cd;
-                                }
+                                    return cd;
+                                });
                             }
                             dm2 = dm1;
                             dm1 = det;
@@ -895,6 +940,7 @@ k_detector_stream(const float* __restrict__ ls, float* __restrict__ lx_out, floa
             }
         }
     }
+    if (NMS) wave_cands_flush(cbuf, cnum, nms, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

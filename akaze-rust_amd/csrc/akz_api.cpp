@@ -57,6 +57,7 @@ struct akz_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf scratch[6];                       // f32 plane temporaries (largest level x batch)
+    DevBuf lazy[6];                          // one-image planes of akz_fetch_plane's recomputation (never shared with scratch users)
     DevBuf small;                            // hmax bits / histogram / counters
     DevBuf cand;                             // NMS candidates
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
@@ -263,7 +264,8 @@ int akz_ctx_destroy(akz_ctx* c) {
     if (!c) return AKZ_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
+    DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
+                      &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
                       &c->small, &c->cand, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab};
     for (DevBuf* b : bufs)
@@ -1580,10 +1582,53 @@ int akz_result_device_plane(const akz_result* r, uint64_t img, uint64_t level, a
     *d_plane = base ? base + (size_t)img * lv.w * lv.h : nullptr;
     return AKZ_OK;
 }
+// A plane that the extraction did not keep (Lxx, Lyy, Lxy, Lstep without AKZ_KEEP_ALL_PLANES) is recomputed for one
+// image from planes that are always kept, with the kernels and in the order of the extraction: second derivatives
+// from the level's Lsmooth (detector_response.rs:9-13), Lstep by repeating the level's diffusion from the previous
+// level's Lt (lib.rs:80-92, :109-118).  Bit-identical to the kept planes; *d_out points into context scratch memory
+// that the next call overwrites.
+static int recompute_plane(const akz_result* r, uint64_t img, uint64_t level, akz_plane plane, const float** d_out) {
+    akz_ctx* c = r->ctx;
+    AKZ_TRY(bind(c));
+    const LevelPlan& lv = r->plan[(size_t)level];
+    const size_t px = (size_t)lv.w * lv.h, pb = px * sizeof(float);
+    auto img_plane = [&](uint64_t l, int p) { return r->planes[(size_t)l][p] + (size_t)img * r->plan[(size_t)l].w * r->plan[(size_t)l].h; };
+    *d_out = nullptr;
+    if (plane == AKZ_LXX || plane == AKZ_LYY || plane == AKZ_LXY) {
+        for (int k = 0; k < 6; ++k) AKZ_TRY(ensure(c, c->lazy[k], pb));
+        float* b[6];
+        for (int k = 0; k < 6; ++k) b[k] = (float*)c->lazy[k].p;
+        AKZ_TRY(detector_impl(c, img_plane(level, AKZ_LSMOOTH), lv.det_sigma, b[0], b[1], b[2], b[3], b[4], b[5], lv.w, lv.h, 1));
+        *d_out = plane == AKZ_LXX ? b[2] : plane == AKZ_LYY ? b[3] : b[4];
+        return AKZ_OK;
+    }
+    if (plane == AKZ_LSTEP && level > 0) {
+        const LevelPlan& pv = r->plan[(size_t)level - 1];
+        for (int k = 0; k < 4; ++k) AKZ_TRY(ensure(c, c->lazy[k], std::max(pb, (size_t)4)));
+        float *A = (float*)c->lazy[0].p, *B = (float*)c->lazy[1].p, *step = (float*)c->lazy[2].p;
+        const float* in = img_plane(level - 1, AKZ_LT);
+        if (lv.octave > pv.octave) {  // first level of an octave: the 2x2 mean of the previous level's Lt
+            launch::half_size(c->stream, in, (float*)c->lazy[3].p, pv.w, pv.h, 1);
+            in = (const float*)c->lazy[3].p;
+        }
+        AKZ_HIP_TRY(hipMemsetAsync(step, 0, pb, c->stream));  // a level without diffusion steps keeps the zero plane (lib.rs:107)
+        AKZ_TRY(fed_impl(c, in, A, B, img_plane(level, AKZ_LFLOW), step, lv.w, lv.h, 1, lv.tau.data(), (uint32_t)lv.tau.size()));
+        *d_out = step;
+        return AKZ_OK;
+    }
+    return AKZ_OK;  // level 0 has no Lflow / Lstep (0 x 0 in the reference)
+}
+
 int akz_fetch_plane(const akz_result* r, uint64_t img, uint64_t level, akz_plane plane, float* out, uint64_t* n_px) {
     const float* d = nullptr;
     AKZ_TRY(akz_result_device_plane(r, img, level, plane, &d));
     const LevelPlan& lv = r->plan[(size_t)level];
+    const bool lazy = !d && (plane == AKZ_LXX || plane == AKZ_LYY || plane == AKZ_LXY || (plane == AKZ_LSTEP && level > 0));
+    if (lazy && !out) {  // size query
+        if (n_px) *n_px = (uint64_t)lv.w * lv.h;
+        return AKZ_OK;
+    }
+    if (lazy) AKZ_TRY(recompute_plane(r, img, level, plane, &d));
     const uint64_t npx = d ? (uint64_t)lv.w * lv.h : 0;
     if (n_px) *n_px = npx;
     if (out && npx) {

@@ -231,8 +231,10 @@ int akz_result_contrast(const akz_result* res, uint64_t img, double* k);
 int akz_result_level_info(const akz_result* res, uint64_t level, double* etime, double* esigma, uint32_t* octave,
                           uint32_t* sublevel, uint32_t* sigma_size, uint32_t* w, uint32_t* h, uint64_t* n_tau,
                           double* tau, uint64_t tau_cap);
-/* lazy D2H of one EvolutionStep image; *n_px = 0 for the 0x0 planes (level 0 Lflow/Lstep, or
-   planes not kept without AKZ_KEEP_ALL_PLANES).  out may be NULL to query the size. */
+/* lazy D2H of one EvolutionStep image; *n_px = 0 for the 0x0 planes (level 0 Lflow/Lstep).  Planes the
+   extraction did not keep (Lxx, Lyy, Lxy, Lstep without AKZ_KEEP_ALL_PLANES) are recomputed for this image
+   from the kept ones with the same kernels — bit-identical, at the cost of a few launches per call — so an
+   EvolutionStep is complete either way.  out may be NULL to query the size. */
 int akz_fetch_plane(const akz_result* res, uint64_t img, uint64_t level, akz_plane plane, float* out,
                     uint64_t* n_px);
 /* device address of a resident plane (NULL if not kept) */

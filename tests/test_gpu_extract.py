@@ -50,9 +50,10 @@ def test_extract_f32_input_and_lean_planes(ctx, amd, ref):
     res = ctx.extract_features(frame, keep_all_planes=False)
     rf = ref.extract(frame)
     assert_same_result(res, rf, planes=False)
-    # planes that are not kept read as 0x0, kept ones are still exact
-    assert res.plane(3, "Lxx").size == 0 and res.plane(3, "Lstep").size == 0
+    # planes that are not kept are recomputed on fetch, kept ones are still exact
+    assert np.array_equal(res.plane(3, "Lxx"), rf.plane(3, "Lxx")) and np.array_equal(res.plane(3, "Lstep"), rf.plane(3, "Lstep"))
     assert np.array_equal(res.plane(3, "Ldet"), rf.plane(3, "Ldet"))
+    assert res.plane(0, "Lstep").size == 0 and rf.plane(0, "Lstep").size == 0
     assert res.plane(0, "Lflow").size == 0 and rf.plane(0, "Lflow").size == 0
 
 
@@ -222,6 +223,20 @@ def test_baseline_c5_4k_5x5_stream_all_pairs_match(ctx, amd, ref):
             assert np.array_equal(got, exp), (i, j)
             n_matches += len(exp)
     assert n_matches > 1000
+
+
+def test_planes_not_kept_are_recomputed_on_fetch(ctx, amd, ref):
+    """Without keep_all_planes Lxx / Lyy / Lxy / Lstep are not written by the extraction; fetching them recomputes
+    them from the kept planes (second derivatives from Lsmooth, Lstep by repeating the level's diffusion, including
+    the first level of an octave): every plane of every level equals the oracle's, for a frame of a batch."""
+    import torch
+    frames = np.stack([amd.synth_frame(517, 389, 30 + i) for i in range(2)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda(), keep_all_planes=False)
+    rf = ref.extract(frames[1])
+    assert_same_result(res, rf, planes=True, img=1)
+    cfg5 = dict(num_sublevels=5, max_octave_evolution=5)  # detector scales up to 5: the unfused derivative path
+    res5 = ctx.extract_features(frames[0], amd.Config(**cfg5), keep_all_planes=False)
+    assert_same_result(res5, ref.extract(frames[0], ref.default_config(**cfg5)), planes=True)
 
 
 def test_candidate_list_overflow_is_retried(amd, ref):

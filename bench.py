@@ -160,8 +160,15 @@ def main():
         """The path's exchange step: counts, then padded 64-byte rows over RCCL (a few MB, latency-bound).
         Fixed capacity => no host synchronisation: both collectives are only enqueued on the side stream."""
         rows = sum(res.counts(i)[1] for res in results for i in range(res.num_images))
+        if gather_cap[0] == 0:
+            # every rank must pad to the SAME capacity: agree on it once (first warm-up step, one host sync); the
+            # frames of a shard are the same every step, so the row counts do not change afterwards
+            most = torch.tensor([rows], dtype=torch.int64, device=dev)
+            dist.all_reduce(most, op=dist.ReduceOp.MAX)
+            most = int(most.item())
+            gather_cap[0] = 1 << max(10, (most + most // 2).bit_length())
         if rows > gather_cap[0]:
-            gather_cap[0] = 1 << max(10, (rows + rows // 2).bit_length())
+            raise SystemExit(f"rank {rank}: {rows} descriptor rows exceed the agreed gather capacity {gather_cap[0]}")
         with torch.cuda.stream(side):
             local = torch.empty((rows, 64), dtype=torch.uint8, device=dev)
             side.synchronize()  # the allocation above is the only thing the aux-stream copy must wait for

@@ -45,6 +45,31 @@ def test_extract_matches_oracle_all_planes(ctx, amd, ref, w, h, idx):
     assert_same_result(res, rf)
 
 
+@pytest.mark.parametrize("w,h", [(11, 11), (12, 40), (33, 17), (81, 41), (159, 79), (160, 80), (161, 81), (2000, 24),
+                                 (24, 1500)])
+def test_extract_edge_sizes(ctx, amd, ref, w, h):
+    """The smallest accepted frame (11 x 11: the detector Scharr of sigma 4 needs 2*4+3), frames smaller than one
+    tile, strips, and the sizes either side of the second octave's admission rule (evolution.rs:138-149: 160 x 80)."""
+    frame = amd.synth_frame(w, h, 3)
+    res = ctx.extract_features(frame)
+    rf = ref.extract(frame)
+    assert res.num_levels == rf.num_levels == (8 if w >= 160 and h >= 80 else 4)
+    assert_same_result(res, rf)
+
+
+def test_extract_flat_and_noise_frames(ctx, amd, ref):
+    """A constant frame (hmax == 0 in the contrast factor, no extrema anywhere) and uniform noise (every NMS
+    neighbourhood busy: 1131 keypoints on 320 x 240)."""
+    flat = np.full((120, 200), 77, np.uint8)
+    res, rf = ctx.extract_features(flat), ref.extract(flat)
+    assert rf.num_keypoints == 0
+    assert_same_result(res, rf)
+    noise = np.random.default_rng(1).integers(0, 256, (240, 320), dtype=np.uint8)
+    res, rf = ctx.extract_features(noise), ref.extract(noise)
+    assert rf.num_keypoints > 1000
+    assert_same_result(res, rf)
+
+
 def test_extract_f32_input_and_lean_planes(ctx, amd, ref):
     frame = (amd.synth_frame(400, 300, 5).astype(np.float32) * np.float32(1.0)) / np.float32(255.0)
     res = ctx.extract_features(frame, keep_all_planes=False)

@@ -12,10 +12,10 @@ PLANES = ["Lt", "Lsmooth", "Lx", "Ly", "Lxx", "Lyy", "Lxy", "Lflow", "Lstep", "L
 KP_FIELDS = ("x", "y", "response", "size", "octave", "class_id", "angle")
 
 
-def assert_same_result(res, rf, planes=True, img=0):
+def assert_same_result(res, rf, planes=True, img=0, equal_nan=False):
     nl, nk, nb = res.counts(img)
     assert nl == rf.num_levels and nb == rf.desc_bytes
-    assert res.contrast(img) == rf.contrast
+    assert res.contrast(img) == rf.contrast or (equal_nan and np.isnan(res.contrast(img)) and np.isnan(rf.contrast))
     if planes:
         for lvl in range(nl):
             info, rinfo = res.level_info(lvl), rf.level_info(lvl)
@@ -25,7 +25,7 @@ def assert_same_result(res, rf, planes=True, img=0):
             for pl in PLANES:
                 a, b = res.plane(lvl, pl, img), rf.plane(lvl, pl)
                 assert a.shape == b.shape, (lvl, pl, a.shape, b.shape)
-                if a.size and not np.array_equal(a, b):
+                if a.size and not np.array_equal(a, b, equal_nan=equal_nan):
                     bad = np.argwhere(a != b)
                     raise AssertionError(f"level {lvl} plane {pl}: {len(bad)} px differ, first {bad[0]}: "
                                          f"{a[tuple(bad[0])]!r} vs {b[tuple(bad[0])]!r}")
@@ -53,17 +53,18 @@ def test_extract_edge_sizes(ctx, amd, ref, w, h):
     frame = amd.synth_frame(w, h, 3)
     res = ctx.extract_features(frame)
     rf = ref.extract(frame)
-    assert res.num_levels == rf.num_levels == (8 if w >= 160 and h >= 80 else 4)
+    assert res.counts(0)[0] == rf.num_levels == (8 if w >= 160 and h >= 80 else 4)
     assert_same_result(res, rf)
 
 
 def test_extract_flat_and_noise_frames(ctx, amd, ref):
-    """A constant frame (hmax == 0 in the contrast factor, no extrema anywhere) and uniform noise (every NMS
-    neighbourhood busy: 1131 keypoints on 320 x 240)."""
+    """A constant frame (no gradient anywhere: the diffusion planes turn NaN in the reference's arithmetic and must
+    do so here, NaN payloads aside; no extrema) and uniform noise (every NMS neighbourhood busy: 1131 keypoints on
+    320 x 240)."""
     flat = np.full((120, 200), 77, np.uint8)
     res, rf = ctx.extract_features(flat), ref.extract(flat)
     assert rf.num_keypoints == 0
-    assert_same_result(res, rf)
+    assert_same_result(res, rf, equal_nan=True)
     noise = np.random.default_rng(1).integers(0, 256, (240, 320), dtype=np.uint8)
     res, rf = ctx.extract_features(noise), ref.extract(noise)
     assert rf.num_keypoints > 1000

@@ -39,6 +39,13 @@ namespace {
 #ifndef AKZ_STENCIL_TH
 #define AKZ_STENCIL_TH 32
 #endif
+// Tile height of k_deriv2 alone (tuning knob).  64 x 30 tiles make its Ldet window 32 rows (four full thread rows per
+// vertical pass instead of five with the last mostly idle) and cut the sigma-4 input window from seven loads per thread
+// to six, yet the detector stage measured the same (3.38 against 3.40 ms per 32-frame step): the kernel is not
+// issue-bound, so it keeps the common tile.
+#ifndef AKZ_DERIV2_TH
+#define AKZ_DERIV2_TH AKZ_STENCIL_TH
+#endif
 constexpr int TW = 64, TH = AKZ_STENCIL_TH, NT = AKZ_STENCIL_NT;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -55,6 +62,7 @@ struct TileGrid {
 struct Tile {
     int bx, by, bz, x0, y0;
 };
+template <int TILE_H = TH>
 __device__ __forceinline__ Tile decode_tile(int t, TileGrid g, int w, int h) {
     const int per = g.tx * g.ty;
     Tile r;
@@ -63,7 +71,7 @@ __device__ __forceinline__ Tile decode_tile(int t, TileGrid g, int w, int h) {
     r.by = rem / g.tx;
     r.bx = rem - r.by * g.tx;
     r.x0 = tile_origin(r.bx, TW, w);
-    r.y0 = tile_origin(r.by, TH, h);
+    r.y0 = tile_origin(r.by, TILE_H, h);
     return r;
 }
 
@@ -468,16 +476,17 @@ k_deriv1(const float* __restrict__ ls, float* __restrict__ lx_out, float* __rest
 // sCnt[0] must be zero on entry (thread 0 clears it behind an earlier barrier of the tile loop); the caller
 // places a barrier after the call before the Ldet window is overwritten.
 // ---------------------------------------------------------------------------------------------
-template <int DW>
+template <int DW, int TILE_H = TH>
 __device__ __forceinline__ void tile_extrema(const float* sD, unsigned* sCnt, int tid, const Tile& tl, int w, int h,
                                              float thr, float bm, unsigned level, Candidate* __restrict__ cand,
                                              unsigned cap, unsigned* __restrict__ count) {
-    constexpr int IT = TW * TH / NT;
-    static_assert(IT * NT == TW * TH && IT <= 32, "whole number of tile pixels per thread");
+    constexpr int IT = (TW * TILE_H + NT - 1) / NT;
+    static_assert(IT <= 32, "one mask bit per pixel of a thread");
     unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int idx = tid + i * NT;
+        if (IT * NT != TW * TILE_H && idx >= TW * TILE_H) continue;
         const int ly = idx / TW, lx = idx - ly * TW;
         const int x = tl.x0 + lx, y = tl.y0 + ly;
         // flat range (w+1) .. len-w-2 of the reference loop; x = w-1 never passes the border test
@@ -492,7 +501,7 @@ __device__ __forceinline__ void tile_extrema(const float* sD, unsigned* sCnt, in
                             (roundf(fy - bm) - 1.0f) < 0.0f || (roundf(fy + bm) + 1.0f) >= (float)h;
         if (is_out) continue;
         // tiles shifted inward overlap their neighbour: only the owner of a pixel reports it
-        if (x < tl.bx * TW || y < tl.by * TH) continue;
+        if (x < tl.bx * TW || y < tl.by * TILE_H) continue;
         mask |= 1u << i;
     }
     const unsigned cnt = (unsigned)__popc(mask);
@@ -534,8 +543,9 @@ __global__ void __launch_bounds__(NT)
 k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float* __restrict__ lxx_out,
          float* __restrict__ lyy_out, float* __restrict__ lxy_out, float* __restrict__ ldet_out, int w, int h,
          TileGrid tg, float kn, float kwn, float quat, NmsArgs nms) {
+    constexpr int T2 = AKZ_DERIV2_TH;                      // tile height of this kernel (see the define)
     constexpr int RING = NMS ? 1 : 0;
-    constexpr int DW = TW + 2 * RING, DH = TH + 2 * RING;  // Ldet window, origin (x0-RING, y0-RING)
+    constexpr int DW = TW + 2 * RING, DH = T2 + 2 * RING;  // Ldet window, origin (x0-RING, y0-RING)
     constexpr int AW = DW, AH = DH + 2 * S;                // H windows,   origin (x0-RING, y0-RING-S)
     constexpr int RW = DW + 2 * S, RH = DH + 2 * S;        // input windows, origin (x0-RING-S, y0-RING-S)
     constexpr int NLOAD = (RH * RW + NT - 1) / NT;
@@ -562,7 +572,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
     }
     float rx[NLOAD], ry[NLOAD];
     auto issue = [&](int tile) {
-        const Tile tl = decode_tile(tile, tg, w, h);
+        const Tile tl = decode_tile<T2>(tile, tg, w, h);
         const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
@@ -655,7 +665,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
             const float lxy = ((0.0f + kn * c0[i]) + kwn * c1[i]) + kn * c2[i];
             det[i] = ((lxx * lyy) - (lxy * lxy)) * quat;
             const int ly = ty + i * NROWT;
-            if (ok[i] && ly >= RING && ly < TH + RING) {
+            if (ok[i] && ly >= RING && ly < T2 + RING) {
                 const size_t g = base + (size_t)(y0 - RING + ly) * w + x;
                 if (lxx_out) lxx_out[g] = lxx;
                 if (lyy_out) lyy_out[g] = lyy;
@@ -683,7 +693,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         __syncthreads();
         if (NMS && tid == 0) sCnt[0] = 0;
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
-        const Tile tl = decode_tile(tile, tg, w, h);
+        const Tile tl = decode_tile<T2>(tile, tg, w, h);
         const int x0 = tl.x0, y0 = tl.y0;
         const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
         // ---- three H passes: thread (tx, ty) owns tile column x0+tx, window rows ty, ty+8, ... ----
@@ -695,7 +705,7 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         if (NMS && tid < 2 * DH) v_pos((tid & 1) ? x0 + TW : x0 - 1, (tid & 1) ? DW - 1 : 0, tid >> 1, x0, y0, base, false);
         __syncthreads();
         if (NMS) {
-            tile_extrema<DW>(sD, sCnt, tid, tl, w, h, nms.thr, nms.border_m, nms.level, nms.cand, nms.cap, nms.count);
+            tile_extrema<DW, T2>(sD, sCnt, tid, tl, w, h, nms.thr, nms.border_m, nms.level, nms.cand, nms.cap, nms.count);
             __syncthreads();  // sD (= sX) is overwritten by the next iteration
         }
     }
@@ -889,10 +899,10 @@ inline long persist_blocks() {
     }();
     return v;
 }
-inline Launch plan_tiles(uint32_t w, uint32_t h, uint32_t n) {
+inline Launch plan_tiles(uint32_t w, uint32_t h, uint32_t n, int tile_h = TH) {
     Launch l;
     l.tg.tx = (int)((w + TW - 1) / TW);
-    l.tg.ty = (int)((h + TH - 1) / TH);
+    l.tg.ty = (int)((h + tile_h - 1) / tile_h);
     l.tg.n = (int)n;
     const long total = (long)l.tg.tx * l.tg.ty * l.tg.n;
     l.grid = dim3((unsigned)std::min<long>(total, persist_blocks()));
@@ -946,8 +956,8 @@ bool detector_nms_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <
 #define AKZ_DET(S, NMSF)                                                                                           \
     case S:                                                                                                        \
         hipLaunchKernelGGL((k_deriv1<S>), l.grid, dim3(NT), 0, s, lsmooth, lx, ly, (int)w, (int)h, l.tg, kn, kwn); \
-        hipLaunchKernelGGL((k_deriv2<S, NMSF>), l.grid, dim3(NT), 0, s, (const float*)lx, (const float*)ly, lxx,   \
-                           lyy, lxy, ldet_out, (int)w, (int)h, l.tg, kn, kwn, quat, na);                           \
+        hipLaunchKernelGGL((k_deriv2<S, NMSF>), l2.grid, dim3(NT), 0, s, (const float*)lx, (const float*)ly, lxx,  \
+                           lyy, lxy, ldet_out, (int)w, (int)h, l2.tg, kn, kwn, quat, na);                          \
         break;
 
 void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
@@ -955,7 +965,7 @@ void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
     const Taps m = taps_scharr_main(sigma);
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
-    const Launch l = plan_tiles(w, h, n);
+    const Launch l = plan_tiles(w, h, n), l2 = plan_tiles(w, h, n, AKZ_DERIV2_TH);
     const NmsArgs na{};
     switch (sigma) {
         AKZ_DET(1, false) AKZ_DET(2, false) AKZ_DET(3, false) AKZ_DET(4, false) AKZ_DET(5, false) AKZ_DET(6, false)
@@ -969,7 +979,7 @@ void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, flo
     const Taps m = taps_scharr_main(sigma);
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
-    const Launch l = plan_tiles(w, h, n);
+    const Launch l = plan_tiles(w, h, n), l2 = plan_tiles(w, h, n, AKZ_DERIV2_TH);
     const NmsArgs na{level, thr, border_m, d_cand, cap, d_count};
     switch (sigma) {
         AKZ_DET(1, true) AKZ_DET(2, true) AKZ_DET(3, true) AKZ_DET(4, true)

@@ -238,3 +238,42 @@ void orientation_windows(unsigned long long* mask, uint32_t* n_windows);
 float border_margin(const LevelPlan& lv, const akz_config& cfg);  // smax * sigma_size (f32)
 
 }  // namespace akz
+
+// ---- plane stores (device code only) -------------------------------------------------------------------------
+// Output planes are written once and not read again by the kernel that writes them.  Streaming (nontemporal) stores
+// lift what a tiled COPY-ONLY kernel reaches from 5.1 to 7.2 TB/s at one plane read : two written and from 5.1 to
+// 6.4 TB/s at 1 : 6 (tools/membw/tilebw n, profiles/r01_tile_bandwidth.txt) — but the stencil and FED kernels
+// measured the same with them (level preparation 1.12-1.15 against 1.16 ms, detector 3.29-3.37 against 3.40 ms per
+// 32-frame step, results identical): they are bound by their on-chip dependency chains, not by the store path.
+// AKZ_NT_STORES=1 builds the streaming form (A/B runs); the default keeps ordinary stores.
+#if defined(__HIPCC__)
+#ifndef AKZ_NT_STORES
+#define AKZ_NT_STORES 0
+#endif
+namespace akz {
+typedef float akz_f4a __attribute__((ext_vector_type(4)));                // 16-byte aligned group of four pixels
+typedef float akz_f4u __attribute__((ext_vector_type(4), aligned(4)));    // dword-aligned group of four pixels
+__device__ __forceinline__ void plane_store(float* p, float v) {
+#if AKZ_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void plane_store4(float* p, float a, float b, float c, float d) {  // p 16-byte aligned
+    const akz_f4a t = {a, b, c, d};
+#if AKZ_NT_STORES
+    __builtin_nontemporal_store(t, reinterpret_cast<akz_f4a*>(p));
+#else
+    *reinterpret_cast<akz_f4a*>(p) = t;
+#endif
+}
+__device__ __forceinline__ void plane_store4u(float* p, akz_f4a t) {  // p dword-aligned
+#if AKZ_NT_STORES
+    __builtin_nontemporal_store((akz_f4u)t, reinterpret_cast<akz_f4u*>(p));
+#else
+    *reinterpret_cast<akz_f4u*>(p) = t;
+#endif
+}
+}  // namespace akz
+#endif

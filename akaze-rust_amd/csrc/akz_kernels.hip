@@ -491,14 +491,14 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
         float* po = L_out + base + (size_t)gy * w;
         float* ps = Lstep ? Lstep + base + (size_t)gy * w : nullptr;
         if (vec_ok && gx + 3 < w) {
-            *reinterpret_cast<float4*>(po + gx) = make_float4(v[0], v[1], v[2], v[3]);
-            if (ps) *reinterpret_cast<float4*>(ps + gx) = make_float4(st[0], st[1], st[2], st[3]);
+            plane_store4(po + gx, v[0], v[1], v[2], v[3]);
+            if (ps) plane_store4(ps + gx, st[0], st[1], st[2], st[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (gx + e < w) {
-                    po[gx + e] = v[e];
-                    if (ps) ps[gx + e] = st[e];
+                    plane_store(po + gx + e, v[e]);
+                    if (ps) plane_store(ps + gx + e, st[e]);
                 }
         }
     }

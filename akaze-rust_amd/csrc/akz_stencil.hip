@@ -343,11 +343,11 @@ __device__ __forceinline__ void store_quad(float* __restrict__ plane, int gx, in
                                            const float (&v)[4]) {
     float* row = plane + (size_t)gy * w;
     if (vec_ok && gx + 3 < w) {
-        *reinterpret_cast<float4*>(row + gx) = make_float4(v[0], v[1], v[2], v[3]);
+        plane_store4(row + gx, v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (gx + e < w) row[gx + e] = v[e];
+            if (gx + e < w) plane_store(row + gx + e, v[e]);
     }
 }
 
@@ -609,10 +609,10 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
         if (NMS) sD[ly * DW + wc] = det;
         if (centre) {
             const size_t g = base + (size_t)y * w + x;
-            if (lxx_out) lxx_out[g] = lxx;
-            if (lyy_out) lyy_out[g] = lyy;
-            if (lxy_out) lxy_out[g] = lxy;
-            ldet_out[g] = det;
+            if (lxx_out) plane_store(lxx_out + g, lxx);
+            if (lyy_out) plane_store(lyy_out + g, lyy);
+            if (lxy_out) plane_store(lxy_out + g, lxy);
+            plane_store(ldet_out + g, det);
         }
     };
     // The column passes of thread (tx, ty): rows ty, ty+8, ... of tile column x0+tx, fully unrolled and
@@ -667,10 +667,10 @@ k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float
             const int ly = ty + i * NROWT;
             if (ok[i] && ly >= RING && ly < T2 + RING) {
                 const size_t g = base + (size_t)(y0 - RING + ly) * w + x;
-                if (lxx_out) lxx_out[g] = lxx;
-                if (lyy_out) lyy_out[g] = lyy;
-                if (lxy_out) lxy_out[g] = lxy;
-                ldet_out[g] = det[i];
+                if (lxx_out) plane_store(lxx_out + g, lxx);
+                if (lyy_out) plane_store(lyy_out + g, lyy);
+                if (lxy_out) plane_store(lxy_out + g, lxy);
+                plane_store(ldet_out + g, det[i]);
             }
         }
         if (NMS) {  // sD aliases sX: every thread has finished reading sX before the barrier in front of this pass

@@ -124,7 +124,7 @@ template <int N>
 __device__ __forceinline__ void store_rows(float* const (&plane)[N], size_t ro, const Lane& L, const f4 (&v)[N]) {
     if (L.store) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) *reinterpret_cast<f4u*>(plane[i] + ro + L.x) = v[i];
+        for (int i = 0; i < N; ++i) plane_store4u(plane[i] + ro + L.x, v[i]);
     }
 }
 // interior row c of the output planes, plus (two rows per strip) the border rows that copy it
@@ -467,11 +467,11 @@ __device__ __forceinline__ PrepLane make_prep_lane(int strip, int lane, int w) {
 }
 __device__ __forceinline__ void prep_store(float* __restrict__ row, const PrepLane& L, int w, f4 v) {
     if (L.vst) {
-        *reinterpret_cast<f4u*>(row + L.x) = v;
+        plane_store4u(row + L.x, v);
     } else if (L.sst) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (L.x + i < w) row[L.x + i] = v[i];
+            if (L.x + i < w) plane_store(row + L.x + i, v[i]);
     }
 }
 // row y of a filled plane; rows 1 and h-2 are also the border rows 0 and h-1
@@ -738,7 +738,7 @@ template <int N>
 __device__ __forceinline__ void det_store(float* const (&plane)[N], size_t ro, const DetLane& L, int w, const f4 (&v)[N]) {
     if (L.vst) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) *reinterpret_cast<f4u*>(plane[i] + ro + L.x) = v[i];
+        for (int i = 0; i < N; ++i) plane_store4u(plane[i] + ro + L.x, v[i]);
     } else if (L.sst) {
 #pragma unroll
         for (int i = 0; i < N; ++i)

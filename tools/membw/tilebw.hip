@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 
-template <int R, int W, int TW, int TH, int VEC>
+typedef float f4_native __attribute__((ext_vector_type(4)));
+
+template <int R, int W, int TW, int TH, int VEC, int NTS = 0>
 __global__ void __launch_bounds__(512) k_tile(const float* __restrict__ in, float* __restrict__ out, int w, int h, int n,
                                                size_t plane, int ntx, int nty) {
     const int ntiles = ntx * nty * n;
@@ -26,29 +28,37 @@ __global__ void __launch_bounds__(512) k_tile(const float* __restrict__ in, floa
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float4 v = *reinterpret_cast<const float4*>(in + r * plane + g);
+                    float4 v;
+                    if (NTS & 2) {
+                        const f4_native t = __builtin_nontemporal_load(reinterpret_cast<const f4_native*>(in + r * plane + g));
+                        v = make_float4(t.x, t.y, t.z, t.w);
+                    } else {
+                        v = *reinterpret_cast<const float4*>(in + r * plane + g);
+                    }
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     acc.x += 1.0f;
-                    *reinterpret_cast<float4*>(out + k * plane + g) = acc;
+                    if (NTS & 1) { f4_native t = {acc.x, acc.y, acc.z, acc.w}; __builtin_nontemporal_store(t, reinterpret_cast<f4_native*>(out + k * plane + g)); }
+                    else *reinterpret_cast<float4*>(out + k * plane + g) = acc;
                 }
             } else {
                 float acc = 0.f;
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc += in[r * plane + g];
+                for (int r = 0; r < R; ++r) acc += (NTS & 2) ? __builtin_nontemporal_load(in + r * plane + g) : in[r * plane + g];
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     acc += 1.0f;
-                    out[k * plane + g] = acc;
+                    if (NTS & 1) __builtin_nontemporal_store(acc, out + k * plane + g);
+                    else out[k * plane + g] = acc;
                 }
             }
         }
     }
 }
 
-template <int R, int W, int TW, int TH, int VEC>
+template <int R, int W, int TW, int TH, int VEC, int NTS = 0>
 void run(const float* in, float* out, int w, int h, int n, int blocks) {
     const int ntx = (w + TW - 1) / TW, nty = (h + TH - 1) / TH;
     const size_t plane = (size_t)w * h * n;
@@ -56,14 +66,15 @@ void run(const float* in, float* out, int w, int h, int n, int blocks) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 2; ++i)
-        hipLaunchKernelGGL((k_tile<R, W, TW, TH, VEC>), dim3(grid), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
+        hipLaunchKernelGGL((k_tile<R, W, TW, TH, VEC, NTS>), dim3(grid), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
     hipEventRecord(a);
     const int it = 10;
     for (int i = 0; i < it; ++i)
-        hipLaunchKernelGGL((k_tile<R, W, TW, TH, VEC>), dim3(grid), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
+        hipLaunchKernelGGL((k_tile<R, W, TW, TH, VEC, NTS>), dim3(grid), dim3(512), 0, 0, in, out, w, h, n, plane, ntx, nty);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double bytes = (double)plane * 4 * (R + W) * it;
+    if (NTS) printf("[nontemporal %s%s] ", (NTS & 1) ? "st" : "", (NTS & 2) ? "ld" : "");
     printf("R%d:W%d tile %3dx%-2d vec%d grid %6d  %5.0f GB/s  (%.0f us)\n", R, W, TW, TH, VEC, grid, bytes / ms / 1e6, ms / it * 1e3);
 }
 
@@ -164,6 +175,24 @@ int main(int argc, char** argv) {
         run_halo<2, 128, 24, 4, 3>(in, out, w, h, n);
         run_halo<2, 256, 16, 4, 3>(in, out, w, h, n);
         run_halo<1, 64, 48, 4, 3>(in, out, w, h, n);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'n') {  // tilebw nontemporal: do streaming stores / loads lift the ceiling?
+        for (int blocks : {0, 1024}) {
+            run<1, 2, 64, 32, 1, 0>(in, out, w, h, n, blocks);
+            run<1, 2, 64, 32, 1, 1>(in, out, w, h, n, blocks);
+            run<1, 2, 64, 32, 1, 3>(in, out, w, h, n, blocks);
+            run<1, 2, 64, 32, 4, 0>(in, out, w, h, n, blocks);
+            run<1, 2, 64, 32, 4, 1>(in, out, w, h, n, blocks);
+            run<2, 4, 64, 32, 1, 0>(in, out, w, h, n, blocks);
+            run<2, 4, 64, 32, 1, 1>(in, out, w, h, n, blocks);
+            run<2, 4, 64, 32, 1, 3>(in, out, w, h, n, blocks);
+            run<2, 4, 64, 32, 4, 0>(in, out, w, h, n, blocks);
+            run<2, 4, 64, 32, 4, 1>(in, out, w, h, n, blocks);
+            run<2, 4, 64, 32, 4, 3>(in, out, w, h, n, blocks);
+            run<1, 6, 64, 32, 1, 0>(in, out, w, h, n, blocks);
+            run<1, 6, 64, 32, 1, 1>(in, out, w, h, n, blocks);
+        }
         return 0;
     }
     if (argc > 1) {  // tilebw sustained

@@ -954,7 +954,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     if (c->det_overlap == 2)
         for (size_t l = 1; l < L; ++l)
             if (plan[l].octave >= kDeferOctave && plan[l - 1].octave < kDeferOctave) defer_level = l;
-    if (c->det_overlap == 2 && (defer_level >= L || (uint64_t)w * h * n < (8u << 20))) ds = nullptr;  // nothing to hide / launch-bound
+    static const uint64_t defer_min_px = [] {
+        const char* e = std::getenv("AKZ_DET_DEFER_MIN_PX");
+        return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
+    }();
+    if (c->det_overlap == 2 && (defer_level >= L || (uint64_t)w * h * n < defer_min_px)) ds = nullptr;  // nothing to hide / launch-bound
     auto overlap_detector = [&](size_t l) -> int {
         if (!ds) return AKZ_OK;
         if (c->det_overlap == 2) {

@@ -1123,16 +1123,26 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
         hipLaunchKernelGGL((k_fed_fused<TW, TH, 8, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
                            (int)h, ht);
 }
-static unsigned contrast_blocks(uint32_t h) { return h > 2 ? std::min<uint32_t>(h - 2, 128u) : 1u; }
+// Workgroups per image of the two contrast passes: 128 fat ones for a batch (one atomicMax / one histogram flush
+// each); a small batch gets more, shorter ones so that the chip is filled (a lone 1080p frame: 38 + 36 us with 128).
+static unsigned contrast_blocks(uint32_t h, uint32_t n) {
+    static const uint32_t target = [] {
+        const char* e = std::getenv("AKZ_CONTRAST_WGS");
+        const long v = e ? std::atol(e) : 0;
+        return v > 0 ? (uint32_t)v : 512u;  // lone 1080p frame: 37 + 34 us with 128, 18 + 24 with 512, 19 + 33 with 1024
+    }();
+    const uint32_t per_image = std::max<uint32_t>(128u, target / std::max<uint32_t>(n, 1u));
+    return h > 2 ? std::min<uint32_t>(h - 2, per_image) : 1u;
+}
 void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
                   unsigned long long* d_hmax_bits) {
-    hipLaunchKernelGGL(k_contrast_max, dim3(contrast_blocks(h), 1, n), dim3(CT), 0, s, blurred, (int)w, (int)h,
+    hipLaunchKernelGGL(k_contrast_max, dim3(contrast_blocks(h, n), 1, n), dim3(CT), 0, s, blurred, (int)w, (int)h,
                        scharr1(), d_hmax_bits);
 }
 void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
                    const unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist) {
     const unsigned copies = nbins <= 512 ? 8u : (nbins <= 2048 ? 2u : 1u);
-    hipLaunchKernelGGL(k_contrast_hist, dim3(contrast_blocks(h), 1, n), dim3(CT), nbins * copies * sizeof(unsigned), s,
+    hipLaunchKernelGGL(k_contrast_hist, dim3(contrast_blocks(h, n), 1, n), dim3(CT), nbins * copies * sizeof(unsigned), s,
                        blurred, (int)w, (int)h, scharr1(), d_hmax_bits, nbins, copies, d_hist);
 }
 void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const uint32_t* d_hist, uint32_t nbins,

@@ -1,0 +1,36 @@
+"""Single 1080p frame: host time inside begin / finish when streaming, and how long the GPU needs for the chain that
+begin enqueues.  python tools/single_probe.py [detector overlap mode]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "akaze-rust_amd", "python"))
+import numpy as np, torch
+import akaze_amd as A
+dev = torch.device("cuda", 0)
+frames = torch.from_numpy(np.stack([A.synth_frame(1920, 1080, i) for i in range(4)])).to(dev)
+cfg = A.Config()
+st = torch.cuda.Stream(dev)
+ctx = A.Context(0, st.cuda_stream)
+ctx.set_detector_overlap(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+one = frames[0:1]
+for _ in range(10):
+    ctx.extract_begin(one, cfg).finish().close()
+torch.cuda.synchronize()
+# begin only: host cost of enqueue, and GPU chain duration
+tb = tf = 0.0
+reps = 200
+t0 = time.perf_counter()
+prev = None
+for _ in range(reps):
+    a = time.perf_counter(); job = ctx.extract_begin(one, cfg); tb += time.perf_counter() - a
+    if prev is not None:
+        a = time.perf_counter(); prev.finish().close(); tf += time.perf_counter() - a
+    prev = job
+prev.finish().close()
+el = time.perf_counter() - t0
+print(f"streamed: {el/reps*1e3:.3f} ms/frame; host in begin {tb/reps*1e3:.3f}, in finish {tf/reps*1e3:.3f}")
+# GPU chain duration of begin alone: enqueue, sync
+torch.cuda.synchronize()
+ts = []
+for _ in range(20):
+    torch.cuda.synchronize(); a = time.perf_counter(); job = ctx.extract_begin(one, cfg); b = time.perf_counter(); torch.cuda.synchronize(); c = time.perf_counter()
+    ts.append((b - a, c - a)); job.finish().close()
+print("begin alone: host %.3f ms, until GPU idle %.3f ms" % (np.median([x for x, _ in ts]) * 1e3, np.median([y for _, y in ts]) * 1e3))

@@ -506,10 +506,21 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
 }
 
 // FED launch plan: the level's n_tau steps are cut into ceil(n_tau / 8) launches of balanced size.
+// Small launches (a lone frame's coarse octaves: 4 to 72 workgroups, every launch at the floor of a dependent
+// dispatch) fuse up to 16 steps on flat 64 x 10 tiles instead: half the launches of a level (AKZ_FED_DEEP_WGS: the
+// largest launch, in workgroups, that takes this form; 0 disables).
 static constexpr uint32_t kFedMaxFuse = 8;
-static uint32_t fed_num_launches(const akz_ctx* c, uint32_t n_tau) {
+static uint32_t fed_max_fuse(const akz_ctx* c, uint32_t w, uint32_t h, uint32_t n) {
+    static const uint64_t deep_wgs = [] {
+        const char* e = std::getenv("AKZ_FED_DEEP_WGS");
+        return e ? (uint64_t)std::atoll(e) : (uint64_t)512;
+    }();
+    return c->fed_mode == 2 && launch::fed_deep_workgroups(w, h, n) <= deep_wgs ? 2 * kFedMaxFuse : kFedMaxFuse;
+}
+static uint32_t fed_num_launches(const akz_ctx* c, uint32_t n_tau, uint32_t w, uint32_t h, uint32_t n) {
     if (c->fed_mode == 0) return n_tau;
-    return (n_tau + kFedMaxFuse - 1) / kFedMaxFuse;
+    const uint32_t fuse = fed_max_fuse(c, w, h, n);
+    return (n_tau + fuse - 1) / fuse;
 }
 // calculate_step x n_tau.  The first launch reads `in` (never written), launches alternate between
 // the buffers A and B such that the LAST one writes A.  `in` may be B or a third buffer, never A
@@ -519,7 +530,7 @@ static float* fed_dst(uint32_t launches, uint32_t k /*1-based*/, float* A, float
 }
 static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float* lflow, float* lstep, uint32_t w,
                     uint32_t h, uint32_t n, const double* taus, uint32_t n_tau) {
-    const uint32_t launches = fed_num_launches(c, n_tau);
+    const uint32_t launches = fed_num_launches(c, n_tau, w, h, n);
     if (launches == 0) {
         if (in != A) AKZ_HIP_TRY(hipMemcpyAsync(A, in, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
         return AKZ_OK;
@@ -538,7 +549,7 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
             launch::fed_step(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, half_tau);
         } else {
             const uint32_t cnt = (n_tau - done + (launches - k + 1) - 1) / (launches - k + 1);  // balanced chunks
-            float ht[8];
+            float ht[2 * kFedMaxFuse];
             for (uint32_t j = 0; j < cnt; ++j) ht[j] = 0.5f * (float)taus[done + j];
             done += cnt;
             launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt,
@@ -1008,7 +1019,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         const float* fed_in = P(i - 1, AKZ_LT);
         float* half_buf = nullptr;
         if (half) {
-            const uint32_t launches = fed_num_launches(c, n_tau);
+            const uint32_t launches = fed_num_launches(c, n_tau, lv.w, lv.h, n);
             half_buf = launches == 0 ? A : (fed_dst(launches, 1, A, B) == A ? B : A);
             fed_in = half_buf;
         }

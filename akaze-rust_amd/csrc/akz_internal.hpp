@@ -120,6 +120,8 @@ void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_o
 // ownership (k_fed_own), variant 1: all values through LDS (k_fed_fused)
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
                uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps, int variant);
+// workgroups of a 9..16-step launch (64 x 10 tiles); fed_fused takes up to 16 steps with variant 2
+uint64_t fed_deep_workgroups(uint32_t w, uint32_t h, uint32_t n);
 void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
                   unsigned long long* d_hmax_bits);
 void contrast_hist(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,

@@ -153,7 +153,7 @@ __global__ void k_fed_step(const float* __restrict__ L, const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 struct FedTaus {
     int n;
-    float half_tau[8];  // 0.5f * (tau as f32) per step (nonlinear_diffusion.rs:67)
+    float half_tau[16];  // 0.5f * (tau as f32) per step (nonlinear_diffusion.rs:67); 8 used by all but k_fed_own<.,.,16,.>
 };
 
 // neighbour lane exchange as a one-instruction DPP move (no LDS crossbar round trip as with ds_bpermute)
@@ -332,7 +332,7 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
     // issued before the first LDS write: a workgroup's lifetime is dominated by this load phase (one fused step costs
     // 17 us per full-resolution batch level, the launch 280), and a rolled loop would wait for the first pair of loads
     // before issuing the second.
-    static_assert(RHMAX * XG <= 2 * NT && (TH + 2) * XG >= NT, "two staging slots per thread, the first always used");
+    static_assert(RHMAX * XG <= 2 * NT && (NT - 1) / XG <= RHMAX, "two staging slots per thread, both inside the LDS planes");
     if (vec_ok) {
         const int i1 = tid + NT;
         const int ly0 = tid / XG, g0 = tid - ly0 * XG;
@@ -1086,6 +1086,10 @@ void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_o
     hipLaunchKernelGGL(k_fed_step, grid2d(w, h, n), dim3(BX, BY), 0, s, lt_in, lflow, lt_out, lstep, (int)w, (int)h,
                        half_tau);
 }
+constexpr int kFedDeepTh = 10;
+uint64_t fed_deep_workgroups(uint32_t w, uint32_t h, uint32_t n) {
+    return (uint64_t)((w + 63) / 64) * ((h + kFedDeepTh - 1) / kFedDeepTh) * n;
+}
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
                uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps, int variant) {
 #ifndef AKZ_FED_NT
@@ -1094,7 +1098,7 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
     constexpr int TW = 64, TH = 32, NT = AKZ_FED_NT;
     FedTaus ht;
     ht.n = (int)n_steps;
-    for (uint32_t i = 0; i < 8; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
+    for (uint32_t i = 0; i < 16; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
     const dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
     if (variant == 2) {
         if (n_steps <= 4) {
@@ -1111,9 +1115,16 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
             } else
                 hipLaunchKernelGGL((k_fed_own<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
                                    (int)h, ht);
-        } else
+        } else if (n_steps <= 8)
             hipLaunchKernelGGL((k_fed_own<TW, TH, 8, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
                                (int)h, ht);
+        else {
+            // up to 16 steps on 64 x 10 tiles (region 96 x 42: 6.3 x the tile, so only where a launch is a handful of
+            // workgroups at the floor of a dependent dispatch and halving the launches is what counts)
+            const dim3 g10((w + TW - 1) / TW, (h + kFedDeepTh - 1) / kFedDeepTh, n);
+            hipLaunchKernelGGL((k_fed_own<TW, kFedDeepTh, 16, NT>), g10, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep,
+                               (int)w, (int)h, ht);
+        }
         return;
     }
     if (n_steps <= 4)

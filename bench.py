@@ -291,7 +291,7 @@ def main():
 
     # ---- the matcher (BASELINE configs[2] / [4]: Hamming match of two descriptor sets), untimed leg, rank 0 ------
     match_leg = None
-    if rank == 0 and not args.no_match:
+    if rank == 0 and world == 1 and not args.no_match:  # N = 1 information; the scaling runs only need `value`
         g = torch.Generator(device=dev).manual_seed(7)
         legs = []
         for n_m in (11264, 65536):  # a 4K frame's keypoint count; a gathered multi-frame set
@@ -318,7 +318,7 @@ def main():
 
     # ---- BASELINE configs[1] taken literally: ONE frame per extract call (untimed extra leg, rank 0) -----------
     single = None
-    if rank == 0 and not args.no_single:
+    if rank == 0 and world == 1 and not args.no_single:
         ctx.set_profiling(0)
         one = d_frames[:1]
         for _ in range(10):
@@ -440,6 +440,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()  # rank 0 may still be in its untimed extra leg: all ranks leave together
         dist.destroy_process_group()
 
 

@@ -1,5 +1,5 @@
 """Single 1080p frame: host time inside begin / finish when streaming, and how long the GPU needs for the chain that
-begin enqueues.  python tools/single_probe.py [detector overlap mode]"""
+begin enqueues.  python tools/single_probe.py [detector overlap mode] [jobs in flight: 2 or 3]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "akaze-rust_amd", "python"))
 import numpy as np, torch
@@ -14,19 +14,20 @@ one = frames[0:1]
 for _ in range(10):
     ctx.extract_begin(one, cfg).finish().close()
 torch.cuda.synchronize()
-# begin only: host cost of enqueue, and GPU chain duration
+# streaming with DEPTH jobs in flight: host cost of begin / finish per frame
+DEPTH = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 tb = tf = 0.0
-reps = 200
+reps = 300
 t0 = time.perf_counter()
-prev = None
+q = []
 for _ in range(reps):
-    a = time.perf_counter(); job = ctx.extract_begin(one, cfg); tb += time.perf_counter() - a
-    if prev is not None:
-        a = time.perf_counter(); prev.finish().close(); tf += time.perf_counter() - a
-    prev = job
-prev.finish().close()
+    a = time.perf_counter(); q.append(ctx.extract_begin(one, cfg)); tb += time.perf_counter() - a
+    if len(q) >= DEPTH:
+        a = time.perf_counter(); q.pop(0).finish().close(); tf += time.perf_counter() - a
+while q:
+    q.pop(0).finish().close()
 el = time.perf_counter() - t0
-print(f"streamed: {el/reps*1e3:.3f} ms/frame; host in begin {tb/reps*1e3:.3f}, in finish {tf/reps*1e3:.3f}")
+print(f"streamed, {DEPTH} in flight: {el/reps*1e3:.3f} ms/frame; host in begin {tb/reps*1e3:.3f}, in finish {tf/reps*1e3:.3f}")
 # GPU chain duration of begin alone: enqueue, sync
 torch.cuda.synchronize()
 ts = []

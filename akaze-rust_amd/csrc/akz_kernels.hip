@@ -721,26 +721,43 @@ k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, uns
     __shared__ float s_ry[ORI_KPB * ORI_NS + 16];
     const unsigned base = xcd_contiguous_group(blockIdx.x, gridDim.x) * ORI_KPB;
     if (base >= nkp) return;  // whole workgroup
-    for (unsigned idx = threadIdx.x; idx < ORI_KPB * ORI_NS; idx += ORI_NT) {
-        const unsigned j = idx / ORI_NS, k = idx - j * ORI_NS;
-        float rx = 0.0f, ry = 0.0f;
-        if (base + j < nkp) {
-            const KpParam kp = kps[base + j];
-            const LevelPtrs lv = tab.lv[kp.level];
-            const float* lx = lv.lx + (size_t)kp.img * lv.stride;
-            const float* ly = lv.ly + (size_t)kp.img * lv.stride;
-            const int a = c_ori.a[k], b = c_ori.b[k];
-            const float fy = roundf(kp.yf + (float)b * kp.scale);
-            const float fx = roundf(kp.xf + (float)a * kp.scale);
-            const int iy = clampi(fy > 0.0f ? (int)fy : 0, 0, (int)lv.h - 1);
-            const int ix = clampi(fx > 0.0f ? (int)fx : 0, 0, (int)lv.w - 1);
-            const float g = c_gauss25[a < 0 ? -a : a][b < 0 ? -b : b];
-            const size_t p = (size_t)iy * lv.w + ix;
-            rx = g * lx[p];
-            ry = g * ly[p];
+    // 14 samples per thread in two batches of 7: the gathers of a batch (keypoint -> level table -> Lx, Ly: three
+    // dependent loads each) are all in flight before the first one is consumed
+    constexpr int ORI_IT = (ORI_KPB * ORI_NS + ORI_NT - 1) / ORI_NT, ORI_UB = 7;
+    static_assert(ORI_IT % ORI_UB == 0, "whole batches");
+    for (int it0 = 0; it0 < ORI_IT; it0 += ORI_UB) {
+        float vx[ORI_UB], vy[ORI_UB], gw[ORI_UB];
+#pragma unroll
+        for (int u = 0; u < ORI_UB; ++u) {
+            const unsigned idx = threadIdx.x + (unsigned)(it0 + u) * ORI_NT;
+            const unsigned j = idx / ORI_NS, k = idx - j * ORI_NS;
+            vx[u] = 0.0f; vy[u] = 0.0f; gw[u] = 0.0f;
+            if (idx < ORI_KPB * ORI_NS && base + j < nkp) {
+                const KpParam kp = kps[base + j];
+                const LevelPtrs lv = tab.lv[kp.level];
+                const float* lx = lv.lx + (size_t)kp.img * lv.stride;
+                const float* ly = lv.ly + (size_t)kp.img * lv.stride;
+                const int a = c_ori.a[k], b = c_ori.b[k];
+                const float fy = roundf(kp.yf + (float)b * kp.scale);
+                const float fx = roundf(kp.xf + (float)a * kp.scale);
+                const int iy = clampi(fy > 0.0f ? (int)fy : 0, 0, (int)lv.h - 1);
+                const int ix = clampi(fx > 0.0f ? (int)fx : 0, 0, (int)lv.w - 1);
+                gw[u] = c_gauss25[a < 0 ? -a : a][b < 0 ? -b : b];
+                const size_t p = (size_t)iy * lv.w + ix;
+                vx[u] = lx[p];
+                vy[u] = ly[p];
+            }
         }
-        s_rx[idx] = rx;
-        s_ry[idx] = ry;
+#pragma unroll
+        for (int u = 0; u < ORI_UB; ++u) {
+            const unsigned idx = threadIdx.x + (unsigned)(it0 + u) * ORI_NT;
+            const unsigned j = idx / ORI_NS;
+            if (idx < ORI_KPB * ORI_NS) {
+                const bool have = base + j < nkp;
+                s_rx[idx] = have ? gw[u] * vx[u] : 0.0f;
+                s_ry[idx] = have ? gw[u] * vy[u] : 0.0f;
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
@@ -748,12 +765,19 @@ k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, uns
     const bool is_y = (lane & 1u) != 0;
     const float* py = s_ry + j * ORI_NS;
     const float* pa = is_y ? py : s_rx + j * ORI_NS;
+    // The samples of a keypoint are the same for every window: they are read from LDS once, a sample that the
+    // reference skips (res_y <= 0, scale_space_extrema.rs:303) becomes -0.0f, and x + (-0.0f) == x bit for bit for
+    // every x, so each window is one unconditional chain of 109 register adds in the reference's order (the LDS
+    // reads inside the chain made the kernel 62 us long whatever the keypoint count).
+    float t[ORI_NS];
+#pragma unroll
+    for (int k = 0; k < ORI_NS; ++k) t[k] = py[k] > 0.0f ? pa[k] : -0.0f;
     float sum = 0.0f, maxv = 0.0f, bx = 0.0f, by = 0.0f;
     unsigned found = 0;
     for (unsigned wdw = 0; wdw < n_windows; ++wdw) {
         if ((window_mask >> wdw) & 1ull) {
-            for (int k = 0; k < ORI_NS; ++k)
-                if (py[k] > 0.0f) sum = sum + pa[k];
+#pragma unroll
+            for (int k = 0; k < ORI_NS; ++k) sum = sum + t[k];
         }
         const float other = __shfl_xor(sum, 1, 64);
         const float sx = is_y ? other : sum, sy = is_y ? sum : other;

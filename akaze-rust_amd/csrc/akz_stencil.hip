@@ -46,7 +46,11 @@ namespace {
 #ifndef AKZ_DERIV2_TH
 #define AKZ_DERIV2_TH AKZ_STENCIL_TH
 #endif
+#ifndef AKZ_DERIV2_TH4
+#define AKZ_DERIV2_TH4 AKZ_DERIV2_TH  // the same knob for the sigma-4 instantiation alone
+#endif
 constexpr int TW = 64, TH = AKZ_STENCIL_TH, NT = AKZ_STENCIL_NT;
+constexpr int deriv2_tile_h(int s) { return s == 4 ? AKZ_DERIV2_TH4 : AKZ_DERIV2_TH; }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -543,7 +547,7 @@ __global__ void __launch_bounds__(NT)
 k_deriv2(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float* __restrict__ lxx_out,
          float* __restrict__ lyy_out, float* __restrict__ lxy_out, float* __restrict__ ldet_out, int w, int h,
          TileGrid tg, float kn, float kwn, float quat, NmsArgs nms) {
-    constexpr int T2 = AKZ_DERIV2_TH;                      // tile height of this kernel (see the define)
+    constexpr int T2 = deriv2_tile_h(S);                   // tile height of this kernel (see the defines)
     constexpr int RING = NMS ? 1 : 0;
     constexpr int DW = TW + 2 * RING, DH = T2 + 2 * RING;  // Ldet window, origin (x0-RING, y0-RING)
     constexpr int AW = DW, AH = DH + 2 * S;                // H windows,   origin (x0-RING, y0-RING-S)
@@ -965,7 +969,7 @@ void detector_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
     const Taps m = taps_scharr_main(sigma);
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
-    const Launch l = plan_tiles(w, h, n), l2 = plan_tiles(w, h, n, AKZ_DERIV2_TH);
+    const Launch l = plan_tiles(w, h, n), l2 = plan_tiles(w, h, n, deriv2_tile_h((int)sigma));
     const NmsArgs na{};
     switch (sigma) {
         AKZ_DET(1, false) AKZ_DET(2, false) AKZ_DET(3, false) AKZ_DET(4, false) AKZ_DET(5, false) AKZ_DET(6, false)
@@ -979,7 +983,7 @@ void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, flo
     const Taps m = taps_scharr_main(sigma);
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
-    const Launch l = plan_tiles(w, h, n), l2 = plan_tiles(w, h, n, AKZ_DERIV2_TH);
+    const Launch l = plan_tiles(w, h, n), l2 = plan_tiles(w, h, n, deriv2_tile_h((int)sigma));
     const NmsArgs na{level, thr, border_m, d_cand, cap, d_count};
     switch (sigma) {
         AKZ_DET(1, true) AKZ_DET(2, true) AKZ_DET(3, true) AKZ_DET(4, true)

@@ -1,6 +1,8 @@
 """The streaming (register-ring) kernels of akz_stream.hip against the CPU oracle and against the LDS-tiled
 kernels: every plane, keypoint and descriptor byte identical, for shapes that exercise the strip / band /
 edge-lane logic (widths that are not multiples of 4 or of the 240/248-pixel strips, several bands, batches)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -135,6 +137,54 @@ def test_deferred_detector_overlap_gives_identical_results(amd, ref):
         assert_same_result(rb, ref.extract(f[0]), planes=False, img=0)
     finally:
         c.close()
+
+
+_LANES_CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "akaze-rust_amd", "python"))
+import numpy as np, torch
+import akaze_amd as A
+frames = [torch.from_numpy(A.synth_frame(*wh, 30 + i)[None]).cuda() for i, wh in enumerate([(320, 240), (517, 389), (640, 480), (320, 240), (200, 120), (517, 389)])]
+c = A.Context(0, torch.cuda.Stream().cuda_stream)
+q, out = [], []
+def retire(j):
+    r = j.finish()
+    h = hashlib.sha256()
+    kp = r.keypoints(0)
+    for f in ("x", "y", "response", "size", "octave", "class_id", "angle"):
+        h.update(np.ascontiguousarray(kp[f]).tobytes())
+    h.update(r.descriptors(0).tobytes())
+    for lvl in range(r.counts(0)[0]):
+        for pl in ("Lt", "Ldet", "Lflow", "Lstep"):
+            h.update(r.plane(lvl, pl, 0).tobytes())
+    out.append(h.hexdigest()); r.close()
+for rep in range(2):
+    for f in frames:
+        q.append(c.extract_begin(f))
+        if len(q) == 3:
+            retire(q.pop(0))
+while q:
+    retire(q.pop(0))
+print(" ".join(out))
+"""
+
+
+def test_two_lanes_give_identical_results(tmp_path):
+    """AKZ_LANES=1 (small jobs alternate between the context's stream and a second one with its own temporaries, three
+    jobs in flight, mixed sizes): every keypoint field, descriptor byte and the Lt / Ldet / Lflow / Lstep planes of
+    every level hash the same as with one lane."""
+    import subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    script = tmp_path / "lanes_child.py"
+    script.write_text(_LANES_CHILD)
+    outs = []
+    for lanes in ("0", "1"):
+        env = dict(os.environ, AKZ_LANES=lanes)
+        run = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=env, timeout=300)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs.append(run.stdout.strip().splitlines()[-1].split())
+    assert len(outs[0]) == 12 and outs[0] == outs[1]
+    assert outs[0][:6] == outs[0][6:]  # the second pass over the same frames
 
 
 @pytest.mark.parametrize("shape", [(96, 132), (131, 248), (77, 516), (40, 1000), (300, 517)])

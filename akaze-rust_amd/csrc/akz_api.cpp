@@ -1065,9 +1065,21 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // ---- levels 1..L-1 (lib.rs:78-119) ----
     AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(w, h, n)));
     const std::vector<float> g1 = gaussian_kernel(1.0f, gaussian_kernel_size(1.0f));  // Lsmooth taps (lib.rs:95)
+    // AKZ_KP_GATE_OCTAVE=o: the gate for the previous batch's keypoint kernels (fed_done, below) is recorded when the
+    // chain reaches octave o instead of behind the last diffusion launch (experiment; default: behind the last one)
+    static const int kp_gate_octave = [] {
+        const char* e = std::getenv("AKZ_KP_GATE_OCTAVE");
+        return e ? std::atoi(e) : -1;
+    }();
+    bool gate_recorded = false;
     for (size_t i = 1; i < L; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
+        if (kp_gate_octave > 0 && !gate_recorded && (int)lv.octave >= kp_gate_octave) {
+            if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
+            AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+            gate_recorded = true;
+        }
         float* A = P(i, AKZ_LT);
         float* B = (float*)c->scratch[5].p;
         const uint32_t n_tau = (uint32_t)lv.tau.size();
@@ -1108,8 +1120,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // The keypoint kernels of the batch that is finished next (orientation, M-LDB: gather-bound, on the auxiliary
     // stream) wait for this point: next to the VALU-bound diffusion launches they cost more than next to the
     // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.
-    if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
-    AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+    if (!gate_recorded) {
+        if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
+        AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+    }
 
     // ---- detector levels that were not overlapped (no side stream, or kernel sizes without a fused form) ----
     // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group

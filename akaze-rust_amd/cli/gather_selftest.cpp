@@ -1,0 +1,151 @@
+// The descriptor exchange of the multi-GPU path (akz_comm_* / akz_gather_*), driven through the C ABI only — what a
+// C++ or Rust host does before a cross-image brute-force match.
+//
+//   gather_selftest                       one rank on device 0
+//   gather_selftest RANK NRANKS ID_FILE   rank RANK of NRANKS, one process per GPU (device = RANK); rank 0 writes the
+//                                         128-byte communicator id to ID_FILE, the others wait for it
+//
+// Every rank extracts frames of its shard (image i -> GPU i mod G), gathers the descriptor rows with the synchronous
+// form and with the pipelined form, and checks that (a) its own rows came back bit for bit in its slot of both
+// results, (b) the two forms agree, (c) the headers carry the row and image counts.  Prints "gather selftest ok".
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/akaze_hip.h"
+
+#define TRY(expr)                                                                          \
+    do {                                                                                   \
+        if ((expr) != AKZ_OK) {                                                            \
+            fprintf(stderr, "FAILED: %s: %s\n", #expr, akz_last_error());                  \
+            return 1;                                                                      \
+        }                                                                                  \
+    } while (0)
+#define CHECK(cond)                                                \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            fprintf(stderr, "CHECK FAILED: %s (line %d)\n", #cond, __LINE__); \
+            return 1;                                              \
+        }                                                          \
+    } while (0)
+
+int main(int argc, char** argv) {
+    int rank = 0, nranks = 1;
+    const char* id_file = nullptr;
+    if (argc == 4) {
+        rank = atoi(argv[1]);
+        nranks = atoi(argv[2]);
+        id_file = argv[3];
+    } else if (argc != 1) {
+        fprintf(stderr, "usage: %s [RANK NRANKS ID_FILE]\n", argv[0]);
+        return 2;
+    }
+    const int device = rank;
+    void* stream = nullptr;
+    TRY(akz_stream_create(device, &stream));
+    akz_ctx* ctx = nullptr;
+    TRY(akz_ctx_create(device, stream, &ctx));
+
+    uint8_t id[AKZ_COMM_ID_BYTES];
+    if (rank == 0) {
+        TRY(akz_comm_unique_id(id));
+        if (id_file) {
+            std::string tmp = std::string(id_file) + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            CHECK(f && fwrite(id, 1, sizeof(id), f) == sizeof(id));
+            fclose(f);
+            CHECK(rename(tmp.c_str(), id_file) == 0);
+        }
+    } else {
+        FILE* f = nullptr;
+        for (int tries = 0; tries < 600 && !(f = fopen(id_file, "rb")); ++tries) usleep(100000);
+        CHECK(f && fread(id, 1, sizeof(id), f) == sizeof(id));
+        fclose(f);
+    }
+    akz_comm* comm = nullptr;
+    TRY(akz_comm_create(device, id, rank, nranks, &comm));
+    int r2 = -1, n2 = -1;
+    TRY(akz_comm_info(comm, &r2, &n2));
+    CHECK(r2 == rank && n2 == nranks);
+
+    // this rank's shard: two frames of a 4-frame-per-rank job
+    const uint32_t W = 320, H = 240, NIMG = 2;
+    akz_config cfg;
+    akz_config_default(&cfg);
+    std::vector<uint8_t> frames((size_t)W * H * NIMG);
+    for (uint32_t i = 0; i < NIMG; ++i) TRY(akz_synth_frame_u8(frames.data() + (size_t)i * W * H, W, H, (uint64_t)rank + (uint64_t)i * nranks, 0, 0));
+    void* d_frames = nullptr;
+    TRY(akz_device_malloc(ctx, frames.size(), &d_frames));
+    TRY(akz_memcpy_h2d(ctx, d_frames, frames.data(), frames.size()));
+    akz_result* res = nullptr;
+    TRY(akz_extract_device_u8(ctx, (const uint8_t*)d_frames, W, H, NIMG, &cfg, 0, &res));
+    uint64_t rows = 0;
+    const uint8_t* d_rows = nullptr;
+    for (uint32_t i = 0; i < NIMG; ++i) {
+        const uint8_t* p = nullptr;
+        uint64_t n = 0;
+        TRY(akz_result_device_descriptors(res, i, &p, &n));
+        if (i == 0) d_rows = p;
+        rows += n;
+    }
+    CHECK(rows > 0);
+    std::vector<uint8_t> mine((size_t)rows * 64);
+    TRY(akz_memcpy_d2h(ctx, mine.data(), d_rows, mine.size()));
+
+    // (1) Appendix C form
+    std::vector<uint64_t> counts((size_t)nranks, 0);
+    const uint8_t* d_all = nullptr;
+    TRY(akz_gather_descriptors(comm, d_rows, rows, &d_all, counts.data()));
+    CHECK(counts[(size_t)rank] == rows);
+    uint64_t total = 0, my_off = 0;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) my_off = total;
+        total += counts[(size_t)r];
+    }
+    std::vector<uint8_t> all((size_t)total * 64);
+    TRY(akz_memcpy_d2h(ctx, all.data(), d_all, all.size()));
+    CHECK(memcmp(all.data() + my_off * 64, mine.data(), mine.size()) == 0);
+
+    // (2) pipelined form, twice in flight order (begin, begin is not allowed to need the first one finished)
+    uint64_t cap = 1;
+    for (uint64_t v : counts) cap = v > cap ? v : cap;
+    cap += cap / 2;
+    const akz_result* rs[1] = {res};
+    akz_gather *g1 = nullptr, *g2 = nullptr;
+    TRY(akz_gather_begin(comm, rs, 1, cap, &g1));
+    TRY(akz_gather_begin_rows(comm, d_rows, rows, cap, nullptr, &g2));
+    for (akz_gather* g : {g1, g2}) {
+        const uint8_t* blocks = nullptr;
+        uint64_t block_rows = 0;
+        std::vector<uint64_t> c2((size_t)nranks, 0), im((size_t)nranks, 0);
+        TRY(akz_gather_stream_wait(g, stream));
+        TRY(akz_gather_finish(g, &blocks, &block_rows, c2.data(), im.data()));
+        CHECK(block_rows == cap + 1);
+        for (int r = 0; r < nranks; ++r) CHECK(c2[(size_t)r] == counts[(size_t)r]);
+        CHECK(im[(size_t)rank] == (g == g1 ? NIMG : 1));
+        uint64_t off = 0;
+        for (int r = 0; r < nranks; ++r) {
+            std::vector<uint8_t> blk((size_t)counts[(size_t)r] * 64);
+            if (!blk.empty()) TRY(akz_memcpy_d2h(ctx, blk.data(), blocks + ((uint64_t)r * block_rows + 1) * 64, blk.size()));
+            CHECK(memcmp(blk.data(), all.data() + off * 64, blk.size()) == 0);
+            off += counts[(size_t)r];
+        }
+        TRY(akz_gather_free(g));
+    }
+    // (3) a shard that does not fit the agreed capacity is refused, not truncated
+    akz_gather* g3 = nullptr;
+    CHECK(akz_gather_begin_rows(comm, d_rows, rows, rows - 1, nullptr, &g3) == AKZ_ERR_BUFFER && g3 == nullptr);
+
+    TRY(akz_result_free(res));
+    TRY(akz_device_free(ctx, d_frames));
+    TRY(akz_comm_destroy(comm));
+    TRY(akz_ctx_destroy(ctx));
+    TRY(akz_stream_destroy(device, stream));
+    printf("gather selftest ok: rank %d of %d, %llu local rows, %llu gathered\n", rank, nranks, (unsigned long long)rows,
+           (unsigned long long)total);
+    return 0;
+}

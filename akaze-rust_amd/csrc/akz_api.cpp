@@ -123,7 +123,7 @@ struct StageTimer {
     bool on;
     hipStream_t s;
     StageTimer(akz_ctx* ctx, int st, hipStream_t stream = nullptr) : c(ctx), stage(st), s(stream ? stream : ctx->stream) {
-        on = c->profiling >= 2 || (c->profiling == 1 && st == AKZ_ST_FED);
+        on = c->profiling >= 2 || (c->profiling == 1 && (st == AKZ_ST_FED || st == AKZ_ST_DETECTOR));
         if (!on) return;
         a = get(c);
         b = get(c);
@@ -997,6 +997,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     auto detector_one_pass = [&](size_t l, hipStream_t st_) -> bool {
         const LevelPlan& lv = plan[l];
         const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
+        if (c->profiling) {
+            c->prof.det_launches += 1;
+            c->prof.det_px += (uint64_t)lv.w * lv.h * n;
+        }
         if (const int fam = detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
             StageTimer st(c, AKZ_ST_DETECTOR, st_);
             (fam == 4 ? launch::detector_tiled_fused : fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
@@ -1152,6 +1156,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         const uint32_t maxn = launch::detector_tiled_set_max();
         for (size_t i = 0; i < kv.second.size(); i += maxn) {
             StageTimer st(c, AKZ_ST_DETECTOR);
+            if (c->profiling) {
+                c->prof.det_launches += 1;
+                for (size_t j = i; j < std::min(kv.second.size(), i + maxn); ++j)
+                    c->prof.det_px += (uint64_t)kv.second[j].w * kv.second[j].h * n;
+            }
             launch::detector_tiled_set(s, kv.first, kv.second.data() + i, (uint32_t)std::min<size_t>(maxn, kv.second.size() - i), n,
                                        (float)cfg.detector_threshold, d_cand, cap, d_count);
         }
@@ -2023,5 +2032,6 @@ int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     return AKZ_OK;
 }
 const char* akz_fed_kernel_name(void) { return "k_fed_own"; }
+const char* akz_detector_kernel_name(void) { return "k_deriv1 + k_deriv2"; }
 
 }  // extern "C"

@@ -1,0 +1,434 @@
+// The path's one exchange step (SURVEY.md 8(e), Appendix C `akz_gather_descriptors`): an RCCL all-gather of the
+// 64-byte descriptor rows of every rank's shard, so that a brute-force Hamming match can run on any GPU of the job.
+// The reference has no counterpart (it is a single-process CPU crate); this is the MI355X-native addition that the
+// one-image-per-GPU sharding needs.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): a process that already carries an RCCL — PyTorch-ROCm ships its
+// own copy under the same soname — gets that one, a plain C++ / Rust host gets /opt/rocm's.  libakaze_hip.so itself
+// has no link-time dependency on it, so single-GPU users never load a communication library.
+//
+// Wire format: ONE all-gather per exchange.  Every rank contributes a block of (1 + cap_rows) 64-byte rows: row 0 is a
+// header {u64 rows, u64 images, u64 cap_rows, u64 sequence}, rows 1.. are its descriptor rows, the rest is padding.
+// A few MB per rank: latency-bound over xGMI, so one fixed-size collective beats exact-size send/recv pairs.
+//
+// Nothing here synchronises the extraction stream: the local rows are copied on the communicator's copy stream, the
+// collective is enqueued behind the copy on its exchange stream, and the caller retires the gather (or makes its
+// matcher's stream wait for it) whenever it wants — typically one step later.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "akz_internal.hpp"
+
+using namespace akz;
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) {
+            r.error = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "unknown");
+            return;
+        }
+        auto sym = [&](const char* name) -> void* {
+            void* p = dlsym(r.handle, name);
+            if (!p && r.error.empty()) r.error = std::string("RCCL symbol missing: ") + name;
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &r;
+}
+
+int rccl_ready() {
+    Rccl* r = rccl();
+    if (!r->error.empty() || !r->handle) {
+        set_error(r->error.empty() ? "RCCL is not available" : r->error);
+        return AKZ_ERR_UNSUPPORTED;
+    }
+    return AKZ_OK;
+}
+
+#define AKZ_NCCL_TRY(expr)                                                                        \
+    do {                                                                                          \
+        ncclResult_t _r = (expr);                                                                 \
+        if (_r != ncclSuccess) {                                                                  \
+            set_error(std::string(#expr) + " failed: " + rccl()->GetErrorString(_r));             \
+            return AKZ_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+constexpr uint64_t kRow = 64;
+
+}  // namespace
+
+struct akz_gather {
+    akz_comm* comm = nullptr;
+    uint8_t* send = nullptr;   // (1 + cap_rows) rows
+    uint8_t* recv = nullptr;   // nranks * (1 + cap_rows) rows
+    uint64_t cap_rows = 0;
+    size_t send_bytes = 0, recv_bytes = 0;
+    hipEvent_t done = nullptr;
+    uint64_t* pinned = nullptr;  // header staging: 8 u64 per rank
+    bool in_use = false;
+};
+
+struct akz_comm {
+    int device = 0, rank = 0, nranks = 1;
+    ncclComm_t nccl = nullptr;
+    hipStream_t xs = nullptr;       // exchange stream: the collectives, in order
+    hipStream_t cs = nullptr;       // copy stream: local rows -> send block, headers -> host (never behind a collective)
+    hipEvent_t ready = nullptr;     // producer-side event the copy stream waits for
+    hipEvent_t copied = nullptr;    // the send block is complete
+    uint8_t* sync_out = nullptr;    // compacted rows of the last akz_gather_descriptors call (Appendix C form)
+    size_t sync_out_bytes = 0;
+    uint64_t sequence = 0;
+    std::vector<akz_gather*> pool;  // every gather object ever handed out (reused when free and large enough)
+};
+
+static void gather_release_buffers(akz_gather* g) {
+    if (g->send) (void)hipFree(g->send);
+    if (g->recv) (void)hipFree(g->recv);
+    if (g->pinned) (void)hipHostFree(g->pinned);
+    if (g->done) (void)hipEventDestroy(g->done);
+    g->send = g->recv = nullptr;
+    g->pinned = nullptr;
+    g->done = nullptr;
+}
+
+static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
+    akz_gather* g = nullptr;
+    for (akz_gather* p : c->pool)
+        if (!p->in_use && p->cap_rows == cap_rows) {
+            g = p;
+            break;
+        }
+    if (!g) {
+        for (akz_gather* p : c->pool)
+            if (!p->in_use) {  // a free object of another capacity: rebuild it
+                gather_release_buffers(p);
+                g = p;
+                break;
+            }
+        if (!g) {
+            g = new akz_gather;
+            g->comm = c;
+            c->pool.push_back(g);
+        }
+        g->cap_rows = cap_rows;
+        g->send_bytes = (size_t)(1 + cap_rows) * kRow;
+        g->recv_bytes = g->send_bytes * (size_t)c->nranks;
+        AKZ_HIP_TRY(hipMalloc((void**)&g->send, g->send_bytes));
+        AKZ_HIP_TRY(hipMalloc((void**)&g->recv, g->recv_bytes));
+        AKZ_HIP_TRY(hipMemsetAsync(g->send, 0, g->send_bytes, c->cs));  // no uninitialised bytes on the wire
+        AKZ_HIP_TRY(hipHostMalloc((void**)&g->pinned, (size_t)c->nranks * kRow + kRow, hipHostMallocDefault));
+        AKZ_HIP_TRY(hipEventCreateWithFlags(&g->done, hipEventDisableTiming));
+    }
+    g->in_use = true;
+    *out = g;
+    return AKZ_OK;
+}
+
+// rows of `n_src` device blocks -> send block (copy stream), then one all-gather (exchange stream).  With wait_copy the
+// call returns once the local rows have been copied (the sources may then be released); it never waits for a collective.
+static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_src, const uint64_t* src_rows, uint64_t n_src,
+                          uint64_t images, hipStream_t producer, bool wait_copy) {
+    uint64_t rows = 0;
+    for (uint64_t i = 0; i < n_src; ++i) rows += src_rows[i];
+    if (rows > g->cap_rows) {
+        set_error("gather: the local shard has more descriptor rows than the agreed capacity");
+        return AKZ_ERR_BUFFER;
+    }
+    if (producer) {  // the rows are complete in the order of this stream
+        AKZ_HIP_TRY(hipEventRecord(c->ready, producer));
+        AKZ_HIP_TRY(hipStreamWaitEvent(c->cs, c->ready, 0));
+    }
+    uint64_t* hdr = g->pinned + (size_t)c->nranks * 8;  // this rank's header, staged in pinned memory
+    hdr[0] = rows;
+    hdr[1] = images;
+    hdr[2] = g->cap_rows;
+    hdr[3] = ++c->sequence;
+    hdr[4] = hdr[5] = hdr[6] = hdr[7] = 0;
+    AKZ_HIP_TRY(hipMemcpyAsync(g->send, hdr, kRow, hipMemcpyHostToDevice, c->cs));
+    uint64_t at = 1;
+    for (uint64_t i = 0; i < n_src; ++i) {
+        if (src_rows[i] == 0) continue;
+        AKZ_HIP_TRY(hipMemcpyAsync(g->send + at * kRow, d_src[i], src_rows[i] * kRow, hipMemcpyDeviceToDevice, c->cs));
+        at += src_rows[i];
+    }
+    AKZ_HIP_TRY(hipEventRecord(c->copied, c->cs));
+    AKZ_HIP_TRY(hipStreamWaitEvent(c->xs, c->copied, 0));
+    AKZ_NCCL_TRY(rccl()->AllGather(g->send, g->recv, g->send_bytes, ncclUint8, c->nccl, c->xs));
+    AKZ_HIP_TRY(hipEventRecord(g->done, c->xs));
+    if (wait_copy) AKZ_HIP_TRY(hipEventSynchronize(c->copied));
+    return AKZ_OK;
+}
+
+extern "C" {
+
+int akz_comm_unique_id(uint8_t* id_out) {
+    if (!id_out) return AKZ_ERR_INVALID_ARG;
+    AKZ_TRY(rccl_ready());
+    ncclUniqueId id;
+    AKZ_NCCL_TRY(rccl()->GetUniqueId(&id));
+    static_assert(sizeof(id) == AKZ_COMM_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(id_out, &id, sizeof(id));
+    return AKZ_OK;
+}
+
+int akz_comm_create(int device, const uint8_t* id, int rank, int nranks, akz_comm** out) {
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) {
+        set_error("akz_comm_create: bad rank / nranks / id");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_TRY(rccl_ready());
+    AKZ_HIP_TRY(hipSetDevice(device));
+    akz_comm* c = new akz_comm;
+    c->device = device;
+    c->rank = rank;
+    c->nranks = nranks;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclResult_t st = rccl()->CommInitRank(&c->nccl, nranks, uid, rank);
+    if (st != ncclSuccess) {
+        set_error(std::string("ncclCommInitRank failed: ") + rccl()->GetErrorString(st));
+        delete c;
+        return AKZ_ERR_HIP;
+    }
+    if (hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->copied, hipEventDisableTiming) != hipSuccess) {
+        set_error("akz_comm_create: stream / event creation failed");
+        (void)rccl()->CommDestroy(c->nccl);
+        delete c;
+        return AKZ_ERR_HIP;
+    }
+    *out = c;
+    return AKZ_OK;
+}
+
+int akz_comm_destroy(akz_comm* c) {
+    if (!c) return AKZ_OK;
+    (void)hipSetDevice(c->device);
+    if (c->xs) (void)hipStreamSynchronize(c->xs);
+    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    if (c->sync_out) (void)hipFree(c->sync_out);
+    for (akz_gather* g : c->pool) {
+        gather_release_buffers(g);
+        delete g;
+    }
+    c->pool.clear();
+    if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->copied) (void)hipEventDestroy(c->copied);
+    if (c->xs) (void)hipStreamDestroy(c->xs);
+    if (c->cs) (void)hipStreamDestroy(c->cs);
+    delete c;
+    return AKZ_OK;
+}
+
+int akz_comm_info(const akz_comm* c, int* rank, int* nranks) {
+    if (!c) return AKZ_ERR_INVALID_ARG;
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    return AKZ_OK;
+}
+
+int akz_gather_begin_rows(akz_comm* c, const uint8_t* d_local, uint64_t n_local, uint64_t cap_rows, void* producer_stream,
+                          akz_gather** out) {
+    if (!c || !out || (n_local && !d_local)) {
+        set_error("akz_gather_begin_rows: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    akz_gather* g = nullptr;
+    AKZ_TRY(gather_acquire(c, cap_rows, &g));
+    const int st = gather_enqueue(c, g, &d_local, &n_local, 1, 1, (hipStream_t)producer_stream, false);
+    if (st != AKZ_OK) {
+        g->in_use = false;
+        return st;
+    }
+    *out = g;
+    return AKZ_OK;
+}
+
+int akz_gather_begin(akz_comm* c, const akz_result* const* results, uint64_t n_results, uint64_t cap_rows,
+                     akz_gather** out) {
+    if (!c || !out || (n_results && !results)) {
+        set_error("akz_gather_begin: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    std::vector<const uint8_t*> src;
+    std::vector<uint64_t> rows;
+    uint64_t images = 0;
+    for (uint64_t i = 0; i < n_results; ++i) {
+        uint64_t n_img = 0;
+        AKZ_TRY(akz_result_num_images(results[i], &n_img));
+        const uint8_t* base = nullptr;
+        uint64_t total = 0;
+        for (uint64_t img = 0; img < n_img; ++img) {  // the images' rows are back to back in one device block
+            const uint8_t* p = nullptr;
+            uint64_t n = 0;
+            AKZ_TRY(akz_result_device_descriptors(results[i], img, &p, &n));
+            if (img == 0) base = p;
+            total += n;
+        }
+        images += n_img;
+        src.push_back(base);
+        rows.push_back(base ? total : 0);
+    }
+    akz_gather* g = nullptr;
+    AKZ_TRY(gather_acquire(c, cap_rows, &g));
+    // akz_extract_finish returns with the descriptor rows complete, so there is no producer stream to wait for.  The
+    // call returns when the local rows have been copied (on the copy stream, which never queues behind a collective):
+    // the results may be freed right away.
+    int st = gather_enqueue(c, g, src.data(), rows.data(), src.size(), images, nullptr, true);
+    if (st != AKZ_OK) {
+        g->in_use = false;
+        return st;
+    }
+    *out = g;
+    return AKZ_OK;
+}
+
+int akz_gather_stream_wait(akz_gather* g, void* stream) {
+    if (!g || !g->in_use) return AKZ_ERR_INVALID_ARG;
+    AKZ_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, g->done, 0));
+    return AKZ_OK;
+}
+
+int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows, uint64_t* counts, uint64_t* images) {
+    if (!g || !g->in_use) {
+        set_error("akz_gather_finish: not a gather in flight");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    akz_comm* c = g->comm;
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    if (counts || images) {  // the headers of all blocks -> host
+        AKZ_HIP_TRY(hipEventSynchronize(g->done));
+        AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost,
+                                     c->cs));
+        AKZ_HIP_TRY(hipStreamSynchronize(c->cs));
+        for (int r = 0; r < c->nranks; ++r) {
+            const uint64_t* h = g->pinned + (size_t)r * 8;
+            if (h[2] != g->cap_rows || h[0] > g->cap_rows) {
+                set_error("gather: ranks disagree on the block capacity (every rank must pass the same cap_rows)");
+                return AKZ_ERR_INVALID_ARG;
+            }
+            if (counts) counts[r] = h[0];
+            if (images) images[r] = h[1];
+        }
+    } else {
+        AKZ_HIP_TRY(hipEventSynchronize(g->done));
+    }
+    if (d_all) *d_all = g->recv;
+    if (block_rows) *block_rows = 1 + g->cap_rows;
+    return AKZ_OK;
+}
+
+int akz_gather_free(akz_gather* g) {
+    if (!g) return AKZ_OK;
+    if (g->in_use && g->done) {
+        (void)hipSetDevice(g->comm->device);
+        (void)hipEventSynchronize(g->done);
+    }
+    g->in_use = false;
+    return AKZ_OK;
+}
+
+// SURVEY.md Appendix C form: synchronous, exact counts, rows of all ranks compacted in rank order.  Two collectives
+// (the counts, then blocks padded to the largest shard); *d_all stays valid until the next call on this communicator.
+int akz_gather_descriptors(akz_comm* c, const uint8_t* d_local, uint64_t n_local, const uint8_t** d_all, uint64_t* counts) {
+    if (!c || !d_all || !counts || (n_local && !d_local)) {
+        set_error("akz_gather_descriptors: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    *d_all = nullptr;
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    akz_gather* g0 = nullptr;  // header-only exchange: every rank learns every shard's row count
+    AKZ_TRY(gather_acquire(c, 0, &g0));
+    const uint8_t* none = nullptr;
+    const uint64_t zero = 0;
+    int st = gather_enqueue(c, g0, &none, &zero, 1, n_local, nullptr, false);
+    std::vector<uint64_t> all((size_t)c->nranks, 0);
+    if (st == AKZ_OK) st = akz_gather_finish(g0, nullptr, nullptr, nullptr, all.data());  // n_local travels as `images`
+    akz_gather_free(g0);
+    AKZ_TRY(st);
+    uint64_t cap = 1, total = 0;
+    for (uint64_t v : all) {
+        cap = std::max(cap, v);
+        total += v;
+    }
+    akz_gather* g = nullptr;
+    AKZ_TRY(gather_acquire(c, cap, &g));
+    const uint8_t* blocks = nullptr;
+    uint64_t block_rows = 0;
+    st = gather_enqueue(c, g, &d_local, &n_local, 1, 1, nullptr, false);
+    if (st == AKZ_OK) st = akz_gather_finish(g, &blocks, &block_rows, counts, nullptr);
+    if (st == AKZ_OK && c->sync_out_bytes < std::max<uint64_t>(1, total) * kRow) {
+        if (c->sync_out) (void)hipFree(c->sync_out);
+        c->sync_out = nullptr;
+        c->sync_out_bytes = 0;
+        const size_t want = (size_t)(std::max<uint64_t>(1, total) * kRow * 5 / 4);
+        if (hipMalloc((void**)&c->sync_out, want) != hipSuccess) {
+            set_error("akz_gather_descriptors: hipMalloc failed");
+            st = AKZ_ERR_HIP;
+        } else {
+            c->sync_out_bytes = want;
+        }
+    }
+    if (st == AKZ_OK) {
+        uint64_t at = 0;
+        for (int r = 0; r < c->nranks && st == AKZ_OK; ++r) {
+            if (counts[r] && hipMemcpyAsync(c->sync_out + at * kRow, blocks + ((uint64_t)r * block_rows + 1) * kRow,
+                                            counts[r] * kRow, hipMemcpyDeviceToDevice, c->cs) != hipSuccess) {
+                set_error("akz_gather_descriptors: compaction copy failed");
+                st = AKZ_ERR_HIP;
+            }
+            at += counts[r];
+        }
+        if (st == AKZ_OK && hipStreamSynchronize(c->cs) != hipSuccess) {
+            set_error("akz_gather_descriptors: synchronisation failed");
+            st = AKZ_ERR_HIP;
+        }
+    }
+    akz_gather_free(g);
+    AKZ_TRY(st);
+    *d_all = c->sync_out;
+    return AKZ_OK;
+}
+
+}  // extern "C"

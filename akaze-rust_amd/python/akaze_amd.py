@@ -61,12 +61,12 @@ STAGES = ["blur0", "contrast", "prep", "fed", "detector", "nms", "host_kp", "ori
 
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 10), ("fed_launches", C.c_uint64), ("fed_px_steps", C.c_uint64),
-                ("calls", C.c_uint64), ("pixels", C.c_uint64)]
+                ("calls", C.c_uint64), ("pixels", C.c_uint64), ("det_launches", C.c_uint64), ("det_px", C.c_uint64)]
 
     def as_dict(self):
         d = {k: self.ms[i] for i, k in enumerate(STAGES)}
         d.update(fed_launches=self.fed_launches, fed_px_steps=self.fed_px_steps, calls=self.calls,
-                 pixels=self.pixels)
+                 pixels=self.pixels, det_launches=self.det_launches, det_px=self.det_px)
         return d
 
 
@@ -148,6 +148,7 @@ def lib():
         "akz_descriptor_match": ([vp, vp, u64, vp, u64, u64, u64, f64, vp, pu64], i32),
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
+        "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
         "akz_match_features": ([vp, vp, vp, u64, vp, vp, u64, u64, f64, u64, C.c_float, vp, pu64], i32),
         "akz_write_features": ([C.c_char_p, vp, u64, vp, u64], i32),
@@ -179,6 +180,16 @@ def lib():
         "akz_ctx_set_detector_overlap": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
+        "akz_comm_unique_id": ([vp], i32),
+        "akz_comm_create": ([i32, vp, i32, i32, C.POINTER(vp)], i32),
+        "akz_comm_destroy": ([vp], i32),
+        "akz_comm_info": ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
+        "akz_gather_descriptors": ([vp, vp, u64, C.POINTER(vp), pu64], i32),
+        "akz_gather_begin": ([vp, C.POINTER(vp), u64, u64, C.POINTER(vp)], i32),
+        "akz_gather_begin_rows": ([vp, vp, u64, u64, vp, C.POINTER(vp)], i32),
+        "akz_gather_stream_wait": ([vp, vp], i32),
+        "akz_gather_finish": ([vp, C.POINTER(vp), pu64, pu64, pu64], i32),
+        "akz_gather_free": ([vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)  # AttributeError here == a symbol of include/akaze_hip.h is missing
@@ -820,6 +831,112 @@ def shard_frames(num_frames, rank, world_size):
     """Frame indices owned by `rank`: image i -> GPU i mod G; extraction needs no
     collective."""
     return list(range(rank, num_frames, world_size))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """akz_comm_unique_id: rank 0 creates it, every rank receives the same 128 bytes (any transport)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().akz_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Gather:
+    """One exchange in flight (akz_gather_begin*): finish() waits on the host, stream_wait() makes a stream wait."""
+
+    def __init__(self, comm, handle):
+        self._comm, self._h = comm, handle
+
+    def stream_wait(self, stream):
+        _check(lib().akz_gather_stream_wait(self._h, C.c_void_p(stream)))
+
+    def finish(self, want_counts=True):
+        """-> (device address of the blocks, rows per block, counts per rank, images per rank); rank r's descriptor
+        rows start one 64-byte row into block r."""
+        p, br = C.c_void_p(), C.c_uint64()
+        n = self._comm.nranks
+        cnt, img = (C.c_uint64 * n)(), (C.c_uint64 * n)()
+        _check(lib().akz_gather_finish(self._h, C.byref(p), C.byref(br), cnt if want_counts else None,
+                                       img if want_counts else None))
+        return p.value, br.value, list(cnt), list(img)
+
+    def free(self):
+        if self._h:
+            lib().akz_gather_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator of the descriptor exchange behind the C ABI (akz_comm_*): one per rank."""
+
+    def __init__(self, device, unique_id, rank, nranks):
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().akz_comm_create(int(device), buf, int(rank), int(nranks), C.byref(self._h)))
+        self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
+
+    def close(self):
+        if self._h:
+            lib().akz_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gather_begin(self, results, cap_rows):
+        """Enqueue the all-gather of the descriptor rows of `results` (ExtractResults of this rank, in order); returns
+        once the local rows are copied, never waits for the collective."""
+        arr = (C.c_void_p * max(1, len(results)))(*[r._h for r in results])
+        g = C.c_void_p()
+        _check(lib().akz_gather_begin(self._h, arr, len(results), int(cap_rows), C.byref(g)))
+        return Gather(self, g)
+
+    def gather_begin_rows(self, rows, cap_rows, producer_stream=None):
+        """The same for a torch CUDA uint8 tensor [n, 64] that is complete in the order of producer_stream."""
+        g = C.c_void_p()
+        n = int(rows.shape[0])
+        _check(lib().akz_gather_begin_rows(self._h, C.c_void_p(rows.data_ptr()) if n else None, n, int(cap_rows),
+                                           C.c_void_p(producer_stream) if producer_stream else None, C.byref(g)))
+        gg = Gather(self, g)
+        gg._keep = rows
+        return gg
+
+    def gather_descriptors(self, rows):
+        """akz_gather_descriptors: synchronous; -> (torch uint8 [sum, 64] copy, counts)."""
+        import torch
+        n = int(rows.shape[0])
+        p = C.c_void_p()
+        cnt = (C.c_uint64 * self.nranks)()
+        torch.cuda.current_stream(rows.device).synchronize()
+        _check(lib().akz_gather_descriptors(self._h, C.c_void_p(rows.data_ptr()) if n else None, n, C.byref(p), cnt))
+        counts = [int(v) for v in cnt]
+        total = sum(counts)
+        out = torch.empty((total, 64), dtype=torch.uint8, device=rows.device)
+        if total:
+            copy_d2d(out.data_ptr(), p.value, total * 64)
+        return out, counts
+
+
+def copy_d2d(dst, src, nbytes):
+    """Synchronous device-to-device copy through the HIP runtime torch already loaded (binding helper)."""
+    import torch
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    fn = hip.hipMemcpy
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    fn.restype = C.c_int
+    if fn(C.c_void_p(dst), C.c_void_p(src), nbytes, 3) != 0:  # hipMemcpyDeviceToDevice
+        raise AkazeError(-2, "hipMemcpy failed")
 
 
 def gather_descriptor_rows(local_rows, group=None, cap_rows=None):

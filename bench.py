@@ -4,29 +4,35 @@
 
     python bench.py --gpus N --steps K --warmup W [--frames F] [--width 1920 --height 1080]
 
-A "step" is one extract_features pass over this rank's shard of F frames that are already
-resident in HBM (uploaded before the timed region).  For N > 1 the step also runs the path's
-one exchange: an RCCL all-gather of the shard's descriptor rows (what a following brute-force
-match needs); extraction itself has no collective.  Rank 0 prints ONE JSON line.
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks (children with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; the parent never touches a GPU), forwards rank 0's JSON line and
+exits non-zero if any rank does.  Under torchrun (WORLD_SIZE set) it is one rank; --gpus must equal WORLD_SIZE.
+
+A "step" is one extract_features pass over this rank's shard of F frames that are already resident in HBM
+(uploaded before the timed region).  For N > 1 the step also runs the path's one exchange: an RCCL all-gather
+of the shard's descriptor rows (what a following brute-force match needs), enqueued without stalling the
+extraction pipeline and retired one step later (the last one inside the timed region); extraction itself has
+no collective.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the FED diffusion kernel (the dominant kernel): algorithmic bytes (12 B per
-                pixel-step) / HIP-event time of the FED launches inside the timed
-                steps, against 8 TB/s HBM peak.  roofline.fed_4k is the same kernel measured on
-                3840x2160 planes (the north-star's quoted point), outside the timed region.
+  roofline      the kernel with the largest share of the step (the detector march or the FED kernel): ALGORITHMIC
+                bytes per launch / average launch duration measured with HIP events on the launching
+                stream inside the timed steps, against the 8 TB/s HBM peak.  `traffic` = HBM bytes per launch from the
+                committed rocprofv3 PMC summary of the same workload (null for any other workload), `traffic_frac` =
+                that traffic / launch time / peak, i.e. real DRAM utilisation.  roofline_2 = the other of the two.
+  fed_standalone  the FED kernel alone (nothing else on the chip): on one 3840x2160 plane (north-star point; its
+                100 MB working set sits in the Infinity Cache) and on a 32 x 1920x1080 level (an HBM number).
   stage_roofline  algorithmic HBM bytes of every GPU stage / its time in one un-pipelined, fully profiled step.
-  single_frame  BASELINE configs[1] taken literally — one 1920x1080 frame per extract_features call: latency of a
-                lone call, the rate of a stream of such calls on one context, and on four contexts driven by four
-                host threads (untimed extra leg; the headline workload is the
-                32-frames-per-GPU batch of configs[3], which is what the 1/2/4/8-GPU metric shards).
-  match         the brute-force Hamming matcher on two descriptor sets (untimed extra leg): pairs/s and fraction of the
-                dense int8 MFMA rate (1024 operations per descriptor pair).
-  cpu_baseline  the CPU oracle (C++ restatement of the reference's CPU path; the Rust reference
-                cannot be built in this image) timed on the host cores on a bounded sample.
+  self_check    untimed: frames of the timed batch extracted one by one give the same keypoints and descriptor bytes.
+  single_frame  BASELINE configs[1] taken literally — one 1920x1080 frame per extract_features call.
+  match         the brute-force Hamming matcher (untimed extra leg): pairs/s and fraction of the dense int8 MFMA rate.
+  cpu_baseline  the CPU oracle (C++ restatement of the reference's CPU path; the Rust reference cannot be built in
+                this image) timed on the host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,15 +44,17 @@ FED_BYTES_PER_PX_STEP = 12.0   # read Lt + read Lflow + write Lt'  (SURVEY.md 8(
 MFMA_I8_PEAK_OPS = 5.0e15      # dense int8 MFMA rate: 2 x the 2.5 PFLOP/s bf16 figure (MI355X_MICROARCH.md)
 
 
-def pmc_traffic():
-    """HBM bytes per FED launch from the committed rocprofv3 PMC summary (profiles/), if present."""
-    p = os.path.join(ROOT, "profiles", "fed_pmc_traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary — only if it was taken on this workload."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(p))
+    except Exception:
+        return None
+    if d.get("workload") != workload:
+        return None
+    e = d.get("kernels", {}).get(kernel)
+    return e.get("hbm_bytes_per_launch") if e else None
 
 
 def effective_cpus():
@@ -72,7 +80,7 @@ def effective_cpus():
     return max(1, n)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -83,20 +91,20 @@ def main():
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
     ap.add_argument("--sublevels", type=int, default=4)
     ap.add_argument("--octaves", type=int, default=4)
-    ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 1 streaming pair, 3 fused streaming, 4 one tiled kernel, 0 tiled pair")
+    ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one tiled kernel, 0 tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
-    ap.add_argument("--det-overlap", type=int, default=0, choices=[0, 1, 2],
-                    help="detector launches on a side stream: 1 = every level as soon as its Lsmooth exists (the FED spans of "
-                         "the roofline then include the time shared with the detector kernels), 2 = the fine octaves' "
-                         "detectors next to the coarse octaves' latency-bound chain only")
+    ap.add_argument("--det-overlap", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="detector launches on a side stream: -1 = the library default, 0 = off, 1 = every level as soon "
+                         "as its Lsmooth exists, 2 = the fine octaves' detectors next to the coarse octaves' chain")
     ap.add_argument("--depth", type=int, default=1, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
     ap.add_argument("--threshold", type=float, default=None,
                     help="detector_threshold override (tuning runs: a huge value removes every extremum candidate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fed4k", action="store_true")
+    ap.add_argument("--no-fed4k", action="store_true", help="skip the stand-alone FED legs")
     ap.add_argument("--no-single", action="store_true", help="skip the single-frame-per-call leg")
     ap.add_argument("--no-match", action="store_true", help="skip the matcher leg")
+    ap.add_argument("--no-self-check", action="store_true")
     ap.add_argument("--parts", type=int, default=1,
                     help="batches per step; batches are software-pipelined on ONE stream (begin(batch j+1) is "
                          "enqueued before finish(batch j)), so the host keypoint phase of a batch runs under the "
@@ -105,77 +113,282 @@ def main():
                     help="finish every batch right after beginning it (no software pipelining): clean per-stage times")
     ap.add_argument("--no-profile", action="store_true", help="do not record stage events in the timed region")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise RCCL and run the descriptor gather even with one rank (self-test)")
-    args = ap.parse_args()
+                    help="run the descriptor exchange (RCCL) even with one rank (self-test of the N > 1 path)")
+    ap.add_argument("--exchange", choices=["capi", "torch"], default="capi",
+                    help="capi: akz_gather_begin/finish of the C ABI (own RCCL communicator, gloo only for rendezvous and "
+                         "barriers); torch: torch.distributed all_gather on the nccl backend")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test without a GPU: a stub context (sleeps, fake rows) and the gloo backend; the "
+                         "line it prints says so and is not a measurement")
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------------
+# launcher: --gpus N without torchrun
+# --------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Start one child per GPU and wait.  The parent imports nothing that could initialise a GPU."""
+    import socket
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0, failed = None, None
+    try:
+        # rank 0's stdout is small (one JSON line); read it while polling so that nobody blocks on a full pipe
+        import threading
+        buf = []
+        t = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+        t.start()
+        alive = set(range(n))
+        while alive and failed is None:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+            time.sleep(0.05)
+        if failed is None:
+            t.join(timeout=10)
+            out0 = b"".join(buf).decode("utf-8", "replace")
+    finally:
+        for p in procs:  # exactly the children started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with status {failed[1]}; the other ranks were stopped\n")
+        return 1
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if not line:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------
+# stub context (launcher / exchange self-test on a machine without GPUs)
+# --------------------------------------------------------------------------------------------------
+class _StubResult:
+    def __init__(self, rows):
+        self.num_images, self._rows = len(rows), rows
+
+    def counts(self, i):
+        return (16, self._rows[i], 61)
+
+    def close(self):
+        pass
+
+
+class _StubJob:
+    def __init__(self, rows):
+        self._rows = rows
+
+    def finish(self):
+        time.sleep(0.002)
+        return _StubResult(self._rows)
+
+
+class _StubContext:
+    """Stands in for akaze_amd.Context when --stub is given: no HIP library, no GPU, fixed row counts."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def extract_begin(self, batch, cfg, keep_all_planes=True):
+        return _StubJob([100 + 7 * self.rank + i for i in range(int(batch.shape[0]))])
+
+    def set_profiling(self, *_):
+        pass
+
+    def get_profile(self, reset=True):
+        return {k: 0.0 for k in ("blur0", "contrast", "prep", "fed", "detector", "nms", "host_kp", "orient", "mldb", "total")} | {
+            "fed_launches": 0, "fed_px_steps": 0, "det_launches": 0, "det_px": 0, "calls": 0, "pixels": 0}
+
+
+# --------------------------------------------------------------------------------------------------
+# one rank
+# --------------------------------------------------------------------------------------------------
+def main_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    import akaze_amd as A
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    stub = args.stub
     use_dist = world > 1 or args.force_dist
+    exchange = "gloo-stub" if stub else args.exchange
+    W, H, F = args.width, args.height, args.frames
+    if F < 1:
+        raise SystemExit(f"rank {rank}: --frames must be >= 1")
+
+    if stub:
+        A = None
+        dev = torch.device("cpu")
+    else:
+        import akaze_amd as A
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if exchange == "torch":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:  # rendezvous, barriers and the two scalar reductions need no GPU: gloo
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    cfg = A.Config(num_sublevels=args.sublevels, max_octave_evolution=args.octaves)  # default 4 x 4, 486-bit M-LDB
-    if args.threshold is not None:
-        cfg.detector_threshold = args.threshold
-    W, H, F = args.width, args.height, args.frames
+    def host_max(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev if exchange == "torch" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # this rank's shard of the world*F frames of a step: image i -> GPU i mod world (weak scaling)
-    frames = np.stack([A.synth_frame(W, H, i) for i in A.shard_frames(world * F, rank, world)])
-    d_frames = torch.from_numpy(frames).to(dev)
-    torch.cuda.synchronize()
+    def host_allgather(v):
+        if not use_dist:
+            return [v]
+        t = torch.tensor([v], dtype=torch.float64, device=dev if exchange == "torch" else "cpu")
+        out = torch.zeros(world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return [float(x) for x in out.tolist()]
 
-    # one context = one host thread + one HIP stream + an auxiliary stream.  The stream is a dedicated
-    # non-blocking one, never the legacy null stream: that one synchronises implicitly with every
-    # blocking stream in the process (RCCL has some) and would serialise the pipeline.
-    main = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(main)
-    ctx = A.Context(local_rank, main.cuda_stream)
-    ctx.set_detector_mode(args.det_mode)
-    ctx.set_prep_mode(args.prep_mode)
-    ctx.set_detector_overlap(args.det_overlap)
+    # ---- this rank's shard of the world*F frames of a step: image i -> GPU i mod world (weak scaling) ----
+    if stub:
+        frames = np.zeros((F, 8, 8), np.uint8)
+        d_frames = torch.from_numpy(frames)
+        cfg = None
+        ctx = _StubContext(rank)
+    else:
+        cfg = A.Config(num_sublevels=args.sublevels, max_octave_evolution=args.octaves)  # default 4 x 4, 486-bit M-LDB
+        if args.threshold is not None:
+            cfg.detector_threshold = args.threshold
+        frames = np.stack([A.synth_frame(W, H, i) for i in A.shard_frames(world * F, rank, world)])
+        d_frames = torch.from_numpy(frames).to(dev)
+        torch.cuda.synchronize()
+        # one context = one host thread + one HIP stream + an auxiliary stream.  The stream is a dedicated
+        # non-blocking one, never the legacy null stream: that one synchronises implicitly with every
+        # blocking stream in the process (RCCL has some) and would serialise the pipeline.
+        main = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(main)
+        ctx = A.Context(local_rank, main.cuda_stream)
+        ctx.set_detector_mode(args.det_mode)
+        ctx.set_prep_mode(args.prep_mode)
+        if args.det_overlap >= 0:
+            ctx.set_detector_overlap(args.det_overlap)
     NP = max(1, min(args.parts, F))
     cut = [(F * i) // NP for i in range(NP + 1)]
     batches = [d_frames[cut[i]:cut[i + 1]] for i in range(NP)]
 
-    side = torch.cuda.Stream(dev)  # collectives run here so that they never wait for the extraction stream
+    # ---- the exchange: one all-gather of descriptor rows per step, begun when the step's results exist, retired when
+    # the next step's results exist (or at the end of the timed region) ----
+    xch = {"host_ms": 0.0, "wait_ms": 0.0, "cap": 0, "pending": None, "comm": None, "mode": exchange if use_dist else "none"}
+    if use_dist and exchange == "capi":
+        try:
+            uid = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(A.comm_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(uid, src=0)
+            xch["comm"] = A.Comm(local_rank, bytes(uid.numpy().tobytes()), rank, world)
+            ok = 1.0
+        except Exception as e:  # RCCL cannot be loaded / initialised: fall back to torch.distributed on every rank
+            sys.stderr.write(f"rank {rank}: C-ABI exchange unavailable ({e}); falling back to torch.distributed\n")
+            ok = 0.0
+        if -host_max(-ok) < 0.5:  # min over ranks
+            if xch["comm"] is not None:
+                xch["comm"].close()
+                xch["comm"] = None
+            xch["mode"] = exchange = "torch"
+            xch["group"] = dist.new_group(backend="nccl")
+    if use_dist and exchange == "torch" and "group" not in xch:
+        xch["group"] = None
+    side = None if stub or not use_dist else torch.cuda.Stream(dev)  # torch collectives run here, never on the extraction stream
 
-    gather_ms = [0.0]
-    host_ms = {"begin": 0.0, "finish": 0.0, "calls": 0}  # host time inside extract_begin / extract_finish
-    gather_cap = [0]  # fixed row capacity of the padded all-gather, set from the first step
+    def agree_capacity(rows):
+        most = int(host_max(float(rows)))
+        xch["cap"] = 1 << max(10, (most + most // 2).bit_length())
 
-    def gather_descriptors(results):
-        """The path's exchange step: counts, then padded 64-byte rows over RCCL (a few MB, latency-bound).
-        Fixed capacity => no host synchronisation: both collectives are only enqueued on the side stream."""
+    def exchange_retire():
+        g = xch["pending"]
+        if g is None:
+            return
+        t0 = time.perf_counter()
+        if exchange == "capi":
+            g.finish(want_counts=False)
+            g.free()
+        elif exchange == "torch":
+            g[0].synchronize()  # event behind the collectives on the side stream
+        xch["wait_ms"] += (time.perf_counter() - t0) * 1e3
+        xch["pending"] = None
+
+    def exchange_begin(results):
         rows = sum(res.counts(i)[1] for res in results for i in range(res.num_images))
-        if gather_cap[0] == 0:
-            # every rank must pad to the SAME capacity: agree on it once (first warm-up step, one host sync); the
-            # frames of a shard are the same every step, so the row counts do not change afterwards
-            most = torch.tensor([rows], dtype=torch.int64, device=dev)
-            dist.all_reduce(most, op=dist.ReduceOp.MAX)
-            most = int(most.item())
-            gather_cap[0] = 1 << max(10, (most + most // 2).bit_length())
-        if rows > gather_cap[0]:
-            raise SystemExit(f"rank {rank}: {rows} descriptor rows exceed the agreed gather capacity {gather_cap[0]}")
-        with torch.cuda.stream(side):
-            local = torch.empty((rows, 64), dtype=torch.uint8, device=dev)
-            side.synchronize()  # the allocation above is the only thing the aux-stream copy must wait for
+        if xch["cap"] == 0:
+            # every rank must pad to the SAME capacity: agree on it once (first warm-up step); the frames of a shard
+            # are the same every step, so the row counts do not change afterwards
+            agree_capacity(rows)
+        if rows > xch["cap"]:
+            raise SystemExit(f"rank {rank}: {rows} descriptor rows exceed the agreed gather capacity {xch['cap']}")
+        exchange_retire()  # step k-1's gather: long complete
+        t0 = time.perf_counter()
+        if exchange == "capi":
+            xch["pending"] = xch["comm"].gather_begin(results, xch["cap"])
+        elif exchange == "torch":
+            cap = xch["cap"]
+            if "bufs" not in xch:  # two sets of preallocated buffers: step k's collective may still run while k+1 fills
+                xch["bufs"] = [(torch.zeros((cap, 64), dtype=torch.uint8, device=dev),
+                                torch.empty((world * cap, 64), dtype=torch.uint8, device=dev),
+                                torch.zeros(1, dtype=torch.int64, device=dev),
+                                torch.zeros(world, dtype=torch.int64, device=dev)) for _ in range(2)]
+                xch["flip"] = 0
+            local, gathered, cnt, cnts = xch["bufs"][xch["flip"]]
+            xch["flip"] ^= 1
             o = 0
             for res in results:
-                o += res.copy_device_descriptors(local[o:])  # complete on return (aux stream)
-            return A.gather_descriptor_rows(local, cap_rows=gather_cap[0])
+                o += res.copy_device_descriptors(local[o:])  # D2D on the context's aux stream, complete on return
+            with torch.cuda.stream(side):
+                cnt.fill_(rows)
+                dist.all_gather_into_tensor(cnts, cnt, group=xch["group"])
+                dist.all_gather_into_tensor(gathered, local, group=xch["group"])
+                ev = torch.cuda.Event()
+                ev.record(side)
+            xch["pending"] = (ev,)
+        xch["host_ms"] += (time.perf_counter() - t0) * 1e3
+
+    if stub:
+        def exchange_begin(results):  # noqa: F811  gloo all-gather of fake rows, synchronous
+            rows = sum(res.counts(i)[1] for res in results for i in range(res.num_images))
+            t0 = time.perf_counter()
+            cnt = torch.tensor([rows], dtype=torch.int64)
+            cnts = torch.zeros(world, dtype=torch.int64)
+            dist.all_gather_into_tensor(cnts, cnt)
+            cap = int(cnts.max().item())
+            local = torch.zeros((cap, 64), dtype=torch.uint8)
+            gathered = torch.empty((world * cap, 64), dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, local)
+            xch["host_ms"] += (time.perf_counter() - t0) * 1e3
+
+    host_ms = {"begin": 0.0, "finish": 0.0, "calls": 0}  # host time inside extract_begin / extract_finish
+    keep_last = {"on": False, "results": None}
 
     def run_steps(k_steps):
         """k_steps passes over the shard as one software-pipelined stream of k_steps*NP batches:
@@ -190,11 +403,15 @@ def main():
             if len(done) == NP:  # a whole step has finished
                 nk = sum(r.counts(i)[1] for r in done for i in range(r.num_images))
                 if use_dist:
-                    tg = time.perf_counter()
-                    gather_descriptors(done)
-                    gather_ms[0] += (time.perf_counter() - tg) * 1e3
-                for r in done:
-                    r.close()
+                    exchange_begin(done)
+                if keep_last["on"]:
+                    if keep_last["results"]:
+                        for r in keep_last["results"]:
+                            r.close()
+                    keep_last["results"] = done
+                else:
+                    for r in done:
+                        r.close()
                 done = []
 
         for _ in range(k_steps):
@@ -214,80 +431,142 @@ def main():
                     retire(res)
         while inflight:
             retire(inflight.pop(0).finish())
+        if use_dist:
+            exchange_retire()  # the last step's gather completes inside the timed region
         return nk
 
     def barrier():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     if args.warmup:
         run_steps(args.warmup)
     # one extra untimed step with full stage profiling (informational stage_ms_per_step); the timed region only
-    # records the FED spans needed for the roofline (light mode: ~30 instead of ~190 HIP events per batch)
+    # records the FED and detector spans needed for the rooflines (light mode: ~40 instead of ~190 HIP events per batch)
     ctx.set_profiling(0 if args.no_profile else 1)
     ctx.get_profile(reset=True)
     run_steps(1)
     warm_prof = ctx.get_profile(reset=True)
     ctx.set_profiling(0 if args.no_profile else 2)
+    keep_last["on"] = not stub and rank == 0 and not args.no_self_check
     barrier()
     t0 = time.perf_counter()
-    gather_ms[0] = 0.0
+    xch["host_ms"] = xch["wait_ms"] = 0.0
     host_ms.update(begin=0.0, finish=0.0, calls=0)
     nk = run_steps(args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_rank = time.perf_counter() - t0
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    keep_last["on"] = False
+    elapsed = host_max(elapsed_rank)
+    per_rank_s = host_allgather(elapsed_rank)
 
     total_px = float(W) * H * F * world * args.steps
     value = total_px / elapsed / 1e6
 
-    # ---- roofline of the dominant kernel (FED step) inside the timed region -------------------
-    fed_s = prof["fed"] / 1e3
-    fed_bytes = FED_BYTES_PER_PX_STEP * prof["fed_px_steps"]
-    achieved = fed_bytes / fed_s / 1e9 if fed_s > 0 else 0.0
-    roofline = {
-        "bound": "hbm", "kernel": A.lib().akz_fed_kernel_name().decode(),
-        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": pmc_traffic(),
-        "launches": prof["fed_launches"],
-        "avg_launch_us": round(prof["fed"] * 1e3 / max(1, prof["fed_launches"]), 2),
-        "algorithmic_bytes_per_launch": round(fed_bytes / max(1, prof["fed_launches"])),
-        "note": "all FED launches of the timed steps (levels 1..15, 1920x1080 down to 240x135); time = sum of "
-                "HIP-event spans around each level's FED launches on the launching stream",
-    }
+    if stub:
+        if rank == 0:
+            print(json.dumps({
+                "metric": "launcher self-test (stub context, no GPU work) - NOT a measurement", "value": 0.0, "unit": "Mpix/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "stub", "stub": True,
+                "config": {"workload": "stub", "frames_per_gpu": F, "exchange": "gloo all-gather of fake rows",
+                           "exchange_ms_per_step": round(xch["host_ms"] / max(1, args.steps), 3),
+                           "per_rank_ms_per_step": [round(s / max(1, args.steps) * 1e3, 3) for s in per_rank_s]}}), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
 
-    # ---- the same kernel on 3840x2160 planes (north-star target point), untimed leg -----------
+    workload_key = {"width": W, "height": H, "frames": F, "octaves": args.octaves, "sublevels": args.sublevels,
+                    "lean": bool(args.lean)}
+
+    # ---- rooflines of the two kernels that dominate the step, from HIP-event spans inside the timed region ----
+    def roof(kernel, ms, launches, alg_bytes, note):
+        s = ms / 1e3
+        achieved = alg_bytes / s / 1e9 if s > 0 else 0.0
+        avg_us = ms * 1e3 / max(1, launches)
+        tr = pmc_traffic(kernel, workload_key)
+        out = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr,
+               "traffic_frac": round(tr / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if tr and avg_us > 0 else None,
+               "launches": launches, "avg_launch_us": round(avg_us, 2),
+               "algorithmic_bytes_per_launch": round(alg_bytes / max(1, launches)),
+               "ms_per_step": round(ms / max(1, args.steps), 3), "note": note}
+        return out
+
+    det_bpp = 4 + 8 + 4 + (0 if args.lean else 12)  # Lsmooth in; Lx, Ly, Ldet (+ Lxx, Lyy, Lxy) out: each once
+    roof_det = roof(A.lib().akz_detector_kernel_name().decode(), prof["detector"], prof["det_launches"],
+                    float(det_bpp) * prof["det_px"],
+                    f"all detector launches of the timed steps ({det_bpp} B per level pixel: Lsmooth read once, every output "
+                    "plane written once); time = sum of HIP-event spans around each launch on the launching stream")
+    roof_fed = roof(A.lib().akz_fed_kernel_name().decode(), prof["fed"], prof["fed_launches"],
+                    FED_BYTES_PER_PX_STEP * prof["fed_px_steps"],
+                    "all FED launches of the timed steps (levels 1..15, 1920x1080 down to 240x135), 12 B per pixel-step "
+                    "ALGORITHMIC: up to 8 steps are fused per launch, so frac can exceed 1 — traffic_frac is the DRAM figure")
+    roofline, roofline_2 = (roof_det, roof_fed) if prof["detector"] >= prof["fed"] else (roof_fed, roof_det)
+
+    # ---- the FED kernel alone: 3840x2160 plane (north-star target point) and a 32 x 1080p level (HBM-resident) ----
+    fed_alone = None
     if rank == 0 and not args.no_fed4k:
-        w4, h4, nst = 3840, 2160, 40
-        lt = torch.rand((h4, w4), dtype=torch.float32, device=dev)
-        lf = torch.rand((h4, w4), dtype=torch.float32, device=dev)
-        taus = np.full(nst, 0.2)
-        ctx.fed_steps(lt, lf, taus)  # warm
-        ctx.set_profiling(True)
-        ctx.get_profile(reset=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ctx.fed_steps(lt, lf, taus)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        p4 = ctx.get_profile(reset=True)
-        ctx.set_profiling(False)
-        launches = max(1, p4["fed_launches"])
-        per = ms / launches * 1e3
-        gbs = FED_BYTES_PER_PX_STEP * w4 * h4 * nst / (ms * 1e-3) / 1e9
-        roofline["fed_4k"] = {"avg_launch_us": round(per, 2), "achieved": round(gbs, 1),
-                              "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst, "launches": launches,
-                              "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * w4 * h4 * nst / launches)}
-        del lt, lf
+        fed_alone = {}
+        for name, shape, nst in (("4k_plane", (2160, 3840), 40), ("level_32x1080p", (32, 1080, 1920), 8)):
+            lt = torch.rand(shape, dtype=torch.float32, device=dev)
+            lf = torch.rand(shape, dtype=torch.float32, device=dev)
+            taus = np.full(nst, 0.2)
+            ctx.fed_steps(lt, lf, taus)  # warm
+            ctx.set_profiling(True)
+            ctx.get_profile(reset=True)
+            reps = 3
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ctx.fed_steps(lt, lf, taus)
+            e1.record()
+            torch.cuda.synchronize()
+            p4 = ctx.get_profile(reset=True)
+            ctx.set_profiling(False)
+            launches = max(1, p4["fed_launches"])
+            ms = p4["fed"]  # spans around the FED launches only (the entry point's input copy is outside them)
+            px = float(np.prod(shape))
+            gbs = FED_BYTES_PER_PX_STEP * px * nst * reps / (ms * 1e-3) / 1e9
+            fed_alone[name] = {"avg_launch_us": round(ms / launches * 1e3, 2), "achieved": round(gbs, 1),
+                               "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst, "launches_per_pass": launches // reps,
+                               "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * px * nst * reps / launches)}
+            tr = pmc_traffic("k_fed_own@" + name, workload_key)
+            if tr:
+                fed_alone[name]["traffic"] = tr
+                fed_alone[name]["traffic_frac"] = round(tr / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            del lt, lf
+
+    # ---- self-check of the timed configuration (untimed): frame k of the batch == the same frame extracted alone ----
+    self_check = None
+    if rank == 0 and keep_last["results"]:
+        import hashlib
+        res_b = keep_last["results"]
+        picks = sorted(set([0, F // 2, F - 1]))
+        ok, sums = True, []
+        for k in picks:
+            part = next(i for i in range(NP) if cut[i] <= k < cut[i + 1])
+            rb, kb = res_b[part], k - cut[part]
+            single = ctx.extract_begin(d_frames[k:k + 1], cfg, keep_all_planes=not args.lean).finish()
+            a = (rb.keypoints(kb).tobytes(), rb.descriptors(kb).tobytes())
+            b = (single.keypoints(0).tobytes(), single.descriptors(0).tobytes())
+            single.close()
+            ok = ok and a == b and len(a[0]) > 0
+            sums.append(hashlib.sha256(a[0] + a[1]).hexdigest()[:16])
+        for r in res_b:
+            r.close()
+        keep_last["results"] = None
+        self_check = {"frames": picks, "identical_to_single_frame_extraction": ok, "sha256_16": sums}
+        if not ok:
+            raise SystemExit("bench.py self-check failed: a frame of the timed batch differs from its single-frame extraction")
 
     # ---- the matcher (BASELINE configs[2] / [4]: Hamming match of two descriptor sets), untimed leg, rank 0 ------
     match_leg = None
@@ -312,6 +591,26 @@ def main():
             pairs = float(n_m) * n_m
             legs.append({"n0": n_m, "n1": n_m, "ms": round(ms_m, 3), "Tpairs_per_s": round(pairs / ms_m / 1e9, 3),
                          "mfma_frac": round(pairs * 2 * 512 / (ms_m * 1e-3) / MFMA_I8_PEAK_OPS, 3)})
+        # all-pairs shape (BASELINE configs[4]): one query image against 16 train sets in one launch
+        n_q, n_sets = 11264, 16
+        dq = torch.randint(0, 256, (n_q, 64), dtype=torch.uint8, device=dev, generator=g)
+        dt = torch.randint(0, 256, (n_q * n_sets, 64), dtype=torch.uint8, device=dev, generator=g)
+        dq[:, 61:] = 0
+        dt[:, 61:] = 0
+        rows = [n_q] * n_sets
+        ctx.descriptor_match_sets_device(dq, dt, rows)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ctx.descriptor_match_sets_device(dq, dt, rows)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_s = e0.elapsed_time(e1) / 5
+        pairs = float(n_q) * n_q * n_sets
+        legs.append({"n0": n_q, "n1": n_q, "train_sets": n_sets, "ms": round(ms_s, 3),
+                     "Tpairs_per_s": round(pairs / ms_s / 1e9, 3),
+                     "mfma_frac": round(pairs * 2 * 512 / (ms_s * 1e-3) / MFMA_I8_PEAK_OPS, 3)})
         match_leg = {"kernel": "k_match_mfma (+ unpack, merge, compaction)", "bound": "mfma",
                      "peak": "%.1f POP/s int8 dense (2 x the 2.5 PFLOP/s bf16 MFMA rate)" % (MFMA_I8_PEAK_OPS / 1e15),
                      "ops_per_pair": 1024, "sets": legs}
@@ -398,7 +697,7 @@ def main():
 
     if rank == 0:
         stage_ms = {k: round(warm_prof[k], 3) for k in A.STAGES}
-        stage_ms["note"] = "one untimed step with full stage profiling, un-pipelined; timed steps record FED spans only"
+        stage_ms["note"] = "one untimed step with full stage profiling, un-pipelined; timed steps record FED and detector spans only"
         # algorithmic HBM bytes of each GPU stage of one step (SURVEY.md 8(d) model: every stage input read once, every
         # kept plane written once) against that stage's time in the profiled step: where the path stands kernel by kernel
         lv = A.plan_levels(W, H, cfg)
@@ -409,15 +708,16 @@ def main():
             "contrast": px[0] * 4 * 2,                                  # two passes over Lt0
             "prep": sum((16 + 12 if half[i] else 4 + 8) * px[i] for i in range(1, len(lv))),  # [2x2 mean: 4 px in, Lt out] Lsmooth, Lflow out
             "fed": sum(FED_BYTES_PER_PX_STEP * len(lv[i]["tau"]) * px[i] for i in range(1, len(lv))),
-            "detector": sum((4 + 8 + 8 + (4 if args.lean else 16)) * p for p in px),  # Lsmooth in; Lx, Ly out and in again; Ldet (+Lxx, Lyy, Lxy) out
+            "detector": sum(det_bpp * p for p in px),                   # Lsmooth in; Lx, Ly, Ldet (+ Lxx, Lyy, Lxy) out, each once
         }
         stage_roofline = {k: {"algorithmic_GB": round(b / 1e9, 3), "achieved_GBps": round(b / 1e9 / (warm_prof[k] * 1e-3), 1),
                               "frac": round(b / 1e9 / (warm_prof[k] * 1e-3) / HBM_PEAK_GBS, 3)}
                           for k, b in stage_bytes.items() if warm_prof[k] > 0}
+        steps = max(1, args.steps)
         out = {
             "metric": f"Mpix/s through extract_features ({args.octaves} oct x {args.sublevels} sub)",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
@@ -426,13 +726,22 @@ def main():
                        "frames_per_gpu": F, "width": W, "height": H, "batches_per_step": NP,
                        "pipelining": "begin(batch j+1) before finish(batch j) on one stream, across steps",
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
-                       "exchange": "RCCL all-gather of descriptor rows" if use_dist else "none (1 GPU)",
+                       "exchange": {"capi": "RCCL all-gather of descriptor rows through the C ABI (akz_gather_begin / _finish), "
+                                            "one fixed-size collective per step, retired one step later",
+                                    "torch": "RCCL all-gather of descriptor rows through torch.distributed, retired one step later",
+                                    "none": "none (1 GPU)"}[xch["mode"]],
+                       "exchange_ms_per_step": round((xch["host_ms"] + xch["wait_ms"]) / steps, 3),
+                       "exchange_host_ms_in_begin_per_step": round(xch["host_ms"] / steps, 3),
+                       "exchange_host_ms_waiting_per_step": round(xch["wait_ms"] / steps, 3),
+                       "per_rank_Mpix_s": [round(float(W) * H * F * args.steps / s / 1e6, 1) for s in per_rank_s],
                        "keypoints_per_step_rank0": nk,
-                       "host_ms_in_gather_per_step": round(gather_ms[0] / max(1, args.steps), 3),
                        "host_ms_in_begin_per_batch": round(host_ms["begin"] / max(1, host_ms["calls"]), 3),
                        "host_ms_in_finish_per_batch": round(host_ms["finish"] / max(1, host_ms["calls"]), 3)},
             "roofline": roofline,
+            "roofline_2": roofline_2,
+            "fed_standalone": fed_alone,
             "cpu_baseline": cpu,
+            "self_check": self_check,
             "stage_ms_per_step": stage_ms,
             "stage_roofline": stage_roofline,
             "single_frame": single,
@@ -440,8 +749,26 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if use_dist:
-        dist.barrier()  # rank 0 may still be in its untimed extra leg: all ranks leave together
+        dist.barrier()  # rank 0 may still be in its untimed extra legs: all ranks leave together
+        if xch["comm"] is not None:
+            xch["comm"].close()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:  # no launcher around us: be the launcher
+            sys.exit(launch_ranks(args, argv))
+    elif int(env_world) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: start bench.py with --gpus equal to the number of "
+                         "ranks (or without WORLD_SIZE in the environment, and it starts the ranks itself)")
+    sys.exit(main_rank(args))
 
 
 if __name__ == "__main__":

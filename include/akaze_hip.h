@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKZ_ABI_VERSION 1
+#define AKZ_ABI_VERSION 2
 
 typedef enum akz_status {
     AKZ_OK = 0,
@@ -263,6 +263,46 @@ int akz_descriptor_match_sets_device(akz_ctx* ctx, const uint8_t* d_q, uint64_t 
                                      const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
                                      double lowes_ratio, akz_match* d_out, uint64_t* d_n_out);
 
+/* ---- multi-GPU: the path's one exchange step ----------------------- */
+/* extract_features has no cross-image state (akaze/src/lib.rs:167-194): images are sharded one per GPU slot and
+   extraction needs no collective.  Before a cross-image brute-force match (feature_matching.rs:23-94 across shards)
+   the 64-byte descriptor rows of every rank are all-gathered over RCCL (xGMI).  The reference is a single-process CPU
+   crate and has no counterpart.  RCCL is loaded at run time (librccl.so.1); without it these calls return
+   AKZ_ERR_UNSUPPORTED and nothing else in the library is affected.
+   One process per GPU: rank 0 creates the id and hands its AKZ_COMM_ID_BYTES bytes to every rank by any means (a
+   file, MPI, torch.distributed); every rank then calls akz_comm_create (collective). */
+#define AKZ_COMM_ID_BYTES 128
+typedef struct akz_comm akz_comm;
+typedef struct akz_gather akz_gather; /* one exchange in flight */
+int akz_comm_unique_id(uint8_t* id_out /* AKZ_COMM_ID_BYTES */);
+int akz_comm_create(int device, const uint8_t* id, int rank, int nranks, akz_comm** out);
+int akz_comm_destroy(akz_comm* comm);
+int akz_comm_info(const akz_comm* comm, int* rank, int* nranks);
+/* Appendix C form, synchronous: every rank contributes n_local rows (device, 64 bytes each, as returned by
+   akz_result_device_descriptors); on return *d_all points at the rows of all ranks in rank order (device memory owned
+   by the communicator, valid until the next call) and counts[r] is rank r's row count (host, nranks entries). */
+int akz_gather_descriptors(akz_comm* comm, const uint8_t* d_local, uint64_t n_local, const uint8_t** d_all,
+                           uint64_t* counts /* nranks */);
+/* Pipelined form: ONE fixed-size all-gather per call, enqueued on the communicator's own streams without touching
+   the extraction stream.  Every rank contributes a block of 1 + cap_rows rows: a header row {u64 rows, u64 images,
+   u64 cap_rows, u64 sequence, 0...} followed by the descriptor rows of all images of all `results` (in order);
+   cap_rows must be the same on every rank and at least the largest shard (AKZ_ERR_BUFFER otherwise).
+   akz_gather_begin returns as soon as the local rows have been copied — the results may be freed, the next batch
+   begun — and never waits for a collective; akz_gather_begin_rows takes raw device rows that are complete in the
+   order of producer_stream (may be NULL: complete now) and must stay valid until the gather is finished. */
+int akz_gather_begin(akz_comm* comm, const akz_result* const* results, uint64_t n_results, uint64_t cap_rows,
+                     akz_gather** out);
+int akz_gather_begin_rows(akz_comm* comm, const uint8_t* d_local, uint64_t n_local, uint64_t cap_rows,
+                          void* producer_stream, akz_gather** out);
+/* make `stream` (e.g. the matcher's) wait for the gathered blocks without a host synchronisation */
+int akz_gather_stream_wait(akz_gather* g, void* stream);
+/* host wait.  *d_all: nranks blocks of *block_rows (= 1 + cap_rows) rows, rank r's descriptor rows start one row into
+   block r; counts / images (host, nranks entries, may be NULL) are read from the headers.  Rows beyond a rank's count
+   are unspecified. */
+int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows, uint64_t* counts, uint64_t* images);
+/* hand the blocks back to the communicator (waits for the collective if it is still running) */
+int akz_gather_free(akz_gather* g);
+
 /* ---- the rest of match_features (host post-filter) -------------------- */
 /* ops::estimate_fundamental_matrix::remove_outliers — estimate_fundamental_matrix.rs:99-165: 8-point
    fundamental matrix + RANSAC over the matches; fewer than 8 matches are returned unchanged.  Host code.
@@ -326,9 +366,11 @@ typedef struct akz_profile {
     uint64_t fed_px_steps;   /* sum over launches of pixels x steps advanced (x batch)       */
     uint64_t calls;          /* extract calls accumulated                                     */
     uint64_t pixels;         /* input pixels accumulated (w*h*n per call)                     */
+    uint64_t det_launches;   /* detector kernel launches inside AKZ_ST_DETECTOR               */
+    uint64_t det_px;         /* sum over those launches of level pixels (x batch)             */
 } akz_profile;
-/* on: 0 = off, 1 = every stage (two HIP events per stage and level), 2 = light: only the FED spans and the
-   host-clock stages (what bench.py uses inside its timed region) */
+/* on: 0 = off, 1 = every stage (two HIP events per stage and level), 2 = light: only the FED and detector spans and
+   the host-clock stages (what bench.py uses inside its timed region) */
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
 /* FED kernel variant: 2 (default) = k_fed_own, LDS tile + register ownership, up to 8 explicit steps
@@ -360,8 +402,9 @@ int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
 int akz_ctx_set_detector_overlap(akz_ctx* ctx, int on);
 /* Same choice for the level-preparation kernel (Lsmooth, Lflow of a level). */
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
-/* name of the default FED kernel (for bench / profiles) */
+/* names of the default FED kernel and of the detector kernel that large launches take (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
+const char* akz_detector_kernel_name(void);
 
 /* ---- image ingest, options files (host code) -------------------- */
 /* What `image::open(path)` hands to the crate (akaze/src/lib.rs:171): JPEG (baseline / progressive

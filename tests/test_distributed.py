@@ -140,3 +140,42 @@ def test_all_pairs_match_gloo(tmp_path, sizes):
     for (i, j), m in seen.items():
         assert m == _np_match(everything[i], everything[j]), (i, j)
 
+
+
+def _bench(*args, env=None, timeout=240):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`bench.py --gpus 2` without torchrun must run TWO ranks (stub context + gloo here: no GPU in this container),
+    forward rank 0's JSON line and report n_gpus 2 with one figure per rank."""
+    import json
+    p = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "4", "--stub")
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["stub"] is True and out["steps"] == 3
+    assert len(out["config"]["per_rank_ms_per_step"]) == 2
+    assert out["config"]["exchange_ms_per_step"] > 0
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus N with a different WORLD_SIZE is an error, never a silent run at another size."""
+    p = _bench("--gpus", "2", "--stub", env={"WORLD_SIZE": "4", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+    p = _bench("--gpus", "1", "--stub", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that dies takes the launch down with a non-zero status (no hang, no JSON line)."""
+    p = _bench("--gpus", "2", "--stub", "--frames", "0")  # zero frames: every rank raises
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

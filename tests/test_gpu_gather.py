@@ -1,0 +1,65 @@
+"""The path's one exchange step through the C ABI (akz_comm_* / akz_gather_*) on one
+GPU: RCCL with a single rank exercises communicator creation, the copy / exchange streams, the wire format and
+both call forms; the multi-rank form of the same binary is `gather_selftest RANK NRANKS ID_FILE` on a multi-GPU node."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "akaze-rust_amd", "bin")
+
+
+def test_gather_selftest_binary_world1():
+    p = subprocess.run([os.path.join(BIN, "gather_selftest")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "gather selftest ok: rank 0 of 1" in p.stdout
+
+
+def test_comm_gather_matches_local_rows(ctx, amd):
+    import torch
+    comm = amd.Comm(0, amd.comm_unique_id(), 0, 1)
+    frames = torch.from_numpy(np.stack([amd.synth_frame(320, 240, i) for i in range(3)])).cuda()
+    res = ctx.extract_features(frames, keep_all_planes=False)
+    rows = sum(res.counts(i)[1] for i in range(3))
+    local = torch.zeros((rows, 64), dtype=torch.uint8, device="cuda")
+    assert res.copy_device_descriptors(local) == rows
+    host = np.concatenate([np.pad(res.descriptors(i), ((0, 0), (0, 3))) for i in range(3)])
+    assert np.array_equal(local.cpu().numpy(), host)
+    # Appendix C form
+    allrows, counts = comm.gather_descriptors(local)
+    assert counts == [rows] and torch.equal(allrows, local)
+    # pipelined form: two gathers in flight, retired in order
+    cap = rows + 100
+    g1 = comm.gather_begin([res], cap)
+    g2 = comm.gather_begin_rows(local, cap, torch.cuda.current_stream().cuda_stream)
+    for g, n_img in ((g1, 3), (g2, 1)):
+        g.stream_wait(torch.cuda.current_stream().cuda_stream)
+        p, block_rows, cnt, img = g.finish()
+        assert block_rows == cap + 1 and cnt == [rows] and img == [n_img]
+        out = torch.empty((rows, 64), dtype=torch.uint8, device="cuda")
+        amd.copy_d2d(out.data_ptr(), p + 64, rows * 64)
+        assert torch.equal(out, local)
+        g.free()
+    with pytest.raises(amd.AkazeError) as e:
+        comm.gather_begin([res], rows - 1)
+    assert e.value.status == -7
+    res.close()
+    comm.close()
+
+
+def test_bench_force_dist_capi_world1():
+    """bench.py's N > 1 code path (gloo rendezvous + C-ABI exchange, retired one step late) with one rank."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--frames", "4", "--no-cpu-baseline", "--no-fed4k", "--no-single", "--no-match"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and "C ABI" in out["config"]["exchange"]
+    assert out["self_check"]["identical_to_single_frame_extraction"] is True
+    assert out["roofline"]["kernel"] and out["roofline_2"]["kernel"]

@@ -77,20 +77,14 @@ struct akz_ctx {
     bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
-    // Second lane for SMALL jobs (a lone frame's pyramid is a chain of ~45 dependent dispatches that leaves the chip
-    // mostly idle): consecutive small jobs alternate between the context's stream and `lane1`, each lane with its own
-    // temporaries, so that the chains of two jobs in flight overlap (opt-in: AKZ_LANES=1; see extract_begin)
-    hipStream_t lane1 = nullptr;
-    DevBuf scratch1[6], small1;
-    int next_lane = 0;
     hipStream_t det = nullptr;          // detector launches of a level, concurrent with the diffusion of later levels
     int det_overlap = 0;                // 1: every level's detector on `det` as soon as its Lsmooth exists; 2: the fine
                                         // octaves' detectors on `det` once the coarse octaves start (akz_ctx_set_detector_overlap)
     // stage profiling (akz_ctx_set_profiling)
     uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
     int prep_mode = 2;  // same values as det_mode, for the level-preparation kernel
-    int det_mode = 2;  // 0: tiled LDS detector kernels, 1: streaming kernels wherever supported, 2: auto
-    int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 1: k_fed_fused, 2: k_fed_own (both <= 8 steps/launch)
+    int det_mode = 2;  // 0: tiled pair, 2: auto, 4: one tiled kernel, 5: column march (akz_ctx_set_detector_mode)
+    int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 2: k_fed_own (<= 8 steps/launch; <= 16 for small launches)
     int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
     akz_profile prof{};
     struct Span { int stage; hipEvent_t a, b; };
@@ -123,7 +117,7 @@ struct StageTimer {
     bool on;
     hipStream_t s;
     StageTimer(akz_ctx* ctx, int st, hipStream_t stream = nullptr) : c(ctx), stage(st), s(stream ? stream : ctx->stream) {
-        on = c->profiling >= 2 || (c->profiling == 1 && (st == AKZ_ST_FED || st == AKZ_ST_DETECTOR));
+        on = c->profiling >= 2 || (c->profiling == 1 && (st == AKZ_ST_FED || (st == AKZ_ST_DETECTOR && s == ctx->stream)));
         if (!on) return;
         a = get(c);
         b = get(c);
@@ -159,7 +153,6 @@ static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return AKZ_OK;
     if (b.p) {
         AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->lane1) AKZ_HIP_TRY(hipStreamSynchronize(c->lane1));
         if (c->aux) AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
         AKZ_HIP_TRY(hipFree(b.p));
         b.p = nullptr;
@@ -271,14 +264,6 @@ int akz_ctx_destroy(akz_ctx* c) {
     if (!c) return AKZ_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->lane1) {
-        (void)hipStreamSynchronize(c->lane1);
-        (void)hipStreamDestroy(c->lane1);
-        c->lane1 = nullptr;
-    }
-    for (DevBuf& b : c->scratch1)
-        if (b.p) (void)hipFree(b.p);
-    if (c->small1.p) (void)hipFree(c->small1.p);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
                       &c->small, &c->cand, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
@@ -569,8 +554,7 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
             float ht[2 * kFedMaxFuse];
             for (uint32_t j = 0; j < cnt; ++j) ht[j] = 0.5f * (float)taus[done + j];
             done += cnt;
-            launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt,
-                              c->fed_mode);
+            launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt);
         }
         cur = dst;
     }
@@ -582,43 +566,25 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
     return AKZ_OK;
 }
 
-// Detector kernel family of one level: 0 = LDS-tiled pair, 1 = streaming pair, 3 = fused streaming kernel,
-// 4 = one LDS-tiled kernel (k_detector_tiled: 495-545 us at 32 x 1080p with all planes kept, 122-129 at 960x540,
-// 37-41 at 480x270, 14-19 at 240x135 — ahead of the tiled pair stand-alone, level with it inside the pipelined
-// extraction of a batch, and clearly ahead for small launches and single frames, where it halves the launches).
-// Measured on MI355X per level of a 32-frame batch (tools/det_levels.py, microseconds, sigma_size 3):
-//                    keep Lxx/Lyy/Lxy: tiled  pair  fused      not kept: tiled  pair  fused
-//   32 x 1920x1080                      535   503    547                  425   387    443
-//   32 x  960x540                       127   139    149                  110    90    115
-//   32 x  480x270                        43    47     34                   39    44     35
-//   32 x  240x135                        20    33     29                   19    28     29
-// (the fused kernel runs one wave per SIMD and only wins where the launch is latency-bound but still fills the
-// chip; the smallest launches are cheapest on the tiled kernels).  Inside the pipelined extraction the streaming
-// pair loses its stand-alone edge at full resolution when all planes are kept (detector stage 4.2 vs 3.9 ms per
-// batch).  With candidate slots reserved in blocks in both families (once per tile, tile_extrema; per wave buffer of
-// 32, wave_cands_push) the tiled kernels are ahead with all planes kept (detector stage 3.34 vs 3.82 ms) and level
-// without them (3.01 vs 2.80 ms stage time, 9.94 vs 9.93 Gpix/s end to end), so the streaming pair is not chosen
-// automatically; det_mode 1 / 3 select it.  AKZ_DET_RULE=a,b,c[,d] overrides the pixel-count thresholds.
+// Detector kernel family of one launch: 0 = LDS-tiled pair (k_deriv1 + k_deriv2: the fallback for kernel sizes and
+// image sizes the other two do not cover), 4 = one LDS-tiled kernel (k_detector_tiled: small launches and single
+// frames, where extract_begin also groups levels of equal sigma_size into one launch), 5 = the one-pass column march
+// (k_detector_march, akz_march.hip: large launches).  Measured on MI355X per level of a 32-frame batch, all planes
+// kept (tools/march_probe.py, microseconds, sigma_size 3): 1920x1080 555 / 503 / 350, 960x540 140 / 124 / 82,
+// 480x270 45 / 41 / 66 (pair / tiled / march).  AKZ_MARCH_MIN_PX overrides the size from which the march is taken.
 static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
                            bool keep_second, bool nms = true) {
+    (void)keep_second;
+    if (c->det_mode == 0) return 0;
     if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;
-    if (c->det_mode == 0 || !launch::detector_stream_supported(sigma, w, h, border_m, nms)) return 0;
-    if (c->det_mode == 1 || c->det_mode == 3) return c->det_mode;
-    static uint64_t pair_keep = ~0ull, pair_lean = ~0ull, fused_min = 2u << 20, tiled1_max = 8u << 20;
-    static bool init = false;
-    if (!init) {
-        init = true;
-        if (const char* e = getenv("AKZ_DET_RULE")) {
-            unsigned long long a = 0, b = 0, f = 0, t1 = 0;
-            const int got = sscanf(e, "%llu,%llu,%llu,%llu", &a, &b, &f, &t1);
-            if (got >= 3) { pair_keep = a; pair_lean = b; fused_min = f; }
-            if (got == 4) tiled1_max = t1;
-        }
-    }
+    if (c->det_mode == 5) return launch::detector_march_supported(sigma, w, h, border_m, nms) ? 5 : 0;
+    static const uint64_t march_min = [] {
+        const char* e = getenv("AKZ_MARCH_MIN_PX");
+        return e ? (uint64_t)atoll(e) : (uint64_t)(8u << 20);
+    }();
     const uint64_t px = (uint64_t)w * h * n;
-    if (px >= (keep_second ? pair_keep : pair_lean)) return 1;
-    // small launches: the one-kernel tiled form, which extract_begin also batches across levels of equal sigma_size
-    if (px < tiled1_max && launch::detector_tiled_fused_supported(sigma)) return fused_min == 0 ? 3 : 4;
+    if (px >= march_min && launch::detector_march_supported(sigma, w, h, border_m, nms)) return 5;
+    if (px < march_min && launch::detector_tiled_fused_supported(sigma)) return 4;
     return 0;
 }
 
@@ -630,7 +596,7 @@ static int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float
     }
     AKZ_TRY(check_plane_args(lsmooth, ldet_out, w, h, n, (int)sigma));
     if (const int fam = detector_family(c, sigma, w, h, n, 0.0f, lxx && lyy && lxy, false)) {
-        (fam == 4 ? launch::detector_tiled_fused : fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+        (fam == 5 ? launch::detector_march : launch::detector_tiled_fused)(
             c->stream, lsmooth, sigma, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, 0, 0.0f, 0.0f, nullptr, 0, nullptr);
         AKZ_HIP_TRY(hipGetLastError());
         return AKZ_OK;
@@ -749,6 +715,7 @@ int akz_op_fed_steps(akz_ctx* c, float* d_lt, const float* d_lflow, float* d_lst
     float* B = (float*)c->scratch[5].p;
     float* in = (float*)c->scratch[3].p;
     AKZ_HIP_TRY(hipMemcpyAsync(in, d_lt, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
+    StageTimer st(c, AKZ_ST_FED);  // the launches alone, without the copy above (stand-alone roofline legs of bench.py)
     return fed_impl(c, in, d_lt, B, d_lflow, d_lstep, w, h, n, taus, n_tau);
 }
 int akz_op_detector_response(akz_ctx* c, const float* d_lsmooth, uint32_t sigma_size, float* d_lx, float* d_ly,
@@ -801,7 +768,6 @@ static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
 static void slab_release(akz_ctx* c, void* p, size_t bytes) {
     if (c->slab_pool.size() >= 8) {
         (void)hipStreamSynchronize(c->stream);
-        if (c->lane1) (void)hipStreamSynchronize(c->lane1);
         if (c->aux) (void)hipStreamSynchronize(c->aux);
         (void)hipFree(c->slab_pool.front().second);
         c->slab_pool.erase(c->slab_pool.begin());
@@ -851,7 +817,6 @@ static void job_destroy(akz_job* j) {
     akz_ctx* c = j->r ? j->r->ctx : nullptr;
     if (c) {
         (void)hipStreamSynchronize(c->stream);
-        if (c->lane1) (void)hipStreamSynchronize(c->lane1);
         if (j->slot >= 0) c->slot_busy[j->slot] = false;
         if (j->nms_done) c->ev_pool.push_back(j->nms_done);
         result_release_device(j->r.get());
@@ -891,45 +856,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     const std::vector<LevelPlan>& plan = r->plan;
     const size_t L = plan.size();
     const bool keep_all = (flags & AKZ_KEEP_ALL_PLANES) != 0;
-    // ---- lane: small jobs alternate between the context's stream and a second one with its own temporaries, so that
-    // the launch chains of consecutive jobs in flight overlap instead of queueing behind each other (a lone 1080p
-    // frame: 0.59 ms of dependent dispatches).  Everything below — helpers included — sees the lane's stream and
-    // buffers as c->stream / c->scratch / c->small; the swap is undone when this function returns. ----
-    static const uint64_t lane_max_px = [] {
-        // Off unless AKZ_LANES=1: measured on a stream of lone 1080p frames it gives 0.586 -> 0.576 ms per frame with
-        // two jobs in flight and 0.556 with three — the host thread (begin 0.14 ms + finish 0.41 ms with its three
-        // round trips) is what such a stream is bound by once the chains overlap.
-        const char* e = std::getenv("AKZ_LANES");
-        if (!e || std::atoi(e) == 0) return (uint64_t)0;
-        const char* m = std::getenv("AKZ_LANE_MAX_PX");
-        return m ? (uint64_t)std::atoll(m) : (uint64_t)(8u << 20);
-    }();
-    bool lane_b = false;
-    if ((uint64_t)w * h * n < lane_max_px && c->det_overlap == 0 && c->profiling == 0) {
-        lane_b = c->next_lane != 0;
-        c->next_lane ^= 1;
-    }
-    struct LaneSwap {
-        akz_ctx* c;
-        bool on;
-        void flip() const {
-            std::swap(c->stream, c->lane1);
-            for (int i = 0; i < 6; ++i) std::swap(c->scratch[i], c->scratch1[i]);
-            std::swap(c->small, c->small1);
-        }
-        ~LaneSwap() {
-            if (on) flip();
-        }
-    } lane{c, false};
-    if (lane_b) {
-        if (!c->lane1) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->lane1, hipStreamNonBlocking));
-        hipEvent_t ready = StageTimer::get(c);  // the frames are ready in the order of the context's stream
-        AKZ_HIP_TRY(hipEventRecord(ready, c->stream));
-        AKZ_HIP_TRY(hipStreamWaitEvent(c->lane1, ready, 0));
-        c->ev_pool.push_back(ready);
-        lane.flip();
-        lane.on = true;
-    }
     hipStream_t s = c->stream;
 
     // ---- pyramid slab layout ----
@@ -1003,7 +929,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         if (const int fam = detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
             StageTimer st(c, AKZ_ST_DETECTOR, st_);
-            (fam == 4 ? launch::detector_tiled_fused : fam == 3 ? launch::detector_fused_stream : launch::detector_stream)(
+            (fam == 5 ? launch::detector_march : launch::detector_tiled_fused)(
                 st_, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX), P(l, AKZ_LYY),
                 P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr, bm, d_cand, cap, d_count);
             return true;
@@ -1997,7 +1923,7 @@ int akz_write_evolutions(const akz_result* r, uint64_t img, const char* dir) {
 }
 
 int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 4) return AKZ_ERR_INVALID_ARG;
+    if (!c || (mode != 0 && mode != 2 && mode != 4 && mode != 5)) return AKZ_ERR_INVALID_ARG;
     c->det_mode = mode;
     return AKZ_OK;
 }
@@ -2027,11 +1953,11 @@ int akz_ctx_set_match_mode(akz_ctx* c, int mode) {
 }
 int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
-    if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
+    if (mode != 0 && mode != 2) return AKZ_ERR_INVALID_ARG;
     c->fed_mode = mode;
     return AKZ_OK;
 }
 const char* akz_fed_kernel_name(void) { return "k_fed_own"; }
-const char* akz_detector_kernel_name(void) { return "k_deriv1 + k_deriv2"; }
+const char* akz_detector_kernel_name(void) { return "k_detector_march"; }
 
 }  // extern "C"

@@ -116,11 +116,10 @@ void flow(hipStream_t s, const float* lsmooth, float* lflow, uint32_t w, uint32_
           uint32_t k_scale_pow);
 void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
               uint32_t h, uint32_t n, float half_tau);
-// n_steps <= 8 explicit steps in one launch (LDS-tiled, temporally fused).  variant 2: register
-// ownership (k_fed_own), variant 1: all values through LDS (k_fed_fused)
+// n_steps <= 16 explicit steps in one launch of k_fed_own (LDS tile + register ownership, temporally fused)
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
-               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps, int variant);
-// workgroups of a 9..16-step launch (64 x 10 tiles); fed_fused takes up to 16 steps with variant 2
+               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps);
+// workgroups of a 9..16-step launch (64 x 10 tiles)
 uint64_t fed_deep_workgroups(uint32_t w, uint32_t h, uint32_t n);
 void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,
                   unsigned long long* d_hmax_bits);
@@ -156,9 +155,6 @@ void detector_tiled_set(hipStream_t s, uint32_t sigma, const DetLevelDesc* level
 void detector_tiled_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                           float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
                           float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
-void detector_fused_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
-                           float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
-                           float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 // streaming 5-tap gaussian_blur (akz_stream.hip)
 bool blur5_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, bool is_u8);
 void blur5_stream_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
@@ -171,11 +167,11 @@ void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uin
 bool prep_stream_supported(uint32_t w, uint32_t h);
 void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, float* lsmooth, float* lflow, uint32_t w,
                  uint32_t h, uint32_t pw, uint32_t ph, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow);
-// streaming (register-ring, barrier-free) detector of one level, akz_stream.hip; d_cand == nullptr: no extrema test
-bool detector_stream_supported(uint32_t sigma, uint32_t w, uint32_t h, float border_m, bool nms);
-void detector_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
-                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level, float thr,
-                     float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
+// one-pass column march (akz_march.hip): 256-thread workgroups own 512-column strips, two columns per thread
+bool detector_march_supported(uint32_t sigma, uint32_t w, uint32_t h, float border_m, bool nms);
+void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
+                    float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level, float thr,
+                    float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 bool detector_nms_fused_supported(uint32_t sigma);
 void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
@@ -241,41 +237,21 @@ float border_margin(const LevelPlan& lv, const akz_config& cfg);  // smax * sigm
 
 }  // namespace akz
 
-// ---- plane stores (device code only) -------------------------------------------------------------------------
-// Output planes are written once and not read again by the kernel that writes them.  Streaming (nontemporal) stores
-// lift what a tiled COPY-ONLY kernel reaches from 5.1 to 7.2 TB/s at one plane read : two written and from 5.1 to
-// 6.4 TB/s at 1 : 6 (tools/membw/tilebw n, profiles/r01_tile_bandwidth.txt) — but the stencil and FED kernels
-// measured the same with them (level preparation 1.12-1.15 against 1.16 ms, detector 3.29-3.37 against 3.40 ms per
-// 32-frame step, results identical): they are bound by their on-chip dependency chains, not by the store path.
-// AKZ_NT_STORES=1 builds the streaming form (A/B runs); the default keeps ordinary stores.
+// ---- plane stores (device code only) --------------------------------------------------------------------------
+// The tiled stencil / FED kernels use ordinary stores: streaming (nontemporal) stores measured the same there in
+// round 1 (those kernels are bound by their on-chip dependency chains); the column march (akz_march.hip), which IS
+// bound by the store path, uses them (+20 %).
 #if defined(__HIPCC__)
-#ifndef AKZ_NT_STORES
-#define AKZ_NT_STORES 0
-#endif
 namespace akz {
 typedef float akz_f4a __attribute__((ext_vector_type(4)));                // 16-byte aligned group of four pixels
 typedef float akz_f4u __attribute__((ext_vector_type(4), aligned(4)));    // dword-aligned group of four pixels
-__device__ __forceinline__ void plane_store(float* p, float v) {
-#if AKZ_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void plane_store(float* p, float v) { *p = v; }
 __device__ __forceinline__ void plane_store4(float* p, float a, float b, float c, float d) {  // p 16-byte aligned
     const akz_f4a t = {a, b, c, d};
-#if AKZ_NT_STORES
-    __builtin_nontemporal_store(t, reinterpret_cast<akz_f4a*>(p));
-#else
     *reinterpret_cast<akz_f4a*>(p) = t;
-#endif
 }
 __device__ __forceinline__ void plane_store4u(float* p, akz_f4a t) {  // p dword-aligned
-#if AKZ_NT_STORES
-    __builtin_nontemporal_store((akz_f4u)t, reinterpret_cast<akz_f4u*>(p));
-#else
     *reinterpret_cast<akz_f4u*>(p) = t;
-#endif
 }
 }  // namespace akz
 #endif

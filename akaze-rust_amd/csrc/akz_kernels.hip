@@ -164,143 +164,14 @@ __device__ __forceinline__ float from_right_lane(float v) {  // lane i receives 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-template <bool INNER>
-__device__ __forceinline__ float4 fed_group(const float4 lc, const float4 cc, const float4 ln, const float4 cn,
-                                            const float4 ls, const float4 cs, float lw, float cw, float le, float ce,
-                                            int gx, int gy, int w, int h, float half_tau, float4& step) {
-    const float l[6] = {lw, lc.x, lc.y, lc.z, lc.w, le};
-    const float c[6] = {cw, cc.x, cc.y, cc.z, cc.w, ce};
-    const float lN[4] = {ln.x, ln.y, ln.z, ln.w}, cN[4] = {cn.x, cn.y, cn.z, cn.w};
-    const float lS[4] = {ls.x, ls.y, ls.z, ls.w}, cS[4] = {cs.x, cs.y, cs.z, cs.w};
-    float xf[5];  // xf[i] = flux between pixel i-1 and i of the group (i = 0 is the west neighbour)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) xf[i] = (c[i] + c[i + 1]) * (l[i + 1] - l[i]);
-    float out[4], st[4];
-    const bool hyp = INNER || (gy + 1 < h), hyn = INNER || (gy > 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float lv = l[i + 1], cv = c[i + 1];
-        const bool hxp = INNER || (gx + i + 1 < w), hxn = INNER || (gx + i > 0);
-        float t = hxp ? (hxn ? xf[i + 1] - xf[i] : xf[i + 1]) : -xf[i];
-        if (hyp) {
-            t = t + (cv + cS[i]) * (lS[i] - lv);
-            if (hyn) t = t - (cN[i] + cv) * (lv - lN[i]);
-        } else {
-            t = t + (cv + cN[i]) * (lN[i] - lv);
-        }
-        st[i] = half_tau * t;
-        out[i] = lv + st[i];
-    }
-    step = make_float4(st[0], st[1], st[2], st[3]);
-    return make_float4(out[0], out[1], out[2], out[3]);
-}
-
-template <int TW, int TH, int HALO, int NT>
-__global__ void __launch_bounds__(NT)
-k_fed_fused(const float* __restrict__ L_in, const float* __restrict__ C, float* __restrict__ L_out,
-            float* __restrict__ Lstep, int w, int h, FedTaus ht) {
-    constexpr int RW = TW + 2 * HALO;    // region width in pixels (multiple of 4)
-    constexpr int XG = RW / 4;           // float4 groups per region row
-    constexpr int RP = RW + 8;           // LDS pitch: 4 pad floats on each side
-    constexpr int RHMAX = TH + 2 * HALO;
-    constexpr int PLANE = (RHMAX + 2) * RP;  // one pad row above and below
-    __shared__ __attribute__((aligned(16))) float sL[2][PLANE];
-    __shared__ __attribute__((aligned(16))) float sC[PLANE];
-    const int tid = threadIdx.x;
-    const int n = ht.n;
-    const int RH = TH + 2 * n;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
-    const bool vec_ok = (w & 3) == 0;
-    auto lds = [&](int ly, int lx) { return (ly + 1) * RP + 4 + lx; };
-
-    // ---- stage the region (out-of-image pixels read as 0 and are never used by in-image ones) ----
-    for (int idx = tid; idx < RH * XG; idx += NT) {
-        const int ly = idx / XG, g = idx - ly * XG;
-        const int gy = y0 - n + ly, gx = x0 - HALO + 4 * g;
-        float4 vl = make_float4(0.f, 0.f, 0.f, 0.f), vc = vl;
-        if (gy >= 0 && gy < h && gx + 3 >= 0 && gx < w) {
-            const float* pl = L_in + base + (size_t)gy * w;
-            const float* pc = C + base + (size_t)gy * w;
-            if (vec_ok && gx >= 0 && gx + 3 < w) {
-                vl = *reinterpret_cast<const float4*>(pl + gx);
-                vc = *reinterpret_cast<const float4*>(pc + gx);
-            } else {
-                float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (gx + e >= 0 && gx + e < w) {
-                        a[e] = pl[gx + e];
-                        b[e] = pc[gx + e];
-                    }
-                vl = make_float4(a[0], a[1], a[2], a[3]);
-                vc = make_float4(b[0], b[1], b[2], b[3]);
-            }
-        }
-        *reinterpret_cast<float4*>(&sL[0][lds(ly, 4 * g)]) = vl;
-        *reinterpret_cast<float4*>(&sC[lds(ly, 4 * g)]) = vc;
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int s = 1; s <= n; ++s) {
-        const int m = n - s;             // pixels beyond the centre that later steps still need
-        const int mx = (m + 3) & ~3;
-        const int ly0 = n - m, rows = TH + 2 * m;
-        const int g0 = (HALO - mx) / 4, groups = (TW + 2 * mx) / 4;
-        const bool last = s == n;
-        const float half_tau = ht.half_tau[s - 1];
-        const float* src = sL[cur];
-        float* dst = sL[cur ^ 1];
-        for (int idx = tid; idx < rows * groups; idx += NT) {
-            const int r = idx / groups, g = g0 + (idx - r * groups);
-            const int ly = ly0 + r;
-            const int gy = y0 - n + ly, gx = x0 - HALO + 4 * g;
-            if (gy < 0 || gy >= h || gx >= w || gx + 3 < 0) continue;
-            const int o = lds(ly, 4 * g);
-            const float4 lc = *reinterpret_cast<const float4*>(src + o);
-            const float4 ln = *reinterpret_cast<const float4*>(src + o - RP);
-            const float4 ls = *reinterpret_cast<const float4*>(src + o + RP);
-            const float4 cc = *reinterpret_cast<const float4*>(sC + o);
-            const float4 cn = *reinterpret_cast<const float4*>(sC + o - RP);
-            const float4 cs = *reinterpret_cast<const float4*>(sC + o + RP);
-            const float lw = src[o - 1], le = src[o + 4], cw = sC[o - 1], ce = sC[o + 4];
-            const bool inner = gy >= 1 && gy + 1 < h && gx >= 1 && gx + 4 < w;
-            float4 st;
-            const float4 res = inner ? fed_group<true>(lc, cc, ln, cn, ls, cs, lw, cw, le, ce, gx, gy, w, h, half_tau, st)
-                                     : fed_group<false>(lc, cc, ln, cn, ls, cs, lw, cw, le, ce, gx, gy, w, h, half_tau, st);
-            if (!last) {
-                *reinterpret_cast<float4*>(dst + o) = res;
-            } else {  // m == 0: exactly the centre tile -> straight to HBM
-                float* po = L_out + base + (size_t)gy * w;
-                float* ps = Lstep ? Lstep + base + (size_t)gy * w : nullptr;
-                if (vec_ok && gx >= 0 && gx + 3 < w) {
-                    *reinterpret_cast<float4*>(po + gx) = res;
-                    if (ps) *reinterpret_cast<float4*>(ps + gx) = st;
-                } else {
-                    const float rv[4] = {res.x, res.y, res.z, res.w}, sv[4] = {st.x, st.y, st.z, st.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (gx + e >= 0 && gx + e < w) {
-                            po[gx + e] = rv[e];
-                            if (ps) ps[gx + e] = sv[e];
-                        }
-                }
-            }
-        }
-        if (!last) __syncthreads();
-        cur ^= 1;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// FED with register ownership (the default).  Same tile / halo / bit-exactness argument as
-// k_fed_fused, different data movement: every thread OWNS two vertically adjacent float4 groups
+// FED with register ownership (the default).  Tile / halo / bit-exactness argument as above; data movement:
+// every thread OWNS two vertically adjacent float4 groups
 // of the region for all n fused steps.  Its Lt values stay in registers, the Lflow pair sums
 // (c + c_neighbour), which are constant over the steps of a level, are formed once, left/right
-// neighbours come from the adjacent lanes by shuffle, and LDS is touched only for the row above and
-// the row below (2 x b128 read + 2 x b128 write per thread and step instead of 6 x b128 + 4
-// bank-conflicted b32 reads per group).  All threads run every step on the whole region (stale
+// neighbours come from the adjacent lanes by a DPP move, and LDS is touched only for the row above and
+// the row below (2 x b128 read + 2 x b128 write per thread and step; a first version that moved every value
+// through LDS spent 66 % of its LDS cycles in bank conflicts and was removed).  All threads run every step on the whole region (stale
 // values further than n - s pixels from the centre are never used), so there is no divergence
 // around the shuffles.
 // ---------------------------------------------------------------------------------------------
@@ -1115,24 +986,17 @@ uint64_t fed_deep_workgroups(uint32_t w, uint32_t h, uint32_t n) {
     return (uint64_t)((w + 63) / 64) * ((h + kFedDeepTh - 1) / kFedDeepTh) * n;
 }
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
-               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps, int variant) {
-#ifndef AKZ_FED_NT
-#define AKZ_FED_NT 512
-#endif
-    constexpr int TW = 64, TH = 32, NT = AKZ_FED_NT;
+               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps) {
+    constexpr int TW = 64, TH = 32, NT = 512;
     FedTaus ht;
     ht.n = (int)n_steps;
     for (uint32_t i = 0; i < 16; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
     const dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
-    if (variant == 2) {
+    {
         if (n_steps <= 4) {
             // halo 4: a 64 x 48 tile gives 18 x 27 (n = 3) or 18 x 28 (n = 4) owner threads of 512; 64 x 32 only 342 / 360
-            // (AKZ_FED_TH4=32 selects the old shape for A/B runs; 64 x 40 and 256-thread 64 x 20 tiles measured slower)
-            static const int th4 = [] {
-                const char* e = std::getenv("AKZ_FED_TH4");
-                return e ? std::atoi(e) : 48;
-            }();
-            if (th4 == 48 && h >= 48) {
+            // (64 x 40 and 256-thread 64 x 20 tiles measured slower)
+            if (h >= 48) {
                 const dim3 g48((w + TW - 1) / TW, (h + 47) / 48, n);
                 hipLaunchKernelGGL((k_fed_own<TW, 48, 4, NT>), g48, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
                                    (int)h, ht);
@@ -1149,14 +1013,7 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
             hipLaunchKernelGGL((k_fed_own<TW, kFedDeepTh, 16, NT>), g10, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep,
                                (int)w, (int)h, ht);
         }
-        return;
     }
-    if (n_steps <= 4)
-        hipLaunchKernelGGL((k_fed_fused<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
-                           (int)h, ht);
-    else
-        hipLaunchKernelGGL((k_fed_fused<TW, TH, 8, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
-                           (int)h, ht);
 }
 // Workgroups per image of the two contrast passes: 128 fat ones for a batch (one atomicMax / one histogram flush
 // each); a small batch gets more, shorter ones so that the chip is filled (a lone 1080p frame: 38 + 36 us with 128).

@@ -1,0 +1,439 @@
+// Detector response of one level in ONE pass (detector_response.rs:8-55 + the extrema test of
+// scale_space_extrema.rs:32-42, :80-87): Lsmooth -> Lx, Ly -> Lxx, Lyy, Lxy -> Ldet -> candidates, as a column march.
+//
+// A 256-thread workgroup owns a strip of 512 columns and marches down a band of rows; a thread owns TWO adjacent
+// columns, so every arithmetic instruction is a packed f32 operation (v_pk_mul_f32 / v_pk_add_f32, IEEE per
+// component, no FMA).  HBM sees each plane once: 4 B read and 12 (+12 with the second derivatives kept) written per
+// pixel, plus the band / strip halos of the input (a few per cent); Lx and Ly are never read back.
+//
+//   * vertical taps (rows r-2S, r-S, r) come from REGISTER rings of the last 2S+1 rows — the row loop is unrolled by
+//     the ring length, so every ring index is static (5 rings x (2S+1) rows x 2 columns: 90 VGPRs at S = 4);
+//   * horizontal taps (columns x-S, x, x+S) come from LDS: each iteration every thread writes its two values of the
+//     rows that the horizontal passes of this iteration read — Lsmooth row v, Lx / Ly row v-S-1, Ldet row v-2S-2 —
+//     into a row buffer, ONE barrier, then reads its neighbours (buffers alternate, so no second barrier).  The
+//     stages are skewed by one iteration each, which is what makes one barrier per row enough:
+//
+//        iteration t:  Lsmooth row v --H--> (Hm, Ho) ring --V--> Lx, Ly row u = v-S   (stored; into LDS next iteration)
+//                      Lx, Ly row u-1 --H (LDS)--> (A, B, C) rings --V--> Lxx, Lyy, Lxy, Ldet row c = u-1-S (stored)
+//                      Ldet rows c-2, c-1, c (registers) + row c-1's neighbours (LDS) --> extrema test of row c-1
+//
+// fill_border (types/image.rs:239-260) is reproduced exactly: a pass result at (x, y) is the interior result at
+// (clamp(x,S,w-1-S), clamp(y,S,h-1-S)).  Columns: every thread reads its horizontal taps around its CLAMPED column, so
+// every LDS position and ring slot holds the filled value of its own column.  Rows: the H pass of virtual row v reads
+// input row clamp(v); the filled Lx / Ly rows above row S are row S (its stage-2 H result is entered into the S ring
+// slots above it when it appears), the rows below h-1-S repeat row h-1-S (the stage-1 V result is held); border rows
+// of the outputs are stored by the band that owns rows S / h-1-S.
+//
+// Arithmetic is the reference's: f32 mul then add, taps left to right starting from 0.0f; the off-axis Scharr taps
+// [-1, 0.., 0, ..0, 1] are evaluated as (0.0f - a) + c (bit-identical for finite values).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "akz_internal.hpp"
+
+namespace akz {
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two pixels of a row, dword-aligned
+
+constexpr int MT = 256;          // threads per workgroup (4 waves)
+constexpr int MW = 2 * MT;       // columns of a strip, halo included
+constexpr int HALO = 16;         // halo columns on each side (>= 2S+2)
+constexpr int USE = MW - 2 * HALO;  // 480 columns owned per strip: strips start on 128-byte boundaries of a row (for the
+                                    // usual widths), which is worth 30 % of HBM bandwidth against strips that do not
+                                    // (tools/membw/marchbw: 3.8 -> 5.0 TB/s for this access shape, 6.0 with streaming stores)
+constexpr int PAD = 8;           // floats left and right of an LDS row (>= S; even: position 0 stays 8-byte aligned)
+constexpr int ROW = MW + 2 * PAD;
+constexpr int CBUF = 32;         // extrema buffered per wave before one atomic reserves their list slots
+#ifndef AKZ_MARCH_PF
+#define AKZ_MARCH_PF 3
+#endif
+
+struct MarchGrid {
+    int nstrips, nbands, band_rows;  // band_rows: interior rows per band
+};
+struct MarchNms {
+    unsigned level;
+    float thr;
+    int xlo, xhi, ylo, yhi;
+    Candidate* cand;
+    unsigned cap;
+    unsigned* count;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ f2 tap_main(f2 a, f2 b, f2 c, float kn, float kwn) {
+    const f2 z = {0.0f, 0.0f};
+    return ((z + kn * a) + kwn * b) + kn * c;
+}
+__device__ __forceinline__ f2 tap_off(f2 a, f2 c) {
+    const f2 z = {0.0f, 0.0f};
+    return (z - a) + c;
+}
+
+__device__ __forceinline__ void cands_flush(Candidate* buf, unsigned& n, const MarchNms& nms, int lane) {
+    if (n == 0) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(nms.count, n);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    const uint4* src = reinterpret_cast<const uint4*>(buf);
+    uint4* dst = reinterpret_cast<uint4*>(nms.cand);
+    for (unsigned e = (unsigned)lane; e < 2u * n; e += 64u)  // 16-byte halves of the 32-byte records
+        if (base + (e >> 1) < nms.cap) dst[2 * (size_t)base + e] = src[e];
+    __builtin_amdgcn_wave_barrier();
+    n = 0;
+}
+// every lane offers the pixels of its pair whose bit is set in m; called by whole waves (wave-uniform control flow)
+template <typename F>
+__device__ __forceinline__ void cands_push(Candidate* buf, unsigned& n, unsigned m, const MarchNms& nms, int lane, F&& make) {
+    while (__ballot(m != 0u)) {  // rare
+        const bool have = m != 0u;
+        const int i = have ? __ffs(m) - 1 : 0;
+        m &= m - 1u;
+        const unsigned long long b = __ballot(have);
+        const unsigned nb = (unsigned)__popcll(b);
+        if (n + nb > (unsigned)CBUF) cands_flush(buf, n, nms, lane);
+        const unsigned before = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+        if (nb <= (unsigned)CBUF) {
+            if (have) buf[n + before] = make(i);
+            n += nb;
+        } else {  // more hits in one row of the wave than the buffer holds: two halves
+            const bool lo = before < (unsigned)CBUF;
+            if (have && lo) buf[before] = make(i);
+            n = (unsigned)CBUF;
+            __builtin_amdgcn_wave_barrier();
+            cands_flush(buf, n, nms, lane);
+            if (have && !lo) buf[before - CBUF] = make(i);
+            n = nb - (unsigned)CBUF;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+struct Cols {          // a thread's two columns
+    int x0;            // image column of the first one (halo threads may lie outside the image)
+    bool st2, st1;     // owner of both columns (one 8-byte store) / of the first only (the image ends between them)
+    bool ldv;          // both columns inside the image: one 8-byte load
+    unsigned boff;     // byte offset of column x0 in a row (meaningful where the thread loads / stores at x0)
+    unsigned lb0, lb1; // byte offsets of the clamped load columns otherwise
+};
+// All global accesses are `uniform row address (SGPR pair) + 32-bit byte offset of the thread`: one address VGPR per
+// thread for every plane and row instead of a 64-bit address computation per access.
+__device__ __forceinline__ float* at(float* row, unsigned boff) { return reinterpret_cast<float*>(reinterpret_cast<char*>(row) + boff); }
+__device__ __forceinline__ const float* at(const float* row, unsigned boff) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + boff);
+}
+template <int N>
+__device__ __forceinline__ void store_rows(float* const (&plane)[N], size_t ro, const Cols& C, const f2 (&v)[N]) {
+    if (C.st2) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            // streaming stores: the planes are written once and not read again by this kernel (+20 % for this access shape)
+            __builtin_nontemporal_store((f2u)v[i], reinterpret_cast<f2u*>(at(plane[i] + ro, C.boff)));
+        }
+    } else if (C.st1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) *at(plane[i] + ro, C.boff) = v[i].x;
+    }
+}
+// interior row r of the output planes, plus (twice per strip) the border rows that copy it
+template <int S, int N>
+__device__ __forceinline__ void store_filled(float* const (&plane)[N], const Cols& C, int w, int h, int r, const f2 (&v)[N]) {
+    store_rows<N>(plane, (size_t)r * w, C, v);
+    if (r == S || r == h - 1 - S) {  // workgroup-uniform
+        if (r == S) {
+#pragma nounroll
+            for (int y = 0; y < S; ++y) store_rows<N>(plane, (size_t)y * w, C, v);
+        }
+        if (r == h - 1 - S) {
+#pragma nounroll
+            for (int y = h - S; y < h; ++y) store_rows<N>(plane, (size_t)y * w, C, v);
+        }
+    }
+}
+
+template <int S, bool NMS, bool KEEP>
+__global__ void __launch_bounds__(MT, (S <= 2 ? 4 : 3))
+k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out,
+                 float* __restrict__ lxx_out, float* __restrict__ lyy_out, float* __restrict__ lxy_out,
+                 float* __restrict__ ldet_out, int w, int h, MarchGrid g, float kn, float kwn, float quat, MarchNms nms) {
+    constexpr int P = 2 * S + 1, NOUT = KEEP ? 4 : 1;
+    static_assert(2 * S + 2 <= HALO, "strip halo");
+    constexpr int PF = S >= 4 ? 2 : AKZ_MARCH_PF;  // input rows in flight ahead of the arithmetic (register budget at S = 4)
+    static_assert(S <= PAD, "LDS padding");
+    __shared__ __attribute__((aligned(16))) float s_row[2][4][ROW];  // [buffer][Lsmooth, Lx, Ly, Ldet][PAD + position]
+    __shared__ Candidate s_cands[NMS ? MT / 64 : 1][NMS ? CBUF : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Candidate* const cbuf = s_cands[NMS ? wv : 0];
+    unsigned cnum = 0;
+    // (image, band, strip), strips fastest: workgroups that run side by side work on the same rows of the image
+    // (integer division runs on the vector ALU: readfirstlane moves the uniform results back to scalar registers, so
+    // that row addresses, loop bounds and branches derived from them stay scalar)
+    const int per = g.nbands * g.nstrips;
+    const int img = __builtin_amdgcn_readfirstlane((int)blockIdx.x / per);
+    const int rem = (int)blockIdx.x - img * per;
+    const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
+    const int cs = S + band * g.band_rows, ce = min(cs + g.band_rows, h - S);  // interior rows of this band
+    if (cs >= ce) return;
+
+    const int X0 = strip * USE - HALO;  // image column of position 0
+    // threads 0..239 own positions 16..495 (so that every wave's stores start on a 512-byte boundary of the strip),
+    // threads 240..247 the right halo, 248..255 the left halo
+    const int p0 = (2 * tid + HALO) & (MW - 1);
+    Cols C;
+    C.x0 = X0 + p0;
+    const bool inner = p0 >= HALO && p0 < MW - HALO;
+    C.st2 = inner && C.x0 + 1 < w;
+    C.st1 = inner && !C.st2 && C.x0 < w;
+    C.ldv = C.x0 >= 0 && C.x0 + 1 <= w - 1;
+    C.boff = (unsigned)C.x0 * 4u;
+    C.lb0 = (unsigned)clampi(C.x0, 0, w - 1) * 4u;
+    C.lb1 = (unsigned)clampi(C.x0 + 1, 0, w - 1) * 4u;
+    // LDS read indices of tap -S of the two columns, evaluated at the clamped column (taps 0 and +S: + S, + 2S)
+    const int i0 = PAD + clampi(clampi(C.x0, S, w - 1 - S) - X0, 0, MW - 1) - S;
+    const int i1 = PAD + clampi(clampi(C.x0 + 1, S, w - 1 - S) - X0, 0, MW - 1) - S;
+    const int wi = PAD + p0;
+    unsigned xok = 0;  // bit i: column i of this thread may hold a candidate
+    if (NMS) {
+        if ((C.st2 || C.st1) && C.x0 >= nms.xlo && C.x0 <= nms.xhi) xok |= 1u;
+        if (C.st2 && C.x0 + 1 >= nms.xlo && C.x0 + 1 <= nms.xhi) xok |= 2u;
+    }
+
+    const size_t base = (size_t)img * (size_t)w * (size_t)h;
+    const float* in = ls + base;
+    float* const out1[2] = {lx_out + base, ly_out + base};
+    float* out2[NOUT];
+    out2[0] = ldet_out + base;
+    if (KEEP) {
+        out2[1] = lxx_out + base;
+        out2[2] = lyy_out + base;
+        out2[3] = lxy_out + base;
+    }
+    float* const(&out2c)[NOUT] = out2;
+
+    // the extrema test of rows [cs, ce) needs Ldet rows cs-1 .. ce, i.e. input rows cs-1-2S .. ce+2S
+    const int v0 = cs - 1 - 2 * S;
+    const int T = (ce - cs) + 4 * S + 3;
+    auto feed = [&](int t) -> f2 {
+        const float* row = in + (size_t)clampi(v0 + min(t, T - 1), S, h - 1 - S) * w;
+        f2 v;
+        if (C.ldv) {
+            v = *reinterpret_cast<const f2u*>(at(row, C.boff));
+        } else {
+            v.x = *at(row, C.lb0);
+            v.y = *at(row, C.lb1);
+        }
+        return v;
+    };
+    f2 q[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) q[i] = feed(i);
+    const f2 zero = {0.0f, 0.0f};
+    f2 rHm[P], rHo[P], rA[P], rB[P], rC[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) rHm[i] = rHo[i] = rA[i] = rB[i] = rC[i] = zero;
+    f2 lx_c = zero, ly_c = zero;  // Lx, Ly of row u-1 (computed by the previous iteration)
+    f2 dm1 = zero, dm2 = zero;    // Ldet of rows c-1, c-2
+
+    for (int t0 = 0; t0 < T; t0 += P) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int t = t0 + k;
+            if (t < T) {
+                const int v = v0 + t, u = v - S, u1 = u - 1, c = u1 - S;
+                const f2 nxt = feed(t + PF);
+                float* const buf = &s_row[t & 1][0][0];
+                *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = q[0];
+                *reinterpret_cast<f2*>(buf + 1 * ROW + wi) = lx_c;
+                *reinterpret_cast<f2*>(buf + 2 * ROW + wi) = ly_c;
+                if (NMS) *reinterpret_cast<f2*>(buf + 3 * ROW + wi) = dm1;
+                __syncthreads();
+                const int k0 = (k + 1) % P, k1 = (k + P - S) % P;  // ring rows r-2S, r-S; slot k = row r
+                // ---- stage 1: H pass of Lsmooth row v, V pass -> Lx, Ly of row u ----
+                {
+                    const float* r0 = buf + i0;
+                    const float* r1 = buf + i1;
+                    const f2 a = {r0[0], r1[0]}, b = {r0[S], r1[S]}, cc = {r0[2 * S], r1[2 * S]};
+                    rHm[k] = tap_main(a, b, cc, kn, kwn);
+                    rHo[k] = tap_off(a, cc);
+                }
+                f2 lx_n = lx_c, ly_n = ly_c;  // below row h-1-S the filled rows repeat it
+                if (u <= h - 1 - S) {
+                    lx_n = tap_off(rHm[k0], rHm[k]);
+                    ly_n = tap_main(rHo[k0], rHo[k1], rHo[k], kn, kwn);
+                }
+                if (u >= cs && u < ce) {
+                    const f2 o1[2] = {lx_n, ly_n};
+                    store_filled<S, 2>(out1, C, w, h, u, o1);
+                }
+                // ---- stage 2: H pass of Lx, Ly row u-1 (in LDS), V pass -> Lxx, Lyy, Lxy, Ldet of row c ----
+                f2 A, B, Cc;
+                {
+                    const float* x0p = buf + ROW + i0;
+                    const float* x1p = buf + ROW + i1;
+                    const float* y0p = buf + 2 * ROW + i0;
+                    const float* y1p = buf + 2 * ROW + i1;
+                    const f2 xa = {x0p[0], x1p[0]}, xb = {x0p[S], x1p[S]}, xc = {x0p[2 * S], x1p[2 * S]};
+                    const f2 ya = {y0p[0], y1p[0]}, yc = {y0p[2 * S], y1p[2 * S]};
+                    A = tap_main(xa, xb, xc, kn, kwn);  // H_main(Lx)
+                    B = tap_off(ya, yc);                // H_off(Ly)
+                    Cc = tap_off(xa, xc);               // H_off(Lx)
+                }
+                rA[k] = A; rB[k] = B; rC[k] = Cc;
+                if (u1 == S) {  // filled Lx / Ly rows 0..S-1 are row S
+#pragma unroll
+                    for (int d = 1; d <= S; ++d) {
+                        rA[(k + P - d) % P] = A; rB[(k + P - d) % P] = B; rC[(k + P - d) % P] = Cc;
+                    }
+                }
+                const f2 lxx = tap_off(rA[k0], rA[k]);
+                const f2 lyy = tap_main(rB[k0], rB[k1], rB[k], kn, kwn);
+                const f2 lxy = tap_main(rC[k0], rC[k1], rC[k], kn, kwn);
+                const f2 det = ((lxx * lyy) - (lxy * lxy)) * quat;
+                if (c >= cs && c < ce) {
+                    f2 o[NOUT];
+                    o[0] = det;
+                    if (KEEP) { o[1] = lxx; o[2] = lyy; o[3] = lxy; }
+                    const f2(&oc)[NOUT] = o;
+                    store_filled<S, NOUT>(out2c, C, w, h, c, oc);
+                }
+                // ---- extrema test of row c-1: dm1, between dm2 (above) and det (below) ----
+                if (NMS) {
+                    const int y = c - 1;
+                    if (y >= cs && y < ce && y >= nms.ylo && y <= nms.yhi) {  // workgroup-uniform
+                        const float* dr = buf + 3 * ROW + wi;
+                        const float left = dr[-1], right = dr[2];
+                        const bool h0 = (dm1.x > nms.thr) & (dm1.x > dm1.y) & (dm1.x > left) & (dm1.x > dm2.x) & (dm1.x > det.x);
+                        const bool h1 = (dm1.y > nms.thr) & (dm1.y > right) & (dm1.y > dm1.x) & (dm1.y > dm2.y) & (dm1.y > det.y);
+                        const unsigned m = ((h0 ? 1u : 0u) | (h1 ? 2u : 0u)) & xok;
+                        cands_push(cbuf, cnum, m, nms, lane, [&](int i) {
+                            Candidate cd;
+                            cd.level = nms.level;
+                            cd.idx = (unsigned)(y * w + C.x0 + i);
+                            cd.v = i == 0 ? dm1.x : dm1.y;
+                            cd.xp = i == 0 ? dm1.y : right;
+                            cd.xm = i == 0 ? left : dm1.x;
+                            cd.yp = i == 0 ? det.x : det.y;
+                            cd.ym = i == 0 ? dm2.x : dm2.y;
+                            cd.img = (unsigned)img;
+                            return cd;
+                        });
+                    }
+                    dm2 = dm1;
+                    dm1 = det;
+                }
+                lx_c = lx_n;
+                ly_c = ly_n;
+#pragma unroll
+                for (int i = 0; i + 1 < PF; ++i) q[i] = q[i + 1];
+                q[PF - 1] = nxt;
+            }
+        }
+    }
+    if (NMS) cands_flush(cbuf, cnum, nms, lane);
+}
+
+inline MarchGrid plan_march(const void* kernel, uint32_t w, uint32_t h, uint32_t n, int S, dim3* grid) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    // Bands: each one re-warms the rings (4S+3 extra rows), so they are as tall as the machine allows — enough
+    // workgroups for `fill` resident workgroups per CU, never shorter than min_rows interior rows.
+    static int fill = 0, min_rows = 0;
+    if (!fill) {
+        const char* e = getenv("AKZ_MARCH_FILL");      // tuning knobs
+        fill = e ? std::max(1, atoi(e)) : 3;
+        const char* m = getenv("AKZ_MARCH_MIN_ROWS");
+        min_rows = m ? std::max(8, atoi(m)) : 64;
+    }
+    (void)kernel;
+    const int use = USE;
+    (void)S;
+    MarchGrid g;
+    g.nstrips = (int)((w + use - 1) / use);
+    const int rows = (int)h - 2 * S;
+    const long cols = (long)n * g.nstrips;
+    const long want = ((long)cus * fill + cols - 1) / cols;  // bands needed to fill the chip
+    long nb = std::max<long>(1, std::min<long>(want, std::max(1, rows / min_rows)));
+    g.band_rows = (int)((rows + nb - 1) / nb);
+    g.nbands = (rows + g.band_rows - 1) / g.band_rows;
+    *grid = dim3((unsigned)(cols * g.nbands));
+    return g;
+}
+
+}  // namespace
+
+namespace launch {
+
+// the candidate rectangle of scale_space_extrema.rs:32-42 and :80-87 (the reference's float expressions; both border
+// tests are monotone in the coordinate, so the admissible coordinates form one interval)
+static void admissible_range(uint32_t dim, float border_m, int* lo, int* hi) {
+    auto out_lo = [&](int v) { return (roundf((float)v - border_m) - 1.0f) < 0.0f; };
+    auto out_hi = [&](int v) { return (roundf((float)v + border_m) + 1.0f) >= (float)dim; };
+    int a = 1, b = (int)dim - 2;
+    while (a <= b && out_lo(a)) ++a;
+    while (b >= a && out_hi(b)) --b;
+    *lo = a;
+    *hi = b;  // empty when lo > hi
+}
+
+bool detector_march_supported(uint32_t sigma, uint32_t w, uint32_t h, float border_m, bool nms) {
+    if (sigma < 1 || sigma > 4) return false;
+    if (w < 4 * sigma + 8 || h < 4 * sigma + 8) return false;
+    // the extrema test reads Ldet one pixel around a candidate: keep that ring inside the interior rows / columns
+    return !nms || border_m >= (float)(sigma + 2);
+}
+
+#define AKZ_MARCH(S)                                                                                                  \
+    case S: {                                                                                                         \
+        dim3 gr;                                                                                                      \
+        if (d_cand && keep) {                                                                                         \
+            const MarchGrid mg = plan_march((const void*)k_detector_march<S, true, true>, w, h, n, S, &gr);            \
+            hipLaunchKernelGGL((k_detector_march<S, true, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy,  \
+                               ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                      \
+        } else if (d_cand) {                                                                                          \
+            const MarchGrid mg = plan_march((const void*)k_detector_march<S, true, false>, w, h, n, S, &gr);           \
+            hipLaunchKernelGGL((k_detector_march<S, true, false>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
+                               ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                      \
+        } else if (keep) {                                                                                            \
+            const MarchGrid mg = plan_march((const void*)k_detector_march<S, false, true>, w, h, n, S, &gr);           \
+            hipLaunchKernelGGL((k_detector_march<S, false, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
+                               ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                      \
+        } else {                                                                                                      \
+            const MarchGrid mg = plan_march((const void*)k_detector_march<S, false, false>, w, h, n, S, &gr);          \
+            hipLaunchKernelGGL((k_detector_march<S, false, false>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy,     \
+                               lxy, ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                 \
+        }                                                                                                             \
+    } break;
+
+// One level's detector response (+ extrema candidates when d_cand is given) in one launch of k_detector_march.
+// lxx / lyy / lxy may be null together (the planes are then not written).
+void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
+                    float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level, float thr,
+                    float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
+    const Taps m = taps_scharr_main(sigma);
+    const float kn = m.wgt[0], kwn = m.wgt[1];
+    const float quat = (float)(sigma * sigma * sigma * sigma);
+    const bool keep = lxx && lyy && lxy;
+    MarchNms na{level, thr, 0, -1, 0, -1, d_cand, cap, d_count};
+    if (d_cand) {
+        admissible_range(w, border_m, &na.xlo, &na.xhi);
+        admissible_range(h, border_m, &na.ylo, &na.yhi);
+    }
+    switch (sigma) {
+        AKZ_MARCH(1) AKZ_MARCH(2) AKZ_MARCH(3) AKZ_MARCH(4)
+        default: break;
+    }
+}
+#undef AKZ_MARCH
+
+}  // namespace launch
+}  // namespace akz

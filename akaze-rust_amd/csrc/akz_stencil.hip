@@ -30,27 +30,12 @@
 namespace akz {
 namespace {
 
-#ifndef AKZ_STENCIL_NT
-#define AKZ_STENCIL_NT 512
-#endif
 #ifndef AKZ_PERSIST_BLOCKS
 #define AKZ_PERSIST_BLOCKS 1024  // 256 CUs x 4 workgroups of 512 threads
 #endif
-#ifndef AKZ_STENCIL_TH
-#define AKZ_STENCIL_TH 32
-#endif
-// Tile height of k_deriv2 alone (tuning knob).  64 x 30 tiles make its Ldet window 32 rows (four full thread rows per
-// vertical pass instead of five with the last mostly idle) and cut the sigma-4 input window from seven loads per thread
-// to six, yet the detector stage measured the same (3.38 against 3.40 ms per 32-frame step): the kernel is not
-// issue-bound, so it keeps the common tile.
-#ifndef AKZ_DERIV2_TH
-#define AKZ_DERIV2_TH AKZ_STENCIL_TH
-#endif
-#ifndef AKZ_DERIV2_TH4
-#define AKZ_DERIV2_TH4 AKZ_DERIV2_TH  // the same knob for the sigma-4 instantiation alone
-#endif
-constexpr int TW = 64, TH = AKZ_STENCIL_TH, NT = AKZ_STENCIL_NT;
-constexpr int deriv2_tile_h(int s) { return s == 4 ? AKZ_DERIV2_TH4 : AKZ_DERIV2_TH; }
+constexpr int TW = 64, TH = 32, NT = 512;
+// k_deriv2 keeps the common tile height: 64 x 30 / 64 x 28 tiles (fewer loads per thread at sigma 4) measured the same
+constexpr int deriv2_tile_h(int) { return TH; }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

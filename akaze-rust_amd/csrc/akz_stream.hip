@@ -1,5 +1,5 @@
-// Barrier-free streaming kernels for gfx950: the level preparation (lib.rs:80-105) and the detector
-// derivatives (detector_response.rs:8-55) as register-ring stencil chains.
+// Barrier-free streaming kernels for gfx950: the level preparation (lib.rs:80-105), the contrast-factor passes
+// (contrast_factor.rs:18-71) and the level-0 blur (lib.rs:56) as register-ring stencil chains.
 //
 // Every lane owns a column of four consecutive pixels and marches down the rows of a strip:
 //
@@ -23,10 +23,9 @@
 // finish together), but never shorter than a few ring lengths (each band re-warms its ring).
 //
 // Where they are used (akz_api.cpp picks per launch; both families give identical bytes): the streaming
-// preparation kernel is ~2x faster than the LDS-tiled one for batches (4.2 vs 2.2 TB/s at 32 x 1080p); the
-// streaming detector pair wins only when Lxx/Lyy/Lxy are not written out.  A 2 reads : 4 writes kernel
-// tops out near 4.4-5.2 TB/s on MI355X even for a plain copy-like loop (tools/membw), so the detector
-// kernels are bounded by their write mix, not by their structure.
+// preparation kernel is ~2x faster than the LDS-tiled one for batches (4.2 vs 2.2 TB/s at 32 x 1080p).  The
+// detector's streaming forms of round 1 (a kernel pair and a fused kernel with four pixels per lane, which needed
+// more than 256 VGPRs) were replaced by the workgroup-wide column march of akz_march.hip.
 //
 // Arithmetic is the reference's: f32 mul then add, taps left to right starting from 0.0f, no FMA.
 // The off-axis Scharr taps [-1, 0.., 0, ..0, 1] are evaluated as (0.0f - a) + c, which is
@@ -46,10 +45,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // four pixels of a row, dword-aligned
 
 constexpr int WAVE = 64, SNT = 256;  // 4 independent waves per workgroup
-#ifndef AKZ_STREAM_PF
-#define AKZ_STREAM_PF 1
-#endif
-constexpr int PF = AKZ_STREAM_PF;     // rows of input taps in flight per wave
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -87,37 +82,6 @@ __device__ __forceinline__ Lane make_lane(int strip, int lane, int w) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) L.cx[i] = (unsigned)clampi(L.x + i, S, w - 1 - S);
     return L;
-}
-// taps a = row[cx-S], b = row[cx], c = row[cx+S] of the lane's four pixels (edge lanes only)
-template <int S, bool NEED_B>
-__device__ __forceinline__ void fetch_edge(const float* __restrict__ row, const Lane& L, f4& a, f4& b, f4& c) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a[i] = row[L.cx[i] - S];
-        if (NEED_B) b[i] = row[L.cx[i]];
-        c[i] = row[L.cx[i] + S];
-    }
-}
-template <int S>
-__device__ __forceinline__ void fetch_vec_x(const float* __restrict__ row, int x, f4& a, f4& b, f4& c) {
-    a = *reinterpret_cast<const f4u*>(row + x - S);
-    b = *reinterpret_cast<const f4u*>(row + x);
-    c = *reinterpret_cast<const f4u*>(row + x + S);
-}
-template <int S>
-__device__ __forceinline__ void fetch_edge_x(const float* __restrict__ row, const unsigned (&cx)[4], f4& a, f4& b, f4& c) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a[i] = row[cx[i] - S];
-        b[i] = row[cx[i]];
-        c[i] = row[cx[i] + S];
-    }
-}
-template <int S, bool NEED_B>
-__device__ __forceinline__ void fetch_vec(const float* __restrict__ row, const Lane& L, f4& a, f4& b, f4& c) {
-    a = *reinterpret_cast<const f4u*>(row + L.x - S);
-    if (NEED_B) b = *reinterpret_cast<const f4u*>(row + L.x);
-    c = *reinterpret_cast<const f4u*>(row + L.x + S);
 }
 // one output row of N planes; ro = offset of the row's first pixel
 template <int N>
@@ -164,245 +128,6 @@ __device__ __forceinline__ Piece wave_piece(long wave, const StreamGrid& g, int 
 // provably uniform and the compiler keeps it in SGPRs with scalar branches
 __device__ __forceinline__ long wave_index() {
     return (long)blockIdx.x * (SNT / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Multiscale first derivatives (detector_response.rs:9-10): Lx = V_off(H_main(Ls)), Ly = V_main(H_off(Ls))
-// ---------------------------------------------------------------------------------------------
-template <int S>
-__global__ void __launch_bounds__(SNT, (S <= 2 ? 4 : S == 3 ? 3 : 2))  // second argument: waves per SIMD the register budget must allow
-k_deriv1_stream(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out, int w, int h,
-                StreamGrid g, float kn, float kwn) {
-    constexpr int P = 2 * S + 1;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const long wave = wave_index();
-    if (wave >= g.waves) return;
-    {
-        const Piece pc = wave_piece(wave, g, S, h);
-        if (pc.cs >= pc.ce) return;
-        const Lane L = make_lane<S, 0>(pc.strip, lane, w);
-        const size_t base = (size_t)pc.img * (size_t)w * (size_t)h;
-        const float* in = ls + base;
-        float* const out[2] = {lx_out + base, ly_out + base};
-        const int v0 = pc.cs - S, T = (pc.ce - pc.cs) + 2 * S;  // H rows v0 .. v0+T-1
-        f4 rM[P], rO[P];
-        f4 qa[PF], qb[PF], qc[PF];  // taps of rows t .. t+PF-1, in flight ahead of the arithmetic
-        auto fetch = [&](int t, f4& fa, f4& fb, f4& fc) {
-            const float* row = in + (size_t)clampi(v0 + std::min(t, T - 1), S, h - 1 - S) * w;
-            if (!L.edge) fetch_vec<S, true>(row, L, fa, fb, fc);
-            else fetch_edge<S, true>(row, L, fa, fb, fc);
-        };
-#pragma unroll
-        for (int i = 0; i < PF; ++i) fetch(i, qa[i], qb[i], qc[i]);
-        for (int t0 = 0; t0 < T; t0 += P) {
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const int t = t0 + k;
-                if (t < T) {
-                    f4 na, nb, nc;
-                    fetch(t + PF, na, nb, nc);
-                    const f4 a = qa[0], b = qb[0], c = qc[0];
-                    rM[k] = tap_main(a, b, c, kn, kwn);
-                    rO[k] = tap_off(a, c);
-                    if (t >= 2 * S) {
-                        const int k0 = (k + 1) % P, k1 = (k + P - S) % P;  // rows c-S, c; k = row c+S
-                        const f4 v[2] = {tap_off(rM[k0], rM[k]), tap_main(rO[k0], rO[k1], rO[k], kn, kwn)};
-                        store_filled<S, 2>(out, L, w, h, v0 + t - S, v);
-                    }
-#pragma unroll
-                    for (int i = 0; i + 1 < PF; ++i) { qa[i] = qa[i + 1]; qb[i] = qb[i + 1]; qc[i] = qc[i + 1]; }
-                    qa[PF - 1] = na; qb[PF - 1] = nb; qc[PF - 1] = nc;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Second derivatives, Hessian determinant and (NMS) the extrema test of scale_space_extrema.rs:32-42,
-// :80-87: Lxx = V_off(H_main(Lx)), Lyy = V_main(H_off(Ly)), Lxy = V_main(H_off(Lx)),
-// Ldet = ((Lxx*Lyy) - (Lxy*Lxy)) * sigma^4.  A pixel is a candidate if Ldet > threshold, Ldet is
-// strictly above its 4 neighbours and the descriptor window fits in the image; the host turns the
-// last test into the rectangle [xlo,xhi] x [ylo,yhi] (same float expressions) and checks that it
-// keeps candidates at least S+2 pixels away from every edge, so only interior rows and columns are
-// ever tested.  With NMS one lane on each side of the wave is a halo lane: it computes Ldet for its
-// neighbour but neither stores nor reports.
-// ---------------------------------------------------------------------------------------------
-struct StreamNms {
-    unsigned level;
-    float thr;
-    int xlo, xhi, ylo, yhi;
-    Candidate* cand;
-    unsigned cap;
-    unsigned* count;
-};
-
-// Extrema of a wave are collected in a small LDS buffer of that wave and appended to the global list in blocks: one
-// device-scope atomic per CAND_BUF candidates instead of one each (a 32-frame batch emits 1.6 x 10^5 candidates, and
-// that many atomics on one address cost 0.6 ms).  All helpers are called by the whole wave (wave-uniform control flow).
-constexpr int CAND_BUF = 32;
-__device__ __forceinline__ void wave_cands_flush(Candidate* buf, unsigned& n, const StreamNms& nms, int lane) {
-    if (n == 0) return;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(nms.count, n);
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    const uint4* src = reinterpret_cast<const uint4*>(buf);
-    uint4* dst = reinterpret_cast<uint4*>(nms.cand);
-    for (unsigned e = (unsigned)lane; e < 2u * n; e += WAVE)  // 16-byte halves of the 32-byte records
-        if (base + (e >> 1) < nms.cap) dst[2 * (size_t)base + e] = src[e];
-    __builtin_amdgcn_wave_barrier();
-    n = 0;
-}
-// every lane offers the pixels of its quad whose bit is set in m (at most two); `make(i)` builds the record of pixel i
-template <typename F>
-__device__ __forceinline__ void wave_cands_push(Candidate* buf, unsigned& n, unsigned m, const StreamNms& nms, int lane,
-                                                F&& make) {
-    while (__ballot(m != 0u)) {  // rare
-        const bool have = m != 0u;
-        const int i = have ? __ffs(m) - 1 : 0;
-        m &= m - 1u;
-        const unsigned long long b = __ballot(have);
-        const unsigned nb = (unsigned)__popcll(b);  // <= 64 > CAND_BUF is possible: flush first, then at most 32 per round
-        if (n + nb > (unsigned)CAND_BUF) wave_cands_flush(buf, n, nms, lane);
-        const unsigned before = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-        if (nb <= (unsigned)CAND_BUF) {
-            if (have) buf[n + before] = make(i);
-            n += nb;
-        } else {  // more hits in one row of the wave than the buffer holds: two halves
-            const bool lo = before < (unsigned)CAND_BUF;
-            if (have && lo) buf[before] = make(i);
-            n = min(nb, (unsigned)CAND_BUF);
-            __builtin_amdgcn_wave_barrier();
-            wave_cands_flush(buf, n, nms, lane);
-            if (have && !lo) buf[before - CAND_BUF] = make(i);
-            n = nb - (unsigned)CAND_BUF;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-template <int S, bool NMS, bool KEEP>
-__global__ void __launch_bounds__(SNT, (S == 1 ? 3 : 2))
-k_deriv2_stream(const float* __restrict__ lx_in, const float* __restrict__ ly_in, float* __restrict__ lxx_out,
-                float* __restrict__ lyy_out, float* __restrict__ lxy_out, float* __restrict__ ldet_out, int w, int h,
-                StreamGrid g, float kn, float kwn, float quat, StreamNms nms) {
-    constexpr int P = 2 * S + 1, HL = NMS ? 1 : 0, NOUT = KEEP ? 4 : 1;
-    __shared__ Candidate s_cands[NMS ? SNT / WAVE : 1][NMS ? CAND_BUF : 1];  // per-wave extrema buffer
-    Candidate* const cbuf = s_cands[NMS ? (threadIdx.x >> 6) : 0];
-    unsigned cnum = 0;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const long wave = wave_index();
-    if (wave >= g.waves) return;
-    {
-        const Piece pc = wave_piece(wave, g, S, h);
-        if (pc.cs >= pc.ce) return;
-        const Lane L = make_lane<S, HL>(pc.strip, lane, w);
-        const size_t base = (size_t)pc.img * (size_t)w * (size_t)h;
-        const float* inx = lx_in + base;
-        const float* iny = ly_in + base;
-        float* out[NOUT];
-        out[0] = ldet_out + base;
-        if (KEEP) {
-            out[1] = lxx_out + base;
-            out[2] = lyy_out + base;
-            out[3] = lxy_out + base;
-        }
-        float* const(&outc)[NOUT] = out;
-        // extrema test: rows [cs, ce) of this piece; it needs Ldet of rows cs-1 and ce as well
-        const int cb = NMS ? std::max(pc.cs - 1, S) : pc.cs;
-        const int cl = NMS ? std::min(pc.ce + 1, h - S) : pc.ce;
-        const int v0 = cb - S, T = (cl - cb) + 2 * S;
-        unsigned xok = 0;  // bit i: pixel i of this lane may be a candidate
-        if (NMS) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i >= L.first && L.x + i >= nms.xlo && L.x + i <= nms.xhi) xok |= 1u << i;
-        }
-        f4 rA[P], rB[P], rC[P];
-        f4 dm2 = 0.0f, dm1 = 0.0f;  // Ldet of rows c-2, c-1
-        f4 qxa[PF], qxb[PF], qxc[PF], qya[PF], qyc[PF];  // taps of rows t .. t+PF-1, in flight ahead of the arithmetic
-        auto fetch = [&](int t, f4& fxa, f4& fxb, f4& fxc, f4& fya, f4& fyc) {
-            const size_t ro = (size_t)clampi(v0 + std::min(t, T - 1), S, h - 1 - S) * w;
-            f4 unused;
-            if (!L.edge) {
-                fetch_vec<S, true>(inx + ro, L, fxa, fxb, fxc);
-                fetch_vec<S, false>(iny + ro, L, fya, unused, fyc);
-            } else {
-                fetch_edge<S, true>(inx + ro, L, fxa, fxb, fxc);
-                fetch_edge<S, false>(iny + ro, L, fya, unused, fyc);
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < PF; ++i) fetch(i, qxa[i], qxb[i], qxc[i], qya[i], qyc[i]);
-        for (int t0 = 0; t0 < T; t0 += P) {
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const int t = t0 + k;
-                if (t < T) {
-                    f4 nxa, nxb, nxc, nya, nyc;
-                    fetch(t + PF, nxa, nxb, nxc, nya, nyc);
-                    const f4 xa = qxa[0], xb = qxb[0], xc = qxc[0], ya = qya[0], yc = qyc[0];
-                    rA[k] = tap_main(xa, xb, xc, kn, kwn);  // H_main(Lx)
-                    rB[k] = tap_off(ya, yc);                // H_off(Ly)
-                    rC[k] = tap_off(xa, xc);                // H_off(Lx)
-                    if (t >= 2 * S) {
-                        const int k0 = (k + 1) % P, k1 = (k + P - S) % P;
-                        const int cr = v0 + t - S;
-                        f4 o[NOUT];
-                        const f4 lxx = tap_off(rA[k0], rA[k]);
-                        const f4 lyy = tap_main(rB[k0], rB[k1], rB[k], kn, kwn);
-                        const f4 lxy = tap_main(rC[k0], rC[k1], rC[k], kn, kwn);
-                        const f4 det = ((lxx * lyy) - (lxy * lxy)) * quat;
-                        o[0] = det;
-                        if (KEEP) {
-                            o[1] = lxx;
-                            o[2] = lyy;
-                            o[3] = lxy;
-                        }
-                        const f4(&oc)[NOUT] = o;
-                        if (cr >= pc.cs && cr < pc.ce) store_filled<S, NOUT>(outc, L, w, h, cr, oc);
-                        if (NMS) {
-                            const int y = cr - 1;  // row under test: dm1, between dm2 (above) and det (below)
-                            if (t >= 2 * S + 2 && y >= pc.cs && y < pc.ce && y >= nms.ylo && y <= nms.yhi) {  // uniform
-                                const float left = __shfl_up(dm1[3], 1), right = __shfl_down(dm1[0], 1);
-                                const float xm[4] = {left, dm1[0], dm1[1], dm1[2]};
-                                const float xp[4] = {dm1[1], dm1[2], dm1[3], right};
-                                unsigned m = 0;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    const float v = dm1[i];
-                                    const bool hit = (v > nms.thr) & (v > xp[i]) & (v > xm[i]) & (v > dm2[i]) & (v > det[i]);
-                                    m |= hit ? 1u << i : 0u;
-                                }
-                                m &= xok;
-                                wave_cands_push(cbuf, cnum, m, nms, lane, [&](int i) {  // at most two pixels of a quad can be strict maxima
-                                    Candidate cd;
-                                    cd.level = nms.level;
-                                    cd.idx = (unsigned)(y * w + L.x + i);
-                                    cd.v = i == 0 ? dm1[0] : i == 1 ? dm1[1] : i == 2 ? dm1[2] : dm1[3];
-                                    cd.xp = i == 0 ? dm1[1] : i == 1 ? dm1[2] : i == 2 ? dm1[3] : right;
-                                    cd.xm = i == 0 ? left : i == 1 ? dm1[0] : i == 2 ? dm1[1] : dm1[2];
-                                    cd.yp = i == 0 ? det[0] : i == 1 ? det[1] : i == 2 ? det[2] : det[3];
-                                    cd.ym = i == 0 ? dm2[0] : i == 1 ? dm2[1] : i == 2 ? dm2[2] : dm2[3];
-                                    cd.img = (unsigned)pc.img;
-                                    return cd;
-                                });
-                            }
-                            dm2 = dm1;
-                            dm1 = det;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i + 1 < PF; ++i) {
-                        qxa[i] = qxa[i + 1]; qxb[i] = qxb[i + 1]; qxc[i] = qxc[i + 1];
-                        qya[i] = qya[i + 1]; qyc[i] = qyc[i + 1];
-                    }
-                    qxa[PF - 1] = nxa; qxb[PF - 1] = nxb; qxc[PF - 1] = nxc; qya[PF - 1] = nya; qyc[PF - 1] = nyc;
-                }
-            }
-        }
-    }
-    if (NMS) wave_cands_flush(cbuf, cnum, nms, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,271 +404,6 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused detector (detector_response.rs:8-55 + the extrema test): Lsmooth -> Lx, Ly -> Lxx, Lyy, Lxy, Ldet
-// in ONE pass over the level: 4 B read and 24 B written per pixel instead of 12 + 24 for the two-kernel
-// form (Lx and Ly are not read back).  Per input row v:
-//
-//   Lsmooth row v --H--> (Hm, Ho) ring in LDS (wave-private, 2S+1 rows) --V--> Lx, Ly of row u = v-S (stored)
-//        --H, neighbours by DPP--> (A, B, C) register rings (2S+1 rows) --V--> Lxx, Lyy, Lxy, Ldet of row
-//        c = v-2S (stored) --> extrema test of row c-1
-//
-// Columns: stage 1 evaluates edge pixels at their clamped column, so every lane holds the FILLED Lx / Ly
-// of its own columns; the stage-2 H results of columns S / w-1-S are broadcast (readlane) into the
-// columns left / right of them.  Rows: the filled Lx rows 0..S-1 (h-S..h-1) are row S (h-1-S): the first
-// band enters that row's stage-2 H result into S+1 ring slots, the last band does the same for the
-// bottom rows and then drains the S output rows that only need those copies.  Two halo lanes on each
-// side of the wave (stage 2 and the extrema test each look one lane sideways): strips are 240 pixels.
-// ---------------------------------------------------------------------------------------------
-template <int I, int S>
-__device__ __forceinline__ float col_minus(const f4& v) {  // value of column (own column I) - S
-    if constexpr (I >= S) return v[I - S];
-    else return from_left_lane(v[4 + I - S]);
-}
-template <int I, int S>
-__device__ __forceinline__ float col_plus(const f4& v) {  // value of column (own column I) + S
-    if constexpr (I + S <= 3) return v[I + S];
-    else return from_right_lane(v[I + S - 4]);
-}
-template <int S>
-__device__ __forceinline__ void shifted(const f4& v, f4& a, f4& c) {
-    a = f4{col_minus<0, S>(v), col_minus<1, S>(v), col_minus<2, S>(v), col_minus<3, S>(v)};
-    c = f4{col_plus<0, S>(v), col_plus<1, S>(v), col_plus<2, S>(v), col_plus<3, S>(v)};
-}
-
-struct DetLane {
-    int x;
-    bool edge;       // stage 1: some pixel is evaluated at a clamped column (or lies outside the image)
-    bool vst, sst;   // owner: one 16-byte store / pixel by pixel (quad crosses the right edge)
-    unsigned lo, hi; // bit i: column x+i < S  /  > w-1-S  (stage-2 H result is a copy of column S / w-1-S)
-    unsigned cx[4];
-};
-template <int S>
-__device__ __forceinline__ DetLane make_det_lane(int strip, int lane, int w) {
-    DetLane L;
-    L.x = strip * (4 * (WAVE - 4)) + 4 * (lane - 2);
-    L.edge = !(L.x >= S && L.x + 3 <= w - 1 - S);
-    const bool owner = lane >= 2 && lane < WAVE - 2 && L.x < w;
-    L.vst = owner && L.x + 3 < w;
-    L.sst = owner && !L.vst;
-    L.lo = L.hi = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        L.cx[i] = (unsigned)clampi(L.x + i, S, w - 1 - S);
-        if (L.x + i < S) L.lo |= 1u << i;
-        if (L.x + i > w - 1 - S) L.hi |= 1u << i;
-    }
-    return L;
-}
-template <int N>
-__device__ __forceinline__ void det_store(float* const (&plane)[N], size_t ro, const DetLane& L, int w, const f4 (&v)[N]) {
-    if (L.vst) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) plane_store4u(plane[i] + ro + L.x, v[i]);
-    } else if (L.sst) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (L.x + e < w) plane[i][ro + L.x + e] = v[i][e];
-    }
-}
-template <int S, int N>
-__device__ __forceinline__ void det_store_filled(float* const (&plane)[N], const DetLane& L, int w, int h, int y, const f4 (&v)[N]) {
-    det_store<N>(plane, (size_t)y * w, L, w, v);
-    if (y == S || y == h - 1 - S) {  // wave-uniform, two rows per strip
-        if (y == S) {
-#pragma nounroll
-            for (int r = 0; r < S; ++r) det_store<N>(plane, (size_t)r * w, L, w, v);
-        }
-        if (y == h - 1 - S) {
-#pragma nounroll
-            for (int r = h - S; r < h; ++r) det_store<N>(plane, (size_t)r * w, L, w, v);
-        }
-    }
-}
-template <int S, bool NMS, bool KEEP>
-__global__ void __launch_bounds__(SNT, (S == 1 ? 2 : 1))  // rings + taps need > 256 VGPRs for S >= 2: one wave per SIMD
-k_detector_stream(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out,
-                  float* __restrict__ lxx_out, float* __restrict__ lyy_out, float* __restrict__ lxy_out,
-                  float* __restrict__ ldet_out, int w, int h, StreamGrid g, float kn, float kwn, float quat,
-                  StreamNms nms) {
-    constexpr int P = 2 * S + 1, NOUT = KEEP ? 4 : 1;
-    __shared__ f4 s_ring[SNT / WAVE][2][P][WAVE];  // stage-1 H results of the last P rows, per wave
-    __shared__ Candidate s_cands[NMS ? SNT / WAVE : 1][NMS ? CAND_BUF : 1];  // per-wave extrema buffer
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    Candidate* const cbuf = s_cands[NMS ? wv : 0];
-    unsigned cnum = 0;
-    const long wave = (long)blockIdx.x * (SNT / WAVE) + wv;
-    if (wave >= g.waves) return;
-    // (image, band, strip), strips fastest; bands split the interior rows evenly
-    const long per = (long)g.nbands * g.nstrips;
-    const int img = (int)(wave / per);
-    const int rem = (int)(wave - (long)img * per);
-    const int band = rem / g.nstrips, strip = rem - band * g.nstrips;
-    const int rows = h - 2 * S;
-    const int cs = S + (int)(((long)band * rows) / g.nbands), ce = S + (int)(((long)(band + 1) * rows) / g.nbands);
-    if (cs >= ce) return;
-    const bool bottom = band == g.nbands - 1;
-    const DetLane L = make_det_lane<S>(strip, lane, w);
-    const bool edge_strip = strip == 0 || strip == g.nstrips - 1;
-    // lane / component that hold columns S and w-1-S in this strip
-    const int x0 = strip * (4 * (WAVE - 4)) - 8;
-    const int src_lo = clampi((S - x0) >> 2, 0, WAVE - 1), c_lo = (S - x0) & 3;
-    const int src_hi = clampi((w - 1 - S - x0) >> 2, 0, WAVE - 1), c_hi = (w - 1 - S - x0) & 3;
-    const size_t base = (size_t)img * (size_t)w * (size_t)h;
-    const float* in = ls + base;
-    float* const out1[2] = {lx_out + base, ly_out + base};
-    float* out2[NOUT];
-    out2[0] = ldet_out + base;
-    if (KEEP) {
-        out2[1] = lxx_out + base;
-        out2[2] = lyy_out + base;
-        out2[3] = lxy_out + base;
-    }
-    float* const(&out2c)[NOUT] = out2;
-    // output rows computed: c_lo_row .. c_hi_row (the extrema test of rows [cs, ce) needs cs-1 and ce too)
-    const int c_first = NMS ? max(cs - 1, S) : cs;
-    const int c_last = NMS ? min(ce, h - 1 - S) : ce - 1;
-    int v0 = c_first - 2 * S;
-    int t_last = (bottom ? h - 1 : c_last + 2 * S) - v0;
-    if (bottom) {  // the last input row must fall on ring index P-1 (the drain below is compiled only there)
-        const int extra = (P - 1 - t_last % P + P) % P;
-        v0 -= extra;
-        t_last += extra;
-    }
-    const int T = t_last + 1;
-    unsigned xok = 0;  // bit i: pixel i of this lane may be a candidate
-    if (NMS && (L.vst || L.sst)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (L.x + i >= nms.xlo && L.x + i <= nms.xhi) xok |= 1u << i;
-    }
-    auto fetch = [&](int t, f4& fa, f4& fb, f4& fc) {
-        const float* row = in + (size_t)clampi(v0 + min(t, T - 1), S, h - 1 - S) * w;
-        if (!L.edge) fetch_vec_x<S>(row, L.x, fa, fb, fc);
-        else fetch_edge_x<S>(row, L.cx, fa, fb, fc);
-    };
-    auto fill_cols = [&](f4& q) {  // wave-uniform call sites only (readlane)
-        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_lo == 0 ? q[0] : c_lo == 1 ? q[1] : c_lo == 2 ? q[2] : q[3]), src_lo));
-        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_hi == 0 ? q[0] : c_hi == 1 ? q[1] : c_hi == 2 ? q[2] : q[3]), src_hi));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (L.lo & (1u << i)) q[i] = lo;
-            if (L.hi & (1u << i)) q[i] = hi;
-        }
-    };
-    f4 rA[P], rB[P], rC[P];
-    f4 dm2 = 0.0f, dm1 = 0.0f;
-    f4 a, b, c;
-    fetch(0, a, b, c);
-    for (int t0 = 0; t0 < T; t0 += P) {
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const int t = t0 + k;
-            if (t < T) {
-                const int v = v0 + t;
-                f4 na, nb, nc;  // the next row's taps are in flight during this row's arithmetic
-                fetch(t + 1, na, nb, nc);
-                const f4 hm = tap_main(a, b, c, kn, kwn), ho = tap_off(a, c);
-                s_ring[wv][0][k][lane] = hm;
-                s_ring[wv][1][k][lane] = ho;
-                if (t >= 2 * S) {
-                    const int k0 = (k + 1) % P, k1 = (k + P - S) % P;  // ring rows u-S, u; k = row u+S
-                    const int u = v - S;
-                    const f4 lx = tap_off(s_ring[wv][0][k0][lane], hm);
-                    const f4 ly = tap_main(s_ring[wv][1][k0][lane], s_ring[wv][1][k1][lane], ho, kn, kwn);
-                    if (u >= cs && u < ce) {
-                        const f4 o1[2] = {lx, ly};
-                        det_store_filled<S, 2>(out1, L, w, h, u, o1);
-                    }
-                    f4 xa, xc, ya, yc;
-                    shifted<S>(lx, xa, xc);
-                    shifted<S>(ly, ya, yc);
-                    f4 A = tap_main(xa, lx, xc, kn, kwn);  // H_main(Lx)
-                    f4 B = tap_off(ya, yc);                // H_off(Ly)
-                    f4 C = tap_off(xa, xc);                // H_off(Lx)
-                    if (edge_strip) {
-                        fill_cols(A);
-                        fill_cols(B);
-                        fill_cols(C);
-                    }
-                    rA[k] = A; rB[k] = B; rC[k] = C;
-                    if (u == S) {  // filled Lx / Ly rows 0..S-1 are row S
-#pragma unroll
-                        for (int d = 1; d <= S; ++d) {
-                            rA[(k + P - d) % P] = A; rB[(k + P - d) % P] = B; rC[(k + P - d) % P] = C;
-                        }
-                    }
-                    if (t >= 4 * S) {
-                        const int cr = u - S;
-                        f4 o[NOUT];
-                        const f4 lxx = tap_off(rA[k0], rA[k]);
-                        const f4 lyy = tap_main(rB[k0], rB[k1], rB[k], kn, kwn);
-                        const f4 lxy = tap_main(rC[k0], rC[k1], rC[k], kn, kwn);
-                        const f4 det = ((lxx * lyy) - (lxy * lxy)) * quat;
-                        o[0] = det;
-                        if (KEEP) { o[1] = lxx; o[2] = lyy; o[3] = lxy; }
-                        const f4(&oc)[NOUT] = o;
-                        if (cr >= cs && cr < ce) det_store_filled<S, NOUT>(out2c, L, w, h, cr, oc);
-                        if (NMS) {
-                            const int y = cr - 1;  // row under test: dm1, between dm2 (above) and det (below)
-                            if (y >= cs && y < ce && y >= nms.ylo && y <= nms.yhi) {  // uniform
-                                const float left = from_left_lane(dm1[3]), right = from_right_lane(dm1[0]);
-                                const float xm[4] = {left, dm1[0], dm1[1], dm1[2]};
-                                const float xp[4] = {dm1[1], dm1[2], dm1[3], right};
-                                unsigned m = 0;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    const float q = dm1[i];
-                                    const bool hit = (q > nms.thr) & (q > xp[i]) & (q > xm[i]) & (q > dm2[i]) & (q > det[i]);
-                                    m |= hit ? 1u << i : 0u;
-                                }
-                                m &= xok;
-                                wave_cands_push(cbuf, cnum, m, nms, lane, [&](int i) {  // at most two pixels of a quad can be strict maxima
-                                    Candidate cd;
-                                    cd.level = nms.level;
-                                    cd.idx = (unsigned)(y * w + L.x + i);
-                                    cd.v = i == 0 ? dm1[0] : i == 1 ? dm1[1] : i == 2 ? dm1[2] : dm1[3];
-                                    cd.xp = i == 0 ? dm1[1] : i == 1 ? dm1[2] : i == 2 ? dm1[3] : right;
-                                    cd.xm = i == 0 ? left : i == 1 ? dm1[0] : i == 2 ? dm1[1] : dm1[2];
-                                    cd.yp = i == 0 ? det[0] : i == 1 ? det[1] : i == 2 ? det[2] : det[3];
-                                    cd.ym = i == 0 ? dm2[0] : i == 1 ? dm2[1] : i == 2 ? dm2[2] : dm2[3];
-                                    cd.img = (unsigned)img;
-                                    return cd;
-                                });
-                            }
-                            dm2 = dm1;
-                            dm1 = det;
-                        }
-                    }
-                    if (k == P - 1 && bottom && u == h - 1 - S) {
-                        // The filled Lx / Ly rows h-S..h-1 are row h-1-S as well: enter its H result once more per
-                        // drained output row (the slot it takes holds the oldest row, which is no longer needed).
-#pragma unroll
-                        for (int d = 1; d <= S; ++d) {
-                            const int cr = u - S + d;
-                            const int j2 = (k + d) % P, j1 = (k + d + P - S) % P, j0 = (k + d + 1) % P;
-                            rA[j2] = A; rB[j2] = B; rC[j2] = C;
-                            f4 o[NOUT];
-                            const f4 lxx = tap_off(rA[j0], rA[j2]);
-                            const f4 lyy = tap_main(rB[j0], rB[j1], rB[j2], kn, kwn);
-                            const f4 lxy = tap_main(rC[j0], rC[j1], rC[j2], kn, kwn);
-                            o[0] = ((lxx * lyy) - (lxy * lxy)) * quat;
-                            if (KEEP) { o[1] = lxx; o[2] = lyy; o[3] = lxy; }
-                            const f4(&oc)[NOUT] = o;
-                            if (cr >= cs && cr < ce) det_store_filled<S, NOUT>(out2c, L, w, h, cr, oc);
-                        }
-                    }
-                }
-                a = na; b = nb; c = nc;
-            }
-        }
-    }
-    if (NMS) wave_cands_flush(cbuf, cnum, nms, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
 // gaussian_blur with a dense 5-tap kernel (types/image.rs:374-380: V(H(in)), fill_border after each pass), the
 // level-0 blur of the pyramid (sigma 1.6).  T = uint8_t folds in create_unit_float_image (types/image.rs:136):
 // the 256 possible values of `f32::from(v) * 1f32 / 255f32` are tabulated once per workgroup with that very
@@ -1062,26 +522,6 @@ inline StreamGrid plan_stream(K kernel, uint32_t w, uint32_t h, uint32_t n, int 
 
 namespace launch {
 
-// The candidate rectangle of scale_space_extrema.rs:32-42 (x in 1..w-2, y in 1..h-2) and :80-87 (descriptor
-// window inside the image) with the reference's float expressions; both border tests are monotone in the
-// coordinate, so the admissible coordinates form one interval.
-static void admissible(uint32_t dim, float border_m, int* lo, int* hi) {
-    auto out_lo = [&](int v) { return (roundf((float)v - border_m) - 1.0f) < 0.0f; };
-    auto out_hi = [&](int v) { return (roundf((float)v + border_m) + 1.0f) >= (float)dim; };
-    int a = 1, b = (int)dim - 2;
-    while (a <= b && out_lo(a)) ++a;
-    while (b >= a && out_hi(b)) --b;
-    *lo = a;
-    *hi = b;  // empty when lo > hi
-}
-
-bool detector_stream_supported(uint32_t sigma, uint32_t w, uint32_t h, float border_m, bool nms) {
-    if (sigma < 1 || sigma > 4) return false;
-    if (w < 4 * sigma + 8 || h < 4 * sigma + 8) return false;
-    // the extrema test reads Ldet one pixel around a candidate: keep that ring inside the interior rows/columns
-    return !nms || border_m >= (float)(sigma + 2);
-}
-
 // 5-tap gaussian_blur as a streaming kernel; u8 input needs 4-byte aligned rows (w % 4 == 0) for its dword loads
 bool blur5_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, bool is_u8) {
     return ntaps == 5 && w >= 16 && h >= 16 && (!is_u8 || (w & 3u) == 0);
@@ -1144,95 +584,6 @@ void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uin
                        in, nullptr, nullptr, nullptr, (int)w, (int)h, (int)w, (int)h, g2, g3[0], g3[1], g3[2], m.wgt[0],
                        m.wgt[1], nullptr, 0u, ca);
 }
-
-#define AKZ_FDET(S)                                                                                                   \
-    case S: {                                                                                                         \
-        dim3 gr;                                                                                                      \
-        if (d_cand && keep) {                                                                                         \
-            const StreamGrid sg = plan_stream(k_detector_stream<S, true, true>, w, h, n, S, 2, 4 * (S + 1), &gr);      \
-            hipLaunchKernelGGL((k_detector_stream<S, true, true>), gr, dim3(SNT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
-                               ldet_out, (int)w, (int)h, sg, kn, kwn, quat, na);                                      \
-        } else if (d_cand) {                                                                                          \
-            const StreamGrid sg = plan_stream(k_detector_stream<S, true, false>, w, h, n, S, 2, 4 * (S + 1), &gr);     \
-            hipLaunchKernelGGL((k_detector_stream<S, true, false>), gr, dim3(SNT), 0, s, lsmooth, lx, ly, lxx, lyy,     \
-                               lxy, ldet_out, (int)w, (int)h, sg, kn, kwn, quat, na);                                 \
-        } else if (keep) {                                                                                            \
-            const StreamGrid sg = plan_stream(k_detector_stream<S, false, true>, w, h, n, S, 2, 4 * (S + 1), &gr);     \
-            hipLaunchKernelGGL((k_detector_stream<S, false, true>), gr, dim3(SNT), 0, s, lsmooth, lx, ly, lxx, lyy,     \
-                               lxy, ldet_out, (int)w, (int)h, sg, kn, kwn, quat, na);                                 \
-        } else {                                                                                                      \
-            const StreamGrid sg = plan_stream(k_detector_stream<S, false, false>, w, h, n, S, 2, 4 * (S + 1), &gr);    \
-            hipLaunchKernelGGL((k_detector_stream<S, false, false>), gr, dim3(SNT), 0, s, lsmooth, lx, ly, lxx, lyy,    \
-                               lxy, ldet_out, (int)w, (int)h, sg, kn, kwn, quat, na);                                 \
-        }                                                                                                             \
-    } break;
-
-// Fused streaming detector of one level (k_detector_stream): same contract as detector_stream.
-void detector_fused_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
-                           float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
-                           float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
-    const Taps m = taps_scharr_main(sigma);
-    const float kn = m.wgt[0], kwn = m.wgt[1];
-    const float quat = (float)(sigma * sigma * sigma * sigma);
-    const bool keep = lxx && lyy && lxy;
-    StreamNms na{level, thr, 0, -1, 0, -1, d_cand, cap, d_count};
-    if (d_cand) {
-        admissible(w, border_m, &na.xlo, &na.xhi);
-        admissible(h, border_m, &na.ylo, &na.yhi);
-    }
-    switch (sigma) {
-        AKZ_FDET(1) AKZ_FDET(2) AKZ_FDET(3) AKZ_FDET(4)
-        default: break;
-    }
-}
-#undef AKZ_FDET
-
-#define AKZ_SDET(S)                                                                                                  \
-    case S: {                                                                                                        \
-        dim3 g1, g2;                                                                                                 \
-        const StreamGrid s1 = plan_stream(k_deriv1_stream<S>, w, h, n, S, 0, 4 * (S + 1), &g1);                                   \
-        hipLaunchKernelGGL((k_deriv1_stream<S>), g1, dim3(SNT), 0, s, lsmooth, lx, ly, (int)w, (int)h, s1, kn, kwn); \
-        if (d_cand) {                                                                                                \
-            if (keep) {                                                                                              \
-                const StreamGrid s2 = plan_stream(k_deriv2_stream<S, true, true>, w, h, n, S, 1, 4 * (S + 1), &g2);               \
-                hipLaunchKernelGGL((k_deriv2_stream<S, true, true>), g2, dim3(SNT), 0, s, (const float*)lx,          \
-                                   (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na); \
-            } else {                                                                                                 \
-                const StreamGrid s2 = plan_stream(k_deriv2_stream<S, true, false>, w, h, n, S, 1, 4 * (S + 1), &g2);              \
-                hipLaunchKernelGGL((k_deriv2_stream<S, true, false>), g2, dim3(SNT), 0, s, (const float*)lx,         \
-                                   (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na); \
-            }                                                                                                        \
-        } else if (keep) {                                                                                           \
-            const StreamGrid s2 = plan_stream(k_deriv2_stream<S, false, true>, w, h, n, S, 0, 4 * (S + 1), &g2);                  \
-            hipLaunchKernelGGL((k_deriv2_stream<S, false, true>), g2, dim3(SNT), 0, s, (const float*)lx,             \
-                               (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na);    \
-        } else {                                                                                                     \
-            const StreamGrid s2 = plan_stream(k_deriv2_stream<S, false, false>, w, h, n, S, 0, 4 * (S + 1), &g2);                 \
-            hipLaunchKernelGGL((k_deriv2_stream<S, false, false>), g2, dim3(SNT), 0, s, (const float*)lx,            \
-                               (const float*)ly, lxx, lyy, lxy, ldet_out, (int)w, (int)h, s2, kn, kwn, quat, na);    \
-        }                                                                                                            \
-    } break;
-
-// Streaming detector of one level: first derivatives, second derivatives + Ldet and, when d_cand is
-// given, the extrema candidates.  lxx/lyy/lxy may be null together (the planes are then not kept).
-void detector_stream(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
-                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level, float thr,
-                     float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {
-    const Taps m = taps_scharr_main(sigma);
-    const float kn = m.wgt[0], kwn = m.wgt[1];
-    const float quat = (float)(sigma * sigma * sigma * sigma);
-    const bool keep = lxx && lyy && lxy;
-    StreamNms na{level, thr, 0, -1, 0, -1, d_cand, cap, d_count};
-    if (d_cand) {
-        admissible(w, border_m, &na.xlo, &na.xhi);
-        admissible(h, border_m, &na.ylo, &na.yhi);
-    }
-    switch (sigma) {
-        AKZ_SDET(1) AKZ_SDET(2) AKZ_SDET(3) AKZ_SDET(4)
-        default: break;
-    }
-}
-#undef AKZ_SDET
 
 }  // namespace launch
 }  // namespace akz

@@ -303,7 +303,7 @@ class Context:
         return lib().akz_ctx_stream(self._h)
 
     def set_fed_mode(self, mode):
-        """2 = register-ownership fused kernel (default), 1 = LDS-only fused kernel, 0 = one launch per step."""
+        """2 = k_fed_own, temporally fused (default), 0 = k_fed_step, one launch per step."""
         _check(lib().akz_ctx_set_fed_mode(self._h, int(mode)))
 
     def set_candidate_hint(self, per_image):
@@ -316,8 +316,8 @@ class Context:
         _check(lib().akz_ctx_set_match_mode(self._h, int(mode)))
 
     def set_detector_mode(self, mode):
-        """2 = automatic (default), 1 = streaming kernel pair, 3 = fused streaming kernel, 4 = one LDS-tiled kernel,
-        0 = LDS-tiled kernel pair."""
+        """2 = automatic (default: column march for large launches, one LDS-tiled kernel for small ones), 5 = column
+        march, 4 = one LDS-tiled kernel, 0 = LDS-tiled kernel pair."""
         _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
 
     def set_detector_overlap(self, mode=1):

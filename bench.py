@@ -91,7 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
     ap.add_argument("--sublevels", type=int, default=4)
     ap.add_argument("--octaves", type=int, default=4)
-    ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one tiled kernel, 0 tiled pair")
+    ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one LDS-tiled kernel, 0 LDS-tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
     ap.add_argument("--det-overlap", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="detector launches on a side stream: -1 = the library default, 0 = off, 1 = every level as soon "
@@ -388,27 +388,25 @@ def main_rank(args):
             xch["host_ms"] += (time.perf_counter() - t0) * 1e3
 
     host_ms = {"begin": 0.0, "finish": 0.0, "calls": 0}  # host time inside extract_begin / extract_finish
-    keep_last = {"on": False, "results": None}
+    keep_last = {"results": None}
 
-    def run_steps(k_steps):
+    def run_steps(k_steps, keep_final=False):
         """k_steps passes over the shard as one software-pipelined stream of k_steps*NP batches:
         begin(batch j+1) is enqueued before finish(batch j), also across step boundaries, so the
         candidate fetch + host keypoint logic of a batch run under the kernels of the next one.
         Every step's results are complete (and, with N > 1, gathered) before run_steps returns."""
-        nk, inflight, done = 0, [], []
+        nk, inflight, done, steps_done = 0, [], [], 0
 
         def retire(res):
-            nonlocal nk, done
+            nonlocal nk, done, steps_done
             done.append(res)
             if len(done) == NP:  # a whole step has finished
                 nk = sum(r.counts(i)[1] for r in done for i in range(r.num_images))
                 if use_dist:
                     exchange_begin(done)
-                if keep_last["on"]:
-                    if keep_last["results"]:
-                        for r in keep_last["results"]:
-                            r.close()
-                    keep_last["results"] = done
+                steps_done += 1
+                if keep_final and steps_done == k_steps:
+                    keep_last["results"] = done  # only the LAST step's results outlive the timed region (self-check)
                 else:
                     for r in done:
                         r.close()
@@ -452,17 +450,16 @@ def main_rank(args):
     run_steps(1)
     warm_prof = ctx.get_profile(reset=True)
     ctx.set_profiling(0 if args.no_profile else 2)
-    keep_last["on"] = not stub and rank == 0 and not args.no_self_check
+    want_check = not stub and rank == 0 and not args.no_self_check
     barrier()
     t0 = time.perf_counter()
     xch["host_ms"] = xch["wait_ms"] = 0.0
     host_ms.update(begin=0.0, finish=0.0, calls=0)
-    nk = run_steps(args.steps)
+    nk = run_steps(args.steps, keep_final=want_check)
     barrier()
     elapsed_rank = time.perf_counter() - t0
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
-    keep_last["on"] = False
     elapsed = host_max(elapsed_rank)
     per_rank_s = host_allgather(elapsed_rank)
 

@@ -373,9 +373,8 @@ typedef struct akz_profile {
    the host-clock stages (what bench.py uses inside its timed region) */
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
-/* FED kernel variant: 2 (default) = k_fed_own, LDS tile + register ownership, up to 8 explicit steps
-   per launch; 1 = k_fed_fused, same tiling with all values through LDS; 0 = k_fed_step, one launch
-   per step.  Results are bit-identical. */
+/* FED kernel variant: 2 (default) = k_fed_own, LDS tile + register ownership, up to 8 explicit steps per launch (16
+   for launches of a few workgroups); 0 = k_fed_step, one launch per step.  Results are bit-identical. */
 int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
 /* Extrema candidates per image that the next extraction reserves room for (default 32768; it grows to 1.25x
    the largest count seen).  A list that overflows is detected by akz_extract_finish, which enlarges it and
@@ -386,12 +385,10 @@ int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
    Hamming distances from one integer GEMM; faster than the popcount scan from 128 x 128 descriptors up),
    0 = popcount kernel (k_match).  Results are identical. */
 int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
-/* Detector kernel variant: 2 (default) = automatic (the LDS-tiled pair, the one-kernel tiled form for
-   launches under 8 Mpx); 1 = streaming pair (first /
-   second derivatives) wherever it is supported (sigma_size <= 4); 3 = the single fused streaming kernel
-   (least HBM traffic, but one wave per SIMD: slower than the pair on MI355X today); 4 = the single
-   LDS-tiled kernel (first and second derivatives in one pass; the automatic choice for small launches);
-   0 = tiled pair only.  Results are bit-identical. */
+/* Detector kernel variant: 2 (default) = automatic (the one-pass column march k_detector_march for launches of
+   8 Mpx and more, the one-kernel LDS-tiled form k_detector_tiled below that); 5 = column march wherever it is
+   supported (sigma_size <= 4); 4 = the LDS-tiled kernel; 0 = the LDS-tiled kernel pair (the fallback for other
+   kernel sizes).  Results are bit-identical. */
 int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
 /* Detector overlap (default 0 = off).  1: launch each level's detector on a low-priority side stream as soon
    as its Lsmooth exists, concurrently with the diffusion of that and later levels (+4..11 % batch

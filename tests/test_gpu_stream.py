@@ -1,6 +1,7 @@
-"""The streaming (register-ring) kernels of akz_stream.hip against the CPU oracle and against the LDS-tiled
-kernels: every plane, keypoint and descriptor byte identical, for shapes that exercise the strip / band /
-edge-lane logic (widths that are not multiples of 4 or of the 240/248-pixel strips, several bands, batches)."""
+"""The streaming (register-ring) kernels of akz_stream.hip and the detector column march of akz_march.hip against the
+CPU oracle and against the LDS-tiled kernels: every plane, keypoint and descriptor byte identical, for shapes that
+exercise the strip / band / edge-column logic (widths that are not multiples of 4 or of the strips, several strips
+and bands, batches)."""
 import os
 
 import numpy as np
@@ -11,10 +12,10 @@ from test_gpu_extract import PLANES, assert_same_result
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 3, 4], ids=["pair", "fused", "tiled_fused"])
+@pytest.fixture(params=[4, 5], ids=["tiled_fused", "march"])
 def sctx(amd, request):
-    """A context with the streaming paths forced on (detector: the two-kernel pair or the fused kernel), so that
-    small test images take them too."""
+    """A context with the streaming preparation / contrast / blur kernels forced on and one of the one-kernel detector
+    forms forced (the LDS-tiled kernel or the column march), so that small test images take them too."""
     import torch
     c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
     c.set_detector_mode(request.param)
@@ -57,6 +58,47 @@ def test_stream_detector_response_op(sctx, ref, sigma):
             assert np.array_equal(got[k].cpu().numpy().reshape(h, w), v), (sigma, w, h, k)
         lean = sctx.detector_response(torch.from_numpy(ls).cuda(), sigma, keep_second=False)
         assert np.array_equal(lean["Ldet"].cpu().numpy().reshape(h, w), exp["Ldet"])
+
+
+@pytest.mark.parametrize("w,h", [(480, 72), (481, 40), (479, 33), (961, 50), (1441, 129), (24, 300), (41, 25)])
+def test_march_strip_and_band_edges(amd, ref, w, h):
+    """The column march on widths around its 480-column strips (one column into the next strip, one short of it, three
+    strips + 1), the smallest supported sizes and tall narrow images (several row bands): all six planes, every
+    sigma_size, against the oracle."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_detector_mode(5)
+    try:
+        rng = np.random.default_rng(w * 1000 + h)
+        ls = rng.random((2, h, w), dtype=np.float32)
+        for sigma in (1, 2, 3, 4):
+            if w < 4 * sigma + 8 or h < 4 * sigma + 8:
+                continue
+            got = c.detector_response(torch.from_numpy(ls).cuda(), sigma)
+            for i in range(2):
+                lx = ref.scharr(ls[i], True, False, sigma)
+                ly = ref.scharr(ls[i], False, True, sigma)
+                exp = {"Lx": lx, "Ly": ly, "Lxx": ref.scharr(lx, True, False, sigma), "Lyy": ref.scharr(ly, False, True, sigma),
+                       "Lxy": ref.scharr(lx, False, True, sigma)}
+                exp["Ldet"] = ((exp["Lxx"] * exp["Lyy"]) - (exp["Lxy"] * exp["Lxy"])) * np.float32(sigma ** 4)
+                for k, v in exp.items():
+                    assert np.array_equal(got[k][i].cpu().numpy(), v), (sigma, w, h, i, k)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("w,h,idx", [(962, 300, 11), (481, 270, 12), (1500, 200, 13)])
+def test_march_extract_candidates_across_strips(amd, ref, w, h, idx):
+    """Whole extraction with the march forced: extrema candidates next to strip and band boundaries must be reported
+    exactly once (keypoints, descriptors and every plane identical to the oracle)."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_detector_mode(5)
+    try:
+        frame = amd.synth_frame(w, h, idx)
+        assert_same_result(c.extract_features(frame), ref.extract(frame, threads=8))
+    finally:
+        c.close()
 
 
 def test_stream_equals_tiled_on_1080p_batch(ctx, sctx, amd):
@@ -137,54 +179,6 @@ def test_deferred_detector_overlap_gives_identical_results(amd, ref):
         assert_same_result(rb, ref.extract(f[0]), planes=False, img=0)
     finally:
         c.close()
-
-
-_LANES_CHILD = r"""
-import hashlib, os, sys
-sys.path.insert(0, os.path.join(sys.argv[1], "akaze-rust_amd", "python"))
-import numpy as np, torch
-import akaze_amd as A
-frames = [torch.from_numpy(A.synth_frame(*wh, 30 + i)[None]).cuda() for i, wh in enumerate([(320, 240), (517, 389), (640, 480), (320, 240), (200, 120), (517, 389)])]
-c = A.Context(0, torch.cuda.Stream().cuda_stream)
-q, out = [], []
-def retire(j):
-    r = j.finish()
-    h = hashlib.sha256()
-    kp = r.keypoints(0)
-    for f in ("x", "y", "response", "size", "octave", "class_id", "angle"):
-        h.update(np.ascontiguousarray(kp[f]).tobytes())
-    h.update(r.descriptors(0).tobytes())
-    for lvl in range(r.counts(0)[0]):
-        for pl in ("Lt", "Ldet", "Lflow", "Lstep"):
-            h.update(r.plane(lvl, pl, 0).tobytes())
-    out.append(h.hexdigest()); r.close()
-for rep in range(2):
-    for f in frames:
-        q.append(c.extract_begin(f))
-        if len(q) == 3:
-            retire(q.pop(0))
-while q:
-    retire(q.pop(0))
-print(" ".join(out))
-"""
-
-
-def test_two_lanes_give_identical_results(tmp_path):
-    """AKZ_LANES=1 (small jobs alternate between the context's stream and a second one with its own temporaries, three
-    jobs in flight, mixed sizes): every keypoint field, descriptor byte and the Lt / Ldet / Lflow / Lstep planes of
-    every level hash the same as with one lane."""
-    import subprocess, sys
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    script = tmp_path / "lanes_child.py"
-    script.write_text(_LANES_CHILD)
-    outs = []
-    for lanes in ("0", "1"):
-        env = dict(os.environ, AKZ_LANES=lanes)
-        run = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=env, timeout=300)
-        assert run.returncode == 0, run.stderr[-2000:]
-        outs.append(run.stdout.strip().splitlines()[-1].split())
-    assert len(outs[0]) == 12 and outs[0] == outs[1]
-    assert outs[0][:6] == outs[0][6:]  # the second pass over the same frames
 
 
 @pytest.mark.parametrize("shape", [(96, 132), (131, 248), (77, 516), (40, 1000), (300, 517)])

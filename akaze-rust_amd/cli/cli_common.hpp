@@ -140,6 +140,10 @@ inline Features read_features(const char* path) {
     f.keypoints.resize(nk);
     f.descriptors.resize(nd * f.desc_bytes);
     CLI_TRY(akz_read_features(path, f.keypoints.data(), f.descriptors.data(), nk, nd * f.desc_bytes, &nk, &nd, &f.desc_bytes));
+    if (nk != nd) {  // the reference would index keypoints[match.index] past the end and panic (lib.rs:267-274)
+        fprintf(stderr, "error: %s holds %llu keypoints but %llu descriptors\n", path, (unsigned long long)nk, (unsigned long long)nd);
+        exit(1);
+    }
     return f;
 }
 
@@ -147,11 +151,30 @@ inline std::vector<akz_match> match(akz_ctx* ctx, const Features& a, const Featu
     // match_features(.., 0.86, 1000, 3.0): the constants of match_features.rs:70-78 / extract_and_match.rs:101-109
     std::vector<akz_match> m(a.keypoints.size() ? a.keypoints.size() : 1);
     uint64_t n = 0;
+    if (a.desc_bytes && b.desc_bytes && a.desc_bytes != b.desc_bytes) {
+        fprintf(stderr, "error: the two feature sets have descriptors of different lengths (%llu and %llu bytes)\n",
+                (unsigned long long)a.desc_bytes, (unsigned long long)b.desc_bytes);
+        exit(1);
+    }
     const uint64_t db = a.desc_bytes ? a.desc_bytes : b.desc_bytes;
-    CLI_TRY(akz_match_features(ctx, a.keypoints.data(), a.descriptors.data(), a.keypoints.size(), b.keypoints.data(),
-                               b.descriptors.data(), b.keypoints.size(), db, 0.86, 1000, 3.0f, m.data(), &n));
+    const uint64_t nd0 = db ? a.descriptors.size() / db : 0, nd1 = db ? b.descriptors.size() / db : 0;
+    CLI_TRY(akz_match_features(ctx, a.keypoints.data(), a.keypoints.size(), a.descriptors.data(), nd0, b.keypoints.data(),
+                               b.keypoints.size(), b.descriptors.data(), nd1, db, 0.86, 1000, 3.0f, m.data(), &n));
     m.resize(n);
     return m;
+}
+
+// the debug pictures are PNG streams (the reference's RgbImage::save picks the encoder from the extension; this
+// library has a PNG encoder only): other extensions are refused rather than written with the wrong content
+inline bool is_png_path(const char* p) {
+    const size_t n = strlen(p);
+    return n >= 4 && (strcmp(p + n - 4, ".png") == 0 || strcmp(p + n - 4, ".PNG") == 0);
+}
+inline void require_png_path(const char* p, const char* option) {
+    if (!is_png_path(p)) {
+        fprintf(stderr, "error: %s %s: only .png output is supported\n", option, p);
+        exit(1);
+    }
 }
 
 inline akz_ctx* open_context() {

@@ -14,6 +14,7 @@ int main(int argc, char** argv) {
         {{'m', "match_image", "IMAGE_FILE_PATH", "Sets a path to write the match image to."}}};
     const cli::Args a = cli::parse(spec, argc, argv);
     const cli::Timer timer;
+    if (const char* mi = a.get("match_image")) cli::require_png_path(mi, "--match_image");
     const char* in0 = a.pos[0].c_str();
     const char* in1 = a.pos[1].c_str();
     const std::string prefix = a.pos[2];

@@ -77,9 +77,6 @@ struct akz_ctx {
     bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
-    hipStream_t det = nullptr;          // detector launches of a level, concurrent with the diffusion of later levels
-    int det_overlap = 0;                // 1: every level's detector on `det` as soon as its Lsmooth exists; 2: the fine
-                                        // octaves' detectors on `det` once the coarse octaves start (akz_ctx_set_detector_overlap)
     // stage profiling (akz_ctx_set_profiling)
     uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
     int prep_mode = 2;  // same values as det_mode, for the level-preparation kernel
@@ -117,7 +114,7 @@ struct StageTimer {
     bool on;
     hipStream_t s;
     StageTimer(akz_ctx* ctx, int st, hipStream_t stream = nullptr) : c(ctx), stage(st), s(stream ? stream : ctx->stream) {
-        on = c->profiling >= 2 || (c->profiling == 1 && (st == AKZ_ST_FED || (st == AKZ_ST_DETECTOR && s == ctx->stream)));
+        on = c->profiling >= 2 || (c->profiling == 1 && (st == AKZ_ST_FED || st == AKZ_ST_DETECTOR));
         if (!on) return;
         a = get(c);
         b = get(c);
@@ -276,10 +273,6 @@ int akz_ctx_destroy(akz_ctx* c) {
         if (c->cand_slot[i].p) (void)hipFree(c->cand_slot[i].p);
         if (c->count_slot[i].p) (void)hipFree(c->count_slot[i].p);
     }
-    if (c->det) {
-        (void)hipStreamSynchronize(c->det);
-        (void)hipStreamDestroy(c->det);
-    }
     if (c->aux) {
         (void)hipStreamSynchronize(c->aux);
         (void)hipStreamDestroy(c->aux);
@@ -291,7 +284,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     c->slab_pool.clear();
     c->spans.clear();
     c->ev_pool.clear();
-    c->aux = c->det = nullptr;
+    c->aux = nullptr;
     c->workers.reset();  // joins the host worker threads
     if (c->fed_done) { (void)hipEventDestroy(c->fed_done); c->fed_done = nullptr; }
     c->dead = true;  // results that are still alive keep the (now resource-less) struct; see result_delete
@@ -899,11 +892,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     job->t_begin_ms = now_ms();
     // ---- detector response (detector_response.rs:38-55) + extrema candidates ----
     // One append list for the whole batch (image id stored per candidate): a single D2H later.  The detector of
-    // level l needs only Lsmooth_l, which exists before that level's diffusion starts.  With detector overlap
-    // enabled its launches go to a side stream and run concurrently with the diffusion of levels l, l+1, ...: the
-    // coarse levels' launches are latency-bound and leave most of the chip idle, the other stream fills it
-    // (+4 % at 32 x 1080p, +11 % at 8 x 4K, -10 % for a single frame; off by default because kernels that share
-    // the chip can no longer be timed individually, which is what bench.py's roofline does).
+    // level l needs only Lsmooth_l; its launches follow the whole diffusion chain on the same stream (running them on
+    // a side stream next to the diffusion was +3 % with the round-1 kernels and is -15 % with the column march, which
+    // saturates the store path on its own: removed).
     const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint, 16u),
                                                       0x7fffffffull / sizeof(Candidate));
     AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
@@ -911,13 +902,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
     Candidate* d_cand = (Candidate*)c->cand_slot[slot].p;
     AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
-    if (c->det_overlap && !c->det) {  // lowest priority: the main stream's launches are dispatched first
-        int least = 0, greatest = 0;
-        AKZ_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        AKZ_HIP_TRY(hipStreamCreateWithPriority(&c->det, hipStreamNonBlocking, least));
-    }
-    hipStream_t ds = c->det_overlap ? c->det : nullptr;
-    std::vector<char> det_launched(L, 0);
     // derivatives, Ldet and extrema candidates of level l in one or two launches on stream `st_`; false when the
     // level's kernel size has no fused form (then the multi-kernel fallback runs on the main stream at the end)
     auto detector_one_pass = [&](size_t l, hipStream_t st_) -> bool {
@@ -943,49 +927,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         return false;
     };
-    // Lsmooth of level l is complete on the main stream: hand the level to the side stream
-    // Mode 2 hands over nothing until the first level of octave `kDeferOctave` has been prepared, then all finer
-    // levels at once: their bandwidth-bound detector launches run next to the coarse octaves' sequential chain of
-    // small, latency-bound preparation / diffusion launches, which leaves most of the chip idle.  The full-size
-    // diffusion launches (90 % of the FED pixel-steps) still run alone, so their timing stays meaningful.
-    constexpr uint32_t kDeferOctave = 2;
-    size_t defer_level = L;
-    if (c->det_overlap == 2)
-        for (size_t l = 1; l < L; ++l)
-            if (plan[l].octave >= kDeferOctave && plan[l - 1].octave < kDeferOctave) defer_level = l;
-    static const uint64_t defer_min_px = [] {
-        const char* e = std::getenv("AKZ_DET_DEFER_MIN_PX");
-        return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
-    }();
-    if (c->det_overlap == 2 && (defer_level >= L || (uint64_t)w * h * n < defer_min_px)) ds = nullptr;  // nothing to hide / launch-bound
-    auto overlap_detector = [&](size_t l) -> int {
-        if (!ds) return AKZ_OK;
-        if (c->det_overlap == 2) {
-            if (l != defer_level) return AKZ_OK;
-            hipEvent_t ready = StageTimer::get(c);
-            AKZ_HIP_TRY(hipEventRecord(ready, s));
-            AKZ_HIP_TRY(hipStreamWaitEvent(ds, ready, 0));
-            c->ev_pool.push_back(ready);
-            // short-lived workgroups (one tile each) on the low-priority side stream: the main stream's small launches
-            // get the slots they free
-            launch::set_tile_grid_limit(1L << 40);
-            for (size_t f = 0; f < l; ++f) det_launched[f] = detector_one_pass(f, ds) ? 1 : 0;
-            launch::set_tile_grid_limit(0);
-            return AKZ_OK;
-        }
-        hipEvent_t ready = StageTimer::get(c);
-        AKZ_HIP_TRY(hipEventRecord(ready, s));
-        AKZ_HIP_TRY(hipStreamWaitEvent(ds, ready, 0));
-        c->ev_pool.push_back(ready);  // the wait refers to the record above; the event itself can be reused
-        det_launched[l] = detector_one_pass(l, ds) ? 1 : 0;
-        return AKZ_OK;
-    };
     // ---- level 0: Lt0 = gaussian_blur(img, base_scale_offset); contrast factor (lib.rs:56-69) ----
     {
         StageTimer st(c, AKZ_ST_BLUR0);
         AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));
     }
-    AKZ_TRY(overlap_detector(0));  // Lsmooth_0 is Lt_0 (lib.rs:62-63)
     {
         StageTimer st(c, AKZ_ST_CONTRAST);
         AKZ_TRY(contrast_impl(c, P(0, AKZ_LSMOOTH), w, h, n, cfg.contrast_percentile, 1.0,
@@ -1039,7 +985,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             float* lstep0 = keep_all ? P(i, AKZ_LSTEP) : nullptr;
             if (lstep0 && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep0, 0, plane_bytes(lv.w, lv.h, n), s));
         }
-        AKZ_TRY(overlap_detector(i));
         {
             StageTimer st(c, AKZ_ST_FED);
             AKZ_TRY(fed_impl(c, fed_in, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
@@ -1059,7 +1004,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group
     std::map<uint32_t, std::vector<launch::DetLevelDesc>> sets;
     for (size_t l = 0; l < L; ++l) {
-        if (det_launched[l]) continue;
         const LevelPlan& lv = plan[l];
         const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
         if (detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all) == 4) {
@@ -1092,12 +1036,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
     }
     AKZ_HIP_TRY(hipGetLastError());
-    if (ds) {  // the main stream (and with it nms_done and the next batch) continues after the side stream's launches
-        hipEvent_t done = StageTimer::get(c);
-        AKZ_HIP_TRY(hipEventRecord(done, ds));
-        AKZ_HIP_TRY(hipStreamWaitEvent(s, done, 0));
-        c->ev_pool.push_back(done);
-    }
     job->nms_done = StageTimer::get(c);
     AKZ_HIP_TRY(hipEventRecord(job->nms_done, s));
     job->slot = slot;
@@ -1364,6 +1302,102 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
     return AKZ_OK;
 }
 
+// `pub mod ops` on CALLER-PROVIDED evolutions (ops::scale_space_extrema::detect_keypoints, scale_space_extrema.rs:199-203,
+// and ops::descriptors::extract_descriptors, descriptors.rs:14-27, take a `Vec<EvolutionStep>` that the caller may have
+// built or modified itself): the host planes of one image are uploaded into a result's slab, the extrema pass runs on
+// the uploaded Ldet planes and the usual finish half (host keypoint logic, orientation, descriptors) follows.
+static int extract_from_planes(akz_ctx* c, uint32_t w, uint32_t h, const akz_config* cfgp, const float* const* planes,
+                               uint64_t n_levels, uint32_t flags, akz_result** out) {
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    AKZ_TRY(bind(c));
+    if (!cfgp || !planes) {
+        set_error("extract_from_planes: null config / plane table");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    int slot = -1;
+    for (int i = 0; i < akz_ctx::kSlots; ++i)
+        if (!c->slot_busy[i]) {
+            slot = i;
+            break;
+        }
+    if (slot < 0) {
+        set_error("extract_from_planes: too many extractions in flight on this context (finish one first)");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    std::unique_ptr<akz_job> job(new akz_job);
+    job->r.reset(new akz_result);
+    akz_result* r = job->r.get();
+    r->ctx = c;
+    ++c->live_results;
+    r->cfg = *cfgp;
+    r->w = w; r->h = h; r->n = 1;
+    r->flags = (flags & ~(uint32_t)AKZ_NO_DETECT) | AKZ_KEEP_ALL_PLANES;
+    AKZ_TRY(build_plan(w, h, r->cfg, r->plan));
+    const std::vector<LevelPlan>& plan = r->plan;
+    const size_t L = plan.size();
+    if (n_levels != L) {
+        set_error("extract_from_planes: the number of evolutions does not match allocate_evolutions(width, height, options)");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const bool detect = !(flags & AKZ_NO_DETECT);
+    for (size_t l = 0; l < L; ++l)
+        for (int p : {(int)AKZ_LT, (int)AKZ_LX, (int)AKZ_LY, (int)AKZ_LDET})
+            if (!planes[l * 10 + p] && (detect || p != AKZ_LDET)) {
+                set_error("extract_from_planes: Lt, Lx, Ly (and Ldet for detection) of every evolution are required");
+                return AKZ_ERR_INVALID_ARG;
+            }
+    hipStream_t s = c->stream;
+    std::memset(r->planes, 0, sizeof(r->planes));
+    size_t off = 0;
+    std::vector<std::pair<float**, size_t>> fix;
+    for (size_t l = 0; l < L; ++l)
+        for (int p = 0; p < 10; ++p) {
+            if (!planes[l * 10 + p]) continue;
+            fix.emplace_back(&r->planes[l][p], off);
+            off += align_up(plane_bytes(plan[l].w, plan[l].h, 1), 256);
+        }
+    const size_t k_off = off;
+    off += 256;
+    AKZ_TRY(slab_acquire(c, off, &r->slab, &r->slab_bytes));
+    for (auto& f : fix) *f.first = (float*)((char*)r->slab + f.second);
+    if (!r->planes[0][AKZ_LSMOOTH]) r->planes[0][AKZ_LSMOOTH] = r->planes[0][AKZ_LT];
+    r->d_k = (double*)((char*)r->slab + k_off);
+    struct Guard {
+        akz_result* r;
+        bool armed = true;
+        ~Guard() {
+            if (armed) result_release_device(r);
+        }
+    } guard{r};
+    job->t_begin_ms = now_ms();
+    AKZ_HIP_TRY(hipMemsetAsync(r->d_k, 0, sizeof(double), s));  // the contrast factor is not part of the inputs
+    for (size_t l = 0; l < L; ++l)
+        for (int p = 0; p < 10; ++p)
+            if (planes[l * 10 + p] && r->planes[l][p] && !(l == 0 && p == AKZ_LSMOOTH && r->planes[0][AKZ_LSMOOTH] == r->planes[0][AKZ_LT]))
+                AKZ_HIP_TRY(hipMemcpyAsync(r->planes[l][p], planes[l * 10 + p], plane_bytes(plan[l].w, plan[l].h, 1),
+                                           hipMemcpyHostToDevice, s));
+    AKZ_HIP_TRY(hipStreamSynchronize(s));  // the caller's planes are pageable host memory: complete before returning
+    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max<uint32_t>(c->cand_cap_hint, 16u), 0x7fffffffull / sizeof(Candidate));
+    AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
+    AKZ_TRY(ensure(c, c->count_slot[slot], 256));
+    uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
+    AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+    if (detect)
+        for (size_t l = 0; l < L; ++l)
+            launch::nms(s, r->planes[l][AKZ_LDET], plan[l].w, plan[l].h, 1, (uint64_t)plan[l].w * plan[l].h, (uint32_t)l,
+                        (float)r->cfg.detector_threshold, border_margin(plan[l], r->cfg), (Candidate*)c->cand_slot[slot].p, cap,
+                        d_count);
+    AKZ_HIP_TRY(hipGetLastError());
+    job->nms_done = StageTimer::get(c);
+    AKZ_HIP_TRY(hipEventRecord(job->nms_done, s));
+    job->slot = slot;
+    job->cap = cap;
+    c->slot_busy[slot] = true;
+    guard.armed = false;
+    return extract_finish(job.release(), out);
+}
+
 template <typename T>
 static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
                         uint32_t flags, akz_result** out) {
@@ -1417,6 +1451,10 @@ int akz_extract_begin_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, ui
     return extract_begin<float>(c, d_imgs, w, h, n, cfg, flags, out);
 }
 int akz_extract_finish(akz_job* job, akz_result** out) { return extract_finish(job, out); }
+int akz_extract_from_planes(akz_ctx* c, uint32_t w, uint32_t h, const akz_config* cfg, const float* const* planes,
+                            uint64_t n_levels, uint32_t flags, akz_result** out) {
+    return extract_from_planes(c, w, h, cfg, planes, n_levels, flags, out);
+}
 int akz_job_abandon(akz_job* job) {
     if (job && job->r) (void)hipSetDevice(job->r->ctx->device);
     job_destroy(job);
@@ -1696,7 +1734,7 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
         launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p,
                            (uint32_t)n1, thr, bound, merged + n0, merged);
     } else {
-        launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, merged + n0, merged);
+        launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, rows_le_61, merged + n0, merged);
     }
     launch::match_compact(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, thr, lowes_ratio * lowes_ratio,
                           d_out, (unsigned long long*)d_n_out);
@@ -1868,14 +1906,21 @@ int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
 }
 int akz_remove_outliers(const akz_keypoint*, uint64_t, const akz_keypoint*, uint64_t, const akz_match*, uint64_t, uint64_t,
                         float, float, akz_match*, uint64_t*);
-int akz_match_features(akz_ctx* c, const akz_keypoint* kp0, const uint8_t* d0, uint64_t n0, const akz_keypoint* kp1,
-                       const uint8_t* d1, uint64_t n1, uint64_t desc_bytes, double lowes_ratio, uint64_t ransac_trials,
-                       float ransac_epsilon_inliers, akz_match* out, uint64_t* n_out) {
+int akz_match_features(akz_ctx* c, const akz_keypoint* kp0, uint64_t n_kp0, const uint8_t* d0, uint64_t n_d0,
+                       const akz_keypoint* kp1, uint64_t n_kp1, const uint8_t* d1, uint64_t n_d1, uint64_t desc_bytes,
+                       double lowes_ratio, uint64_t ransac_trials, float ransac_epsilon_inliers, akz_match* out,
+                       uint64_t* n_out) {
     if (!n_out) return AKZ_ERR_INVALID_ARG;
-    std::vector<akz_match> raw((size_t)std::max<uint64_t>(1, n0));
+    // a match indexes the keypoint lists with descriptor indices (lib.rs:267-274): the reference panics on a set with
+    // more descriptors than keypoints as soon as such a match reaches RANSAC; here it is refused up front
+    if (n_d0 > n_kp0 || n_d1 > n_kp1) {
+        set_error("match_features: a feature set has more descriptors than keypoints");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    std::vector<akz_match> raw((size_t)std::max<uint64_t>(1, n_d0));
     uint64_t n_raw = 0;
-    AKZ_TRY(akz_descriptor_match(c, d0, n0, d1, n1, desc_bytes, 10000, lowes_ratio, raw.data(), &n_raw));  // lib.rs:261-266
-    return akz_remove_outliers(kp0, n0, kp1, n1, raw.data(), n_raw, ransac_trials, 0.05f, ransac_epsilon_inliers, out,
+    AKZ_TRY(akz_descriptor_match(c, d0, n_d0, d1, n_d1, desc_bytes, 10000, lowes_ratio, raw.data(), &n_raw));  // lib.rs:261-266
+    return akz_remove_outliers(kp0, n_kp0, kp1, n_kp1, raw.data(), n_raw, ransac_trials, 0.05f, ransac_epsilon_inliers, out,
                                n_out);                                                                        // lib.rs:267-274
 }
 // akaze::extract_features(input_image_path, options) — akaze/src/lib.rs:167-194
@@ -1925,12 +1970,6 @@ int akz_write_evolutions(const akz_result* r, uint64_t img, const char* dir) {
 int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
     if (!c || (mode != 0 && mode != 2 && mode != 4 && mode != 5)) return AKZ_ERR_INVALID_ARG;
     c->det_mode = mode;
-    return AKZ_OK;
-}
-
-int akz_ctx_set_detector_overlap(akz_ctx* c, int on) {
-    if (!c) return AKZ_ERR_INVALID_ARG;
-    c->det_overlap = on < 0 ? 0 : (on > 2 ? 1 : on);
     return AKZ_OK;
 }
 

@@ -865,6 +865,24 @@ int akz_image_save_plane_png(const char* path, const float* plane, uint32_t widt
     return img::encode_png(path, out.data(), width, height, 1);
 }
 
+int akz_random_color(uint8_t* rgb) {
+    if (!rgb) return AKZ_ERR_INVALID_ARG;
+    const img::Rgb c = img::random_color();
+    rgb[0] = c.r; rgb[1] = c.g; rgb[2] = c.b;
+    return AKZ_OK;
+}
+int akz_draw_circle(uint8_t* rgb, uint32_t width, uint32_t height, float x, float y, const uint8_t* color, float radius) {
+    if (!rgb || !color) { set_error("akz_draw_circle: null argument"); return AKZ_ERR_INVALID_ARG; }
+    img::draw_circle(rgb, width, height, x, y, img::Rgb{color[0], color[1], color[2]}, radius);
+    return AKZ_OK;
+}
+int akz_draw_line(uint8_t* rgb, uint32_t width, uint32_t height, float x0, float y0, float x1, float y1,
+                  const uint8_t* color, float radius) {
+    if (!rgb || !color) { set_error("akz_draw_line: null argument"); return AKZ_ERR_INVALID_ARG; }
+    img::draw_line(rgb, width, height, x0, y0, x1, y1, img::Rgb{color[0], color[1], color[2]}, radius);
+    return AKZ_OK;
+}
+
 int akz_draw_keypoints(uint8_t* rgb, uint32_t width, uint32_t height, const akz_keypoint* kps, uint64_t n) {
     if ((!rgb && width && height) || (!kps && n)) { set_error("akz_draw_keypoints: null argument"); return AKZ_ERR_INVALID_ARG; }
     for (uint64_t i = 0; i < n; ++i) img::draw_circle(rgb, width, height, kps[i].x, kps[i].y, img::random_color(), kps[i].size);

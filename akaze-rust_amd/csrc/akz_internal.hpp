@@ -187,8 +187,9 @@ void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint3
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64);
 uint32_t match_num_chunks(uint32_t n0, uint32_t n1);
+// rows_le_61: rows are M-LDB descriptors (at most 61 bytes): bytes 61..63 are padding and not compared
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
-           MatchRec* d_part, MatchRec* d_out);
+           bool rows_le_61, MatchRec* d_part, MatchRec* d_out);
 void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out);
 // the same scan on the matrix cores (akz_match.hip): descriptor bits unpacked to int8, distances from one integer
 // GEMM; identical records.  Rows of the unpacked images are padded (match_mfma_rows).
@@ -212,9 +213,6 @@ void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t
                 uint32_t threshold, uint32_t* bound, MatchRec* d_part, MatchRec* d_out);
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out);
-// workgroups of the following persistent tiled launches issued by this thread (0: built-in value); a huge value makes
-// every workgroup take one tile
-void set_tile_grid_limit(long blocks);
 }  // namespace launch
 
 // ---- host keypoint logic (akz_keypoints.cpp) ---------------------------------------------

@@ -102,6 +102,22 @@ struct Json {
         p += (size_t)(e - b);
         return v;
     }
+    // an unsigned integer field (serde's u8 / u32 / u64 / usize): digits only, exact, at most `max`; anything else —
+    // null, a sign, a fraction, an exponent, a value out of range — is an error, as it is for serde
+    uint64_t uint(uint64_t max) {
+        ws();
+        const size_t b = p;
+        uint64_t v = 0;
+        bool over = false;
+        while (p < s.size() && s[p] >= '0' && s[p] <= '9') {
+            const uint64_t d = (uint64_t)(s[p] - '0');
+            if (v > (UINT64_MAX - d) / 10) over = true;
+            else v = v * 10 + d;
+            ++p;
+        }
+        if (p == b || over || v > max || (p < s.size() && (s[p] == '.' || s[p] == 'e' || s[p] == 'E'))) ok = false;
+        return ok ? v : 0;
+    }
     void skip() {  // any value
         ws();
         if (eat('{')) { if (!eat('}')) { do { key(); skip(); } while (ok && eat(',')); expect('}'); } }
@@ -161,8 +177,8 @@ int parse_features_json(const std::string& s, FeaturesData& f) {
                             if (fk == "point") { j.expect('['); kp.x = (float)j.number(); j.expect(','); kp.y = (float)j.number(); j.expect(']'); }
                             else if (fk == "response") kp.response = (float)j.number();
                             else if (fk == "size") kp.size = (float)j.number();
-                            else if (fk == "octave") kp.octave = (uint64_t)j.number();
-                            else if (fk == "class_id") kp.class_id = (uint64_t)j.number();
+                            else if (fk == "octave") kp.octave = j.uint(UINT64_MAX);
+                            else if (fk == "class_id") kp.class_id = j.uint(UINT64_MAX);
                             else if (fk == "angle") kp.angle = (float)j.number();
                             else j.skip();
                         } while (j.ok && j.eat(','));
@@ -182,7 +198,7 @@ int parse_features_json(const std::string& s, FeaturesData& f) {
                             if (fk == "vector") {
                                 j.expect('[');
                                 if (!j.eat(']')) {
-                                    do d.push_back((uint8_t)j.number()); while (j.ok && j.eat(','));
+                                    do d.push_back((uint8_t)j.uint(255)); while (j.ok && j.eat(','));
                                     j.expect(']');
                                 }
                             } else j.skip();
@@ -314,7 +330,16 @@ int akz_write_matches(const char* path, const akz_match* m, uint64_t n) {
 }
 
 // akaze_util::deserialize_matches_from_file — lib.rs:56-67.  out == NULL returns the count only.
+static int read_matches_impl(const char* path, akz_match* out, uint64_t cap, uint64_t* n_out);
 int akz_read_matches(const char* path, akz_match* out, uint64_t cap, uint64_t* n_out) {
+    try {
+        return read_matches_impl(path, out, cap, n_out);
+    } catch (const std::exception& e) {  // bad_alloc / length_error on absurd element counts: nothing throws across the ABI
+        set_error(std::string("read_matches: ") + e.what());
+        return AKZ_ERR_NO_MEMORY;
+    }
+}
+static int read_matches_impl(const char* path, akz_match* out, uint64_t cap, uint64_t* n_out) {
     if (!path || !n_out) return AKZ_ERR_INVALID_ARG;
     std::string s;
     AKZ_TRY(read_file(path, s));
@@ -328,8 +353,8 @@ int akz_read_matches(const char* path, akz_match* out, uint64_t cap, uint64_t* n
                 j.expect('{');
                 do {
                     const std::string k = j.key();
-                    if (k == "index_0") m.index_0 = (uint64_t)j.number();
-                    else if (k == "index_1") m.index_1 = (uint64_t)j.number();
+                    if (k == "index_0") m.index_0 = j.uint(UINT64_MAX);
+                    else if (k == "index_1") m.index_1 = j.uint(UINT64_MAX);
                     else if (k == "distance") m.distance = j.number();
                     else j.skip();
                 } while (j.ok && j.eat(','));
@@ -383,7 +408,21 @@ int akz_config_to_json(const akz_config* cfg, char* buf, uint64_t cap, uint64_t*
     return AKZ_OK;
 }
 
+static int config_from_json_impl(const char* json, akz_config* cfg);
 int akz_config_from_json(const char* json, akz_config* cfg) {
+    try {
+        akz_config tmp;
+        if (!json || !cfg) return AKZ_ERR_INVALID_ARG;
+        tmp = *cfg;
+        const int st = config_from_json_impl(json, &tmp);  // *cfg is untouched unless the whole text parsed
+        if (st == AKZ_OK) *cfg = tmp;
+        return st;
+    } catch (const std::exception& e) {
+        set_error(std::string("config_from_json: ") + e.what());
+        return AKZ_ERR_NO_MEMORY;
+    }
+}
+static int config_from_json_impl(const char* json, akz_config* cfg) {
     if (!json || !cfg) return AKZ_ERR_INVALID_ARG;
     const std::string s(json);
     Json j(s);
@@ -391,16 +430,16 @@ int akz_config_from_json(const char* json, akz_config* cfg) {
     if (!j.eat('}')) {
         do {
             const std::string k = j.key();
-            if (k == "num_sublevels") cfg->num_sublevels = (uint32_t)j.number();
-            else if (k == "max_octave_evolution") cfg->max_octave_evolution = (uint32_t)j.number();
+            if (k == "num_sublevels") cfg->num_sublevels = (uint32_t)j.uint(UINT32_MAX);
+            else if (k == "max_octave_evolution") cfg->max_octave_evolution = (uint32_t)j.uint(UINT32_MAX);
             else if (k == "base_scale_offset") cfg->base_scale_offset = j.number();
             else if (k == "initial_contrast") cfg->initial_contrast = j.number();
             else if (k == "contrast_percentile") cfg->contrast_percentile = j.number();
-            else if (k == "contrast_factor_num_bins") cfg->contrast_factor_num_bins = (uint64_t)j.number();
+            else if (k == "contrast_factor_num_bins") cfg->contrast_factor_num_bins = j.uint(UINT64_MAX);
             else if (k == "derivative_factor") cfg->derivative_factor = j.number();
             else if (k == "detector_threshold") cfg->detector_threshold = j.number();
-            else if (k == "descriptor_channels") cfg->descriptor_channels = (uint64_t)j.number();
-            else if (k == "descriptor_pattern_size") cfg->descriptor_pattern_size = (uint64_t)j.number();
+            else if (k == "descriptor_channels") cfg->descriptor_channels = j.uint(UINT64_MAX);
+            else if (k == "descriptor_pattern_size") cfg->descriptor_pattern_size = j.uint(UINT64_MAX);
             else j.skip();
         } while (j.ok && j.eat(','));
         j.expect('}');

@@ -823,7 +823,9 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
 // ---------------------------------------------------------------------------------------------
 constexpr int MT = 256;  // queries per workgroup == train rows per LDS tile
 
-__device__ __forceinline__ unsigned hamming64(const uint4 (&q)[4], const uint4* __restrict__ row) {
+// tail_mask: which bits of the last dword (bytes 60..63 of a row) are compared — 0xff for M-LDB rows (61 bytes;
+// bytes 61..63 are padding that neither matcher kernel looks at), all ones for full 64-byte rows
+__device__ __forceinline__ unsigned hamming64(const uint4 (&q)[4], const uint4* __restrict__ row, unsigned tail_mask) {
     unsigned d = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -831,7 +833,7 @@ __device__ __forceinline__ unsigned hamming64(const uint4 (&q)[4], const uint4* 
         d += __popc(q[k].x ^ t.x);
         d += __popc(q[k].y ^ t.y);
         d += __popc(q[k].z ^ t.z);
-        d += __popc(q[k].w ^ t.w);
+        d += __popc((q[k].w ^ t.w) & (k == 3 ? tail_mask : 0xffffffffu));
     }
     return d;
 }
@@ -849,7 +851,7 @@ __device__ __forceinline__ void top2_feed(unsigned d, unsigned j, unsigned& min_
 // queries; k_match_merge folds the chunks in index order, which reproduces the sequential scan exactly
 // (top-2 of a union = top-2 of the per-part top-2s; ties keep the lowest index).
 __global__ void __launch_bounds__(MT) k_match(const uint4* __restrict__ d0, unsigned n0, const uint4* __restrict__ d1,
-                                             unsigned n1, unsigned chunk_rows, unsigned threshold,
+                                             unsigned n1, unsigned chunk_rows, unsigned threshold, unsigned tail_mask,
                                              MatchRec* __restrict__ out) {
     __shared__ uint4 s_tile[MT * 4];
     const unsigned i = blockIdx.x * MT + threadIdx.x;
@@ -866,14 +868,14 @@ __global__ void __launch_bounds__(MT) k_match(const uint4* __restrict__ d0, unsi
         __syncthreads();
         unsigned r = 0;
         for (; r + 4 <= rows; r += 4) {  // four independent popcount chains per iteration
-            const unsigned da = hamming64(q, s_tile + (r + 0) * 4), db = hamming64(q, s_tile + (r + 1) * 4);
-            const unsigned dc = hamming64(q, s_tile + (r + 2) * 4), dd = hamming64(q, s_tile + (r + 3) * 4);
+            const unsigned da = hamming64(q, s_tile + (r + 0) * 4, tail_mask), db = hamming64(q, s_tile + (r + 1) * 4, tail_mask);
+            const unsigned dc = hamming64(q, s_tile + (r + 2) * 4, tail_mask), dd = hamming64(q, s_tile + (r + 3) * 4, tail_mask);
             top2_feed(da, base + r + 0, min_d, second, min_j);
             top2_feed(db, base + r + 1, min_d, second, min_j);
             top2_feed(dc, base + r + 2, min_d, second, min_j);
             top2_feed(dd, base + r + 3, min_d, second, min_j);
         }
-        for (; r < rows; ++r) top2_feed(hamming64(q, s_tile + r * 4), base + r, min_d, second, min_j);
+        for (; r < rows; ++r) top2_feed(hamming64(q, s_tile + r * 4, tail_mask), base + r, min_d, second, min_j);
     }
     if (live) {
         MatchRec m;
@@ -1078,13 +1080,14 @@ void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t ch
     hipLaunchKernelGGL(k_match_merge, dim3((n0 + 255) / 256), dim3(256), 0, s, d_part, n0, chunks, threshold, d_out);
 }
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
-           MatchRec* d_part, MatchRec* d_out) {
+           bool rows_le_61, MatchRec* d_part, MatchRec* d_out) {
     if (n0 == 0) return;
     const uint32_t chunks = match_num_chunks(n0, n1);
     const uint32_t tiles = std::max<uint32_t>(1, (n1 + MT - 1) / MT);
     const uint32_t chunk_rows = ((tiles + chunks - 1) / chunks) * MT;
     hipLaunchKernelGGL(k_match, dim3((n0 + MT - 1) / MT, chunks), dim3(MT), 0, s, reinterpret_cast<const uint4*>(d0), n0,
-                       reinterpret_cast<const uint4*>(d1), n1, chunk_rows, threshold, chunks > 1 ? d_part : d_out);
+                       reinterpret_cast<const uint4*>(d1), n1, chunk_rows, threshold, rows_le_61 ? 0xffu : 0xffffffffu,
+                       chunks > 1 ? d_part : d_out);
     if (chunks > 1) match_merge(s, d_part, n0, chunks, threshold, d_out);
 }
 void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,

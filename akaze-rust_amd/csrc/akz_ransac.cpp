@@ -20,7 +20,7 @@
 //     (tests/test_reference_outputs.py).  akz_random_seed reseeds the calling thread's source.
 // Not reproducible bit for bit (and not a parity target): the HashSet iteration order of the
 // 8 sampled indices (random per process) and nalgebra's f32 SVD.  Here the sample is taken in ascending
-// index order and the decomposition is a cyclic Jacobi eigen-solve of A^T A in f64.
+// index order and the decomposition is a one-sided Jacobi SVD of the 8x9 matrix in f64.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -38,40 +38,44 @@ DefaultSource& default_source() {
 
 namespace {
 
-// eigen-decomposition of the symmetric 9x9 matrix m (destroyed): eigenvalues in val, vectors in the
-// columns of vec
-void jacobi9(double m[9][9], double val[9], double vec[9][9]) {
-    for (int i = 0; i < 9; ++i)
-        for (int j = 0; j < 9; ++j) vec[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0.0;
-        for (int i = 0; i < 9; ++i)
-            for (int j = i + 1; j < 9; ++j) off += m[i][j] * m[i][j];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 9; ++p)
-            for (int q = p + 1; q < 9; ++q) {
-                if (std::fabs(m[p][q]) < 1e-300) continue;
-                const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+// Thin SVD of the 8x9 design matrix A by one-sided (Hestenes) Jacobi rotations on the columns of A^T (9x8, f64): the
+// rotated columns become orthogonal, their norms are the 8 singular values and the normalised columns the right
+// singular vectors of A.  Works on A itself, not on A^T A, so the condition number is not squared (pixel coordinates
+// of ~1e3 give entries of ~1e6: the eigenvalue route lost the smallest singular values in rounding noise).
+void svd_rows(const float a[8][9], double sigma[8], double vt[8][9]) {
+    double m[9][8];
+    for (int r = 0; r < 8; ++r)
+        for (int k = 0; k < 9; ++k) m[k][r] = (double)a[r][k];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 8; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
                 for (int k = 0; k < 9; ++k) {
-                    const double a = m[k][p], b = m[k][q];
-                    m[k][p] = c * a - s * b;
-                    m[k][q] = s * a + c * b;
+                    alpha += m[k][p] * m[k][p];
+                    beta += m[k][q] * m[k][q];
+                    gamma += m[k][p] * m[k][q];
                 }
+                if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta) || gamma == 0.0) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
                 for (int k = 0; k < 9; ++k) {
-                    const double a = m[p][k], b = m[q][k];
-                    m[p][k] = c * a - s * b;
-                    m[q][k] = s * a + c * b;
-                }
-                for (int k = 0; k < 9; ++k) {
-                    const double a = vec[k][p], b = vec[k][q];
-                    vec[k][p] = c * a - s * b;
-                    vec[k][q] = s * a + c * b;
+                    const double x = m[k][p], y = m[k][q];
+                    m[k][p] = c * x - sn * y;
+                    m[k][q] = sn * x + c * y;
                 }
             }
+        if (!rotated) break;
     }
-    for (int i = 0; i < 9; ++i) val[i] = m[i][i];
+    for (int i = 0; i < 8; ++i) {
+        double nrm = 0.0;
+        for (int k = 0; k < 9; ++k) nrm += m[k][i] * m[k][i];
+        nrm = std::sqrt(nrm);
+        sigma[i] = nrm;
+        for (int k = 0; k < 9; ++k) vt[i][k] = nrm > 0.0 ? m[k][i] / nrm : 0.0;
+    }
 }
 
 struct Model {
@@ -87,25 +91,17 @@ bool estimate(const akz_keypoint* k0, const akz_keypoint* k1, const akz_match* s
         const float row[9] = {x0 * x1, x0 * y1, x0, y0 * x1, y0 * y1, y0, x1, y1, 1.0f};
         std::memcpy(a[i], row, sizeof(row));
     }
-    double m[9][9], val[9], vec[9][9];
-    for (int i = 0; i < 9; ++i)
-        for (int j = 0; j < 9; ++j) {
-            double s = 0.0;
-            for (int r = 0; r < 8; ++r) s += (double)a[r][i] * (double)a[r][j];
-            m[i][j] = s;
-        }
-    jacobi9(m, val, vec);
-    int order[9];
-    for (int i = 0; i < 9; ++i) order[i] = i;
-    std::sort(order, order + 9, [&](int x, int y) { return val[x] > val[y]; });
+    double sigma[8], vt[8][9];
+    svd_rows(a, sigma, vt);
     // the 8 singular values an SVD of the 8x9 matrix returns (the 9th direction is its null space)
-    int rank = 0;
-    for (int i = 0; i < 8; ++i)
-        if ((float)std::sqrt(std::max(0.0, val[order[i]])) > epsilon) ++rank;
+    int rank = 0, mi = 0;
+    for (int i = 0; i < 8; ++i) {
+        if ((float)sigma[i] > epsilon) ++rank;
+        if (sigma[i] < sigma[mi]) mi = i;  // smallest of the 8
+    }
     if (rank != 8) return false;
-    const int mi = order[7];  // smallest of the 8
     float v[9];
-    for (int i = 0; i < 9; ++i) v[i] = (float)vec[i][mi];
+    for (int i = 0; i < 9; ++i) v[i] = (float)vt[mi][i];
     const float f[3][3] = {{v[0], v[3], v[6]}, {v[1], v[4], v[7]}, {v[2], v[5], v[8]}};
     std::memcpy(out.f, f, sizeof(f));
     return true;
@@ -173,6 +169,25 @@ extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0,
             epsilon_inlier)
             out[k++] = matches[i];
     *n_out = k;
+    return AKZ_OK;
+}
+
+// ops::estimate_fundamental_matrix::estimate_fundamental_matrix (:17-69) for exactly 8 matches: *found = 0 is the
+// reference's `None` (rank < 8 at `epsilon`); f = the 3x3 matrix, row-major
+extern "C" int akz_estimate_fundamental_matrix(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1,
+                                               uint64_t n1, const akz_match* matches8, float epsilon, float* f, int* found) {
+    if (!keypoints_0 || !keypoints_1 || !matches8 || !f || !found) {
+        set_error("estimate_fundamental_matrix: null pointer");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < 8; ++i)
+        if (matches8[i].index_0 >= n0 || matches8[i].index_1 >= n1) {
+            set_error("estimate_fundamental_matrix: match index out of range");
+            return AKZ_ERR_INVALID_ARG;
+        }
+    Model md;
+    *found = estimate(keypoints_0, keypoints_1, matches8, epsilon, md) ? 1 : 0;
+    if (*found) std::memcpy(f, md.f, sizeof(md.f));
     return AKZ_OK;
 }
 

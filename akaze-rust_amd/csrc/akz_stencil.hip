@@ -878,9 +878,7 @@ struct Launch {
     dim3 grid;
 };
 // workgroups of a persistent launch; AKZ_PERSIST_BLOCKS in the environment overrides the built-in value (tuning runs)
-thread_local long g_tile_grid_limit = 0;  // launch::set_tile_grid_limit: per-thread override for the next launches
 inline long persist_blocks() {
-    if (g_tile_grid_limit > 0) return g_tile_grid_limit;
     static const long v = [] {
         const char* e = std::getenv("AKZ_PERSIST_BLOCKS");
         const long x = e ? std::atol(e) : 0;
@@ -901,8 +899,6 @@ inline Launch plan_tiles(uint32_t w, uint32_t h, uint32_t n, int tile_h = TH) {
 }  // namespace
 
 namespace launch {
-
-void set_tile_grid_limit(long blocks) { g_tile_grid_limit = blocks; }
 
 bool blur_fused_supported(uint32_t ntaps) { return ntaps == 3 || ntaps == 5; }
 

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("AKAZE_HIP_LIB") or os.path.join(_PKG, "libakaze_hip.s
 
 AKZ_KEEP_ALL_PLANES = 1
 AKZ_NO_HOST_DESCRIPTORS = 2
+AKZ_NO_DETECT = 4
 
 PLANES = ["Lt", "Lsmooth", "Lx", "Ly", "Lxx", "Lyy", "Lxy", "Lflow", "Lstep", "Ldet"]
 
@@ -133,6 +134,10 @@ def lib():
         "akz_extract_begin_device_u8": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
         "akz_extract_begin_device_f32": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
         "akz_extract_finish": ([vp, C.POINTER(vp)], i32),
+        "akz_extract_from_planes": ([vp, u32, u32, C.POINTER(Config), C.POINTER(vp), u64, u32, C.POINTER(vp)], i32),
+        "akz_random_color": ([vp], i32),
+        "akz_draw_circle": ([vp, u32, u32, C.c_float, C.c_float, vp, C.c_float], i32),
+        "akz_draw_line": ([vp, u32, u32, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_float], i32),
         "akz_job_abandon": ([vp], i32),
         "akz_result_free": ([vp], i32),
         "akz_result_num_images": ([vp, pu64], i32),
@@ -150,7 +155,8 @@ def lib():
         "akz_fed_kernel_name": ([], C.c_char_p),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
-        "akz_match_features": ([vp, vp, vp, u64, vp, vp, u64, u64, f64, u64, C.c_float, vp, pu64], i32),
+        "akz_estimate_fundamental_matrix": ([vp, u64, vp, u64, vp, C.c_float, fp, C.POINTER(i32)], i32),
+        "akz_match_features": ([vp, vp, u64, vp, u64, vp, u64, vp, u64, u64, f64, u64, C.c_float, vp, pu64], i32),
         "akz_write_features": ([C.c_char_p, vp, u64, vp, u64], i32),
         "akz_read_features": ([C.c_char_p, vp, vp, u64, u64, pu64, pu64, pu64], i32),
         "akz_write_matches": ([C.c_char_p, vp, u64], i32),
@@ -177,7 +183,6 @@ def lib():
         "akz_descriptor_match_sets_device": ([vp, vp, u64, vp, C.POINTER(u64), u64, u64, f64, vp, vp], i32),
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
-        "akz_ctx_set_detector_overlap": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
         "akz_comm_unique_id": ([vp], i32),
@@ -320,12 +325,6 @@ class Context:
         march, 4 = one LDS-tiled kernel, 0 = LDS-tiled kernel pair."""
         _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
 
-    def set_detector_overlap(self, mode=1):
-        """0 = off; 1 = every level's detector on a side stream as soon as its Lsmooth exists (concurrent with the
-        diffusion of that and later levels); 2 = the fine octaves' detectors on the side stream once the coarse
-        octaves (2, 3, ...) start, so that the full-size diffusion launches still run alone."""
-        _check(lib().akz_ctx_set_detector_overlap(self._h, int(mode)))
-
     def set_prep_mode(self, mode):
         """Level-preparation kernel: 2 = automatic (default), 1 = streaming, 0 = LDS-tiled."""
         _check(lib().akz_ctx_set_prep_mode(self._h, int(mode)))
@@ -382,6 +381,27 @@ class Context:
         res = C.c_void_p()
         _check(lib().akz_extract_features_file(self._h, os.fsencode(path), C.byref(cfg),
                                                AKZ_KEEP_ALL_PLANES if keep_all_planes else 0, C.byref(res)))
+        return ExtractResult(self, res)
+
+    def extract_from_planes(self, w, h, planes, options=None, detect=True):
+        """ops::scale_space_extrema::detect_keypoints / ops::descriptors::extract_descriptors on evolutions the caller
+        holds: planes[level][name] -> 2-D float32 array (names of PLANES; missing ones are skipped; Lt, Lx, Ly and —
+        for detection — Ldet are required).  Returns an ExtractResult."""
+        options = options or Config()
+        n = len(planes)
+        keep = []
+        tab = (C.c_void_p * (n * 10))()
+        for l, lv in enumerate(planes):
+            for p, name in enumerate(PLANES):
+                a = lv.get(name)
+                if a is None or a.size == 0:
+                    continue
+                a = np.ascontiguousarray(a, np.float32)
+                keep.append(a)
+                tab[l * 10 + p] = a.ctypes.data
+        res = C.c_void_p()
+        _check(lib().akz_extract_from_planes(self._h, w, h, C.byref(options), tab, n, 0 if detect else AKZ_NO_DETECT,
+                                             C.byref(res)))
         return ExtractResult(self, res)
 
     def extract_begin(self, frames, options=None, keep_all_planes=True, host_descriptors=True):
@@ -790,6 +810,20 @@ def deserialize_matches_from_file(path):
     return m
 
 
+def estimate_fundamental_matrix(keypoints_0, keypoints_1, matches8, epsilon):
+    """ops::estimate_fundamental_matrix::estimate_fundamental_matrix (:17-69): 3x3 float32 matrix or None."""
+    k0 = np.ascontiguousarray(keypoints_0, KEYPOINT_DTYPE)
+    k1 = np.ascontiguousarray(keypoints_1, KEYPOINT_DTYPE)
+    m = np.ascontiguousarray(matches8, MATCH_DTYPE)
+    if len(m) != 8:
+        raise ValueError("exactly 8 matches")
+    f = np.zeros(9, np.float32)
+    found = C.c_int()
+    _check(lib().akz_estimate_fundamental_matrix(k0.ctypes.data, len(k0), k1.ctypes.data, len(k1), m.ctypes.data, epsilon,
+                                                 f.ctypes.data_as(C.POINTER(C.c_float)), C.byref(found)))
+    return f.reshape(3, 3) if found.value else None
+
+
 def remove_outliers(keypoints_0, keypoints_1, matches, num_trials, epsilon_model, epsilon_inlier):
     """ops::estimate_fundamental_matrix::remove_outliers (estimate_fundamental_matrix.rs:99-165); host only."""
     k0 = np.ascontiguousarray(keypoints_0, KEYPOINT_DTYPE)
@@ -817,9 +851,13 @@ def match_features(keypoints_0, descriptors_0, keypoints_1, descriptors_1, lowes
     d1 = np.ascontiguousarray(descriptors_1, np.uint8)
     out = np.zeros(max(1, len(d0)), MATCH_DTYPE)
     n = C.c_uint64()
-    _check(lib().akz_match_features(c._h, k0.ctypes.data_as(C.c_void_p), d0.ctypes.data_as(C.c_void_p), len(d0),
-                                    k1.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p), len(d1),
-                                    d0.shape[1] if d0.ndim == 2 else 61, lowes_ratio, ransac_trials,
+    nb0 = d0.shape[1] if d0.ndim == 2 and len(d0) else None
+    nb1 = d1.shape[1] if d1.ndim == 2 and len(d1) else None
+    if nb0 is not None and nb1 is not None and nb0 != nb1:
+        raise ValueError(f"descriptor lengths differ: {nb0} and {nb1} bytes")
+    _check(lib().akz_match_features(c._h, k0.ctypes.data_as(C.c_void_p), len(k0), d0.ctypes.data_as(C.c_void_p), len(d0),
+                                    k1.ctypes.data_as(C.c_void_p), len(k1), d1.ctypes.data_as(C.c_void_p), len(d1),
+                                    nb0 or nb1 or 61, lowes_ratio, ransac_trials,
                                     ransac_epsilon_inliers, out.ctypes.data_as(C.c_void_p), C.byref(n)))
     return out[:n.value].copy()
 

@@ -93,9 +93,6 @@ def parse_args(argv=None):
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one LDS-tiled kernel, 0 LDS-tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
-    ap.add_argument("--det-overlap", type=int, default=-1, choices=[-1, 0, 1, 2],
-                    help="detector launches on a side stream: -1 = the library default, 0 = off, 1 = every level as soon "
-                         "as its Lsmooth exists, 2 = the fine octaves' detectors next to the coarse octaves' chain")
     ap.add_argument("--depth", type=int, default=1, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
     ap.add_argument("--threshold", type=float, default=None,
@@ -293,8 +290,6 @@ def main_rank(args):
         ctx = A.Context(local_rank, main.cuda_stream)
         ctx.set_detector_mode(args.det_mode)
         ctx.set_prep_mode(args.prep_mode)
-        if args.det_overlap >= 0:
-            ctx.set_detector_overlap(args.det_overlap)
     NP = max(1, min(args.parts, F))
     cut = [(F * i) // NP for i in range(NP + 1)]
     batches = [d_frames[cut[i]:cut[i + 1]] for i in range(NP)]

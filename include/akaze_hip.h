@@ -90,7 +90,10 @@ enum {
        Lxx/Lyy/Lxy/Lstep are never written. */
     AKZ_KEEP_ALL_PLANES = 1u << 0,
     /* leave keypoints/descriptors on the device only (no D2H of descriptors) */
-    AKZ_NO_HOST_DESCRIPTORS = 1u << 1
+    AKZ_NO_HOST_DESCRIPTORS = 1u << 1,
+    /* akz_extract_from_planes only: upload the planes, skip the extrema pass (keypoints come from the caller through
+       akz_result_describe_keypoints) */
+    AKZ_NO_DETECT = 1u << 2
 };
 
 typedef struct akz_ctx akz_ctx;
@@ -203,6 +206,17 @@ int akz_extract_begin_device_f32(akz_ctx* ctx, const float* d_imgs, uint32_t w, 
 int akz_extract_finish(akz_job* job, akz_result** out);
 int akz_job_abandon(akz_job* job);
 
+/* ops::scale_space_extrema::detect_keypoints (scale_space_extrema.rs:199-203) and ops::descriptors::extract_descriptors
+   (descriptors.rs:14-27) on evolutions the CALLER holds (the reference's `pub mod ops` takes `&[EvolutionStep]` that
+   need not come from extract_features): planes = n_levels x 10 host pointers in akz_plane order (row-major f32 of the
+   level's size, NULL where the caller has nothing; Lt, Lx, Ly of every level are required, Ldet unless
+   AKZ_NO_DETECT), n_levels = what akz_plan_num_levels returns for (w, h, cfg).  The planes are uploaded, the extrema
+   test runs on the uploaded Ldet, and the result carries keypoints (with orientation) and descriptors exactly as if
+   the pyramid had been built here.  With AKZ_NO_DETECT the result has no keypoints and serves
+   akz_result_describe_keypoints / akz_fetch_plane. */
+int akz_extract_from_planes(akz_ctx* ctx, uint32_t w, uint32_t h, const akz_config* cfg, const float* const* planes,
+                            uint64_t n_levels, uint32_t flags, akz_result** out);
+
 int akz_result_free(akz_result* res);
 int akz_result_num_images(const akz_result* res, uint64_t* n_images);
 /* (Vec<EvolutionStep>.len(), Vec<Keypoint>.len(), Descriptor.vector.len()) of image `img` */
@@ -311,13 +325,21 @@ int akz_gather_free(akz_gather* g);
 int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1, uint64_t n1,
                         const akz_match* matches, uint64_t n_matches, uint64_t num_trials, float epsilon_model,
                         float epsilon_inlier, akz_match* out, uint64_t* n_out);
+/* ops::estimate_fundamental_matrix::estimate_fundamental_matrix — estimate_fundamental_matrix.rs:17-69: the 8-point
+   model of exactly 8 matches; *found = 0 where the reference returns None (fewer than 8 singular values above
+   epsilon); f receives the 3x3 matrix row by row. */
+int akz_estimate_fundamental_matrix(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1,
+                                    uint64_t n1, const akz_match* matches8, float epsilon, float* f /* 9 */, int* found);
 /* akaze::match_features — akaze/src/lib.rs:252-275: descriptor_match(d0, d1, 10000, lowes_ratio) on the
    GPU, then remove_outliers(kp0, kp1, matches, ransac_trials, 0.05, ransac_epsilon_inliers) on the host.
-   Descriptors are host arrays of n x desc_bytes; out must hold n0 entries. */
-int akz_match_features(akz_ctx* ctx, const akz_keypoint* keypoints_0, const uint8_t* descriptors_0, uint64_t n0,
-                       const akz_keypoint* keypoints_1, const uint8_t* descriptors_1, uint64_t n1, uint64_t desc_bytes,
-                       double lowes_ratio, uint64_t ransac_trials, float ransac_epsilon_inliers, akz_match* out,
-                       uint64_t* n_out);
+   Descriptors are host arrays of n_descriptors x desc_bytes (both sets the same desc_bytes); keypoints and
+   descriptors of a set are counted separately, as the reference's slices are — a set with more descriptors than
+   keypoints is AKZ_ERR_INVALID_ARG (the reference panics once such a match reaches RANSAC).  out must hold
+   n_descriptors_0 entries. */
+int akz_match_features(akz_ctx* ctx, const akz_keypoint* keypoints_0, uint64_t n_keypoints_0, const uint8_t* descriptors_0,
+                       uint64_t n_descriptors_0, const akz_keypoint* keypoints_1, uint64_t n_keypoints_1,
+                       const uint8_t* descriptors_1, uint64_t n_descriptors_1, uint64_t desc_bytes, double lowes_ratio,
+                       uint64_t ransac_trials, float ransac_epsilon_inliers, akz_match* out, uint64_t* n_out);
 
 /* ---- on-disk formats of akaze-util ---------------------------------- */
 /* akaze_util::{serialize,deserialize}_{features,matches}_{to,from}_file — akaze-util/src/lib.rs:17-67.
@@ -390,14 +412,7 @@ int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
    supported (sigma_size <= 4); 4 = the LDS-tiled kernel; 0 = the LDS-tiled kernel pair (the fallback for other
    kernel sizes).  Results are bit-identical. */
 int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
-/* Detector overlap (default 0 = off).  1: launch each level's detector on a low-priority side stream as soon
-   as its Lsmooth exists, concurrently with the diffusion of that and later levels (+4..11 % batch
-   throughput on MI355X, -10 % for single frames).  2: hand the detectors of octaves 0 and 1 to the side
-   stream when the chain reaches octave 2, so that only the small, latency-bound launches of the coarse
-   octaves share the chip (+2.5 %; batches of 8 Mpx and more, otherwise as 0).  Results are identical.
-   Off by default because concurrently running kernels cannot be timed individually. */
-int akz_ctx_set_detector_overlap(akz_ctx* ctx, int on);
-/* Same choice for the level-preparation kernel (Lsmooth, Lflow of a level). */
+/* Level-preparation kernel (Lsmooth, Lflow of a level): 2 (default) = automatic, 1 = streaming, 0 = LDS-tiled. */
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
 /* names of the default FED kernel and of the detector kernel that large launches take (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
@@ -442,6 +457,14 @@ int akz_image_save_plane_png(const char* path, const float* plane, uint32_t widt
    into directory `dir` (must exist).  Needs a result extracted with AKZ_KEEP_ALL_PLANES to contain every
    plane; planes that were not kept are skipped like the reference skips 0x0 images. */
 int akz_write_evolutions(const akz_result* res, uint64_t img, const char* dir);
+/* types::image::random_color (image.rs:385-392): the next colour of the calling thread's default random source */
+int akz_random_color(uint8_t* rgb /* 3 */);
+/* types::image::draw_circle (image.rs:418-443) / draw_line (image.rs:453-480) on an 8-bit RGB image; pixels outside the
+   image are skipped (the reference would panic) */
+int akz_draw_circle(uint8_t* rgb, uint32_t width, uint32_t height, float x, float y, const uint8_t* color /* 3 */,
+                    float radius);
+int akz_draw_line(uint8_t* rgb, uint32_t width, uint32_t height, float x0, float y0, float x1, float y1,
+                  const uint8_t* color /* 3 */, float radius);
 /* types::keypoint::draw_keypoints_to_image (keypoint.rs:52-56): blends a disc of radius `size` at every
    keypoint into the RGB image, each in the next random_color() of the calling thread's default source
    (image.rs:385-392; see akz_random_seed).  Pixels outside the image are skipped (the reference would panic). */

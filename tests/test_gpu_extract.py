@@ -417,3 +417,33 @@ def test_result_may_outlive_its_context(amd, ref):
         job.finish()
     res.close()
     del job
+
+
+def test_ops_on_caller_held_evolutions(ctx, amd, ref):
+    """`pub mod ops` on evolutions the caller holds (ops::scale_space_extrema::detect_keypoints,
+    ops::descriptors::extract_descriptors): the ORACLE's planes, uploaded through akz_extract_from_planes, give the
+    oracle's keypoints (with orientation) and descriptors; with detection switched off the pyramid still serves
+    caller-supplied keypoints."""
+    frame = amd.synth_frame(517, 389, 31)
+    rf = ref.extract(frame)
+    planes = [{pl: rf.plane(lvl, pl) for pl in PLANES} for lvl in range(rf.num_levels)]
+    res = ctx.extract_from_planes(517, 389, planes)
+    kp, rk = res.keypoints(), rf.keypoints()
+    assert len(kp) == rf.num_keypoints > 50
+    for f in KP_FIELDS:
+        assert np.array_equal(kp[f], rk[f]), f
+    assert np.array_equal(res.descriptors(), rf.descriptors())
+    for lvl in (0, 5, rf.num_levels - 1):
+        assert np.array_equal(res.plane(lvl, "Ldet"), rf.plane(lvl, "Ldet"))
+    # only what the two ops read (detect_keypoints: Ldet, Lx, Ly; extract_descriptors: Lt, Lx, Ly)
+    slim = [{pl: rf.plane(lvl, pl) for pl in ("Lt", "Lx", "Ly")} for lvl in range(rf.num_levels)]
+    r2 = ctx.extract_from_planes(517, 389, slim, detect=False)
+    assert r2.counts()[1] == 0
+    k2, d2 = r2.describe_keypoints(rk, compute_orientation=False)
+    assert np.array_equal(d2, rf.descriptors())
+    with pytest.raises(amd.AkazeError):
+        ctx.extract_from_planes(517, 389, slim)          # detection needs Ldet
+    with pytest.raises(amd.AkazeError):
+        ctx.extract_from_planes(517, 389, planes[:-1])   # wrong number of evolutions
+    res.close()
+    r2.close()

@@ -295,3 +295,28 @@ def test_descriptor_match_chunked_large(mctx, ref):
         exp = ref.descriptor_match(d0, d1, thr, ratio)
         assert len(exp) > 100 and np.array_equal(got, exp)
     assert 1 not in got["index_0"] and 3 not in got["index_0"]
+
+
+def test_device_match_ignores_padding_bytes_in_both_kernels(ctx, ref):
+    """akz_descriptor_match_device takes 64-byte rows of which an M-LDB descriptor uses 61: bytes 61..63 are padding and
+    must not be compared by EITHER kernel (popcount and matrix-core), whatever they hold."""
+    import torch
+    rng = np.random.default_rng(77)
+    d0 = rng.integers(0, 256, (300, 61), dtype=np.uint8)
+    d1 = rng.integers(0, 256, (500, 61), dtype=np.uint8)
+    d1[::4][:100] = d0[:100]
+    d1[::4][:100, 7] ^= 0x11
+    exp = ref.descriptor_match(d0, d1, 10000, 0.86)
+    assert len(exp) > 50
+    r0 = np.concatenate([d0, rng.integers(1, 256, (300, 3), dtype=np.uint8)], axis=1)  # garbage in the padding
+    r1 = np.concatenate([d1, rng.integers(1, 256, (500, 3), dtype=np.uint8)], axis=1)
+    for mode in (0, 1):
+        ctx.set_match_mode(mode)
+        try:
+            out, cnt = ctx.descriptor_match_device(torch.from_numpy(r0).cuda(), torch.from_numpy(r1).cuda(), 10000, 0.86)
+            torch.cuda.synchronize()
+            n = int(cnt.cpu()[0])
+            got = out.cpu().numpy()[:n].reshape(-1).view(ctx_match_dtype())
+            assert np.array_equal(got, exp), mode
+        finally:
+            ctx.set_match_mode(2)

@@ -140,47 +140,6 @@ def test_stream_contrast_factor(sctx, ref, shape):
     assert float(sctx.contrast_factor(torch.from_numpy(flat).cuda()).cpu().numpy()[0]) == ref.contrast_factor(flat)
 
 
-def test_detector_overlap_gives_identical_results(amd, ref):
-    """Detector launches on a side stream (concurrent with the diffusion of later levels): same bytes, also with two
-    batches in flight."""
-    import torch
-    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
-    c.set_detector_overlap(1)
-    try:
-        fa = np.stack([amd.synth_frame(486, 270, i) for i in range(3)])
-        fb = np.stack([amd.synth_frame(640, 360, 40 + i) for i in range(2)])
-        ja = c.extract_begin(torch.from_numpy(fa).cuda())
-        jb = c.extract_begin(torch.from_numpy(fb).cuda(), keep_all_planes=False)
-        ra, rb = ja.finish(), jb.finish()
-        for i in range(3):
-            assert_same_result(ra, ref.extract(fa[i]), planes=(i == 1), img=i)
-        for i in range(2):
-            assert_same_result(rb, ref.extract(fb[i]), planes=False, img=i)
-        r = c.extract_features(amd.synth_frame(517, 389, 2), amd.Config(num_sublevels=5, max_octave_evolution=5))
-        assert_same_result(r, ref.extract(amd.synth_frame(517, 389, 2), ref.default_config(num_sublevels=5, max_octave_evolution=5)),
-                           planes=False)
-    finally:
-        c.close()
-
-
-def test_deferred_detector_overlap_gives_identical_results(amd, ref):
-    """Overlap mode 2 (fine octaves' detectors on a low-priority side stream while the coarse octaves' chain runs;
-    active from 8 Mpx per batch): same bytes as the oracle."""
-    import torch
-    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
-    c.set_detector_overlap(2)
-    try:
-        f = np.stack([amd.synth_frame(1920, 1080, 7 + i) for i in range(5)])
-        d = torch.from_numpy(f).cuda()
-        ja = c.extract_begin(d)
-        jb = c.extract_begin(d[:4], keep_all_planes=False)
-        ra, rb = ja.finish(), jb.finish()
-        assert_same_result(ra, ref.extract(f[4]), planes=True, img=4)
-        assert_same_result(rb, ref.extract(f[0]), planes=False, img=0)
-    finally:
-        c.close()
-
-
 @pytest.mark.parametrize("shape", [(96, 132), (131, 248), (77, 516), (40, 1000), (300, 517)])
 def test_stream_blur5(sctx, ref, shape):
     """The level-0 blur (sigma 1.6 -> 5 taps) through the streaming kernel: f32 input for any width, u8 input (with the

@@ -308,3 +308,30 @@ def test_features_and_matches_file_formats(amd, tmp_path):
     open(p, "wb").write(b"\x05\x00\x00")
     with pytest.raises(amd.AkazeError):
         amd.deserialize_features_from_file(p)
+
+
+def test_estimate_fundamental_matrix_is_the_smallest_of_eight_singular_vectors(amd):
+    """estimate_fundamental_matrix (estimate_fundamental_matrix.rs:17-69) with pixel coordinates of ~1e3 (design-matrix
+    entries of ~1e6): the model is the right singular vector of the SMALLEST OF THE EIGHT singular values of the 8x9
+    system (numpy's f64 SVD as the judge), unit length, and `None` when fewer than 8 singular values exceed epsilon."""
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        k0 = np.zeros(8, amd.KEYPOINT_DTYPE)
+        k1 = np.zeros(8, amd.KEYPOINT_DTYPE)
+        k0["x"], k0["y"] = rng.uniform(0, 2000, 8), rng.uniform(0, 1500, 8)
+        k1["x"], k1["y"] = k0["x"] + rng.uniform(-30, 30, 8), k0["y"] + rng.uniform(-30, 30, 8)
+        m = np.zeros(8, amd.MATCH_DTYPE)
+        m["index_0"] = m["index_1"] = np.arange(8)
+        f = amd.estimate_fundamental_matrix(k0, k1, m, 0.05)
+        x0, y0, x1, y1 = (k0["x"].astype(np.float32), k0["y"].astype(np.float32), k1["x"].astype(np.float32),
+                          k1["y"].astype(np.float32))
+        a = np.stack([x0 * x1, x0 * y1, x0, y0 * x1, y0 * y1, y0, x1, y1, np.ones(8, np.float32)], axis=1).astype(np.float64)
+        _, sv, vt = np.linalg.svd(a, full_matrices=False)
+        assert f is not None and sv[7] > 0.05
+        v = np.array([f[0, 0], f[1, 0], f[2, 0], f[0, 1], f[1, 1], f[2, 1], f[0, 2], f[1, 2], f[2, 2]], np.float64)
+        assert abs(np.linalg.norm(v) - 1.0) < 1e-5
+        assert abs(abs(float(v @ vt[7])) - 1.0) < 1e-4, trial          # same direction up to sign
+        assert abs(np.linalg.norm(a @ v) - sv[7]) < 1e-3 * max(1.0, sv[7])
+    # degenerate: all correspondences identical -> rank 1 -> None
+    k0["x"] = k0["y"] = k1["x"] = k1["y"] = 10.0
+    assert amd.estimate_fundamental_matrix(k0, k1, m, 0.05) is None

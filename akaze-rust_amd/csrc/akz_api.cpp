@@ -1937,7 +1937,7 @@ int akz_extract_features_file(akz_ctx* c, const char* path, const akz_config* cf
     return st;
 }
 
-// types::evolution::write_evolutions — evolution.rs:162-218 (file names: build_path, :162-167)
+// types::evolution::write_evolutions — evolution.rs:175-218 (file names: build_path, :163-168)
 int akz_write_evolutions(const akz_result* r, uint64_t img, const char* dir) {
     if (!r || !dir) {
         set_error("akz_write_evolutions: null argument");
@@ -1959,7 +1959,9 @@ int akz_write_evolutions(const akz_result* r, uint64_t img, const char* dir) {
             buf.resize(n_px);
             AKZ_TRY(akz_fetch_plane(r, img, l, o.p, buf.data(), &n_px));
             char name[64];
-            snprintf(name, sizeof(name), "%s%05llu.png", o.label, (unsigned long long)l);
+            // build_path (evolution.rs:163-168) formats "{label}{idx:05}.png" and then calls set_extension(".png"), which
+            // replaces the text after the last dot by ".png" itself: the files are called Lt_00000..png (two dots)
+            snprintf(name, sizeof(name), "%s%05llu..png", o.label, (unsigned long long)l);
             const std::string path = std::string(dir) + "/" + name;
             AKZ_TRY(akz_image_save_plane_png(path.c_str(), buf.data(), w, h));
         }

@@ -453,7 +453,8 @@ int akz_image_save_png(const char* path, const uint8_t* pixels, uint32_t width, 
 /* types::image::save — normalize to [0,1] (min/max), `(v * 255) as u8`, write (types/image.rs:168-197);
    a 0x0 plane writes nothing */
 int akz_image_save_plane_png(const char* path, const float* plane, uint32_t width, uint32_t height);
-/* types::evolution::write_evolutions (evolution.rs:162-218): Lt_00000.png ... Ldet_000NN.png of image `img`
+/* types::evolution::write_evolutions (evolution.rs:175-218): Lt_00000..png ... Ldet_000NN..png (sic: build_path's
+   set_extension(".png"), evolution.rs:163-168, keeps the dot of its argument) of image `img`
    into directory `dir` (must exist).  Needs a result extracted with AKZ_KEEP_ALL_PLANES to contain every
    plane; planes that were not kept are skipped like the reference skips 0x0 images. */
 int akz_write_evolutions(const akz_result* res, uint64_t img, const char* dir);

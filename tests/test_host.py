@@ -335,3 +335,20 @@ def test_estimate_fundamental_matrix_is_the_smallest_of_eight_singular_vectors(a
     # degenerate: all correspondences identical -> rank 1 -> None
     k0["x"] = k0["y"] = k1["x"] = k1["y"] = 10.0
     assert amd.estimate_fundamental_matrix(k0, k1, m, 0.05) is None
+
+
+def test_rust_shim_covers_the_reference_api():
+    """The Rust shim cannot be compiled here (no rustc): tools/check_shim.py compares its public items — module paths,
+    parameter names and types, return types, public struct fields, trait methods — with the reference crate's (read from
+    the reference sources when present, else from the committed snapshot) and its extern "C" block with the header."""
+    import subprocess, sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_shim.py")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "reference public items: 38" in p.stdout
+    # every name the reference's own callers import (akaze-util/src/bin/*.rs, akaze/tests/integration-test.rs:9-11)
+    import json
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_api.json")))
+    for name in ("extract_features", "match_features", "types::evolution::Config", "types::evolution::write_evolutions",
+                 "types::keypoint::draw_keypoints_to_image", "types::feature_match::draw_matches",
+                 "types::feature_match::Match", "types::keypoint::Keypoint", "types::keypoint::Descriptor"):
+        assert name in api, name

@@ -26,6 +26,27 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 M64 = (1 << 64) - 1
 
 
+def luma_pil(path):
+    """image::open(path).to_luma() with an INDEPENDENT decoder (PIL / libjpeg-turbo instead of this repository's
+    akz_image.cpp): `image` 0.21 weights in f32, truncating cast."""
+    rgb = np.asarray(PIL.open(path).convert("RGB")).astype(np.float32)
+    l = (np.float32(0.2126) * rgb[..., 0] + np.float32(0.7152) * rgb[..., 1]) + np.float32(0.0722) * rgb[..., 2]
+    return l.astype(np.uint8)
+
+
+_EXTRACTED = {}
+
+
+def extracted(ref, name, decoder, amd=None):
+    """the oracle's result for tests/golden/<name>.jpg decoded by `decoder` ("product" or "pil"), computed once"""
+    key = (name, decoder)
+    if key not in _EXTRACTED:
+        src = os.path.join(GOLDEN, f"{name}.jpg")
+        luma = amd.load_image_luma(src) if decoder == "product" else luma_pil(src)
+        _EXTRACTED[key] = ref.extract(luma, threads=8)
+    return _EXTRACTED[key]
+
+
 def xorshift128plus(s0=42, s1=69):
     while True:
         x, y = s0, s1
@@ -59,7 +80,7 @@ def test_oracle_keypoints_match_the_reference_picture(amd, ref, name):
     base = np.asarray(PIL.open(src).convert("RGB")).astype(np.int32)
     published = np.asarray(PIL.open(os.path.join(GOLDEN, f"keypoints-{name}.jpg")).convert("RGB")).astype(np.int32)
     assert base.shape == published.shape == (1512, 2016, 3)
-    kp = ref.extract(amd.load_image_luma(src), threads=8).keypoints()
+    kp = extracted(ref, name, "product", amd).keypoints()
     assert len(kp) > 3000
     cnt, owner = disc_cover(kp, base.shape[:2])
 
@@ -90,7 +111,7 @@ def test_product_drawing_reproduces_the_reference_picture(amd, ref):
     """akz_draw_keypoints on the input image with the oracle's keypoints, from a freshly seeded source, is the published
     picture up to its JPEG re-encoding."""
     src = os.path.join(GOLDEN, "1.jpg")
-    kp = ref.extract(amd.load_image_luma(src), threads=8).keypoints()
+    kp = extracted(ref, "1", "product", amd).keypoints()
     amd.random_seed(42, 69)
     drawn = amd.draw_keypoints(amd.load_image_rgb(src), kp).astype(np.int32)
     published = np.asarray(PIL.open(os.path.join(GOLDEN, "keypoints-1.jpg")).convert("RGB")).astype(np.int32)
@@ -115,7 +136,7 @@ def test_oracle_matches_are_the_lines_of_the_reference_match_picture(amd, ref):
     published = np.asarray(PIL.open(os.path.join(GOLDEN, "match_image.jpg")).convert("RGB")).astype(np.int32)
     assert published.shape == base.shape == (1512, 4032, 3)
     changed = np.abs(published - base).sum(axis=2) > 40
-    r0, r1 = (ref.extract(amd.load_image_luma(p), threads=8) for p in paths)
+    r0, r1 = (extracted(ref, n, "product", amd) for n in ("1", "2"))
     k0, k1 = r0.keypoints(), r1.keypoints()
     matches = ref.descriptor_match(r0.descriptors(), r1.descriptors(), 10000, 0.86)
     ref.random_seed(42, 69)
@@ -137,3 +158,82 @@ def test_oracle_matches_are_the_lines_of_the_reference_match_picture(amd, ref):
     rng = np.random.default_rng(3)
     control = np.array([drawn(int(a), int(b)) for a, b in zip(rng.integers(0, len(k0), 400), rng.integers(0, len(k1), 400))])
     assert control.mean() < 0.15, control.mean()   # the lines are nearly parallel, so a few random pairs fall onto one
+
+
+@pytest.mark.parametrize("name", ["1", "2"])
+def test_oracle_pin_holds_with_an_independent_jpeg_decoder(ref, name):
+    """The same colour-index pin with NO product code on the path: the JPEG is decoded by PIL.  libjpeg-turbo and the
+    reference's jpeg-decoder differ by up to 2 levels on 0.15 % of the pixels, which adds or removes a handful of
+    keypoints near the detector threshold (7395 instead of 7393 on 1.jpg), so the oracle's index may run ahead of or
+    behind the reference's by a few places — but it must do so as a slowly changing offset: > 98.5 % of the isolated
+    discs carry the stream colour of index i + d with |d| <= 6, and d changes only a few dozen times over the ~1 500
+    checked discs (measured: 19 changes on 1.jpg, final offset -2)."""
+    src = os.path.join(GOLDEN, f"{name}.jpg")
+    base = np.asarray(PIL.open(src).convert("RGB")).astype(np.int32)
+    published = np.asarray(PIL.open(os.path.join(GOLDEN, f"keypoints-{name}.jpg")).convert("RGB")).astype(np.int32)
+    kp = extracted(ref, name, "pil").keypoints()
+    assert len(kp) > 3000
+    cnt, owner = disc_cover(kp, base.shape[:2])
+    changed = np.abs(published - base).sum(axis=2) > 40
+    mine = cnt > 0
+    assert (mine & changed).sum() / (mine | changed).sum() > 0.94
+    stream = xorshift128plus()
+    vals = np.array([next(stream) & 0xFF for _ in range(3 * (len(kp) + 16))], np.float64).reshape(-1, 3)
+    single = cnt == 1
+    checked = good = 0
+    drifts = []
+    for i in range(len(kp)):
+        sel = single & (owner == i)
+        if sel.sum() < 30:
+            continue
+        colour = np.clip(np.median(2 * published[sel] - base[sel], axis=0), 0, 255)
+        checked += 1
+        cands = [d for d in range(-6, 7) if 0 <= i + d < len(vals) and np.abs(colour - vals[i + d]).max() < 14]
+        if cands:
+            good += 1
+            prev = drifts[-1] if drifts else 0
+            drifts.append(min(cands, key=lambda d: abs(d - prev)))
+    assert checked > 800 and good / checked > 0.985, (good, checked)
+    changes = int(np.count_nonzero(np.diff(drifts)))
+    assert changes <= 40 and abs(drifts[-1]) <= 6, (changes, drifts[-1])
+
+
+def test_every_line_of_the_reference_match_picture_is_an_oracle_nearest_neighbour_pair(ref):
+    """The converse of the test above, per line and with no product code on the path (PIL decode): rasterise the lines
+    (i, nn(i)) of the oracle's ratio-test matches that the picture shows, and require that they EXPLAIN the picture —
+    more than 99 % of all changed pixels of match_image.jpg lie on such a line.  A drawn line whose endpoints the
+    oracle's Hamming search does not pair (wrong descriptor bits on either side) would leave its pixels unexplained;
+    with half of the explained lines removed the coverage drops well below the bar (control)."""
+    paths = [os.path.join(GOLDEN, n) for n in ("1.jpg", "2.jpg")]
+    base = np.concatenate([np.asarray(PIL.open(p).convert("RGB")).astype(np.int32) for p in paths], axis=1)
+    published = np.asarray(PIL.open(os.path.join(GOLDEN, "match_image.jpg")).convert("RGB")).astype(np.int32)
+    changed = np.abs(published - base).sum(axis=2) > 40
+    h, w = changed.shape
+    r0, r1 = (extracted(ref, n, "pil") for n in ("1", "2"))
+    k0, k1 = r0.keypoints(), r1.keypoints()
+    matches = ref.descriptor_match(r0.descriptors(), r1.descriptors(), 10000, 0.86)
+
+    def samples(i0, i1):
+        x0, y0, x1, y1 = float(k0["x"][i0]), float(k0["y"][i0]), float(k1["x"][i1]) + w / 2, float(k1["y"][i1])
+        n = int(max(abs(x1 - x0), abs(y1 - y0), 2))
+        return np.linspace(x0, x1, n).astype(int).clip(0, w - 1), np.linspace(y0, y1, n).astype(int).clip(0, h - 1)
+
+    shown = []
+    for m in matches:
+        xs, ys = samples(int(m["index_0"]), int(m["index_1"]))
+        if changed[ys, xs].mean() > 0.9:
+            shown.append((xs, ys))
+    assert len(shown) > 250
+    rad = h // 500 + 3  # draw_line's radius (feature_match.rs: height / 500) plus JPEG blur
+    disc = [(dx, dy) for dx in range(-rad, rad + 1) for dy in range(-rad, rad + 1) if dx * dx + dy * dy <= rad * rad]
+
+    def coverage(lines):
+        mask = np.zeros_like(changed)
+        for xs, ys in lines:
+            for dx, dy in disc:
+                mask[(ys + dy).clip(0, h - 1), (xs + dx).clip(0, w - 1)] = True
+        return (changed & mask).sum() / changed.sum()
+
+    full = coverage(shown)
+    assert full > 0.99, full
+    assert coverage(shown[::2]) < 0.93   # control: the check notices missing lines

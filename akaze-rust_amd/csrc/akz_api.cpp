@@ -79,7 +79,7 @@ struct akz_ctx {
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     // stage profiling (akz_ctx_set_profiling)
     uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
-    int prep_mode = 2;  // same values as det_mode, for the level-preparation kernel
+    int prep_mode = 2;  // level preparation: 0 LDS-tiled, 1 streaming, 2 auto (fused with the first diffusion steps for large launches), 3 fused wherever supported
     int det_mode = 2;  // 0: tiled pair, 2: auto, 4: one tiled kernel, 5: column march (akz_ctx_set_detector_mode)
     int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 2: k_fed_own (<= 8 steps/launch; <= 16 for small launches)
     int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
@@ -969,13 +969,52 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             half_buf = launches == 0 ? A : (fed_dst(launches, 1, A, B) == A ? B : A);
             fed_in = half_buf;
         }
+        // Large launches of levels that diffuse: preparation and the first (up to four) diffusion steps in ONE launch of
+        // k_level_march (akz_march.hip) — Lt is read once for both, 4 B read + 12 (+4) B written per pixel instead of
+        // 12 + 12 (+4); a new octave's 2x2 mean is materialised first.  Remaining steps follow in k_fed_own launches.
+        static const uint64_t level_min_px = [] {
+            const char* e = std::getenv("AKZ_LEVEL_MIN_PX");
+            return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
+        }();
+        const bool fuse_level = n_tau >= 1 && c->fed_mode == 2 && launch::level_march_supported(lv.w, lv.h) &&
+                                (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)lv.w * lv.h * n >= level_min_px));
+        if (fuse_level) {
+            const uint32_t n1 = std::min<uint32_t>(n_tau, 4u), rem = n_tau - n1;
+            const uint32_t rest = rem ? fed_num_launches(c, rem, lv.w, lv.h, n) : 0;
+            float* d1 = fed_dst(rest + 1, 1, A, B);
+            const float* level_in = P(i - 1, AKZ_LT);
+            if (half) {
+                StageTimer st(c, AKZ_ST_PREP);
+                float* hb = d1 == A ? B : A;
+                launch::half_size(s, P(i - 1, AKZ_LT), hb, pv.w, pv.h, n);
+                level_in = hb;
+            }
+            float ht[4];
+            for (uint32_t j = 0; j < n1; ++j) ht[j] = 0.5f * (float)lv.tau[j];
+            {
+                StageTimer st(c, AKZ_ST_FED);
+                launch::level_march(s, level_in, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), d1,
+                                    (rem == 0 && keep_all) ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n, g1.data(), r->d_k,
+                                    lv.octave, ht, n1);
+                if (c->profiling) {
+                    c->prof.fed_launches += 1;
+                    c->prof.fed_px_steps += (uint64_t)lv.w * lv.h * n * n1;
+                    c->prof.fused_px += (uint64_t)lv.w * lv.h * n;
+                }
+                if (rem)
+                    AKZ_TRY(fed_impl(c, d1, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
+                                     lv.tau.data() + n1, rem));
+            }
+            AKZ_HIP_TRY(hipGetLastError());
+            continue;
+        }
         {
             StageTimer st(c, AKZ_ST_PREP);
             // measured on MI355X: the streaming kernel is ~2x faster for cloned levels of a batch (a single
             // frame is launch-latency bound and stays on the tiled kernel); for the first
             // level of an octave (2x2 mean of a 4x larger input) the two are equal, the tiled one stays
             const bool stream_prep = c->prep_mode != 0 && launch::prep_stream_supported(lv.w, lv.h) &&
-                                     (c->prep_mode == 1 || (!half && (uint64_t)lv.w * lv.h * n >= c->stream_min_px));
+                                     (c->prep_mode == 1 || (c->prep_mode >= 2 && !half && (uint64_t)lv.w * lv.h * n >= c->stream_min_px));
             if (stream_prep)
                 launch::prep_stream(s, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
                                     pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
@@ -1976,7 +2015,7 @@ int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
 }
 
 int akz_ctx_set_prep_mode(akz_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
+    if (!c || mode < 0 || mode > 3) return AKZ_ERR_INVALID_ARG;
     c->prep_mode = mode;
     return AKZ_OK;
 }

@@ -172,6 +172,11 @@ bool detector_march_supported(uint32_t sigma, uint32_t w, uint32_t h, float bord
 void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy,
                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level, float thr,
                     float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
+// level preparation + the first n_steps <= 4 diffusion steps of a level in one launch (akz_march.hip, k_level_march)
+bool level_march_supported(uint32_t w, uint32_t h);
+void level_march(hipStream_t s, const float* prev, float* lsmooth, float* lflow, float* lt_out, float* lstep, uint32_t w,
+                 uint32_t h, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow, const float* half_taus,
+                 uint32_t n_steps);
 bool detector_nms_fused_supported(uint32_t sigma);
 void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,

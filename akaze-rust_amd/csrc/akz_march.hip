@@ -126,31 +126,34 @@ __device__ __forceinline__ float* at(float* row, unsigned boff) { return reinter
 __device__ __forceinline__ const float* at(const float* row, unsigned boff) {
     return reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + boff);
 }
+// ro: byte offset of the row inside the image's plane (32 bits: a plane of one image is far below 4 GiB), so that an
+// access is `plane of the image (SGPR pair) + one 32-bit VGPR offset` with no 64-bit arithmetic per plane and row
 template <int N>
-__device__ __forceinline__ void store_rows(float* const (&plane)[N], size_t ro, const Cols& C, const f2 (&v)[N]) {
+__device__ __forceinline__ void store_rows(float* const (&plane)[N], unsigned ro, const Cols& C, const f2 (&v)[N]) {
     if (C.st2) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             // streaming stores: the planes are written once and not read again by this kernel (+20 % for this access shape)
-            __builtin_nontemporal_store((f2u)v[i], reinterpret_cast<f2u*>(at(plane[i] + ro, C.boff)));
+            __builtin_nontemporal_store((f2u)v[i], reinterpret_cast<f2u*>(at(plane[i], ro + C.boff)));
         }
     } else if (C.st1) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) *at(plane[i] + ro, C.boff) = v[i].x;
+        for (int i = 0; i < N; ++i) *at(plane[i], ro + C.boff) = v[i].x;
     }
 }
 // interior row r of the output planes, plus (twice per strip) the border rows that copy it
 template <int S, int N>
 __device__ __forceinline__ void store_filled(float* const (&plane)[N], const Cols& C, int w, int h, int r, const f2 (&v)[N]) {
-    store_rows<N>(plane, (size_t)r * w, C, v);
+    const unsigned wb = (unsigned)w * 4u;
+    store_rows<N>(plane, (unsigned)r * wb, C, v);
     if (r == S || r == h - 1 - S) {  // workgroup-uniform
         if (r == S) {
 #pragma nounroll
-            for (int y = 0; y < S; ++y) store_rows<N>(plane, (size_t)y * w, C, v);
+            for (int y = 0; y < S; ++y) store_rows<N>(plane, (unsigned)y * wb, C, v);
         }
         if (r == h - 1 - S) {
 #pragma nounroll
-            for (int y = h - S; y < h; ++y) store_rows<N>(plane, (size_t)y * w, C, v);
+            for (int y = h - S; y < h; ++y) store_rows<N>(plane, (unsigned)y * wb, C, v);
         }
     }
 }
@@ -219,13 +222,13 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
     const int v0 = cs - 1 - 2 * S;
     const int T = (ce - cs) + 4 * S + 3;
     auto feed = [&](int t) -> f2 {
-        const float* row = in + (size_t)clampi(v0 + min(t, T - 1), S, h - 1 - S) * w;
+        const unsigned ro = (unsigned)clampi(v0 + min(t, T - 1), S, h - 1 - S) * ((unsigned)w * 4u);
         f2 v;
         if (C.ldv) {
-            v = *reinterpret_cast<const f2u*>(at(row, C.boff));
+            v = *reinterpret_cast<const f2u*>(at(in, ro + C.boff));
         } else {
-            v.x = *at(row, C.lb0);
-            v.y = *at(row, C.lb1);
+            v.x = *at(in, ro + C.lb0);
+            v.y = *at(in, ro + C.lb1);
         }
         return v;
     };
@@ -337,6 +340,271 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
     if (NMS) cands_flush(cbuf, cnum, nms, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One pyramid level that continues its octave, in ONE pass (lib.rs:92-118): the previous level's final Lt ->
+// Lsmooth = gaussian_blur(Lt, 1.0) -> Scharr pair at scale 1 -> Lflow = pm_g2 -> the level's first N <= 4 FED steps
+// (nonlinear_diffusion.rs:15-144) -> Lt (+ Lstep).  Same march as the detector: 512-column strips on 128-byte boundaries,
+// two columns per thread in packed f32, vertical taps from register rings, horizontal neighbours from one LDS exchange
+// per row.  HBM sees 4 B read and 12 (+4 with Lstep) written per pixel — the separate preparation and diffusion
+// launches read 12 and write 12 (+4), and re-read their tile halos.
+//
+// Stages of iteration t (v = first virtual row + t), each one row behind the one it reads from:
+//     Lt_prev row v    --H gauss-->  GH ring --V gauss-->  Lsmooth row v-1             (stored)
+//     Lsmooth row v-2  --H scharr--> HM, HO rings --V scharr, pm_g2--> Lflow row v-3   (stored; into the c ring)
+//     FED stage s = 1..N: L^s row v-4-s from L^(s-1) rows v-5-s .. v-3-s (stage 1: the Lt_prev ring), the c ring and
+//     the x-pair sums c(x-1)+c(x), c(x)+c(x+1) of that row (formed once per row, delayed through a ring)
+// Rings have 4 or 8 slots and the row loop is unrolled 8 times, so every ring index is static.
+//
+// Borders.  The two blurs: fill_border with half width 1, columns by evaluating at the clamped column, rows by entering
+// row 1's H result into the slot of row 0 and by holding the V result below row h-2 (as in the detector).  FED has no
+// filled border: missing-neighbour terms are dropped with the reference's expression per case (:84-137) — rows by
+// workgroup-uniform branches, columns by selects in the few threads that touch column 0 or w-1.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LevelTaus {
+    float half_tau[4];  // 0.5f * (tau as f32) per fused step (nonlinear_diffusion.rs:67)
+};
+__device__ __forceinline__ f2 tap3(f2 a, f2 b, f2 c, float k0, float k1, float k2) {
+    const f2 z = {0.0f, 0.0f};
+    return ((z + k0 * a) + k1 * b) + k2 * c;
+}
+__device__ __forceinline__ double octave_contrast(double k, unsigned pow) {  // lib.rs:84: one octave at a time, in f64
+    for (unsigned i = 0; i < pow; ++i) k = k * 0.75;
+    return k;
+}
+__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {  // lib.rs:30-37
+    const double dx = (double)lx, dy = (double)ly;
+    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
+}
+
+template <int N, bool KEEPSTEP>
+__global__ void __launch_bounds__(MT, 3)
+k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, float* __restrict__ lflow_out,
+              float* __restrict__ lt_out, float* __restrict__ lstep_out, int w, int h, MarchGrid g, float g0, float g1,
+              float g2, float kn, float kwn, const double* __restrict__ d_k, unsigned k_pow, LevelTaus ht) {
+    static_assert(N >= 1 && N <= 4, "fused diffusion steps");
+    static_assert(N + 3 <= HALO, "strip halo");
+    constexpr int NPL = 3 + N;  // LDS rows per iteration: Lt_prev, Lsmooth, Lflow, L^0 .. L^(N-1)
+    constexpr int PF = 2;
+    __shared__ __attribute__((aligned(16))) float s_row[2][NPL][ROW];
+    const int tid = threadIdx.x;
+    const int per = g.nbands * g.nstrips;
+    const int img = __builtin_amdgcn_readfirstlane((int)blockIdx.x / per);
+    const int rem = (int)blockIdx.x - img * per;
+    const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
+    const int cs = 1 + band * g.band_rows, ce = min(cs + g.band_rows, h - 1);  // interior rows of Lsmooth / Lflow
+    if (cs >= ce) return;
+    const int lt0 = cs == 1 ? 0 : cs, lt1 = ce == h - 1 ? h : ce;  // rows of Lt / Lstep (no filled border there)
+
+    const int X0 = strip * USE - HALO;
+    const int p0 = (2 * tid + HALO) & (MW - 1);
+    Cols C;
+    C.x0 = X0 + p0;
+    const bool inner = p0 >= HALO && p0 < MW - HALO;
+    C.st2 = inner && C.x0 + 1 < w;
+    C.st1 = inner && !C.st2 && C.x0 < w;
+    C.ldv = C.x0 >= 0 && C.x0 + 1 <= w - 1;
+    C.boff = (unsigned)C.x0 * 4u;
+    C.lb0 = (unsigned)clampi(C.x0, 0, w - 1) * 4u;
+    C.lb1 = (unsigned)clampi(C.x0 + 1, 0, w - 1) * 4u;
+    // LDS indices of tap -1 of the two columns of the blur / Scharr passes (evaluated at the clamped column)
+    const int i0 = PAD + clampi(clampi(C.x0, 1, w - 2) - X0, 0, MW - 1) - 1;
+    const int i1 = PAD + clampi(clampi(C.x0 + 1, 1, w - 2) - X0, 0, MW - 1) - 1;
+    const int wi = PAD + p0;
+    // FED: which x-neighbours exist (only threads at column 0 / w-1 have one missing)
+    const bool hxn0 = C.x0 > 0, hxp0 = C.x0 + 1 < w, hxn1 = C.x0 + 1 > 0, hxp1 = C.x0 + 2 < w;
+    const bool edge_col = !(hxn0 && hxp0 && hxn1 && hxp1);
+
+    const size_t base = (size_t)img * (size_t)w * (size_t)h;
+    const float* in = prev + base;
+    float* const o_ls[1] = {lsmooth_out + base};
+    float* const o_lf[1] = {lflow_out + base};
+    float* o_lt[KEEPSTEP ? 2 : 1];
+    o_lt[0] = lt_out + base;
+    if (KEEPSTEP) o_lt[1] = lstep_out + base;
+    float* const(&o_ltc)[KEEPSTEP ? 2 : 1] = o_lt;
+    const double kc = octave_contrast(d_k[img], k_pow);
+    const double inverse_k = 1.0 / (kc * kc);
+
+    // Lt row r needs Lt_prev rows r-N-2 .. r+N+2 (N steps, the c ring one row wider, c itself two blurs of half width 1)
+    const int v0 = lt0 - N - 2;
+    const int T = (lt1 - lt0) + 2 * N + 6;
+    auto feed = [&](int t) -> f2 {
+        const unsigned ro = (unsigned)clampi(v0 + min(t, T - 1), 0, h - 1) * ((unsigned)w * 4u);
+        f2 v;
+        if (C.ldv) {
+            v = *reinterpret_cast<const f2u*>(at(in, ro + C.boff));
+        } else {
+            v.x = *at(in, ro + C.lb0);
+            v.y = *at(in, ro + C.lb1);
+        }
+        return v;
+    };
+    f2 q[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) q[i] = feed(i);
+    const f2 zero = {0.0f, 0.0f};
+    f2 LP[8], CR[8];              // Lt_prev rows v .. v-6; Lflow (filled) rows v-3 .. v-5-N
+    f2 GH[4], HM[4], HO[4];       // H results of the last three rows of the two blurs
+    f2 SXW[4], SXE[4];            // c(x-1)+c(x), c(x)+c(x+1) of rows v-5 .. v-4-N
+    f2 W[N > 1 ? N - 1 : 1][4];   // W[s-2]: L^(s-1) rows of stage s >= 2
+#pragma unroll
+    for (int i = 0; i < 8; ++i) LP[i] = CR[i] = zero;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        GH[i] = HM[i] = HO[i] = SXW[i] = SXE[i] = zero;
+#pragma unroll
+        for (int j = 0; j < (N > 1 ? N - 1 : 1); ++j) W[j][i] = zero;
+    }
+    f2 ls_c = zero, lf_c = zero, gh_c = zero;  // Lsmooth row v-2, Lflow row v-4, H gauss of row v-1 (previous iteration's results)
+
+    for (int t0 = 0; t0 < T; t0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k;
+            if (t < T) {
+                const int v = v0 + t;
+                const f2 nxt = feed(t + PF);
+                float* const buf = &s_row[t & 1][0][0];
+                LP[k & 7] = q[0];
+                *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = q[0];
+                *reinterpret_cast<f2*>(buf + 1 * ROW + wi) = ls_c;
+                *reinterpret_cast<f2*>(buf + 2 * ROW + wi) = CR[(k - 5) & 7];
+                *reinterpret_cast<f2*>(buf + 3 * ROW + wi) = LP[(k - 5) & 7];
+#pragma unroll
+                for (int s = 2; s <= N; ++s) *reinterpret_cast<f2*>(buf + (2 + s) * ROW + wi) = W[s - 2][(k - 1) & 3];
+                __syncthreads();
+                // ---- gaussian_blur(Lt, 1.0): H pass of row v, V pass -> Lsmooth row u = v-1 ----
+                f2 gh = gh_c;  // below row h-2 the filled rows repeat it
+                if (v <= h - 2) {
+                    const float* r0 = buf + i0;
+                    const float* r1 = buf + i1;
+                    const f2 a = {r0[0], r1[0]}, b = {r0[1], r1[1]}, c = {r0[2], r1[2]};
+                    gh = tap3(a, b, c, g0, g1, g2);
+                }
+                gh_c = gh;
+                GH[k & 3] = gh;
+                if (v == 1) GH[(k - 1) & 3] = gh;  // filled row 0 is row 1
+                const int u = v - 1;
+                f2 ls_n = ls_c;
+                if (u <= h - 2) ls_n = tap3(GH[(k - 2) & 3], GH[(k - 1) & 3], GH[k & 3], g0, g1, g2);
+                if (u >= cs && u < ce) {
+                    const f2 o[1] = {ls_n};
+                    store_filled<1, 1>(o_ls, C, w, h, u, o);
+                }
+                // ---- Scharr pair at scale 1 of Lsmooth row u-1 (in LDS), V pass -> Lx1, Ly1 -> Lflow row c = v-3 ----
+                {
+                    const float* r0 = buf + ROW + i0;
+                    const float* r1 = buf + ROW + i1;
+                    const f2 a = {r0[0], r1[0]}, b = {r0[1], r1[1]}, c = {r0[2], r1[2]};
+                    HM[k & 3] = tap_main(a, b, c, kn, kwn);
+                    HO[k & 3] = tap_off(a, c);
+                }
+                if (u - 1 == 1) {  // filled row 0 is row 1
+                    HM[(k - 1) & 3] = HM[k & 3];
+                    HO[(k - 1) & 3] = HO[k & 3];
+                }
+                const int c = v - 3;
+                f2 lf_n = lf_c;
+                if (c <= h - 2) {
+                    const f2 lx1 = tap_off(HM[(k - 2) & 3], HM[k & 3]);
+                    const f2 ly1 = tap_main(HO[(k - 2) & 3], HO[(k - 1) & 3], HO[k & 3], kn, kwn);
+                    lf_n = f2{pm_g2_px(lx1.x, ly1.x, inverse_k), pm_g2_px(lx1.y, ly1.y, inverse_k)};
+                }
+                CR[(k - 3) & 7] = lf_n;
+                if (c == 1) CR[(k - 4) & 7] = lf_n;  // filled row 0 is row 1
+                if (c >= cs && c < ce) {
+                    const f2 o[1] = {lf_n};
+                    store_filled<1, 1>(o_lf, C, w, h, c, o);
+                }
+                // ---- x-pair sums of the Lflow row the first FED stage works on (row v-5, in LDS) ----
+                {
+                    const float* cr = buf + 2 * ROW + wi;
+                    const f2 cc = CR[(k - 5) & 7];
+                    SXW[k & 3] = f2{cr[-1] + cc.x, cc.x + cc.y};
+                    SXE[k & 3] = f2{cc.x + cc.y, cc.y + cr[2]};
+                }
+                // ---- FED stages: L^s row r = v-4-s ----
+                f2 lnew = zero, st = zero;
+#pragma unroll
+                for (int s = 1; s <= N; ++s) {
+                    const int r = v - 4 - s;
+                    f2 Lm, Lc, Lp;
+                    if (s == 1) {
+                        Lm = LP[(k - 6) & 7]; Lc = LP[(k - 5) & 7]; Lp = LP[(k - 4) & 7];
+                    } else {
+                        W[s - 2][k & 3] = lnew;  // L^(s-1) row r+1, produced by stage s-1 just now
+                        Lm = W[s - 2][(k - 2) & 3]; Lc = W[s - 2][(k - 1) & 3]; Lp = lnew;
+                    }
+                    const float* lr = buf + (2 + s) * ROW + wi;  // L^(s-1) row r with its neighbours
+                    const f2 Lw = {lr[-1], Lc.x}, Le = {Lc.y, lr[2]};
+                    const f2 cN = CR[(k - 5 - s) & 7], cC = CR[(k - 4 - s) & 7], cS = CR[(k - 3 - s) & 7];
+                    const f2 SU = cN + cC, SV = cC + cS;
+                    const f2 XFW = SXW[(k - (s - 1)) & 3] * (Lc - Lw);  // x_neg: (c_W + c) * (L - L_W)
+                    const f2 XFE = SXE[(k - (s - 1)) & 3] * (Le - Lc);  // x_pos: (c + c_E) * (L_E - L)
+                    f2 tx;
+                    if (!edge_col) {
+                        tx = XFE - XFW;
+                    } else {  // columns 0 / w-1: the missing term is dropped (:94-102, :122-137)
+                        tx.x = hxp0 ? (hxn0 ? XFE.x - XFW.x : XFE.x) : -XFW.x;
+                        tx.y = hxp1 ? (hxn1 ? XFE.y - XFW.y : XFE.y) : -XFW.y;
+                    }
+                    f2 tt;
+                    if (r + 1 < h) {                       // workgroup-uniform
+                        tt = tx + SV * (Lp - Lc);          // + y_pos
+                        if (r > 0) tt = tt - SU * (Lc - Lm);  // - y_neg
+                    } else {
+                        tt = tx + SU * (Lm - Lc);          // last row: y_pos taken towards y-1 (:104-119)
+                    }
+                    st = ht.half_tau[s - 1] * tt;
+                    lnew = Lc + st;
+                }
+                {
+                    const int r = v - 4 - N;
+                    if (r >= lt0 && r < lt1) {
+                        f2 o[KEEPSTEP ? 2 : 1];
+                        o[0] = lnew;
+                        if (KEEPSTEP) o[1] = st;
+                        const f2(&oc)[KEEPSTEP ? 2 : 1] = o;
+                        store_rows<KEEPSTEP ? 2 : 1>(o_ltc, (unsigned)r * ((unsigned)w * 4u), C, oc);
+                    }
+                }
+                ls_c = ls_n;
+                lf_c = lf_n;
+#pragma unroll
+                for (int i = 0; i + 1 < PF; ++i) q[i] = q[i + 1];
+                q[PF - 1] = nxt;
+            }
+        }
+    }
+}
+
+inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    static int fill = 0, min_rows = 0;
+    if (!fill) {
+        const char* e = getenv("AKZ_LEVEL_FILL");  // tuning knobs
+        fill = e ? std::max(1, atoi(e)) : 3;
+        const char* m = getenv("AKZ_LEVEL_MIN_ROWS");
+        min_rows = m ? std::max(8, atoi(m)) : 64;
+    }
+    MarchGrid g;
+    g.nstrips = (int)((w + USE - 1) / USE);
+    const int rows = (int)h - 2;
+    const long cols = (long)n * g.nstrips;
+    const long want = ((long)cus * fill + cols - 1) / cols;
+    long nb = std::max<long>(1, std::min<long>(want, std::max(1, rows / min_rows)));
+    g.band_rows = (int)((rows + nb - 1) / nb);
+    g.nbands = (rows + g.band_rows - 1) / g.band_rows;
+    *grid = dim3((unsigned)(cols * g.nbands));
+    return g;
+}
+
 inline MarchGrid plan_march(const void* kernel, uint32_t w, uint32_t h, uint32_t n, int S, dim3* grid) {
     static int cus = 0;
     if (!cus) {
@@ -434,6 +702,36 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
     }
 }
 #undef AKZ_MARCH
+
+bool level_march_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16; }
+
+#define AKZ_LEVEL(NS)                                                                                                  \
+    case NS: {                                                                                                        \
+        if (lstep)                                                                                                    \
+            hipLaunchKernelGGL((k_level_march<NS, true>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep,     \
+                               (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht);          \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_level_march<NS, false>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep,    \
+                               (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht);          \
+    } break;
+
+// Level preparation + the level's first n_steps (1..4) diffusion steps in one launch of k_level_march.  prev: the
+// level's Lt before diffusion (the previous level's final Lt, or its 2x2 mean), must not alias lt_out.  lstep (may be
+// null) receives the increment of the LAST fused step.
+void level_march(hipStream_t s, const float* prev, float* lsmooth, float* lflow, float* lt_out, float* lstep, uint32_t w,
+                 uint32_t h, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow, const float* half_taus,
+                 uint32_t n_steps) {
+    const Taps m = taps_scharr_main(1);
+    LevelTaus ht;
+    for (uint32_t i = 0; i < 4; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
+    dim3 gr;
+    const MarchGrid mg = plan_level_march(w, h, n, &gr);
+    switch (n_steps) {
+        AKZ_LEVEL(1) AKZ_LEVEL(2) AKZ_LEVEL(3) AKZ_LEVEL(4)
+        default: break;
+    }
+}
+#undef AKZ_LEVEL
 
 }  // namespace launch
 }  // namespace akz

@@ -62,12 +62,12 @@ STAGES = ["blur0", "contrast", "prep", "fed", "detector", "nms", "host_kp", "ori
 
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 10), ("fed_launches", C.c_uint64), ("fed_px_steps", C.c_uint64),
-                ("calls", C.c_uint64), ("pixels", C.c_uint64), ("det_launches", C.c_uint64), ("det_px", C.c_uint64)]
+                ("calls", C.c_uint64), ("pixels", C.c_uint64), ("det_launches", C.c_uint64), ("det_px", C.c_uint64), ("fused_px", C.c_uint64)]
 
     def as_dict(self):
         d = {k: self.ms[i] for i, k in enumerate(STAGES)}
         d.update(fed_launches=self.fed_launches, fed_px_steps=self.fed_px_steps, calls=self.calls,
-                 pixels=self.pixels, det_launches=self.det_launches, det_px=self.det_px)
+                 pixels=self.pixels, det_launches=self.det_launches, det_px=self.det_px, fused_px=self.fused_px)
         return d
 
 
@@ -326,7 +326,8 @@ class Context:
         _check(lib().akz_ctx_set_detector_mode(self._h, int(mode)))
 
     def set_prep_mode(self, mode):
-        """Level-preparation kernel: 2 = automatic (default), 1 = streaming, 0 = LDS-tiled."""
+        """Level preparation: 2 = automatic (default: fused with the first diffusion steps for large launches), 3 = fused
+        wherever supported, 1 = streaming kernel, 0 = LDS-tiled kernel."""
         _check(lib().akz_ctx_set_prep_mode(self._h, int(mode)))
 
     def set_profiling(self, on=True):

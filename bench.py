@@ -499,9 +499,12 @@ def main_rank(args):
                     f"all detector launches of the timed steps ({det_bpp} B per level pixel: Lsmooth read once, every output "
                     "plane written once); time = sum of HIP-event spans around each launch on the launching stream")
     roof_fed = roof(A.lib().akz_fed_kernel_name().decode(), prof["fed"], prof["fed_launches"],
-                    FED_BYTES_PER_PX_STEP * prof["fed_px_steps"],
-                    "all FED launches of the timed steps (levels 1..15, 1920x1080 down to 240x135), 12 B per pixel-step "
-                    "ALGORITHMIC: up to 8 steps are fused per launch, so frac can exceed 1 — traffic_frac is the DRAM figure")
+                    FED_BYTES_PER_PX_STEP * prof["fed_px_steps"] + 12.0 * prof["fused_px"],
+                    "all diffusion launches of the timed steps (levels 1..15, 1920x1080 down to 240x135): k_level_march "
+                    "(level preparation + the level's first <= 4 FED steps in one launch, levels of 8 Mpx and more) and "
+                    "k_fed_own (<= 8 steps per launch); 12 B per pixel-step ALGORITHMIC plus 12 B per pixel for a "
+                    "preparation that runs inside the launch — steps are fused, so frac can exceed 1; traffic_frac is "
+                    "the DRAM figure")
     roofline, roofline_2 = (roof_det, roof_fed) if prof["detector"] >= prof["fed"] else (roof_fed, roof_det)
 
     # ---- the FED kernel alone: 3840x2160 plane (north-star target point) and a 32 x 1080p level (HBM-resident) ----
@@ -698,14 +701,26 @@ def main_rank(args):
         stage_bytes = {
             "blur0": px[0] * (1 + 4),                                   # u8 in, f32 Lt0 out
             "contrast": px[0] * 4 * 2,                                  # two passes over Lt0
-            "prep": sum((16 + 12 if half[i] else 4 + 8) * px[i] for i in range(1, len(lv))),  # [2x2 mean: 4 px in, Lt out] Lsmooth, Lflow out
-            "fed": sum(FED_BYTES_PER_PX_STEP * len(lv[i]["tau"]) * px[i] for i in range(1, len(lv))),
+            # level preparation ([2x2 mean: 4 px in, Lt out,] Lsmooth, Lflow out) + diffusion: one line, because large levels run
+            # both in one kernel (k_level_march)
+            "prep+fed": sum((16 + 12 if half[i] else 4 + 8) * px[i] for i in range(1, len(lv))) +
+                        sum(FED_BYTES_PER_PX_STEP * len(lv[i]["tau"]) * px[i] for i in range(1, len(lv))),
             "detector": sum(det_bpp * p for p in px),                   # Lsmooth in; Lx, Ly, Ldet (+ Lxx, Lyy, Lxy) out, each once
         }
-        stage_roofline = {k: {"algorithmic_GB": round(b / 1e9, 3), "achieved_GBps": round(b / 1e9 / (warm_prof[k] * 1e-3), 1),
-                              "frac": round(b / 1e9 / (warm_prof[k] * 1e-3) / HBM_PEAK_GBS, 3)}
-                          for k, b in stage_bytes.items() if warm_prof[k] > 0}
+        stage_t = dict(warm_prof)
+        stage_t["prep+fed"] = warm_prof["prep"] + warm_prof["fed"]
+        stage_roofline = {k: {"algorithmic_GB": round(b / 1e9, 3), "ms": round(stage_t[k], 3),
+                              "achieved_GBps": round(b / 1e9 / (stage_t[k] * 1e-3), 1),
+                              "frac": round(b / 1e9 / (stage_t[k] * 1e-3) / HBM_PEAK_GBS, 3)}
+                          for k, b in stage_bytes.items() if stage_t[k] > 0}
         steps = max(1, args.steps)
+        whole = sum(stage_bytes.values())  # 575.8 B per input pixel at 4 x 4 with all planes kept
+        whole_gbs = whole / 1e9 / (elapsed / steps) if world == 1 else None
+        stage_roofline["whole_path"] = {"algorithmic_GB": round(whole / 1e9, 3),
+                                        "B_per_input_pixel": round(whole / (float(W) * H * F), 1),
+                                        "achieved_GBps": round(whole_gbs, 1) if whole_gbs else None,
+                                        "frac": round(whole_gbs / HBM_PEAK_GBS, 3) if whole_gbs else None,
+                                        "note": "all stages' algorithmic bytes / the timed step (pipelined, keypoint kernels included)"}
         out = {
             "metric": f"Mpix/s through extract_features ({args.octaves} oct x {args.sublevels} sub)",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,

@@ -390,6 +390,7 @@ typedef struct akz_profile {
     uint64_t pixels;         /* input pixels accumulated (w*h*n per call)                     */
     uint64_t det_launches;   /* detector kernel launches inside AKZ_ST_DETECTOR               */
     uint64_t det_px;         /* sum over those launches of level pixels (x batch)             */
+    uint64_t fused_px;       /* level pixels (x batch) whose preparation ran inside a FED launch (k_level_march) */
 } akz_profile;
 /* on: 0 = off, 1 = every stage (two HIP events per stage and level), 2 = light: only the FED and detector spans and
    the host-clock stages (what bench.py uses inside its timed region) */
@@ -412,7 +413,10 @@ int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
    supported (sigma_size <= 4); 4 = the LDS-tiled kernel; 0 = the LDS-tiled kernel pair (the fallback for other
    kernel sizes).  Results are bit-identical. */
 int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
-/* Level-preparation kernel (Lsmooth, Lflow of a level): 2 (default) = automatic, 1 = streaming, 0 = LDS-tiled. */
+/* Level preparation (Lsmooth, Lflow of a level): 2 (default) = automatic — for launches of 8 Mpx and more the
+   preparation and the level's first (up to four) diffusion steps run in ONE kernel (k_level_march), smaller launches take
+   the streaming or the LDS-tiled preparation kernel; 3 = the fused kernel wherever it is supported; 1 = streaming
+   preparation, 0 = LDS-tiled preparation (both without fusion).  Results are bit-identical. */
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
 /* names of the default FED kernel and of the detector kernel that large launches take (for bench / profiles) */
 const char* akz_fed_kernel_name(void);

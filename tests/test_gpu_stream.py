@@ -12,14 +12,14 @@ from test_gpu_extract import PLANES, assert_same_result
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[4, 5], ids=["tiled_fused", "march"])
+@pytest.fixture(params=[(4, 1), (5, 3)], ids=["tiled_fused+stream_prep", "march+level_march"])
 def sctx(amd, request):
     """A context with the streaming preparation / contrast / blur kernels forced on and one of the one-kernel detector
     forms forced (the LDS-tiled kernel or the column march), so that small test images take them too."""
     import torch
     c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
-    c.set_detector_mode(request.param)
-    c.set_prep_mode(1)
+    c.set_detector_mode(request.param[0])
+    c.set_prep_mode(request.param[1])  # 1: streaming preparation kernel; 3: preparation fused with the first diffusion steps
     yield c
     c.close()
 
@@ -97,6 +97,27 @@ def test_march_extract_candidates_across_strips(amd, ref, w, h, idx):
     try:
         frame = amd.synth_frame(w, h, idx)
         assert_same_result(c.extract_features(frame), ref.extract(frame, threads=8))
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("w,h,idx", [(480, 64, 21), (481, 97, 22), (479, 130, 23), (961, 66, 24), (1445, 160, 25), (16, 300, 26),
+                                     (35, 16, 27)])
+def test_level_march_strip_and_band_edges(amd, ref, w, h, idx):
+    """The fused level kernel (preparation + first diffusion steps) on widths around its 480-column strips, minimal
+    sizes and tall narrow images (several row bands), default and 5 x 5 configurations (2 .. 4 fused steps, levels with
+    more than four steps continue in k_fed_own, new octaves start from a materialised 2x2 mean), with and without
+    Lstep: every plane of every level, keypoints and descriptors against the oracle."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_prep_mode(3)
+    try:
+        frame = amd.synth_frame(w, h, idx)
+        assert_same_result(c.extract_features(frame), ref.extract(frame), equal_nan=True)
+        kw = dict(num_sublevels=5, max_octave_evolution=5)
+        assert_same_result(c.extract_features(frame, amd.Config(**kw)), ref.extract(frame, ref.default_config(**kw)), equal_nan=True)
+        lean = c.extract_features(frame, keep_all_planes=False)
+        assert_same_result(lean, ref.extract(frame), equal_nan=True)  # Lstep recomputed on fetch
     finally:
         c.close()
 

@@ -1490,6 +1490,78 @@ int akz_extract_begin_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, ui
     return extract_begin<float>(c, d_imgs, w, h, n, cfg, flags, out);
 }
 int akz_extract_finish(akz_job* job, akz_result** out) { return extract_finish(job, out); }
+// Measurement hook (bench.py `single_frame.graph`): is a lone frame's begin phase — a chain of ~45 dependent
+// launches — shorter as ONE hipGraph launch?  The begin phase of (d_imgs, w, h, n, cfg) is stream-captured into a
+// graph (same kernels, same buffers), then `reps` graph launches and `reps` plain enqueues of the same chain are
+// timed from an idle stream with HIP events.  Results of the captured chain are discarded.
+int akz_ctx_graph_probe(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
+                        uint32_t flags, uint32_t reps, double* ms_graph, double* ms_plain, uint64_t* graph_nodes) {
+    AKZ_TRY(bind(c));
+    if (!d_imgs || !cfg || !ms_graph || !ms_plain || reps == 0) return AKZ_ERR_INVALID_ARG;
+    const int prof = c->profiling;
+    c->profiling = 0;
+    struct Restore { akz_ctx* c; int p; ~Restore() { c->profiling = p; } } restore{c, prof};
+    // 1. warm: every buffer the chain uses exists afterwards (no allocation may happen while capturing)
+    for (int i = 0; i < 2; ++i) {
+        akz_result* r = nullptr;
+        AKZ_TRY(extract_impl<uint8_t>(c, d_imgs, w, h, n, cfg, flags, &r));
+        result_delete(r);
+    }
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    AKZ_HIP_TRY(hipEventCreate(&e0));
+    AKZ_HIP_TRY(hipEventCreate(&e1));
+    // 2. plain chain, from an idle stream each time
+    double plain = 0.0;
+    for (uint32_t i = 0; i < reps; ++i) {
+        akz_job* job = nullptr;
+        AKZ_HIP_TRY(hipEventRecord(e0, c->stream));
+        AKZ_TRY(extract_begin<uint8_t>(c, d_imgs, w, h, n, cfg, flags, &job));
+        AKZ_HIP_TRY(hipEventRecord(e1, c->stream));
+        AKZ_HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        AKZ_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        plain += ms;
+        job_destroy(job);
+    }
+    // 3. the same chain as a graph
+    akz_job* cap = nullptr;
+    AKZ_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    const int st = extract_begin<uint8_t>(c, d_imgs, w, h, n, cfg, flags, &cap);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+    if (st != AKZ_OK || ce != hipSuccess || !graph) {
+        if (cap) job_destroy(cap);
+        if (st == AKZ_OK) set_error(std::string("stream capture of the begin phase failed: ") + hipGetErrorString(ce));
+        return st != AKZ_OK ? st : AKZ_ERR_HIP;
+    }
+    size_t nodes = 0;
+    (void)hipGraphGetNodes(graph, nullptr, &nodes);
+    if (graph_nodes) *graph_nodes = nodes;
+    hipGraphExec_t exec = nullptr;
+    AKZ_HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    AKZ_HIP_TRY(hipGraphLaunch(exec, c->stream));  // warm
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    double gms = 0.0;
+    for (uint32_t i = 0; i < reps; ++i) {
+        AKZ_HIP_TRY(hipEventRecord(e0, c->stream));
+        AKZ_HIP_TRY(hipGraphLaunch(exec, c->stream));
+        AKZ_HIP_TRY(hipEventRecord(e1, c->stream));
+        AKZ_HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        AKZ_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        gms += ms;
+    }
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    job_destroy(cap);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_graph = gms / reps;
+    *ms_plain = plain / reps;
+    return AKZ_OK;
+}
+
 int akz_extract_from_planes(akz_ctx* c, uint32_t w, uint32_t h, const akz_config* cfg, const float* const* planes,
                             uint64_t n_levels, uint32_t flags, akz_result** out) {
     return extract_from_planes(c, w, h, cfg, planes, n_levels, flags, out);
@@ -2037,7 +2109,7 @@ int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     c->fed_mode = mode;
     return AKZ_OK;
 }
-const char* akz_fed_kernel_name(void) { return "k_fed_own"; }
+const char* akz_fed_kernel_name(void) { return "k_level_march + k_fed_own"; }
 const char* akz_detector_kernel_name(void) { return "k_detector_march"; }
 
 }  // extern "C"

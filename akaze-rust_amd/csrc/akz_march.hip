@@ -412,7 +412,8 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     const int wi = PAD + p0;
     // FED: which x-neighbours exist (only threads at column 0 / w-1 have one missing)
     const bool hxn0 = C.x0 > 0, hxp0 = C.x0 + 1 < w, hxn1 = C.x0 + 1 > 0, hxp1 = C.x0 + 2 < w;
-    const bool edge_col = !(hxn0 && hxp0 && hxn1 && hxp1);
+    // wave-uniform, so that the selects below are a scalar branch that 99 % of the waves never take
+    const bool edge_col = __ballot(!(hxn0 && hxp0 && hxn1 && hxp1)) != 0ull;
 
     const size_t base = (size_t)img * (size_t)w * (size_t)h;
     const float* in = prev + base;

@@ -152,6 +152,7 @@ def lib():
         "akz_result_device_plane": ([vp, u64, u64, i32, C.POINTER(vp)], i32),
         "akz_descriptor_match": ([vp, vp, u64, vp, u64, u64, u64, f64, vp, pu64], i32),
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
+        "akz_ctx_graph_probe": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, u32, pf64, pf64, pu64], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
@@ -338,6 +339,17 @@ class Context:
         p = Profile()
         _check(lib().akz_ctx_get_profile(self._h, C.byref(p), int(reset)))
         return p.as_dict()
+
+    def graph_probe(self, frames, options=None, keep_all_planes=True, reps=50):
+        """akz_ctx_graph_probe: (ms per hipGraph launch of the begin phase, ms per plain enqueue of it, graph nodes)."""
+        options = options or Config()
+        t = frames if frames.dim() == 3 else frames.unsqueeze(0)
+        n, h, w = t.shape
+        g, p, nodes = C.c_double(), C.c_double(), C.c_uint64()
+        _check(lib().akz_ctx_graph_probe(self._h, C.c_void_p(t.data_ptr()), w, h, n, C.byref(options),
+                                         AKZ_KEEP_ALL_PLANES if keep_all_planes else 0, reps, C.byref(g), C.byref(p),
+                                         C.byref(nodes)))
+        return g.value, p.value, nodes.value
 
     # ---- the hot path --------------------------------------------------------------------
     def extract_features(self, image, options=None, keep_all_planes=True, host_descriptors=True):

@@ -534,10 +534,6 @@ def main_rank(args):
             fed_alone[name] = {"avg_launch_us": round(ms / launches * 1e3, 2), "achieved": round(gbs, 1),
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst, "launches_per_pass": launches // reps,
                                "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * px * nst * reps / launches)}
-            tr = pmc_traffic("k_fed_own@" + name, workload_key)
-            if tr:
-                fed_alone[name]["traffic"] = tr
-                fed_alone[name]["traffic_frac"] = round(tr / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             del lt, lf
 
     # ---- self-check of the timed configuration (untimed): frame k of the batch == the same frame extracted alone ----
@@ -635,6 +631,13 @@ def main_rank(args):
         single = {"workload": f"one {W}x{H} frame per extract_features call (BASELINE configs[1])",
                   "latency_ms": round(lat * 1e3, 3), "stream_ms_per_frame": round(thr * 1e3, 3),
                   "stream_Mpix_s": round(W * H / thr / 1e6, 1)}
+        try:  # the begin phase (scale space, detector, extrema) as one hipGraph launch against the plain launch chain
+            g_ms, p_ms, nodes = ctx.graph_probe(one, cfg, keep_all_planes=not args.lean, reps=50)
+            single["graph"] = {"begin_phase_graph_ms": round(g_ms, 3), "begin_phase_plain_ms": round(p_ms, 3), "graph_nodes": nodes,
+                               "note": "GPU time of the begin phase from an idle stream (HIP events), graph launch vs "
+                                       "plain enqueue of the same kernels"}
+        except Exception as e:
+            single["graph"] = {"error": str(e)}
         # the same calls from K host threads with one context + stream each: a lone 1080p chain is launch-latency
         # bound and leaves most of the chip idle, concurrent chains fill it (ctypes releases the GIL in the calls)
         import threading

@@ -418,6 +418,12 @@ int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
    the streaming or the LDS-tiled preparation kernel; 3 = the fused kernel wherever it is supported; 1 = streaming
    preparation, 0 = LDS-tiled preparation (both without fusion).  Results are bit-identical. */
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
+/* Is the begin phase of an extraction (scale space + detector + extrema of a batch: ~45 dependent launches for a lone
+   1080p frame) shorter as ONE hipGraph launch?  Captures it for (d_imgs, w, h, n, cfg) and times `reps` graph launches
+   against `reps` plain enqueues, each from an idle stream (HIP events): *ms_graph, *ms_plain per launch, *graph_nodes
+   (may be NULL) the node count.  Results of the probe's extractions are discarded. */
+int akz_ctx_graph_probe(akz_ctx* ctx, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
+                        uint32_t flags, uint32_t reps, double* ms_graph, double* ms_plain, uint64_t* graph_nodes);
 /* names of the default FED kernel and of the detector kernel that large launches take (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
 const char* akz_detector_kernel_name(void);

@@ -320,7 +320,7 @@ def main_rank(args):
 
     def agree_capacity(rows):
         most = int(host_max(float(rows)))
-        xch["cap"] = 1 << max(10, (most + most // 2).bit_length())
+        xch["cap"] = max(1024, (most + most // 4 + 4095) // 4096 * 4096)  # 25 % head-room, whole 256 KiB blocks
 
     def exchange_retire():
         g = xch["pending"]

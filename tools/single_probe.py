@@ -9,7 +9,6 @@ frames = torch.from_numpy(np.stack([A.synth_frame(1920, 1080, i) for i in range(
 cfg = A.Config()
 st = torch.cuda.Stream(dev)
 ctx = A.Context(0, st.cuda_stream)
-ctx.set_detector_overlap(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 one = frames[0:1]
 for _ in range(10):
     ctx.extract_begin(one, cfg).finish().close()

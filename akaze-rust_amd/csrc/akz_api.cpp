@@ -948,6 +948,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         return e ? std::atoi(e) : -1;
     }();
     bool gate_recorded = false;
+    static const bool det_early = [] {
+        const char* e = std::getenv("AKZ_DET_EARLY");
+        return e ? std::atoi(e) != 0 : false;
+    }();
+    std::vector<char> det_launched(L, 0);
     for (size_t i = 1; i < L; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
@@ -1005,6 +1010,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                     AKZ_TRY(fed_impl(c, d1, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
                                      lv.tau.data() + n1, rem));
             }
+            if (det_early && detector_family(c, lv.det_sigma, lv.w, lv.h, n, border_margin(lv, cfg), keep_all) == 5)
+                det_launched[i] = detector_one_pass(i, s);
             AKZ_HIP_TRY(hipGetLastError());
             continue;
         }
@@ -1051,7 +1058,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                                                              (uint32_t)l, bm});
             continue;
         }
-        if (detector_one_pass(l, s)) continue;
+        if (det_launched[l] || detector_one_pass(l, s)) continue;
         {
             StageTimer st(c, AKZ_ST_DETECTOR);
             AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),

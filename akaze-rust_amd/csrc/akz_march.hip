@@ -54,7 +54,22 @@ constexpr int CBUF = 32;         // extrema buffered per wave before one atomic 
 
 struct MarchGrid {
     int nstrips, nbands, band_rows;  // band_rows: interior rows per band
+    int total;                       // workgroups with work; the grid is rounded up to a multiple of 8
 };
+// Workgroup i runs on XCD i mod 8.  Numbering the (image, band, strip) cells so that each XCD walks a CONTIGUOUS eighth
+// of them keeps an image's strips -- which share their halo columns -- in one L2, and lets each XCD's address translation
+// cover an eighth of the planes instead of all of them (measured: a launch on planes the previous launch did not touch
+// is a third slower than a repeat on the same planes, and in the pyramid every launch is of the first kind).
+#ifndef AKZ_MARCH_XCD
+#define AKZ_MARCH_XCD 1
+#endif
+__device__ __forceinline__ int march_cell() {
+#if AKZ_MARCH_XCD
+    return (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+#else
+    return (int)blockIdx.x;
+#endif
+}
 struct MarchNms {
     unsigned level;
     float thr;
@@ -113,59 +128,122 @@ __device__ __forceinline__ void cands_push(Candidate* buf, unsigned& n, unsigned
     }
 }
 
+// ---- global memory: raw buffer accesses --------------------------------------------------------------------------------
+// Every access of the row loop is `buffer_{load,store}_dwordx2 data, voffset, rsrc, soffset`: rsrc = one image's plane
+// (num_records = its bytes), voffset = the thread's column offset, soffset = the row's byte offset (scalar).  The
+// hardware drops an access whose voffset is out of range (voffset >= num_records - soffset), so a thread that owns no
+// column, and a row that is not stored this iteration, present VO_NONE instead of branching around the instruction.
+// Two things follow.  (1) Stores and loads are straight-line code, no exec-mask branches and no per-access address
+// arithmetic on the vector ALU.  (2) The compiler can COUNT the memory operations between a load and its use and waits
+// with vmcnt(n) for exactly that load; with the stores under divergent branches it could not, and drained the whole
+// queue (vmcnt(0)) once per row -- which bound these kernels by the memory latency of one row, not by bandwidth.
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned VO_NONE = 0x40000000u;  // out of range for every plane the kernels accept (<= 2^30 bytes per image)
+constexpr int RSRC_FLAGS = 0x00020000;     // raw buffer, dword data format (gfx9 word 3)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* plane_of_image, int w, int h) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane_of_image), 0, w * h * 4, RSRC_FLAGS);
+}
+
 struct Cols {          // a thread's two columns
     int x0;            // image column of the first one (halo threads may lie outside the image)
-    bool st2, st1;     // owner of both columns (one 8-byte store) / of the first only (the image ends between them)
-    bool ldv;          // both columns inside the image: one 8-byte load
-    unsigned boff;     // byte offset of column x0 in a row (meaningful where the thread loads / stores at x0)
-    unsigned lb0, lb1; // byte offsets of the clamped load columns otherwise
+    unsigned vo_st;    // store offset: byte offset of column x0 for the owner of the pair, VO_NONE otherwise
+    unsigned vo_st1;   // odd widths: byte offset of column x0+1 if it is owned and inside the image, VO_NONE otherwise
+    unsigned vo_ld;    // load offset: byte offset of column clamp(x0, 0, w-2)
+    int ld_dup;        // 0: the loaded pair is (x0, x0+1); 1 / 2: both columns clamp to the pair's first / second column
+    bool ld_edge;      // wave-uniform: some lane of the wave has ld_dup != 0
 };
-// All global accesses are `uniform row address (SGPR pair) + 32-bit byte offset of the thread`: one address VGPR per
-// thread for every plane and row instead of a 64-bit address computation per access.
-__device__ __forceinline__ float* at(float* row, unsigned boff) { return reinterpret_cast<float*>(reinterpret_cast<char*>(row) + boff); }
-__device__ __forceinline__ const float* at(const float* row, unsigned boff) {
-    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + boff);
+__device__ __forceinline__ Cols make_cols(int x0, bool inner, int w) {
+    Cols C;
+    C.x0 = x0;
+    C.vo_st = (inner && x0 < w) ? (unsigned)x0 * 4u : VO_NONE;
+    C.vo_st1 = (inner && x0 + 1 < w) ? (unsigned)(x0 + 1) * 4u : VO_NONE;
+    const int xl = min(max(x0, 0), w - 2);
+    C.vo_ld = (unsigned)xl * 4u;
+    C.ld_dup = x0 < 0 ? 1 : (x0 > w - 2 ? 2 : 0);
+    C.ld_edge = __ballot(C.ld_dup != 0) != 0ull;
+    return C;
 }
-// ro: byte offset of the row inside the image's plane (32 bits: a plane of one image is far below 4 GiB), so that an
-// access is `plane of the image (SGPR pair) + one 32-bit VGPR offset` with no 64-bit arithmetic per plane and row
-template <int N>
-__device__ __forceinline__ void store_rows(float* const (&plane)[N], unsigned ro, const Cols& C, const f2 (&v)[N]) {
-    if (C.st2) {
+// A workgroup- or wave-uniform condition that is almost never true: kept a branch (the empty asm stops the compiler from
+// turning the guarded register moves into selects that every row of every wave would execute).
+__device__ __forceinline__ bool rare(bool c) {
+    if (__builtin_expect(c, 0)) {
+        asm volatile("");
+        return true;
+    }
+    return false;
+}
+// the dwords at columns (xl, xl+1), xl = clamp(x0, 0, w-2), of row `ro` (byte offset of an existing row of the plane) ...
+// (ODDW: rows of an odd-width image are not all 8-byte aligned, which 8-byte buffer accesses need: two dwords)
+template <bool ODDW>
+__device__ __forceinline__ f2 load_pair(__amdgpu_buffer_rsrc_t rs, unsigned ro, const Cols& C) {
+    if (!ODDW) return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)C.vo_ld, (int)ro, 0));
+    f2 v;
+    v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)C.vo_ld, (int)ro, 0));
+    v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)C.vo_ld + 4, (int)ro, 0));
+    return v;
+}
+// ... and what they mean for the thread: (in[clamp(x0)], in[clamp(x0+1)]).  Applied where the pair is CONSUMED, rows
+// after the load was issued, so that nothing waits for the load early.
+__device__ __forceinline__ f2 fix_pair(f2 v, const Cols& C) {
+    if (rare(C.ld_edge)) {  // waves at the left / right edge of the image only
+        if (C.ld_dup == 1) v.y = v.x;
+        if (C.ld_dup == 2) v.x = v.y;
+    }
+    return v;
+}
+// Row r of N planes; `on` (workgroup-uniform): the row is stored at all.  A row that is not stored is presented as
+// (row 0, VO_NONE): the row offset must stay inside the plane for the range check to mean anything.
+// ODDW: a pair can straddle the right edge of the image, so the two columns are stored one by one.
+template <int N, bool ODDW, bool NT = true>
+__device__ __forceinline__ void store_rows(const __amdgpu_buffer_rsrc_t (&plane)[N], int r, int w, bool on, const Cols& C,
+                                           const f2 (&v)[N]) {
+    const unsigned ro = on ? (unsigned)r * ((unsigned)w * 4u) : 0u;
+    // streaming stores (NT): the plane is written once and not read again soon; they also leave the Infinity Cache
+    // alone, which ordinary stores fill
+    constexpr int AUX = NT ? 2 : 0;
+    if (!ODDW) {
+        const unsigned vo = on ? C.vo_st : VO_NONE;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v[i]), plane[i], (int)vo, (int)ro, AUX);
+    } else {
+        const unsigned vo0 = on ? C.vo_st : VO_NONE, vo1 = on ? C.vo_st1 : VO_NONE;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            // streaming stores: the planes are written once and not read again by this kernel (+20 % for this access shape)
-            __builtin_nontemporal_store((f2u)v[i], reinterpret_cast<f2u*>(at(plane[i], ro + C.boff)));
+            const float a = v[i].x, b = v[i].y;  // (bit_cast of a vector ELEMENT picks element 0 with this compiler)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), plane[i], (int)vo0, (int)ro, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b), plane[i], (int)vo1, (int)ro, AUX);
         }
-    } else if (C.st1) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) *at(plane[i], ro + C.boff) = v[i].x;
     }
 }
-// interior row r of the output planes, plus (twice per strip) the border rows that copy it
-template <int S, int N>
-__device__ __forceinline__ void store_filled(float* const (&plane)[N], const Cols& C, int w, int h, int r, const f2 (&v)[N]) {
-    const unsigned wb = (unsigned)w * 4u;
-    store_rows<N>(plane, (unsigned)r * wb, C, v);
-    if (r == S || r == h - 1 - S) {  // workgroup-uniform
+// interior row r of the output planes, plus (twice per image) the border rows that copy it
+template <int S, int N, bool ODDW, bool NT = true>
+__device__ __forceinline__ void store_filled(const __amdgpu_buffer_rsrc_t (&plane)[N], const Cols& C, int w, int h, int r, bool on,
+                                             const f2 (&v)[N]) {
+    store_rows<N, ODDW, NT>(plane, r, w, on, C, v);
+    if (on && (r == S || r == h - 1 - S)) {  // workgroup-uniform, two rows of an image
         if (r == S) {
 #pragma nounroll
-            for (int y = 0; y < S; ++y) store_rows<N>(plane, (unsigned)y * wb, C, v);
+            for (int y = 0; y < S; ++y) store_rows<N, ODDW, NT>(plane, y, w, true, C, v);
         }
         if (r == h - 1 - S) {
 #pragma nounroll
-            for (int y = h - S; y < h; ++y) store_rows<N>(plane, (unsigned)y * wb, C, v);
+            for (int y = h - S; y < h; ++y) store_rows<N, ODDW, NT>(plane, y, w, true, C, v);
         }
     }
 }
 
-template <int S, bool NMS, bool KEEP>
-__global__ void __launch_bounds__(MT, (S <= 2 ? 4 : 3))
+template <int S, bool NMS, bool KEEP, bool ODDW>
+__global__ void __launch_bounds__(MT, 3)
 k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float* __restrict__ ly_out,
                  float* __restrict__ lxx_out, float* __restrict__ lyy_out, float* __restrict__ lxy_out,
                  float* __restrict__ ldet_out, int w, int h, MarchGrid g, float kn, float kwn, float quat, MarchNms nms) {
     constexpr int P = 2 * S + 1, NOUT = KEEP ? 4 : 1;
     static_assert(2 * S + 2 <= HALO, "strip halo");
-    constexpr int PF = S >= 4 ? 2 : AKZ_MARCH_PF;  // input rows in flight ahead of the arithmetic (register budget at S = 4)
+    // input rows in flight ahead of the arithmetic; they sit in a ring of R slots, R a divisor of the unroll count P
+    // (static indices), so no register is ever copied -- a copy would have to wait for the load it copies
+    constexpr int R = P % 3 == 0 ? 3 : P;
+    constexpr int PF = AKZ_MARCH_PF < R - 1 ? AKZ_MARCH_PF : R - 1;
     static_assert(S <= PAD, "LDS padding");
     __shared__ __attribute__((aligned(16))) float s_row[2][4][ROW];  // [buffer][Lsmooth, Lx, Ly, Ldet][PAD + position]
     __shared__ Candidate s_cands[NMS ? MT / 64 : 1][NMS ? CBUF : 1];
@@ -177,8 +255,10 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
     // (integer division runs on the vector ALU: readfirstlane moves the uniform results back to scalar registers, so
     // that row addresses, loop bounds and branches derived from them stay scalar)
     const int per = g.nbands * g.nstrips;
-    const int img = __builtin_amdgcn_readfirstlane((int)blockIdx.x / per);
-    const int rem = (int)blockIdx.x - img * per;
+    const int cell = march_cell();
+    if (cell >= g.total) return;
+    const int img = __builtin_amdgcn_readfirstlane(cell / per);
+    const int rem = cell - img * per;
     const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
     const int cs = S + band * g.band_rows, ce = min(cs + g.band_rows, h - S);  // interior rows of this band
     if (cs >= ce) return;
@@ -187,52 +267,37 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
     // threads 0..239 own positions 16..495 (so that every wave's stores start on a 512-byte boundary of the strip),
     // threads 240..247 the right halo, 248..255 the left halo
     const int p0 = (2 * tid + HALO) & (MW - 1);
-    Cols C;
-    C.x0 = X0 + p0;
     const bool inner = p0 >= HALO && p0 < MW - HALO;
-    C.st2 = inner && C.x0 + 1 < w;
-    C.st1 = inner && !C.st2 && C.x0 < w;
-    C.ldv = C.x0 >= 0 && C.x0 + 1 <= w - 1;
-    C.boff = (unsigned)C.x0 * 4u;
-    C.lb0 = (unsigned)clampi(C.x0, 0, w - 1) * 4u;
-    C.lb1 = (unsigned)clampi(C.x0 + 1, 0, w - 1) * 4u;
+    const Cols C = make_cols(X0 + p0, inner, w);
     // LDS read indices of tap -S of the two columns, evaluated at the clamped column (taps 0 and +S: + S, + 2S)
     const int i0 = PAD + clampi(clampi(C.x0, S, w - 1 - S) - X0, 0, MW - 1) - S;
     const int i1 = PAD + clampi(clampi(C.x0 + 1, S, w - 1 - S) - X0, 0, MW - 1) - S;
     const int wi = PAD + p0;
     unsigned xok = 0;  // bit i: column i of this thread may hold a candidate
     if (NMS) {
-        if ((C.st2 || C.st1) && C.x0 >= nms.xlo && C.x0 <= nms.xhi) xok |= 1u;
-        if (C.st2 && C.x0 + 1 >= nms.xlo && C.x0 + 1 <= nms.xhi) xok |= 2u;
+        if (inner && C.x0 < w && C.x0 >= nms.xlo && C.x0 <= nms.xhi) xok |= 1u;
+        if (inner && C.x0 + 1 < w && C.x0 + 1 >= nms.xlo && C.x0 + 1 <= nms.xhi) xok |= 2u;
     }
 
     const size_t base = (size_t)img * (size_t)w * (size_t)h;
-    const float* in = ls + base;
-    float* const out1[2] = {lx_out + base, ly_out + base};
-    float* out2[NOUT];
-    out2[0] = ldet_out + base;
+    const __amdgpu_buffer_rsrc_t in = plane_rsrc(ls + base, w, h);
+    const __amdgpu_buffer_rsrc_t out1[2] = {plane_rsrc(lx_out + base, w, h), plane_rsrc(ly_out + base, w, h)};
+    __amdgpu_buffer_rsrc_t out2[NOUT];
+    out2[0] = plane_rsrc(ldet_out + base, w, h);
     if (KEEP) {
-        out2[1] = lxx_out + base;
-        out2[2] = lyy_out + base;
-        out2[3] = lxy_out + base;
+        out2[1] = plane_rsrc(lxx_out + base, w, h);
+        out2[2] = plane_rsrc(lyy_out + base, w, h);
+        out2[3] = plane_rsrc(lxy_out + base, w, h);
     }
-    float* const(&out2c)[NOUT] = out2;
+    const __amdgpu_buffer_rsrc_t(&out2c)[NOUT] = out2;
 
     // the extrema test of rows [cs, ce) needs Ldet rows cs-1 .. ce, i.e. input rows cs-1-2S .. ce+2S
     const int v0 = cs - 1 - 2 * S;
     const int T = (ce - cs) + 4 * S + 3;
     auto feed = [&](int t) -> f2 {
-        const unsigned ro = (unsigned)clampi(v0 + min(t, T - 1), S, h - 1 - S) * ((unsigned)w * 4u);
-        f2 v;
-        if (C.ldv) {
-            v = *reinterpret_cast<const f2u*>(at(in, ro + C.boff));
-        } else {
-            v.x = *at(in, ro + C.lb0);
-            v.y = *at(in, ro + C.lb1);
-        }
-        return v;
+        return load_pair<ODDW>(in, (unsigned)clampi(v0 + min(t, T - 1), S, h - 1 - S) * ((unsigned)w * 4u), C);
     };
-    f2 q[PF];
+    f2 q[R];
 #pragma unroll
     for (int i = 0; i < PF; ++i) q[i] = feed(i);
     const f2 zero = {0.0f, 0.0f};
@@ -246,11 +311,11 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int t = t0 + k;
-            if (t < T) {
+            {  // (whole groups of P rows: the up to P-1 rows past T store nothing, their output rows lie past ce)
                 const int v = v0 + t, u = v - S, u1 = u - 1, c = u1 - S;
-                const f2 nxt = feed(t + PF);
+                q[(k + PF) % R] = feed(t + PF);
                 float* const buf = &s_row[t & 1][0][0];
-                *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = q[0];
+                *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = fix_pair(q[k % R], C);
                 *reinterpret_cast<f2*>(buf + 1 * ROW + wi) = lx_c;
                 *reinterpret_cast<f2*>(buf + 2 * ROW + wi) = ly_c;
                 if (NMS) *reinterpret_cast<f2*>(buf + 3 * ROW + wi) = dm1;
@@ -269,9 +334,9 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
                     lx_n = tap_off(rHm[k0], rHm[k]);
                     ly_n = tap_main(rHo[k0], rHo[k1], rHo[k], kn, kwn);
                 }
-                if (u >= cs && u < ce) {
+                {
                     const f2 o1[2] = {lx_n, ly_n};
-                    store_filled<S, 2>(out1, C, w, h, u, o1);
+                    store_filled<S, 2, ODDW>(out1, C, w, h, u, u >= cs && u < ce, o1);
                 }
                 // ---- stage 2: H pass of Lx, Ly row u-1 (in LDS), V pass -> Lxx, Lyy, Lxy, Ldet of row c ----
                 f2 A, B, Cc;
@@ -297,12 +362,12 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
                 const f2 lyy = tap_main(rB[k0], rB[k1], rB[k], kn, kwn);
                 const f2 lxy = tap_main(rC[k0], rC[k1], rC[k], kn, kwn);
                 const f2 det = ((lxx * lyy) - (lxy * lxy)) * quat;
-                if (c >= cs && c < ce) {
+                {
                     f2 o[NOUT];
                     o[0] = det;
                     if (KEEP) { o[1] = lxx; o[2] = lyy; o[3] = lxy; }
                     const f2(&oc)[NOUT] = o;
-                    store_filled<S, NOUT>(out2c, C, w, h, c, oc);
+                    store_filled<S, NOUT, ODDW>(out2c, C, w, h, c, c >= cs && c < ce, oc);
                 }
                 // ---- extrema test of row c-1: dm1, between dm2 (above) and det (below) ----
                 if (NMS) {
@@ -331,9 +396,6 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
                 }
                 lx_c = lx_n;
                 ly_c = ly_n;
-#pragma unroll
-                for (int i = 0; i + 1 < PF; ++i) q[i] = q[i + 1];
-                q[PF - 1] = nxt;
             }
         }
     }
@@ -376,7 +438,7 @@ __device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) 
     return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
 }
 
-template <int N, bool KEEPSTEP>
+template <int N, bool KEEPSTEP, bool ODDW>
 __global__ void __launch_bounds__(MT, 3)
 k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, float* __restrict__ lflow_out,
               float* __restrict__ lt_out, float* __restrict__ lstep_out, int w, int h, MarchGrid g, float g0, float g1,
@@ -384,12 +446,18 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     static_assert(N >= 1 && N <= 4, "fused diffusion steps");
     static_assert(N + 3 <= HALO, "strip halo");
     constexpr int NPL = 3 + N;  // LDS rows per iteration: Lt_prev, Lsmooth, Lflow, L^0 .. L^(N-1)
-    constexpr int PF = 2;
+#ifndef AKZ_LEVEL_PF
+#define AKZ_LEVEL_PF 2
+#endif
+    constexpr int PF = AKZ_LEVEL_PF;  // input rows in flight (<= 3: they sit in a ring of 4 slots with static indices)
+    static_assert(PF >= 1 && PF <= 3, "prefetch ring");
     __shared__ __attribute__((aligned(16))) float s_row[2][NPL][ROW];
     const int tid = threadIdx.x;
     const int per = g.nbands * g.nstrips;
-    const int img = __builtin_amdgcn_readfirstlane((int)blockIdx.x / per);
-    const int rem = (int)blockIdx.x - img * per;
+    const int cell = march_cell();
+    if (cell >= g.total) return;
+    const int img = __builtin_amdgcn_readfirstlane(cell / per);
+    const int rem = cell - img * per;
     const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
     const int cs = 1 + band * g.band_rows, ce = min(cs + g.band_rows, h - 1);  // interior rows of Lsmooth / Lflow
     if (cs >= ce) return;
@@ -397,15 +465,8 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
 
     const int X0 = strip * USE - HALO;
     const int p0 = (2 * tid + HALO) & (MW - 1);
-    Cols C;
-    C.x0 = X0 + p0;
     const bool inner = p0 >= HALO && p0 < MW - HALO;
-    C.st2 = inner && C.x0 + 1 < w;
-    C.st1 = inner && !C.st2 && C.x0 < w;
-    C.ldv = C.x0 >= 0 && C.x0 + 1 <= w - 1;
-    C.boff = (unsigned)C.x0 * 4u;
-    C.lb0 = (unsigned)clampi(C.x0, 0, w - 1) * 4u;
-    C.lb1 = (unsigned)clampi(C.x0 + 1, 0, w - 1) * 4u;
+    const Cols C = make_cols(X0 + p0, inner, w);
     // LDS indices of tap -1 of the two columns of the blur / Scharr passes (evaluated at the clamped column)
     const int i0 = PAD + clampi(clampi(C.x0, 1, w - 2) - X0, 0, MW - 1) - 1;
     const int i1 = PAD + clampi(clampi(C.x0 + 1, 1, w - 2) - X0, 0, MW - 1) - 1;
@@ -416,13 +477,13 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     const bool edge_col = __ballot(!(hxn0 && hxp0 && hxn1 && hxp1)) != 0ull;
 
     const size_t base = (size_t)img * (size_t)w * (size_t)h;
-    const float* in = prev + base;
-    float* const o_ls[1] = {lsmooth_out + base};
-    float* const o_lf[1] = {lflow_out + base};
-    float* o_lt[KEEPSTEP ? 2 : 1];
-    o_lt[0] = lt_out + base;
-    if (KEEPSTEP) o_lt[1] = lstep_out + base;
-    float* const(&o_ltc)[KEEPSTEP ? 2 : 1] = o_lt;
+    const __amdgpu_buffer_rsrc_t in = plane_rsrc(prev + base, w, h);
+    const __amdgpu_buffer_rsrc_t o_ls[1] = {plane_rsrc(lsmooth_out + base, w, h)};
+    const __amdgpu_buffer_rsrc_t o_lf[1] = {plane_rsrc(lflow_out + base, w, h)};
+    __amdgpu_buffer_rsrc_t o_lt[KEEPSTEP ? 2 : 1];
+    o_lt[0] = plane_rsrc(lt_out + base, w, h);
+    if (KEEPSTEP) o_lt[1] = plane_rsrc(lstep_out + base, w, h);
+    const __amdgpu_buffer_rsrc_t(&o_ltc)[KEEPSTEP ? 2 : 1] = o_lt;
     const double kc = octave_contrast(d_k[img], k_pow);
     const double inverse_k = 1.0 / (kc * kc);
 
@@ -430,17 +491,9 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     const int v0 = lt0 - N - 2;
     const int T = (lt1 - lt0) + 2 * N + 6;
     auto feed = [&](int t) -> f2 {
-        const unsigned ro = (unsigned)clampi(v0 + min(t, T - 1), 0, h - 1) * ((unsigned)w * 4u);
-        f2 v;
-        if (C.ldv) {
-            v = *reinterpret_cast<const f2u*>(at(in, ro + C.boff));
-        } else {
-            v.x = *at(in, ro + C.lb0);
-            v.y = *at(in, ro + C.lb1);
-        }
-        return v;
+        return load_pair<ODDW>(in, (unsigned)clampi(v0 + min(t, T - 1), 0, h - 1) * ((unsigned)w * 4u), C);
     };
-    f2 q[PF];
+    f2 q[4];
 #pragma unroll
     for (int i = 0; i < PF; ++i) q[i] = feed(i);
     const f2 zero = {0.0f, 0.0f};
@@ -458,16 +511,18 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     }
     f2 ls_c = zero, lf_c = zero, gh_c = zero;  // Lsmooth row v-2, Lflow row v-4, H gauss of row v-1 (previous iteration's results)
 
+    // The row loop runs whole groups of 8 (static ring indices); the up to 7 rows past T store nothing: their Lsmooth,
+    // Lflow and Lt rows lie past ce / lt1.
     for (int t0 = 0; t0 < T; t0 += 8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int t = t0 + k;
-            if (t < T) {
+            {
                 const int v = v0 + t;
-                const f2 nxt = feed(t + PF);
+                q[(k + PF) & 3] = feed(t + PF);
                 float* const buf = &s_row[t & 1][0][0];
-                LP[k & 7] = q[0];
-                *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = q[0];
+                LP[k & 7] = fix_pair(q[k & 3], C);
+                *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = LP[k & 7];
                 *reinterpret_cast<f2*>(buf + 1 * ROW + wi) = ls_c;
                 *reinterpret_cast<f2*>(buf + 2 * ROW + wi) = CR[(k - 5) & 7];
                 *reinterpret_cast<f2*>(buf + 3 * ROW + wi) = LP[(k - 5) & 7];
@@ -484,13 +539,13 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                 }
                 gh_c = gh;
                 GH[k & 3] = gh;
-                if (v == 1) GH[(k - 1) & 3] = gh;  // filled row 0 is row 1
+                if (rare(v == 1)) GH[(k - 1) & 3] = gh;  // filled row 0 is row 1
                 const int u = v - 1;
                 f2 ls_n = ls_c;
                 if (u <= h - 2) ls_n = tap3(GH[(k - 2) & 3], GH[(k - 1) & 3], GH[k & 3], g0, g1, g2);
-                if (u >= cs && u < ce) {
+                {
                     const f2 o[1] = {ls_n};
-                    store_filled<1, 1>(o_ls, C, w, h, u, o);
+                    store_filled<1, 1, ODDW>(o_ls, C, w, h, u, u >= cs && u < ce, o);
                 }
                 // ---- Scharr pair at scale 1 of Lsmooth row u-1 (in LDS), V pass -> Lx1, Ly1 -> Lflow row c = v-3 ----
                 {
@@ -500,7 +555,7 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                     HM[k & 3] = tap_main(a, b, c, kn, kwn);
                     HO[k & 3] = tap_off(a, c);
                 }
-                if (u - 1 == 1) {  // filled row 0 is row 1
+                if (rare(u - 1 == 1)) {  // filled row 0 is row 1
                     HM[(k - 1) & 3] = HM[k & 3];
                     HO[(k - 1) & 3] = HO[k & 3];
                 }
@@ -512,10 +567,10 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                     lf_n = f2{pm_g2_px(lx1.x, ly1.x, inverse_k), pm_g2_px(lx1.y, ly1.y, inverse_k)};
                 }
                 CR[(k - 3) & 7] = lf_n;
-                if (c == 1) CR[(k - 4) & 7] = lf_n;  // filled row 0 is row 1
-                if (c >= cs && c < ce) {
+                if (rare(c == 1)) CR[(k - 4) & 7] = lf_n;  // filled row 0 is row 1
+                {
                     const f2 o[1] = {lf_n};
-                    store_filled<1, 1>(o_lf, C, w, h, c, o);
+                    store_filled<1, 1, ODDW>(o_lf, C, w, h, c, c >= cs && c < ce, o);
                 }
                 // ---- x-pair sums of the Lflow row the first FED stage works on (row v-5, in LDS) ----
                 {
@@ -561,19 +616,16 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                 }
                 {
                     const int r = v - 4 - N;
-                    if (r >= lt0 && r < lt1) {
+                    {
                         f2 o[KEEPSTEP ? 2 : 1];
                         o[0] = lnew;
                         if (KEEPSTEP) o[1] = st;
                         const f2(&oc)[KEEPSTEP ? 2 : 1] = o;
-                        store_rows<KEEPSTEP ? 2 : 1>(o_ltc, (unsigned)r * ((unsigned)w * 4u), C, oc);
+                        store_rows<KEEPSTEP ? 2 : 1, ODDW>(o_ltc, r, w, r >= lt0 && r < lt1, C, oc);
                     }
                 }
                 ls_c = ls_n;
                 lf_c = lf_n;
-#pragma unroll
-                for (int i = 0; i + 1 < PF; ++i) q[i] = q[i + 1];
-                q[PF - 1] = nxt;
             }
         }
     }
@@ -602,11 +654,12 @@ inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid
     long nb = std::max<long>(1, std::min<long>(want, std::max(1, rows / min_rows)));
     g.band_rows = (int)((rows + nb - 1) / nb);
     g.nbands = (rows + g.band_rows - 1) / g.band_rows;
-    *grid = dim3((unsigned)(cols * g.nbands));
+    g.total = (int)(cols * g.nbands);
+    *grid = dim3((unsigned)((g.total + 7) / 8 * 8));
     return g;
 }
 
-inline MarchGrid plan_march(const void* kernel, uint32_t w, uint32_t h, uint32_t n, int S, dim3* grid) {
+inline MarchGrid plan_march(uint32_t w, uint32_t h, uint32_t n, int S, dim3* grid) {
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -623,7 +676,6 @@ inline MarchGrid plan_march(const void* kernel, uint32_t w, uint32_t h, uint32_t
         const char* m = getenv("AKZ_MARCH_MIN_ROWS");
         min_rows = m ? std::max(8, atoi(m)) : 64;
     }
-    (void)kernel;
     const int use = USE;
     (void)S;
     MarchGrid g;
@@ -634,7 +686,8 @@ inline MarchGrid plan_march(const void* kernel, uint32_t w, uint32_t h, uint32_t
     long nb = std::max<long>(1, std::min<long>(want, std::max(1, rows / min_rows)));
     g.band_rows = (int)((rows + nb - 1) / nb);
     g.nbands = (rows + g.band_rows - 1) / g.band_rows;
-    *grid = dim3((unsigned)(cols * g.nbands));
+    g.total = (int)(cols * g.nbands);
+    *grid = dim3((unsigned)((g.total + 7) / 8 * 8));
     return g;
 }
 
@@ -657,30 +710,34 @@ static void admissible_range(uint32_t dim, float border_m, int* lo, int* hi) {
 bool detector_march_supported(uint32_t sigma, uint32_t w, uint32_t h, float border_m, bool nms) {
     if (sigma < 1 || sigma > 4) return false;
     if (w < 4 * sigma + 8 || h < 4 * sigma + 8) return false;
+    if ((uint64_t)w * h > (1ull << 28)) return false;  // buffer range checks: one image's plane stays below 2^30 bytes
     // the extrema test reads Ldet one pixel around a candidate: keep that ring inside the interior rows / columns
     return !nms || border_m >= (float)(sigma + 2);
 }
 
-#define AKZ_MARCH(S)                                                                                                  \
-    case S: {                                                                                                         \
-        dim3 gr;                                                                                                      \
-        if (d_cand && keep) {                                                                                         \
-            const MarchGrid mg = plan_march((const void*)k_detector_march<S, true, true>, w, h, n, S, &gr);            \
-            hipLaunchKernelGGL((k_detector_march<S, true, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy,  \
-                               ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                      \
-        } else if (d_cand) {                                                                                          \
-            const MarchGrid mg = plan_march((const void*)k_detector_march<S, true, false>, w, h, n, S, &gr);           \
-            hipLaunchKernelGGL((k_detector_march<S, true, false>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
-                               ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                      \
-        } else if (keep) {                                                                                            \
-            const MarchGrid mg = plan_march((const void*)k_detector_march<S, false, true>, w, h, n, S, &gr);           \
-            hipLaunchKernelGGL((k_detector_march<S, false, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, \
-                               ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                      \
-        } else {                                                                                                      \
-            const MarchGrid mg = plan_march((const void*)k_detector_march<S, false, false>, w, h, n, S, &gr);          \
-            hipLaunchKernelGGL((k_detector_march<S, false, false>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy,     \
-                               lxy, ldet_out, (int)w, (int)h, mg, kn, kwn, quat, na);                                 \
-        }                                                                                                             \
+template <int S, bool NMS, bool KEEP>
+static void launch_detector_march(hipStream_t s, const float* lsmooth, float* lx, float* ly, float* lxx, float* lyy, float* lxy,
+                                  float* ldet_out, uint32_t w, uint32_t h, uint32_t n, float kn, float kwn, float quat,
+                                  const MarchNms& na) {
+    dim3 gr;
+    const MarchGrid mg = plan_march(w, h, n, S, &gr);
+    if (w & 1u)
+        hipLaunchKernelGGL((k_detector_march<S, NMS, KEEP, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out,
+                           (int)w, (int)h, mg, kn, kwn, quat, na);
+    else
+        hipLaunchKernelGGL((k_detector_march<S, NMS, KEEP, false>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out,
+                           (int)w, (int)h, mg, kn, kwn, quat, na);
+}
+#define AKZ_MARCH(S)                                                                                              \
+    case S: {                                                                                                     \
+        if (d_cand && keep)                                                                                       \
+            launch_detector_march<S, true, true>(s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, kn, kwn, quat, na);   \
+        else if (d_cand)                                                                                          \
+            launch_detector_march<S, true, false>(s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, kn, kwn, quat, na);  \
+        else if (keep)                                                                                            \
+            launch_detector_march<S, false, true>(s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, kn, kwn, quat, na);  \
+        else                                                                                                      \
+            launch_detector_march<S, false, false>(s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out, w, h, n, kn, kwn, quat, na); \
     } break;
 
 // One level's detector response (+ extrema candidates when d_cand is given) in one launch of k_detector_march.
@@ -692,6 +749,9 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
     const bool keep = lxx && lyy && lxy;
+#ifdef AKZ_EXP_NO_NMS  // timing experiment only: no candidates come out
+    d_cand = nullptr;
+#endif
     MarchNms na{level, thr, 0, -1, 0, -1, d_cand, cap, d_count};
     if (d_cand) {
         admissible_range(w, border_m, &na.xlo, &na.xhi);
@@ -704,16 +764,23 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
 }
 #undef AKZ_MARCH
 
-bool level_march_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16; }
+bool level_march_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16 && (uint64_t)w * h <= (1ull << 28); }
 
-#define AKZ_LEVEL(NS)                                                                                                  \
-    case NS: {                                                                                                        \
-        if (lstep)                                                                                                    \
-            hipLaunchKernelGGL((k_level_march<NS, true>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep,     \
-                               (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht);          \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_level_march<NS, false>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep,    \
-                               (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht);          \
+template <int NS, bool KEEPSTEP>
+static void launch_level_march(hipStream_t s, dim3 gr, const MarchGrid& mg, const float* prev, float* lsmooth, float* lflow,
+                               float* lt_out, float* lstep, uint32_t w, uint32_t h, const float* g3, const Taps& m,
+                               const double* d_k, uint32_t k_pow, const LevelTaus& ht) {
+    if (w & 1u)
+        hipLaunchKernelGGL((k_level_march<NS, KEEPSTEP, true>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep, (int)w,
+                           (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht);
+    else
+        hipLaunchKernelGGL((k_level_march<NS, KEEPSTEP, false>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep, (int)w,
+                           (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht);
+}
+#define AKZ_LEVEL(NS)                                                                                                        \
+    case NS: {                                                                                                               \
+        if (lstep) launch_level_march<NS, true>(s, gr, mg, prev, lsmooth, lflow, lt_out, lstep, w, h, g3, m, d_k, k_pow, ht);  \
+        else launch_level_march<NS, false>(s, gr, mg, prev, lsmooth, lflow, lt_out, lstep, w, h, g3, m, d_k, k_pow, ht);       \
     } break;
 
 // Level preparation + the level's first n_steps (1..4) diffusion steps in one launch of k_level_march.  prev: the

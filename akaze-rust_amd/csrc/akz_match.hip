@@ -37,8 +37,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int KB = 512;            // int8 columns per descriptor (64 bytes x 8 bits)
-constexpr int MM_NT = 1024;        // threads per workgroup: 16 waves, four per SIMD
-constexpr int MM_QW = 32;          // queries per wave: one 32-column block, its B operand resident in 64 VGPRs
+// 32-column query blocks per wave.  With 2, every A operand read from LDS feeds two MFMAs (half the LDS traffic per
+// product) but the 128 resident operand registers leave room for only 8 waves per workgroup: measured 25-35 % SLOWER at
+// 11 K and 90 K rows (profiles/r02_match_variants.txt) -- the loop is bound by the MFMA pipe and its latency hiding,
+// not by LDS bandwidth -- so the default stays 1 (16 waves, four per SIMD).
+#ifndef AKZ_MM_NB
+#define AKZ_MM_NB 1
+#endif
+constexpr int MM_NB = AKZ_MM_NB;
+constexpr int MM_NT = 1024 / MM_NB;  // threads per workgroup
+constexpr int MM_QW = 32 * MM_NB;  // queries per wave; their B operands stay resident (64 VGPRs per block)
 constexpr int MM_QB = (MM_NT / 64) * MM_QW;  // queries per workgroup (512)
 #ifndef AKZ_MM_SUB
 #define AKZ_MM_SUB 4
@@ -113,30 +121,37 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
-    const unsigned q_first = blockIdx.x * MM_QB + wave * MM_QW;  // this wave's 32 queries
+    const unsigned q_first = blockIdx.x * MM_QB + wave * MM_QW;  // this wave's 64 queries: block b = queries q_first + 32 b ..
 
-    // B operand: 16 K-steps of this wave's 32 queries, resident for the whole chunk
-    v4i bq[16];
-    {
-        const uint8_t* row = q8 + (size_t)(q_first + r) * KB + 16 * h;
+    // B operands: 16 K-steps of each of this wave's query blocks, resident for the whole chunk
+    v4i bq[MM_NB][16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) bq[s] = *reinterpret_cast<const v4i*>(row + 32 * s);
-        // pin the operand here: otherwise the waits for these loads are placed at their first use inside the tile loop
+    for (int b = 0; b < MM_NB; ++b) {
+        const uint8_t* row = q8 + (size_t)(q_first + 32 * b + r) * KB + 16 * h;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bq[s]));
+        for (int s = 0; s < 16; ++s) bq[b][s] = *reinterpret_cast<const v4i*>(row + 32 * s);
     }
-    const unsigned pq = qpop[q_first + r];
-    unsigned min_d = threshold, second = threshold, min_j = 0u;
+    // pin the operands here: otherwise the waits for these loads are placed at their first use inside the tile loop
+#pragma unroll
+    for (int b = 0; b < MM_NB; ++b)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bq[b][s]));
+    unsigned pq[MM_NB], min_d[MM_NB], second[MM_NB], min_j[MM_NB];
     // A chunk starts without knowing anything about its queries, and while `second` is still large nearly every tile
-    // contains a row that beats it for one of the wave's queries (the slow path below then runs for the whole wave:
-    // a third of the kernel's time with 16 chunks).  All workgroups that scan for a query therefore share an upper
-    // bound of its final second-best distance: bound[q] only ever receives some chunk's current `second`, which is
-    // never below the final value, so rows with a distance ABOVE the bound cannot appear in the final (min, second,
-    // argmin) — rows AT the bound still take the exact path (they can decide a tie) — and skipping them leaves the
-    // merged result identical.  The bound is re-read every fourth tile past the L1 (agent-scope atomic load) and the
-    // value is used four tiles later, so the load is never waited for.
-    unsigned limit = threshold;  // min(second, bound[q] + 1): a tile whose best distance is >= limit changes nothing that matters
-    unsigned b_seen = threshold;  // bound[q] as last read (consumed four tiles after the load was issued: never waited for)
+    // contains a row that beats it for one of the wave's queries (the slow path below then runs for the whole wave).
+    // All workgroups that scan for a query therefore share an upper bound of its final second-best distance: bound[q]
+    // only ever receives some chunk's current `second`, which is never below the final value, so rows with a distance
+    // ABOVE the bound cannot appear in the final (min, second, argmin) — rows AT the bound still take the exact path
+    // (they can decide a tie) — and skipping them leaves the merged result identical.  The bound is re-read every
+    // fourth tile past the L1 (agent-scope atomic load) and the value is used four tiles later: never waited for.
+    unsigned limit[MM_NB];   // min(second, bound[q] + 1): a tile whose best distance is >= limit changes nothing that matters
+    unsigned b_seen[MM_NB];  // bound[q] as last read
+#pragma unroll
+    for (int b = 0; b < MM_NB; ++b) {
+        pq[b] = qpop[q_first + 32 * b + r];
+        min_d[b] = second[b] = limit[b] = b_seen[b] = threshold;
+        min_j[b] = 0u;
+    }
 
     unsigned t_begin, t_end, row0 = 0u, record = blockIdx.y;
     if (table) {  // one train set per chunk
@@ -148,16 +163,28 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
         t_begin = blockIdx.y * chunk_tiles;
         t_end = min(tiles_total, t_begin + chunk_tiles);
     }
-    // Staging: the next LDS tile is fetched one 32-row part at a time (one 16-byte piece per thread and part, 32
-    // pieces per row): part p is requested before the MFMA chain of sub-tile p of the current tile and handed to the
+    // Staging: the next LDS tile is fetched one 32-row part at a time (32 rows x 32 sixteen-byte pieces = 1024 pieces,
+    // two per thread): part p is requested before the MFMA chain of sub-tile p of the current tile and handed to the
     // other LDS buffer after that sub-tile's epilogue, so one register stage serves MM_SUB parts per barrier.
-    static_assert(32 * KB / 16 == MM_NT, "one 16-byte piece per thread and 32-row part");
-    const unsigned st_src = (tid >> 5) * KB + (tid & 31u) * 16u, st_dst = (tid >> 5) * MM_PITCH + (tid & 31u) * 16u;
-    uint4 stage;
+    constexpr int PIECES = 32 * KB / 16 / MM_NT;
+    static_assert(PIECES * MM_NT * 16 == 32 * KB, "whole pieces per thread and 32-row part");
+    unsigned st_src[PIECES], st_dst[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const unsigned idx = tid + (unsigned)p * MM_NT;
+        st_src[p] = (idx >> 5) * KB + (idx & 31u) * 16u;
+        st_dst[p] = (idx >> 5) * MM_PITCH + (idx & 31u) * 16u;
+    }
+    uint4 stage[PIECES];
     auto fetch = [&](unsigned tile, int part) {
-        stage = *reinterpret_cast<const uint4*>(t8 + ((size_t)tile * MM_TR + 32u * part) * KB + st_src);
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            stage[p] = *reinterpret_cast<const uint4*>(t8 + ((size_t)tile * MM_TR + 32u * part) * KB + st_src[p]);
     };
-    auto commit = [&](int buf, int part) { *reinterpret_cast<uint4*>(&s_tile[buf][32 * part * MM_PITCH + st_dst]) = stage; };
+    auto commit = [&](int buf, int part) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) *reinterpret_cast<uint4*>(&s_tile[buf][32 * part * MM_PITCH + st_dst[p]]) = stage[p];
+    };
     if (t_begin < t_end) {
 #pragma unroll
         for (int part = 0; part < MM_SUB; ++part) {
@@ -171,70 +198,85 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
         const bool more = tile + 1 < t_end;
         const bool partial = (tile + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
         if (((tile - t_begin) & 3u) == 0u) {  // use the value requested four tiles ago, request the next one
-            limit = min(limit, min(second, b_seen < 0xffffffffu ? b_seen + 1u : b_seen));
-            b_seen = __hip_atomic_load(bound + q_first + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int b = 0; b < MM_NB; ++b) {
+                limit[b] = min(limit[b], min(second[b], b_seen[b] < 0xffffffffu ? b_seen[b] + 1u : b_seen[b]));
+                b_seen[b] = __hip_atomic_load(bound + q_first + 32 * b + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
 #pragma unroll
         for (int sub = 0; sub < MM_SUB; ++sub) {
             if (more) fetch(tile + 1, sub);  // in flight under the MFMA chain below
-            v16i acc;
+            v16i acc[MM_NB];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            for (int b = 0; b < MM_NB; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][i] = 0;
             const uint8_t* arow = &s_tile[buf][(32 * sub + r) * MM_PITCH + 16 * h];
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(arow + 32 * s), bq[s], acc, 0, 0, 0);
-            // schedule: keep AKZ_MM_AHEAD operand reads in flight ahead of the MFMA that consumes them (an LDS read
+            for (int s = 0; s < 16; ++s) {
+                const v4i a = *reinterpret_cast<const v4i*>(arow + 32 * s);
+#pragma unroll
+                for (int b = 0; b < MM_NB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[b][s], acc[b], 0, 0, 0);
+            }
+            // schedule: keep AKZ_MM_AHEAD operand reads in flight ahead of the MFMAs that consume them (an LDS read
             // takes ~100 cycles, an MFMA 32; left alone the scheduler issues read, wait, MFMA, read, wait, ...)
 #if AKZ_MM_AHEAD > 0
             __builtin_amdgcn_sched_group_barrier(0x100, AKZ_MM_AHEAD, 0);
 #pragma unroll
             for (int s = 0; s < 16 - AKZ_MM_AHEAD; ++s) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MM_NB, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, AKZ_MM_AHEAD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, AKZ_MM_AHEAD * MM_NB, 0);
 #endif
-            // distances of this lane's 16 train rows of the sub-tile (ascending index) to its query
+            // distances of this lane's 16 train rows of the sub-tile (ascending index) to its queries
             const unsigned j0 = tile * MM_TR - row0 + 32 * sub + 4 * h;  // row index inside the set
-            // acc[i] = 2 <a, b> - |a| (the row counts ride in the product), so hamming = |b| - acc[i]: the smallest
-            // distance of the 16 rows is pq minus the largest accumulator
-            int top = acc[0];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) top = max(top, acc[i]);
-            if (partial || (int)pq - top < (int)limit) {  // rare: see `limit`
-                // exact update from the tile's two smallest distances and the first row of the smallest: keys
-                // (acc << 4 | 15 - i) order by accumulator, then by ascending row; top two keys by max3 / med3
-                int key[16];
+            for (int b = 0; b < MM_NB; ++b) {
+                // acc[i] = 2 <a, b> - |a| (the row counts ride in the product), so hamming = |b| - acc[i]: the smallest
+                // distance of the 16 rows is pq minus the largest accumulator
+                int top = acc[b][0];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
-                    key[i] = (partial && j0 + row >= n1) ? INT_MIN : (acc[i] << 4) + (15 - i);  // padding rows never match
-                }
-                int M = INT_MIN, S = INT_MIN;
+                for (int i = 1; i < 16; ++i) top = max(top, acc[b][i]);
+                #ifdef AKZ_MM_NOSLOW
+                if (partial) {
+#else
+                if (partial || (int)pq[b] - top < (int)limit[b]) {  // rare: see `limit`
+#endif
+                    // exact update from the tile's two smallest distances and the first row of the smallest: keys
+                    // (acc << 4 | 15 - i) order by accumulator, then by ascending row; top two keys by max3 / med3
+                    int key[16];
 #pragma unroll
-                for (int g = 0; g < 5; ++g) {  // five groups of three keys, then the sixteenth
-                    const int a = key[3 * g], b = key[3 * g + 1], c = key[3 * g + 2];
-                    const int gm = max(a, max(b, c)), gs = max(min(a, b), min(max(a, b), c));  // largest, median
-                    S = max(min(M, gm), max(S, gs));
-                    M = max(M, gm);
-                }
-                S = max(S, min(M, key[15]));
-                M = max(M, key[15]);
-                const int i1 = 15 - (M & 15);
-                const unsigned tb = M == INT_MIN ? 0xffffffffu : (unsigned)((int)pq - (M >> 4));
-                const unsigned ts = S == INT_MIN ? 0xffffffffu : (unsigned)((int)pq - (S >> 4));
-                const unsigned before = second;
-                if (tb < min_d) {  // rows of a lane arrive in ascending order: the sequential rule (:41-49) folded per tile
-                    second = min(min_d, ts);
-                    min_d = tb;
-                    min_j = j0 + (unsigned)((i1 & 3) + 8 * (i1 >> 2));
-                } else {
-                    second = min(second, tb);
-                }
-                if (second < before) {
-                    atomicMin(bound + q_first + r, second);
-                    limit = min(limit, second);
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
+                        key[i] = (partial && j0 + row >= n1) ? INT_MIN : (acc[b][i] << 4) + (15 - i);  // padding rows never match
+                    }
+                    int M = INT_MIN, S = INT_MIN;
+#pragma unroll
+                    for (int g = 0; g < 5; ++g) {  // five groups of three keys, then the sixteenth
+                        const int ka = key[3 * g], kb = key[3 * g + 1], kc = key[3 * g + 2];
+                        const int gm = max(ka, max(kb, kc)), gs = max(min(ka, kb), min(max(ka, kb), kc));  // largest, median
+                        S = max(min(M, gm), max(S, gs));
+                        M = max(M, gm);
+                    }
+                    S = max(S, min(M, key[15]));
+                    M = max(M, key[15]);
+                    const int i1 = 15 - (M & 15);
+                    const unsigned tb = M == INT_MIN ? 0xffffffffu : (unsigned)((int)pq[b] - (M >> 4));
+                    const unsigned ts = S == INT_MIN ? 0xffffffffu : (unsigned)((int)pq[b] - (S >> 4));
+                    const unsigned before = second[b];
+                    if (tb < min_d[b]) {  // rows of a lane arrive in ascending order: the sequential rule (:41-49) folded per tile
+                        second[b] = min(min_d[b], ts);
+                        min_d[b] = tb;
+                        min_j[b] = j0 + (unsigned)((i1 & 3) + 8 * (i1 >> 2));
+                    } else {
+                        second[b] = min(second[b], tb);
+                    }
+                    if (second[b] < before) {
+                        atomicMin(bound + q_first + 32 * b + r, second[b]);
+                        limit[b] = min(limit[b], second[b]);
+                    }
                 }
             }
             if (more) commit(buf ^ 1, sub);
@@ -242,10 +284,11 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
         __syncthreads();
     }
     // the two lanes of a column hold disjoint row sets: order-free merge, then one record per live query
-    {
-        const unsigned o_min = __shfl_xor(min_d, 32, 64), o_sec = __shfl_xor(second, 32, 64);
-        const unsigned o_j = __shfl_xor(min_j, 32, 64);
-        unsigned m = min_d, s2 = second, j = min_j;
+#pragma unroll
+    for (int b = 0; b < MM_NB; ++b) {
+        const unsigned o_min = __shfl_xor(min_d[b], 32, 64), o_sec = __shfl_xor(second[b], 32, 64);
+        const unsigned o_j = __shfl_xor(min_j[b], 32, 64);
+        unsigned m = min_d[b], s2 = second[b], j = min_j[b];
         if (o_min < m || (o_min == m && o_min < threshold && o_j < j)) {  // the other lane holds the winner
             s2 = min(o_sec, m);
             m = o_min;
@@ -253,7 +296,7 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
         } else {
             s2 = min(s2, o_min);
         }
-        const unsigned q = q_first + r;
+        const unsigned q = q_first + 32 * b + r;
         if (h == 0 && q < n0) {
             MatchRec rec;
             rec.min_d = m; rec.second_d = s2; rec.min_j = j; rec._pad = 0;

@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "akz_internal.hpp"
 
@@ -54,6 +55,7 @@ constexpr int CBUF = 32;         // extrema buffered per wave before one atomic 
 
 struct MarchGrid {
     int nstrips, nbands, band_rows;  // band_rows: interior rows per band
+    int edge_rows;                   // level march: rows of the first band (the last one takes what is left); 0: band_rows
     int total;                       // workgroups with work; the grid is rounded up to a multiple of 8
 };
 // Workgroup i runs on XCD i mod 8.  Numbering the (image, band, strip) cells so that each XCD walks a CONTIGUOUS eighth
@@ -425,6 +427,7 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
 struct LevelTaus {
     float half_tau[4];  // 0.5f * (tau as f32) per fused step (nonlinear_diffusion.rs:67)
 };
+__device__ __forceinline__ f2 lds2(const float* p) { return f2{p[0], p[1]}; }  // two neighbouring floats, any alignment
 __device__ __forceinline__ f2 tap3(f2 a, f2 b, f2 c, float k0, float k1, float k2) {
     const f2 z = {0.0f, 0.0f};
     return ((z + k0 * a) + k1 * b) + k2 * c;
@@ -459,7 +462,10 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     const int img = __builtin_amdgcn_readfirstlane(cell / per);
     const int rem = cell - img * per;
     const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
-    const int cs = 1 + band * g.band_rows, ce = min(cs + g.band_rows, h - 1);  // interior rows of Lsmooth / Lflow
+    // interior rows of Lsmooth / Lflow: the first band has edge_rows rows, the last one what is left (bands at the image's
+    // first and last rows run the loop with the border cases, which is slower per row, and get fewer rows for it)
+    const int cs = 1 + (band == 0 ? 0 : g.edge_rows + (band - 1) * g.band_rows);
+    const int ce = band == g.nbands - 1 ? h - 1 : min(cs + (band == 0 ? g.edge_rows : g.band_rows), h - 1);
     if (cs >= ce) return;
     const int lt0 = cs == 1 ? 0 : cs, lt1 = ce == h - 1 ? h : ce;  // rows of Lt / Lstep (no filled border there)
 
@@ -471,6 +477,7 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     const int i0 = PAD + clampi(clampi(C.x0, 1, w - 2) - X0, 0, MW - 1) - 1;
     const int i1 = PAD + clampi(clampi(C.x0 + 1, 1, w - 2) - X0, 0, MW - 1) - 1;
     const int wi = PAD + p0;
+    const bool edge_h = __ballot(i0 != wi - 1 || i1 != wi) != 0ull;  // wave-uniform: some lane reads at a clamped column
     // FED: which x-neighbours exist (only threads at column 0 / w-1 have one missing)
     const bool hxn0 = C.x0 > 0, hxp0 = C.x0 + 1 < w, hxn1 = C.x0 + 1 > 0, hxp1 = C.x0 + 2 < w;
     // wave-uniform, so that the selects below are a scalar branch that 99 % of the waves never take
@@ -513,6 +520,8 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
 
     // The row loop runs whole groups of 8 (static ring indices); the up to 7 rows past T store nothing: their Lsmooth,
     // Lflow and Lt rows lie past ce / lt1.
+    auto rows = [&](auto mid_tag) {
+    constexpr bool MID = decltype(mid_tag)::value;
     for (int t0 = 0; t0 < T; t0 += 8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -531,53 +540,65 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                 __syncthreads();
                 // ---- gaussian_blur(Lt, 1.0): H pass of row v, V pass -> Lsmooth row u = v-1 ----
                 f2 gh = gh_c;  // below row h-2 the filled rows repeat it
-                if (v <= h - 2) {
-                    const float* r0 = buf + i0;
-                    const float* r1 = buf + i1;
-                    const f2 a = {r0[0], r1[0]}, b = {r0[1], r1[1]}, c = {r0[2], r1[2]};
+                if (MID || v <= h - 2) {
+                    f2 a, b, c;
+                    if (!rare(edge_h)) {  // the neighbours as two (odd-aligned) pairs, the centre from registers
+                        a = lds2(buf + wi - 1); b = LP[k & 7]; c = lds2(buf + wi + 1);
+                    } else {
+                        const float* r0 = buf + i0;
+                        const float* r1 = buf + i1;
+                        a = f2{r0[0], r1[0]}; b = f2{r0[1], r1[1]}; c = f2{r0[2], r1[2]};
+                    }
                     gh = tap3(a, b, c, g0, g1, g2);
                 }
                 gh_c = gh;
                 GH[k & 3] = gh;
-                if (rare(v == 1)) GH[(k - 1) & 3] = gh;  // filled row 0 is row 1
+                if (!MID && rare(v == 1)) GH[(k - 1) & 3] = gh;  // filled row 0 is row 1
                 const int u = v - 1;
                 f2 ls_n = ls_c;
-                if (u <= h - 2) ls_n = tap3(GH[(k - 2) & 3], GH[(k - 1) & 3], GH[k & 3], g0, g1, g2);
+                if (MID || u <= h - 2) ls_n = tap3(GH[(k - 2) & 3], GH[(k - 1) & 3], GH[k & 3], g0, g1, g2);
                 {
                     const f2 o[1] = {ls_n};
-                    store_filled<1, 1, ODDW>(o_ls, C, w, h, u, u >= cs && u < ce, o);
+                    if (MID) store_rows<1, ODDW>(o_ls, u, w, u >= cs && u < ce, C, o);
+                    else store_filled<1, 1, ODDW>(o_ls, C, w, h, u, u >= cs && u < ce, o);
                 }
                 // ---- Scharr pair at scale 1 of Lsmooth row u-1 (in LDS), V pass -> Lx1, Ly1 -> Lflow row c = v-3 ----
                 {
-                    const float* r0 = buf + ROW + i0;
-                    const float* r1 = buf + ROW + i1;
-                    const f2 a = {r0[0], r1[0]}, b = {r0[1], r1[1]}, c = {r0[2], r1[2]};
+                    f2 a, b, c;
+                    if (!rare(edge_h)) {
+                        a = lds2(buf + ROW + wi - 1); b = ls_c; c = lds2(buf + ROW + wi + 1);
+                    } else {
+                        const float* r0 = buf + ROW + i0;
+                        const float* r1 = buf + ROW + i1;
+                        a = f2{r0[0], r1[0]}; b = f2{r0[1], r1[1]}; c = f2{r0[2], r1[2]};
+                    }
                     HM[k & 3] = tap_main(a, b, c, kn, kwn);
                     HO[k & 3] = tap_off(a, c);
                 }
-                if (rare(u - 1 == 1)) {  // filled row 0 is row 1
+                if (!MID && rare(u - 1 == 1)) {  // filled row 0 is row 1
                     HM[(k - 1) & 3] = HM[k & 3];
                     HO[(k - 1) & 3] = HO[k & 3];
                 }
                 const int c = v - 3;
                 f2 lf_n = lf_c;
-                if (c <= h - 2) {
+                if (MID || c <= h - 2) {
                     const f2 lx1 = tap_off(HM[(k - 2) & 3], HM[k & 3]);
                     const f2 ly1 = tap_main(HO[(k - 2) & 3], HO[(k - 1) & 3], HO[k & 3], kn, kwn);
                     lf_n = f2{pm_g2_px(lx1.x, ly1.x, inverse_k), pm_g2_px(lx1.y, ly1.y, inverse_k)};
                 }
                 CR[(k - 3) & 7] = lf_n;
-                if (rare(c == 1)) CR[(k - 4) & 7] = lf_n;  // filled row 0 is row 1
+                if (!MID && rare(c == 1)) CR[(k - 4) & 7] = lf_n;  // filled row 0 is row 1
                 {
                     const f2 o[1] = {lf_n};
-                    store_filled<1, 1, ODDW>(o_lf, C, w, h, c, c >= cs && c < ce, o);
+                    if (MID) store_rows<1, ODDW>(o_lf, c, w, c >= cs && c < ce, C, o);
+                    else store_filled<1, 1, ODDW>(o_lf, C, w, h, c, c >= cs && c < ce, o);
                 }
                 // ---- x-pair sums of the Lflow row the first FED stage works on (row v-5, in LDS) ----
                 {
                     const float* cr = buf + 2 * ROW + wi;
                     const f2 cc = CR[(k - 5) & 7];
-                    SXW[k & 3] = f2{cr[-1] + cc.x, cc.x + cc.y};
-                    SXE[k & 3] = f2{cc.x + cc.y, cc.y + cr[2]};
+                    SXW[k & 3] = lds2(cr - 1) + cc;  // {c(x0-1) + c(x0), c(x0) + c(x0+1)}
+                    SXE[k & 3] = cc + lds2(cr + 1);  // {c(x0) + c(x0+1), c(x0+1) + c(x0+2)}
                 }
                 // ---- FED stages: L^s row r = v-4-s ----
                 f2 lnew = zero, st = zero;
@@ -592,7 +613,7 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                         Lm = W[s - 2][(k - 2) & 3]; Lc = W[s - 2][(k - 1) & 3]; Lp = lnew;
                     }
                     const float* lr = buf + (2 + s) * ROW + wi;  // L^(s-1) row r with its neighbours
-                    const f2 Lw = {lr[-1], Lc.x}, Le = {Lc.y, lr[2]};
+                    const f2 Lw = lds2(lr - 1), Le = lds2(lr + 1);  // {L(x0-1), L(x0)}, {L(x0+1), L(x0+2)}
                     const f2 cN = CR[(k - 5 - s) & 7], cC = CR[(k - 4 - s) & 7], cS = CR[(k - 3 - s) & 7];
                     const f2 SU = cN + cC, SV = cC + cS;
                     const f2 XFW = SXW[(k - (s - 1)) & 3] * (Lc - Lw);  // x_neg: (c_W + c) * (L - L_W)
@@ -605,9 +626,9 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                         tx.y = hxp1 ? (hxn1 ? XFE.y - XFW.y : XFE.y) : -XFW.y;
                     }
                     f2 tt;
-                    if (r + 1 < h) {                       // workgroup-uniform
+                    if (MID || r + 1 < h) {                // workgroup-uniform
                         tt = tx + SV * (Lp - Lc);          // + y_pos
-                        if (r > 0) tt = tt - SU * (Lc - Lm);  // - y_neg
+                        if (MID || r > 0) tt = tt - SU * (Lc - Lm);  // - y_neg
                     } else {
                         tt = tx + SU * (Lm - Lc);          // last row: y_pos taken towards y-1 (:104-119)
                     }
@@ -619,7 +640,7 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                     {
                         f2 o[KEEPSTEP ? 2 : 1];
                         o[0] = lnew;
-                        if (KEEPSTEP) o[1] = st;
+                        if constexpr (KEEPSTEP) o[1] = st;
                         const f2(&oc)[KEEPSTEP ? 2 : 1] = o;
                         store_rows<KEEPSTEP ? 2 : 1, ODDW>(o_ltc, r, w, r >= lt0 && r < lt1, C, oc);
                     }
@@ -629,6 +650,13 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
             }
         }
     }
+    };
+    // Bands that stay clear of the image's first and last rows (every row they touch, the up to 7 surplus rows included)
+    // run a copy of the loop without the border cases: no held or back-filled rows, every diffusion row has both y
+    // neighbours.
+    const int v_last = v0 + ((T + 7) & ~7) - 1;
+    if (v0 >= N + 5 && v_last <= h - 2) rows(std::true_type{});
+    else rows(std::false_type{});
 }
 
 inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid) {
@@ -652,8 +680,27 @@ inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid
     const long cols = (long)n * g.nstrips;
     const long want = ((long)cus * fill + cols - 1) / cols;
     long nb = std::max<long>(1, std::min<long>(want, std::max(1, rows / min_rows)));
-    g.band_rows = (int)((rows + nb - 1) / nb);
-    g.nbands = (rows + g.band_rows - 1) / g.band_rows;
+    static int edge_pct = 0;
+    if (!edge_pct) {
+        const char* e = getenv("AKZ_LEVEL_EDGE");  // rows of an edge band in percent of a middle band's
+        edge_pct = e ? std::min(100, std::max(25, atoi(e))) : 75;
+    }
+    if (nb >= 3) {
+        // 2 edge bands of rho * m rows + (nb - 2) middle bands of m rows = rows
+        const double m = (double)rows / ((double)(nb - 2) + 2.0 * edge_pct / 100.0);
+        g.band_rows = std::max(1, (int)(m + 0.999));
+        g.edge_rows = std::max(1, (int)((rows - (long)(nb - 2) * g.band_rows) / 2));
+        g.nbands = (int)nb;
+        if (g.edge_rows + (long)(nb - 2) * g.band_rows >= rows) {  // degenerate: uniform bands
+            g.band_rows = (int)((rows + nb - 1) / nb);
+            g.edge_rows = g.band_rows;
+            g.nbands = (rows + g.band_rows - 1) / g.band_rows;
+        }
+    } else {
+        g.band_rows = (int)((rows + nb - 1) / nb);
+        g.edge_rows = g.band_rows;
+        g.nbands = (rows + g.band_rows - 1) / g.band_rows;
+    }
     g.total = (int)(cols * g.nbands);
     *grid = dim3((unsigned)((g.total + 7) / 8 * 8));
     return g;
@@ -685,6 +732,7 @@ inline MarchGrid plan_march(uint32_t w, uint32_t h, uint32_t n, int S, dim3* gri
     const long want = ((long)cus * fill + cols - 1) / cols;  // bands needed to fill the chip
     long nb = std::max<long>(1, std::min<long>(want, std::max(1, rows / min_rows)));
     g.band_rows = (int)((rows + nb - 1) / nb);
+    g.edge_rows = g.band_rows;
     g.nbands = (rows + g.band_rows - 1) / g.band_rows;
     g.total = (int)(cols * g.nbands);
     *grid = dim3((unsigned)((g.total + 7) / 8 * 8));
@@ -749,9 +797,6 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
     const float kn = m.wgt[0], kwn = m.wgt[1];
     const float quat = (float)(sigma * sigma * sigma * sigma);
     const bool keep = lxx && lyy && lxy;
-#ifdef AKZ_EXP_NO_NMS  // timing experiment only: no candidates come out
-    d_cand = nullptr;
-#endif
     MarchNms na{level, thr, 0, -1, 0, -1, d_cand, cap, d_count};
     if (d_cand) {
         admissible_range(w, border_m, &na.xlo, &na.xhi);

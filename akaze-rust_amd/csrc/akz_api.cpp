@@ -77,6 +77,7 @@ struct akz_ctx {
     bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
+    hipStream_t coarse = nullptr;       // the coarse octaves' chain (diffusion + detectors), next to the fine detectors
     // stage profiling (akz_ctx_set_profiling)
     uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
     int prep_mode = 2;  // level preparation: 0 LDS-tiled, 1 streaming, 2 auto (fused with the first diffusion steps for large launches), 3 fused wherever supported
@@ -151,6 +152,7 @@ static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p) {
         AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->aux) AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
+        if (c->coarse) AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
         AKZ_HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -276,6 +278,11 @@ int akz_ctx_destroy(akz_ctx* c) {
     if (c->aux) {
         (void)hipStreamSynchronize(c->aux);
         (void)hipStreamDestroy(c->aux);
+    }
+    if (c->coarse) {
+        (void)hipStreamSynchronize(c->coarse);
+        (void)hipStreamDestroy(c->coarse);
+        c->coarse = nullptr;
     }
     for (auto& s : c->slab_pool) (void)hipFree(s.second);
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -762,6 +769,7 @@ static void slab_release(akz_ctx* c, void* p, size_t bytes) {
     if (c->slab_pool.size() >= 8) {
         (void)hipStreamSynchronize(c->stream);
         if (c->aux) (void)hipStreamSynchronize(c->aux);
+        if (c->coarse) (void)hipStreamSynchronize(c->coarse);
         (void)hipFree(c->slab_pool.front().second);
         c->slab_pool.erase(c->slab_pool.begin());
     }
@@ -894,7 +902,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // One append list for the whole batch (image id stored per candidate): a single D2H later.  The detector of
     // level l needs only Lsmooth_l; its launches follow the whole diffusion chain on the same stream (running them on
     // a side stream next to the diffusion was +3 % with the round-1 kernels and is -15 % with the column march, which
-    // saturates the store path on its own: removed).
+    // saturates the store path on its own; with only the half-resolution octave's detectors on the side stream it is
+    // still -5 %: removed).
     const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint, 16u),
                                                       0x7fffffffull / sizeof(Candidate));
     AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
@@ -948,17 +957,49 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         return e ? std::atoi(e) : -1;
     }();
     bool gate_recorded = false;
-    static const bool det_early = [] {
-        const char* e = std::getenv("AKZ_DET_EARLY");
-        return e ? std::atoi(e) != 0 : false;
+    // Fork.  From octave `fork_octave` on the levels are small: their launches (diffusion, preparation, detectors) do not
+    // fill the chip and are bound by launch-to-launch latency -- about 1 ms of the step for 8 % of its pixels.  That
+    // chain moves to a second stream when octave fork_octave - 1 is finished, and the main stream goes straight to the
+    // detectors of the fine octaves (bandwidth-bound, 2.2 ms): the two run side by side and join before the candidate
+    // list is read.  (Running two BIG kernels side by side is a loss -- see above -- so the fork is at octave 2.)
+    static const int fork_octave = [] {
+        const char* e = std::getenv("AKZ_FORK_OCTAVE");  // 0: no fork
+        return e ? std::atoi(e) : 2;
     }();
-    std::vector<char> det_launched(L, 0);
+    // (a lone 1080p frame is a chain of dependent launches either way and only pays for the two events: measured
+    // 0.596 -> 0.625 ms per streamed frame; batches from 8 Mpx on fork)
+    static const uint64_t fork_min_px = [] {
+        const char* e = std::getenv("AKZ_FORK_MIN_PX");
+        return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
+    }();
+    hipStream_t ls = s;  // the stream the level loop enqueues on
+    struct StreamRestore {  // the helpers (fed_impl, StageTimer, ...) enqueue on c->stream
+        akz_ctx* c;
+        hipStream_t main;
+        ~StreamRestore() { c->stream = main; }
+    } stream_restore{c, s};
+    size_t fork_level = L;  // first level of the coarse chain
     for (size_t i = 1; i < L; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
+        if (fork_octave > 0 && fork_level == L && (int)lv.octave >= fork_octave && (uint64_t)w * h * n >= fork_min_px) {
+            if (!gate_recorded) {  // the previous batch's keypoint kernels may start here too
+                if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
+                AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+                gate_recorded = true;
+            }
+            if (!c->coarse) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->coarse, hipStreamNonBlocking));
+            hipEvent_t fine_done = StageTimer::get(c);
+            AKZ_HIP_TRY(hipEventRecord(fine_done, s));
+            AKZ_HIP_TRY(hipStreamWaitEvent(c->coarse, fine_done, 0));
+            c->ev_pool.push_back(fine_done);
+            fork_level = i;
+            ls = c->coarse;
+            c->stream = c->coarse;
+        }
         if (kp_gate_octave > 0 && !gate_recorded && (int)lv.octave >= kp_gate_octave) {
             if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
-            AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+            AKZ_HIP_TRY(hipEventRecord(c->fed_done, ls));
             gate_recorded = true;
         }
         float* A = P(i, AKZ_LT);
@@ -991,14 +1032,14 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             if (half) {
                 StageTimer st(c, AKZ_ST_PREP);
                 float* hb = d1 == A ? B : A;
-                launch::half_size(s, P(i - 1, AKZ_LT), hb, pv.w, pv.h, n);
+                launch::half_size(ls, P(i - 1, AKZ_LT), hb, pv.w, pv.h, n);
                 level_in = hb;
             }
             float ht[4];
             for (uint32_t j = 0; j < n1; ++j) ht[j] = 0.5f * (float)lv.tau[j];
             {
                 StageTimer st(c, AKZ_ST_FED);
-                launch::level_march(s, level_in, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), d1,
+                launch::level_march(ls, level_in, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), d1,
                                     (rem == 0 && keep_all) ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n, g1.data(), r->d_k,
                                     lv.octave, ht, n1);
                 if (c->profiling) {
@@ -1010,8 +1051,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                     AKZ_TRY(fed_impl(c, d1, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
                                      lv.tau.data() + n1, rem));
             }
-            if (det_early && detector_family(c, lv.det_sigma, lv.w, lv.h, n, border_margin(lv, cfg), keep_all) == 5)
-                det_launched[i] = detector_one_pass(i, s);
             AKZ_HIP_TRY(hipGetLastError());
             continue;
         }
@@ -1023,13 +1062,13 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             const bool stream_prep = c->prep_mode != 0 && launch::prep_stream_supported(lv.w, lv.h) &&
                                      (c->prep_mode == 1 || (c->prep_mode >= 2 && !half && (uint64_t)lv.w * lv.h * n >= c->stream_min_px));
             if (stream_prep)
-                launch::prep_stream(s, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
+                launch::prep_stream(ls, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
                                     pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
             else
-                launch::prep_fused(s, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
+                launch::prep_fused(ls, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
                                    pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
             float* lstep0 = keep_all ? P(i, AKZ_LSTEP) : nullptr;
-            if (lstep0 && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep0, 0, plane_bytes(lv.w, lv.h, n), s));
+            if (lstep0 && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep0, 0, plane_bytes(lv.w, lv.h, n), ls));
         }
         {
             StageTimer st(c, AKZ_ST_FED);
@@ -1043,43 +1082,57 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.
     if (!gate_recorded) {
         if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
-        AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+        AKZ_HIP_TRY(hipEventRecord(c->fed_done, ls));
     }
 
-    // ---- detector levels that were not overlapped (no side stream, or kernel sizes without a fused form) ----
+    // ---- detectors: levels [lo, hi) on stream st (c->stream is st while this runs) ----
     // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group
-    std::map<uint32_t, std::vector<launch::DetLevelDesc>> sets;
-    for (size_t l = 0; l < L; ++l) {
-        const LevelPlan& lv = plan[l];
-        const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
-        if (detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all) == 4) {
-            sets[lv.det_sigma].push_back(launch::DetLevelDesc{P(l, AKZ_LSMOOTH), P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
-                                                             P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h,
-                                                             (uint32_t)l, bm});
-            continue;
-        }
-        if (det_launched[l] || detector_one_pass(l, s)) continue;
-        {
-            StageTimer st(c, AKZ_ST_DETECTOR);
-            AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
-                                  P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n));
-        }
-        StageTimer st(c, AKZ_ST_NMS);
-        launch::nms(s, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l, thr, bm, d_cand, cap,
-                    d_count);
-    }
-    for (auto& kv : sets) {
-        const uint32_t maxn = launch::detector_tiled_set_max();
-        for (size_t i = 0; i < kv.second.size(); i += maxn) {
-            StageTimer st(c, AKZ_ST_DETECTOR);
-            if (c->profiling) {
-                c->prof.det_launches += 1;
-                for (size_t j = i; j < std::min(kv.second.size(), i + maxn); ++j)
-                    c->prof.det_px += (uint64_t)kv.second[j].w * kv.second[j].h * n;
+    auto detectors = [&](size_t lo, size_t hi, hipStream_t st_) -> int {
+        std::map<uint32_t, std::vector<launch::DetLevelDesc>> sets;
+        for (size_t l = lo; l < hi; ++l) {
+            const LevelPlan& lv = plan[l];
+            const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
+            if (detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all) == 4) {
+                sets[lv.det_sigma].push_back(launch::DetLevelDesc{P(l, AKZ_LSMOOTH), P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
+                                                                 P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h,
+                                                                 (uint32_t)l, bm});
+                continue;
             }
-            launch::detector_tiled_set(s, kv.first, kv.second.data() + i, (uint32_t)std::min<size_t>(maxn, kv.second.size() - i), n,
-                                       (float)cfg.detector_threshold, d_cand, cap, d_count);
+            if (detector_one_pass(l, st_)) continue;
+            {
+                StageTimer st(c, AKZ_ST_DETECTOR);
+                AKZ_TRY(detector_impl(c, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX),
+                                      P(l, AKZ_LYY), P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n));
+            }
+            StageTimer st(c, AKZ_ST_NMS);
+            launch::nms(st_, P(l, AKZ_LDET), lv.w, lv.h, n, (uint64_t)lv.w * lv.h, (uint32_t)l, thr, bm, d_cand, cap,
+                        d_count);
         }
+        for (auto& kv : sets) {
+            const uint32_t maxn = launch::detector_tiled_set_max();
+            for (size_t i = 0; i < kv.second.size(); i += maxn) {
+                StageTimer st(c, AKZ_ST_DETECTOR, st_);
+                if (c->profiling) {
+                    c->prof.det_launches += 1;
+                    for (size_t j = i; j < std::min(kv.second.size(), i + maxn); ++j)
+                        c->prof.det_px += (uint64_t)kv.second[j].w * kv.second[j].h * n;
+                }
+                launch::detector_tiled_set(st_, kv.first, kv.second.data() + i, (uint32_t)std::min<size_t>(maxn, kv.second.size() - i),
+                                           n, (float)cfg.detector_threshold, d_cand, cap, d_count);
+            }
+        }
+        return AKZ_OK;
+    };
+    if (fork_level < L) {  // the coarse chain ends with its own detectors; then the main stream takes the fine ones and joins
+        AKZ_TRY(detectors(fork_level, L, c->coarse));
+        hipEvent_t coarse_done = StageTimer::get(c);
+        AKZ_HIP_TRY(hipEventRecord(coarse_done, c->coarse));
+        c->stream = s;
+        AKZ_TRY(detectors(0, fork_level, s));
+        AKZ_HIP_TRY(hipStreamWaitEvent(s, coarse_done, 0));
+        c->ev_pool.push_back(coarse_done);
+    } else {
+        AKZ_TRY(detectors(0, L, s));
     }
     AKZ_HIP_TRY(hipGetLastError());
     job->nms_done = StageTimer::get(c);

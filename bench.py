@@ -22,6 +22,8 @@ Extra objects on that line:
                 that traffic / launch time / peak, i.e. real DRAM utilisation.  roofline_2 = the other of the two.
   fed_standalone  the FED kernel alone (nothing else on the chip): on one 3840x2160 plane (north-star point; its
                 100 MB working set sits in the Infinity Cache) and on a 32 x 1920x1080 level (an HBM number).
+  detector_standalone  the detector kernel alone on a 32 x 1920x1080 level, four plane sets in turn so that its input
+                comes from HBM, not from the Infinity Cache; roofline.standalone_frac repeats its sigma_size 3 figure.
   stage_roofline  algorithmic HBM bytes of every GPU stage / its time in one un-pipelined, fully profiled step.
   self_check    untimed: frames of the timed batch extracted one by one give the same keypoints and descriptor bytes.
   single_frame  BASELINE configs[1] taken literally — one 1920x1080 frame per extract_features call.
@@ -497,7 +499,10 @@ def main_rank(args):
     roof_det = roof(A.lib().akz_detector_kernel_name().decode(), prof["detector"], prof["det_launches"],
                     float(det_bpp) * prof["det_px"],
                     f"all detector launches of the timed steps ({det_bpp} B per level pixel: Lsmooth read once, every output "
-                    "plane written once); time = sum of HIP-event spans around each launch on the launching stream")
+                    "plane written once); time = sum of HIP-event spans around each launch on the launching stream. In the "
+                    "step the fine-octave launches share the chip with the coarse octaves' chain and the previous batch's "
+                    "keypoint kernels (that overlap is worth +7 % throughput), which stretches the spans: standalone_frac "
+                    "is the same kernel alone on HBM-cold planes (detector_standalone)")
     roof_fed = roof(A.lib().akz_fed_kernel_name().decode(), prof["fed"], prof["fed_launches"],
                     FED_BYTES_PER_PX_STEP * prof["fed_px_steps"] + 12.0 * prof["fused_px"],
                     "all diffusion launches of the timed steps (levels 1..15, 1920x1080 down to 240x135): k_level_march "
@@ -535,6 +540,44 @@ def main_rank(args):
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst, "launches_per_pass": launches // reps,
                                "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * px * nst * reps / launches)}
             del lt, lf
+
+    # ---- the detector kernel alone, on HBM-cold inputs: four plane sets of a 32 x 1080p level in turn (a launch that
+    # re-reads the plane it read last time finds most of it in the 256 MB Infinity Cache and looks 25 % faster than any
+    # launch of the pyramid, where every level's Lsmooth was written long before) ----
+    det_alone = None
+    if rank == 0 and not args.no_fed4k and not args.lean:
+        n_, h_, w_ = 32, 1080, 1920
+        pb = n_ * h_ * w_ * 4
+        big = torch.empty(4 * 7 * pb + (1 << 21), dtype=torch.uint8, device=dev)  # carved like the product's slab
+        base = (big.data_ptr() + (1 << 21) - 1) >> 21 << 21
+        sets = [[base + (7 * k + i) * pb for i in range(7)] for k in range(4)]
+        src = torch.rand((n_, h_, w_), dtype=torch.float32, device=dev)
+        for k in range(4):
+            A.copy_d2d(sets[k][0], src.data_ptr(), pb)
+        det_alone = {}
+        for S in (2, 3, 4):
+            def call(k):
+                p_ = sets[k]
+                A._check(A.lib().akz_op_detector_response(ctx._h, p_[0], S, p_[1], p_[2], p_[3], p_[4], p_[5], p_[6], w_, h_, n_))
+            for k in range(4):
+                call(k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            e0.record()
+            for _ in range(reps):
+                for k in range(4):
+                    call(k)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / (4 * reps) * 1e3
+            gbs = 28.0 * n_ * h_ * w_ / us / 1e3
+            det_alone[f"sigma_size_{S}"] = {"avg_launch_us": round(us, 1), "achieved": round(gbs, 1),
+                                            "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        det_alone["note"] = ("k_detector_march alone on one 32 x 1080p level, 28 B/px, inputs not in any cache; a plain "
+                             "streaming kernel with the same 1 read : 6 writes reaches 5.0-5.5 TB/s on this part "
+                             "(tools/membw/hbm_ceiling.hip)")
+        del big, src
+        roof_det["standalone_frac"] = det_alone["sigma_size_3"]["frac"]
 
     # ---- self-check of the timed configuration (untimed): frame k of the batch == the same frame extracted alone ----
     self_check = None
@@ -750,6 +793,7 @@ def main_rank(args):
             "roofline": roofline,
             "roofline_2": roofline_2,
             "fed_standalone": fed_alone,
+            "detector_standalone": det_alone,
             "cpu_baseline": cpu,
             "self_check": self_check,
             "stage_ms_per_step": stage_ms,

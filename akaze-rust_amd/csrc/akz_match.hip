@@ -197,13 +197,19 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
         const int buf = (int)((tile - t_begin) & 1u);
         const bool more = tile + 1 < t_end;
         const bool partial = (tile + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
-        if (((tile - t_begin) & 3u) == 0u) {  // use the value requested four tiles ago, request the next one
+#ifndef AKZ_MM_REFRESH
+#define AKZ_MM_REFRESH 1  // tiles between two reads of the shared bound (power of two)
+#endif
+        if (((tile - t_begin) & (AKZ_MM_REFRESH - 1u)) == 0u) {  // use the value requested last time, request the next one
 #pragma unroll
             for (int b = 0; b < MM_NB; ++b) {
                 limit[b] = min(limit[b], min(second[b], b_seen[b] < 0xffffffffu ? b_seen[b] + 1u : b_seen[b]));
                 b_seen[b] = __hip_atomic_load(bound + q_first + 32 * b + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        // (Sharing the bound between the two lanes of a column directly -- max of their minima bounds the second-best
+        // too -- was tried: any cross-lane instruction here costs 38 spilled registers at the 128 of 16 waves, and the
+        // lanes already meet through `bound`, which is now read every tile.)
 #pragma unroll
         for (int sub = 0; sub < MM_SUB; ++sub) {
             if (more) fetch(tile + 1, sub);  // in flight under the MFMA chain below

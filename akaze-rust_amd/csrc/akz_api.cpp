@@ -484,9 +484,11 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
     // a multiple of 256 bytes: the runtime then clears it with one fill kernel instead of two (body + tail), which is
     // one dependent dispatch less in a lone frame's launch chain
     const size_t small_bytes = ((size_t)n * (8 + nbins * 4) + 255) / 256 * 256;
-    AKZ_TRY(ensure(c, c->small, small_bytes));
+    const size_t thr_bytes = (size_t)n * (nbins + 1) * sizeof(double);  // bin thresholds (streaming form), not cleared
+    AKZ_TRY(ensure(c, c->small, small_bytes + thr_bytes));
     unsigned long long* d_hmax = (unsigned long long*)c->small.p;
     uint32_t* d_hist = (uint32_t*)((char*)c->small.p + (size_t)n * 8);
+    double* d_thr = (double*)((char*)c->small.p + small_bytes);
     AKZ_HIP_TRY(hipMemsetAsync(c->small.p, 0, small_bytes, c->stream));
     const size_t ks = gaussian_kernel_size((float)gscale);
     const bool stream = c->prep_mode != 0 && gscale > 0.0 && launch::contrast_stream_supported(w, h, (uint32_t)ks, (uint32_t)nbins) &&
@@ -494,7 +496,7 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
     if (stream) {
         // both passes recompute blur + Scharr from the input in registers: no blurred plane is written or re-read
         const std::vector<float> g3 = gaussian_kernel((float)gscale, ks);
-        launch::contrast_stream(c->stream, d_in, w, h, n, g3.data(), d_hmax, (uint32_t)nbins, d_hist);
+        launch::contrast_stream(c->stream, d_in, w, h, n, g3.data(), d_hmax, (uint32_t)nbins, d_hist, d_thr);
     } else {
         AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
         float* blurred = (float*)c->scratch[1].p;

@@ -162,7 +162,7 @@ void blur5_stream_f32(hipStream_t s, const float* in, float* out, uint32_t w, ui
 // streaming contrast-factor passes (akz_stream.hip): max and histogram of the gradient of blur(in) in two launches
 bool contrast_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins);
 void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
-                     unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist);
+                     unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist, double* d_thr);
 // streaming form of prep_fused (akz_stream.hip)
 bool prep_stream_supported(uint32_t w, uint32_t h);
 void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, float* lsmooth, float* lflow, uint32_t w,

@@ -266,8 +266,45 @@ struct ContrastArgs {
     unsigned long long* hmax_bits;  // per image, non-negative f64 as its bit pattern (orders like the value)
     unsigned* hist;                 // per image, nbins counters
     unsigned nbins;
+    const double* thr;              // MODE 2: per image, nbins + 1 bin thresholds on Lx^2 + Ly^2 (k_contrast_thresholds)
 };
 constexpr int CHIST_COPIES = 4;  // sub-histograms per wave (lanes spread over them) against same-bin conflicts
+
+// The histogram bin of a pixel with ss = Lx^2 + Ly^2 (f64), exactly as contrast_factor.rs:49-57 computes it.
+__device__ __forceinline__ unsigned contrast_bin(double ss, double hmax, unsigned nbins) {
+    const double gm = sqrt(ss);
+    const double f = floor((double)nbins * (gm / hmax));
+    return f >= (double)nbins ? nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
+}
+// thr[img][b] = the smallest ss >= 0 (+inf included) whose bin is >= b; NaN if there is none, and for b = nbins.
+// contrast_bin is non-decreasing in ss (correctly rounded sqrt, division by a constant, multiplication, floor), and
+// non-negative doubles order like their bit patterns: a 64-step bisection per threshold.  One workgroup per image.
+__global__ void k_contrast_thresholds(const unsigned long long* __restrict__ hmax_bits, unsigned nbins, double* __restrict__ thr) {
+    const double hmax = __longlong_as_double((long long)hmax_bits[blockIdx.x]);
+    double* out = thr + (size_t)blockIdx.x * (nbins + 1);
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (unsigned b = threadIdx.x; b <= nbins; b += blockDim.x) {
+        if (b == 0) { out[0] = 0.0; continue; }
+        if (b == nbins) { out[b] = nan; continue; }
+        unsigned long long lo = 0ull, hi = 0x7ff0000000000000ull;  // bit patterns of +0.0 and +inf
+        if (!(contrast_bin(__longlong_as_double((long long)hi), hmax, nbins) >= b)) { out[b] = nan; continue; }
+        {   // the threshold lies next to (b hmax / nbins)^2: a bracket of +-2^-30 around it, if it is one, saves half the steps
+            const double x = (double)b * hmax / (double)nbins, c = x * x;
+            const double a = c * (1.0 - 0x1p-30), d = c * (1.0 + 0x1p-30);
+            if (a > 0.0 && d < __longlong_as_double(0x7fe0000000000000ll) && contrast_bin(a, hmax, nbins) < b &&
+                contrast_bin(d, hmax, nbins) >= b) {
+                lo = (unsigned long long)__double_as_longlong(a) + 1ull;
+                hi = (unsigned long long)__double_as_longlong(d);
+            }
+        }
+        while (lo < hi) {  // invariant: pred(hi) holds
+            const unsigned long long mid = lo + ((hi - lo) >> 1);
+            if (contrast_bin(__longlong_as_double((long long)mid), hmax, nbins) >= b) hi = mid;
+            else lo = mid + 1;
+        }
+        out[b] = __longlong_as_double((long long)hi);
+    }
+}
 
 template <bool HALF, int MODE>
 __global__ void __launch_bounds__(SNT, 3)
@@ -275,7 +312,7 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
               float* __restrict__ lflow, int w, int h, int pw, int ph, StreamGrid g, float g0, float g1, float g2,
               float kn, float kwn, const double* __restrict__ d_k, unsigned k_pow, ContrastArgs ca) {
     static_assert(!(HALF && MODE != 0), "the contrast passes read the level itself");
-    extern __shared__ unsigned s_chist[];  // MODE 2: [wave][copy][bin]
+    extern __shared__ __attribute__((aligned(16))) unsigned s_chist[];  // MODE 2: [wave][copy][bin], then [wave][bin thresholds]
     const int lane = threadIdx.x & (WAVE - 1);
     const long wave = wave_index();
     if (wave >= g.waves) return;
@@ -288,8 +325,9 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
     float* ltp = HALF ? lt_out + base : nullptr;
     float* lsp = MODE == 0 ? lsmooth + base : nullptr;
     float* lfp = MODE == 0 ? lflow + base : nullptr;
-    double inverse_k = 0.0, hmax = 0.0, gmax = 0.0;
+    double inverse_k = 0.0, hmax = 0.0, gmax = 0.0, bin_scale = 0.0;
     unsigned* myhist = nullptr;
+    const double* mythr = nullptr;
     unsigned colmask = 0;  // MODE 1/2: pixels of this lane inside the interior columns 1..w-2 (contrast_factor.rs:35)
     if (MODE == 0) {
         double kc = d_k[pc.img];
@@ -304,6 +342,12 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
             unsigned* wh = s_chist + (size_t)(threadIdx.x >> 6) * CHIST_COPIES * ca.nbins;
             for (unsigned b = lane; b < CHIST_COPIES * ca.nbins; b += WAVE) wh[b] = 0u;  // wave-private: no barrier
             myhist = wh + (lane & (CHIST_COPIES - 1)) * ca.nbins;
+            // the image's bin thresholds, wave-private too (behind the histograms of all waves, 8-byte aligned)
+            double* wt = reinterpret_cast<double*>(s_chist + (size_t)(SNT / WAVE) * CHIST_COPIES * ca.nbins + (ca.nbins & 1u)) +
+                         (size_t)(threadIdx.x >> 6) * (ca.nbins + 1);
+            for (unsigned b = lane; b <= ca.nbins; b += WAVE) wt[b] = ca.thr[(size_t)pc.img * (ca.nbins + 1) + b];
+            mythr = wt;
+            bin_scale = (double)ca.nbins * (1.0 / hmax);
         }
     }
     const int v0 = pc.cs - 2, T = (pc.ce - pc.cs) + 4;  // input rows v0 .. v0+T-1 (clamped to 1..h-2 when loaded)
@@ -371,10 +415,16 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
                                     if (ss > gmax) gmax = ss;
                                     continue;
                                 }
-                                const double gm = sqrt(ss);
-                                if (gm != 0.0) {
-                                    const double f = floor((double)ca.nbins * (gm / hmax));
-                                    const unsigned b = f >= (double)ca.nbins ? ca.nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
+                                // bin = contrast_bin(ss, hmax, nbins), a non-decreasing function of ss: a guess from
+                                // the hardware's approximate square root (off by one bin at most), settled by the
+                                // exact thresholds of the two neighbouring bins -- instead of a correctly rounded f64
+                                // square root and division per pixel
+                                if (ss != 0.0) {  // sqrt(ss) != 0.0 (contrast_factor.rs:51)
+                                    const double ga = __builtin_amdgcn_sqrt(ss) * bin_scale;
+                                    const unsigned g = min(ga > 0.0 ? (unsigned)ga : 0u, ca.nbins - 1u);  // NaN -> 0
+                                    unsigned b = g;
+                                    if (ss < mythr[g]) b = g - 1u;
+                                    else if (ss >= mythr[g + 1u]) b = g + 1u;
                                     atomicAdd(&myhist[b], 1u);
                                 }
                             }
@@ -558,29 +608,33 @@ void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, flo
     if (half) {
         const StreamGrid g = plan_stream(k_prep_stream<true, 0>, w, h, n, 1, 1, prep_min_rows(), &grid);
         hipLaunchKernelGGL((k_prep_stream<true, 0>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
-                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ContrastArgs{});
+                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ContrastArgs{nullptr, nullptr, 0u, nullptr});
     } else {
         const StreamGrid g = plan_stream(k_prep_stream<false, 0>, w, h, n, 1, 1, prep_min_rows(), &grid);
         hipLaunchKernelGGL((k_prep_stream<false, 0>), grid, dim3(SNT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
-                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ContrastArgs{});
+                           (int)pw, (int)ph, g, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ContrastArgs{nullptr, nullptr, 0u, nullptr});
     }
 }
 
 // compute_contrast_factor's two passes over gaussian_blur(in, sigma with the 3 taps g3) without materialising the
-// blurred plane: maximum, then histogram (d_hmax_bits / d_hist zeroed by the caller).  nbins <= 1024.
+// blurred plane: maximum, bin thresholds, histogram (d_hmax_bits / d_hist zeroed by the caller; d_thr: n x (nbins + 1)
+// doubles).  nbins <= 640.
 bool contrast_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins) {
-    return ntaps == 3 && nbins <= 1024 && prep_stream_supported(w, h);
+    return ntaps == 3 && nbins <= 640 && prep_stream_supported(w, h);  // 61 KB of LDS at 640 bins
 }
 void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
-                     unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist) {
+                     unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist, double* d_thr) {
     const Taps m = taps_scharr_main(1);
-    const ContrastArgs ca{d_hmax_bits, d_hist, nbins};
+    const ContrastArgs ca{d_hmax_bits, d_hist, nbins, d_thr};
     dim3 grid;
     const StreamGrid g1 = plan_stream(k_prep_stream<false, 1>, w, h, n, 1, 1, prep_min_rows(), &grid);
     hipLaunchKernelGGL((k_prep_stream<false, 1>), grid, dim3(SNT), 0, s, in, nullptr, nullptr, nullptr, (int)w, (int)h,
                        (int)w, (int)h, g1, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], nullptr, 0u, ca);
+    hipLaunchKernelGGL(k_contrast_thresholds, dim3(n), dim3(320), 0, s, d_hmax_bits, nbins, d_thr);
     const StreamGrid g2 = plan_stream(k_prep_stream<false, 2>, w, h, n, 1, 1, prep_min_rows(), &grid);
-    hipLaunchKernelGGL((k_prep_stream<false, 2>), grid, dim3(SNT), (SNT / WAVE) * CHIST_COPIES * nbins * sizeof(unsigned), s,
+    const size_t lds = ((size_t)(SNT / WAVE) * CHIST_COPIES * nbins + (nbins & 1u)) * sizeof(unsigned) +
+                       (size_t)(SNT / WAVE) * (nbins + 1) * sizeof(double);
+    hipLaunchKernelGGL((k_prep_stream<false, 2>), grid, dim3(SNT), lds, s,
                        in, nullptr, nullptr, nullptr, (int)w, (int)h, (int)w, (int)h, g2, g3[0], g3[1], g3[2], m.wgt[0],
                        m.wgt[1], nullptr, 0u, ca);
 }

@@ -895,7 +895,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         akz_result* r;
         bool armed = true;
         ~Guard() {
-            if (armed) result_release_device(r);
+            if (!armed) return;
+            // work already enqueued (possibly on the coarse stream, which nothing has joined yet) still writes the slab
+            akz_ctx* c = r->ctx;
+            if (c && c->coarse) (void)hipStreamSynchronize(c->coarse);
+            result_release_device(r);
         }
     } guard{r};
 

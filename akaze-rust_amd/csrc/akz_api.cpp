@@ -1897,7 +1897,7 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
     const uint32_t chunks = mfma ? launch::match_mfma_chunks((uint32_t)n0, (uint32_t)n1)
                                  : launch::match_num_chunks((uint32_t)n0, (uint32_t)n1);
     AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * (chunks + 1) * sizeof(MatchRec)));
-    MatchRec* merged = (MatchRec*)c->match_rec.p;
+    MatchRec* rec = (MatchRec*)c->match_rec.p;  // [chunk][query], then the merged records
     if (mfma) {
         const uint32_t q_rows = launch::match_mfma_rows((uint32_t)n0, true), t_rows = launch::match_mfma_rows((uint32_t)n1, false);
         AKZ_TRY(ensure(c, c->mm_q8, (size_t)q_rows * 512));
@@ -1909,12 +1909,15 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
         launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, 1, nullptr);
         launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, nullptr);
         launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p,
-                           (uint32_t)n1, thr, bound, merged + n0, merged);
+                           (uint32_t)n1, thr, bound, chunks, rec);
     } else {
-        launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, rows_le_61, merged + n0, merged);
+        launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, rows_le_61, chunks, rec);
     }
-    launch::match_compact(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, thr, lowes_ratio * lowes_ratio,
-                          d_out, (unsigned long long*)d_n_out);
+    // more than a few chunks: a parallel merge first (the compaction is one workgroup)
+    const bool premerge = chunks > 4;
+    if (premerge) launch::match_merge(c->stream, rec, (uint32_t)n0, chunks, thr, rec + (size_t)chunks * n0);
+    launch::match_compact(c->stream, premerge ? rec + (size_t)chunks * n0 : rec, (uint32_t)n0, premerge ? 1u : chunks, thr,
+                          lowes_ratio * lowes_ratio, d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
 }
@@ -1961,7 +1964,11 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     const uint32_t q_rows = launch::match_mfma_rows((uint32_t)n0, true);
     // padded train image: every set starts on a tile boundary
     std::vector<uint32_t> tiles;  // {first source row, valid rows} per tile
-    std::vector<launch::MatchChunkHost> chunks(n_sets);
+    // every set is cut into `cps` chunks (ascending rows; a short set leaves its last chunks empty) so that the
+    // workgroups fill whole rounds of the chip; the chunks of a set share its pruning bounds
+    const uint32_t cps = launch::match_mfma_multi_chunks((uint32_t)n0, (uint32_t)n_sets,
+                                                         (uint32_t)((total_rows / n_sets + tr - 1) / tr));
+    std::vector<launch::MatchChunkHost> chunks((size_t)n_sets * cps);
     uint64_t src = 0;
     for (uint64_t k = 0; k < n_sets; ++k) {
         const uint32_t t0 = (uint32_t)(tiles.size() / 2), rows = (uint32_t)set_rows[k];
@@ -1969,7 +1976,10 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
             tiles.push_back((uint32_t)(src + r));
             tiles.push_back(std::min(tr, rows - r));
         }
-        chunks[k] = launch::MatchChunkHost{t0, (uint32_t)(tiles.size() / 2), t0 * tr, rows, (uint32_t)(k * q_rows), (uint32_t)k};
+        const uint32_t t1 = (uint32_t)(tiles.size() / 2), per = (t1 - t0 + cps - 1) / cps;
+        for (uint32_t j = 0; j < cps; ++j)
+            chunks[k * cps + j] = launch::MatchChunkHost{std::min(t0 + j * per, t1), std::min(t0 + (j + 1) * per, t1), t0 * tr, rows,
+                                                        (uint32_t)(k * q_rows), (uint32_t)(k * cps + j)};
         src += rows;
     }
     const uint32_t n_tiles = (uint32_t)(tiles.size() / 2), t_rows = std::max(1u, n_tiles) * tr;
@@ -1981,8 +1991,8 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     AKZ_TRY(ensure(c, c->mm_t8, (size_t)t_rows * 512));
     AKZ_TRY(ensure(c, c->mm_pop, ((size_t)q_rows * (1 + n_sets) + t_rows) * sizeof(uint32_t)));
     const size_t tab_tiles = std::max<size_t>(1, tiles.size()) * sizeof(uint32_t);
-    AKZ_TRY(ensure(c, c->mm_tab, tab_tiles + n_sets * sizeof(launch::MatchChunkHost)));
-    AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * n_sets * sizeof(MatchRec)));
+    AKZ_TRY(ensure(c, c->mm_tab, tab_tiles + chunks.size() * sizeof(launch::MatchChunkHost)));
+    AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * chunks.size() * sizeof(MatchRec)));
     uint32_t* qpop = (uint32_t*)c->mm_pop.p;
     uint32_t* bound = qpop + q_rows;
     uint32_t* tpop = bound + (size_t)n_sets * q_rows;
@@ -1990,7 +2000,7 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     void* d_chunks = (char*)c->mm_tab.p + tab_tiles;
     if (!tiles.empty())
         AKZ_HIP_TRY(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), n_sets * sizeof(launch::MatchChunkHost), hipMemcpyHostToDevice,
+    AKZ_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(launch::MatchChunkHost), hipMemcpyHostToDevice,
                                c->stream));
     AKZ_HIP_TRY(hipStreamSynchronize(c->stream));  // the tables are stack / heap objects of this call
     launch::unpack_bits(c->stream, d_q, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, (uint32_t)n_sets,
@@ -1998,8 +2008,8 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     if (n_tiles)
         launch::unpack_bits(c->stream, d_train, 0, n_tiles * tr, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, d_tiles);
     launch::match_mfma_multi(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
-                             (uint32_t)n_sets, thr, bound, (MatchRec*)c->match_rec.p);
-    launch::match_compact_sets(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, (uint32_t)n_sets, thr,
+                             (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p);
+    launch::match_compact_sets(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, (uint32_t)n_sets, cps, thr,
                                lowes_ratio * lowes_ratio, d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;

@@ -192,14 +192,16 @@ void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint3
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64);
 uint32_t match_num_chunks(uint32_t n0, uint32_t n1);
+// Both scans write one record per (chunk of the train set, query): d_rec[chunk * n0 + query]; match_compact merges a
+// query's chunk records (ascending rows: the lowest row wins among equal minima) and applies the ratio test.
 // rows_le_61: rows are M-LDB descriptors (at most 61 bytes): bytes 61..63 are padding and not compared
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
-           bool rows_le_61, MatchRec* d_part, MatchRec* d_out);
-void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out);
+           bool rows_le_61, uint32_t chunks, MatchRec* d_rec);
 // the same scan on the matrix cores (akz_match.hip): descriptor bits unpacked to int8, distances from one integer
 // GEMM; identical records.  Rows of the unpacked images are padded (match_mfma_rows).
 uint32_t match_mfma_rows(uint32_t n, bool queries);
 uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1);
+uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tiles);  // chunks per set of a multi-set launch
 // bound (queries only): n_bound arrays of n_pad per-query pruning bounds, set to threshold; d_tiles (train images of
 // several sets): per LDS tile {first source row, valid rows}
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
@@ -210,14 +212,16 @@ struct MatchChunkHost {  // = MatchChunk of akz_match.hip
     uint32_t t_begin, t_end, row0, n_rows, bound_off, record;
 };
 void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
-                      const void* d_table, uint32_t n_sets, uint32_t threshold, uint32_t* bound, MatchRec* d_out);
-// n_sets > 1: set k's records at d_rec + k * n0, its matches at d_out + k * n0, its count at d_n_out[k]
-void match_compact_sets(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t n_sets, uint32_t threshold, double ratio2,
-                        akz_match* d_out, unsigned long long* d_n_out);
+                      const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out);
 void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
-                uint32_t threshold, uint32_t* bound, MatchRec* d_part, MatchRec* d_out);
-void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
+                uint32_t threshold, uint32_t* bound, uint32_t chunks, MatchRec* d_rec);
+// set k's `chunks` chunk records at d_rec + k * chunks * n0, its matches at d_out + k * n0, its count at d_n_out[k]
+void match_compact_sets(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t n_sets, uint32_t chunks, uint32_t threshold,
+                        double ratio2, akz_match* d_out, unsigned long long* d_n_out);
+void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t chunks, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out);
+// the same merge as a kernel of its own, one thread per query (many chunks): d_out[query]
+void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out);
 }  // namespace launch
 
 // ---- host keypoint logic (akz_keypoints.cpp) ---------------------------------------------

@@ -848,7 +848,7 @@ __device__ __forceinline__ void top2_feed(unsigned d, unsigned j, unsigned& min_
 }
 // blockIdx.x: 256 queries (one per thread, in registers); blockIdx.y: a chunk of the train set, staged
 // through LDS 256 rows at a time.  Each workgroup writes the chunk-local (min, second, argmin) of its
-// queries; k_match_merge folds the chunks in index order, which reproduces the sequential scan exactly
+// queries; k_match_compact folds the chunks in index order, which reproduces the sequential scan exactly
 // (top-2 of a union = top-2 of the per-part top-2s; ties keep the lowest index).
 __global__ void __launch_bounds__(MT) k_match(const uint4* __restrict__ d0, unsigned n0, const uint4* __restrict__ d1,
                                              unsigned n1, unsigned chunk_rows, unsigned threshold, unsigned tail_mask,
@@ -883,6 +883,8 @@ __global__ void __launch_bounds__(MT) k_match(const uint4* __restrict__ d0, unsi
         out[(size_t)blockIdx.y * n0 + i] = m;
     }
 }
+// Merge of every query's records over the chunks of one train set, one thread per query (the pair call has up to a
+// hundred chunks: too many records for the single workgroup of k_match_compact to fold on its own).
 __global__ void k_match_merge(const MatchRec* __restrict__ part, unsigned n0, unsigned chunks, unsigned threshold,
                               MatchRec* __restrict__ out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -898,14 +900,16 @@ __global__ void k_match_merge(const MatchRec* __restrict__ part, unsigned n0, un
     out[i] = o;
 }
 
-// Lowe ratio^2 + threshold test (feature_matching.rs:61-63) and ordered compaction, one workgroup.
-__global__ void __launch_bounds__(1024) k_match_compact(const MatchRec* __restrict__ rec, unsigned n0,
+// Merge of a query's records over the chunks of one train set (chunks in ascending row order: the strict '<' of
+// top2_feed keeps the lowest row among equal minima, as the sequential scan does), then the Lowe ratio^2 + threshold
+// test (feature_matching.rs:61-63) and ordered compaction; one workgroup per train set.
+__global__ void __launch_bounds__(1024) k_match_compact(const MatchRec* __restrict__ rec, unsigned n0, unsigned chunks,
                                                         unsigned threshold, double ratio2,
                                                         akz_match* __restrict__ out,
                                                         unsigned long long* __restrict__ n_out) {
     __shared__ unsigned s_wave[16];
     __shared__ unsigned s_base;
-    rec += (size_t)blockIdx.x * n0;  // one workgroup per set of records (blockIdx.x = 0 for a single set)
+    rec += (size_t)blockIdx.x * chunks * n0;  // records [chunk][query] of this set (blockIdx.x = 0 for a single set)
     out += (size_t)blockIdx.x * n0;
     n_out += blockIdx.x;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -916,7 +920,13 @@ __global__ void __launch_bounds__(1024) k_match_compact(const MatchRec* __restri
         bool keep = false;
         MatchRec m = {0, 0, 0, 0};
         if (i < n0) {
-            m = rec[i];
+            unsigned min_d = threshold, second = threshold, min_j = 0;
+            for (unsigned c = 0; c < chunks; ++c) {
+                const MatchRec p = rec[(size_t)c * n0 + i];
+                top2_feed(p.min_d, p.min_j, min_d, second, min_j);
+                if (p.second_d < second) second = p.second_d;  // second_d >= min_d of its chunk >= min_d
+            }
+            m.min_d = min_d; m.second_d = second; m.min_j = min_j;
             keep = ((double)m.min_d < (double)m.second_d * ratio2) && (m.min_d < threshold);
         }
         const unsigned long long bal = __ballot(keep);
@@ -1076,27 +1086,25 @@ uint32_t match_num_chunks(uint32_t n0, uint32_t n1) {
     return std::max<uint32_t>(1, std::min<uint32_t>({want, (tiles + 3) / 4, 64u}));
 }
 // d_part: chunks * n0 records of scratch; d_out: n0 merged records
-void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out) {
-    hipLaunchKernelGGL(k_match_merge, dim3((n0 + 255) / 256), dim3(256), 0, s, d_part, n0, chunks, threshold, d_out);
-}
+// records of every query over `chunks` chunks of the train set: d_rec[chunk * n0 + query] (merged by match_compact)
 void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uint32_t n1, uint32_t threshold,
-           bool rows_le_61, MatchRec* d_part, MatchRec* d_out) {
+           bool rows_le_61, uint32_t chunks, MatchRec* d_rec) {
     if (n0 == 0) return;
-    const uint32_t chunks = match_num_chunks(n0, n1);
     const uint32_t tiles = std::max<uint32_t>(1, (n1 + MT - 1) / MT);
     const uint32_t chunk_rows = ((tiles + chunks - 1) / chunks) * MT;
     hipLaunchKernelGGL(k_match, dim3((n0 + MT - 1) / MT, chunks), dim3(MT), 0, s, reinterpret_cast<const uint4*>(d0), n0,
-                       reinterpret_cast<const uint4*>(d1), n1, chunk_rows, threshold, rows_le_61 ? 0xffu : 0xffffffffu,
-                       chunks > 1 ? d_part : d_out);
-    if (chunks > 1) match_merge(s, d_part, n0, chunks, threshold, d_out);
+                       reinterpret_cast<const uint4*>(d1), n1, chunk_rows, threshold, rows_le_61 ? 0xffu : 0xffffffffu, d_rec);
 }
-void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t threshold, double ratio2,
+void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out) {
+    hipLaunchKernelGGL(k_match_merge, dim3((n0 + 255) / 256), dim3(256), 0, s, d_part, n0, chunks, threshold, d_out);
+}
+void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t chunks, uint32_t threshold, double ratio2,
                    akz_match* d_out, unsigned long long* d_n_out) {
-    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, s, d_rec, n0, threshold, ratio2, d_out, d_n_out);
+    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, s, d_rec, n0, chunks, threshold, ratio2, d_out, d_n_out);
 }
-void match_compact_sets(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t n_sets, uint32_t threshold, double ratio2,
-                        akz_match* d_out, unsigned long long* d_n_out) {
-    hipLaunchKernelGGL(k_match_compact, dim3(n_sets), dim3(1024), 0, s, d_rec, n0, threshold, ratio2, d_out, d_n_out);
+void match_compact_sets(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t n_sets, uint32_t chunks, uint32_t threshold,
+                        double ratio2, akz_match* d_out, unsigned long long* d_n_out) {
+    hipLaunchKernelGGL(k_match_compact, dim3(n_sets), dim3(1024), 0, s, d_rec, n0, chunks, threshold, ratio2, d_out, d_n_out);
 }
 
 }  // namespace launch

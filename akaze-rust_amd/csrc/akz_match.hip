@@ -21,7 +21,7 @@
 // has its column (query) on the lane and rows (i & 3) + 8 (i >> 2) + 4 h, i = 0..15, in the registers
 // (cdna_hip_programming.md, C/D layout): ascending train index inside a lane, so the reference's update rule
 // applies directly; the two lanes of a column are merged at the end of the chunk with the order-free form of the
-// rule ((distance, index) lexicographic minimum; second = min of the others), and the chunks by k_match_merge.
+// rule ((distance, index) lexicographic minimum; second = min of the others), and the chunks by k_match_compact.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -351,24 +351,42 @@ void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bo
 }
 uint32_t match_mfma_tile_rows() { return MM_TR; }
 uint32_t match_mfma_query_block() { return MM_QB; }
+// Chunks per train set of a multi-set launch: one workgroup per CU is resident, so a launch runs in rounds of 256
+// workgroups; with one chunk per set 22 query blocks x 16 sets are 352 workgroups = 1.4 rounds that take as long as 2.
+// Same estimate as match_mfma_chunks: rounds x (tiles per chunk + the query load).
+uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tiles) {
+    if (const char* e = std::getenv("AKZ_MM_SET_CHUNKS")) return std::max(1, std::min(16, std::atoi(e)));
+    const uint64_t qblocks = (std::max<uint32_t>(n0, 1) + MM_QB - 1) / MM_QB;
+    constexpr uint32_t kQueryLoad = 512 / MM_TR;
+    uint32_t best = 1;
+    uint64_t best_cost = ~0ull;
+    for (uint32_t c = 1; c <= 8 && (c == 1 || avg_tiles / c >= 2 * kQueryLoad); ++c) {
+        const uint64_t rounds = (qblocks * n_sets * c + 255) / 256;
+        const uint64_t cost = rounds * ((avg_tiles + c - 1) / c + kQueryLoad);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
 // One launch for a query set against SEVERAL train sets (padded image t8 as laid out by unpack_bits with a tile table):
-// chunk c of d_table describes set c (one chunk per set); record c * n0 + q = top-2 of query q over set c.
+// d_table holds n_chunks chunk descriptors (several per set, ascending rows); record r * n0 + q = top-2 of query q over
+// the chunk with record index r.
 void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
-                      const void* d_table, uint32_t n_sets, uint32_t threshold, uint32_t* bound, MatchRec* d_out) {
-    if (n0 == 0 || n_sets == 0) return;
-    hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, n_sets), dim3(MM_NT), 0, s, q8, qpop, n0, t8, 0u, 0u,
+                      const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out) {
+    if (n0 == 0 || n_chunks == 0) return;
+    hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, n_chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, 0u, 0u,
                        threshold, bound, d_out, reinterpret_cast<const MatchChunk*>(d_table));
 }
-// top-2 records of every query over the whole train set in d_out (d_part: chunks x n0 scratch records)
+// records of every query over `chunks` chunks of the train set: d_rec[chunk * n0 + query] (merged by match_compact)
 void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
-                uint32_t threshold, uint32_t* bound, MatchRec* d_part, MatchRec* d_out) {
+                uint32_t threshold, uint32_t* bound, uint32_t chunks, MatchRec* d_rec) {
     if (n0 == 0) return;
-    const uint32_t chunks = match_mfma_chunks(n0, n1);
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
     const uint32_t chunk_tiles = (tiles + chunks - 1) / chunks;
     hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, n1,
-                       chunk_tiles, threshold, bound, chunks > 1 ? d_part : d_out, (const MatchChunk*)nullptr);
-    if (chunks > 1) match_merge(s, d_part, n0, chunks, threshold, d_out);
+                       chunk_tiles, threshold, bound, d_rec, (const MatchChunk*)nullptr);
 }
 
 }  // namespace launch

@@ -435,6 +435,18 @@ static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t 
     AKZ_TRY(taps_from_dense(k.data(), (uint32_t)k.size(), t));
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
     constexpr bool is_u8 = std::is_same<T, uint8_t>::value;
+    // large batches: the column march (HBM-bound: 0.33 GB of a 32-frame 1080p batch); AKZ_BLUR_MARCH_MIN_PX moves the threshold
+    static const uint64_t blur_march_min_px = [] {
+        const char* e = std::getenv("AKZ_BLUR_MARCH_MIN_PX");
+        return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
+    }();
+    if ((const void*)d_in != (const void*)d_out && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= blur_march_min_px)) &&
+        launch::blur5_march_supported(w, h, (uint32_t)k.size())) {
+        if constexpr (is_u8) launch::blur5_march_u8(c->stream, d_in, d_out, w, h, n, k.data());
+        else launch::blur5_march_f32(c->stream, d_in, d_out, w, h, n, k.data());
+        AKZ_HIP_TRY(hipGetLastError());
+        return AKZ_OK;
+    }
     if ((const void*)d_in != (const void*)d_out && c->prep_mode != 0 &&
         launch::blur5_stream_supported(w, h, (uint32_t)k.size(), is_u8) &&
         (!is_u8 || ((uintptr_t)d_in & 3u) == 0) && (c->prep_mode == 1 || (uint64_t)w * h * n >= c->stream_min_px)) {

@@ -659,6 +659,110 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     else rows(std::false_type{});
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// gaussian_blur with a dense 5-tap kernel as a march (types/image.rs:374-380: V(H(in)), fill_border after each pass):
+// the level-0 blur of the pyramid (sigma 1.6) for large batches.  T = uint8_t folds in create_unit_float_image
+// (types/image.rs:136): the 256 possible values of `f32::from(v) * 1f32 / 255f32` are tabulated once per workgroup
+// with that very expression.  Per iteration: the input row v (two pixels per thread, converted where they are consumed)
+// goes to LDS, one barrier, H pass from two even-aligned and two odd-aligned LDS pairs next to the thread's own pair,
+// V pass over a 5-slot ring -> row v-2 stored.  The plane is stored with ordinary stores: the contrast passes read it
+// next and find most of it in the Infinity Cache.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BlurTaps5 {
+    float k[5];
+};
+__device__ __forceinline__ f2 tap5(f2 a, f2 b, f2 c, f2 d, f2 e, const BlurTaps5& t) {
+    const f2 z = {0.0f, 0.0f};
+    return ((((z + t.k[0] * a) + t.k[1] * b) + t.k[2] * c) + t.k[3] * d) + t.k[4] * e;
+}
+template <typename T, bool ODDW>
+__global__ void __launch_bounds__(MT, 3)
+k_blur5_march(const T* __restrict__ in, float* __restrict__ out, int w, int h, MarchGrid g, BlurTaps5 tp) {
+    constexpr int S = 2, P = 5, R = 5, PF = 3;
+    constexpr bool U8 = sizeof(T) == 1;
+    __shared__ __attribute__((aligned(16))) float s_row[2][ROW];
+    __shared__ float s_lut[256];
+    const int tid = threadIdx.x;
+    if (U8) s_lut[tid & 255] = ((float)(tid & 255) * 1.0f) / 255.0f;  // MT == 256; made visible by the loop's first barrier
+    const int per = g.nbands * g.nstrips;
+    const int cell = march_cell();
+    if (cell >= g.total) return;
+    const int img = __builtin_amdgcn_readfirstlane(cell / per);
+    const int rem = cell - img * per;
+    const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
+    const int cs = S + band * g.band_rows, ce = min(cs + g.band_rows, h - S);  // interior rows of this band
+    if (cs >= ce) return;
+
+    const int X0 = strip * USE - HALO;
+    const int p0 = (2 * tid + HALO) & (MW - 1);
+    const bool inner = p0 >= HALO && p0 < MW - HALO;
+    const Cols C = make_cols(X0 + p0, inner, w);
+    // LDS read indices of tap -2 of the two columns, evaluated at the clamped column
+    const int i0 = PAD + clampi(clampi(C.x0, S, w - 1 - S) - X0, 0, MW - 1) - S;
+    const int i1 = PAD + clampi(clampi(C.x0 + 1, S, w - 1 - S) - X0, 0, MW - 1) - S;
+    const int wi = PAD + p0;
+    const bool edge_h = __ballot(i0 != wi - S || i1 != wi + 1 - S) != 0ull;  // some lane reads at a clamped column
+
+    const size_t base = (size_t)img * (size_t)w * (size_t)h;
+    // u8 input: the same range-checked addressing in bytes
+    const __amdgpu_buffer_rsrc_t rin = U8 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in + base), 0, w * h, RSRC_FLAGS)
+                                          : plane_rsrc(reinterpret_cast<const float*>(in + base), w, h);
+    const __amdgpu_buffer_rsrc_t rout[1] = {plane_rsrc(out + base, w, h)};
+    const int v0 = cs - S, T_ = (ce - cs) + 2 * S;  // H rows v0 .. v0 + T_ - 1
+    typedef typename std::conditional<U8, unsigned, f2>::type Raw;
+    auto feed = [&](int t) -> Raw {
+        const int row = clampi(v0 + min(t, T_ - 1), S, h - 1 - S);  // fill_border after the H pass: its rows 0..S-1 are row S
+        if constexpr (U8) {
+            const unsigned vo = C.vo_ld >> 2;  // byte offset of column clamp(x0, 0, w-2)
+            if (!ODDW) return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rin, (int)vo, row * w, 0);
+            const unsigned a = __builtin_amdgcn_raw_buffer_load_b8(rin, (int)vo, row * w, 0);
+            const unsigned b = __builtin_amdgcn_raw_buffer_load_b8(rin, (int)vo + 1, row * w, 0);
+            return (a & 255u) | ((b & 255u) << 8);
+        } else {
+            return load_pair<ODDW>(rin, (unsigned)row * ((unsigned)w * 4u), C);
+        }
+    };
+    auto unit = [&](Raw q) -> f2 {  // create_unit_float_image of the pair, then the clamped-column meaning of it
+        f2 v;
+        if constexpr (U8) v = f2{s_lut[q & 255u], s_lut[(q >> 8) & 255u]};
+        else v = q;
+        return fix_pair(v, C);
+    };
+    Raw q[R];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) q[i] = feed(i);
+    const f2 zero = {0.0f, 0.0f};
+    f2 RH[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) RH[i] = zero;
+    if (U8) __syncthreads();  // the table
+
+    for (int t0 = 0; t0 < T_; t0 += P) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int t = t0 + k;  // (whole groups of P rows: the rows past T_ store nothing)
+            const int v = v0 + t, c = v - S;
+            q[(k + PF) % R] = feed(t + PF);
+            float* const buf = &s_row[t & 1][0];
+            const f2 own = unit(q[k % R]);
+            *reinterpret_cast<f2*>(buf + wi) = own;
+            __syncthreads();
+            f2 a, b, m, d, e;
+            if (!rare(edge_h)) {
+                a = *reinterpret_cast<const f2*>(buf + wi - 2); b = lds2(buf + wi - 1); m = own;
+                d = lds2(buf + wi + 1); e = *reinterpret_cast<const f2*>(buf + wi + 2);
+            } else {
+                const float* r0 = buf + i0;
+                const float* r1 = buf + i1;
+                a = f2{r0[0], r1[0]}; b = f2{r0[1], r1[1]}; m = f2{r0[2], r1[2]}; d = f2{r0[3], r1[3]}; e = f2{r0[4], r1[4]};
+            }
+            RH[k] = tap5(a, b, m, d, e, tp);
+            const f2 o[1] = {tap5(RH[(k + 1) % P], RH[(k + 2) % P], RH[(k + 3) % P], RH[(k + 4) % P], RH[k], tp)};
+            store_filled<S, 1, ODDW, false>(rout, C, w, h, c, t >= 2 * S && c >= cs && c < ce, o);
+        }
+    }
+}
+
 inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid) {
     static int cus = 0;
     if (!cus) {
@@ -808,6 +912,26 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
     }
 }
 #undef AKZ_MARCH
+
+// 5-tap gaussian_blur as a march (u8 input: rows of even width are 2-byte aligned, which the 16-bit loads need)
+bool blur5_march_supported(uint32_t w, uint32_t h, uint32_t ntaps) {
+    return ntaps == 5 && w >= 16 && h >= 16 && (uint64_t)w * h <= (1ull << 28);
+}
+template <typename T>
+static void blur5_march_t(hipStream_t s, const T* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
+    BlurTaps5 tp;
+    for (int i = 0; i < 5; ++i) tp.k[i] = k[i];
+    dim3 gr;
+    const MarchGrid mg = plan_march(w, h, n, 2, &gr);
+    if (w & 1u) hipLaunchKernelGGL((k_blur5_march<T, true>), gr, dim3(MT), 0, s, in, out, (int)w, (int)h, mg, tp);
+    else hipLaunchKernelGGL((k_blur5_march<T, false>), gr, dim3(MT), 0, s, in, out, (int)w, (int)h, mg, tp);
+}
+void blur5_march_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
+    blur5_march_t<uint8_t>(s, in, out, w, h, n, k);
+}
+void blur5_march_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
+    blur5_march_t<float>(s, in, out, w, h, n, k);
+}
 
 bool level_march_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16 && (uint64_t)w * h <= (1ull << 28); }
 

@@ -3,7 +3,7 @@ f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # last batch: find last k_blur5_stream
-idx=[i for i,r in enumerate(rows) if 'k_blur5_stream' in r['Kernel_Name']][-1]
+idx=[i for i,r in enumerate(rows) if 'k_blur5' in r['Kernel_Name']][-1]
 t0=int(rows[idx]['Start_Timestamp'])
 for r in rows[idx:]:
     n=r['Kernel_Name'].replace('void akz::(anonymous namespace)::','').split('(')[0]

@@ -968,13 +968,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // ---- levels 1..L-1 (lib.rs:78-119) ----
     AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(w, h, n)));
     const std::vector<float> g1 = gaussian_kernel(1.0f, gaussian_kernel_size(1.0f));  // Lsmooth taps (lib.rs:95)
-    // AKZ_KP_GATE_OCTAVE=o: the gate for the previous batch's keypoint kernels (fed_done, below) is recorded when the
-    // chain reaches octave o instead of behind the last diffusion launch (experiment; default: behind the last one)
-    static const int kp_gate_octave = [] {
-        const char* e = std::getenv("AKZ_KP_GATE_OCTAVE");
-        return e ? std::atoi(e) : -1;
-    }();
-    bool gate_recorded = false;
+    bool gate_recorded = false;  // fed_done: the point behind which the previous batch's keypoint kernels may run
     // Fork.  From octave `fork_octave` on the levels are small: their launches (diffusion, preparation, detectors) do not
     // fill the chip and are bound by launch-to-launch latency -- about 1 ms of the step for 8 % of its pixels.  That
     // chain moves to a second stream when octave fork_octave - 1 is finished, and the main stream goes straight to the
@@ -1014,11 +1008,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             fork_level = i;
             ls = c->coarse;
             c->stream = c->coarse;
-        }
-        if (kp_gate_octave > 0 && !gate_recorded && (int)lv.octave >= kp_gate_octave) {
-            if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
-            AKZ_HIP_TRY(hipEventRecord(c->fed_done, ls));
-            gate_recorded = true;
         }
         float* A = P(i, AKZ_LT);
         float* B = (float*)c->scratch[5].p;
@@ -1349,13 +1338,10 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* d_oo = (OrientOut*)c->kp_out.p;
         AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params, total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
-        static const bool kp_after_fed = [] {
-            const char* e = std::getenv("AKZ_KP_AFTER_FED");  // tuning: 0 launches the keypoint kernels at once
-            return !e || std::atoi(e) != 0;
-        }();
-        // behind the diffusion of the batch begun last (no wait if that is this batch or has passed the point);
-        // small jobs are bound by the latency of this chain, not by the chip, and do not wait
-        if (kp_after_fed && c->fed_done && (uint64_t)r->w * r->h * n >= (8u << 20))
+        // behind the fine octaves' diffusion of the batch begun last (no wait if that is this batch or has passed the
+        // point; placing the gate earlier, later or nowhere was measured: no difference); small jobs are bound by the
+        // latency of this chain, not by the chip, and do not wait
+        if (c->fed_done && (uint64_t)r->w * r->h * n >= (8u << 20))
             AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_done, 0));
         launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());

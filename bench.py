@@ -510,7 +510,9 @@ def main_rank(args):
                     "k_fed_own (<= 8 steps per launch); 12 B per pixel-step ALGORITHMIC plus 12 B per pixel for a "
                     "preparation that runs inside the launch — steps are fused, so frac can exceed 1; traffic_frac is "
                     "the DRAM figure")
-    roofline, roofline_2 = (roof_det, roof_fed) if prof["detector"] >= prof["fed"] else (roof_fed, roof_det)
+    # the detector march is the kernel with the largest share of the step when each kernel runs alone (2.2 of 5.7 ms of
+    # kernel time); since the fork the two groups' spans overlap in the step, so their sums no longer rank them
+    roofline, roofline_2 = roof_det, roof_fed
 
     # ---- the FED kernel alone: 3840x2160 plane (north-star target point) and a 32 x 1080p level (HBM-resident) ----
     fed_alone = None

@@ -85,8 +85,10 @@ def effective_cpus():
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (the first ~100 ms of a process run 2-3 % below the steady state -- clocks, buffer growth -- so the defaults warm
+    # up for ten steps and time forty: 0.3 s in all)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step (C4: 256 frames / 8 GPUs)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

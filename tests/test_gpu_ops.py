@@ -1,5 +1,7 @@
 """GPU parity tests, one per op of the C ABI, against the CPU oracle on the same seeded inputs.
 Bar: bit-exact (f32 results compared by value so that -0.0 == +0.0, NaNs never expected)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -212,6 +214,51 @@ def test_descriptor_match_ragged_sizes(ctx, ref, n0, n1):
             finally:
                 ctx.set_match_mode(2)
             assert np.array_equal(got, exp), (mode, ratio, thr, len(got), len(exp))
+
+
+@pytest.mark.parametrize("chunks_per_set", [None, 2, 3, 16])
+def test_descriptor_match_sets_chunked(ctx, ref, chunks_per_set):
+    """A multi-set launch with every set cut into several chunks (the form large sets take so that the workgroups fill
+    whole rounds of the chip; forced here through AKZ_MM_SET_CHUNKS): sets shorter than the chunk count leave chunks
+    empty, equal minima in different chunks must resolve to the lowest row, and the per-set pruning bound is shared by
+    the set's chunks."""
+    import torch
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (24, 61), dtype=np.uint8)
+
+    def make(n):
+        d = base[rng.integers(0, 24, n)].copy()  # many exact duplicates: ties across chunks
+        d[rng.random(d.shape) < 0.02] ^= 0x11
+        return d
+
+    def rows64(d):
+        r = np.zeros((len(d), 64), np.uint8)
+        r[:, :61] = d
+        return r
+
+    q = make(600)
+    sets = [make(n) for n in (1500, 1, 127, 0, 385, 2600)]
+    dq = torch.from_numpy(rows64(q)).cuda()
+    cat = torch.from_numpy(np.concatenate([rows64(t) for t in sets])).cuda()
+    old = os.environ.get("AKZ_MM_SET_CHUNKS")
+    try:
+        if chunks_per_set is None:
+            os.environ.pop("AKZ_MM_SET_CHUNKS", None)
+        else:
+            os.environ["AKZ_MM_SET_CHUNKS"] = str(chunks_per_set)
+        for ratio, thr in ((0.86, 10000), (1.3, 10000)):
+            out, cnt = ctx.descriptor_match_sets_device(dq, cat, [len(t) for t in sets], thr, ratio)
+            ctx.synchronize()
+            out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+            for k, t in enumerate(sets):
+                got = out[k][:int(cnt[k])].copy().view(ctx_match_dtype()).reshape(-1)
+                exp = ref.descriptor_match(q, t, thr, ratio)
+                assert np.array_equal(got, exp), (chunks_per_set, ratio, k, len(got), len(exp))
+    finally:
+        if old is None:
+            os.environ.pop("AKZ_MM_SET_CHUNKS", None)
+        else:
+            os.environ["AKZ_MM_SET_CHUNKS"] = old
 
 
 @pytest.mark.parametrize("mode", [1, 0])

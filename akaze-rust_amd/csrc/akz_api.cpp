@@ -994,7 +994,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     for (size_t i = 1; i < L; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
-        if (fork_octave > 0 && fork_level == L && (int)lv.octave >= fork_octave && (uint64_t)w * h * n >= fork_min_px) {
+        // (full stage profiling attributes time to stages: it keeps everything on one stream)
+        if (fork_octave > 0 && c->profiling < 2 && fork_level == L && (int)lv.octave >= fork_octave &&
+            (uint64_t)w * h * n >= fork_min_px) {
             if (!gate_recorded) {  // the previous batch's keypoint kernels may start here too
                 if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
                 AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));

@@ -742,7 +742,8 @@ def main_rank(args):
 
     if rank == 0:
         stage_ms = {k: round(warm_prof[k], 3) for k in A.STAGES}
-        stage_ms["note"] = "one untimed step with full stage profiling, un-pipelined; timed steps record FED and detector spans only"
+        stage_ms["note"] = ("one untimed step with full stage profiling, un-pipelined and on ONE stream (the coarse octaves' chain is "
+                            "not forked, so that every stage's time is its own); timed steps record FED and detector spans only")
         # algorithmic HBM bytes of each GPU stage of one step (SURVEY.md 8(d) model: every stage input read once, every
         # kept plane written once) against that stage's time in the profiled step: where the path stands kernel by kernel
         lv = A.plan_levels(W, H, cfg)

@@ -1,3 +1,8 @@
+// The column-march kernels of the pyramid (gfx950): k_detector_march (below), k_level_march (level preparation + the
+// level's first diffusion steps) and k_blur5_march (the level-0 blur).  They share the strip / band geometry, the
+// range-checked buffer accesses ("global memory" section) and the one-LDS-exchange-per-row structure described here
+// for the detector:
+//
 // Detector response of one level in ONE pass (detector_response.rs:8-55 + the extrema test of
 // scale_space_extrema.rs:32-42, :80-87): Lsmooth -> Lx, Ly -> Lxx, Lyy, Lxy -> Ldet -> candidates, as a column march.
 //

@@ -518,7 +518,7 @@ def main_rank(args):
 
     # ---- the FED kernel alone: 3840x2160 plane (north-star target point) and a 32 x 1080p level (HBM-resident) ----
     fed_alone = None
-    if rank == 0 and not args.no_fed4k:
+    if rank == 0 and world == 1 and not args.no_fed4k:  # N = 1 information
         fed_alone = {}
         for name, shape, nst in (("4k_plane", (2160, 3840), 40), ("level_32x1080p", (32, 1080, 1920), 8)):
             lt = torch.rand(shape, dtype=torch.float32, device=dev)
@@ -549,7 +549,7 @@ def main_rank(args):
     # re-reads the plane it read last time finds most of it in the 256 MB Infinity Cache and looks 25 % faster than any
     # launch of the pyramid, where every level's Lsmooth was written long before) ----
     det_alone = None
-    if rank == 0 and not args.no_fed4k and not args.lean:
+    if rank == 0 and world == 1 and not args.no_fed4k and not args.lean:
         n_, h_, w_ = 32, 1080, 1920
         pb = n_ * h_ * w_ * 4
         big = torch.empty(4 * 7 * pb + (1 << 21), dtype=torch.uint8, device=dev)  # carved like the product's slab

@@ -2186,6 +2186,13 @@ int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     return AKZ_OK;
 }
 const char* akz_fed_kernel_name(void) { return "k_level_march + k_fed_own"; }
+int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half_width, int32_t* rows, uint32_t cap,
+                          uint32_t* n_bands) {
+    if (!n_bands || (cap && !rows) || kind < 0 || kind > 1 || w < 16 || h < 16 || n == 0 || half_width < 1 || half_width > 4)
+        return AKZ_ERR_INVALID_ARG;
+    *n_bands = launch::march_band_rows(kind, w, h, n, half_width, rows, cap);
+    return AKZ_OK;
+}
 const char* akz_detector_kernel_name(void) { return "k_detector_march"; }
 
 }  // extern "C"

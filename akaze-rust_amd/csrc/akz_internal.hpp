@@ -160,6 +160,7 @@ bool blur5_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, bool is_u8);
 void blur5_stream_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
 void blur5_stream_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
 // streaming contrast-factor passes (akz_stream.hip): max and histogram of the gradient of blur(in) in two launches
+uint32_t march_band_rows(int kind, uint32_t w, uint32_t h, uint32_t n, int S, int32_t* cs_ce, uint32_t cap);  // test hook
 bool blur5_march_supported(uint32_t w, uint32_t h, uint32_t ntaps);  // akz_march.hip: the same blur as a column march
 void blur5_march_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
 void blur5_march_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);

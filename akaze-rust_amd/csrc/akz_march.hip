@@ -77,6 +77,20 @@ __device__ __forceinline__ int march_cell() {
     return (int)blockIdx.x;
 #endif
 }
+// Interior rows [cs, ce) of a band -- the one place the kernels and the host-side check (launch::march_band_rows) get
+// them from.  Detector / blur: uniform bands of band_rows rows from row S.  Level kernel: the first band has edge_rows
+// rows, the last one takes what is left (bands at the image's first and last rows run the loop with the border cases,
+// which is slower per row, and get fewer rows for it).
+__host__ __device__ __forceinline__ void uniform_band_rows(const MarchGrid& g, int band, int S, int h, int* cs, int* ce) {
+    *cs = S + band * g.band_rows;
+    const int e = *cs + g.band_rows;
+    *ce = e < h - S ? e : h - S;
+}
+__host__ __device__ __forceinline__ void level_band_rows(const MarchGrid& g, int band, int h, int* cs, int* ce) {
+    *cs = 1 + (band == 0 ? 0 : g.edge_rows + (band - 1) * g.band_rows);
+    const int e = *cs + (band == 0 ? g.edge_rows : g.band_rows);
+    *ce = band == g.nbands - 1 ? h - 1 : (e < h - 1 ? e : h - 1);
+}
 struct MarchNms {
     unsigned level;
     float thr;
@@ -267,7 +281,8 @@ k_detector_march(const float* __restrict__ ls, float* __restrict__ lx_out, float
     const int img = __builtin_amdgcn_readfirstlane(cell / per);
     const int rem = cell - img * per;
     const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
-    const int cs = S + band * g.band_rows, ce = min(cs + g.band_rows, h - S);  // interior rows of this band
+    int cs, ce;  // interior rows of this band
+    uniform_band_rows(g, band, S, h, &cs, &ce);
     if (cs >= ce) return;
 
     const int X0 = strip * USE - HALO;  // image column of position 0
@@ -469,8 +484,8 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
     // interior rows of Lsmooth / Lflow: the first band has edge_rows rows, the last one what is left (bands at the image's
     // first and last rows run the loop with the border cases, which is slower per row, and get fewer rows for it)
-    const int cs = 1 + (band == 0 ? 0 : g.edge_rows + (band - 1) * g.band_rows);
-    const int ce = band == g.nbands - 1 ? h - 1 : min(cs + (band == 0 ? g.edge_rows : g.band_rows), h - 1);
+    int cs, ce;
+    level_band_rows(g, band, h, &cs, &ce);
     if (cs >= ce) return;
     const int lt0 = cs == 1 ? 0 : cs, lt1 = ce == h - 1 ? h : ce;  // rows of Lt / Lstep (no filled border there)
 
@@ -695,7 +710,8 @@ k_blur5_march(const T* __restrict__ in, float* __restrict__ out, int w, int h, M
     const int img = __builtin_amdgcn_readfirstlane(cell / per);
     const int rem = cell - img * per;
     const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
-    const int cs = S + band * g.band_rows, ce = min(cs + g.band_rows, h - S);  // interior rows of this band
+    int cs, ce;  // interior rows of this band
+    uniform_band_rows(g, band, S, h, &cs, &ce);
     if (cs >= ce) return;
 
     const int X0 = strip * USE - HALO;
@@ -936,6 +952,21 @@ void blur5_march_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, ui
 }
 void blur5_march_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
     blur5_march_t<float>(s, in, out, w, h, n, k);
+}
+
+// Test hook (CPU): the bands the planners cut an n-image batch of w x h into -- kind 0: detector / blur march with
+// kernel half width S, kind 1: level march.  Writes up to cap [cs, ce) pairs, returns the number of bands.
+uint32_t march_band_rows(int kind, uint32_t w, uint32_t h, uint32_t n, int S, int32_t* cs_ce, uint32_t cap) {
+    dim3 gr;
+    const MarchGrid g = kind == 1 ? plan_level_march(w, h, n, &gr) : plan_march(w, h, n, S, &gr);
+    for (int b = 0; b < g.nbands && (uint32_t)b < cap; ++b) {
+        int cs, ce;
+        if (kind == 1) level_band_rows(g, b, (int)h, &cs, &ce);
+        else uniform_band_rows(g, b, S, (int)h, &cs, &ce);
+        cs_ce[2 * b] = cs;
+        cs_ce[2 * b + 1] = ce;
+    }
+    return (uint32_t)g.nbands;
 }
 
 bool level_march_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16 && (uint64_t)w * h <= (1ull << 28); }

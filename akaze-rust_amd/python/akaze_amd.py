@@ -153,6 +153,7 @@ def lib():
         "akz_descriptor_match": ([vp, vp, u64, vp, u64, u64, u64, f64, vp, pu64], i32),
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
         "akz_ctx_graph_probe": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, u32, pf64, pf64, pu64], i32),
+        "akz_debug_march_bands": ([i32, u32, u32, u32, i32, C.POINTER(i32), u32, pu32], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),

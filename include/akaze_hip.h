@@ -424,6 +424,12 @@ int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
    (may be NULL) the node count.  Results of the probe's extractions are discarded. */
 int akz_ctx_graph_probe(akz_ctx* ctx, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
                         uint32_t flags, uint32_t reps, double* ms_graph, double* ms_plain, uint64_t* graph_nodes);
+/* Diagnostics (host only, no GPU work): the row bands the column-march planners cut an n-image batch of w x h into.
+   kind 0: detector / blur march with filter half width `half_width` (interior rows half_width .. h-1-half_width),
+   kind 1: level march (interior rows 1 .. h-2; first and last band shorter).  Writes up to `cap` (first, end) row pairs
+   to rows, the number of bands to *n_bands.  Used by the CPU tests to check that the bands tile the rows exactly. */
+int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half_width, int32_t* rows, uint32_t cap,
+                          uint32_t* n_bands);
 /* names of the default FED kernel and of the detector kernel that large launches take (for bench / profiles) */
 const char* akz_fed_kernel_name(void);
 const char* akz_detector_kernel_name(void);

@@ -352,3 +352,32 @@ def test_rust_shim_covers_the_reference_api():
                  "types::keypoint::draw_keypoints_to_image", "types::feature_match::draw_matches",
                  "types::feature_match::Match", "types::keypoint::Keypoint", "types::keypoint::Descriptor"):
         assert name in api, name
+
+
+def test_march_bands_tile_the_rows(amd):
+    """The row bands of the column-march planners (host code; no GPU): for many heights, widths and batch sizes the
+    bands are non-empty, ascending, disjoint and cover exactly the interior rows -- [S, h-S) for the detector / blur
+    march, [1, h-1) for the level march with its shorter first and last band."""
+    import ctypes as C
+    lib = amd.lib()
+    rows = (C.c_int32 * 512)()
+    nb = C.c_uint32()
+    checked = 0
+    for kind, halves in ((0, (1, 2, 3, 4)), (1, (1,))):
+        for S in halves:
+            for h in (16, 17, 33, 64, 65, 100, 135, 270, 540, 1080, 1081, 2160, 4099):
+                for w, n in ((16, 1), (480, 1), (481, 3), (1920, 1), (1920, 32), (960, 32), (3840, 8), (240, 256)):
+                    if h < 4 * S + 8:
+                        continue
+                    assert lib.akz_debug_march_bands(kind, w, h, n, S, rows, 256, C.byref(nb)) == 0
+                    k = nb.value
+                    assert 1 <= k <= 256, (kind, S, w, h, n, k)
+                    lo, hi = (S, h - S) if kind == 0 else (1, h - 1)
+                    at = lo
+                    for b in range(k):
+                        cs, ce = rows[2 * b], rows[2 * b + 1]
+                        assert cs == at and ce > cs, (kind, S, w, h, n, b, cs, ce, at)
+                        at = ce
+                    assert at == hi, (kind, S, w, h, n, at, hi)
+                    checked += 1
+    assert checked > 300

@@ -78,6 +78,12 @@ struct akz_ctx {
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     hipStream_t coarse = nullptr;       // the coarse octaves' chain (diffusion + detectors), next to the fine detectors
+    // Lanes: child contexts (own streams, scratch planes, candidate slots) that small jobs are dealt to in turn, so that
+    // the launch chains of consecutive single frames -- 44 back-to-back launches of a few hundred workgroups each --
+    // overlap on the chip instead of queueing on one stream (akz_ctx_set_lanes).
+    std::vector<akz_ctx*> lanes;
+    unsigned next_lane = 0;
+    hipEvent_t lane_in = nullptr;       // inputs of the job are ready on the caller's stream
     // stage profiling (akz_ctx_set_profiling)
     uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
     int prep_mode = 2;  // level preparation: 0 LDS-tiled, 1 streaming, 2 auto (fused with the first diffusion steps for large launches), 3 fused wherever supported
@@ -262,6 +268,9 @@ int akz_stream_destroy(int device, void* stream) {
 int akz_ctx_destroy(akz_ctx* c) {
     if (!c) return AKZ_OK;
     (void)hipSetDevice(c->device);
+    for (akz_ctx* l : c->lanes) (void)akz_ctx_destroy(l);
+    c->lanes.clear();
+    if (c->lane_in) { (void)hipEventDestroy(c->lane_in); c->lane_in = nullptr; }
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
@@ -300,6 +309,7 @@ int akz_ctx_destroy(akz_ctx* c) {
 }
 int akz_ctx_synchronize(akz_ctx* c) {
     AKZ_TRY(bind(c));
+    for (akz_ctx* l : c->lanes) AKZ_TRY(akz_ctx_synchronize(l));
     AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
     return AKZ_OK;
 }
@@ -1547,13 +1557,55 @@ int akz_extract_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t
     return extract_impl<float>(c, d_imgs, w, h, n, cfg, flags, out);
 }
 
+// lanes = 1 (default): every job runs on the context's own stream.  lanes = k > 1: jobs below 8 Mpx are dealt to k child
+// contexts in turn (larger jobs fill the chip on their own and stay on the context).  A job's result belongs to the
+// lane it ran on; nothing else changes for the caller (same begin / finish / result calls, bit-identical results).
+int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
+    AKZ_TRY(bind(c));
+    if (lanes < 1 || lanes > 8) return AKZ_ERR_INVALID_ARG;
+    const size_t want = lanes == 1 ? 0 : lanes;
+    while (c->lanes.size() > want) {
+        AKZ_TRY(akz_ctx_destroy(c->lanes.back()));
+        c->lanes.pop_back();
+    }
+    while (c->lanes.size() < want) {
+        void* st = nullptr;
+        AKZ_TRY(akz_stream_create(c->device, &st));
+        akz_ctx* l = nullptr;
+        const int rc = akz_ctx_create(c->device, st, &l);
+        if (rc != AKZ_OK) {
+            (void)akz_stream_destroy(c->device, st);
+            return rc;
+        }
+        l->own_stream = true;
+        l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
+        l->cand_cap_hint = c->cand_cap_hint;
+        c->lanes.push_back(l);
+    }
+    c->next_lane = 0;
+    return AKZ_OK;
+}
+static int extract_begin_dispatch(akz_ctx* c, const void* d_imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
+                                  const akz_config* cfg, uint32_t flags, akz_job** out) {
+    akz_ctx* on = c;
+    if (c && !c->lanes.empty() && (uint64_t)w * h * n < (8u << 20)) {
+        AKZ_TRY(bind(c));
+        on = c->lanes[c->next_lane++ % c->lanes.size()];
+        // the lane starts when the caller's stream has reached this point (its inputs are complete)
+        if (!c->lane_in) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->lane_in, hipEventDisableTiming));
+        AKZ_HIP_TRY(hipEventRecord(c->lane_in, c->stream));
+        AKZ_HIP_TRY(hipStreamWaitEvent(on->stream, c->lane_in, 0));
+    }
+    return is_u8 ? extract_begin<uint8_t>(on, (const uint8_t*)d_imgs, w, h, n, cfg, flags, out)
+                 : extract_begin<float>(on, (const float*)d_imgs, w, h, n, cfg, flags, out);
+}
 int akz_extract_begin_device_u8(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n,
                                 const akz_config* cfg, uint32_t flags, akz_job** out) {
-    return extract_begin<uint8_t>(c, d_imgs, w, h, n, cfg, flags, out);
+    return extract_begin_dispatch(c, d_imgs, true, w, h, n, cfg, flags, out);
 }
 int akz_extract_begin_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t h, uint32_t n,
                                  const akz_config* cfg, uint32_t flags, akz_job** out) {
-    return extract_begin<float>(c, d_imgs, w, h, n, cfg, flags, out);
+    return extract_begin_dispatch(c, d_imgs, false, w, h, n, cfg, flags, out);
 }
 int akz_extract_finish(akz_job* job, akz_result** out) { return extract_finish(job, out); }
 // Measurement hook (bench.py `single_frame.graph`): is a lone frame's begin phase — a chain of ~45 dependent
@@ -2159,30 +2211,35 @@ int akz_write_evolutions(const akz_result* r, uint64_t img, const char* dir) {
 int akz_ctx_set_detector_mode(akz_ctx* c, int mode) {
     if (!c || (mode != 0 && mode != 2 && mode != 4 && mode != 5)) return AKZ_ERR_INVALID_ARG;
     c->det_mode = mode;
+    for (akz_ctx* l : c->lanes) l->det_mode = mode;
     return AKZ_OK;
 }
 
 int akz_ctx_set_prep_mode(akz_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 3) return AKZ_ERR_INVALID_ARG;
     c->prep_mode = mode;
+    for (akz_ctx* l : c->lanes) l->prep_mode = mode;
     return AKZ_OK;
 }
 
 int akz_ctx_set_candidate_hint(akz_ctx* c, uint32_t per_image) {
     AKZ_TRY(bind(c));
     c->cand_cap_hint = std::max<uint32_t>(per_image, 16u);
+    for (akz_ctx* l : c->lanes) l->cand_cap_hint = c->cand_cap_hint;
     return AKZ_OK;
 }
 int akz_ctx_set_match_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
     if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
     c->match_mode = mode;
+    for (akz_ctx* l : c->lanes) l->match_mode = mode;
     return AKZ_OK;
 }
 int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
     if (mode != 0 && mode != 2) return AKZ_ERR_INVALID_ARG;
     c->fed_mode = mode;
+    for (akz_ctx* l : c->lanes) l->fed_mode = mode;
     return AKZ_OK;
 }
 const char* akz_fed_kernel_name(void) { return "k_level_march + k_fed_own"; }

@@ -154,6 +154,7 @@ def lib():
         "akz_descriptor_match_device": ([vp, vp, u64, vp, u64, u64, f64, vp, vp], i32),
         "akz_ctx_graph_probe": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, u32, pf64, pf64, pu64], i32),
         "akz_debug_march_bands": ([i32, u32, u32, u32, i32, C.POINTER(i32), u32, pu32], i32),
+        "akz_ctx_set_lanes": ([vp, u32], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
@@ -317,6 +318,11 @@ class Context:
         """Room for extrema candidates per image in the next extraction (a list that overflows is enlarged and the
         extrema pass repeated by finish: same results)."""
         _check(lib().akz_ctx_set_candidate_hint(self._h, int(per_image)))
+
+    def set_lanes(self, lanes):
+        """Deal jobs below 8 Mpx to `lanes` child contexts in turn (1 = off): the launch chains of consecutive single
+        frames then overlap on the chip."""
+        _check(lib().akz_ctx_set_lanes(self._h, int(lanes)))
 
     def set_match_mode(self, mode):
         """2 = automatic (default), 1 = matrix-core matcher, 0 = popcount matcher."""

@@ -215,6 +215,9 @@ class _StubContext:
     def extract_begin(self, batch, cfg, keep_all_planes=True):
         return _StubJob([100 + 7 * self.rank + i for i in range(int(batch.shape[0]))])
 
+    def set_lanes(self, *_):
+        pass
+
     def set_profiling(self, *_):
         pass
 
@@ -678,6 +681,23 @@ def main_rank(args):
         single = {"workload": f"one {W}x{H} frame per extract_features call (BASELINE configs[1])",
                   "latency_ms": round(lat * 1e3, 3), "stream_ms_per_frame": round(thr * 1e3, 3),
                   "stream_Mpix_s": round(W * H / thr / 1e6, 1)}
+        # the same stream on ONE context with lanes: frames dealt to 2 / 4 child contexts, that many begun ahead
+        single["lanes"] = {}
+        for lanes in (2, 4):
+            ctx.set_lanes(lanes)
+            for _ in range(2 * lanes):
+                ctx.extract_begin(one, cfg, keep_all_planes=not args.lean).finish().close()
+            t1 = time.perf_counter()
+            pending = []
+            for _ in range(reps):
+                pending.append(ctx.extract_begin(one, cfg, keep_all_planes=not args.lean))
+                if len(pending) > lanes:
+                    pending.pop(0).finish().close()
+            while pending:
+                pending.pop(0).finish().close()
+            thr_l = (time.perf_counter() - t1) / reps
+            single["lanes"][str(lanes)] = {"stream_ms_per_frame": round(thr_l * 1e3, 3), "stream_Mpix_s": round(W * H / thr_l / 1e6, 1)}
+        ctx.set_lanes(1)
         try:  # the begin phase (scale space, detector, extrema) as one hipGraph launch against the plain launch chain
             g_ms, p_ms, nodes = ctx.graph_probe(one, cfg, keep_all_planes=not args.lean, reps=50)
             single["graph"] = {"begin_phase_graph_ms": round(g_ms, 3), "begin_phase_plain_ms": round(p_ms, 3), "graph_nodes": nodes,

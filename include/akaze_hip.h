@@ -404,6 +404,13 @@ int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
    repeats the extrema pass on the stored Ldet planes — results are the same, the call is slower; the setter
    exists so that this path can be tested and so that callers with very dense frames can skip the retry. */
 int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
+/* Lanes for small jobs.  A lone 1080p frame is a chain of ~45 launches of a few hundred workgroups each: the chip is busy
+   but only a fraction of it at a time.  With lanes = k (2..8) the extract_begin calls of jobs below 8 Mpx are dealt in
+   turn to k child contexts with their own streams, scratch planes and candidate buffers, so that the chains of
+   consecutive frames overlap; larger jobs, and everything at lanes = 1 (default), run on the context's own stream.
+   The caller's stream is respected (a lane starts behind what the caller enqueued before the call); results are
+   bit-identical and are used through the same calls. */
+int akz_ctx_set_lanes(akz_ctx* ctx, uint32_t lanes);
 /* Matcher kernel: 2 (default) and 1 = matrix-core kernel (k_match_mfma: descriptor bits unpacked to int8,
    Hamming distances from one integer GEMM; faster than the popcount scan from 128 x 128 descriptors up),
    0 = popcount kernel (k_match).  Results are identical. */

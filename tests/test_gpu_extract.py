@@ -162,6 +162,34 @@ def test_begin_finish_pipelined_matches_oracle(ctx, amd, ref):
     assert_same_result(r, ref.extract(fa[0]), planes=False)
 
 
+def test_lanes_stream_of_single_frames(amd, ref):
+    """akz_ctx_set_lanes: single frames dealt to three child contexts, several jobs in flight, results identical to the
+    oracle in every plane; a batch above the lane threshold runs on the context itself; lanes can be changed between
+    jobs and the context is destroyed with results of its lanes still alive."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_lanes(3)
+    frames = [amd.synth_frame(640, 360, 40 + i) for i in range(7)]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    jobs = [c.extract_begin(d) for d in dev[:5]]          # five jobs in flight over three lanes
+    res = [j.finish() for j in jobs]
+    jobs = [c.extract_begin(d) for d in dev[5:]]
+    res += [j.finish() for j in jobs]
+    for f, r in zip(frames, res):
+        assert_same_result(r, ref.extract(f), planes=True)
+    big = np.stack([amd.synth_frame(1920, 1080, i) for i in range(5)])  # 10 Mpx: not dealt to a lane
+    rb = c.extract_begin(torch.from_numpy(big).cuda()).finish()
+    assert_same_result(rb, ref.extract(big[4], threads=8), planes=False, img=4)
+    c.set_lanes(1)
+    r1 = c.extract_begin(dev[0]).finish()
+    assert_same_result(r1, ref.extract(frames[0]), planes=False)
+    c.set_lanes(2)
+    r2 = c.extract_begin(dev[1]).finish()
+    c.close()                                             # results of lanes outlive the context
+    assert r2.keypoints(0).tobytes() == res[1].keypoints(0).tobytes()
+    assert r2.descriptors(0).tobytes() == res[1].descriptors(0).tobytes()
+
+
 def test_baseline_c2_1080p_frame(ctx, amd, ref):
     """BASELINE.json configs[1]: one 1920x1080 synthetic frame, 4 octaves x 4 sublevels."""
     frame = amd.synth_frame(1920, 1080, 0)

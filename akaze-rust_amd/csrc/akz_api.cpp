@@ -1001,6 +1001,26 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         ~StreamRestore() { c->stream = main; }
     } stream_restore{c, s};
     size_t fork_level = L;  // first level of the coarse chain
+    // Resident tail: from the first level whose image fits one compute unit, ALL remaining levels (preparation and
+    // every diffusion step, across octaves) are one launch with one workgroup per image (akz_resident.hip).
+    size_t res_first = L;
+    if (c->fed_mode == 2 && c->prep_mode >= 2) {
+        size_t f = 1;
+        while (f < L && !launch::octave_resident_supported(plan[f].w, plan[f].h)) ++f;
+        f = std::max(f, L > (size_t)launch::kResidentMaxLevels ? L - (size_t)launch::kResidentMaxLevels : (size_t)1);
+        size_t steps = 0;
+        bool ok = true;
+        for (size_t l = L; l-- > f;) {
+            if (plan[l].tau.empty()) ok = false;
+            steps += plan[l].tau.size();
+            if (steps > (size_t)launch::kResidentMaxSteps) {  // keep the tail that fits
+                steps -= plan[l].tau.size();
+                f = l + 1;
+                break;
+            }
+        }
+        if (ok && f < L) res_first = f;
+    }
     for (size_t i = 1; i < L; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
@@ -1020,6 +1040,26 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             fork_level = i;
             ls = c->coarse;
             c->stream = c->coarse;
+        }
+        if (i == res_first) {
+            std::vector<launch::ResidentLevel> rl;
+            std::vector<std::vector<float>> ht(L);
+            uint64_t px_steps = 0;
+            for (size_t l = i; l < L; ++l) {
+                for (double t : plan[l].tau) ht[l].push_back(0.5f * (float)t);
+                rl.push_back(launch::ResidentLevel{P(l, AKZ_LT), P(l, AKZ_LSMOOTH), P(l, AKZ_LFLOW), keep_all ? P(l, AKZ_LSTEP) : nullptr,
+                                                   plan[l].w, plan[l].h, plan[l].octave > plan[l - 1].octave,
+                                                   (uint32_t)plan[l].tau.size(), ht[l].data(), plan[l].octave});
+                px_steps += (uint64_t)plan[l].w * plan[l].h * n * plan[l].tau.size();
+            }
+            StageTimer st(c, AKZ_ST_FED);
+            launch::octave_resident(ls, P(i - 1, AKZ_LT), pv.w, pv.h, n, rl.data(), (uint32_t)rl.size(), g1.data(), r->d_k);
+            if (c->profiling) {
+                c->prof.fed_launches += 1;
+                c->prof.fed_px_steps += px_steps;
+            }
+            AKZ_HIP_TRY(hipGetLastError());
+            break;
         }
         float* A = P(i, AKZ_LT);
         float* B = (float*)c->scratch[5].p;

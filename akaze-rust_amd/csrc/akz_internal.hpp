@@ -181,6 +181,21 @@ bool level_march_supported(uint32_t w, uint32_t h);
 void level_march(hipStream_t s, const float* prev, float* lsmooth, float* lflow, float* lt_out, float* lstep, uint32_t w,
                  uint32_t h, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow, const float* half_taus,
                  uint32_t n_steps);
+// the remaining levels of the pyramid, from the first one whose image fits a compute unit, in ONE launch with one
+// workgroup per image (akz_resident.hip, k_octave_resident): preparation and every diffusion step of every level
+struct ResidentLevel {
+    float *lt, *lsmooth, *lflow, *lstep;  // image 0 of the batch; lstep may be null
+    uint32_t w, h;
+    bool half;              // the level opens an octave (2x2 mean of the previous level's final Lt)
+    uint32_t n_tau;         // >= 1
+    const float* half_tau;  // 0.5f * (tau as f32) per step
+    uint32_t k_pow;         // octave
+};
+constexpr int kResidentMaxLevels = 10;
+constexpr int kResidentMaxSteps = 448;
+bool octave_resident_supported(uint32_t w, uint32_t h);
+void octave_resident(hipStream_t s, const float* prev, uint32_t pw, uint32_t ph, uint32_t n, const ResidentLevel* levels,
+                     uint32_t n_levels, const float* g3, const double* d_k);
 bool detector_nms_fused_supported(uint32_t sigma);
 void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,

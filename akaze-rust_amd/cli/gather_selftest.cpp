@@ -136,9 +136,22 @@ int main(int argc, char** argv) {
         }
         TRY(akz_gather_free(g));
     }
-    // (3) a shard that does not fit the agreed capacity is refused, not truncated
-    akz_gather* g3 = nullptr;
-    CHECK(akz_gather_begin_rows(comm, d_rows, rows, rows - 1, nullptr, &g3) == AKZ_ERR_BUFFER && g3 == nullptr);
+    // (3) a shard that does not fit the agreed capacity: the rank still takes part in the collective (header only), EVERY
+    // rank gets AKZ_ERR_BUFFER from finish together with the counts, and the communicator stays usable
+    uint64_t largest = 0;
+    for (uint64_t v : counts) largest = v > largest ? v : largest;
+    if (largest > 0) {
+        akz_gather* g3 = nullptr;
+        TRY(akz_gather_begin_rows(comm, d_rows, rows, largest - 1, nullptr, &g3));
+        std::vector<uint64_t> c3((size_t)nranks, 0);
+        CHECK(akz_gather_finish(g3, nullptr, nullptr, c3.data(), nullptr) == AKZ_ERR_BUFFER);
+        for (int r = 0; r < nranks; ++r) CHECK(c3[(size_t)r] == counts[(size_t)r]);
+        TRY(akz_gather_free(g3));
+        akz_gather* g4 = nullptr;
+        TRY(akz_gather_begin_rows(comm, d_rows, rows, largest, nullptr, &g4));
+        TRY(akz_gather_finish(g4, nullptr, nullptr, c3.data(), nullptr));
+        TRY(akz_gather_free(g4));
+    }
 
     TRY(akz_result_free(res));
     TRY(akz_device_free(ctx, d_frames));

@@ -64,6 +64,7 @@ struct akz_ctx {
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
     int match_mode = 2;                      // 0: popcount kernel, 1 / 2 (default): matrix-core kernel (akz_ctx_set_match_mode)
+    uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
     DevBuf cosi;                             // (cos, sin) per keypoint
     DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
                                              // rows, keypoint params, (cos, sin), contrast factors
@@ -445,11 +446,8 @@ static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t 
     AKZ_TRY(taps_from_dense(k.data(), (uint32_t)k.size(), t));
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
     constexpr bool is_u8 = std::is_same<T, uint8_t>::value;
-    // large batches: the column march (HBM-bound: 0.33 GB of a 32-frame 1080p batch); AKZ_BLUR_MARCH_MIN_PX moves the threshold
-    static const uint64_t blur_march_min_px = [] {
-        const char* e = std::getenv("AKZ_BLUR_MARCH_MIN_PX");
-        return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
-    }();
+    // large batches: the column march (HBM-bound: 0.33 GB of a 32-frame 1080p batch)
+    constexpr uint64_t blur_march_min_px = 8u << 20;
     if ((const void*)d_in != (const void*)d_out && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= blur_march_min_px)) &&
         launch::blur5_march_supported(w, h, (uint32_t)k.size())) {
         if constexpr (is_u8) launch::blur5_march_u8(c->stream, d_in, d_out, w, h, n, k.data());
@@ -533,14 +531,11 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
 
 // FED launch plan: the level's n_tau steps are cut into ceil(n_tau / 8) launches of balanced size.
 // Small launches (a lone frame's coarse octaves: 4 to 72 workgroups, every launch at the floor of a dependent
-// dispatch) fuse up to 16 steps on flat 64 x 10 tiles instead: half the launches of a level (AKZ_FED_DEEP_WGS: the
-// largest launch, in workgroups, that takes this form; 0 disables).
+// dispatch) fuse up to 16 steps on flat 64 x 10 tiles instead: half the launches of a level (launches of at most 512
+// workgroups take this form).
 static constexpr uint32_t kFedMaxFuse = 8;
 static uint32_t fed_max_fuse(const akz_ctx* c, uint32_t w, uint32_t h, uint32_t n) {
-    static const uint64_t deep_wgs = [] {
-        const char* e = std::getenv("AKZ_FED_DEEP_WGS");
-        return e ? (uint64_t)std::atoll(e) : (uint64_t)512;
-    }();
+    constexpr uint64_t deep_wgs = 512;
     return c->fed_mode == 2 && launch::fed_deep_workgroups(w, h, n) <= deep_wgs ? 2 * kFedMaxFuse : kFedMaxFuse;
 }
 static uint32_t fed_num_launches(const akz_ctx* c, uint32_t n_tau, uint32_t w, uint32_t h, uint32_t n) {
@@ -595,17 +590,14 @@ static int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float
 // frames, where extract_begin also groups levels of equal sigma_size into one launch), 5 = the one-pass column march
 // (k_detector_march, akz_march.hip: large launches).  Measured on MI355X per level of a 32-frame batch, all planes
 // kept (tools/march_probe.py, microseconds, sigma_size 3): 1920x1080 555 / 503 / 350, 960x540 140 / 124 / 82,
-// 480x270 45 / 41 / 66 (pair / tiled / march).  AKZ_MARCH_MIN_PX overrides the size from which the march is taken.
+// 480x270 45 / 41 / 66 (pair / tiled / march): the march from 8 Mpx per launch on.
 static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m,
                            bool keep_second, bool nms = true) {
     (void)keep_second;
     if (c->det_mode == 0) return 0;
     if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;
     if (c->det_mode == 5) return launch::detector_march_supported(sigma, w, h, border_m, nms) ? 5 : 0;
-    static const uint64_t march_min = [] {
-        const char* e = getenv("AKZ_MARCH_MIN_PX");
-        return e ? (uint64_t)atoll(e) : (uint64_t)(8u << 20);
-    }();
+    constexpr uint64_t march_min = 8u << 20;
     const uint64_t px = (uint64_t)w * h * n;
     if (px >= march_min && launch::detector_march_supported(sigma, w, h, border_m, nms)) return 5;
     if (px < march_min && launch::detector_tiled_fused_supported(sigma)) return 4;
@@ -984,16 +976,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // chain moves to a second stream when octave fork_octave - 1 is finished, and the main stream goes straight to the
     // detectors of the fine octaves (bandwidth-bound, 2.2 ms): the two run side by side and join before the candidate
     // list is read.  (Running two BIG kernels side by side is a loss -- see above -- so the fork is at octave 2.)
-    static const int fork_octave = [] {
-        const char* e = std::getenv("AKZ_FORK_OCTAVE");  // 0: no fork
-        return e ? std::atoi(e) : 2;
-    }();
+    constexpr int fork_octave = 2;
     // (a lone 1080p frame is a chain of dependent launches either way and only pays for the two events: measured
     // 0.596 -> 0.625 ms per streamed frame; batches from 8 Mpx on fork)
-    static const uint64_t fork_min_px = [] {
-        const char* e = std::getenv("AKZ_FORK_MIN_PX");
-        return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
-    }();
+    constexpr uint64_t fork_min_px = 8u << 20;
     hipStream_t ls = s;  // the stream the level loop enqueues on
     struct StreamRestore {  // the helpers (fed_impl, StageTimer, ...) enqueue on c->stream
         akz_ctx* c;
@@ -1003,8 +989,12 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     size_t fork_level = L;  // first level of the coarse chain
     // Resident tail: from the first level whose image fits one compute unit, ALL remaining levels (preparation and
     // every diffusion step, across octaves) are one launch with one workgroup per image (akz_resident.hip).
+    // One workgroup advances an image by one diffusion step in ~2 us whatever the batch size, so a lone frame, whose
+    // launch chain is bound by latency, keeps the separate launches (octave 3 of a 1080p frame: 0.11 ms as 12 launches
+    // against 0.32 ms resident); a batch that forks its coarse chain onto the second stream hides that latency under
+    // the fine detectors and gains what the 17 small launches cost those detectors (5.9 -> 5.3 ms per 32-frame step).
     size_t res_first = L;
-    if (c->fed_mode == 2 && c->prep_mode >= 2) {
+    if (c->fed_mode == 2 && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= fork_min_px))) {
         size_t f = 1;
         while (f < L && !launch::octave_resident_supported(plan[f].w, plan[f].h)) ++f;
         f = std::max(f, L > (size_t)launch::kResidentMaxLevels ? L - (size_t)launch::kResidentMaxLevels : (size_t)1);
@@ -1077,10 +1067,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         // Large launches of levels that diffuse: preparation and the first (up to four) diffusion steps in ONE launch of
         // k_level_march (akz_march.hip) — Lt is read once for both, 4 B read + 12 (+4) B written per pixel instead of
         // 12 + 12 (+4); a new octave's 2x2 mean is materialised first.  Remaining steps follow in k_fed_own launches.
-        static const uint64_t level_min_px = [] {
-            const char* e = std::getenv("AKZ_LEVEL_MIN_PX");
-            return e ? (uint64_t)std::atoll(e) : (uint64_t)(8u << 20);
-        }();
+        constexpr uint64_t level_min_px = 8u << 20;
         const bool fuse_level = n_tau >= 1 && c->fed_mode == 2 && launch::level_march_supported(lv.w, lv.h) &&
                                 (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)lv.w * lv.h * n >= level_min_px));
         if (fuse_level) {
@@ -1322,26 +1309,10 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
     uint64_t total_kp = 0;
     r->desc_off.assign(n + 1, 0);
     {
-        static const bool host_timing = std::getenv("AKZ_HOST_TIMING") != nullptr;  // per-call breakdown on stderr
-        std::atomic<long> t_sort_us{0}, t_sel_us{0};
-        auto work = [&](uint32_t img) {
-            const double t0 = host_timing ? now_ms() : 0.0;
+        c->pool().run(n, [&](size_t img) {  // images are independent
             sort_candidates(cands[img], plan);
-            const double t1 = host_timing ? now_ms() : 0.0;
             select_keypoints(cands[img], plan, cfg, hk[img], &r->n_extrema[img]);
-            if (host_timing) {
-                t_sort_us += (long)((t1 - t0) * 1e3);
-                t_sel_us += (long)((now_ms() - t1) * 1e3);
-            }
-        };
-        c->pool().run(n, [&](size_t img) { work((uint32_t)img); });  // images are independent
-        if (host_timing) {
-            size_t tc = 0, tk = 0;
-            for (uint32_t img = 0; img < n; ++img) { tc += cands[img].size(); tk += hk[img].size(); }
-            fprintf(stderr, "[akz host] %u images, %zu candidates -> %zu keypoints; wall %.2f ms (fetch + bucketing before: %.2f ms); "
-                    "summed over images: sort %.2f ms, select %.2f ms\n", n, tc, tk, now_ms() - t_host0, t_host0 - t_counts,
-                    t_sort_us.load() / 1e3, t_sel_us.load() / 1e3);
-        }
+        });
     }
     for (uint32_t img = 0; img < n; ++img) {
         r->desc_off[img] = total_kp;
@@ -1604,6 +1575,13 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
     AKZ_TRY(bind(c));
     if (lanes < 1 || lanes > 8) return AKZ_ERR_INVALID_ARG;
     const size_t want = lanes == 1 ? 0 : lanes;
+    // a lane that goes away must have no extraction in flight: its job would be finished on destroyed streams
+    for (size_t i = want; i < c->lanes.size(); ++i)
+        for (int k = 0; k < akz_ctx::kSlots; ++k)
+            if (c->lanes[i]->slot_busy[k]) {
+                set_error("akz_ctx_set_lanes: a lane that would be removed has an extraction in flight (finish or abandon it first)");
+                return AKZ_ERR_INVALID_ARG;
+            }
     while (c->lanes.size() > want) {
         AKZ_TRY(akz_ctx_destroy(c->lanes.back()));
         c->lanes.pop_back();
@@ -1620,6 +1598,10 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->own_stream = true;
         l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
         l->cand_cap_hint = c->cand_cap_hint;
+        l->stream_min_px = c->stream_min_px;
+        l->profiling = c->profiling;
+        l->dbg_pair_chunks = c->dbg_pair_chunks;
+        l->dbg_set_chunks = c->dbg_set_chunks;
         c->lanes.push_back(l);
     }
     c->next_lane = 0;
@@ -1986,7 +1968,7 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
     // popcount kernel at 128 x 128, 35 against 190 at 1024 x 1024, 3.0 ms against 9.9 at 90 K x 90 K; mode 0 keeps the
     // popcount kernel selectable
     const bool mfma = n0 && n1 && c->match_mode != 0 && rows_le_61;
-    const uint32_t chunks = mfma ? launch::match_mfma_chunks((uint32_t)n0, (uint32_t)n1)
+    const uint32_t chunks = mfma ? launch::match_mfma_chunks((uint32_t)n0, (uint32_t)n1, c->dbg_pair_chunks)
                                  : launch::match_num_chunks((uint32_t)n0, (uint32_t)n1);
     AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * (chunks + 1) * sizeof(MatchRec)));
     MatchRec* rec = (MatchRec*)c->match_rec.p;  // [chunk][query], then the merged records
@@ -2058,8 +2040,10 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     std::vector<uint32_t> tiles;  // {first source row, valid rows} per tile
     // every set is cut into `cps` chunks (ascending rows; a short set leaves its last chunks empty) so that the
     // workgroups fill whole rounds of the chip; the chunks of a set share its pruning bounds
-    const uint32_t cps = launch::match_mfma_multi_chunks((uint32_t)n0, (uint32_t)n_sets,
-                                                         (uint32_t)((total_rows / n_sets + tr - 1) / tr));
+    // (chunks are the launch's gridDim.y: at most 65535 of them)
+    const uint32_t cps = std::max(1u, std::min(launch::match_mfma_multi_chunks((uint32_t)n0, (uint32_t)n_sets,
+                                                                               (uint32_t)((total_rows / n_sets + tr - 1) / tr), c->dbg_set_chunks),
+                                               65535u / (uint32_t)n_sets));
     std::vector<launch::MatchChunkHost> chunks((size_t)n_sets * cps);
     uint64_t src = 0;
     for (uint64_t k = 0; k < n_sets; ++k) {
@@ -2172,6 +2156,7 @@ int akz_ctx_set_profiling(akz_ctx* c, int on) {
     AKZ_TRY(bind(c));
     if (on < 0 || on > 2) return AKZ_ERR_INVALID_ARG;
     c->profiling = on == 1 ? 2 : on == 2 ? 1 : 0;  // API: 1 = all stages, 2 = light (FED spans only)
+    for (akz_ctx* l : c->lanes) l->profiling = c->profiling;
     return AKZ_OK;
 }
 int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
@@ -2181,6 +2166,18 @@ int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
     resolve_spans(c);
     *out = c->prof;
     if (reset) c->prof = akz_profile{};
+    for (akz_ctx* l : c->lanes) {  // jobs dealt to the lanes are part of this context's profile
+        akz_profile p{};
+        AKZ_TRY(akz_ctx_get_profile(l, &p, reset));
+        for (size_t i = 0; i < sizeof(p.ms) / sizeof(p.ms[0]); ++i) out->ms[i] += p.ms[i];
+        out->calls += p.calls;
+        out->pixels += p.pixels;
+        out->fed_launches += p.fed_launches;
+        out->fed_px_steps += p.fed_px_steps;
+        out->det_launches += p.det_launches;
+        out->det_px += p.det_px;
+        out->fused_px += p.fused_px;
+    }
     return AKZ_OK;
 }
 int akz_remove_outliers(const akz_keypoint*, uint64_t, const akz_keypoint*, uint64_t, const akz_match*, uint64_t, uint64_t,
@@ -2291,5 +2288,15 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
     return AKZ_OK;
 }
 const char* akz_detector_kernel_name(void) { return "k_detector_march"; }
+int akz_debug_set_match_chunks(akz_ctx* c, uint32_t pair_chunks, uint32_t set_chunks) {
+    if (!c || set_chunks > 16) return AKZ_ERR_INVALID_ARG;
+    c->dbg_pair_chunks = pair_chunks;
+    c->dbg_set_chunks = set_chunks;
+    for (akz_ctx* l : c->lanes) {
+        l->dbg_pair_chunks = pair_chunks;
+        l->dbg_set_chunks = set_chunks;
+    }
+    return AKZ_OK;
+}
 
 }  // extern "C"

@@ -8,7 +8,12 @@
 // has no link-time dependency on it, so single-GPU users never load a communication library.
 //
 // Wire format: ONE all-gather per exchange.  Every rank contributes a block of (1 + cap_rows) 64-byte rows: row 0 is a
-// header {u64 rows, u64 images, u64 cap_rows, u64 sequence}, rows 1.. are its descriptor rows, the rest is padding.
+// header {u64 rows, u64 images, u64 cap_rows, u64 sequence, u64 overflow}, rows 1.. are its descriptor rows, the rest is
+// padding.  A rank whose shard does not fit cap_rows STILL takes part in the collective: it sends the header alone with
+// `overflow` set and `rows` = what it needed, and akz_gather_finish reports AKZ_ERR_BUFFER on EVERY rank (with the
+// counts filled in, so that all ranks can agree on a larger capacity and repeat the exchange).  What no rank can
+// detect before the collective is a DIFFERENT cap_rows on different ranks -- the message sizes then differ, which RCCL
+// does not survive: cap_rows is part of the job's contract, and the header check in finish is best effort only.
 // A few MB per rank: latency-bound over xGMI, so one fixed-size collective beats exact-size send/recv pairs.
 //
 // Nothing here synchronises the extraction stream: the local rows are copied on the communicator's copy stream, the
@@ -98,6 +103,7 @@ struct akz_gather {
     hipEvent_t done = nullptr;
     uint64_t* pinned = nullptr;  // header staging: 8 u64 per rank
     bool in_use = false;
+    bool overflow = false;     // this rank's shard did not fit: it sent its header only
 };
 
 struct akz_comm {
@@ -126,13 +132,13 @@ static void gather_release_buffers(akz_gather* g) {
 static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
     akz_gather* g = nullptr;
     for (akz_gather* p : c->pool)
-        if (!p->in_use && p->cap_rows == cap_rows) {
+        if (!p->in_use && p->send && p->cap_rows == cap_rows) {
             g = p;
             break;
         }
     if (!g) {
         for (akz_gather* p : c->pool)
-            if (!p->in_use) {  // a free object of another capacity: rebuild it
+            if (!p->in_use) {  // a free object of another capacity (or one whose allocation failed earlier): rebuild it
                 gather_release_buffers(p);
                 g = p;
                 break;
@@ -142,16 +148,25 @@ static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
             g->comm = c;
             c->pool.push_back(g);
         }
+        // the object matches a capacity only once every buffer exists: a failure part-way leaves it free and empty
+        g->cap_rows = ~0ull;
+        const size_t send_bytes = (size_t)(1 + cap_rows) * kRow, recv_bytes = send_bytes * (size_t)c->nranks;
+        const bool ok = hipMalloc((void**)&g->send, send_bytes) == hipSuccess && hipMalloc((void**)&g->recv, recv_bytes) == hipSuccess &&
+                        hipMemsetAsync(g->send, 0, send_bytes, c->cs) == hipSuccess &&  // no uninitialised bytes on the wire
+                        hipHostMalloc((void**)&g->pinned, (size_t)c->nranks * kRow + kRow, hipHostMallocDefault) == hipSuccess &&
+                        hipEventCreateWithFlags(&g->done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            gather_release_buffers(g);
+            set_error("gather: allocating the exchange buffers failed");
+            return AKZ_ERR_HIP;
+        }
         g->cap_rows = cap_rows;
-        g->send_bytes = (size_t)(1 + cap_rows) * kRow;
-        g->recv_bytes = g->send_bytes * (size_t)c->nranks;
-        AKZ_HIP_TRY(hipMalloc((void**)&g->send, g->send_bytes));
-        AKZ_HIP_TRY(hipMalloc((void**)&g->recv, g->recv_bytes));
-        AKZ_HIP_TRY(hipMemsetAsync(g->send, 0, g->send_bytes, c->cs));  // no uninitialised bytes on the wire
-        AKZ_HIP_TRY(hipHostMalloc((void**)&g->pinned, (size_t)c->nranks * kRow + kRow, hipHostMallocDefault));
-        AKZ_HIP_TRY(hipEventCreateWithFlags(&g->done, hipEventDisableTiming));
+        g->send_bytes = send_bytes;
+        g->recv_bytes = recv_bytes;
     }
     g->in_use = true;
+    g->overflow = false;
     *out = g;
     return AKZ_OK;
 }
@@ -162,10 +177,9 @@ static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_sr
                           uint64_t images, hipStream_t producer, bool wait_copy) {
     uint64_t rows = 0;
     for (uint64_t i = 0; i < n_src; ++i) rows += src_rows[i];
-    if (rows > g->cap_rows) {
-        set_error("gather: the local shard has more descriptor rows than the agreed capacity");
-        return AKZ_ERR_BUFFER;
-    }
+    // a shard that does not fit still takes part (header only, marked): a rank that skipped the collective would leave
+    // every other rank waiting in it, and every later collective of the communicator mismatched
+    g->overflow = rows > g->cap_rows;
     if (producer) {  // the rows are complete in the order of this stream
         AKZ_HIP_TRY(hipEventRecord(c->ready, producer));
         AKZ_HIP_TRY(hipStreamWaitEvent(c->cs, c->ready, 0));
@@ -175,10 +189,11 @@ static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_sr
     hdr[1] = images;
     hdr[2] = g->cap_rows;
     hdr[3] = ++c->sequence;
-    hdr[4] = hdr[5] = hdr[6] = hdr[7] = 0;
+    hdr[4] = g->overflow ? 1 : 0;
+    hdr[5] = hdr[6] = hdr[7] = 0;
     AKZ_HIP_TRY(hipMemcpyAsync(g->send, hdr, kRow, hipMemcpyHostToDevice, c->cs));
     uint64_t at = 1;
-    for (uint64_t i = 0; i < n_src; ++i) {
+    for (uint64_t i = 0; i < n_src && !g->overflow; ++i) {
         if (src_rows[i] == 0) continue;
         AKZ_HIP_TRY(hipMemcpyAsync(g->send + at * kRow, d_src[i], src_rows[i] * kRow, hipMemcpyDeviceToDevice, c->cs));
         at += src_rows[i];
@@ -337,22 +352,25 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
     }
     akz_comm* c = g->comm;
     AKZ_HIP_TRY(hipSetDevice(c->device));
-    if (counts || images) {  // the headers of all blocks -> host
-        AKZ_HIP_TRY(hipEventSynchronize(g->done));
-        AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost,
-                                     c->cs));
-        AKZ_HIP_TRY(hipStreamSynchronize(c->cs));
-        for (int r = 0; r < c->nranks; ++r) {
-            const uint64_t* h = g->pinned + (size_t)r * 8;
-            if (h[2] != g->cap_rows || h[0] > g->cap_rows) {
-                set_error("gather: ranks disagree on the block capacity (every rank must pass the same cap_rows)");
-                return AKZ_ERR_INVALID_ARG;
-            }
-            if (counts) counts[r] = h[0];
-            if (images) images[r] = h[1];
+    // the headers of all blocks -> host (64 bytes per rank): an overflow anywhere is an error everywhere
+    AKZ_HIP_TRY(hipEventSynchronize(g->done));
+    AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost, c->cs));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->cs));
+    bool overflow = false;
+    for (int r = 0; r < c->nranks; ++r) {
+        const uint64_t* h = g->pinned + (size_t)r * 8;
+        if (h[2] != g->cap_rows) {
+            set_error("gather: ranks disagree on the block capacity (every rank must pass the same cap_rows)");
+            return AKZ_ERR_INVALID_ARG;
         }
-    } else {
-        AKZ_HIP_TRY(hipEventSynchronize(g->done));
+        overflow = overflow || h[4] != 0 || h[0] > g->cap_rows;
+        if (counts) counts[r] = h[0];
+        if (images) images[r] = h[1];
+    }
+    if (overflow) {
+        set_error("gather: a rank's shard has more descriptor rows than the agreed capacity (counts hold what each rank needed; "
+                  "repeat the exchange with a larger cap_rows on every rank)");
+        return AKZ_ERR_BUFFER;
     }
     if (d_all) *d_all = g->recv;
     if (block_rows) *block_rows = 1 + g->cap_rows;

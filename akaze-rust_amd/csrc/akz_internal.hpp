@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/akaze_hip.h"
+#include "../../include/akaze_hip_debug.h"
 
 namespace akz {
 
@@ -219,8 +220,8 @@ void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uin
 // the same scan on the matrix cores (akz_match.hip): descriptor bits unpacked to int8, distances from one integer
 // GEMM; identical records.  Rows of the unpacked images are padded (match_mfma_rows).
 uint32_t match_mfma_rows(uint32_t n, bool queries);
-uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1);
-uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tiles);  // chunks per set of a multi-set launch
+uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1, uint32_t forced = 0);
+uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tiles, uint32_t forced = 0);  // chunks per set of a multi-set launch
 // bound (queries only): n_bound arrays of n_pad per-query pruning bounds, set to threshold; d_tiles (train images of
 // several sets): per LDS tile {first source row, valid rows}
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,

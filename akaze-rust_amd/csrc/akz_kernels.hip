@@ -1030,11 +1030,7 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
 // Workgroups per image of the two contrast passes: 128 fat ones for a batch (one atomicMax / one histogram flush
 // each); a small batch gets more, shorter ones so that the chip is filled (a lone 1080p frame: 38 + 36 us with 128).
 static unsigned contrast_blocks(uint32_t h, uint32_t n) {
-    static const uint32_t target = [] {
-        const char* e = std::getenv("AKZ_CONTRAST_WGS");
-        const long v = e ? std::atol(e) : 0;
-        return v > 0 ? (uint32_t)v : 512u;  // lone 1080p frame: 37 + 34 us with 128, 18 + 24 with 512, 19 + 33 with 1024
-    }();
+    constexpr uint32_t target = 512u;  // lone 1080p frame: 37 + 34 us with 128, 18 + 24 with 512, 19 + 33 with 1024
     const uint32_t per_image = std::max<uint32_t>(128u, target / std::max<uint32_t>(n, 1u));
     return h > 2 ? std::min<uint32_t>(h - 2, per_image) : 1u;
 }

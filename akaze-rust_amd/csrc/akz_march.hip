@@ -792,24 +792,14 @@ inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    static int fill = 0, min_rows = 0;
-    if (!fill) {
-        const char* e = getenv("AKZ_LEVEL_FILL");  // tuning knobs
-        fill = e ? std::max(1, atoi(e)) : 3;
-        const char* m = getenv("AKZ_LEVEL_MIN_ROWS");
-        min_rows = m ? std::max(8, atoi(m)) : 64;
-    }
+    constexpr int fill = 3, min_rows = 64;  // (swept in round 2: flat within +-1.5 % around these)
     MarchGrid g;
     g.nstrips = (int)((w + USE - 1) / USE);
     const int rows = (int)h - 2;
     const long cols = (long)n * g.nstrips;
     const long want = ((long)cus * fill + cols - 1) / cols;
     long nb = std::max<long>(1, std::min<long>(want, std::max(1, rows / min_rows)));
-    static int edge_pct = 0;
-    if (!edge_pct) {
-        const char* e = getenv("AKZ_LEVEL_EDGE");  // rows of an edge band in percent of a middle band's
-        edge_pct = e ? std::min(100, std::max(25, atoi(e))) : 75;
-    }
+    constexpr int edge_pct = 75;  // rows of an edge band in percent of a middle band's
     if (nb >= 3) {
         // 2 edge bands of rho * m rows + (nb - 2) middle bands of m rows = rows
         const double m = (double)rows / ((double)(nb - 2) + 2.0 * edge_pct / 100.0);
@@ -841,13 +831,7 @@ inline MarchGrid plan_march(uint32_t w, uint32_t h, uint32_t n, int S, dim3* gri
     }
     // Bands: each one re-warms the rings (4S+3 extra rows), so they are as tall as the machine allows — enough
     // workgroups for `fill` resident workgroups per CU, never shorter than min_rows interior rows.
-    static int fill = 0, min_rows = 0;
-    if (!fill) {
-        const char* e = getenv("AKZ_MARCH_FILL");      // tuning knobs
-        fill = e ? std::max(1, atoi(e)) : 3;
-        const char* m = getenv("AKZ_MARCH_MIN_ROWS");
-        min_rows = m ? std::max(8, atoi(m)) : 64;
-    }
+    constexpr int fill = 3, min_rows = 64;
     const int use = USE;
     (void)S;
     MarchGrid g;

@@ -320,10 +320,10 @@ uint32_t match_mfma_rows(uint32_t n, bool queries) {
     const uint32_t m = queries ? (uint32_t)MM_QB : (uint32_t)MM_TR;
     return (std::max<uint32_t>(n, 1) + m - 1) / m * m;
 }
-uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1) {
-    if (const char* e = std::getenv("AKZ_MM_CHUNKS")) {  // tuning override
+uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1, uint32_t forced) {
+    if (forced) {  // akz_debug_set_match_chunks
         const uint32_t tiles_e = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
-        return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::atoi(e), tiles_e));
+        return std::max<uint32_t>(1, std::min<uint32_t>(forced, tiles_e));
     }
     const uint32_t qblocks = (std::max<uint32_t>(n0, 1) + MM_QB - 1) / MM_QB;
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
@@ -354,8 +354,8 @@ uint32_t match_mfma_query_block() { return MM_QB; }
 // Chunks per train set of a multi-set launch: one workgroup per CU is resident, so a launch runs in rounds of 256
 // workgroups; with one chunk per set 22 query blocks x 16 sets are 352 workgroups = 1.4 rounds that take as long as 2.
 // Same estimate as match_mfma_chunks: rounds x (tiles per chunk + the query load).
-uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tiles) {
-    if (const char* e = std::getenv("AKZ_MM_SET_CHUNKS")) return std::max(1, std::min(16, std::atoi(e)));
+uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tiles, uint32_t forced) {
+    if (forced) return std::min(16u, forced);  // akz_debug_set_match_chunks
     const uint64_t qblocks = (std::max<uint32_t>(n0, 1) + MM_QB - 1) / MM_QB;
     constexpr uint32_t kQueryLoad = 512 / MM_TR;
     uint32_t best = 1;

@@ -28,8 +28,6 @@
 // (H pass at the pixel's own column, fill_border = reading the plane at clamped coordinates in the V pass).
 #include <hip/hip_runtime.h>
 
-#include <cstdio>
-#include <cstdlib>
 #include <type_traits>
 
 #include "akz_internal.hpp"
@@ -55,8 +53,6 @@ struct ResArgs {
     const float* prev;  // final Lt of the level before the first resident one, image 0; images pw*ph apart
     int pw, ph;
     int n_levels;
-    int dbg;
-    unsigned long long* ts;
     float g0, g1, g2;   // gaussian_kernel(1.0, 3)
     float kn, kwn;      // scale-1 Scharr main-axis taps [kn, kwn, kn]
     const double* d_k;  // contrast factor per image
@@ -365,7 +361,6 @@ __device__ __forceinline__ void fed_step(v2 (&P)[4][8], const v2 (&C)[4][8], con
     }
 }
 
-#define AKZ_TS(n) do { if (a.ts && threadIdx.x == 0 && blockIdx.x == 0 && l == 0) a.ts[n] = __builtin_readcyclecounter(); } while (0)
 template <bool VEC>
 __global__ void __launch_bounds__(RNT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_octave_resident(const ResArgs a) {
@@ -406,7 +401,6 @@ k_octave_resident(const ResArgs a) {
         const double inverse_k = 1.0 / (kc * kc);
 
         // ---- Lsmooth = gaussian_blur(Lt, 1.0): H pass at the own columns, V pass from the border-filled plane ----
-        AKZ_TS(0);
         plane_put(sm, g, P);
         __syncthreads();
         {
@@ -427,10 +421,8 @@ k_octave_resident(const ResArgs a) {
             __syncthreads();
             plane_put(sm, g, T);
             __syncthreads();
-            AKZ_TS(1);
             plane_vpass<false>(sm, g, a.g0, a.g1, a.g2, T);  // T = Lsmooth
-            AKZ_TS(2);
-            if (!(a.dbg & 4)) patch_store<VEC>(lv.lsmooth + off, g, T);
+            patch_store<VEC>(lv.lsmooth + off, g, T);
             __syncthreads();
             plane_put(sm, g, T);
             __syncthreads();
@@ -453,16 +445,11 @@ k_octave_resident(const ResArgs a) {
             __syncthreads();
             plane_put(sm, g, C);
             __syncthreads();
-            AKZ_TS(3);
             plane_vpass<true>(sm, g, 0.0f, 0.0f, 0.0f, C);  // C = Lx
-            AKZ_TS(4);
             __syncthreads();
             plane_put(sm, g, T);
             __syncthreads();
-            AKZ_TS(5);
             plane_vpass<false>(sm, g, a.kn, a.kwn, a.kn, T);  // T = Ly
-            AKZ_TS(6);
-            if (a.dbg & 8) { AKZ_FOR_PATCH(k, c, i) C[k][i][c] = C[k][i][c] * T[k][i][c]; } else
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -472,8 +459,7 @@ k_octave_resident(const ResArgs a) {
                     asm volatile("" : "+v"(C[k][i]));
                     if (i & 1) __builtin_amdgcn_sched_barrier(0);  // four divisions in flight, not sixty-four
                 }
-            AKZ_TS(7);
-            if (!(a.dbg & 4)) patch_store<VEC>(lv.lflow + off, g, C);
+            patch_store<VEC>(lv.lflow + off, g, C);
             // beyond the image: the negative of the border pixel's value (rows after columns)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -497,7 +483,6 @@ k_octave_resident(const ResArgs a) {
             }
         }
         __syncthreads();  // the plane is dead: its memory becomes the edge arrays
-        AKZ_TS(8);
 
         // ---- edges of Lflow (once per level), then the diffusion steps ----
         Nbr nb;
@@ -530,9 +515,8 @@ k_octave_resident(const ResArgs a) {
             __syncthreads();
         }
         int par = 1;
-        AKZ_TS(9);
         const float* ht = a.half_tau + lv.tau0;
-        for (int s = (a.dbg & 1) ? lv.n_tau - 1 : 0; s + 1 < lv.n_tau; ++s) {
+        for (int s = 0; s + 1 < lv.n_tau; ++s) {
             const Edges rd = edges_of(sm, par), wr = edges_of(sm, par ^ 1);
             fed_step<false, VEC>(P, C, CT, CB, CL, CR, rd, nb, ht[s], nullptr, g);
             edges_put(wr, tid, P);
@@ -546,7 +530,6 @@ k_octave_resident(const ResArgs a) {
             patch_store<VEC>(lv.lt + off, g, P);
         }
         __syncthreads();  // the edge arrays are dead: the next level's plane overwrites them
-        AKZ_TS(10);
     }
 }
 
@@ -564,13 +547,6 @@ void octave_resident(hipStream_t s, const float* prev, uint32_t pw, uint32_t ph,
     a.prev = prev;
     a.pw = (int)pw; a.ph = (int)ph;
     a.n_levels = (int)n_levels;
-    { const char* e = getenv("AKZ_RES_DBG"); a.dbg = e ? atoi(e) : 0; }
-    static unsigned long long* d_ts = nullptr;
-    a.ts = nullptr;
-    if (a.dbg & 2) {
-        if (!d_ts) (void)hipMalloc(&d_ts, 16 * 8);
-        a.ts = d_ts;
-    }
     a.g0 = g3[0]; a.g1 = g3[1]; a.g2 = g3[2];
     std::vector<float> m, o;
     scharr_kernels(1, m, o);
@@ -593,14 +569,6 @@ void octave_resident(hipStream_t s, const float* prev, uint32_t pw, uint32_t ph,
     for (uint32_t l = 0; l < n_levels; ++l) vec = vec && (levels[l].w & 3) == 0;
     if (vec) hipLaunchKernelGGL(k_octave_resident<true>, dim3(n), dim3(RNT), 0, s, a);
     else hipLaunchKernelGGL(k_octave_resident<false>, dim3(n), dim3(RNT), 0, s, a);
-    if (a.ts) {
-        unsigned long long h[16];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h, a.ts, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[res ts]");
-        for (int i = 1; i <= 10; ++i) fprintf(stderr, " %d:%lld", i, (long long)(h[i] - h[i - 1]));
-        fprintf(stderr, "\n");
-    }
 }
 
 }  // namespace launch

@@ -877,15 +877,8 @@ struct Launch {
     TileGrid tg;
     dim3 grid;
 };
-// workgroups of a persistent launch; AKZ_PERSIST_BLOCKS in the environment overrides the built-in value (tuning runs)
-inline long persist_blocks() {
-    static const long v = [] {
-        const char* e = std::getenv("AKZ_PERSIST_BLOCKS");
-        const long x = e ? std::atol(e) : 0;
-        return x > 0 ? x : (long)AKZ_PERSIST_BLOCKS;
-    }();
-    return v;
-}
+// workgroups of a persistent launch
+inline long persist_blocks() { return (long)AKZ_PERSIST_BLOCKS; }
 inline Launch plan_tiles(uint32_t w, uint32_t h, uint32_t n, int tile_h = TH) {
     Launch l;
     l.tg.tx = (int)((w + TW - 1) / TW);

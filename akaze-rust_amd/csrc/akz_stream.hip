@@ -342,8 +342,8 @@ k_prep_stream(const float* __restrict__ prev, float* __restrict__ lt_out, float*
             unsigned* wh = s_chist + (size_t)(threadIdx.x >> 6) * CHIST_COPIES * ca.nbins;
             for (unsigned b = lane; b < CHIST_COPIES * ca.nbins; b += WAVE) wh[b] = 0u;  // wave-private: no barrier
             myhist = wh + (lane & (CHIST_COPIES - 1)) * ca.nbins;
-            // the image's bin thresholds, wave-private too (behind the histograms of all waves, 8-byte aligned)
-            double* wt = reinterpret_cast<double*>(s_chist + (size_t)(SNT / WAVE) * CHIST_COPIES * ca.nbins + (ca.nbins & 1u)) +
+            // the image's bin thresholds, wave-private too (behind the histograms of all waves: an even number of words, so 8-byte aligned for every bin count)
+            double* wt = reinterpret_cast<double*>(s_chist + (size_t)(SNT / WAVE) * CHIST_COPIES * ca.nbins) +
                          (size_t)(threadIdx.x >> 6) * (ca.nbins + 1);
             for (unsigned b = lane; b <= ca.nbins; b += WAVE) wt[b] = ca.thr[(size_t)pc.img * (ca.nbins + 1) + b];
             mythr = wt;
@@ -592,14 +592,7 @@ void blur5_stream_f32(hipStream_t s, const float* in, float* out, uint32_t w, ui
 }
 
 bool prep_stream_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16; }
-static int prep_min_rows() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("AKZ_PREP_MIN_ROWS");  // tuning knob
-        v = e ? std::max(1, atoi(e)) : 8;
-    }
-    return v;
-}
+static int prep_min_rows() { return 8; }
 
 void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, float* lsmooth, float* lflow, uint32_t w,
                  uint32_t h, uint32_t pw, uint32_t ph, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow) {
@@ -632,7 +625,7 @@ void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uin
                        (int)w, (int)h, g1, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], nullptr, 0u, ca);
     hipLaunchKernelGGL(k_contrast_thresholds, dim3(n), dim3(320), 0, s, d_hmax_bits, nbins, d_thr);
     const StreamGrid g2 = plan_stream(k_prep_stream<false, 2>, w, h, n, 1, 1, prep_min_rows(), &grid);
-    const size_t lds = ((size_t)(SNT / WAVE) * CHIST_COPIES * nbins + (nbins & 1u)) * sizeof(unsigned) +
+    const size_t lds = ((size_t)(SNT / WAVE) * CHIST_COPIES * nbins) * sizeof(unsigned) +
                        (size_t)(SNT / WAVE) * (nbins + 1) * sizeof(double);
     hipLaunchKernelGGL((k_prep_stream<false, 2>), grid, dim3(SNT), lds, s,
                        in, nullptr, nullptr, nullptr, (int)w, (int)h, (int)w, (int)h, g2, g3[0], g3[1], g3[2], m.wgt[0],

@@ -156,6 +156,7 @@ def lib():
         "akz_debug_march_bands": ([i32, u32, u32, u32, i32, C.POINTER(i32), u32, pu32], i32),
         "akz_ctx_set_lanes": ([vp, u32], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
+        "akz_debug_set_match_chunks": ([vp, u32, u32], i32),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
         "akz_estimate_fundamental_matrix": ([vp, u64, vp, u64, vp, C.c_float, fp, C.POINTER(i32)], i32),
@@ -346,6 +347,10 @@ class Context:
         p = Profile()
         _check(lib().akz_ctx_get_profile(self._h, C.byref(p), int(reset)))
         return p.as_dict()
+
+    def debug_set_match_chunks(self, pair_chunks=0, set_chunks=0):
+        """akz_debug_set_match_chunks (include/akaze_hip_debug.h): force the matcher's chunk counts; 0 = automatic."""
+        _check(lib().akz_debug_set_match_chunks(self._h, int(pair_chunks), int(set_chunks)))
 
     def graph_probe(self, frames, options=None, keep_all_planes=True, reps=50):
         """akz_ctx_graph_probe: (ms per hipGraph launch of the begin phase, ms per plain enqueue of it, graph nodes)."""
@@ -906,6 +911,7 @@ class Gather:
 
     def __init__(self, comm, handle):
         self._comm, self._h = comm, handle
+        comm._gathers.add(self)  # akz_comm_destroy deletes its gather objects: Comm.close() invalidates the handles
 
     def stream_wait(self, stream):
         _check(lib().akz_gather_stream_wait(self._h, C.c_void_p(stream)))
@@ -924,6 +930,7 @@ class Gather:
         if self._h:
             lib().akz_gather_free(self._h)
             self._h = None
+        self._comm._gathers.discard(self)
 
     def __del__(self):
         try:
@@ -941,8 +948,17 @@ class Comm:
         _check(lib().akz_comm_create(int(device), buf, int(rank), int(nranks), C.byref(self._h)))
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
 
+    @property
+    def _gathers(self):
+        import weakref
+        if "_gs" not in self.__dict__:
+            self.__dict__["_gs"] = weakref.WeakSet()
+        return self.__dict__["_gs"]
+
     def close(self):
         if self._h:
+            for g in list(self._gathers):  # exchanges still held by the caller: retire them while their objects exist
+                g.free()
             lib().akz_comm_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -1005,8 +1021,9 @@ def gather_descriptor_rows(local_rows, group=None, cap_rows=None):
     cap_rows=None: capacity = the largest shard (needs one host sync to read the counts); returns
     ([sum n_r, 64] rows in rank order, counts per rank as a list).
     cap_rows=int:  fixed capacity, NO host synchronisation — returns the padded [world, cap_rows, 64]
-    tensor and the device tensor of counts; rows beyond a rank's count are zero.  Raises if the local
-    shard does not fit."""
+    tensor and the device tensor of counts; rows beyond a rank's count are zero.  A shard that does not fit
+    contributes no rows: its count (> cap_rows, seen by every rank) says so and the caller repeats the
+    exchange with a larger capacity on every rank."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -1016,10 +1033,10 @@ def gather_descriptor_rows(local_rows, group=None, cap_rows=None):
     cnts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(cnts, cnt, group=group)
     if cap_rows is not None:
-        if n_local > cap_rows:
-            raise ValueError(f"local shard has {n_local} rows, capacity is {cap_rows}")
+        # a shard that does not fit still takes part (a rank that skipped the collective would leave its peers waiting
+        # in it): it contributes no rows, and every rank sees the overflow in the gathered counts
         padded = torch.zeros((cap_rows, 64), dtype=torch.uint8, device=dev)
-        if n_local:
+        if 0 < n_local <= cap_rows:
             padded[:n_local] = local_rows
         gathered = torch.empty((world * cap_rows, 64), dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(gathered, padded, group=group)

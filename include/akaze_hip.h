@@ -300,7 +300,11 @@ int akz_gather_descriptors(akz_comm* comm, const uint8_t* d_local, uint64_t n_lo
 /* Pipelined form: ONE fixed-size all-gather per call, enqueued on the communicator's own streams without touching
    the extraction stream.  Every rank contributes a block of 1 + cap_rows rows: a header row {u64 rows, u64 images,
    u64 cap_rows, u64 sequence, 0...} followed by the descriptor rows of all images of all `results` (in order);
-   cap_rows must be the same on every rank and at least the largest shard (AKZ_ERR_BUFFER otherwise).
+   cap_rows MUST be the same on every rank (the message sizes of the collective depend on it: a mismatch is fatal
+   for the communicator and cannot be detected before the collective is issued) and should be at least the largest
+   shard.  A rank whose shard does not fit still takes part — it sends its header alone, marked — and
+   akz_gather_finish then returns AKZ_ERR_BUFFER on EVERY rank, with counts[] holding what each rank needed, so that
+   all ranks can repeat the exchange with the same larger capacity; the communicator stays usable.
    akz_gather_begin returns as soon as the local rows have been copied — the results may be freed, the next batch
    begun — and never waits for a collective; akz_gather_begin_rows takes raw device rows that are complete in the
    order of producer_stream (may be NULL: complete now) and must stay valid until the gather is finished. */
@@ -425,22 +429,6 @@ int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
    the streaming or the LDS-tiled preparation kernel; 3 = the fused kernel wherever it is supported; 1 = streaming
    preparation, 0 = LDS-tiled preparation (both without fusion).  Results are bit-identical. */
 int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
-/* Is the begin phase of an extraction (scale space + detector + extrema of a batch: ~45 dependent launches for a lone
-   1080p frame) shorter as ONE hipGraph launch?  Captures it for (d_imgs, w, h, n, cfg) and times `reps` graph launches
-   against `reps` plain enqueues, each from an idle stream (HIP events): *ms_graph, *ms_plain per launch, *graph_nodes
-   (may be NULL) the node count.  Results of the probe's extractions are discarded. */
-int akz_ctx_graph_probe(akz_ctx* ctx, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
-                        uint32_t flags, uint32_t reps, double* ms_graph, double* ms_plain, uint64_t* graph_nodes);
-/* Diagnostics (host only, no GPU work): the row bands the column-march planners cut an n-image batch of w x h into.
-   kind 0: detector / blur march with filter half width `half_width` (interior rows half_width .. h-1-half_width),
-   kind 1: level march (interior rows 1 .. h-2; first and last band shorter).  Writes up to `cap` (first, end) row pairs
-   to rows, the number of bands to *n_bands.  Used by the CPU tests to check that the bands tile the rows exactly. */
-int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half_width, int32_t* rows, uint32_t cap,
-                          uint32_t* n_bands);
-/* names of the default FED kernel and of the detector kernel that large launches take (for bench / profiles) */
-const char* akz_fed_kernel_name(void);
-const char* akz_detector_kernel_name(void);
-
 /* ---- image ingest, options files (host code) -------------------- */
 /* What `image::open(path)` hands to the crate (akaze/src/lib.rs:171): JPEG (baseline / progressive
    Huffman, 8 bit, 1 or 3 components), PNG (non-interlaced) and binary PNM, decoded to 8-bit luma

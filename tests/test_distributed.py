@@ -34,6 +34,16 @@ def _worker(rank, world, port, counts, out_dir):
         strip = torch.cat([padded[r, :cnts[r]] for r in range(world)], dim=0)
         assert torch.equal(strip, rows)
         assert all(int(padded[r, cnts[r]:].sum()) == 0 for r in range(world))
+        # a capacity that the largest shard exceeds: no rank leaves the collective (that would hang the others); the
+        # gathered counts tell every rank which shard did not fit, the shards that fit arrive intact
+        cap = max(cnts) - 1
+        small, dcnt2 = A.gather_descriptor_rows(local, cap_rows=cap)
+        assert [int(v) for v in dcnt2.tolist()] == list(cnts)
+        for r in range(world):
+            if cnts[r] <= cap:
+                assert torch.equal(small[r, :cnts[r]], rows[sum(cnts[:r]):sum(cnts[:r + 1])])
+            else:
+                assert int(small[r].sum()) == 0
         np.save(os.path.join(out_dir, f"rows_{rank}.npy"), rows.numpy())
         np.save(os.path.join(out_dir, f"cnts_{rank}.npy"), np.array(cnts))
         np.save(os.path.join(out_dir, f"local_{rank}.npy"), local.numpy())

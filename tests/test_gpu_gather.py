@@ -43,11 +43,20 @@ def test_comm_gather_matches_local_rows(ctx, amd):
         amd.copy_d2d(out.data_ptr(), p + 64, rows * 64)
         assert torch.equal(out, local)
         g.free()
+    # a shard that does not fit: the rank still takes part in the collective, finish reports AKZ_ERR_BUFFER (on every
+    # rank) and the communicator stays usable; a gather still held when the communicator closes is retired by close()
+    g3 = comm.gather_begin([res], rows - 1)
     with pytest.raises(amd.AkazeError) as e:
-        comm.gather_begin([res], rows - 1)
+        g3.finish()
     assert e.value.status == -7
+    g3.free()
+    g4 = comm.gather_begin([res], rows)
+    assert g4.finish()[2] == [rows]
+    g5 = comm.gather_begin([res], rows)   # never finished nor freed by the caller
     res.close()
     comm.close()
+    g5.free()
+    del g4, g5
 
 
 def test_bench_force_dist_capi_world1():

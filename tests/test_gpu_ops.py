@@ -219,7 +219,7 @@ def test_descriptor_match_ragged_sizes(ctx, ref, n0, n1):
 @pytest.mark.parametrize("chunks_per_set", [None, 2, 3, 16])
 def test_descriptor_match_sets_chunked(ctx, ref, chunks_per_set):
     """A multi-set launch with every set cut into several chunks (the form large sets take so that the workgroups fill
-    whole rounds of the chip; forced here through AKZ_MM_SET_CHUNKS): sets shorter than the chunk count leave chunks
+    whole rounds of the chip; forced here through akz_debug_set_match_chunks): sets shorter than the chunk count leave chunks
     empty, equal minima in different chunks must resolve to the lowest row, and the per-set pruning bound is shared by
     the set's chunks."""
     import torch
@@ -240,12 +240,8 @@ def test_descriptor_match_sets_chunked(ctx, ref, chunks_per_set):
     sets = [make(n) for n in (1500, 1, 127, 0, 385, 2600)]
     dq = torch.from_numpy(rows64(q)).cuda()
     cat = torch.from_numpy(np.concatenate([rows64(t) for t in sets])).cuda()
-    old = os.environ.get("AKZ_MM_SET_CHUNKS")
     try:
-        if chunks_per_set is None:
-            os.environ.pop("AKZ_MM_SET_CHUNKS", None)
-        else:
-            os.environ["AKZ_MM_SET_CHUNKS"] = str(chunks_per_set)
+        ctx.debug_set_match_chunks(0, chunks_per_set or 0)
         for ratio, thr in ((0.86, 10000), (1.3, 10000)):
             out, cnt = ctx.descriptor_match_sets_device(dq, cat, [len(t) for t in sets], thr, ratio)
             ctx.synchronize()
@@ -255,10 +251,7 @@ def test_descriptor_match_sets_chunked(ctx, ref, chunks_per_set):
                 exp = ref.descriptor_match(q, t, thr, ratio)
                 assert np.array_equal(got, exp), (chunks_per_set, ratio, k, len(got), len(exp))
     finally:
-        if old is None:
-            os.environ.pop("AKZ_MM_SET_CHUNKS", None)
-        else:
-            os.environ["AKZ_MM_SET_CHUNKS"] = old
+        ctx.debug_set_match_chunks(0, 0)
 
 
 @pytest.mark.parametrize("mode", [1, 0])

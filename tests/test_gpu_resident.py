@@ -1,0 +1,76 @@
+"""k_octave_resident (akz_resident.hip): the coarse end of the pyramid as one launch with one workgroup per image.
+Every EvolutionStep plane, keypoint and descriptor byte against the CPU oracle, for shapes that exercise its patch
+grid: widths / heights that are not multiples of the 8 x 8 patches or of 4 (scalar global accesses), a single border
+column or row in the last patch, images that are resident from level 1 on (no 2x2 mean in front), several octaves
+inside one launch, batches, the lean plane set, non-default pyramids, and -- in the default mode, where only batches
+of 8 Mpx and more take it -- a 1080p batch at the size the bench runs."""
+import numpy as np
+import pytest
+
+from test_gpu_extract import assert_same_result
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def rctx(amd):
+    """prep mode 3: the fused / resident kernels wherever they are supported, whatever the batch size"""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_prep_mode(3)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("w,h", [
+    (64, 64),      # resident from level 1 on (clone in front), one octave
+    (161, 81),     # two octaves; odd sizes; 80 x 40 second octave
+    (200, 137),    # h - 1 = 136: the last row of patches holds ONE image row
+    (257, 120),    # w - 1 = 256: the last column of patches holds ONE image column
+    (505, 393),    # 252 x 196 does not fit, 126 x 98 does: widths that are not multiples of 4
+    (480, 270),    # 240 x 135 from octave 1: the shape of a 1080p frame's last octave, 510 of 512 patches
+    (512, 256),    # 64 x 32 patches exactly fill the workgroup at octave 1 (256 x 128 -> 32 x 16), multiples of 8
+    (1001, 300),   # wide and flat
+])
+def test_resident_all_planes(rctx, amd, ref, w, h):
+    frame = amd.synth_frame(w, h, (w * 7 + h) % 50)
+    rf = ref.extract(frame)
+    assert_same_result(rctx.extract_features(frame), rf)
+
+
+def test_resident_lean_batch_and_pyramids(rctx, amd, ref):
+    """Lstep not kept (null plane pointer in the launch), a batch (one workgroup per image), 5 x 5 and 3-sublevel
+    pyramids (five levels per octave; 13 to 54 steps per level)."""
+    import torch
+    frames = np.stack([amd.synth_frame(486, 270, 20 + i) for i in range(5)])
+    lean = rctx.extract_features(torch.from_numpy(frames).cuda(), keep_all_planes=False)
+    full = rctx.extract_features(torch.from_numpy(frames).cuda())
+    for i in range(5):
+        rf = ref.extract(frames[i])
+        assert_same_result(lean, rf, planes=False, img=i)
+        assert_same_result(full, rf, planes=(i in (0, 4)), img=i)
+        for lvl in (5, 11):  # kept planes of the lean set are exact too
+            assert np.array_equal(lean.plane(lvl, "Lflow", i), rf.plane(lvl, "Lflow"))
+            assert np.array_equal(lean.plane(lvl, "Lt", i), rf.plane(lvl, "Lt"))
+    frame = amd.synth_frame(640, 360, 7)
+    for kw in (dict(num_sublevels=5, max_octave_evolution=5), dict(num_sublevels=3, detector_threshold=0.0005),
+               dict(num_sublevels=2, max_octave_evolution=6)):
+        assert_same_result(rctx.extract_features(frame, amd.Config(**kw)), ref.extract(frame, ref.default_config(**kw)))
+
+
+def test_resident_flat_and_noise(rctx, amd, ref):
+    """A constant frame (the contrast factor is 0, Lflow NaN from level 1 on, in the reference too) and uniform noise."""
+    flat = np.full((120, 200), 77, np.uint8)
+    assert_same_result(rctx.extract_features(flat), ref.extract(flat), equal_nan=True)
+    noise = np.random.default_rng(3).integers(0, 256, (135, 240), dtype=np.uint8)
+    assert_same_result(rctx.extract_features(noise), ref.extract(noise))
+
+
+def test_default_mode_1080p_batch_all_planes(ctx, amd, ref):
+    """The bench's shape in the default mode: a 4-frame 1080p batch (8.3 Mpx: the march kernels of the fine octaves, the
+    forked coarse chain and the resident last octave all engage); EVERY plane of one frame against the oracle."""
+    import torch
+    frames = np.stack([amd.synth_frame(1920, 1080, 60 + i) for i in range(4)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda())
+    assert_same_result(res, ref.extract(frames[2], threads=16), img=2)
+    assert_same_result(res, ref.extract(frames[0], threads=16), planes=False, img=0)

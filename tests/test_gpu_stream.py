@@ -153,7 +153,7 @@ def test_stream_contrast_factor(sctx, ref, shape):
     import torch
     rng = np.random.default_rng(shape[1])
     imgs = np.stack([ref.gaussian_blur(rng.random(shape, dtype=np.float32) * np.float32(s), 1.6) for s in (1.0, 0.3, 0.05)])
-    for nbins, pct in ((300, 0.7), (64, 0.5), (1000, 0.9)):
+    for nbins, pct in ((300, 0.7), (64, 0.5), (1000, 0.9), (301, 0.7), (77, 0.35)):  # odd counts too: the f64 thresholds follow the histograms in LDS
         got = sctx.contrast_factor(torch.from_numpy(imgs).cuda(), pct, 1.0, nbins).cpu().numpy()
         for i in range(3):
             assert float(got[i]) == ref.contrast_factor(imgs[i], pct, 1.0, nbins), (nbins, pct, i)

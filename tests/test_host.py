@@ -13,9 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
+    syms = set()
+    for name in ("akaze_hip.h", "akaze_hip_debug.h"):  # the drop-in boundary and the measurement / test hooks
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        syms |= set(re.findall(r"\b(akz_[a-z0-9_]+)\s*\(", hdr))
+    return sorted(syms)
+
+
+def test_debug_hooks_are_not_in_the_public_header():
     hdr = open(os.path.join(ROOT, "include", "akaze_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(akz_[a-z0-9_]+)\s*\(", hdr)))
+    for s in ("akz_ctx_graph_probe", "akz_debug_", "akz_fed_kernel_name", "akz_detector_kernel_name"):
+        assert s not in hdr, s
 
 
 def test_library_exports_every_declared_symbol(amd):
@@ -128,6 +137,13 @@ def test_isa_has_no_contracted_fma():
     rows, bad = isa_audit.audit(os.path.join(pkg, "csrc", "akz_kernels.s"))
     rows2, bad2 = isa_audit.audit(os.path.join(pkg, "csrc", "akz_stencil.s"))
     assert len(rows) >= 14 and len(rows2) >= 18 and not bad and not bad2, (bad, bad2)
+    # k_octave_resident: f64 FMAs only, five per pm_g2 division (its expansion); no f32 FMA at all (the 2x2 mean's
+    # division by 4 is a multiplication by 0.25)
+    import re
+    res = open(os.path.join(pkg, "csrc", "akz_resident.s")).read()
+    assert not re.findall(r"\bv_(?:pk_fma|fma|fmac|mad|mac|fmaak|fmamk)_(?:f32|legacy_f32)\b", res)
+    n_div = len(re.findall(r"\bv_div_fmas_f64\b", res))
+    assert n_div >= 2 and len(re.findall(r"\bv_(?:fma|fmac)_f64", res)) == 5 * n_div
     pure = {r[0]: r[1] for r in rows + rows2}
     for k, v in pure.items():
         if k.startswith(("k_fed", "k_filter_v", "k_filter_hIf", "k_ldet", "k_nms", "k_orientation", "k_deriv",

@@ -79,6 +79,9 @@ struct akz_ctx {
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     hipStream_t coarse = nullptr;       // the coarse octaves' chain (diffusion + detectors), next to the fine detectors
+    hipStream_t copy = nullptr;         // uploads of host frames (akz_extract_begin_host_*), under the kernels of the batch before
+    DevBuf stage[kSlots];               // staging buffers of those uploads, one per job slot
+    hipEvent_t staged[kSlots] = {nullptr, nullptr, nullptr};
     // Lanes: child contexts (own streams, scratch planes, candidate slots) that small jobs are dealt to in turn, so that
     // the launch chains of consecutive single frames -- 44 back-to-back launches of a few hundred workgroups each --
     // overlap on the chip instead of queueing on one stream (akz_ctx_set_lanes).
@@ -160,6 +163,7 @@ static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
         AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->aux) AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
         if (c->coarse) AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
+        if (c->copy) AKZ_HIP_TRY(hipStreamSynchronize(c->copy));
         AKZ_HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -281,9 +285,17 @@ int akz_ctx_destroy(akz_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
         if (b.p) (void)hipHostFree(b.p);
+    if (c->copy) {
+        (void)hipStreamSynchronize(c->copy);
+        (void)hipStreamDestroy(c->copy);
+        c->copy = nullptr;
+    }
     for (int i = 0; i < akz_ctx::kSlots; ++i) {
         if (c->cand_slot[i].p) (void)hipFree(c->cand_slot[i].p);
         if (c->count_slot[i].p) (void)hipFree(c->count_slot[i].p);
+        if (c->stage[i].p) (void)hipFree(c->stage[i].p);
+        if (c->staged[i]) (void)hipEventDestroy(c->staged[i]);
+        c->staged[i] = nullptr;
     }
     if (c->aux) {
         (void)hipStreamSynchronize(c->aux);
@@ -843,7 +855,7 @@ static void job_destroy(akz_job* j) {
 
 template <typename T>
 static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
-                         uint32_t flags, akz_job** out) {
+                         uint32_t flags, akz_job** out, int want_slot = -1) {
     if (!out) return AKZ_ERR_INVALID_ARG;
     *out = nullptr;
     AKZ_TRY(bind(c));
@@ -851,13 +863,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         set_error("extract: null image/config or empty batch");
         return AKZ_ERR_INVALID_ARG;
     }
-    int slot = -1;
-    for (int i = 0; i < akz_ctx::kSlots; ++i)
-        if (!c->slot_busy[i]) {
-            slot = i;
-            break;
-        }
-    if (slot < 0) {
+    int slot = want_slot;
+    for (int i = 0; i < akz_ctx::kSlots && slot < 0; ++i)
+        if (!c->slot_busy[i]) slot = i;
+    if (slot < 0 || c->slot_busy[slot]) {
         set_error("extract_begin: too many extractions in flight on this context (finish one first)");
         return AKZ_ERR_INVALID_ARG;
     }
@@ -1607,8 +1616,8 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
     c->next_lane = 0;
     return AKZ_OK;
 }
-static int extract_begin_dispatch(akz_ctx* c, const void* d_imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
-                                  const akz_config* cfg, uint32_t flags, akz_job** out) {
+static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
+                                  const akz_config* cfg, uint32_t flags, akz_job** out, bool on_host = false) {
     akz_ctx* on = c;
     if (c && !c->lanes.empty() && (uint64_t)w * h * n < (8u << 20)) {
         AKZ_TRY(bind(c));
@@ -1618,8 +1627,43 @@ static int extract_begin_dispatch(akz_ctx* c, const void* d_imgs, bool is_u8, ui
         AKZ_HIP_TRY(hipEventRecord(c->lane_in, c->stream));
         AKZ_HIP_TRY(hipStreamWaitEvent(on->stream, c->lane_in, 0));
     }
-    return is_u8 ? extract_begin<uint8_t>(on, (const uint8_t*)d_imgs, w, h, n, cfg, flags, out)
-                 : extract_begin<float>(on, (const float*)d_imgs, w, h, n, cfg, flags, out);
+    int slot = -1;
+    const void* d_imgs = imgs;
+    if (on_host) {
+        // Frames in host memory: upload on the context's copy stream into the staging buffer of the job slot this
+        // extraction will hold (exclusive until its finish); only this job's kernels wait for the copy, so it runs
+        // under whatever the main stream is doing for the batch before.
+        if (out) *out = nullptr;
+        AKZ_TRY(bind(on));
+        if (!imgs || w == 0 || h == 0 || n == 0) {
+            set_error("extract_begin_host: null or empty frames");
+            return AKZ_ERR_INVALID_ARG;
+        }
+        for (int i = 0; i < akz_ctx::kSlots && slot < 0; ++i)
+            if (!on->slot_busy[i]) slot = i;
+        if (slot < 0) {
+            set_error("extract_begin: too many extractions in flight on this context (finish one first)");
+            return AKZ_ERR_INVALID_ARG;
+        }
+        const size_t bytes = (size_t)w * h * n * (is_u8 ? 1 : sizeof(float));
+        AKZ_TRY(ensure(on, on->stage[slot], bytes));
+        if (!on->copy) AKZ_HIP_TRY(hipStreamCreateWithFlags(&on->copy, hipStreamNonBlocking));
+        if (!on->staged[slot]) AKZ_HIP_TRY(hipEventCreateWithFlags(&on->staged[slot], hipEventDisableTiming));
+        AKZ_HIP_TRY(hipMemcpyAsync(on->stage[slot].p, imgs, bytes, hipMemcpyHostToDevice, on->copy));
+        AKZ_HIP_TRY(hipEventRecord(on->staged[slot], on->copy));
+        AKZ_HIP_TRY(hipStreamWaitEvent(on->stream, on->staged[slot], 0));
+        d_imgs = on->stage[slot].p;
+    }
+    return is_u8 ? extract_begin<uint8_t>(on, (const uint8_t*)d_imgs, w, h, n, cfg, flags, out, slot)
+                 : extract_begin<float>(on, (const float*)d_imgs, w, h, n, cfg, flags, out, slot);
+}
+int akz_extract_begin_host_u8(akz_ctx* c, const uint8_t* h_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
+                              uint32_t flags, akz_job** out) {
+    return extract_begin_dispatch(c, h_imgs, true, w, h, n, cfg, flags, out, true);
+}
+int akz_extract_begin_host_f32(akz_ctx* c, const float* h_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
+                               uint32_t flags, akz_job** out) {
+    return extract_begin_dispatch(c, h_imgs, false, w, h, n, cfg, flags, out, true);
 }
 int akz_extract_begin_device_u8(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t h, uint32_t n,
                                 const akz_config* cfg, uint32_t flags, akz_job** out) {

@@ -133,6 +133,8 @@ def lib():
         "akz_extract_device_f32": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
         "akz_extract_begin_device_u8": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
         "akz_extract_begin_device_f32": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_begin_host_u8": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
+        "akz_extract_begin_host_f32": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, C.POINTER(vp)], i32),
         "akz_extract_finish": ([vp, C.POINTER(vp)], i32),
         "akz_extract_from_planes": ([vp, u32, u32, C.POINTER(Config), C.POINTER(vp), u64, u32, C.POINTER(vp)], i32),
         "akz_random_color": ([vp], i32),
@@ -442,6 +444,28 @@ class Context:
             t = t.unsqueeze(0)
         n, h, w = t.shape
         fn = lib().akz_extract_begin_device_u8 if t.dtype == torch.uint8 else lib().akz_extract_begin_device_f32
+        job = C.c_void_p()
+        _check(fn(self._h, C.c_void_p(t.data_ptr()), w, h, n, C.byref(options), flags, C.byref(job)))
+        return Job(self, job, t)
+
+    def extract_begin_host(self, frames, options=None, keep_all_planes=True, host_descriptors=True):
+        """extract_begin for frames in HOST memory (akz_extract_begin_host_*): a numpy array or a torch CPU tensor
+        [N, H, W] (uint8 or float32), ideally pinned (torch .pin_memory()): the upload runs on the context's copy
+        stream, under the kernels of the batch begun before.  The Job keeps the frames alive until it is finished."""
+        import torch
+        options = options or Config()
+        flags = (AKZ_KEEP_ALL_PLANES if keep_all_planes else 0) | (0 if host_descriptors else AKZ_NO_HOST_DESCRIPTORS)
+        t = frames
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t))
+        if not (isinstance(t, torch.Tensor) and not t.is_cuda and t.is_contiguous()):
+            raise ValueError("host images must be contiguous numpy arrays or torch CPU tensors")
+        if t.dtype not in (torch.uint8, torch.float32):
+            raise ValueError("host images must be uint8 or float32")
+        if t.dim() == 2:
+            t = t.unsqueeze(0)
+        n, h, w = t.shape
+        fn = lib().akz_extract_begin_host_u8 if t.dtype == torch.uint8 else lib().akz_extract_begin_host_f32
         job = C.c_void_p()
         _check(fn(self._h, C.c_void_p(t.data_ptr()), w, h, n, C.byref(options), flags, C.byref(job)))
         return Job(self, job, t)

@@ -203,6 +203,15 @@ int akz_extract_begin_device_u8(akz_ctx* ctx, const uint8_t* d_imgs, uint32_t w,
                                 const akz_config* cfg, uint32_t flags, akz_job** out);
 int akz_extract_begin_device_f32(akz_ctx* ctx, const float* d_imgs, uint32_t w, uint32_t h, uint32_t n,
                                  const akz_config* cfg, uint32_t flags, akz_job** out);
+/* The same for frames in HOST memory (the reference's extract_features starts from host data, lib.rs:171-178): the
+   n frames are copied into a staging buffer of the context on its COPY stream, the extraction waits for that copy
+   only -- so with batch j+1 begun before batch j is finished, the upload of j+1 runs under the kernels of j.  Pinned
+   memory (hipHostMalloc / hipHostRegister) makes the copy asynchronous; pageable memory works and is staged by the
+   runtime.  h_imgs must stay valid until the job is finished or abandoned. */
+int akz_extract_begin_host_u8(akz_ctx* ctx, const uint8_t* h_imgs, uint32_t w, uint32_t h, uint32_t n,
+                              const akz_config* cfg, uint32_t flags, akz_job** out);
+int akz_extract_begin_host_f32(akz_ctx* ctx, const float* h_imgs, uint32_t w, uint32_t h, uint32_t n,
+                               const akz_config* cfg, uint32_t flags, akz_job** out);
 int akz_extract_finish(akz_job* job, akz_result** out);
 int akz_job_abandon(akz_job* job);
 

@@ -475,3 +475,30 @@ def test_ops_on_caller_held_evolutions(ctx, amd, ref):
         ctx.extract_from_planes(517, 389, planes[:-1])   # wrong number of evolutions
     res.close()
     r2.close()
+
+
+def test_host_frames_begin_matches_device_frames(amd, ref):
+    """akz_extract_begin_host_*: frames in (pinned) host memory, uploaded on the context's copy stream into per-slot
+    staging buffers.  Three jobs in flight with three DIFFERENT batches (a staging buffer that was reused too early
+    would mix them up), then a second round that reuses the slots; u8 and f32; byte-identical to device input."""
+    import torch
+    c = amd.Context(0, torch.cuda.Stream().cuda_stream)
+    try:
+        sets = [np.stack([amd.synth_frame(400, 300, 10 * k + i) for i in range(2)]) for k in range(3)]
+        exp = [c.extract_features(torch.from_numpy(s).cuda(), keep_all_planes=False) for s in sets]
+        for rnd in range(2):
+            hosts = [torch.from_numpy(s).pin_memory() if rnd == 0 else s.copy() for s in sets]  # pinned, then pageable
+            jobs = [c.extract_begin_host(h, keep_all_planes=False) for h in hosts]
+            got = [j.finish() for j in jobs]
+            for g, e in zip(got, exp):
+                for i in range(2):
+                    assert g.keypoints(i).tobytes() == e.keypoints(i).tobytes()
+                    assert g.descriptors(i).tobytes() == e.descriptors(i).tobytes()
+                    assert g.contrast(i) == e.contrast(i)
+        f32 = (sets[1].astype(np.float32) * np.float32(1.0)) / np.float32(255.0)
+        g = c.extract_begin_host(f32).finish()
+        assert_same_result(g, ref.extract(f32[1]), img=1)
+        with pytest.raises(amd.AkazeError):
+            [c.extract_begin_host(sets[0]) for _ in range(4)]  # a fourth job in flight is refused
+    finally:
+        c.close()

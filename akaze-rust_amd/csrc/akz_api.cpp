@@ -60,11 +60,13 @@ struct akz_ctx {
     DevBuf lazy[6];                          // one-image planes of akz_fetch_plane's recomputation (never shared with scratch users)
     DevBuf small;                            // hmax bits / histogram / counters
     DevBuf cand;                             // NMS candidates
+    DevBuf cand_sorted, sort_scratch;        // the list in scan order (device sort of extract_finish) and the sort's scratch
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
     int match_mode = 2;                      // 0: popcount kernel, 1 / 2 (default): matrix-core kernel (akz_ctx_set_match_mode)
     uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
+    int dbg_host_sort = -1;                            // akz_debug_set_host_sort: 1 / 0 force the host / the device sort, -1 automatic
     DevBuf cosi;                             // (cos, sin) per keypoint
     DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
                                              // rows, keypoint params, (cos, sin), contrast factors
@@ -100,8 +102,9 @@ struct akz_ctx {
     std::vector<hipEvent_t> ev_pool;  // recycled events
     hipEvent_t fed_done = nullptr;     // recorded by every extract_begin behind its last diffusion launch
     std::unique_ptr<WorkerPool> workers;  // host threads of the finish half (started on first use)
+    unsigned host_threads = 0;            // akz_ctx_set_host_threads; 0 = sized by host_cpu_share()
     WorkerPool& pool() {
-        if (!workers) workers.reset(new WorkerPool(std::min(host_cpu_share(), 16u) - 1));
+        if (!workers) workers.reset(new WorkerPool(std::min(host_threads ? host_threads : host_cpu_share(), 16u) - 1));
         return *workers;
     }
 };
@@ -279,7 +282,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
-                      &c->small, &c->cand, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
+                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1218,11 +1221,26 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
     const double t_fetch0 = now_ms();
     double t_counts = t_fetch0;
 
-    // ---- candidates: the list length, then exactly the used part of the list ----
+    // ---- candidates: sorted into scan order on the device, then the list length and exactly the used part ----
     uint32_t cap = job->cap;
     uint32_t* d_count = (uint32_t*)c->count_slot[job->slot].p;
-    std::vector<std::vector<Candidate>> cands(n);
+    const uint64_t max_px = (uint64_t)plan[0].w * plan[0].h;
+    // Where the list is put into scan order: with four or more host threads bucketing + sorting are 0.15 ms of wall time
+    // per 32-frame batch and the dozen small launches of the device sort cost the kernels of the next batch more
+    // (-1.5 % throughput); with the two threads a rank has on a node whose cores are shared by eight ranks they are a
+    // fifth of a host phase that no longer hides under the GPU step (+7 % throughput with the device sort).
+    bool sorted = false;
+    if (c->dbg_host_sort == 0 || (c->dbg_host_sort < 0 && c->pool().size() < 4)) {
+        AKZ_TRY(ensure(c, c->cand_sorted, (size_t)cap * sizeof(Candidate)));
+        AKZ_TRY(ensure(c, c->sort_scratch, launch::sort_candidates_scratch(cap, max_px, (uint32_t)L, n)));
+        sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
+                                                n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p);
+        AKZ_HIP_TRY(hipGetLastError());
+    }
+    const Candidate* hc = nullptr;   // the whole list on the host (pinned)
+    uint32_t total_c = 0;
     for (int attempt = 0;; ++attempt) {
+        const Candidate* d_list = sorted ? (const Candidate*)c->cand_sorted.p : (const Candidate*)c->cand_slot[job->slot].p;
         AKZ_TRY(ensure_pinned(c, c->pin[1], 256));
         uint32_t* total_p = (uint32_t*)c->pin[1].p;
         AKZ_HIP_TRY(hipMemcpyAsync(total_p, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1236,22 +1254,22 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             AKZ_HIP_TRY(hipMemcpyAsync(c->pin[5].p, r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
             if (spec) {
                 AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec * sizeof(Candidate)));
-                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->cand_slot[job->slot].p, (size_t)spec * sizeof(Candidate),
-                                           hipMemcpyDeviceToHost, s));
+                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, d_list, (size_t)spec * sizeof(Candidate), hipMemcpyDeviceToHost, s));
             }
         }
         AKZ_HIP_TRY(hipStreamSynchronize(s));
         t_counts = now_ms();
-        const uint32_t total_c = *total_p;
+        total_c = *total_p;
         if (attempt == 0) r->k_host.assign((const double*)c->pin[5].p, (const double*)c->pin[5].p + n);
         c->last_total_cands = total_c;
         c->cand_cap_hint = std::max(c->cand_cap_hint, (uint32_t)((uint64_t)total_c * 5 / 4 / n) + 64u);
-        if (total_c > cap) {  // overflow: grow and redo the NMS pass alone on the stored Ldet planes
+        if (total_c > cap) {  // overflow: grow and redo the NMS pass alone on the stored Ldet planes (the host sorts that list)
             if (attempt >= 3) {
                 set_error("NMS candidate buffer overflow");
                 return AKZ_ERR_OVERFLOW;
             }
             cap = total_c + total_c / 8;
+            sorted = false;
             AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
             AKZ_TRY(ensure(c, c->cand_slot[job->slot], (size_t)cap * sizeof(Candidate)));
             AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
@@ -1268,14 +1286,28 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             if (have) keep.assign((const Candidate*)c->pin[0].p, (const Candidate*)c->pin[0].p + have);  // ensure_pinned may move the buffer
             AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)total_c * sizeof(Candidate)));
             if (have) std::memcpy(c->pin[0].p, keep.data(), (size_t)have * sizeof(Candidate));
-            AKZ_HIP_TRY(hipMemcpyAsync((Candidate*)c->pin[0].p + have, (const Candidate*)c->cand_slot[job->slot].p + have,
-                                       (size_t)(total_c - have) * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+            AKZ_HIP_TRY(hipMemcpyAsync((Candidate*)c->pin[0].p + have, d_list + have, (size_t)(total_c - have) * sizeof(Candidate),
+                                       hipMemcpyDeviceToHost, s));
             AKZ_HIP_TRY(hipStreamSynchronize(s));
         }
         AKZ_TRY(ensure_pinned(c, c->pin[0], sizeof(Candidate)));
-        Candidate* hc = (Candidate*)c->pin[0].p;
+        hc = (const Candidate*)c->pin[0].p;
+        break;
+    }
+    // per image: a range of the sorted list, or (host fallback) a bucket of the unordered one, sorted below
+    std::vector<std::vector<Candidate>> cands;
+    std::vector<std::pair<const Candidate*, size_t>> span(n, {nullptr, 0});
+    if (sorted) {
+        size_t at = 0;
+        for (uint32_t img = 0; img < n; ++img) {
+            const Candidate* b = hc + at;
+            const Candidate* e = std::partition_point(b, hc + total_c, [&](const Candidate& x) { return x.img <= img; });
+            span[img] = {b, (size_t)(e - b)};
+            at += (size_t)(e - b);
+        }
+    } else {
+        cands.resize(n);
         // bucket the unordered list by image: slices of the list are counted and scattered by separate threads
-        // (a 32-frame batch has ~2 x 10^5 candidates)
         const unsigned slices = (unsigned)std::min<size_t>((size_t)total_c / 16384 + 1, (size_t)c->pool().size());
         std::vector<std::vector<uint32_t>> at(slices, std::vector<uint32_t>(n, 0));  // counts, then write offsets
         auto slice_range = [&](unsigned t, size_t* b, size_t* e) {
@@ -1304,7 +1336,6 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             for (size_t i = b; i < e; ++i)
                 if (hc[i].img < n) cands[hc[i].img][at[t][hc[i].img]++] = hc[i];
         });
-        break;
     }
     c->slot_busy[job->slot] = false;  // the candidate buffers may be reused by the next begin
     job->slot = -1;
@@ -1319,8 +1350,11 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
     r->desc_off.assign(n + 1, 0);
     {
         c->pool().run(n, [&](size_t img) {  // images are independent
-            sort_candidates(cands[img], plan);
-            select_keypoints(cands[img], plan, cfg, hk[img], &r->n_extrema[img]);
+            if (!sorted) {
+                sort_candidates(cands[img], plan);
+                span[img] = {cands[img].data(), cands[img].size()};
+            }
+            select_keypoints(span[img].first, span[img].second, plan, cfg, hk[img], &r->n_extrema[img]);
         });
     }
     for (uint32_t img = 0; img < n; ++img) {
@@ -1608,9 +1642,11 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
         l->cand_cap_hint = c->cand_cap_hint;
         l->stream_min_px = c->stream_min_px;
+        l->host_threads = c->host_threads;
         l->profiling = c->profiling;
         l->dbg_pair_chunks = c->dbg_pair_chunks;
         l->dbg_set_chunks = c->dbg_set_chunks;
+        l->dbg_host_sort = c->dbg_host_sort;
         c->lanes.push_back(l);
     }
     c->next_lane = 0;
@@ -2188,7 +2224,7 @@ int akz_host_select_keypoints(uint32_t w, uint32_t h, const akz_config* cfg, con
     sort_candidates(c, plan);
     std::vector<HostKeypoint> hk;
     uint64_t ne = 0;
-    select_keypoints(c, plan, *cfg, hk, &ne);
+    select_keypoints(c.data(), c.size(), plan, *cfg, hk, &ne);
     *n_out = hk.size();
     if (n_extrema) *n_extrema = ne;
     if (out)
@@ -2303,6 +2339,19 @@ int akz_ctx_set_prep_mode(akz_ctx* c, int mode) {
     return AKZ_OK;
 }
 
+int akz_ctx_set_host_threads(akz_ctx* c, uint32_t threads) {
+    AKZ_TRY(bind(c));
+    if (threads > 256) return AKZ_ERR_INVALID_ARG;
+    for (int k = 0; k < akz_ctx::kSlots; ++k)
+        if (c->slot_busy[k]) {
+            set_error("akz_ctx_set_host_threads: extractions are in flight on this context");
+            return AKZ_ERR_INVALID_ARG;
+        }
+    c->host_threads = threads;
+    c->workers.reset();  // joins the old pool; the next finish starts the new one
+    for (akz_ctx* l : c->lanes) AKZ_TRY(akz_ctx_set_host_threads(l, threads));
+    return AKZ_OK;
+}
 int akz_ctx_set_candidate_hint(akz_ctx* c, uint32_t per_image) {
     AKZ_TRY(bind(c));
     c->cand_cap_hint = std::max<uint32_t>(per_image, 16u);
@@ -2332,6 +2381,12 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
     return AKZ_OK;
 }
 const char* akz_detector_kernel_name(void) { return "k_detector_march"; }
+int akz_debug_set_host_sort(akz_ctx* c, int on) {
+    if (!c) return AKZ_ERR_INVALID_ARG;
+    c->dbg_host_sort = on < 0 ? -1 : (on != 0);
+    for (akz_ctx* l : c->lanes) l->dbg_host_sort = c->dbg_host_sort;
+    return AKZ_OK;
+}
 int akz_debug_set_match_chunks(akz_ctx* c, uint32_t pair_chunks, uint32_t set_chunks) {
     if (!c || set_chunks > 16) return AKZ_ERR_INVALID_ARG;
     c->dbg_pair_chunks = pair_chunks;

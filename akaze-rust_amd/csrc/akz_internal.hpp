@@ -203,6 +203,11 @@ void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, flo
                         float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat);
+// the candidate list into scan order on the device (akz_sort.hip): by image, level, flat pixel index.  false: the
+// batch needs more key bits than the sort takes (the host then sorts)
+size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images);
+bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, uint64_t max_px,
+                            uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted);
 // candidates of all images are appended to ONE list (d_count is a single counter, cap the list capacity)
 void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
@@ -256,7 +261,7 @@ struct HostKeypoint {
 // unordered NMS survivors of one image into the reference's scan order: level, then flat index
 void sort_candidates(std::vector<Candidate>& cands, const std::vector<LevelPlan>& plan);
 // scale_space_extrema.rs:12-132 on raster-ordered candidates, then :141-178 (refinement w/o orientation)
-void select_keypoints(const std::vector<Candidate>& cands_sorted, const std::vector<LevelPlan>& plan,
+void select_keypoints(const Candidate* cands_sorted, size_t n_cands, const std::vector<LevelPlan>& plan,
                       const akz_config& cfg, std::vector<HostKeypoint>& out, uint64_t* n_extrema);
 // which of the sliding windows of compute_main_orientation contain atan2f(a, a), a > 0
 void orientation_windows(unsigned long long* mask, uint32_t* n_windows);

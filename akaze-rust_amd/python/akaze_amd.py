@@ -158,7 +158,9 @@ def lib():
         "akz_debug_march_bands": ([i32, u32, u32, u32, i32, C.POINTER(i32), u32, pu32], i32),
         "akz_ctx_set_lanes": ([vp, u32], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
+        "akz_ctx_set_host_threads": ([vp, u32], i32),
         "akz_debug_set_match_chunks": ([vp, u32, u32], i32),
+        "akz_debug_set_host_sort": ([vp, i32], i32),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
         "akz_estimate_fundamental_matrix": ([vp, u64, vp, u64, vp, C.c_float, fp, C.POINTER(i32)], i32),
@@ -349,6 +351,14 @@ class Context:
         p = Profile()
         _check(lib().akz_ctx_get_profile(self._h, C.byref(p), int(reset)))
         return p.as_dict()
+
+    def set_host_threads(self, threads):
+        """akz_ctx_set_host_threads: host threads of the finish half (0 = automatic)."""
+        _check(lib().akz_ctx_set_host_threads(self._h, int(threads)))
+
+    def debug_set_host_sort(self, on):
+        """akz_debug_set_host_sort: candidates bucketed and sorted on the host instead of the device sort."""
+        _check(lib().akz_debug_set_host_sort(self._h, -1 if on is None else (1 if on else 0)))
 
     def debug_set_match_chunks(self, pair_chunks=0, set_chunks=0):
         """akz_debug_set_match_chunks (include/akaze_hip_debug.h): force the matcher's chunk counts; 0 = automatic."""

@@ -120,10 +120,98 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", choices=["capi", "torch"], default="capi",
                     help="capi: akz_gather_begin/finish of the C ABI (own RCCL communicator, gloo only for rendezvous and "
                          "barriers); torch: torch.distributed all_gather on the nccl backend")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a ONE-GPU box: every rank runs on device 0 (real extraction ranks, "
+                         "real rendezvous, capacity agreement and pipelined retire); the descriptor rows travel D2H -> gloo "
+                         "all-gather -> H2D, because RCCL refuses two ranks on one device.  The line says so.")
+    ap.add_argument("--host-share", type=int, default=0,
+                    help="run as ONE rank of a K-rank node: the affinity mask is cut to 1/K of the allowed cores before "
+                         "anything touches the GPU (the context's host worker pool is sized by the mask)")
+    ap.add_argument("--no-host-share-leg", action="store_true", help="skip the child run that measures --host-share 8")
+    ap.add_argument("--sort", choices=["auto", "host", "device"], default="auto",
+                    help="A/B: where the extrema candidates are put into scan order (akz_debug_set_host_sort)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test without a GPU: a stub context (sleeps, fake rows) and the gloo backend; the "
                          "line it prints says so and is not a measurement")
     return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------------
+# host placement of a rank: BEFORE anything initialises HIP (the runtime's helper threads inherit the mask)
+# --------------------------------------------------------------------------------------------------
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(local_rank):
+    """NUMA node of the local_rank-th GPU from the KFD topology in sysfs (no HIP call): the GPU nodes in node order are
+    the runtime's device order unless *_VISIBLE_DEVICES reorders them, which is honoured for plain index lists."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    gpus = []
+    for name in sorted(os.listdir(base), key=lambda s: int(s) if s.isdigit() else 1 << 30):
+        try:
+            props = dict(ln.split(None, 1) for ln in open(os.path.join(base, name, "properties")).read().splitlines() if " " in ln)
+        except Exception:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            gpus.append(props)
+    order = list(range(len(gpus)))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v and all(p.strip().isdigit() for p in v.split(",")):
+            order = [order[int(p)] for p in v.split(",") if int(p) < len(order)]
+    if local_rank >= len(order):
+        return None
+    p = gpus[order[local_rank]]
+    loc, dom = int(p.get("location_id", "0")), int(p.get("domain", "0"))
+    bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+    try:
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+    except Exception:
+        return None
+    return node if node >= 0 else None
+
+
+def place_rank(args):
+    """Affinity of this rank, set before the first GPU call: --host-share K keeps 1/K of the allowed cores (and sets
+    LOCAL_WORLD_SIZE=K); a rank of a multi-rank job takes its share of the cores of ITS GPU's NUMA node."""
+    info = {}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return info
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    usable = effective_cpus()  # the mask cut down by the cgroup CPU quota: what the whole node's ranks share
+    if args.host_share > 1:
+        k = args.host_share
+        keep = allowed[:max(1, usable // k)]
+        os.sched_setaffinity(0, keep)
+        info = {"host_share": k, "cpus": len(keep), "of": usable}
+    elif local_world > 1 and not args.stub:
+        node = None
+        try:
+            node = gpu_numa_node(0 if args.share_gpu else local_rank)
+            if node is not None:
+                cpus = sorted(_parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) & set(allowed))
+                # the ranks whose GPUs hang off this node split its cores
+                peers = [r for r in range(local_world) if gpu_numa_node(0 if args.share_gpu else r) == node]
+                if cpus and local_rank in peers:
+                    per = max(1, len(cpus) // len(peers))
+                    i = peers.index(local_rank)
+                    keep = cpus[i * per:(i + 1) * per] or cpus
+                    os.sched_setaffinity(0, keep)
+                    info = {"numa_node": node, "cpus": max(1, min(len(keep), usable // local_world)), "mask": len(keep),
+                            "ranks_on_node": len(peers)}
+        except Exception as e:  # placement is best effort: never a reason to fail the run
+            info = {"numa_node": node, "error": str(e)}
+    return info
 
 
 # --------------------------------------------------------------------------------------------------
@@ -140,6 +228,7 @@ def launch_ranks(args, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("AKZ_BENCH_PINNED", None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
@@ -235,6 +324,8 @@ def main_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    placement = place_rank(args)  # before torch / HIP exist in this process
+    dev_index = 0 if args.share_gpu else local_rank
 
     import numpy as np
     import torch
@@ -242,7 +333,7 @@ def main_rank(args):
 
     stub = args.stub
     use_dist = world > 1 or args.force_dist
-    exchange = "gloo-stub" if stub else args.exchange
+    exchange = "gloo-stub" if stub else ("gloo" if args.share_gpu else args.exchange)
     W, H, F = args.width, args.height, args.frames
     if F < 1:
         raise SystemExit(f"rank {rank}: --frames must be >= 1")
@@ -252,8 +343,8 @@ def main_rank(args):
         dev = torch.device("cpu")
     else:
         import akaze_amd as A
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
 
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -296,9 +387,13 @@ def main_rank(args):
         # blocking stream in the process (RCCL has some) and would serialise the pipeline.
         main = torch.cuda.Stream(dev)
         torch.cuda.set_stream(main)
-        ctx = A.Context(local_rank, main.cuda_stream)
+        ctx = A.Context(dev_index, main.cuda_stream)
+        if placement.get("cpus"):  # this rank owns exactly these cores: no second division by LOCAL_WORLD_SIZE
+            ctx.set_host_threads(placement["cpus"])
         ctx.set_detector_mode(args.det_mode)
         ctx.set_prep_mode(args.prep_mode)
+        if args.sort != "auto":
+            ctx.debug_set_host_sort(args.sort == "host")
     NP = max(1, min(args.parts, F))
     cut = [(F * i) // NP for i in range(NP + 1)]
     batches = [d_frames[cut[i]:cut[i + 1]] for i in range(NP)]
@@ -308,18 +403,19 @@ def main_rank(args):
     if not stub and not args.no_host_input:
         h_frames = torch.from_numpy(frames).pin_memory()
         h_batches = [h_frames[cut[i]:cut[i + 1]] for i in range(NP)]
-    src = {"host": False}
+    frame_src = {"host": False}
 
     # ---- the exchange: one all-gather of descriptor rows per step, begun when the step's results exist, retired when
     # the next step's results exist (or at the end of the timed region) ----
-    xch = {"host_ms": 0.0, "wait_ms": 0.0, "cap": 0, "pending": None, "comm": None, "mode": exchange if use_dist else "none"}
+    xch = {"host_ms": 0.0, "wait_ms": 0.0, "cap": 0, "pending": None, "comm": None, "mode": exchange if use_dist else "none",
+           "ranks_seen": None, "seq": 0}
     if use_dist and exchange == "capi":
         try:
             uid = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8)
             if rank == 0:
                 uid = torch.frombuffer(bytearray(A.comm_unique_id()), dtype=torch.uint8).clone()
             dist.broadcast(uid, src=0)
-            xch["comm"] = A.Comm(local_rank, bytes(uid.numpy().tobytes()), rank, world)
+            xch["comm"] = A.Comm(dev_index, bytes(uid.numpy().tobytes()), rank, world)
             ok = 1.0
         except Exception as e:  # RCCL cannot be loaded / initialised: fall back to torch.distributed on every rank
             sys.stderr.write(f"rank {rank}: C-ABI exchange unavailable ({e}); falling back to torch.distributed\n")
@@ -344,10 +440,18 @@ def main_rank(args):
             return
         t0 = time.perf_counter()
         if exchange == "capi":
-            g.finish(want_counts=False)
+            _, _, cnts_r, imgs_r = g.finish(want_counts=True)  # the headers of all blocks: who took part
+            xch["ranks_seen"] = sum(1 for v in imgs_r if v > 0)
             g.free()
         elif exchange == "torch":
             g[0].synchronize()  # event behind the collectives on the side stream
+            xch["ranks_seen"] = int((g[1] > 0).sum().item())
+        elif exchange == "gloo":
+            work, gathered_h, gathered_d, seq = g
+            work.wait()
+            gathered_d.copy_(gathered_h, non_blocking=True)  # H2D: where a following match would read the rows
+            hdr = gathered_h.view(world, -1, 64)[:, 0, :].contiguous().view(torch.int64)  # row 0 of every block
+            xch["ranks_seen"] = int(((hdr[:, 1] > 0) & (hdr[:, 3] == seq) & (hdr[:, 2] == xch["cap"])).sum().item())
         xch["wait_ms"] += (time.perf_counter() - t0) * 1e3
         xch["pending"] = None
 
@@ -382,7 +486,27 @@ def main_rank(args):
                 dist.all_gather_into_tensor(gathered, local, group=xch["group"])
                 ev = torch.cuda.Event()
                 ev.record(side)
-            xch["pending"] = (ev,)
+            xch["pending"] = (ev, cnts)
+        elif exchange == "gloo":
+            # --share-gpu rehearsal: the wire format of the C ABI (header row + rows, fixed capacity) over the host
+            cap = xch["cap"]
+            if "bufs" not in xch:
+                xch["bufs"] = [(torch.zeros((1 + cap, 64), dtype=torch.uint8, device=dev),
+                                torch.zeros((1 + cap, 64), dtype=torch.uint8).pin_memory(),
+                                torch.empty((world * (1 + cap), 64), dtype=torch.uint8).pin_memory(),
+                                torch.empty((world * (1 + cap), 64), dtype=torch.uint8, device=dev)) for _ in range(2)]
+                xch["flip"] = 0
+            local_d, local_h, gathered_h, gathered_d = xch["bufs"][xch["flip"]]
+            xch["flip"] ^= 1
+            o = 1
+            for res in results:
+                o += res.copy_device_descriptors(local_d[o:])
+            xch["seq"] += 1
+            n_img = sum(res.num_images for res in results)
+            local_h.copy_(local_d)  # D2H (synchronous: the rows are complete)
+            local_h[0].view(torch.int64)[:4] = torch.tensor([rows, n_img, cap, xch["seq"]], dtype=torch.int64)
+            work = dist.all_gather_into_tensor(gathered_h, local_h, async_op=True)
+            xch["pending"] = (work, gathered_h, gathered_d, xch["seq"])
         xch["host_ms"] += (time.perf_counter() - t0) * 1e3
 
     if stub:
@@ -426,7 +550,7 @@ def main_rank(args):
         for _ in range(k_steps):
             for bi, bt in enumerate(batches):
                 tb = time.perf_counter()
-                if src["host"]:
+                if frame_src["host"]:
                     job = ctx.extract_begin_host(h_batches[bi], cfg, keep_all_planes=not args.lean)
                 else:
                     job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean)
@@ -464,7 +588,7 @@ def main_rank(args):
     run_steps(1)
     warm_prof = ctx.get_profile(reset=True)
     ctx.set_profiling(0 if args.no_profile else 2)
-    want_check = not stub and rank == 0 and not args.no_self_check
+    want_check = not stub and ((rank == 0 and not args.no_self_check) or use_dist or F <= 4)
     barrier()
     t0 = time.perf_counter()
     xch["host_ms"] = xch["wait_ms"] = 0.0
@@ -485,14 +609,14 @@ def main_rank(args):
     host_input = None
     if h_batches is not None:
         ctx.set_profiling(0)
-        src["host"] = True
+        frame_src["host"] = True
         run_steps(min(3, max(1, args.warmup)))
         barrier()
         t0 = time.perf_counter()
         nk_h = run_steps(args.steps)
         barrier()
         el_h = host_max(time.perf_counter() - t0)
-        src["host"] = False
+        frame_src["host"] = False
         v_h = total_px / el_h / 1e6
         host_input = {"value": round(v_h, 2), "unit": "Mpix/s", "ms_per_step": round(el_h / max(1, args.steps) * 1e3, 3),
                       "of_hbm_resident": round(v_h / value, 4), "keypoints_per_step_rank0": nk_h,
@@ -617,6 +741,29 @@ def main_rank(args):
                              "(tools/membw/hbm_ceiling.hip)")
         del big, src
         roof_det["standalone_frac"] = det_alone["sigma_size_3"]["frac"]
+
+    # ---- what every rank computed, by GLOBAL frame index (frame i of the job lives on rank i mod world): sha256 of the
+    # keypoints + descriptor bytes of the first frames of each shard, gathered to rank 0.  A --gpus 2 --share-gpu run and
+    # a single-rank run over the same frames must print the same table (tests/test_gpu_gather.py). ----
+    frame_sha = None
+    if not stub and keep_last["results"]:
+        import hashlib
+        mine = {}
+        gidx = A.shard_frames(world * F, rank, world)
+        for k in range(min(F, 4 if F <= 4 else 2)):
+            part = next(i for i in range(NP) if cut[i] <= k < cut[i + 1])
+            rb, kb = keep_last["results"][part], k - cut[part]
+            mine[int(gidx[k])] = hashlib.sha256(rb.keypoints(kb).tobytes() + rb.descriptors(kb).tobytes()).hexdigest()[:16]
+        if use_dist:
+            allsha = [None] * world
+            dist.all_gather_object(allsha, mine)
+            frame_sha = {str(k): v for d in allsha for k, v in sorted(d.items())}
+        else:
+            frame_sha = {str(k): v for k, v in sorted(mine.items())}
+        if not (rank == 0 and not args.no_self_check):
+            for r in keep_last["results"]:
+                r.close()
+            keep_last["results"] = None
 
     # ---- self-check of the timed configuration (untimed): frame k of the batch == the same frame extracted alone ----
     self_check = None
@@ -772,6 +919,27 @@ def main_rank(args):
         single["multi_context"] = {"contexts": K, "ms_per_frame": round(per * 1e3, 3),
                                    "Mpix_s": round(W * H / per / 1e6, 1)}
 
+    # ---- one rank of an 8-rank node: a child run of the same workload with 1/8 of the host cores (the affinity mask is
+    # cut before the child touches the GPU); this process is idle meanwhile.  The host half of a batch (candidate
+    # bucketing, keypoint selection, libm) must still hide under the next batch's kernels. ----
+    host_share_leg = None
+    if rank == 0 and world == 1 and not args.no_host_share_leg and not args.host_share and not stub:
+        try:
+            torch.cuda.synchronize()
+            cmd = [sys.executable, os.path.abspath(__file__), "--host-share", "8", "--steps", str(min(args.steps, 20)),
+                   "--warmup", str(min(args.warmup, 5)), "--frames", str(F), "--width", str(W), "--height", str(H),
+                   "--octaves", str(args.octaves), "--sublevels", str(args.sublevels), "--no-cpu-baseline", "--no-fed4k",
+                   "--no-single", "--no-match", "--no-self-check", "--no-host-input", "--no-host-share-leg"] + (["--lean"] if args.lean else [])
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            ln = [x for x in p.stdout.splitlines() if x.startswith("{")]
+            d = json.loads(ln[-1])
+            host_share_leg = {"value": d["value"], "of_full_host": round(d["value"] / value, 4),
+                              "cpus": d["config"]["placement"]["cpus"], "cpus_full": effective_cpus(),
+                              "host_ms_in_finish_per_batch": d["config"]["host_ms_in_finish_per_batch"]}
+        except Exception as e:
+            host_share_leg = {"error": str(e)[:200]}
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -828,6 +996,8 @@ def main_rank(args):
             "metric": f"Mpix/s through extract_features ({args.octaves} oct x {args.sublevels} sub)",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            **({"rehearsal": "all ranks share ONE GPU (--share-gpu): a functional run of the N > 1 path, not a scaling number"}
+               if args.share_gpu else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
@@ -836,7 +1006,14 @@ def main_rank(args):
                        "frames_per_gpu": F, "width": W, "height": H, "batches_per_step": NP,
                        "pipelining": "begin(batch j+1) before finish(batch j) on one stream, across steps",
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
-                       "exchange": {"capi": "RCCL all-gather of descriptor rows through the C ABI (akz_gather_begin / _finish), "
+                       "exchange_ranks_seen": xch["ranks_seen"],
+                       "placement": placement or None,
+                       "share_gpu": bool(args.share_gpu),
+                       "frame_sha256_16": frame_sha,
+                       "host_share_8ranks_Mpix_s": host_share_leg,
+                       "exchange": {"gloo": "--share-gpu rehearsal: every rank on device 0; descriptor rows D2H -> gloo all-gather "
+                                            "(C-ABI wire format) -> H2D, retired one step later",
+                                    "capi": "RCCL all-gather of descriptor rows through the C ABI (akz_gather_begin / _finish), "
                                             "one fixed-size collective per step, retired one step later",
                                     "torch": "RCCL all-gather of descriptor rows through torch.distributed, retired one step later",
                                     "none": "none (1 GPU)"}[xch["mode"]],

@@ -424,6 +424,11 @@ int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
    The caller's stream is respected (a lane starts behind what the caller enqueued before the call); results are
    bit-identical and are used through the same calls. */
 int akz_ctx_set_lanes(akz_ctx* ctx, uint32_t lanes);
+/* Host threads of the finish half of an extraction (candidate bucketing, per-image keypoint selection, libm calls):
+   0 (default) = automatic -- the affinity mask of the process, cut down by the cgroup CPU quota and divided by
+   LOCAL_WORLD_SIZE (one process per GPU: torchrun sets it), at most 16.  A launcher that has already pinned each rank
+   to its own cores passes that number here.  Not while extractions are in flight. */
+int akz_ctx_set_host_threads(akz_ctx* ctx, uint32_t threads);
 /* Matcher kernel: 2 (default) and 1 = matrix-core kernel (k_match_mfma: descriptor bits unpacked to int8,
    Hamming distances from one integer GEMM; faster than the popcount scan from 128 x 128 descriptors up),
    0 = popcount kernel (k_match).  Results are identical. */

@@ -27,6 +27,10 @@ const char* akz_detector_kernel_name(void);
    pair call, `set_chunks` (1..16) per set of a multi-set call; 0 = automatic (the default).  Results are identical for
    every value -- which is what the tests that use this check. */
 int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_chunks);
+/* Test hook: where the extrema candidates are put into scan order: 1 = bucketed and sorted on the HOST (also the fallback
+   that a candidate-list overflow and over-wide sort keys take), 0 = device sort, -1 = automatic (the default: device
+   sort for contexts with fewer than four host threads).  Results are identical. */
+int akz_debug_set_host_sort(akz_ctx* ctx, int on);
 
 #ifdef __cplusplus
 }

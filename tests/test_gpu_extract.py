@@ -502,3 +502,25 @@ def test_host_frames_begin_matches_device_frames(amd, ref):
             [c.extract_begin_host(sets[0]) for _ in range(4)]  # a fourth job in flight is refused
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("host_sort", [True, False])
+def test_candidate_order_host_and_device_sort(amd, ref, host_sort):
+    """The unordered candidate list is put into the reference's scan order either on the host (bucket by image, counting
+    sort) or on the device (radix sort by image, level, pixel): a batch with different candidate counts per image, an
+    image without any candidate, and a second call that reuses the buffers."""
+    import torch
+    c = amd.Context(0, torch.cuda.Stream().cuda_stream)
+    c.debug_set_host_sort(host_sort)
+    try:
+        frames = np.stack([amd.synth_frame(486, 270, 30 + i) for i in range(4)])
+        frames[2] = 128  # flat: no candidates at all
+        for _ in range(2):
+            res = c.extract_features(torch.from_numpy(frames).cuda(), keep_all_planes=False)
+            for i in range(4):
+                assert_same_result(res, ref.extract(frames[i]), planes=False, img=i, equal_nan=True)
+            res.close()
+        one = amd.synth_frame(1001, 300, 4)
+        assert_same_result(c.extract_features(one, keep_all_planes=False), ref.extract(one), planes=False)
+    finally:
+        c.close()

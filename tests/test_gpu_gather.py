@@ -72,3 +72,41 @@ def test_bench_force_dist_capi_world1():
     assert out["n_gpus"] == 1 and "C ABI" in out["config"]["exchange"]
     assert out["self_check"]["identical_to_single_frame_extraction"] is True
     assert out["roofline"]["kernel"] and out["roofline_2"]["kernel"]
+    assert out["config"]["exchange_ranks_seen"] == 1
+
+
+def _bench_json(extra, timeout=900):
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-fed4k", "--no-single", "--no-match", "--no-host-share-leg", "--width", "960", "--height", "540"] + extra,
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_two_real_ranks_share_one_gpu():
+    """The first N > 1 run, on the hardware there is: `bench.py --gpus 2 --share-gpu` starts two REAL extraction ranks on
+    device 0 (launcher, gloo rendezvous, capacity agreement, two HIP extraction processes at once, pipelined retire of
+    the exchange, rank pinning before HIP starts); the rows travel over gloo because RCCL refuses two ranks on one
+    device.  Frame i of the job lives on rank i mod 2: every frame's keypoints + descriptors must equal what ONE rank
+    computes for the same global frames."""
+    two = _bench_json(["--gpus", "2", "--share-gpu", "--frames", "2"])
+    one = _bench_json(["--gpus", "1", "--frames", "4"])
+    assert two["n_gpus"] == 2 and two["config"]["share_gpu"] is True and "rehearsal" in two
+    assert two["config"]["exchange_ranks_seen"] == 2
+    assert len(two["config"]["per_rank_Mpix_s"]) == 2 and all(v > 0 for v in two["config"]["per_rank_Mpix_s"])
+    assert two["self_check"]["identical_to_single_frame_extraction"] is True
+    sha2, sha1 = two["config"]["frame_sha256_16"], one["config"]["frame_sha256_16"]
+    assert sorted(sha2) == ["0", "1", "2", "3"] and sha2 == sha1, (sha2, sha1)
+    assert one["host_input"]["value"] > 0 and two["config"]["placement"] is not None
+
+
+def test_bench_host_share_of_an_8_rank_node():
+    """One rank with 1/8 of the host cores (the mask is cut before the process touches the GPU): same results, and the
+    line carries the share it ran with."""
+    full = _bench_json(["--frames", "4", "--no-host-input"])
+    eighth = _bench_json(["--frames", "4", "--no-host-input", "--host-share", "8"])
+    assert eighth["config"]["placement"]["host_share"] == 8 and eighth["config"]["placement"]["cpus"] >= 1
+    assert eighth["config"]["frame_sha256_16"] == full["config"]["frame_sha256_16"]

@@ -18,6 +18,7 @@ def rctx(amd):
     import torch
     c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
     c.set_prep_mode(3)
+    c.debug_set_host_sort(False)  # and the device sort of the candidate list (default only with < 4 host threads)
     yield c
     c.close()
 

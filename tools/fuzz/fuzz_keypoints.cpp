@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
             }
         std::vector<HostKeypoint> got, exp;
         uint64_t ne_got = 0, ne_exp = 0;
-        select_keypoints(shuffled, plan, cfg, got, &ne_got);
+        select_keypoints(shuffled.data(), shuffled.size(), plan, cfg, got, &ne_got);
         naive(cands, plan, cfg, exp, &ne_exp);
         if (ne_got != ne_exp || got.size() != exp.size()) {
             fprintf(stderr, "round %d: %zu/%llu keypoints/extrema, expected %zu/%llu\n", it, got.size(),

@@ -153,6 +153,57 @@ int main(int argc, char** argv) {
         TRY(akz_gather_free(g4));
     }
 
+    // (4) BASELINE configs[4] through the C ABI: all-pairs match over a gather; this rank's images are the queries.  Every
+    // (query, image) list must equal akz_descriptor_match of the two images' rows (taken from the gathered blocks).
+    {
+        akz_gather* g5 = nullptr;
+        TRY(akz_gather_begin(comm, rs, 1, cap, &g5));
+        akz_pairs* pairs = nullptr;
+        TRY(akz_match_all_pairs(ctx, g5, 10000, 0.86, &pairs));
+        uint64_t n_images = 0, first = 0, owned = 0;
+        TRY(akz_pairs_info(pairs, &n_images, &first, &owned));
+        CHECK(n_images == (uint64_t)NIMG * nranks && owned == NIMG && first == (uint64_t)rank * NIMG);
+        // per-image rows of this rank as the gather reports them == the result's own counts
+        uint64_t tab[8] = {0}, tab_n = 0;
+        TRY(akz_gather_image_rows(g5, rank, tab, 8, &tab_n));
+        CHECK(tab_n == NIMG);
+        std::vector<std::vector<uint8_t>> img_rows((size_t)n_images);
+        uint64_t off = 0;
+        for (uint64_t j = 0; j < n_images; ++j) {
+            uint64_t nr = 0;
+            int owner = -1;
+            TRY(akz_pairs_image_rows(pairs, j, &nr, &owner));
+            CHECK(owner == (int)(j / NIMG));
+            if (owner == rank) {
+                uint64_t nk = 0;
+                TRY(akz_result_counts(res, j - first, nullptr, &nk, nullptr));
+                CHECK(nk == nr && tab[j - first] == nr);
+            }
+            img_rows[(size_t)j].assign(all.begin() + (long)(off * 64), all.begin() + (long)((off + nr) * 64));  // `all`: rank-major rows of (1)
+            off += nr;
+        }
+        CHECK(off == total);
+        uint64_t checked = 0;
+        for (uint64_t q = first; q < first + owned; ++q)
+            for (uint64_t j = 0; j < n_images; ++j) {
+                uint64_t n = 0;
+                TRY(akz_pairs_matches(pairs, q, j, nullptr, 0, &n));
+                if (j == q) { CHECK(n == 0); continue; }
+                std::vector<akz_match> got((size_t)n + 1), exp(img_rows[(size_t)q].size() / 64 + 1);
+                TRY(akz_pairs_matches(pairs, q, j, got.data(), n, &n));
+                uint64_t ne = 0;
+                TRY(akz_descriptor_match(ctx, img_rows[(size_t)q].data(), img_rows[(size_t)q].size() / 64, img_rows[(size_t)j].data(),
+                                         img_rows[(size_t)j].size() / 64, 64, 10000, 0.86, exp.data(), &ne));
+                CHECK(n == ne && memcmp(got.data(), exp.data(), (size_t)n * sizeof(akz_match)) == 0);
+                checked += n;
+            }
+        CHECK(checked > 0);
+        uint64_t bad = 0;
+        CHECK(akz_pairs_matches(pairs, (first + owned) % n_images == first ? n_images : (first + owned) % n_images, 0, nullptr, 0, &bad) != AKZ_OK || nranks == 1);
+        TRY(akz_pairs_free(pairs));
+        TRY(akz_gather_free(g5));
+    }
+
     TRY(akz_result_free(res));
     TRY(akz_device_free(ctx, d_frames));
     TRY(akz_comm_destroy(comm));

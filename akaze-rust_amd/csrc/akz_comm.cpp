@@ -8,8 +8,8 @@
 // has no link-time dependency on it, so single-GPU users never load a communication library.
 //
 // Wire format: ONE all-gather per exchange.  Every rank contributes a block of (1 + cap_rows) 64-byte rows: row 0 is a
-// header {u64 rows, u64 images, u64 cap_rows, u64 sequence, u64 overflow}, rows 1.. are its descriptor rows, the rest is
-// padding.  A rank whose shard does not fit cap_rows STILL takes part in the collective: it sends the header alone with
+// header {u64 rows, u64 images, u64 cap_rows, u64 sequence, u64 overflow, u64 table rows}, rows 1.. are its descriptor
+// rows, followed by the table of rows per image (eight u64 per row; it counts against cap_rows), the rest is padding.  A rank whose shard does not fit cap_rows STILL takes part in the collective: it sends the header alone with
 // `overflow` set and `rows` = what it needed, and akz_gather_finish reports AKZ_ERR_BUFFER on EVERY rank (with the
 // counts filled in, so that all ranks can agree on a larger capacity and repeat the exchange).  What no rank can
 // detect before the collective is a DIFFERENT cap_rows on different ranks -- the message sizes then differ, which RCCL
@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -104,6 +105,10 @@ struct akz_gather {
     uint64_t* pinned = nullptr;  // header staging: 8 u64 per rank
     bool in_use = false;
     bool overflow = false;     // this rank's shard did not fit: it sent its header only
+    bool finished = false;     // akz_gather_finish has read the headers and the per-image tables
+    std::vector<uint64_t> hdr_rows, hdr_images;      // per rank, from the headers
+    std::vector<std::vector<uint64_t>> image_rows;   // per rank: rows of every image of its shard
+    std::vector<uint64_t> table;                     // this rank's per-image table, staged for the send block
 };
 
 struct akz_comm {
@@ -167,6 +172,7 @@ static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
     }
     g->in_use = true;
     g->overflow = false;
+    g->finished = false;
     *out = g;
     return AKZ_OK;
 }
@@ -174,12 +180,18 @@ static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
 // rows of `n_src` device blocks -> send block (copy stream), then one all-gather (exchange stream).  With wait_copy the
 // call returns once the local rows have been copied (the sources may then be released); it never waits for a collective.
 static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_src, const uint64_t* src_rows, uint64_t n_src,
-                          uint64_t images, hipStream_t producer, bool wait_copy) {
+                          uint64_t images, hipStream_t producer, bool wait_copy, const std::vector<uint64_t>* per_image = nullptr) {
     uint64_t rows = 0;
     for (uint64_t i = 0; i < n_src; ++i) rows += src_rows[i];
+    // rows per image travel behind the descriptor rows, eight per 64-byte row (raw rows of akz_gather_begin_rows are one
+    // image and need no table)
+    g->table.clear();
+    if (per_image) g->table = *per_image;
+    const uint64_t table_rows = (g->table.size() + 7) / 8;
+    g->table.resize(table_rows * 8, 0);
     // a shard that does not fit still takes part (header only, marked): a rank that skipped the collective would leave
     // every other rank waiting in it, and every later collective of the communicator mismatched
-    g->overflow = rows > g->cap_rows;
+    g->overflow = rows + table_rows > g->cap_rows;
     if (producer) {  // the rows are complete in the order of this stream
         AKZ_HIP_TRY(hipEventRecord(c->ready, producer));
         AKZ_HIP_TRY(hipStreamWaitEvent(c->cs, c->ready, 0));
@@ -190,7 +202,8 @@ static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_sr
     hdr[2] = g->cap_rows;
     hdr[3] = ++c->sequence;
     hdr[4] = g->overflow ? 1 : 0;
-    hdr[5] = hdr[6] = hdr[7] = 0;
+    hdr[5] = g->overflow ? 0 : table_rows;
+    hdr[6] = hdr[7] = 0;
     AKZ_HIP_TRY(hipMemcpyAsync(g->send, hdr, kRow, hipMemcpyHostToDevice, c->cs));
     uint64_t at = 1;
     for (uint64_t i = 0; i < n_src && !g->overflow; ++i) {
@@ -198,6 +211,8 @@ static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_sr
         AKZ_HIP_TRY(hipMemcpyAsync(g->send + at * kRow, d_src[i], src_rows[i] * kRow, hipMemcpyDeviceToDevice, c->cs));
         at += src_rows[i];
     }
+    if (!g->overflow && table_rows)  // (pageable source: the runtime stages it before the call returns)
+        AKZ_HIP_TRY(hipMemcpyAsync(g->send + at * kRow, g->table.data(), table_rows * kRow, hipMemcpyHostToDevice, c->cs));
     AKZ_HIP_TRY(hipEventRecord(c->copied, c->cs));
     AKZ_HIP_TRY(hipStreamWaitEvent(c->xs, c->copied, 0));
     AKZ_NCCL_TRY(rccl()->AllGather(g->send, g->recv, g->send_bytes, ncclUint8, c->nccl, c->xs));
@@ -307,7 +322,7 @@ int akz_gather_begin(akz_comm* c, const akz_result* const* results, uint64_t n_r
     *out = nullptr;
     AKZ_HIP_TRY(hipSetDevice(c->device));
     std::vector<const uint8_t*> src;
-    std::vector<uint64_t> rows;
+    std::vector<uint64_t> rows, per_image;
     uint64_t images = 0;
     for (uint64_t i = 0; i < n_results; ++i) {
         uint64_t n_img = 0;
@@ -320,6 +335,7 @@ int akz_gather_begin(akz_comm* c, const akz_result* const* results, uint64_t n_r
             AKZ_TRY(akz_result_device_descriptors(results[i], img, &p, &n));
             if (img == 0) base = p;
             total += n;
+            per_image.push_back(n);
         }
         images += n_img;
         src.push_back(base);
@@ -330,7 +346,7 @@ int akz_gather_begin(akz_comm* c, const akz_result* const* results, uint64_t n_r
     // akz_extract_finish returns with the descriptor rows complete, so there is no producer stream to wait for.  The
     // call returns when the local rows have been copied (on the copy stream, which never queues behind a collective):
     // the results may be freed right away.
-    int st = gather_enqueue(c, g, src.data(), rows.data(), src.size(), images, nullptr, true);
+    int st = gather_enqueue(c, g, src.data(), rows.data(), src.size(), images, nullptr, true, &per_image);
     if (st != AKZ_OK) {
         g->in_use = false;
         return st;
@@ -354,26 +370,60 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
     AKZ_HIP_TRY(hipSetDevice(c->device));
     // the headers of all blocks -> host (64 bytes per rank): an overflow anywhere is an error everywhere
     AKZ_HIP_TRY(hipEventSynchronize(g->done));
-    AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost, c->cs));
-    AKZ_HIP_TRY(hipStreamSynchronize(c->cs));
-    bool overflow = false;
-    for (int r = 0; r < c->nranks; ++r) {
-        const uint64_t* h = g->pinned + (size_t)r * 8;
-        if (h[2] != g->cap_rows) {
-            set_error("gather: ranks disagree on the block capacity (every rank must pass the same cap_rows)");
-            return AKZ_ERR_INVALID_ARG;
+    if (!g->finished) {
+        AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost, c->cs));
+        AKZ_HIP_TRY(hipStreamSynchronize(c->cs));
+        g->hdr_rows.assign((size_t)c->nranks, 0);
+        g->hdr_images.assign((size_t)c->nranks, 0);
+        g->image_rows.assign((size_t)c->nranks, {});
+        bool overflow = false;
+        for (int r = 0; r < c->nranks; ++r) {
+            const uint64_t* h = g->pinned + (size_t)r * 8;
+            if (h[2] != g->cap_rows) {
+                set_error("gather: ranks disagree on the block capacity (every rank must pass the same cap_rows)");
+                return AKZ_ERR_INVALID_ARG;
+            }
+            overflow = overflow || h[4] != 0 || h[0] + h[5] > g->cap_rows;
+            g->hdr_rows[(size_t)r] = h[0];
+            g->hdr_images[(size_t)r] = h[1];
         }
-        overflow = overflow || h[4] != 0 || h[0] > g->cap_rows;
-        if (counts) counts[r] = h[0];
-        if (images) images[r] = h[1];
+        if (!overflow)
+            for (int r = 0; r < c->nranks; ++r) {  // the per-image tables (a few rows per rank)
+                const uint64_t* h = g->pinned + (size_t)r * 8;
+                std::vector<uint64_t>& t = g->image_rows[(size_t)r];
+                t.assign((size_t)h[5] * 8, 0);
+                if (h[5])
+                    AKZ_HIP_TRY(hipMemcpy(t.data(), g->recv + (size_t)r * g->send_bytes + (1 + h[0]) * kRow, h[5] * kRow,
+                                          hipMemcpyDeviceToHost));
+                t.resize((size_t)std::min<uint64_t>(h[1], t.size()));
+                if (h[5] == 0 && h[1] == 1) t.assign(1, h[0]);  // raw rows: one image
+            }
+        g->overflow = overflow;
+        g->finished = true;
     }
-    if (overflow) {
+    for (int r = 0; r < c->nranks; ++r) {
+        if (counts) counts[r] = g->hdr_rows[(size_t)r];
+        if (images) images[r] = g->hdr_images[(size_t)r];
+    }
+    if (g->overflow) {
         set_error("gather: a rank's shard has more descriptor rows than the agreed capacity (counts hold what each rank needed; "
                   "repeat the exchange with a larger cap_rows on every rank)");
         return AKZ_ERR_BUFFER;
     }
     if (d_all) *d_all = g->recv;
     if (block_rows) *block_rows = 1 + g->cap_rows;
+    return AKZ_OK;
+}
+
+int akz_gather_image_rows(akz_gather* g, int rank, uint64_t* rows_per_image, uint64_t cap, uint64_t* n_images) {
+    if (!g || !g->in_use || !g->finished || rank < 0 || rank >= g->comm->nranks) {
+        set_error("akz_gather_image_rows: not a finished gather / rank out of range");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const std::vector<uint64_t>& t = g->image_rows[(size_t)rank];
+    if (n_images) *n_images = t.size();
+    if (rows_per_image)
+        for (size_t i = 0; i < t.size() && i < cap; ++i) rows_per_image[i] = t[i];
     return AKZ_OK;
 }
 
@@ -446,6 +496,121 @@ int akz_gather_descriptors(akz_comm* c, const uint8_t* d_local, uint64_t n_local
     akz_gather_free(g);
     AKZ_TRY(st);
     *d_all = c->sync_out;
+    return AKZ_OK;
+}
+
+// ---- all-pairs match over a finished gather (BASELINE configs[4]) ------------------------------------------------------
+}  // extern "C"
+struct akz_pairs {
+    akz_ctx* ctx = nullptr;
+    int device = 0;
+    uint8_t* d_all = nullptr;            // rows of every image of the job, rank-major, compacted
+    std::vector<uint64_t> rows, offset;  // per image
+    std::vector<int> owner;
+    uint64_t first_owned = 0, n_owned = 0;
+    std::vector<akz_match*> d_out;       // per owned image: n_images x rows(query) records
+    std::vector<uint64_t*> d_cnt;        // per owned image: n_images counts
+    std::vector<std::vector<uint64_t>> cnt;
+};
+extern "C" {
+
+int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold, double lowes_ratio, akz_pairs** out) {
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!ctx || !g || !g->in_use) {
+        set_error("akz_match_all_pairs: null context / not a gather in flight");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    akz_comm* c = g->comm;
+    const uint8_t* blocks = nullptr;
+    uint64_t block_rows = 0;
+    AKZ_TRY(akz_gather_finish(g, &blocks, &block_rows, nullptr, nullptr));
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    std::unique_ptr<akz_pairs, int (*)(akz_pairs*)> p(new akz_pairs, akz_pairs_free);
+    p->ctx = ctx;
+    p->device = c->device;
+    uint64_t total = 0;
+    for (int r = 0; r < c->nranks; ++r) {
+        if (r == c->rank) p->first_owned = p->rows.size();
+        uint64_t in_rank = 0;
+        for (uint64_t n : g->image_rows[(size_t)r]) {
+            p->offset.push_back(total + in_rank);
+            p->rows.push_back(n);
+            p->owner.push_back(r);
+            in_rank += n;
+        }
+        if (in_rank != g->hdr_rows[(size_t)r]) {
+            set_error("akz_match_all_pairs: a block's per-image table does not add up to its row count");
+            return AKZ_ERR_INVALID_ARG;
+        }
+        if (r == c->rank) p->n_owned = g->image_rows[(size_t)r].size();
+        total += in_rank;
+    }
+    const uint64_t n_images = p->rows.size();
+    AKZ_HIP_TRY(hipMalloc((void**)&p->d_all, std::max<uint64_t>(1, total) * kRow));
+    hipStream_t ms = (hipStream_t)akz_ctx_stream(ctx);  // the matcher's stream: the compaction copies run on it, in front of the launches
+    uint64_t at = 0;
+    for (int r = 0; r < c->nranks; ++r) {
+        const uint64_t n = g->hdr_rows[(size_t)r];
+        if (n)
+            AKZ_HIP_TRY(hipMemcpyAsync(p->d_all + at * kRow, blocks + ((uint64_t)r * block_rows + 1) * kRow, n * kRow,
+                                       hipMemcpyDeviceToDevice, ms));
+        at += n;
+    }
+    p->d_out.assign((size_t)p->n_owned, nullptr);
+    p->d_cnt.assign((size_t)p->n_owned, nullptr);
+    p->cnt.assign((size_t)p->n_owned, std::vector<uint64_t>((size_t)n_images, 0));
+    for (uint64_t k = 0; k < p->n_owned; ++k) {
+        const uint64_t q = p->first_owned + k, n0 = p->rows[(size_t)q];
+        AKZ_HIP_TRY(hipMalloc((void**)&p->d_out[(size_t)k], std::max<uint64_t>(1, n0 * n_images) * sizeof(akz_match)));
+        AKZ_HIP_TRY(hipMalloc((void**)&p->d_cnt[(size_t)k], n_images * sizeof(uint64_t)));
+        AKZ_TRY(akz_descriptor_match_sets_device(ctx, p->d_all + p->offset[(size_t)q] * kRow, n0, p->d_all, p->rows.data(), n_images,
+                                                 distance_threshold, lowes_ratio, p->d_out[(size_t)k], p->d_cnt[(size_t)k]));
+    }
+    for (uint64_t k = 0; k < p->n_owned; ++k)
+        AKZ_HIP_TRY(hipMemcpyAsync(p->cnt[(size_t)k].data(), p->d_cnt[(size_t)k], n_images * sizeof(uint64_t), hipMemcpyDeviceToHost, ms));
+    AKZ_HIP_TRY(hipStreamSynchronize(ms));
+    *out = p.release();
+    return AKZ_OK;
+}
+int akz_pairs_info(const akz_pairs* p, uint64_t* n_images, uint64_t* first_owned, uint64_t* n_owned) {
+    if (!p) return AKZ_ERR_INVALID_ARG;
+    if (n_images) *n_images = p->rows.size();
+    if (first_owned) *first_owned = p->first_owned;
+    if (n_owned) *n_owned = p->n_owned;
+    return AKZ_OK;
+}
+int akz_pairs_image_rows(const akz_pairs* p, uint64_t image, uint64_t* rows, int* owner_rank) {
+    if (!p || image >= p->rows.size()) return AKZ_ERR_INVALID_ARG;
+    if (rows) *rows = p->rows[(size_t)image];
+    if (owner_rank) *owner_rank = p->owner[(size_t)image];
+    return AKZ_OK;
+}
+int akz_pairs_matches(const akz_pairs* p, uint64_t query, uint64_t image, akz_match* out, uint64_t cap, uint64_t* n) {
+    if (!p || !n || query < p->first_owned || query >= p->first_owned + p->n_owned || image >= p->rows.size()) {
+        set_error("akz_pairs_matches: the query must be an image this rank owns, the image one of the job");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const size_t k = (size_t)(query - p->first_owned);
+    const uint64_t cnt = image == query ? 0 : p->cnt[k][(size_t)image];
+    *n = cnt;
+    const uint64_t take = std::min(cnt, cap);
+    if (out && take) {
+        AKZ_HIP_TRY(hipSetDevice(p->device));
+        AKZ_HIP_TRY(hipMemcpy(out, p->d_out[k] + image * p->rows[(size_t)query], take * sizeof(akz_match), hipMemcpyDeviceToHost));
+    }
+    return AKZ_OK;
+}
+int akz_pairs_free(akz_pairs* p) {
+    if (!p) return AKZ_OK;
+    (void)hipSetDevice(p->device);
+    if (p->ctx) (void)akz_ctx_synchronize(p->ctx);
+    if (p->d_all) (void)hipFree(p->d_all);
+    for (akz_match* m : p->d_out)
+        if (m) (void)hipFree(m);
+    for (uint64_t* m : p->d_cnt)
+        if (m) (void)hipFree(m);
+    delete p;
     return AKZ_OK;
 }
 

@@ -200,6 +200,12 @@ def lib():
         "akz_gather_descriptors": ([vp, vp, u64, C.POINTER(vp), pu64], i32),
         "akz_gather_begin": ([vp, C.POINTER(vp), u64, u64, C.POINTER(vp)], i32),
         "akz_gather_begin_rows": ([vp, vp, u64, u64, vp, C.POINTER(vp)], i32),
+        "akz_gather_image_rows": ([vp, i32, pu64, u64, pu64], i32),
+        "akz_match_all_pairs": ([vp, vp, u64, C.c_double, C.POINTER(vp)], i32),
+        "akz_pairs_info": ([vp, pu64, pu64, pu64], i32),
+        "akz_pairs_image_rows": ([vp, u64, pu64, C.POINTER(i32)], i32),
+        "akz_pairs_matches": ([vp, u64, u64, vp, u64, pu64], i32),
+        "akz_pairs_free": ([vp], i32),
         "akz_gather_stream_wait": ([vp, vp], i32),
         "akz_gather_finish": ([vp, C.POINTER(vp), pu64, pu64, pu64], i32),
         "akz_gather_free": ([vp], i32),
@@ -960,11 +966,66 @@ class Gather:
                                        img if want_counts else None))
         return p.value, br.value, list(cnt), list(img)
 
+    def image_rows(self, rank):
+        """akz_gather_image_rows: rows of every image of `rank`'s shard (after finish())."""
+        n = C.c_uint64()
+        _check(lib().akz_gather_image_rows(self._h, int(rank), None, 0, C.byref(n)))
+        out = (C.c_uint64 * max(1, n.value))()
+        _check(lib().akz_gather_image_rows(self._h, int(rank), out, n.value, C.byref(n)))
+        return [int(v) for v in out[:n.value]]
+
+    def match_all_pairs(self, ctx, distance_threshold=10000, lowes_ratio=0.86):
+        """akz_match_all_pairs (BASELINE configs[4]): this rank's images as queries against every image of the job."""
+        p = C.c_void_p()
+        _check(lib().akz_match_all_pairs(ctx._h, self._h, int(distance_threshold), float(lowes_ratio), C.byref(p)))
+        return Pairs(ctx, p)
+
     def free(self):
         if self._h:
             lib().akz_gather_free(self._h)
             self._h = None
         self._comm._gathers.discard(self)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Pairs:
+    """Result of akz_match_all_pairs: match lists of this rank's images against every image of the job."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._h = ctx, handle  # (the context must outlive the pairs object)
+        n, f, o = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().akz_pairs_info(self._h, C.byref(n), C.byref(f), C.byref(o)))
+        self.n_images, self.first_owned, self.n_owned = n.value, f.value, o.value
+
+    def image_rows(self, image):
+        r, o = C.c_uint64(), C.c_int32()
+        _check(lib().akz_pairs_image_rows(self._h, int(image), C.byref(r), C.byref(o)))
+        return r.value, o.value
+
+    def count(self, query, image):
+        n = C.c_uint64()
+        _check(lib().akz_pairs_matches(self._h, int(query), int(image), None, 0, C.byref(n)))
+        return n.value
+
+    def matches(self, query, image):
+        n = self.count(query, image)
+        out = np.zeros(max(n, 1), MATCH_DTYPE)
+        m = C.c_uint64()
+        _check(lib().akz_pairs_matches(self._h, int(query), int(image), out.ctypes.data_as(C.c_void_p), n, C.byref(m)))
+        return out[:m.value].copy()
+
+    def total_matches(self):
+        return sum(self.count(q, j) for q in range(self.first_owned, self.first_owned + self.n_owned) for j in range(self.n_images))
+
+    def free(self):
+        if self._h:
+            lib().akz_pairs_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:

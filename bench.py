@@ -835,6 +835,84 @@ def main_rank(args):
                      "peak": "%.1f POP/s int8 dense (2 x the 2.5 PFLOP/s bf16 MFMA rate)" % (MFMA_I8_PEAK_OPS / 1e15),
                      "ops_per_pair": 1024, "sets": legs}
 
+    # ---- BASELINE configs[2] and configs[4] end to end (extra legs, rank 0, own clocks) --------------------------------
+    c3_leg = c5_leg = None
+    if rank == 0 and world == 1 and not args.no_match:
+        ctx.set_profiling(0)
+        # configs[2]: a 3840x2160 pair -- ONE extract call on the two-frame batch (host frames, descriptors back on the
+        # host) + match_features with its reference signature (descriptor_match on the GPU, RANSAC filter on the host)
+        pair = np.stack([A.synth_frame(3840, 2160, 0), A.synth_frame(3840, 2160, 0, shift=(17, 9))])
+        h_pair = torch.from_numpy(pair).pin_memory()
+        cfg44 = A.Config()
+        t_ex = t_mt = 0.0
+        n_m = n_k = 0
+        reps_p = 6
+        for it in range(reps_p + 2):
+            torch.cuda.synchronize()
+            a0 = time.perf_counter()
+            rp = ctx.extract_begin_host(h_pair, cfg44, keep_all_planes=not args.lean).finish()
+            k0, k1, q0, q1 = rp.keypoints(0), rp.keypoints(1), rp.descriptors(0), rp.descriptors(1)
+            a1 = time.perf_counter()
+            mm = A.match_features(k0, q0, k1, q1, 0.86, 1000, 3.0, ctx=ctx)
+            a2 = time.perf_counter()
+            rp.close()
+            if it >= 2:
+                t_ex += a1 - a0
+                t_mt += a2 - a1
+                n_m, n_k = len(mm), len(k0) + len(k1)
+        c3_leg = {"workload": "BASELINE configs[2]: 3840x2160 synthetic pair from pinned host memory, one extract call on the "
+                              "2-frame batch (upload, scale space, keypoints, descriptors to the host) + match_features(0.86, "
+                              "1000 RANSAC trials, eps 3.0)",
+                  "ms_per_pair": round((t_ex + t_mt) / reps_p * 1e3, 3), "extract_ms": round(t_ex / reps_p * 1e3, 3),
+                  "match_features_ms": round(t_mt / reps_p * 1e3, 3),
+                  "Mpix_s": round(2 * 3840 * 2160 / ((t_ex + t_mt) / reps_p) / 1e6, 1), "keypoints": n_k, "matches": n_m}
+        del h_pair, pair
+        # configs[4] on one GPU: a stream of 3840x2160 frames, 5 octaves x 5 sublevels, then the exchange and the all-pairs
+        # match of every frame against every other one through the C ABI (akz_gather_begin -> akz_match_all_pairs)
+        try:
+            n_fr, per = 16, 8
+            cfg55 = A.Config(num_sublevels=5, max_octave_evolution=5)
+            fr4k = torch.from_numpy(np.stack([A.synth_frame(3840, 2160, i) for i in range(n_fr)])).pin_memory()
+            comm1 = A.Comm(dev_index, A.comm_unique_id(), 0, 1)
+            best = None
+            for it in range(3):
+                torch.cuda.synchronize()
+                b0 = time.perf_counter()
+                jobs, ress = [], []
+                for k in range(0, n_fr, per):
+                    jobs.append(ctx.extract_begin_host(fr4k[k:k + per], cfg55, keep_all_planes=not args.lean, host_descriptors=False))
+                    if len(jobs) > 1:
+                        ress.append(jobs.pop(0).finish())
+                while jobs:
+                    ress.append(jobs.pop(0).finish())
+                b1 = time.perf_counter()
+                rows = sum(r.counts(i)[1] for r in ress for i in range(r.num_images))
+                g = comm1.gather_begin(ress, rows + 64)
+                for r in ress:
+                    r.close()
+                pr = g.match_all_pairs(ctx)
+                b2 = time.perf_counter()
+                tot = pr.total_matches()
+                pairs_n = sum(pr.image_rows(q)[0] * pr.image_rows(j)[0] for q in range(pr.n_images) for j in range(pr.n_images) if q != j)
+                pr.free()
+                g.free()
+                cur = {"extract_ms": (b1 - b0) * 1e3, "match_ms": (b2 - b1) * 1e3, "rows": rows, "matches": tot, "pairs": pairs_n}
+                if it > 0 and (best is None or cur["extract_ms"] + cur["match_ms"] < best["extract_ms"] + best["match_ms"]):
+                    best = cur
+            comm1.close()
+            tt = (best["extract_ms"] + best["match_ms"]) / 1e3
+            c5_leg = {"workload": f"BASELINE configs[4] on one GPU: {n_fr} 3840x2160 frames from pinned host memory in batches of {per}, "
+                                  "5 octaves x 5 sublevels, descriptors kept on the device; RCCL gather (world 1) and the all-pairs "
+                                  "match of every frame against every other (akz_match_all_pairs: one multi-set launch per frame)",
+                      "extract_ms": round(best["extract_ms"], 2), "extract_Mpix_s": round(n_fr * 3840 * 2160 / best["extract_ms"] / 1e3, 1),
+                      "gather_and_match_ms": round(best["match_ms"], 2),
+                      "Tpairs_per_s": round(best["pairs"] / best["match_ms"] / 1e9, 3),
+                      "end_to_end_Mpix_s": round(n_fr * 3840 * 2160 / tt / 1e6, 1), "descriptor_rows": best["rows"],
+                      "image_pairs": n_fr * (n_fr - 1), "matches": best["matches"]}
+            del fr4k
+        except Exception as e:
+            c5_leg = {"error": str(e)[:300]}
+
     # ---- BASELINE configs[1] taken literally: ONE frame per extract call (untimed extra leg, rank 0) -----------
     single = None
     if rank == 0 and world == 1 and not args.no_single:
@@ -1034,6 +1112,8 @@ def main_rank(args):
             "stage_ms_per_step": stage_ms,
             "stage_roofline": stage_roofline,
             "single_frame": single,
+            "pair_4k": c3_leg,
+            "stream_5x5_all_pairs": c5_leg,
             "match": match_leg,
         }
         print(json.dumps(out), flush=True)

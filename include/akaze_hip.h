@@ -308,7 +308,9 @@ int akz_gather_descriptors(akz_comm* comm, const uint8_t* d_local, uint64_t n_lo
                            uint64_t* counts /* nranks */);
 /* Pipelined form: ONE fixed-size all-gather per call, enqueued on the communicator's own streams without touching
    the extraction stream.  Every rank contributes a block of 1 + cap_rows rows: a header row {u64 rows, u64 images,
-   u64 cap_rows, u64 sequence, 0...} followed by the descriptor rows of all images of all `results` (in order);
+   u64 cap_rows, u64 sequence, u64 overflow, u64 table rows, 0, 0} followed by the descriptor rows of all images of all
+   `results` (in order) and, for akz_gather_begin, a table of the rows per image (eight u64 per row; it counts against
+   cap_rows: allow one row per eight images);
    cap_rows MUST be the same on every rank (the message sizes of the collective depend on it: a mismatch is fatal
    for the communicator and cannot be detected before the collective is issued) and should be at least the largest
    shard.  A rank whose shard does not fit still takes part — it sends its header alone, marked — and
@@ -327,8 +329,29 @@ int akz_gather_stream_wait(akz_gather* g, void* stream);
    block r; counts / images (host, nranks entries, may be NULL) are read from the headers.  Rows beyond a rank's count
    are unspecified. */
 int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows, uint64_t* counts, uint64_t* images);
+/* rows of every image of rank `rank`'s shard, in its shard order (host, after akz_gather_finish): a block carries them
+   behind its descriptor rows, eight u64 per row (akz_gather_begin_rows sends its rows as ONE image).  *n_images = the
+   rank's image count; rows_per_image receives min(cap, *n_images) entries. */
+int akz_gather_image_rows(akz_gather* g, int rank, uint64_t* rows_per_image, uint64_t cap, uint64_t* n_images);
 /* hand the blocks back to the communicator (waits for the collective if it is still running) */
 int akz_gather_free(akz_gather* g);
+
+/* BASELINE configs[4] — the cross-GPU all-pairs match for hosts that are not Python: after an
+   exchange every rank holds the descriptor rows of every image of the job; this rank matches the images IT owns (the
+   ones it contributed to `gather`), as queries, against every image of the job: 1 / nranks of the ordered pairs, one
+   multi-set launch of the matcher per owned image (ops::feature_matching::descriptor_match per pair,
+   feature_matching.rs:23-94; results identical to akz_descriptor_match of the pair).  Images are numbered rank-major
+   over the job.  Finishes the gather if the caller has not; the gather may be freed afterwards. */
+typedef struct akz_pairs akz_pairs;
+int akz_match_all_pairs(akz_ctx* ctx, akz_gather* gather, uint64_t distance_threshold, double lowes_ratio, akz_pairs** out);
+/* *n_images: images of the whole job; this rank's are first_owned .. first_owned + n_owned - 1 */
+int akz_pairs_info(const akz_pairs* p, uint64_t* n_images, uint64_t* first_owned, uint64_t* n_owned);
+int akz_pairs_image_rows(const akz_pairs* p, uint64_t image, uint64_t* rows, int* owner_rank);
+/* matches of owned image `query` (a job-wide image number) against `image`: index_0 into the query's rows, index_1
+   into `image`'s; ordered by index_0.  out may be NULL (count only); at most cap records are written.  The pair
+   (query, query) is empty. */
+int akz_pairs_matches(const akz_pairs* p, uint64_t query, uint64_t image, akz_match* out, uint64_t cap, uint64_t* n);
+int akz_pairs_free(akz_pairs* p);
 
 /* ---- the rest of match_features (host post-filter) -------------------- */
 /* ops::estimate_fundamental_matrix::remove_outliers — estimate_fundamental_matrix.rs:99-165: 8-point

@@ -50,9 +50,17 @@ def test_comm_gather_matches_local_rows(ctx, amd):
         g3.finish()
     assert e.value.status == -7
     g3.free()
-    g4 = comm.gather_begin([res], rows)
-    assert g4.finish()[2] == [rows]
-    g5 = comm.gather_begin([res], rows)   # never finished nor freed by the caller
+    g4 = comm.gather_begin([res], rows + 1)  # + one row for the table of rows per image (3 images)
+    assert g4.finish()[2] == [rows] and g4.image_rows(0) == [res.counts(i)[1] for i in range(3)]
+    pairs = g4.match_all_pairs(ctx)          # BASELINE configs[4] through the C ABI: every image against every other one
+    assert (pairs.n_images, pairs.first_owned, pairs.n_owned) == (3, 0, 3)
+    for q in range(3):
+        for j in range(3):
+            got = pairs.matches(q, j)
+            exp = ctx.descriptor_match(res.descriptors(q), res.descriptors(j), 10000, 0.86) if q != j else got[:0]
+            assert np.array_equal(got, exp), (q, j)
+    pairs.free()
+    g5 = comm.gather_begin([res], rows + 1)   # never finished nor freed by the caller
     res.close()
     comm.close()
     g5.free()

@@ -57,6 +57,7 @@ struct akz_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf scratch[6];                       // f32 plane temporaries (largest level x batch)
+    DevBuf scratch_coarse;                   // the coarse chain's own diffusion scratch: it outlives the batch's join (see extract_begin)
     DevBuf lazy[6];                          // one-image planes of akz_fetch_plane's recomputation (never shared with scratch users)
     DevBuf small;                            // hmax bits / histogram / counters
     DevBuf cand;                             // NMS candidates
@@ -281,7 +282,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     if (c->lane_in) { (void)hipEventDestroy(c->lane_in); c->lane_in = nullptr; }
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
-                      &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5],
+                      &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
                       &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab};
     for (DevBuf* b : bufs)
@@ -327,6 +328,7 @@ int akz_ctx_synchronize(akz_ctx* c) {
     AKZ_TRY(bind(c));
     for (akz_ctx* l : c->lanes) AKZ_TRY(akz_ctx_synchronize(l));
     AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->coarse) AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
     return AKZ_OK;
 }
 void* akz_ctx_stream(akz_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -849,6 +851,7 @@ static void job_destroy(akz_job* j) {
     akz_ctx* c = j->r ? j->r->ctx : nullptr;
     if (c) {
         (void)hipStreamSynchronize(c->stream);
+        if (c->coarse) (void)hipStreamSynchronize(c->coarse);  // a forked batch completes on the coarse stream
         if (j->slot >= 0) c->slot_busy[j->slot] = false;
         if (j->nms_done) c->ev_pool.push_back(j->nms_done);
         result_release_device(j->r.get());
@@ -988,7 +991,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // chain moves to a second stream when octave fork_octave - 1 is finished, and the main stream goes straight to the
     // detectors of the fine octaves (bandwidth-bound, 2.2 ms): the two run side by side and join before the candidate
     // list is read.  (Running two BIG kernels side by side is a loss -- see above -- so the fork is at octave 2.)
-    constexpr int fork_octave = 2;
+    constexpr int fork_octave = 2;  // (forking at octave 3 instead, octave 2 on the main stream: -4 %)
     // (a lone 1080p frame is a chain of dependent launches either way and only pays for the two events: measured
     // 0.596 -> 0.625 ms per streamed frame; batches from 8 Mpx on fork)
     constexpr uint64_t fork_min_px = 8u << 20;
@@ -1064,7 +1067,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             break;
         }
         float* A = P(i, AKZ_LT);
-        float* B = (float*)c->scratch[5].p;
+        if (fork_level < L) AKZ_TRY(ensure(c, c->scratch_coarse, plane_bytes(plan[fork_level].w, plan[fork_level].h, n)));
+        float* B = (float*)(fork_level < L ? c->scratch_coarse.p : c->scratch[5].p);
         const uint32_t n_tau = (uint32_t)lv.tau.size();
         const bool half = lv.octave > pv.octave;
         // FED input: the previous level's final Lt (clone, lib.rs:92, no copy needed) or its 2x2 mean
@@ -1181,20 +1185,38 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         return AKZ_OK;
     };
-    if (fork_level < L) {  // the coarse chain ends with its own detectors; then the main stream takes the fine ones and joins
+    hipStream_t done_on = s;  // the stream behind whose work the batch's candidate list is complete
+    if (fork_level < L) {
+        // The coarse chain ends with its own detectors; the main stream takes the fine ones.  The JOIN is on the coarse
+        // stream: it waits for the fine detectors and records the batch's completion, and the main stream goes straight
+        // on to the next batch.  (Joined on the main stream, that stream sat idle for 0.35-0.5 ms per 32-frame step: next
+        // to the bandwidth-bound fine detectors the coarse chain's small launches are starved -- HBM latency grows
+        // several-fold -- and finish well after them.  Now that tail runs under the next batch's level-0 kernels; the
+        // chain has its own diffusion scratch, and the chains of consecutive batches follow each other on one stream.)
+        bool own_kernels = true;  // the multi-kernel detector fallback borrows context scratch planes: then join on the main stream
+        for (size_t l = fork_level; l < L; ++l) {
+            const int fam = detector_family(c, plan[l].det_sigma, plan[l].w, plan[l].h, n, border_margin(plan[l], cfg), keep_all);
+            own_kernels = own_kernels && (fam != 0 || launch::detector_nms_fused_supported(plan[l].det_sigma));
+        }
         AKZ_TRY(detectors(fork_level, L, c->coarse));
-        hipEvent_t coarse_done = StageTimer::get(c);
-        AKZ_HIP_TRY(hipEventRecord(coarse_done, c->coarse));
         c->stream = s;
         AKZ_TRY(detectors(0, fork_level, s));
-        AKZ_HIP_TRY(hipStreamWaitEvent(s, coarse_done, 0));
-        c->ev_pool.push_back(coarse_done);
+        hipEvent_t ev = StageTimer::get(c);
+        if (own_kernels) {
+            AKZ_HIP_TRY(hipEventRecord(ev, s));
+            AKZ_HIP_TRY(hipStreamWaitEvent(c->coarse, ev, 0));
+            done_on = c->coarse;
+        } else {
+            AKZ_HIP_TRY(hipEventRecord(ev, c->coarse));
+            AKZ_HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+        }
+        c->ev_pool.push_back(ev);
     } else {
         AKZ_TRY(detectors(0, L, s));
     }
     AKZ_HIP_TRY(hipGetLastError());
     job->nms_done = StageTimer::get(c);
-    AKZ_HIP_TRY(hipEventRecord(job->nms_done, s));
+    AKZ_HIP_TRY(hipEventRecord(job->nms_done, done_on));
     job->slot = slot;
     job->cap = cap;
     c->slot_busy[slot] = true;

@@ -65,7 +65,7 @@ struct akz_ctx {
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
-    int match_mode = 2;                      // 0: popcount kernel, 1 / 2 (default): matrix-core kernel (akz_ctx_set_match_mode)
+    int match_mode = 2;                      // 0: popcount kernel, 1: matrix cores on int8 operands, 2 (default) / 3: on FP4 operands (akz_ctx_set_match_mode)
     uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
     int dbg_host_sort = -1;                            // akz_debug_set_host_sort: 1 / 0 force the host / the device sort, -1 automatic
     DevBuf cosi;                             // (cos, sin) per keypoint
@@ -2082,10 +2082,11 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
         uint32_t* qpop = (uint32_t*)c->mm_pop.p;
         uint32_t* bound = qpop + q_rows;
         uint32_t* tpop = bound + q_rows;
-        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, 1, nullptr);
-        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, nullptr);
+        const bool fp4 = c->match_mode >= 2;
+        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, 1, nullptr, fp4);
+        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, nullptr, fp4);
         launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p,
-                           (uint32_t)n1, thr, bound, chunks, rec);
+                           (uint32_t)n1, thr, bound, chunks, rec, fp4);
     } else {
         launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, rows_le_61, chunks, rec);
     }
@@ -2181,12 +2182,13 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     AKZ_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(launch::MatchChunkHost), hipMemcpyHostToDevice,
                                c->stream));
     AKZ_HIP_TRY(hipStreamSynchronize(c->stream));  // the tables are stack / heap objects of this call
+    const bool fp4 = c->match_mode >= 2;
     launch::unpack_bits(c->stream, d_q, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, (uint32_t)n_sets,
-                        nullptr);
+                        nullptr, fp4);
     if (n_tiles)
-        launch::unpack_bits(c->stream, d_train, 0, n_tiles * tr, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, d_tiles);
+        launch::unpack_bits(c->stream, d_train, 0, n_tiles * tr, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, d_tiles, fp4);
     launch::match_mfma_multi(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
-                             (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p);
+                             (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p, fp4);
     launch::match_compact_sets(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, (uint32_t)n_sets, cps, thr,
                                lowes_ratio * lowes_ratio, d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());
@@ -2382,7 +2384,7 @@ int akz_ctx_set_candidate_hint(akz_ctx* c, uint32_t per_image) {
 }
 int akz_ctx_set_match_mode(akz_ctx* c, int mode) {
     AKZ_TRY(bind(c));
-    if (mode < 0 || mode > 2) return AKZ_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 3) return AKZ_ERR_INVALID_ARG;
     c->match_mode = mode;
     for (akz_ctx* l : c->lanes) l->match_mode = mode;
     return AKZ_OK;
@@ -2394,7 +2396,7 @@ int akz_ctx_set_fed_mode(akz_ctx* c, int mode) {
     for (akz_ctx* l : c->lanes) l->fed_mode = mode;
     return AKZ_OK;
 }
-const char* akz_fed_kernel_name(void) { return "k_level_march + k_fed_own"; }
+const char* akz_fed_kernel_name(void) { return "k_level_march + k_fed_own"; }  // (+ k_octave_resident: same profile group)
 int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half_width, int32_t* rows, uint32_t cap,
                           uint32_t* n_bands) {
     if (!n_bands || (cap && !rows) || kind < 0 || kind > 1 || w < 16 || h < 16 || n == 0 || half_width < 1 || half_width > 4)

@@ -230,16 +230,16 @@ uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tile
 // bound (queries only): n_bound arrays of n_pad per-query pruning bounds, set to threshold; d_tiles (train images of
 // several sets): per LDS tile {first source row, valid rows}
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
-                 uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles);
+                 uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles, bool fp4 = false);
 uint32_t match_mfma_tile_rows();
 uint32_t match_mfma_query_block();
 struct MatchChunkHost {  // = MatchChunk of akz_match.hip
     uint32_t t_begin, t_end, row0, n_rows, bound_off, record;
 };
 void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
-                      const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out);
+                      const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out, bool fp4 = false);
 void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
-                uint32_t threshold, uint32_t* bound, uint32_t chunks, MatchRec* d_rec);
+                uint32_t threshold, uint32_t* bound, uint32_t chunks, MatchRec* d_rec, bool fp4 = false);
 // set k's `chunks` chunk records at d_rec + k * chunks * n0, its matches at d_out + k * n0, its count at d_n_out[k]
 void match_compact_sets(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t n_sets, uint32_t chunks, uint32_t threshold,
                         double ratio2, akz_match* d_out, unsigned long long* d_n_out);

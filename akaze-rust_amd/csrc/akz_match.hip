@@ -66,10 +66,14 @@ constexpr int MM_PITCH = KB + 16;  // LDS row pitch in bytes
 // i.e. the kernel's epilogue is a maximum over accumulators instead of 16 additions of row counts.
 // tiles (optional): for images of SEVERAL sets laid out one after the other, each padded to whole LDS tiles — entry
 // t = {first source row, number of valid rows} of padded rows t * MM_TR .. + MM_TR - 1 (n is ignored then).
+// fp4 (the form k_match_fp4 reads): 4 bits per column, 256 bytes per row -- bit 1 -> +1.0, bit 0 -> -1.0 (e2m1 codes
+// 0x2 / 0xA) in the 488 columns of the 61 descriptor bytes, 0 in the other 24, the same for queries and train rows:
+//     <a', b'> = 488 - 2 hamming(a, b),
+// so no bit counts are needed at all (and every sum is a small integer, exact in the f32 accumulators).
 __global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, bool query,
                                                      uint8_t* __restrict__ out, unsigned* __restrict__ pop,
                                                      unsigned* __restrict__ bound, unsigned threshold, unsigned n_bound,
-                                                     const uint2* __restrict__ tiles) {
+                                                     const uint2* __restrict__ tiles, bool fp4) {
     const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (row >= n_pad) return;
     unsigned src = row;
@@ -83,6 +87,20 @@ __global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__
     const unsigned byte = (live && lane < 61u) ? d[(size_t)src * 64 + lane] : 0u;
     unsigned c = __popc(byte);
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (fp4) {
+        unsigned v4 = 0u;
+        if (live && lane < 61u) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) v4 |= (((byte >> b) & 1u) ? 0x2u : 0xAu) << (4 * b);
+        }
+        *reinterpret_cast<unsigned*>(out + (size_t)row * (KB / 2) + 4 * lane) = v4;
+        if (lane == 0) {
+            pop[row] = c;
+            if (bound)
+                for (unsigned k = 0; k < n_bound; ++k) bound[(size_t)k * n_pad + row] = threshold;
+        }
+        return;
+    }
     uint2 v;
     v.x = (byte & 1u) | ((byte & 2u) << 7) | ((byte & 4u) << 14) | ((byte & 8u) << 21);
     v.y = ((byte >> 4) & 1u) | (((byte >> 4) & 2u) << 7) | (((byte >> 4) & 4u) << 14) | (((byte >> 4) & 8u) << 21);
@@ -311,6 +329,187 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same scan on the block-scaled FP4 matrix instruction (gfx950: v_mfma_scale_f32_32x32x64_f8f6f4, twice the K per
+// instruction and per operand byte of the int8 form at the same issue cost).  Operands are the +-1 images of
+// k_unpack_bits(fp4): e2m1 holds +-1 exactly, the block scales are 1 (E8M0 127), and a dot product of 488 terms of +-1 is
+// an integer of magnitude <= 488: the f32 accumulators are exact.  hamming = (488 - dot) / 2.  Structure, pruning bound,
+// tie rule and output are those of k_match_mfma; a train row is 256 bytes, a wave's query operands 32 registers.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int KB4 = KB / 2;           // bytes per unpacked row
+constexpr int MM_PITCH4 = KB4 + 16;   // LDS row pitch: 16-byte operand reads of 16 consecutive rows fall into different banks
+constexpr int kBits = 488;            // columns that carry +-1 (61 bytes)
+
+// NB: 32-query blocks per wave.  1 (used): 16 waves of 32 queries (1024 threads); 2: 8 waves of 64 queries (512 threads),
+// every train operand read from LDS feeding two matrix instructions -- measured 30 % SLOWER at 90 K rows (2.36 against
+// 1.80 ms, profiles/r03_match_variants.txt), as for the int8 form: the loop needs its 16 waves.
+template <int NB>
+__global__ void __launch_bounds__(1024 / NB) k_match_fp4(const uint8_t* __restrict__ q4, unsigned n0, const uint8_t* __restrict__ t4,
+                                                         unsigned n1, unsigned chunk_tiles, unsigned threshold,
+                                                         unsigned* __restrict__ bound, MatchRec* __restrict__ out,
+                                                         const MatchChunk* __restrict__ table) {
+    constexpr int NT = 1024 / NB;
+    static_assert(MM_SUB == 4 && MM_QB == 512 && (NB == 1 || NB == 2), "staging below: two 64-row parts per 128-row tile");
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH4];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const unsigned q_first = blockIdx.x * MM_QB + wave * 32u * NB;
+    auto op = [](v4i x) { return v8i{x.x, x.y, x.z, x.w, 0, 0, 0, 0}; };  // FP4 operands occupy the first four registers
+
+    v4i bq[NB][8];  // B operands: the wave's queries, eight K-steps of 64 columns, resident for the whole chunk
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint8_t* row = q4 + (size_t)(q_first + 32 * b + r) * KB4 + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bq[b][s] = *reinterpret_cast<const v4i*>(row + 32 * s);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(bq[b][s]));
+    unsigned min_d[NB], second[NB], limit[NB], b_seen[NB], min_j[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        min_d[b] = second[b] = limit[b] = b_seen[b] = threshold;
+        min_j[b] = 0u;
+    }
+
+    unsigned t_begin, t_end, row0 = 0u, record = blockIdx.y;
+    if (table) {
+        const MatchChunk ck = table[blockIdx.y];
+        t_begin = ck.t_begin; t_end = ck.t_end; row0 = ck.row0; n1 = ck.n_rows; record = ck.record;
+        bound += ck.bound_off;
+    } else {
+        const unsigned tiles_total = (n1 + MM_TR - 1) / MM_TR;
+        t_begin = blockIdx.y * chunk_tiles;
+        t_end = min(tiles_total, t_begin + chunk_tiles);
+    }
+    // staging: the next tile arrives in two 64-row parts (1024 sixteen-byte pieces each) through one register stage:
+    // requested before sub-tiles 0 / 2, handed to the other LDS buffer after sub-tiles 1 / 3
+    constexpr int PIECES = 1024 / NT;
+    unsigned st_src[PIECES], st_dst[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const unsigned idx = tid + (unsigned)p * NT;
+        st_src[p] = (idx >> 4) * KB4 + (idx & 15u) * 16u;
+        st_dst[p] = (idx >> 4) * MM_PITCH4 + (idx & 15u) * 16u;
+    }
+    uint4 stage[PIECES];
+    auto fetch = [&](unsigned tile, int part) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            stage[p] = *reinterpret_cast<const uint4*>(t4 + ((size_t)tile * MM_TR + 64u * part) * KB4 + st_src[p]);
+    };
+    auto commit = [&](int buf, int part) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) *reinterpret_cast<uint4*>(&s_tile[buf][64 * part * MM_PITCH4 + st_dst[p]]) = stage[p];
+    };
+    if (t_begin < t_end) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            fetch(t_begin, part);
+            commit(0, part);
+        }
+    }
+    __syncthreads();
+    for (unsigned tile = t_begin; tile < t_end; ++tile) {
+        const int buf = (int)((tile - t_begin) & 1u);
+        const bool more = tile + 1 < t_end;
+        const bool partial = (tile + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            limit[b] = min(limit[b], min(second[b], b_seen[b] < 0xffffffffu ? b_seen[b] + 1u : b_seen[b]));
+            b_seen[b] = __hip_atomic_load(bound + q_first + 32 * b + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int sub = 0; sub < MM_SUB; ++sub) {
+            if (more && (sub & 1) == 0) fetch(tile + 1, sub >> 1);  // in flight under the MFMA chains below
+            v16f acc[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][i] = 0.0f;
+            const uint8_t* arow = &s_tile[buf][(32 * sub + r) * MM_PITCH4 + 16 * h];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const v4i a = *reinterpret_cast<const v4i*>(arow + 32 * s);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op(a), op(bq[b][s]), acc[b], 4, 4, 0, 127, 0, 127);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int s = 0; s < 8 - 3; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB, 0);
+            const unsigned j0 = tile * MM_TR - row0 + 32 * sub + 4 * h;  // row index inside the set
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float topf = acc[b][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) topf = fmaxf(topf, acc[b][i]);
+                const int best = (kBits - (int)topf) >> 1;  // the smallest distance of the lane's 16 rows
+                if (partial || best < (int)limit[b]) {  // rare: see `limit` in k_match_mfma
+                    int key[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
+                        key[i] = (partial && j0 + row >= n1) ? INT_MIN : ((int)acc[b][i] << 4) + (15 - i);  // padding rows never match
+                    }
+                    int M = INT_MIN, S = INT_MIN;
+#pragma unroll
+                    for (int g = 0; g < 5; ++g) {
+                        const int ka = key[3 * g], kb = key[3 * g + 1], kc = key[3 * g + 2];
+                        const int gm = max(ka, max(kb, kc)), gs = max(min(ka, kb), min(max(ka, kb), kc));
+                        S = max(min(M, gm), max(S, gs));
+                        M = max(M, gm);
+                    }
+                    S = max(S, min(M, key[15]));
+                    M = max(M, key[15]);
+                    const int i1 = 15 - (M & 15);
+                    const unsigned tb = M == INT_MIN ? 0xffffffffu : (unsigned)((kBits - (M >> 4)) >> 1);
+                    const unsigned ts = S == INT_MIN ? 0xffffffffu : (unsigned)((kBits - (S >> 4)) >> 1);
+                    const unsigned before = second[b];
+                    if (tb < min_d[b]) {
+                        second[b] = min(min_d[b], ts);
+                        min_d[b] = tb;
+                        min_j[b] = j0 + (unsigned)((i1 & 3) + 8 * (i1 >> 2));
+                    } else {
+                        second[b] = min(second[b], tb);
+                    }
+                    if (second[b] < before) {
+                        atomicMin(bound + q_first + 32 * b + r, second[b]);
+                        limit[b] = min(limit[b], second[b]);
+                    }
+                }
+            }
+            if (more && (sub & 1) == 1) commit(buf ^ 1, sub >> 1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const unsigned o_min = __shfl_xor(min_d[b], 32, 64), o_sec = __shfl_xor(second[b], 32, 64), o_j = __shfl_xor(min_j[b], 32, 64);
+        unsigned m = min_d[b], s2 = second[b], j = min_j[b];
+        if (o_min < m || (o_min == m && o_min < threshold && o_j < j)) {
+            s2 = min(o_sec, m);
+            m = o_min;
+            j = o_j;
+        } else {
+            s2 = min(s2, o_min);
+        }
+        const unsigned q = q_first + 32 * b + r;
+        if (h == 0 && q < n0) {
+            MatchRec rec;
+            rec.min_d = m; rec.second_d = s2; rec.min_j = j; rec._pad = 0;
+            out[(size_t)record * n0 + q] = rec;
+        }
+    }
+}
+
 }  // namespace
 
 namespace launch {
@@ -345,9 +544,9 @@ uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1, uint32_t forced) {
     return best;
 }
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
-                 uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles) {
+                 uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles, bool fp4) {
     hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, query, out8, pop, bound, threshold,
-                       n_bound, reinterpret_cast<const uint2*>(d_tiles));
+                       n_bound, reinterpret_cast<const uint2*>(d_tiles), fp4);
 }
 uint32_t match_mfma_tile_rows() { return MM_TR; }
 uint32_t match_mfma_query_block() { return MM_QB; }
@@ -374,17 +573,27 @@ uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tile
 // d_table holds n_chunks chunk descriptors (several per set, ascending rows); record r * n0 + q = top-2 of query q over
 // the chunk with record index r.
 void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8,
-                      const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out) {
+                      const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out, bool fp4) {
     if (n0 == 0 || n_chunks == 0) return;
+    if (fp4) {
+        hipLaunchKernelGGL(k_match_fp4<1>, dim3((n0 + MM_QB - 1) / MM_QB, n_chunks), dim3(1024), 0, s, q8, n0, t8, 0u, 0u, threshold, bound,
+                               d_out, reinterpret_cast<const MatchChunk*>(d_table));
+        return;
+    }
     hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, n_chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, 0u, 0u,
                        threshold, bound, d_out, reinterpret_cast<const MatchChunk*>(d_table));
 }
 // records of every query over `chunks` chunks of the train set: d_rec[chunk * n0 + query] (merged by match_compact)
 void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
-                uint32_t threshold, uint32_t* bound, uint32_t chunks, MatchRec* d_rec) {
+                uint32_t threshold, uint32_t* bound, uint32_t chunks, MatchRec* d_rec, bool fp4) {
     if (n0 == 0) return;
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
     const uint32_t chunk_tiles = (tiles + chunks - 1) / chunks;
+    if (fp4) {
+        hipLaunchKernelGGL(k_match_fp4<1>, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(1024), 0, s, q8, n0, t8, n1, chunk_tiles, threshold,
+                               bound, d_rec, (const MatchChunk*)nullptr);
+        return;
+    }
     hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, n1,
                        chunk_tiles, threshold, bound, d_rec, (const MatchChunk*)nullptr);
 }

@@ -452,9 +452,9 @@ int akz_ctx_set_lanes(akz_ctx* ctx, uint32_t lanes);
    LOCAL_WORLD_SIZE (one process per GPU: torchrun sets it), at most 16.  A launcher that has already pinned each rank
    to its own cores passes that number here.  Not while extractions are in flight. */
 int akz_ctx_set_host_threads(akz_ctx* ctx, uint32_t threads);
-/* Matcher kernel: 2 (default) and 1 = matrix-core kernel (k_match_mfma: descriptor bits unpacked to int8,
-   Hamming distances from one integer GEMM; faster than the popcount scan from 128 x 128 descriptors up),
-   0 = popcount kernel (k_match).  Results are identical. */
+/* Matcher kernel: 2 (default) and 3 = matrix cores on FP4 operands (k_match_fp4: descriptor bits as +-1 in e2m1,
+   v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, hamming = (488 - dot) / 2, exact in f32), 1 = matrix cores
+   on int8 operands (k_match_mfma), 0 = popcount kernel (k_match).  Results are identical. */
 int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
 /* Detector kernel variant: 2 (default) = automatic (the one-pass column march k_detector_march for launches of
    8 Mpx and more, the one-kernel LDS-tiled form k_detector_tiled below that); 5 = column march wherever it is

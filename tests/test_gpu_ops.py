@@ -168,9 +168,9 @@ def test_detector_response(ctx, ref, sigma):
     same(host(lean["Ldet"]), ldet)
 
 
-@pytest.fixture(params=[0, 1], ids=["popcount", "mfma"])
+@pytest.fixture(params=[0, 1, 3], ids=["popcount", "mfma_i8", "mfma_fp4"])
 def mctx(request, ctx):
-    """The context with the matcher kernel forced: 0 = popcount scan, 1 = matrix-core (integer GEMM) scan."""
+    """The context with the matcher kernel forced: 0 = popcount scan, 1 = matrix-core scan on int8 operands, 3 = on FP4 operands."""
     ctx.set_match_mode(request.param)
     yield ctx
     ctx.set_match_mode(2)
@@ -207,7 +207,7 @@ def test_descriptor_match_ragged_sizes(ctx, ref, n0, n1):
     d1[rng.random(d1.shape) < 0.02] ^= 0x01
     for ratio, thr in ((0.86, 10000), (1.5, 10000), (0.99, 12)):
         exp = ref.descriptor_match(d0, d1, thr, ratio)
-        for mode in (1, 0):
+        for mode in (1, 0, 3):
             ctx.set_match_mode(mode)
             try:
                 got = ctx.descriptor_match(d0, d1, thr, ratio)
@@ -254,7 +254,7 @@ def test_descriptor_match_sets_chunked(ctx, ref, chunks_per_set):
         ctx.debug_set_match_chunks(0, 0)
 
 
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [1, 0, 3])
 def test_descriptor_match_sets(ctx, ref, mode):
     """One query set against several train sets in one launch (sizes around the tile sizes, an empty set, duplicates
     across sets): every set's match list equals the oracle's descriptor_match of that pair."""
@@ -350,7 +350,7 @@ def test_device_match_ignores_padding_bytes_in_both_kernels(ctx, ref):
     assert len(exp) > 50
     r0 = np.concatenate([d0, rng.integers(1, 256, (300, 3), dtype=np.uint8)], axis=1)  # garbage in the padding
     r1 = np.concatenate([d1, rng.integers(1, 256, (500, 3), dtype=np.uint8)], axis=1)
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         ctx.set_match_mode(mode)
         try:
             out, cnt = ctx.descriptor_match_device(torch.from_numpy(r0).cuda(), torch.from_numpy(r1).cuda(), 10000, 0.86)

@@ -5,7 +5,7 @@
 # into profiles/.
 TAG=${1:-rXX}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd /tmp
-B="--no-cpu-baseline --no-single --no-match --no-fed4k --no-self-check"
+B="--no-cpu-baseline --no-single --no-match --no-fed4k --no-self-check --no-host-input --no-host-share-leg"
 python3 $R/bench.py 2>/dev/null | grep '^{' > $O/${TAG}_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $R/bench.py $B > $O/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_fetch -- python3 $R/bench.py --steps 2 --warmup 1 $B > $O/${TAG}_fetch.log 2>&1

@@ -88,7 +88,7 @@ doc = dict(
     calibration=cal,
     kernels={
         "k_detector_march": group(["k_detector_march", "k_detector_tiled"]),  # every detector launch, as bench.py counts them
-        "k_level_march + k_fed_own": group(["k_level_march", "k_fed_own"]),
+        "k_level_march + k_fed_own": group(["k_level_march", "k_fed_own", "k_octave_resident"]),  # every diffusion launch
     })
 json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "kernels"} for k, v in doc["kernels"].items()}), json.dumps(cal))

@@ -25,7 +25,7 @@ def timeit(a, b, reps=20):
     print(f"n0={a.shape[0]} n1={b.shape[0]} matches={int(cnt.item())} {ms*1e3:.1f} us  {pairs/ms/1e6:.2f} Gpairs/s "
           f"({pairs*32/ms/1e9:.2f} T xor+popc lane-ops/s)")
 big0 = torch.cat([d0] * 8); big1 = torch.cat([d1] * 8)
-for mode, name in ((0, "popcount"), (1, "mfma")):
+for mode, name in ((0, "popcount"), (1, "mfma i8"), (3, "mfma fp4")):
     ctx.set_match_mode(mode)
     print(name)
     timeit(d0[:2000], d1[:2000])
@@ -42,8 +42,10 @@ def time_fn(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-t_pairs = time_fn(lambda: [ctx.descriptor_match_device(d0, s_) for s_ in sets])
-t_multi = time_fn(lambda: ctx.descriptor_match_sets_device(d0, cat, rows))
-pairs = d0.shape[0] * sum(rows)
-print(f"all-pairs step, 1 x {d0.shape[0]} queries against 16 x {rows[0]} rows: 16 pair launches {t_pairs*1e3:.0f} us "
-      f"({pairs/t_pairs/1e9:.2f} T pairs/s), one multi-set launch {t_multi*1e3:.0f} us ({pairs/t_multi/1e9:.2f} T pairs/s)")
+for mode, name in ((1, "mfma i8"), (3, "mfma fp4")):
+    ctx.set_match_mode(mode)
+    t_pairs = time_fn(lambda: [ctx.descriptor_match_device(d0, s_) for s_ in sets])
+    t_multi = time_fn(lambda: ctx.descriptor_match_sets_device(d0, cat, rows))
+    pairs = d0.shape[0] * sum(rows)
+    print(f"{name}: all-pairs step, 1 x {d0.shape[0]} queries against 16 x {rows[0]} rows: 16 pair launches {t_pairs*1e3:.0f} us "
+          f"({pairs/t_pairs/1e9:.2f} T pairs/s), one multi-set launch {t_multi*1e3:.0f} us ({pairs/t_multi/1e9:.2f} T pairs/s)")

@@ -985,7 +985,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // ---- levels 1..L-1 (lib.rs:78-119) ----
     AKZ_TRY(ensure(c, c->scratch[5], plane_bytes(w, h, n)));
     const std::vector<float> g1 = gaussian_kernel(1.0f, gaussian_kernel_size(1.0f));  // Lsmooth taps (lib.rs:95)
-    bool gate_recorded = false;  // fed_done: the point behind which the previous batch's keypoint kernels may run
     // Fork.  From octave `fork_octave` on the levels are small: their launches (diffusion, preparation, detectors) do not
     // fill the chip and are bound by launch-to-launch latency -- about 1 ms of the step for 8 % of its pixels.  That
     // chain moves to a second stream when octave fork_octave - 1 is finished, and the main stream goes straight to the
@@ -1026,26 +1025,14 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         if (ok && f < L) res_first = f;
     }
-    for (size_t i = 1; i < L; ++i) {
+    // (full stage profiling attributes time to stages: it keeps everything on one stream)
+    if (fork_octave > 0 && c->profiling < 2 && (uint64_t)w * h * n >= fork_min_px)
+        for (size_t i = 1; i < L && fork_level == L; ++i)
+            if ((int)plan[i].octave >= fork_octave) fork_level = i;
+    auto run_levels = [&](size_t lo, size_t hi) -> int {
+    for (size_t i = lo; i < hi; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
-        // (full stage profiling attributes time to stages: it keeps everything on one stream)
-        if (fork_octave > 0 && c->profiling < 2 && fork_level == L && (int)lv.octave >= fork_octave &&
-            (uint64_t)w * h * n >= fork_min_px) {
-            if (!gate_recorded) {  // the previous batch's keypoint kernels may start here too
-                if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
-                AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
-                gate_recorded = true;
-            }
-            if (!c->coarse) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->coarse, hipStreamNonBlocking));
-            hipEvent_t fine_done = StageTimer::get(c);
-            AKZ_HIP_TRY(hipEventRecord(fine_done, s));
-            AKZ_HIP_TRY(hipStreamWaitEvent(c->coarse, fine_done, 0));
-            c->ev_pool.push_back(fine_done);
-            fork_level = i;
-            ls = c->coarse;
-            c->stream = c->coarse;
-        }
         if (i == res_first) {
             std::vector<launch::ResidentLevel> rl;
             std::vector<std::vector<float>> ht(L);
@@ -1067,8 +1054,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             break;
         }
         float* A = P(i, AKZ_LT);
-        if (fork_level < L) AKZ_TRY(ensure(c, c->scratch_coarse, plane_bytes(plan[fork_level].w, plan[fork_level].h, n)));
-        float* B = (float*)(fork_level < L ? c->scratch_coarse.p : c->scratch[5].p);
+        const bool on_coarse = i >= fork_level;  // the coarse chain has its own ping-pong plane (it outlives the batch's join)
+        if (on_coarse) AKZ_TRY(ensure(c, c->scratch_coarse, plane_bytes(plan[fork_level].w, plan[fork_level].h, n)));
+        float* B = (float*)(on_coarse ? c->scratch_coarse.p : c->scratch[5].p);
         const uint32_t n_tau = (uint32_t)lv.tau.size();
         const bool half = lv.octave > pv.octave;
         // FED input: the previous level's final Lt (clone, lib.rs:92, no copy needed) or its 2x2 mean
@@ -1138,14 +1126,16 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                              lv.tau.data(), n_tau));
         }
     }
+    return AKZ_OK;
+    };
 
+    // the fine levels (all levels when the batch does not fork) on the main stream
+    AKZ_TRY(run_levels(1, fork_level));
     // The keypoint kernels of the batch that is finished next (orientation, M-LDB: gather-bound, on the auxiliary
     // stream) wait for this point: next to the VALU-bound diffusion launches they cost more than next to the
     // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.
-    if (!gate_recorded) {
-        if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
-        AKZ_HIP_TRY(hipEventRecord(c->fed_done, ls));
-    }
+    if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
+    AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
 
     // ---- detectors: levels [lo, hi) on stream st (c->stream is st while this runs) ----
     // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group
@@ -1187,17 +1177,27 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     };
     hipStream_t done_on = s;  // the stream behind whose work the batch's candidate list is complete
     if (fork_level < L) {
-        // The coarse chain ends with its own detectors; the main stream takes the fine ones.  The JOIN is on the coarse
-        // stream: it waits for the fine detectors and records the batch's completion, and the main stream goes straight
-        // on to the next batch.  (Joined on the main stream, that stream sat idle for 0.35-0.5 ms per 32-frame step: next
-        // to the bandwidth-bound fine detectors the coarse chain's small launches are starved -- HBM latency grows
-        // several-fold -- and finish well after them.  Now that tail runs under the next batch's level-0 kernels; the
-        // chain has its own diffusion scratch, and the chains of consecutive batches follow each other on one stream.)
+        // The coarse chain (levels from fork_level on, then their detectors) runs on the second stream; the main stream
+        // takes the fine detectors.  The JOIN is on the coarse stream: it waits for the fine detectors and records the
+        // batch's completion, and the main stream goes straight on to the next batch.  (Joined on the main stream, that
+        // stream sat idle for 0.35-0.5 ms per 32-frame step: next to the bandwidth-bound fine detectors the coarse
+        // chain's small launches are starved -- HBM latency grows several-fold -- and finish well after them.  Now that
+        // tail runs under the next batch's level-0 kernels; the chain has its own diffusion scratch, and the chains of
+        // consecutive batches follow each other on one stream.)
         bool own_kernels = true;  // the multi-kernel detector fallback borrows context scratch planes: then join on the main stream
         for (size_t l = fork_level; l < L; ++l) {
             const int fam = detector_family(c, plan[l].det_sigma, plan[l].w, plan[l].h, n, border_margin(plan[l], cfg), keep_all);
             own_kernels = own_kernels && (fam != 0 || launch::detector_nms_fused_supported(plan[l].det_sigma));
         }
+        if (!c->coarse) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->coarse, hipStreamNonBlocking));
+        hipEvent_t fine_done = StageTimer::get(c);
+        AKZ_HIP_TRY(hipEventRecord(fine_done, s));
+        AKZ_HIP_TRY(hipStreamWaitEvent(c->coarse, fine_done, 0));
+        c->ev_pool.push_back(fine_done);
+        // (holding the chain back until the full-resolution detectors, or all fine detectors, have finished: -2 ... -5 %)
+        ls = c->coarse;
+        c->stream = c->coarse;
+        AKZ_TRY(run_levels(fork_level, L));
         AKZ_TRY(detectors(fork_level, L, c->coarse));
         c->stream = s;
         AKZ_TRY(detectors(0, fork_level, s));

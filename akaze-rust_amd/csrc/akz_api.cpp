@@ -1104,6 +1104,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             AKZ_HIP_TRY(hipGetLastError());
             continue;
         }
+        // (Preparation + the first eight diffusion steps as ONE tiled launch -- k_prep and k_fed_own fused, tile + halo 8 + 2 --
+        // was built and measured in round 3: 20 us per launch at best against 6-8 + 8-10 for the pair (the preparation then runs
+        // on the whole diffusion region, 2.3 x the tile); a lone 1080p frame 0.59 -> 0.86 ms, batches -1 ... -4 %.  Removed.)
         {
             StageTimer st(c, AKZ_ST_PREP);
             // measured on MI355X: the streaming kernel is ~2x faster for cloned levels of a batch (a single
@@ -1401,7 +1404,7 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
     // runtime pin user pages in place, which serialises concurrent contexts
     AKZ_TRY(ensure_pinned(c, c->pin[3], std::max<size_t>(1, total_kp) * sizeof(KpParam)));
     KpParam* params = (KpParam*)c->pin[3].p;
-    for (uint32_t img = 0; img < n; ++img)
+    c->pool().run(n, [&](size_t img) {  // (per image on the workers: with few host threads every serial loop over 7 x 10^4 keypoints counts)
         for (size_t i = 0; i < hk[img].size(); ++i) {
             const HostKeypoint& k = hk[img][i];
             KpParam& p = params[r->desc_off[img] + i];
@@ -1410,9 +1413,10 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             p.yf = k.y / ratio;
             p.scale = std::round(0.5f * k.size / ratio);
             p.level = k.class_id;
-            p.img = img;
+            p.img = (uint32_t)img;
             p._pad[0] = p._pad[1] = p._pad[2] = 0;
         }
+    });
     r->kps.assign(n, {});
     if (total_kp) {
         unsigned long long wmask = 0;
@@ -1449,8 +1453,9 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
                 cosi[2 * g + 1] = sinf(ang);
             }
         });
-        for (uint32_t img = 0; img < n; ++img)
+        c->pool().run(n, [&](size_t img) {
             for (size_t i = 0; i < hk[img].size(); ++i) hk[img][i].angle = angles[r->desc_off[img] + i];
+        });
         AKZ_HIP_TRY(hipMemcpyAsync(c->cosi.p, cosi, total_kp * 2 * sizeof(float), hipMemcpyHostToDevice, s));
         const double t_ml0 = now_ms();
         if (c->profiling) c->prof.ms[AKZ_ST_ORIENT] += t_ml0 - t_or0;
@@ -1466,19 +1471,24 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
             uint8_t* rows = (uint8_t*)c->pin[2].p;
             AKZ_HIP_TRY(hipMemcpyAsync(rows, r->d_desc64, total_kp * 64, hipMemcpyDeviceToHost, s));
             AKZ_HIP_TRY(hipStreamSynchronize(s));
-            r->rows64.assign(rows, rows + total_kp * 64);  // un-padded lazily by akz_result_descriptors
+            r->rows64.resize(total_kp * 64);  // un-padded lazily by akz_result_descriptors
+            const size_t kRowChunk = 8192;
+            c->pool().run((total_kp + kRowChunk - 1) / kRowChunk, [&](size_t j) {
+                const size_t b = j * kRowChunk * 64, e = std::min<size_t>(total_kp * 64, b + kRowChunk * 64);
+                std::memcpy(r->rows64.data() + b, rows + b, e - b);
+            });
         } else {
             AKZ_HIP_TRY(hipStreamSynchronize(s));
         }
         if (c->profiling) c->prof.ms[AKZ_ST_MLDB] += now_ms() - t_ml0;
     }
-    for (uint32_t img = 0; img < n; ++img) {
+    c->pool().run(n, [&](size_t img) {
         r->kps[img].resize(hk[img].size());
         for (size_t i = 0; i < hk[img].size(); ++i) {
             const HostKeypoint& k = hk[img][i];
             r->kps[img][i] = akz_keypoint{k.x, k.y, k.response, k.size, k.octave, k.class_id, k.angle, 0};
         }
-    }
+    });
     if (c->profiling) {
         resolve_spans(c);  // only spans whose events have completed are resolved
         c->prof.ms[AKZ_ST_TOTAL] += now_ms() - job->t_begin_ms;

@@ -52,6 +52,12 @@ static unsigned host_cpu_share() {
     return std::max(1u, n);
 }
 
+// Pixels per launch (w * h * batch) from which a launch fills the chip on its own: the column-march kernels, the fork of
+// the coarse chain and the resident coarse octave engage from here on (swept again in round 3: 4 Mpx is -7 ... -9 % on
+// 8-frame batches, 8 000 000 -- so that a lone 4K frame qualifies -- changes nothing for it: that frame is bound by the
+// host's per-image selection and the finish round trips, not by its kernels).
+static constexpr uint64_t kBigLaunchPx() { return 8u << 20; }
+
 struct akz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -464,7 +470,7 @@ static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t 
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
     constexpr bool is_u8 = std::is_same<T, uint8_t>::value;
     // large batches: the column march (HBM-bound: 0.33 GB of a 32-frame 1080p batch)
-    constexpr uint64_t blur_march_min_px = 8u << 20;
+    const uint64_t blur_march_min_px = kBigLaunchPx();
     if ((const void*)d_in != (const void*)d_out && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= blur_march_min_px)) &&
         launch::blur5_march_supported(w, h, (uint32_t)k.size())) {
         if constexpr (is_u8) launch::blur5_march_u8(c->stream, d_in, d_out, w, h, n, k.data());
@@ -614,7 +620,7 @@ static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_
     if (c->det_mode == 0) return 0;
     if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;
     if (c->det_mode == 5) return launch::detector_march_supported(sigma, w, h, border_m, nms) ? 5 : 0;
-    constexpr uint64_t march_min = 8u << 20;
+    const uint64_t march_min = kBigLaunchPx();
     const uint64_t px = (uint64_t)w * h * n;
     if (px >= march_min && launch::detector_march_supported(sigma, w, h, border_m, nms)) return 5;
     if (px < march_min && launch::detector_tiled_fused_supported(sigma)) return 4;
@@ -993,7 +999,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     constexpr int fork_octave = 2;  // (forking at octave 3 instead, octave 2 on the main stream: -4 %)
     // (a lone 1080p frame is a chain of dependent launches either way and only pays for the two events: measured
     // 0.596 -> 0.625 ms per streamed frame; batches from 8 Mpx on fork)
-    constexpr uint64_t fork_min_px = 8u << 20;
+    const uint64_t fork_min_px = kBigLaunchPx();
     hipStream_t ls = s;  // the stream the level loop enqueues on
     struct StreamRestore {  // the helpers (fed_impl, StageTimer, ...) enqueue on c->stream
         akz_ctx* c;
@@ -1071,7 +1077,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         // Large launches of levels that diffuse: preparation and the first (up to four) diffusion steps in ONE launch of
         // k_level_march (akz_march.hip) — Lt is read once for both, 4 B read + 12 (+4) B written per pixel instead of
         // 12 + 12 (+4); a new octave's 2x2 mean is materialised first.  Remaining steps follow in k_fed_own launches.
-        constexpr uint64_t level_min_px = 8u << 20;
+        const uint64_t level_min_px = kBigLaunchPx();
         const bool fuse_level = n_tau >= 1 && c->fed_mode == 2 && launch::level_march_supported(lv.w, lv.h) &&
                                 (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)lv.w * lv.h * n >= level_min_px));
         if (fuse_level) {
@@ -1433,7 +1439,7 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
         // behind the fine octaves' diffusion of the batch begun last (no wait if that is this batch or has passed the
         // point; placing the gate earlier, later or nowhere was measured: no difference); small jobs are bound by the
         // latency of this chain, not by the chip, and do not wait
-        if (c->fed_done && (uint64_t)r->w * r->h * n >= (8u << 20))
+        if (c->fed_done && (uint64_t)r->w * r->h * n >= kBigLaunchPx())
             AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_done, 0));
         launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());
@@ -1687,7 +1693,7 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
 static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
                                   const akz_config* cfg, uint32_t flags, akz_job** out, bool on_host = false) {
     akz_ctx* on = c;
-    if (c && !c->lanes.empty() && (uint64_t)w * h * n < (8u << 20)) {
+    if (c && !c->lanes.empty() && (uint64_t)w * h * n < kBigLaunchPx()) {
         AKZ_TRY(bind(c));
         on = c->lanes[c->next_lane++ % c->lanes.size()];
         // the lane starts when the caller's stream has reached this point (its inputs are complete)

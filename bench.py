@@ -125,8 +125,8 @@ def parse_args(argv=None):
                          "real rendezvous, capacity agreement and pipelined retire); the descriptor rows travel D2H -> gloo "
                          "all-gather -> H2D, because RCCL refuses two ranks on one device.  The line says so.")
     ap.add_argument("--host-share", type=int, default=0,
-                    help="run as ONE rank of a K-rank node: the affinity mask is cut to 1/K of the allowed cores before "
-                         "anything touches the GPU (the context's host worker pool is sized by the mask)")
+                    help="run as ONE rank of a K-rank node: the context's host worker pool gets 1/K of the usable cores "
+                         "(akz_ctx_set_host_threads)")
     ap.add_argument("--no-host-share-leg", action="store_true", help="skip the child run that measures --host-share 8")
     ap.add_argument("--sort", choices=["auto", "host", "device"], default="auto",
                     help="A/B: where the extrema candidates are put into scan order (akz_debug_set_host_sort)")
@@ -190,10 +190,11 @@ def place_rank(args):
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     usable = effective_cpus()  # the mask cut down by the cgroup CPU quota: what the whole node's ranks share
     if args.host_share > 1:
+        # 1/K of the usable cores as a THREAD budget for the context's host pool.  The mask itself is left alone: on a
+        # shared box "the first usable/K CPUs" are as likely as not busy with somebody else's work (seen: 0.62 against
+        # 0.87 for the same build), and a rank of a real node floats over its node's cores the same way.
         k = args.host_share
-        keep = allowed[:max(1, usable // k)]
-        os.sched_setaffinity(0, keep)
-        info = {"host_share": k, "cpus": len(keep), "of": usable}
+        info = {"host_share": k, "cpus": max(1, usable // k), "of": usable}
     elif local_world > 1 and not args.stub:
         node = None
         try:
@@ -831,8 +832,9 @@ def main_rank(args):
         legs.append({"n0": n_q, "n1": n_q, "train_sets": n_sets, "ms": round(ms_s, 3),
                      "Tpairs_per_s": round(pairs / ms_s / 1e9, 3),
                      "mfma_frac": round(pairs * 2 * 512 / (ms_s * 1e-3) / MFMA_I8_PEAK_OPS, 3)})
-        match_leg = {"kernel": "k_match_mfma (+ unpack, merge, compaction)", "bound": "mfma",
-                     "peak": "%.1f POP/s int8 dense (2 x the 2.5 PFLOP/s bf16 MFMA rate)" % (MFMA_I8_PEAK_OPS / 1e15),
+        match_leg = {"kernel": "k_match_fp4 (+ unpack, merge, compaction): +-1 operands in FP4 on v_mfma_scale_f32_32x32x64_f8f6f4", "bound": "mfma",
+                     "peak": "mfma_frac is against %.1f POP/s, the dense int8 rate (2 x the 2.5 PFLOP/s bf16 MFMA rate) that the "
+                             "int8 form of the kernel is bound by; the FP4 instruction's own dense rate is twice that" % (MFMA_I8_PEAK_OPS / 1e15),
                      "ops_per_pair": 1024, "sets": legs}
 
     # ---- BASELINE configs[2] and configs[4] end to end (extra legs, rank 0, own clocks) --------------------------------
@@ -997,8 +999,8 @@ def main_rank(args):
         single["multi_context"] = {"contexts": K, "ms_per_frame": round(per * 1e3, 3),
                                    "Mpix_s": round(W * H / per / 1e6, 1)}
 
-    # ---- one rank of an 8-rank node: a child run of the same workload with 1/8 of the host cores (the affinity mask is
-    # cut before the child touches the GPU); this process is idle meanwhile.  The host half of a batch (candidate
+    # ---- one rank of an 8-rank node: a child run of the same workload whose context gets 1/8 of the usable host cores
+    # as its thread budget; this process is idle meanwhile.  The host half of a batch (candidate
     # bucketing, keypoint selection, libm) must still hide under the next batch's kernels. ----
     host_share_leg = None
     if rank == 0 and world == 1 and not args.no_host_share_leg and not args.host_share and not stub:

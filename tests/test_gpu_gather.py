@@ -112,8 +112,7 @@ def test_bench_two_real_ranks_share_one_gpu():
 
 
 def test_bench_host_share_of_an_8_rank_node():
-    """One rank with 1/8 of the host cores (the mask is cut before the process touches the GPU): same results, and the
-    line carries the share it ran with."""
+    """One rank with 1/8 of the host cores as its thread budget: same results, and the line carries the share it ran with."""
     full = _bench_json(["--frames", "4", "--no-host-input"])
     eighth = _bench_json(["--frames", "4", "--no-host-input", "--host-share", "8"])
     assert eighth["config"]["placement"]["host_share"] == 8 and eighth["config"]["placement"]["cpus"] >= 1

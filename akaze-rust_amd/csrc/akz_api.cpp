@@ -34,7 +34,7 @@ struct DevBuf {
 
 // Host cores this process can count on: the affinity mask, cut down by the cgroup CPU quota, divided among the ranks
 // of a one-process-per-GPU job on this host (LOCAL_WORLD_SIZE, set by torchrun).
-static unsigned host_cpu_share() {
+unsigned akz::host_cpu_share() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));

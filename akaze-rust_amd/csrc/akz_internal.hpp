@@ -12,6 +12,8 @@
 namespace akz {
 
 void set_error(const std::string& msg);
+// host cores this process can count on: affinity mask, cgroup CPU quota, ranks per host (akz_api.cpp)
+unsigned host_cpu_share();
 
 #define AKZ_HIP_TRY(expr)                                                                          \
     do {                                                                                           \

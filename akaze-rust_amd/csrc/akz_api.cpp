@@ -71,6 +71,10 @@ struct akz_ctx {
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
+    void* tab_ring = nullptr;                // pinned staging ring of the multi-set matcher's tables
+    size_t tab_ring_bytes = 0;
+    uint64_t tab_ring_next = 0;
+    hipEvent_t tab_ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int match_mode = 2;                      // 0: popcount kernel, 1: matrix cores on int8 operands, 2 (default) / 3: on FP4 operands (akz_ctx_set_match_mode)
     uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
     int dbg_host_sort = -1;                            // akz_debug_set_host_sort: 1 / 0 force the host / the device sort, -1 automatic
@@ -295,6 +299,12 @@ int akz_ctx_destroy(akz_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
         if (b.p) (void)hipHostFree(b.p);
+    if (c->tab_ring) (void)hipHostFree(c->tab_ring);
+    c->tab_ring = nullptr;
+    for (hipEvent_t& e : c->tab_ring_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
     if (c->copy) {
         (void)hipStreamSynchronize(c->copy);
         (void)hipStreamDestroy(c->copy);
@@ -2193,11 +2203,28 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     uint32_t* tpop = bound + (size_t)n_sets * q_rows;
     uint32_t* d_tiles = (uint32_t*)c->mm_tab.p;
     void* d_chunks = (char*)c->mm_tab.p + tab_tiles;
-    if (!tiles.empty())
-        AKZ_HIP_TRY(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(launch::MatchChunkHost), hipMemcpyHostToDevice,
-                               c->stream));
-    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));  // the tables are stack / heap objects of this call
+    // The tables travel through a ring of pinned staging slots, so that the call returns without waiting for its copies
+    // (a synchronisation here made every call of an all-pairs loop wait for the previous call's kernel).
+    {
+        constexpr int kRing = 4;
+        const size_t need = tab_tiles + chunks.size() * sizeof(launch::MatchChunkHost);
+        if (c->tab_ring_bytes < need) {
+            AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->tab_ring) AKZ_HIP_TRY(hipHostFree(c->tab_ring));
+            c->tab_ring = nullptr;
+            c->tab_ring_bytes = 0;
+            AKZ_HIP_TRY(hipHostMalloc(&c->tab_ring, (need + need / 2 + 4096) * kRing, hipHostMallocDefault));
+            c->tab_ring_bytes = need + need / 2 + 4096;
+        }
+        const int slot = (int)(c->tab_ring_next++ % kRing);
+        if (!c->tab_ring_ev[slot]) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->tab_ring_ev[slot], hipEventDisableTiming));
+        else AKZ_HIP_TRY(hipEventSynchronize(c->tab_ring_ev[slot]));  // the copy that used this slot four calls ago
+        char* stage = (char*)c->tab_ring + (size_t)slot * c->tab_ring_bytes;
+        if (!tiles.empty()) std::memcpy(stage, tiles.data(), tiles.size() * sizeof(uint32_t));
+        std::memcpy(stage + tab_tiles, chunks.data(), chunks.size() * sizeof(launch::MatchChunkHost));
+        AKZ_HIP_TRY(hipMemcpyAsync(d_tiles, stage, need, hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP_TRY(hipEventRecord(c->tab_ring_ev[slot], c->stream));
+    }
     const bool fp4 = c->match_mode >= 2;
     launch::unpack_bits(c->stream, d_q, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, (uint32_t)n_sets,
                         nullptr, fp4);

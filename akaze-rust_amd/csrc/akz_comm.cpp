@@ -505,6 +505,7 @@ struct akz_pairs {
     akz_ctx* ctx = nullptr;
     int device = 0;
     uint8_t* d_all = nullptr;            // rows of every image of the job, rank-major, compacted
+    uint8_t* d_block = nullptr;          // the records and counts of all owned images
     std::vector<uint64_t> rows, offset;  // per image
     std::vector<int> owner;
     uint64_t first_owned = 0, n_owned = 0;
@@ -560,10 +561,21 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     p->d_out.assign((size_t)p->n_owned, nullptr);
     p->d_cnt.assign((size_t)p->n_owned, nullptr);
     p->cnt.assign((size_t)p->n_owned, std::vector<uint64_t>((size_t)n_images, 0));
+    // one block for every owned image's records and counts (a device allocation per image cost more than its launch)
+    size_t bytes = 0;
+    std::vector<size_t> off_out((size_t)p->n_owned), off_cnt((size_t)p->n_owned);
+    for (uint64_t k = 0; k < p->n_owned; ++k) {
+        const uint64_t n0 = p->rows[(size_t)(p->first_owned + k)];
+        off_out[(size_t)k] = bytes;
+        bytes += (std::max<uint64_t>(1, n0 * n_images) * sizeof(akz_match) + 255) / 256 * 256;
+        off_cnt[(size_t)k] = bytes;
+        bytes += (n_images * sizeof(uint64_t) + 255) / 256 * 256;
+    }
+    AKZ_HIP_TRY(hipMalloc((void**)&p->d_block, std::max<size_t>(bytes, 256)));
     for (uint64_t k = 0; k < p->n_owned; ++k) {
         const uint64_t q = p->first_owned + k, n0 = p->rows[(size_t)q];
-        AKZ_HIP_TRY(hipMalloc((void**)&p->d_out[(size_t)k], std::max<uint64_t>(1, n0 * n_images) * sizeof(akz_match)));
-        AKZ_HIP_TRY(hipMalloc((void**)&p->d_cnt[(size_t)k], n_images * sizeof(uint64_t)));
+        p->d_out[(size_t)k] = (akz_match*)(p->d_block + off_out[(size_t)k]);
+        p->d_cnt[(size_t)k] = (uint64_t*)(p->d_block + off_cnt[(size_t)k]);
         AKZ_TRY(akz_descriptor_match_sets_device(ctx, p->d_all + p->offset[(size_t)q] * kRow, n0, p->d_all, p->rows.data(), n_images,
                                                  distance_threshold, lowes_ratio, p->d_out[(size_t)k], p->d_cnt[(size_t)k]));
     }
@@ -606,10 +618,7 @@ int akz_pairs_free(akz_pairs* p) {
     (void)hipSetDevice(p->device);
     if (p->ctx) (void)akz_ctx_synchronize(p->ctx);
     if (p->d_all) (void)hipFree(p->d_all);
-    for (akz_match* m : p->d_out)
-        if (m) (void)hipFree(m);
-    for (uint64_t* m : p->d_cnt)
-        if (m) (void)hipFree(m);
+    if (p->d_block) (void)hipFree(p->d_block);
     delete p;
     return AKZ_OK;
 }

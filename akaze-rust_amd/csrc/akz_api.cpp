@@ -58,6 +58,21 @@ unsigned akz::host_cpu_share() {
 // host's per-image selection and the finish round trips, not by its kernels).
 static constexpr uint64_t kBigLaunchPx() { return 8u << 20; }
 
+// The finish half of a lane's jobs on a thread of the library (akz_ctx_set_eager_finish): started by begin, so that the
+// candidate round trip, the host keypoint logic and the keypoint kernels of frame i run while the caller's thread
+// enqueues frame i + 1 on another lane; akz_extract_finish then only collects the result.  One thread per lane, jobs
+// in the order they were begun.  Every other use of the lane (bind) first waits until the thread is idle, so the lane's
+// state is never touched from two threads at once.
+struct akz_job;
+struct Finisher {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::vector<akz_job*> queue;
+    unsigned in_flight = 0;  // queued + running
+    bool quit = false;
+};
+
 struct akz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -82,12 +97,13 @@ struct akz_ctx {
     DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
                                              // rows, keypoint params, (cos, sin), contrast factors
     std::vector<std::pair<size_t, void*>> slab_pool;  // freed device blocks (pyramid slabs, descriptor rows)
+    std::mutex slab_m;                                // results are freed by the caller while a lane's finisher thread allocates
     // extractions in flight (akz_extract_begin_* / akz_extract_finish)
     static constexpr int kSlots = 3;
     DevBuf cand_slot[kSlots], count_slot[kSlots];
     bool slot_busy[kSlots] = {false, false, false};
     uint32_t cand_cap_hint = 1u << 15;  // grows to 1.25x the largest candidate count seen
-    int live_results = 0;               // akz_result objects (also inside jobs) that still point at this context
+    std::atomic<int> live_results{0};   // akz_result objects (also inside jobs) that still point at this context
     bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
     uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
@@ -100,6 +116,9 @@ struct akz_ctx {
     // overlap on the chip instead of queueing on one stream (akz_ctx_set_lanes).
     std::vector<akz_ctx*> lanes;
     unsigned next_lane = 0;
+    bool is_lane = false;               // this context is a lane of another one
+    bool eager_finish = false;          // akz_ctx_set_eager_finish: jobs dealt to lanes are finished by the lanes' threads
+    std::shared_ptr<Finisher> fin;      // (a lane's) finisher thread (shared with its jobs: one may outlive the context), started with its first eager job
     hipEvent_t lane_in = nullptr;       // inputs of the job are ready on the caller's stream
     // stage profiling (akz_ctx_set_profiling)
     uint64_t stream_min_px = 2u << 20;  // pixels per launch (w*h*n) from which the streaming kernels pay off
@@ -206,7 +225,26 @@ static int ensure_aux(akz_ctx* c) {
     if (!c->aux) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     return AKZ_OK;
 }
-static int bind(akz_ctx* c) {
+// wait until the context's finisher thread (if any) has nothing queued or running; a no-op on that thread itself
+static void finisher_drain(akz_ctx* c) {
+    Finisher* f = c->fin.get();
+    if (!f || f->th.get_id() == std::this_thread::get_id()) return;
+    std::unique_lock<std::mutex> lk(f->m);
+    f->done.wait(lk, [&] { return f->in_flight == 0; });
+}
+static void finisher_stop(akz_ctx* c) {
+    Finisher* f = c->fin.get();
+    if (!f) return;
+    {
+        std::unique_lock<std::mutex> lk(f->m);
+        f->done.wait(lk, [&] { return f->in_flight == 0; });
+        f->quit = true;
+    }
+    f->wake.notify_all();
+    if (f->th.joinable()) f->th.join();
+    c->fin.reset();
+}
+static int bind(akz_ctx* c, bool lanes_too = true) {
     if (!c) {
         set_error("null context");
         return AKZ_ERR_INVALID_ARG;
@@ -215,6 +253,9 @@ static int bind(akz_ctx* c) {
         set_error("the context of this object was destroyed");
         return AKZ_ERR_INVALID_ARG;
     }
+    finisher_drain(c);
+    if (lanes_too)  // (every call but the one that deals a job to a lane: setters forward to the lanes, queries read them)
+        for (akz_ctx* l : c->lanes) finisher_drain(l);
     AKZ_HIP_TRY(hipSetDevice(c->device));
     // The HIP runtime keeps ONE last-error slot per thread, shared with every other user of the runtime in the
     // process (PyTorch probes that fail on purpose, ...): drop whatever is in it so that the hipGetLastError()
@@ -287,6 +328,7 @@ int akz_stream_destroy(int device, void* stream) {
 int akz_ctx_destroy(akz_ctx* c) {
     if (!c) return AKZ_OK;
     (void)hipSetDevice(c->device);
+    finisher_stop(c);
     for (akz_ctx* l : c->lanes) (void)akz_ctx_destroy(l);
     c->lanes.clear();
     if (c->lane_in) { (void)hipEventDestroy(c->lane_in); c->lane_in = nullptr; }
@@ -802,6 +844,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
     bytes = align_up(std::max<size_t>(bytes, 256), 256);
+    std::lock_guard<std::mutex> lk(c->slab_m);
     for (size_t i = 0; i < c->slab_pool.size(); ++i)
         if (c->slab_pool[i].first >= bytes && c->slab_pool[i].first <= bytes + bytes / 4 + 65536) {
             *p = c->slab_pool[i].second;
@@ -815,6 +858,7 @@ static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
     return AKZ_OK;
 }
 static void slab_release(akz_ctx* c, void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(c->slab_m);
     if (c->slab_pool.size() >= 8) {
         (void)hipStreamSynchronize(c->stream);
         if (c->aux) (void)hipStreamSynchronize(c->aux);
@@ -839,6 +883,12 @@ struct akz_job {
     uint32_t cap = 0;         // candidate capacity per image
     hipEvent_t nms_done = nullptr;
     double t_begin_ms = 0.0;
+    // eager finish: the lane's thread runs the finish half and leaves its outcome here (guarded by fin->m)
+    std::shared_ptr<Finisher> fin;
+    bool finished = false;
+    int rc = 0;
+    akz_result* out = nullptr;
+    std::string err;
 };
 
 static void result_release_device(akz_result* r) {
@@ -862,15 +912,31 @@ static void result_delete(akz_result* r) {
     if (c && --c->live_results == 0 && c->dead) delete c;
 }
 void ResultDeleter::operator()(akz_result* r) const { result_delete(r); }
+// a job that will not produce a result hands back what it holds on its context (the shell itself is deleted by the caller)
+static void job_release(akz_job* j) {
+    akz_ctx* c = j->r ? j->r->ctx : nullptr;
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->coarse) (void)hipStreamSynchronize(c->coarse);  // a forked batch completes on the coarse stream
+    if (j->slot >= 0) c->slot_busy[j->slot] = false;
+    j->slot = -1;
+    if (j->nms_done) c->ev_pool.push_back(j->nms_done);
+    j->nms_done = nullptr;
+    result_release_device(j->r.get());
+}
+// the outcome of an eagerly finished job, once its lane's thread is through with it
+static void job_wait(akz_job* j) {
+    if (!j->fin) return;
+    std::unique_lock<std::mutex> lk(j->fin->m);
+    j->fin->done.wait(lk, [&] { return j->finished; });
+}
 static void job_destroy(akz_job* j) {
     if (!j) return;
-    akz_ctx* c = j->r ? j->r->ctx : nullptr;
-    if (c) {
-        (void)hipStreamSynchronize(c->stream);
-        if (c->coarse) (void)hipStreamSynchronize(c->coarse);  // a forked batch completes on the coarse stream
-        if (j->slot >= 0) c->slot_busy[j->slot] = false;
-        if (j->nms_done) c->ev_pool.push_back(j->nms_done);
-        result_release_device(j->r.get());
+    if (j->fin) {
+        job_wait(j);
+        if (j->out) result_delete(j->out);
+    } else {
+        job_release(j);
     }
     delete j;
 }
@@ -1244,15 +1310,22 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     return AKZ_OK;
 }
 
-static int extract_finish(akz_job* jobp, akz_result** out) {
-    if (!jobp || !out) return AKZ_ERR_INVALID_ARG;
+// The finish half proper.  The job shell stays with the caller; on failure everything the job held is released.
+static int extract_finish_body(akz_job* jobp, akz_result** out) {
     *out = nullptr;
-    std::unique_ptr<akz_job, void (*)(akz_job*)> job(jobp, job_destroy);  // always consumed
+    std::unique_ptr<akz_job, void (*)(akz_job*)> job(jobp, job_release);
     akz_result* r = job->r.get();
     akz_ctx* c = r->ctx;
     AKZ_TRY(bind(c));
-    AKZ_TRY(ensure_aux(c));
-    hipStream_t s = c->aux;  // everything below waits only for THIS job's kernels
+    // everything below waits only for THIS job's kernels: on the context's auxiliary stream, behind the job's event.  An
+    // eagerly finished job of a lane stays on the lane's own stream (its finish half is enqueued right behind its begin
+    // half): the streams of a process share a few hardware queues, each of which runs its packets in order, so every
+    // further stream of a lane queues its keypoint kernels behind the launch chain of some other lane
+    hipStream_t s = c->stream;
+    if (!(c->is_lane && job->fin)) {
+        AKZ_TRY(ensure_aux(c));
+        s = c->aux;
+    }
     const akz_config& cfg = r->cfg;
     const std::vector<LevelPlan>& plan = r->plan;
     const size_t L = plan.size();
@@ -1514,9 +1587,63 @@ static int extract_finish(akz_job* jobp, akz_result** out) {
     c->ev_pool.push_back(job->nms_done);
     job->nms_done = nullptr;
     *out = job->r.release();
-    akz_job* raw = job.release();
-    delete raw;
+    (void)job.release();
     return AKZ_OK;
+}
+static int extract_finish(akz_job* jobp, akz_result** out) {
+    if (!jobp || !out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc;
+    if (jobp->fin) {  // finished (or being finished) by its lane's thread
+        job_wait(jobp);
+        rc = jobp->rc;
+        *out = jobp->out;
+        if (rc != AKZ_OK) set_error(jobp->err);
+    } else {
+        rc = extract_finish_body(jobp, out);
+    }
+    delete jobp;
+    return rc;
+}
+static void finisher_loop(akz_ctx* c, Finisher* f) {
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        akz_job* j = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(f->m);
+            f->wake.wait(lk, [&] { return f->quit || !f->queue.empty(); });
+            if (f->queue.empty()) return;  // quit is only set with nothing in flight
+            j = f->queue.front();
+            f->queue.erase(f->queue.begin());
+        }
+        akz_result* res = nullptr;
+        const int rc = extract_finish_body(j, &res);
+        std::string err = rc != AKZ_OK ? get_error() : std::string();
+        {
+            std::lock_guard<std::mutex> lk(f->m);
+            j->rc = rc;
+            j->out = res;
+            j->err.swap(err);
+            j->finished = true;
+            --f->in_flight;
+        }
+        f->done.notify_all();
+    }
+}
+static void finisher_post(akz_ctx* lane, akz_job* j) {
+    if (!lane->fin) {
+        lane->fin.reset(new Finisher);
+        Finisher* f = lane->fin.get();
+        f->th = std::thread([lane, f] { finisher_loop(lane, f); });
+    }
+    Finisher* f = lane->fin.get();
+    {
+        std::lock_guard<std::mutex> lk(f->m);
+        j->fin = lane->fin;
+        f->queue.push_back(j);
+        ++f->in_flight;
+    }
+    f->wake.notify_one();
 }
 
 // `pub mod ops` on CALLER-PROVIDED evolutions (ops::scale_space_extrema::detect_keypoints, scale_space_extrema.rs:199-203,
@@ -1667,12 +1794,13 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
     if (lanes < 1 || lanes > 8) return AKZ_ERR_INVALID_ARG;
     const size_t want = lanes == 1 ? 0 : lanes;
     // a lane that goes away must have no extraction in flight: its job would be finished on destroyed streams
-    for (size_t i = want; i < c->lanes.size(); ++i)
+    for (size_t i = want; i < c->lanes.size(); ++i) {
         for (int k = 0; k < akz_ctx::kSlots; ++k)
             if (c->lanes[i]->slot_busy[k]) {
                 set_error("akz_ctx_set_lanes: a lane that would be removed has an extraction in flight (finish or abandon it first)");
                 return AKZ_ERR_INVALID_ARG;
             }
+    }
     while (c->lanes.size() > want) {
         AKZ_TRY(akz_ctx_destroy(c->lanes.back()));
         c->lanes.pop_back();
@@ -1687,6 +1815,7 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
             return rc;
         }
         l->own_stream = true;
+        l->is_lane = true;
         l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
         l->cand_cap_hint = c->cand_cap_hint;
         l->stream_min_px = c->stream_min_px;
@@ -1700,11 +1829,19 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
     c->next_lane = 0;
     return AKZ_OK;
 }
+// on != 0: the finish half of every job that is dealt to a lane starts on the lane's own thread as soon as the job has
+// been begun; akz_extract_finish waits for it and hands the result over (bit-identical; errors of the finish half are
+// reported there as before).  Jobs that stay on the context itself (no lanes, or 8 Mpx and more) are not affected.
+int akz_ctx_set_eager_finish(akz_ctx* c, int on) {
+    AKZ_TRY(bind(c));
+    c->eager_finish = on != 0;
+    return AKZ_OK;
+}
 static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
                                   const akz_config* cfg, uint32_t flags, akz_job** out, bool on_host = false) {
     akz_ctx* on = c;
     if (c && !c->lanes.empty() && (uint64_t)w * h * n < kBigLaunchPx()) {
-        AKZ_TRY(bind(c));
+        AKZ_TRY(bind(c, false));
         on = c->lanes[c->next_lane++ % c->lanes.size()];
         // the lane starts when the caller's stream has reached this point (its inputs are complete)
         if (!c->lane_in) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->lane_in, hipEventDisableTiming));
@@ -1738,8 +1875,10 @@ static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint
         AKZ_HIP_TRY(hipStreamWaitEvent(on->stream, on->staged[slot], 0));
         d_imgs = on->stage[slot].p;
     }
-    return is_u8 ? extract_begin<uint8_t>(on, (const uint8_t*)d_imgs, w, h, n, cfg, flags, out, slot)
-                 : extract_begin<float>(on, (const float*)d_imgs, w, h, n, cfg, flags, out, slot);
+    const int rc = is_u8 ? extract_begin<uint8_t>(on, (const uint8_t*)d_imgs, w, h, n, cfg, flags, out, slot)
+                         : extract_begin<float>(on, (const float*)d_imgs, w, h, n, cfg, flags, out, slot);
+    if (rc == AKZ_OK && on != c && c->eager_finish) finisher_post(on, *out);
+    return rc;
 }
 int akz_extract_begin_host_u8(akz_ctx* c, const uint8_t* h_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
                               uint32_t flags, akz_job** out) {
@@ -1835,7 +1974,10 @@ int akz_extract_from_planes(akz_ctx* c, uint32_t w, uint32_t h, const akz_config
     return extract_from_planes(c, w, h, cfg, planes, n_levels, flags, out);
 }
 int akz_job_abandon(akz_job* job) {
-    if (job && job->r) (void)hipSetDevice(job->r->ctx->device);
+    if (!job) return AKZ_OK;
+    job_wait(job);
+    const akz_result* r = job->out ? job->out : job->r.get();
+    if (r) (void)hipSetDevice(r->ctx->device);
     job_destroy(job);
     return AKZ_OK;
 }

@@ -157,6 +157,7 @@ def lib():
         "akz_ctx_graph_probe": ([vp, vp, u32, u32, u32, C.POINTER(Config), u32, u32, pf64, pf64, pu64], i32),
         "akz_debug_march_bands": ([i32, u32, u32, u32, i32, C.POINTER(i32), u32, pu32], i32),
         "akz_ctx_set_lanes": ([vp, u32], i32),
+        "akz_ctx_set_eager_finish": ([vp, i32], i32),
         "akz_fed_kernel_name": ([], C.c_char_p),
         "akz_ctx_set_host_threads": ([vp, u32], i32),
         "akz_debug_set_match_chunks": ([vp, u32, u32], i32),
@@ -334,6 +335,11 @@ class Context:
         """Deal jobs below 8 Mpx to `lanes` child contexts in turn (1 = off): the launch chains of consecutive single
         frames then overlap on the chip."""
         _check(lib().akz_ctx_set_lanes(self._h, int(lanes)))
+
+    def set_eager_finish(self, on=True):
+        """With lanes: the finish half of every job dealt to a lane starts on that lane's own thread as soon as the job
+        has been begun; `finish()` then only collects the result (same results)."""
+        _check(lib().akz_ctx_set_eager_finish(self._h, 1 if on else 0))
 
     def set_match_mode(self, mode):
         """2 = automatic (default), 1 = matrix-core matcher, 0 = popcount matcher."""
@@ -639,10 +645,15 @@ class Job:
         self._frames = None
         return ExtractResult(self._ctx, res)
 
-    def __del__(self):
+    def abandon(self):
+        """Drop the extraction without a result (akz_job_abandon)."""
         if getattr(self, "_h", None):
             lib().akz_job_abandon(self._h)
             self._h = None
+        self._frames = None
+
+    def __del__(self):
+        self.abandon()
 
 
 class ExtractResult:

@@ -38,6 +38,12 @@ import subprocess
 import sys
 import time
 
+# Hardware queues the HIP runtime multiplexes this process's streams onto (default 4; each runs its packets in order).
+# The lanes of the single-frame legs are one stream each: with 4 queues the chains of 3-4 lanes queue behind each other
+# (0.53 -> 0.47 ms per streamed 1080p frame); the batch headline is indifferent (measured both ways).  A deployment
+# knob, read by the runtime when it initialises -- INTEGRATION.md lists it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "akaze-rust_amd", "python")]
 
@@ -306,6 +312,9 @@ class _StubContext:
 
     def extract_begin(self, batch, cfg, keep_all_planes=True):
         return _StubJob([100 + 7 * self.rank + i for i in range(int(batch.shape[0]))])
+
+    def set_eager_finish(self, *_):
+        pass
 
     def set_lanes(self, *_):
         pass
@@ -956,6 +965,52 @@ def main_rank(args):
                 pending.pop(0).finish().close()
             thr_l = (time.perf_counter() - t1) / reps
             single["lanes"][str(lanes)] = {"stream_ms_per_frame": round(thr_l * 1e3, 3), "stream_Mpix_s": round(W * H / thr_l / 1e6, 1)}
+        # ... and with the finish half of every frame on its lane's own thread (akz_ctx_set_eager_finish): the caller's
+        # thread only enqueues the next frames and collects results; lone 4K frames the same way
+        def stream_eager(frame, lanes, reps_e):
+            ctx.set_lanes(lanes)
+            ctx.set_eager_finish(True)
+            for _ in range(2 * lanes):
+                ctx.extract_begin(frame, cfg, keep_all_planes=not args.lean).finish().close()
+            t_e = time.perf_counter()
+            pend = []
+            for _ in range(reps_e):
+                pend.append(ctx.extract_begin(frame, cfg, keep_all_planes=not args.lean))
+                if len(pend) >= lanes:
+                    pend.pop(0).finish().close()
+            while pend:
+                pend.pop(0).finish().close()
+            dt = (time.perf_counter() - t_e) / reps_e
+            ctx.set_eager_finish(False)
+            return dt
+        single["eager_finish"] = {}
+        for lanes in (2, 3, 4):
+            thr_e = stream_eager(one, lanes, reps)
+            single["eager_finish"][str(lanes)] = {"stream_ms_per_frame": round(thr_e * 1e3, 3), "stream_Mpix_s": round(W * H / thr_e / 1e6, 1)}
+        if not stub:
+            try:
+                one4k = torch.from_numpy(A.synth_frame(3840, 2160, 3)[None]).to(dev)
+                ctx.set_lanes(1)
+                def stream_plain(frame, reps_p):
+                    t_p = time.perf_counter()
+                    prev = None
+                    for _ in range(reps_p):
+                        job = ctx.extract_begin(frame, cfg, keep_all_planes=not args.lean)
+                        if prev is not None:
+                            prev.finish().close()
+                        prev = job
+                    prev.finish().close()
+                    return (time.perf_counter() - t_p) / reps_p
+                stream_plain(one4k, 6)  # (warm-up in the same pattern: two pyramids alive at a time)
+                thr4 = stream_plain(one4k, 30)
+                thr4e = stream_eager(one4k, 4, 40)
+                single["lone_4k"] = {"workload": "one 3840x2160 frame per extract_features call",
+                                     "stream_ms_per_frame": round(thr4 * 1e3, 3), "stream_Mpix_s": round(3840 * 2160 / thr4 / 1e6, 1),
+                                     "eager_finish_4_lanes": {"stream_ms_per_frame": round(thr4e * 1e3, 3),
+                                                              "stream_Mpix_s": round(3840 * 2160 / thr4e / 1e6, 1)}}
+                del one4k
+            except Exception as e:
+                single["lone_4k"] = {"error": str(e)[:300]}
         ctx.set_lanes(1)
         try:  # the begin phase (scale space, detector, extrema) as one hipGraph launch against the plain launch chain
             g_ms, p_ms, nodes = ctx.graph_probe(one, cfg, keep_all_planes=not args.lean, reps=50)
@@ -1086,6 +1141,7 @@ def main_rank(args):
                        "frames_per_gpu": F, "width": W, "height": H, "batches_per_step": NP,
                        "pipelining": "begin(batch j+1) before finish(batch j) on one stream, across steps",
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "exchange_ranks_seen": xch["ranks_seen"],
                        "placement": placement or None,
                        "share_gpu": bool(args.share_gpu),

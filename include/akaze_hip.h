@@ -447,6 +447,14 @@ int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
    The caller's stream is respected (a lane starts behind what the caller enqueued before the call); results are
    bit-identical and are used through the same calls. */
 int akz_ctx_set_lanes(akz_ctx* ctx, uint32_t lanes);
+/* Eager finish (with lanes).  on != 0: the finish half of every job that is dealt to a lane -- the candidate round trip,
+   the order-dependent keypoint selection of the host, the orientation / descriptor kernels and their copies -- is started
+   by akz_extract_begin_* on a thread owned by that lane; akz_extract_finish waits for it and hands the result over.  The
+   caller's thread is then free to begin the next frames on the other lanes meanwhile: a stream of lone frames is bound
+   by the longer of the two halves instead of their sum.  Results, error reporting (through akz_extract_finish) and
+   akz_job_abandon are unchanged; any other call on a context waits until its lanes' threads are idle.  Jobs that stay
+   on the context itself (lanes = 1, or 8 Mpx and more) are not affected.  Default off. */
+int akz_ctx_set_eager_finish(akz_ctx* ctx, int on);
 /* Host threads of the finish half of an extraction (candidate bucketing, per-image keypoint selection, libm calls):
    0 (default) = automatic -- the affinity mask of the process, cut down by the cgroup CPU quota and divided by
    LOCAL_WORLD_SIZE (one process per GPU: torchrun sets it), at most 16.  A launcher that has already pinned each rank

@@ -190,6 +190,62 @@ def test_lanes_stream_of_single_frames(amd, ref):
     assert r2.descriptors(0).tobytes() == res[1].descriptors(0).tobytes()
 
 
+def test_eager_finish_on_lanes(amd, ref):
+    """akz_ctx_set_eager_finish: the finish half of jobs on lanes runs on the lanes' own threads.  A stream of frames with
+    several jobs in flight (more than one per lane), frames of different sizes, a job that is abandoned, an overflowing
+    candidate list (the finish half's retry path on the thread), a result freed while its lane is busy with a later job,
+    other calls on the context in between (they wait for the threads), switching the mode off again and destroying the
+    context with results alive: every plane, keypoint and descriptor byte against the oracle."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_lanes(3)
+    c.set_eager_finish(True)
+    sizes = [(640, 360), (505, 393), (640, 360), (161, 81), (640, 360), (800, 450), (640, 360), (480, 270)]
+    frames = [amd.synth_frame(w, h, 70 + i) for i, (w, h) in enumerate(sizes)]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    refs = [ref.extract(f) for f in frames]
+    res = [None] * len(frames)
+    pending = []
+    for i, d in enumerate(dev):                            # five jobs in flight over three lanes
+        pending.append((i, c.extract_begin(d)))
+        if len(pending) == 5:
+            k, j = pending.pop(0)
+            res[k] = j.finish()
+    for k, j in pending:
+        res[k] = j.finish()
+    for r, rf in zip(res, refs):
+        assert_same_result(r, rf, planes=True)
+    # a job nobody finishes, then the same frame again
+    c.extract_begin(dev[1]).abandon()
+    j_a, j_b = c.extract_begin(dev[1]), c.extract_begin(dev[5])
+    c.synchronize()                                        # a call on the context between begin and finish
+    assert_same_result(j_b.finish(), refs[5], planes=False)
+    assert_same_result(j_a.finish(), refs[1], planes=False)
+    # candidate overflow: the retry of the extrema pass runs on the lane's thread
+    c.set_lanes(1)
+    c.set_candidate_hint(16)
+    c.set_lanes(2)
+    ro = [c.extract_begin(dev[0]), c.extract_begin(dev[5])]
+    assert_same_result(ro[1].finish(), refs[5], planes=False)
+    assert_same_result(ro[0].finish(), refs[0], planes=False)
+    # results freed while their lanes work on later jobs
+    hold = [c.extract_begin(d) for d in dev[:4]]
+    first = [hold[0].finish(), hold[1].finish()]
+    more = [c.extract_begin(d) for d in dev[4:6]]
+    first[0].close(), first[1].close()
+    for j, k in zip(hold[2:] + more, (2, 3, 4, 5)):
+        assert_same_result(j.finish(), refs[k], planes=False)
+    c.set_eager_finish(False)
+    assert_same_result(c.extract_begin(dev[7]).finish(), refs[7], planes=False)
+    c.set_eager_finish(True)
+    last = c.extract_begin(dev[6]).finish()
+    unfinished = c.extract_begin(dev[2])                  # still owned by its lane's thread when the context goes away
+    c.close()
+    assert last.keypoints(0).tobytes() == res[6].keypoints(0).tobytes()
+    assert last.descriptors(0).tobytes() == res[6].descriptors(0).tobytes()
+    unfinished.abandon()
+
+
 def test_baseline_c2_1080p_frame(ctx, amd, ref):
     """BASELINE.json configs[1]: one 1920x1080 synthetic frame, 4 octaves x 4 sublevels."""
     frame = amd.synth_frame(1920, 1080, 0)

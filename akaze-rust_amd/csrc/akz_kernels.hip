@@ -585,6 +585,23 @@ constexpr OriTable make_ori_table() {
     return t;
 }
 __constant__ OriTable c_ori = make_ori_table();
+// The same samples ordered by row (b), then column (a): the order in which phase 1 hands them to consecutive threads, so
+// that neighbouring lanes gather neighbouring pixels of a row; order[i] is the sample's index in the reference's order.
+struct OriOrder {
+    unsigned char k[112];
+};
+constexpr OriOrder make_ori_order() {
+    OriOrder o{};
+    const OriTable t = make_ori_table();
+    int n = 0;
+    for (int b = -6; b <= 6; ++b)
+        for (int a = -6; a <= 6; ++a)
+            for (int k = 0; k < 109; ++k)
+                if (t.a[k] == a && t.b[k] == b) o.k[n++] = (unsigned char)k;
+    for (; n < 112; ++n) o.k[n] = 0;
+    return o;
+}
+__constant__ OriOrder c_ori_rows = make_ori_order();
 
 // Workgroups are numbered so that each XCD (workgroup id mod 8) walks a CONTIGUOUS range of the keypoint
 // list: neighbours in the list are neighbours in the image, and their sample windows then share lines in
@@ -612,11 +629,13 @@ k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, uns
     static_assert(ORI_IT % ORI_UB == 0, "whole batches");
     for (int it0 = 0; it0 < ORI_IT; it0 += ORI_UB) {
         float vx[ORI_UB], vy[ORI_UB], gw[ORI_UB];
+        unsigned slot[ORI_UB];
 #pragma unroll
         for (int u = 0; u < ORI_UB; ++u) {
             const unsigned idx = threadIdx.x + (unsigned)(it0 + u) * ORI_NT;
-            const unsigned j = idx / ORI_NS, k = idx - j * ORI_NS;
+            const unsigned j = idx / ORI_NS, k = c_ori_rows.k[idx - j * ORI_NS];
             vx[u] = 0.0f; vy[u] = 0.0f; gw[u] = 0.0f;
+            slot[u] = j * ORI_NS + k;
             if (idx < ORI_KPB * ORI_NS && base + j < nkp) {
                 const KpParam kp = kps[base + j];
                 const LevelPtrs lv = tab.lv[kp.level];
@@ -639,8 +658,8 @@ k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, uns
             const unsigned j = idx / ORI_NS;
             if (idx < ORI_KPB * ORI_NS) {
                 const bool have = base + j < nkp;
-                s_rx[idx] = have ? gw[u] * vx[u] : 0.0f;
-                s_ry[idx] = have ? gw[u] * vy[u] : 0.0f;
+                s_rx[slot[u]] = have ? gw[u] * vx[u] : 0.0f;
+                s_ry[slot[u]] = have ? gw[u] * vy[u] : 0.0f;
             }
         }
     }
@@ -705,6 +724,24 @@ constexpr PairTable make_pairs() {
     return t;
 }
 __constant__ PairTable c_pairs = make_pairs();
+// The 486 bits of a 3-channel row, in order: (channel << 10) | (cell a << 5) | cell b -- the comparison behind bit i, so
+// that the lanes need neither the divisions of the general formula nor two dependent table look-ups per bit
+struct BitTable3 {
+    unsigned short e[512];
+};
+constexpr BitTable3 make_bits3() {
+    BitTable3 t{};
+    const PairTable p = make_pairs();
+    const int npairs[3] = {6, 36, 120}, pbase[3] = {0, 6, 42};
+    int b = 0;
+    for (int g = 0; g < 3; ++g)
+        for (int pos = 0; pos < 3; ++pos)
+            for (int q = 0; q < npairs[g]; ++q)
+                t.e[b++] = (unsigned short)((pos << 10) | (p.a[pbase[g] + q] << 5) | p.b[pbase[g] + q]);
+    for (; b < 512; ++b) t.e[b] = 0;  // a cell against itself: the bit is 0
+    return t;
+}
+__constant__ BitTable3 c_bits3 = make_bits3();
 
 // Four keypoints (waves) per workgroup.  The three grids sample the same rotated lattice: offsets
 // k, l in [-10, 10) for the 2x2 and 4x4 grids and [-10, 11) for the 3x3 grid, and a sample's
@@ -735,15 +772,23 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
     const float* Lx = lv.lx + ioff;
     const float* Ly = lv.ly + ioff;
     const float co = cs.x, si = cs.y, scale = kp.scale;
+    unsigned short bits3[8];  // this lane's comparisons (fetched before the gathers are waited for)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bits3[r] = c_bits3.e[r * 64 + (int)lane];
     if (live) {
         // All gathers of a lane (7 lattice points x 3 planes) are issued before the first one is consumed: with the
         // rolled loop a wave waited for seven memory round trips in a row (29 us per keypoint, 0.45 ms per batch).
         constexpr int NIT = (MLDB_NS + 63) / 64;
+        const bool k_fast = fabsf(co) >= fabsf(si);  // wave-uniform
         unsigned pidx[NIT];
+        int widx[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int sidx = min((int)lane + 64 * it, MLDB_NS - 1);  // the surplus lanes of the last round repeat a sample
-            const int kk = sidx / MLDB_LAT, ll = sidx - kk * MLDB_LAT;
+            // consecutive lanes walk the lattice direction that is closer to the image's x axis (a step in k moves
+            // (co, si) * scale pixels, a step in l (-si, co) * scale): their gathers then share cache lines
+            const int qa = sidx / MLDB_LAT, qb = sidx - qa * MLDB_LAT;
+            const int kk = k_fast ? qb : qa, ll = k_fast ? qa : qb;
             const int k = kk - 10, l = ll - 10;
             const float lf = (float)l + 0.5f, kf = (float)k + 0.5f;
             const float sample_y = kp.yf + (lf * co * scale + kf * si * scale);
@@ -751,6 +796,7 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
             const int y1 = clampi((int)roundf(sample_y), 0, (int)lv.h - 1);
             const int x1 = clampi((int)roundf(sample_x), 0, (int)lv.w - 1);
             pidx[it] = (unsigned)y1 * (unsigned)lv.w + (unsigned)x1;
+            widx[it] = kk * MLDB_LAT + ll;
         }
         float vt[NIT], vx[NIT], vy[NIT];
 #pragma unroll
@@ -773,35 +819,53 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
                     v1 = -rx * si + ry * co;  // rrx -> dx
                 }
             }
-            s_win[wv][0][sidx] = vt[it];
-            s_win[wv][1][sidx] = v1;
-            s_win[wv][2][sidx] = v2;
+            s_win[wv][0][widx[it]] = vt[it];
+            s_win[wv][1][widx[it]] = v1;
+            s_win[wv][2][widx[it]] = v2;
         }
     }
     __syncthreads();
-    if (live && lane < 29) {
+    // Cell sums: lanes 0..28 of wave 0 take the cells of the workgroup's keypoint 0, lanes 32..60 those of keypoint 1;
+    // wave 1 keypoints 2 and 3 the same way (a wave that sums for one keypoint issues the same instructions for 29 lanes)
+    const unsigned cl = lane & 31u, ckp = 2u * wv + (lane >> 5);  // cell and keypoint (of the workgroup) of this lane
+    if (wv < MLDB_KPB / 2 && cl < 29 && xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB + ckp < nkp) {
         // cell ids 0..3: 2x2 grid (step 10), 4..12: 3x3 (step 7), 13..28: 4x4 (step 5)
-        const int g = lane < 4 ? 0 : (lane < 13 ? 1 : 2);
+        const int g = cl < 4 ? 0 : (cl < 13 ? 1 : 2);
         const int step = g == 0 ? 10 : (g == 1 ? 7 : 5), ng = g + 2;
-        const int ci = (int)lane - (g == 0 ? 0 : (g == 1 ? 4 : 13));
+        const int ci = (int)cl - (g == 0 ? 0 : (g == 1 ? 4 : 13));
         const int kk0 = (ci / ng) * step, ll0 = (ci % ng) * step;  // lattice origin of the cell
         const int per_cell = step * step;
-        const float* b0 = &s_win[wv][0][0];
-        const float* b1 = &s_win[wv][1][0];
-        const float* b2 = &s_win[wv][2][0];
+        const float* b0 = &s_win[ckp][0][0];
+        const float* b1 = &s_win[ckp][1][0];
+        const float* b2 = &s_win[ckp][2][0];
         float di = 0.0f, dx = 0.0f, dy = 0.0f;
-        int dk = 0, dl = 0;  // k outer, l inner (descriptors.rs:108-109)
-        for (int t = 0; t < per_cell; ++t) {
-            const int o = (kk0 + dk) * MLDB_LAT + ll0 + dl;
-            di = di + b0[o];
-            dx = dx + b1[o];
-            dy = dy + b2[o];
-            if (++dl == step) { dl = 0; ++dk; }
+        // k outer, l inner (descriptors.rs:108-109).  A lattice row of the cell is read at once (ten values per plane,
+        // whatever the cell's width: the surplus ones lie in the next row or in the padding and are not added) and then
+        // added in order: one LDS round trip per row instead of one per sample on the serial path; the loop is unrolled
+        // over all ten possible rows (rows beyond the cell re-read its last row and add nothing) so that the reads of
+        // the next rows are in flight while a row is added
+#pragma unroll
+        for (int dk = 0; dk < 10; ++dk) {
+            const int o = (kk0 + min(dk, step - 1)) * MLDB_LAT + ll0;
+            float r0[10], r1[10], r2[10];
+#pragma unroll
+            for (int dl = 0; dl < 10; ++dl) {
+                r0[dl] = b0[o + dl];
+                r1[dl] = b1[o + dl];
+                r2[dl] = b2[o + dl];
+            }
+#pragma unroll
+            for (int dl = 0; dl < 10; ++dl)
+                if (dk < step && dl < step) {
+                    di = di + r0[dl];
+                    dx = dx + r1[dl];
+                    dy = dy + r2[dl];
+                }
         }
         const float ns = (float)per_cell;
-        s_val[wv][0][lane] = di / ns;
-        s_val[wv][1][lane] = dx / ns;
-        s_val[wv][2][lane] = dy / ns;
+        s_val[ckp][0][cl] = di / ns;
+        s_val[ckp][1][cl] = dx / ns;
+        s_val[ckp][2][cl] = dy / ns;
     }
     __syncthreads();
     // bit order: grid 0 (6 pairs), grid 1 (36), grid 2 (120); inside a grid channel-major
@@ -811,7 +875,10 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
     for (int r = 0; r < 8; ++r) {
         const unsigned b = (unsigned)r * 64u + lane;
         bool bit = false;
-        if (b < total) {
+        if (channels == 3) {  // (uniform)
+            const unsigned e = bits3[r];
+            bit = s_val[wv][e >> 10][(e >> 5) & 31u] > s_val[wv][e >> 10][e & 31u];
+        } else if (b < total) {
             unsigned rel, npairs, pbase;
             if (b < seg0) { rel = b; npairs = 6; pbase = 0; }
             else if (b < seg1) { rel = b - seg0; npairs = 36; pbase = 6; }

@@ -129,6 +129,36 @@ public:
                 }
         return best;
     }
+    // The cells a query of (x, y, radius) walks on `level`, computed ahead of the walk (select_keypoints does it for a
+    // block of candidates at a time: straight-line code the compiler vectorises, and the cell heads can be prefetched):
+    // first cell + whether the range spans a second column / row.
+    struct Cells {
+        uint32_t first;
+        uint32_t dx, dy;  // 0 / 1 and 0 / nx
+    };
+    Cells cells(uint32_t level, float x, float y, float radius) const {
+        const G& g = grids_[level];
+        const int x0 = cx(g, x - radius), x1 = cx(g, x + radius), y0 = cy(g, y - radius), y1 = cy(g, y + radius);
+        return Cells{(uint32_t)(g.base + (size_t)y0 * g.nx + x0), (uint32_t)(x1 - x0), (uint32_t)((y1 - y0) * g.nx)};
+    }
+    void prefetch(const Cells& c) const {
+        __builtin_prefetch(head_ + c.first);
+        __builtin_prefetch(head_ + c.first + c.dy);
+    }
+    uint32_t min_slot_in(const Cells& c, float x, float y, float d2max, uint32_t best) const {
+        const int32_t h[4] = {head_[c.first], head_[c.first + c.dx], head_[c.first + c.dy], head_[c.first + c.dy + c.dx]};
+        if ((h[0] & h[1] & h[2] & h[3]) == -1) return best;
+        for (int k = 0; k < 4; ++k) {
+            if (((k & 1) && !c.dx) || ((k & 2) && !c.dy)) continue;  // the range spans one column / row: the cell repeats
+            for (int32_t s = h[k]; s != -1; s = next_[s]) {
+                if ((uint32_t)s >= best) continue;
+                const P p = pos_[s];
+                const float dist = (x - p.x) * (x - p.x) + (y - p.y) * (y - p.y);
+                if (dist <= d2max) best = (uint32_t)s;
+            }
+        }
+        return best;
+    }
     // is there a slot >= from within sqrt(d2max) of (x, y)?
     bool any_slot_from(uint32_t level, float x, float y, float radius, float d2max, uint32_t from) const {
         const G& g = grids_[level];
@@ -209,44 +239,70 @@ void select_keypoints(const Candidate* cands, size_t n_cands, const std::vector<
         lc[l] = LevelConst{(float)(plan[l].esigma * cfg.derivative_factor), powf(2.0f, (float)plan[l].octave)};
 
     // ---- first pass: scale_space_extrema.rs:43-100 ----
-    for (size_t ci = 0; ci < n_cands; ++ci) {
-        const Candidate& c = cands[ci];
-        const LevelPlan& lv = plan[c.level];
-        HostKeypoint kp;
-        kp.ly = c.idx / lv.w;
-        kp.lx = c.idx - kp.ly * lv.w;
-        kp.response = std::fabs(c.v);
-        kp.size = lc[c.level].size;
-        kp.octave = lv.octave;
-        kp.class_id = c.level;
-        kp.x = (float)kp.lx;
-        kp.y = (float)kp.ly;
-        kp.angle = 0.0f;
-        kp.xp = c.xp; kp.xm = c.xm; kp.yp = c.yp; kp.ym = c.ym;
-        const float ratio = lc[c.level].ratio;
-        const float qx = kp.x * ratio, qy = kp.y * ratio;
-        const float size2 = kp.size * kp.size;
-        // first (lowest-index) cache entry on this or the previous level within `size`
-        uint32_t hit = grids.min_slot_within(c.level, qx, qy, kp.size + 1.0f, size2, UINT32_MAX);
-        if (c.level > 0) hit = grids.min_slot_within(c.level - 1, qx, qy, kp.size + 1.0f, size2, hit);
-        bool is_repeated = false, is_extremum = true;
-        if (hit != UINT32_MAX) {
-            if (kp.response > cache[hit].response) is_repeated = true;
-            else is_extremum = false;
+    // Candidates arrive sorted by level.  Per block of a level's candidates, first everything that does not depend on
+    // the cache (coordinates, the grid cells of the two look-ups; their heads are prefetched), then the sequential logic.
+    constexpr size_t kBlock = 64;
+    float bqx[kBlock], bqy[kBlock];
+    uint32_t blx[kBlock], bly[kBlock];
+    SlotGrids::Cells bc0[kBlock], bc1[kBlock];
+    for (size_t c0 = 0; c0 < n_cands;) {
+        const uint32_t level = cands[c0].level;
+        size_t nb = 1;
+        while (nb < kBlock && c0 + nb < n_cands && cands[c0 + nb].level == level) ++nb;
+        const LevelPlan& lv = plan[level];
+        const float size = lc[level].size, ratio = lc[level].ratio, radius = size + 1.0f, size2 = size * size;
+        const uint32_t w = lv.w;
+        const double inv_w = 1.0 / (double)w;
+        for (size_t j = 0; j < nb; ++j) {
+            const uint32_t idx = cands[c0 + j].idx;
+            uint32_t ry = (uint32_t)((double)idx * inv_w);  // idx / w without the integer division: exact after the fix-up
+            if (ry * w > idx) --ry;
+            else if ((ry + 1) * w <= idx) ++ry;
+            bly[j] = ry;
+            blx[j] = idx - ry * w;
+            bqx[j] = (float)blx[j] * ratio;
+            bqy[j] = (float)bly[j] * ratio;
+            bc0[j] = grids.cells(level, bqx[j], bqy[j], radius);
+            grids.prefetch(bc0[j]);
+            if (level > 0) {
+                bc1[j] = grids.cells(level - 1, bqx[j], bqy[j], radius);
+                grids.prefetch(bc1[j]);
+            }
         }
-        if (!is_extremum) continue;
-        // (the border test already ran on the device)
-        kp.x = kp.x * ratio + 0.5f * (ratio - 1.0f);
-        kp.y = kp.y * ratio + 0.5f * (ratio - 1.0f);
-        if (!is_repeated) {
-            cache.push_back(kp);
-            grids.insert(kp.class_id, (int32_t)(cache.size() - 1), kp.x, kp.y);
-        } else {
-            const HostKeypoint old = cache[hit];
-            grids.remove(old.class_id, (int32_t)hit, old.x, old.y);
-            cache[hit] = kp;
-            grids.insert(kp.class_id, (int32_t)hit, kp.x, kp.y);
+        for (size_t j = 0; j < nb; ++j) {
+            const Candidate& c = cands[c0 + j];
+            const float response = std::fabs(c.v);
+            // first (lowest-index) cache entry on this or the previous level within `size`
+            uint32_t hit = grids.min_slot_in(bc0[j], bqx[j], bqy[j], size2, UINT32_MAX);
+            if (level > 0) hit = grids.min_slot_in(bc1[j], bqx[j], bqy[j], size2, hit);
+            bool is_repeated = false;
+            if (hit != UINT32_MAX) {
+                if (response > cache[hit].response) is_repeated = true;
+                else continue;  // not an extremum
+            }
+            // (the border test already ran on the device)
+            HostKeypoint kp;
+            kp.lx = blx[j];
+            kp.ly = bly[j];
+            kp.response = response;
+            kp.size = size;
+            kp.octave = lv.octave;
+            kp.class_id = level;
+            kp.x = (float)kp.lx * ratio + 0.5f * (ratio - 1.0f);
+            kp.y = (float)kp.ly * ratio + 0.5f * (ratio - 1.0f);
+            kp.angle = 0.0f;
+            kp.xp = c.xp; kp.xm = c.xm; kp.yp = c.yp; kp.ym = c.ym;
+            if (!is_repeated) {
+                cache.push_back(kp);
+                grids.insert(kp.class_id, (int32_t)(cache.size() - 1), kp.x, kp.y);
+            } else {
+                const HostKeypoint old = cache[hit];
+                grids.remove(old.class_id, (int32_t)hit, old.x, old.y);
+                cache[hit] = kp;
+                grids.insert(kp.class_id, (int32_t)hit, kp.x, kp.y);
+            }
         }
+        c0 += nb;
     }
 
     // ---- second pass: drop points repeated on the next level LATER in the cache (:109-129), and on the survivors

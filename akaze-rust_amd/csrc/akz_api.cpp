@@ -588,7 +588,12 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
     const size_t ks = gaussian_kernel_size((float)gscale);
     const bool stream = c->prep_mode != 0 && gscale > 0.0 && launch::contrast_stream_supported(w, h, (uint32_t)ks, (uint32_t)nbins) &&
                         (c->prep_mode == 1 || (uint64_t)w * h * n >= c->stream_min_px);
-    if (stream) {
+    const bool march = gscale > 0.0 && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= kBigLaunchPx())) &&
+                       launch::contrast_march_supported(w, h, (uint32_t)ks, (uint32_t)nbins);
+    if (march) {
+        const std::vector<float> g3 = gaussian_kernel((float)gscale, ks);
+        launch::contrast_march(c->stream, d_in, w, h, n, g3.data(), d_hmax, (uint32_t)nbins, d_hist, d_thr);
+    } else if (stream) {
         // both passes recompute blur + Scharr from the input in registers: no blurred plane is written or re-read
         const std::vector<float> g3 = gaussian_kernel((float)gscale, ks);
         launch::contrast_stream(c->stream, d_in, w, h, n, g3.data(), d_hmax, (uint32_t)nbins, d_hist, d_thr);

@@ -167,6 +167,11 @@ uint32_t march_band_rows(int kind, uint32_t w, uint32_t h, uint32_t n, int S, in
 bool blur5_march_supported(uint32_t w, uint32_t h, uint32_t ntaps);  // akz_march.hip: the same blur as a column march
 void blur5_march_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
 void blur5_march_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k);
+// the same two passes as column marches (akz_march.hip: two columns per thread, bound by the plane read, not by arithmetic)
+bool contrast_march_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins);
+void contrast_march(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
+                    unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist, double* d_thr);
+void contrast_thresholds(hipStream_t s, const unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t n, double* d_thr);
 bool contrast_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins);
 void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
                      unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist, double* d_thr);

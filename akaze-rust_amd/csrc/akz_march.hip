@@ -680,6 +680,184 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The two passes of compute_contrast_factor (contrast_factor.rs:18-71) as marches: the front of k_level_march --
+// gaussian_blur(in, 1.0), the scale-1 Scharr pair -- with nothing stored; over the interior pixels (rows 1..h-2,
+// columns 1..w-2, :33-35) MODE 1 takes the maximum of lx^2 + ly^2 in f64 (sqrt is monotone and correctly rounded:
+// max sqrt(s) == sqrt(max s)), MODE 2 the histogram of floor(nbins * (sqrt(s) / hmax)) (:49-57).  The bin of a pixel
+// is a non-decreasing function of s: a guess from the hardware's approximate square root, off by one bin at most, is
+// settled by the exact thresholds of the two neighbouring bins (k_contrast_thresholds, akz_stream.hip) instead of a
+// correctly rounded f64 square root and division per pixel.  Two columns per thread, packed arithmetic, one LDS
+// exchange per row.  Both passes stay bound by instruction issue (about 50 instructions per pixel, a third of them
+// f64): 82 + 125 us per 32 x 1080p against 111 + 135 for k_prep_stream<false, 1 / 2>.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ContrastMarchArgs {
+    unsigned long long* hmax_bits;  // per image, non-negative f64 as its bit pattern (orders like the value)
+    unsigned* hist;                 // per image, nbins counters
+    unsigned nbins;
+    const double* thr;              // MODE 2: per image, nbins + 1 bin thresholds on lx^2 + ly^2
+};
+constexpr int CM_COPIES = 2;  // sub-histograms per wave (lanes spread over them) against same-bin conflicts
+template <int MODE, bool ODDW>
+__global__ void __launch_bounds__(MT, 8)
+k_contrast_march(const float* __restrict__ in_plane, int w, int h, MarchGrid g, float g0, float g1, float g2, float kn,
+                 float kwn, ContrastMarchArgs ca) {
+    constexpr int PF = 2;
+    __shared__ __attribute__((aligned(16))) float s_row[2][2][ROW];  // per iteration: the input row, Lsmooth row v-2
+    extern __shared__ __attribute__((aligned(16))) unsigned s_chist[];  // MODE 2: [wave][copy][bin], then [wave][thresholds]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = g.nbands * g.nstrips;
+    const int cell = march_cell();
+    if (cell >= g.total) return;
+    const int img = __builtin_amdgcn_readfirstlane(cell / per);
+    const int rem = cell - img * per;
+    const int band = __builtin_amdgcn_readfirstlane(rem / g.nstrips), strip = rem - band * g.nstrips;
+    int cs, ce;
+    level_band_rows(g, band, h, &cs, &ce);
+    if (cs >= ce) return;
+    const int lt0 = cs == 1 ? 0 : cs, lt1 = ce == h - 1 ? h : ce;
+
+    const int X0 = strip * USE - HALO;
+    const int p0 = (2 * tid + HALO) & (MW - 1);
+    const bool inner = p0 >= HALO && p0 < MW - HALO;
+    const Cols C = make_cols(X0 + p0, inner, w);
+    const int i0 = PAD + clampi(clampi(C.x0, 1, w - 2) - X0, 0, MW - 1) - 1;
+    const int i1 = PAD + clampi(clampi(C.x0 + 1, 1, w - 2) - X0, 0, MW - 1) - 1;
+    const int wi = PAD + p0;
+    const bool edge_h = __ballot(i0 != wi - 1 || i1 != wi) != 0ull;
+    // the thread's columns that are interior pixels it owns
+    const bool own0 = inner && C.x0 >= 1 && C.x0 <= w - 2, own1 = inner && C.x0 + 1 >= 1 && C.x0 + 1 <= w - 2;
+
+    const __amdgpu_buffer_rsrc_t in = plane_rsrc(in_plane + (size_t)img * (size_t)w * (size_t)h, w, h);
+    double gmax = 0.0, bin_scale = 0.0;
+    unsigned* myhist = nullptr;
+    const double* mythr = nullptr;
+    if (MODE == 2) {
+        const double hmax = __longlong_as_double((long long)ca.hmax_bits[img]);
+        unsigned* wh = s_chist + (size_t)wv * CM_COPIES * ca.nbins;
+        for (unsigned b = (unsigned)lane; b < CM_COPIES * ca.nbins; b += 64u) wh[b] = 0u;  // wave-private: no barrier needed
+        myhist = wh + (lane & (CM_COPIES - 1)) * ca.nbins;
+        // the image's bin thresholds, one copy per workgroup (behind the histograms: an even number of words, so 8-byte
+        // aligned for every bin count); the first barrier of the row loop orders these writes before the first read
+        double* wt = reinterpret_cast<double*>(s_chist + (size_t)(MT / 64) * CM_COPIES * ca.nbins);
+        for (unsigned b = (unsigned)tid; b <= ca.nbins; b += MT) wt[b] = ca.thr[(size_t)img * (ca.nbins + 1) + b];
+        mythr = wt;
+        bin_scale = (double)ca.nbins * (1.0 / hmax);
+    }
+
+    const int v0 = lt0 - 2;
+    const int T = (lt1 - lt0) + 6;
+    auto feed = [&](int t) -> f2 {
+        return load_pair<ODDW>(in, (unsigned)clampi(v0 + min(t, T - 1), 0, h - 1) * ((unsigned)w * 4u), C);
+    };
+    f2 q[4];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) q[i] = feed(i);
+    const f2 zero = {0.0f, 0.0f};
+    f2 GH[4], HM[4], HO[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GH[i] = HM[i] = HO[i] = zero;
+    f2 ls_c = zero, gh_c = zero;  // Lsmooth row v-2, H gauss of row v-1 (the previous iteration's results)
+
+    auto take = [&](double ss) {
+        if (MODE == 1) {
+            if (ss > gmax) gmax = ss;
+        } else if (ss != 0.0) {  // sqrt(ss) != 0.0 (contrast_factor.rs:51)
+            const double ga = __builtin_amdgcn_sqrt(ss) * bin_scale;
+            const unsigned gb = min(ga > 0.0 ? (unsigned)ga : 0u, ca.nbins - 1u);  // NaN -> 0
+            unsigned b = gb;
+            if (ss < mythr[gb]) b = gb - 1u;
+            else if (ss >= mythr[gb + 1u]) b = gb + 1u;
+            atomicAdd(&myhist[b], 1u);
+        }
+    };
+    auto rows = [&](auto mid_tag) {
+    constexpr bool MID = decltype(mid_tag)::value;
+    for (int t0 = 0; t0 < T; t0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + k;
+            const int v = v0 + t;
+            q[(k + PF) & 3] = feed(t + PF);
+            float* const buf = &s_row[t & 1][0][0];
+            const f2 lp = fix_pair(q[k & 3], C);
+            *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = lp;
+            *reinterpret_cast<f2*>(buf + 1 * ROW + wi) = ls_c;
+            __syncthreads();
+            // ---- gaussian_blur(in, 1.0): H pass of row v, V pass -> Lsmooth row u = v-1 ----
+            f2 gh = gh_c;  // below row h-2 the filled rows repeat it
+            if (MID || v <= h - 2) {
+                f2 a, b, c;
+                if (!rare(edge_h)) {
+                    a = lds2(buf + wi - 1); b = lp; c = lds2(buf + wi + 1);
+                } else {
+                    const float* r0 = buf + i0;
+                    const float* r1 = buf + i1;
+                    a = f2{r0[0], r1[0]}; b = f2{r0[1], r1[1]}; c = f2{r0[2], r1[2]};
+                }
+                gh = tap3(a, b, c, g0, g1, g2);
+            }
+            gh_c = gh;
+            GH[k & 3] = gh;
+            if (!MID && rare(v == 1)) GH[(k - 1) & 3] = gh;  // filled row 0 is row 1
+            const int u = v - 1;
+            f2 ls_n = ls_c;
+            if (MID || u <= h - 2) ls_n = tap3(GH[(k - 2) & 3], GH[(k - 1) & 3], GH[k & 3], g0, g1, g2);
+            // ---- Scharr pair at scale 1 of Lsmooth row u-1 (in LDS), V pass -> lx, ly of row c = v-3 ----
+            {
+                f2 a, b, c;
+                if (!rare(edge_h)) {
+                    a = lds2(buf + ROW + wi - 1); b = ls_c; c = lds2(buf + ROW + wi + 1);
+                } else {
+                    const float* r0 = buf + ROW + i0;
+                    const float* r1 = buf + ROW + i1;
+                    a = f2{r0[0], r1[0]}; b = f2{r0[1], r1[1]}; c = f2{r0[2], r1[2]};
+                }
+                HM[k & 3] = tap_main(a, b, c, kn, kwn);
+                HO[k & 3] = tap_off(a, c);
+            }
+            if (!MID && rare(u - 1 == 1)) {  // filled row 0 is row 1
+                HM[(k - 1) & 3] = HM[k & 3];
+                HO[(k - 1) & 3] = HO[k & 3];
+            }
+            const int c = v - 3;
+            if (c >= cs && c < ce) {  // workgroup-uniform: the band's interior rows
+                const f2 lx1 = tap_off(HM[(k - 2) & 3], HM[k & 3]);
+                const f2 ly1 = tap_main(HO[(k - 2) & 3], HO[(k - 1) & 3], HO[k & 3], kn, kwn);
+                if (own0) {
+                    const double dx = (double)lx1.x, dy = (double)ly1.x;
+                    take(dx * dx + dy * dy);
+                }
+                if (own1) {
+                    const double dx = (double)lx1.y, dy = (double)ly1.y;
+                    take(dx * dx + dy * dy);
+                }
+            }
+            ls_c = ls_n;
+        }
+    }
+    };
+    const int v_last = v0 + ((T + 3) & ~3) - 1;
+    if (v0 >= 5 && v_last <= h - 2) rows(std::true_type{});
+    else rows(std::false_type{});
+
+    if (MODE == 1) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(sqrt(gmax));
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(bits, o, 64);
+            bits = other > bits ? other : bits;
+        }
+        if (lane == 0 && bits != 0ull) atomicMax(ca.hmax_bits + img, bits);
+    } else {
+        const unsigned* wh = s_chist + (size_t)wv * CM_COPIES * ca.nbins;
+        for (unsigned b = (unsigned)lane; b < ca.nbins; b += 64u) {
+            unsigned v = 0;
+            for (int cpy = 0; cpy < CM_COPIES; ++cpy) v += wh[cpy * ca.nbins + b];
+            if (v) atomicAdd(&ca.hist[(size_t)img * ca.nbins + b], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // gaussian_blur with a dense 5-tap kernel as a march (types/image.rs:374-380: V(H(in)), fill_border after each pass):
 // the level-0 blur of the pyramid (sigma 1.6) for large batches.  T = uint8_t folds in create_unit_float_image
 // (types/image.rs:136): the 256 possible values of `f32::from(v) * 1f32 / 255f32` are tabulated once per workgroup
@@ -784,7 +962,7 @@ k_blur5_march(const T* __restrict__ in, float* __restrict__ out, int w, int h, M
     }
 }
 
-inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid) {
+inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid, int fill_wg = 3, int min_band_rows = 64) {
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -792,7 +970,7 @@ inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    constexpr int fill = 3, min_rows = 64;  // (swept in round 2: flat within +-1.5 % around these)
+    const int fill = fill_wg, min_rows = min_band_rows;  // (level kernels: 3 / 64, swept in round 2: flat within +-1.5 % around these)
     MarchGrid g;
     g.nstrips = (int)((w + USE - 1) / USE);
     const int rows = (int)h - 2;
@@ -936,6 +1114,31 @@ void blur5_march_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, ui
 }
 void blur5_march_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const float* k) {
     blur5_march_t<float>(s, in, out, w, h, n, k);
+}
+
+// compute_contrast_factor's two passes over gaussian_blur(in, 1.0 with the 3 taps g3) as marches (d_hmax_bits / d_hist
+// zeroed by the caller; d_thr: n x (nbins + 1) doubles, filled between the passes).  nbins <= 640.
+bool contrast_march_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins) {
+    return ntaps == 3 && nbins >= 1 && nbins <= 640 && level_march_supported(w, h);
+}
+void contrast_march(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
+                    unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist, double* d_thr) {
+    const Taps m = taps_scharr_main(1);
+    const ContrastMarchArgs ca{d_hmax_bits, d_hist, nbins, d_thr};
+    dim3 gr;
+    // light kernels (52-59 registers, 8 to 20 KB of LDS): eight workgroups per compute unit hide the row latency that
+    // three leave exposed (maximum pass 103 -> 82 us per 32 x 1080p); a band warms up over six rows only
+    const MarchGrid mg = plan_level_march(w, h, n, &gr, 8, 32);
+    if (w & 1u)
+        hipLaunchKernelGGL((k_contrast_march<1, true>), gr, dim3(MT), 0, s, in, (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], ca);
+    else
+        hipLaunchKernelGGL((k_contrast_march<1, false>), gr, dim3(MT), 0, s, in, (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], ca);
+    contrast_thresholds(s, d_hmax_bits, nbins, n, d_thr);
+    const size_t lds = ((size_t)(MT / 64) * CM_COPIES * nbins) * sizeof(unsigned) + (size_t)(nbins + 1) * sizeof(double);
+    if (w & 1u)
+        hipLaunchKernelGGL((k_contrast_march<2, true>), gr, dim3(MT), lds, s, in, (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], ca);
+    else
+        hipLaunchKernelGGL((k_contrast_march<2, false>), gr, dim3(MT), lds, s, in, (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], ca);
 }
 
 // Test hook (CPU): the bands the planners cut an n-image batch of w x h into -- kind 0: detector / blur march with

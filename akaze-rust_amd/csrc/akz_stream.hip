@@ -615,6 +615,9 @@ void prep_stream(hipStream_t s, const float* prev, bool half, float* lt_out, flo
 bool contrast_stream_supported(uint32_t w, uint32_t h, uint32_t ntaps, uint32_t nbins) {
     return ntaps == 3 && nbins <= 640 && prep_stream_supported(w, h);  // 61 KB of LDS at 640 bins
 }
+void contrast_thresholds(hipStream_t s, const unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t n, double* d_thr) {
+    hipLaunchKernelGGL(k_contrast_thresholds, dim3(n), dim3(320), 0, s, d_hmax_bits, nbins, d_thr);
+}
 void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint32_t n, const float* g3,
                      unsigned long long* d_hmax_bits, uint32_t nbins, uint32_t* d_hist, double* d_thr) {
     const Taps m = taps_scharr_main(1);
@@ -623,7 +626,7 @@ void contrast_stream(hipStream_t s, const float* in, uint32_t w, uint32_t h, uin
     const StreamGrid g1 = plan_stream(k_prep_stream<false, 1>, w, h, n, 1, 1, prep_min_rows(), &grid);
     hipLaunchKernelGGL((k_prep_stream<false, 1>), grid, dim3(SNT), 0, s, in, nullptr, nullptr, nullptr, (int)w, (int)h,
                        (int)w, (int)h, g1, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], nullptr, 0u, ca);
-    hipLaunchKernelGGL(k_contrast_thresholds, dim3(n), dim3(320), 0, s, d_hmax_bits, nbins, d_thr);
+    contrast_thresholds(s, d_hmax_bits, nbins, n, d_thr);
     const StreamGrid g2 = plan_stream(k_prep_stream<false, 2>, w, h, n, 1, 1, prep_min_rows(), &grid);
     const size_t lds = ((size_t)(SNT / WAVE) * CHIST_COPIES * nbins) * sizeof(unsigned) +
                        (size_t)(SNT / WAVE) * (nbins + 1) * sizeof(double);

@@ -161,6 +161,26 @@ def test_stream_contrast_factor(sctx, ref, shape):
     assert float(sctx.contrast_factor(torch.from_numpy(flat).cuda()).cpu().numpy()[0]) == ref.contrast_factor(flat)
 
 
+@pytest.mark.parametrize("shape", [(700, 520), (200, 480), (333, 961), (129, 1440), (16, 16), (65, 481)])
+def test_contrast_march(amd, ref, shape):
+    """k_contrast_march (the two contrast passes as column marches; prep mode 3 takes them for any size): images cut into
+    several bands (band seams inside the image), widths at and around the 480-column strips (one strip exactly, strips
+    with a single owned column, three strips), odd widths (dword accesses), the smallest supported image; a batch whose
+    images have different maxima, several bin counts and percentiles; a constant image (no gradient: 0.03)."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    c.set_prep_mode(3)
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    imgs = np.stack([ref.gaussian_blur(rng.random(shape, dtype=np.float32) * np.float32(s), 1.6) for s in (1.0, 0.3, 0.05)])
+    for nbins, pct in ((300, 0.7), (64, 0.5), (640, 0.9), (301, 0.7), (1, 0.7)):
+        got = c.contrast_factor(torch.from_numpy(imgs).cuda(), pct, 1.0, nbins).cpu().numpy()
+        for i in range(3):
+            assert float(got[i]) == ref.contrast_factor(imgs[i], pct, 1.0, nbins), (nbins, pct, i)
+    flat = np.full(shape, 0.25, np.float32)
+    assert float(c.contrast_factor(torch.from_numpy(flat).cuda()).cpu().numpy()[0]) == ref.contrast_factor(flat)
+    c.close()
+
+
 @pytest.mark.parametrize("shape", [(96, 132), (131, 248), (77, 516), (40, 1000), (300, 517)])
 def test_stream_blur5(sctx, ref, shape):
     """The level-0 blur (sigma 1.6 -> 5 taps) through the streaming kernel: f32 input for any width, u8 input (with the

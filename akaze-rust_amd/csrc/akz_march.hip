@@ -1142,11 +1142,14 @@ void contrast_march(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint
         hipLaunchKernelGGL((k_contrast_march<2, false>), gr, dim3(MT), lds, s, in, (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], ca);
 }
 
+// (half-resolution launches of a 32-frame batch: with 64-row bands there are 512 workgroups for 768 places; 40-row bands
+// fill them, 101 -> 94 us per launch)
+static int level_min_band_rows(uint32_t w, uint32_t h, uint32_t n) { return (uint64_t)w * h * n < (48u << 20) ? 40 : 64; }
 // Test hook (CPU): the bands the planners cut an n-image batch of w x h into -- kind 0: detector / blur march with
 // kernel half width S, kind 1: level march.  Writes up to cap [cs, ce) pairs, returns the number of bands.
 uint32_t march_band_rows(int kind, uint32_t w, uint32_t h, uint32_t n, int S, int32_t* cs_ce, uint32_t cap) {
     dim3 gr;
-    const MarchGrid g = kind == 1 ? plan_level_march(w, h, n, &gr) : plan_march(w, h, n, S, &gr);
+    const MarchGrid g = kind == 1 ? plan_level_march(w, h, n, &gr, 3, level_min_band_rows(w, h, n)) : plan_march(w, h, n, S, &gr);
     for (int b = 0; b < g.nbands && (uint32_t)b < cap; ++b) {
         int cs, ce;
         if (kind == 1) level_band_rows(g, b, (int)h, &cs, &ce);
@@ -1186,7 +1189,7 @@ void level_march(hipStream_t s, const float* prev, float* lsmooth, float* lflow,
     LevelTaus ht;
     for (uint32_t i = 0; i < 4; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
     dim3 gr;
-    const MarchGrid mg = plan_level_march(w, h, n, &gr);
+    const MarchGrid mg = plan_level_march(w, h, n, &gr, 3, level_min_band_rows(w, h, n));
     switch (n_steps) {
         AKZ_LEVEL(1) AKZ_LEVEL(2) AKZ_LEVEL(3) AKZ_LEVEL(4)
         default: break;

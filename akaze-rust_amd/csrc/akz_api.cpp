@@ -1158,7 +1158,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         // Large launches of levels that diffuse: preparation and the first (up to four) diffusion steps in ONE launch of
         // k_level_march (akz_march.hip) — Lt is read once for both, 4 B read + 12 (+4) B written per pixel instead of
         // 12 + 12 (+4); a new octave's 2x2 mean is materialised first.  Remaining steps follow in k_fed_own launches.
-        const uint64_t level_min_px = kBigLaunchPx();
+        // (from 4 Mpx per launch -- the third octave of a 32-frame 1080p batch -- on: one launch less per level in the
+        // coarse chain that runs next to the fine detectors, +1.0 % throughput, measured 4 x 80 steps each way)
+        const uint64_t level_min_px = 4000000;
         const bool fuse_level = n_tau >= 1 && c->fed_mode == 2 && launch::level_march_supported(lv.w, lv.h) &&
                                 (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)lv.w * lv.h * n >= level_min_px));
         if (fuse_level) {

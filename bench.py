@@ -677,7 +677,7 @@ def main_rank(args):
     roof_fed = roof(A.lib().akz_fed_kernel_name().decode(), prof["fed"], prof["fed_launches"],
                     FED_BYTES_PER_PX_STEP * prof["fed_px_steps"] + 12.0 * prof["fused_px"],
                     "all diffusion launches of the timed steps (levels 1..15, 1920x1080 down to 240x135): k_level_march "
-                    "(level preparation + the level's first <= 4 FED steps in one launch, levels of 8 Mpx and more) and "
+                    "(level preparation + the level's first <= 4 FED steps in one launch, levels of 4 Mpx and more) and "
                     "k_fed_own (<= 8 steps per launch); 12 B per pixel-step ALGORITHMIC plus 12 B per pixel for a "
                     "preparation that runs inside the launch — steps are fused, so frac can exceed 1; traffic_frac is "
                     "the DRAM figure")

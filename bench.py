@@ -272,12 +272,12 @@ def launch_ranks(args, argv):
     if failed is not None:
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with status {failed[1]}; the other ranks were stopped\n")
         return 1
-    sys.stdout.write(out0 or "")
-    sys.stdout.flush()
     line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
     if not line:
         sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
         return 1
+    sys.stdout.write(line[-1] + "\n")
+    sys.stdout.flush()
     return 0
 
 
@@ -335,6 +335,11 @@ def main_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     placement = place_rank(args)  # before torch / HIP exist in this process
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL writes a version banner to stdout
+    # when a communicator is created) goes to stderr instead
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     dev_index = 0 if args.share_gpu else local_rank
 
     import numpy as np
@@ -643,7 +648,7 @@ def main_rank(args):
                 "vs_baseline": None, "dtype": "f32", "data": "stub", "stub": True,
                 "config": {"workload": "stub", "frames_per_gpu": F, "exchange": "gloo all-gather of fake rows",
                            "exchange_ms_per_step": round(xch["host_ms"] / max(1, args.steps), 3),
-                           "per_rank_ms_per_step": [round(s / max(1, args.steps) * 1e3, 3) for s in per_rank_s]}}), flush=True)
+                           "per_rank_ms_per_step": [round(s / max(1, args.steps) * 1e3, 3) for s in per_rank_s]}}), file=json_out, flush=True)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -1174,7 +1179,7 @@ def main_rank(args):
             "stream_5x5_all_pairs": c5_leg,
             "match": match_leg,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()  # rank 0 may still be in its untimed extra legs: all ranks leave together
         if xch["comm"] is not None:

@@ -1624,7 +1624,14 @@ static void finisher_loop(akz_ctx* c, Finisher* f) {
             f->queue.erase(f->queue.begin());
         }
         akz_result* res = nullptr;
-        const int rc = extract_finish_body(j, &res);
+        int rc;
+        try {
+            rc = extract_finish_body(j, &res);
+        } catch (const std::exception& e) {  // (allocation failure on this thread must not take the process down)
+            set_error(std::string("extract_finish: ") + e.what());
+            rc = AKZ_ERR_NO_MEMORY;
+            res = nullptr;
+        }
         std::string err = rc != AKZ_OK ? get_error() : std::string();
         {
             std::lock_guard<std::mutex> lk(f->m);

@@ -75,3 +75,14 @@ def test_default_mode_1080p_batch_all_planes(ctx, amd, ref):
     res = ctx.extract_features(torch.from_numpy(frames).cuda())
     assert_same_result(res, ref.extract(frames[2], threads=16), img=2)
     assert_same_result(res, ref.extract(frames[0], threads=16), planes=False, img=0)
+
+
+def test_default_mode_odd_batch_all_planes(ctx, amd, ref):
+    """The default mode on a batch of odd-sized frames above the 8 Mpx threshold (6 x 1501 x 999: dword accesses in
+    every march kernel, four strips with a narrow last one, octave sizes 750 x 499, 375 x 249, 187 x 124): every plane of
+    one frame, keypoints and descriptors of all."""
+    import torch
+    frames = np.stack([amd.synth_frame(1501, 999, 80 + i) for i in range(6)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda())
+    for i in range(6):
+        assert_same_result(res, ref.extract(frames[i], threads=16), planes=(i == 3), img=i)

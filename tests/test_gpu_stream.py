@@ -30,6 +30,18 @@ def test_stream_extract_matches_oracle_all_planes(sctx, amd, ref, w, h, idx):
     assert_same_result(sctx.extract_features(frame), ref.extract(frame))
 
 
+def test_random_shapes_all_planes(sctx, amd, ref):
+    """A seeded sweep over image shapes (widths around the 480-column strips and the 8 x 8 patches, heights that put band
+    seams at arbitrary rows, odd sizes, flat and tall images): every plane, keypoint and descriptor byte against the
+    oracle through the forced kernels (march / level march / contrast march / resident, or tiled + streaming)."""
+    rng = np.random.default_rng(20261004)
+    shapes = [(int(rng.integers(96, 1100)), int(rng.integers(64, 700))) for _ in range(8)]
+    shapes += [(479, 97), (481, 133), (961, 66), (1441, 81), (130, 641)]
+    for k, (w, h) in enumerate(shapes):
+        frame = amd.synth_frame(w, h, 100 + k)
+        assert_same_result(sctx.extract_features(frame), ref.extract(frame, threads=8)), (w, h)
+
+
 def test_stream_batch_and_nondefault_config(sctx, amd, ref):
     import torch
     frames = np.stack([amd.synth_frame(486, 270, i) for i in range(3)])

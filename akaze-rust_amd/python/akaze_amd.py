@@ -23,6 +23,7 @@ LIB_PATH = os.environ.get("AKAZE_HIP_LIB") or os.path.join(_PKG, "libakaze_hip.s
 AKZ_KEEP_ALL_PLANES = 1
 AKZ_NO_HOST_DESCRIPTORS = 2
 AKZ_NO_DETECT = 4
+AKZ_INPUT_READY = 8
 
 PLANES = ["Lt", "Lsmooth", "Lx", "Ly", "Lxx", "Lyy", "Lxy", "Lflow", "Lstep", "Ldet"]
 
@@ -453,12 +454,15 @@ class Context:
                                              C.byref(res)))
         return ExtractResult(self, res)
 
-    def extract_begin(self, frames, options=None, keep_all_planes=True, host_descriptors=True):
+    def extract_begin(self, frames, options=None, keep_all_planes=True, host_descriptors=True, input_ready=False):
         """First half of extract_features on a torch CUDA tensor [N, H, W] (uint8 or float32): enqueue the
-        GPU work up to the extrema candidates and return a Job without synchronising."""
+        GPU work up to the extrema candidates and return a Job without synchronising.  input_ready=True (AKZ_INPUT_READY):
+        the frames are complete in device memory now (nothing pending on any stream writes them): the first stages of a
+        large batch then run ahead, under the kernels of the batch begun before."""
         import torch
         options = options or Config()
-        flags = (AKZ_KEEP_ALL_PLANES if keep_all_planes else 0) | (0 if host_descriptors else AKZ_NO_HOST_DESCRIPTORS)
+        flags = (AKZ_KEEP_ALL_PLANES if keep_all_planes else 0) | (0 if host_descriptors else AKZ_NO_HOST_DESCRIPTORS) | \
+                (AKZ_INPUT_READY if input_ready else 0)
         t = frames
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
             raise ValueError("device images must be contiguous torch CUDA tensors")

@@ -9,7 +9,8 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; the parent never touches a GPU), forw
 exits non-zero if any rank does.  Under torchrun (WORLD_SIZE set) it is one rank; --gpus must equal WORLD_SIZE.
 
 A "step" is one extract_features pass over this rank's shard of F frames that are already resident in HBM
-(uploaded before the timed region).  For N > 1 the step also runs the path's one exchange: an RCCL all-gather
+(uploaded and synchronised before the timed region; the calls say so with AKZ_INPUT_READY, which lets a batch's first
+two stages run under the kernels of the batch before -- --no-input-ready drops the flag).  For N > 1 the step also runs the path's one exchange: an RCCL all-gather
 of the shard's descriptor rows (what a following brute-force match needs), enqueued without stalling the
 extraction pipeline and retired one step later (the last one inside the timed region); extraction itself has
 no collective.  Rank 0 prints ONE JSON line.
@@ -120,6 +121,8 @@ def parse_args(argv=None):
                          "kernels of the next")
     ap.add_argument("--sync", action="store_true",
                     help="finish every batch right after beginning it (no software pipelining): clean per-stage times")
+    ap.add_argument("--no-input-ready", action="store_true",
+                    help="do not pass AKZ_INPUT_READY for the resident frames (the first stages of a batch then wait for the batch before)")
     ap.add_argument("--no-profile", action="store_true", help="do not record stage events in the timed region")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the descriptor exchange (RCCL) even with one rank (self-test of the N > 1 path)")
@@ -310,7 +313,7 @@ class _StubContext:
     def __init__(self, rank):
         self.rank = rank
 
-    def extract_begin(self, batch, cfg, keep_all_planes=True):
+    def extract_begin(self, batch, cfg, keep_all_planes=True, input_ready=False):
         return _StubJob([100 + 7 * self.rank + i for i in range(int(batch.shape[0]))])
 
     def set_eager_finish(self, *_):
@@ -568,7 +571,8 @@ def main_rank(args):
                 if frame_src["host"]:
                     job = ctx.extract_begin_host(h_batches[bi], cfg, keep_all_planes=not args.lean)
                 else:
-                    job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean)
+                    # (the frames were uploaded and synchronised before the first step: AKZ_INPUT_READY holds)
+                    job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean, input_ready=not args.no_input_ready)
                 host_ms["begin"] += (time.perf_counter() - tb) * 1e3
                 host_ms["calls"] += 1
                 if args.sync:
@@ -1147,6 +1151,7 @@ def main_rank(args):
                        "pipelining": "begin(batch j+1) before finish(batch j) on one stream, across steps",
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "input_ready_flag": not args.no_input_ready,
                        "exchange_ranks_seen": xch["ranks_seen"],
                        "placement": placement or None,
                        "share_gpu": bool(args.share_gpu),

@@ -93,7 +93,14 @@ enum {
     AKZ_NO_HOST_DESCRIPTORS = 1u << 1,
     /* akz_extract_from_planes only: upload the planes, skip the extrema pass (keypoints come from the caller through
        akz_result_describe_keypoints) */
-    AKZ_NO_DETECT = 1u << 2
+    AKZ_NO_DETECT = 1u << 2,
+    /* akz_extract_begin_device_*: the caller promises that the frames are COMPLETE in device memory when the call is made
+       -- nothing still pending on the context's stream (or on any other) writes them -- and stay untouched until the job
+       is finished.  The first stages of a large batch (level-0 blur, contrast factor) then do not wait for the work the
+       context's stream still holds for the batch before and run under that batch's kernels.  Without the flag the
+       library has to assume that the frames are produced by whatever the caller enqueued on the stream before the call.
+       (akz_extract_begin_host_* knows when its own upload is complete and always runs ahead.)  Results are identical. */
+    AKZ_INPUT_READY = 1u << 3
 };
 
 typedef struct akz_ctx akz_ctx;

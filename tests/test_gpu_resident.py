@@ -86,3 +86,32 @@ def test_default_mode_odd_batch_all_planes(ctx, amd, ref):
     res = ctx.extract_features(torch.from_numpy(frames).cuda())
     for i in range(6):
         assert_same_result(res, ref.extract(frames[i], threads=16), planes=(i == 3), img=i)
+
+
+def test_input_ready_batches_run_ahead(ctx, amd, ref):
+    """AKZ_INPUT_READY: the level-0 blur and the contrast factor of a large batch run on their own stream, under the
+    kernels of the batch begun before (three different 5-frame 1080p batches, two in flight; the contrast scratch of the
+    context is shared by them).  Identical to the same batches without the flag; every plane of one frame and the
+    keypoints / descriptors of others against the oracle.  Host frames (the library's own upload) take the same path."""
+    import torch
+    batches = [np.stack([amd.synth_frame(1920, 1080, 200 + 5 * b + i) for i in range(5)]) for b in range(3)]
+    dev = [torch.from_numpy(b).cuda() for b in batches]
+    torch.cuda.synchronize()
+    jobs = [ctx.extract_begin(dev[0], input_ready=True), ctx.extract_begin(dev[1], input_ready=True)]
+    res = [jobs[0].finish()]
+    jobs.append(ctx.extract_begin(dev[2], input_ready=True))
+    res += [jobs[1].finish(), jobs[2].finish()]
+    plain = [ctx.extract_begin(d).finish() for d in dev]
+    host = [ctx.extract_begin_host(torch.from_numpy(b).pin_memory()) for b in batches[:2]]
+    host = [j.finish() for j in host]
+    for b in range(3):
+        for i in range(5):
+            assert res[b].keypoints(i).tobytes() == plain[b].keypoints(i).tobytes(), (b, i)
+            assert res[b].descriptors(i).tobytes() == plain[b].descriptors(i).tobytes(), (b, i)
+            if b < 2:
+                assert host[b].keypoints(i).tobytes() == plain[b].keypoints(i).tobytes(), (b, i)
+                assert host[b].descriptors(i).tobytes() == plain[b].descriptors(i).tobytes(), (b, i)
+        assert float(res[b].contrast(4)) == float(plain[b].contrast(4))
+    assert_same_result(res[1], ref.extract(batches[1][2], threads=16), img=2)
+    assert_same_result(res[2], ref.extract(batches[2][0], threads=16), planes=False, img=0)
+    assert_same_result(host[1], ref.extract(batches[1][4], threads=16), planes=False, img=4)

@@ -1046,7 +1046,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     AKZ_TRY(ensure(c, c->count_slot[slot], 256));
     uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
     Candidate* d_cand = (Candidate*)c->cand_slot[slot].p;
-    AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
     // derivatives, Ldet and extrema candidates of level l in one or two launches on stream `st_`; false when the
     // level's kernel size has no fused form (then the multi-kernel fallback runs on the main stream at the end)
     auto detector_one_pass = [&](size_t l, hipStream_t st_) -> bool {
@@ -1096,6 +1095,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         c->stream = c->pre;
         early = true;
     }
+    // the job's candidate counter is cleared on the stream of its first stage (every detector launch comes behind that)
+    AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
     {
         StageTimer st(c, AKZ_ST_BLUR0);
         AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));
@@ -1158,6 +1159,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     for (size_t i = lo; i < hi; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
+
         if (i == res_first) {
             std::vector<launch::ResidentLevel> rl;
             std::vector<std::vector<float>> ht(L);

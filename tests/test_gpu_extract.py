@@ -246,6 +246,17 @@ def test_eager_finish_on_lanes(amd, ref):
     unfinished.abandon()
 
 
+def test_eager_finish_soak_short():
+    """tools/eager_soak.py for a few seconds: lone frames of six sizes over 2-4 lanes with eager finish, random abandons,
+    late frees, lane re-sizing; every result against the synchronous extraction of the same frame (a 90 s run checks
+    ~48 000 frames)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "eager_soak.py"), "4"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "no mismatch" in p.stdout
+
+
 def test_baseline_c2_1080p_frame(ctx, amd, ref):
     """BASELINE.json configs[1]: one 1920x1080 synthetic frame, 4 octaves x 4 sublevels."""
     frame = amd.synth_frame(1920, 1080, 0)

@@ -1078,8 +1078,9 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // on a stream of their own that does NOT wait for what the context's stream still has to do for the batch before, and
     // the context's stream picks up behind them.  They then run under the previous batch's detectors instead of in front
     // of this batch's first level: 0.3-0.4 ms less on the critical path of a 5 ms step (+3.7 %, 5 x 80 steps each way).
-    // The contrast scratch (c->small) is shared by the jobs of a context: a job's early stages wait for those of the job
-    // before (pre_done).  Only with the march kernels (they use no other context scratch).
+    // The contrast scratch (c->small) is shared by the jobs of a context: a job's early stages wait for the level-0 stages
+    // of the job before, on whichever stream those ran (pre_done).  Only with the march kernels (they use no other
+    // context scratch).
     struct StreamRestore {  // the helpers (gaussian_blur_impl, fed_impl, StageTimer, ...) enqueue on c->stream
         akz_ctx* c;
         hipStream_t main;
@@ -1106,9 +1107,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         AKZ_TRY(contrast_impl(c, P(0, AKZ_LSMOOTH), w, h, n, cfg.contrast_percentile, 1.0,
                               cfg.contrast_factor_num_bins, r->d_k));
     }
+    // every job marks the end of its level-0 stages (the last use of the context's contrast scratch): a later job that
+    // runs ahead waits for exactly that, whichever stream it was recorded on
+    if (!c->pre_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming));
+    AKZ_HIP_TRY(hipEventRecord(c->pre_done, c->stream));
     if (early) {
-        if (!c->pre_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming));
-        AKZ_HIP_TRY(hipEventRecord(c->pre_done, c->pre));
         c->stream = s;
         AKZ_HIP_TRY(hipStreamWaitEvent(s, c->pre_done, 0));
     }

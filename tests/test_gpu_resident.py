@@ -115,3 +115,14 @@ def test_input_ready_batches_run_ahead(ctx, amd, ref):
     assert_same_result(res[1], ref.extract(batches[1][2], threads=16), img=2)
     assert_same_result(res[2], ref.extract(batches[2][0], threads=16), planes=False, img=0)
     assert_same_result(host[1], ref.extract(batches[1][4], threads=16), planes=False, img=4)
+
+
+def test_batch_soak_short():
+    """tools/batch_soak.py for a few seconds: batches of 1-7 1080p frames from device and pinned host memory, with and
+    without AKZ_INPUT_READY, one or two in flight; every frame against its synchronous extraction (a 75 s run checks
+    ~11 000 frames in ~2 900 batches)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "batch_soak.py"), "5"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "no mismatch" in p.stdout

@@ -198,7 +198,6 @@ static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
         AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->aux) AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
         if (c->coarse) AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
-    if (c->pre) AKZ_HIP_TRY(hipStreamSynchronize(c->pre));
         if (c->pre) AKZ_HIP_TRY(hipStreamSynchronize(c->pre));
         if (c->copy) AKZ_HIP_TRY(hipStreamSynchronize(c->copy));
         AKZ_HIP_TRY(hipFree(b.p));

@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define AKZ_ABI_VERSION 2
+/* 3 (round 3): additions only -- akz_extract_begin_host_*, akz_ctx_set_host_threads, akz_ctx_set_eager_finish,
+   akz_gather_image_rows, akz_match_all_pairs / akz_pairs_*, AKZ_INPUT_READY; the gather's overflow protocol.  Every
+   entry point of version 2 keeps its signature and meaning. */
+#define AKZ_ABI_VERSION 3
 
 typedef enum akz_status {
     AKZ_OK = 0,

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(amd):
     assert not missing, missing
     # and the binding declares a signature for each of them
     assert sorted(set(syms) - set(L._declared)) == []
-    assert L.akz_abi_version() == 2
+    assert L.akz_abi_version() == 3
 
 
 def test_no_oracle_in_product_path():

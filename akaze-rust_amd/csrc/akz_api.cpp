@@ -57,6 +57,16 @@ unsigned akz::host_cpu_share() {
 // 8-frame batches, 8 000 000 -- so that a lone 4K frame qualifies -- changes nothing for it: that frame is bound by the
 // host's per-image selection and the finish round trips, not by its kernels).
 static constexpr uint64_t kBigLaunchPx() { return 8u << 20; }
+// GPU_MAX_HW_QUEUES as the HIP runtime of this process read it when it initialised (the variable has to be set before the
+// process's first HIP call, so what the environment says now is what the runtime saw); 4 is the runtime's default
+static unsigned hw_queue_budget() {
+    static const unsigned q = [] {
+        const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? (unsigned)v : 4u;
+    }();
+    return q;
+}
 
 // The finish half of a lane's jobs on a thread of the library (akz_ctx_set_eager_finish): started by begin, so that the
 // candidate round trip, the host keypoint logic and the keypoint kernels of frame i run while the caller's thread
@@ -1077,6 +1087,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // on a stream of their own that does NOT wait for what the context's stream still has to do for the batch before, and
     // the context's stream picks up behind them.  They then run under the previous batch's detectors instead of in front
     // of this batch's first level: 0.3-0.4 ms less on the critical path of a 5 ms step (+3.7 %, 5 x 80 steps each way).
+    // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says
+    // otherwise), each of which runs its packets in order: with four, the run-ahead stream lands on the queue of the
+    // context's stream or of the coarse chain and everything serialises behind everything (13.4 -> 7.7 Gpix/s, measured).
+    // So the stages run ahead only in a process whose environment asks for eight queues or more.
     // The contrast scratch (c->small) is shared by the jobs of a context: a job's early stages wait for the level-0 stages
     // of the job before, on whichever stream those ran (pre_done).  Only with the march kernels (they use no other
     // context scratch).
@@ -1086,7 +1100,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         ~StreamRestore() { c->stream = main; }
     } stream_restore{c, s};
     bool early = false;
-    if ((input_ready || (flags & AKZ_INPUT_READY)) && c->profiling < 2 && c->prep_mode == 2 && (uint64_t)w * h * n >= kBigLaunchPx() &&
+    if ((input_ready || (flags & AKZ_INPUT_READY)) && hw_queue_budget() >= 8 && c->profiling < 2 && c->prep_mode == 2 && (uint64_t)w * h * n >= kBigLaunchPx() &&
         launch::blur5_march_supported(w, h, (uint32_t)gaussian_kernel_size((float)cfg.base_scale_offset)) &&
         launch::contrast_march_supported(w, h, (uint32_t)gaussian_kernel_size(1.0f), (uint32_t)cfg.contrast_factor_num_bins)) {
         if (!c->pre) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking));

@@ -102,7 +102,9 @@ enum {
        is finished.  The first stages of a large batch (level-0 blur, contrast factor) then do not wait for the work the
        context's stream still holds for the batch before and run under that batch's kernels.  Without the flag the
        library has to assume that the frames are produced by whatever the caller enqueued on the stream before the call.
-       (akz_extract_begin_host_* knows when its own upload is complete and always runs ahead.)  Results are identical. */
+       (akz_extract_begin_host_* knows when its own upload is complete and always runs ahead.)  Results are identical.
+       Takes effect only in a process started with GPU_MAX_HW_QUEUES >= 8 in its environment (threading):
+       with the runtime's default of 4 in-order hardware queues one more busy stream would serialise the pipeline. */
     AKZ_INPUT_READY = 1u << 3
 };
 

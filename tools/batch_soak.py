@@ -4,6 +4,7 @@ kernels, the fork and the run-ahead stages) from device or pinned host memory, w
 two batches in flight; keypoints and descriptors of every frame against the synchronous extraction of that frame alone.
 python tools/batch_soak.py [seconds]"""
 import os, sys, time, random
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: lanes on their own queues, run-ahead stages on
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "akaze-rust_amd", "python"))
 import numpy as np, torch
 import akaze_amd as A

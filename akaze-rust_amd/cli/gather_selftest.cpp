@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/akaze_hip.h"
+#include "../../include/akaze_hip_debug.h"
 
 #define TRY(expr)                                                                          \
     do {                                                                                   \

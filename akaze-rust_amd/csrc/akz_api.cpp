@@ -85,7 +85,9 @@ struct Finisher {
 
 struct akz_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // the stream the enqueueing helpers use: the caller's stream, except while extract_begin
+                                             // puts a batch's early stages or its coarse chain on a stream of their own
+    hipStream_t main = nullptr;              // the caller's stream (never changes; what other threads synchronise with)
     bool own_stream = false;
     DevBuf scratch[6];                       // f32 plane temporaries (largest level x batch)
     DevBuf scratch_coarse;                   // the coarse chain's own diffusion scratch: it outlives the batch's join (see extract_begin)
@@ -111,11 +113,11 @@ struct akz_ctx {
     // extractions in flight (akz_extract_begin_* / akz_extract_finish)
     static constexpr int kSlots = 3;
     DevBuf cand_slot[kSlots], count_slot[kSlots];
-    bool slot_busy[kSlots] = {false, false, false};
-    uint32_t cand_cap_hint = 1u << 15;  // grows to 1.25x the largest candidate count seen
+    std::atomic<bool> slot_busy[kSlots] = {{false}, {false}, {false}};  // (begin on the caller's thread, finish possibly on the finisher's)
+    std::atomic<uint32_t> cand_cap_hint{1u << 15};  // grows to 1.25x the largest candidate count seen
     std::atomic<int> live_results{0};   // akz_result objects (also inside jobs) that still point at this context
     bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
-    uint32_t last_total_cands = 0;      // candidates of the previous finished job (speculative fetch size)
+    std::atomic<uint32_t> last_total_cands{0};  // candidates of the previous finished job (speculative fetch size)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
     hipStream_t coarse = nullptr;       // the coarse octaves' chain (diffusion + detectors), next to the fine detectors
     hipStream_t pre = nullptr;          // level-0 blur + contrast factor of a batch whose input is known to be complete:
@@ -137,12 +139,22 @@ struct akz_ctx {
     int prep_mode = 2;  // level preparation: 0 LDS-tiled, 1 streaming, 2 auto (fused with the first diffusion steps for large launches), 3 fused wherever supported
     int det_mode = 2;  // 0: tiled pair, 2: auto, 4: one tiled kernel, 5: column march (akz_ctx_set_detector_mode)
     int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 2: k_fed_own (<= 8 steps/launch; <= 16 for small launches)
+    // schedule experiments (akz_debug_set_schedule): [0] early stages on the copy stream instead of a stream of their own,
+    // [1] early stages held back until the batch before has finished its fine-level diffusion, [2] run ahead only with
+    // GPU_MAX_HW_QUEUES >= 8
+    int sched[4] = {0, 0, 1, 0};
     int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
     akz_profile prof{};
     struct Span { int stage; hipEvent_t a, b; };
     std::vector<Span> spans;          // recorded, not yet resolved
     std::vector<hipEvent_t> ev_pool;  // recycled events
-    hipEvent_t fed_done = nullptr;     // recorded by every extract_begin behind its last diffusion launch
+    std::mutex ev_m;                  // guards spans and ev_pool (begin records on the caller's thread while a finish resolves)
+    // Every extract_begin records, behind its last fine-level diffusion launch, the event fed_ev[seq % kFedRing] of its
+    // sequence number: the keypoint kernels of job i are held back until job i + 1 has passed that point, and the early
+    // stages of job i + 1 until job i has (see extract_begin).  Four slots: at most kSlots jobs are in flight.
+    static constexpr int kFedRing = 4;
+    hipEvent_t fed_ev[kFedRing] = {nullptr, nullptr, nullptr, nullptr};
+    std::atomic<uint64_t> begin_seq{0};  // sequence number of the job begun last
     std::unique_ptr<WorkerPool> workers;  // host threads of the finish half (started on first use)
     unsigned host_threads = 0;            // akz_ctx_set_host_threads; 0 = sized by host_cpu_share()
     WorkerPool& pool() {
@@ -158,10 +170,13 @@ struct StageTimer {
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
     static hipEvent_t get(akz_ctx* c) {
-        if (!c->ev_pool.empty()) {
-            hipEvent_t e = c->ev_pool.back();
-            c->ev_pool.pop_back();
-            return e;
+        {
+            std::lock_guard<std::mutex> lk(c->ev_m);
+            if (!c->ev_pool.empty()) {
+                hipEvent_t e = c->ev_pool.back();
+                c->ev_pool.pop_back();
+                return e;
+            }
         }
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
@@ -179,10 +194,17 @@ struct StageTimer {
     ~StageTimer() {
         if (!on) return;
         (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(c->ev_m);
         c->spans.push_back({stage, a, b});
     }
 };
+static void ev_put(akz_ctx* c, hipEvent_t e) {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(c->ev_m);
+    c->ev_pool.push_back(e);
+}
 static void resolve_spans(akz_ctx* c) {
+    std::lock_guard<std::mutex> lk(c->ev_m);
     std::vector<akz_ctx::Span> pending;
     for (auto& sp : c->spans) {
         if (hipEventQuery(sp.b) != hipSuccess) {  // still in flight (a later job): keep for the next call
@@ -205,7 +227,7 @@ static double now_ms() {
 static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return AKZ_OK;
     if (b.p) {
-        AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+        AKZ_HIP_TRY(hipStreamSynchronize(c->main));
         if (c->aux) AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
         if (c->coarse) AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
         if (c->pre) AKZ_HIP_TRY(hipStreamSynchronize(c->pre));
@@ -222,7 +244,8 @@ static int ensure(akz_ctx* c, DevBuf& b, size_t bytes) {
 static int ensure_pinned(akz_ctx* c, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return AKZ_OK;
     if (b.p) {
-        AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+        AKZ_HIP_TRY(hipStreamSynchronize(c->main));
+        if (c->aux) AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
         AKZ_HIP_TRY(hipHostFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -257,7 +280,9 @@ static void finisher_stop(akz_ctx* c) {
     if (f->th.joinable()) f->th.join();
     c->fin.reset();
 }
-static int bind(akz_ctx* c, bool lanes_too = true) {
+// drain_self = false: extract_begin on a context whose jobs are finished by its own thread -- the two halves touch disjoint
+// state (see akz_ctx) and run side by side; every other entry point waits until that thread is idle
+static int bind(akz_ctx* c, bool lanes_too = true, bool drain_self = true) {
     if (!c) {
         set_error("null context");
         return AKZ_ERR_INVALID_ARG;
@@ -266,7 +291,7 @@ static int bind(akz_ctx* c, bool lanes_too = true) {
         set_error("the context of this object was destroyed");
         return AKZ_ERR_INVALID_ARG;
     }
-    finisher_drain(c);
+    if (drain_self) finisher_drain(c);
     if (lanes_too)  // (every call but the one that deals a job to a lane: setters forward to the lanes, queries read them)
         for (akz_ctx* l : c->lanes) finisher_drain(l);
     AKZ_HIP_TRY(hipSetDevice(c->device));
@@ -320,7 +345,7 @@ int akz_ctx_create(int device, void* stream, akz_ctx** out) {
     }
     std::unique_ptr<akz_ctx> c(new akz_ctx);
     c->device = device;
-    c->stream = (hipStream_t)stream;  // NULL == the default stream
+    c->stream = c->main = (hipStream_t)stream;  // NULL == the default stream
     *out = c.release();
     return AKZ_OK;
 }
@@ -396,7 +421,10 @@ int akz_ctx_destroy(akz_ctx* c) {
     c->ev_pool.clear();
     c->aux = nullptr;
     c->workers.reset();  // joins the host worker threads
-    if (c->fed_done) { (void)hipEventDestroy(c->fed_done); c->fed_done = nullptr; }
+    for (hipEvent_t& e : c->fed_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
     c->dead = true;  // results that are still alive keep the (now resource-less) struct; see result_delete
     if (c->live_results == 0) delete c;
     return AKZ_OK;
@@ -407,9 +435,10 @@ int akz_ctx_synchronize(akz_ctx* c) {
     AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->coarse) AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
     if (c->pre) AKZ_HIP_TRY(hipStreamSynchronize(c->pre));
+    if (c->copy) AKZ_HIP_TRY(hipStreamSynchronize(c->copy));
     return AKZ_OK;
 }
-void* akz_ctx_stream(akz_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* akz_ctx_stream(akz_ctx* c) { return c ? (void*)c->main : nullptr; }
 
 int akz_device_malloc(akz_ctx* c, size_t bytes, void** d_out) {
     AKZ_TRY(bind(c));
@@ -885,10 +914,11 @@ static int slab_acquire(akz_ctx* c, size_t bytes, void** p, size_t* got) {
 static void slab_release(akz_ctx* c, void* p, size_t bytes) {
     std::lock_guard<std::mutex> lk(c->slab_m);
     if (c->slab_pool.size() >= 8) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->main);
         if (c->aux) (void)hipStreamSynchronize(c->aux);
         if (c->coarse) (void)hipStreamSynchronize(c->coarse);
         if (c->pre) (void)hipStreamSynchronize(c->pre);
+        if (c->copy) (void)hipStreamSynchronize(c->copy);
         (void)hipFree(c->slab_pool.front().second);
         c->slab_pool.erase(c->slab_pool.begin());
     }
@@ -908,6 +938,7 @@ struct akz_job {
     int slot = -1;            // candidate / counter buffers used by this job
     uint32_t cap = 0;         // candidate capacity per image
     hipEvent_t nms_done = nullptr;
+    uint64_t seq = 0;         // position in the context's order of begins (fed_ev ring)
     double t_begin_ms = 0.0;
     // eager finish: the lane's thread runs the finish half and leaves its outcome here (guarded by fin->m)
     std::shared_ptr<Finisher> fin;
@@ -942,12 +973,13 @@ void ResultDeleter::operator()(akz_result* r) const { result_delete(r); }
 static void job_release(akz_job* j) {
     akz_ctx* c = j->r ? j->r->ctx : nullptr;
     if (!c) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->main);
     if (c->coarse) (void)hipStreamSynchronize(c->coarse);  // a forked batch completes on the coarse stream
     if (c->pre) (void)hipStreamSynchronize(c->pre);
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
     if (j->slot >= 0) c->slot_busy[j->slot] = false;
     j->slot = -1;
-    if (j->nms_done) c->ev_pool.push_back(j->nms_done);
+    ev_put(c, j->nms_done);
     j->nms_done = nullptr;
     result_release_device(j->r.get());
 }
@@ -973,7 +1005,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                          uint32_t flags, akz_job** out, int want_slot = -1, hipEvent_t input_ready = nullptr) {
     if (!out) return AKZ_ERR_INVALID_ARG;
     *out = nullptr;
-    AKZ_TRY(bind(c));
+    AKZ_TRY(bind(c, true, c && c->is_lane));  // (a lane's finish half shares the lane's one stream: begin waits for it)
     if (!d_imgs || !cfgp || n == 0) {
         set_error("extract: null image/config or empty batch");
         return AKZ_ERR_INVALID_ARG;
@@ -1038,6 +1070,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             akz_ctx* c = r->ctx;
             if (c && c->coarse) (void)hipStreamSynchronize(c->coarse);
             if (c && c->pre) (void)hipStreamSynchronize(c->pre);
+            if (c && c->copy) (void)hipStreamSynchronize(c->copy);
             result_release_device(r);
         }
     } guard{r};
@@ -1049,12 +1082,15 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // a side stream next to the diffusion was +3 % with the round-1 kernels and is -15 % with the column march, which
     // saturates the store path on its own; with only the half-resolution octave's detectors on the side stream it is
     // still -5 %: removed).
-    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint, 16u),
+    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint.load(), 16u),
                                                       0x7fffffffull / sizeof(Candidate));
     AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
     AKZ_TRY(ensure(c, c->count_slot[slot], 256));
     uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
     Candidate* d_cand = (Candidate*)c->cand_slot[slot].p;
+    if (!c->fed_ev[0])
+        for (hipEvent_t& e : c->fed_ev) AKZ_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint64_t seq = c->begin_seq.load() + 1;  // published when this job's event has been recorded
     // derivatives, Ldet and extrema candidates of level l in one or two launches on stream `st_`; false when the
     // level's kernel size has no fused form (then the multi-kernel fallback runs on the main stream at the end)
     auto detector_one_pass = [&](size_t l, hipStream_t st_) -> bool {
@@ -1100,13 +1136,23 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         ~StreamRestore() { c->stream = main; }
     } stream_restore{c, s};
     bool early = false;
-    if ((input_ready || (flags & AKZ_INPUT_READY)) && hw_queue_budget() >= 8 && c->profiling < 2 && c->prep_mode == 2 && (uint64_t)w * h * n >= kBigLaunchPx() &&
+    if ((input_ready || (flags & AKZ_INPUT_READY)) && (!c->sched[2] || hw_queue_budget() >= 8) && c->profiling < 2 && c->prep_mode == 2 && (uint64_t)w * h * n >= kBigLaunchPx() &&
         launch::blur5_march_supported(w, h, (uint32_t)gaussian_kernel_size((float)cfg.base_scale_offset)) &&
         launch::contrast_march_supported(w, h, (uint32_t)gaussian_kernel_size(1.0f), (uint32_t)cfg.contrast_factor_num_bins)) {
-        if (!c->pre) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking));
-        if (input_ready) AKZ_HIP_TRY(hipStreamWaitEvent(c->pre, input_ready, 0));
-        if (c->pre_done) AKZ_HIP_TRY(hipStreamWaitEvent(c->pre, c->pre_done, 0));
-        c->stream = c->pre;
+        hipStream_t ps = nullptr;
+        if (c->sched[0]) {
+            if (!c->copy) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+            ps = c->copy;
+        } else {
+            if (!c->pre) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking));
+            ps = c->pre;
+        }
+        if (input_ready) AKZ_HIP_TRY(hipStreamWaitEvent(ps, input_ready, 0));
+        if (c->pre_done) AKZ_HIP_TRY(hipStreamWaitEvent(ps, c->pre_done, 0));
+        // however early the caller begins this batch, its first two stages start when the batch before goes from its
+        // (VALU-bound) diffusion launches to its (bandwidth-bound) detectors: that is what they are meant to run under
+        if (c->sched[1] && seq > 1) AKZ_HIP_TRY(hipStreamWaitEvent(ps, c->fed_ev[(seq - 1) % akz_ctx::kFedRing], 0));
+        c->stream = ps;
         early = true;
     }
     // the job's candidate counter is cleared on the stream of its first stage (every detector launch comes behind that)
@@ -1171,6 +1217,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     if (fork_octave > 0 && c->profiling < 2 && (uint64_t)w * h * n >= fork_min_px)
         for (size_t i = 1; i < L && fork_level == L; ++i)
             if ((int)plan[i].octave >= fork_octave) fork_level = i;
+    // small frames in a large batch: the resident tail may start before octave 2 -- the chain then forks where the tail
+    // starts (run_levels stops at the resident launch, which covers every level behind it: a fork behind that point
+    // would run those levels a second time as separate launches)
+    if (fork_level < L && res_first < fork_level) fork_level = res_first;
     auto run_levels = [&](size_t lo, size_t hi) -> int {
     for (size_t i = lo; i < hi; ++i) {
         const LevelPlan& lv = plan[i];
@@ -1282,8 +1332,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // The keypoint kernels of the batch that is finished next (orientation, M-LDB: gather-bound, on the auxiliary
     // stream) wait for this point: next to the VALU-bound diffusion launches they cost more than next to the
     // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.
-    if (!c->fed_done) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->fed_done, hipEventDisableTiming));
-    AKZ_HIP_TRY(hipEventRecord(c->fed_done, s));
+    AKZ_HIP_TRY(hipEventRecord(c->fed_ev[seq % akz_ctx::kFedRing], s));
+    c->begin_seq.store(seq);
 
     // ---- detectors: levels [lo, hi) on stream st (c->stream is st while this runs) ----
     // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group
@@ -1341,7 +1391,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         hipEvent_t fine_done = StageTimer::get(c);
         AKZ_HIP_TRY(hipEventRecord(fine_done, s));
         AKZ_HIP_TRY(hipStreamWaitEvent(c->coarse, fine_done, 0));
-        c->ev_pool.push_back(fine_done);
+        ev_put(c, fine_done);
         // (holding the chain back until the full-resolution detectors, or all fine detectors, have finished: -2 ... -5 %)
         ls = c->coarse;
         c->stream = c->coarse;
@@ -1358,7 +1408,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             AKZ_HIP_TRY(hipEventRecord(ev, c->coarse));
             AKZ_HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         }
-        c->ev_pool.push_back(ev);
+        ev_put(c, ev);
     } else {
         AKZ_TRY(detectors(0, L, s));
     }
@@ -1367,6 +1417,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     AKZ_HIP_TRY(hipEventRecord(job->nms_done, done_on));
     job->slot = slot;
     job->cap = cap;
+    job->seq = seq;
     c->slot_busy[slot] = true;
     guard.armed = false;
     *out = job.release();
@@ -1379,12 +1430,12 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     std::unique_ptr<akz_job, void (*)(akz_job*)> job(jobp, job_release);
     akz_result* r = job->r.get();
     akz_ctx* c = r->ctx;
-    AKZ_TRY(bind(c));
+    AKZ_TRY(bind(c, false));
     // everything below waits only for THIS job's kernels: on the context's auxiliary stream, behind the job's event.  An
     // eagerly finished job of a lane stays on the lane's own stream (its finish half is enqueued right behind its begin
     // half): the streams of a process share a few hardware queues, each of which runs its packets in order, so every
     // further stream of a lane queues its keypoint kernels behind the launch chain of some other lane
-    hipStream_t s = c->stream;
+    hipStream_t s = c->main;  // (never c->stream: extract_begin may be swapping it on the caller's thread right now)
     if (!(c->is_lane && job->fin)) {
         AKZ_TRY(ensure_aux(c));
         s = c->aux;
@@ -1425,7 +1476,8 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         // previous job of this context had (+25 %) and the contrast factors, so that one synchronisation serves all.
         uint32_t spec = 0;
         if (attempt == 0) {
-            spec = std::min<uint32_t>(cap, c->last_total_cands + c->last_total_cands / 4 + 64u);
+            const uint32_t last = c->last_total_cands.load();
+            spec = std::min<uint32_t>(cap, last + last / 4 + 64u);
             if ((size_t)spec * sizeof(Candidate) > (1u << 20)) spec = 0;  // large lists: exactly the used part, below
             AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
             AKZ_HIP_TRY(hipMemcpyAsync(c->pin[5].p, r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1439,7 +1491,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         total_c = *total_p;
         if (attempt == 0) r->k_host.assign((const double*)c->pin[5].p, (const double*)c->pin[5].p + n);
         c->last_total_cands = total_c;
-        c->cand_cap_hint = std::max(c->cand_cap_hint, (uint32_t)((uint64_t)total_c * 5 / 4 / n) + 64u);
+        c->cand_cap_hint = std::max(c->cand_cap_hint.load(), (uint32_t)((uint64_t)total_c * 5 / 4 / n) + 64u);
         if (total_c > cap) {  // overflow: grow and redo the NMS pass alone on the stored Ldet planes (the host sorts that list)
             if (attempt >= 3) {
                 set_error("NMS candidate buffer overflow");
@@ -1447,7 +1499,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             }
             cap = total_c + total_c / 8;
             sorted = false;
-            AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+            AKZ_HIP_TRY(hipStreamSynchronize(c->main));
             AKZ_TRY(ensure(c, c->cand_slot[job->slot], (size_t)cap * sizeof(Candidate)));
             AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
             for (size_t l = 0; l < L; ++l)
@@ -1582,11 +1634,12 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* d_oo = (OrientOut*)c->kp_out.p;
         AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params, total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
-        // behind the fine octaves' diffusion of the batch begun last (no wait if that is this batch or has passed the
-        // point; placing the gate earlier, later or nowhere was measured: no difference); small jobs are bound by the
-        // latency of this chain, not by the chip, and do not wait
-        if (c->fed_done && (uint64_t)r->w * r->h * n >= kBigLaunchPx())
-            AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_done, 0));
+        // behind the fine octaves' diffusion of the batch begun right after this one, if there is one (next to the
+        // VALU-bound diffusion launches these gather-bound kernels cost more than next to the bandwidth-bound detectors that
+        // follow; the NEXT batch, not the one begun last: with two batches begun ahead that one is a whole step away); small
+        // jobs are bound by the latency of this chain, not by the chip, and do not wait
+        if ((uint64_t)r->w * r->h * n >= kBigLaunchPx() && c->begin_seq.load() > job->seq)
+            AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_ev[(job->seq + 1) % akz_ctx::kFedRing], 0));
         launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());
         OrientOut* oo = (OrientOut*)c->pin[1].p;
@@ -1647,7 +1700,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         c->prof.calls += 1;
         c->prof.pixels += (uint64_t)r->w * r->h * n;
     }
-    c->ev_pool.push_back(job->nms_done);
+    ev_put(c, job->nms_done);
     job->nms_done = nullptr;
     *out = job->r.release();
     (void)job.release();
@@ -1792,7 +1845,7 @@ static int extract_from_planes(akz_ctx* c, uint32_t w, uint32_t h, const akz_con
                 AKZ_HIP_TRY(hipMemcpyAsync(r->planes[l][p], planes[l * 10 + p], plane_bytes(plan[l].w, plan[l].h, 1),
                                            hipMemcpyHostToDevice, s));
     AKZ_HIP_TRY(hipStreamSynchronize(s));  // the caller's planes are pageable host memory: complete before returning
-    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max<uint32_t>(c->cand_cap_hint, 16u), 0x7fffffffull / sizeof(Candidate));
+    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max<uint32_t>(c->cand_cap_hint.load(), 16u), 0x7fffffffull / sizeof(Candidate));
     AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
     AKZ_TRY(ensure(c, c->count_slot[slot], 256));
     uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
@@ -1887,7 +1940,7 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->own_stream = true;
         l->is_lane = true;
         l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
-        l->cand_cap_hint = c->cand_cap_hint;
+        l->cand_cap_hint = c->cand_cap_hint.load();
         l->stream_min_px = c->stream_min_px;
         l->host_threads = c->host_threads;
         l->profiling = c->profiling;
@@ -1925,7 +1978,7 @@ static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint
         // extraction will hold (exclusive until its finish); only this job's kernels wait for the copy, so it runs
         // under whatever the main stream is doing for the batch before.
         if (out) *out = nullptr;
-        AKZ_TRY(bind(on));
+        AKZ_TRY(bind(on, true, on->is_lane));
         if (!imgs || w == 0 || h == 0 || n == 0) {
             set_error("extract_begin_host: null or empty frames");
             return AKZ_ERR_INVALID_ARG;
@@ -1948,7 +2001,7 @@ static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint
     hipEvent_t ready = on_host ? on->staged[slot] : nullptr;  // frames this library uploaded: complete behind that event
     const int rc = is_u8 ? extract_begin<uint8_t>(on, (const uint8_t*)d_imgs, w, h, n, cfg, flags, out, slot, ready)
                          : extract_begin<float>(on, (const float*)d_imgs, w, h, n, cfg, flags, out, slot, ready);
-    if (rc == AKZ_OK && on != c && c->eager_finish) finisher_post(on, *out);
+    if (rc == AKZ_OK && c->eager_finish) finisher_post(on, *out);
     return rc;
 }
 int akz_extract_begin_host_u8(akz_ctx* c, const uint8_t* h_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,
@@ -1976,6 +2029,10 @@ int akz_ctx_graph_probe(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t 
                         uint32_t flags, uint32_t reps, double* ms_graph, double* ms_plain, uint64_t* graph_nodes) {
     AKZ_TRY(bind(c));
     if (!d_imgs || !cfg || !ms_graph || !ms_plain || reps == 0) return AKZ_ERR_INVALID_ARG;
+    if ((uint64_t)w * h * n >= kBigLaunchPx()) {  // such a batch forks its coarse chain and completes on that stream: not one capture
+        set_error("akz_ctx_graph_probe: batches of 8 Mpx and more fork onto a second stream and cannot be captured from one");
+        return AKZ_ERR_INVALID_ARG;
+    }
     const int prof = c->profiling;
     c->profiling = 0;
     struct Restore { akz_ctx* c; int p; ~Restore() { c->profiling = p; } } restore{c, prof};
@@ -2200,7 +2257,7 @@ int akz_result_copy_device_descriptors(const akz_result* r, uint8_t* d_dst, uint
         set_error("copy_device_descriptors: destination too small");
         return AKZ_ERR_BUFFER;
     }
-    AKZ_TRY(bind(r->ctx));
+    AKZ_TRY(bind(r->ctx, true, false));
     // on the auxiliary stream and complete on return: the context's main stream may already be busy
     // with the next batch, and the caller typically hands d_dst to a collective on yet another stream
     akz_ctx* c = r->ctx;
@@ -2299,7 +2356,7 @@ int akz_fetch_plane(const akz_result* r, uint64_t img, uint64_t level, akz_plane
 static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const uint8_t* d_d1, uint64_t n1,
                              uint64_t distance_threshold, double lowes_ratio, akz_match* d_out, uint64_t* d_n_out,
                              bool rows_le_61) {
-    AKZ_TRY(bind(c));
+    AKZ_TRY(bind(c, true, false));  // (the matcher shares nothing with a finish half that may be running on the context's thread)
     if (!d_out || !d_n_out || (n0 && !d_d0) || (n1 && !d_d1) || n0 > 0x7fffffffull || n1 > 0x7fffffffull) {
         set_error("descriptor_match: bad arguments");
         return AKZ_ERR_INVALID_ARG;
@@ -2350,7 +2407,7 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
 int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
                                      const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
                                      double lowes_ratio, akz_match* d_out, uint64_t* d_n_out) {
-    AKZ_TRY(bind(c));
+    AKZ_TRY(bind(c, true, false));
     if ((n0 && !d_out) || !d_n_out || (n_sets && !set_rows) || (n0 && !d_q) || n0 > 0x7fffffffull || n_sets > 65535) {
         set_error("descriptor_match_sets: bad arguments");
         return AKZ_ERR_INVALID_ARG;
@@ -2454,7 +2511,7 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
 int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8_t* d1, uint64_t n1,
                          uint64_t desc_bytes, uint64_t distance_threshold, double lowes_ratio, akz_match* out,
                          uint64_t* n_out) {
-    AKZ_TRY(bind(c));
+    AKZ_TRY(bind(c, true, false));
     if (!n_out || desc_bytes == 0 || desc_bytes > 64 || (n0 && (!d0 || !out)) || (n1 && !d1)) {
         set_error("descriptor_match: bad arguments (desc_bytes must be 1..64)");
         return AKZ_ERR_INVALID_ARG;
@@ -2635,7 +2692,7 @@ int akz_ctx_set_host_threads(akz_ctx* c, uint32_t threads) {
 int akz_ctx_set_candidate_hint(akz_ctx* c, uint32_t per_image) {
     AKZ_TRY(bind(c));
     c->cand_cap_hint = std::max<uint32_t>(per_image, 16u);
-    for (akz_ctx* l : c->lanes) l->cand_cap_hint = c->cand_cap_hint;
+    for (akz_ctx* l : c->lanes) l->cand_cap_hint = c->cand_cap_hint.load();
     return AKZ_OK;
 }
 int akz_ctx_set_match_mode(akz_ctx* c, int mode) {
@@ -2660,7 +2717,13 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
     *n_bands = launch::march_band_rows(kind, w, h, n, half_width, rows, cap);
     return AKZ_OK;
 }
-const char* akz_detector_kernel_name(void) { return "k_detector_march"; }
+const char* akz_detector_kernel_name(void) { return "detector (k_detector_march + k_detector_tiled)"; }
+int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
+    if (!c || key < 0 || key > 3) return AKZ_ERR_INVALID_ARG;
+    AKZ_TRY(bind(c));
+    c->sched[key] = value;
+    return AKZ_OK;
+}
 int akz_debug_set_host_sort(akz_ctx* c, int on) {
     if (!c) return AKZ_ERR_INVALID_ARG;
     c->dbg_host_sort = on < 0 ? -1 : (on != 0);

@@ -68,7 +68,9 @@ public:
         for (size_t l = 0; l < plan.size(); ++l) {
             const LevelPlan& up = plan[std::min(l + 1, plan.size() - 1)];
             G g;
-            g.cell = std::max(16.0f, 2.0f * ((float)(up.esigma * cfg.derivative_factor) + 1.0f));
+            // (strictly wider than the widest query -- radius = size(l+1) + 1 -- so that the rounding of x - radius and
+            // x + radius can never spread a query over three cells; cells() still checks)
+            g.cell = std::max(16.0f, 2.0f * ((float)(up.esigma * cfg.derivative_factor) + 1.0f) * 1.001f);
             g.inv = 1.0f / g.cell;
             g.nx = std::max(1, (int)std::ceil(width / g.cell) + 1);
             g.ny = std::max(1, (int)std::ceil(height / g.cell) + 1);
@@ -135,11 +137,13 @@ public:
     struct Cells {
         uint32_t first;
         uint32_t dx, dy;  // 0 / 1 and 0 / nx
+        bool wide;        // the range spans more than 2 x 2 cells (cannot happen with the cell sizes above): general walk
     };
     Cells cells(uint32_t level, float x, float y, float radius) const {
         const G& g = grids_[level];
         const int x0 = cx(g, x - radius), x1 = cx(g, x + radius), y0 = cy(g, y - radius), y1 = cy(g, y + radius);
-        return Cells{(uint32_t)(g.base + (size_t)y0 * g.nx + x0), (uint32_t)(x1 - x0), (uint32_t)((y1 - y0) * g.nx)};
+        const bool wide = x1 - x0 > 1 || y1 - y0 > 1;
+        return Cells{(uint32_t)(g.base + (size_t)y0 * g.nx + x0), (uint32_t)std::min(1, x1 - x0), (uint32_t)(std::min(1, y1 - y0) * g.nx), wide};
     }
     void prefetch(const Cells& c) const {
         __builtin_prefetch(head_ + c.first);
@@ -273,8 +277,11 @@ void select_keypoints(const Candidate* cands, size_t n_cands, const std::vector<
             const Candidate& c = cands[c0 + j];
             const float response = std::fabs(c.v);
             // first (lowest-index) cache entry on this or the previous level within `size`
-            uint32_t hit = grids.min_slot_in(bc0[j], bqx[j], bqy[j], size2, UINT32_MAX);
-            if (level > 0) hit = grids.min_slot_in(bc1[j], bqx[j], bqy[j], size2, hit);
+            uint32_t hit = bc0[j].wide ? grids.min_slot_within(level, bqx[j], bqy[j], radius, size2, UINT32_MAX)
+                                       : grids.min_slot_in(bc0[j], bqx[j], bqy[j], size2, UINT32_MAX);
+            if (level > 0)
+                hit = bc1[j].wide ? grids.min_slot_within(level - 1, bqx[j], bqy[j], radius, size2, hit)
+                                  : grids.min_slot_in(bc1[j], bqx[j], bqy[j], size2, hit);
             bool is_repeated = false;
             if (hit != UINT32_MAX) {
                 if (response > cache[hit].response) is_repeated = true;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/akaze_hip.h"
+#include "../../include/akaze_hip_debug.h"
 
 namespace {
 struct SplitMix64 {

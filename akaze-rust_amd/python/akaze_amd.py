@@ -163,6 +163,7 @@ def lib():
         "akz_ctx_set_host_threads": ([vp, u32], i32),
         "akz_debug_set_match_chunks": ([vp, u32, u32], i32),
         "akz_debug_set_host_sort": ([vp, i32], i32),
+        "akz_debug_set_schedule": ([vp, i32, i32], i32),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
         "akz_estimate_fundamental_matrix": ([vp, u64, vp, u64, vp, C.c_float, fp, C.POINTER(i32)], i32),
@@ -341,6 +342,10 @@ class Context:
         """With lanes: the finish half of every job dealt to a lane starts on that lane's own thread as soon as the job
         has been begun; `finish()` then only collects the result (same results)."""
         _check(lib().akz_ctx_set_eager_finish(self._h, 1 if on else 0))
+
+    def debug_set_schedule(self, key, value):
+        """akz_debug_set_schedule: schedule variants of a large batch (measurement hook, identical results)."""
+        _check(lib().akz_debug_set_schedule(self._h, int(key), int(value)))
 
     def set_match_mode(self, mode):
         """2 = automatic (default), 1 = matrix-core matcher, 0 = popcount matcher."""

@@ -104,6 +104,8 @@ def parse_args(argv=None):
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one LDS-tiled kernel, 0 LDS-tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
+    ap.add_argument("--eager", type=int, default=0, help="akz_ctx_set_eager_finish: the finish half on the context's own thread")
+    ap.add_argument("--sched", type=str, default="", help="akz_debug_set_schedule pairs, e.g. 0=1,1=1,2=0")
     ap.add_argument("--depth", type=int, default=1, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
     ap.add_argument("--threshold", type=float, default=None,
@@ -409,6 +411,11 @@ def main_rank(args):
         if placement.get("cpus"):  # this rank owns exactly these cores: no second division by LOCAL_WORLD_SIZE
             ctx.set_host_threads(placement["cpus"])
         ctx.set_detector_mode(args.det_mode)
+        if args.eager:
+            ctx.set_eager_finish(True)
+        for kv in filter(None, args.sched.split(",")):
+            k, v = kv.split("=")
+            ctx.debug_set_schedule(int(k), int(v))
         ctx.set_prep_mode(args.prep_mode)
         if args.sort != "auto":
             ctx.debug_set_host_sort(args.sort == "host")
@@ -617,6 +624,7 @@ def main_rank(args):
     elapsed_rank = time.perf_counter() - t0
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
+    host_ms_timed = dict(host_ms)  # the accumulators go on counting in the host-input leg below: the line reports THIS region
     elapsed = host_max(elapsed_rank)
     per_rank_s = host_allgather(elapsed_rank)
 
@@ -1168,8 +1176,8 @@ def main_rank(args):
                        "exchange_host_ms_waiting_per_step": round(xch["wait_ms"] / steps, 3),
                        "per_rank_Mpix_s": [round(float(W) * H * F * args.steps / s / 1e6, 1) for s in per_rank_s],
                        "keypoints_per_step_rank0": nk,
-                       "host_ms_in_begin_per_batch": round(host_ms["begin"] / max(1, host_ms["calls"]), 3),
-                       "host_ms_in_finish_per_batch": round(host_ms["finish"] / max(1, host_ms["calls"]), 3)},
+                       "host_ms_in_begin_per_batch": round(host_ms_timed["begin"] / max(1, host_ms_timed["calls"]), 3),
+                       "host_ms_in_finish_per_batch": round(host_ms_timed["finish"] / max(1, host_ms_timed["calls"]), 3)},
             "host_input": host_input,
             "roofline": roofline,
             "roofline_2": roofline_2,

@@ -410,11 +410,6 @@ int akz_host_select_keypoints(uint32_t w, uint32_t h, const akz_config* cfg, con
                               akz_keypoint* out, uint64_t cap, uint64_t* n_out, uint64_t* n_extrema);
 
 /* ---- measurement hooks --------------------------------------------------------------- */
-/* Deterministic synthetic 8-bit luma frame (integer-only, SplitMix64-seeded):
-   gradient background + w*h/2048 random rectangles/discs + +-8 noise.  (shift_x, shift_y)
-   translates the shapes, giving a second view of the same frame for match tests.  Host code. */
-int akz_synth_frame_u8(uint8_t* out, uint32_t w, uint32_t h, uint64_t frame_index, int32_t shift_x,
-                       int32_t shift_y);
 /* Stage timing with HIP events recorded on the context's stream (device stages) and the host
    clock (host stages).  Off by default; when on, every extract call adds its stage times. */
 typedef enum akz_stage {
@@ -444,9 +439,6 @@ typedef struct akz_profile {
    the host-clock stages (what bench.py uses inside its timed region) */
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
-/* FED kernel variant: 2 (default) = k_fed_own, LDS tile + register ownership, up to 8 explicit steps per launch (16
-   for launches of a few workgroups); 0 = k_fed_step, one launch per step.  Results are bit-identical. */
-int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
 /* Extrema candidates per image that the next extraction reserves room for (default 32768; it grows to 1.25x
    the largest count seen).  A list that overflows is detected by akz_extract_finish, which enlarges it and
    repeats the extrema pass on the stored Ldet planes — results are the same, the call is slower; the setter
@@ -472,20 +464,6 @@ int akz_ctx_set_eager_finish(akz_ctx* ctx, int on);
    LOCAL_WORLD_SIZE (one process per GPU: torchrun sets it), at most 16.  A launcher that has already pinned each rank
    to its own cores passes that number here.  Not while extractions are in flight. */
 int akz_ctx_set_host_threads(akz_ctx* ctx, uint32_t threads);
-/* Matcher kernel: 2 (default) and 3 = matrix cores on FP4 operands (k_match_fp4: descriptor bits as +-1 in e2m1,
-   v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, hamming = (488 - dot) / 2, exact in f32), 1 = matrix cores
-   on int8 operands (k_match_mfma), 0 = popcount kernel (k_match).  Results are identical. */
-int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
-/* Detector kernel variant: 2 (default) = automatic (the one-pass column march k_detector_march for launches of
-   8 Mpx and more, the one-kernel LDS-tiled form k_detector_tiled below that); 5 = column march wherever it is
-   supported (sigma_size <= 4); 4 = the LDS-tiled kernel; 0 = the LDS-tiled kernel pair (the fallback for other
-   kernel sizes).  Results are bit-identical. */
-int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
-/* Level preparation (Lsmooth, Lflow of a level): 2 (default) = automatic — for launches of 8 Mpx and more the
-   preparation and the level's first (up to four) diffusion steps run in ONE kernel (k_level_march), smaller launches take
-   the streaming or the LDS-tiled preparation kernel; 3 = the fused kernel wherever it is supported; 1 = streaming
-   preparation, 0 = LDS-tiled preparation (both without fusion).  Results are bit-identical. */
-int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
 /* ---- image ingest, options files (host code) -------------------- */
 /* What `image::open(path)` hands to the crate (akaze/src/lib.rs:171): JPEG (baseline / progressive
    Huffman, 8 bit, 1 or 3 components), PNG (non-interlaced) and binary PNM, decoded to 8-bit luma

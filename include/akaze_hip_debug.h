@@ -27,10 +27,40 @@ const char* akz_detector_kernel_name(void);
    pair call, `set_chunks` (1..16) per set of a multi-set call; 0 = automatic (the default).  Results are identical for
    every value -- which is what the tests that use this check. */
 int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_chunks);
+/* Measurement hook: schedule variants of a large batch (results are identical).  key 0: the early stages (level-0 blur,
+   contrast factor) of a batch whose input is complete run on the context's copy stream (1) or on a stream of their own
+   (0); key 1: they are held back until the batch before has finished its fine-level diffusion (1) or start at once (0);
+   key 2: they run ahead only in a process with GPU_MAX_HW_QUEUES >= 8 (1) or always (0). */
+int akz_debug_set_schedule(akz_ctx* ctx, int key, int value);
 /* Test hook: where the extrema candidates are put into scan order: 1 = bucketed and sorted on the HOST (also the fallback
    that a candidate-list overflow and over-wide sort keys take), 0 = device sort, -1 = automatic (the default: device
    sort for contexts with fewer than four host threads).  Results are identical. */
 int akz_debug_set_host_sort(akz_ctx* ctx, int on);
+
+/* ---- kernel-family selectors and the synthetic frame generator (tests, bench, tools): every mode gives bit-identical
+   results; a drop-in host never calls these ---------------------------------------------------------------------- */
+/* Deterministic synthetic 8-bit luma frame (integer-only, SplitMix64-seeded):
+   gradient background + w*h/2048 random rectangles/discs + +-8 noise.  (shift_x, shift_y)
+   translates the shapes, giving a second view of the same frame for match tests.  Host code. */
+int akz_synth_frame_u8(uint8_t* out, uint32_t w, uint32_t h, uint64_t frame_index, int32_t shift_x,
+                       int32_t shift_y);
+/* FED kernel variant: 2 (default) = k_fed_own, LDS tile + register ownership, up to 8 explicit steps per launch (16
+   for launches of a few workgroups); 0 = k_fed_step, one launch per step.  Results are bit-identical. */
+int akz_ctx_set_fed_mode(akz_ctx* ctx, int mode);
+/* Matcher kernel: 2 (default) and 3 = matrix cores on FP4 operands (k_match_fp4: descriptor bits as +-1 in e2m1,
+   v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, hamming = (488 - dot) / 2, exact in f32), 1 = matrix cores
+   on int8 operands (k_match_mfma), 0 = popcount kernel (k_match).  Results are identical. */
+int akz_ctx_set_match_mode(akz_ctx* ctx, int mode);
+/* Detector kernel variant: 2 (default) = automatic (the one-pass column march k_detector_march for launches of
+   8 Mpx and more, the one-kernel LDS-tiled form k_detector_tiled below that); 5 = column march wherever it is
+   supported (sigma_size <= 4); 4 = the LDS-tiled kernel; 0 = the LDS-tiled kernel pair (the fallback for other
+   kernel sizes).  Results are bit-identical. */
+int akz_ctx_set_detector_mode(akz_ctx* ctx, int mode);
+/* Level preparation (Lsmooth, Lflow of a level): 2 (default) = automatic — for launches of 8 Mpx and more the
+   preparation and the level's first (up to four) diffusion steps run in ONE kernel (k_level_march), smaller launches take
+   the streaming or the LDS-tiled preparation kernel; 3 = the fused kernel wherever it is supported; 1 = streaming
+   preparation, 0 = LDS-tiled preparation (both without fusion).  Results are bit-identical. */
+int akz_ctx_set_prep_mode(akz_ctx* ctx, int mode);
 
 #ifdef __cplusplus
 }

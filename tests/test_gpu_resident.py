@@ -68,11 +68,18 @@ def test_resident_flat_and_noise(rctx, amd, ref):
 
 
 def test_default_mode_1080p_batch_all_planes(ctx, amd, ref):
-    """The bench's shape in the default mode: a 4-frame 1080p batch (8.3 Mpx: the march kernels of the fine octaves, the
-    forked coarse chain and the resident last octave all engage); EVERY plane of one frame against the oracle."""
+    """The bench's shape in the default mode: a 5-frame 1080p batch (10.4 Mpx, above the 8 388 608 px gate: the blur,
+    contrast, level and detector marches of the fine octaves, the forked coarse chain and the resident last octave all
+    engage -- four frames are 8 294 400 px and only take the level march); EVERY plane of one frame against the oracle."""
     import torch
-    frames = np.stack([amd.synth_frame(1920, 1080, 60 + i) for i in range(4)])
+    frames = np.stack([amd.synth_frame(1920, 1080, 60 + i) for i in range(5)])
+    ctx.set_profiling(2)  # light: counts launches without moving the batch onto one stream
+    ctx.get_profile(reset=True)
     res = ctx.extract_features(torch.from_numpy(frames).cuda())
+    prof = ctx.get_profile(reset=True)
+    ctx.set_profiling(0)
+    # octave 0's three diffusing levels went through k_level_march (preparation inside the diffusion launch)
+    assert prof["fused_px"] >= 3 * 5 * 1920 * 1080, prof
     assert_same_result(res, ref.extract(frames[2], threads=16), img=2)
     assert_same_result(res, ref.extract(frames[0], threads=16), planes=False, img=0)
 
@@ -115,6 +122,42 @@ def test_input_ready_batches_run_ahead(ctx, amd, ref):
     assert_same_result(res[1], ref.extract(batches[1][2], threads=16), img=2)
     assert_same_result(res[2], ref.extract(batches[2][0], threads=16), planes=False, img=0)
     assert_same_result(host[1], ref.extract(batches[1][4], threads=16), planes=False, img=4)
+
+
+def test_eager_finish_batches_three_in_flight(amd, ref):
+    """akz_ctx_set_eager_finish on a context without lanes: the finish half of every batch runs on the context's own
+    thread while the caller begins the next ones (three 5-frame 1080p batches begun back to back, device and host input,
+    every schedule variant); finish() only collects.  Identical to the plain pipelined calls; one frame's planes and
+    others' keypoints against the oracle; an abandoned job and a context destroyed with a job in flight do no harm."""
+    import torch
+    ctx = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    batches = [np.stack([amd.synth_frame(1920, 1080, 300 + 5 * b + i) for i in range(5)]) for b in range(3)]
+    dev = [torch.from_numpy(b).cuda() for b in batches]
+    torch.cuda.synchronize()
+    plain = [ctx.extract_begin(d).finish() for d in dev]
+    ctx.set_eager_finish(True)
+    for sched in ((0, 0), (1, 1), (0, 1), (1, 0)):
+        ctx.debug_set_schedule(0, sched[0])
+        ctx.debug_set_schedule(1, sched[1])
+        ctx.debug_set_schedule(2, 0)
+        jobs = [ctx.extract_begin(dev[0], input_ready=True), ctx.extract_begin(dev[1], input_ready=True),
+                ctx.extract_begin_host(torch.from_numpy(batches[2]).pin_memory())]
+        res = [j.finish() for j in jobs]
+        for b in range(3):
+            for i in range(5):
+                assert res[b].keypoints(i).tobytes() == plain[b].keypoints(i).tobytes(), (sched, b, i)
+                assert res[b].descriptors(i).tobytes() == plain[b].descriptors(i).tobytes(), (sched, b, i)
+    assert_same_result(res[0], ref.extract(batches[0][1], threads=16), img=1)
+    assert_same_result(res[2], ref.extract(batches[2][3], threads=16), planes=False, img=3)
+    # small jobs take the same thread; abandon one, and destroy the context with one still in flight
+    small = torch.from_numpy(amd.synth_frame(640, 360, 7)).cuda()
+    ja, jb = ctx.extract_begin(small), ctx.extract_begin(small)
+    del ja
+    rb = jb.finish()
+    assert_same_result(rb, ref.extract(amd.synth_frame(640, 360, 7)), planes=False)
+    jc = ctx.extract_begin(dev[1], input_ready=True)
+    del jc
+    ctx.close()
 
 
 def test_batch_soak_short():

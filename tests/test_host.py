@@ -23,7 +23,8 @@ def declared_symbols():
 
 def test_debug_hooks_are_not_in_the_public_header():
     hdr = open(os.path.join(ROOT, "include", "akaze_hip.h")).read()
-    for s in ("akz_ctx_graph_probe", "akz_debug_", "akz_fed_kernel_name", "akz_detector_kernel_name"):
+    for s in ("akz_ctx_graph_probe", "akz_debug_", "akz_fed_kernel_name", "akz_detector_kernel_name", "akz_ctx_set_fed_mode",
+              "akz_ctx_set_match_mode", "akz_ctx_set_detector_mode", "akz_ctx_set_prep_mode", "akz_synth_frame_u8"):
         assert s not in hdr, s
 
 

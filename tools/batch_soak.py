@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak of the pipelined batch path: batches of 1-7 1080p frames (2-14 Mpx: both sides of the 8 Mpx threshold of the march
-kernels, the fork and the run-ahead stages) from device or pinned host memory, with and without AKZ_INPUT_READY, one or
-two batches in flight; keypoints and descriptors of every frame against the synchronous extraction of that frame alone.
+kernels, the fork and the run-ahead stages) from device or pinned host memory, with and without AKZ_INPUT_READY, up to
+three batches in flight, the finish half on the caller's thread or on the context's own (akz_ctx_set_eager_finish), every
+schedule variant of akz_debug_set_schedule; keypoints and descriptors of every frame against the synchronous extraction of that frame alone.
 python tools/batch_soak.py [seconds]"""
 import os, sys, time, random
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: lanes on their own queues, run-ahead stages on
@@ -38,7 +39,19 @@ with torch.cuda.stream(st):
         batches += 1
         frames += len(ids)
 
+    flips = 0
     while time.time() < t_end:
+        if batches >= 40 * (flips + 1):  # a new schedule every 40 batches, between jobs: the finish half on the context's own
+            while inflight:              # thread or on the caller's, early stages on the copy stream or their own, gated or not
+                check(inflight.pop(0))
+            flips += 1
+            ctx.set_eager_finish(random.random() < 0.6)
+            ctx.debug_set_schedule(0, random.randrange(2))
+            ctx.debug_set_schedule(1, random.randrange(2))
+            ctx.debug_set_schedule(2, 0)
+        k = random.randrange(0, 3)       # jobs left in flight while the next one is begun (the context holds three)
+        while len(inflight) > k:
+            check(inflight.pop(0))
         n = random.randrange(1, 8)
         ids = [random.randrange(NF) for _ in range(n)]
         arr = np.stack([host[k] for k in ids])
@@ -53,8 +66,6 @@ with torch.cuda.stream(st):
                 torch.cuda.synchronize()  # the promise of AKZ_INPUT_READY: the upload is complete
             job = ctx.extract_begin(t, keep_all_planes=not lean, input_ready=ready)
         inflight.append((ids, job, t))
-        if len(inflight) > random.randrange(1, 3):
-            check(inflight.pop(0))
     while inflight:
         check(inflight.pop(0))
     ctx.close()

@@ -3,7 +3,7 @@
 # names match the patterns given (args: tag pattern...).  Run from the repo root through gpurun.
 TAG=$1; shift
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp
-B="--steps 20 --warmup 5 --no-cpu-baseline --no-single --no-match --no-fed4k --no-self-check --no-host-input --no-host-share-leg"
+B="$EXTRA --steps 20 --warmup 5 --no-cpu-baseline --no-single --no-match --no-fed4k --no-self-check --no-host-input --no-host-share-leg"
 rm -rf /tmp/ks_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$TAG -- python3 $R/bench.py $B > $O/bench.log 2>&1
 f=$(find /tmp/ks_$TAG -name "*kernel_stats.csv" | head -1)

@@ -87,7 +87,7 @@ doc = dict(
            "HBM bytes = FETCH_SIZE x fetch_factor + WRITE_SIZE (KiB x 1024)",
     calibration=cal,
     kernels={
-        "k_detector_march": group(["k_detector_march", "k_detector_tiled"]),  # every detector launch, as bench.py counts them
+        "detector (k_detector_march + k_detector_tiled)": group(["k_detector_march", "k_detector_tiled"]),  # every detector launch, as bench.py counts them
         "k_level_march + k_fed_own": group(["k_level_march", "k_fed_own", "k_octave_resident"]),  # every diffusion launch
     })
 json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)

@@ -57,17 +57,6 @@ unsigned akz::host_cpu_share() {
 // 8-frame batches, 8 000 000 -- so that a lone 4K frame qualifies -- changes nothing for it: that frame is bound by the
 // host's per-image selection and the finish round trips, not by its kernels).
 static constexpr uint64_t kBigLaunchPx() { return 8u << 20; }
-// GPU_MAX_HW_QUEUES as the HIP runtime of this process read it when it initialised (the variable has to be set before the
-// process's first HIP call, so what the environment says now is what the runtime saw); 4 is the runtime's default
-static unsigned hw_queue_budget() {
-    static const unsigned q = [] {
-        const char* e = std::getenv("GPU_MAX_HW_QUEUES");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? (unsigned)v : 4u;
-    }();
-    return q;
-}
-
 // The finish half of a lane's jobs on a thread of the library (akz_ctx_set_eager_finish): started by begin, so that the
 // candidate round trip, the host keypoint logic and the keypoint kernels of frame i run while the caller's thread
 // enqueues frame i + 1 on another lane; akz_extract_finish then only collects the result.  One thread per lane, jobs
@@ -139,10 +128,19 @@ struct akz_ctx {
     int prep_mode = 2;  // level preparation: 0 LDS-tiled, 1 streaming, 2 auto (fused with the first diffusion steps for large launches), 3 fused wherever supported
     int det_mode = 2;  // 0: tiled pair, 2: auto, 4: one tiled kernel, 5: column march (akz_ctx_set_detector_mode)
     int fed_mode = 2;  // 0: k_fed_step (1 step/launch), 2: k_fed_own (<= 8 steps/launch; <= 16 for small launches)
-    // schedule experiments (akz_debug_set_schedule): [0] early stages on the copy stream instead of a stream of their own,
-    // [1] early stages held back until the batch before has finished its fine-level diffusion, [2] run ahead only with
-    // GPU_MAX_HW_QUEUES >= 8
-    int sched[4] = {0, 0, 1, 0};
+    // schedule variants (akz_debug_set_schedule): [0] where the early stages of a batch run -- 0 the copy stream if the
+    // placement probe found it a queue and a pipe of its own (below), 1 the copy stream regardless, 2 a stream of their own
+    // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
+    // has finished its fine-level diffusion (default) or not; [2] no placement probe
+    int sched[4] = {0, 1, 0, 0};
+    // Stream placement (place_streams): the runtime multiplexes a process's streams onto a few in-order hardware queues
+    // (GPU_MAX_HW_QUEUES, 4 by default); two busy streams of a context on one queue serialise the whole pipeline, so the
+    // first large batch measures which of the context's streams actually run side by side and replaces those that do not
+    bool placed = false;
+    int pre_mode = 0;            // early stages: 0 on the context's stream, 2 on the copy stream
+    int place_replaced = 0;      // streams that were re-created because they shared a queue with another one
+    int place_collisions = 0;    // pairs that still share a queue (no free queue was found)
+    hipEvent_t probe_ev[2] = {nullptr, nullptr};
     int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
     akz_profile prof{};
     struct Span { int stage; hipEvent_t a, b; };
@@ -422,6 +420,10 @@ int akz_ctx_destroy(akz_ctx* c) {
     c->aux = nullptr;
     c->workers.reset();  // joins the host worker threads
     for (hipEvent_t& e : c->fed_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    for (hipEvent_t& e : c->probe_ev) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
@@ -1000,6 +1002,127 @@ static void job_destroy(akz_job* j) {
     delete j;
 }
 
+// ---- stream placement ----------------------------------------------------------------------------------------------
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES in-order hardware queues (4 by default), and the
+// command processor of the chip has FOUR pipes: hardware queues k and k + 4 share one, and a pipe switches between its
+// queues at ~25 us a switch (tools/queues/queue_probe.hip: 40 tiny kernels on each of two streams drain in 0.23 ms on
+// different pipes, in 1.0 ms on one; a dependency across two queues of one pipe costs +55 us).  A batch pipeline that
+// keeps four streams busy -- the caller's, the coarse chain's, the finish half's, the uploads' / early stages' -- therefore
+// wants exactly four queues on four pipes: two of its streams on one QUEUE serialise everything behind everything
+// (13.4 -> 7.7 Gpix/s, round 3), two on one PIPE cost 15 % (11.7 against 13.8 Gpix/s, round 4).  Which queue a stream got
+// cannot be asked, so it is measured.
+// Do streams a and b get in each other's way?  (1) a 120 us single-wave spin on each, from idle: on one hardware queue the
+// second starts when the first has finished; (2) 24 tiny kernels on each, interleaved: on one pipe they drain several
+// times slower than `alone_ms`, what 24 of them take on one stream.
+static int streams_interfere(akz_ctx* c, hipStream_t a, hipStream_t b, float alone_ms, bool* bad) {
+    constexpr uint32_t kDelayUs = 120;
+    *bad = false;
+    float ms = 0.0f;
+    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[0], a));
+    launch::delay(a, kDelayUs);
+    launch::delay(b, kDelayUs);
+    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[1], b));
+    AKZ_HIP_TRY(hipGetLastError());
+    AKZ_HIP_TRY(hipEventSynchronize(c->probe_ev[1]));
+    AKZ_HIP_TRY(hipStreamSynchronize(a));
+    AKZ_HIP_TRY(hipEventElapsedTime(&ms, c->probe_ev[0], c->probe_ev[1]));
+    if (ms > 1.6f * (float)kDelayUs * 1e-3f) {
+        *bad = true;
+        return AKZ_OK;
+    }
+    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[0], a));
+    for (int k = 0; k < 24; ++k) {
+        launch::delay(a, 1);
+        launch::delay(b, 1);
+    }
+    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[1], b));
+    AKZ_HIP_TRY(hipGetLastError());
+    AKZ_HIP_TRY(hipEventSynchronize(c->probe_ev[1]));
+    AKZ_HIP_TRY(hipStreamSynchronize(a));
+    AKZ_HIP_TRY(hipEventElapsedTime(&ms, c->probe_ev[0], c->probe_ev[1]));
+    *bad = ms > 4.0f * alone_ms;  // (different pipes: 1.8 x, one pipe: 8 x)
+    return AKZ_OK;
+}
+// The first large batch of a context checks that its busy streams do not share a hardware queue or a pipe.  A stream of the
+// library that does is replaced by a fresh one (up to eight tries: the runtime hands a new stream the least-used queue,
+// and the rejected ones stay alive until the end so that they keep theirs occupied).  The early stages of a batch run
+// on the copy stream (idle for resident frames; for host frames the blur has to follow the upload anyway) -- a fifth busy
+// stream would have to share a pipe with one of the four.  About 0.4 ms per pair, once per context.
+static int place_streams(akz_ctx* c) {
+    c->placed = true;
+    if (c->is_lane) return AKZ_OK;
+    finisher_drain(c);  // (the finish half uses c->aux)
+    AKZ_TRY(ensure_aux(c));
+    if (!c->coarse) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->coarse, hipStreamNonBlocking));
+    if (!c->copy) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    if (c->sched[2]) {  // (measurement: no probe -- streams as the runtime placed them)
+        c->pre_mode = 2;
+        return AKZ_OK;
+    }
+    AKZ_HIP_TRY(hipStreamSynchronize(c->main));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->copy));
+    for (hipEvent_t& e : c->probe_ev)
+        if (!e) AKZ_HIP_TRY(hipEventCreate(&e));
+    launch::delay(c->main, 1);  // (the first launch of a kernel loads its code object: not part of a measurement)
+    AKZ_HIP_TRY(hipStreamSynchronize(c->main));
+    float alone_ms = 0.0f;
+    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[0], c->main));
+    for (int k = 0; k < 24; ++k) launch::delay(c->main, 1);
+    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[1], c->main));
+    AKZ_HIP_TRY(hipEventSynchronize(c->probe_ev[1]));
+    AKZ_HIP_TRY(hipEventElapsedTime(&alone_ms, c->probe_ev[0], c->probe_ev[1]));
+    std::vector<hipStream_t> accepted{c->main}, rejected;
+    auto collides = [&](hipStream_t x, bool* hit) -> int {
+        *hit = false;
+        for (hipStream_t a : accepted) {
+            AKZ_TRY(streams_interfere(c, a, x, alone_ms, hit));
+            if (*hit) return AKZ_OK;
+        }
+        return AKZ_OK;
+    };
+    // *slot ends up a stream that interferes with none of `accepted`, or keeps its value (free = false)
+    auto settle = [&](hipStream_t* slot, bool* free) -> int {
+        bool hit = false;
+        AKZ_TRY(collides(*slot, &hit));
+        for (int attempt = 0; hit && attempt < 8; ++attempt) {
+            hipStream_t fresh = nullptr;
+            AKZ_HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+            bool fresh_hit = false;
+            const int st = collides(fresh, &fresh_hit);
+            if (st != AKZ_OK) {
+                rejected.push_back(fresh);
+                return st;
+            }
+            if (!fresh_hit) {
+                rejected.push_back(*slot);
+                *slot = fresh;
+                hit = false;
+                ++c->place_replaced;
+            } else {
+                rejected.push_back(fresh);
+            }
+        }
+        *free = !hit;
+        return AKZ_OK;
+    };
+    int st = AKZ_OK;
+    bool free_coarse = false, free_aux = false, free_copy = false;
+    if ((st = settle(&c->coarse, &free_coarse)) == AKZ_OK) {
+        accepted.push_back(c->coarse);
+        if ((st = settle(&c->aux, &free_aux)) == AKZ_OK) {
+            accepted.push_back(c->aux);
+            st = settle(&c->copy, &free_copy);
+        }
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    AKZ_TRY(st);
+    c->place_collisions = (free_coarse ? 0 : 1) + (free_aux ? 0 : 1) + (free_copy ? 0 : 1);
+    c->pre_mode = free_copy ? 2 : 0;
+    return AKZ_OK;
+}
+
 template <typename T>
 static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
                          uint32_t flags, akz_job** out, int want_slot = -1, hipEvent_t input_ready = nullptr) {
@@ -1120,13 +1243,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // Running ahead.  These two stages need nothing but the frames, and the contrast passes are bound by arithmetic, not
     // by bandwidth: when the frames are known to be complete -- the caller says so (AKZ_INPUT_READY) or this library
     // uploaded them itself (akz_extract_begin_host_*: `input_ready` is the upload's event) -- a large batch enqueues them
-    // on a stream of their own that does NOT wait for what the context's stream still has to do for the batch before, and
-    // the context's stream picks up behind them.  They then run under the previous batch's detectors instead of in front
+    // on the context's copy stream, which does NOT wait for what the context's stream still has to do for the batch before,
+    // and the context's stream picks up behind them.  They then run under the previous batch's detectors instead of in front
     // of this batch's first level: 0.3-0.4 ms less on the critical path of a 5 ms step (+3.7 %, 5 x 80 steps each way).
-    // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says
-    // otherwise), each of which runs its packets in order: with four, the run-ahead stream lands on the queue of the
-    // context's stream or of the coarse chain and everything serialises behind everything (13.4 -> 7.7 Gpix/s, measured).
-    // So the stages run ahead only in a process whose environment asks for eight queues or more.
+    // (place_streams, above: on the context's stream instead when the copy stream could not be given a hardware queue and
+    // a pipe of its own.)
     // The contrast scratch (c->small) is shared by the jobs of a context: a job's early stages wait for the level-0 stages
     // of the job before, on whichever stream those ran (pre_done).  Only with the march kernels (they use no other
     // context scratch).
@@ -1136,11 +1257,14 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         ~StreamRestore() { c->stream = main; }
     } stream_restore{c, s};
     bool early = false;
-    if ((input_ready || (flags & AKZ_INPUT_READY)) && (!c->sched[2] || hw_queue_budget() >= 8) && c->profiling < 2 && c->prep_mode == 2 && (uint64_t)w * h * n >= kBigLaunchPx() &&
+    const bool big = (uint64_t)w * h * n >= kBigLaunchPx();
+    if (big && !c->placed) AKZ_TRY(place_streams(c));
+    const int pre_mode = c->sched[0] == 0 ? c->pre_mode : c->sched[0] == 1 ? 2 : c->sched[0] == 2 ? 1 : 0;  // (1: a stream of its own, measurement only)
+    if ((input_ready || (flags & AKZ_INPUT_READY)) && pre_mode != 0 && c->profiling < 2 && c->prep_mode == 2 && big &&
         launch::blur5_march_supported(w, h, (uint32_t)gaussian_kernel_size((float)cfg.base_scale_offset)) &&
         launch::contrast_march_supported(w, h, (uint32_t)gaussian_kernel_size(1.0f), (uint32_t)cfg.contrast_factor_num_bins)) {
         hipStream_t ps = nullptr;
-        if (c->sched[0]) {
+        if (pre_mode == 2) {
             if (!c->copy) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
             ps = c->copy;
         } else {
@@ -2722,6 +2846,15 @@ int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
     if (!c || key < 0 || key > 3) return AKZ_ERR_INVALID_ARG;
     AKZ_TRY(bind(c));
     c->sched[key] = value;
+    return AKZ_OK;
+}
+int akz_debug_stream_placement(akz_ctx* c, int* info) {
+    if (!c || !info) return AKZ_ERR_INVALID_ARG;
+    AKZ_TRY(bind(c));
+    info[0] = c->placed ? 1 : 0;
+    info[1] = c->pre_mode;
+    info[2] = c->place_replaced;
+    info[3] = c->place_collisions;
     return AKZ_OK;
 }
 int akz_debug_set_host_sort(akz_ctx* c, int on) {

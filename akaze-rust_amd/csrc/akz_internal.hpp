@@ -112,6 +112,7 @@ namespace launch {
 void filter_h_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t);
 void filter_h_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t);
 void filter_v_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t);
+void delay(hipStream_t s, uint32_t microseconds);  // one wave spinning on the 100 MHz counter (stream-placement probe)
 void half_size(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n);
 void pm_g2(hipStream_t s, const float* lx, const float* ly, float* out, uint32_t w, uint32_t h, uint32_t n,
            const double* d_k, uint32_t k_scale_pow);

@@ -47,6 +47,14 @@ __global__ void k_filter_v(const float* __restrict__ in, float* __restrict__ out
     out[base + (size_t)y * w + x] = acc;
 }
 
+// One wave that spins for `ticks` of the constant 100 MHz counter and exits (stream-placement probe of akz_api.cpp: two
+// streams whose delays add up share a hardware queue).  Every lane reaches the exit: the loop is bounded by the clock.
+__global__ void k_delay(unsigned long long ticks, unsigned* sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    while (wall_clock64() - t0 < ticks && spins < (1u << 26)) ++spins;
+    if (sink && spins == 0xffffffffu) *sink = spins;  // (keeps the loop)
+}
 // half_size for widths that are multiples of 8 (source rows and output pairs 16- / 8-byte aligned): a thread reads two
 // float4 (source rows 2y and 2y+1, four columns) and writes two outputs -- the one-pixel form below reads the source as
 // 8-byte pairs with a stride of two, which reached 1.45 TB/s on a 32-frame half-resolution level (57 us).
@@ -1054,6 +1062,9 @@ void filter_h_u8(hipStream_t s, const uint8_t* in, float* out, uint32_t w, uint3
 }
 void filter_v_f32(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n, const Taps& t) {
     hipLaunchKernelGGL(k_filter_v, grid2d(w, h, n), dim3(BX, BY), 0, s, in, out, (int)w, (int)h, t);
+}
+void delay(hipStream_t s, uint32_t microseconds) {
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, s, (unsigned long long)microseconds * 100ull, (unsigned*)nullptr);
 }
 void half_size(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, uint32_t n) {
     if ((w & 7u) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0) {

@@ -164,6 +164,7 @@ def lib():
         "akz_debug_set_match_chunks": ([vp, u32, u32], i32),
         "akz_debug_set_host_sort": ([vp, i32], i32),
         "akz_debug_set_schedule": ([vp, i32, i32], i32),
+        "akz_debug_stream_placement": ([vp, C.POINTER(i32)], i32),
         "akz_detector_kernel_name": ([], C.c_char_p),
         "akz_remove_outliers": ([vp, u64, vp, u64, vp, u64, u64, C.c_float, C.c_float, vp, pu64], i32),
         "akz_estimate_fundamental_matrix": ([vp, u64, vp, u64, vp, C.c_float, fp, C.POINTER(i32)], i32),
@@ -346,6 +347,13 @@ class Context:
     def debug_set_schedule(self, key, value):
         """akz_debug_set_schedule: schedule variants of a large batch (measurement hook, identical results)."""
         _check(lib().akz_debug_set_schedule(self._h, int(key), int(value)))
+
+    def debug_stream_placement(self):
+        """akz_debug_stream_placement: what the context's stream-placement probe found."""
+        info = (C.c_int32 * 4)()
+        _check(lib().akz_debug_stream_placement(self._h, info))
+        return {"probed": bool(info[0]), "early_stages": ("context stream", "own stream", "copy stream")[info[1]],
+                "streams_replaced": int(info[2]), "streams_sharing_a_queue": int(info[3])}
 
     def set_match_mode(self, mode):
         """2 = automatic (default), 1 = matrix-core matcher, 0 = popcount matcher."""

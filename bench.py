@@ -39,11 +39,9 @@ import subprocess
 import sys
 import time
 
-# Hardware queues the HIP runtime multiplexes this process's streams onto (default 4; each runs its packets in order).
-# The lanes of the single-frame legs are one stream each: with 4 queues the chains of 3-4 lanes queue behind each other
-# (0.53 -> 0.47 ms per streamed 1080p frame); the batch headline is indifferent (measured both ways).  A deployment
-# knob, read by the runtime when it initialises -- INTEGRATION.md lists it.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES is left alone: with the runtime's default of four hardware queues -- one per pipe of the command
+# processor -- the context's stream-placement probe gives each of its four busy streams a queue of its own; config.
+# stream_placement of the line says what it found.)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "akaze-rust_amd", "python")]
@@ -106,7 +104,7 @@ def parse_args(argv=None):
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
     ap.add_argument("--eager", type=int, default=0, help="akz_ctx_set_eager_finish: the finish half on the context's own thread")
     ap.add_argument("--sched", type=str, default="", help="akz_debug_set_schedule pairs, e.g. 0=1,1=1,2=0")
-    ap.add_argument("--depth", type=int, default=1, choices=[1, 2],
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
     ap.add_argument("--threshold", type=float, default=None,
                     help="detector_threshold override (tuning runs: a huge value removes every extremum candidate)")
@@ -1156,9 +1154,10 @@ def main_rank(args):
                                    f"({args.octaves} octaves x {args.sublevels} sublevels, 486-bit M-LDB), {F} frames per GPU per step "
                                    "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)",
                        "frames_per_gpu": F, "width": W, "height": H, "batches_per_step": NP,
-                       "pipelining": "begin(batch j+1) before finish(batch j) on one stream, across steps",
+                       "pipelining": f"begin(batch j+{args.depth}) before finish(batch j) on one context, across steps" + (", finish half on the context's own thread" if args.eager else ""),
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "stream_placement": ctx.debug_stream_placement(),
                        "input_ready_flag": not args.no_input_ready,
                        "exchange_ranks_seen": xch["ranks_seen"],
                        "placement": placement or None,

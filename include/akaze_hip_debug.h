@@ -27,11 +27,16 @@ const char* akz_detector_kernel_name(void);
    pair call, `set_chunks` (1..16) per set of a multi-set call; 0 = automatic (the default).  Results are identical for
    every value -- which is what the tests that use this check. */
 int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_chunks);
-/* Measurement hook: schedule variants of a large batch (results are identical).  key 0: the early stages (level-0 blur,
-   contrast factor) of a batch whose input is complete run on the context's copy stream (1) or on a stream of their own
-   (0); key 1: they are held back until the batch before has finished its fine-level diffusion (1) or start at once (0);
-   key 2: they run ahead only in a process with GPU_MAX_HW_QUEUES >= 8 (1) or always (0). */
+/* Measurement hook: schedule variants of a large batch (results are identical).  key 0: where the early stages
+   (level-0 blur, contrast factor) of a batch whose input is complete run: 0 = the copy stream if the context's
+   stream-placement probe found it a hardware queue and a pipe of its own (default), 1 = the copy stream regardless, 2 = a
+   stream of their own (a fifth busy stream), 3 = the context's stream (no running ahead); key 1: they are held back until
+   the batch before has finished its fine-level diffusion (1, default) or start at once (0); key 2: 1 = no placement probe. */
 int akz_debug_set_schedule(akz_ctx* ctx, int key, int value);
+/* What the stream-placement probe of the context's first large batch found: info[0] = it has run, info[1] = early stages on
+   the context's stream (0) or the copy stream (2), info[2] = streams it re-created because they shared a hardware queue
+   or a command-processor pipe with another busy stream of the context, info[3] = streams that still share one. */
+int akz_debug_stream_placement(akz_ctx* ctx, int* info);
 /* Test hook: where the extrema candidates are put into scan order: 1 = bucketed and sorted on the HOST (also the fallback
    that a candidate-list overflow and over-wide sort keys take), 0 = device sort, -1 = automatic (the default: device
    sort for contexts with fewer than four host threads).  Results are identical. */

@@ -3,11 +3,6 @@ import sys
 
 import pytest
 
-# Eight hardware queues for the process's HIP streams (read by the runtime at its first call, i.e. before any test imports
-# torch): what bench.py runs with, and the condition under which large batches run their first stages ahead
-# (threading) -- the GPU tests exercise that path.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "akaze-rust_amd", "python"), ROOT):
     if p not in sys.path:

@@ -136,10 +136,9 @@ def test_eager_finish_batches_three_in_flight(amd, ref):
     torch.cuda.synchronize()
     plain = [ctx.extract_begin(d).finish() for d in dev]
     ctx.set_eager_finish(True)
-    for sched in ((0, 0), (1, 1), (0, 1), (1, 0)):
+    for sched in ((0, 1), (1, 1), (2, 0), (3, 0), (1, 0)):
         ctx.debug_set_schedule(0, sched[0])
         ctx.debug_set_schedule(1, sched[1])
-        ctx.debug_set_schedule(2, 0)
         jobs = [ctx.extract_begin(dev[0], input_ready=True), ctx.extract_begin(dev[1], input_ready=True),
                 ctx.extract_begin_host(torch.from_numpy(batches[2]).pin_memory())]
         res = [j.finish() for j in jobs]
@@ -149,6 +148,8 @@ def test_eager_finish_batches_three_in_flight(amd, ref):
                 assert res[b].descriptors(i).tobytes() == plain[b].descriptors(i).tobytes(), (sched, b, i)
     assert_same_result(res[0], ref.extract(batches[0][1], threads=16), img=1)
     assert_same_result(res[2], ref.extract(batches[2][3], threads=16), planes=False, img=3)
+    pl = ctx.debug_stream_placement()
+    assert pl["probed"] and pl["streams_sharing_a_queue"] == 0, pl  # (the test process asks for eight hardware queues)
     # small jobs take the same thread; abandon one, and destroy the context with one still in flight
     small = torch.from_numpy(amd.synth_frame(640, 360, 7)).cuda()
     ja, jb = ctx.extract_begin(small), ctx.extract_begin(small)

@@ -5,7 +5,6 @@ three batches in flight, the finish half on the caller's thread or on the contex
 schedule variant of akz_debug_set_schedule; keypoints and descriptors of every frame against the synchronous extraction of that frame alone.
 python tools/batch_soak.py [seconds]"""
 import os, sys, time, random
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: lanes on their own queues, run-ahead stages on
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "akaze-rust_amd", "python"))
 import numpy as np, torch
 import akaze_amd as A
@@ -46,9 +45,8 @@ with torch.cuda.stream(st):
                 check(inflight.pop(0))
             flips += 1
             ctx.set_eager_finish(random.random() < 0.6)
-            ctx.debug_set_schedule(0, random.randrange(2))
+            ctx.debug_set_schedule(0, random.randrange(4))
             ctx.debug_set_schedule(1, random.randrange(2))
-            ctx.debug_set_schedule(2, 0)
         k = random.randrange(0, 3)       # jobs left in flight while the next one is begun (the context holds three)
         while len(inflight) > k:
             check(inflight.pop(0))

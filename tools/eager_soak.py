@@ -3,7 +3,6 @@
 results freed late, other calls on the context in between, lanes re-sized; every result compared with the result of the
 same frame extracted synchronously on a second context.  python tools/eager_soak.py [seconds]"""
 import os, sys, time, random
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: lanes on their own queues, run-ahead stages on
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "akaze-rust_amd", "python"))
 import numpy as np, torch
 import akaze_amd as A

@@ -87,6 +87,7 @@ struct akz_ctx {
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
+    DevBuf mm_cols;                          // both-direction launches: the train rows' (best, second) state, seed records and bound
     void* tab_ring = nullptr;                // pinned staging ring of the multi-set matcher's tables
     size_t tab_ring_bytes = 0;
     uint64_t tab_ring_next = 0;
@@ -372,7 +373,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
                       &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
-                      &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab};
+                      &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
@@ -2528,10 +2529,11 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
 // One query set against several train sets in ONE matrix-core launch (all-pairs matching: a query image against
 // the descriptor sets of all other images).  A pair of 11 K-row sets alone runs at 1.2 T pairs/s, a launch over
 // many sets at the rate of one large product (3 T pairs/s), and every set is unpacked once per call.
-int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
-                                     const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
-                                     double lowes_ratio, akz_match* d_out, uint64_t* d_n_out) {
+static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train, const uint64_t* set_rows,
+                           uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out, uint64_t* d_n_out,
+                           akz_match* d_out_cols, uint64_t* d_n_cols) {
     AKZ_TRY(bind(c, true, false));
+    const bool cols = d_n_cols != nullptr;  // the opposite direction too: every set's rows against the query set
     if ((n0 && !d_out) || !d_n_out || (n_sets && !set_rows) || (n0 && !d_q) || n0 > 0x7fffffffull || n_sets > 65535) {
         set_error("descriptor_match_sets: bad arguments");
         return AKZ_ERR_INVALID_ARG;
@@ -2543,9 +2545,24 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
         return AKZ_ERR_INVALID_ARG;
     }
     if (n_sets == 0) return AKZ_OK;
-    if (n0 == 0) {
+    if (cols && total_rows && !d_out_cols) {
+        set_error("descriptor_match_sets_mutual: null output for the opposite direction");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    if (n0 == 0) {  // (no query rows: nothing can match in either direction)
         AKZ_HIP_TRY(hipMemsetAsync(d_n_out, 0, n_sets * sizeof(uint64_t), c->stream));
+        if (cols) AKZ_HIP_TRY(hipMemsetAsync(d_n_cols, 0, n_sets * sizeof(uint64_t), c->stream));
         return AKZ_OK;
+    }
+    if (cols && c->match_mode < 2) {  // both directions ride on the FP4 kernel only: the other kernels match direction by direction
+        uint64_t off = 0;
+        for (uint64_t k = 0; k < n_sets; ++k) {
+            if (set_rows[k] == 0) AKZ_HIP_TRY(hipMemsetAsync(d_n_cols + k, 0, sizeof(uint64_t), c->stream));
+            else
+                AKZ_TRY(match_device_impl(c, d_train + off * 64, set_rows[k], d_q, n0, distance_threshold, lowes_ratio, d_out_cols + off,
+                                          d_n_cols + k, true));
+            off += set_rows[k];
+        }
     }
     if (c->match_mode == 0) {  // popcount kernel: set by set
         uint64_t off = 0;
@@ -2556,6 +2573,7 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
         }
         return AKZ_OK;
     }
+    const bool mutual = cols && c->match_mode >= 2;
     const uint32_t thr = (uint32_t)std::min<uint64_t>(distance_threshold, 0x7fffffffull);
     const uint32_t tr = launch::match_mfma_tile_rows();
     const uint32_t q_rows = launch::match_mfma_rows((uint32_t)n0, true);
@@ -2568,9 +2586,11 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
                                                                                (uint32_t)((total_rows / n_sets + tr - 1) / tr), c->dbg_set_chunks),
                                                65535u / (uint32_t)n_sets));
     std::vector<launch::MatchChunkHost> chunks((size_t)n_sets * cps);
+    std::vector<launch::MatchColSetHost> colsets(mutual ? (size_t)n_sets : 0);
     uint64_t src = 0;
     for (uint64_t k = 0; k < n_sets; ++k) {
         const uint32_t t0 = (uint32_t)(tiles.size() / 2), rows = (uint32_t)set_rows[k];
+        if (mutual) colsets[(size_t)k] = launch::MatchColSetHost{t0 * tr, rows, (uint32_t)src};
         for (uint32_t r = 0; r < rows; r += tr) {
             tiles.push_back((uint32_t)(src + r));
             tiles.push_back(std::min(tr, rows - r));
@@ -2586,11 +2606,24 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
         set_error("descriptor_match_sets: too many sets for this query set");
         return AKZ_ERR_INVALID_ARG;
     }
+    // (both directions: the train image is also read as a QUERY image by the seed launch -- whole query blocks of rows)
+    const uint32_t t_rows_q = mutual ? launch::match_mfma_rows(t_rows, true) : t_rows;
     AKZ_TRY(ensure(c, c->mm_q8, (size_t)q_rows * 512));
-    AKZ_TRY(ensure(c, c->mm_t8, (size_t)t_rows * 512));
+    AKZ_TRY(ensure(c, c->mm_t8, (size_t)t_rows_q * 512));
     AKZ_TRY(ensure(c, c->mm_pop, ((size_t)q_rows * (1 + n_sets) + t_rows) * sizeof(uint32_t)));
     const size_t tab_tiles = std::max<size_t>(1, tiles.size()) * sizeof(uint32_t);
-    AKZ_TRY(ensure(c, c->mm_tab, tab_tiles + chunks.size() * sizeof(launch::MatchChunkHost)));
+    const size_t tab_chunks = chunks.size() * sizeof(launch::MatchChunkHost), tab_cols = colsets.size() * sizeof(launch::MatchColSetHost);
+    AKZ_TRY(ensure(c, c->mm_tab, tab_tiles + tab_chunks + tab_cols));
+    unsigned long long* cbest = nullptr;
+    uint32_t *csecond = nullptr, *seed_bound = nullptr;
+    MatchRec* seed_rec = nullptr;
+    if (mutual) {  // per row of the padded train image: 8 + 4 (state) + 4 + 16 (seed launch) bytes
+        AKZ_TRY(ensure(c, c->mm_cols, (size_t)t_rows_q * 32));
+        cbest = (unsigned long long*)c->mm_cols.p;
+        seed_rec = (MatchRec*)((char*)c->mm_cols.p + (size_t)t_rows_q * 8);
+        csecond = (uint32_t*)((char*)c->mm_cols.p + (size_t)t_rows_q * 24);
+        seed_bound = csecond + t_rows_q;
+    }
     AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * chunks.size() * sizeof(MatchRec)));
     uint32_t* qpop = (uint32_t*)c->mm_pop.p;
     uint32_t* bound = qpop + q_rows;
@@ -2601,7 +2634,7 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
     // (a synchronisation here made every call of an all-pairs loop wait for the previous call's kernel).
     {
         constexpr int kRing = 4;
-        const size_t need = tab_tiles + chunks.size() * sizeof(launch::MatchChunkHost);
+        const size_t need = tab_tiles + tab_chunks + tab_cols;
         if (c->tab_ring_bytes < need) {
             AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->tab_ring) AKZ_HIP_TRY(hipHostFree(c->tab_ring));
@@ -2615,7 +2648,8 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
         else AKZ_HIP_TRY(hipEventSynchronize(c->tab_ring_ev[slot]));  // the copy that used this slot four calls ago
         char* stage = (char*)c->tab_ring + (size_t)slot * c->tab_ring_bytes;
         if (!tiles.empty()) std::memcpy(stage, tiles.data(), tiles.size() * sizeof(uint32_t));
-        std::memcpy(stage + tab_tiles, chunks.data(), chunks.size() * sizeof(launch::MatchChunkHost));
+        std::memcpy(stage + tab_tiles, chunks.data(), tab_chunks);
+        if (tab_cols) std::memcpy(stage + tab_tiles + tab_chunks, colsets.data(), tab_cols);
         AKZ_HIP_TRY(hipMemcpyAsync(d_tiles, stage, need, hipMemcpyHostToDevice, c->stream));
         AKZ_HIP_TRY(hipEventRecord(c->tab_ring_ev[slot], c->stream));
     }
@@ -2624,12 +2658,41 @@ int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0
                         nullptr, fp4);
     if (n_tiles)
         launch::unpack_bits(c->stream, d_train, 0, n_tiles * tr, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, d_tiles, fp4);
-    launch::match_mfma_multi(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
-                             (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p, fp4);
+    if (mutual) {
+        // the opposite direction rides along: seed the train rows' state from the first rows of the query set, then one pass
+        launch::match_cols_seed(c->stream, (const uint8_t*)c->mm_q8.p, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, n_tiles * tr, thr,
+                                seed_bound, seed_rec, cbest, csecond);
+        launch::match_fp4_multi_mutual(c->stream, (const uint8_t*)c->mm_q8.p, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
+                                       (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p, cbest, csecond);
+        launch::match_compact_cols(c->stream, cbest, csecond, (const char*)d_chunks + tab_chunks, (uint32_t)n_sets, thr,
+                                   lowes_ratio * lowes_ratio, d_out_cols, (unsigned long long*)d_n_cols);
+    } else {
+        launch::match_mfma_multi(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
+                                 (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p, fp4);
+    }
     launch::match_compact_sets(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, (uint32_t)n_sets, cps, thr,
                                lowes_ratio * lowes_ratio, d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
+}
+int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
+                                     const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
+                                     double lowes_ratio, akz_match* d_out, uint64_t* d_n_out) {
+    return match_sets_impl(c, d_q, n0, d_train, set_rows, n_sets, distance_threshold, lowes_ratio, d_out, d_n_out, nullptr, nullptr);
+}
+// Both directions of every (query set, train set k) block from ONE pass over the distances (hamming is symmetric): besides
+// the lists of akz_descriptor_match_sets_device, the match list of set k's rows AS QUERIES against the query set as train
+// (feature_matching.rs:23-94 with the two sets exchanged) goes to d_out_cols + (rows of the sets before k), its length to
+// d_n_cols[k].  Identical to two akz_descriptor_match_device calls per block, at the matrix-core work of one.
+int akz_descriptor_match_sets_mutual_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
+                                            const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
+                                            double lowes_ratio, akz_match* d_out, uint64_t* d_n_out, akz_match* d_out_cols,
+                                            uint64_t* d_n_cols) {
+    if (!d_n_cols) {
+        set_error("descriptor_match_sets_mutual: null count output");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    return match_sets_impl(c, d_q, n0, d_train, set_rows, n_sets, distance_threshold, lowes_ratio, d_out, d_n_out, d_out_cols, d_n_cols);
 }
 
 int akz_descriptor_match(akz_ctx* c, const uint8_t* d0, uint64_t n0, const uint8_t* d1, uint64_t n1,

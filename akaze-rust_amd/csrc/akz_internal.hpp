@@ -248,6 +248,17 @@ void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, ui
                       const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out, bool fp4 = false);
 void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
                 uint32_t threshold, uint32_t* bound, uint32_t chunks, MatchRec* d_rec, bool fp4 = false);
+// both directions of a multi-set launch (FP4 form): see k_match_fp4<.., COLS> in akz_match.hip
+struct MatchColSetHost {  // = ColSet of akz_match.hip
+    uint32_t row0, rows, out0;
+};
+uint32_t match_cols_seed_rows(uint32_t n0);
+void match_cols_seed(hipStream_t s, const uint8_t* q4, uint32_t n0, const uint8_t* t4, uint32_t t_rows, uint32_t threshold,
+                     uint32_t* d_bound, MatchRec* d_seed, unsigned long long* cbest, uint32_t* csecond);
+void match_fp4_multi_mutual(hipStream_t s, const uint8_t* q4, uint32_t n0, const uint8_t* t4, const void* d_table, uint32_t n_chunks,
+                            uint32_t threshold, uint32_t* bound, MatchRec* d_out, unsigned long long* cbest, uint32_t* csecond);
+void match_compact_cols(hipStream_t s, const unsigned long long* cbest, const uint32_t* csecond, const void* d_sets, uint32_t n_sets,
+                        uint32_t threshold, double ratio2, akz_match* d_out, unsigned long long* d_n_out);
 // set k's `chunks` chunk records at d_rec + k * chunks * n0, its matches at d_out + k * n0, its count at d_n_out[k]
 void match_compact_sets(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t n_sets, uint32_t chunks, uint32_t threshold,
                         double ratio2, akz_match* d_out, unsigned long long* d_n_out);

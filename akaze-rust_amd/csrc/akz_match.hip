@@ -344,17 +344,39 @@ constexpr int kBits = 488;            // columns that carry +-1 (61 bytes)
 // NB: 32-query blocks per wave.  1 (used): 16 waves of 32 queries (1024 threads); 2: 8 waves of 64 queries (512 threads),
 // every train operand read from LDS feeding two matrix instructions -- measured 30 % SLOWER at 90 K rows (2.36 against
 // 1.80 ms, profiles/r03_match_variants.txt), as for the int8 form: the loop needs its 16 waves.
-template <int NB>
-__global__ void __launch_bounds__(1024 / NB) k_match_fp4(const uint8_t* __restrict__ q4, unsigned n0, const uint8_t* __restrict__ t4,
-                                                         unsigned n1, unsigned chunk_tiles, unsigned threshold,
-                                                         unsigned* __restrict__ bound, MatchRec* __restrict__ out,
-                                                         const MatchChunk* __restrict__ table) {
-    constexpr int NT = 1024 / NB;
-    static_assert(MM_SUB == 4 && MM_QB == 512 && (NB == 1 || NB == 2), "staging below: two 64-row parts per 128-row tile");
+#ifndef AKZ_MM4_NB
+#define AKZ_MM4_NB 1
+#endif
+#ifndef AKZ_MM4_NT
+#define AKZ_MM4_NT 1024
+#endif
+constexpr int MM4_QB = (AKZ_MM4_NT / 64) * 32 * AKZ_MM4_NB;  // queries per workgroup of the FP4 kernel
+// BOTH DIRECTIONS of a block in one pass (COLS; akz_descriptor_match_sets_mutual_device): hamming is symmetric, so the
+// distances of the queries to a train set are also the distances of that set's rows to the queries, and the match list
+// of the opposite direction (feature_matching.rs:23-94 with the two sets exchanged) needs, for every TRAIN row, the two
+// smallest distances over the queries and the lowest query index among the minima.  A train row's candidates sit in
+// different lanes, waves and workgroups, so its state lives in memory: cbest[row] = (distance << 32 | query), csecond[row],
+// both indexed by the row of the padded train image; an element enters with
+//     old = atomicMin(cbest, mine);  atomicMin(csecond, max(old, mine) >> 32)
+// (the second smallest distance is the smallest among the losers of the first exchange; the packed minimum keeps the lowest
+// query among equal distances).  Elements ABOVE the row's current csecond cannot be one of its final two and are skipped;
+// whether a sub-tile holds any candidate at all is decided from the lane's best distance -- which the row direction
+// computes anyway -- against the loosest csecond of the sub-tile's 32 rows, read once per tile.  The state starts from
+// the exact result over the first col_q0 queries (a separate small launch of this kernel with the roles exchanged,
+// launch::match_cols_seed): from a bound of thousands of samples on, a train row sees a dozen candidates in all.
+template <int NB, int NT, bool COLS = false>
+__global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4, unsigned n0, const uint8_t* __restrict__ t4,
+                                                  unsigned n1, unsigned chunk_tiles, unsigned threshold,
+                                                  unsigned* __restrict__ bound, MatchRec* __restrict__ out,
+                                                  const MatchChunk* __restrict__ table,
+                                                  unsigned long long* __restrict__ cbest = nullptr,
+                                                  unsigned* __restrict__ csecond = nullptr, unsigned col_q0 = 0) {
+    constexpr int QB = (NT / 64) * 32 * NB;
+    static_assert(MM_SUB == 4 && (NB == 1 || NB == 2) && (NT == 512 || NT == 1024), "staging below: two 64-row parts per 128-row tile");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH4];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
-    const unsigned q_first = blockIdx.x * MM_QB + wave * 32u * NB;
+    const unsigned q_first = blockIdx.x * QB + wave * 32u * NB;
     auto op = [](v4i x) { return v8i{x.x, x.y, x.z, x.w, 0, 0, 0, 0}; };  // FP4 operands occupy the first four registers
 
     v4i bq[NB][8];  // B operands: the wave's queries, eight K-steps of 64 columns, resident for the whole chunk
@@ -422,6 +444,20 @@ __global__ void __launch_bounds__(1024 / NB) k_match_fp4(const uint8_t* __restri
             limit[b] = min(limit[b], min(second[b], b_seen[b] < 0xffffffffu ? b_seen[b] + 1u : b_seen[b]));
             b_seen[b] = __hip_atomic_load(bound + q_first + 32 * b + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // COLS: the loosest csecond of each of the tile's four 32-row sub-tiles (lane l looks at rows 2l, 2l+1: a sub-tile
+        // is one 16-lane row of the wave, reduced with four DPP steps)
+        unsigned clim[4] = {0u, 0u, 0u, 0u};
+        if constexpr (COLS) {
+            const unsigned long long two = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(csecond + (size_t)tile * MM_TR) + lane,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned m = max((unsigned)two, (unsigned)(two >> 32));
+            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, false));  // row_shr:1
+            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x112, 0xf, 0xf, false));  // row_shr:2
+            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xf, 0xf, false));  // row_shr:4
+            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x118, 0xf, 0xf, false));  // row_shr:8
+#pragma unroll
+            for (int k = 0; k < 4; ++k) clim[k] = (unsigned)__builtin_amdgcn_readlane((int)m, 16 * k + 15);
+        }
 #pragma unroll
         for (int sub = 0; sub < MM_SUB; ++sub) {
             if (more && (sub & 1) == 0) fetch(tile + 1, sub >> 1);  // in flight under the MFMA chains below
@@ -452,6 +488,29 @@ __global__ void __launch_bounds__(1024 / NB) k_match_fp4(const uint8_t* __restri
 #pragma unroll
                 for (int i = 1; i < 16; ++i) topf = fmaxf(topf, acc[b][i]);
                 const int best = (kBits - (int)topf) >> 1;  // the smallest distance of the lane's 16 rows
+                bool col_hit = false;
+                if constexpr (COLS) {
+                    const unsigned q = q_first + 32 * b + r;
+                    col_hit = best <= (int)clim[sub] && q >= col_q0 && q < n0;
+                }
+                if (COLS && col_hit) {  // some row of the sub-tile may take this query as one of its two nearest
+                    const unsigned q = q_first + 32 * b + r;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned rowi = (unsigned)((i & 3) + 8 * (i >> 2));
+                        const unsigned d = (unsigned)((kBits - (int)acc[b][i]) >> 1);
+                        if (d <= clim[sub] && d < threshold && !(partial && j0 + rowi >= n1)) {
+                            const size_t prow = (size_t)tile * MM_TR + 32u * sub + 4u * h + rowi;
+                            const unsigned sec = __hip_atomic_load(csecond + prow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (d <= sec) {
+                                const unsigned long long mine = ((unsigned long long)d << 32) | q;
+                                const unsigned long long old = atomicMin(cbest + prow, mine);
+                                const unsigned loser = (unsigned)(max(old, mine) >> 32);
+                                if (loser < sec) atomicMin(csecond + prow, loser);
+                            }
+                        }
+                    }
+                }
                 if (partial || best < (int)limit[b]) {  // rare: see `limit` in k_match_mfma
                     int key[16];
 #pragma unroll
@@ -510,13 +569,72 @@ __global__ void __launch_bounds__(1024 / NB) k_match_fp4(const uint8_t* __restri
     }
 }
 
+// ---- the opposite direction's state and lists (COLS) ----------------------------------------------------------------
+// seed records (the train rows as queries against the first col_q0 rows of the query image) -> cbest / csecond
+__global__ void k_cols_init(const MatchRec* __restrict__ seed, unsigned rows, unsigned long long* __restrict__ cbest,
+                            unsigned* __restrict__ csecond) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const MatchRec m = seed[i];
+    cbest[i] = ((unsigned long long)m.min_d << 32) | m.min_j;
+    csecond[i] = m.second_d;
+}
+// One workgroup per train set: its rows' (best, second) -> Lowe ratio^2 + threshold test (feature_matching.rs:61-63) and
+// ordered compaction, as k_match_compact does for the query direction.  sets[k] = {first padded row, rows, first output}.
+struct ColSet {
+    unsigned row0, rows, out0;
+};
+__global__ void __launch_bounds__(1024) k_match_compact_cols(const unsigned long long* __restrict__ cbest,
+                                                             const unsigned* __restrict__ csecond, const ColSet* __restrict__ sets,
+                                                             unsigned threshold, double ratio2, akz_match* __restrict__ out,
+                                                             unsigned long long* __restrict__ n_out) {
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_base;
+    const ColSet cs = sets[blockIdx.x];
+    out += cs.out0;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (unsigned start = 0; start < cs.rows; start += 1024) {
+        const unsigned i = start + threadIdx.x;
+        bool keep = false;
+        unsigned min_d = 0, min_j = 0;
+        if (i < cs.rows) {
+            const unsigned long long b = cbest[(size_t)cs.row0 + i];
+            const unsigned second = csecond[(size_t)cs.row0 + i];
+            min_d = (unsigned)(b >> 32);
+            min_j = (unsigned)b;
+            keep = ((double)min_d < (double)second * ratio2) && (min_d < threshold);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        unsigned off = s_base;
+        for (unsigned wv = 0; wv < wave; ++wv) off += s_wave[wv];
+        if (keep) {
+            akz_match o;
+            o.index_0 = i; o.index_1 = min_j; o.distance = (double)min_d;
+            out[off + before] = o;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (unsigned wv = 0; wv < 16; ++wv) tot += s_wave[wv];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_out[blockIdx.x] = s_base;
+}
+
 }  // namespace
 
 namespace launch {
 
 // rows of the unpacked image of a set of n descriptors (queries: whole workgroups; train: whole tiles)
 uint32_t match_mfma_rows(uint32_t n, bool queries) {
-    const uint32_t m = queries ? (uint32_t)MM_QB : (uint32_t)MM_TR;
+    const uint32_t m = queries ? (uint32_t)std::max(MM_QB, MM4_QB) : (uint32_t)MM_TR;
     return (std::max<uint32_t>(n, 1) + m - 1) / m * m;
 }
 uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1, uint32_t forced) {
@@ -576,12 +694,42 @@ void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, ui
                       const void* d_table, uint32_t n_chunks, uint32_t threshold, uint32_t* bound, MatchRec* d_out, bool fp4) {
     if (n0 == 0 || n_chunks == 0) return;
     if (fp4) {
-        hipLaunchKernelGGL(k_match_fp4<1>, dim3((n0 + MM_QB - 1) / MM_QB, n_chunks), dim3(1024), 0, s, q8, n0, t8, 0u, 0u, threshold, bound,
-                               d_out, reinterpret_cast<const MatchChunk*>(d_table));
+        hipLaunchKernelGGL((k_match_fp4<AKZ_MM4_NB, AKZ_MM4_NT>), dim3((n0 + MM4_QB - 1) / MM4_QB, n_chunks), dim3(AKZ_MM4_NT), 0, s, q8, n0, t8, 0u, 0u,
+                           threshold, bound, d_out, reinterpret_cast<const MatchChunk*>(d_table));
         return;
     }
     hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, n_chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, 0u, 0u,
                        threshold, bound, d_out, reinterpret_cast<const MatchChunk*>(d_table));
+}
+// Both directions (FP4 form only).  match_cols_seed: the padded train image's rows as QUERIES against the first seed_rows
+// (a multiple of the tile height, or all n0 if fewer) rows of the query image -> exact (best, second) of every train row
+// over those queries in cbest / csecond; d_bound / d_seed: scratch of t_rows_pad u32 / MatchRec (t_rows_pad: the padded
+// train rows rounded up to whole query blocks; both images are allocated to that).
+uint32_t match_cols_seed_rows(uint32_t n0) { return std::min<uint32_t>(n0, 4u * MM_TR); }
+void match_cols_seed(hipStream_t s, const uint8_t* q4, uint32_t n0, const uint8_t* t4, uint32_t t_rows, uint32_t threshold,
+                     uint32_t* d_bound, MatchRec* d_seed, unsigned long long* cbest, uint32_t* csecond) {
+    const uint32_t seed = match_cols_seed_rows(n0);
+    if (t_rows == 0) return;
+    (void)hipMemsetAsync(d_bound, 0xff, (size_t)match_mfma_rows(t_rows, true) * sizeof(uint32_t), s);  // no pruning bound yet
+    const uint32_t tiles = (std::max<uint32_t>(seed, 1) + MM_TR - 1) / MM_TR;
+    hipLaunchKernelGGL((k_match_fp4<AKZ_MM4_NB, AKZ_MM4_NT>), dim3((t_rows + MM4_QB - 1) / MM4_QB, 1), dim3(AKZ_MM4_NT), 0, s, t4, t_rows, q4,
+                       seed, tiles, threshold, d_bound, d_seed, (const MatchChunk*)nullptr, (unsigned long long*)nullptr,
+                       (unsigned*)nullptr, 0u);
+    hipLaunchKernelGGL(k_cols_init, dim3((t_rows + 255) / 256), dim3(256), 0, s, d_seed, t_rows, cbest, csecond);
+}
+// the multi-set launch with the opposite direction riding along (queries from seed_rows on)
+void match_fp4_multi_mutual(hipStream_t s, const uint8_t* q4, uint32_t n0, const uint8_t* t4, const void* d_table, uint32_t n_chunks,
+                            uint32_t threshold, uint32_t* bound, MatchRec* d_out, unsigned long long* cbest, uint32_t* csecond) {
+    if (n0 == 0 || n_chunks == 0) return;
+    hipLaunchKernelGGL((k_match_fp4<AKZ_MM4_NB, AKZ_MM4_NT, true>), dim3((n0 + MM4_QB - 1) / MM4_QB, n_chunks), dim3(AKZ_MM4_NT), 0, s, q4, n0,
+                       t4, 0u, 0u, threshold, bound, d_out, reinterpret_cast<const MatchChunk*>(d_table), cbest, csecond,
+                       match_cols_seed_rows(n0));
+}
+void match_compact_cols(hipStream_t s, const unsigned long long* cbest, const uint32_t* csecond, const void* d_sets, uint32_t n_sets,
+                        uint32_t threshold, double ratio2, akz_match* d_out, unsigned long long* d_n_out) {
+    if (n_sets == 0) return;
+    hipLaunchKernelGGL(k_match_compact_cols, dim3(n_sets), dim3(1024), 0, s, cbest, csecond, reinterpret_cast<const ColSet*>(d_sets),
+                       threshold, ratio2, d_out, d_n_out);
 }
 // records of every query over `chunks` chunks of the train set: d_rec[chunk * n0 + query] (merged by match_compact)
 void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t n0, const uint8_t* t8, uint32_t n1,
@@ -590,8 +738,8 @@ void match_mfma(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, uint32_t
     const uint32_t tiles = (std::max<uint32_t>(n1, 1) + MM_TR - 1) / MM_TR;
     const uint32_t chunk_tiles = (tiles + chunks - 1) / chunks;
     if (fp4) {
-        hipLaunchKernelGGL(k_match_fp4<1>, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(1024), 0, s, q8, n0, t8, n1, chunk_tiles, threshold,
-                               bound, d_rec, (const MatchChunk*)nullptr);
+        hipLaunchKernelGGL((k_match_fp4<AKZ_MM4_NB, AKZ_MM4_NT>), dim3((n0 + MM4_QB - 1) / MM4_QB, chunks), dim3(AKZ_MM4_NT), 0, s, q8, n0, t8, n1,
+                           chunk_tiles, threshold, bound, d_rec, (const MatchChunk*)nullptr);
         return;
     }
     hipLaunchKernelGGL(k_match_mfma, dim3((n0 + MM_QB - 1) / MM_QB, chunks), dim3(MM_NT), 0, s, q8, qpop, n0, t8, n1,

@@ -193,6 +193,7 @@ def lib():
         "akz_ctx_set_match_mode": ([vp, i32], i32),
         "akz_ctx_set_candidate_hint": ([vp, u32], i32),
         "akz_descriptor_match_sets_device": ([vp, vp, u64, vp, C.POINTER(u64), u64, u64, f64, vp, vp], i32),
+        "akz_descriptor_match_sets_mutual_device": ([vp, vp, u64, vp, C.POINTER(u64), u64, u64, f64, vp, vp, vp, vp], i32),
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
@@ -540,6 +541,24 @@ class Context:
                                                       distance_threshold, lowes_ratio, C.c_void_p(out.data_ptr()),
                                                       C.c_void_p(cnt.data_ptr())))
         return out, cnt[:ns]
+
+    def descriptor_match_sets_mutual_device(self, q, train, rows, distance_threshold=10000, lowes_ratio=0.86):
+        """descriptor_match_sets_device plus the opposite direction of every block from the same pass: returns (matches,
+        counts, col_matches [sum(rows), 24] uint8 -- set k's list starts at row sum(rows[:k]) --, col_counts [n_sets])."""
+        import torch
+        n0, ns, tot = int(q.shape[0]), len(rows), int(sum(rows))
+        out = torch.empty((ns, max(n0, 1), 24), dtype=torch.uint8, device=q.device)
+        if n0 == 0:
+            out = out[:, :0]
+        cnt = torch.zeros(max(ns, 1), dtype=torch.int64, device=q.device)
+        cout = torch.empty((max(tot, 1), 24), dtype=torch.uint8, device=q.device)
+        ccnt = torch.zeros(max(ns, 1), dtype=torch.int64, device=q.device)
+        arr = (C.c_uint64 * max(ns, 1))(*[int(r) for r in rows])
+        _check(lib().akz_descriptor_match_sets_mutual_device(
+            self._h, C.c_void_p(q.data_ptr()) if n0 else None, n0, C.c_void_p(train.data_ptr()) if tot else None, arr, ns,
+            distance_threshold, lowes_ratio, C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()), C.c_void_p(cout.data_ptr()),
+            C.c_void_p(ccnt.data_ptr())))
+        return out, cnt[:ns], cout[:tot], ccnt[:ns]
 
     def descriptor_match_device(self, d0, d1, distance_threshold=10000, lowes_ratio=0.86):
         """Same on torch CUDA uint8 tensors of 64-byte descriptor rows; returns (matches tensor view, count)."""

@@ -297,6 +297,17 @@ int akz_descriptor_match_device(akz_ctx* ctx, const uint8_t* d_d0, uint64_t n0, 
 int akz_descriptor_match_sets_device(akz_ctx* ctx, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
                                      const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
                                      double lowes_ratio, akz_match* d_out, uint64_t* d_n_out);
+/* The same launch with the OPPOSITE direction riding along: hamming(a, b) = hamming(b, a), so one pass over the distances of
+   a (query set, train set k) block yields both descriptor_match(query set, set k) -- rows as above -- and
+   descriptor_match(set k, query set) (feature_matching.rs:23-94 with the arguments exchanged: index_0 a row of set k,
+   index_1 a row of the query set, lowest index among equal minima): its matches go to d_out_cols + (number of rows of the
+   sets before k) (room for set_rows[k]), its count to d_n_cols[k] (device uint64).  Identical to 2 * n_sets calls of
+   akz_descriptor_match_device at the matrix-core work of n_sets.  (On the FP4 matcher, the default; the other matcher
+   kernels compute the second direction separately.) */
+int akz_descriptor_match_sets_mutual_device(akz_ctx* ctx, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
+                                            const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
+                                            double lowes_ratio, akz_match* d_out, uint64_t* d_n_out, akz_match* d_out_cols,
+                                            uint64_t* d_n_cols);
 
 /* ---- multi-GPU: the path's one exchange step ----------------------- */
 /* extract_features has no cross-image state (akaze/src/lib.rs:167-194): images are sharded one per GPU slot and

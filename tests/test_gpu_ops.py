@@ -295,6 +295,55 @@ def test_descriptor_match_sets(ctx, ref, mode):
     finally:
         ctx.set_match_mode(2)
 
+@pytest.mark.parametrize("mode", [3, 1, 0])
+@pytest.mark.parametrize("n_q", [700, 90, 5000])
+def test_descriptor_match_sets_mutual(ctx, ref, mode, n_q):
+    """Both directions of every (query set, train set) block from one pass (akz_descriptor_match_sets_mutual_device): the
+    query direction as test_descriptor_match_sets, and for every train set its rows as queries against the query set --
+    equal to the oracle's descriptor_match with the arguments exchanged.  Many exact duplicates (ties must resolve to the
+    lowest index in BOTH directions), query sets shorter than / equal to / far beyond the seed rows, set sizes around
+    the tile height, an empty set, thresholds that cut, several query blocks (concurrent updates of one train row)."""
+    import torch
+    rng = np.random.default_rng(1234 + n_q)
+    base = rng.integers(0, 256, (48, 61), dtype=np.uint8)
+
+    def make(n):
+        d = base[rng.integers(0, 48, n)].copy()
+        d[rng.random(d.shape) < 0.03] ^= 0x42
+        return d
+
+    def rows64(d):
+        r = np.zeros((len(d), 64), np.uint8)
+        r[:, :61] = d
+        return r
+
+    q = make(n_q)
+    sets = [make(n) for n in (129, 0, 1, 128, 1000, 37, 2051, 640)]
+    dq = torch.from_numpy(rows64(q)).cuda()
+    cat = torch.from_numpy(np.concatenate([rows64(t) for t in sets])).cuda()
+    rows = [len(t) for t in sets]
+    ctx.set_match_mode(mode)
+    try:
+        for ratio, thr in ((0.86, 10000), (1.2, 10000), (0.95, 9)):
+            out, cnt, cout, ccnt = ctx.descriptor_match_sets_mutual_device(dq, cat, rows, thr, ratio)
+            ctx.synchronize()
+            out, cnt, cout, ccnt = out.cpu().numpy(), cnt.cpu().numpy(), cout.cpu().numpy(), ccnt.cpu().numpy()
+            off = total = 0
+            for k, t in enumerate(sets):
+                got = out[k][:int(cnt[k])].copy().view(ctx_match_dtype()).reshape(-1)
+                assert np.array_equal(got, ref.descriptor_match(q, t, thr, ratio)), (mode, ratio, thr, k, "query direction")
+                gotc = cout[off:off + int(ccnt[k])].copy().view(ctx_match_dtype()).reshape(-1)
+                expc = ref.descriptor_match(t, q, thr, ratio)
+                assert np.array_equal(gotc, expc), (mode, n_q, ratio, thr, k, len(gotc), len(expc), "opposite direction")
+                off += len(t)
+                total += len(expc)
+            assert total > 50
+        out, cnt, cout, ccnt = ctx.descriptor_match_sets_mutual_device(dq[:0], cat, rows)
+        assert int(cnt.sum().item()) == 0 and int(ccnt.sum().item()) == 0
+    finally:
+        ctx.set_match_mode(2)
+
+
 
 def ctx_match_dtype():
     import akaze_amd

@@ -2529,18 +2529,25 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
 // One query set against several train sets in ONE matrix-core launch (all-pairs matching: a query image against
 // the descriptor sets of all other images).  A pair of 11 K-row sets alone runs at 1.2 T pairs/s, a launch over
 // many sets at the rate of one large product (3 T pairs/s), and every set is unpacked once per call.
+// set_first (optional): first row of set k inside d_train (sets anywhere in one block of rows, e.g. a gather's); without
+// it the sets follow each other
 static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train, const uint64_t* set_rows,
                            uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out, uint64_t* d_n_out,
-                           akz_match* d_out_cols, uint64_t* d_n_cols) {
+                           akz_match* d_out_cols, uint64_t* d_n_cols, const uint64_t* set_first = nullptr) {
     AKZ_TRY(bind(c, true, false));
     const bool cols = d_n_cols != nullptr;  // the opposite direction too: every set's rows against the query set
     if ((n0 && !d_out) || !d_n_out || (n_sets && !set_rows) || (n0 && !d_q) || n0 > 0x7fffffffull || n_sets > 65535) {
         set_error("descriptor_match_sets: bad arguments");
         return AKZ_ERR_INVALID_ARG;
     }
-    uint64_t total_rows = 0;
-    for (uint64_t k = 0; k < n_sets; ++k) total_rows += set_rows[k];
-    if ((total_rows && !d_train) || total_rows > 0x7fffffffull) {
+    uint64_t total_rows = 0, last_row = 0;
+    std::vector<uint64_t> first(n_sets);  // first row of every set in d_train
+    for (uint64_t k = 0; k < n_sets; ++k) {
+        first[(size_t)k] = set_first ? set_first[k] : total_rows;
+        total_rows += set_rows[k];
+        last_row = std::max(last_row, first[(size_t)k] + set_rows[k]);
+    }
+    if ((total_rows && !d_train) || total_rows > 0x7fffffffull || last_row > 0xffffffffull) {
         set_error("descriptor_match_sets: bad train sets");
         return AKZ_ERR_INVALID_ARG;
     }
@@ -2559,18 +2566,15 @@ static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const ui
         for (uint64_t k = 0; k < n_sets; ++k) {
             if (set_rows[k] == 0) AKZ_HIP_TRY(hipMemsetAsync(d_n_cols + k, 0, sizeof(uint64_t), c->stream));
             else
-                AKZ_TRY(match_device_impl(c, d_train + off * 64, set_rows[k], d_q, n0, distance_threshold, lowes_ratio, d_out_cols + off,
-                                          d_n_cols + k, true));
+                AKZ_TRY(match_device_impl(c, d_train + first[(size_t)k] * 64, set_rows[k], d_q, n0, distance_threshold, lowes_ratio,
+                                          d_out_cols + off, d_n_cols + k, true));
             off += set_rows[k];
         }
     }
     if (c->match_mode == 0) {  // popcount kernel: set by set
-        uint64_t off = 0;
-        for (uint64_t k = 0; k < n_sets; ++k) {
-            AKZ_TRY(match_device_impl(c, d_q, n0, d_train + off * 64, set_rows[k], distance_threshold, lowes_ratio,
+        for (uint64_t k = 0; k < n_sets; ++k)
+            AKZ_TRY(match_device_impl(c, d_q, n0, d_train + first[(size_t)k] * 64, set_rows[k], distance_threshold, lowes_ratio,
                                       d_out + k * n0, d_n_out + k, true));
-            off += set_rows[k];
-        }
         return AKZ_OK;
     }
     const bool mutual = cols && c->match_mode >= 2;
@@ -2592,7 +2596,7 @@ static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const ui
         const uint32_t t0 = (uint32_t)(tiles.size() / 2), rows = (uint32_t)set_rows[k];
         if (mutual) colsets[(size_t)k] = launch::MatchColSetHost{t0 * tr, rows, (uint32_t)src};
         for (uint32_t r = 0; r < rows; r += tr) {
-            tiles.push_back((uint32_t)(src + r));
+            tiles.push_back((uint32_t)(first[(size_t)k] + r));
             tiles.push_back(std::min(tr, rows - r));
         }
         const uint32_t t1 = (uint32_t)(tiles.size() / 2), per = (t1 - t0 + cps - 1) / cps;
@@ -2675,6 +2679,15 @@ static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const ui
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
 }
+}  // extern "C"
+// (akz_comm.cpp: the all-pairs match takes its sets where they lie in the gathered block)
+int akz::match_sets_at(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_rows, const uint64_t* set_first,
+                       const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
+                       uint64_t* d_n_out, akz_match* d_out_cols, uint64_t* d_n_cols) {
+    return match_sets_impl(c, d_q, n0, d_rows, set_rows, n_sets, distance_threshold, lowes_ratio, d_out, d_n_out, d_out_cols, d_n_cols,
+                           set_first);
+}
+extern "C" {
 int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,
                                      const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold,
                                      double lowes_ratio, akz_match* d_out, uint64_t* d_n_out) {

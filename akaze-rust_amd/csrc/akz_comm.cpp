@@ -109,8 +109,11 @@ struct akz_gather {
     std::vector<uint64_t> hdr_rows, hdr_images;      // per rank, from the headers
     std::vector<std::vector<uint64_t>> image_rows;   // per rank: rows of every image of its shard
     std::vector<uint64_t> table;                     // this rank's per-image table, staged for the send block
+    hipEvent_t readers = nullptr;                    // akz_match_all_pairs: its copies out of recv have run (another stream)
+    bool readers_pending = false;
 };
 
+static void pairs_destroy(akz_pairs* p);  // (defined with akz_pairs, below)
 struct akz_comm {
     int device = 0, rank = 0, nranks = 1;
     ncclComm_t nccl = nullptr;
@@ -122,6 +125,7 @@ struct akz_comm {
     size_t sync_out_bytes = 0;
     uint64_t sequence = 0;
     std::vector<akz_gather*> pool;  // every gather object ever handed out (reused when free and large enough)
+    std::vector<akz_pairs*> pairs_pool;  // freed all-pairs results: device block, pinned counts and event are reused
 };
 
 static void gather_release_buffers(akz_gather* g) {
@@ -129,6 +133,9 @@ static void gather_release_buffers(akz_gather* g) {
     if (g->recv) (void)hipFree(g->recv);
     if (g->pinned) (void)hipHostFree(g->pinned);
     if (g->done) (void)hipEventDestroy(g->done);
+    if (g->readers) (void)hipEventDestroy(g->readers);
+    g->readers = nullptr;
+    g->readers_pending = false;
     g->send = g->recv = nullptr;
     g->pinned = nullptr;
     g->done = nullptr;
@@ -192,6 +199,10 @@ static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_sr
     // a shard that does not fit still takes part (header only, marked): a rank that skipped the collective would leave
     // every other rank waiting in it, and every later collective of the communicator mismatched
     g->overflow = rows + table_rows > g->cap_rows;
+    if (g->readers_pending) {  // an all-pairs match of the step before still copies out of these buffers on its own stream
+        AKZ_HIP_TRY(hipStreamWaitEvent(c->cs, g->readers, 0));
+        g->readers_pending = false;
+    }
     if (producer) {  // the rows are complete in the order of this stream
         AKZ_HIP_TRY(hipEventRecord(c->ready, producer));
         AKZ_HIP_TRY(hipStreamWaitEvent(c->cs, c->ready, 0));
@@ -278,6 +289,8 @@ int akz_comm_destroy(akz_comm* c) {
         delete g;
     }
     c->pool.clear();
+    for (akz_pairs* p : c->pairs_pool) pairs_destroy(p);
+    c->pairs_pool.clear();
     if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->copied) (void)hipEventDestroy(c->copied);
@@ -500,19 +513,50 @@ int akz_gather_descriptors(akz_comm* c, const uint8_t* d_local, uint64_t n_local
 }
 
 // ---- all-pairs match over a finished gather (BASELINE configs[4]) ------------------------------------------------------
+// Every unordered image pair {a, b} of the job is matched ONCE, in both directions, by the rank that owns its LEAD image
+// (pairs_lead below: a balanced rule, every image leads about half of its pairs).  The lead image is the query set of one
+// both-direction launch (akz_descriptor_match_sets_mutual_device) against the images it leads, taken where they lie in
+// the gathered block; hamming(a, b) = hamming(b, a), so the launch's matrix-core work serves descriptor_match(a, b) AND
+// descriptor_match(b, a).  Round 3 matched every ORDERED pair (and every image against itself): 2.1 x the work.
 }  // extern "C"
 struct akz_pairs {
     akz_ctx* ctx = nullptr;
+    akz_comm* comm = nullptr;
     int device = 0;
-    uint8_t* d_all = nullptr;            // rows of every image of the job, rank-major, compacted
-    uint8_t* d_block = nullptr;          // the records and counts of all owned images
-    std::vector<uint64_t> rows, offset;  // per image
+    uint8_t* d_block = nullptr;          // the gathered rows (compacted, rank-major), then every list and count
+    size_t block_bytes = 0;
+    uint64_t* h_cnt = nullptr;           // pinned: the counts of every list, copied behind the launches
+    size_t h_cnt_entries = 0;
+    hipEvent_t done = nullptr;           // the counts have arrived
+    bool waited = false;
+    std::vector<uint64_t> rows, offset;  // per image: rows, first row in the compacted block
     std::vector<int> owner;
     uint64_t first_owned = 0, n_owned = 0;
-    std::vector<akz_match*> d_out;       // per owned image: n_images x rows(query) records
-    std::vector<uint64_t*> d_cnt;        // per owned image: n_images counts
-    std::vector<std::vector<uint64_t>> cnt;
+    struct Lead {                        // one per owned image
+        std::vector<uint64_t> sets;      // the images it leads, ascending
+        std::vector<uint64_t> col0;      // first record of set k's opposite-direction list
+        akz_match *d_rows = nullptr, *d_cols = nullptr;  // [sets][rows of the lead], [sum of the sets' rows]
+        size_t cnt0 = 0;                 // index of its counts in h_cnt: sets.size() (lead -> set) then sets.size() (set -> lead)
+    };
+    std::vector<Lead> lead;
 };
+// the image of an unordered pair that serves as the query set of its block
+static uint64_t pairs_lead(uint64_t a, uint64_t b) {
+    const uint64_t lo = std::min(a, b), hi = std::max(a, b);
+    return ((hi - lo) & 1u) ? lo : hi;
+}
+static void pairs_destroy(akz_pairs* p) {
+    if (!p) return;
+    if (p->d_block) (void)hipFree(p->d_block);
+    if (p->h_cnt) (void)hipHostFree(p->h_cnt);
+    if (p->done) (void)hipEventDestroy(p->done);
+    delete p;
+}
+static void pairs_release(akz_pairs* p) {  // back to the communicator's pool (device block, pinned counts, event stay with it)
+    if (!p) return;
+    if (p->comm) p->comm->pairs_pool.push_back(p);
+    else pairs_destroy(p);
+}
 extern "C" {
 
 int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold, double lowes_ratio, akz_pairs** out) {
@@ -527,9 +571,25 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     uint64_t block_rows = 0;
     AKZ_TRY(akz_gather_finish(g, &blocks, &block_rows, nullptr, nullptr));
     AKZ_HIP_TRY(hipSetDevice(c->device));
-    std::unique_ptr<akz_pairs, int (*)(akz_pairs*)> p(new akz_pairs, akz_pairs_free);
+    // a pairs object of an earlier step whose buffers can be reused (steady state: no allocation)
+    akz_pairs* p = nullptr;
+    if (!c->pairs_pool.empty()) {
+        p = c->pairs_pool.back();
+        c->pairs_pool.pop_back();
+    } else {
+        p = new akz_pairs;
+    }
+    struct Back {  // on any error the object returns to the pool
+        akz_pairs* p;
+        bool armed = true;
+        ~Back() { if (armed) pairs_release(p); }
+    } back{p};
     p->ctx = ctx;
+    p->comm = c;
     p->device = c->device;
+    p->waited = false;
+    p->rows.clear(); p->offset.clear(); p->owner.clear(); p->lead.clear();
+    p->first_owned = p->n_owned = 0;
     uint64_t total = 0;
     for (int r = 0; r < c->nranks; ++r) {
         if (r == c->rank) p->first_owned = p->rows.size();
@@ -548,41 +608,82 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
         total += in_rank;
     }
     const uint64_t n_images = p->rows.size();
-    AKZ_HIP_TRY(hipMalloc((void**)&p->d_all, std::max<uint64_t>(1, total) * kRow));
-    hipStream_t ms = (hipStream_t)akz_ctx_stream(ctx);  // the matcher's stream: the compaction copies run on it, in front of the launches
+    // layout of the block: rows | per lead: lists lead -> set, lists set -> lead | counts
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t bytes = up(std::max<uint64_t>(1, total) * kRow), n_cnt = 0;
+    p->lead.resize((size_t)p->n_owned);
+    std::vector<size_t> off_rows((size_t)p->n_owned), off_cols((size_t)p->n_owned);
+    for (uint64_t k = 0; k < p->n_owned; ++k) {
+        akz_pairs::Lead& L = p->lead[(size_t)k];
+        const uint64_t q = p->first_owned + k;
+        uint64_t col_rows = 0;
+        for (uint64_t j = 0; j < n_images; ++j)
+            if (j != q && pairs_lead(q, j) == q) {
+                L.sets.push_back(j);
+                L.col0.push_back(col_rows);
+                col_rows += p->rows[(size_t)j];
+            }
+        off_rows[(size_t)k] = bytes;
+        bytes += up(std::max<uint64_t>(1, L.sets.size() * p->rows[(size_t)q]) * sizeof(akz_match));
+        off_cols[(size_t)k] = bytes;
+        bytes += up(std::max<uint64_t>(1, col_rows) * sizeof(akz_match));
+        L.cnt0 = n_cnt;
+        n_cnt += 2 * L.sets.size();
+    }
+    const size_t off_cnt = bytes;
+    bytes += up(std::max<size_t>(1, n_cnt) * sizeof(uint64_t));
+    hipStream_t ms = (hipStream_t)akz_ctx_stream(ctx);  // the matcher's stream: everything below is enqueued on it, in order
+    if (p->block_bytes < bytes) {
+        if (p->d_block) {
+            AKZ_HIP_TRY(hipStreamSynchronize(ms));  // (an earlier step's launches may still read the old block)
+            AKZ_HIP_TRY(hipFree(p->d_block));
+        }
+        p->d_block = nullptr;
+        p->block_bytes = 0;
+        AKZ_HIP_TRY(hipMalloc((void**)&p->d_block, bytes + bytes / 4));
+        p->block_bytes = bytes + bytes / 4;
+    }
+    if (p->h_cnt_entries < std::max<size_t>(1, n_cnt)) {
+        if (p->h_cnt) AKZ_HIP_TRY(hipHostFree(p->h_cnt));
+        p->h_cnt = nullptr;
+        p->h_cnt_entries = 0;
+        AKZ_HIP_TRY(hipHostMalloc((void**)&p->h_cnt, std::max<size_t>(1, n_cnt) * 2 * sizeof(uint64_t), hipHostMallocDefault));
+        p->h_cnt_entries = std::max<size_t>(1, n_cnt) * 2;
+    }
+    if (!p->done) AKZ_HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+    // the gathered rows, compacted: the gather's buffers go back to the communicator as soon as these copies have run
     uint64_t at = 0;
     for (int r = 0; r < c->nranks; ++r) {
         const uint64_t n = g->hdr_rows[(size_t)r];
         if (n)
-            AKZ_HIP_TRY(hipMemcpyAsync(p->d_all + at * kRow, blocks + ((uint64_t)r * block_rows + 1) * kRow, n * kRow,
+            AKZ_HIP_TRY(hipMemcpyAsync(p->d_block + at * kRow, blocks + ((uint64_t)r * block_rows + 1) * kRow, n * kRow,
                                        hipMemcpyDeviceToDevice, ms));
         at += n;
     }
-    p->d_out.assign((size_t)p->n_owned, nullptr);
-    p->d_cnt.assign((size_t)p->n_owned, nullptr);
-    p->cnt.assign((size_t)p->n_owned, std::vector<uint64_t>((size_t)n_images, 0));
-    // one block for every owned image's records and counts (a device allocation per image cost more than its launch)
-    size_t bytes = 0;
-    std::vector<size_t> off_out((size_t)p->n_owned), off_cnt((size_t)p->n_owned);
+    if (!g->readers) AKZ_HIP_TRY(hipEventCreateWithFlags(&g->readers, hipEventDisableTiming));
+    AKZ_HIP_TRY(hipEventRecord(g->readers, ms));
+    g->readers_pending = true;
+    uint64_t* d_cnt = (uint64_t*)(p->d_block + off_cnt);
+    if (n_cnt) AKZ_HIP_TRY(hipMemsetAsync(d_cnt, 0, n_cnt * sizeof(uint64_t), ms));
     for (uint64_t k = 0; k < p->n_owned; ++k) {
-        const uint64_t n0 = p->rows[(size_t)(p->first_owned + k)];
-        off_out[(size_t)k] = bytes;
-        bytes += (std::max<uint64_t>(1, n0 * n_images) * sizeof(akz_match) + 255) / 256 * 256;
-        off_cnt[(size_t)k] = bytes;
-        bytes += (n_images * sizeof(uint64_t) + 255) / 256 * 256;
+        akz_pairs::Lead& L = p->lead[(size_t)k];
+        const uint64_t q = p->first_owned + k;
+        L.d_rows = (akz_match*)(p->d_block + off_rows[(size_t)k]);
+        L.d_cols = (akz_match*)(p->d_block + off_cols[(size_t)k]);
+        if (L.sets.empty()) continue;
+        std::vector<uint64_t> first, rows;
+        for (uint64_t j : L.sets) {
+            first.push_back(p->offset[(size_t)j]);
+            rows.push_back(p->rows[(size_t)j]);
+        }
+        AKZ_TRY(akz::match_sets_at(ctx, p->d_block + p->offset[(size_t)q] * kRow, p->rows[(size_t)q], p->d_block, first.data(), rows.data(),
+                                   L.sets.size(), distance_threshold, lowes_ratio, L.d_rows, d_cnt + L.cnt0, L.d_cols,
+                                   d_cnt + L.cnt0 + L.sets.size()));
     }
-    AKZ_HIP_TRY(hipMalloc((void**)&p->d_block, std::max<size_t>(bytes, 256)));
-    for (uint64_t k = 0; k < p->n_owned; ++k) {
-        const uint64_t q = p->first_owned + k, n0 = p->rows[(size_t)q];
-        p->d_out[(size_t)k] = (akz_match*)(p->d_block + off_out[(size_t)k]);
-        p->d_cnt[(size_t)k] = (uint64_t*)(p->d_block + off_cnt[(size_t)k]);
-        AKZ_TRY(akz_descriptor_match_sets_device(ctx, p->d_all + p->offset[(size_t)q] * kRow, n0, p->d_all, p->rows.data(), n_images,
-                                                 distance_threshold, lowes_ratio, p->d_out[(size_t)k], p->d_cnt[(size_t)k]));
-    }
-    for (uint64_t k = 0; k < p->n_owned; ++k)
-        AKZ_HIP_TRY(hipMemcpyAsync(p->cnt[(size_t)k].data(), p->d_cnt[(size_t)k], n_images * sizeof(uint64_t), hipMemcpyDeviceToHost, ms));
-    AKZ_HIP_TRY(hipStreamSynchronize(ms));
-    *out = p.release();
+    if (n_cnt) AKZ_HIP_TRY(hipMemcpyAsync(p->h_cnt, d_cnt, n_cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, ms));
+    AKZ_HIP_TRY(hipEventRecord(p->done, ms));
+    back.armed = false;
+    *out = p;
     return AKZ_OK;
 }
 int akz_pairs_info(const akz_pairs* p, uint64_t* n_images, uint64_t* first_owned, uint64_t* n_owned) {
@@ -598,28 +699,51 @@ int akz_pairs_image_rows(const akz_pairs* p, uint64_t image, uint64_t* rows, int
     if (owner_rank) *owner_rank = p->owner[(size_t)image];
     return AKZ_OK;
 }
-int akz_pairs_matches(const akz_pairs* p, uint64_t query, uint64_t image, akz_match* out, uint64_t cap, uint64_t* n) {
-    if (!p || !n || query < p->first_owned || query >= p->first_owned + p->n_owned || image >= p->rows.size()) {
-        set_error("akz_pairs_matches: the query must be an image this rank owns, the image one of the job");
+int akz_pairs_holder(const akz_pairs* p, uint64_t image_a, uint64_t image_b, int* rank) {
+    if (!p || !rank || image_a >= p->rows.size() || image_b >= p->rows.size() || image_a == image_b) {
+        set_error("akz_pairs_holder: two different images of the job");
         return AKZ_ERR_INVALID_ARG;
     }
-    const size_t k = (size_t)(query - p->first_owned);
-    const uint64_t cnt = image == query ? 0 : p->cnt[k][(size_t)image];
+    *rank = p->owner[(size_t)pairs_lead(image_a, image_b)];
+    return AKZ_OK;
+}
+int akz_pairs_matches(const akz_pairs* pc, uint64_t query, uint64_t image, akz_match* out, uint64_t cap, uint64_t* n) {
+    akz_pairs* p = const_cast<akz_pairs*>(pc);
+    if (!p || !n || query >= p->rows.size() || image >= p->rows.size()) {
+        set_error("akz_pairs_matches: images of the job");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    *n = 0;
+    if (query == image) return AKZ_OK;  // (an image is not matched against itself)
+    const uint64_t lead = pairs_lead(query, image);
+    if (lead < p->first_owned || lead >= p->first_owned + p->n_owned) {
+        set_error("akz_pairs_matches: this pair was matched by the rank akz_pairs_holder names");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const akz_pairs::Lead& L = p->lead[(size_t)(lead - p->first_owned)];
+    const uint64_t other = lead == query ? image : query;
+    const size_t k = (size_t)(std::lower_bound(L.sets.begin(), L.sets.end(), other) - L.sets.begin());
+    AKZ_HIP_TRY(hipSetDevice(p->device));
+    if (!p->waited) {
+        AKZ_HIP_TRY(hipEventSynchronize(p->done));
+        p->waited = true;
+    }
+    const bool forward = lead == query;  // the lead's rows are the queries of the list asked for
+    const uint64_t cnt = p->h_cnt[L.cnt0 + (forward ? 0 : L.sets.size()) + k];
     *n = cnt;
     const uint64_t take = std::min(cnt, cap);
     if (out && take) {
-        AKZ_HIP_TRY(hipSetDevice(p->device));
-        AKZ_HIP_TRY(hipMemcpy(out, p->d_out[k] + image * p->rows[(size_t)query], take * sizeof(akz_match), hipMemcpyDeviceToHost));
+        const akz_match* src = forward ? L.d_rows + k * p->rows[(size_t)lead] : L.d_cols + L.col0[k];
+        AKZ_HIP_TRY(hipMemcpy(out, src, take * sizeof(akz_match), hipMemcpyDeviceToHost));
     }
     return AKZ_OK;
 }
 int akz_pairs_free(akz_pairs* p) {
     if (!p) return AKZ_OK;
     (void)hipSetDevice(p->device);
-    if (p->ctx) (void)akz_ctx_synchronize(p->ctx);
-    if (p->d_all) (void)hipFree(p->d_all);
-    if (p->d_block) (void)hipFree(p->d_block);
-    delete p;
+    // the buffers go back to the communicator's pool: the next step's launches are ordered behind this step's on the
+    // matcher's stream, and a reader of this object has waited for `done`
+    pairs_release(p);
     return AKZ_OK;
 }
 

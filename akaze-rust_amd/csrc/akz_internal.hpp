@@ -46,6 +46,12 @@ DefaultSource& default_source();
         if (_s != AKZ_OK) return _s; \
     } while (0)
 
+// one query set against sets that lie anywhere in one block of 64-byte rows (set k: rows set_first[k] .. + set_rows[k]);
+// with d_n_cols also the opposite direction of every block (akz_descriptor_match_sets_mutual_device) -- akz_api.cpp
+int match_sets_at(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_rows, const uint64_t* set_first,
+                  const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
+                  uint64_t* d_n_out, akz_match* d_out_cols, uint64_t* d_n_cols);
+
 // ---- host-side planning (akz_plan.cpp) ---------------------------------------------------
 struct LevelPlan {
     double etime = 0, esigma = 0;

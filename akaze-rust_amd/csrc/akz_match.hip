@@ -359,11 +359,15 @@ constexpr int MM4_QB = (AKZ_MM4_NT / 64) * 32 * AKZ_MM4_NB;  // queries per work
 // both indexed by the row of the padded train image; an element enters with
 //     old = atomicMin(cbest, mine);  atomicMin(csecond, max(old, mine) >> 32)
 // (the second smallest distance is the smallest among the losers of the first exchange; the packed minimum keeps the lowest
-// query among equal distances).  Elements ABOVE the row's current csecond cannot be one of its final two and are skipped;
-// whether a sub-tile holds any candidate at all is decided from the lane's best distance -- which the row direction
-// computes anyway -- against the loosest csecond of the sub-tile's 32 rows, read once per tile.  The state starts from
-// the exact result over the first col_q0 queries (a separate small launch of this kernel with the roles exchanged,
-// launch::match_cols_seed): from a bound of thousands of samples on, a train row sees a dozen candidates in all.
+// query among equal distances).  Elements ABOVE the row's current csecond cannot be one of its final two and are skipped:
+// the rows' bounds travel with the tile -- staged one tile ahead into LDS as accumulator limits 488 - 2 csecond (stale
+// values are only looser) -- and every lane compares its 16 accumulators with the limits of its 16 rows (four 16-byte LDS
+// reads that a whole half-wave shares); only a true candidate leaves the straight-line path.  The state starts from the
+// exact result over the first col_q0 queries (a separate small launch of this kernel with the roles exchanged,
+// launch::match_cols_seed): from a bound of thousands of samples on, a train row sees a handful of candidates in all.
+// (Measured on the way, 16 x 4K 5x5 frames, 120 blocks: gate on the loosest bound of a sub-tile + per-candidate bound loads
+// 58 ms; bulk bound loads, chunks rotated against the query blocks, 2048 seed rows 18.5 ms -- of which 7 ms the bound loads
+// and 1.6 ms the atomics; the same pass without the opposite direction 9.6 ms.)
 template <int NB, int NT, bool COLS = false>
 __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4, unsigned n0, const uint8_t* __restrict__ t4,
                                                   unsigned n1, unsigned chunk_tiles, unsigned threshold,
@@ -374,6 +378,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     constexpr int QB = (NT / 64) * 32 * NB;
     static_assert(MM_SUB == 4 && (NB == 1 || NB == 2) && (NT == 512 || NT == 1024), "staging below: two 64-row parts per 128-row tile");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH4];
+    __shared__ __attribute__((aligned(16))) float s_lim[2][COLS ? MM_TR : 4];  // COLS: accumulator limits of the tile's rows
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
     const unsigned q_first = blockIdx.x * QB + wave * 32u * NB;
@@ -399,7 +404,10 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
 
     unsigned t_begin, t_end, row0 = 0u, record = blockIdx.y;
     if (table) {
-        const MatchChunk ck = table[blockIdx.y];
+        // COLS: workgroups that are dispatched together (consecutive query blocks) take DIFFERENT chunks, so that a train row
+        // meets the query blocks one after the other and its bound tightens between the visits
+        const unsigned chunk = COLS ? (blockIdx.y + blockIdx.x * 7u) % gridDim.y : blockIdx.y;
+        const MatchChunk ck = table[chunk];
         t_begin = ck.t_begin; t_end = ck.t_end; row0 = ck.row0; n1 = ck.n_rows; record = ck.record;
         bound += ck.bound_off;
     } else {
@@ -418,20 +426,41 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
         st_dst[p] = (idx >> 4) * MM_PITCH4 + (idx & 15u) * 16u;
     }
     uint4 stage[PIECES];
+    unsigned long long lim_lo = 0, lim_hi = 0;  // COLS: csecond of rows 4 tid .. 4 tid + 3 of the tile being staged (tid < 32)
     auto fetch = [&](unsigned tile, int part) {
 #pragma unroll
         for (int p = 0; p < PIECES; ++p)
             stage[p] = *reinterpret_cast<const uint4*>(t4 + ((size_t)tile * MM_TR + 64u * part) * KB4 + st_src[p]);
+        if constexpr (COLS) {
+            if (part == 0 && tid < 32u) {
+                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(csecond + (size_t)tile * MM_TR + 4u * tid);
+                lim_lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lim_hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     };
-    auto commit = [&](int buf, int part) {
+    auto commit = [&](int buf, int part, unsigned tile) {
 #pragma unroll
         for (int p = 0; p < PIECES; ++p) *reinterpret_cast<uint4*>(&s_tile[buf][64 * part * MM_PITCH4 + st_dst[p]]) = stage[p];
+        if constexpr (COLS) {
+            if (part == 0 && tid < 32u) {
+                const unsigned sec[4] = {(unsigned)lim_lo, (unsigned)(lim_lo >> 32), (unsigned)lim_hi, (unsigned)(lim_hi >> 32)};
+                float4 lim;
+                float* lp = &lim.x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned row = tile * MM_TR - row0 + 4u * tid + (unsigned)k;  // row of the set: padding rows never take part
+                    lp[k] = row < n1 ? (float)(kBits - 2 * (int)min(sec[k], 1000u)) : 1e9f;
+                }
+                *reinterpret_cast<float4*>(&s_lim[buf][4u * tid]) = lim;
+            }
+        }
     };
     if (t_begin < t_end) {
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
             fetch(t_begin, part);
-            commit(0, part);
+            commit(0, part, t_begin);
         }
     }
     __syncthreads();
@@ -443,20 +472,6 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
         for (int b = 0; b < NB; ++b) {
             limit[b] = min(limit[b], min(second[b], b_seen[b] < 0xffffffffu ? b_seen[b] + 1u : b_seen[b]));
             b_seen[b] = __hip_atomic_load(bound + q_first + 32 * b + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // COLS: the loosest csecond of each of the tile's four 32-row sub-tiles (lane l looks at rows 2l, 2l+1: a sub-tile
-        // is one 16-lane row of the wave, reduced with four DPP steps)
-        unsigned clim[4] = {0u, 0u, 0u, 0u};
-        if constexpr (COLS) {
-            const unsigned long long two = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(csecond + (size_t)tile * MM_TR) + lane,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned m = max((unsigned)two, (unsigned)(two >> 32));
-            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, false));  // row_shr:1
-            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x112, 0xf, 0xf, false));  // row_shr:2
-            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xf, 0xf, false));  // row_shr:4
-            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x118, 0xf, 0xf, false));  // row_shr:8
-#pragma unroll
-            for (int k = 0; k < 4; ++k) clim[k] = (unsigned)__builtin_amdgcn_readlane((int)m, 16 * k + 15);
         }
 #pragma unroll
         for (int sub = 0; sub < MM_SUB; ++sub) {
@@ -488,25 +503,37 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
 #pragma unroll
                 for (int i = 1; i < 16; ++i) topf = fmaxf(topf, acc[b][i]);
                 const int best = (kBits - (int)topf) >> 1;  // the smallest distance of the lane's 16 rows
-                bool col_hit = false;
                 if constexpr (COLS) {
-                    const unsigned q = q_first + 32 * b + r;
-                    col_hit = best <= (int)clim[sub] && q >= col_q0 && q < n0;
-                }
-                if (COLS && col_hit) {  // some row of the sub-tile may take this query as one of its two nearest
-                    const unsigned q = q_first + 32 * b + r;
+                    // the limits of the lane's 16 rows (four groups of four consecutive rows, shared by the half-wave)
+                    const float* lp = &s_lim[buf][32 * sub + 4 * h];
+                    float lim[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const unsigned rowi = (unsigned)((i & 3) + 8 * (i >> 2));
-                        const unsigned d = (unsigned)((kBits - (int)acc[b][i]) >> 1);
-                        if (d <= clim[sub] && d < threshold && !(partial && j0 + rowi >= n1)) {
-                            const size_t prow = (size_t)tile * MM_TR + 32u * sub + 4u * h + rowi;
-                            const unsigned sec = __hip_atomic_load(csecond + prow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (d <= sec) {
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 v = *reinterpret_cast<const float4*>(lp + 8 * g4);
+                        lim[4 * g4] = v.x; lim[4 * g4 + 1] = v.y; lim[4 * g4 + 2] = v.z; lim[4 * g4 + 3] = v.w;
+                    }
+                    bool col_hit = false;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) col_hit = col_hit || acc[b][i] >= lim[i];
+                    const unsigned q = q_first + 32 * b + r;
+                    col_hit = col_hit && q >= col_q0 && q < n0;
+#ifdef AKZ_MM_COLS_NOHIT  // measurement: the pass without the opposite direction's candidates
+                    col_hit = false;
+#endif
+                    if (col_hit) {  // a row of the sub-tile may take this query as one of its two nearest
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const unsigned d = (unsigned)((kBits - (int)acc[b][i]) >> 1);
+                            if (acc[b][i] >= lim[i] && d < threshold) {
+                                const size_t prow = (size_t)tile * MM_TR + 32u * sub + 4u * h + (unsigned)((i & 3) + 8 * (i >> 2));
+#ifdef AKZ_MM_COLS_NOATOMIC  // measurement: candidates found, nothing entered
+                                if (d == 0xdeadbeefu) csecond[prow] = d;
+#else
                                 const unsigned long long mine = ((unsigned long long)d << 32) | q;
                                 const unsigned long long old = atomicMin(cbest + prow, mine);
                                 const unsigned loser = (unsigned)(max(old, mine) >> 32);
-                                if (loser < sec) atomicMin(csecond + prow, loser);
+                                if (loser < threshold) atomicMin(csecond + prow, loser);
+#endif
                             }
                         }
                     }
@@ -545,7 +572,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                     }
                 }
             }
-            if (more && (sub & 1) == 1) commit(buf ^ 1, sub >> 1);
+            if (more && (sub & 1) == 1) commit(buf ^ 1, sub >> 1, tile + 1);
         }
         __syncthreads();
     }
@@ -705,7 +732,10 @@ void match_mfma_multi(hipStream_t s, const uint8_t* q8, const uint32_t* qpop, ui
 // (a multiple of the tile height, or all n0 if fewer) rows of the query image -> exact (best, second) of every train row
 // over those queries in cbest / csecond; d_bound / d_seed: scratch of t_rows_pad u32 / MatchRec (t_rows_pad: the padded
 // train rows rounded up to whole query blocks; both images are allocated to that).
-uint32_t match_cols_seed_rows(uint32_t n0) { return std::min<uint32_t>(n0, 4u * MM_TR); }
+#ifndef AKZ_MM_SEED_TILES
+#define AKZ_MM_SEED_TILES 16
+#endif
+uint32_t match_cols_seed_rows(uint32_t n0) { return std::min<uint32_t>(n0, (uint32_t)AKZ_MM_SEED_TILES * MM_TR); }
 void match_cols_seed(hipStream_t s, const uint8_t* q4, uint32_t n0, const uint8_t* t4, uint32_t t_rows, uint32_t threshold,
                      uint32_t* d_bound, MatchRec* d_seed, unsigned long long* cbest, uint32_t* csecond) {
     const uint32_t seed = match_cols_seed_rows(n0);

@@ -209,6 +209,7 @@ def lib():
         "akz_match_all_pairs": ([vp, vp, u64, C.c_double, C.POINTER(vp)], i32),
         "akz_pairs_info": ([vp, pu64, pu64, pu64], i32),
         "akz_pairs_image_rows": ([vp, u64, pu64, C.POINTER(i32)], i32),
+        "akz_pairs_holder": ([vp, u64, u64, C.POINTER(i32)], i32),
         "akz_pairs_matches": ([vp, u64, u64, vp, u64, pu64], i32),
         "akz_pairs_free": ([vp], i32),
         "akz_gather_stream_wait": ([vp, vp], i32),
@@ -1022,7 +1023,8 @@ class Gather:
         return [int(v) for v in out[:n.value]]
 
     def match_all_pairs(self, ctx, distance_threshold=10000, lowes_ratio=0.86):
-        """akz_match_all_pairs (BASELINE configs[4]): this rank's images as queries against every image of the job."""
+        """akz_match_all_pairs (BASELINE configs[4]): every unordered image pair once, both directions, on the rank that owns
+        the pair's lead image (Pairs.holder)."""
         p = C.c_void_p()
         _check(lib().akz_match_all_pairs(ctx._h, self._h, int(distance_threshold), float(lowes_ratio), C.byref(p)))
         return Pairs(ctx, p)
@@ -1041,7 +1043,7 @@ class Gather:
 
 
 class Pairs:
-    """Result of akz_match_all_pairs: match lists of this rank's images against every image of the job."""
+    """Result of akz_match_all_pairs: both match lists of every image pair this rank holds (Pairs.holder / held)."""
 
     def __init__(self, ctx, handle):
         self._ctx, self._h = ctx, handle  # (the context must outlive the pairs object)
@@ -1066,8 +1068,18 @@ class Pairs:
         _check(lib().akz_pairs_matches(self._h, int(query), int(image), out.ctypes.data_as(C.c_void_p), n, C.byref(m)))
         return out[:m.value].copy()
 
-    def total_matches(self):
-        return sum(self.count(q, j) for q in range(self.first_owned, self.first_owned + self.n_owned) for j in range(self.n_images))
+    def holder(self, a, b):
+        """akz_pairs_holder: the rank whose Pairs object holds both lists of the pair {a, b}."""
+        r = C.c_int32()
+        _check(lib().akz_pairs_holder(self._h, int(a), int(b), C.byref(r)))
+        return r.value
+
+    def held(self, rank):
+        """ordered pairs (query, image) whose lists this rank holds"""
+        return [(a, b) for a in range(self.n_images) for b in range(self.n_images) if a != b and self.holder(a, b) == rank]
+
+    def total_matches(self, rank=0):
+        return sum(self.count(a, b) for a, b in self.held(rank))
 
     def free(self):
         if self._h:
@@ -1228,34 +1240,40 @@ def gather_descriptor_sets(local_sets, group=None):
     return sets, owners
 
 
-def all_pairs_match(local_sets, match_fn, group=None, match_sets_fn=None):
-    """Cross-GPU all-pairs Hamming match: after gather_descriptor_sets every rank matches the images it OWNS (as
-    queries) against every other image of the job, i.e. 1/world of the ordered pairs each; nothing else is
-    exchanged.  match_fn(rows_i, rows_j) is Context.descriptor_match_device on the GPUs.  With
-    match_sets_fn(rows_i, all_rows, rows_per_set) -> [matches of set 0, ...] (Context.descriptor_match_sets_device:
-    one launch per query image against the concatenated sets of all images) match_fn is not called.
+def pairs_lead(a, b):
+    """The image of the unordered pair {a, b} that serves as the query set of its block (akz_match_all_pairs' rule: the
+    lower one if the indices differ by an odd number, else the higher one -- every image leads about half of its pairs)."""
+    lo, hi = min(a, b), max(a, b)
+    return lo if (hi - lo) & 1 else hi
 
-    Returns {(i, j): matches} for this rank's share, i and j being global (rank-major) image indices."""
+
+def all_pairs_match(local_sets, match_fn, group=None, match_sets_fn=None):
+    """Cross-GPU all-pairs Hamming match: after gather_descriptor_sets every UNORDERED image pair is matched once, in both
+    directions, by the rank that owns the pair's lead image (pairs_lead); nothing else is exchanged.  match_fn(rows_i,
+    rows_j) is Context.descriptor_match_device on the GPUs.  With match_sets_fn(rows_i, train_rows, rows_per_set) ->
+    ([matches of rows_i against set 0, ...], [matches of set 0 against rows_i, ...]) (Context.
+    descriptor_match_sets_mutual_device: one launch per lead image, both directions from one pass) match_fn is not called.
+
+    Returns {(i, j): matches} for the ordered pairs this rank holds, i and j being global (rank-major) image indices."""
     import torch
     import torch.distributed as dist
     sets, owners = gather_descriptor_sets(local_sets, group)
     rank = dist.get_rank(group)
     out = {}
-    cat = rows = None
-    if match_sets_fn is not None:
-        cat = torch.cat(sets, dim=0) if sets else None
-        rows = [int(t.shape[0]) for t in sets]
     for i, owner in enumerate(owners):
         if owner != rank:
             continue
-        if match_sets_fn is not None:
-            per_set = match_sets_fn(sets[i], cat, rows)
-            for j in range(len(sets)):
-                if i != j:
-                    out[(i, j)] = per_set[j]
+        led = [j for j in range(len(sets)) if j != i and pairs_lead(i, j) == i]
+        if not led:
             continue
-        for j in range(len(sets)):
-            if i != j:
-                out[(i, j)] = match_fn(sets[i], sets[j])
+        if match_sets_fn is not None:
+            fwd, rev = match_sets_fn(sets[i], torch.cat([sets[j] for j in led], dim=0), [int(sets[j].shape[0]) for j in led])
+            for k, j in enumerate(led):
+                out[(i, j)] = fwd[k]
+                out[(j, i)] = rev[k]
+            continue
+        for j in led:
+            out[(i, j)] = match_fn(sets[i], sets[j])
+            out[(j, i)] = match_fn(sets[j], sets[i])
     return out
 

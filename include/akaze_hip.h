@@ -360,19 +360,24 @@ int akz_gather_image_rows(akz_gather* g, int rank, uint64_t* rows_per_image, uin
 int akz_gather_free(akz_gather* g);
 
 /* BASELINE configs[4] — the cross-GPU all-pairs match for hosts that are not Python: after an
-   exchange every rank holds the descriptor rows of every image of the job; this rank matches the images IT owns (the
-   ones it contributed to `gather`), as queries, against every image of the job: 1 / nranks of the ordered pairs, one
-   multi-set launch of the matcher per owned image (ops::feature_matching::descriptor_match per pair,
-   feature_matching.rs:23-94; results identical to akz_descriptor_match of the pair).  Images are numbered rank-major
-   over the job.  Finishes the gather if the caller has not; the gather may be freed afterwards. */
+   exchange every rank holds the descriptor rows of every image of the job (numbered rank-major).  Every UNORDERED image
+   pair {a, b} is matched once, in both directions, by the rank that owns the pair's lead image (lo if hi - lo is odd,
+   else hi: every image leads about half of its pairs): the lead image is the query set of one both-direction launch
+   (akz_descriptor_match_sets_mutual_device) against the images it leads, so the matrix-core work of a block serves
+   descriptor_match(a, b) and descriptor_match(b, a) (ops::feature_matching::descriptor_match, feature_matching.rs:23-94;
+   every list identical to akz_descriptor_match of the pair).  The call enqueues on the context's stream and returns; it
+   allocates only when the job grows (buffers are pooled in the communicator) and finishes the gather if the caller has
+   not; the gather may be freed afterwards (a later exchange that reuses its buffers is ordered behind this call's copies). */
 typedef struct akz_pairs akz_pairs;
 int akz_match_all_pairs(akz_ctx* ctx, akz_gather* gather, uint64_t distance_threshold, double lowes_ratio, akz_pairs** out);
 /* *n_images: images of the whole job; this rank's are first_owned .. first_owned + n_owned - 1 */
 int akz_pairs_info(const akz_pairs* p, uint64_t* n_images, uint64_t* first_owned, uint64_t* n_owned);
 int akz_pairs_image_rows(const akz_pairs* p, uint64_t image, uint64_t* rows, int* owner_rank);
-/* matches of owned image `query` (a job-wide image number) against `image`: index_0 into the query's rows, index_1
-   into `image`'s; ordered by index_0.  out may be NULL (count only); at most cap records are written.  The pair
-   (query, query) is empty. */
+/* the rank whose akz_pairs holds both lists of the pair {image_a, image_b} (the owner of its lead image) */
+int akz_pairs_holder(const akz_pairs* p, uint64_t image_a, uint64_t image_b, int* rank);
+/* descriptor_match(query, image) for a pair this rank holds (akz_pairs_holder; either image may be the query): index_0
+   into the query's rows, index_1 into `image`'s; ordered by index_0.  out may be NULL (count only); at most cap records are
+   written.  The pair (query, query) is empty.  The first call waits for the launches of akz_match_all_pairs. */
 int akz_pairs_matches(const akz_pairs* p, uint64_t query, uint64_t image, akz_match* out, uint64_t cap, uint64_t* n);
 int akz_pairs_free(akz_pairs* p);
 

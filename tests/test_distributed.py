@@ -116,9 +116,10 @@ def _pairs_worker(rank, world, port, sizes, out_dir):
         assert owners == [r for r in range(world) for _ in sizes[r]]
         res = A.all_pairs_match(local, _np_match)
 
-        def np_match_sets(q, cat, rows):  # the multi-set form: one call per query image against all sets
+        def np_match_sets(q, cat, rows):  # the both-direction multi-set form: one call per lead image against the sets it leads
             offs = np.concatenate([[0], np.cumsum(rows)])
-            return [_np_match(q, cat[offs[k]:offs[k + 1]]) for k in range(len(rows))]
+            return ([_np_match(q, cat[offs[k]:offs[k + 1]]) for k in range(len(rows))],
+                    [_np_match(cat[offs[k]:offs[k + 1]], q) for k in range(len(rows))])
 
         assert A.all_pairs_match(local, None, match_sets_fn=np_match_sets) == res
         with open(os.path.join(out_dir, f"pairs_{rank}.pkl"), "wb") as f:
@@ -129,8 +130,9 @@ def _pairs_worker(rank, world, port, sizes, out_dir):
 
 @pytest.mark.parametrize("sizes", [((6, 9), (4,)), ((5,), (0, 7, 3)), ((), (8, 2))])
 def test_all_pairs_match_gloo(tmp_path, sizes):
-    """BASELINE configs[4]'s cross-GPU all-pairs match on two CPU ranks: every ordered image pair is matched exactly
-    once, by the rank that owns the query image, with the result a single process gets."""
+    """BASELINE configs[4]'s cross-GPU all-pairs match on two CPU ranks: every UNORDERED image pair is matched exactly once,
+    in both directions, by the rank that owns the pair's lead image (akz_match_all_pairs' rule), with the results a single
+    process gets for both ordered pairs."""
     import pickle
     import torch
     import torch.multiprocessing as mp
@@ -142,7 +144,10 @@ def test_all_pairs_match_gloo(tmp_path, sizes):
     seen = {}
     for r in range(world):
         res = pickle.load(open(tmp_path / f"pairs_{r}.pkl", "rb"))
-        assert all(owners[i] == r for (i, _j) in res)
+        sys.path.insert(0, os.path.join(ROOT, "akaze-rust_amd", "python"))
+        import akaze_amd as A
+        assert all(owners[A.pairs_lead(i, j)] == r for (i, j) in res)
+        assert all((j, i) in res for (i, j) in res)  # both directions of a pair live on one rank
         assert not (set(res) & set(seen))
         seen.update(res)
     n = len(everything)

@@ -59,6 +59,20 @@ def test_comm_gather_matches_local_rows(ctx, amd):
             got = pairs.matches(q, j)
             exp = ctx.descriptor_match(res.descriptors(q), res.descriptors(j), 10000, 0.86) if q != j else got[:0]
             assert np.array_equal(got, exp), (q, j)
+    assert sorted(pairs.held(0)) == [(a, b) for a in range(3) for b in range(3) if a != b]
+    total = pairs.total_matches()
+    pairs.free()
+    g4.free()
+    g4 = comm.gather_begin([res], rows + 1)  # the next step: the freed object's buffers are reused, the lists are the same
+    pairs = g4.match_all_pairs(ctx)
+    assert pairs.total_matches() == total and total > 0
+    for mode in (1, 0):  # the other matcher kernels compute the second direction separately: same lists
+        ctx.set_match_mode(mode)
+        other = g4.match_all_pairs(ctx)
+        for q, j in ((0, 1), (1, 0), (2, 0), (0, 2)):
+            assert np.array_equal(other.matches(q, j), pairs.matches(q, j)), (mode, q, j)
+        other.free()
+    ctx.set_match_mode(2)
     pairs.free()
     g5 = comm.gather_begin([res], rows + 1)   # never finished nor freed by the caller
     res.close()

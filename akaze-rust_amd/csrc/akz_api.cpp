@@ -56,7 +56,10 @@ unsigned akz::host_cpu_share() {
 // the coarse chain and the resident coarse octave engage from here on (swept again in round 3: 4 Mpx is -7 ... -9 % on
 // 8-frame batches, 8 000 000 -- so that a lone 4K frame qualifies -- changes nothing for it: that frame is bound by the
 // host's per-image selection and the finish round trips, not by its kernels).
-static constexpr uint64_t kBigLaunchPx() { return 8u << 20; }
+#ifndef AKZ_BIG_PX
+#define AKZ_BIG_PX (8u << 20)
+#endif
+static constexpr uint64_t kBigLaunchPx() { return AKZ_BIG_PX; }
 // The finish half of a lane's jobs on a thread of the library (akz_ctx_set_eager_finish): started by begin, so that the
 // candidate round trip, the host keypoint logic and the keypoint kernels of frame i run while the caller's thread
 // enqueues frame i + 1 on another lane; akz_extract_finish then only collects the result.  One thread per lane, jobs
@@ -1399,7 +1402,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             const uint32_t rest = rem ? fed_num_launches(c, rem, lv.w, lv.h, n) : 0;
             float* d1 = fed_dst(rest + 1, 1, A, B);
             const float* level_in = P(i - 1, AKZ_LT);
-            if (half) {
+            // a new octave: the 2x2 mean of the previous Lt is formed inside the level kernel where the widths allow it
+            // (one launch and one plane round trip less per octave), materialised first otherwise
+            const bool fold_half = half && launch::level_march_half_supported(lv.w, lv.h, pv.w, pv.h, n1);
+            if (half && !fold_half) {
                 StageTimer st(c, AKZ_ST_PREP);
                 float* hb = d1 == A ? B : A;
                 launch::half_size(ls, P(i - 1, AKZ_LT), hb, pv.w, pv.h, n);
@@ -1411,7 +1417,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                 StageTimer st(c, AKZ_ST_FED);
                 launch::level_march(ls, level_in, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), d1,
                                     (rem == 0 && keep_all) ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n, g1.data(), r->d_k,
-                                    lv.octave, ht, n1);
+                                    lv.octave, ht, n1, fold_half ? pv.w : 0u, fold_half ? pv.h : 0u);
                 if (c->profiling) {
                     c->prof.fed_launches += 1;
                     c->prof.fed_px_steps += (uint64_t)lv.w * lv.h * n * n1;
@@ -2126,7 +2132,9 @@ static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint
     hipEvent_t ready = on_host ? on->staged[slot] : nullptr;  // frames this library uploaded: complete behind that event
     const int rc = is_u8 ? extract_begin<uint8_t>(on, (const uint8_t*)d_imgs, w, h, n, cfg, flags, out, slot, ready)
                          : extract_begin<float>(on, (const float*)d_imgs, w, h, n, cfg, flags, out, slot, ready);
-    if (rc == AKZ_OK && c->eager_finish) finisher_post(on, *out);
+    // a job dealt to a lane is always finished by the lane's own thread (lanes whose jobs wait for the caller's finish call
+    // measured SLOWER than no lanes: the chains overlap on the chip but the finish halves queue on one host thread)
+    if (rc == AKZ_OK && (c->eager_finish || on != c)) finisher_post(on, *out);
     return rc;
 }
 int akz_extract_begin_host_u8(akz_ctx* c, const uint8_t* h_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfg,

@@ -193,9 +193,12 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
                     float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 // level preparation + the first n_steps <= 4 diffusion steps of a level in one launch (akz_march.hip, k_level_march)
 bool level_march_supported(uint32_t w, uint32_t h);
+// pw, ph != 0: `prev` is the previous octave's last Lt (pw x ph) and the level starts from its 2x2 mean, formed inside the
+// kernel (level_march_half_supported)
+bool level_march_half_supported(uint32_t w, uint32_t h, uint32_t pw, uint32_t ph, uint32_t n_steps);
 void level_march(hipStream_t s, const float* prev, float* lsmooth, float* lflow, float* lt_out, float* lstep, uint32_t w,
                  uint32_t h, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow, const float* half_taus,
-                 uint32_t n_steps);
+                 uint32_t n_steps, uint32_t pw = 0, uint32_t ph = 0);
 // the remaining levels of the pyramid, from the first one whose image fits a compute unit, in ONE launch with one
 // workgroup per image (akz_resident.hip, k_octave_resident): preparation and every diffusion step of every level
 struct ResidentLevel {

@@ -461,11 +461,17 @@ __device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) 
     return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
 }
 
-template <int N, bool KEEPSTEP, bool ODDW>
+// HALF: the level opens an octave and `prev` is the previous octave's last Lt (pw x ph = 2w x 2h, pw a multiple of 4): its
+// 2x2 mean (half_size, types/image.rs:102-118: (((0 + a(2x,2y)) + a(2x,2y+1)) + a(2x+1,2y)) + a(2x+1,2y+1)) / 4) is formed
+// where a row is consumed, from two 16-byte loads per thread and row -- no separate k_half_size launch, no half-size
+// plane written and read back.
+typedef unsigned u4m __attribute__((ext_vector_type(4)));
+template <int N, bool KEEPSTEP, bool ODDW, bool HALF = false>
 __global__ void __launch_bounds__(MT, 3)
 k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, float* __restrict__ lflow_out,
               float* __restrict__ lt_out, float* __restrict__ lstep_out, int w, int h, MarchGrid g, float g0, float g1,
-              float g2, float kn, float kwn, const double* __restrict__ d_k, unsigned k_pow, LevelTaus ht) {
+              float g2, float kn, float kwn, const double* __restrict__ d_k, unsigned k_pow, LevelTaus ht, int pw = 0, int ph = 0) {
+    static_assert(!(HALF && ODDW), "the 2x2 mean is folded in for even level widths only");
     static_assert(N >= 1 && N <= 4, "fused diffusion steps");
     static_assert(N + 3 <= HALO, "strip halo");
     constexpr int NPL = 3 + N;  // LDS rows per iteration: Lt_prev, Lsmooth, Lflow, L^0 .. L^(N-1)
@@ -504,7 +510,7 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     const bool edge_col = __ballot(!(hxn0 && hxp0 && hxn1 && hxp1)) != 0ull;
 
     const size_t base = (size_t)img * (size_t)w * (size_t)h;
-    const __amdgpu_buffer_rsrc_t in = plane_rsrc(prev + base, w, h);
+    const __amdgpu_buffer_rsrc_t in = HALF ? plane_rsrc(prev + (size_t)img * (size_t)pw * (size_t)ph, pw, ph) : plane_rsrc(prev + base, w, h);
     const __amdgpu_buffer_rsrc_t o_ls[1] = {plane_rsrc(lsmooth_out + base, w, h)};
     const __amdgpu_buffer_rsrc_t o_lf[1] = {plane_rsrc(lflow_out + base, w, h)};
     __amdgpu_buffer_rsrc_t o_lt[KEEPSTEP ? 2 : 1];
@@ -517,10 +523,33 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
     // Lt row r needs Lt_prev rows r-N-2 .. r+N+2 (N steps, the c ring one row wider, c itself two blurs of half width 1)
     const int v0 = lt0 - N - 2;
     const int T = (lt1 - lt0) + 2 * N + 6;
-    auto feed = [&](int t) -> f2 {
-        return load_pair<ODDW>(in, (unsigned)clampi(v0 + min(t, T - 1), 0, h - 1) * ((unsigned)w * 4u), C);
+    struct Fed {  // a row as loaded: the pair itself, or (HALF) the 2 x 4 source pixels of the pair
+        f2 v;
+        u4m top, bot;
     };
-    f2 q[4];
+    auto feed = [&](int t) -> Fed {
+        Fed f;
+        const unsigned row = (unsigned)clampi(v0 + min(t, T - 1), 0, h - 1);
+        if constexpr (HALF) {
+            const unsigned ro = 2u * row * ((unsigned)pw * 4u);
+            f.top = __builtin_amdgcn_raw_buffer_load_b128(in, (int)(2u * C.vo_ld), (int)ro, 0);
+            f.bot = __builtin_amdgcn_raw_buffer_load_b128(in, (int)(2u * C.vo_ld), (int)(ro + (unsigned)pw * 4u), 0);
+        } else {
+            f.v = load_pair<ODDW>(in, row * ((unsigned)w * 4u), C);
+        }
+        return f;
+    };
+    auto pair_of = [&](const Fed& f) -> f2 {
+        if constexpr (HALF) {
+            float a = 0.0f, b = 0.0f;
+            a = a + __uint_as_float(f.top.x); a = a + __uint_as_float(f.bot.x); a = a + __uint_as_float(f.top.y); a = a + __uint_as_float(f.bot.y);
+            b = b + __uint_as_float(f.top.z); b = b + __uint_as_float(f.bot.z); b = b + __uint_as_float(f.top.w); b = b + __uint_as_float(f.bot.w);
+            return f2{a / 4.0f, b / 4.0f};
+        } else {
+            return f.v;
+        }
+    };
+    Fed q[4];
 #pragma unroll
     for (int i = 0; i < PF; ++i) q[i] = feed(i);
     const f2 zero = {0.0f, 0.0f};
@@ -550,7 +579,7 @@ k_level_march(const float* __restrict__ prev, float* __restrict__ lsmooth_out, f
                 const int v = v0 + t;
                 q[(k + PF) & 3] = feed(t + PF);
                 float* const buf = &s_row[t & 1][0][0];
-                LP[k & 7] = fix_pair(q[k & 3], C);
+                LP[k & 7] = fix_pair(pair_of(q[k & 3]), C);
                 *reinterpret_cast<f2*>(buf + 0 * ROW + wi) = LP[k & 7];
                 *reinterpret_cast<f2*>(buf + 1 * ROW + wi) = ls_c;
                 *reinterpret_cast<f2*>(buf + 2 * ROW + wi) = CR[(k - 5) & 7];
@@ -1055,7 +1084,13 @@ static void launch_detector_march(hipStream_t s, const float* lsmooth, float* lx
                                   float* ldet_out, uint32_t w, uint32_t h, uint32_t n, float kn, float kwn, float quat,
                                   const MarchNms& na) {
     dim3 gr;
-    const MarchGrid mg = plan_march(w, h, n, S, &gr);
+#ifndef AKZ_DET_FILL
+#define AKZ_DET_FILL 3
+#endif
+#ifndef AKZ_DET_MINROWS
+#define AKZ_DET_MINROWS 64
+#endif
+    const MarchGrid mg = plan_march(w, h, n, S, &gr, AKZ_DET_FILL, AKZ_DET_MINROWS);
     if (w & 1u)
         hipLaunchKernelGGL((k_detector_march<S, NMS, KEEP, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out,
                            (int)w, (int)h, mg, kn, kwn, quat, na);
@@ -1144,12 +1179,15 @@ void contrast_march(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint
 
 // (half-resolution launches of a 32-frame batch: with 64-row bands there are 512 workgroups for 768 places; 40-row bands
 // fill them, 101 -> 94 us per launch)
+#ifndef AKZ_LVL_FILL
+#define AKZ_LVL_FILL 3
+#endif
 static int level_min_band_rows(uint32_t w, uint32_t h, uint32_t n) { return (uint64_t)w * h * n < (48u << 20) ? 40 : 64; }
 // Test hook (CPU): the bands the planners cut an n-image batch of w x h into -- kind 0: detector / blur march with
 // kernel half width S, kind 1: level march.  Writes up to cap [cs, ce) pairs, returns the number of bands.
 uint32_t march_band_rows(int kind, uint32_t w, uint32_t h, uint32_t n, int S, int32_t* cs_ce, uint32_t cap) {
     dim3 gr;
-    const MarchGrid g = kind == 1 ? plan_level_march(w, h, n, &gr, 3, level_min_band_rows(w, h, n)) : plan_march(w, h, n, S, &gr);
+    const MarchGrid g = kind == 1 ? plan_level_march(w, h, n, &gr, AKZ_LVL_FILL, level_min_band_rows(w, h, n)) : plan_march(w, h, n, S, &gr);
     for (int b = 0; b < g.nbands && (uint32_t)b < cap; ++b) {
         int cs, ce;
         if (kind == 1) level_band_rows(g, b, (int)h, &cs, &ce);
@@ -1165,7 +1203,14 @@ bool level_march_supported(uint32_t w, uint32_t h) { return w >= 16 && h >= 16 &
 template <int NS, bool KEEPSTEP>
 static void launch_level_march(hipStream_t s, dim3 gr, const MarchGrid& mg, const float* prev, float* lsmooth, float* lflow,
                                float* lt_out, float* lstep, uint32_t w, uint32_t h, const float* g3, const Taps& m,
-                               const double* d_k, uint32_t k_pow, const LevelTaus& ht) {
+                               const double* d_k, uint32_t k_pow, const LevelTaus& ht, uint32_t pw, uint32_t ph) {
+    if constexpr (NS == 4) {  // (the first level of an octave always has four or more steps)
+        if (pw) {
+            hipLaunchKernelGGL((k_level_march<NS, KEEPSTEP, false, true>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep, (int)w,
+                               (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht, (int)pw, (int)ph);
+            return;
+        }
+    }
     if (w & 1u)
         hipLaunchKernelGGL((k_level_march<NS, KEEPSTEP, true>), gr, dim3(MT), 0, s, prev, lsmooth, lflow, lt_out, lstep, (int)w,
                            (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow, ht);
@@ -1175,21 +1220,25 @@ static void launch_level_march(hipStream_t s, dim3 gr, const MarchGrid& mg, cons
 }
 #define AKZ_LEVEL(NS)                                                                                                        \
     case NS: {                                                                                                               \
-        if (lstep) launch_level_march<NS, true>(s, gr, mg, prev, lsmooth, lflow, lt_out, lstep, w, h, g3, m, d_k, k_pow, ht);  \
-        else launch_level_march<NS, false>(s, gr, mg, prev, lsmooth, lflow, lt_out, lstep, w, h, g3, m, d_k, k_pow, ht);       \
+        if (lstep) launch_level_march<NS, true>(s, gr, mg, prev, lsmooth, lflow, lt_out, lstep, w, h, g3, m, d_k, k_pow, ht, pw, ph);  \
+        else launch_level_march<NS, false>(s, gr, mg, prev, lsmooth, lflow, lt_out, lstep, w, h, g3, m, d_k, k_pow, ht, pw, ph);       \
     } break;
 
 // Level preparation + the level's first n_steps (1..4) diffusion steps in one launch of k_level_march.  prev: the
 // level's Lt before diffusion (the previous level's final Lt, or its 2x2 mean), must not alias lt_out.  lstep (may be
 // null) receives the increment of the LAST fused step.
+// the 2x2 mean of a pw x ph plane can be formed inside the level kernel (level_march with pw, ph given)
+bool level_march_half_supported(uint32_t w, uint32_t h, uint32_t pw, uint32_t ph, uint32_t n_steps) {
+    return n_steps == 4 && (pw & 3u) == 0 && (w & 1u) == 0 && w == pw / 2 && h == ph / 2 && (uint64_t)pw * ph <= (1ull << 28);
+}
 void level_march(hipStream_t s, const float* prev, float* lsmooth, float* lflow, float* lt_out, float* lstep, uint32_t w,
                  uint32_t h, uint32_t n, const float* g3, const double* d_k, uint32_t k_pow, const float* half_taus,
-                 uint32_t n_steps) {
+                 uint32_t n_steps, uint32_t pw, uint32_t ph) {
     const Taps m = taps_scharr_main(1);
     LevelTaus ht;
     for (uint32_t i = 0; i < 4; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
     dim3 gr;
-    const MarchGrid mg = plan_level_march(w, h, n, &gr, 3, level_min_band_rows(w, h, n));
+    const MarchGrid mg = plan_level_march(w, h, n, &gr, AKZ_LVL_FILL, level_min_band_rows(w, h, n));
     switch (n_steps) {
         AKZ_LEVEL(1) AKZ_LEVEL(2) AKZ_LEVEL(3) AKZ_LEVEL(4)
         default: break;

@@ -966,27 +966,10 @@ def main_rank(args):
         single = {"workload": f"one {W}x{H} frame per extract_features call (BASELINE configs[1])",
                   "latency_ms": round(lat * 1e3, 3), "stream_ms_per_frame": round(thr * 1e3, 3),
                   "stream_Mpix_s": round(W * H / thr / 1e6, 1)}
-        # the same stream on ONE context with lanes: frames dealt to 2 / 4 child contexts, that many begun ahead
-        single["lanes"] = {}
-        for lanes in (2, 4):
-            ctx.set_lanes(lanes)
-            for _ in range(2 * lanes):
-                ctx.extract_begin(one, cfg, keep_all_planes=not args.lean).finish().close()
-            t1 = time.perf_counter()
-            pending = []
-            for _ in range(reps):
-                pending.append(ctx.extract_begin(one, cfg, keep_all_planes=not args.lean))
-                if len(pending) > lanes:
-                    pending.pop(0).finish().close()
-            while pending:
-                pending.pop(0).finish().close()
-            thr_l = (time.perf_counter() - t1) / reps
-            single["lanes"][str(lanes)] = {"stream_ms_per_frame": round(thr_l * 1e3, 3), "stream_Mpix_s": round(W * H / thr_l / 1e6, 1)}
-        # ... and with the finish half of every frame on its lane's own thread (akz_ctx_set_eager_finish): the caller's
-        # thread only enqueues the next frames and collects results; lone 4K frames the same way
+        # the same stream on ONE context with lanes: frames dealt to 2 .. 4 child contexts, each of which finishes its frames
+        # on its own thread; the caller's thread only enqueues the next frames and collects results; lone 4K frames the same way
         def stream_eager(frame, lanes, reps_e):
             ctx.set_lanes(lanes)
-            ctx.set_eager_finish(True)
             for _ in range(2 * lanes):
                 ctx.extract_begin(frame, cfg, keep_all_planes=not args.lean).finish().close()
             t_e = time.perf_counter()
@@ -998,12 +981,11 @@ def main_rank(args):
             while pend:
                 pend.pop(0).finish().close()
             dt = (time.perf_counter() - t_e) / reps_e
-            ctx.set_eager_finish(False)
             return dt
-        single["eager_finish"] = {}
+        single["lanes"] = {}
         for lanes in (2, 3, 4):
             thr_e = stream_eager(one, lanes, reps)
-            single["eager_finish"][str(lanes)] = {"stream_ms_per_frame": round(thr_e * 1e3, 3), "stream_Mpix_s": round(W * H / thr_e / 1e6, 1)}
+            single["lanes"][str(lanes)] = {"stream_ms_per_frame": round(thr_e * 1e3, 3), "stream_Mpix_s": round(W * H / thr_e / 1e6, 1)}
         if not stub:
             try:
                 one4k = torch.from_numpy(A.synth_frame(3840, 2160, 3)[None]).to(dev)
@@ -1023,7 +1005,7 @@ def main_rank(args):
                 thr4e = stream_eager(one4k, 4, 40)
                 single["lone_4k"] = {"workload": "one 3840x2160 frame per extract_features call",
                                      "stream_ms_per_frame": round(thr4 * 1e3, 3), "stream_Mpix_s": round(3840 * 2160 / thr4 / 1e6, 1),
-                                     "eager_finish_4_lanes": {"stream_ms_per_frame": round(thr4e * 1e3, 3),
+                                     "lanes_4": {"stream_ms_per_frame": round(thr4e * 1e3, 3),
                                                               "stream_Mpix_s": round(3840 * 2160 / thr4e / 1e6, 1)}}
                 del one4k
             except Exception as e:

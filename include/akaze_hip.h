@@ -462,18 +462,21 @@ int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
 int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
 /* Lanes for small jobs.  A lone 1080p frame is a chain of ~45 launches of a few hundred workgroups each: the chip is busy
    but only a fraction of it at a time.  With lanes = k (2..8) the extract_begin calls of jobs below 8 Mpx are dealt in
-   turn to k child contexts with their own streams, scratch planes and candidate buffers, so that the chains of
-   consecutive frames overlap; larger jobs, and everything at lanes = 1 (default), run on the context's own stream.
-   The caller's stream is respected (a lane starts behind what the caller enqueued before the call); results are
-   bit-identical and are used through the same calls. */
+   turn to k child contexts with their own streams, scratch planes, candidate buffers and HOST THREAD: the finish half of
+   a lane's job (candidate round trip, keypoint selection, orientation / descriptor kernels and their copies) starts on
+   the lane's thread as soon as the job has been begun, so that the chains of consecutive frames overlap on the chip and
+   their host halves on the host; akz_extract_finish waits for the lane and hands the result over.  Larger jobs, and
+   everything at lanes = 1 (default), run on the context itself.  The caller's stream is respected (a lane starts behind
+   what the caller enqueued before the call); results are bit-identical and are used through the same calls. */
 int akz_ctx_set_lanes(akz_ctx* ctx, uint32_t lanes);
-/* Eager finish (with lanes).  on != 0: the finish half of every job that is dealt to a lane -- the candidate round trip,
-   the order-dependent keypoint selection of the host, the orientation / descriptor kernels and their copies -- is started
-   by akz_extract_begin_* on a thread owned by that lane; akz_extract_finish waits for it and hands the result over.  The
-   caller's thread is then free to begin the next frames on the other lanes meanwhile: a stream of lone frames is bound
-   by the longer of the two halves instead of their sum.  Results, error reporting (through akz_extract_finish) and
-   akz_job_abandon are unchanged; any other call on a context waits until its lanes' threads are idle.  Jobs that stay
-   on the context itself (lanes = 1, or 8 Mpx and more) are not affected.  Default off. */
+/* The finish half on the context's own thread.  on != 0: the finish half of EVERY job of the context -- also the batches
+   that run on the context itself -- is started by akz_extract_begin_* on a thread the library owns; akz_extract_finish waits
+   for it and hands the result over (results, error reporting through akz_extract_finish and akz_job_abandon are
+   unchanged).  The caller's thread then only enqueues: with two or three batches begun ahead, whatever else it does between
+   the calls (the exchange of a multi-GPU job, file I/O) no longer delays the keypoint half of the batches in flight.
+   Entry points that share state with the finish half (result queries that launch kernels, the setters) wait until the
+   thread is idle; akz_extract_begin_*, the matcher and akz_result_free do not.  Default off (jobs dealt to lanes are
+   always finished by their lane's thread). */
 int akz_ctx_set_eager_finish(akz_ctx* ctx, int on);
 /* Host threads of the finish half of an extraction (candidate bucketing, per-image keypoint selection, libm calls):
    0 (default) = automatic -- the affinity mask of the process, cut down by the cgroup CPU quota and divided by

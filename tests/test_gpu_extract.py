@@ -407,11 +407,13 @@ def test_all_pairs_match_over_rccl_world1(ctx, amd, ref):
         ctx.synchronize()
         return out.cpu().numpy()[:int(cnt.item())].view(amd.MATCH_DTYPE).reshape(-1)
 
-    def match_sets(q, cat, rows):  # one launch per query image against all images' sets
-        out, cnt = ctx.descriptor_match_sets_device(q, cat, rows, 10000, 0.86)
+    def match_sets(q, cat, rows):  # one both-direction launch per lead image against the sets it leads
+        out, cnt, cout, ccnt = ctx.descriptor_match_sets_mutual_device(q, cat, rows, 10000, 0.86)
         ctx.synchronize()
-        out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
-        return [out[k][:int(cnt[k])].copy().view(amd.MATCH_DTYPE).reshape(-1) for k in range(len(rows))]
+        out, cnt, cout, ccnt = out.cpu().numpy(), cnt.cpu().numpy(), cout.cpu().numpy(), ccnt.cpu().numpy()
+        offs = np.concatenate([[0], np.cumsum(rows)])
+        return ([out[k][:int(cnt[k])].copy().view(amd.MATCH_DTYPE).reshape(-1) for k in range(len(rows))],
+                [cout[offs[k]:offs[k] + int(ccnt[k])].copy().view(amd.MATCH_DTYPE).reshape(-1) for k in range(len(rows))])
 
     try:
         pairs = amd.all_pairs_match(local, match)

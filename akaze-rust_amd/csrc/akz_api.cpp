@@ -124,7 +124,8 @@ struct akz_ctx {
     std::vector<akz_ctx*> lanes;
     unsigned next_lane = 0;
     bool is_lane = false;               // this context is a lane of another one
-    bool eager_finish = false;          // akz_ctx_set_eager_finish: jobs dealt to lanes are finished by the lanes' threads
+    bool eager_finish = true;           // akz_ctx_set_eager_finish (default on): the finish half of every job begun through
+                                        // akz_extract_begin_* runs on the context's own thread (a lane's on the lane's)
     std::shared_ptr<Finisher> fin;      // (a lane's) finisher thread (shared with its jobs: one may outlive the context), started with its first eager job
     hipEvent_t lane_in = nullptr;       // inputs of the job are ready on the caller's stream
     // stage profiling (akz_ctx_set_profiling)

@@ -145,14 +145,28 @@ def test_begin_finish_pipelined_matches_oracle(ctx, amd, ref):
     import torch
     fa = np.stack([amd.synth_frame(480, 270, i) for i in range(2)])
     fb = np.stack([amd.synth_frame(480, 270, 10 + i) for i in range(3)])
-    ja = ctx.extract_begin(torch.from_numpy(fa).cuda())
-    jb = ctx.extract_begin(torch.from_numpy(fb).cuda())
-    jc = ctx.extract_begin(torch.from_numpy(fa).cuda())
-    with pytest.raises(amd.AkazeError):
-        ctx.extract_begin(torch.from_numpy(fa).cuda())
-    ra = ja.finish()
-    rb = jb.finish()
-    del jc  # abandoned without finishing
+    ctx.set_eager_finish(False)  # (with the finish half on the context's own thread -- the default -- a job gives its slot
+    try:                         #  back as soon as that thread has fetched its candidates, whenever that is)
+        ja = ctx.extract_begin(torch.from_numpy(fa).cuda())
+        jb = ctx.extract_begin(torch.from_numpy(fb).cuda())
+        jc = ctx.extract_begin(torch.from_numpy(fa).cuda())
+        with pytest.raises(amd.AkazeError):
+            ctx.extract_begin(torch.from_numpy(fa).cuda())
+        ra = ja.finish()
+        rb = jb.finish()
+        del jc  # abandoned without finishing
+    finally:
+        ctx.set_eager_finish(True)
+    # the same three jobs with the finish half on the context's own thread
+    ea = ctx.extract_begin(torch.from_numpy(fa).cuda())
+    eb = ctx.extract_begin(torch.from_numpy(fb).cuda())
+    ec = ctx.extract_begin(torch.from_numpy(fa).cuda())
+    rea, reb = ea.finish(), eb.finish()
+    del ec
+    for i in range(2):
+        assert rea.keypoints(i).tobytes() == ra.keypoints(i).tobytes() and rea.descriptors(i).tobytes() == ra.descriptors(i).tobytes()
+    for i in range(3):
+        assert reb.keypoints(i).tobytes() == rb.keypoints(i).tobytes() and reb.descriptors(i).tobytes() == rb.descriptors(i).tobytes()
     for i in range(2):
         assert_same_result(ra, ref.extract(fa[i]), planes=(i == 0), img=i)
     for i in range(3):
@@ -504,7 +518,10 @@ def test_result_may_outlive_its_context(amd, ref):
     c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
     frame = amd.synth_frame(480, 270, 3)
     res = c.extract_features(frame)
-    job = c.extract_begin(torch.from_numpy(frame[None]).cuda())
+    c.set_eager_finish(False)
+    job = c.extract_begin(torch.from_numpy(frame[None]).cuda())      # its finish half would run in finish(): refused later
+    c.set_eager_finish(True)
+    job_e = c.extract_begin(torch.from_numpy(frame[None]).cuda())    # finished by the context's own thread before it goes
     c.close()
     q = ref.extract(frame)
     assert res.keypoints().tobytes() == q.keypoints().tobytes() and np.array_equal(res.descriptors(), q.descriptors())
@@ -512,6 +529,11 @@ def test_result_may_outlive_its_context(amd, ref):
         res.plane(2, "Lt")
     with pytest.raises(amd.AkazeError):
         job.finish()
+    late = job_e.finish()
+    assert late.keypoints().tobytes() == q.keypoints().tobytes() and np.array_equal(late.descriptors(), q.descriptors())
+    with pytest.raises(amd.AkazeError):
+        late.plane(2, "Lt")
+    late.close()
     res.close()
     del job
 
@@ -567,6 +589,7 @@ def test_host_frames_begin_matches_device_frames(amd, ref):
         f32 = (sets[1].astype(np.float32) * np.float32(1.0)) / np.float32(255.0)
         g = c.extract_begin_host(f32).finish()
         assert_same_result(g, ref.extract(f32[1]), img=1)
+        c.set_eager_finish(False)  # (jobs finished by the context's own thread give their slots back on their own)
         with pytest.raises(amd.AkazeError):
             [c.extract_begin_host(sets[0]) for _ in range(4)]  # a fourth job in flight is refused
     finally:

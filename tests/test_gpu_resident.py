@@ -134,6 +134,7 @@ def test_eager_finish_batches_three_in_flight(amd, ref):
     batches = [np.stack([amd.synth_frame(1920, 1080, 300 + 5 * b + i) for i in range(5)]) for b in range(3)]
     dev = [torch.from_numpy(b).cuda() for b in batches]
     torch.cuda.synchronize()
+    ctx.set_eager_finish(False)  # (the default is on)
     plain = [ctx.extract_begin(d).finish() for d in dev]
     ctx.set_eager_finish(True)
     for sched in ((0, 1), (1, 1), (2, 0), (3, 0), (1, 0)):

@@ -145,6 +145,7 @@ struct akz_ctx {
     int pre_mode = 0;            // early stages: 0 on the context's stream, 2 on the copy stream
     int place_replaced = 0;      // streams that were re-created because they shared a queue with another one
     int place_collisions = 0;    // pairs that still share a queue (no free queue was found)
+    int lane_collisions = 0;     // lanes whose stream still shares a queue or a pipe with another lane's
     hipEvent_t probe_ev[2] = {nullptr, nullptr};
     int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
     akz_profile prof{};
@@ -1053,42 +1054,38 @@ static int streams_interfere(akz_ctx* c, hipStream_t a, hipStream_t b, float alo
 // and the rejected ones stay alive until the end so that they keep theirs occupied).  The early stages of a batch run
 // on the copy stream (idle for resident frames; for host frames the blur has to follow the upload anyway) -- a fifth busy
 // stream would have to share a pipe with one of the four.  About 0.4 ms per pair, once per context.
-static int place_streams(akz_ctx* c) {
-    c->placed = true;
-    if (c->is_lane) return AKZ_OK;
-    finisher_drain(c);  // (the finish half uses c->aux)
-    AKZ_TRY(ensure_aux(c));
-    if (!c->coarse) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->coarse, hipStreamNonBlocking));
-    if (!c->copy) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
-    if (c->sched[2]) {  // (measurement: no probe -- streams as the runtime placed them)
-        c->pre_mode = 2;
+// the probe's working set: streams already accepted, rejected ones (kept alive until the end so that they keep their queues
+// occupied), the time 24 tiny kernels take on one stream
+struct StreamPlacer {
+    akz_ctx* c;
+    float alone_ms = 0.0f;
+    std::vector<hipStream_t> accepted, rejected;
+    explicit StreamPlacer(akz_ctx* ctx) : c(ctx) {}
+    ~StreamPlacer() {
+        for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    }
+    int calibrate(hipStream_t on) {
+        for (hipEvent_t& e : c->probe_ev)
+            if (!e) AKZ_HIP_TRY(hipEventCreate(&e));
+        launch::delay(on, 1);  // (the first launch of a kernel loads its code object: not part of a measurement)
+        AKZ_HIP_TRY(hipStreamSynchronize(on));
+        AKZ_HIP_TRY(hipEventRecord(c->probe_ev[0], on));
+        for (int k = 0; k < 24; ++k) launch::delay(on, 1);
+        AKZ_HIP_TRY(hipEventRecord(c->probe_ev[1], on));
+        AKZ_HIP_TRY(hipEventSynchronize(c->probe_ev[1]));
+        AKZ_HIP_TRY(hipEventElapsedTime(&alone_ms, c->probe_ev[0], c->probe_ev[1]));
         return AKZ_OK;
     }
-    AKZ_HIP_TRY(hipStreamSynchronize(c->main));
-    AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
-    AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
-    AKZ_HIP_TRY(hipStreamSynchronize(c->copy));
-    for (hipEvent_t& e : c->probe_ev)
-        if (!e) AKZ_HIP_TRY(hipEventCreate(&e));
-    launch::delay(c->main, 1);  // (the first launch of a kernel loads its code object: not part of a measurement)
-    AKZ_HIP_TRY(hipStreamSynchronize(c->main));
-    float alone_ms = 0.0f;
-    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[0], c->main));
-    for (int k = 0; k < 24; ++k) launch::delay(c->main, 1);
-    AKZ_HIP_TRY(hipEventRecord(c->probe_ev[1], c->main));
-    AKZ_HIP_TRY(hipEventSynchronize(c->probe_ev[1]));
-    AKZ_HIP_TRY(hipEventElapsedTime(&alone_ms, c->probe_ev[0], c->probe_ev[1]));
-    std::vector<hipStream_t> accepted{c->main}, rejected;
-    auto collides = [&](hipStream_t x, bool* hit) -> int {
+    int collides(hipStream_t x, bool* hit) {
         *hit = false;
         for (hipStream_t a : accepted) {
             AKZ_TRY(streams_interfere(c, a, x, alone_ms, hit));
             if (*hit) return AKZ_OK;
         }
         return AKZ_OK;
-    };
-    // *slot ends up a stream that interferes with none of `accepted`, or keeps its value (free = false)
-    auto settle = [&](hipStream_t* slot, bool* free) -> int {
+    }
+    // *slot ends up a stream that interferes with none of `accepted` (and joins them), or keeps its value (free = false)
+    int settle(hipStream_t* slot, bool* free) {
         bool hit = false;
         AKZ_TRY(collides(*slot, &hit));
         for (int attempt = 0; hit && attempt < 8; ++attempt) {
@@ -1110,21 +1107,54 @@ static int place_streams(akz_ctx* c) {
             }
         }
         *free = !hit;
+        accepted.push_back(*slot);
         return AKZ_OK;
-    };
-    int st = AKZ_OK;
-    bool free_coarse = false, free_aux = false, free_copy = false;
-    if ((st = settle(&c->coarse, &free_coarse)) == AKZ_OK) {
-        accepted.push_back(c->coarse);
-        if ((st = settle(&c->aux, &free_aux)) == AKZ_OK) {
-            accepted.push_back(c->aux);
-            st = settle(&c->copy, &free_copy);
-        }
     }
-    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-    AKZ_TRY(st);
+};
+static int place_streams(akz_ctx* c) {
+    c->placed = true;
+    if (c->is_lane) return AKZ_OK;
+    finisher_drain(c);  // (the finish half uses c->aux)
+    AKZ_TRY(ensure_aux(c));
+    if (!c->coarse) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->coarse, hipStreamNonBlocking));
+    if (!c->copy) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    if (c->sched[2]) {  // (measurement: no probe -- streams as the runtime placed them)
+        c->pre_mode = 2;
+        return AKZ_OK;
+    }
+    AKZ_HIP_TRY(hipStreamSynchronize(c->main));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->copy));
+    StreamPlacer sp(c);
+    AKZ_TRY(sp.calibrate(c->main));
+    sp.accepted.push_back(c->main);
+    bool free_coarse = false, free_aux = false, free_copy = false;
+    AKZ_TRY(sp.settle(&c->coarse, &free_coarse));
+    AKZ_TRY(sp.settle(&c->aux, &free_aux));
+    AKZ_TRY(sp.settle(&c->copy, &free_copy));
     c->place_collisions = (free_coarse ? 0 : 1) + (free_aux ? 0 : 1) + (free_copy ? 0 : 1);
     c->pre_mode = free_copy ? 2 : 0;
+    return AKZ_OK;
+}
+// Lanes: a lane enqueues both halves of its jobs on its one stream, and the point of lanes is that their launch chains run
+// side by side -- the same check for the lanes' streams (among themselves: the caller's stream carries only the events
+// that order a lane behind the caller's work).  Up to four lanes can have a pipe each.
+static int place_lanes(akz_ctx* c) {
+    if (c->sched[2] || c->lanes.empty()) return AKZ_OK;
+    for (akz_ctx* l : c->lanes) AKZ_HIP_TRY(hipStreamSynchronize(l->main));
+    StreamPlacer sp(c);
+    AKZ_TRY(sp.calibrate(c->lanes[0]->main));
+    c->lane_collisions = 0;
+    for (akz_ctx* l : c->lanes) {
+        bool free = false;
+        hipStream_t st = l->main;
+        AKZ_TRY(sp.settle(&st, &free));
+        if (st != l->main) {  // (the replaced stream is destroyed with the placer's rejects; the lane owns the new one)
+            l->main = l->stream = st;
+        }
+        if (!free) ++c->lane_collisions;
+    }
     return AKZ_OK;
 }
 
@@ -2082,7 +2112,7 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         c->lanes.push_back(l);
     }
     c->next_lane = 0;
-    return AKZ_OK;
+    return place_lanes(c);
 }
 // on != 0: the finish half of every job that is dealt to a lane starts on the lane's own thread as soon as the job has
 // been begun; akz_extract_finish waits for it and hands the result over (bit-identical; errors of the finish half are
@@ -2939,7 +2969,7 @@ int akz_debug_stream_placement(akz_ctx* c, int* info) {
     info[0] = c->placed ? 1 : 0;
     info[1] = c->pre_mode;
     info[2] = c->place_replaced;
-    info[3] = c->place_collisions;
+    info[3] = c->place_collisions + c->lane_collisions;
     return AKZ_OK;
 }
 int akz_debug_set_host_sort(akz_ctx* c, int on) {

@@ -31,8 +31,13 @@ extern "C" {
 
 /* 3 (round 3): additions only -- akz_extract_begin_host_*, akz_ctx_set_host_threads, akz_ctx_set_eager_finish,
    akz_gather_image_rows, akz_match_all_pairs / akz_pairs_*, AKZ_INPUT_READY; the gather's overflow protocol.  Every
-   entry point of version 2 keeps its signature and meaning. */
-#define AKZ_ABI_VERSION 3
+   entry point of version 2 keeps its signature and meaning.
+   4 (round 4): akz_descriptor_match_sets_mutual_device and akz_pairs_holder added; akz_match_all_pairs matches every
+   unordered image pair once and a rank's akz_pairs holds both lists of the pairs whose lead image it owns (version 3: the
+   ordered pairs whose query image it owns); akz_ctx_set_eager_finish covers the context's own jobs and defaults to on;
+   the kernel-family selectors and the synthetic-frame generator moved to akaze_hip_debug.h (still exported).  No
+   signature changed. */
+#define AKZ_ABI_VERSION 4
 
 typedef enum akz_status {
     AKZ_OK = 0,
@@ -238,6 +243,10 @@ int akz_job_abandon(akz_job* job);
 int akz_extract_from_planes(akz_ctx* ctx, uint32_t w, uint32_t h, const akz_config* cfg, const float* const* planes,
                             uint64_t n_levels, uint32_t flags, akz_result** out);
 
+/* Releases the result; its device blocks (pyramid planes, descriptor rows) go back to the context's pool.  Work of the
+   CALLER that reads device pointers obtained from the result (akz_result_device_plane, akz_result_device_descriptors) must
+   have completed: the next batch's first stages may run ahead on another stream of the context (AKZ_INPUT_READY,
+   akz_extract_begin_host_*) and write a pooled block before anything still queued on the caller's stream has run. */
 int akz_result_free(akz_result* res);
 int akz_result_num_images(const akz_result* res, uint64_t* n_images);
 /* (Vec<EvolutionStep>.len(), Vec<Keypoint>.len(), Descriptor.vector.len()) of image `img` */

@@ -124,6 +124,23 @@ def test_input_ready_batches_run_ahead(ctx, amd, ref):
     assert_same_result(host[1], ref.extract(batches[1][4], threads=16), planes=False, img=4)
 
 
+def test_small_frames_large_batch_resident_tail_runs_once(ctx, amd, ref):
+    """Small frames in a batch above the 8 Mpx gate (72 x 480x270 = 9.3 Mpx): the resident tail starts at octave 1 (240 x
+    135 fits one compute unit), BEFORE the octave the coarse chain would fork at -- the chain then forks where the tail
+    starts and the levels behind it are not run a second time as separate launches (round-3 advice): three fused level
+    launches + one resident launch, every plane of one frame against the oracle."""
+    import torch
+    frames = np.stack([amd.synth_frame(480, 270, 500 + i) for i in range(72)])
+    ctx.set_profiling(2)
+    ctx.get_profile(reset=True)
+    res = ctx.extract_features(torch.from_numpy(frames).cuda())
+    prof = ctx.get_profile(reset=True)
+    ctx.set_profiling(0)
+    assert prof["fed_launches"] <= 5, prof
+    assert_same_result(res, ref.extract(frames[41]), img=41)
+    assert_same_result(res, ref.extract(frames[0]), planes=False, img=0)
+
+
 def test_eager_finish_batches_three_in_flight(amd, ref):
     """akz_ctx_set_eager_finish on a context without lanes: the finish half of every batch runs on the context's own
     thread while the caller begins the next ones (three 5-frame 1080p batches begun back to back, device and host input,

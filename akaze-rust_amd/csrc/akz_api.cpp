@@ -1158,6 +1158,30 @@ static int place_lanes(akz_ctx* c) {
     return AKZ_OK;
 }
 
+// Streams of another component of the process that are busy beside a context's (the exchange stream of akz_comm: one RCCL
+// collective per step): they get queues and pipes that the caller's stream, the coarse chain's and the finish half's do not
+// use -- with four pipes that leaves the copy stream's, which carries the least.
+int akz::place_streams_beside(akz_ctx* c, hipStream_t* slots, int n_slots, int* still_shared) {
+    AKZ_TRY(bind(c));
+    if (still_shared) *still_shared = 0;
+    if (c->is_lane || c->sched[2] || n_slots <= 0) return AKZ_OK;
+    if (!c->placed) AKZ_TRY(place_streams(c));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->main));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->coarse));
+    AKZ_HIP_TRY(hipStreamSynchronize(c->aux));
+    for (int i = 0; i < n_slots; ++i) AKZ_HIP_TRY(hipStreamSynchronize(slots[i]));
+    StreamPlacer sp(c);
+    AKZ_TRY(sp.calibrate(c->main));
+    sp.accepted = {c->main, c->coarse, c->aux};
+    for (int i = 0; i < n_slots; ++i) {
+        bool free = false;
+        AKZ_TRY(sp.settle(&slots[i], &free));
+        sp.accepted.pop_back();  // (the component's own streams may share among themselves)
+        if (!free && still_shared) ++*still_shared;
+    }
+    return AKZ_OK;
+}
+
 template <typename T>
 static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
                          uint32_t flags, akz_job** out, int want_slot = -1, hipEvent_t input_ready = nullptr) {

@@ -300,6 +300,20 @@ int akz_comm_destroy(akz_comm* c) {
     return AKZ_OK;
 }
 
+int akz_comm_place_streams(akz_comm* c, akz_ctx* ctx) {
+    if (!c || !ctx) {
+        set_error("akz_comm_place_streams: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t slots[2] = {c->xs, c->cs};
+    int shared = 0;
+    const int st = akz::place_streams_beside(ctx, slots, 2, &shared);
+    c->xs = slots[0];
+    c->cs = slots[1];
+    return st;
+}
+
 int akz_comm_info(const akz_comm* c, int* rank, int* nranks) {
     if (!c) return AKZ_ERR_INVALID_ARG;
     if (rank) *rank = c->rank;

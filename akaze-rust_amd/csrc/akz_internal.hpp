@@ -52,6 +52,10 @@ int match_sets_at(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_
                   const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
                   uint64_t* d_n_out, akz_match* d_out_cols, uint64_t* d_n_cols);
 
+// streams of another component that run beside a context's: each slot ends up on a hardware queue and a pipe that the
+// context's caller, coarse and finish streams do not use (a colliding stream is destroyed and replaced) -- akz_api.cpp
+int place_streams_beside(akz_ctx* c, hipStream_t* slots, int n_slots, int* still_shared);
+
 // ---- host-side planning (akz_plan.cpp) ---------------------------------------------------
 struct LevelPlan {
     double etime = 0, esigma = 0;

@@ -201,6 +201,7 @@ def lib():
         "akz_comm_unique_id": ([vp], i32),
         "akz_comm_create": ([i32, vp, i32, i32, C.POINTER(vp)], i32),
         "akz_comm_destroy": ([vp], i32),
+        "akz_comm_place_streams": ([vp, vp], i32),
         "akz_comm_info": ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
         "akz_gather_descriptors": ([vp, vp, u64, C.POINTER(vp), pu64], i32),
         "akz_gather_begin": ([vp, C.POINTER(vp), u64, u64, C.POINTER(vp)], i32),
@@ -1101,6 +1102,11 @@ class Comm:
         buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
         _check(lib().akz_comm_create(int(device), buf, int(rank), int(nranks), C.byref(self._h)))
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
+
+    def place_streams(self, ctx):
+        """akz_comm_place_streams: the communicator's streams onto queues / pipes that the context's busy streams do not use
+        (once, before the first step)."""
+        _check(lib().akz_comm_place_streams(self._h, ctx._h))
 
     @property
     def _gathers(self):

@@ -438,6 +438,8 @@ def main_rank(args):
                 uid = torch.frombuffer(bytearray(A.comm_unique_id()), dtype=torch.uint8).clone()
             dist.broadcast(uid, src=0)
             xch["comm"] = A.Comm(dev_index, bytes(uid.numpy().tobytes()), rank, world)
+            # the collective of a step runs beside the next batch's kernels: its streams go where the context's busy ones are not
+            xch["comm"].place_streams(ctx)
             ok = 1.0
         except Exception as e:  # RCCL cannot be loaded / initialised: fall back to torch.distributed on every rank
             sys.stderr.write(f"rank {rank}: C-ABI exchange unavailable ({e}); falling back to torch.distributed\n")

@@ -332,6 +332,11 @@ typedef struct akz_gather akz_gather; /* one exchange in flight */
 int akz_comm_unique_id(uint8_t* id_out /* AKZ_COMM_ID_BYTES */);
 int akz_comm_create(int device, const uint8_t* id, int rank, int nranks, akz_comm** out);
 int akz_comm_destroy(akz_comm* comm);
+/* Optional, once, with idle streams (before the first step): moves the communicator's two streams onto hardware queues and
+   command-processor pipes that `ctx`'s busy streams (the caller's, the coarse chain's, the finish half's) do not use -- the
+   collective of a step runs beside the next batch's kernels, and two busy streams on one queue or pipe slow both (see
+   akz_ctx / INTEGRATION.md, threading).  Triggers the context's own stream-placement probe if it has not run. */
+int akz_comm_place_streams(akz_comm* comm, akz_ctx* ctx);
 int akz_comm_info(const akz_comm* comm, int* rank, int* nranks);
 /* Appendix C form, synchronous: every rank contributes n_local rows (device, 64 bytes each, as returned by
    akz_result_device_descriptors); on return *d_all points at the rows of all ranks in rank order (device memory owned

@@ -21,6 +21,7 @@ def test_gather_selftest_binary_world1():
 def test_comm_gather_matches_local_rows(ctx, amd):
     import torch
     comm = amd.Comm(0, amd.comm_unique_id(), 0, 1)
+    comm.place_streams(ctx)  # its two streams onto queues / pipes the context's busy streams do not use
     frames = torch.from_numpy(np.stack([amd.synth_frame(320, 240, i) for i in range(3)])).cuda()
     res = ctx.extract_features(frames, keep_all_planes=False)
     rows = sum(res.counts(i)[1] for i in range(3))

@@ -376,6 +376,8 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                                                   unsigned long long* __restrict__ cbest = nullptr,
                                                   unsigned* __restrict__ csecond = nullptr, unsigned col_q0 = 0) {
     constexpr int QB = (NT / 64) * 32 * NB;
+    // (12 waves -- NT = 768, one or two query blocks per wave -- measured in round 4: 2.68 / 2.44 ms against 1.80 at 90 K rows,
+    //  profiles/r04_match_mutual.txt: the loop wants its 16 waves; that form is not maintained)
     static_assert(MM_SUB == 4 && (NB == 1 || NB == 2) && (NT == 512 || NT == 1024), "staging below: two 64-row parts per 128-row tile");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH4];
     __shared__ __attribute__((aligned(16))) float s_lim[2][COLS ? MM_TR : 4];  // COLS: accumulator limits of the tile's rows
@@ -417,14 +419,16 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     }
     // staging: the next tile arrives in two 64-row parts (1024 sixteen-byte pieces each) through one register stage:
     // requested before sub-tiles 0 / 2, handed to the other LDS buffer after sub-tiles 1 / 3
-    constexpr int PIECES = 1024 / NT;
+    constexpr int PIECES = (1024 + NT - 1) / NT;
+    constexpr bool EXACT = PIECES * NT == 1024;  // (768 threads: the second piece exists for the first 256 only)
     unsigned st_src[PIECES], st_dst[PIECES];
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
-        const unsigned idx = tid + (unsigned)p * NT;
+        const unsigned idx = min(tid + (unsigned)p * NT, 1023u);  // (a surplus thread repeats piece 1023: same bytes, same place)
         st_src[p] = (idx >> 4) * KB4 + (idx & 15u) * 16u;
         st_dst[p] = (idx >> 4) * MM_PITCH4 + (idx & 15u) * 16u;
     }
+    (void)EXACT;
     uint4 stage[PIECES];
     unsigned long long lim_lo = 0, lim_hi = 0;  // COLS: csecond of rows 4 tid .. 4 tid + 3 of the tile being staged (tid < 32)
     auto fetch = [&](unsigned tile, int part) {

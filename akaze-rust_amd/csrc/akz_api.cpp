@@ -2567,14 +2567,15 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
         uint32_t* bound = qpop + q_rows;
         uint32_t* tpop = bound + q_rows;
         const bool fp4 = c->match_mode >= 2;
-        launch::unpack_bits(c->stream, d_d0, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, 1, nullptr, fp4);
-        launch::unpack_bits(c->stream, d_d1, (uint32_t)n1, t_rows, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, nullptr, fp4);
+        launch::unpack_pair(c->stream, d_d0, (uint32_t)n0, q_rows, (uint8_t*)c->mm_q8.p, qpop, bound, thr, d_d1, (uint32_t)n1, t_rows,
+                            (uint8_t*)c->mm_t8.p, tpop, fp4);
         launch::match_mfma(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p,
                            (uint32_t)n1, thr, bound, chunks, rec, fp4);
     } else {
         launch::match(c->stream, d_d0, (uint32_t)n0, d_d1, (uint32_t)n1, thr, rows_le_61, chunks, rec);
     }
-    // more than a few chunks: a parallel merge first (the compaction is one workgroup)
+    // more than a few chunks: a parallel merge first (the compaction is ONE workgroup, i.e. one compute unit's load path:
+    // folding 11 chunks of 11 K queries there took 35 us against 5 for the 44-workgroup merge)
     const bool premerge = chunks > 4;
     if (premerge) launch::match_merge(c->stream, rec, (uint32_t)n0, chunks, thr, rec + (size_t)chunks * n0);
     launch::match_compact(c->stream, premerge ? rec + (size_t)chunks * n0 : rec, (uint32_t)n0, premerge ? 1u : chunks, thr,

@@ -252,6 +252,9 @@ uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tile
 // several sets): per LDS tile {first source row, valid rows}
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
                  uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles, bool fp4 = false);
+// both sets of a pair call in one launch (query form with one bound array, train form)
+void unpack_pair(hipStream_t s, const uint8_t* dq, uint32_t nq, uint32_t q_pad, uint8_t* outq, uint32_t* popq, uint32_t* bound, uint32_t threshold,
+                 const uint8_t* dt, uint32_t nt, uint32_t t_pad, uint8_t* outt, uint32_t* popt, bool fp4);
 uint32_t match_mfma_tile_rows();
 uint32_t match_mfma_query_block();
 struct MatchChunkHost {  // = MatchChunk of akz_match.hip

@@ -70,11 +70,10 @@ constexpr int MM_PITCH = KB + 16;  // LDS row pitch in bytes
 // 0x2 / 0xA) in the 488 columns of the 61 descriptor bytes, 0 in the other 24, the same for queries and train rows:
 //     <a', b'> = 488 - 2 hamming(a, b),
 // so no bit counts are needed at all (and every sum is a small integer, exact in the f32 accumulators).
-__global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, bool query,
-                                                     uint8_t* __restrict__ out, unsigned* __restrict__ pop,
-                                                     unsigned* __restrict__ bound, unsigned threshold, unsigned n_bound,
-                                                     const uint2* __restrict__ tiles, bool fp4) {
-    const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+__device__ __forceinline__ void unpack_row(unsigned row, unsigned lane, const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, bool query,
+                                           uint8_t* __restrict__ out, unsigned* __restrict__ pop,
+                                           unsigned* __restrict__ bound, unsigned threshold, unsigned n_bound,
+                                           const uint2* __restrict__ tiles, bool fp4) {
     if (row >= n_pad) return;
     unsigned src = row;
     bool live = row < n;
@@ -119,6 +118,22 @@ __global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__
         if (bound)
             for (unsigned k = 0; k < n_bound; ++k) bound[(size_t)k * n_pad + row] = threshold;
     }
+}
+
+__global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, bool query,
+                                                     uint8_t* __restrict__ out, unsigned* __restrict__ pop,
+                                                     unsigned* __restrict__ bound, unsigned threshold, unsigned n_bound,
+                                                     const uint2* __restrict__ tiles, bool fp4) {
+    unpack_row(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63u, d, n, n_pad, query, out, pop, bound, threshold, n_bound, tiles, fp4);
+}
+// a pair call's two sets in one launch: rows [0, q_pad) are the query set, the rest the train set
+__global__ void __launch_bounds__(256) k_unpack_pair(const uint8_t* __restrict__ dq, unsigned nq, unsigned q_pad, uint8_t* __restrict__ outq,
+                                                     unsigned* __restrict__ popq, unsigned* __restrict__ bound, unsigned threshold,
+                                                     const uint8_t* __restrict__ dt, unsigned nt, unsigned t_pad, uint8_t* __restrict__ outt,
+                                                     unsigned* __restrict__ popt, bool fp4) {
+    const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row < q_pad) unpack_row(row, lane, dq, nq, q_pad, true, outq, popq, bound, threshold, 1u, nullptr, fp4);
+    else unpack_row(row - q_pad, lane, dt, nt, t_pad, false, outt, popt, nullptr, 0u, 0u, nullptr, fp4);
 }
 
 // blockIdx.x: 512 queries; blockIdx.y: a chunk of `chunk_tiles` train tiles.  q8 / t8: unpacked sets, rows padded
@@ -619,41 +634,54 @@ __global__ void __launch_bounds__(1024) k_match_compact_cols(const unsigned long
                                                              const unsigned* __restrict__ csecond, const ColSet* __restrict__ sets,
                                                              unsigned threshold, double ratio2, akz_match* __restrict__ out,
                                                              unsigned long long* __restrict__ n_out) {
-    __shared__ unsigned s_wave[16];
+    constexpr int IT = 16;  // (rounds of 16 x 1024 rows, two barriers each: as k_match_compact)
+    __shared__ unsigned s_cnt[IT][16];
     __shared__ unsigned s_base;
     const ColSet cs = sets[blockIdx.x];
     out += cs.out0;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
-    for (unsigned start = 0; start < cs.rows; start += 1024) {
-        const unsigned i = start + threadIdx.x;
-        bool keep = false;
-        unsigned min_d = 0, min_j = 0;
-        if (i < cs.rows) {
-            const unsigned long long b = cbest[(size_t)cs.row0 + i];
-            const unsigned second = csecond[(size_t)cs.row0 + i];
-            min_d = (unsigned)(b >> 32);
-            min_j = (unsigned)b;
-            keep = ((double)min_d < (double)second * ratio2) && (min_d < threshold);
+    for (unsigned start = 0; start < cs.rows; start += IT * 1024u) {
+        unsigned md[IT], mj[IT], keepmask = 0u;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const unsigned i = start + (unsigned)it * 1024u + threadIdx.x;
+            bool keep = false;
+            md[it] = mj[it] = 0u;
+            if (i < cs.rows) {
+                const unsigned long long b = cbest[(size_t)cs.row0 + i];
+                const unsigned second = csecond[(size_t)cs.row0 + i];
+                md[it] = (unsigned)(b >> 32);
+                mj[it] = (unsigned)b;
+                keep = ((double)md[it] < (double)second * ratio2) && (md[it] < threshold);
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (lane == 0) s_cnt[it][wave] = (unsigned)__popcll(bal);
+            keepmask |= keep ? 1u << it : 0u;
         }
-        const unsigned long long bal = __ballot(keep);
-        const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wave] = __popcll(bal);
         __syncthreads();
         unsigned off = s_base;
-        for (unsigned wv = 0; wv < wave; ++wv) off += s_wave[wv];
-        if (keep) {
-            akz_match o;
-            o.index_0 = i; o.index_1 = min_j; o.distance = (double)min_d;
-            out[off + before] = o;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            unsigned row = 0, below = 0;
+#pragma unroll
+            for (unsigned w = 0; w < 16; ++w) {
+                const unsigned c = s_cnt[it][w];
+                row += c;
+                below += w < wave ? c : 0u;
+            }
+            const bool keep = (keepmask >> it) & 1u;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                akz_match o;
+                o.index_0 = start + (unsigned)it * 1024u + threadIdx.x; o.index_1 = mj[it]; o.distance = (double)md[it];
+                out[off + below + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = o;
+            }
+            off += row;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned tot = 0;
-            for (unsigned wv = 0; wv < 16; ++wv) tot += s_wave[wv];
-            s_base += tot;
-        }
+        if (threadIdx.x == 0) s_base = off;
         __syncthreads();
     }
     if (threadIdx.x == 0) n_out[blockIdx.x] = s_base;
@@ -696,6 +724,11 @@ void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bo
                  uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles, bool fp4) {
     hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, query, out8, pop, bound, threshold,
                        n_bound, reinterpret_cast<const uint2*>(d_tiles), fp4);
+}
+void unpack_pair(hipStream_t s, const uint8_t* dq, uint32_t nq, uint32_t q_pad, uint8_t* outq, uint32_t* popq, uint32_t* bound, uint32_t threshold,
+                 const uint8_t* dt, uint32_t nt, uint32_t t_pad, uint8_t* outt, uint32_t* popt, bool fp4) {
+    hipLaunchKernelGGL(k_unpack_pair, dim3((q_pad + t_pad + 3) / 4), dim3(256), 0, s, dq, nq, q_pad, outq, popq, bound, threshold, dt, nt,
+                       t_pad, outt, popt, fp4);
 }
 uint32_t match_mfma_tile_rows() { return MM_TR; }
 uint32_t match_mfma_query_block() { return MM_QB; }

@@ -87,6 +87,8 @@ struct akz_ctx {
     DevBuf small;                            // hmax bits / histogram / counters
     DevBuf cand;                             // NMS candidates
     DevBuf cand_sorted, sort_scratch;        // the list in scan order (device sort of extract_finish) and the sort's scratch
+    DevBuf rel_scratch;                      // the selection's neighbour lists (launch::candidate_relations)
+    int dbg_select = -1;                     // akz_debug_set_select: 1 / 0 force the neighbour-list / the grid selection, -1 automatic
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
@@ -99,8 +101,8 @@ struct akz_ctx {
     uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
     int dbg_host_sort = -1;                            // akz_debug_set_host_sort: 1 / 0 force the host / the device sort, -1 automatic
     DevBuf cosi;                             // (cos, sin) per keypoint
-    DevBuf pin[6];                           // pinned host staging: candidates, orientation sums, descriptor
-                                             // rows, keypoint params, (cos, sin), contrast factors
+    DevBuf pin[8];                           // pinned host staging: candidates, orientation sums, descriptor
+                                             // rows, keypoint params, (cos, sin), contrast factors, neighbour lists, their flags
     std::vector<std::pair<size_t, void*>> slab_pool;  // freed device blocks (pyramid slabs, descriptor rows)
     std::mutex slab_m;                                // results are freed by the caller while a lane's finisher thread allocates
     // extractions in flight (akz_extract_begin_* / akz_extract_finish)
@@ -377,7 +379,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
-                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
+                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1643,14 +1645,34 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // per 32-frame batch and the dozen small launches of the device sort cost the kernels of the next batch more
     // (-1.5 % throughput); with the two threads a rank has on a node whose cores are shared by eight ranks they are a
     // fifth of a host phase that no longer hides under the GPU step (+7 % throughput with the device sort).
+    // The selection itself (round 4): with the list sorted on the device, the device also answers which candidates can be
+    // within `size` of which (k_relations) and the host's order-dependent logic walks those short lists on three small
+    // arrays instead of querying a spatial grid per image (select_keypoints_rel: the same answers, a quarter of the host
+    // time).  Taken where the host is the bottleneck -- contexts with fewer than four host threads, and lone frames, whose
+    // latency is the sum of the two halves -- and not for large batches on many-core hosts, where the extra small launches
+    // cost the kernels of the next batch more than the idle host threads gain.
+    const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < kBigLaunchPx()));
     bool sorted = false;
-    if (c->dbg_host_sort == 0 || (c->dbg_host_sort < 0 && c->pool().size() < 4)) {
+    uint16_t* d_rel = nullptr;
+    uint32_t* d_rel_flags = nullptr;
+    if (c->dbg_host_sort == 0 || (c->dbg_host_sort < 0 && (c->pool().size() < 4 || want_rel))) {
         AKZ_TRY(ensure(c, c->cand_sorted, (size_t)cap * sizeof(Candidate)));
         AKZ_TRY(ensure(c, c->sort_scratch, launch::sort_candidates_scratch(cap, max_px, (uint32_t)L, n)));
         sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
                                                 n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p);
         AKZ_HIP_TRY(hipGetLastError());
+        if (sorted && want_rel) {
+            std::vector<float> lsize, lratio;
+            selection_level_constants(plan, cfg, lsize, lratio);
+            std::vector<uint32_t> lw(L);
+            for (size_t l = 0; l < L; ++l) lw[l] = plan[l].w;
+            AKZ_TRY(ensure(c, c->rel_scratch, launch::candidate_relations_bytes(cap, (uint32_t)L, n)));
+            launch::candidate_relations(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), (uint32_t)L, n,
+                                        c->rel_scratch.p, &d_rel, &d_rel_flags);
+            AKZ_HIP_TRY(hipGetLastError());
+        }
     }
+    constexpr size_t kRelRow = (size_t)(kRel1 + kRel2) * sizeof(uint16_t);
     const Candidate* hc = nullptr;   // the whole list on the host (pinned)
     uint32_t total_c = 0;
     for (int attempt = 0;; ++attempt) {
@@ -1670,6 +1692,14 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             if (spec) {
                 AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec * sizeof(Candidate)));
                 AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, d_list, (size_t)spec * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+                if (d_rel) {
+                    AKZ_TRY(ensure_pinned(c, c->pin[6], (size_t)spec * kRelRow));
+                    AKZ_HIP_TRY(hipMemcpyAsync(c->pin[6].p, d_rel, (size_t)spec * kRelRow, hipMemcpyDeviceToHost, s));
+                }
+            }
+            if (d_rel) {
+                AKZ_TRY(ensure_pinned(c, c->pin[7], (size_t)n * sizeof(uint32_t)));
+                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[7].p, d_rel_flags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             }
         }
         AKZ_HIP_TRY(hipStreamSynchronize(s));
@@ -1685,6 +1715,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             }
             cap = total_c + total_c / 8;
             sorted = false;
+            d_rel = nullptr;  // (the lists belong to the truncated list)
             AKZ_HIP_TRY(hipStreamSynchronize(c->main));
             AKZ_TRY(ensure(c, c->cand_slot[job->slot], (size_t)cap * sizeof(Candidate)));
             AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
@@ -1703,6 +1734,14 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             if (have) std::memcpy(c->pin[0].p, keep.data(), (size_t)have * sizeof(Candidate));
             AKZ_HIP_TRY(hipMemcpyAsync((Candidate*)c->pin[0].p + have, d_list + have, (size_t)(total_c - have) * sizeof(Candidate),
                                        hipMemcpyDeviceToHost, s));
+            if (d_rel) {
+                std::vector<uint8_t> keep_rel;
+                if (have) keep_rel.assign((const uint8_t*)c->pin[6].p, (const uint8_t*)c->pin[6].p + (size_t)have * kRelRow);
+                AKZ_TRY(ensure_pinned(c, c->pin[6], (size_t)total_c * kRelRow));
+                if (have) std::memcpy(c->pin[6].p, keep_rel.data(), keep_rel.size());
+                AKZ_HIP_TRY(hipMemcpyAsync((uint8_t*)c->pin[6].p + (size_t)have * kRelRow, (const uint8_t*)d_rel + (size_t)have * kRelRow,
+                                           (size_t)(total_c - have) * kRelRow, hipMemcpyDeviceToHost, s));
+            }
             AKZ_HIP_TRY(hipStreamSynchronize(s));
         }
         AKZ_TRY(ensure_pinned(c, c->pin[0], sizeof(Candidate)));
@@ -1769,7 +1808,11 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                 sort_candidates(cands[img], plan);
                 span[img] = {cands[img].data(), cands[img].size()};
             }
-            select_keypoints(span[img].first, span[img].second, plan, cfg, hk[img], &r->n_extrema[img]);
+            if (d_rel && sorted && ((const uint32_t*)c->pin[7].p)[img] == 0)  // (a flagged image: a list was too short, or > 65 534 candidates)
+                select_keypoints_rel(span[img].first, span[img].second, (const uint16_t*)c->pin[6].p + (size_t)(span[img].first - hc) * (kRel1 + kRel2),
+                                     kRel1, kRel2, plan, cfg, hk[img], &r->n_extrema[img]);
+            else
+                select_keypoints(span[img].first, span[img].second, plan, cfg, hk[img], &r->n_extrema[img]);
         });
     }
     for (uint32_t img = 0; img < n; ++img) {
@@ -2133,6 +2176,7 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->dbg_pair_chunks = c->dbg_pair_chunks;
         l->dbg_set_chunks = c->dbg_set_chunks;
         l->dbg_host_sort = c->dbg_host_sort;
+        l->dbg_select = c->dbg_select;
         c->lanes.push_back(l);
     }
     c->next_lane = 0;
@@ -2995,6 +3039,12 @@ int akz_debug_stream_placement(akz_ctx* c, int* info) {
     info[1] = c->pre_mode;
     info[2] = c->place_replaced;
     info[3] = c->place_collisions + c->lane_collisions;
+    return AKZ_OK;
+}
+int akz_debug_set_select(akz_ctx* c, int mode) {
+    if (!c) return AKZ_ERR_INVALID_ARG;
+    c->dbg_select = mode < 0 ? -1 : (mode != 0);
+    for (akz_ctx* l : c->lanes) l->dbg_select = c->dbg_select;
     return AKZ_OK;
 }
 int akz_debug_set_host_sort(akz_ctx* c, int on) {

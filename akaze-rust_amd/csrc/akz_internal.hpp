@@ -114,6 +114,7 @@ struct LevelPtrs {  // device addresses of the planes one kernel needs, image 0 
     uint64_t stride;  // elements between consecutive images
 };
 constexpr int kMaxLevels = 64;
+constexpr int kRel1 = 6, kRel2 = 4;  // neighbour lists of the keypoint selection (akz_sort.hip, k_relations)
 struct LevelTable {
     LevelPtrs lv[kMaxLevels];
 };
@@ -229,6 +230,12 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images);
 bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, uint64_t max_px,
                             uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted);
+// who can be within `size` of whom (akz_sort.hip, k_relations): per candidate of the SORTED list kRel1 indices of earlier
+// candidates of its own / the previous level and kRel2 of the next level, relative to its image's first candidate
+size_t candidate_relations_bytes(uint32_t cap, uint32_t n_levels, uint32_t n_images);
+void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
+                         const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, void* scratch, uint16_t** d_rel_out,
+                         uint32_t** d_flags_out);
 // candidates of all images are appended to ONE list (d_count is a single counter, cap the list capacity)
 void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
@@ -298,6 +305,11 @@ void sort_candidates(std::vector<Candidate>& cands, const std::vector<LevelPlan>
 // scale_space_extrema.rs:12-132 on raster-ordered candidates, then :141-178 (refinement w/o orientation)
 void select_keypoints(const Candidate* cands_sorted, size_t n_cands, const std::vector<LevelPlan>& plan,
                       const akz_config& cfg, std::vector<HostKeypoint>& out, uint64_t* n_extrema);
+// the same selection from the device's neighbour lists (launch::candidate_relations; rel: k1 + k2 entries per candidate)
+void select_keypoints_rel(const Candidate* cands_sorted, size_t n_cands, const uint16_t* rel, int k1, int k2, const std::vector<LevelPlan>& plan,
+                          const akz_config& cfg, std::vector<HostKeypoint>& out, uint64_t* n_extrema);
+// the per-level constants of the selection (f32, as select_keypoints forms them)
+void selection_level_constants(const std::vector<LevelPlan>& plan, const akz_config& cfg, std::vector<float>& size, std::vector<float>& ratio);
 // which of the sliding windows of compute_main_orientation contain atan2f(a, a), a > 0
 void orientation_windows(unsigned long long* mask, uint32_t* n_windows);
 float border_margin(const LevelPlan& lv, const akz_config& cfg);  // smax * sigma_size (f32)

@@ -338,4 +338,143 @@ void select_keypoints(const Candidate* cands, size_t n_cands, const std::vector<
     if (n_extrema) *n_extrema = extrema;
 }
 
+void selection_level_constants(const std::vector<LevelPlan>& plan, const akz_config& cfg, std::vector<float>& size, std::vector<float>& ratio) {
+    size.resize(plan.size());
+    ratio.resize(plan.size());
+    for (size_t l = 0; l < plan.size(); ++l) {
+        size[l] = (float)(plan[l].esigma * cfg.derivative_factor);
+        ratio[l] = powf(2.0f, (float)plan[l].octave);
+    }
+}
+
+// The same selection as select_keypoints (scale_space_extrema.rs:43-178) from the device's neighbour lists: rel holds, per
+// candidate, kRel1 candidates of its own (earlier) / the previous level within `size` of its query point and kRel2
+// candidates of the next level within `size` of its stored position (launch::candidate_relations; indices into this
+// image's list, 0xffff = none).  A cache entry is represented by the candidate that occupies it: alive[c], slot[c]; a
+// replacement in place (:70-76 / :95-99) hands the slot to the new candidate.  "First cache entry within size" = the
+// lowest slot among the alive neighbours; "a later entry of the next level within size" = an alive next-level neighbour
+// with a slot >= the entry's own.
+void select_keypoints_rel(const Candidate* cands, size_t n, const uint16_t* rel, int k1, int k2, const std::vector<LevelPlan>& plan,
+                          const akz_config& cfg, std::vector<HostKeypoint>& out, uint64_t* n_extrema) {
+    out.clear();
+    if (n_extrema) *n_extrema = 0;
+    if (plan.empty() || n == 0) return;
+    static thread_local std::vector<uint32_t> slot_tl, occ_tl;
+    static thread_local std::vector<uint8_t> alive_tl;
+    std::vector<uint32_t>&slot = slot_tl, &occ = occ_tl;
+    std::vector<uint8_t>& alive = alive_tl;
+    slot.assign(n, 0);
+    alive.assign(n, 0);
+    occ.clear();
+    occ.reserve(n);
+    const size_t K = (size_t)k1 + (size_t)k2;
+    // the rare candidate whose list overflowed (0xfffe): its partner levels are scanned here, with the selection's own
+    // expressions.  first[l] = the image's first candidate of level l (the list is sorted by level)
+    std::vector<uint32_t> first(plan.size() + 2, (uint32_t)n);
+    {
+        uint32_t at = 0;
+        for (size_t l = 0; l <= plan.size(); ++l) {
+            while (at < n && cands[at].level < l) ++at;
+            first[l] = at;
+        }
+        first[plan.size() + 1] = (uint32_t)n;
+    }
+    struct Pos { float qx, qy, px, py, size2; };
+    auto pos_of = [&](size_t c) {
+        const LevelPlan& lv = plan[cands[c].level];
+        const float ratio = powf(2.0f, (float)lv.octave), size = (float)(lv.esigma * cfg.derivative_factor);
+        const uint32_t ly = cands[c].idx / lv.w, lx = cands[c].idx - ly * lv.w;
+        Pos p;
+        p.qx = (float)lx * ratio; p.qy = (float)ly * ratio;
+        p.px = p.qx + 0.5f * (ratio - 1.0f); p.py = p.qy + 0.5f * (ratio - 1.0f);
+        p.size2 = size * size;
+        return p;
+    };
+    for (size_t c = 0; c < n; ++c) {
+        const uint16_t* r = rel + c * K;
+        uint32_t hit = UINT32_MAX, hc = 0;
+        if (r[0] == 0xfffeu) {
+            const uint32_t l = cands[c].level;
+            const Pos me = pos_of(c);
+            for (size_t q = l > 0 ? first[l - 1] : first[l]; q < c; ++q) {
+                if (!alive[q] || slot[q] >= hit) continue;
+                const Pos o = pos_of(q);
+                const float dist = (me.qx - o.px) * (me.qx - o.px) + (me.qy - o.py) * (me.qy - o.py);
+                if (dist <= me.size2) {
+                    hit = slot[q];
+                    hc = (uint32_t)q;
+                }
+            }
+        } else {
+            for (int j = 0; j < k1 && r[j] != 0xffffu; ++j) {
+                const uint32_t q = r[j];
+                if (alive[q] && slot[q] < hit) {
+                    hit = slot[q];
+                    hc = q;
+                }
+            }
+        }
+        if (hit != UINT32_MAX) {
+            if (std::fabs(cands[c].v) > std::fabs(cands[hc].v)) {  // replaces the entry in place
+                alive[hc] = 0;
+                alive[c] = 1;
+                slot[c] = hit;
+                occ[hit] = (uint32_t)c;
+            }
+            continue;  // (else: not an extremum)
+        }
+        alive[c] = 1;
+        slot[c] = (uint32_t)occ.size();
+        occ.push_back((uint32_t)c);
+    }
+    uint64_t extrema = 0;
+    out.reserve(occ.size());
+    for (uint32_t i = 0; i < occ.size(); ++i) {
+        const uint32_t k = occ[i];
+        const uint16_t* r = rel + (size_t)k * K + k1;
+        bool repeated = false;
+        if (r[0] == 0xfffeu) {
+            const uint32_t l = cands[k].level;
+            const Pos me = pos_of(k);
+            for (size_t q = first[l + 1]; q < first[l + 2] && !repeated; ++q) {
+                if (!alive[q] || slot[q] < i) continue;
+                const Pos o = pos_of(q);
+                const float dist = (me.px - o.px) * (me.px - o.px) + (me.py - o.py) * (me.py - o.py);
+                repeated = dist <= me.size2;
+            }
+        } else {
+            for (int j = 0; j < k2 && r[j] != 0xffffu; ++j) {
+                const uint32_t q = r[j];
+                if (alive[q] && slot[q] >= i) {
+                    repeated = true;
+                    break;
+                }
+            }
+        }
+        if (repeated) continue;
+        ++extrema;
+        const Candidate& cd = cands[k];
+        const LevelPlan& lv = plan[cd.level];
+        const float ratio = powf(2.0f, (float)lv.octave);
+        const uint32_t ly = cd.idx / lv.w, lx = cd.idx - ly * lv.w;
+        const float d_x = 0.5f * (cd.xp - cd.xm), d_y = 0.5f * (cd.yp - cd.ym);
+        const float b0 = -d_x, b1 = -d_y;
+        if (std::fabs(b0) <= 1.0f && std::fabs(b1) <= 1.0f) {
+            HostKeypoint kp;
+            kp.lx = lx;
+            kp.ly = ly;
+            kp.response = std::fabs(cd.v);
+            kp.size = (float)(lv.esigma * cfg.derivative_factor);
+            kp.octave = lv.octave;
+            kp.class_id = cd.level;
+            kp.angle = 0.0f;
+            kp.xp = cd.xp; kp.xm = cd.xm; kp.yp = cd.yp; kp.ym = cd.ym;
+            kp.x = ((float)lx + b0) * ratio + 0.5f * (ratio - 1.0f);
+            kp.y = ((float)ly + b1) * ratio + 0.5f * (ratio - 1.0f);
+            out.push_back(kp);
+        }
+    }
+    if (n_extrema) *n_extrema = extrema;
+}
+
 }  // namespace akz

@@ -163,6 +163,7 @@ def lib():
         "akz_ctx_set_host_threads": ([vp, u32], i32),
         "akz_debug_set_match_chunks": ([vp, u32, u32], i32),
         "akz_debug_set_host_sort": ([vp, i32], i32),
+        "akz_debug_set_select": ([vp, i32], i32),
         "akz_debug_set_schedule": ([vp, i32, i32], i32),
         "akz_debug_stream_placement": ([vp, C.POINTER(i32)], i32),
         "akz_detector_kernel_name": ([], C.c_char_p),
@@ -346,6 +347,10 @@ class Context:
         """With lanes: the finish half of every job dealt to a lane starts on that lane's own thread as soon as the job
         has been begun; `finish()` then only collects the result (same results)."""
         _check(lib().akz_ctx_set_eager_finish(self._h, 1 if on else 0))
+
+    def debug_set_select(self, mode):
+        """akz_debug_set_select: keypoint selection from the device's neighbour lists (1), the host's grids (0), automatic (None)."""
+        _check(lib().akz_debug_set_select(self._h, -1 if mode is None else (1 if mode else 0)))
 
     def debug_set_schedule(self, key, value):
         """akz_debug_set_schedule: schedule variants of a large batch (measurement hook, identical results)."""

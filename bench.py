@@ -103,6 +103,7 @@ def parse_args(argv=None):
     ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one LDS-tiled kernel, 0 LDS-tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
     ap.add_argument("--eager", type=int, default=1, help="akz_ctx_set_eager_finish (the library's default: on): the finish half on the context's own thread")
+    ap.add_argument("--select", type=int, default=-1, help="akz_debug_set_select: keypoint selection from the device's neighbour lists (1), the host's grids (0), automatic (-1)")
     ap.add_argument("--sched", type=str, default="", help="akz_debug_set_schedule pairs, e.g. 0=1,1=1,2=0")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
@@ -410,6 +411,7 @@ def main_rank(args):
             ctx.set_host_threads(placement["cpus"])
         ctx.set_detector_mode(args.det_mode)
         ctx.set_eager_finish(bool(args.eager))
+        ctx.debug_set_select(None if args.select < 0 else bool(args.select))
         for kv in filter(None, args.sched.split(",")):
             k, v = kv.split("=")
             ctx.debug_set_schedule(int(k), int(v))

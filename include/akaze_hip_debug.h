@@ -41,6 +41,11 @@ int akz_debug_stream_placement(akz_ctx* ctx, int* info);
    that a candidate-list overflow and over-wide sort keys take), 0 = device sort, -1 = automatic (the default: device
    sort for contexts with fewer than four host threads).  Results are identical. */
 int akz_debug_set_host_sort(akz_ctx* ctx, int on);
+/* Test hook: how the host's keypoint selection finds "the first cache entry within size": 1 = from the device's neighbour
+   lists (k_relations; needs the device sort, which it switches on), 0 = from the host's spatial grids, -1 = automatic (the
+   default: neighbour lists for contexts with fewer than four host threads and for jobs below 8 Mpx).  Results are
+   identical. */
+int akz_debug_set_select(akz_ctx* ctx, int mode);
 
 /* ---- kernel-family selectors and the synthetic frame generator (tests, bench, tools): every mode gives bit-identical
    results; a drop-in host never calls these ---------------------------------------------------------------------- */

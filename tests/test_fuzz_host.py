@@ -1,6 +1,7 @@
 """The host-side parsers (image decoders, akaze-util file readers) under AddressSanitizer + UBSan on corrupted
 inputs: they must reject or decode, never read or write out of bounds.  CPU build only (tools/fuzz/fuzz_host.cpp)."""
 import os
+import re
 import shutil
 import subprocess
 
@@ -67,6 +68,8 @@ def test_keypoint_selection_matches_linear_scans_under_sanitizers(tmp_path):
     assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
     assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
     assert "identical to the linear scans" in run.stdout
+    m = re.search(r"\((\d+) rounds also through the neighbour lists", run.stdout)
+    assert m and int(m.group(1)) >= 300, run.stdout  # select_keypoints_rel (the device's neighbour lists, brute-forced here)
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")

@@ -446,6 +446,51 @@ def test_all_pairs_match_over_rccl_world1(ctx, amd, ref):
     assert total > 20
 
 
+def test_selection_from_device_neighbour_lists(amd, ref):
+    """The host's order-dependent keypoint selection fed by the device's neighbour lists (k_relations: who can be within
+    `size` of whom; akz_debug_set_select(1)) against the spatial-grid form (0): identical keypoints and descriptors on
+    single frames, a batch, a 4K frame, a 5 x 5 pyramid and a noise frame whose dense candidates overflow the lists (those
+    images fall back to the grids); one frame of each group against the oracle."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        cases = [
+            ("320x240", amd.synth_frame(320, 240, 5)[None], None, True),
+            ("1080p", amd.synth_frame(1920, 1080, 6)[None], None, True),
+            ("batch", np.stack([amd.synth_frame(640, 360, 70 + i) for i in range(5)]), None, True),
+            ("4k", amd.synth_frame(3840, 2160, 2)[None], None, False),
+            ("5x5", amd.synth_frame(800, 600, 9)[None], dict(num_sublevels=5, max_octave_evolution=5), True),
+            ("noise", np.random.default_rng(11).integers(0, 256, (1, 270, 480), dtype=np.uint8), None, True),
+        ]
+        for name, frames, kw, check_oracle in cases:
+            cfg = amd.Config(**kw) if kw else amd.Config()
+            dev = torch.from_numpy(frames).cuda()
+            c.debug_set_select(True)
+            r1 = c.extract_features(dev, cfg, keep_all_planes=False)
+            c.debug_set_select(False)
+            r0 = c.extract_features(dev, cfg, keep_all_planes=False)
+            for i in range(len(frames)):
+                assert r1.counts(i) == r0.counts(i), (name, i, r1.counts(i), r0.counts(i))
+                assert r1.keypoints(i).tobytes() == r0.keypoints(i).tobytes(), (name, i)
+                assert r1.descriptors(i).tobytes() == r0.descriptors(i).tobytes(), (name, i)
+            assert r1.counts(0)[1] > 10, name
+            if check_oracle:
+                i = len(frames) - 1
+                q = ref.extract(frames[i], ref.default_config(**kw) if kw else None)
+                assert r1.keypoints(i).tobytes() == q.keypoints().tobytes(), name
+                assert np.array_equal(r1.descriptors(i), q.descriptors()), name
+        # pipelined jobs through the lists (lone frames take them by default)
+        c.debug_set_select(None)
+        one = torch.from_numpy(amd.synth_frame(1920, 1080, 6)[None]).cuda()
+        base = c.extract_features(one, keep_all_planes=False)
+        jobs = [c.extract_begin(one, keep_all_planes=False) for _ in range(3)]
+        for j in jobs:
+            r = j.finish()
+            assert r.keypoints(0).tobytes() == base.keypoints(0).tobytes() and r.descriptors(0).tobytes() == base.descriptors(0).tobytes()
+    finally:
+        c.close()
+
+
 def test_describe_caller_supplied_keypoints(ctx, amd, ref):
     """compute_main_orientation + extract_descriptors as stand-alone ops (scale_space_extrema.rs:207-329,
     descriptors.rs:14-35) on keypoints the detector did not produce: the detector's own list reordered, and moved /

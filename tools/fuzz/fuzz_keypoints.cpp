@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 40;
     std::mt19937 rng(20261003);
     auto uni = [&](int lo, int hi) { return (int)(rng() % (unsigned)(hi - lo + 1)) + lo; };
-    long total_c = 0, total_k = 0;
+    long total_c = 0, total_k = 0, rel_rounds = 0, overflowed = 0;
     for (int it = 0; it < rounds; ++it) {
         akz_config cfg{};  // Config::default() (types/evolution.rs:40-55)
         cfg.num_sublevels = 4; cfg.max_octave_evolution = 4; cfg.base_scale_offset = 1.6; cfg.initial_contrast = 0.001;
@@ -146,9 +146,72 @@ int main(int argc, char** argv) {
                 fprintf(stderr, "round %d: keypoint %zu differs\n", it, i);
                 return 1;
             }
+        // the same selection from neighbour lists (select_keypoints_rel; on the GPU box they come from k_relations): who
+        // lies within `size` of whom, by brute force with the selection's own expressions
+        {
+            const int K1 = kRel1, K2 = kRel2;  // the device's list lengths: dense clusters overflow them, which marks the candidate
+                                               // (0xfffe) for the host's own scan of its partner levels
+            const size_t n = cands.size();
+            std::vector<uint16_t> rel(n * (size_t)(K1 + K2), 0xffffu);
+            bool overflow = n > 65533;
+            std::vector<uint8_t> o1(n, 0), o2(n, 0);
+            std::vector<float> px(n), py(n), qx(n), qy(n), sz(n);
+            for (size_t i = 0; i < n; ++i) {
+                const LevelPlan& lv = plan[cands[i].level];
+                const float ratio = powf(2.0f, (float)lv.octave);
+                const uint32_t ly = cands[i].idx / lv.w, lx = cands[i].idx - ly * lv.w;
+                qx[i] = (float)lx * ratio; qy[i] = (float)ly * ratio;
+                px[i] = qx[i] + 0.5f * (ratio - 1.0f); py[i] = qy[i] + 0.5f * (ratio - 1.0f);
+                sz[i] = (float)(lv.esigma * cfg.derivative_factor);
+            }
+            for (size_t i = 0; i < n && !overflow; ++i) {
+                int u1 = 0, u2 = 0;
+                for (size_t j = 0; j < n; ++j) {
+                    if (j == i) continue;
+                    const uint32_t li = cands[i].level, lj = cands[j].level;
+                    if ((lj == li && j < i) || (li > 0 && lj == li - 1)) {
+                        const float d = (qx[i] - px[j]) * (qx[i] - px[j]) + (qy[i] - py[j]) * (qy[i] - py[j]);
+                        if (d <= sz[i] * sz[i]) {
+                            if (u1 < K1) rel[i * (size_t)(K1 + K2) + (size_t)u1++] = (uint16_t)j;
+                            else o1[i] = 1;
+                        }
+                    } else if (lj == li + 1) {
+                        const float d = (px[i] - px[j]) * (px[i] - px[j]) + (py[i] - py[j]) * (py[i] - py[j]);
+                        if (d <= sz[i] * sz[i]) {
+                            if (u2 < K2) rel[i * (size_t)(K1 + K2) + (size_t)K1 + (size_t)u2++] = (uint16_t)j;
+                            else o2[i] = 1;
+                        }
+                    }
+                }
+            }
+            for (size_t i = 0; i < n; ++i) {
+                if (o1[i]) rel[i * (size_t)(K1 + K2)] = 0xfffeu;
+                if (o2[i]) rel[i * (size_t)(K1 + K2) + (size_t)K1] = 0xfffeu;
+                overflowed += o1[i] + o2[i];
+            }
+            if (!overflow) {
+                std::vector<HostKeypoint> got2;
+                uint64_t ne2 = 0;
+                select_keypoints_rel(cands.data(), n, rel.data(), K1, K2, plan, cfg, got2, &ne2);
+                if (ne2 != ne_exp || got2.size() != exp.size()) {
+                    fprintf(stderr, "round %d (neighbour lists): %zu/%llu keypoints/extrema, expected %zu/%llu\n", it, got2.size(),
+                            (unsigned long long)ne2, exp.size(), (unsigned long long)ne_exp);
+                    return 1;
+                }
+                for (size_t i = 0; i < got2.size(); ++i)
+                    if (got2[i].x != exp[i].x || got2[i].y != exp[i].y || got2[i].response != exp[i].response ||
+                        got2[i].class_id != exp[i].class_id || got2[i].size != exp[i].size || got2[i].octave != exp[i].octave ||
+                        got2[i].lx != exp[i].lx || got2[i].ly != exp[i].ly) {
+                        fprintf(stderr, "round %d (neighbour lists): keypoint %zu differs\n", it, i);
+                        return 1;
+                    }
+                ++rel_rounds;
+            }
+        }
         total_c += (long)cands.size();
         total_k += (long)got.size();
     }
-    printf("selected %ld keypoints from %ld candidates, identical to the linear scans\n", total_k, total_c);
+    printf("selected %ld keypoints from %ld candidates, identical to the linear scans (%ld rounds also through the neighbour lists, %ld overflowed lists)\n", total_k, total_c,
+           rel_rounds, overflowed);
     return 0;
 }

@@ -1651,7 +1651,10 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // time).  Taken where the host is the bottleneck -- contexts with fewer than four host threads, and lone frames, whose
     // latency is the sum of the two halves -- and not for large batches on many-core hosts, where the extra small launches
     // cost the kernels of the next batch more than the idle host threads gain.
-    const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < kBigLaunchPx()));
+    // (... and for images of 6 Mpx and more, whose sequential selection -- 1.4 ms per 4K frame on the grids -- is the longest
+    // single piece of a synchronous call)
+    const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < kBigLaunchPx() ||
+                                                                        (uint64_t)r->w * r->h >= 6000000ull));
     bool sorted = false;
     uint16_t* d_rel = nullptr;
     uint32_t* d_rel_flags = nullptr;

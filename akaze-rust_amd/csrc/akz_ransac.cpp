@@ -159,16 +159,31 @@ extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0,
     }
     std::vector<Model> models((size_t)num_trials);
     std::vector<int64_t> inliers((size_t)num_trials, -1);  // -1: no model (rank-deficient sample)
+    // the matched point pairs side by side (x0, y0, x1, y1 as four arrays): the inlier count of a trial -- model_error over
+    // every match, 8 M evaluations for the 8 000 matches of a 4K pair at 1 000 trials -- is then a streaming loop the
+    // compiler vectorises instead of two gathers of 32-byte keypoints per evaluation.  Same expression per match, same
+    // operation order (pr[2] = pl[2] = 1.0f: the products with them are exact).
+    std::vector<float> px0((size_t)n_matches), py0((size_t)n_matches), px1((size_t)n_matches), py1((size_t)n_matches);
+    for (uint64_t i = 0; i < n_matches; ++i) {
+        px0[(size_t)i] = keypoints_0[matches[i].index_0].x; py0[(size_t)i] = keypoints_0[matches[i].index_0].y;
+        px1[(size_t)i] = keypoints_1[matches[i].index_1].x; py1[(size_t)i] = keypoints_1[matches[i].index_1].y;
+    }
     auto run_trials = [&](uint64_t lo, uint64_t hi) {
+        const float *x0 = px0.data(), *y0 = py0.data(), *x1 = px1.data(), *y1 = py1.data();
         for (uint64_t trial = lo; trial < hi; ++trial) {
             akz_match sample[8];
             for (int i = 0; i < 8; ++i) sample[i] = matches[samples[(size_t)trial * 8 + i]];
             Model model;
             if (!estimate(keypoints_0, keypoints_1, sample, epsilon_model, model)) continue;
+            const float f00 = model.f[0][0], f01 = model.f[0][1], f02 = model.f[0][2], f10 = model.f[1][0], f11 = model.f[1][1],
+                        f12 = model.f[1][2], f20 = model.f[2][0], f21 = model.f[2][1], f22 = model.f[2][2];
             int64_t inl = 0;
-            for (uint64_t i = 0; i < n_matches; ++i)
-                if (model_error(model, keypoints_0[matches[i].index_0], keypoints_1[matches[i].index_1]) < epsilon_inlier)
-                    ++inl;
+            for (uint64_t i = 0; i < n_matches; ++i) {  // model_error(model, k0, k1) < epsilon_inlier
+                const float r0 = (x1[i] * f00 + y1[i] * f10) + f20, r1 = (x1[i] * f01 + y1[i] * f11) + f21,
+                            r2 = (x1[i] * f02 + y1[i] * f12) + f22;
+                const float sres = (r0 * x0[i] + r1 * y0[i]) + r2;
+                inl += std::fabs(sres) < epsilon_inlier ? 1 : 0;
+            }
             models[(size_t)trial] = model;
             inliers[(size_t)trial] = inl;
         }

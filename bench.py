@@ -894,11 +894,12 @@ def main_rank(args):
                 n_m, n_k = len(mm), len(k0) + len(k1)
         # the same pairs as a stream: pair j + 1 is begun before pair j is collected and matched (its finish half runs on the
         # context's own thread under the caller's match_features of the pair before)
-        t_s0 = time.perf_counter()
         prev_job = None
-        n_stream = 12
-        for it in range(n_stream + 1):
-            job = ctx.extract_begin_host(h_pair, cfg44, keep_all_planes=not args.lean) if it < n_stream else None
+        n_stream, n_warm = 12, 3
+        for it in range(n_warm + n_stream + 1):
+            if it == n_warm:  # (the first pairs of the stream grow the pooled blocks of two pyramids in flight)
+                t_s0 = time.perf_counter()
+            job = ctx.extract_begin_host(h_pair, cfg44, keep_all_planes=not args.lean) if it < n_warm + n_stream else None
             if prev_job is not None:
                 rs = prev_job.finish()
                 A.match_features(rs.keypoints(0), rs.descriptors(0), rs.keypoints(1), rs.descriptors(1), 0.86, 1000, 3.0, ctx=ctx)

@@ -1368,7 +1368,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // chain moves to a second stream when octave fork_octave - 1 is finished, and the main stream goes straight to the
     // detectors of the fine octaves (bandwidth-bound, 2.2 ms): the two run side by side and join before the candidate
     // list is read.  (Running two BIG kernels side by side is a loss -- see above -- so the fork is at octave 2.)
-    constexpr int fork_octave = 2;  // (forking at octave 3 instead, octave 2 on the main stream: -4 %)
+    const int fork_octave = c->sched[3] > 0 ? c->sched[3] : 2;  // (forking at octave 3 instead, octave 2 on the main stream: -4 %; sched[3]: measurement)
     // (a lone 1080p frame is a chain of dependent launches either way and only pays for the two events: measured
     // 0.596 -> 0.625 ms per streamed frame; batches from 8 Mpx on fork)
     const uint64_t fork_min_px = kBigLaunchPx();

@@ -531,19 +531,23 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                         const float4 v = *reinterpret_cast<const float4*>(lp + 8 * g4);
                         lim[4 * g4] = v.x; lim[4 * g4 + 1] = v.y; lim[4 * g4 + 2] = v.z; lim[4 * g4 + 3] = v.w;
                     }
-                    bool col_hit = false;
+                    // one compare per accumulator; the 16 lane masks are OR-ed on the scalar unit (written as `hit = hit || ...`
+                    // the compiler built a 16-bit mask per lane out of ~50 vector instructions -- on every sub-tile)
+                    unsigned long long any = 0ull;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) col_hit = col_hit || acc[b][i] >= lim[i];
+                    for (int i = 0; i < 16; ++i) any |= __ballot(acc[b][i] >= lim[i]);
                     const unsigned q = q_first + 32 * b + r;
-                    col_hit = col_hit && q >= col_q0 && q < n0;
+                    const bool q_live = q >= col_q0 && q < n0;
+                    bool col_hit = (any & __ballot(q_live)) != 0ull;  // wave-uniform
 #ifdef AKZ_MM_COLS_NOHIT  // measurement: the pass without the opposite direction's candidates
                     col_hit = false;
 #endif
-                    if (col_hit) {  // a row of the sub-tile may take this query as one of its two nearest
+                    if (col_hit && q_live) {  // a row of the sub-tile may take one of the wave's queries as one of its two nearest
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
-                            const unsigned d = (unsigned)((kBits - (int)acc[b][i]) >> 1);
-                            if (acc[b][i] >= lim[i] && d < threshold) {
+                            if (acc[b][i] >= lim[i]) {  // (one compare per element on the way through: the rest only for a candidate)
+                                const unsigned d = (unsigned)((kBits - (int)acc[b][i]) >> 1);
+                                if (d >= threshold) continue;
                                 const size_t prow = (size_t)tile * MM_TR + 32u * sub + 4u * h + (unsigned)((i & 3) + 8 * (i >> 2));
 #ifdef AKZ_MM_COLS_NOATOMIC  // measurement: candidates found, nothing entered
                                 if (d == 0xdeadbeefu) csecond[prow] = d;

@@ -355,6 +355,8 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int KB4 = KB / 2;           // bytes per unpacked row
 constexpr int MM_PITCH4 = KB4 + 16;   // LDS row pitch: 16-byte operand reads of 16 consecutive rows fall into different banks
 constexpr int kBits = 488;            // columns that carry +-1 (61 bytes)
+constexpr float kPadAcc = -1.0e30f;   // accumulator given to the padding rows of a partial tile (a real one is >= -488)
+constexpr float kPadKey = -1.0e5f;    // ... and what tells their keys 16 acc + (15 - i) from real ones (>= -7808)
 
 // NB: 32-query blocks per wave.  1 (used): 16 waves of 32 queries (1024 threads); 2: 8 waves of 64 queries (512 threads),
 // every train operand read from LDS feeding two matrix instructions -- measured 30 % SLOWER at 90 K rows (2.36 against
@@ -364,6 +366,13 @@ constexpr int kBits = 488;            // columns that carry +-1 (61 bytes)
 #endif
 #ifndef AKZ_MM4_NT
 #define AKZ_MM4_NT 1024
+#endif
+// AKZ_MM4_BOUND = 1: the workgroups that scan for a query share an upper bound of its second distance (bound[q], as in
+// k_match_mfma; pushed once per tile).  With the exact update at its round-4 cost that pays only for very large sets
+// (89 816 x 89 816: 1551 -> 1495 us); a 4K pair (61 against 64 us), the multi-set launch of the all-pairs step (478 against
+// 491 us) and the step itself do better without the atomics and the re-reads, so it is off (profiles/r04_match_mutual.txt).
+#ifndef AKZ_MM4_BOUND
+#define AKZ_MM4_BOUND 0
 #endif
 constexpr int MM4_QB = (AKZ_MM4_NT / 64) * 32 * AKZ_MM4_NB;  // queries per workgroup of the FP4 kernel
 // BOTH DIRECTIONS of a block in one pass (COLS; akz_descriptor_match_sets_mutual_device): hamming is symmetric, so the
@@ -412,12 +421,14 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(bq[b][s]));
-    unsigned min_d[NB], second[NB], limit[NB], b_seen[NB], min_j[NB];
+    unsigned min_d[NB], second[NB], limit[NB], b_seen[NB], pushed[NB], min_j[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        min_d[b] = second[b] = limit[b] = b_seen[b] = threshold;
+        min_d[b] = second[b] = limit[b] = b_seen[b] = pushed[b] = threshold;
         min_j[b] = 0u;
     }
+    (void)pushed;
+    (void)bound;  // (AKZ_MM4_BOUND 0)
 
     unsigned t_begin, t_end, row0 = 0u, record = blockIdx.y;
     if (table) {
@@ -487,11 +498,17 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
         const int buf = (int)((tile - t_begin) & 1u);
         const bool more = tile + 1 < t_end;
         const bool partial = (tile + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
+#if AKZ_MM4_BOUND > 0
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             limit[b] = min(limit[b], min(second[b], b_seen[b] < 0xffffffffu ? b_seen[b] + 1u : b_seen[b]));
+            if (second[b] < min(pushed[b], b_seen[b])) {  // once per tile, and only what the others do not know yet
+                atomicMin(bound + q_first + 32 * b + r, second[b]);
+                pushed[b] = second[b];
+            }
             b_seen[b] = __hip_atomic_load(bound + q_first + 32 * b + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#endif
 #pragma unroll
         for (int sub = 0; sub < MM_SUB; ++sub) {
             if (more && (sub & 1) == 0) fetch(tile + 1, sub >> 1);  // in flight under the MFMA chains below
@@ -518,10 +535,17 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
             const unsigned j0 = tile * MM_TR - row0 + 32 * sub + 4 * h;  // row index inside the set
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
+                if (partial) {  // uniform, the last tile of a set: padding rows never match
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (j0 + (unsigned)((i & 3) + 8 * (i >> 2)) >= n1) acc[b][i] = kPadAcc;
+                }
                 float topf = acc[b][0];
 #pragma unroll
                 for (int i = 1; i < 16; ++i) topf = fmaxf(topf, acc[b][i]);
-                const int best = (kBits - (int)topf) >> 1;  // the smallest distance of the lane's 16 rows
+                // the smallest distance of the lane's 16 rows (the accumulators are 488 - 2 d: the half is exact; as a float, so
+                // that 16 padding rows stay above any threshold)
+                const float bestf = ((float)kBits - topf) * 0.5f;
                 if constexpr (COLS) {
                     // the limits of the lane's 16 rows (four groups of four consecutive rows, shared by the half-wave)
                     const float* lp = &s_lim[buf][32 * sub + 4 * h];
@@ -561,36 +585,42 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                         }
                     }
                 }
-                if (partial || best < (int)limit[b]) {  // rare: see `limit` in k_match_mfma
-                    int key[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const unsigned row = (unsigned)((i & 3) + 8 * (i >> 2));
-                        key[i] = (partial && j0 + row >= n1) ? INT_MIN : ((int)acc[b][i] << 4) + (15 - i);  // padding rows never match
-                    }
-                    int M = INT_MIN, S = INT_MIN;
-#pragma unroll
-                    for (int g = 0; g < 5; ++g) {
-                        const int ka = key[3 * g], kb = key[3 * g + 1], kc = key[3 * g + 2];
-                        const int gm = max(ka, max(kb, kc)), gs = max(min(ka, kb), min(max(ka, kb), kc));
-                        S = max(min(M, gm), max(S, gs));
-                        M = max(M, gm);
-                    }
-                    S = max(S, min(M, key[15]));
-                    M = max(M, key[15]);
-                    const int i1 = 15 - (M & 15);
-                    const unsigned tb = M == INT_MIN ? 0xffffffffu : (unsigned)((kBits - (M >> 4)) >> 1);
-                    const unsigned ts = S == INT_MIN ? 0xffffffffu : (unsigned)((kBits - (S >> 4)) >> 1);
-                    const unsigned before = second[b];
+                // The exact update.  best < limit <= second: the lane's 16 rows improve its second distance at least (see `limit`
+                // in k_match_mfma).  Unless they also hold a new minimum that is all there is to do; a new minimum needs the
+                // row of the first largest accumulator and the second largest one: keys 16 acc + (15 - i), exact in fp32,
+                // through a top-2 network of v_max3 / v_med3 (~58 instructions, for about a third of the sub-tiles).  The
+                // SIMD's vector issue is what the loop runs out of next to its matrix instructions (one MFMA holds it for 8
+                // of its 32 cycles, every other instruction for 4): the former body -- integer keys and the padding tests of
+                // a partial tile on every entry, ~110 instructions for 47..95 % of the sub-tiles -- cost 12 % of the kernel
+                // at 89 816 x 89 816 and 22 % in the multi-set launch (round 4, profiles/r04_match_mutual.txt).
+                if (bestf < (float)limit[b]) {
+                    const unsigned tb = (unsigned)bestf, before = second[b];
                     if (tb < min_d[b]) {
+                        float key[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) key[i] = __builtin_fmaf(acc[b][i], 16.0f, (float)(15 - i));
+                        float M = __builtin_fmaxf(key[0], key[1]), S = __builtin_fminf(key[0], key[1]);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float ka = key[2 + 3 * g], kb = key[3 + 3 * g], kc = key[4 + 3 * g];
+                            const float gm = __builtin_fmaxf(ka, __builtin_fmaxf(kb, kc)), gs = __builtin_amdgcn_fmed3f(ka, kb, kc);
+                            S = __builtin_fmaxf(__builtin_fminf(M, gm), __builtin_fmaxf(S, gs));
+                            M = __builtin_fmaxf(M, gm);
+                        }
+                        {
+                            const float gm = __builtin_fmaxf(key[14], key[15]), gs = __builtin_fminf(key[14], key[15]);
+                            S = __builtin_fmaxf(__builtin_fminf(M, gm), __builtin_fmaxf(S, gs));
+                            M = __builtin_fmaxf(M, gm);
+                        }
+                        const int i1 = 15 - ((int)M & 15);
+                        const unsigned ts = S < kPadKey ? 0xffffffffu : (unsigned)((kBits - ((int)S >> 4)) >> 1);
                         second[b] = min(min_d[b], ts);
                         min_d[b] = tb;
                         min_j[b] = j0 + (unsigned)((i1 & 3) + 8 * (i1 >> 2));
                     } else {
-                        second[b] = min(second[b], tb);
+                        second[b] = tb;
                     }
                     if (second[b] < before) {
-                        atomicMin(bound + q_first + 32 * b + r, second[b]);
                         limit[b] = min(limit[b], second[b]);
                     }
                 }
@@ -781,7 +811,9 @@ void match_cols_seed(hipStream_t s, const uint8_t* q4, uint32_t n0, const uint8_
                      uint32_t* d_bound, MatchRec* d_seed, unsigned long long* cbest, uint32_t* csecond) {
     const uint32_t seed = match_cols_seed_rows(n0);
     if (t_rows == 0) return;
+#if AKZ_MM4_BOUND
     (void)hipMemsetAsync(d_bound, 0xff, (size_t)match_mfma_rows(t_rows, true) * sizeof(uint32_t), s);  // no pruning bound yet
+#endif
     const uint32_t tiles = (std::max<uint32_t>(seed, 1) + MM_TR - 1) / MM_TR;
     hipLaunchKernelGGL((k_match_fp4<AKZ_MM4_NB, AKZ_MM4_NT>), dim3((t_rows + MM4_QB - 1) / MM4_QB, 1), dim3(AKZ_MM4_NT), 0, s, t4, t_rows, q4,
                        seed, tiles, threshold, d_bound, d_seed, (const MatchChunk*)nullptr, (unsigned long long*)nullptr,

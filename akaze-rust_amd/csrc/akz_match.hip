@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     // (12 waves -- NT = 768, one or two query blocks per wave -- measured in round 4: 2.68 / 2.44 ms against 1.80 at 90 K rows,
     //  profiles/r04_match_mutual.txt: the loop wants its 16 waves; that form is not maintained)
     static_assert(MM_SUB == 4 && (NB == 1 || NB == 2) && (NT == 512 || NT == 1024), "staging below: two 64-row parts per 128-row tile");
+    static_assert(!COLS || NB == 1, "the opposite direction's pending exchange: one query per lane");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH4];
     __shared__ __attribute__((aligned(16))) float s_lim[2][COLS ? MM_TR : 4];  // COLS: accumulator limits of the tile's rows
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -457,6 +458,19 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     (void)EXACT;
     uint4 stage[PIECES];
     unsigned long long lim_lo = 0, lim_hi = 0;  // COLS: csecond of rows 4 tid .. 4 tid + 3 of the tile being staged (tid < 32)
+    // COLS: the lane's last exchange with a train row's cbest whose loser has not been entered in csecond yet
+    unsigned long long pend_old = 0ull;
+    unsigned pend_d = 0u, pend_row = 0xffffffffu;
+    auto settle = [&]() {
+        if constexpr (COLS) {
+            if (pend_row != 0xffffffffu) {
+                const unsigned long long mine = ((unsigned long long)pend_d << 32) | (q_first + r);
+                const unsigned loser = (unsigned)((pend_old > mine ? pend_old : mine) >> 32);
+                if (loser < threshold) atomicMin(csecond + pend_row, loser);
+                pend_row = 0xffffffffu;
+            }
+        }
+    };
     auto fetch = [&](unsigned tile, int part) {
 #pragma unroll
         for (int p = 0; p < PIECES; ++p)
@@ -532,6 +546,14 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB, 0);
+            // The half tile requested before the previous chain goes to LDS while this chain runs, BEFORE its accumulators
+            // are looked at: the wait for the loads is a wait for everything the wave has in flight, the atomics of the
+            // opposite direction included (vmcnt counts them for 600..3000 cycles), and here those are a chain or two old.
+            // Their answers are in by then too: settled without another wait.
+            if ((sub & 1) == 1) {
+                if (more) commit(buf ^ 1, sub >> 1, tile + 1);
+                settle();
+            }
             const unsigned j0 = tile * MM_TR - row0 + 32 * sub + 4 * h;  // row index inside the set
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -546,7 +568,11 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                 // the smallest distance of the lane's 16 rows (the accumulators are 488 - 2 d: the half is exact; as a float, so
                 // that 16 padding rows stay above any threshold)
                 const float bestf = ((float)kBits - topf) * 0.5f;
+#ifdef AKZ_MM_COLS_NOCMP  // measurement: the pass without the opposite direction's compares
+                if constexpr (false) {
+#else
                 if constexpr (COLS) {
+#endif
                     // the limits of the lane's 16 rows (four groups of four consecutive rows, shared by the half-wave)
                     const float* lp = &s_lim[buf][32 * sub + 4 * h];
                     float lim[16];
@@ -555,32 +581,51 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                         const float4 v = *reinterpret_cast<const float4*>(lp + 8 * g4);
                         lim[4 * g4] = v.x; lim[4 * g4 + 1] = v.y; lim[4 * g4 + 2] = v.z; lim[4 * g4 + 3] = v.w;
                     }
-                    // one compare per accumulator; the 16 lane masks are OR-ed on the scalar unit (written as `hit = hit || ...`
-                    // the compiler built a 16-bit mask per lane out of ~50 vector instructions -- on every sub-tile)
-                    unsigned long long any = 0ull;
+                    // One compare per accumulator; the 16 lane masks stay on the scalar unit.  A sub-tile with a candidate
+                    // (30..60 % of them: 1024 pairs at 2 / samples-so-far each) is then scanned mask by mask with scalar
+                    // branches, and only the accumulator that holds one is looked at by its lanes.  (Round 4: as a per-lane
+                    // loop over the 16 accumulators -- compare, branch, execution mask each -- the scan was 2.5 ms of the
+                    // 10.3 ms all-pairs step; `hit = hit || ...` had the compiler build a 16-bit mask per lane out of ~50
+                    // vector instructions on every sub-tile.)
+                    unsigned long long hit[16], any = 0ull;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) any |= __ballot(acc[b][i] >= lim[i]);
+                    for (int i = 0; i < 16; ++i) {
+                        hit[i] = __ballot(acc[b][i] >= lim[i]);
+                        any |= hit[i];
+                    }
                     const unsigned q = q_first + 32 * b + r;
                     const bool q_live = q >= col_q0 && q < n0;
-                    bool col_hit = (any & __ballot(q_live)) != 0ull;  // wave-uniform
+                    const unsigned long long live = __ballot(q_live);
 #ifdef AKZ_MM_COLS_NOHIT  // measurement: the pass without the opposite direction's candidates
-                    col_hit = false;
+                    any = 0ull;
 #endif
-                    if (col_hit && q_live) {  // a row of the sub-tile may take one of the wave's queries as one of its two nearest
+                    if ((any & live) != 0ull) {  // a row of the sub-tile may take one of the wave's queries as one of its two nearest
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            if (acc[b][i] >= lim[i]) {  // (one compare per element on the way through: the rest only for a candidate)
-                                const unsigned d = (unsigned)((kBits - (int)acc[b][i]) >> 1);
-                                if (d >= threshold) continue;
-                                const size_t prow = (size_t)tile * MM_TR + 32u * sub + 4u * h + (unsigned)((i & 3) + 8 * (i >> 2));
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            // (wave-uniform tests, four accumulators at a time first: a scan of sixteen dependent scalar
+                            //  compare-and-branch steps was ~300 cycles that the wave's workgroup then waited for at the barrier)
+                            if (((hit[4 * g4] | hit[4 * g4 + 1] | hit[4 * g4 + 2] | hit[4 * g4 + 3]) & live) == 0ull) continue;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int i = 4 * g4 + k;
+                                if ((hit[i] & live) == 0ull) continue;
+                                if (acc[b][i] >= lim[i] && q_live) {
+                                    const unsigned d = (unsigned)((kBits - (int)acc[b][i]) >> 1);
+                                    if (d < threshold) {
+                                        const size_t prow = (size_t)tile * MM_TR + 32u * sub + 4u * h + (unsigned)((i & 3) + 8 * (i >> 2));
 #ifdef AKZ_MM_COLS_NOATOMIC  // measurement: candidates found, nothing entered
-                                if (d == 0xdeadbeefu) csecond[prow] = d;
+                                        if (d == 0xdeadbeefu) csecond[prow] = d;
 #else
-                                const unsigned long long mine = ((unsigned long long)d << 32) | q;
-                                const unsigned long long old = atomicMin(cbest + prow, mine);
-                                const unsigned loser = (unsigned)(max(old, mine) >> 32);
-                                if (loser < threshold) atomicMin(csecond + prow, loser);
+                                        // (the exchange's answer is looked at after the next commit, or when the lane's next
+                                        //  candidate comes first: a wave that waited for it here held its workgroup at the barrier)
+                                        if (__ballot(pend_row != 0xffffffffu) != 0ull) settle();
+                                        const unsigned long long mine = ((unsigned long long)d << 32) | q;
+                                        pend_old = atomicMin(cbest + prow, mine);
+                                        pend_d = d;
+                                        pend_row = (unsigned)prow;
 #endif
+                                    }
+                                }
                             }
                         }
                     }
@@ -625,10 +670,10 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                     }
                 }
             }
-            if (more && (sub & 1) == 1) commit(buf ^ 1, sub >> 1, tile + 1);
         }
         __syncthreads();
     }
+    settle();
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const unsigned o_min = __shfl_xor(min_d[b], 32, 64), o_sec = __shfl_xor(second[b], 32, 64), o_j = __shfl_xor(min_j[b], 32, 64);

@@ -371,6 +371,9 @@ constexpr float kPadKey = -1.0e5f;    // ... and what tells their keys 16 acc + 
 // k_match_mfma; pushed once per tile).  With the exact update at its round-4 cost that pays only for very large sets
 // (89 816 x 89 816: 1551 -> 1495 us); a 4K pair (61 against 64 us), the multi-set launch of the all-pairs step (478 against
 // 491 us) and the step itself do better without the atomics and the re-reads, so it is off (profiles/r04_match_mutual.txt).
+#ifndef AKZ_MM4_STEP
+#define AKZ_MM4_STEP 2
+#endif
 #ifndef AKZ_MM4_BOUND
 #define AKZ_MM4_BOUND 0
 #endif
@@ -404,8 +407,14 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     //  profiles/r04_match_mutual.txt: the loop wants its 16 waves; that form is not maintained)
     static_assert(MM_SUB == 4 && (NB == 1 || NB == 2) && (NT == 512 || NT == 1024), "staging below: two 64-row parts per 128-row tile");
     static_assert(!COLS || NB == 1, "the opposite direction's pending exchange: one query per lane");
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][MM_TR * MM_PITCH4];
-    __shared__ __attribute__((aligned(16))) float s_lim[2][COLS ? MM_TR : 4];  // COLS: accumulator limits of the tile's rows
+    // Two buffers of STEP tiles each: one barrier per STEP tiles (4 STEP sub-tiles).  The waves of a workgroup meet at that
+    // barrier, so a step takes what its slowest wave takes, and what differs between the waves -- exact updates, candidates of
+    // the opposite direction -- averages out over more sub-tiles (round 4, profiles/r04_match_mutual.txt).
+    // (two tiles per step: 89 816 x 89 816 1596 -> 1557 us, multi-set launch 481 -> 470 us; with the opposite direction one
+    //  tile -- its limits are a step old when they are used, and two tiles cost it 11 spilled registers: 8.8 -> 9.6 ms)
+    constexpr int STEP = COLS ? 1 : AKZ_MM4_STEP, SUBS = MM_SUB * STEP;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][STEP * MM_TR * MM_PITCH4];
+    __shared__ __attribute__((aligned(16))) float s_lim[2][COLS ? STEP * MM_TR : 4];  // COLS: accumulator limits of the rows
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
     const unsigned q_first = blockIdx.x * QB + wave * 32u * NB;
@@ -444,8 +453,8 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
         t_begin = blockIdx.y * chunk_tiles;
         t_end = min(tiles_total, t_begin + chunk_tiles);
     }
-    // staging: the next tile arrives in two 64-row parts (1024 sixteen-byte pieces each) through one register stage:
-    // requested before sub-tiles 0 / 2, handed to the other LDS buffer after sub-tiles 1 / 3
+    // staging: the next step's tiles arrive in 64-row parts (1024 sixteen-byte pieces each) through one register stage:
+    // part p requested before chain 2 p, handed to the other LDS buffer after chain 2 p + 1 has been issued
     constexpr int PIECES = (1024 + NT - 1) / NT;
     constexpr bool EXACT = PIECES * NT == 1024;  // (768 threads: the second piece exists for the first 256 only)
     unsigned st_src[PIECES], st_dst[PIECES];
@@ -476,8 +485,9 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
         for (int p = 0; p < PIECES; ++p)
             stage[p] = *reinterpret_cast<const uint4*>(t4 + ((size_t)tile * MM_TR + 64u * part) * KB4 + st_src[p]);
         if constexpr (COLS) {
-            if (part == 0 && tid < 32u) {
-                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(csecond + (size_t)tile * MM_TR + 4u * tid);
+            if ((part & 1) == 0 && tid < 32u) {  // (the bounds of a tile's 128 rows come with its first part)
+                const unsigned long long* src =
+                    reinterpret_cast<const unsigned long long*>(csecond + (size_t)tile * MM_TR + 64u * part + 4u * tid);
                 lim_lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 lim_hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -487,31 +497,33 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
 #pragma unroll
         for (int p = 0; p < PIECES; ++p) *reinterpret_cast<uint4*>(&s_tile[buf][64 * part * MM_PITCH4 + st_dst[p]]) = stage[p];
         if constexpr (COLS) {
-            if (part == 0 && tid < 32u) {
+            if ((part & 1) == 0 && tid < 32u) {
                 const unsigned sec[4] = {(unsigned)lim_lo, (unsigned)(lim_lo >> 32), (unsigned)lim_hi, (unsigned)(lim_hi >> 32)};
                 float4 lim;
                 float* lp = &lim.x;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const unsigned row = tile * MM_TR - row0 + 4u * tid + (unsigned)k;  // row of the set: padding rows never take part
+                    const unsigned row = tile * MM_TR + 64u * part - row0 + 4u * tid + (unsigned)k;  // row of the set: padding rows never take part
                     lp[k] = row < n1 ? (float)(kBits - 2 * (int)min(sec[k], 1000u)) : 1e9f;
                 }
-                *reinterpret_cast<float4*>(&s_lim[buf][4u * tid]) = lim;
+                *reinterpret_cast<float4*>(&s_lim[buf][64u * part + 4u * tid]) = lim;
             }
         }
     };
     if (t_begin < t_end) {
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            fetch(t_begin, part);
-            commit(0, part, t_begin);
+        for (int part = 0; part < 2 * STEP; ++part) {
+            if (part < 2 * (int)min((unsigned)STEP, t_end - t_begin)) {
+                fetch(t_begin, part);
+                commit(0, part, t_begin);
+            }
         }
     }
     __syncthreads();
-    for (unsigned tile = t_begin; tile < t_end; ++tile) {
-        const int buf = (int)((tile - t_begin) & 1u);
-        const bool more = tile + 1 < t_end;
-        const bool partial = (tile + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
+    for (unsigned tile = t_begin; tile < t_end; tile += STEP) {
+        const int buf = (int)(((tile - t_begin) / STEP) & 1u);
+        const unsigned here = min((unsigned)STEP, t_end - tile);                                   // tiles of this step
+        const unsigned next = tile + STEP < t_end ? min((unsigned)STEP, t_end - tile - STEP) : 0u;  // ... and of the next
 #if AKZ_MM4_BOUND > 0
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -524,8 +536,11 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
         }
 #endif
 #pragma unroll
-        for (int sub = 0; sub < MM_SUB; ++sub) {
-            if (more && (sub & 1) == 0) fetch(tile + 1, sub >> 1);  // in flight under the MFMA chains below
+        for (int sub = 0; sub < SUBS; ++sub) {
+            if (sub >= MM_SUB && (unsigned)sub >= MM_SUB * here) break;  // (uniform: the last step of a chunk may be short)
+            const bool more = (unsigned)(sub >> 1) < 2u * next;          // part sub / 2 of the next step exists
+            const bool partial = (tile + (sub / MM_SUB) + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
+            if (more && (sub & 1) == 0) fetch(tile + STEP, sub >> 1);  // in flight under the MFMA chains below
             v16f acc[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b)
@@ -551,7 +566,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
             // opposite direction included (vmcnt counts them for 600..3000 cycles), and here those are a chain or two old.
             // Their answers are in by then too: settled without another wait.
             if ((sub & 1) == 1) {
-                if (more) commit(buf ^ 1, sub >> 1, tile + 1);
+                if (more) commit(buf ^ 1, sub >> 1, tile + STEP);
                 settle();
             }
             const unsigned j0 = tile * MM_TR - row0 + 32 * sub + 4 * h;  // row index inside the set

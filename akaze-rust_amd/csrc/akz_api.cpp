@@ -97,6 +97,16 @@ struct akz_ctx {
     size_t tab_ring_bytes = 0;
     uint64_t tab_ring_next = 0;
     hipEvent_t tab_ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // A second set of the multi-set matcher's scratch: akz_match_all_pairs runs the launches of consecutive lead images
+    // alternately on the caller's stream and on the finish stream (akz::match_sets_at, side 1), so that the small launches
+    // around one image's pass (unpack, seed, compactions: 130 us of 550) run under the other's
+    struct MatchSide {
+        DevBuf q8, t8, pop, tab, cols, rec;
+        void* ring = nullptr;
+        size_t ring_bytes = 0;
+        uint64_t ring_next = 0;
+        hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    } ms1;
     int match_mode = 2;                      // 0: popcount kernel, 1: matrix cores on int8 operands, 2 (default) / 3: on FP4 operands (akz_ctx_set_match_mode)
     uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
     int dbg_host_sort = -1;                            // akz_debug_set_host_sort: 1 / 0 force the host / the device sort, -1 automatic
@@ -380,13 +390,20 @@ int akz_ctx_destroy(akz_ctx* c) {
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
                       &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
-                      &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols};
+                      &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols,
+                      &c->ms1.q8, &c->ms1.t8, &c->ms1.pop, &c->ms1.tab, &c->ms1.cols, &c->ms1.rec};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
         if (b.p) (void)hipHostFree(b.p);
     if (c->tab_ring) (void)hipHostFree(c->tab_ring);
     c->tab_ring = nullptr;
+    if (c->ms1.ring) (void)hipHostFree(c->ms1.ring);
+    c->ms1.ring = nullptr;
+    for (hipEvent_t& e : c->ms1.ring_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
     for (hipEvent_t& e : c->tab_ring_ev) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
@@ -2644,7 +2661,7 @@ int akz_descriptor_match_device(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, co
 // it the sets follow each other
 static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train, const uint64_t* set_rows,
                            uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out, uint64_t* d_n_out,
-                           akz_match* d_out_cols, uint64_t* d_n_cols, const uint64_t* set_first = nullptr) {
+                           akz_match* d_out_cols, uint64_t* d_n_cols, const uint64_t* set_first = nullptr, int side = 0) {
     AKZ_TRY(bind(c, true, false));
     const bool cols = d_n_cols != nullptr;  // the opposite direction too: every set's rows against the query set
     if ((n0 && !d_out) || !d_n_out || (n_sets && !set_rows) || (n0 && !d_q) || n0 > 0x7fffffffull || n_sets > 65535) {
@@ -2688,6 +2705,16 @@ static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const ui
                                       d_out + k * n0, d_n_out + k, true));
         return AKZ_OK;
     }
+    // (side 1: the finish stream and the second scratch set -- akz_match_all_pairs alternates; FP4 forms only)
+    const bool alt = side == 1 && c->match_mode >= 2;
+    if (alt) AKZ_TRY(ensure_aux(c));
+    hipStream_t st = alt ? c->aux : c->stream;
+    DevBuf &b_q8 = alt ? c->ms1.q8 : c->mm_q8, &b_t8 = alt ? c->ms1.t8 : c->mm_t8, &b_pop = alt ? c->ms1.pop : c->mm_pop;
+    DevBuf &b_tab = alt ? c->ms1.tab : c->mm_tab, &b_cols = alt ? c->ms1.cols : c->mm_cols, &b_rec = alt ? c->ms1.rec : c->match_rec;
+    void*& ring = alt ? c->ms1.ring : c->tab_ring;
+    size_t& ring_bytes = alt ? c->ms1.ring_bytes : c->tab_ring_bytes;
+    uint64_t& ring_next = alt ? c->ms1.ring_next : c->tab_ring_next;
+    hipEvent_t* ring_ev = alt ? c->ms1.ring_ev : c->tab_ring_ev;
     const bool mutual = cols && c->match_mode >= 2;
     const uint32_t thr = (uint32_t)std::min<uint64_t>(distance_threshold, 0x7fffffffull);
     const uint32_t tr = launch::match_mfma_tile_rows();
@@ -2723,69 +2750,69 @@ static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const ui
     }
     // (both directions: the train image is also read as a QUERY image by the seed launch -- whole query blocks of rows)
     const uint32_t t_rows_q = mutual ? launch::match_mfma_rows(t_rows, true) : t_rows;
-    AKZ_TRY(ensure(c, c->mm_q8, (size_t)q_rows * 512));
-    AKZ_TRY(ensure(c, c->mm_t8, (size_t)t_rows_q * 512));
-    AKZ_TRY(ensure(c, c->mm_pop, ((size_t)q_rows * (1 + n_sets) + t_rows) * sizeof(uint32_t)));
+    AKZ_TRY(ensure(c, b_q8, (size_t)q_rows * 512));
+    AKZ_TRY(ensure(c, b_t8, (size_t)t_rows_q * 512));
+    AKZ_TRY(ensure(c, b_pop, ((size_t)q_rows * (1 + n_sets) + t_rows) * sizeof(uint32_t)));
     const size_t tab_tiles = std::max<size_t>(1, tiles.size()) * sizeof(uint32_t);
     const size_t tab_chunks = chunks.size() * sizeof(launch::MatchChunkHost), tab_cols = colsets.size() * sizeof(launch::MatchColSetHost);
-    AKZ_TRY(ensure(c, c->mm_tab, tab_tiles + tab_chunks + tab_cols));
+    AKZ_TRY(ensure(c, b_tab, tab_tiles + tab_chunks + tab_cols));
     unsigned long long* cbest = nullptr;
     uint32_t *csecond = nullptr, *seed_bound = nullptr;
     MatchRec* seed_rec = nullptr;
     if (mutual) {  // per row of the padded train image: 8 + 4 (state) + 4 + 16 (seed launch) bytes
-        AKZ_TRY(ensure(c, c->mm_cols, (size_t)t_rows_q * 32));
-        cbest = (unsigned long long*)c->mm_cols.p;
-        seed_rec = (MatchRec*)((char*)c->mm_cols.p + (size_t)t_rows_q * 8);
-        csecond = (uint32_t*)((char*)c->mm_cols.p + (size_t)t_rows_q * 24);
+        AKZ_TRY(ensure(c, b_cols, (size_t)t_rows_q * 32));
+        cbest = (unsigned long long*)b_cols.p;
+        seed_rec = (MatchRec*)((char*)b_cols.p + (size_t)t_rows_q * 8);
+        csecond = (uint32_t*)((char*)b_cols.p + (size_t)t_rows_q * 24);
         seed_bound = csecond + t_rows_q;
     }
-    AKZ_TRY(ensure(c, c->match_rec, std::max<uint64_t>(1, n0) * chunks.size() * sizeof(MatchRec)));
-    uint32_t* qpop = (uint32_t*)c->mm_pop.p;
+    AKZ_TRY(ensure(c, b_rec, std::max<uint64_t>(1, n0) * chunks.size() * sizeof(MatchRec)));
+    uint32_t* qpop = (uint32_t*)b_pop.p;
     uint32_t* bound = qpop + q_rows;
     uint32_t* tpop = bound + (size_t)n_sets * q_rows;
-    uint32_t* d_tiles = (uint32_t*)c->mm_tab.p;
-    void* d_chunks = (char*)c->mm_tab.p + tab_tiles;
+    uint32_t* d_tiles = (uint32_t*)b_tab.p;
+    void* d_chunks = (char*)b_tab.p + tab_tiles;
     // The tables travel through a ring of pinned staging slots, so that the call returns without waiting for its copies
     // (a synchronisation here made every call of an all-pairs loop wait for the previous call's kernel).
     {
         constexpr int kRing = 4;
         const size_t need = tab_tiles + tab_chunks + tab_cols;
-        if (c->tab_ring_bytes < need) {
-            AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->tab_ring) AKZ_HIP_TRY(hipHostFree(c->tab_ring));
-            c->tab_ring = nullptr;
-            c->tab_ring_bytes = 0;
-            AKZ_HIP_TRY(hipHostMalloc(&c->tab_ring, (need + need / 2 + 4096) * kRing, hipHostMallocDefault));
-            c->tab_ring_bytes = need + need / 2 + 4096;
+        if (ring_bytes < need) {
+            AKZ_HIP_TRY(hipStreamSynchronize(st));
+            if (ring) AKZ_HIP_TRY(hipHostFree(ring));
+            ring = nullptr;
+            ring_bytes = 0;
+            AKZ_HIP_TRY(hipHostMalloc(&ring, (need + need / 2 + 4096) * kRing, hipHostMallocDefault));
+            ring_bytes = need + need / 2 + 4096;
         }
-        const int slot = (int)(c->tab_ring_next++ % kRing);
-        if (!c->tab_ring_ev[slot]) AKZ_HIP_TRY(hipEventCreateWithFlags(&c->tab_ring_ev[slot], hipEventDisableTiming));
-        else AKZ_HIP_TRY(hipEventSynchronize(c->tab_ring_ev[slot]));  // the copy that used this slot four calls ago
-        char* stage = (char*)c->tab_ring + (size_t)slot * c->tab_ring_bytes;
+        const int slot = (int)(ring_next++ % kRing);
+        if (!ring_ev[slot]) AKZ_HIP_TRY(hipEventCreateWithFlags(&ring_ev[slot], hipEventDisableTiming));
+        else AKZ_HIP_TRY(hipEventSynchronize(ring_ev[slot]));  // the copy that used this slot four calls ago
+        char* stage = (char*)ring + (size_t)slot * ring_bytes;
         if (!tiles.empty()) std::memcpy(stage, tiles.data(), tiles.size() * sizeof(uint32_t));
         std::memcpy(stage + tab_tiles, chunks.data(), tab_chunks);
         if (tab_cols) std::memcpy(stage + tab_tiles + tab_chunks, colsets.data(), tab_cols);
-        AKZ_HIP_TRY(hipMemcpyAsync(d_tiles, stage, need, hipMemcpyHostToDevice, c->stream));
-        AKZ_HIP_TRY(hipEventRecord(c->tab_ring_ev[slot], c->stream));
+        AKZ_HIP_TRY(hipMemcpyAsync(d_tiles, stage, need, hipMemcpyHostToDevice, st));
+        AKZ_HIP_TRY(hipEventRecord(ring_ev[slot], st));
     }
     const bool fp4 = c->match_mode >= 2;
-    launch::unpack_bits(c->stream, d_q, (uint32_t)n0, q_rows, true, (uint8_t*)c->mm_q8.p, qpop, bound, thr, (uint32_t)n_sets,
+    launch::unpack_bits(st, d_q, (uint32_t)n0, q_rows, true, (uint8_t*)b_q8.p, qpop, bound, thr, (uint32_t)n_sets,
                         nullptr, fp4);
     if (n_tiles)
-        launch::unpack_bits(c->stream, d_train, 0, n_tiles * tr, false, (uint8_t*)c->mm_t8.p, tpop, nullptr, 0, 0, d_tiles, fp4);
+        launch::unpack_bits(st, d_train, 0, n_tiles * tr, false, (uint8_t*)b_t8.p, tpop, nullptr, 0, 0, d_tiles, fp4);
     if (mutual) {
         // the opposite direction rides along: seed the train rows' state from the first rows of the query set, then one pass
-        launch::match_cols_seed(c->stream, (const uint8_t*)c->mm_q8.p, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, n_tiles * tr, thr,
+        launch::match_cols_seed(st, (const uint8_t*)b_q8.p, (uint32_t)n0, (const uint8_t*)b_t8.p, n_tiles * tr, thr,
                                 seed_bound, seed_rec, cbest, csecond);
-        launch::match_fp4_multi_mutual(c->stream, (const uint8_t*)c->mm_q8.p, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
-                                       (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p, cbest, csecond);
-        launch::match_compact_cols(c->stream, cbest, csecond, (const char*)d_chunks + tab_chunks, (uint32_t)n_sets, thr,
+        launch::match_fp4_multi_mutual(st, (const uint8_t*)b_q8.p, (uint32_t)n0, (const uint8_t*)b_t8.p, d_chunks,
+                                       (uint32_t)chunks.size(), thr, bound, (MatchRec*)b_rec.p, cbest, csecond);
+        launch::match_compact_cols(st, cbest, csecond, (const char*)d_chunks + tab_chunks, (uint32_t)n_sets, thr,
                                    lowes_ratio * lowes_ratio, d_out_cols, (unsigned long long*)d_n_cols);
     } else {
-        launch::match_mfma_multi(c->stream, (const uint8_t*)c->mm_q8.p, qpop, (uint32_t)n0, (const uint8_t*)c->mm_t8.p, d_chunks,
-                                 (uint32_t)chunks.size(), thr, bound, (MatchRec*)c->match_rec.p, fp4);
+        launch::match_mfma_multi(st, (const uint8_t*)b_q8.p, qpop, (uint32_t)n0, (const uint8_t*)b_t8.p, d_chunks,
+                                 (uint32_t)chunks.size(), thr, bound, (MatchRec*)b_rec.p, fp4);
     }
-    launch::match_compact_sets(c->stream, (const MatchRec*)c->match_rec.p, (uint32_t)n0, (uint32_t)n_sets, cps, thr,
+    launch::match_compact_sets(st, (const MatchRec*)b_rec.p, (uint32_t)n0, (uint32_t)n_sets, cps, thr,
                                lowes_ratio * lowes_ratio, d_out, (unsigned long long*)d_n_out);
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
@@ -2794,9 +2821,13 @@ static int match_sets_impl(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const ui
 // (akz_comm.cpp: the all-pairs match takes its sets where they lie in the gathered block)
 int akz::match_sets_at(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_rows, const uint64_t* set_first,
                        const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
-                       uint64_t* d_n_out, akz_match* d_out_cols, uint64_t* d_n_cols) {
+                       uint64_t* d_n_out, akz_match* d_out_cols, uint64_t* d_n_cols, int side) {
     return match_sets_impl(c, d_q, n0, d_rows, set_rows, n_sets, distance_threshold, lowes_ratio, d_out, d_n_out, d_out_cols, d_n_cols,
-                           set_first);
+                           set_first, side);
+}
+hipStream_t akz::match_side_stream(akz_ctx* c) {
+    if (!c || c->match_mode < 2 || bind(c, true, false) != AKZ_OK || ensure_aux(c) != AKZ_OK) return nullptr;
+    return c->aux;
 }
 extern "C" {
 int akz_descriptor_match_sets_device(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_train,

@@ -542,6 +542,7 @@ struct akz_pairs {
     uint64_t* h_cnt = nullptr;           // pinned: the counts of every list, copied behind the launches
     size_t h_cnt_entries = 0;
     hipEvent_t done = nullptr;           // the counts have arrived
+    hipEvent_t fork = nullptr, join = nullptr;  // the matcher's second stream: after the rows are in place / before the counts leave
     bool waited = false;
     std::vector<uint64_t> rows, offset;  // per image: rows, first row in the compacted block
     std::vector<int> owner;
@@ -564,6 +565,8 @@ static void pairs_destroy(akz_pairs* p) {
     if (p->d_block) (void)hipFree(p->d_block);
     if (p->h_cnt) (void)hipHostFree(p->h_cnt);
     if (p->done) (void)hipEventDestroy(p->done);
+    if (p->fork) (void)hipEventDestroy(p->fork);
+    if (p->join) (void)hipEventDestroy(p->join);
     delete p;
 }
 static void pairs_release(akz_pairs* p) {  // back to the communicator's pool (device block, pinned counts, event stay with it)
@@ -679,6 +682,25 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     g->readers_pending = true;
     uint64_t* d_cnt = (uint64_t*)(p->d_block + off_cnt);
     if (n_cnt) AKZ_HIP_TRY(hipMemsetAsync(d_cnt, 0, n_cnt * sizeof(uint64_t), ms));
+    // Consecutive lead images alternate between the matcher's stream and its side stream (own scratch): around an image's
+    // one big pass sit an unpack, a seed launch and two compactions that do not fill the chip (130 of 550 us at 16 x 4K) --
+    // they run under the other image's pass.
+    hipStream_t side = p->n_owned > 1 ? akz::match_side_stream(ctx) : nullptr;
+    if (side) {
+        if (!p->fork) AKZ_HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+        if (!p->join) AKZ_HIP_TRY(hipEventCreateWithFlags(&p->join, hipEventDisableTiming));
+        AKZ_HIP_TRY(hipEventRecord(p->fork, ms));
+        AKZ_HIP_TRY(hipStreamWaitEvent(side, p->fork, 0));
+    }
+    struct Join {  // (also on an error return: the side stream's work is ordered before whatever follows on the matcher's)
+        hipStream_t side, ms;
+        hipEvent_t ev;
+        ~Join() {
+            if (side && hipEventRecord(ev, side) == hipSuccess) (void)hipStreamWaitEvent(ms, ev, 0);
+        }
+    };
+    {
+    Join joiner{side, ms, p->join};
     for (uint64_t k = 0; k < p->n_owned; ++k) {
         akz_pairs::Lead& L = p->lead[(size_t)k];
         const uint64_t q = p->first_owned + k;
@@ -692,7 +714,8 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
         }
         AKZ_TRY(akz::match_sets_at(ctx, p->d_block + p->offset[(size_t)q] * kRow, p->rows[(size_t)q], p->d_block, first.data(), rows.data(),
                                    L.sets.size(), distance_threshold, lowes_ratio, L.d_rows, d_cnt + L.cnt0, L.d_cols,
-                                   d_cnt + L.cnt0 + L.sets.size()));
+                                   d_cnt + L.cnt0 + L.sets.size(), side && (k & 1) ? 1 : 0));
+    }
     }
     if (n_cnt) AKZ_HIP_TRY(hipMemcpyAsync(p->h_cnt, d_cnt, n_cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, ms));
     AKZ_HIP_TRY(hipEventRecord(p->done, ms));

@@ -50,7 +50,10 @@ DefaultSource& default_source();
 // with d_n_cols also the opposite direction of every block (akz_descriptor_match_sets_mutual_device) -- akz_api.cpp
 int match_sets_at(akz_ctx* c, const uint8_t* d_q, uint64_t n0, const uint8_t* d_rows, const uint64_t* set_first,
                   const uint64_t* set_rows, uint64_t n_sets, uint64_t distance_threshold, double lowes_ratio, akz_match* d_out,
-                  uint64_t* d_n_out, akz_match* d_out_cols, uint64_t* d_n_cols);
+                  uint64_t* d_n_out, akz_match* d_out_cols, uint64_t* d_n_cols, int side = 0);
+// side 1 of match_sets_at enqueues on this stream with its own scratch (nullptr: the matcher mode has one side only); the
+// caller orders it after its inputs and joins it before its outputs are read
+hipStream_t match_side_stream(akz_ctx* c);
 
 // streams of another component that run beside a context's: each slot ends up on a hardware queue and a pipe that the
 // context's caller, coarse and finish streams do not use (a colliding stream is destroyed and replaced) -- akz_api.cpp

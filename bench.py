@@ -48,7 +48,8 @@ sys.path[:0] = [os.path.join(ROOT, "akaze-rust_amd", "python")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FED_BYTES_PER_PX_STEP = 12.0   # read Lt + read Lflow + write Lt'  
-MFMA_I8_PEAK_OPS = 5.0e15      # dense int8 MFMA rate: 2 x the 2.5 PFLOP/s bf16 figure (MI355X_MICROARCH.md)
+MFMA_FP4_PEAK_OPS = 10.0e15    # dense FP4 MFMA rate (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands): 4 x the 2.5 PFLOP/s bf16 figure
+                               # (MI355X_MICROARCH.md, Matrix cores)
 
 
 def pmc_traffic(kernel, workload):
@@ -838,7 +839,7 @@ def main_rank(args):
             ms_m = e0.elapsed_time(e1) / reps_m
             pairs = float(n_m) * n_m
             legs.append({"n0": n_m, "n1": n_m, "ms": round(ms_m, 3), "Tpairs_per_s": round(pairs / ms_m / 1e9, 3),
-                         "mfma_frac": round(pairs * 2 * 512 / (ms_m * 1e-3) / MFMA_I8_PEAK_OPS, 3)})
+                         "mfma_frac": round(pairs * 2 * 512 / (ms_m * 1e-3) / MFMA_FP4_PEAK_OPS, 3)})
         # all-pairs shape (BASELINE configs[4]): one query image against 16 train sets in one launch
         n_q, n_sets = 11264, 16
         dq = torch.randint(0, 256, (n_q, 64), dtype=torch.uint8, device=dev, generator=g)
@@ -858,10 +859,11 @@ def main_rank(args):
         pairs = float(n_q) * n_q * n_sets
         legs.append({"n0": n_q, "n1": n_q, "train_sets": n_sets, "ms": round(ms_s, 3),
                      "Tpairs_per_s": round(pairs / ms_s / 1e9, 3),
-                     "mfma_frac": round(pairs * 2 * 512 / (ms_s * 1e-3) / MFMA_I8_PEAK_OPS, 3)})
+                     "mfma_frac": round(pairs * 2 * 512 / (ms_s * 1e-3) / MFMA_FP4_PEAK_OPS, 3)})
         match_leg = {"kernel": "k_match_fp4 (+ unpack, merge, compaction): +-1 operands in FP4 on v_mfma_scale_f32_32x32x64_f8f6f4", "bound": "mfma",
-                     "peak": "mfma_frac is against %.1f POP/s, the dense int8 rate (2 x the 2.5 PFLOP/s bf16 MFMA rate) that the "
-                             "int8 form of the kernel is bound by; the FP4 instruction's own dense rate is twice that" % (MFMA_I8_PEAK_OPS / 1e15),
+                     "peak": "mfma_frac is against %.0f PFLOP/s, the dense FP4 rate of the instruction at 2.4 GHz; under this instruction "
+                             "the chip holds ~2.0 GHz, and chains of it with one ds_read_b128 each and nothing else sustain 7.0-7.7 PFLOP/s "
+                             "(tools/mfma_probe/fp4_rate.hip, profiles/r04_fp4_rate.txt)" % (MFMA_FP4_PEAK_OPS / 1e15),
                      "ops_per_pair": 1024, "sets": legs}
 
     # ---- BASELINE configs[2] and configs[4] end to end (extra legs, rank 0, own clocks) --------------------------------

@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_rate(const uint8_t* __restrict__
     for (int s = 0; s < 8; ++s) bq[s] = *reinterpret_cast<const v4i*>(src + (size_t)(tid & 127u) * PITCH + 32 * s);
     for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(bq[s]));
     float top = -1e30f;
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned it = 0; it < iters; ++it) {
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -60,9 +60,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_rate(const uint8_t* __restrict__
             }
         }
     }
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (top == 12345.0f) sink[tid] = top;
-    if (tid == 0) cycles[blockIdx.x] = c1 - c0;
+    if (tid == 0) {  // the workgroup's FIRST wave: the SIMD issues its oldest wave first, so this one runs almost as if alone
+        cycles[2 * blockIdx.x] = c1 - c0;
+        cycles[2 * blockIdx.x + 1] = r1 - r0;  // 100 MHz ticks
+    }
 }
 
 template <int MODE, int WAVES>
@@ -76,12 +79,14 @@ static void run(const char* what, const uint8_t* d_src, float* d_sink, unsigned 
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> cyc(blocks);
-    hipMemcpy(cyc.data(), d_cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double sum = 0; for (auto c : cyc) sum += (double)c;
-    const double per_simd = (double)iters * 32.0 * (WAVES / 4);  // MFMAs one SIMD executes
-    std::printf("%-44s %2d waves/CU x %3d WGs: %6.1f cycles per MFMA per SIMD, %.0f MHz, %.2f PFLOP/s\n", what, WAVES, blocks,
-                sum / blocks / per_simd, sum / blocks / (ms * 1e3), (double)blocks * WAVES * iters * 32.0 * 32 * 32 * 64 * 2 / (ms * 1e-3) / 1e15);
+    std::vector<unsigned long long> cyc(2 * blocks);
+    hipMemcpy(cyc.data(), d_cyc, 2 * blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum = 0, ticks = 0;
+    for (int b = 0; b < blocks; ++b) { sum += (double)cyc[2 * b]; ticks += (double)cyc[2 * b + 1]; }
+    const double pf = (double)blocks * WAVES * iters * 32.0 * 32 * 32 * 64 * 2 / (ms * 1e-3) / 1e15, mhz = 100.0 * sum / ticks;
+    // every SIMD executes iters * 32 * WAVES / 4 MFMAs in the launch's `ms`: cycles per MFMA per SIMD at the in-kernel clock
+    std::printf("%-44s %2d waves/CU: %.2f PFLOP/s; clock %4.0f MHz; %5.1f cycles per MFMA per SIMD (32 = the instruction); first wave alone-ish: %5.1f per own MFMA\n",
+                what, WAVES, pf, mhz, ms * 1e-3 * mhz * 1e6 / ((double)iters * 32.0 * (WAVES / 4)), sum / blocks / ((double)iters * 32.0));
 }
 
 int main() {
@@ -92,7 +97,7 @@ int main() {
         b = (uint8_t)(((x >> 16) & 1 ? 0x2 : 0xa) | (((x >> 17) & 1 ? 0x2 : 0xa) << 4));
     }
     uint8_t* d_src; float* d_sink; unsigned long long* d_cyc;
-    hipMalloc(&d_src, h.size()); hipMalloc(&d_sink, 4096 * 4); hipMalloc(&d_cyc, 1024 * 8);
+    hipMalloc(&d_src, h.size()); hipMalloc(&d_sink, 4096 * 4); hipMalloc(&d_cyc, 2048 * 8);
     hipMemcpy(d_src, h.data(), h.size(), hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
         run<0, 16>("MFMA chains, operands in registers", d_src, d_sink, d_cyc, 256);

@@ -170,6 +170,10 @@ struct akz_ctx {
     // stages of job i + 1 until job i has (see extract_begin).  Four slots: at most kSlots jobs are in flight.
     static constexpr int kFedRing = 4;
     hipEvent_t fed_ev[kFedRing] = {nullptr, nullptr, nullptr, nullptr};
+    // ... and pre_ev[seq % kFedRing] behind the last diffusion launch of its FIRST octave: from there to the detectors the
+    // main stream carries the half-resolution octave's launches, which are bound by latency and leave most of the chip's
+    // bandwidth unused -- that is where the next job's blur and contrast passes go (sched[1] = 2)
+    hipEvent_t pre_ev[kFedRing] = {nullptr, nullptr, nullptr, nullptr};
     std::atomic<uint64_t> begin_seq{0};  // sequence number of the job begun last
     std::unique_ptr<WorkerPool> workers;  // host threads of the finish half (started on first use)
     unsigned host_threads = 0;            // akz_ctx_set_host_threads; 0 = sized by host_cpu_share()
@@ -445,6 +449,10 @@ int akz_ctx_destroy(akz_ctx* c) {
     c->aux = nullptr;
     c->workers.reset();  // joins the host worker threads
     for (hipEvent_t& e : c->fed_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    for (hipEvent_t& e : c->pre_ev) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
@@ -1291,6 +1299,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     Candidate* d_cand = (Candidate*)c->cand_slot[slot].p;
     if (!c->fed_ev[0])
         for (hipEvent_t& e : c->fed_ev) AKZ_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!c->pre_ev[0])
+        for (hipEvent_t& e : c->pre_ev) AKZ_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const uint64_t seq = c->begin_seq.load() + 1;  // published when this job's event has been recorded
     // derivatives, Ldet and extrema candidates of level l in one or two launches on stream `st_`; false when the
     // level's kernel size has no fused form (then the multi-kernel fallback runs on the main stream at the end)
@@ -1353,7 +1363,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         if (c->pre_done) AKZ_HIP_TRY(hipStreamWaitEvent(ps, c->pre_done, 0));
         // however early the caller begins this batch, its first two stages start when the batch before goes from its
         // (VALU-bound) diffusion launches to its (bandwidth-bound) detectors: that is what they are meant to run under
-        if (c->sched[1] && seq > 1) AKZ_HIP_TRY(hipStreamWaitEvent(ps, c->fed_ev[(seq - 1) % akz_ctx::kFedRing], 0));
+        if (c->sched[1] && seq > 1)
+            AKZ_HIP_TRY(hipStreamWaitEvent(ps, (c->sched[1] == 2 ? c->pre_ev : c->fed_ev)[(seq - 1) % akz_ctx::kFedRing], 0));
         c->stream = ps;
         early = true;
     }
@@ -1533,7 +1544,13 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     };
 
     // the fine levels (all levels when the batch does not fork) on the main stream
-    AKZ_TRY(run_levels(1, fork_level));
+    {
+        size_t oct1 = 1;  // first level past the first octave (fork_level if there is none on the main stream)
+        while (oct1 < fork_level && plan[oct1].octave == plan[0].octave) ++oct1;
+        AKZ_TRY(run_levels(1, oct1));
+        AKZ_HIP_TRY(hipEventRecord(c->pre_ev[seq % akz_ctx::kFedRing], s));
+        AKZ_TRY(run_levels(oct1, fork_level));
+    }
     // The keypoint kernels of the batch that is finished next (orientation, M-LDB: gather-bound, on the auxiliary
     // stream) wait for this point: next to the VALU-bound diffusion launches they cost more than next to the
     // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.

@@ -8,7 +8,8 @@ rm -rf /tmp/ks_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$TAG -- python3 $R/bench.py $B > $O/bench.log 2>&1
 f=$(find /tmp/ks_$TAG -name "*kernel_stats.csv" | head -1)
 cp $f $O/kernel_stats.csv
-python3 $R/tools/queue_busy.py $(find /tmp/ks_$TAG -name "*kernel_trace.csv" | head -1) > $O/queue_busy.txt
+cp $(find /tmp/ks_$TAG -name "*kernel_trace.csv" | head -1) $O/kernel_trace.csv
+python3 $R/tools/queue_busy.py $O/kernel_trace.csv > $O/queue_busy.txt
 python3 $R/tools/step_timeline.py $(find /tmp/ks_$TAG -name "*kernel_trace.csv" | head -1) > $O/step_timeline.txt
 python3 - "$f" "$@" <<'PY'
 import csv, sys

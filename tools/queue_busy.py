@@ -1,10 +1,19 @@
 #!/usr/bin/env python3
-"""Per hardware queue: busy fraction, dispatches and the largest idle gaps over the steady-state middle of a rocprofv3
-kernel_trace.csv of bench.py.  Usage: queue_busy.py kernel_trace.csv"""
+"""Per hardware queue: busy fraction, dispatches and the largest idle gaps over the steady-state part of a rocprofv3
+kernel_trace.csv of bench.py (the timed steps: the dispatches after the last idle period of 20 ms or more, less the
+first and last tenth).  Usage: queue_busy.py kernel_trace.csv"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 n = len(rows)
-rows = rows[n // 3: 2 * n // 3]
+start = 0
+end_so_far = 0
+for i, r in enumerate(rows):  # the last long idle period of the whole device: warm-up / placement probe | timed steps
+    if i and int(r["Start_Timestamp"]) - end_so_far > 20_000_000:
+        start = i
+    end_so_far = max(end_so_far, int(r["End_Timestamp"]))
+rows = rows[start:]
+n = len(rows)
+rows = rows[n // 10: n - n // 10]
 t0, t1 = int(rows[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in rows)
 def nm(r): return r["Kernel_Name"].replace("void ", "").replace("akz::(anonymous namespace)::", "").split("(")[0][:40]
 byq = {}

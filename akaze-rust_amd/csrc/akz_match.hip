@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     // the opposite direction -- averages out over more sub-tiles (round 4, profiles/r04_match_mutual.txt).
     // (two tiles per step: 89 816 x 89 816 1596 -> 1557 us, multi-set launch 481 -> 470 us; with the opposite direction one
     //  tile -- its limits are a step old when they are used, and two tiles cost it 11 spilled registers: 8.8 -> 9.6 ms)
-    constexpr int STEP = COLS ? 1 : AKZ_MM4_STEP, SUBS = MM_SUB * STEP;
+    constexpr int STEP = (COLS || NT < 1024) ? 1 : AKZ_MM4_STEP, SUBS = MM_SUB * STEP;  // (two 512-thread workgroups per CU: one tile each)
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][STEP * MM_TR * MM_PITCH4];
     __shared__ __attribute__((aligned(16))) float s_lim[2][COLS ? STEP * MM_TR : 4];  // COLS: accumulator limits of the rows
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -470,9 +470,16 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     // COLS: the lane's last exchange with a train row's cbest whose loser has not been entered in csecond yet
     unsigned long long pend_old = 0ull;
     unsigned pend_d = 0u, pend_row = 0xffffffffu;
+#ifdef AKZ_MM_COUNT
+    __shared__ unsigned s_count[4];
+    if (tid < 4) s_count[tid] = 0;
+#endif
     auto settle = [&]() {
         if constexpr (COLS) {
             if (pend_row != 0xffffffffu) {
+#ifdef AKZ_MM_COUNT
+                if (pend_old > (((unsigned long long)pend_d << 32) | (q_first + r))) atomicAdd(&s_count[2], 1u);
+#endif
                 const unsigned long long mine = ((unsigned long long)pend_d << 32) | (q_first + r);
                 const unsigned loser = (unsigned)((pend_old > mine ? pend_old : mine) >> 32);
                 if (loser < threshold) atomicMin(csecond + pend_row, loser);
@@ -615,6 +622,9 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                     any = 0ull;
 #endif
                     if ((any & live) != 0ull) {  // a row of the sub-tile may take one of the wave's queries as one of its two nearest
+#ifdef AKZ_MM_COUNT
+                        if (lane == 0) atomicAdd(&s_count[0], 1u);
+#endif
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
                             // (wave-uniform tests, four accumulators at a time first: a scan of sixteen dependent scalar
@@ -633,6 +643,10 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
 #else
                                         // (the exchange's answer is looked at after the next commit, or when the lane's next
                                         //  candidate comes first: a wave that waited for it here held its workgroup at the barrier)
+#ifdef AKZ_MM_COUNT
+                                        atomicAdd(&s_count[1], 1u);
+                                        if (d < csecond[prow]) atomicAdd(&s_count[3], 1u);
+#endif
                                         if (__ballot(pend_row != 0xffffffffu) != 0ull) settle();
                                         const unsigned long long mine = ((unsigned long long)d << 32) | q;
                                         pend_old = atomicMin(cbest + prow, mine);
@@ -689,6 +703,11 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
         __syncthreads();
     }
     settle();
+#ifdef AKZ_MM_COUNT
+    __syncthreads();
+    if (COLS && tid == 0)
+        printf("COUNT %u %u %u %u %u\n", (t_end - t_begin) * 4u * 16u, s_count[0], s_count[1], s_count[2], s_count[3]);
+#endif
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const unsigned o_min = __shfl_xor(min_d[b], 32, 64), o_sec = __shfl_xor(second[b], 32, 64), o_j = __shfl_xor(min_j[b], 32, 64);

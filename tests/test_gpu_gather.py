@@ -82,6 +82,41 @@ def test_comm_gather_matches_local_rows(ctx, amd):
     del g4, g5
 
 
+def test_all_pairs_steps_of_different_sizes(ctx, amd):
+    """akz_match_all_pairs over consecutive steps with 5, 2, 1 and 7 images of different sizes: consecutive lead images
+    run on two streams with a scratch set each (akz::match_sets_at, side 0 / 1), which grow and are reused from step to
+    step; every list equals the pair's descriptor_match (feature_matching.rs:23-94) in both directions."""
+    import torch
+    comm = amd.Comm(0, amd.comm_unique_id(), 0, 1)
+    sizes = [(320, 240), (480, 360), (256, 200), (400, 300), (352, 288), (640, 480), (300, 220)]
+    ress = [ctx.extract_features(torch.from_numpy(amd.synth_frame(w, h, i)[None]).cuda(), keep_all_planes=False)
+            for i, (w, h) in enumerate(sizes)]
+    ref = {}
+    def expected(a, b):
+        if (a, b) not in ref:
+            ref[(a, b)] = ctx.descriptor_match(ress[a].descriptors(0), ress[b].descriptors(0), 10000, 0.86)
+        return ref[(a, b)]
+    for pick in ([0, 1, 2, 3, 4], [5, 2], [6], [3, 5, 0, 6, 1, 4, 2], [0, 1, 2, 3, 4]):
+        rows = sum(ress[i].counts(0)[1] for i in pick)
+        g = comm.gather_begin([ress[i] for i in pick], rows + 8)
+        pairs = g.match_all_pairs(ctx)
+        assert pairs.n_images == len(pick)
+        n = 0
+        for a in range(len(pick)):
+            for b in range(len(pick)):
+                if a == b:
+                    continue
+                got = pairs.matches(a, b)
+                assert np.array_equal(got, expected(pick[a], pick[b])), (pick, a, b)
+                n += len(got)
+        assert n == pairs.total_matches() and (n > 0 or len(pick) == 1)
+        pairs.free()
+        g.free()
+    for r in ress:
+        r.close()
+    comm.close()
+
+
 def test_bench_force_dist_capi_world1():
     """bench.py's N > 1 code path (gloo rendezvous + C-ABI exchange, retired one step late) with one rank."""
     import json

@@ -227,6 +227,25 @@ def _two_view_scene(n, n_outliers, seed):
     return k0, k1, m
 
 
+def test_remove_outliers_concurrent_callers(amd):
+    """The trials of a call run on a process-wide pool of host threads; callers that arrive while it is busy start their
+    own threads.  Every caller thread has its own random source: seeded alike, four concurrent callers get the result of
+    a lone call."""
+    import threading
+    k0, k1, m = _two_view_scene(400, 60, 3)
+    amd.random_seed(7, 11)
+    alone = amd.remove_outliers(k0, k1, m, 400, 0.05, 0.5)
+    out = [None] * 4
+    def work(i):
+        for _ in range(5):
+            amd.random_seed(7, 11)
+            out[i] = amd.remove_outliers(k0, k1, m, 400, 0.05, 0.5)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert all(np.array_equal(o, alone) for o in out) and len(alone) >= 8
+
+
 def test_remove_outliers_host(amd, ref):
     """remove_outliers (estimate_fundamental_matrix.rs:99-165) on the host: behavioural checks and
     agreement with the oracle's restatement (different SVD method)."""

@@ -91,6 +91,7 @@ struct akz_ctx {
     int dbg_select = -1;                     // akz_debug_set_select: 1 / 0 force the neighbour-list / the grid selection, -1 automatic
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
+    DevBuf ransac_dev, ransac_pin;           // match_features: the trials' inputs and outputs on the device / pinned staging of both
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
     DevBuf mm_cols;                          // both-direction launches: the train rows' (best, second) state, seed records and bound
     void* tab_ring = nullptr;                // pinned staging ring of the multi-set matcher's tables
@@ -395,11 +396,12 @@ int akz_ctx_destroy(akz_ctx* c) {
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
                       &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols,
-                      &c->ms1.q8, &c->ms1.t8, &c->ms1.pop, &c->ms1.tab, &c->ms1.cols, &c->ms1.rec};
+                      &c->ms1.q8, &c->ms1.t8, &c->ms1.pop, &c->ms1.tab, &c->ms1.cols, &c->ms1.rec, &c->ransac_dev};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : c->pin)
         if (b.p) (void)hipHostFree(b.p);
+    if (c->ransac_pin.p) (void)hipHostFree(c->ransac_pin.p);
     if (c->tab_ring) (void)hipHostFree(c->tab_ring);
     c->tab_ring = nullptr;
     if (c->ms1.ring) (void)hipHostFree(c->ms1.ring);
@@ -2972,8 +2974,38 @@ int akz_match_features(akz_ctx* c, const akz_keypoint* kp0, uint64_t n_kp0, cons
     std::vector<akz_match> raw((size_t)std::max<uint64_t>(1, n_d0));
     uint64_t n_raw = 0;
     AKZ_TRY(akz_descriptor_match(c, d0, n_d0, d1, n_d1, desc_bytes, 10000, lowes_ratio, raw.data(), &n_raw));  // lib.rs:261-266
-    return akz_remove_outliers(kp0, n_kp0, kp1, n_kp1, raw.data(), n_raw, ransac_trials, 0.05f, ransac_epsilon_inliers, out,
-                               n_out);                                                                        // lib.rs:267-274
+    // lib.rs:267-274.  The trials run on the device (akz_fmatrix.hip: the host's model source, same bits) when there is
+    // enough of them to pay for a launch and a round trip (~60 us); the samples, the choice of the winner and the final
+    // filter stay on the host.  A 4K pair (8 264 matches, 1 000 trials): 1.3-1.4 ms on 16 host threads -> see DESIGN 6.
+    TrialsOnDevice on_device;
+    if (c && ransac_trials * (n_raw + 4000) >= 400000)
+        on_device = [c](const float* x0, const float* y0, const float* x1, const float* y1, uint32_t n, const uint32_t* samples,
+                        uint32_t trials, float eps_model, float eps_inlier, float* models, int32_t* inliers) -> int {
+            AKZ_TRY(bind(c, true, false));
+            const size_t b_pts = (size_t)n * 4 * sizeof(float), b_smp = (size_t)trials * 8 * sizeof(uint32_t);
+            const size_t b_mdl = (size_t)trials * 9 * sizeof(float), b_inl = (size_t)trials * sizeof(int32_t);
+            auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+            const size_t in_bytes = up(b_pts) + up(b_smp), out_bytes = up(b_mdl) + up(b_inl);
+            AKZ_TRY(ensure(c, c->ransac_dev, in_bytes + out_bytes));
+            AKZ_TRY(ensure_pinned(c, c->ransac_pin, in_bytes + out_bytes));
+            char* h = (char*)c->ransac_pin.p;
+            char* d = (char*)c->ransac_dev.p;
+            std::memcpy(h, x0, (size_t)n * 4); std::memcpy(h + (size_t)n * 4, y0, (size_t)n * 4);
+            std::memcpy(h + (size_t)n * 8, x1, (size_t)n * 4); std::memcpy(h + (size_t)n * 12, y1, (size_t)n * 4);
+            std::memcpy(h + up(b_pts), samples, b_smp);
+            hipStream_t st = c->stream;
+            AKZ_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+            launch::ransac_trials(st, (const float*)d, n, (const uint32_t*)(d + up(b_pts)), trials, eps_model, eps_inlier,
+                                  (float*)(d + in_bytes), (int32_t*)(d + in_bytes + up(b_mdl)));
+            AKZ_HIP_TRY(hipGetLastError());
+            AKZ_HIP_TRY(hipMemcpyAsync(h + in_bytes, d + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
+            AKZ_HIP_TRY(hipStreamSynchronize(st));
+            std::memcpy(models, h + in_bytes, b_mdl);
+            std::memcpy(inliers, h + in_bytes + up(b_mdl), b_inl);
+            return AKZ_OK;
+        };
+    return remove_outliers_impl(kp0, n_kp0, kp1, n_kp1, raw.data(), n_raw, ransac_trials, 0.05f, ransac_epsilon_inliers, out, n_out,
+                                on_device);
 }
 // akaze::extract_features(input_image_path, options) — akaze/src/lib.rs:167-194
 int akz_extract_features_file(akz_ctx* c, const char* path, const akz_config* cfg, uint32_t flags, akz_result** out) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -14,6 +15,15 @@ namespace akz {
 void set_error(const std::string& msg);
 // host cores this process can count on: affinity mask, cgroup CPU quota, ranks per host (akz_api.cpp)
 unsigned host_cpu_share();
+
+// remove_outliers (estimate_fundamental_matrix.rs:99-165) with the trials optionally run by the caller's hook (akz_ransac.cpp;
+// match_features hands in the device kernel of akz_fmatrix.hip): (x0, y0, x1, y1 of every match, n, 8 sample indices per
+// trial, trials, epsilon_model, epsilon_inlier) -> 9 model floats and the inlier count (-1: no model) per trial
+using TrialsOnDevice = std::function<int(const float*, const float*, const float*, const float*, uint32_t, const uint32_t*, uint32_t,
+                                         float, float, float*, int32_t*)>;
+int remove_outliers_impl(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1, uint64_t n1,
+                         const akz_match* matches, uint64_t n_matches, uint64_t num_trials, float epsilon_model,
+                         float epsilon_inlier, akz_match* out, uint64_t* n_out, const TrialsOnDevice& trials_on_device);
 
 #define AKZ_HIP_TRY(expr)                                                                          \
     do {                                                                                           \
@@ -263,6 +273,9 @@ uint32_t match_mfma_multi_chunks(uint32_t n0, uint32_t n_sets, uint32_t avg_tile
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
                  uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles, bool fp4 = false);
 // both sets of a pair call in one launch (query form with one bound array, train form)
+// one workgroup per RANSAC trial: model of its eight samples (akz_fmatrix.hpp) + inlier count over all matches (akz_fmatrix.hip)
+void ransac_trials(hipStream_t s, const float* d_pts, uint32_t n_matches, const uint32_t* d_samples, uint32_t trials, float epsilon_model,
+                   float epsilon_inlier, float* d_models, int32_t* d_inliers);
 void unpack_pair(hipStream_t s, const uint8_t* dq, uint32_t nq, uint32_t q_pad, uint8_t* outq, uint32_t* popq, uint32_t* bound, uint32_t threshold,
                  const uint8_t* dt, uint32_t nt, uint32_t t_pad, uint8_t* outt, uint32_t* popt, bool fp4);
 uint32_t match_mfma_tile_rows();

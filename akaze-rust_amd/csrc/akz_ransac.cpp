@@ -29,6 +29,7 @@
 #include <mutex>
 #include <vector>
 
+#include "akz_fmatrix.hpp"
 #include "akz_internal.hpp"
 #include "akz_pool.hpp"
 
@@ -42,82 +43,23 @@ DefaultSource& default_source() {
 
 namespace {
 
-// Thin SVD of the 8x9 design matrix A by one-sided (Hestenes) Jacobi rotations on the columns of A^T (9x8, f64): the
-// rotated columns become orthogonal, their norms are the 8 singular values and the normalised columns the right
-// singular vectors of A.  Works on A itself, not on A^T A, so the condition number is not squared (pixel coordinates
-// of ~1e3 give entries of ~1e6: the eigenvalue route lost the smallest singular values in rounding noise).
-void svd_rows(const float a[8][9], double sigma[8], double vt[8][9]) {
-    double m[9][8];
-    for (int r = 0; r < 8; ++r)
-        for (int k = 0; k < 9; ++k) m[k][r] = (double)a[r][k];
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < 8; ++p)
-            for (int q = p + 1; q < 8; ++q) {
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int k = 0; k < 9; ++k) {
-                    alpha += m[k][p] * m[k][p];
-                    beta += m[k][q] * m[k][q];
-                    gamma += m[k][p] * m[k][q];
-                }
-                if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta) || gamma == 0.0) continue;
-                rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
-                for (int k = 0; k < 9; ++k) {
-                    const double x = m[k][p], y = m[k][q];
-                    m[k][p] = c * x - sn * y;
-                    m[k][q] = sn * x + c * y;
-                }
-            }
-        if (!rotated) break;
-    }
-    for (int i = 0; i < 8; ++i) {
-        double nrm = 0.0;
-        for (int k = 0; k < 9; ++k) nrm += m[k][i] * m[k][i];
-        nrm = std::sqrt(nrm);
-        sigma[i] = nrm;
-        for (int k = 0; k < 9; ++k) vt[i][k] = nrm > 0.0 ? m[k][i] / nrm : 0.0;
-    }
-}
-
 struct Model {
-    float f[3][3];
+    float f[9];  // row-major 3 x 3
 };
 
-// estimate_fundamental_matrix (:17-69)
+// estimate_fundamental_matrix (:17-69): the model itself is akz_fmatrix.hpp (shared with the device kernel)
 bool estimate(const akz_keypoint* k0, const akz_keypoint* k1, const akz_match* sample, float epsilon, Model& out) {
-    float a[8][9];
+    float x0[8], y0[8], x1[8], y1[8];
     for (int i = 0; i < 8; ++i) {
-        const float x0 = k0[sample[i].index_0].x, y0 = k0[sample[i].index_0].y;
-        const float x1 = k1[sample[i].index_1].x, y1 = k1[sample[i].index_1].y;
-        const float row[9] = {x0 * x1, x0 * y1, x0, y0 * x1, y0 * y1, y0, x1, y1, 1.0f};
-        std::memcpy(a[i], row, sizeof(row));
+        x0[i] = k0[sample[i].index_0].x; y0[i] = k0[sample[i].index_0].y;
+        x1[i] = k1[sample[i].index_1].x; y1[i] = k1[sample[i].index_1].y;
     }
-    double sigma[8], vt[8][9];
-    svd_rows(a, sigma, vt);
-    // the 8 singular values an SVD of the 8x9 matrix returns (the 9th direction is its null space)
-    int rank = 0, mi = 0;
-    for (int i = 0; i < 8; ++i) {
-        if ((float)sigma[i] > epsilon) ++rank;
-        if (sigma[i] < sigma[mi]) mi = i;  // smallest of the 8
-    }
-    if (rank != 8) return false;
-    float v[9];
-    for (int i = 0; i < 9; ++i) v[i] = (float)vt[mi][i];
-    const float f[3][3] = {{v[0], v[3], v[6]}, {v[1], v[4], v[7]}, {v[2], v[5], v[8]}};
-    std::memcpy(out.f, f, sizeof(f));
-    return true;
+    return fundamental_from_8(x0, y0, x1, y1, epsilon, out.f);
 }
 
 // evaluate_model (:79-83): |p_r^T F p_l|
 float model_error(const Model& md, const akz_keypoint& k0, const akz_keypoint& k1) {
-    const float pr[3] = {k1.x, k1.y, 1.0f}, pl[3] = {k0.x, k0.y, 1.0f};
-    float row[3];
-    for (int j = 0; j < 3; ++j) row[j] = (pr[0] * md.f[0][j] + pr[1] * md.f[1][j]) + pr[2] * md.f[2][j];
-    const float s = (row[0] * pl[0] + row[1] * pl[1]) + row[2] * pl[2];
-    return std::fabs(s);
+    return fundamental_error(md.f, k0.x, k0.y, k1.x, k1.y);
 }
 
 }  // namespace
@@ -125,9 +67,12 @@ float model_error(const Model& md, const akz_keypoint& k0, const akz_keypoint& k
 
 using namespace akz;
 
-extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1,
-                                   uint64_t n1, const akz_match* matches, uint64_t n_matches, uint64_t num_trials,
-                                   float epsilon_model, float epsilon_inlier, akz_match* out, uint64_t* n_out) {
+// trials_on_device (match_features with a context): runs the trials elsewhere -- px0 .. py1 (n_matches floats each), the
+// samples (8 per trial), -> models (9 floats per trial), inliers (-1: no model); AKZ_OK or an error (the host path then
+// takes over)
+int akz::remove_outliers_impl(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1, uint64_t n1,
+                              const akz_match* matches, uint64_t n_matches, uint64_t num_trials, float epsilon_model,
+                              float epsilon_inlier, akz_match* out, uint64_t* n_out, const TrialsOnDevice& trials_on_device) {
     if (!n_out || (n_matches && (!matches || !out))) {
         set_error("remove_outliers: null pointer");
         return AKZ_ERR_INVALID_ARG;
@@ -178,23 +123,34 @@ extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0,
             for (int i = 0; i < 8; ++i) sample[i] = matches[samples[(size_t)trial * 8 + i]];
             Model model;
             if (!estimate(keypoints_0, keypoints_1, sample, epsilon_model, model)) continue;
-            const float f00 = model.f[0][0], f01 = model.f[0][1], f02 = model.f[0][2], f10 = model.f[1][0], f11 = model.f[1][1],
-                        f12 = model.f[1][2], f20 = model.f[2][0], f21 = model.f[2][1], f22 = model.f[2][2];
             int64_t inl = 0;
-            for (uint64_t i = 0; i < n_matches; ++i) {  // model_error(model, k0, k1) < epsilon_inlier
-                const float r0 = (x1[i] * f00 + y1[i] * f10) + f20, r1 = (x1[i] * f01 + y1[i] * f11) + f21,
-                            r2 = (x1[i] * f02 + y1[i] * f12) + f22;
-                const float sres = (r0 * x0[i] + r1 * y0[i]) + r2;
-                inl += std::fabs(sres) < epsilon_inlier ? 1 : 0;
-            }
+            for (uint64_t i = 0; i < n_matches; ++i)  // model_error(model, k0, k1) < epsilon_inlier
+                inl += fundamental_error(model.f, x0[i], y0[i], x1[i], y1[i]) < epsilon_inlier ? 1 : 0;
             models[(size_t)trial] = model;
             inliers[(size_t)trial] = inl;
         }
     };
-    // (a model costs ~9 us -- the 8 x 9 singular value decomposition -- and an inlier count ~1 ns per match)
+    bool on_device = false;
+    if (trials_on_device && num_trials <= 0x7fffffffull && n_matches <= 0x7fffffffull) {
+        std::vector<uint32_t> smp((size_t)num_trials * 8);
+        for (size_t i = 0; i < smp.size(); ++i) smp[i] = (uint32_t)samples[i];
+        std::vector<float> mdl((size_t)num_trials * 9);
+        std::vector<int32_t> inl((size_t)num_trials);
+        if (trials_on_device(px0.data(), py0.data(), px1.data(), py1.data(), (uint32_t)n_matches, smp.data(), (uint32_t)num_trials,
+                             epsilon_model, epsilon_inlier, mdl.data(), inl.data()) == AKZ_OK) {
+            for (uint64_t t = 0; t < num_trials; ++t) {
+                inliers[(size_t)t] = inl[(size_t)t];
+                if (inl[(size_t)t] >= 0) std::memcpy(models[(size_t)t].f, &mdl[(size_t)t * 9], sizeof(float) * 9);
+            }
+            on_device = true;
+        }
+    }
+    // (a model costs ~5-9 us -- the 8 x 9 singular value decomposition -- and an inlier count ~0.3-1 ns per match)
     const unsigned nthreads = (unsigned)std::min<uint64_t>(std::min(host_cpu_share(), 16u),
                                                           std::max<uint64_t>(1, num_trials * (n_matches + 9000) / 2000000));  // ~0.1 ms of work per thread at least
-    if (nthreads <= 1) {
+    if (on_device) {
+        // (done)
+    } else if (nthreads <= 1) {
         run_trials(0, num_trials);
     } else {
         // the trials go to a pool of host threads that lives as long as the process (starting 16 threads per call was a
@@ -229,6 +185,13 @@ extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0,
             out[k++] = matches[i];
     *n_out = k;
     return AKZ_OK;
+}
+
+extern "C" int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1,
+                                   uint64_t n1, const akz_match* matches, uint64_t n_matches, uint64_t num_trials,
+                                   float epsilon_model, float epsilon_inlier, akz_match* out, uint64_t* n_out) {
+    return akz::remove_outliers_impl(keypoints_0, n0, keypoints_1, n1, matches, n_matches, num_trials, epsilon_model, epsilon_inlier, out,
+                                     n_out, akz::TrialsOnDevice());
 }
 
 // ops::estimate_fundamental_matrix::estimate_fundamental_matrix (:17-69) for exactly 8 matches: *found = 0 is the

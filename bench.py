@@ -914,7 +914,7 @@ def main_rank(args):
                   "ms_per_pair": round((t_ex + t_mt) / reps_p * 1e3, 3), "extract_ms": round(t_ex / reps_p * 1e3, 3),
                   "match_features_ms": round(t_mt / reps_p * 1e3, 3),
                   "match_features_split_ms": {"descriptor_match (GPU scan incl. descriptor upload, match download)": round(t_dm / reps_p * 1e3, 3),
-                                              "remove_outliers (1000 RANSAC trials on the host threads)": round((t_mt - t_dm) / reps_p * 1e3, 3)},
+                                              "remove_outliers (1000 RANSAC trials: samples, winner and final filter on the host, models + inlier counts on the device)": round((t_mt - t_dm) / reps_p * 1e3, 3)},
                   "streamed_ms_per_pair": round(t_stream * 1e3, 3),
                   "streamed_note": "pair j+1 begun before pair j is collected: its extraction runs under match_features of the pair before",
                   "Mpix_s": round(2 * 3840 * 2160 / ((t_ex + t_mt) / reps_p) / 1e6, 1), "keypoints": n_k, "matches": n_m}

@@ -320,6 +320,33 @@ def test_match_features_full_dropin(ctx, amd, ref):
     assert set(got["index_0"].tolist()) <= set(raw["index_0"].tolist())
 
 
+def test_match_features_trials_on_device_equal_host_trials(ctx, amd):
+    """match_features runs its RANSAC trials on the device (akz_fmatrix.hip: one workgroup per trial, the model from the same
+    source as the host's, akz_fmatrix.hpp); remove_outliers runs them on host threads.  Same samples (the calling thread's
+    random source), same models bit for bit, same winner: identical lists -- on a real pair, on a scene where many samples
+    are rank-deficient (collinear points: no model) and with more trials than matches."""
+    f0 = amd.synth_frame(1280, 720, 5)
+    f1 = amd.synth_frame(1280, 720, 5, shift=(11, 6))
+    r0, r1 = ctx.extract_features(f0, keep_all_planes=False), ctx.extract_features(f1, keep_all_planes=False)
+    k0, d0, k1, d1 = r0.keypoints(), r0.descriptors(), r1.keypoints(), r1.descriptors()
+    raw = ctx.descriptor_match(d0, d1, 10000, 0.86)
+    assert len(raw) > 500
+    for trials, eps in ((1000, 3.0), (4000, 0.5), (997, 10.0)):
+        amd.random_seed(42, 69)
+        host = amd.remove_outliers(k0, k1, raw, trials, 0.05, eps)
+        amd.random_seed(42, 69)
+        dev = amd.match_features(k0, d0, k1, d1, 0.86, trials, eps, ctx=ctx)
+        assert np.array_equal(dev, host) and 8 <= len(dev) <= len(raw), (trials, eps)
+    # collinear keypoints in image 0 (y = 2 x): the design matrix of most samples loses rank -> no model for those trials
+    kc = k0.copy()
+    kc["y"] = 2.0 * kc["x"]
+    amd.random_seed(1, 2)
+    host = amd.remove_outliers(kc, k1, raw, 2000, 0.05, 3.0)
+    amd.random_seed(1, 2)
+    dev = amd.match_features(kc, d0, k1, d1, 0.86, 2000, 3.0, ctx=ctx)
+    assert np.array_equal(dev, host)
+
+
 def test_baseline_c4_batch_is_independent_per_image(ctx, amd, ref):
     """BASELINE.json configs[3] (a batch of 1080p frames sharded one image per GPU slot): a frame's result does
     not depend on what else is in the batch or where it sits, and equals the oracle's for a sampled frame."""

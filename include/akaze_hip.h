@@ -409,7 +409,8 @@ int akz_remove_outliers(const akz_keypoint* keypoints_0, uint64_t n0, const akz_
 int akz_estimate_fundamental_matrix(const akz_keypoint* keypoints_0, uint64_t n0, const akz_keypoint* keypoints_1,
                                     uint64_t n1, const akz_match* matches8, float epsilon, float* f /* 9 */, int* found);
 /* akaze::match_features — akaze/src/lib.rs:252-275: descriptor_match(d0, d1, 10000, lowes_ratio) on the
-   GPU, then remove_outliers(kp0, kp1, matches, ransac_trials, 0.05, ransac_epsilon_inliers) on the host.
+   GPU, then remove_outliers(kp0, kp1, matches, ransac_trials, 0.05, ransac_epsilon_inliers): samples, winner and final
+   filter on the host, the trials' models and inlier counts on the device (the host's arithmetic, bit for bit).
    Descriptors are host arrays of n_descriptors x desc_bytes (both sets the same desc_bytes); keypoints and
    descriptors of a set are counted separately, as the reference's slices are — a set with more descriptors than
    keypoints is AKZ_ERR_INVALID_ARG (the reference panics once such a match reaches RANSAC).  out must hold

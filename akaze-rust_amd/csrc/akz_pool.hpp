@@ -45,7 +45,14 @@ public:
             current_ = r;
             ++generation_;
         }
-        cv_.notify_all();
+        // wake as many workers as there is work for besides the caller: with 15 sleeping workers and two pieces (the two
+        // images of a 4K pair) notify_all woke all of them to find nothing -- one after the other through the mutex, ~0.1 ms
+        // per run() and several runs per finish (2 x 4K call: 4.06 ms with 16 threads against 3.29 with 2)
+        if (count - 1 >= threads_.size()) {
+            cv_.notify_all();
+        } else {
+            for (size_t i = 0; i + 1 < count; ++i) cv_.notify_one();
+        }
         drain(*r);
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&] { return r->pending == 0; });

@@ -348,8 +348,11 @@ __global__ void __launch_bounds__(MM_NT) k_match_mfma(const uint8_t* __restrict_
 // The same scan on the block-scaled FP4 matrix instruction (gfx950: v_mfma_scale_f32_32x32x64_f8f6f4, twice the K per
 // instruction and per operand byte of the int8 form at the same issue cost).  Operands are the +-1 images of
 // k_unpack_bits(fp4): e2m1 holds +-1 exactly, the block scales are 1 (E8M0 127), and a dot product of 488 terms of +-1 is
-// an integer of magnitude <= 488: the f32 accumulators are exact.  hamming = (488 - dot) / 2.  Structure, pruning bound,
-// tie rule and output are those of k_match_mfma; a train row is 256 bytes, a wave's query operands 32 registers.
+// an integer of magnitude <= 488: the f32 accumulators are exact.  hamming = (488 - dot) / 2.  Structure, tie rule and
+// output are those of k_match_mfma; a train row is 256 bytes, a wave's query operands 32 registers.  What differs since
+// round 4: the exact top-2 update costs what the case needs (see `The exact update` in the kernel), the second-distance
+// bound shared between workgroups is off (AKZ_MM4_BOUND), the one-direction form takes two tiles per barrier (AKZ_MM4_STEP),
+// and a staged half tile goes to LDS before the chain's accumulators are looked at.
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int KB4 = KB / 2;           // bytes per unpacked row
@@ -367,6 +370,7 @@ constexpr float kPadKey = -1.0e5f;    // ... and what tells their keys 16 acc + 
 #ifndef AKZ_MM4_NT
 #define AKZ_MM4_NT 1024
 #endif
+// AKZ_MM4_STEP: tiles per barrier of the one-direction form (two LDS buffers of STEP tiles each).
 // AKZ_MM4_BOUND = 1: the workgroups that scan for a query share an upper bound of its second distance (bound[q], as in
 // k_match_mfma; pushed once per tile).  With the exact update at its round-4 cost that pays only for very large sets
 // (89 816 x 89 816: 1551 -> 1495 us); a 4K pair (61 against 64 us), the multi-set launch of the all-pairs step (478 against
@@ -394,7 +398,10 @@ constexpr int MM4_QB = (AKZ_MM4_NT / 64) * 32 * AKZ_MM4_NB;  // queries per work
 // launch::match_cols_seed): from a bound of thousands of samples on, a train row sees a handful of candidates in all.
 // (Measured on the way, 16 x 4K 5x5 frames, 120 blocks: gate on the loosest bound of a sub-tile + per-candidate bound loads
 // 58 ms; bulk bound loads, chunks rotated against the query blocks, 2048 seed rows 18.5 ms -- of which 7 ms the bound loads
-// and 1.6 ms the atomics; the same pass without the opposite direction 9.6 ms.)
+// and 1.6 ms the atomics; limits in LDS 13.1 ms; compares OR-ed on the scalar unit 12.5 ms; candidates found by scalar
+// masks, losers settled after the next commit 8.8 ms; lead images on two streams 7.3 ms.  A third of the sub-tiles hold a
+// candidate -- 3.3 per train row and lead image, as 2 ln(rows / seed rows) says -- and what one costs is the time its wave
+// keeps the workgroup waiting at the tile's barrier: profiles/r04_match_mutual.txt.)
 template <int NB, int NT, bool COLS = false>
 __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4, unsigned n0, const uint8_t* __restrict__ t4,
                                                   unsigned n1, unsigned chunk_tiles, unsigned threshold,

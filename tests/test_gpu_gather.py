@@ -117,6 +117,38 @@ def test_all_pairs_steps_of_different_sizes(ctx, amd):
     comm.close()
 
 
+def test_all_pairs_while_extractions_are_in_flight(ctx, amd):
+    """The matcher's side stream is the context's finish stream: an all-pairs step enqueued while two batches of the same
+    context are being finished by its own thread (their keypoint kernels and copies go to that stream too) gives the lists
+    of a quiet context, and the batches' results are what a lone extraction gives."""
+    import torch
+    comm = amd.Comm(0, amd.comm_unique_id(), 0, 1)
+    small = [ctx.extract_features(torch.from_numpy(amd.synth_frame(400, 300, 20 + i)[None]).cuda(), keep_all_planes=False) for i in range(6)]
+    rows = sum(r.counts(0)[1] for r in small)
+    g = comm.gather_begin(small, rows + 8)
+    quiet = g.match_all_pairs(ctx)
+    want = {(a, b): quiet.matches(a, b) for a in range(6) for b in range(6) if a != b}
+    quiet.free(); g.free()
+    big = torch.from_numpy(np.stack([amd.synth_frame(1920, 1080, 40 + i) for i in range(5)])).cuda()  # 10.4 Mpx: the batch path
+    lone = ctx.extract_features(big, keep_all_planes=False)
+    for it in range(6):
+        jobs = [ctx.extract_begin(big, keep_all_planes=False), ctx.extract_begin(big, keep_all_planes=False)]
+        g = comm.gather_begin(small, rows + 8)
+        pairs = g.match_all_pairs(ctx)
+        for (a, b), exp in want.items():
+            assert np.array_equal(pairs.matches(a, b), exp), (it, a, b)
+        pairs.free(); g.free()
+        for j in jobs:
+            r = j.finish()
+            for i in range(5):
+                assert r.counts(i) == lone.counts(i) and np.array_equal(r.descriptors(i), lone.descriptors(i))
+            r.close()
+    for r in small:
+        r.close()
+    lone.close()
+    comm.close()
+
+
 def test_bench_force_dist_capi_world1():
     """bench.py's N > 1 code path (gloo rendezvous + C-ABI exchange, retired one step late) with one rank."""
     import json

@@ -324,7 +324,7 @@ def test_descriptor_match_sets_mutual(ctx, ref, mode, n_q):
     rows = [len(t) for t in sets]
     ctx.set_match_mode(mode)
     try:
-        for ratio, thr in ((0.86, 10000), (1.2, 10000), (0.95, 9)):
+        for ratio, thr in ((0.86, 10000), (1.2, 10000), (0.95, 9), (0.86, 2 ** 63 - 1)):  # (the last: no threshold at all)
             out, cnt, cout, ccnt = ctx.descriptor_match_sets_mutual_device(dq, cat, rows, thr, ratio)
             ctx.synchronize()
             out, cnt, cout, ccnt = out.cpu().numpy(), cnt.cpu().numpy(), cout.cpu().numpy(), ccnt.cpu().numpy()
@@ -348,6 +348,26 @@ def test_descriptor_match_sets_mutual(ctx, ref, mode, n_q):
 def ctx_match_dtype():
     import akaze_amd
     return akaze_amd.MATCH_DTYPE
+
+
+@pytest.mark.parametrize("n1", [1, 2, 33, 129, 300])
+def test_descriptor_match_unbounded_threshold_tiny_train_sets(mctx, ref, n1):
+    """distance_threshold = usize::MAX-like values (feature_matching.rs:23-30 takes a usize) with train sets of one row, two
+    rows and sizes that leave most of the last tile as padding: the second distance of a query then stays at the threshold
+    (a huge number) or comes from a real row, never from a padding row -- lists equal the oracle's for every kernel."""
+    ctx = mctx
+    rng = np.random.default_rng(1000 + n1)
+    d0 = rng.integers(0, 256, (700, 61), dtype=np.uint8)
+    d1 = rng.integers(0, 256, (n1, 61), dtype=np.uint8)
+    d1[0] = d0[5]
+    if n1 > 1:
+        d1[n1 - 1] = d0[5]          # an exact tie between the first and the last row: the lower row wins
+        d1[n1 // 2] = d0[640] ^ 1
+    for thr in (2 ** 63 - 1, 2 ** 31, 489, 244):
+        for ratio in (0.86, 1.0):
+            got = ctx.descriptor_match(d0, d1, thr, ratio)
+            exp = ref.descriptor_match(d0, d1, thr, ratio)
+            assert np.array_equal(got, exp), (n1, thr, ratio, len(got), len(exp))
 
 
 def test_descriptor_match_full_width_rows(ctx, ref):

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2] as one 2-frame batch call against two 1-frame jobs dealt to lanes, each followed by match_features.
+python tools/pair_lanes.py"""
 import os, sys, time
 sys.path.insert(0, "akaze-rust_amd/python")
 import numpy as np, torch

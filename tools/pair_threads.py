@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""One synchronous extract call on a 2 x 3840x2160 batch under different host pool sizes (akz_ctx_set_host_threads), wall
+time and the stage clocks: what waking the pool costs a small job.  python tools/pair_threads.py"""
 import os, sys, time
 sys.path.insert(0, "akaze-rust_amd/python")
 import numpy as np, torch

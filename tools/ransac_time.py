@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""akz_remove_outliers (host trials) by match count on the cores this process may use: python tools/ransac_time.py
+(taskset -c 0-3 python tools/ransac_time.py for fewer cores)"""
 import sys, time, os, numpy as np
 sys.path.insert(0,'akaze-rust_amd/python')
 import akaze_amd as A

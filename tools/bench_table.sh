@@ -1,5 +1,5 @@
 #!/bin/bash
-# The workload table of DESIGN.md 4.4: bench.py over the other BASELINE shapes (run through gpurun from the repo root).
+# The workload table of DESIGN.md 4.5: bench.py over the other BASELINE shapes (run through gpurun from the repo root).
 J='import json,sys; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print("| %s | %.0f | %.2f ms | %.2f |" % (sys.argv[1], d["value"], d["ms_per_step"], r["frac"]))'
 # each shape twice, the better line kept: the first process that touches a new slab size on a fresh box runs up to 15 % slow
 J2='import json,sys; a=[json.loads(l) for l in sys.stdin if l.startswith("{")]; d=max(a,key=lambda x:x["value"]); r=d["roofline"]; print("| %s | %.0f | %.2f ms | %.2f |" % (sys.argv[1], d["value"], d["ms_per_step"], r["frac"]))'

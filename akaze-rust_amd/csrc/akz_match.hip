@@ -378,6 +378,11 @@ constexpr float kPadKey = -1.0e5f;    // ... and what tells their keys 16 acc + 
 #ifndef AKZ_MM4_STEP
 #define AKZ_MM4_STEP 2
 #endif
+// AKZ_MM4_RING: tiles staged ahead in the both-direction form, one barrier per that many tiles (2: 7.32 -> 7.17 ms for the
+// all-pairs step of 16 x 4K 5x5 frames; the limits a lane compares with are then two tiles old instead of one).
+#ifndef AKZ_MM4_RING
+#define AKZ_MM4_RING 2
+#endif
 #ifndef AKZ_MM4_BOUND
 #define AKZ_MM4_BOUND 0
 #endif
@@ -420,8 +425,11 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
     // (two tiles per step: 89 816 x 89 816 1596 -> 1557 us, multi-set launch 481 -> 470 us; with the opposite direction one
     //  tile -- its limits are a step old when they are used, and two tiles cost it 11 spilled registers: 8.8 -> 9.6 ms)
     constexpr int STEP = (COLS || NT < 1024) ? 1 : AKZ_MM4_STEP, SUBS = MM_SUB * STEP;  // (two 512-thread workgroups per CU: one tile each)
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][STEP * MM_TR * MM_PITCH4];
-    __shared__ __attribute__((aligned(16))) float s_lim[2][COLS ? STEP * MM_TR : 4];  // COLS: accumulator limits of the rows
+    // AHEAD (the both-direction form): steps staged ahead in a ring of 2 AHEAD buffers, one barrier per AHEAD steps -- the same
+    // halving of the barriers without the doubled loop body (AKZ_MM4_RING)
+    constexpr int AHEAD = (COLS && STEP == 1 && NT == 1024) ? AKZ_MM4_RING : 1, NBUF = 2 * AHEAD;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[NBUF][STEP * MM_TR * MM_PITCH4];
+    __shared__ __attribute__((aligned(16))) float s_lim[NBUF][COLS ? STEP * MM_TR : 4];  // COLS: accumulator limits of the rows
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
     const unsigned q_first = blockIdx.x * QB + wave * 32u * NB;
@@ -524,20 +532,26 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
             }
         }
     };
-    if (t_begin < t_end) {
 #pragma unroll
-        for (int part = 0; part < 2 * STEP; ++part) {
-            if (part < 2 * (int)min((unsigned)STEP, t_end - t_begin)) {
-                fetch(t_begin, part);
-                commit(0, part, t_begin);
+    for (int ah = 0; ah < AHEAD; ++ah) {
+        const unsigned t0 = t_begin + (unsigned)(ah * STEP);
+        if (t0 < t_end) {
+#pragma unroll
+            for (int part = 0; part < 2 * STEP; ++part) {
+                if (part < 2 * (int)min((unsigned)STEP, t_end - t0)) {
+                    fetch(t0, part);
+                    commit(ah, part, t0);
+                }
             }
         }
     }
     __syncthreads();
     for (unsigned tile = t_begin; tile < t_end; tile += STEP) {
-        const int buf = (int)(((tile - t_begin) / STEP) & 1u);
-        const unsigned here = min((unsigned)STEP, t_end - tile);                                   // tiles of this step
-        const unsigned next = tile + STEP < t_end ? min((unsigned)STEP, t_end - tile - STEP) : 0u;  // ... and of the next
+        const unsigned step = (tile - t_begin) / STEP;
+        const int buf = (int)(step % NBUF), buf_to = (int)((step + AHEAD) % NBUF);
+        const unsigned to = tile + AHEAD * STEP;                                                 // the step staged during this one
+        const unsigned here = min((unsigned)STEP, t_end - tile);                                 // tiles of this step
+        const unsigned next = to < t_end ? min((unsigned)STEP, t_end - to) : 0u;                  // ... and of the one being staged
 #if AKZ_MM4_BOUND > 0
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -554,7 +568,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
             if (sub >= MM_SUB && (unsigned)sub >= MM_SUB * here) break;  // (uniform: the last step of a chunk may be short)
             const bool more = (unsigned)(sub >> 1) < 2u * next;          // part sub / 2 of the next step exists
             const bool partial = (tile + (sub / MM_SUB) + 1) * MM_TR - row0 > n1;  // uniform: only the last tile of the set
-            if (more && (sub & 1) == 0) fetch(tile + STEP, sub >> 1);  // in flight under the MFMA chains below
+            if (more && (sub & 1) == 0) fetch(to, sub >> 1);  // in flight under the MFMA chains below
             v16f acc[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b)
@@ -580,7 +594,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
             // opposite direction included (vmcnt counts them for 600..3000 cycles), and here those are a chain or two old.
             // Their answers are in by then too: settled without another wait.
             if ((sub & 1) == 1) {
-                if (more) commit(buf ^ 1, sub >> 1, tile + STEP);
+                if (more) commit(buf_to, sub >> 1, to);
                 settle();
             }
             const unsigned j0 = tile * MM_TR - row0 + 32 * sub + 4 * h;  // row index inside the set
@@ -707,7 +721,7 @@ __global__ void __launch_bounds__(NT) k_match_fp4(const uint8_t* __restrict__ q4
                 }
             }
         }
-        __syncthreads();
+        if (AHEAD == 1 || step % AHEAD == AHEAD - 1 || tile + STEP >= t_end) __syncthreads();  // (uniform)
     }
     settle();
 #ifdef AKZ_MM_COUNT

@@ -85,3 +85,20 @@ def test_worker_pool_under_thread_sanitizer(tmp_path):
     run = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
     assert "ThreadSanitizer" not in run.stderr and "pool ok" in run.stdout, run.stderr[-3000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"), reason="needs g++ and the HIP headers")
+def test_remove_outliers_pool_under_thread_sanitizer(tmp_path):
+    """akz_remove_outliers under ThreadSanitizer: its trials run on a process-wide pool of host threads, callers that arrive
+    while it is busy start their own; four caller threads seeded alike get the list of a lone call
+    (tools/fuzz/ransac_tsan.cpp compiles akz_ransac.cpp with the two symbols it takes from akz_api.cpp stubbed)."""
+    exe = str(tmp_path / "ransac_tsan")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-ffp-contract=off",
+                            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                            os.path.join(ROOT, "tools", "fuzz", "ransac_tsan.cpp"), "-o", exe], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "ThreadSanitizer" not in run.stderr and "ransac ok" in run.stdout, run.stderr[-3000:]

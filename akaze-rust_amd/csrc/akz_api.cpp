@@ -1617,12 +1617,15 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         AKZ_HIP_TRY(hipStreamWaitEvent(c->coarse, fine_done, 0));
         ev_put(c, fine_done);
         // (holding the chain back until the full-resolution detectors, or all fine detectors, have finished: -2 ... -5 %)
+        // The fine detectors are ENQUEUED first: the coarse chain is dozens of small launches, and a caller that is not
+        // ahead of the chip -- one synchronous call on a 4K pair -- kept the main stream idle for the 0.19 ms it took to
+        // enqueue them (the two streams run side by side either way).
+        AKZ_TRY(detectors(0, fork_level, s));
         ls = c->coarse;
         c->stream = c->coarse;
         AKZ_TRY(run_levels(fork_level, L));
         AKZ_TRY(detectors(fork_level, L, c->coarse));
         c->stream = s;
-        AKZ_TRY(detectors(0, fork_level, s));
         hipEvent_t ev = StageTimer::get(c);
         if (own_kernels) {
             AKZ_HIP_TRY(hipEventRecord(ev, s));

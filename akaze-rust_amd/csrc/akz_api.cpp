@@ -124,7 +124,8 @@ struct akz_ctx {
     std::atomic<int> live_results{0};   // akz_result objects (also inside jobs) that still point at this context
     bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
     std::atomic<uint32_t> last_total_cands{0};  // candidates of the previous finished job (speculative fetch size)
-    hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels
+    hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels (created under aux_m: the caller's thread and the finisher's may both be first)
+    std::mutex aux_m;
     hipStream_t coarse = nullptr;       // the coarse octaves' chain (diffusion + detectors), next to the fine detectors
     hipStream_t pre = nullptr;          // level-0 blur + contrast factor of a batch whose input is known to be complete:
     hipEvent_t pre_done = nullptr;      // they run ahead, under the kernels of the batch before (extract_begin)
@@ -279,6 +280,8 @@ static int ensure_pinned(akz_ctx* c, DevBuf& b, size_t bytes) {
 // The auxiliary stream carries the finish-side copies and the per-keypoint kernels.  (A lowest-priority
 // stream was measured and made no difference to the main-stream kernels, so it is a plain stream.)
 static int ensure_aux(akz_ctx* c) {
+    // (the matcher's entry points bind without draining the finisher thread, whose finish half creates the stream too)
+    std::lock_guard<std::mutex> lk(c->aux_m);
     if (!c->aux) AKZ_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     return AKZ_OK;
 }

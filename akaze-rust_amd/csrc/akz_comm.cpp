@@ -106,6 +106,7 @@ struct akz_gather {
     bool in_use = false;
     bool overflow = false;     // this rank's shard did not fit: it sent its header only
     bool finished = false;     // akz_gather_finish has read the headers and the per-image tables
+    bool delivered = false;    // external transport: akz_gather_deliver has been called (`done` is recorded)
     std::vector<uint64_t> hdr_rows, hdr_images;      // per rank, from the headers
     std::vector<std::vector<uint64_t>> image_rows;   // per rank: rows of every image of its shard
     std::vector<uint64_t> table;                     // this rank's per-image table, staged for the send block
@@ -114,9 +115,11 @@ struct akz_gather {
 };
 
 static void pairs_destroy(akz_pairs* p);  // (defined with akz_pairs, below)
+static void pairs_orphan_all(akz_comm* c);
 struct akz_comm {
     int device = 0, rank = 0, nranks = 1;
     ncclComm_t nccl = nullptr;
+    bool external = false;          // akz_comm_create_external: the CALLER moves the blocks between ranks (no RCCL in the process)
     hipStream_t xs = nullptr;       // exchange stream: the collectives, in order
     hipStream_t cs = nullptr;       // copy stream: local rows -> send block, headers -> host (never behind a collective)
     hipEvent_t ready = nullptr;     // producer-side event the copy stream waits for
@@ -125,7 +128,9 @@ struct akz_comm {
     size_t sync_out_bytes = 0;
     uint64_t sequence = 0;
     std::vector<akz_gather*> pool;  // every gather object ever handed out (reused when free and large enough)
-    std::vector<akz_pairs*> pairs_pool;  // freed all-pairs results: device block, pinned counts and event are reused
+    std::vector<akz_pairs*> pairs_pool;  // freed all-pairs results: device block, pinned counts and event are reused (at most kPairsPool)
+    std::vector<akz_pairs*> live_pairs;  // handed out and not yet freed: akz_comm_destroy orphans them (their comm pointer is cleared)
+    static constexpr size_t kPairsPool = 2;  // two steps' objects alternate in a pipelined job; more would only hold device memory
 };
 
 static void gather_release_buffers(akz_gather* g) {
@@ -180,6 +185,7 @@ static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
     g->in_use = true;
     g->overflow = false;
     g->finished = false;
+    g->delivered = false;
     *out = g;
     return AKZ_OK;
 }
@@ -225,6 +231,11 @@ static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_sr
     if (!g->overflow && table_rows)  // (pageable source: the runtime stages it before the call returns)
         AKZ_HIP_TRY(hipMemcpyAsync(g->send + at * kRow, g->table.data(), table_rows * kRow, hipMemcpyHostToDevice, c->cs));
     AKZ_HIP_TRY(hipEventRecord(c->copied, c->cs));
+    if (c->external) {
+        // the caller carries the blocks (akz_gather_blocks / akz_gather_deliver): the send block must be complete on return
+        AKZ_HIP_TRY(hipEventSynchronize(c->copied));
+        return AKZ_OK;
+    }
     AKZ_HIP_TRY(hipStreamWaitEvent(c->xs, c->copied, 0));
     AKZ_NCCL_TRY(rccl()->AllGather(g->send, g->recv, g->send_bytes, ncclUint8, c->nccl, c->xs));
     AKZ_HIP_TRY(hipEventRecord(g->done, c->xs));
@@ -271,10 +282,67 @@ int akz_comm_create(int device, const uint8_t* id, int rank, int nranks, akz_com
         hipEventCreateWithFlags(&c->copied, hipEventDisableTiming) != hipSuccess) {
         set_error("akz_comm_create: stream / event creation failed");
         (void)rccl()->CommDestroy(c->nccl);
+        if (c->xs) (void)hipStreamDestroy(c->xs);
+        if (c->cs) (void)hipStreamDestroy(c->cs);
+        if (c->ready) (void)hipEventDestroy(c->ready);
+        if (c->copied) (void)hipEventDestroy(c->copied);
         delete c;
         return AKZ_ERR_HIP;
     }
     *out = c;
+    return AKZ_OK;
+}
+
+// A communicator whose blocks the CALLER moves between the ranks (MPI, gloo, shared memory, a test that runs several
+// ranks on one GPU -- which RCCL refuses): same wire format, same gather objects, same all-pairs match; RCCL is not loaded.
+int akz_comm_create_external(int device, int rank, int nranks, akz_comm** out) {
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) {
+        set_error("akz_comm_create_external: bad rank / nranks");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    AKZ_HIP_TRY(hipSetDevice(device));
+    akz_comm* c = new akz_comm;
+    c->device = device;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->external = true;
+    if (hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->copied, hipEventDisableTiming) != hipSuccess) {
+        set_error("akz_comm_create_external: stream / event creation failed");
+        if (c->xs) (void)hipStreamDestroy(c->xs);
+        if (c->cs) (void)hipStreamDestroy(c->cs);
+        if (c->ready) (void)hipEventDestroy(c->ready);
+        if (c->copied) (void)hipEventDestroy(c->copied);
+        delete c;
+        return AKZ_ERR_HIP;
+    }
+    *out = c;
+    return AKZ_OK;
+}
+
+int akz_gather_blocks(akz_gather* g, const uint8_t** d_send, uint8_t** d_recv, uint64_t* block_bytes) {
+    if (!g || !g->in_use || !g->comm->external) {
+        set_error("akz_gather_blocks: a gather in flight on a communicator of akz_comm_create_external");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    if (d_send) *d_send = g->send;
+    if (d_recv) *d_recv = g->recv;
+    if (block_bytes) *block_bytes = g->send_bytes;
+    return AKZ_OK;
+}
+int akz_gather_deliver(akz_gather* g, void* stream) {
+    if (!g || !g->in_use || !g->comm->external) {
+        set_error("akz_gather_deliver: a gather in flight on a communicator of akz_comm_create_external");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    akz_comm* c = g->comm;
+    AKZ_HIP_TRY(hipSetDevice(c->device));
+    AKZ_HIP_TRY(hipEventRecord(g->done, stream ? (hipStream_t)stream : c->xs));  // (NULL: the blocks are complete now)
+    g->delivered = true;
     return AKZ_OK;
 }
 
@@ -291,6 +359,7 @@ int akz_comm_destroy(akz_comm* c) {
     c->pool.clear();
     for (akz_pairs* p : c->pairs_pool) pairs_destroy(p);
     c->pairs_pool.clear();
+    pairs_orphan_all(c);  // results the caller still holds stay readable; their akz_pairs_free no longer touches this object
     if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->copied) (void)hipEventDestroy(c->copied);
@@ -384,6 +453,10 @@ int akz_gather_begin(akz_comm* c, const akz_result* const* results, uint64_t n_r
 
 int akz_gather_stream_wait(akz_gather* g, void* stream) {
     if (!g || !g->in_use) return AKZ_ERR_INVALID_ARG;
+    if (g->comm->external && !g->delivered) {
+        set_error("gather: the blocks of this exchange have not been delivered yet (akz_gather_deliver)");
+        return AKZ_ERR_INVALID_ARG;
+    }
     AKZ_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, g->done, 0));
     return AKZ_OK;
 }
@@ -395,6 +468,10 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
     }
     akz_comm* c = g->comm;
     AKZ_HIP_TRY(hipSetDevice(c->device));
+    if (c->external && !g->delivered) {
+        set_error("gather: the blocks of this exchange have not been delivered yet (akz_gather_deliver)");
+        return AKZ_ERR_INVALID_ARG;
+    }
     // the headers of all blocks -> host (64 bytes per rank): an overflow anywhere is an error everywhere
     AKZ_HIP_TRY(hipEventSynchronize(g->done));
     if (!g->finished) {
@@ -456,7 +533,7 @@ int akz_gather_image_rows(akz_gather* g, int rank, uint64_t* rows_per_image, uin
 
 int akz_gather_free(akz_gather* g) {
     if (!g) return AKZ_OK;
-    if (g->in_use && g->done) {
+    if (g->in_use && g->done && (!g->comm->external || g->delivered)) {
         (void)hipSetDevice(g->comm->device);
         (void)hipEventSynchronize(g->done);
     }
@@ -472,6 +549,11 @@ int akz_gather_descriptors(akz_comm* c, const uint8_t* d_local, uint64_t n_local
         return AKZ_ERR_INVALID_ARG;
     }
     *d_all = nullptr;
+    if (c->external) {
+        set_error("akz_gather_descriptors: the synchronous form needs the library's own transport (akz_comm_create); with "
+                  "akz_comm_create_external use akz_gather_begin_rows / akz_gather_blocks / akz_gather_deliver");
+        return AKZ_ERR_UNSUPPORTED;
+    }
     AKZ_HIP_TRY(hipSetDevice(c->device));
     akz_gather* g0 = nullptr;  // header-only exchange: every rank learns every shard's row count
     AKZ_TRY(gather_acquire(c, 0, &g0));
@@ -543,6 +625,8 @@ struct akz_pairs {
     size_t h_cnt_entries = 0;
     hipEvent_t done = nullptr;           // the counts have arrived
     hipEvent_t fork = nullptr, join = nullptr;  // the matcher's second stream: after the rows are in place / before the counts leave
+    hipStream_t last_stream = nullptr;   // the matcher's stream of the step that used these buffers last (reuse on another one waits for `done`)
+    bool used = false;                   // `done` has been recorded at least once
     bool waited = false;
     std::vector<uint64_t> rows, offset;  // per image: rows, first row in the compacted block
     std::vector<int> owner;
@@ -569,10 +653,26 @@ static void pairs_destroy(akz_pairs* p) {
     if (p->join) (void)hipEventDestroy(p->join);
     delete p;
 }
-static void pairs_release(akz_pairs* p) {  // back to the communicator's pool (device block, pinned counts, event stay with it)
+// Lifetime rule (akaze_hip.h): an akz_pairs may outlive its communicator.  While the communicator lives, a freed object goes
+// back to its pool (at most kPairsPool of them; the rest are destroyed); akz_comm_destroy clears the comm pointer of every
+// object still held by the caller, whose akz_pairs_free then destroys it on its own.
+static void pairs_release(akz_pairs* p) {
     if (!p) return;
-    if (p->comm) p->comm->pairs_pool.push_back(p);
-    else pairs_destroy(p);
+    akz_comm* c = p->comm;
+    if (c) {
+        auto it = std::find(c->live_pairs.begin(), c->live_pairs.end(), p);
+        if (it != c->live_pairs.end()) c->live_pairs.erase(it);
+        if (c->pairs_pool.size() < akz_comm::kPairsPool) {
+            c->pairs_pool.push_back(p);
+            return;
+        }
+    }
+    if (p->used && p->done) (void)hipEventSynchronize(p->done);  // launches of its last step may still read the block
+    pairs_destroy(p);
+}
+static void pairs_orphan_all(akz_comm* c) {
+    for (akz_pairs* p : c->live_pairs) p->comm = nullptr;
+    c->live_pairs.clear();
 }
 extern "C" {
 
@@ -603,6 +703,7 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     } back{p};
     p->ctx = ctx;
     p->comm = c;
+    c->live_pairs.push_back(p);
     p->device = c->device;
     p->waited = false;
     p->rows.clear(); p->offset.clear(); p->owner.clear(); p->lead.clear();
@@ -650,9 +751,13 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     const size_t off_cnt = bytes;
     bytes += up(std::max<size_t>(1, n_cnt) * sizeof(uint64_t));
     hipStream_t ms = (hipStream_t)akz_ctx_stream(ctx);  // the matcher's stream: everything below is enqueued on it, in order
+    // A pooled object's buffers were last used by launches on `last_stream`.  On the same stream this step's copies are
+    // ordered behind them; on another one (a second context on this communicator, a context that was recreated) they are
+    // not: this step's first write waits for that step's `done`.
+    if (p->used && p->last_stream != ms) AKZ_HIP_TRY(hipStreamWaitEvent(ms, p->done, 0));
     if (p->block_bytes < bytes) {
         if (p->d_block) {
-            AKZ_HIP_TRY(hipStreamSynchronize(ms));  // (an earlier step's launches may still read the old block)
+            if (p->used) AKZ_HIP_TRY(hipEventSynchronize(p->done));  // (an earlier step's launches may still read the old block)
             AKZ_HIP_TRY(hipFree(p->d_block));
         }
         p->d_block = nullptr;
@@ -661,6 +766,7 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
         p->block_bytes = bytes + bytes / 4;
     }
     if (p->h_cnt_entries < std::max<size_t>(1, n_cnt)) {
+        if (p->h_cnt && p->used) AKZ_HIP_TRY(hipEventSynchronize(p->done));  // (the last step's count copy targets it)
         if (p->h_cnt) AKZ_HIP_TRY(hipHostFree(p->h_cnt));
         p->h_cnt = nullptr;
         p->h_cnt_entries = 0;
@@ -719,6 +825,8 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     }
     if (n_cnt) AKZ_HIP_TRY(hipMemcpyAsync(p->h_cnt, d_cnt, n_cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, ms));
     AKZ_HIP_TRY(hipEventRecord(p->done, ms));
+    p->last_stream = ms;
+    p->used = true;
     back.armed = false;
     *out = p;
     return AKZ_OK;
@@ -773,6 +881,29 @@ int akz_pairs_matches(const akz_pairs* pc, uint64_t query, uint64_t image, akz_m
         const akz_match* src = forward ? L.d_rows + k * p->rows[(size_t)lead] : L.d_cols + L.col0[k];
         AKZ_HIP_TRY(hipMemcpy(out, src, take * sizeof(akz_match), hipMemcpyDeviceToHost));
     }
+    return AKZ_OK;
+}
+int akz_pairs_totals(const akz_pairs* pc, uint64_t* n_lists, uint64_t* n_matches, uint64_t* n_distances) {
+    akz_pairs* p = const_cast<akz_pairs*>(pc);
+    if (!p) return AKZ_ERR_INVALID_ARG;
+    AKZ_HIP_TRY(hipSetDevice(p->device));
+    if (!p->waited) {
+        AKZ_HIP_TRY(hipEventSynchronize(p->done));
+        p->waited = true;
+    }
+    uint64_t lists = 0, matches = 0, dist = 0;
+    for (uint64_t k = 0; k < p->n_owned; ++k) {
+        const akz_pairs::Lead& L = p->lead[(size_t)k];
+        const uint64_t rq = p->rows[(size_t)(p->first_owned + k)];
+        for (size_t i = 0; i < L.sets.size(); ++i) {
+            lists += 2;
+            matches += p->h_cnt[L.cnt0 + i] + p->h_cnt[L.cnt0 + L.sets.size() + i];
+            dist += rq * p->rows[(size_t)L.sets[i]];
+        }
+    }
+    if (n_lists) *n_lists = lists;
+    if (n_matches) *n_matches = matches;
+    if (n_distances) *n_distances = dist;
     return AKZ_OK;
 }
 int akz_pairs_free(akz_pairs* p) {

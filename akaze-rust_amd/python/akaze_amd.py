@@ -201,6 +201,9 @@ def lib():
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
         "akz_comm_unique_id": ([vp], i32),
         "akz_comm_create": ([i32, vp, i32, i32, C.POINTER(vp)], i32),
+        "akz_comm_create_external": ([i32, i32, i32, C.POINTER(vp)], i32),
+        "akz_gather_blocks": ([vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)], i32),
+        "akz_gather_deliver": ([vp, vp], i32),
         "akz_comm_destroy": ([vp], i32),
         "akz_comm_place_streams": ([vp, vp], i32),
         "akz_comm_info": ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
@@ -214,6 +217,7 @@ def lib():
         "akz_pairs_holder": ([vp, u64, u64, C.POINTER(i32)], i32),
         "akz_pairs_matches": ([vp, u64, u64, vp, u64, pu64], i32),
         "akz_pairs_free": ([vp], i32),
+        "akz_pairs_totals": ([vp, pu64, pu64, pu64], i32),
         "akz_gather_stream_wait": ([vp, vp], i32),
         "akz_gather_finish": ([vp, C.POINTER(vp), pu64, pu64, pu64], i32),
         "akz_gather_free": ([vp], i32),
@@ -1010,6 +1014,31 @@ class Gather:
     def stream_wait(self, stream):
         _check(lib().akz_gather_stream_wait(self._h, C.c_void_p(stream)))
 
+    def blocks(self):
+        """akz_gather_blocks (external transport): (device address of this rank's block, device address where the blocks of
+        all ranks go, bytes per block)."""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(lib().akz_gather_blocks(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def deliver(self, stream=None):
+        """akz_gather_deliver: every rank's block has been written where blocks() said, in the order of `stream`."""
+        _check(lib().akz_gather_deliver(self._h, C.c_void_p(stream) if stream else None))
+
+    def exchange_over(self, group=None):
+        """External transport over torch.distributed (any backend; gloo in the one-GPU rehearsals): this rank's block D2H,
+        one all-gather of the fixed-size blocks, H2D, deliver.  Synchronous."""
+        import torch
+        import torch.distributed as dist
+        send, recv, nbytes = self.blocks()
+        world = self._comm.nranks
+        h_send = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        h_recv = torch.empty(world * nbytes, dtype=torch.uint8).pin_memory()
+        copy_raw(h_send.data_ptr(), send, nbytes, 2)       # D2H
+        dist.all_gather_into_tensor(h_recv, h_send, group=group)
+        copy_raw(recv, h_recv.data_ptr(), world * nbytes, 1)  # H2D
+        self.deliver()
+
     def finish(self, want_counts=True):
         """-> (device address of the blocks, rows per block, counts per rank, images per rank); rank r's descriptor
         rows start one 64-byte row into block r."""
@@ -1087,6 +1116,13 @@ class Pairs:
     def total_matches(self, rank=0):
         return sum(self.count(a, b) for a, b in self.held(rank))
 
+    def totals(self):
+        """akz_pairs_totals: (match lists held, records in them, descriptor pairs whose distance was formed); waits for the
+        launches."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().akz_pairs_totals(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def free(self):
         if self._h:
             lib().akz_pairs_free(self._h)
@@ -1100,12 +1136,18 @@ class Pairs:
 
 
 class Comm:
-    """RCCL communicator of the descriptor exchange behind the C ABI (akz_comm_*): one per rank."""
+    """Communicator of the descriptor exchange behind the C ABI (akz_comm_*): one per rank.  unique_id = the bytes of
+    comm_unique_id() from rank 0: RCCL carries the blocks (akz_comm_create); unique_id = None: the caller does
+    (akz_comm_create_external; Gather.blocks / Gather.deliver)."""
 
     def __init__(self, device, unique_id, rank, nranks):
         self._h = C.c_void_p()
-        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
-        _check(lib().akz_comm_create(int(device), buf, int(rank), int(nranks), C.byref(self._h)))
+        self.external = unique_id is None
+        if self.external:
+            _check(lib().akz_comm_create_external(int(device), int(rank), int(nranks), C.byref(self._h)))
+        else:
+            buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+            _check(lib().akz_comm_create(int(device), buf, int(rank), int(nranks), C.byref(self._h)))
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
 
     def place_streams(self, ctx):
@@ -1167,15 +1209,20 @@ class Comm:
         return out, counts
 
 
-def copy_d2d(dst, src, nbytes):
-    """Synchronous device-to-device copy through the HIP runtime torch already loaded (binding helper)."""
+def copy_raw(dst, src, nbytes, kind):
+    """Synchronous hipMemcpy through the HIP runtime torch already loaded (binding helper); kind 1 H2D, 2 D2H, 3 D2D."""
     import torch
     hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
     fn = hip.hipMemcpy
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     fn.restype = C.c_int
-    if fn(C.c_void_p(dst), C.c_void_p(src), nbytes, 3) != 0:  # hipMemcpyDeviceToDevice
+    if fn(C.c_void_p(dst), C.c_void_p(src), nbytes, int(kind)) != 0:
         raise AkazeError(-2, "hipMemcpy failed")
+
+
+def copy_d2d(dst, src, nbytes):
+    """Synchronous device-to-device copy (binding helper)."""
+    copy_raw(dst, src, nbytes, 3)
 
 
 def gather_descriptor_rows(local_rows, group=None, cap_rows=None):

@@ -331,6 +331,15 @@ typedef struct akz_comm akz_comm;
 typedef struct akz_gather akz_gather; /* one exchange in flight */
 int akz_comm_unique_id(uint8_t* id_out /* AKZ_COMM_ID_BYTES */);
 int akz_comm_create(int device, const uint8_t* id, int rank, int nranks, akz_comm** out);
+/* The same communicator with the transport left to the CALLER (MPI, gloo, shared memory; a rehearsal of several ranks on
+   ONE GPU, which RCCL refuses): RCCL is not loaded, no id is needed, the call is not collective.  An exchange is then
+       akz_gather_begin / akz_gather_begin_rows  -> this rank's block is complete in device memory on return
+       akz_gather_blocks(g, &d_send, &d_recv, &bytes)  -> move every rank r's d_send block to d_recv + r * bytes on every
+                                                          rank (this rank's own block included)
+       akz_gather_deliver(g, stream)                   -> the blocks are complete in the order of `stream` (NULL: now)
+   and everything behind it (akz_gather_finish, akz_gather_stream_wait, akz_match_all_pairs, ...) as with RCCL.  The wire
+   format is the one described below; akz_gather_descriptors (the synchronous two-collective form) is not available. */
+int akz_comm_create_external(int device, int rank, int nranks, akz_comm** out);
 int akz_comm_destroy(akz_comm* comm);
 /* Optional, once, with idle streams (before the first step): moves the communicator's two streams onto hardware queues and
    command-processor pipes that `ctx`'s busy streams (the caller's, the coarse chain's, the finish half's) do not use -- the
@@ -360,6 +369,9 @@ int akz_gather_begin(akz_comm* comm, const akz_result* const* results, uint64_t 
                      akz_gather** out);
 int akz_gather_begin_rows(akz_comm* comm, const uint8_t* d_local, uint64_t n_local, uint64_t cap_rows,
                           void* producer_stream, akz_gather** out);
+/* external transport only (akz_comm_create_external): the block this rank sends, where the blocks of all ranks go, bytes per block */
+int akz_gather_blocks(akz_gather* g, const uint8_t** d_send, uint8_t** d_recv, uint64_t* block_bytes);
+int akz_gather_deliver(akz_gather* g, void* stream);
 /* make `stream` (e.g. the matcher's) wait for the gathered blocks without a host synchronisation */
 int akz_gather_stream_wait(akz_gather* g, void* stream);
 /* host wait.  *d_all: nranks blocks of *block_rows (= 1 + cap_rows) rows, rank r's descriptor rows start one row into
@@ -393,6 +405,13 @@ int akz_pairs_holder(const akz_pairs* p, uint64_t image_a, uint64_t image_b, int
    into the query's rows, index_1 into `image`'s; ordered by index_0.  out may be NULL (count only); at most cap records are
    written.  The pair (query, query) is empty.  The first call waits for the launches of akz_match_all_pairs. */
 int akz_pairs_matches(const akz_pairs* p, uint64_t query, uint64_t image, akz_match* out, uint64_t cap, uint64_t* n);
+/* Everything this rank holds at once (waits for the launches like the first akz_pairs_matches): *n_lists = match lists held
+   (two per unordered pair it leads), *n_matches = their records in all, *n_distances = descriptor pairs whose distance was
+   formed (rows(a) x rows(b) per unordered pair; each serves both directions).  Any pointer may be NULL. */
+int akz_pairs_totals(const akz_pairs* p, uint64_t* n_lists, uint64_t* n_matches, uint64_t* n_distances);
+/* Lifetime: an akz_pairs may be freed before or after akz_comm_destroy of the communicator it came from (the communicator
+   keeps a list of the objects it has handed out and cuts them loose when it is destroyed; until then a freed object's
+   buffers are pooled there, at most two of them).  It must be freed before akz_ctx_destroy of the context it ran on. */
 int akz_pairs_free(akz_pairs* p);
 
 /* ---- the rest of match_features (host post-filter) -------------------- */

@@ -117,6 +117,41 @@ def test_all_pairs_steps_of_different_sizes(ctx, amd):
     comm.close()
 
 
+def test_pairs_outlive_their_communicator(ctx, amd):
+    """Lifetime rule of akz_pairs (include/akaze_hip.h): a result that is still held when its communicator is destroyed
+    stays readable and is freed afterwards without touching the communicator (round-4 advice: akz_pairs_free pushed the
+    object into the pool of a deleted akz_comm); freed objects beyond the pool's two are destroyed, pooled ones reused
+    by a SECOND context on the same communicator (another matcher stream: the reuse waits for the last step's event)."""
+    import torch
+    comm = amd.Comm(0, amd.comm_unique_id(), 0, 1)
+    frames = torch.from_numpy(np.stack([amd.synth_frame(320, 240, i) for i in range(3)])).cuda()
+    res = ctx.extract_features(frames, keep_all_planes=False)
+    rows = sum(res.counts(i)[1] for i in range(3))
+    held = []
+    for _ in range(4):  # four results alive at once: more than the pool keeps
+        g = comm.gather_begin([res], rows + 8)
+        held.append(g.match_all_pairs(ctx))
+        g.free()
+    exp = {(q, j): ctx.descriptor_match(res.descriptors(q), res.descriptors(j), 10000, 0.86) for q in range(3) for j in range(3) if q != j}
+    for p in held[:3]:
+        p.free()            # two go to the pool, the third is destroyed
+    st2 = torch.cuda.Stream()
+    ctx2 = amd.Context(0, st2.cuda_stream)
+    g = comm.gather_begin([res], rows + 8)
+    p2 = g.match_all_pairs(ctx2)  # pooled buffers, last used on ctx's stream
+    for k, v in exp.items():
+        assert np.array_equal(p2.matches(*k), v), k
+    g.free()
+    last = held[3]
+    comm.close()            # `last` and `p2` are still held
+    for k, v in exp.items():
+        assert np.array_equal(last.matches(*k), v), k
+    last.free()
+    p2.free()
+    ctx2.close()
+    res.close()
+
+
 def test_all_pairs_while_extractions_are_in_flight(ctx, amd):
     """The matcher's side stream is the context's finish stream: an all-pairs step enqueued while two batches of the same
     context are being finished by its own thread (their keypoint kernels and copies go to that stream too) gives the lists

@@ -2,8 +2,11 @@
 // C++ or Rust host does before a cross-image brute-force match.
 //
 //   gather_selftest                       one rank on device 0
-//   gather_selftest RANK NRANKS ID_FILE   rank RANK of NRANKS, one process per GPU (device = RANK); rank 0 writes the
-//                                         128-byte communicator id to ID_FILE, the others wait for it
+//   gather_selftest RANK NRANKS ID_FILE [DEVICE]
+//                                         rank RANK of NRANKS, one process per GPU (device = RANK unless DEVICE is given: the
+//                                         one-GPU rehearsal of tests/test_comm_faults.py, whose stand-in for librccl carries
+//                                         the blocks between processes); rank 0 writes the 128-byte communicator id to
+//                                         ID_FILE, the others wait for it
 //
 // Every rank extracts frames of its shard (image i -> GPU i mod G), gathers the descriptor rows with the synchronous
 // form and with the pipelined form, and checks that (a) its own rows came back bit for bit in its slot of both
@@ -37,15 +40,17 @@
 int main(int argc, char** argv) {
     int rank = 0, nranks = 1;
     const char* id_file = nullptr;
-    if (argc == 4) {
+    int device_arg = -1;
+    if (argc == 4 || argc == 5) {
         rank = atoi(argv[1]);
         nranks = atoi(argv[2]);
         id_file = argv[3];
+        if (argc == 5) device_arg = atoi(argv[4]);
     } else if (argc != 1) {
-        fprintf(stderr, "usage: %s [RANK NRANKS ID_FILE]\n", argv[0]);
+        fprintf(stderr, "usage: %s [RANK NRANKS ID_FILE [DEVICE]]\n", argv[0]);
         return 2;
     }
-    const int device = rank;
+    const int device = device_arg >= 0 ? device_arg : rank;
     void* stream = nullptr;
     TRY(akz_stream_create(device, &stream));
     akz_ctx* ctx = nullptr;

@@ -3,6 +3,10 @@
 1920x1080 frames, one process per GPU, frames sharded one-per-GPU-slot across ranks.
 
     python bench.py --gpus N --steps K --warmup W [--frames F] [--width 1920 --height 1080]
+    python bench.py --gpus N --workload c5     (BASELINE configs[4]: 4K frames, 5 x 5, exchange + cross-GPU all-pairs match)
+
+The timed region of K steps is run --regions times (default 5) in one process; `value` / `ms_per_step` are the MEDIAN region
+(config.regions holds all of them): the pool's boxes differ by +-3 % from run to run, which is as much as a round's gain.
 
 With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks (children with
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; the parent never touches a GPU), forwards rank 0's JSON line and
@@ -93,14 +97,21 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     # (the first ~100 ms of a process run 2-3 % below the steady state -- clocks, buffer growth -- so the defaults warm
     # up for ten steps and time forty: 0.3 s in all)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step (C4: 256 frames / 8 GPUs)")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps per region (default 40; 8 with --workload c5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default 10; 3 with --workload c5)")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of --steps steps each, back to back in one process; the line reports the median region")
+    ap.add_argument("--workload", choices=["frames", "c5"], default="frames",
+                    help="frames: BASELINE configs[1]/[3] (1080p frames, 4 x 4, descriptor gather with N > 1) -- the headline; "
+                         "c5: BASELINE configs[4] -- 3840x2160 frames, 5 octaves x 5 sublevels, frame f on rank f mod N, descriptors "
+                         "stay on the device, exchange + all-pairs match (akz_gather_begin -> akz_match_all_pairs -> totals read) "
+                         "inside the timed step")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 32 = C4: 256 frames / 8 GPUs; 8 with --workload c5 = C5: 64 frames / 8 GPUs)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--lean", action="store_true", help="do not materialise Lxx/Lyy/Lxy/Lstep")
-    ap.add_argument("--sublevels", type=int, default=4)
-    ap.add_argument("--octaves", type=int, default=4)
+    ap.add_argument("--sublevels", type=int, default=None)
+    ap.add_argument("--octaves", type=int, default=None)
     ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one LDS-tiled kernel, 0 LDS-tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
     ap.add_argument("--eager", type=int, default=1, help="akz_ctx_set_eager_finish (the library's default: on): the finish half on the context's own thread")
@@ -131,6 +142,9 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", choices=["capi", "torch"], default="capi",
                     help="capi: akz_gather_begin/finish of the C ABI (own RCCL communicator, gloo only for rendezvous and "
                          "barriers); torch: torch.distributed all_gather on the nccl backend")
+    ap.add_argument("--match-ctx", choices=["shared", "own"], default="shared",
+                    help="--workload c5: the all-pairs launches on the extraction context's stream (shared) or on a context and "
+                         "stream of their own (own: they run beside the next steps' extraction kernels)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a ONE-GPU box: every rank runs on device 0 (real extraction ranks, "
                          "real rendezvous, capacity agreement and pipelined retire); the descriptor rows travel D2H -> gloo "
@@ -144,7 +158,14 @@ def parse_args(argv=None):
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test without a GPU: a stub context (sleeps, fake rows) and the gloo backend; the "
                          "line it prints says so and is not a measurement")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    c5 = args.workload == "c5"
+    for name, frames_default, c5_default in (("steps", 40, 8), ("warmup", 10, 3), ("frames", 32, 8), ("width", 1920, 3840),
+                                             ("height", 1080, 2160), ("sublevels", 4, 5), ("octaves", 4, 5)):
+        if getattr(args, name) is None:
+            setattr(args, name, c5_default if c5 else frames_default)
+    args.regions = max(1, args.regions)
+    return args
 
 
 # --------------------------------------------------------------------------------------------------
@@ -315,7 +336,7 @@ class _StubContext:
     def __init__(self, rank):
         self.rank = rank
 
-    def extract_begin(self, batch, cfg, keep_all_planes=True, input_ready=False):
+    def extract_begin(self, batch, cfg, keep_all_planes=True, input_ready=False, host_descriptors=True):
         return _StubJob([100 + 7 * self.rank + i for i in range(int(batch.shape[0]))])
 
     def set_eager_finish(self, *_):
@@ -352,8 +373,13 @@ def main_rank(args):
     import torch.distributed as dist
 
     stub = args.stub
-    use_dist = world > 1 or args.force_dist
-    exchange = "gloo-stub" if stub else ("gloo" if args.share_gpu else args.exchange)
+    c5 = args.workload == "c5"
+    use_dist = world > 1 or args.force_dist          # a process group exists (rendezvous, barriers, reductions)
+    use_xch = use_dist or c5                          # a step has an exchange (c5: also at N = 1, the all-pairs match reads gathered blocks)
+    # capi: RCCL behind the C ABI; external: the C ABI's blocks carried by gloo (--share-gpu: RCCL refuses two ranks on one device)
+    exchange = "gloo-stub" if stub else ("external" if args.share_gpu else args.exchange)
+    if c5 and (stub or exchange == "torch"):
+        raise SystemExit("--workload c5 runs through the C ABI (akz_gather_begin -> akz_match_all_pairs): not with --stub / --exchange torch")
     W, H, F = args.width, args.height, args.frames
     if F < 1:
         raise SystemExit(f"rank {rank}: --frames must be >= 1")
@@ -367,18 +393,29 @@ def main_rank(args):
         dev = torch.device("cuda", dev_index)
 
     if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # a rank that never arrives (a GPU that failed to initialise, a crashed peer) must not leave the others waiting
+        # for the default half hour: the rendezvous and every later collective of the group give up after five minutes
+        tmo = datetime.timedelta(seconds=int(os.environ.get("AKZ_BENCH_RENDEZVOUS_S", "300")))
         if exchange == "torch":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:  # rendezvous, barriers and the two scalar reductions need no GPU: gloo
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
 
     def host_max(v):
         if not use_dist:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=dev if exchange == "torch" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def host_sum(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev if exchange == "torch" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
     def host_allgather(v):
@@ -425,37 +462,56 @@ def main_rank(args):
     # the same batches in pinned host memory (the reference's extract_features starts from host data, lib.rs:171-178):
     # second timed region, upload of batch j+1 on the context's copy stream under the kernels of batch j
     h_batches = None
-    if not stub and not args.no_host_input:
+    if not stub and not args.no_host_input and not c5:
         h_frames = torch.from_numpy(frames).pin_memory()
         h_batches = [h_frames[cut[i]:cut[i + 1]] for i in range(NP)]
     frame_src = {"host": False}
 
     # ---- the exchange: one all-gather of descriptor rows per step, begun when the step's results exist, retired when
-    # the next step's results exist (or at the end of the timed region) ----
-    xch = {"host_ms": 0.0, "wait_ms": 0.0, "cap": 0, "pending": None, "comm": None, "mode": exchange if use_dist else "none",
-           "ranks_seen": None, "seq": 0}
-    if use_dist and exchange == "capi":
+    # the next step's results exist (or at the end of the timed region).  --workload c5: the all-pairs match of the step
+    # (akz_match_all_pairs over the gathered blocks) is enqueued right behind the exchange and its totals are read at
+    # retire time -- exchange, match and the read of the lists' counts are all inside the timed region ----
+    xch = {"host_ms": 0.0, "wait_ms": 0.0, "cap": 0, "pending": None, "comm": None, "mode": exchange if use_xch else "none",
+           "ranks_seen": None, "seq": 0, "lists": 0, "matches": 0, "dist": 0, "dist_sum": 0, "steps": 0}
+    if use_xch and exchange in ("capi", "external"):
         try:
-            uid = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(A.comm_unique_id()), dtype=torch.uint8).clone()
-            dist.broadcast(uid, src=0)
-            xch["comm"] = A.Comm(dev_index, bytes(uid.numpy().tobytes()), rank, world)
+            if exchange == "external":
+                xch["comm"] = A.Comm(dev_index, None, rank, world)
+            else:
+                uid = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8)
+                if rank == 0:
+                    uid = torch.frombuffer(bytearray(A.comm_unique_id()), dtype=torch.uint8).clone()
+                if use_dist:
+                    dist.broadcast(uid, src=0)
+                xch["comm"] = A.Comm(dev_index, bytes(uid.numpy().tobytes()), rank, world)
             # the collective of a step runs beside the next batch's kernels: its streams go where the context's busy ones are not
             xch["comm"].place_streams(ctx)
             ok = 1.0
-        except Exception as e:  # RCCL cannot be loaded / initialised: fall back to torch.distributed on every rank
-            sys.stderr.write(f"rank {rank}: C-ABI exchange unavailable ({e}); falling back to torch.distributed\n")
+        except Exception as e:  # RCCL cannot be loaded / initialised
+            sys.stderr.write(f"rank {rank}: C-ABI exchange unavailable ({e})\n")
             ok = 0.0
-        if -host_max(-ok) < 0.5:  # min over ranks
+        if -host_max(-ok) < 0.5:  # min over ranks: every rank takes the same fallback
             if xch["comm"] is not None:
                 xch["comm"].close()
                 xch["comm"] = None
-            xch["mode"] = exchange = "torch"
-            xch["group"] = dist.new_group(backend="nccl")
+            if c5:
+                # the all-pairs match needs the C ABI's gather objects: the blocks travel over the process group instead
+                sys.stderr.write(f"rank {rank}: falling back to the caller-carried transport (akz_comm_create_external over the process group)\n")
+                xch["mode"] = exchange = "external"
+                xch["comm"] = A.Comm(dev_index, None, rank, world)
+            else:
+                sys.stderr.write(f"rank {rank}: falling back to torch.distributed\n")
+                xch["mode"] = exchange = "torch"
+                xch["group"] = dist.new_group(backend="nccl")
     if use_dist and exchange == "torch" and "group" not in xch:
         xch["group"] = None
     side = None if stub or not use_dist else torch.cuda.Stream(dev)  # torch collectives run here, never on the extraction stream
+    # --match-ctx own: the all-pairs launches of a step on a context (stream, scratch) of their own, beside the next steps'
+    # extraction kernels (matrix cores beside HBM-bound stencils) instead of in line with them on the extraction stream
+    match_ctx = ctx
+    if c5 and args.match_ctx == "own":
+        match_stream = torch.cuda.Stream(dev)
+        match_ctx = A.Context(dev_index, match_stream.cuda_stream)
 
     def agree_capacity(rows):
         most = int(host_max(float(rows)))
@@ -466,19 +522,19 @@ def main_rank(args):
         if g is None:
             return
         t0 = time.perf_counter()
-        if exchange == "capi":
-            _, _, cnts_r, imgs_r = g.finish(want_counts=True)  # the headers of all blocks: who took part
+        if exchange in ("capi", "external"):
+            gth, pr = g
+            if pr is not None:
+                xch["lists"], xch["matches"], xch["dist"] = pr.totals()  # waits for the step's launches, reads every list's count
+                xch["dist_sum"] += xch["dist"]
+                xch["steps"] += 1
+                pr.free()
+            _, _, cnts_r, imgs_r = gth.finish(want_counts=True)  # the headers of all blocks: who took part
             xch["ranks_seen"] = sum(1 for v in imgs_r if v > 0)
-            g.free()
+            gth.free()
         elif exchange == "torch":
             g[0].synchronize()  # event behind the collectives on the side stream
             xch["ranks_seen"] = int((g[1] > 0).sum().item())
-        elif exchange == "gloo":
-            work, gathered_h, gathered_d, seq = g
-            work.wait()
-            gathered_d.copy_(gathered_h, non_blocking=True)  # H2D: where a following match would read the rows
-            hdr = gathered_h.view(world, -1, 64)[:, 0, :].contiguous().view(torch.int64)  # row 0 of every block
-            xch["ranks_seen"] = int(((hdr[:, 1] > 0) & (hdr[:, 3] == seq) & (hdr[:, 2] == xch["cap"])).sum().item())
         xch["wait_ms"] += (time.perf_counter() - t0) * 1e3
         xch["pending"] = None
 
@@ -490,10 +546,16 @@ def main_rank(args):
             agree_capacity(rows)
         if rows > xch["cap"]:
             raise SystemExit(f"rank {rank}: {rows} descriptor rows exceed the agreed gather capacity {xch['cap']}")
-        exchange_retire()  # step k-1's gather: long complete
+        exchange_retire()  # step k-1's gather (and all-pairs match): long complete
         t0 = time.perf_counter()
-        if exchange == "capi":
-            xch["pending"] = xch["comm"].gather_begin(results, xch["cap"])
+        if exchange in ("capi", "external"):
+            gth = xch["comm"].gather_begin(results, xch["cap"])
+            if exchange == "external":
+                # the C ABI's wire format over the process group: this rank's block D2H, one gloo all-gather of the
+                # fixed-size blocks, H2D into the gather's receive blocks, akz_gather_deliver (synchronous)
+                gth.exchange_over()
+            pr = gth.match_all_pairs(match_ctx) if c5 else None  # enqueues and returns
+            xch["pending"] = (gth, pr)
         elif exchange == "torch":
             cap = xch["cap"]
             if "bufs" not in xch:  # two sets of preallocated buffers: step k's collective may still run while k+1 fills
@@ -514,26 +576,6 @@ def main_rank(args):
                 ev = torch.cuda.Event()
                 ev.record(side)
             xch["pending"] = (ev, cnts)
-        elif exchange == "gloo":
-            # --share-gpu rehearsal: the wire format of the C ABI (header row + rows, fixed capacity) over the host
-            cap = xch["cap"]
-            if "bufs" not in xch:
-                xch["bufs"] = [(torch.zeros((1 + cap, 64), dtype=torch.uint8, device=dev),
-                                torch.zeros((1 + cap, 64), dtype=torch.uint8).pin_memory(),
-                                torch.empty((world * (1 + cap), 64), dtype=torch.uint8).pin_memory(),
-                                torch.empty((world * (1 + cap), 64), dtype=torch.uint8, device=dev)) for _ in range(2)]
-                xch["flip"] = 0
-            local_d, local_h, gathered_h, gathered_d = xch["bufs"][xch["flip"]]
-            xch["flip"] ^= 1
-            o = 1
-            for res in results:
-                o += res.copy_device_descriptors(local_d[o:])
-            xch["seq"] += 1
-            n_img = sum(res.num_images for res in results)
-            local_h.copy_(local_d)  # D2H (synchronous: the rows are complete)
-            local_h[0].view(torch.int64)[:4] = torch.tensor([rows, n_img, cap, xch["seq"]], dtype=torch.int64)
-            work = dist.all_gather_into_tensor(gathered_h, local_h, async_op=True)
-            xch["pending"] = (work, gathered_h, gathered_d, xch["seq"])
         xch["host_ms"] += (time.perf_counter() - t0) * 1e3
 
     if stub:
@@ -564,7 +606,7 @@ def main_rank(args):
             done.append(res)
             if len(done) == NP:  # a whole step has finished
                 nk = sum(r.counts(i)[1] for r in done for i in range(r.num_images))
-                if use_dist:
+                if use_xch:
                     exchange_begin(done)
                 steps_done += 1
                 if keep_final and steps_done == k_steps:
@@ -581,7 +623,9 @@ def main_rank(args):
                     job = ctx.extract_begin_host(h_batches[bi], cfg, keep_all_planes=not args.lean)
                 else:
                     # (the frames were uploaded and synchronised before the first step: AKZ_INPUT_READY holds)
-                    job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean, input_ready=not args.no_input_ready)
+                    # (c5: the descriptor rows stay on the device -- the exchange and the matcher read them there)
+                    job = ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean, input_ready=not args.no_input_ready,
+                                            host_descriptors=not c5)
                 host_ms["begin"] += (time.perf_counter() - tb) * 1e3
                 host_ms["calls"] += 1
                 if args.sync:
@@ -595,8 +639,8 @@ def main_rank(args):
                     retire(res)
         while inflight:
             retire(inflight.pop(0).finish())
-        if use_dist:
-            exchange_retire()  # the last step's gather completes inside the timed region
+        if use_xch:
+            exchange_retire()  # the last step's gather (and all-pairs match) completes inside the timed region
         return nk
 
     def barrier():
@@ -616,22 +660,33 @@ def main_rank(args):
     run_steps(1)
     warm_prof = ctx.get_profile(reset=True)
     ctx.set_profiling(0 if args.no_profile else 2)
-    want_check = not stub and ((rank == 0 and not args.no_self_check) or use_dist or F <= 4)
-    barrier()
-    t0 = time.perf_counter()
+    want_check = not stub and not c5 and ((rank == 0 and not args.no_self_check) or use_dist or F <= 4)
+    # The timed region -- exactly args.steps steps between two barriers -- is run args.regions times back to back; the
+    # line reports the MEDIAN region (max over ranks per region) and lists them all: one 0.2 s region per run cannot
+    # resolve a 2 % change on boxes that differ by 3 % from run to run.
     xch["host_ms"] = xch["wait_ms"] = 0.0
+    xch["dist_sum"], xch["steps"] = 0, 0
     host_ms.update(begin=0.0, finish=0.0, calls=0)
-    nk = run_steps(args.steps, keep_final=want_check)
-    barrier()
-    elapsed_rank = time.perf_counter() - t0
-    prof = ctx.get_profile(reset=True)
+    regions = []  # (elapsed max over ranks, this rank's elapsed)
+    for reg in range(args.regions):
+        barrier()
+        t0 = time.perf_counter()
+        nk = run_steps(args.steps, keep_final=want_check and reg == args.regions - 1)
+        barrier()
+        el = time.perf_counter() - t0
+        regions.append((host_max(el), el))
+    prof = ctx.get_profile(reset=True)  # spans of ALL regions: the rooflines average over args.regions * args.steps steps
     ctx.set_profiling(False)
-    host_ms_timed = dict(host_ms)  # the accumulators go on counting in the host-input leg below: the line reports THIS region
-    elapsed = host_max(elapsed_rank)
+    timed_steps = args.steps * args.regions
+    host_ms_timed = dict(host_ms)  # the accumulators go on counting in the host-input leg below: the line reports the timed regions
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    med = order[(len(order) - 1) // 2]   # the median region (the lower one of an even count: a run that happened)
+    elapsed, elapsed_rank = regions[med]
     per_rank_s = host_allgather(elapsed_rank)
 
     total_px = float(W) * H * F * world * args.steps
     value = total_px / elapsed / 1e6
+    region_values = [round(total_px / r[0] / 1e6, 1) for r in regions]
 
     # ---- the same steps with the frames in pinned HOST memory, H2D inside the timed region (informational: `value`
     # stays the HBM-resident figure the bench contract asks for) ----
@@ -640,11 +695,14 @@ def main_rank(args):
         ctx.set_profiling(0)
         frame_src["host"] = True
         run_steps(min(3, max(1, args.warmup)))
-        barrier()
-        t0 = time.perf_counter()
-        nk_h = run_steps(args.steps)
-        barrier()
-        el_h = host_max(time.perf_counter() - t0)
+        els = []
+        for _ in range(min(3, args.regions)):
+            barrier()
+            t0 = time.perf_counter()
+            nk_h = run_steps(args.steps)
+            barrier()
+            els.append(host_max(time.perf_counter() - t0))
+        el_h = sorted(els)[(len(els) - 1) // 2]
         frame_src["host"] = False
         v_h = total_px / el_h / 1e6
         host_input = {"value": round(v_h, 2), "unit": "Mpix/s", "ms_per_step": round(el_h / max(1, args.steps) * 1e3, 3),
@@ -661,7 +719,8 @@ def main_rank(args):
                 "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "stub", "stub": True,
                 "config": {"workload": "stub", "frames_per_gpu": F, "exchange": "gloo all-gather of fake rows",
-                           "exchange_ms_per_step": round(xch["host_ms"] / max(1, args.steps), 3),
+                           "exchange_ms_per_step": round(xch["host_ms"] / max(1, timed_steps), 3),
+                           "regions": {"n": args.regions, "reported": "median"},
                            "per_rank_ms_per_step": [round(s / max(1, args.steps) * 1e3, 3) for s in per_rank_s]}}), file=json_out, flush=True)
         if use_dist:
             dist.barrier()
@@ -682,7 +741,7 @@ def main_rank(args):
                "traffic_frac": round(tr / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if tr and avg_us > 0 else None,
                "launches": launches, "avg_launch_us": round(avg_us, 2),
                "algorithmic_bytes_per_launch": round(alg_bytes / max(1, launches)),
-               "ms_per_step": round(ms / max(1, args.steps), 3), "note": note}
+               "ms_per_step": round(ms / max(1, timed_steps), 3), "note": note}
         return out
 
     det_bpp = 4 + 8 + 4 + (0 if args.lean else 12)  # Lsmooth in; Lx, Ly, Ldet (+ Lxx, Lyy, Lxy) out: each once
@@ -706,7 +765,7 @@ def main_rank(args):
 
     # ---- the FED kernel alone: 3840x2160 plane (north-star target point) and a 32 x 1080p level (HBM-resident) ----
     fed_alone = None
-    if rank == 0 and world == 1 and not args.no_fed4k:  # N = 1 information
+    if rank == 0 and world == 1 and not args.no_fed4k and not c5:  # N = 1 information
         fed_alone = {}
         for name, shape, nst in (("4k_plane", (2160, 3840), 40), ("level_32x1080p", (32, 1080, 1920), 8)):
             lt = torch.rand(shape, dtype=torch.float32, device=dev)
@@ -737,7 +796,7 @@ def main_rank(args):
     # re-reads the plane it read last time finds most of it in the 256 MB Infinity Cache and looks 25 % faster than any
     # launch of the pyramid, where every level's Lsmooth was written long before) ----
     det_alone = None
-    if rank == 0 and world == 1 and not args.no_fed4k and not args.lean:
+    if rank == 0 and world == 1 and not args.no_fed4k and not args.lean and not c5:
         n_, h_, w_ = 32, 1080, 1920
         pb = n_ * h_ * w_ * 4
         big = torch.empty(4 * 7 * pb + (1 << 21), dtype=torch.uint8, device=dev)  # carved like the product's slab
@@ -819,7 +878,7 @@ def main_rank(args):
 
     # ---- the matcher (BASELINE configs[2] / [4]: Hamming match of two descriptor sets), untimed leg, rank 0 ------
     match_leg = None
-    if rank == 0 and world == 1 and not args.no_match:  # N = 1 information; the scaling runs only need `value`
+    if rank == 0 and world == 1 and not args.no_match and not c5:  # N = 1 information; the scaling runs only need `value`
         g = torch.Generator(device=dev).manual_seed(7)
         legs = []
         for n_m in (11264, 65536):  # a 4K frame's keypoint count; a gathered multi-frame set
@@ -868,7 +927,7 @@ def main_rank(args):
 
     # ---- BASELINE configs[2] and configs[4] end to end (extra legs, rank 0, own clocks) --------------------------------
     c3_leg = c5_leg = None
-    if rank == 0 and world == 1 and not args.no_match:
+    if rank == 0 and world == 1 and not args.no_match and not c5:
         ctx.set_profiling(0)
         # configs[2]: a 3840x2160 pair -- ONE extract call on the two-frame batch (host frames, descriptors back on the
         # host) + match_features with its reference signature (descriptor_match on the GPU, RANSAC filter on the host)
@@ -969,7 +1028,7 @@ def main_rank(args):
 
     # ---- BASELINE configs[1] taken literally: ONE frame per extract call (untimed extra leg, rank 0) -----------
     single = None
-    if rank == 0 and world == 1 and not args.no_single:
+    if rank == 0 and world == 1 and not args.no_single and not c5:
         ctx.set_profiling(0)
         one = d_frames[:1]
         for _ in range(10):
@@ -1083,7 +1142,7 @@ def main_rank(args):
     # as its thread budget; this process is idle meanwhile.  The host half of a batch (candidate
     # bucketing, keypoint selection, libm) must still hide under the next batch's kernels. ----
     host_share_leg = None
-    if rank == 0 and world == 1 and not args.no_host_share_leg and not args.host_share and not stub:
+    if rank == 0 and world == 1 and not args.no_host_share_leg and not args.host_share and not stub and not c5:
         try:
             torch.cuda.synchronize()
             cmd = [sys.executable, os.path.abspath(__file__), "--host-share", "8", "--steps", str(min(args.steps, 20)),
@@ -1100,17 +1159,74 @@ def main_rank(args):
         except Exception as e:
             host_share_leg = {"error": str(e)[:200]}
 
+    # ---- --workload c5: what the job matched, and an untimed check of sampled pairs against the pairwise matcher ----
+    c5_info = None
+    if c5:
+        steps_seen = max(1, xch["steps"])
+        dist_job = host_sum(float(xch["dist_sum"]) / steps_seen)       # descriptor pairs whose distance a step forms, all ranks
+        lists_all = host_allgather(float(xch["lists"]))
+        matches_job = host_sum(float(xch["matches"]))
+        # one more step, synchronously, keeping the gather and the pairs object
+        ress = [ctx.extract_begin(bt, cfg, keep_all_planes=not args.lean, host_descriptors=False).finish() for bt in batches]
+        gth = xch["comm"].gather_begin(ress, xch["cap"])
+        if exchange == "external":
+            gth.exchange_over()
+        for r_ in ress:
+            r_.close()
+        pr = gth.match_all_pairs(match_ctx)
+        base, block_rows, cnts_c, imgs_c = gth.finish()
+        table = []
+        for r_ in range(world):
+            o = 0
+            for n_ in gth.image_rows(r_):
+                table.append((r_, o, n_))
+                o += n_
+
+        def rows_of(i):
+            r_, o, n_ = table[i]
+            t = torch.zeros((max(n_, 1), 64), dtype=torch.uint8, device=dev)
+            if n_:
+                A.copy_d2d(t.data_ptr(), base + ((r_ * block_rows + 1 + o) * 64), n_ * 64)
+            return t[:n_]
+        held = [(a, b) for (a, b) in pr.held(rank) if a < b]
+        picks = held[:: max(1, len(held) // 3)][:3]
+        ok_pairs = True
+        for a, b in picks:
+            ta, tb = rows_of(a), rows_of(b)
+            for q, j, tq, tj in ((a, b, ta, tb), (b, a, tb, ta)):
+                m_t, m_n = ctx.descriptor_match_device(tq, tj)
+                torch.cuda.synchronize()
+                exp = m_t[:int(m_n.item())].cpu().numpy().view(A.MATCH_DTYPE).reshape(-1)
+                ok_pairs = ok_pairs and np.array_equal(pr.matches(q, j), exp)
+        every = sorted((a, b) for a in range(pr.n_images) for b in range(pr.n_images) if a != b)
+        holders_ok = all(0 <= pr.holder(a, b) < world for a, b in every[:: max(1, len(every) // 64)])
+        n_images = pr.n_images
+        pr.free()
+        gth.free()
+        ok_all = host_sum(0.0 if (ok_pairs and holders_ok) else 1.0) == 0.0
+        c5_info = {"images_per_step": n_images, "unordered_image_pairs_per_step": n_images * (n_images - 1) // 2,
+                   "descriptor_pairs_per_step": int(dist_job),
+                   "Tdistances_per_s": round(dist_job * args.steps / elapsed / 1e12, 3),
+                   "match_lists_held_per_rank": [int(v) for v in lists_all],
+                   "matches_per_step": int(matches_job),
+                   "pairs_check": {"sampled_pairs_per_rank": len(picks), "both_directions_equal_descriptor_match": bool(ok_all)},
+                   "match_context": args.match_ctx}
+        if not ok_all:
+            raise SystemExit("bench.py --workload c5: a sampled pair's lists differ from akz_descriptor_match_device of the pair")
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import akaze_ref as R
         cores = effective_cpus()  # affinity mask and cgroup quota, not the machine's core count
-        n_sample = 8  # ~2.5 s of host work on the GPU box (32 frames give the same figure in 10 s)
+        cfg_ref = R.default_config()
+        cfg_ref.num_sublevels, cfg_ref.max_octave_evolution = args.sublevels, args.octaves
+        n_sample = 2 if c5 else 8  # ~2.5 s of host work on the GPU box (32 frames give the same figure in 10 s)
         t1 = time.perf_counter()
         kp_ref = 0
         for i in range(n_sample):
-            r = R.extract(frames[i % F], threads=cores)
+            r = R.extract(frames[i % F], cfg=cfg_ref, threads=cores)
             kp_ref += r.num_keypoints
             r.close()
         dt = time.perf_counter() - t1
@@ -1145,24 +1261,43 @@ def main_rank(args):
                               "frac": round(b / 1e9 / (stage_t[k] * 1e-3) / HBM_PEAK_GBS, 3)}
                           for k, b in stage_bytes.items() if stage_t[k] > 0}
         steps = max(1, args.steps)
-        whole = sum(stage_bytes.values())  # 575.8 B per input pixel at 4 x 4 with all planes kept
+        # THE whole-path byte model is SURVEY.md 8(d)'s: level 0 60 B/px; a level that continues its octave 64 + 12 n_l; the first
+        # level of an octave 76 + 12 n_l (n_l diffusion steps) -- 575.8 B per input pixel at 4 x 4, 704.3 at 5 x 5, all planes kept
+        whole = sum((60 if i == 0 else (76 if half[i] else 64) + 12 * len(lv[i]["tau"])) * px[i] for i in range(len(lv)))
         whole_gbs = whole / 1e9 / (elapsed / steps) if world == 1 else None
-        stage_roofline["whole_path"] = {"algorithmic_GB": round(whole / 1e9, 3),
+        stage_sum = sum(stage_bytes.values())
+        stage_roofline["whole_path"] = {"model": "SURVEY.md 8(d)", "algorithmic_GB": round(whole / 1e9, 3),
                                         "B_per_input_pixel": round(whole / (float(W) * H * F), 1),
                                         "achieved_GBps": round(whole_gbs, 1) if whole_gbs else None,
                                         "frac": round(whole_gbs / HBM_PEAK_GBS, 3) if whole_gbs else None,
-                                        "note": "all stages' algorithmic bytes / the timed step (pipelined, keypoint kernels included)"}
+                                        "stage_sum_B_per_input_pixel": round(stage_sum / (float(W) * H * F), 1),
+                                        "note": "SURVEY.md 8(d)'s bytes per input pixel x the step's pixels / the timed step (pipelined, keypoint "
+                                                "kernels included).  The model counts every diffusion step as a pass over HBM and the "
+                                                "derivative planes as written and read again: the kernels here fuse both, so the path can sit "
+                                                "above 'its' roofline -- the DRAM figure is roofline.traffic_frac and profiles/*_pmc_per_kernel.txt.  "
+                                                "stage_sum_B_per_input_pixel is the sum of the per-stage rows above (each stage's own inputs and "
+                                                "outputs once), a smaller model kept for the per-stage fractions only"}
         out = {
-            "metric": f"Mpix/s through extract_features ({args.octaves} oct x {args.sublevels} sub)",
+            "metric": f"Mpix/s through extract_features ({args.octaves} oct x {args.sublevels} sub)" +
+                      (" + exchange + cross-GPU all-pairs match" if c5 else ""),
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             **({"rehearsal": "all ranks share ONE GPU (--share-gpu): a functional run of the N > 1 path, not a scaling number"}
                if args.share_gpu else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
-                                   f"({args.octaves} octaves x {args.sublevels} sublevels, 486-bit M-LDB), {F} frames per GPU per step "
-                                   "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)",
+            "config": {"workload": (f"BASELINE configs[4]: {W}x{H} synthetic 8-bit luma frames resident in HBM, {args.octaves} octaves x "
+                                    f"{args.sublevels} sublevels, 486-bit M-LDB, {F} frames per GPU per step (frame f on rank f mod N), "
+                                    "descriptor rows stay on the device; per step: extraction, exchange of the rows (akz_gather_begin), "
+                                    "all-pairs match of every frame of the job against every other (akz_match_all_pairs: every unordered "
+                                    "pair once, both directions, on the rank that owns its lead frame), totals of all held lists read")
+                                   if c5 else
+                                   (f"{W}x{H} synthetic 8-bit luma frames resident in HBM, Config::default() "
+                                    f"({args.octaves} octaves x {args.sublevels} sublevels, 486-bit M-LDB), {F} frames per GPU per step "
+                                    "(BASELINE configs[1] frame shape; configs[3] sharding: one image per GPU slot)"),
+                       "regions": {"n": args.regions, "reported": "median", "Mpix_s": region_values,
+                                   "min": min(region_values), "max": max(region_values)},
+                       "all_pairs": c5_info,
                        "frames_per_gpu": F, "width": W, "height": H, "batches_per_step": NP,
                        "pipelining": f"begin(batch j+{args.depth}) before finish(batch j) on one context, across steps" + (", finish half on the context's own thread" if args.eager else ""),
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
@@ -1174,15 +1309,16 @@ def main_rank(args):
                        "share_gpu": bool(args.share_gpu),
                        "frame_sha256_16": frame_sha,
                        "host_share_8ranks_Mpix_s": host_share_leg,
-                       "exchange": {"gloo": "--share-gpu rehearsal: every rank on device 0; descriptor rows D2H -> gloo all-gather "
-                                            "(C-ABI wire format) -> H2D, retired one step later",
+                       "exchange": {"external": "the C ABI's blocks carried by the caller (akz_comm_create_external: akz_gather_begin -> block "
+                                                "D2H -> gloo all-gather -> H2D -> akz_gather_deliver): --share-gpu rehearsal with every rank "
+                                                "on device 0, or the fallback when RCCL cannot be initialised",
                                     "capi": "RCCL all-gather of descriptor rows through the C ABI (akz_gather_begin / _finish), "
                                             "one fixed-size collective per step, retired one step later",
                                     "torch": "RCCL all-gather of descriptor rows through torch.distributed, retired one step later",
                                     "none": "none (1 GPU)"}[xch["mode"]],
-                       "exchange_ms_per_step": round((xch["host_ms"] + xch["wait_ms"]) / steps, 3),
-                       "exchange_host_ms_in_begin_per_step": round(xch["host_ms"] / steps, 3),
-                       "exchange_host_ms_waiting_per_step": round(xch["wait_ms"] / steps, 3),
+                       "exchange_ms_per_step": round((xch["host_ms"] + xch["wait_ms"]) / timed_steps, 3),
+                       "exchange_host_ms_in_begin_per_step": round(xch["host_ms"] / timed_steps, 3),
+                       "exchange_host_ms_waiting_per_step": round(xch["wait_ms"] / timed_steps, 3),
                        "per_rank_Mpix_s": [round(float(W) * H * F * args.steps / s / 1e6, 1) for s in per_rank_s],
                        "keypoints_per_step_rank0": nk,
                        "host_ms_in_begin_per_batch": round(host_ms_timed["begin"] / max(1, host_ms_timed["calls"]), 3),
@@ -1204,8 +1340,9 @@ def main_rank(args):
         print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()  # rank 0 may still be in its untimed extra legs: all ranks leave together
-        if xch["comm"] is not None:
-            xch["comm"].close()
+    if xch["comm"] is not None:
+        xch["comm"].close()
+    if use_dist:
         dist.destroy_process_group()
     return 0
 

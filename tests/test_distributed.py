@@ -1,5 +1,8 @@
 """world_size-2 tests of the multi-GPU logic on CPU (gloo): per-image sharding and the descriptor-row
-all-gather that precedes a cross-image match.  The same code runs over RCCL on the GPUs."""
+all-gather that precedes a cross-image match, as the Python helpers `akaze_amd.gather_descriptor_rows` / `all_pairs_match`
+(torch.distributed) do them.  The PRODUCT's exchange is `akz_comm.cpp` behind the C ABI (its own RCCL communicator, or a
+caller-carried transport): that one needs a device and is driven by tests/test_gpu_gather.py -- two and three real ranks on
+one GPU with the C ABI's blocks over gloo -- and by tests/test_comm_faults.py against a stub librccl."""
 import os
 import socket
 import sys

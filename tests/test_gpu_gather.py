@@ -117,6 +117,63 @@ def test_all_pairs_steps_of_different_sizes(ctx, amd):
     comm.close()
 
 
+@pytest.mark.parametrize("world,per", [(2, 3), (3, 2)])
+def test_all_pairs_ranks_sharing_one_gpu(tmp_path, world, per):
+    """BASELINE configs[4] with MORE THAN ONE rank, on the hardware there is: `world` real ranks on device 0 (tests/c5_rank.py),
+    frame f on rank f mod world, the C ABI's blocks carried over gloo (akz_comm_create_external), akz_match_all_pairs on every
+    rank.  Each rank checks every list it holds against akz_descriptor_match of the pair; here: every ORDERED pair of the job is
+    held by exactly one rank, both directions of a pair by the same one, and the work is spread over the ranks."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "c5_rank.py"), str(r), str(world), str(port), str(tmp_path), str(per)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=420)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    n_job = world * per
+    seen = {}
+    for r in range(world):
+        d = json.load(open(tmp_path / f"held_{r}.json"))
+        assert d["frames"] == list(range(r, n_job, world))
+        for a, b, n in d["held"]:
+            assert (a, b) not in seen, (a, b)
+            seen[(a, b)] = r
+    assert sorted(seen) == [(a, b) for a in range(n_job) for b in range(n_job) if a != b]
+    assert all(seen[(a, b)] == seen[(b, a)] for a, b in seen)
+    per_rank = [sum(1 for v in seen.values() if v == r) for r in range(world)]
+    assert min(per_rank) > 0 and max(per_rank) <= 2 * min(per_rank) + 2, per_rank
+
+
+def test_bench_c5_workload_two_ranks_sharing_one_gpu():
+    """`bench.py --gpus 2 --share-gpu --workload c5`: the configs[4] step (extraction, exchange, all-pairs match, totals read)
+    with two ranks, reduced frame size; the line carries the job's pairs, the lists held per rank and the sampled check."""
+    two = _bench_json(["--gpus", "2", "--share-gpu", "--workload", "c5", "--frames", "2", "--width", "1280", "--height", "720",
+                       "--steps", "2", "--warmup", "1", "--regions", "2", "--no-cpu-baseline"])
+    ap = two["config"]["all_pairs"]
+    assert two["n_gpus"] == 2 and "all-pairs" in two["metric"] and two["config"]["exchange_ranks_seen"] == 2
+    assert ap["images_per_step"] == 4 and ap["unordered_image_pairs_per_step"] == 6
+    assert sum(ap["match_lists_held_per_rank"]) == 12 and min(ap["match_lists_held_per_rank"]) > 0
+    assert ap["pairs_check"]["both_directions_equal_descriptor_match"] is True and ap["descriptor_pairs_per_step"] > 0
+    assert two["config"]["regions"]["n"] == 2 and len(two["config"]["regions"]["Mpix_s"]) == 2
+    one = _bench_json(["--gpus", "1", "--workload", "c5", "--frames", "4", "--width", "1280", "--height", "720",
+                       "--steps", "2", "--warmup", "1", "--regions", "2", "--no-cpu-baseline"])
+    assert one["config"]["all_pairs"]["descriptor_pairs_per_step"] == ap["descriptor_pairs_per_step"]
+    assert one["config"]["all_pairs"]["matches_per_step"] == ap["matches_per_step"]
+
+
 def test_pairs_outlive_their_communicator(ctx, amd):
     """Lifetime rule of akz_pairs (include/akaze_hip.h): a result that is still held when its communicator is destroyed
     stays readable and is freed afterwards without touching the communicator (round-4 advice: akz_pairs_free pushed the
@@ -204,7 +261,7 @@ def _bench_json(extra, timeout=900):
     import json
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--regions", "2", "--no-cpu-baseline",
                         "--no-fed4k", "--no-single", "--no-match", "--no-host-share-leg", "--width", "960", "--height", "540"] + extra,
                        env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]

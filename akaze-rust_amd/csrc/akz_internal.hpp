@@ -68,6 +68,11 @@ hipStream_t match_side_stream(akz_ctx* c);
 // streams of another component that run beside a context's: each slot ends up on a hardware queue and a pipe that the
 // context's caller, coarse and finish streams do not use (a colliding stream is destroyed and replaced) -- akz_api.cpp
 int place_streams_beside(akz_ctx* c, hipStream_t* slots, int n_slots, int* still_shared);
+// what the stream-placement probe concludes from its timings (akz_api.cpp; akz_debug_placement_verdict for the tests):
+// spin_pair_ms = two spins of spin_ms on two streams, first start to second end; tiny_pair_ms = 24 + 24 interleaved tiny
+// kernels on two streams (negative: not measured); tiny_alone_ms = 24 of them on one stream
+enum { kPlaceQueue = 1, kPlacePipe = 2, kPlaceAmbiguous = 4 };
+int placement_verdict(float spin_pair_ms, float tiny_pair_ms, float tiny_alone_ms, float spin_ms);
 
 // ---- host-side planning (akz_plan.cpp) ---------------------------------------------------
 struct LevelPlan {

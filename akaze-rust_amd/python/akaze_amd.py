@@ -63,12 +63,17 @@ STAGES = ["blur0", "contrast", "prep", "fed", "detector", "nms", "host_kp", "ori
 
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 10), ("fed_launches", C.c_uint64), ("fed_px_steps", C.c_uint64),
-                ("calls", C.c_uint64), ("pixels", C.c_uint64), ("det_launches", C.c_uint64), ("det_px", C.c_uint64), ("fused_px", C.c_uint64)]
+                ("calls", C.c_uint64), ("pixels", C.c_uint64), ("det_launches", C.c_uint64), ("det_px", C.c_uint64), ("fused_px", C.c_uint64),
+                ("placement_probed", C.c_uint32), ("placement_early_stages", C.c_uint32), ("placement_replaced", C.c_uint32),
+                ("placement_shared", C.c_uint32), ("placement_retries", C.c_uint32), ("placement_reserved", C.c_uint32)]
 
     def as_dict(self):
         d = {k: self.ms[i] for i, k in enumerate(STAGES)}
         d.update(fed_launches=self.fed_launches, fed_px_steps=self.fed_px_steps, calls=self.calls,
-                 pixels=self.pixels, det_launches=self.det_launches, det_px=self.det_px, fused_px=self.fused_px)
+                 pixels=self.pixels, det_launches=self.det_launches, det_px=self.det_px, fused_px=self.fused_px,
+                 placement={"probed": bool(self.placement_probed), "early_stages_on": "copy stream" if self.placement_early_stages == 2 else "caller's stream",
+                            "streams_replaced": self.placement_replaced, "streams_still_shared": self.placement_shared,
+                            "measurements_repeated": self.placement_retries})
         return d
 
 
@@ -198,6 +203,8 @@ def lib():
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
+        "akz_ctx_warmup": ([vp], i32),
+        "akz_debug_placement_verdict": ([C.c_float, C.c_float, C.c_float, C.c_float], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
         "akz_comm_unique_id": ([vp], i32),
         "akz_comm_create": ([i32, vp, i32, i32, C.POINTER(vp)], i32),
@@ -380,6 +387,10 @@ class Context:
         """Level preparation: 2 = automatic (default: fused with the first diffusion steps for large launches), 3 = fused
         wherever supported, 1 = streaming kernel, 0 = LDS-tiled kernel."""
         _check(lib().akz_ctx_set_prep_mode(self._h, int(mode)))
+
+    def warmup(self):
+        """akz_ctx_warmup: the stream-placement probe now (idle streams, no capture) instead of inside the first large batch."""
+        _check(lib().akz_ctx_warmup(self._h))
 
     def set_profiling(self, on=True):
         """0/False off, 1/True every stage, 2 light (FED spans + host-clock stages only)."""

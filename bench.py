@@ -456,6 +456,9 @@ def main_rank(args):
         ctx.set_prep_mode(args.prep_mode)
         if args.sort != "auto":
             ctx.debug_set_host_sort(args.sort == "host")
+        # the stream-placement probe now, on idle streams, instead of inside the first large extract_begin (which then
+        # stays asynchronous); config.stream_placement says what it found
+        ctx.warmup()
     NP = max(1, min(args.parts, F))
     cut = [(F * i) // NP for i in range(NP + 1)]
     batches = [d_frames[cut[i]:cut[i + 1]] for i in range(NP)]
@@ -1302,7 +1305,7 @@ def main_rank(args):
                        "pipelining": f"begin(batch j+{args.depth}) before finish(batch j) on one context, across steps" + (", finish half on the context's own thread" if args.eager else ""),
                        "planes": "lean" if args.lean else "all 10 EvolutionStep planes materialised",
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "stream_placement": ctx.debug_stream_placement(),
+                       "stream_placement": ctx.get_profile(reset=False)["placement"],
                        "input_ready_flag": not args.no_input_ready,
                        "exchange_ranks_seen": xch["ranks_seen"],
                        "placement": placement or None,

@@ -484,11 +484,23 @@ typedef struct akz_profile {
     uint64_t det_launches;   /* detector kernel launches inside AKZ_ST_DETECTOR               */
     uint64_t det_px;         /* sum over those launches of level pixels (x batch)             */
     uint64_t fused_px;       /* level pixels (x batch) whose preparation ran inside a FED launch (k_level_march) */
+    /* What the context's stream-placement probe found (akz_ctx_warmup / the first large batch; state, not accumulated):
+       probed 0/1; early_stages 2 = a batch's level-0 stages run ahead on the copy stream, 0 = on the caller's stream (the
+       copy stream could not be given a hardware queue and a pipe of its own: perf only, -5 %); replaced = streams the probe
+       re-created; shared = streams that still share a queue or pipe with another busy one; retries = measurements repeated
+       because the first answer was "shared" or ambiguous */
+    uint32_t placement_probed, placement_early_stages, placement_replaced, placement_shared, placement_retries, placement_reserved;
 } akz_profile;
 /* on: 0 = off, 1 = every stage (two HIP events per stage and level), 2 = light: only the FED and detector spans and
    the host-clock stages (what bench.py uses inside its timed region) */
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
+/* Optional, once, with the caller's stream idle and NOT being captured: runs the stream-placement probe now (~2 ms: spins
+   and tiny kernels on the context's streams, which are synchronised) instead of inside the first large akz_extract_begin_*
+   -- that call then stays asynchronous.  The probe measures which of the context's streams share a hardware queue or a
+   command-processor pipe and replaces those that do; every timing that says "shared" is repeated and the shortest decides.
+   Results never depend on it; akz_ctx_get_profile reports what it found. */
+int akz_ctx_warmup(akz_ctx* ctx);
 /* Extrema candidates per image that the next extraction reserves room for (default 32768; it grows to 1.25x
    the largest count seen).  A list that overflows is detected by akz_extract_finish, which enlarges it and
    repeats the extrema pass on the stored Ldet planes — results are the same, the call is slower; the setter

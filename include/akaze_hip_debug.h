@@ -37,6 +37,12 @@ int akz_debug_set_schedule(akz_ctx* ctx, int key, int value);
    the context's stream (0) or the copy stream (2), info[2] = streams it re-created because they shared a hardware queue
    or a command-processor pipe with another busy stream of the context, info[3] = streams that still share one. */
 int akz_debug_stream_placement(akz_ctx* ctx, int* info);
+/* The probe's decision as a pure function of its timings (host only, no GPU): bit 0 = the two streams share a hardware
+   queue, bit 1 = a command-processor pipe, bit 2 = too close to a threshold to trust a single measurement (the probe then
+   repeats it and lets the shortest decide).  spin_pair_ms: two spins of spin_ms each on two streams, first start to second
+   end; tiny_pair_ms: 24 + 24 interleaved tiny kernels on the two streams (negative: not measured); tiny_alone_ms: 24 of
+   them on one stream. */
+int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float tiny_alone_ms, float spin_ms);
 /* Test hook: where the extrema candidates are put into scan order: 1 = bucketed and sorted on the HOST (also the fallback
    that a candidate-list overflow and over-wide sort keys take), 0 = device sort, -1 = automatic (the default: device
    sort for contexts with fewer than four host threads).  Results are identical. */

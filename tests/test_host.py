@@ -418,3 +418,28 @@ def test_march_bands_tile_the_rows(amd):
                     assert at == hi, (kind, S, w, h, n, at, hi)
                     checked += 1
     assert checked > 300
+
+
+def test_placement_verdict_on_recorded_timings(amd):
+    """The stream-placement probe's decision (akz_api.cpp, akz::placement_verdict) on the timings recorded in
+    profiles/r04_queue_probe.txt: bit 0 = one hardware queue, bit 1 = one command-processor pipe, bit 2 = ambiguous (the
+    probe repeats such a measurement and lets the shortest decide)."""
+    v = amd.lib().akz_debug_placement_verdict
+    spin = 0.120
+    # one 120 us spin on each of two streams: 123-158 us side by side, 244-245 us on one hardware queue
+    for t in (0.123, 0.133, 0.143, 0.157):
+        assert v(t, -1.0, 0.126, spin) & 1 == 0, t
+    for t in (0.244, 0.245, 0.300):
+        assert v(t, -1.0, 0.126, spin) & 1 == 1, t
+    assert v(0.180, -1.0, 0.126, spin) & 4 and v(0.200, -1.0, 0.126, spin) & 5 == 5   # near the threshold: ambiguous either way
+    assert v(0.130, -1.0, 0.126, spin) & 4 == 0 and v(0.245, -1.0, 0.126, spin) & 4 == 0
+    # 40 tiny kernels on each stream: 78-161 us alone, 198-315 us on different pipes, 913-1149 us on one pipe
+    alone = 0.126
+    for t in (0.198, 0.238, 0.292, 0.315):
+        assert v(0.0, t, alone, spin) & 2 == 0 and v(0.0, t, alone, spin) & 4 == 0, t
+    for t in (0.913, 0.997, 1.048, 1.149):
+        assert v(0.0, t, alone, spin) == 2, t
+    # 634 us -- one reading of that table, a pair on different pipes -- says "shared" once and is marked ambiguous: the probe
+    # measures again, and the next (shortest) reading of such a pair, ~0.25 ms, clears it
+    assert v(0.0, 0.634, alone, spin) == 6
+    assert v(0.0, min(0.634, 0.245), alone, spin) == 0

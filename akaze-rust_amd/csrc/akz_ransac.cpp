@@ -21,6 +21,8 @@
 // Not reproducible bit for bit (and not a parity target): the HashSet iteration order of the
 // 8 sampled indices (random per process) and nalgebra's f32 SVD.  Here the sample is taken in ascending
 // index order and the decomposition is a one-sided Jacobi SVD of the 8x9 matrix in f64.
+#include <unistd.h>
+
 #include <algorithm>
 #include <thread>
 #include <cmath>
@@ -155,12 +157,25 @@ int akz::remove_outliers_impl(const akz_keypoint* keypoints_0, uint64_t n0, cons
     } else {
         // the trials go to a pool of host threads that lives as long as the process (starting 16 threads per call was a
         // third of a 1 000-trial call's 1.3 ms); a second caller at the same time starts its own threads, as before
+        // The pool is never destroyed (its threads end with the process) and belongs to the process that made it: after a
+        // fork() the child inherits the object but none of its threads, so a pid that differs drops it (leaked: joining
+        // threads that do not exist would hang) and starts a new one.  A child forked while another thread held pool_m
+        // never gets the lock and takes the per-call threads below.
         static std::mutex pool_m;
-        static std::unique_ptr<WorkerPool> pool;
+        static WorkerPool* pool = nullptr;
+        static pid_t pool_pid = 0;
         std::unique_lock<std::mutex> lk(pool_m, std::try_to_lock);
         if (lk.owns_lock()) {
-            if (!pool || pool->size() < nthreads) pool.reset(new WorkerPool(nthreads - 1));
-            const uint64_t per = std::max<uint64_t>(1, num_trials / (4ull * nthreads));  // handed out dynamically
+            const pid_t me = getpid();
+            if (pool && pool_pid != me) pool = nullptr;
+            if (!pool || pool->size() < nthreads) {
+                if (pool && pool_pid == me) delete pool;
+                pool = new WorkerPool(nthreads - 1);
+                pool_pid = me;
+            }
+            // handed out dynamically, four pieces per thread -- unless the pool is wider than this call wants (it was grown by
+            // a larger one): then exactly nthreads pieces, so that a small call does not wake sixteen threads
+            const uint64_t per = std::max<uint64_t>(1, num_trials / ((pool->size() > nthreads ? 1ull : 4ull) * nthreads));
             const size_t pieces = (size_t)((num_trials + per - 1) / per);
             pool->run(pieces, [&](size_t i) { run_trials((uint64_t)i * per, std::min<uint64_t>(num_trials, ((uint64_t)i + 1) * per)); });
         } else {

@@ -443,3 +443,41 @@ def test_placement_verdict_on_recorded_timings(amd):
     # measures again, and the next (shortest) reading of such a pair, ~0.25 ms, clears it
     assert v(0.0, 0.634, alone, spin) == 6
     assert v(0.0, min(0.634, 0.245), alone, spin) == 0
+
+
+def test_remove_outliers_pool_survives_fork(amd):
+    """akz_remove_outliers' process-wide pool of trial threads (akz_ransac.cpp) after fork(): the child inherits the pool
+    object but none of its threads -- it must notice (pid), start its own, give the parent's result for the same random
+    source, and exit cleanly (round-4 advice)."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    k0 = np.zeros(n, amd.KEYPOINT_DTYPE)
+    k1 = np.zeros(n, amd.KEYPOINT_DTYPE)
+    k0["x"], k0["y"] = rng.uniform(0, 1900, n), rng.uniform(0, 1000, n)
+    k1["x"], k1["y"] = k0["x"] + 17 + rng.normal(0, 0.4, n), k0["y"] + 9 + rng.normal(0, 0.4, n)
+    m = np.zeros(n, amd.MATCH_DTYPE)
+    m["index_0"] = m["index_1"] = np.arange(n)
+    amd.random_seed(42, 69)
+    first = amd.remove_outliers(k0, k1, m, 1000, 0.05, 3.0)   # grows the pool in THIS process
+    assert 8 <= len(first) <= n
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        rc = 1
+        try:
+            os.close(r)
+            amd.random_seed(42, 69)
+            again = amd.remove_outliers(k0, k1, m, 1000, 0.05, 3.0)
+            rc = 0 if np.array_equal(again, first) else 2
+            os.write(w, b"k")
+        finally:
+            os._exit(rc)
+    os.close(w)
+    import select
+    ready, _, _ = select.select([r], [], [], 60)
+    if not ready:
+        os.kill(pid, 9)
+    _, status = os.waitpid(pid, 0)
+    assert ready and os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    amd.random_seed(42, 69)
+    assert np.array_equal(amd.remove_outliers(k0, k1, m, 1000, 0.05, 3.0), first)   # the parent's pool is untouched

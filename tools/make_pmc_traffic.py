@@ -81,7 +81,9 @@ open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.txt"), "w").write("\n
 bench = json.loads(open(f"{out_dir}/{tag}_bench.json").read().strip().splitlines()[-1])
 cfgb = bench["config"]
 doc = dict(
-    workload=dict(width=cfgb["width"], height=cfgb["height"], frames=cfgb["frames_per_gpu"], octaves=4, sublevels=4,
+    workload=dict(width=cfgb["width"], height=cfgb["height"], frames=cfgb["frames_per_gpu"],
+                  octaves=int(re.search(r"\((\d+) oct x (\d+) sub\)", bench["metric"]).group(1)),
+                  sublevels=int(re.search(r"\((\d+) oct x (\d+) sub\)", bench["metric"]).group(2)),
                   lean=cfgb["planes"] == "lean"),
     source=f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1` ({tag}); "
            "HBM bytes = FETCH_SIZE x fetch_factor + WRITE_SIZE (KiB x 1024)",
@@ -90,6 +92,8 @@ doc = dict(
         "detector (k_detector_march + k_detector_tiled)": group(["k_detector_march", "k_detector_tiled"]),  # every detector launch, as bench.py counts them
         "k_level_march + k_fed_own": group(["k_level_march", "k_fed_own", "k_octave_resident"]),  # every diffusion launch
     })
-json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+# pmc_traffic.json is what bench.py reads for its DEFAULT workload; any other shape gets a file of its own
+default_shape = (doc["workload"]["width"], doc["workload"]["height"], doc["workload"]["frames"], doc["workload"]["octaves"]) == (1920, 1080, 32, 4)
+json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json" if default_shape else f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "kernels"} for k, v in doc["kernels"].items()}), json.dumps(cal))
 print("\n".join(lines[:14]))

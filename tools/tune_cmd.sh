@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs a command against builds with different compile-time defines (device objects rebuilt on the GPU box):
-#   tools/tune_cmd.sh "python tools/slab_probe.py | tail -2" "-DAKZ_MARCH_PF=3" "-DAKZ_MARCH_PF=6"
+#   tools/tune_cmd.sh "python bench.py --no-single --no-match | cut -c1-120" "-DAKZ_MARCH_PF=3" "-DAKZ_MARCH_PF=6"
 CMD=$1; shift
 for t in "$@"; do
   rm -f akaze-rust_amd/csrc/akz_kernels.o akaze-rust_amd/csrc/akz_stencil.o akaze-rust_amd/csrc/akz_stream.o akaze-rust_amd/csrc/akz_march.o akaze-rust_amd/csrc/akz_match.o

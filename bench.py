@@ -793,6 +793,18 @@ def main_rank(args):
             fed_alone[name] = {"avg_launch_us": round(ms / launches * 1e3, 2), "achieved": round(gbs, 1),
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": nst, "launches_per_pass": launches // reps,
                                "algorithmic_bytes_per_launch": round(FED_BYTES_PER_PX_STEP * px * nst * reps / launches)}
+            if name == "4k_plane":
+                # the same launch under the FETCH_SIZE / WRITE_SIZE passes (tools/pmc_calib.py, committed in profiles/pmc_traffic.json):
+                # what it really moves -- `frac` above counts 12 B per pixel-step, the launch fuses 8 steps and its 100 MB
+                # working set sits in the Infinity Cache
+                try:
+                    cal = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["calibration"]["fed_own_4k"]
+                    tr = (cal["fetch_kib_per_launch"] + cal["write_kib_per_launch"]) * 1024.0
+                    us = ms / launches * 1e3
+                    fed_alone[name].update({"traffic": round(tr), "traffic_frac": round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "bound": "vector issue / LDS latency, not HBM: frac > 1 is 8-step temporal fusion on a cache-resident plane"})
+                except Exception:
+                    fed_alone[name].update({"traffic": None, "traffic_frac": None})
             del lt, lf
 
     # ---- the detector kernel alone, on HBM-cold inputs: four plane sets of a 32 x 1080p level in turn (a launch that

@@ -57,9 +57,9 @@ unsigned akz::host_cpu_share() {
 // 8-frame batches, 8 000 000 -- so that a lone 4K frame qualifies -- changes nothing for it: that frame is bound by the
 // host's per-image selection and the finish round trips, not by its kernels).
 #ifndef AKZ_BIG_PX
-#define AKZ_BIG_PX (8u << 20)
+#define AKZ_BIG_PX 8000000u  // (a lone 3840 x 2160 frame -- 8.29 Mpx -- is a big job: 2.68 -> 2.37 ms per call, profiles/r05_lone_ab.txt)
 #endif
-static constexpr uint64_t kBigLaunchPx() { return AKZ_BIG_PX; }
+static constexpr uint64_t kBigLaunchPxDefault = AKZ_BIG_PX;
 // The finish half of a lane's jobs on a thread of the library (akz_ctx_set_eager_finish): started by begin, so that the
 // candidate round trip, the host keypoint logic and the keypoint kernels of frame i run while the caller's thread
 // enqueues frame i + 1 on another lane; akz_extract_finish then only collects the result.  One thread per lane, jobs
@@ -151,7 +151,8 @@ struct akz_ctx {
     // placement probe found it a queue and a pipe of its own (below), 1 the copy stream regardless, 2 a stream of their own
     // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
     // has finished its fine-level diffusion (default) or not; [2] no placement probe
-    int sched[4] = {0, 1, 0, 0};
+    int sched[5] = {0, 1, 0, 0, 0};
+    uint64_t big_px = kBigLaunchPxDefault;  // jobs of this many pixels (w*h*n) and more take the batch path: column-march kernels, forked coarse chain, resident tail (sched[4]: measurement)
     // Stream placement (place_streams): the runtime multiplexes a process's streams onto a few in-order hardware queues
     // (GPU_MAX_HW_QUEUES, 4 by default); two busy streams of a context on one queue serialise the whole pipeline, so the
     // first large batch measures which of the context's streams actually run side by side and replaces those that do not
@@ -612,7 +613,7 @@ static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t 
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
     constexpr bool is_u8 = std::is_same<T, uint8_t>::value;
     // large batches: the column march (HBM-bound: 0.33 GB of a 32-frame 1080p batch)
-    const uint64_t blur_march_min_px = kBigLaunchPx();
+    const uint64_t blur_march_min_px = c->big_px;
     if ((const void*)d_in != (const void*)d_out && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= blur_march_min_px)) &&
         launch::blur5_march_supported(w, h, (uint32_t)k.size())) {
         if constexpr (is_u8) launch::blur5_march_u8(c->stream, d_in, d_out, w, h, n, k.data());
@@ -678,7 +679,7 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
     const size_t ks = gaussian_kernel_size((float)gscale);
     const bool stream = c->prep_mode != 0 && gscale > 0.0 && launch::contrast_stream_supported(w, h, (uint32_t)ks, (uint32_t)nbins) &&
                         (c->prep_mode == 1 || (uint64_t)w * h * n >= c->stream_min_px);
-    const bool march = gscale > 0.0 && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= kBigLaunchPx())) &&
+    const bool march = gscale > 0.0 && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= c->big_px)) &&
                        launch::contrast_march_supported(w, h, (uint32_t)ks, (uint32_t)nbins);
     if (march) {
         const std::vector<float> g3 = gaussian_kernel((float)gscale, ks);
@@ -767,7 +768,7 @@ static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_
     if (c->det_mode == 0) return 0;
     if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;
     if (c->det_mode == 5) return launch::detector_march_supported(sigma, w, h, border_m, nms) ? 5 : 0;
-    const uint64_t march_min = kBigLaunchPx();
+    const uint64_t march_min = c->big_px;
     const uint64_t px = (uint64_t)w * h * n;
     if (px >= march_min && launch::detector_march_supported(sigma, w, h, border_m, nms)) return 5;
     if (px < march_min && launch::detector_tiled_fused_supported(sigma)) return 4;
@@ -1395,7 +1396,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         ~StreamRestore() { c->stream = main; }
     } stream_restore{c, s};
     bool early = false;
-    const bool big = (uint64_t)w * h * n >= kBigLaunchPx();
+    const bool big = (uint64_t)w * h * n >= c->big_px;
     if (big && !c->placed) AKZ_TRY(place_streams(c));
     const int pre_mode = c->sched[0] == 0 ? c->pre_mode : c->sched[0] == 1 ? 2 : c->sched[0] == 2 ? 1 : 0;  // (1: a stream of its own, measurement only)
     if ((input_ready || (flags & AKZ_INPUT_READY)) && pre_mode != 0 && c->profiling < 2 && c->prep_mode == 2 && big &&
@@ -1449,7 +1450,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     const int fork_octave = c->sched[3] > 0 ? c->sched[3] : 2;  // (forking at octave 3 instead, octave 2 on the main stream: -4 %; sched[3]: measurement)
     // (a lone 1080p frame is a chain of dependent launches either way and only pays for the two events: measured
     // 0.596 -> 0.625 ms per streamed frame; batches from 8 Mpx on fork)
-    const uint64_t fork_min_px = kBigLaunchPx();
+    const uint64_t fork_min_px = c->big_px;
     hipStream_t ls = s;  // the stream the level loop enqueues on
     size_t fork_level = L;  // first level of the coarse chain
     // Resident tail: from the first level whose image fits one compute unit, ALL remaining levels (preparation and
@@ -1740,7 +1741,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // cost the kernels of the next batch more than the idle host threads gain.
     // (... and for images of 6 Mpx and more, whose sequential selection -- 1.4 ms per 4K frame on the grids -- is the longest
     // single piece of a synchronous call)
-    const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < kBigLaunchPx() ||
+    const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < c->big_px ||
                                                                         (uint64_t)r->w * r->h >= 6000000ull));
     bool sorted = false;
     uint16_t* d_rel = nullptr;
@@ -1957,7 +1958,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         // VALU-bound diffusion launches these gather-bound kernels cost more than next to the bandwidth-bound detectors that
         // follow; the NEXT batch, not the one begun last: with two batches begun ahead that one is a whole step away); small
         // jobs are bound by the latency of this chain, not by the chip, and do not wait
-        if ((uint64_t)r->w * r->h * n >= kBigLaunchPx() && c->begin_seq.load() > job->seq)
+        if ((uint64_t)r->w * r->h * n >= c->big_px && c->begin_seq.load() > job->seq)
             AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_ev[(job->seq + 1) % akz_ctx::kFedRing], 0));
         launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());
@@ -2261,6 +2262,7 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
         l->cand_cap_hint = c->cand_cap_hint.load();
         l->stream_min_px = c->stream_min_px;
+        l->big_px = c->big_px;
         l->host_threads = c->host_threads;
         l->profiling = c->profiling;
         l->dbg_pair_chunks = c->dbg_pair_chunks;
@@ -2283,7 +2285,7 @@ int akz_ctx_set_eager_finish(akz_ctx* c, int on) {
 static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
                                   const akz_config* cfg, uint32_t flags, akz_job** out, bool on_host = false) {
     akz_ctx* on = c;
-    if (c && !c->lanes.empty() && (uint64_t)w * h * n < kBigLaunchPx()) {
+    if (c && !c->lanes.empty() && (uint64_t)w * h * n < c->big_px) {
         AKZ_TRY(bind(c, false));
         on = c->lanes[c->next_lane++ % c->lanes.size()];
         // the lane starts when the caller's stream has reached this point (its inputs are complete)
@@ -2351,7 +2353,7 @@ int akz_ctx_graph_probe(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t 
                         uint32_t flags, uint32_t reps, double* ms_graph, double* ms_plain, uint64_t* graph_nodes) {
     AKZ_TRY(bind(c));
     if (!d_imgs || !cfg || !ms_graph || !ms_plain || reps == 0) return AKZ_ERR_INVALID_ARG;
-    if ((uint64_t)w * h * n >= kBigLaunchPx()) {  // such a batch forks its coarse chain and completes on that stream: not one capture
+    if ((uint64_t)w * h * n >= c->big_px) {  // such a batch forks its coarse chain and completes on that stream: not one capture
         set_error("akz_ctx_graph_probe: batches of 8 Mpx and more fork onto a second stream and cannot be captured from one");
         return AKZ_ERR_INVALID_ARG;
     }
@@ -3172,9 +3174,13 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
 }
 const char* akz_detector_kernel_name(void) { return "detector (k_detector_march + k_detector_tiled)"; }
 int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
-    if (!c || key < 0 || key > 3) return AKZ_ERR_INVALID_ARG;
+    if (!c || key < 0 || key > 4) return AKZ_ERR_INVALID_ARG;
     AKZ_TRY(bind(c));
     c->sched[key] = value;
+    if (key == 4) {
+        c->big_px = value > 0 ? (uint64_t)value * 1000u : kBigLaunchPxDefault;
+        for (akz_ctx* l : c->lanes) l->big_px = c->big_px;
+    }
     return AKZ_OK;
 }
 int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float tiny_alone_ms, float spin_ms) {

@@ -31,7 +31,9 @@ int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_
    (level-0 blur, contrast factor) of a batch whose input is complete run: 0 = the copy stream if the context's
    stream-placement probe found it a hardware queue and a pipe of its own (default), 1 = the copy stream regardless, 2 = a
    stream of their own (a fifth busy stream), 3 = the context's stream (no running ahead); key 1: they are held back until
-   the batch before has finished its fine-level diffusion (1, default) or start at once (0); key 2: 1 = no placement probe. */
+   the batch before has finished its fine-level diffusion (1, default) or start at once (0); key 2: 1 = no placement probe;
+   key 3: octave at which the coarse chain forks (0 = default 2); key 4: the job size in thousands of pixels (w*h*n) from
+   which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (8 000). */
 int akz_debug_set_schedule(akz_ctx* ctx, int key, int value);
 /* What the stream-placement probe of the context's first large batch found: info[0] = it has run, info[1] = early stages on
    the context's stream (0) or the copy stream (2), info[2] = streams it re-created because they shared a hardware queue

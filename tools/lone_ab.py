@@ -8,7 +8,8 @@ import numpy as np, torch
 import akaze_amd as A
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 dev = torch.device("cuda", 0)
-frame = torch.from_numpy(A.synth_frame(W, H, 0)[None]).to(dev)
+NF = int(os.environ.get("LONE_FRAMES", "1"))  # frames per call (1: a lone frame)
+frame = torch.from_numpy(np.stack([A.synth_frame(W, H, i) for i in range(NF)])).to(dev)
 cfg = A.Config()
 st = torch.cuda.Stream(dev)
 torch.cuda.set_stream(st)
@@ -51,5 +52,5 @@ for rnd in range(3):
         r = ctx.extract_begin(frame, cfg).finish()
         sig = (r.keypoints(0).tobytes(), r.descriptors(0).tobytes()); r.close()
         ref = ref or sig
-        print(f"{W}x{H} {name:22s} latency {lat*1e3:.3f} ms  streamed {thr*1e3:.3f} ms/frame  begin: host {hb*1e3:.3f} ms, GPU idle after {gb*1e3:.3f} ms  same={sig == ref}", flush=True)
+        print(f"{NF}x{W}x{H} {name:22s} latency {lat*1e3:.3f} ms  streamed {thr*1e3:.3f} ms/frame  begin: host {hb*1e3:.3f} ms, GPU idle after {gb*1e3:.3f} ms  same={sig == ref}", flush=True)
 print(ctx.get_profile()["placement"])

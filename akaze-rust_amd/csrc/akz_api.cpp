@@ -56,10 +56,23 @@ unsigned akz::host_cpu_share() {
 // the coarse chain and the resident coarse octave engage from here on (swept again in round 3: 4 Mpx is -7 ... -9 % on
 // 8-frame batches, 8 000 000 -- so that a lone 4K frame qualifies -- changes nothing for it: that frame is bound by the
 // host's per-image selection and the finish round trips, not by its kernels).
-#ifndef AKZ_BIG_PX
-#define AKZ_BIG_PX 8000000u  // (a lone 3840 x 2160 frame -- 8.29 Mpx -- is a big job: 2.68 -> 2.37 ms per call, profiles/r05_lone_ab.txt)
+// From which job size (w*h*n pixels) a job takes the BATCH path -- column-march kernels, the coarse chain forked onto its own
+// stream, the resident tail -- instead of the chain of tiled launches (profiles/r05_lone_ab.txt, one MI355X):
+//   job            latency of one call   per job in a stream of jobs
+//   1 x 1080p      0.98 / 1.21 ms        0.60 / 0.62 ms      (tiled chain / batch path)
+//   1 x 2016x1512  1.21 / 1.28           0.77 / 0.67
+//   2 x 1080p      1.42 / 1.51           0.90 / 0.78
+//   3 x 1080p      1.76 / 1.78           1.09 / 0.92
+//   1 x 4K         2.65 / 2.40           1.50 / 1.37
+// The batch path is the more efficient use of the chip from 3 Mpx on, but its forked chain and resident tail end later when
+// nothing else is in flight: a SYNCHRONOUS call (akz_extract_*: its latency is all the caller sees) takes it from 6 Mpx, a job
+// of the begin / finish interface (a caller that keeps jobs in flight) from 3 Mpx.
+#ifndef AKZ_BIG_PX_SYNC
+#define AKZ_BIG_PX_SYNC 6000000u
 #endif
-static constexpr uint64_t kBigLaunchPxDefault = AKZ_BIG_PX;
+#ifndef AKZ_BIG_PX_ASYNC
+#define AKZ_BIG_PX_ASYNC 3000000u
+#endif
 // The finish half of a lane's jobs on a thread of the library (akz_ctx_set_eager_finish): started by begin, so that the
 // candidate round trip, the host keypoint logic and the keypoint kernels of frame i run while the caller's thread
 // enqueues frame i + 1 on another lane; akz_extract_finish then only collects the result.  One thread per lane, jobs
@@ -91,6 +104,8 @@ struct akz_ctx {
     int dbg_select = -1;                     // akz_debug_set_select: 1 / 0 force the neighbour-list / the grid selection, -1 automatic
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
+    DevBuf match_state;                      // k_match_merge_compact's per-workgroup counts (zeroed when allocated, then told apart by epoch)
+    uint32_t match_epoch = 0;
     DevBuf ransac_dev, ransac_pin;           // match_features: the trials' inputs and outputs on the device / pinned staging of both
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
     DevBuf mm_cols;                          // both-direction launches: the train rows' (best, second) state, seed records and bound
@@ -152,7 +167,13 @@ struct akz_ctx {
     // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
     // has finished its fine-level diffusion (default) or not; [2] no placement probe
     int sched[5] = {0, 1, 0, 0, 0};
-    uint64_t big_px = kBigLaunchPxDefault;  // jobs of this many pixels (w*h*n) and more take the batch path: column-march kernels, forked coarse chain, resident tail (sched[4]: measurement)
+    uint64_t big_px = AKZ_BIG_PX_ASYNC;  // the gate of the job being begun (set by extract_begin from the two below; the begin half's helpers read it)
+    uint64_t big_px_sync = AKZ_BIG_PX_SYNC, big_px_async = AKZ_BIG_PX_ASYNC;  // (sched[4] sets both: measurement)
+    // pixels per LAUNCH (level w*h*n) from which the blur, the contrast passes and the detectors take their column-march
+    // form: 8 Mpx (a 32 x 480x270 level: 41 us tiled against 66 for the march, which would run one strip per image row);
+    // inside a batch-path job smaller than that, the job's own size -- its full-resolution launches march, the rest is tiled
+    static constexpr uint64_t kLaunchMarchPx = 8u << 20;
+    uint64_t launch_min_px = kLaunchMarchPx;
     // Stream placement (place_streams): the runtime multiplexes a process's streams onto a few in-order hardware queues
     // (GPU_MAX_HW_QUEUES, 4 by default); two busy streams of a context on one queue serialise the whole pipeline, so the
     // first large batch measures which of the context's streams actually run side by side and replaces those that do not
@@ -399,7 +420,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
-                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec,
+                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec, &c->match_state,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols,
                       &c->ms1.q8, &c->ms1.t8, &c->ms1.pop, &c->ms1.tab, &c->ms1.cols, &c->ms1.rec, &c->ransac_dev};
     for (DevBuf* b : bufs)
@@ -613,7 +634,7 @@ static int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t 
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, t.hw));
     constexpr bool is_u8 = std::is_same<T, uint8_t>::value;
     // large batches: the column march (HBM-bound: 0.33 GB of a 32-frame 1080p batch)
-    const uint64_t blur_march_min_px = c->big_px;
+    const uint64_t blur_march_min_px = c->launch_min_px;
     if ((const void*)d_in != (const void*)d_out && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= blur_march_min_px)) &&
         launch::blur5_march_supported(w, h, (uint32_t)k.size())) {
         if constexpr (is_u8) launch::blur5_march_u8(c->stream, d_in, d_out, w, h, n, k.data());
@@ -679,7 +700,7 @@ static int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, 
     const size_t ks = gaussian_kernel_size((float)gscale);
     const bool stream = c->prep_mode != 0 && gscale > 0.0 && launch::contrast_stream_supported(w, h, (uint32_t)ks, (uint32_t)nbins) &&
                         (c->prep_mode == 1 || (uint64_t)w * h * n >= c->stream_min_px);
-    const bool march = gscale > 0.0 && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= c->big_px)) &&
+    const bool march = gscale > 0.0 && (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)w * h * n >= c->launch_min_px)) &&
                        launch::contrast_march_supported(w, h, (uint32_t)ks, (uint32_t)nbins);
     if (march) {
         const std::vector<float> g3 = gaussian_kernel((float)gscale, ks);
@@ -768,7 +789,7 @@ static int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_
     if (c->det_mode == 0) return 0;
     if (c->det_mode == 4) return launch::detector_tiled_fused_supported(sigma) ? 4 : 0;
     if (c->det_mode == 5) return launch::detector_march_supported(sigma, w, h, border_m, nms) ? 5 : 0;
-    const uint64_t march_min = c->big_px;
+    const uint64_t march_min = c->launch_min_px;
     const uint64_t px = (uint64_t)w * h * n;
     if (px >= march_min && launch::detector_march_supported(sigma, w, h, border_m, nms)) return 5;
     if (px < march_min && launch::detector_tiled_fused_supported(sigma)) return 4;
@@ -922,6 +943,7 @@ struct akz_result {
     akz_ctx* ctx = nullptr;
     akz_config cfg;
     uint32_t w = 0, h = 0, n = 0, flags = 0;
+    uint64_t big_px = 0;            // the job-size gate this job was begun under (AKZ_BIG_PX_SYNC / _ASYNC)
     std::vector<LevelPlan> plan;
     void* slab = nullptr;
     size_t slab_bytes = 0;
@@ -1262,10 +1284,18 @@ int akz::place_streams_beside(akz_ctx* c, hipStream_t* slots, int n_slots, int* 
 
 template <typename T>
 static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uint32_t n, const akz_config* cfgp,
-                         uint32_t flags, akz_job** out, int want_slot = -1, hipEvent_t input_ready = nullptr) {
+                         uint32_t flags, akz_job** out, int want_slot = -1, hipEvent_t input_ready = nullptr, bool sync_call = false) {
     if (!out) return AKZ_ERR_INVALID_ARG;
     *out = nullptr;
     AKZ_TRY(bind(c, true, c && c->is_lane));  // (a lane's finish half shares the lane's one stream: begin waits for it)
+    c->big_px = sync_call ? c->big_px_sync : c->big_px_async;  // (see AKZ_BIG_PX_SYNC)
+    struct GateRestore {  // the per-op entry points (akz_op_*) use the same helpers: they see the begin / finish interface's gate
+        akz_ctx* c;
+        ~GateRestore() {
+            c->big_px = c->big_px_async;
+            c->launch_min_px = akz_ctx::kLaunchMarchPx;
+        }
+    } gate_restore{c};
     if (!d_imgs || !cfgp || n == 0) {
         set_error("extract: null image/config or empty batch");
         return AKZ_ERR_INVALID_ARG;
@@ -1284,6 +1314,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     ++c->live_results;
     r->cfg = *cfgp;
     r->w = w; r->h = h; r->n = n; r->flags = flags;
+    r->big_px = c->big_px;  // (the finish half may run on another thread while the next job is begun with another gate)
     AKZ_TRY(build_plan(w, h, r->cfg, r->plan));
     const akz_config& cfg = r->cfg;
     const std::vector<LevelPlan>& plan = r->plan;
@@ -1397,6 +1428,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     } stream_restore{c, s};
     bool early = false;
     const bool big = (uint64_t)w * h * n >= c->big_px;
+    c->launch_min_px = big ? std::min<uint64_t>(akz_ctx::kLaunchMarchPx, (uint64_t)w * h * n) : akz_ctx::kLaunchMarchPx;
     if (big && !c->placed) AKZ_TRY(place_streams(c));
     const int pre_mode = c->sched[0] == 0 ? c->pre_mode : c->sched[0] == 1 ? 2 : c->sched[0] == 2 ? 1 : 0;  // (1: a stream of its own, measurement only)
     if ((input_ready || (flags & AKZ_INPUT_READY)) && pre_mode != 0 && c->profiling < 2 && c->prep_mode == 2 && big &&
@@ -1741,7 +1773,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // cost the kernels of the next batch more than the idle host threads gain.
     // (... and for images of 6 Mpx and more, whose sequential selection -- 1.4 ms per 4K frame on the grids -- is the longest
     // single piece of a synchronous call)
-    const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < c->big_px ||
+    const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < r->big_px ||
                                                                         (uint64_t)r->w * r->h >= 6000000ull));
     bool sorted = false;
     uint16_t* d_rel = nullptr;
@@ -1958,7 +1990,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         // VALU-bound diffusion launches these gather-bound kernels cost more than next to the bandwidth-bound detectors that
         // follow; the NEXT batch, not the one begun last: with two batches begun ahead that one is a whole step away); small
         // jobs are bound by the latency of this chain, not by the chip, and do not wait
-        if ((uint64_t)r->w * r->h * n >= c->big_px && c->begin_seq.load() > job->seq)
+        if ((uint64_t)r->w * r->h * n >= r->big_px && c->begin_seq.load() > job->seq)
             AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_ev[(job->seq + 1) % akz_ctx::kFedRing], 0));
         launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
         AKZ_HIP_TRY(hipGetLastError());
@@ -2191,7 +2223,7 @@ static int extract_impl(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, uin
     if (!out) return AKZ_ERR_INVALID_ARG;
     *out = nullptr;
     akz_job* job = nullptr;
-    AKZ_TRY(extract_begin<T>(c, d_imgs, w, h, n, cfgp, flags, &job));
+    AKZ_TRY(extract_begin<T>(c, d_imgs, w, h, n, cfgp, flags, &job, -1, nullptr, /*sync_call=*/true));
     return extract_finish(job, out);
 }
 
@@ -2262,7 +2294,8 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
         l->cand_cap_hint = c->cand_cap_hint.load();
         l->stream_min_px = c->stream_min_px;
-        l->big_px = c->big_px;
+        l->big_px_sync = c->big_px_sync;
+        l->big_px_async = c->big_px_async;
         l->host_threads = c->host_threads;
         l->profiling = c->profiling;
         l->dbg_pair_chunks = c->dbg_pair_chunks;
@@ -2285,7 +2318,7 @@ int akz_ctx_set_eager_finish(akz_ctx* c, int on) {
 static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
                                   const akz_config* cfg, uint32_t flags, akz_job** out, bool on_host = false) {
     akz_ctx* on = c;
-    if (c && !c->lanes.empty() && (uint64_t)w * h * n < c->big_px) {
+    if (c && !c->lanes.empty() && (uint64_t)w * h * n < c->big_px_async) {
         AKZ_TRY(bind(c, false));
         on = c->lanes[c->next_lane++ % c->lanes.size()];
         // the lane starts when the caller's stream has reached this point (its inputs are complete)
@@ -2353,8 +2386,8 @@ int akz_ctx_graph_probe(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t 
                         uint32_t flags, uint32_t reps, double* ms_graph, double* ms_plain, uint64_t* graph_nodes) {
     AKZ_TRY(bind(c));
     if (!d_imgs || !cfg || !ms_graph || !ms_plain || reps == 0) return AKZ_ERR_INVALID_ARG;
-    if ((uint64_t)w * h * n >= c->big_px) {  // such a batch forks its coarse chain and completes on that stream: not one capture
-        set_error("akz_ctx_graph_probe: batches of 8 Mpx and more fork onto a second stream and cannot be captured from one");
+    if ((uint64_t)w * h * n >= c->big_px_async) {  // such a batch forks its coarse chain and completes on that stream: not one capture
+        set_error("akz_ctx_graph_probe: jobs of 3 Mpx and more fork onto a second stream and cannot be captured from one");
         return AKZ_ERR_INVALID_ARG;
     }
     const int prof = c->profiling;
@@ -2712,6 +2745,20 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
     }
     // more than a few chunks: a parallel merge first (the compaction is ONE workgroup, i.e. one compute unit's load path:
     // folding 11 chunks of 11 K queries there took 35 us against 5 for the 44-workgroup merge)
+    // Query sets of a few workgroups and more: merge, ratio test and ordered compaction in ONE launch (k_match_merge_compact:
+    // 44 workgroups for a 4K frame's 11 K rows); tiny ones keep the single-workgroup compaction
+    if (n0 >= 2048) {
+        const size_t need = launch::match_merge_compact_state_bytes((uint32_t)n0);
+        if (c->match_state.bytes < need) {
+            AKZ_TRY(ensure(c, c->match_state, need * 2));
+            AKZ_HIP_TRY(hipMemsetAsync(c->match_state.p, 0, c->match_state.bytes, c->stream));
+        }
+        if (++c->match_epoch == 0) ++c->match_epoch;
+        launch::match_merge_compact(c->stream, rec, (uint32_t)n0, chunks, thr, lowes_ratio * lowes_ratio, d_out,
+                                    (unsigned long long*)d_n_out, c->match_state.p, c->match_epoch);
+        AKZ_HIP_TRY(hipGetLastError());
+        return AKZ_OK;
+    }
     const bool premerge = chunks > 4;
     if (premerge) launch::match_merge(c->stream, rec, (uint32_t)n0, chunks, thr, rec + (size_t)chunks * n0);
     launch::match_compact(c->stream, premerge ? rec + (size_t)chunks * n0 : rec, (uint32_t)n0, premerge ? 1u : chunks, thr,
@@ -3178,8 +3225,12 @@ int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
     AKZ_TRY(bind(c));
     c->sched[key] = value;
     if (key == 4) {
-        c->big_px = value > 0 ? (uint64_t)value * 1000u : kBigLaunchPxDefault;
-        for (akz_ctx* l : c->lanes) l->big_px = c->big_px;
+        c->big_px_sync = value > 0 ? (uint64_t)value * 1000u : (uint64_t)AKZ_BIG_PX_SYNC;
+        c->big_px_async = value > 0 ? (uint64_t)value * 1000u : (uint64_t)AKZ_BIG_PX_ASYNC;
+        for (akz_ctx* l : c->lanes) {
+            l->big_px_sync = c->big_px_sync;
+            l->big_px_async = c->big_px_async;
+        }
     }
     return AKZ_OK;
 }

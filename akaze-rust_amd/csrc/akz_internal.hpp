@@ -310,6 +310,11 @@ void match_compact(hipStream_t s, const MatchRec* d_rec, uint32_t n0, uint32_t c
                    akz_match* d_out, unsigned long long* d_n_out);
 // the same merge as a kernel of its own, one thread per query (many chunks): d_out[query]
 void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out);
+// merge + ratio test + ordered compaction of one set in one launch; d_state: match_merge_compact_state_bytes(n0) bytes that
+// were zero when allocated and are only ever written by this kernel; epoch: different for every call on that buffer, never 0
+size_t match_merge_compact_state_bytes(uint32_t n0);
+void match_merge_compact(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, double ratio2,
+                         akz_match* d_out, unsigned long long* d_n_out, void* d_state, uint32_t epoch);
 }  // namespace launch
 
 // ---- host keypoint logic (akz_keypoints.cpp) ---------------------------------------------

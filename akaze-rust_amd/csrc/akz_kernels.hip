@@ -1058,6 +1058,68 @@ __global__ void __launch_bounds__(1024) k_match_compact(const MatchRec* __restri
     if (threadIdx.x == 0) *n_out = s_base;
 }
 
+// Merge + ratio test + ORDERED compaction of one train set in ONE launch of many workgroups (the pair call: 11 chunks of
+// 11 K queries took a 44-workgroup merge, 5 us, and then the single-workgroup compaction above, 9 us).  A workgroup folds
+// the chunk records of its 256 queries exactly as k_match_merge does, counts its accepted matches and publishes the
+// count in state[blockIdx.x] = epoch << 32 | count; its place in the output is the sum of the counts of the workgroups
+// before it, which it reads as they appear (a look-back over aggregates: nobody waits for a prefix, only for counts that
+// every workgroup publishes as soon as it has merged).  Workgroups are dispatched in index order and wait only for lower
+// indices, so the wait terminates however many of them the chip holds at a time.  `epoch` differs from call to call: the
+// state words of earlier calls read as "not yet published" and the buffer is never cleared.  Output order = query order,
+// as feature_matching.rs:37-81 produces it.
+__global__ void __launch_bounds__(256) k_match_merge_compact(const MatchRec* __restrict__ part, unsigned n0, unsigned chunks,
+                                                             unsigned threshold, double ratio2, akz_match* __restrict__ out,
+                                                             unsigned long long* __restrict__ n_out,
+                                                             unsigned long long* __restrict__ state, unsigned epoch) {
+    __shared__ unsigned s_cnt[4];
+    __shared__ unsigned s_prefix;
+    const unsigned b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned i = b * 256u + tid;
+    unsigned min_d = threshold, second = threshold, min_j = 0;
+    bool keep = false;
+    if (i < n0) {
+        for (unsigned c = 0; c < chunks; ++c) {  // ascending rows: the strict '<' keeps the lowest row among equal minima
+            const MatchRec m = part[(size_t)c * n0 + i];
+            top2_feed(m.min_d, m.min_j, min_d, second, min_j);
+            if (m.second_d < second) second = m.second_d;
+        }
+        keep = ((double)min_d < (double)second * ratio2) && (min_d < threshold);
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_cnt[wave] = (unsigned)__popcll(bal);
+    __syncthreads();
+    const unsigned total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    unsigned below = 0;
+    for (unsigned w = 0; w < wave; ++w) below += s_cnt[w];
+    if (tid == 0)
+        __hip_atomic_store(state + b, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {  // the counts of the workgroups before this one, 64 at a time
+        unsigned sum = 0;
+        for (unsigned j0 = 0; j0 < b; j0 += 64u) {
+            const unsigned j = j0 + lane;
+            unsigned v = 0;
+            if (j < b) {
+                unsigned long long w;
+                do {
+                    w = __hip_atomic_load(state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((unsigned)(w >> 32) != epoch);
+                v = (unsigned)w;
+            }
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            sum += v;
+        }
+        if (lane == 0) s_prefix = sum;
+    }
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    if (keep) {
+        akz_match o;
+        o.index_0 = i; o.index_1 = min_j; o.distance = (double)min_d;
+        out[prefix + below + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = o;
+    }
+    if (b == gridDim.x - 1 && tid == 0) *n_out = (unsigned long long)prefix + total;
+}
+
 inline dim3 grid2d(uint32_t w, uint32_t h, uint32_t n) { return dim3((w + BX - 1) / BX, (h + BY - 1) / BY, n); }
 
 }  // namespace
@@ -1204,6 +1266,12 @@ void match(hipStream_t s, const uint8_t* d0, uint32_t n0, const uint8_t* d1, uin
     const uint32_t chunk_rows = ((tiles + chunks - 1) / chunks) * MT;
     hipLaunchKernelGGL(k_match, dim3((n0 + MT - 1) / MT, chunks), dim3(MT), 0, s, reinterpret_cast<const uint4*>(d0), n0,
                        reinterpret_cast<const uint4*>(d1), n1, chunk_rows, threshold, rows_le_61 ? 0xffu : 0xffffffffu, d_rec);
+}
+size_t match_merge_compact_state_bytes(uint32_t n0) { return ((size_t)(n0 + 255) / 256 + 1) * sizeof(unsigned long long); }
+void match_merge_compact(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, double ratio2,
+                         akz_match* d_out, unsigned long long* d_n_out, void* d_state, uint32_t epoch) {
+    hipLaunchKernelGGL(k_match_merge_compact, dim3((n0 + 255) / 256), dim3(256), 0, s, d_part, n0, chunks, threshold, ratio2, d_out,
+                       d_n_out, (unsigned long long*)d_state, epoch);
 }
 void match_merge(hipStream_t s, const MatchRec* d_part, uint32_t n0, uint32_t chunks, uint32_t threshold, MatchRec* d_out) {
     hipLaunchKernelGGL(k_match_merge, dim3((n0 + 255) / 256), dim3(256), 0, s, d_part, n0, chunks, threshold, d_out);

@@ -28,9 +28,11 @@ def measure():
         ctx.extract_begin(frame, cfg).finish().close()
     torch.cuda.synchronize()
     reps = 100
+    for _ in range(5):
+        ctx.extract_features(frame, cfg).close()
     t = time.perf_counter()
     for _ in range(reps):
-        ctx.extract_begin(frame, cfg).finish().close()
+        ctx.extract_features(frame, cfg).close()          # the synchronous entry point (akz_extract_device_*)
     lat = (time.perf_counter() - t) / reps
     t = time.perf_counter(); prev = None
     for _ in range(reps):
@@ -52,5 +54,5 @@ for rnd in range(3):
         r = ctx.extract_begin(frame, cfg).finish()
         sig = (r.keypoints(0).tobytes(), r.descriptors(0).tobytes()); r.close()
         ref = ref or sig
-        print(f"{NF}x{W}x{H} {name:22s} latency {lat*1e3:.3f} ms  streamed {thr*1e3:.3f} ms/frame  begin: host {hb*1e3:.3f} ms, GPU idle after {gb*1e3:.3f} ms  same={sig == ref}", flush=True)
+        print(f"{NF}x{W}x{H} {name:22s} sync call {lat*1e3:.3f} ms  streamed {thr*1e3:.3f} ms/frame  begin: host {hb*1e3:.3f} ms, GPU idle after {gb*1e3:.3f} ms  same={sig == ref}", flush=True)
 print(ctx.get_profile()["placement"])

@@ -10,9 +10,9 @@ def show(sel):
     for r in sel:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         print(f"{(s - t0) / 1e3:8.1f} {(e - s) / 1e3:8.1f} {nm(r)[:56]:56s} wgs={int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])} x {r['Workgroup_Size_X']}")
-firsts = [i for i, r in enumerate(rows) if nm(r).startswith("k_unpack_bits")]
-a = firsts[2 * 15]  # the 16th pair call (two unpack launches per call)
+firsts = [i for i, r in enumerate(rows) if nm(r).startswith("k_unpack_pair")]
+a = firsts[-1]  # the last pair call: unpack, scan, merge + compaction
 print("pair call:")
-show(rows[a:a + 6])
+show(rows[a:a + 3])
 print("multi-set call:")
 show(rows[-5:])

@@ -120,6 +120,60 @@ __device__ __forceinline__ void unpack_row(unsigned row, unsigned lane, const ui
     }
 }
 
+// The FP4 form with FOUR rows per wave: 16 lanes per row, a lane expands one u32 of the row (four descriptor bytes) into 32
+// e2m1 codes (one 16-byte store) -- a quarter of the waves of unpack_row and word-wide loads (the pair call's unpack launch
+// 9.7 -> 5 us).  Same bytes out as unpack_row(fp4): bit 1 -> 0x2 (+1.0), bit 0 -> 0xA (-1.0) for bytes 0..60, zero beyond.
+__device__ __forceinline__ unsigned fp4_codes_of_byte(unsigned b) {  // bit i of b -> nibble i
+    unsigned x = (b | (b << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return 0xAAAAAAAAu ^ (x << 3);
+}
+__device__ __forceinline__ void unpack_rows_fp4(unsigned row, unsigned sub, const uint8_t* __restrict__ d, unsigned n, unsigned n_pad,
+                                                uint8_t* __restrict__ out, unsigned* __restrict__ pop, unsigned* __restrict__ bound,
+                                                unsigned threshold, unsigned n_bound, const uint2* __restrict__ tiles) {
+    if (row >= n_pad) return;  // (whole 16-lane groups leave together)
+    unsigned src = row;
+    bool live = row < n;
+    if (tiles) {
+        const uint2 e = tiles[row / MM_TR];
+        const unsigned local = row % MM_TR;
+        live = local < e.y;
+        src = e.x + local;
+    }
+    unsigned word = live ? reinterpret_cast<const unsigned*>(d + (size_t)src * 64)[sub] : 0u;
+    if (sub == 15u) word &= 0xffu;  // bytes 61..63 are padding: never compared (feature_matching.rs works on the 61 bytes)
+    unsigned c = __popc(word);
+    for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 16);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (live) {
+        v.x = fp4_codes_of_byte(word & 0xffu);
+        if (sub < 15u) {
+            v.y = fp4_codes_of_byte((word >> 8) & 0xffu);
+            v.z = fp4_codes_of_byte((word >> 16) & 0xffu);
+            v.w = fp4_codes_of_byte(word >> 24);
+        }
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)row * (KB / 2) + 16 * sub) = v;
+    if (sub == 0) {
+        pop[row] = c;
+        if (bound)
+            for (unsigned k = 0; k < n_bound; ++k) bound[(size_t)k * n_pad + row] = threshold;
+    }
+}
+__global__ void __launch_bounds__(256) k_unpack_bits_fp4(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, uint8_t* __restrict__ out,
+                                                         unsigned* __restrict__ pop, unsigned* __restrict__ bound, unsigned threshold,
+                                                         unsigned n_bound, const uint2* __restrict__ tiles) {
+    unpack_rows_fp4(blockIdx.x * 16 + (threadIdx.x >> 4), threadIdx.x & 15u, d, n, n_pad, out, pop, bound, threshold, n_bound, tiles);
+}
+__global__ void __launch_bounds__(256) k_unpack_pair_fp4(const uint8_t* __restrict__ dq, unsigned nq, unsigned q_pad, uint8_t* __restrict__ outq,
+                                                         unsigned* __restrict__ popq, unsigned* __restrict__ bound, unsigned threshold,
+                                                         const uint8_t* __restrict__ dt, unsigned nt, unsigned t_pad, uint8_t* __restrict__ outt,
+                                                         unsigned* __restrict__ popt) {
+    const unsigned row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15u;  // (q_pad is a multiple of 16: a group is all query or all train)
+    if (row < q_pad) unpack_rows_fp4(row, sub, dq, nq, q_pad, outq, popq, bound, threshold, 1u, nullptr);
+    else unpack_rows_fp4(row - q_pad, sub, dt, nt, t_pad, outt, popt, nullptr, 0u, 0u, nullptr);
+}
 __global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ d, unsigned n, unsigned n_pad, bool query,
                                                      uint8_t* __restrict__ out, unsigned* __restrict__ pop,
                                                      unsigned* __restrict__ bound, unsigned threshold, unsigned n_bound,
@@ -856,11 +910,21 @@ uint32_t match_mfma_chunks(uint32_t n0, uint32_t n1, uint32_t forced) {
 }
 void unpack_bits(hipStream_t s, const uint8_t* d, uint32_t n, uint32_t n_pad, bool query, uint8_t* out8, uint32_t* pop,
                  uint32_t* bound, uint32_t threshold, uint32_t n_bound, const uint32_t* d_tiles, bool fp4) {
+    if (fp4) {
+        hipLaunchKernelGGL(k_unpack_bits_fp4, dim3((n_pad + 15) / 16), dim3(256), 0, s, d, n, n_pad, out8, pop, bound, threshold, n_bound,
+                           reinterpret_cast<const uint2*>(d_tiles));
+        return;
+    }
     hipLaunchKernelGGL(k_unpack_bits, dim3((n_pad + 3) / 4), dim3(256), 0, s, d, n, n_pad, query, out8, pop, bound, threshold,
                        n_bound, reinterpret_cast<const uint2*>(d_tiles), fp4);
 }
 void unpack_pair(hipStream_t s, const uint8_t* dq, uint32_t nq, uint32_t q_pad, uint8_t* outq, uint32_t* popq, uint32_t* bound, uint32_t threshold,
                  const uint8_t* dt, uint32_t nt, uint32_t t_pad, uint8_t* outt, uint32_t* popt, bool fp4) {
+    if (fp4 && q_pad % 16 == 0) {
+        hipLaunchKernelGGL(k_unpack_pair_fp4, dim3((q_pad + t_pad + 15) / 16), dim3(256), 0, s, dq, nq, q_pad, outq, popq, bound, threshold,
+                           dt, nt, t_pad, outt, popt);
+        return;
+    }
     hipLaunchKernelGGL(k_unpack_pair, dim3((q_pad + t_pad + 3) / 4), dim3(256), 0, s, dq, nq, q_pad, outq, popq, bound, threshold, dt, nt,
                        t_pad, outt, popt, fp4);
 }

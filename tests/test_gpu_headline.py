@@ -87,3 +87,27 @@ def test_pair_4k_host_batch_then_match_features(ctx, amd, ref):
     exp = ref.remove_outliers(q[0].keypoints(), q[1].keypoints(), raw, 1000, 0.05, 3.0)
     assert np.array_equal(got, exp) and 8 <= len(got) <= len(raw)
     rp.close()
+
+
+@pytest.mark.parametrize("w,h,n", [(2016, 1512, 1), (1920, 1080, 2), (1920, 1080, 3), (3840, 2160, 1), (1600, 1200, 1)])
+def test_job_size_gates_both_entry_points(ctx, amd, ref, w, h, n):
+    """Jobs between 3 and 8 Mpx take different kernel families by ENTRY POINT (akz_api.cpp, AKZ_BIG_PX_SYNC / _ASYNC): a
+    synchronous call (akz_extract_device_*) takes the batch path -- column marches on its full-resolution launches, forked
+    coarse chain, resident tail -- from 6 Mpx, a job of the begin / finish interface from 3 Mpx; 1600 x 1200 (1.9 Mpx) stays on
+    the tiled chain either way.  Both must equal the oracle, planes included (lib.rs:167-194)."""
+    import torch
+    frames = np.stack([amd.synth_frame(w, h, 40 + i) for i in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    sync = ctx.extract_features(d, keep_all_planes=True)
+    asyn = ctx.extract_begin(d, amd.Config(), keep_all_planes=True).finish()
+    for img in range(n):
+        rf = ref.extract(frames[img], threads=8)
+        L = rf.num_levels
+        for res in (sync, asyn):
+            assert_same_result(res, rf, planes=False, img=img)
+            _planes_equal(res, rf, img, [(0, "Lt"), (1, "Lflow"), (2, "Lsmooth"), (3, "Ldet"), (3, "Lxx"), (4, "Lt"), (5, "Lstep"),
+                                         (7, "Ly"), (8, "Lt"), (L - 1, "Lt"), (L - 1, "Ldet"), (L - 2, "Lflow")])
+        rf.close()
+    sync.close()
+    asyn.close()

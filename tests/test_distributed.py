@@ -197,3 +197,20 @@ def test_bench_launcher_fails_when_a_rank_fails():
     p = _bench("--gpus", "2", "--stub", "--frames", "0")  # zero frames: every rank raises
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_rank_gives_up_when_a_peer_never_arrives():
+    """A rank whose peers never reach the rendezvous (a crashed process, a GPU that did not initialise) ends with an error
+    after AKZ_BENCH_RENDEZVOUS_S seconds instead of waiting for the default half hour -- on a real node that is the
+    difference between a failed run and a hung one."""
+    import socket
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    t0 = time.monotonic()
+    p = _bench("--gpus", "2", "--stub", "--steps", "2", "--warmup", "1",
+               env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "AKZ_BENCH_RENDEZVOUS_S": "8"}, timeout=120)
+    assert p.returncode != 0 and time.monotonic() - t0 < 90
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

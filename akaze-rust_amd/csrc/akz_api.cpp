@@ -1481,7 +1481,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // list is read.  (Running two BIG kernels side by side is a loss -- see above -- so the fork is at octave 2.)
     const int fork_octave = c->sched[3] > 0 ? c->sched[3] : 2;  // (forking at octave 3 instead, octave 2 on the main stream: -4 %; sched[3]: measurement)
     // (a lone 1080p frame is a chain of dependent launches either way and only pays for the two events: measured
-    // 0.596 -> 0.625 ms per streamed frame; batches from 8 Mpx on fork)
+    // 0.596 -> 0.625 ms per streamed frame; batch-path jobs (AKZ_BIG_PX_SYNC / _ASYNC) fork)
     const uint64_t fork_min_px = c->big_px;
     hipStream_t ls = s;  // the stream the level loop enqueues on
     size_t fork_level = L;  // first level of the coarse chain
@@ -2261,7 +2261,7 @@ int akz_extract_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t
     return extract_impl<float>(c, d_imgs, w, h, n, cfg, flags, out);
 }
 
-// lanes = 1 (default): every job runs on the context's own stream.  lanes = k > 1: jobs below 8 Mpx are dealt to k child
+// lanes = 1 (default): every job runs on the context's own stream.  lanes = k > 1: jobs below the batch-path gate (3 Mpx) are dealt to k child
 // contexts in turn (larger jobs fill the chip on their own and stay on the context).  A job's result belongs to the
 // lane it ran on; nothing else changes for the caller (same begin / finish / result calls, bit-identical results).
 int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
@@ -2309,7 +2309,7 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
 }
 // on != 0: the finish half of every job that is dealt to a lane starts on the lane's own thread as soon as the job has
 // been begun; akz_extract_finish waits for it and hands the result over (bit-identical; errors of the finish half are
-// reported there as before).  Jobs that stay on the context itself (no lanes, or 8 Mpx and more) are not affected.
+// reported there as before).  Jobs that stay on the context itself (no lanes, or batch-path jobs) are not affected.
 int akz_ctx_set_eager_finish(akz_ctx* c, int on) {
     AKZ_TRY(bind(c));
     c->eager_finish = on != 0;

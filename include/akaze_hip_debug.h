@@ -33,7 +33,7 @@ int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_
    stream of their own (a fifth busy stream), 3 = the context's stream (no running ahead); key 1: they are held back until
    the batch before has finished its fine-level diffusion (1, default) or start at once (0); key 2: 1 = no placement probe;
    key 3: octave at which the coarse chain forks (0 = default 2); key 4: the job size in thousands of pixels (w*h*n) from
-   which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (8 000). */
+   which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (6 000 for a synchronous call, 3 000 for a job of the begin / finish interface). */
 int akz_debug_set_schedule(akz_ctx* ctx, int key, int value);
 /* What the stream-placement probe of the context's first large batch found: info[0] = it has run, info[1] = early stages on
    the context's stream (0) or the copy stream (2), info[2] = streams it re-created because they shared a hardware queue
@@ -51,7 +51,7 @@ int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float ti
 int akz_debug_set_host_sort(akz_ctx* ctx, int on);
 /* Test hook: how the host's keypoint selection finds "the first cache entry within size": 1 = from the device's neighbour
    lists (k_relations; needs the device sort, which it switches on), 0 = from the host's spatial grids, -1 = automatic (the
-   default: neighbour lists for contexts with fewer than four host threads and for jobs below 8 Mpx).  Results are
+   default: neighbour lists for contexts with fewer than four host threads, for jobs that do not take the batch path and for images of 6 Mpx and more).  Results are
    identical. */
 int akz_debug_set_select(akz_ctx* ctx, int mode);
 

@@ -145,6 +145,12 @@ def parse_args(argv=None):
     ap.add_argument("--match-ctx", choices=["shared", "own"], default="shared",
                     help="--workload c5: the all-pairs launches on the extraction context's stream (shared) or on a context and "
                          "stream of their own (own: they run beside the next steps' extraction kernels)")
+    ap.add_argument("--no-c5-leg", action="store_true",
+                    help="N > 1: skip the extra leg that runs BASELINE configs[4] (4K frames, 5 x 5, exchange + all-pairs match) over "
+                         "all ranks after the headline measurement")
+    ap.add_argument("--c5-leg-frames", type=int, default=4, help="3840x2160 frames per rank in that leg")
+    ap.add_argument("--c5-leg-timeout", type=int, default=180,
+                    help="seconds after which the leg is given up: rank 0 prints the line without it and every rank exits 0")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a ONE-GPU box: every rank runs on device 0 (real extraction ranks, "
                          "real rendezvous, capacity agreement and pipelined retire); the descriptor rows travel D2H -> gloo "
@@ -1370,6 +1376,72 @@ def main_rank(args):
             "stream_5x5_all_pairs": c5_leg,
             "match": match_leg,
         }
+    # ---- N > 1: BASELINE configs[4] over ALL ranks as an extra leg (own clock, after the headline figures are complete): 4K
+    # frames, 5 octaves x 5 sublevels, frame f on rank f mod N, descriptors stay on the device; per step extraction -> exchange
+    # (akz_gather_begin) -> akz_match_all_pairs -> totals of every held list read.  Un-pipelined (one step at a time): the figure
+    # of `--workload c5`, which pipelines the steps, is higher.  The driver's `bench.py --gpus N` thereby measures configs[4]
+    # too.  A watchdog guards the headline: if the leg does not finish, rank 0 prints the line without it and every rank exits 0.
+    leg = None
+    if world > 1 and not stub and not c5 and not args.no_c5_leg and xch["comm"] is not None and exchange in ("capi", "external"):
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["config"]["all_pairs_c5_leg"] = {"error": f"given up after {args.c5_leg_timeout} s; the figures above were complete before it began"}
+                print(json.dumps(out), file=json_out, flush=True)
+            os._exit(0)
+        wd = threading.Timer(args.c5_leg_timeout, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            n5, W5, H5, steps5 = max(1, args.c5_leg_frames), 3840, 2160, 3
+            cfg55 = A.Config(num_sublevels=5, max_octave_evolution=5)
+            d5 = torch.from_numpy(np.stack([A.synth_frame(W5, H5, i) for i in A.shard_frames(world * n5, rank, world)])).to(dev)
+            torch.cuda.synchronize()
+            ctx.set_profiling(0)
+
+            def extract5():
+                return ctx.extract_begin(d5, cfg55, keep_all_planes=not args.lean, input_ready=True, host_descriptors=False).finish()
+            r5 = extract5()
+            rows5 = sum(r5.counts(i)[1] for i in range(r5.num_images))
+            r5.close()
+            most = int(host_max(float(rows5)))
+            cap5 = max(1024, (most + most // 4 + 4095) // 4096 * 4096)
+
+            def step5():
+                r_ = extract5()
+                g_ = xch["comm"].gather_begin([r_], cap5)
+                if exchange == "external":
+                    g_.exchange_over()
+                r_.close()
+                p_ = g_.match_all_pairs(ctx)
+                tot = p_.totals()  # waits for the launches, reads every held list's count
+                n_img = p_.n_images
+                p_.free()
+                g_.free()
+                return tot, n_img
+            step5()
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(steps5):
+                tot5, n_img5 = step5()
+            barrier()
+            el5 = host_max(time.perf_counter() - t5)
+            dist5, match5 = host_sum(float(tot5[2])), host_sum(float(tot5[1]))
+            lists5 = host_allgather(float(tot5[0]))
+            leg = {"workload": f"BASELINE configs[4] over {world} ranks: {n5} 3840x2160 frames per rank per step, 5 octaves x 5 sublevels, "
+                               "descriptors on the device; extraction -> exchange -> akz_match_all_pairs -> totals read, one step at a "
+                               "time (un-pipelined; `--workload c5` pipelines)",
+                   "Mpix_s": round(float(W5) * H5 * n5 * world * steps5 / el5 / 1e6, 1), "ms_per_step": round(el5 / steps5 * 1e3, 2),
+                   "images_per_step": int(n_img5), "unordered_image_pairs_per_step": int(n_img5) * (int(n_img5) - 1) // 2,
+                   "Tdistances_per_s": round(dist5 * steps5 / el5 / 1e12, 3), "matches_per_step": int(match5),
+                   "match_lists_held_per_rank": [int(v) for v in lists5], "transport": exchange}
+            del d5
+        except Exception as e:  # (a failure on one rank leaves the others in a collective: the watchdog ends them)
+            leg = {"error": str(e)[:300]}
+        wd.cancel()
+    if rank == 0:
+        out["config"]["all_pairs_c5_leg"] = leg
         print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()  # rank 0 may still be in its untimed extra legs: all ranks leave together

@@ -274,9 +274,14 @@ def test_bench_two_real_ranks_share_one_gpu():
     the exchange, rank pinning before HIP starts); the rows travel over gloo because RCCL refuses two ranks on one
     device.  Frame i of the job lives on rank i mod 2: every frame's keypoints + descriptors must equal what ONE rank
     computes for the same global frames."""
-    two = _bench_json(["--gpus", "2", "--share-gpu", "--frames", "2"])
+    two = _bench_json(["--gpus", "2", "--share-gpu", "--frames", "2", "--c5-leg-frames", "2"])
     one = _bench_json(["--gpus", "1", "--frames", "4"])
     assert two["n_gpus"] == 2 and two["config"]["share_gpu"] is True and "rehearsal" in two
+    # the default N > 1 run also measures BASELINE configs[4] over all ranks (extra leg, own clock)
+    leg = two["config"]["all_pairs_c5_leg"]
+    assert leg["images_per_step"] == 4 and leg["unordered_image_pairs_per_step"] == 6 and leg["Mpix_s"] > 0
+    assert sum(leg["match_lists_held_per_rank"]) == 12 and leg["matches_per_step"] > 0 and leg["transport"] == "external"
+    assert one["config"]["all_pairs_c5_leg"] is None
     assert two["config"]["exchange_ranks_seen"] == 2
     assert len(two["config"]["per_rank_Mpix_s"]) == 2 and all(v > 0 for v in two["config"]["per_rank_Mpix_s"])
     assert two["self_check"]["identical_to_single_frame_extraction"] is True

@@ -36,6 +36,9 @@ namespace {
 constexpr int TW = 64, TH = 32, NT = 512;
 // k_deriv2 keeps the common tile height: 64 x 30 / 64 x 28 tiles (fewer loads per thread at sigma 4) measured the same
 constexpr int deriv2_tile_h(int) { return TH; }
+// k_detector_tiled: its two LDS buffers grow with sigma_size -- 51.4 / 54.7 / 58.1 KB at S = 2 / 3 / 4 with 64 x 32 tiles, i.e.
+// TWO workgroups per CU from S = 3 on (160 KB of LDS).  Tiles of 30 / 28 rows keep them under 53.3 KB: three per CU.
+constexpr int det_tile_h(int S) { return S <= 2 ? TH : (S == 3 ? 30 : 28); }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -165,11 +168,15 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
     constexpr int BW = TW + 2, BH = TH + 2;  // Lsmooth,   origin (x0-1, y0-1)
     constexpr int CH = TH + 2;               // H_scharr,  origin (x0,   y0-1), width TW
     constexpr int NLOAD = (IH * IW + NT - 1) / NT;
+    // The Scharr H-pass windows take the place of the windows that are dead by then (the input window after the first pass,
+    // H_g after the second; a barrier lies between every pass): 28.3 KB instead of 45.7, i.e. FOUR 512-thread workgroups per
+    // CU instead of three -- the 1 020 tiles of a lone 1080p level run as one round instead of one and a third.
+    static_assert(CH * TW <= IH * IW && CH * TW <= AH * AW, "the Scharr windows fit the windows they alias");
     __shared__ float sI[IH * IW];
     __shared__ float sA[AH * AW];
     __shared__ float sB[BH * BW];
-    __shared__ float sM[CH * TW];
-    __shared__ float sO[CH * TW];
+    float* const sM = sI;
+    float* const sO = sA;
     const int tid = threadIdx.x;
     const int ntiles = tg.tx * tg.ty * tg.n;
     float regs[NLOAD];
@@ -735,11 +742,12 @@ template <int S, bool NMS, bool KEEP>
 __global__ void __launch_bounds__(NT)
 k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
     constexpr int R = NMS ? 1 : 0;
-    constexpr int W0W = TW + 2 * R + 4 * S, W0H = TH + 2 * R + 4 * S;  // Lsmooth, origin (x0-R-2S, y0-R-2S)
+    constexpr int DTH = det_tile_h(S);                                  // tile height (see det_tile_h)
+    constexpr int W0W = TW + 2 * R + 4 * S, W0H = DTH + 2 * R + 4 * S;  // Lsmooth, origin (x0-R-2S, y0-R-2S)
     constexpr int H1W = TW + 2 * R + 2 * S, H1H = W0H;                 // Hm, Ho,   origin (x0-R-S,  y0-R-2S)
-    constexpr int W2W = H1W, W2H = TH + 2 * R + 2 * S;                 // Lx, Ly,   origin (x0-R-S,  y0-R-S)
+    constexpr int W2W = H1W, W2H = DTH + 2 * R + 2 * S;                // Lx, Ly,   origin (x0-R-S,  y0-R-S)
     constexpr int H2W = TW + 2 * R, H2H = W2H;                         // A, B, C,  origin (x0-R,    y0-R-S)
-    constexpr int DW = H2W, DH = TH + 2 * R;                           // Ldet,     origin (x0-R,    y0-R)
+    constexpr int DW = H2W, DH = DTH + 2 * R;                          // Ldet,     origin (x0-R,    y0-R)
     constexpr int PSZ = (W0W * W0H > 2 * W2W * W2H) ? W0W * W0H : 2 * W2W * W2H;
     constexpr int QSZ = (2 * H1W * H1H > 3 * H2W * H2H) ? 2 * H1W * H1H : 3 * H2W * H2H;
     static_assert(DW * DH <= PSZ, "Ldet window must fit in the buffer it aliases");
@@ -767,7 +775,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
     auto issue = [&](int tile) {
         const DetLevel& dl = ds.lv[level_of(tile)];
         const int w = dl.w, h = dl.h;
-        const Tile tl = decode_tile(tile - dl.tile0, dl.tg, w, h);
+        const Tile tl = decode_tile<DTH>(tile - dl.tile0, dl.tg, w, h);
         const float* src = dl.ls + (size_t)tl.bz * (size_t)w * (size_t)h;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
@@ -790,7 +798,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         const DetLevel& dl = ds.lv[level_of(tile)];
         const int w = dl.w, h = dl.h;
-        const Tile tl = decode_tile(tile - dl.tile0, dl.tg, w, h);
+        const Tile tl = decode_tile<DTH>(tile - dl.tile0, dl.tg, w, h);
         const int x0 = tl.x0, y0 = tl.y0;
         const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
         float* const lx_out = dl.lx;
@@ -822,7 +830,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
             const float vy = tap_main(sHo[o - S * H1W], sHo[o], sHo[o + S * H1W], kn, kwn);
             sLx[idx] = vx;
             sLy[idx] = vy;
-            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + TH) {
+            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
                 const size_t gi = base + (size_t)y * w + x;
                 lx_out[gi] = vx;
                 ly_out[gi] = vy;
@@ -855,7 +863,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
             const float lxy = tap_main(sC[o - S * H2W], sC[o], sC[o + S * H2W], kn, kwn);
             const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
             if (NMS) sD[idx] = det;
-            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + TH) {
+            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
                 const size_t gi = base + (size_t)y * w + x;
                 if (KEEP) {
                     lxx_out[gi] = lxx;
@@ -867,7 +875,7 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
         }
         __syncthreads();
         if (NMS) {
-            tile_extrema<DW>(sD, sCnt, tid, tl, w, h, ds.thr, dl.border_m, dl.level, ds.cand, ds.cap, ds.count);
+            tile_extrema<DW, DTH>(sD, sCnt, tid, tl, w, h, ds.thr, dl.border_m, dl.level, ds.cand, ds.cap, ds.count);
             __syncthreads();  // sD (= sP) is overwritten by the next iteration
         }
     }
@@ -1001,7 +1009,7 @@ void detector_tiled_set(hipStream_t s, uint32_t sigma, const DetLevelDesc* level
         DetLevel& o = ds.lv[i];
         o.ls = d.lsmooth; o.lx = d.lx; o.ly = d.ly; o.lxx = d.lxx; o.lyy = d.lyy; o.lxy = d.lxy; o.ldet = d.ldet;
         o.w = (int)d.w; o.h = (int)d.h;
-        o.tg = plan_tiles(d.w, d.h, n).tg;
+        o.tg = plan_tiles(d.w, d.h, n, det_tile_h((int)sigma)).tg;
         o.tile0 = (int)total;
         o.level = d.level;
         o.border_m = d.border_m;

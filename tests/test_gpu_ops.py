@@ -406,6 +406,33 @@ def test_descriptor_match_chunked_large(mctx, ref):
     assert 1 not in got["index_0"] and 3 not in got["index_0"]
 
 
+@pytest.mark.parametrize("n0,n1", [(2048, 300), (2049, 4097), (11264, 2500), (30001, 777)])
+def test_descriptor_match_large_query_sets_one_launch_epilogue(mctx, ref, n0, n1):
+    """Query sets of 2 048 rows and more take k_match_merge_compact: the merge of the chunk records, the ratio test and the
+    ORDERED compaction in one launch of many workgroups (a look-back over the workgroups' counts, told apart from the counts
+    of earlier calls by an epoch).  Sizes on both sides of the 256-row workgroups, accepted matches in some workgroups only
+    (so that most counts are zero), exact duplicates across chunks, and the same call twice (the state words of the first
+    call must read as "not yet published" in the second): identical to the oracle's sequential scan
+    (feature_matching.rs:37-81), in every matcher kernel."""
+    ctx = mctx
+    rng = np.random.default_rng(n0 * 31 + n1)
+    d0 = rng.integers(0, 256, (n0, 61), dtype=np.uint8)
+    d1 = rng.integers(0, 256, (n1, 61), dtype=np.uint8)
+    hot = np.concatenate([np.arange(0, min(n0, 300)), np.arange(n0 // 2, min(n0, n0 // 2 + 700)), np.arange(max(0, n0 - 5), n0)])
+    for i in hot[::2]:   # near-duplicates: these queries pass the ratio test; the workgroups in between accept nothing
+        j = int((i * 13 + 5) % n1)
+        d1[j] = d0[i]
+        d1[j, int(i % 61)] ^= 0x5
+    if n1 > 600:
+        d1[7] = d0[hot[1]]; d1[n1 - 3] = d0[hot[1]]   # an exact tie far apart: lowest index wins, the ratio test rejects it
+    for ratio, thr in ((0.86, 10000), (0.95, 30)):
+        exp = ref.descriptor_match(d0, d1, thr, ratio)
+        got = ctx.descriptor_match(d0, d1, thr, ratio)
+        again = ctx.descriptor_match(d0, d1, thr, ratio)
+        assert np.array_equal(got, exp) and np.array_equal(again, exp), (ratio, thr, len(got), len(exp))
+    assert len(ref.descriptor_match(d0, d1, 10000, 0.86)) > 50
+
+
 def test_device_match_ignores_padding_bytes_in_both_kernels(ctx, ref):
     """akz_descriptor_match_device takes 64-byte rows of which an M-LDB descriptor uses 61: bytes 61..63 are padding and
     must not be compared by EITHER kernel (popcount and matrix-core), whatever they hold."""

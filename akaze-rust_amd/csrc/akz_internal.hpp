@@ -132,7 +132,7 @@ struct LevelPtrs {  // device addresses of the planes one kernel needs, image 0 
     uint64_t stride;  // elements between consecutive images
 };
 constexpr int kMaxLevels = 64;
-constexpr int kRel1 = 6, kRel2 = 4;  // neighbour lists of the keypoint selection (akz_sort.hip, k_relations)
+constexpr int kRel1 = 12, kRel2 = 4;  // neighbour lists of the keypoint selection (akz_sort.hip, k_relations): 32-byte rows.  Six earlier neighbours overflowed on a third of a 4K frame's fine-level candidates -- the host then scans the partner levels itself -- : host selection 0.79 -> 0.45 ms per 4K frame with twelve (nine suffice; sixteen give nothing more)
 struct LevelTable {
     LevelPtrs lv[kMaxLevels];
 };

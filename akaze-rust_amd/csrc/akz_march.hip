@@ -1090,15 +1090,7 @@ static void launch_detector_march(hipStream_t s, const float* lsmooth, float* lx
 #ifndef AKZ_DET_MINROWS
 #define AKZ_DET_MINROWS 64
 #endif
-#ifndef AKZ_DET_SMALL_ROWS
-#define AKZ_DET_SMALL_ROWS 64
-#endif
-#ifndef AKZ_DET_SMALL_PX
-#define AKZ_DET_SMALL_PX (12u << 20)
-#endif
-    // (a lone 4K frame is 8 strips: at 64 rows per band 264 workgroups, one per CU)
-    const int min_rows = (uint64_t)w * h * n < (uint64_t)AKZ_DET_SMALL_PX ? AKZ_DET_SMALL_ROWS : AKZ_DET_MINROWS;
-    const MarchGrid mg = plan_march(w, h, n, S, &gr, AKZ_DET_FILL, min_rows);
+    const MarchGrid mg = plan_march(w, h, n, S, &gr, AKZ_DET_FILL, AKZ_DET_MINROWS);
     if (w & 1u)
         hipLaunchKernelGGL((k_detector_march<S, NMS, KEEP, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out,
                            (int)w, (int)h, mg, kn, kwn, quat, na);
@@ -1190,13 +1182,7 @@ void contrast_march(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint
 #ifndef AKZ_LVL_FILL
 #define AKZ_LVL_FILL 3
 #endif
-#ifndef AKZ_LVL_SMALL_ROWS
-#define AKZ_LVL_SMALL_ROWS 40
-#endif
-static int level_min_band_rows(uint32_t w, uint32_t h, uint32_t n) {
-    const uint64_t px = (uint64_t)w * h * n;
-    return px < (12u << 20) ? AKZ_LVL_SMALL_ROWS : px < (48u << 20) ? 40 : 64;
-}
+static int level_min_band_rows(uint32_t w, uint32_t h, uint32_t n) { return (uint64_t)w * h * n < (48u << 20) ? 40 : 64; }
 // Test hook (CPU): the bands the planners cut an n-image batch of w x h into -- kind 0: detector / blur march with
 // kernel half width S, kind 1: level march.  Writes up to cap [cs, ce) pairs, returns the number of bands.
 uint32_t march_band_rows(int kind, uint32_t w, uint32_t h, uint32_t n, int S, int32_t* cs_ce, uint32_t cap) {

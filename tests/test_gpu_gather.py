@@ -174,6 +174,50 @@ def test_bench_c5_workload_two_ranks_sharing_one_gpu():
     assert one["config"]["all_pairs"]["matches_per_step"] == ap["matches_per_step"]
 
 
+def test_external_transport_single_rank_and_its_error_paths(ctx, amd):
+    """akz_comm_create_external (the caller carries the blocks): a gather may not be finished, waited for or matched before
+    akz_gather_deliver; the synchronous two-collective form is refused; with the one rank's block copied into place the
+    exchange gives the local rows back and akz_match_all_pairs equals pairwise descriptor_match."""
+    import torch
+    comm = amd.Comm(0, None, 0, 1)
+    assert comm.external
+    frames = torch.from_numpy(np.stack([amd.synth_frame(320, 240, i) for i in range(3)])).cuda()
+    res = ctx.extract_features(frames, keep_all_planes=False)
+    rows = sum(res.counts(i)[1] for i in range(3))
+    local = torch.zeros((rows, 64), dtype=torch.uint8, device="cuda")
+    res.copy_device_descriptors(local)
+    with pytest.raises(amd.AkazeError) as e:
+        comm.gather_descriptors(local)
+    assert e.value.status < 0 and "akz_comm_create" in str(e.value)
+    g = comm.gather_begin([res], rows + 8)
+    for call in (lambda: g.finish(), lambda: g.stream_wait(torch.cuda.current_stream().cuda_stream), lambda: g.match_all_pairs(ctx)):
+        with pytest.raises(amd.AkazeError) as e:
+            call()
+        assert "deliver" in str(e.value)
+    send, recv, nbytes = g.blocks()
+    assert nbytes == (1 + rows + 8) * 64
+    amd.copy_d2d(recv, send, nbytes)
+    g.deliver()
+    p, block_rows, cnt, img = g.finish()
+    assert block_rows == rows + 9 and cnt == [rows] and img == [3]
+    out = torch.empty((rows, 64), dtype=torch.uint8, device="cuda")
+    amd.copy_d2d(out.data_ptr(), p + 64, rows * 64)
+    assert torch.equal(out, local)
+    pairs = g.match_all_pairs(ctx)
+    for q in range(3):
+        for j in range(3):
+            if q != j:
+                assert np.array_equal(pairs.matches(q, j), ctx.descriptor_match(res.descriptors(q), res.descriptors(j), 10000, 0.86)), (q, j)
+    lists, matches, dists = pairs.totals()
+    assert lists == 6 and matches == pairs.total_matches() and dists == sum(res.counts(a)[1] * res.counts(b)[1] for a in range(3) for b in range(a + 1, 3))
+    pairs.free()
+    g.free()
+    g2 = comm.gather_begin([res], rows + 8)   # never delivered: freeing it and closing the communicator must not wait
+    g2.free()
+    res.close()
+    comm.close()
+
+
 def test_pairs_outlive_their_communicator(ctx, amd):
     """Lifetime rule of akz_pairs (include/akaze_hip.h): a result that is still held when its communicator is destroyed
     stays readable and is freed afterwards without touching the communicator (round-4 advice: akz_pairs_free pushed the

@@ -166,7 +166,7 @@ struct akz_ctx {
     // placement probe found it a queue and a pipe of its own (below), 1 the copy stream regardless, 2 a stream of their own
     // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
     // has finished its fine-level diffusion (default) or not; [2] no placement probe
-    int sched[6] = {0, 1, 0, 0, 0, 0};  // [5] (measurement): 1 = blur / contrast / detector launches keep the 8 Mpx march threshold inside small batch-path jobs
+    int sched[5] = {0, 1, 0, 0, 0};
     uint64_t big_px = AKZ_BIG_PX_ASYNC;  // the gate of the job being begun (set by extract_begin from the two below; the begin half's helpers read it)
     uint64_t big_px_sync = AKZ_BIG_PX_SYNC, big_px_async = AKZ_BIG_PX_ASYNC;  // (sched[4] sets both: measurement)
     // pixels per LAUNCH (level w*h*n) from which the blur, the contrast passes and the detectors take their column-march
@@ -1428,7 +1428,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     } stream_restore{c, s};
     bool early = false;
     const bool big = (uint64_t)w * h * n >= c->big_px;
-    c->launch_min_px = big && c->sched[5] == 0 ? std::min<uint64_t>(akz_ctx::kLaunchMarchPx, (uint64_t)w * h * n) : akz_ctx::kLaunchMarchPx;
+    c->launch_min_px = big ? std::min<uint64_t>(akz_ctx::kLaunchMarchPx, (uint64_t)w * h * n) : akz_ctx::kLaunchMarchPx;
     if (big && !c->placed) AKZ_TRY(place_streams(c));
     const int pre_mode = c->sched[0] == 0 ? c->pre_mode : c->sched[0] == 1 ? 2 : c->sched[0] == 2 ? 1 : 0;  // (1: a stream of its own, measurement only)
     if ((input_ready || (flags & AKZ_INPUT_READY)) && pre_mode != 0 && c->profiling < 2 && c->prep_mode == 2 && big &&
@@ -3221,7 +3221,7 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
 }
 const char* akz_detector_kernel_name(void) { return "detector (k_detector_march + k_detector_tiled)"; }
 int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
-    if (!c || key < 0 || key > 5) return AKZ_ERR_INVALID_ARG;
+    if (!c || key < 0 || key > 4) return AKZ_ERR_INVALID_ARG;
     AKZ_TRY(bind(c));
     c->sched[key] = value;
     if (key == 4) {

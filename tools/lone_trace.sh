@@ -33,7 +33,7 @@ python3 - "$f" > $O/timeline.txt <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 def nm(r): return r["Kernel_Name"].replace("void ", "").replace("akz::(anonymous namespace)::", "").split("(")[0][:40]
-blur = [i for i, r in enumerate(rows) if "k_blur<2" in nm(r)]
+blur = [i for i, r in enumerate(rows) if "k_blur" in nm(r) and "unsigned char" in nm(r)]
 # the streamed part: frames -8 .. -3 ; the synchronous call: the last blur
 a, b = blur[-7], blur[-3]
 t0 = int(rows[a]["Start_Timestamp"])

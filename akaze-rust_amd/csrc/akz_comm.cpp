@@ -22,7 +22,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -120,6 +122,7 @@ struct akz_comm {
     int device = 0, rank = 0, nranks = 1;
     ncclComm_t nccl = nullptr;
     bool external = false;          // akz_comm_create_external: the CALLER moves the blocks between ranks (no RCCL in the process)
+    double timeout_s = 0.0;         // akz_comm_set_timeout: how long akz_gather_finish waits for an exchange (0: without limit)
     hipStream_t xs = nullptr;       // exchange stream: the collectives, in order
     hipStream_t cs = nullptr;       // copy stream: local rows -> send block, headers -> host (never behind a collective)
     hipEvent_t ready = nullptr;     // producer-side event the copy stream waits for
@@ -369,6 +372,11 @@ int akz_comm_destroy(akz_comm* c) {
     return AKZ_OK;
 }
 
+int akz_comm_set_timeout(akz_comm* c, double seconds) {
+    if (!c || !(seconds >= 0.0)) return AKZ_ERR_INVALID_ARG;
+    c->timeout_s = seconds;
+    return AKZ_OK;
+}
 int akz_comm_place_streams(akz_comm* c, akz_ctx* ctx) {
     if (!c || !ctx) {
         set_error("akz_comm_place_streams: null argument");
@@ -473,6 +481,20 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
         return AKZ_ERR_INVALID_ARG;
     }
     // the headers of all blocks -> host (64 bytes per rank): an overflow anywhere is an error everywhere
+    if (c->timeout_s > 0.0 && !g->finished) {  // a peer that never joined leaves the collective waiting for ever: give up with a message
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipEventQuery(g->done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) AKZ_HIP_TRY(q);
+            (void)hipGetLastError();
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+                set_error("gather: the exchange did not complete within the communicator's timeout (akz_comm_set_timeout): a peer is missing or hung");
+                return AKZ_ERR_TIMEOUT;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
     AKZ_HIP_TRY(hipEventSynchronize(g->done));
     if (!g->finished) {
         AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost, c->cs));

@@ -212,6 +212,7 @@ def lib():
         "akz_gather_blocks": ([vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)], i32),
         "akz_gather_deliver": ([vp, vp], i32),
         "akz_comm_destroy": ([vp], i32),
+        "akz_comm_set_timeout": ([vp, f64], i32),
         "akz_comm_place_streams": ([vp, vp], i32),
         "akz_comm_info": ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
         "akz_gather_descriptors": ([vp, vp, u64, C.POINTER(vp), pu64], i32),
@@ -1164,6 +1165,10 @@ class Comm:
             buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
             _check(lib().akz_comm_create(int(device), buf, int(rank), int(nranks), C.byref(self._h)))
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
+
+    def set_timeout(self, seconds):
+        """akz_comm_set_timeout: how long finish() waits for an exchange before AKZ_ERR_TIMEOUT (0: without limit)."""
+        _check(lib().akz_comm_set_timeout(self._h, float(seconds)))
 
     def place_streams(self, ctx):
         """akz_comm_place_streams: the communicator's streams onto queues / pipes that the context's busy streams do not use

@@ -495,6 +495,8 @@ def main_rank(args):
                 xch["comm"] = A.Comm(dev_index, bytes(uid.numpy().tobytes()), rank, world)
             # the collective of a step runs beside the next batch's kernels: its streams go where the context's busy ones are not
             xch["comm"].place_streams(ctx)
+            # a peer that died leaves a collective waiting for ever: this rank then fails with a message instead of hanging
+            xch["comm"].set_timeout(float(os.environ.get("AKZ_BENCH_RENDEZVOUS_S", "300")))
             ok = 1.0
         except Exception as e:  # RCCL cannot be loaded / initialised
             sys.stderr.write(f"rank {rank}: C-ABI exchange unavailable ({e})\n")

@@ -36,8 +36,12 @@ extern "C" {
    unordered image pair once and a rank's akz_pairs holds both lists of the pairs whose lead image it owns (version 3: the
    ordered pairs whose query image it owns); akz_ctx_set_eager_finish covers the context's own jobs and defaults to on;
    the kernel-family selectors and the synthetic-frame generator moved to akaze_hip_debug.h (still exported).  No
-   signature changed. */
-#define AKZ_ABI_VERSION 4
+   signature changed.
+   5 (round 5): additions -- akz_comm_create_external / akz_gather_blocks / akz_gather_deliver (the exchange carried by the
+   caller), akz_comm_set_timeout, akz_pairs_totals, akz_ctx_warmup; akz_profile grew by the placement_* fields at its END
+   (a caller built against version 4 must not pass its smaller struct to akz_ctx_get_profile); an akz_pairs may be freed
+   after its communicator; AKZ_ERR_TIMEOUT.  No signature changed. */
+#define AKZ_ABI_VERSION 5
 
 typedef enum akz_status {
     AKZ_OK = 0,
@@ -49,7 +53,8 @@ typedef enum akz_status {
     AKZ_ERR_UNSUPPORTED = -6,  /* reference behaviour that does not terminate / panics   */
     AKZ_ERR_BUFFER = -7,       /* caller buffer too small                                */
     AKZ_ERR_IO = -8,           /* an image file cannot be read / written or is malformed */
-    AKZ_ERR_NO_MEMORY = -9     /* host allocation failed                                 */
+    AKZ_ERR_NO_MEMORY = -9,    /* host allocation failed                                 */
+    AKZ_ERR_TIMEOUT = -10      /* an exchange did not complete within akz_comm_set_timeout (a peer is missing or hung) */
 } akz_status;
 
 /* types::evolution::Config — akaze/src/types/evolution.rs:8-38 (defaults :40-55). */
@@ -341,6 +346,11 @@ int akz_comm_create(int device, const uint8_t* id, int rank, int nranks, akz_com
    format is the one described below; akz_gather_descriptors (the synchronous two-collective form) is not available. */
 int akz_comm_create_external(int device, int rank, int nranks, akz_comm** out);
 int akz_comm_destroy(akz_comm* comm);
+/* How long akz_gather_finish (and what calls it: akz_gather_descriptors, akz_match_all_pairs) waits for an exchange before
+   it gives up with AKZ_ERR_TIMEOUT -- a peer that crashed or never joined leaves a collective waiting for ever, and a host
+   that can report that is worth more than one that hangs.  0 (default): wait without limit.  After a timeout the gather is
+   still in flight (akz_gather_free waits for it): the job is expected to end. */
+int akz_comm_set_timeout(akz_comm* comm, double seconds);
 /* Optional, once, with idle streams (before the first step): moves the communicator's two streams onto hardware queues and
    command-processor pipes that `ctx`'s busy streams (the caller's, the coarse chain's, the finish half's) do not use -- the
    collective of a step runs beside the next batch's kernels, and two busy streams on one queue or pipe slow both (see

@@ -212,6 +212,22 @@ def test_external_transport_single_rank_and_its_error_paths(ctx, amd):
     assert lists == 6 and matches == pairs.total_matches() and dists == sum(res.counts(a)[1] * res.counts(b)[1] for a in range(3) for b in range(a + 1, 3))
     pairs.free()
     g.free()
+    # akz_comm_set_timeout: an exchange that does not complete in time is an error (a peer is missing), not a hang; here the
+    # blocks are "delivered" behind half a second of work on another stream
+    comm.set_timeout(0.05)
+    g3 = comm.gather_begin([res], rows + 8)
+    send, recv, nbytes = g3.blocks()
+    amd.copy_d2d(recv, send, nbytes)
+    slow = torch.cuda.Stream()
+    with torch.cuda.stream(slow):
+        torch.cuda._sleep(int(1.0e9))   # ~0.5 s of spinning at ~2 GHz
+    g3.deliver(slow.cuda_stream)
+    with pytest.raises(amd.AkazeError) as e:
+        g3.finish()
+    assert e.value.status == -10 and "timeout" in str(e.value)
+    comm.set_timeout(0)
+    assert g3.finish()[2] == [rows]   # without a limit the same gather completes
+    g3.free()
     g2 = comm.gather_begin([res], rows + 8)   # never delivered: freeing it and closing the communicator must not wait
     g2.free()
     res.close()

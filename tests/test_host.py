@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(amd):
     # and the binding declares a signature for each of them
     assert sorted(set(syms) - set(L._declared)) == []
     hdr = open(os.path.join(ROOT, "include", "akaze_hip.h")).read()
-    assert L.akz_abi_version() == int(re.search(r"#define\s+AKZ_ABI_VERSION\s+(\d+)", hdr).group(1)) == 4
+    assert L.akz_abi_version() == int(re.search(r"#define\s+AKZ_ABI_VERSION\s+(\d+)", hdr).group(1)) == 5
 
 
 def test_no_oracle_in_product_path():

@@ -1048,8 +1048,11 @@ class Gather:
             copy_raw(recv, send, nbytes, 3)
             self.deliver()
             return
-        h_send = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-        h_recv = torch.empty(world * nbytes, dtype=torch.uint8).pin_memory()
+        stage = self._comm.__dict__.setdefault("_stage", {})   # pinned staging, kept per block size (pinning costs milliseconds)
+        if stage.get("nbytes") != nbytes:
+            stage.update(nbytes=nbytes, send=torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
+                         recv=torch.empty(world * nbytes, dtype=torch.uint8).pin_memory())
+        h_send, h_recv = stage["send"], stage["recv"]
         copy_raw(h_send.data_ptr(), send, nbytes, 2)       # D2H
         dist.all_gather_into_tensor(h_recv, h_send, group=group)
         copy_raw(recv, h_recv.data_ptr(), world * nbytes, 1)  # H2D
@@ -1229,14 +1232,20 @@ class Comm:
         return out, counts
 
 
+_hip_memcpy = None
+
+
 def copy_raw(dst, src, nbytes, kind):
     """Synchronous hipMemcpy through the HIP runtime torch already loaded (binding helper); kind 1 H2D, 2 D2H, 3 D2D."""
-    import torch
-    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-    fn = hip.hipMemcpy
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    fn.restype = C.c_int
-    if fn(C.c_void_p(dst), C.c_void_p(src), nbytes, int(kind)) != 0:
+    global _hip_memcpy
+    if _hip_memcpy is None:
+        import torch
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        fn = hip.hipMemcpy
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        fn.restype = C.c_int
+        _hip_memcpy = fn
+    if _hip_memcpy(C.c_void_p(dst), C.c_void_p(src), nbytes, int(kind)) != 0:
         raise AkazeError(-2, "hipMemcpy failed")
 
 

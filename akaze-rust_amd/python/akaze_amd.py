@@ -1233,20 +1233,28 @@ class Comm:
 
 
 _hip_memcpy = None
+_hip_stream_sync = None
 
 
 def copy_raw(dst, src, nbytes, kind):
-    """Synchronous hipMemcpy through the HIP runtime torch already loaded (binding helper); kind 1 H2D, 2 D2H, 3 D2D."""
-    global _hip_memcpy
+    """hipMemcpy through the HIP runtime torch already loaded, COMPLETE on return (binding helper); kind 1 H2D, 2 D2H,
+    3 D2D.  (A device-to-device hipMemcpy may return before the copy has run -- it is enqueued on the null stream, which work
+    on a non-blocking stream does not wait for -- so that kind is followed by a synchronisation of the null stream.)"""
+    global _hip_memcpy, _hip_stream_sync
     if _hip_memcpy is None:
         import torch
         hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
         fn = hip.hipMemcpy
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         fn.restype = C.c_int
-        _hip_memcpy = fn
+        sy = hip.hipStreamSynchronize
+        sy.argtypes = [C.c_void_p]
+        sy.restype = C.c_int
+        _hip_memcpy, _hip_stream_sync = fn, sy
     if _hip_memcpy(C.c_void_p(dst), C.c_void_p(src), nbytes, int(kind)) != 0:
         raise AkazeError(-2, "hipMemcpy failed")
+    if int(kind) == 3 and _hip_stream_sync(None) != 0:
+        raise AkazeError(-2, "hipStreamSynchronize failed")
 
 
 def copy_d2d(dst, src, nbytes):

@@ -826,6 +826,7 @@ def main_rank(args):
         base = (big.data_ptr() + (1 << 21) - 1) >> 21 << 21
         sets = [[base + (7 * k + i) * pb for i in range(7)] for k in range(4)]
         src = torch.rand((n_, h_, w_), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()  # (the copies below run on the null stream, which does not wait for this stream's kernels)
         for k in range(4):
             A.copy_d2d(sets[k][0], src.data_ptr(), pb)
         det_alone = {}
@@ -1225,7 +1226,9 @@ def main_rank(args):
 
         def rows_of(i):
             r_, o, n_ = table[i]
-            t = torch.zeros((max(n_, 1), 64), dtype=torch.uint8, device=dev)
+            # (torch.empty, not zeros: a fill kernel on the non-blocking stream is not ordered against the synchronous copy)
+            t = torch.empty((max(n_, 1), 64), dtype=torch.uint8, device=dev)
+            torch.cuda.current_stream().synchronize()
             if n_:
                 A.copy_d2d(t.data_ptr(), base + ((r_ * block_rows + 1 + o) * 64), n_ * 64)
             return t[:n_]
@@ -1238,7 +1241,12 @@ def main_rank(args):
                 m_t, m_n = ctx.descriptor_match_device(tq, tj)
                 torch.cuda.synchronize()
                 exp = m_t[:int(m_n.item())].cpu().numpy().view(A.MATCH_DTYPE).reshape(-1)
-                ok_pairs = ok_pairs and np.array_equal(pr.matches(q, j), exp)
+                got = pr.matches(q, j)
+                if not np.array_equal(got, exp):
+                    ok_pairs = False
+                    nd = int((got[:min(len(got), len(exp))] != exp[:min(len(got), len(exp))]).sum())
+                    sys.stderr.write(f"rank {rank}: pair ({q}, {j}): {len(got)} matches held, {len(exp)} from the pairwise call, "
+                                     f"{nd} of the common prefix differ; rows {len(tq)} x {len(tj)}\n")
         every = sorted((a, b) for a in range(pr.n_images) for b in range(pr.n_images) if a != b)
         holders_ok = all(0 <= pr.holder(a, b) < world for a, b in every[:: max(1, len(every) // 64)])
         n_images = pr.n_images

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "akz_internal.hpp"
+#include "akz_select.hpp"
 #include "akz_pool.hpp"
 
 namespace akz {
@@ -101,7 +102,12 @@ struct akz_ctx {
     DevBuf cand;                             // NMS candidates
     DevBuf cand_sorted, sort_scratch;        // the list in scan order (device sort of extract_finish) and the sort's scratch
     DevBuf rel_scratch;                      // the selection's neighbour lists (launch::candidate_relations)
-    int dbg_select = -1;                     // akz_debug_set_select: 1 / 0 force the neighbour-list / the grid selection, -1 automatic
+    DevBuf sel_scratch, sel_recs;            // the selection on the device (launch::select_device): its scratch, the selected keypoints
+    int dbg_select = -1;                     // akz_debug_set_select: 2 / 1 / 0 force the device / the neighbour-list / the grid selection, -1 automatic
+    std::atomic<uint32_t> last_total_kp{0};  // keypoints of the previous finished job (speculative fetch size of the device selection)
+    std::atomic<int> sel_last_mode{-1};      // akz_debug_select_info: how the last finished job was selected (0 grids, 1 lists, 2 device), the
+    std::atomic<uint32_t> sel_last_ticks[4];
+    std::atomic<uint32_t> sel_last_rounds{0}, sel_last_fallback{0};  // device's longest run of rounds, images that sent it back to the host
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
     DevBuf match_state;                      // k_match_merge_compact's per-workgroup counts (zeroed when allocated, then told apart by epoch)
@@ -127,8 +133,9 @@ struct akz_ctx {
     uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
     int dbg_host_sort = -1;                            // akz_debug_set_host_sort: 1 / 0 force the host / the device sort, -1 automatic
     DevBuf cosi;                             // (cos, sin) per keypoint
-    DevBuf pin[8];                           // pinned host staging: candidates, orientation sums, descriptor
-                                             // rows, keypoint params, (cos, sin), contrast factors, neighbour lists, their flags
+    DevBuf pin[10];                          // pinned host staging: candidates, orientation sums, descriptor
+                                             // rows, keypoint params, (cos, sin), contrast factors, neighbour lists, their flags,
+                                             // the device selection's headers, its orientation sums
     std::vector<std::pair<size_t, void*>> slab_pool;  // freed device blocks (pyramid slabs, descriptor rows)
     std::mutex slab_m;                                // results are freed by the caller while a lane's finisher thread allocates
     // extractions in flight (akz_extract_begin_* / akz_extract_finish)
@@ -420,7 +427,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
-                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec, &c->match_state,
+                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->sel_scratch, &c->sel_recs, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec, &c->match_state,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols,
                       &c->ms1.q8, &c->ms1.t8, &c->ms1.pop, &c->ms1.tab, &c->ms1.cols, &c->ms1.rec, &c->ransac_dev};
     for (DevBuf* b : bufs)
@@ -1775,29 +1782,73 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // single piece of a synchronous call)
     const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < 4 || (uint64_t)r->w * r->h * n < r->big_px ||
                                                                         (uint64_t)r->w * r->h >= 6000000ull));
-    bool sorted = false;
+    // The selection ITSELF on the device (round 5; akz_select.hpp, launch::select_device): the order-dependent walk as
+    // dependency rounds over the same neighbour lists, one workgroup per image, and the orientation sums right behind it on
+    // the keypoints it leaves -- the host neither fetches the candidate list nor selects, and one of the two round trips of
+    // the finish half is gone.  Taken where the neighbour lists are (the host's selection is the longest piece of a lone
+    // image's call); an image whose lists overflowed sends the job down the host's path below.
+    // ... and where the call waits for it: a job with another one begun behind it is part of a stream, whose rate the chip
+    // bounds, not the host (lone 1080p frames: 0.60 ms per frame with the host's selection, 0.61 with the device's; a
+    // synchronous call 0.98 -> 0.95 ms, a 4K frame 2.06 -> 1.81 ms, either way)
+    const bool want_dev = c->dbg_select == 2 ||
+                          (c->dbg_select < 0 && want_rel &&
+                           (c->pool().size() < 4 || (uint64_t)r->w * r->h >= 6000000ull || !(c->begin_seq.load() > job->seq)));
+    bool sorted = false, dev_sel = false;
     uint16_t* d_rel = nullptr;
     uint32_t* d_rel_flags = nullptr;
-    if (c->dbg_host_sort == 0 || (c->dbg_host_sort < 0 && (c->pool().size() < 4 || want_rel))) {
+    uint32_t *d_sel_hdr = nullptr, *d_sel_total = nullptr;
+    std::vector<float> lsize, lratio;
+    selection_level_constants(plan, cfg, lsize, lratio);
+    LevelTable tab;
+    std::memset(&tab, 0, sizeof(tab));
+    for (size_t l = 0; l < L; ++l) {
+        tab.lv[l].lt = P(l, AKZ_LT);
+        tab.lv[l].lx = P(l, AKZ_LX);
+        tab.lv[l].ly = P(l, AKZ_LY);
+        tab.lv[l].w = plan[l].w;
+        tab.lv[l].h = plan[l].h;
+        tab.lv[l].stride = (uint64_t)plan[l].w * plan[l].h;
+    }
+    unsigned long long wmask = 0;
+    uint32_t nwin = 0;
+    orientation_windows(&wmask, &nwin);
+    if (c->dbg_host_sort == 0 || (c->dbg_host_sort < 0 && (c->pool().size() < 4 || want_rel)) || want_dev) {
         AKZ_TRY(ensure(c, c->cand_sorted, (size_t)cap * sizeof(Candidate)));
         AKZ_TRY(ensure(c, c->sort_scratch, launch::sort_candidates_scratch(cap, max_px, (uint32_t)L, n)));
+        void* selp = nullptr;
+        if (want_dev) {
+            AKZ_TRY(ensure(c, c->sel_scratch, launch::select_device_bytes(cap, n)));
+            selp = c->sel_scratch.p;
+        }
         sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
-                                                n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p);
+                                                n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p,
+                                                selp ? launch::select_device_revcnt(selp, cap, n) : nullptr);
         AKZ_HIP_TRY(hipGetLastError());
-        if (sorted && want_rel) {
-            std::vector<float> lsize, lratio;
-            selection_level_constants(plan, cfg, lsize, lratio);
+        if (sorted && (want_rel || want_dev)) {
             std::vector<uint32_t> lw(L);
             for (size_t l = 0; l < L; ++l) lw[l] = plan[l].w;
             AKZ_TRY(ensure(c, c->rel_scratch, launch::candidate_relations_bytes(cap, (uint32_t)L, n)));
             launch::candidate_relations(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), (uint32_t)L, n,
-                                        c->rel_scratch.p, &d_rel, &d_rel_flags);
+                                        c->rel_scratch.p, &d_rel, &d_rel_flags, selp);
             AKZ_HIP_TRY(hipGetLastError());
+            if (want_dev) {
+                AKZ_TRY(ensure(c, c->sel_recs, (size_t)cap * sizeof(sel::KpRec)));
+                AKZ_TRY(ensure(c, c->kp_in, (size_t)cap * sizeof(KpParam)));
+                AKZ_TRY(ensure(c, c->kp_out, (size_t)cap * sizeof(OrientOut)));
+                launch::select_device(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), (uint32_t)L, n,
+                                      c->rel_scratch.p, selp, c->sel_recs.p, (KpParam*)c->kp_in.p, &d_sel_hdr, &d_sel_total);
+                if ((uint64_t)r->w * r->h * n >= r->big_px && c->begin_seq.load() > job->seq)  // (as the host path's orientation below)
+                    AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_ev[(job->seq + 1) % akz_ctx::kFedRing], 0));
+                launch::orientation_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, cap, wmask, nwin, (OrientOut*)c->kp_out.p);
+                AKZ_HIP_TRY(hipGetLastError());
+                dev_sel = true;
+            }
         }
     }
     constexpr size_t kRelRow = (size_t)(kRel1 + kRel2) * sizeof(uint16_t);
     const Candidate* hc = nullptr;   // the whole list on the host (pinned)
-    uint32_t total_c = 0;
+    uint32_t total_c = 0, spec_kp = 0;
+    uint64_t total_kp = 0;
     for (int attempt = 0;; ++attempt) {
         const Candidate* d_list = sorted ? (const Candidate*)c->cand_sorted.p : (const Candidate*)c->cand_slot[job->slot].p;
         AKZ_TRY(ensure_pinned(c, c->pin[1], 256));
@@ -1806,7 +1857,20 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         // Small jobs are bound by the latency of these round trips: fetch, with the count, as many candidates as the
         // previous job of this context had (+25 %) and the contrast factors, so that one synchronisation serves all.
         uint32_t spec = 0;
-        if (attempt == 0) {
+        if (attempt == 0 && dev_sel) {  // the device's selection: its headers and as many keypoints / orientation sums as the last job had (+25 %)
+            const uint32_t last = c->last_total_kp.load();
+            spec_kp = std::min<uint32_t>(cap, last + last / 4 + 256u);
+            AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[5].p, r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+            AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 32));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[8].p, d_sel_hdr, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+            AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec_kp * sizeof(sel::KpRec)));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->sel_recs.p, (size_t)spec_kp * sizeof(sel::KpRec), hipMemcpyDeviceToHost, s));
+            AKZ_TRY(ensure_pinned(c, c->pin[9], (size_t)spec_kp * sizeof(OrientOut)));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[9].p, c->kp_out.p, (size_t)spec_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+            AKZ_TRY(ensure_pinned(c, c->pin[7], (size_t)n * sizeof(uint32_t)));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[7].p, d_rel_flags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        } else if (attempt == 0) {
             const uint32_t last = c->last_total_cands.load();
             spec = std::min<uint32_t>(cap, last + last / 4 + 64u);
             if ((size_t)spec * sizeof(Candidate) > (1u << 20)) spec = 0;  // large lists: exactly the used part, below
@@ -1838,6 +1902,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             }
             cap = total_c + total_c / 8;
             sorted = false;
+            dev_sel = false;
             d_rel = nullptr;  // (the lists belong to the truncated list)
             AKZ_HIP_TRY(hipStreamSynchronize(c->main));
             AKZ_TRY(ensure(c, c->cand_slot[job->slot], (size_t)cap * sizeof(Candidate)));
@@ -1848,6 +1913,37 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                             (Candidate*)c->cand_slot[job->slot].p, cap, d_count);
             AKZ_HIP_TRY(hipGetLastError());
             continue;
+        }
+        if (dev_sel) {
+            const uint32_t* hdr = (const uint32_t*)c->pin[8].p;
+            uint32_t max_rounds = 0, fallen = 0;
+            for (uint32_t img = 0; img < n; ++img) {
+                if (hdr[img * 8 + 2] != 0) {  // an image for the host's selection: the whole job takes it (its lists are fetched below)
+                    dev_sel = false;
+                    ++fallen;
+                    fallen |= hdr[img * 8 + 2] << 16;
+                }
+                total_kp += hdr[img * 8];
+                max_rounds = std::max(max_rounds, hdr[img * 8 + 3]);
+            }
+            for (int k = 0; k < 4; ++k) c->sel_last_ticks[k] = hdr[4 + k];  // (image 0's phases)
+            c->sel_last_rounds = max_rounds;
+            c->sel_last_fallback = fallen;
+            if (dev_sel && total_kp > spec_kp) {  // more keypoints than last time: the rest
+                std::vector<uint8_t> keep_r((const uint8_t*)c->pin[0].p, (const uint8_t*)c->pin[0].p + (size_t)spec_kp * sizeof(sel::KpRec));
+                std::vector<uint8_t> keep_o((const uint8_t*)c->pin[9].p, (const uint8_t*)c->pin[9].p + (size_t)spec_kp * sizeof(OrientOut));
+                AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)total_kp * sizeof(sel::KpRec)));
+                AKZ_TRY(ensure_pinned(c, c->pin[9], (size_t)total_kp * sizeof(OrientOut)));
+                std::memcpy(c->pin[0].p, keep_r.data(), keep_r.size());
+                std::memcpy(c->pin[9].p, keep_o.data(), keep_o.size());
+                AKZ_HIP_TRY(hipMemcpyAsync((sel::KpRec*)c->pin[0].p + spec_kp, (const sel::KpRec*)c->sel_recs.p + spec_kp,
+                                           (size_t)(total_kp - spec_kp) * sizeof(sel::KpRec), hipMemcpyDeviceToHost, s));
+                AKZ_HIP_TRY(hipMemcpyAsync((OrientOut*)c->pin[9].p + spec_kp, (const OrientOut*)c->kp_out.p + spec_kp,
+                                           (size_t)(total_kp - spec_kp) * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+                AKZ_HIP_TRY(hipStreamSynchronize(s));
+            }
+            if (dev_sel) break;
+            total_kp = 0;
         }
         const uint32_t have = std::min(spec, total_c);  // already on the host
         if (total_c > have) {
@@ -1874,7 +1970,9 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // per image: a range of the sorted list, or (host fallback) a bucket of the unordered one, sorted below
     std::vector<std::vector<Candidate>> cands;
     std::vector<std::pair<const Candidate*, size_t>> span(n, {nullptr, 0});
-    if (sorted) {
+    if (dev_sel) {
+        // (nothing of the candidate list is on the host)
+    } else if (sorted) {
         size_t at = 0;
         for (uint32_t img = 0; img < n; ++img) {
             const Candidate* b = hc + at;
@@ -1914,6 +2012,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                 if (hc[i].img < n) cands[hc[i].img][at[t][hc[i].img]++] = hc[i];
         });
     }
+    c->sel_last_mode = dev_sel ? 2 : (d_rel && sorted ? 1 : 0);
     c->slot_busy[job->slot] = false;  // the candidate buffers may be reused by the next begin
     job->slot = -1;
     if (c->profiling) c->prof.ms[AKZ_ST_NMS] += now_ms() - t_counts;  // candidate D2H after the counts arrived
@@ -1923,21 +2022,42 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     const double t_host0 = now_ms();
     std::vector<std::vector<HostKeypoint>> hk(n);
     r->n_extrema.assign(n, 0);
-    uint64_t total_kp = 0;
     r->desc_off.assign(n + 1, 0);
-    {
+    if (dev_sel) {  // the device's selection: the records into the host's form (size and octave follow from the level)
+        const uint32_t* hdr = (const uint32_t*)c->pin[8].p;
+        const sel::KpRec* recs = (const sel::KpRec*)c->pin[0].p;
+        std::vector<uint64_t> first(n + 1, 0);
+        for (uint32_t img = 0; img < n; ++img) first[img + 1] = first[img] + hdr[img * 8];
+        c->pool().run(n, [&](size_t img) {
+            r->n_extrema[img] = hdr[img * 8 + 1];
+            hk[img].resize(hdr[img * 8]);
+            for (size_t i = 0; i < hk[img].size(); ++i) {
+                const sel::KpRec& q = recs[first[img] + i];
+                HostKeypoint& k = hk[img][i];
+                k.x = q.x; k.y = q.y; k.response = q.response;
+                k.size = lsize[q.level];
+                k.octave = plan[q.level].octave;
+                k.class_id = q.level;
+                k.angle = 0.0f;
+                k.lx = k.ly = 0;
+                k.xp = k.xm = k.yp = k.ym = 0.0f;
+            }
+        });
+        c->last_total_kp = (uint32_t)total_kp;
+    } else {
         c->pool().run(n, [&](size_t img) {  // images are independent
             if (!sorted) {
                 sort_candidates(cands[img], plan);
                 span[img] = {cands[img].data(), cands[img].size()};
             }
-            if (d_rel && sorted && ((const uint32_t*)c->pin[7].p)[img] == 0)  // (a flagged image: a list was too short, or > 65 534 candidates)
+            if (d_rel && sorted && (((const uint32_t*)c->pin[7].p)[img] & 1u) == 0)  // (bit 0: > 65 533 candidates; bit 1 only keeps the image from the device's selection)
                 select_keypoints_rel(span[img].first, span[img].second, (const uint16_t*)c->pin[6].p + (size_t)(span[img].first - hc) * (kRel1 + kRel2),
                                      kRel1, kRel2, plan, cfg, hk[img], &r->n_extrema[img]);
             else
                 select_keypoints(span[img].first, span[img].second, plan, cfg, hk[img], &r->n_extrema[img]);
         });
     }
+    total_kp = 0;
     for (uint32_t img = 0; img < n; ++img) {
         r->desc_off[img] = total_kp;
         total_kp += hk[img].size();
@@ -1946,21 +2066,14 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     if (c->profiling) c->prof.ms[AKZ_ST_HOST_KP] += now_ms() - t_host0;
 
     // ---- orientation (device sums + host atan2f) and M-LDB descriptors ----
-    LevelTable tab;
-    std::memset(&tab, 0, sizeof(tab));
-    for (size_t l = 0; l < L; ++l) {
-        tab.lv[l].lt = P(l, AKZ_LT);
-        tab.lv[l].lx = P(l, AKZ_LX);
-        tab.lv[l].ly = P(l, AKZ_LY);
-        tab.lv[l].w = plan[l].w;
-        tab.lv[l].h = plan[l].h;
-        tab.lv[l].stride = (uint64_t)plan[l].w * plan[l].h;
-    }
     // keypoint parameters are built directly in pinned memory: pageable H2D copies above ~1 MiB make the
     // runtime pin user pages in place, which serialises concurrent contexts
-    AKZ_TRY(ensure_pinned(c, c->pin[3], std::max<size_t>(1, total_kp) * sizeof(KpParam)));
-    KpParam* params = (KpParam*)c->pin[3].p;
-    c->pool().run(n, [&](size_t img) {  // (per image on the workers: with few host threads every serial loop over 7 x 10^4 keypoints counts)
+    KpParam* params = nullptr;
+    if (!dev_sel) {
+        AKZ_TRY(ensure_pinned(c, c->pin[3], std::max<size_t>(1, total_kp) * sizeof(KpParam)));
+        params = (KpParam*)c->pin[3].p;
+    }
+    if (!dev_sel) c->pool().run(n, [&](size_t img) {  // (per image on the workers: with few host threads every serial loop over 7 x 10^4 keypoints counts)
         for (size_t i = 0; i < hk[img].size(); ++i) {
             const HostKeypoint& k = hk[img][i];
             KpParam& p = params[r->desc_off[img] + i];
@@ -1975,28 +2088,31 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     });
     r->kps.assign(n, {});
     if (total_kp) {
-        unsigned long long wmask = 0;
-        uint32_t nwin = 0;
-        orientation_windows(&wmask, &nwin);
         const double t_or0 = now_ms();
-        AKZ_TRY(ensure(c, c->kp_in, total_kp * sizeof(KpParam)));
-        AKZ_TRY(ensure(c, c->kp_out, total_kp * sizeof(OrientOut)));
-        AKZ_TRY(ensure(c, c->cosi, total_kp * 2 * sizeof(float)));
-        AKZ_TRY(ensure_pinned(c, c->pin[1], total_kp * std::max(sizeof(OrientOut), 2 * sizeof(float))));
         KpParam* d_kp = (KpParam*)c->kp_in.p;
-        OrientOut* d_oo = (OrientOut*)c->kp_out.p;
-        AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params, total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
-        // behind the fine octaves' diffusion of the batch begun right after this one, if there is one (next to the
-        // VALU-bound diffusion launches these gather-bound kernels cost more than next to the bandwidth-bound detectors that
-        // follow; the NEXT batch, not the one begun last: with two batches begun ahead that one is a whole step away); small
-        // jobs are bound by the latency of this chain, not by the chip, and do not wait
-        if ((uint64_t)r->w * r->h * n >= r->big_px && c->begin_seq.load() > job->seq)
-            AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_ev[(job->seq + 1) % akz_ctx::kFedRing], 0));
-        launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
-        AKZ_HIP_TRY(hipGetLastError());
-        OrientOut* oo = (OrientOut*)c->pin[1].p;
-        AKZ_HIP_TRY(hipMemcpyAsync(oo, d_oo, total_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
-        AKZ_HIP_TRY(hipStreamSynchronize(s));
+        OrientOut* oo = nullptr;
+        AKZ_TRY(ensure(c, c->cosi, total_kp * 2 * sizeof(float)));
+        if (dev_sel) {  // (parameters and sums are the device selection's: already here)
+            oo = (OrientOut*)c->pin[9].p;
+        } else {
+            AKZ_TRY(ensure(c, c->kp_in, total_kp * sizeof(KpParam)));
+            AKZ_TRY(ensure(c, c->kp_out, total_kp * sizeof(OrientOut)));
+            AKZ_TRY(ensure_pinned(c, c->pin[1], total_kp * std::max(sizeof(OrientOut), 2 * sizeof(float))));
+            d_kp = (KpParam*)c->kp_in.p;
+            OrientOut* d_oo = (OrientOut*)c->kp_out.p;
+            AKZ_HIP_TRY(hipMemcpyAsync(d_kp, params, total_kp * sizeof(KpParam), hipMemcpyHostToDevice, s));
+            // behind the fine octaves' diffusion of the batch begun right after this one, if there is one (next to the
+            // VALU-bound diffusion launches these gather-bound kernels cost more than next to the bandwidth-bound detectors that
+            // follow; the NEXT batch, not the one begun last: with two batches begun ahead that one is a whole step away); small
+            // jobs are bound by the latency of this chain, not by the chip, and do not wait
+            if ((uint64_t)r->w * r->h * n >= r->big_px && c->begin_seq.load() > job->seq)
+                AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_ev[(job->seq + 1) % akz_ctx::kFedRing], 0));
+            launch::orientation(s, tab, d_kp, (uint32_t)total_kp, wmask, nwin, d_oo);
+            AKZ_HIP_TRY(hipGetLastError());
+            oo = (OrientOut*)c->pin[1].p;
+            AKZ_HIP_TRY(hipMemcpyAsync(oo, d_oo, total_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+            AKZ_HIP_TRY(hipStreamSynchronize(s));
+        }
         AKZ_TRY(ensure_pinned(c, c->pin[4], total_kp * 2 * sizeof(float)));
         float* cosi = (float*)c->pin[4].p;
         std::vector<float> angles(total_kp);
@@ -3246,9 +3362,20 @@ int akz_debug_stream_placement(akz_ctx* c, int* info) {
     info[3] = c->place_collisions + c->lane_collisions;
     return AKZ_OK;
 }
+int akz_debug_select_info(akz_ctx* c, int* info) {
+    if (!c || !info) return AKZ_ERR_INVALID_ARG;
+    AKZ_TRY(bind(c));
+    const akz_ctx* q = c->lanes.empty() ? c : c->lanes[0];
+    info[0] = q->sel_last_mode.load();
+    info[1] = (int)q->sel_last_rounds.load();
+    info[2] = (int)q->sel_last_fallback.load();
+    info[3] = (int)q->last_total_cands.load();
+    for (int k = 0; k < 4; ++k) info[4 + k] = (int)q->sel_last_ticks[k].load();
+    return AKZ_OK;
+}
 int akz_debug_set_select(akz_ctx* c, int mode) {
     if (!c) return AKZ_ERR_INVALID_ARG;
-    c->dbg_select = mode < 0 ? -1 : (mode != 0);
+    c->dbg_select = mode < 0 ? -1 : (mode >= 2 ? 2 : (mode != 0));
     for (akz_ctx* l : c->lanes) l->dbg_select = c->dbg_select;
     return AKZ_OK;
 }

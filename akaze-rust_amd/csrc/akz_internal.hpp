@@ -132,7 +132,7 @@ struct LevelPtrs {  // device addresses of the planes one kernel needs, image 0 
     uint64_t stride;  // elements between consecutive images
 };
 constexpr int kMaxLevels = 64;
-constexpr int kRel1 = 12, kRel2 = 4;  // neighbour lists of the keypoint selection (akz_sort.hip, k_relations): 32-byte rows.  Six earlier neighbours overflowed on a third of a 4K frame's fine-level candidates -- the host then scans the partner levels itself -- : host selection 0.79 -> 0.45 ms per 4K frame with twelve (nine suffice; sixteen give nothing more)
+constexpr int kRel1 = 12, kRel2 = 6;  // neighbour lists of the keypoint selection (akz_sort.hip, k_relations): 36-byte rows (four next-level places overflowed on enough candidates of a 4K frame for k_select's second pass to spend half its time scanning for them).  Six earlier neighbours overflowed on a third of a 4K frame's fine-level candidates -- the host then scans the partner levels itself -- : host selection 0.79 -> 0.45 ms per 4K frame with twelve (nine suffice; sixteen give nothing more)
 struct LevelTable {
     LevelPtrs lv[kMaxLevels];
 };
@@ -247,18 +247,33 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
 // batch needs more key bits than the sort takes (the host then sorts)
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images);
 bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, uint64_t max_px,
-                            uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted);
+                            uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted, uint32_t* d_zero = nullptr);
 // who can be within `size` of whom (akz_sort.hip, k_relations): per candidate of the SORTED list kRel1 indices of earlier
 // candidates of its own / the previous level and kRel2 of the next level, relative to its image's first candidate
 size_t candidate_relations_bytes(uint32_t cap, uint32_t n_levels, uint32_t n_images);
 void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
                          const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, void* scratch, uint16_t** d_rel_out,
-                         uint32_t** d_flags_out);
+                         uint32_t** d_flags_out, void* sel_scratch = nullptr);
+// The selection itself on the device (akz_sort.hip: k_sel_prepare, k_select, k_sel_pack; akz_select.hpp): dependency rounds
+// over the neighbour lists, one workgroup per image.  sel_scratch (select_device_bytes) must have been handed to
+// sort_candidates_device (d_zero = select_device_revcnt(...)) and to candidate_relations of the same list.  Leaves, in image
+// order, the selected keypoints (d_recs: 16-byte records x, y, response, level) and the parameters of the keypoint kernels
+// (d_pars), room for `cap` of each; *d_hdr_out: per image {keypoints, extrema, status, rounds} -- status != 0: the image is
+// for the host's selection (an overflowed list, too many candidates) and the whole job should take that path --;
+// *d_total_out: the keypoint count of the job
+size_t select_device_bytes(uint32_t cap, uint32_t n_images);
+uint32_t* select_device_revcnt(void* sel_scratch, uint32_t cap, uint32_t n_images);
+void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
+                   const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, const void* rel_scratch, void* sel_scratch, void* d_recs,
+                   KpParam* d_pars, uint32_t** d_hdr_out, uint32_t** d_total_out);
 // candidates of all images are appended to ONE list (d_count is a single counter, cap the list capacity)
 void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint32_t nkp,
                  unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out);
+// the same with the keypoint count still on the device (*d_nkp <= max_kp: the grid is sized for max_kp)
+void orientation_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t max_kp,
+                         unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out);
 // d_cosi: (cosf(angle), sinf(angle)) per keypoint from the host libm (descriptors.rs:55-56)
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64);

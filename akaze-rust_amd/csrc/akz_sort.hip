@@ -8,10 +8,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "akz_internal.hpp"
+#include "akz_select.hpp"
 
 namespace akz {
 namespace {
@@ -40,10 +42,11 @@ __global__ void k_candidate_keys(const Candidate* __restrict__ cand, unsigned ca
     pos[i] = i;
 }
 __global__ void k_candidate_gather(const Candidate* __restrict__ cand, unsigned cap, const unsigned* __restrict__ d_count,
-                                   const unsigned* __restrict__ pos, Candidate* __restrict__ out) {
+                                   const unsigned* __restrict__ pos, Candidate* __restrict__ out, unsigned* __restrict__ zero) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*d_count, cap)) return;
     out[i] = cand[pos[i]];
+    if (zero) zero[i] = 0u;  // (the reverse-list counters of the device selection, one per list entry)
 }
 
 // ---- who can meet whom in the keypoint selection (round 4) ------------------------------------------------------------
@@ -66,9 +69,10 @@ struct RelLevels {  // per level, as select_keypoints computes them
 };
 // first list position of every (image, level): offs[img * (L + 1) + level], level == L: the image's end
 __global__ void k_rel_offsets(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap, unsigned n_levels,
-                              unsigned n_images, unsigned* __restrict__ offs) {
+                              unsigned n_images, unsigned* __restrict__ offs, unsigned* __restrict__ img_flags) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_images * (n_levels + 1)) return;
+    if (t < n_images) img_flags[t] = 0u;  // (only k_relations and k_sel_prepare, which come later, set them)
     const unsigned img = t / (n_levels + 1), level = t - img * (n_levels + 1);
     const unsigned n = min(*d_count, cap);
     unsigned lo = 0, hi = n;  // first entry with (img', level') >= (img, level)
@@ -91,7 +95,8 @@ __device__ __forceinline__ unsigned rel_lower_bound(const Candidate* __restrict_
 }
 __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
                                                    RelLevels lv, const unsigned* __restrict__ offs, unsigned short* __restrict__ rel,
-                                                   unsigned* __restrict__ img_flags) {
+                                                   unsigned* __restrict__ img_flags, unsigned* __restrict__ revcnt,
+                                                   unsigned short* __restrict__ rev) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*d_count, cap)) return;
     const Candidate c = sorted[i];
@@ -130,6 +135,10 @@ __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__
                 if (used < room) out[first + used] = (unsigned short)(j - img0);
                 else overflow = true;
                 ++used;
+                if (first == 0 && revcnt) {  // the device selection: j learns that this candidate looks at it (akz_select.hpp)
+                    const unsigned at = atomicAdd(&revcnt[j], 1u);
+                    if (at < (unsigned)sel::kRev) rev[(size_t)j * sel::kRev + at] = (unsigned short)(i - img0);
+                }
             }
         }
     };
@@ -142,18 +151,465 @@ __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__
     if (too_many) img_flags[c.img] = 1u;
 }
 
+
+// ---- the selection itself (round 5): akz_select.hpp ------------------------------------------------------------------------
+// k_sel_prepare (one thread per candidate): everything a candidate's turn needs in one 48-byte row -- its earlier neighbours,
+// its rank in the reverse list of each, whether its response beats each neighbour's, its next-level neighbours --, its
+// state before the first turn (a candidate without earlier neighbours opens a cache position of its own), and the images
+// the device cannot do (a list of earlier neighbours or a reverse list that overflowed): those go to the host's selection.
+typedef sel::Row<kRel1, kRel2> SelRow;
+static_assert(sizeof(SelRow) == 64 && kRel1 == 12 && kRel2 == 6, "four 16-byte loads; k_select knows where the fields are");
+__global__ void __launch_bounds__(256) k_sel_prepare(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
+                                                     unsigned n_levels, unsigned n_images, const unsigned* __restrict__ offs,
+                                                     const unsigned short* __restrict__ rel, const unsigned* __restrict__ revcnt,
+                                                     const unsigned short* __restrict__ rev, SelRow* __restrict__ rows,
+                                                     unsigned char* __restrict__ state0, unsigned* __restrict__ img_flags) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(*d_count, cap)) return;
+    const Candidate c = sorted[i];
+    if (c.img >= n_images || c.level >= n_levels) return;
+    const unsigned img0 = offs[(size_t)c.img * (n_levels + 1)];
+    const unsigned me = i - img0;
+    const unsigned short* row = rel + (size_t)i * (kRel1 + kRel2);
+    const bool over = row[0] == sel::kListOverflow || revcnt[i] > (unsigned)sel::kRev;  // (an overflowed next-level list: k_select scans that level)
+    SelRow out;
+    const float mine = fabsf(c.v);
+    unsigned wins = 0;
+    bool open = true;
+#pragma unroll
+    for (int j = 0; j < kRel1; ++j) {
+        const unsigned short q = row[j];
+        unsigned pred = sel::kNone;
+        if (!open || q >= sel::kListOverflow) {
+            open = false;
+        } else {
+            const unsigned qi = img0 + q, cnt = min(revcnt[qi], (unsigned)sel::kRev);
+            for (unsigned m = 0; m < cnt; ++m) {  // the member of q's reverse list right before this candidate
+                const unsigned e = rev[(size_t)qi * sel::kRev + m];
+                if (e < me && (pred == sel::kNone || e > pred)) pred = e;
+            }
+            if (mine > fabsf(sorted[qi].v)) wins |= 1u << j;  // (scale_space_extrema.rs:62: strictly larger replaces)
+        }
+        out.rel1[j] = open ? q : sel::kNone;
+        out.pred[j] = (unsigned short)pred;
+    }
+    out.wins = (unsigned short)wins;
+#pragma unroll
+    for (int j = 0; j < kRel2; ++j) out.rel2[j] = row[kRel1 + j];
+    {
+        const float d_x = 0.5f * (c.xp - c.xm), d_y = 0.5f * (c.yp - c.ym);
+        unsigned len = 0;
+#pragma unroll
+        for (int j = 0; j < kRel1; ++j) len += out.rel1[j] != sel::kNone ? 1u : 0u;
+        out.refined = (unsigned short)((fabsf(-d_x) <= 1.0f && fabsf(-d_y) <= 1.0f ? 1u : 0u) | (len << 8));
+    }
+    rows[i] = out;
+    state0[i] = row[0] == sel::kNone ? (unsigned char)(sel::kDecided | sel::kAccepted) : (unsigned char)0;
+    if (over) atomicOr(&img_flags[c.img], (row[0] == sel::kListOverflow ? 2u : 0u) | (revcnt[i] > (unsigned)sel::kRev ? 16u : 0u));
+}
+
+// k_select: one workgroup per image; a byte (state, done) and the creator of its cache position per candidate in LDS.  Thread
+// t owns the candidates t, t + 1024, ... and walks them in index order: when the current one is ready (sel::ready) it takes
+// its turn and moves on; otherwise it looks again.  No barrier separates the turns: whoever sees a neighbour's done counter
+// at its own rank sees everything the earlier members of that reverse list wrote (LDS operations of a wave execute in
+// order), and the lowest undecided candidate of the image is always ready, so every wave keeps moving.  A look fetches the
+// neighbours' bytes at once; the row of the next candidate is fetched while the current one waits.  Then the second pass and
+// the refinement's test (a bit on the byte of the cache position's creator), a count of those bits per chunk of creators,
+// and every survivor writes its keypoint at the rank of its cache position.  One workgroup's loops over tens of candidates
+// per thread are bound by the latency of their loads: they fetch for several candidates before they use the first.
+constexpr int SEL_NT = 1024;
+constexpr unsigned SEL_MAX_CANDS = 49152;      // x 3 bytes = 144 KB of the 160 KB; an image with more goes to the host
+constexpr unsigned SEL_MAX_LOOKS = 4u << 20;   // (a turn that never becomes ready cannot happen; if it did, the image goes to the host)
+constexpr unsigned char SEL_SURVIVOR = 8;      // on the byte of a cache position's creator: its occupant is a keypoint
+struct SelOut {
+    unsigned* hdr;        // per image, 8 words: keypoints, extrema (before the refinement), status (0: done here), looks of the
+                          // slowest thread, 10 ns ticks of the four phases (first states, turns, second pass, output)
+    sel::KpRec* recs;     // per image at its first candidate's list position (one image: final)
+    KpParam* pars;
+    unsigned* total;      // one image: the keypoint count again, for the kernels that follow
+};
+struct SelPacked {  // a row as its sixteen dwords: 0..5 rel1 (two per dword), 6..11 pred, 12 wins | rel2[0], 13..14 rel2[1..4], 15 rel2[5] | refined
+    uint4 v[4];
+};
+__device__ __forceinline__ SelPacked sel_load_row(const SelRow* __restrict__ p) {
+    SelPacked r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q[2]; r.v[3] = q[3];
+    return r;
+}
+__device__ __forceinline__ void sel_compiler_fence() { __asm__ volatile("" ::: "memory"); }
+__global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__ sorted, RelLevels lv, const unsigned* __restrict__ offs,
+                                                   const SelRow* __restrict__ rows, const unsigned char* __restrict__ state0,
+                                                   const unsigned* __restrict__ img_flags, SelOut out) {
+    __shared__ unsigned short s_origin[SEL_MAX_CANDS];
+    __shared__ unsigned char s_sd[SEL_MAX_CANDS + 16];  // (+ the spare byte)
+    __shared__ unsigned s_base[SEL_NT];
+    __shared__ unsigned s_part[SEL_NT / 64];
+    __shared__ unsigned s_extrema, s_abort, s_looks;
+    const unsigned img = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const unsigned L = lv.n_levels;
+    const unsigned* o = offs + (size_t)img * (L + 1);
+    const unsigned img0 = o[0], n = o[L] - img0;
+    unsigned status = img_flags[img];
+    if (n > SEL_MAX_CANDS) status |= 1u;
+    if (status != 0u || n == 0u) {
+        if (tid == 0) {
+            out.hdr[img * 8 + 0] = 0u; out.hdr[img * 8 + 1] = 0u; out.hdr[img * 8 + 2] = status; out.hdr[img * 8 + 3] = 0u;
+            if (out.total) *out.total = 0u;
+        }
+        return;
+    }
+    const Candidate* cand = sorted + img0;
+    const SelRow* rowI = rows + img0;
+    const unsigned long long t0 = wall_clock64();  // (100 MHz; the phases' durations go into the header: akz_debug_select_info)
+    if (tid == 0) { s_extrema = 0u; s_abort = 0u; s_looks = 0u; }
+#ifndef AKZ_SEL_BLOCKED
+#define AKZ_SEL_BLOCKED 0
+#endif
+    // this thread's candidates: a contiguous run of the list (its neighbours of the same level are mostly its own, so that
+    // the lanes of a wave wait for each other less than with candidates dealt out in turn)
+    const unsigned per = (n + SEL_NT - 1) / SEL_NT;
+    auto cand_of = [&](unsigned k) -> unsigned { return k >= per ? 0xffffffffu : (AKZ_SEL_BLOCKED ? tid * per + k : tid + k * SEL_NT); };
+    unsigned long long mask = 0ull;  // this thread's undecided candidates: bit k <-> candidate cand_of(k)
+    constexpr int U = 8;
+    for (unsigned k0 = 0; k0 < per; k0 += U) {
+        unsigned char st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned c = cand_of(k0 + u);
+            st[u] = c < n ? state0[img0 + c] : (unsigned char)1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned c = cand_of(k0 + u);
+            if (c < n) {
+                s_sd[c] = st[u];
+                s_origin[c] = st[u] ? (unsigned short)c : sel::kNone;
+                if (!st[u]) mask |= 1ull << (k0 + u);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long t1 = wall_clock64();
+    auto OG = [&](unsigned short q) -> unsigned short { return s_origin[q]; };
+    // The loop below runs ~100 times on the slowest thread and a wave pays for its longest path every time: it is kept short.
+    // The lists stay packed in their dwords and are shifted down as the neighbours get through; a neighbour's contribution is
+    // folded in when it is through (sel::advance), so that the turn itself is three stores.
+    SelPacked nxt;
+    int b_cur = -1, b_nxt = -1;
+    auto fetch = [&](SelPacked& r, int& b) {
+        b = -1;
+        if (mask) {
+            b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            r = sel_load_row(rowI + cand_of((unsigned)b));
+        }
+    };
+    unsigned wq[6], wp[6], wins = 0, len = 0, hit_q = 0;  // neighbours / their predecessors still waited for (entry 0: the next one)
+    sel::Progress prog;
+    auto open_row = [&](const SelPacked& r) {
+        wq[0] = r.v[0].x; wq[1] = r.v[0].y; wq[2] = r.v[0].z; wq[3] = r.v[0].w; wq[4] = r.v[1].x; wq[5] = r.v[1].y;
+        wp[0] = r.v[1].z; wp[1] = r.v[1].w; wp[2] = r.v[2].x; wp[3] = r.v[2].y; wp[4] = r.v[2].z; wp[5] = r.v[2].w;
+        wins = r.v[3].x & 0xffffu;
+        len = (r.v[3].w >> 24) & 15u;
+        sel::start(&prog);
+    };
+    {
+        SelPacked first;
+        fetch(first, b_cur);
+        if (b_cur >= 0) open_row(first);
+    }
+    fetch(nxt, b_nxt);
+    unsigned looks = 0, waited = 0;
+    while (b_cur >= 0) {
+        ++looks;
+        while ((unsigned)prog.through < len) {
+            const unsigned q = wq[0] & 0xffffu, pr = wp[0] & 0xffffu;
+            const bool has_pred = pr != sel::kNone;
+            // the predecessor's byte BEFORE the neighbour's, the neighbour's before its cache position (the writers store in the
+            // opposite order; LDS operations of a wave execute in the order they are issued)
+            sel_compiler_fence();
+            const unsigned bp = s_sd[has_pred ? pr : SEL_MAX_CANDS];
+            sel_compiler_fence();
+            const unsigned bq = s_sd[q];
+            sel_compiler_fence();
+            const unsigned oq = s_origin[q];
+            sel_compiler_fence();
+            const int before = prog.at;
+            if (!sel::advance(&prog, has_pred, (unsigned char)bp, (unsigned char)bq, (unsigned short)oq)) break;
+            if (prog.at != before) hit_q = q;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                wq[i] = __builtin_amdgcn_alignbit(wq[i + 1], wq[i], 16);
+                wp[i] = __builtin_amdgcn_alignbit(wp[i + 1], wp[i], 16);
+            }
+            wq[5] >>= 16;
+            wp[5] >>= 16;
+        }
+        if ((unsigned)prog.through == len) {
+            const unsigned short c = (unsigned short)cand_of((unsigned)b_cur);
+            unsigned short oc;
+            bool kills;
+            const unsigned char mine = sel::turn(prog, c, (unsigned short)wins, &oc, &kills);
+            s_origin[c] = oc;
+            sel_compiler_fence();  // (the position's creator is in place before anyone can see the turn as taken)
+            if (kills) s_sd[hit_q] = (unsigned char)(s_sd[hit_q] | sel::kKilled);
+            sel_compiler_fence();  // (the replaced entry is dead before anyone can see the turn as taken)
+            s_sd[c] = mine;
+            sel_compiler_fence();
+            b_cur = b_nxt;
+            if (b_cur >= 0) open_row(nxt);
+            fetch(nxt, b_nxt);
+            waited = 0;
+        } else if (++waited > SEL_MAX_LOOKS || *(volatile unsigned*)&s_abort) {
+            *(volatile unsigned*)&s_abort = 1u;
+            break;
+        }
+    }
+    atomicMax(&s_looks, looks);
+    __syncthreads();
+    const unsigned long long t2 = wall_clock64();
+    if (s_abort) status = 4u;
+    if (status != 0u) {
+        if (tid == 0) {
+            out.hdr[img * 8 + 0] = 0u; out.hdr[img * 8 + 1] = 0u; out.hdr[img * 8 + 2] = status; out.hdr[img * 8 + 3] = s_looks;
+            if (out.total) *out.total = 0u;
+        }
+        return;
+    }
+    // second pass (:109-129) and the refinement's test (:141-178) on this thread's candidates
+    unsigned long long surv = 0ull;
+    unsigned my_extrema = 0;
+    constexpr int U2 = 4;
+    for (unsigned k0 = 0; k0 < per; k0 += U2) {
+        uint4 tail[U2];  // the row's last 16 bytes: wins, the next-level neighbours, the refinement's flag
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const unsigned c = cand_of(k0 + u);
+            tail[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < n && sel::alive(s_sd[c] & 7u)) tail[u] = reinterpret_cast<const uint4*>(rowI + c)[3];
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const unsigned c = cand_of(k0 + u);
+            if (c >= n || !sel::alive(s_sd[c] & 7u)) continue;
+            union { uint4 v; unsigned short h[8]; } t;
+            t.v = tail[u];
+            const unsigned short* r2 = &t.h[1];  // (bytes 50 .. 61 of the row)
+            const unsigned short mine = s_origin[c];
+            bool repeated;
+            if (r2[0] == sel::kListOverflow) {
+                // more next-level neighbours than the list holds: that level's candidates in the band of rows that can lie within
+                // `size` of this one's stored position, with the selection's own expressions (as the host does for such a candidate)
+                repeated = false;
+                const Candidate cd = cand[c];
+                const unsigned l = cd.level, w = lv.w[l];
+                if (l + 1 < L) {
+                    const float ratio = lv.ratio[l], size = lv.size[l], size2 = size * size;
+                    const unsigned ly = cd.idx / w, lx = cd.idx - ly * w;
+                    const float px = (float)lx * ratio + 0.5f * (ratio - 1.0f), py = (float)ly * ratio + 0.5f * (ratio - 1.0f);
+                    const float pr = lv.ratio[l + 1], off = 0.5f * (pr - 1.0f), reach = size + 1.0f;
+                    const unsigned pw = lv.w[l + 1];
+                    const float ylo = (py - reach - off) / pr - 1.0f, yhi = (py + reach - off) / pr + 1.0f;
+                    if (yhi >= 0.0f) {
+                        const unsigned r0 = ylo <= 0.0f ? 0u : (unsigned)ylo;
+                        const unsigned long long last = (unsigned long long)((unsigned)yhi + 1u) * pw;
+                        const unsigned e = o[l + 2];
+                        for (unsigned j = rel_lower_bound(sorted, o[l + 1], e, r0 * pw); j < e && !repeated; ++j) {
+                            const Candidate p = sorted[j];
+                            if ((unsigned long long)p.idx >= last) break;
+                            const unsigned q = j - img0;
+                            if (!sel::alive(s_sd[q] & 7u) || s_origin[q] < mine) continue;
+                            const unsigned qy = p.idx / pw, qx = p.idx - qy * pw;
+                            const float sx = (float)qx * pr + off, sy = (float)qy * pr + off;
+                            const float dist = (px - sx) * (px - sx) + (py - sy) * (py - sy);
+                            repeated = dist <= size2;
+                        }
+                    }
+                }
+            } else {
+                repeated = sel::repeated_later<kRel2>(mine, r2, [&](unsigned short q) { return (unsigned char)(s_sd[q] & 7u); }, OG);
+            }
+            if (repeated) continue;
+            ++my_extrema;
+            if (t.h[7] & 1u) surv |= 1ull << (k0 + u);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_extrema += __shfl_xor(my_extrema, off, 64);
+    if (lane == 0 && my_extrema) atomicAdd(&s_extrema, my_extrema);
+    __syncthreads();  // (every alive / origin test of the second pass is through: the survivor bits may go onto the bytes)
+    const unsigned long long t3 = wall_clock64();
+    for (unsigned long long m = surv; m; m &= m - 1ull) {
+        const unsigned c = cand_of((unsigned)(__ffsll((long long)m) - 1));
+        const unsigned short org = s_origin[c];
+        s_sd[org] = (unsigned char)(s_sd[org] | SEL_SURVIVOR);  // (one occupant per cache position: one writer per byte)
+    }
+    __syncthreads();
+    // keypoints in cache order = in the order of the positions' creators: bits per contiguous chunk, an exclusive scan
+    const unsigned o0 = min(n, tid * per), o1 = min(n, o0 + per);
+    unsigned mine_n = 0;
+    for (unsigned q = o0; q < o1; ++q) mine_n += (s_sd[q] & SEL_SURVIVOR) ? 1u : 0u;
+    unsigned incl = mine_n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    unsigned before = 0, total = 0;
+    for (unsigned w = 0; w < SEL_NT / 64; ++w) {
+        const unsigned v = s_part[w];
+        if (w < wv) before += v;
+        total += v;
+    }
+    s_base[tid] = before + incl - mine_n;
+    __syncthreads();
+    // every survivor's keypoint at the rank of its cache position
+    for (unsigned long long m = surv; m;) {
+        unsigned cs[U2];
+        Candidate cds[U2];
+        int nb = 0;
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            cs[u] = 0xffffffffu;
+            if (m) {
+                cs[u] = cand_of((unsigned)(__ffsll((long long)m) - 1));
+                m &= m - 1ull;
+                cds[u] = cand[cs[u]];
+                ++nb;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            if (cs[u] == 0xffffffffu) continue;
+            const Candidate cd = cds[u];
+            const unsigned org = s_origin[cs[u]], chunk = org / per;
+            unsigned at = s_base[chunk];
+            for (unsigned q = chunk * per; q < org; ++q) at += (s_sd[q] & SEL_SURVIVOR) ? 1u : 0u;
+            const unsigned l = cd.level, w = lv.w[l];
+            const unsigned ly = cd.idx / w, lx = cd.idx - ly * w;
+            const float ratio = lv.ratio[l];
+            sel::KpRec rec;
+            rec.level = l;
+            (void)sel::refine(lx, ly, cd.v, cd.xp, cd.xm, cd.yp, cd.ym, ratio, &rec);
+            KpParam p;
+            p.xf = rec.x / ratio;
+            p.yf = rec.y / ratio;
+            p.scale = roundf(0.5f * lv.size[l] / ratio);
+            p.level = l;
+            p.img = img;
+            p._pad[0] = p._pad[1] = p._pad[2] = 0u;
+            out.recs[img0 + at] = rec;
+            out.pars[img0 + at] = p;
+        }
+        (void)nb;
+    }
+    if (tid == 0) {
+        out.hdr[img * 8 + 0] = total; out.hdr[img * 8 + 1] = s_extrema; out.hdr[img * 8 + 2] = 0u; out.hdr[img * 8 + 3] = s_looks;
+        out.hdr[img * 8 + 4] = (unsigned)(t1 - t0); out.hdr[img * 8 + 5] = (unsigned)(t2 - t1); out.hdr[img * 8 + 6] = (unsigned)(t3 - t2);
+        out.hdr[img * 8 + 7] = (unsigned)(wall_clock64() - t3);
+        if (out.total) *out.total = total;
+    }
+}
+
+// several images: the per-image runs into one list in image order (the keypoint kernels and the descriptor rows index it)
+__global__ void __launch_bounds__(256) k_sel_pack(const unsigned* __restrict__ offs, unsigned n_levels, unsigned n_images,
+                                                  const unsigned* __restrict__ hdr, const sel::KpRec* __restrict__ recs_in,
+                                                  const KpParam* __restrict__ pars_in, sel::KpRec* __restrict__ recs, KpParam* __restrict__ pars,
+                                                  unsigned* __restrict__ total) {
+    __shared__ unsigned s_red[256];
+    const unsigned img = blockIdx.x, tid = threadIdx.x;
+    unsigned part = 0;
+    for (unsigned j = tid; j < img; j += 256) part += hdr[j * 8];
+    s_red[tid] = part;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)tid < off) s_red[tid] += s_red[tid + off];
+        __syncthreads();
+    }
+    const unsigned base = s_red[0], cnt = hdr[img * 8], img0 = offs[(size_t)img * (n_levels + 1)];
+    for (unsigned i = blockIdx.y * 256 + tid; i < cnt; i += gridDim.y * 256) {
+        recs[base + i] = recs_in[img0 + i];
+        pars[base + i] = pars_in[img0 + i];
+    }
+    if (img + 1 == n_images && blockIdx.y == 0 && tid == 0) *total = base + cnt;
+}
+
 }  // namespace
 
 namespace launch {
 
+static size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 size_t candidate_relations_bytes(uint32_t cap, uint32_t n_levels, uint32_t n_images) {
     const size_t offs = ((size_t)n_images * (n_levels + 1) * 4 + 255) / 256 * 256, flags = ((size_t)n_images * 4 + 255) / 256 * 256;
     return offs + flags + (size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t) + 256;
 }
+// scratch of the device selection: reverse-list counters | reverse lists | rows | first states | headers | total |
+// per-image keypoint runs (several images)
+struct SelLayout {
+    size_t revcnt, rev, rows, state0, hdr, total, recs_tmp, pars_tmp, end;
+};
+static SelLayout sel_layout(uint32_t cap, uint32_t n_images) {
+    SelLayout l;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t b = at; at += up256(bytes); return b; };
+    l.revcnt = take((size_t)cap * 4);
+    l.rev = take((size_t)cap * sel::kRev * 2);
+    l.rows = take((size_t)cap * sizeof(SelRow));
+    l.state0 = take(cap);
+    l.hdr = take((size_t)n_images * 32);
+    l.total = take(4);
+    l.recs_tmp = take(n_images > 1 ? (size_t)cap * sizeof(sel::KpRec) : 0);
+    l.pars_tmp = take(n_images > 1 ? (size_t)cap * sizeof(KpParam) : 0);
+    l.end = at;
+    return l;
+}
+size_t select_device_bytes(uint32_t cap, uint32_t n_images) { return sel_layout(cap, n_images).end + 256; }
+uint32_t* select_device_revcnt(void* sel_scratch, uint32_t cap, uint32_t n_images) {
+    return (uint32_t*)((char*)sel_scratch + sel_layout(cap, n_images).revcnt);
+}
+void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
+                   const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, const void* rel_scratch, void* sel_scratch, void* d_recs,
+                   KpParam* d_pars, uint32_t** d_hdr_out, uint32_t** d_total_out) {
+    const SelLayout l = sel_layout(cap, n_images);
+    char* p = (char*)sel_scratch;
+    const size_t offs_b = up256((size_t)n_images * (n_levels + 1) * 4), flags_b = up256((size_t)n_images * 4);
+    const unsigned* offs = (const unsigned*)rel_scratch;
+    unsigned* flags = (unsigned*)((char*)rel_scratch + offs_b);
+    const unsigned short* rel = (const unsigned short*)((const char*)rel_scratch + offs_b + flags_b);
+    RelLevels lv;
+    std::memset(&lv, 0, sizeof(lv));
+    for (uint32_t k = 0; k < n_levels && k < (uint32_t)kMaxLevels; ++k) {
+        lv.size[k] = size[k];
+        lv.ratio[k] = ratio[k];
+        lv.w[k] = level_w[k];
+    }
+    lv.n_levels = n_levels;
+    lv.n_images = n_images;
+    hipLaunchKernelGGL(k_sel_prepare, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, n_levels, n_images, offs, rel,
+                       (const unsigned*)(p + l.revcnt), (const unsigned short*)(p + l.rev), (SelRow*)(p + l.rows),
+                       (unsigned char*)(p + l.state0), flags);
+    SelOut out;
+    out.hdr = (unsigned*)(p + l.hdr);
+    unsigned* total = (unsigned*)(p + l.total);
+    const bool one = n_images == 1;
+    out.recs = one ? (sel::KpRec*)d_recs : (sel::KpRec*)(p + l.recs_tmp);
+    out.pars = one ? d_pars : (KpParam*)(p + l.pars_tmp);
+    out.total = one ? total : nullptr;
+    hipLaunchKernelGGL(k_select, dim3(n_images), dim3(SEL_NT), 0, s, d_sorted, lv, offs, (const SelRow*)(p + l.rows),
+                       (const unsigned char*)(p + l.state0), (const unsigned*)flags, out);
+    if (!one)
+        hipLaunchKernelGGL(k_sel_pack, dim3(n_images, 4), dim3(256), 0, s, offs, n_levels, n_images, (const unsigned*)out.hdr,
+                           (const sel::KpRec*)out.recs, (const KpParam*)out.pars, (sel::KpRec*)d_recs, d_pars, total);
+    *d_hdr_out = out.hdr;
+    *d_total_out = total;
+}
 // d_rel_out / d_flags_out: where the lists and the per-image overflow flags are inside `scratch`
 void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
                          const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, void* scratch, uint16_t** d_rel_out,
-                         uint32_t** d_flags_out) {
+                         uint32_t** d_flags_out, void* sel_scratch) {
     const size_t offs_b = ((size_t)n_images * (n_levels + 1) * 4 + 255) / 256 * 256, flags_b = ((size_t)n_images * 4 + 255) / 256 * 256;
     unsigned* offs = (unsigned*)scratch;
     unsigned* flags = (unsigned*)((char*)scratch + offs_b);
@@ -169,10 +625,16 @@ void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap,
     }
     lv.n_levels = n_levels;
     lv.n_images = n_images;
-    (void)hipMemsetAsync(flags, 0, (size_t)n_images * 4, s);
     const unsigned no = n_images * (n_levels + 1);
-    hipLaunchKernelGGL(k_rel_offsets, dim3((no + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, n_levels, n_images, offs);
-    hipLaunchKernelGGL(k_relations, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rel, flags);
+    hipLaunchKernelGGL(k_rel_offsets, dim3((no + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, n_levels, n_images, offs, flags);
+    unsigned* revcnt = nullptr;
+    unsigned short* rev = nullptr;
+    if (sel_scratch) {  // (the counters were zeroed by the sort's gather)
+        const SelLayout l = sel_layout(cap, n_images);
+        revcnt = (unsigned*)((char*)sel_scratch + l.revcnt);
+        rev = (unsigned short*)((char*)sel_scratch + l.rev);
+    }
+    hipLaunchKernelGGL(k_relations, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rel, flags, revcnt, rev);
 }
 
 // scratch layout: keys in | keys out | positions in | positions out | rocPRIM's temporary storage
@@ -195,7 +657,7 @@ size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels,
     return 2 * a + 2 * b + sort_temp(cap, kb.total) + 256;
 }
 bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, uint64_t max_px,
-                            uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted) {
+                            uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted, uint32_t* d_zero) {
     if (cap == 0) return true;
     const KeyBits kb = key_bits(max_px, n_levels, n_images);
     if (kb.total > 63) return false;
@@ -210,7 +672,7 @@ bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap
     const unsigned nb = (cap + 255) / 256;
     hipLaunchKernelGGL(k_candidate_keys, dim3(nb), dim3(256), 0, s, d_cand, cap, d_count, kb, k_in, p_in);
     if (rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, p_in, p_out, cap, 0, kb.total, s) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_candidate_gather, dim3(nb), dim3(256), 0, s, d_cand, cap, d_count, p_out, d_sorted);
+    hipLaunchKernelGGL(k_candidate_gather, dim3(nb), dim3(256), 0, s, d_cand, cap, d_count, p_out, d_sorted, d_zero);
     return true;
 }
 

@@ -169,6 +169,7 @@ def lib():
         "akz_debug_set_match_chunks": ([vp, u32, u32], i32),
         "akz_debug_set_host_sort": ([vp, i32], i32),
         "akz_debug_set_select": ([vp, i32], i32),
+        "akz_debug_select_info": ([vp, C.POINTER(C.c_int)], i32),
         "akz_debug_set_schedule": ([vp, i32, i32], i32),
         "akz_debug_stream_placement": ([vp, C.POINTER(i32)], i32),
         "akz_detector_kernel_name": ([], C.c_char_p),
@@ -361,8 +362,9 @@ class Context:
         _check(lib().akz_ctx_set_eager_finish(self._h, 1 if on else 0))
 
     def debug_set_select(self, mode):
-        """akz_debug_set_select: keypoint selection from the device's neighbour lists (1), the host's grids (0), automatic (None)."""
-        _check(lib().akz_debug_set_select(self._h, -1 if mode is None else (1 if mode else 0)))
+        """akz_debug_set_select: keypoint selection on the device (2), on the host from the device's neighbour lists (1 / True),
+        from the host's grids (0 / False), automatic (None)."""
+        _check(lib().akz_debug_set_select(self._h, -1 if mode is None else (2 if mode == 2 and mode is not True else (1 if mode else 0))))
 
     def debug_set_schedule(self, key, value):
         """akz_debug_set_schedule: schedule variants of a large batch (measurement hook, identical results)."""
@@ -405,6 +407,13 @@ class Context:
     def set_host_threads(self, threads):
         """akz_ctx_set_host_threads: host threads of the finish half (0 = automatic)."""
         _check(lib().akz_ctx_set_host_threads(self._h, int(threads)))
+
+    def debug_select_info(self):
+        """akz_debug_select_info: (where the last job's selection ran: 0 grids / 1 lists / 2 device, most rounds of an image,
+        images that fell back to the host, candidates)."""
+        info = (C.c_int * 8)()
+        _check(lib().akz_debug_select_info(self._h, info))
+        return tuple(info)
 
     def debug_set_host_sort(self, on):
         """akz_debug_set_host_sort: candidates bucketed and sorted on the host instead of the device sort."""

@@ -49,11 +49,16 @@ int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float ti
    that a candidate-list overflow and over-wide sort keys take), 0 = device sort, -1 = automatic (the default: device
    sort for contexts with fewer than four host threads).  Results are identical. */
 int akz_debug_set_host_sort(akz_ctx* ctx, int on);
-/* Test hook: how the host's keypoint selection finds "the first cache entry within size": 1 = from the device's neighbour
-   lists (k_relations; needs the device sort, which it switches on), 0 = from the host's spatial grids, -1 = automatic (the
-   default: neighbour lists for contexts with fewer than four host threads, for jobs that do not take the batch path and for images of 6 Mpx and more).  Results are
-   identical. */
+/* Test hook: where and how the order-dependent keypoint selection runs: 2 = on the device (dependency rounds over the
+   neighbour lists, k_select; a job with an image whose lists overflowed falls back to 1), 1 = on the host from the device's
+   neighbour lists (k_relations; needs the device sort, which it switches on), 0 = on the host from its spatial grids,
+   -1 = automatic (the default: on the device for contexts with fewer than four host threads, for jobs that do not take the
+   batch path and for images of 6 Mpx and more; the grids otherwise).  Results are identical. */
 int akz_debug_set_select(akz_ctx* ctx, int mode);
+/* The selection of the last finished job: info[0] = where it ran (0 / 1 / 2 as above), info[1] = the most dependency rounds
+   an image took on the device, info[2] = images that sent the job back to the host's selection, info[3] = candidates,
+   info[4 .. 7] = 10 ns ticks of k_select's phases on image 0 (first states, turns, second pass, output).  info: 8 ints. */
+int akz_debug_select_info(akz_ctx* ctx, int* info);
 
 /* ---- kernel-family selectors and the synthetic frame generator (tests, bench, tools): every mode gives bit-identical
    results; a drop-in host never calls these ---------------------------------------------------------------------- */

@@ -70,6 +70,8 @@ def test_keypoint_selection_matches_linear_scans_under_sanitizers(tmp_path):
     assert "identical to the linear scans" in run.stdout
     m = re.search(r"\((\d+) rounds also through the neighbour lists", run.stdout)
     assert m and int(m.group(1)) >= 300, run.stdout  # select_keypoints_rel (the device's neighbour lists, brute-forced here)
+    m = re.search(r"(\d+) rounds also as the device's data flow of turns", run.stdout)
+    assert m and int(m.group(1)) >= 150, run.stdout  # akz_select.hpp as k_select uses it: owners in index order, interleaved at random
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")

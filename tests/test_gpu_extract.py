@@ -473,6 +473,74 @@ def test_all_pairs_match_over_rccl_world1(ctx, amd, ref):
     assert total > 20
 
 
+def test_selection_on_the_device(amd, ref):
+    """The order-dependent keypoint selection as dependency rounds on the device (k_select, akz_debug_set_select(2)): keypoints,
+    extrema counts and descriptors identical to the host's grid selection on single frames, batches (the per-image runs are
+    packed into one list), a 4K frame, a 5 x 5 pyramid, noise frames with dense candidates; a noise frame with more candidates
+    than the kernel holds sends its job back to the host and still gives the same answer; one frame of each group against the
+    oracle."""
+    import torch
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        noise = np.random.default_rng(11).integers(0, 256, (1, 270, 480), dtype=np.uint8)
+        cases = [
+            ("320x240", amd.synth_frame(320, 240, 5)[None], None, True, 2),
+            ("1080p", amd.synth_frame(1920, 1080, 6)[None], None, True, 2),
+            ("batch", np.stack([amd.synth_frame(640, 360, 70 + i) for i in range(5)]), None, True, 2),
+            ("batch17", np.stack([amd.synth_frame(480, 270, 170 + i) for i in range(17)]), None, False, 2),
+            ("4k", amd.synth_frame(3840, 2160, 2)[None], None, False, 2),
+            ("5x5", amd.synth_frame(800, 600, 9)[None], dict(num_sublevels=5, max_octave_evolution=5), True, 2),
+            ("flat", np.full((1, 240, 320), 90, np.uint8), None, False, 2),
+            ("noise", noise, None, True, 2),
+            ("dense", noise, dict(detector_threshold=1e-7), True, 2),
+            ("many", np.random.default_rng(12).integers(0, 256, (1, 1200, 2048), dtype=np.uint8), None, False, None),
+            ("batch+many", np.concatenate([amd.synth_frame(2048, 1200, 3)[None],
+                                           np.random.default_rng(13).integers(0, 256, (1, 1200, 2048), dtype=np.uint8)]), None, False, None),
+        ]
+        fell_back = 0
+        for name, frames, kw, check_oracle, where in cases:
+            cfg = amd.Config(**kw) if kw else amd.Config()
+            dev = torch.from_numpy(frames).cuda()
+            c.debug_set_select(2)
+            r2 = c.extract_features(dev, cfg, keep_all_planes=False)
+            info = c.debug_select_info()
+            if where is None:  # (more candidates than a workgroup's LDS holds: the job goes back to the host's selection)
+                fell_back += info[0] != 2 and (info[2] & 0xffff) >= 1
+            else:
+                assert info[0] == where, (name, info)
+                assert info[2] == 0 and (info[1] >= 1 or r2.counts(0)[1] == 0), (name, info)
+            c.debug_set_select(False)
+            r0 = c.extract_features(dev, cfg, keep_all_planes=False)
+            assert c.debug_select_info()[0] == 0
+            for i in range(len(frames)):
+                assert r2.counts(i) == r0.counts(i), (name, i, r2.counts(i), r0.counts(i), info)
+                assert r2.keypoints(i).tobytes() == r0.keypoints(i).tobytes(), (name, i)
+                assert r2.descriptors(i).tobytes() == r0.descriptors(i).tobytes(), (name, i)
+            if name != "flat":
+                assert r2.counts(0)[1] > 10, name
+            if check_oracle:
+                i = len(frames) - 1
+                q = ref.extract(frames[i], ref.default_config(**kw) if kw else None)
+                assert r2.keypoints(i).tobytes() == q.keypoints().tobytes(), name
+                assert np.array_equal(r2.descriptors(i), q.descriptors()), name
+        assert fell_back >= 1
+        # pipelined jobs, and a job with more keypoints than the one before it (the speculative fetch is too short)
+        c.debug_set_select(2)
+        small = torch.from_numpy(amd.synth_frame(320, 240, 5)[None]).cuda()
+        one = torch.from_numpy(amd.synth_frame(1920, 1080, 6)[None]).cuda()
+        c.debug_set_select(False)
+        base = c.extract_features(one, keep_all_planes=False)
+        c.debug_set_select(2)
+        c.extract_features(small, keep_all_planes=False).close()
+        jobs = [c.extract_begin(one, keep_all_planes=False) for _ in range(3)]
+        for j in jobs:
+            r = j.finish()
+            assert r.keypoints(0).tobytes() == base.keypoints(0).tobytes() and r.descriptors(0).tobytes() == base.descriptors(0).tobytes()
+        assert c.debug_select_info()[0] == 2
+    finally:
+        c.close()
+
+
 def test_selection_from_device_neighbour_lists(amd, ref):
     """The host's order-dependent keypoint selection fed by the device's neighbour lists (k_relations: who can be within
     `size` of whom; akz_debug_set_select(1)) against the spatial-grid form (0): identical keypoints and descriptors on

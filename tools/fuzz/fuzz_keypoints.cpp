@@ -14,6 +14,7 @@
 #include "../../include/akaze_hip.h"
 
 #include "../../akaze-rust_amd/csrc/akz_internal.hpp"
+#include "../../akaze-rust_amd/csrc/akz_select.hpp"
 
 using namespace akz;
 
@@ -84,7 +85,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 40;
     std::mt19937 rng(20261003);
     auto uni = [&](int lo, int hi) { return (int)(rng() % (unsigned)(hi - lo + 1)) + lo; };
-    long total_c = 0, total_k = 0, rel_rounds = 0, overflowed = 0;
+    long total_c = 0, total_k = 0, rel_rounds = 0, overflowed = 0, dep_rounds = 0, max_rounds = 0;
     for (int it = 0; it < rounds; ++it) {
         akz_config cfg{};  // Config::default() (types/evolution.rs:40-55)
         cfg.num_sublevels = 4; cfg.max_octave_evolution = 4; cfg.base_scale_offset = 1.6; cfg.initial_contrast = 0.001;
@@ -95,7 +96,9 @@ int main(int argc, char** argv) {
         std::vector<LevelPlan> plan;
         if (build_plan(w, h, cfg, plan) != AKZ_OK) continue;
         // candidates: a few cluster centres in full-resolution coordinates, every level draws points around them
-        const int n_centres = uni(1, 12), per_level = uni(0, 400);
+        // (every other round sparser: lists that fit the device's neighbour lists, which the dependency rounds below need)
+        const bool sparse = it % 2 == 1;
+        const int n_centres = uni(1, 12), per_level = sparse ? uni(0, 120) : uni(0, 400);
         std::vector<std::pair<float, float>> centres;
         for (int c = 0; c < n_centres; ++c) centres.emplace_back((float)uni(0, (int)w - 1), (float)uni(0, (int)h - 1));
         std::vector<Candidate> cands;
@@ -104,7 +107,7 @@ int main(int argc, char** argv) {
             const float ratio = (float)(1u << lv.octave);
             for (int k = 0; k < per_level; ++k) {
                 const auto& ce = centres[(size_t)uni(0, n_centres - 1)];
-                const int spread = uni(0, 3) == 0 ? 40 : 4;
+                const int spread = sparse ? uni(8, 160) : (uni(0, 3) == 0 ? 40 : 4);
                 const int x = std::min<int>((int)lv.w - 1, std::max(0, (int)(ce.first / ratio) + uni(-spread, spread)));
                 const int y = std::min<int>((int)lv.h - 1, std::max(0, (int)(ce.second / ratio) + uni(-spread, spread)));
                 Candidate c{};
@@ -184,11 +187,13 @@ int main(int argc, char** argv) {
                     }
                 }
             }
+            long overflowed_now = 0;
             for (size_t i = 0; i < n; ++i) {
                 if (o1[i]) rel[i * (size_t)(K1 + K2)] = 0xfffeu;
                 if (o2[i]) rel[i * (size_t)(K1 + K2) + (size_t)K1] = 0xfffeu;
-                overflowed += o1[i] + o2[i];
+                overflowed_now += o1[i] + o2[i];
             }
+            overflowed += overflowed_now;
             if (!overflow) {
                 std::vector<HostKeypoint> got2;
                 uint64_t ne2 = 0;
@@ -206,12 +211,122 @@ int main(int argc, char** argv) {
                         return 1;
                     }
                 ++rel_rounds;
+                // the same selection as dependency rounds (akz_select.hpp; on the GPU box akz_select.hip runs them): reverse lists,
+                // ranks, then rounds in which every ready candidate takes its turn -- here in a random order with every write
+                // visible at once, which is the worst interleaving a workgroup could produce
+                bool dev_ok = overflowed_now == 0;
+                std::vector<std::vector<uint16_t>> rev(n);
+                for (size_t i = 0; i < n && dev_ok; ++i)
+                    for (int j = 0; j < K1; ++j) {
+                        const uint16_t q = rel[i * (size_t)(K1 + K2) + (size_t)j];
+                        if (q == sel::kNone) break;
+                        rev[q].push_back((uint16_t)i);
+                    }
+                for (size_t i = 0; i < n; ++i) dev_ok = dev_ok && rev[i].size() <= (size_t)sel::kRev;
+                if (dev_ok) {
+                    // rows as k_sel_prepare forms them, then the turns as k_select takes them: `threads` owners, each walking its
+                    // candidates (c % threads == owner) in index order, interleaved at random, every write visible at once
+                    typedef sel::Row<kRel1, kRel2> Row;
+                    std::vector<Row> rows(n);
+                    std::vector<uint8_t> sd(n, 0);
+                    std::vector<uint16_t> origin(n, sel::kNone);
+                    const size_t threads = (size_t)uni(1, 96);
+                    std::vector<std::vector<uint16_t>> own(threads);
+                    size_t undecided = 0;
+                    for (size_t i = 0; i < n; ++i) {
+                        const uint16_t* r1 = &rel[i * (size_t)(K1 + K2)];
+                        Row& rw = rows[i];
+                        rw.wins = 0;
+                        unsigned len = 0;
+                        for (int j = 0; j < K1; ++j) {
+                            rw.rel1[j] = r1[j];
+                            rw.pred[j] = sel::kNone;
+                            if (r1[j] == sel::kNone) continue;
+                            ++len;
+                            for (uint16_t m : rev[r1[j]])
+                                if (m < i && (rw.pred[j] == sel::kNone || m > rw.pred[j])) rw.pred[j] = m;
+                            if (std::fabs(cands[i].v) > std::fabs(cands[r1[j]].v)) rw.wins |= (uint16_t)(1u << j);
+                        }
+                        for (int j = 0; j < K2; ++j) rw.rel2[j] = r1[K1 + j];
+                        rw.refined = (uint16_t)(len << 8);
+                        if (r1[0] == sel::kNone) { sd[i] = sel::kDecided | sel::kAccepted; origin[i] = (uint16_t)i; }
+                        else { own[i % threads].push_back((uint16_t)i); ++undecided; }
+                    }
+                    auto SD = [&](uint16_t q) { return sd[q]; };
+                    auto OG = [&](uint16_t q) { return origin[q]; };
+                    std::vector<size_t> at_of(threads, 0);
+                    std::vector<sel::Progress> prog(threads);
+                    for (auto& pr : prog) sel::start(&pr);
+                    long looks = 0, idle = 0;
+                    while (undecided) {
+                        const size_t t = (size_t)uni(0, (int)threads - 1);
+                        if (at_of[t] >= own[t].size()) continue;
+                        const uint16_t c = own[t][at_of[t]];
+                        const Row& rw = rows[c];
+                        const int len = rw.refined >> 8;
+                        ++looks;
+                        // one neighbour per look (the device goes on while they are through: any interleaving in between is allowed)
+                        bool moved = false;
+                        if (prog[t].through < len) {
+                            const int j = prog[t].through;
+                            const bool has_pred = rw.pred[j] != sel::kNone;
+                            const uint8_t bp = has_pred ? sd[rw.pred[j]] : (uint8_t)0;
+                            const uint8_t bq = sd[rw.rel1[j]];
+                            moved = sel::advance(&prog[t], has_pred, bp, bq, origin[rw.rel1[j]]);
+                        }
+                        if (prog[t].through < len) {
+                            if (!moved && ++idle > 4000000) { fprintf(stderr, "round %d: the turns stalled with %zu candidates\n", it, undecided); return 1; }
+                            continue;
+                        }
+                        idle = 0;
+                        uint16_t oc;
+                        bool kills;
+                        const uint8_t mine = sel::turn(prog[t], c, rw.wins, &oc, &kills);
+                        origin[c] = oc;
+                        if (kills) sd[rw.rel1[prog[t].at]] |= sel::kKilled;
+                        sd[c] = mine;
+                        ++at_of[t];
+                        sel::start(&prog[t]);
+                        --undecided;
+                    }
+                    max_rounds = std::max(max_rounds, looks);
+                    const std::vector<uint8_t>& state = sd;
+                    // second pass, refinement, cache order = order of the origins
+                    std::vector<int32_t> at(n, -1);
+                    uint64_t ne3 = 0;
+                    for (size_t k = 0; k < n; ++k) {
+                        if (!sel::alive(state[k])) continue;
+                        if (sel::repeated_later<kRel2>(origin[k], rows[k].rel2, SD, OG)) continue;
+                        ++ne3;
+                        at[origin[k]] = (int32_t)k;
+                    }
+                    std::vector<sel::KpRec> got3;
+                    for (size_t o = 0; o < n; ++o) {
+                        if (at[o] < 0) continue;
+                        const Candidate& cd = cands[(size_t)at[o]];
+                        const LevelPlan& lv = plan[cd.level];
+                        sel::KpRec rec{};
+                        rec.level = cd.level;
+                        if (sel::refine(cd.idx % lv.w, cd.idx / lv.w, cd.v, cd.xp, cd.xm, cd.yp, cd.ym, powf(2.0f, (float)lv.octave), &rec)) got3.push_back(rec);
+                    }
+                    if (ne3 != ne_exp || got3.size() != exp.size()) {
+                        fprintf(stderr, "round %d (dependency rounds): %zu/%llu keypoints/extrema, expected %zu/%llu\n", it, got3.size(),
+                                (unsigned long long)ne3, exp.size(), (unsigned long long)ne_exp);
+                        return 1;
+                    }
+                    for (size_t i = 0; i < got3.size(); ++i)
+                        if (got3[i].x != exp[i].x || got3[i].y != exp[i].y || got3[i].response != exp[i].response || got3[i].level != exp[i].class_id) {
+                            fprintf(stderr, "round %d (dependency rounds): keypoint %zu differs\n", it, i);
+                            return 1;
+                        }
+                    ++dep_rounds;
+                }
             }
         }
         total_c += (long)cands.size();
         total_k += (long)got.size();
     }
-    printf("selected %ld keypoints from %ld candidates, identical to the linear scans (%ld rounds also through the neighbour lists, %ld overflowed lists)\n", total_k, total_c,
-           rel_rounds, overflowed);
+    printf("selected %ld keypoints from %ld candidates, identical to the linear scans (%ld rounds also through the neighbour lists, %ld overflowed lists; "
+           "%ld rounds also as the device's data flow of turns, at most %ld looks)\n", total_k, total_c, rel_rounds, overflowed, dep_rounds, max_rounds);
     return 0;
 }

@@ -1788,11 +1788,11 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // the finish half is gone.  Taken where the neighbour lists are (the host's selection is the longest piece of a lone
     // image's call); an image whose lists overflowed sends the job down the host's path below.
     // ... and where the call waits for it: a job with another one begun behind it is part of a stream, whose rate the chip
-    // bounds, not the host (lone 1080p frames: 0.60 ms per frame with the host's selection, 0.61 with the device's; a
-    // synchronous call 0.98 -> 0.95 ms, a 4K frame 2.06 -> 1.81 ms, either way)
-    const bool want_dev = c->dbg_select == 2 ||
-                          (c->dbg_select < 0 && want_rel &&
-                           (c->pool().size() < 4 || (uint64_t)r->w * r->h >= 6000000ull || !(c->begin_seq.load() > job->seq)));
+    // bounds, not the host -- and k_select's workgroup wants nearly all of a compute unit's LDS, which a chip busy with the
+    // next job's kernels frees only at their ends (pairs of 4K frames streamed: 2.9 ms per pair with the host's selection,
+    // 4.4 with the device's; the synchronous pair 4.3 -> 3.7 ms, a lone 4K frame 2.06 -> 1.81 ms, a lone 1080p frame
+    // 0.98 -> 0.95 ms)
+    const bool want_dev = c->dbg_select == 2 || (c->dbg_select < 0 && want_rel && (c->pool().size() < 4 || !(c->begin_seq.load() > job->seq)));
     bool sorted = false, dev_sel = false;
     uint16_t* d_rel = nullptr;
     uint32_t* d_rel_flags = nullptr;

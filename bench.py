@@ -115,7 +115,7 @@ def parse_args(argv=None):
     ap.add_argument("--det-mode", type=int, default=2, help="detector kernels: 2 auto, 5 column march, 4 one LDS-tiled kernel, 0 LDS-tiled pair")
     ap.add_argument("--prep-mode", type=int, default=2, help="level-preparation kernel: 2 auto, 1 streaming, 0 LDS-tiled")
     ap.add_argument("--eager", type=int, default=1, help="akz_ctx_set_eager_finish (the library's default: on): the finish half on the context's own thread")
-    ap.add_argument("--select", type=int, default=-1, help="akz_debug_set_select: keypoint selection from the device's neighbour lists (1), the host's grids (0), automatic (-1)")
+    ap.add_argument("--select", type=int, default=-1, help="akz_debug_set_select: keypoint selection on the device (2), on the host from the device's neighbour lists (1), from the host's grids (0), automatic (-1)")
     ap.add_argument("--sched", type=str, default="", help="akz_debug_set_schedule pairs, e.g. 0=1,1=1,2=0")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="batches begun ahead of the one being finished (the context holds at most three in flight)")
@@ -455,7 +455,7 @@ def main_rank(args):
             ctx.set_host_threads(placement["cpus"])
         ctx.set_detector_mode(args.det_mode)
         ctx.set_eager_finish(bool(args.eager))
-        ctx.debug_set_select(None if args.select < 0 else bool(args.select))
+        ctx.debug_set_select(None if args.select < 0 else args.select)
         for kv in filter(None, args.sched.split(",")):
             k, v = kv.split("=")
             ctx.debug_set_schedule(int(k), int(v))
@@ -1155,6 +1155,7 @@ def main_rank(args):
         def single_worker(k):
             st_k = torch.cuda.Stream(dev)
             ctx_k = A.Context(local_rank, st_k.cuda_stream)
+            ctx_k.debug_set_select(None if args.select < 0 else args.select)
             fr = d_frames[k % F: k % F + 1]
             for _ in range(5):
                 ctx_k.extract_begin(fr, cfg, keep_all_planes=not args.lean).finish().close()

@@ -25,6 +25,14 @@ const std::string& get_error();
 }
 using namespace akz;
 
+namespace {
+struct SelKpHost {  // a keypoint of the device's selection as the host fetches it (akz_sort.hip: SelKp)
+    sel::KpRec rec;
+    OrientOut sums;
+};
+static_assert(sizeof(SelKpHost) == 32, "the device writes 32-byte records");
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
@@ -146,6 +154,7 @@ struct akz_ctx {
     std::atomic<int> live_results{0};   // akz_result objects (also inside jobs) that still point at this context
     bool dead = false;                  // akz_ctx_destroy was called; the struct lives until the last result is freed
     std::atomic<uint32_t> last_total_cands{0};  // candidates of the previous finished job (speculative fetch size)
+    std::atomic<uint64_t> last_cand_shape{0};   // ... and its shape (w << 40 | h << 16 | n)
     hipStream_t aux = nullptr;          // finish-side copies and keypoint kernels (created under aux_m: the caller's thread and the finisher's may both be first)
     std::mutex aux_m;
     hipStream_t coarse = nullptr;       // the coarse octaves' chain (diffusion + detectors), next to the fine detectors
@@ -1380,8 +1389,17 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // a side stream next to the diffusion was +3 % with the round-1 kernels and is -15 % with the column march, which
     // saturates the store path on its own; with only the half-resolution octave's detectors on the side stream it is
     // still -5 %: removed).
-    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint.load(), 16u),
-                                                      0x7fffffffull / sizeof(Candidate));
+    uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * std::max<uint32_t>(c->cand_cap_hint.load(), 16u),
+                                                0x7fffffffull / sizeof(Candidate));
+    // A job like the one before it (same shape) whose list was short gets a list no longer than the one-launch sort takes
+    // (launch::sort_small_capacity): should this image have more candidates after all, the overflow path of the finish half
+    // redoes the extrema with room for them.
+    {
+        const uint32_t last = c->last_total_cands.load();
+        if (c->last_cand_shape.load() == (((uint64_t)w << 40) | ((uint64_t)h << 16) | n) && last > 0 &&
+            (uint64_t)last * 5 / 4 + 64 <= launch::sort_small_capacity())
+            cap = std::min(cap, launch::sort_small_capacity());
+    }
     AKZ_TRY(ensure(c, c->cand_slot[slot], (size_t)cap * sizeof(Candidate)));
     AKZ_TRY(ensure(c, c->count_slot[slot], 256));
     uint32_t* d_count = (uint32_t*)c->count_slot[slot].p;
@@ -1820,26 +1838,31 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             AKZ_TRY(ensure(c, c->sel_scratch, launch::select_device_bytes(cap, n)));
             selp = c->sel_scratch.p;
         }
-        sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
-                                                n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p,
-                                                selp ? launch::select_device_revcnt(selp, cap, n) : nullptr);
+        std::vector<uint32_t> lw(L), lh(L);
+        for (size_t l = 0; l < L; ++l) {
+            lw[l] = plan[l].w;
+            lh[l] = plan[l].h;
+        }
+        uint32_t* d_zero = selp ? launch::select_device_revcnt(selp, cap, n) : nullptr;
+        sorted = n == 1 && launch::sort_candidates_rows(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, lw.data(), lh.data(), (uint32_t)L,
+                                                        (Candidate*)c->cand_sorted.p, d_zero);
+        if (!sorted)
+            sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
+                                                    n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p, d_zero);
         AKZ_HIP_TRY(hipGetLastError());
         if (sorted && (want_rel || want_dev)) {
-            std::vector<uint32_t> lw(L);
-            for (size_t l = 0; l < L; ++l) lw[l] = plan[l].w;
-            AKZ_TRY(ensure(c, c->rel_scratch, launch::candidate_relations_bytes(cap, (uint32_t)L, n)));
-            launch::candidate_relations(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), (uint32_t)L, n,
-                                        c->rel_scratch.p, &d_rel, &d_rel_flags, selp);
+            AKZ_TRY(ensure(c, c->rel_scratch, launch::candidate_relations_bytes(cap, lh.data(), (uint32_t)L, n)));
+            launch::candidate_relations(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), lh.data(),
+                                        (uint32_t)L, n, c->rel_scratch.p, &d_rel, &d_rel_flags, selp);
             AKZ_HIP_TRY(hipGetLastError());
             if (want_dev) {
-                AKZ_TRY(ensure(c, c->sel_recs, (size_t)cap * sizeof(sel::KpRec)));
+                AKZ_TRY(ensure(c, c->sel_recs, (size_t)cap * sizeof(SelKpHost)));
                 AKZ_TRY(ensure(c, c->kp_in, (size_t)cap * sizeof(KpParam)));
-                AKZ_TRY(ensure(c, c->kp_out, (size_t)cap * sizeof(OrientOut)));
-                launch::select_device(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), (uint32_t)L, n,
-                                      c->rel_scratch.p, selp, c->sel_recs.p, (KpParam*)c->kp_in.p, &d_sel_hdr, &d_sel_total);
+                launch::select_device(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), lh.data(),
+                                      (uint32_t)L, n, c->rel_scratch.p, selp, r->d_k, c->sel_recs.p, (KpParam*)c->kp_in.p, &d_sel_hdr, &d_sel_total);
                 if ((uint64_t)r->w * r->h * n >= r->big_px && c->begin_seq.load() > job->seq)  // (as the host path's orientation below)
                     AKZ_HIP_TRY(hipStreamWaitEvent(s, c->fed_ev[(job->seq + 1) % akz_ctx::kFedRing], 0));
-                launch::orientation_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, cap, wmask, nwin, (OrientOut*)c->kp_out.p);
+                launch::orientation_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, cap, wmask, nwin, &((SelKpHost*)c->sel_recs.p)->sums, 2);
                 AKZ_HIP_TRY(hipGetLastError());
                 dev_sel = true;
             }
@@ -1853,23 +1876,21 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         const Candidate* d_list = sorted ? (const Candidate*)c->cand_sorted.p : (const Candidate*)c->cand_slot[job->slot].p;
         AKZ_TRY(ensure_pinned(c, c->pin[1], 256));
         uint32_t* total_p = (uint32_t*)c->pin[1].p;
-        AKZ_HIP_TRY(hipMemcpyAsync(total_p, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        const bool dev_fetch = attempt == 0 && dev_sel;  // (the device's selection brings the count with its headers)
+        if (!dev_fetch) AKZ_HIP_TRY(hipMemcpyAsync(total_p, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         // Small jobs are bound by the latency of these round trips: fetch, with the count, as many candidates as the
         // previous job of this context had (+25 %) and the contrast factors, so that one synchronisation serves all.
         uint32_t spec = 0;
-        if (attempt == 0 && dev_sel) {  // the device's selection: its headers and as many keypoints / orientation sums as the last job had (+25 %)
+        if (dev_fetch) {  // the device's selection: two copies -- the headers (with the list's length, the contrast factors and the
+                          // images' flags) and as many keypoints with their orientation sums as the last job had (+25 %)
             const uint32_t last = c->last_total_kp.load();
             spec_kp = std::min<uint32_t>(cap, last + last / 4 + 256u);
+            AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 64));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[8].p, d_sel_hdr, (size_t)n * 64, hipMemcpyDeviceToHost, s));
+            AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec_kp * sizeof(SelKpHost)));
+            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->sel_recs.p, (size_t)spec_kp * sizeof(SelKpHost), hipMemcpyDeviceToHost, s));
             AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
-            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[5].p, r->d_k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-            AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 32));
-            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[8].p, d_sel_hdr, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-            AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec_kp * sizeof(sel::KpRec)));
-            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->sel_recs.p, (size_t)spec_kp * sizeof(sel::KpRec), hipMemcpyDeviceToHost, s));
-            AKZ_TRY(ensure_pinned(c, c->pin[9], (size_t)spec_kp * sizeof(OrientOut)));
-            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[9].p, c->kp_out.p, (size_t)spec_kp * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
             AKZ_TRY(ensure_pinned(c, c->pin[7], (size_t)n * sizeof(uint32_t)));
-            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[7].p, d_rel_flags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         } else if (attempt == 0) {
             const uint32_t last = c->last_total_cands.load();
             spec = std::min<uint32_t>(cap, last + last / 4 + 64u);
@@ -1891,9 +1912,18 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         }
         AKZ_HIP_TRY(hipStreamSynchronize(s));
         t_counts = now_ms();
+        if (dev_fetch) {  // (into the places where the host's path looks for them, should the job go back to it)
+            const uint32_t* hdr = (const uint32_t*)c->pin[8].p;
+            *total_p = hdr[8];
+            for (uint32_t img = 0; img < n; ++img) {
+                ((uint32_t*)c->pin[7].p)[img] = hdr[img * 16 + 9];
+                std::memcpy((double*)c->pin[5].p + img, &hdr[img * 16 + 10], sizeof(double));
+            }
+        }
         total_c = *total_p;
         if (attempt == 0) r->k_host.assign((const double*)c->pin[5].p, (const double*)c->pin[5].p + n);
         c->last_total_cands = total_c;
+        c->last_cand_shape = ((uint64_t)r->w << 40) | ((uint64_t)r->h << 16) | n;
         c->cand_cap_hint = std::max(c->cand_cap_hint.load(), (uint32_t)((uint64_t)total_c * 5 / 4 / n) + 64u);
         if (total_c > cap) {  // overflow: grow and redo the NMS pass alone on the stored Ldet planes (the host sorts that list)
             if (attempt >= 3) {
@@ -1918,28 +1948,23 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             const uint32_t* hdr = (const uint32_t*)c->pin[8].p;
             uint32_t max_rounds = 0, fallen = 0;
             for (uint32_t img = 0; img < n; ++img) {
-                if (hdr[img * 8 + 2] != 0) {  // an image for the host's selection: the whole job takes it (its lists are fetched below)
+                if (hdr[img * 16 + 2] != 0) {  // an image for the host's selection: the whole job takes it (its lists are fetched below)
                     dev_sel = false;
                     ++fallen;
-                    fallen |= hdr[img * 8 + 2] << 16;
+                    fallen |= hdr[img * 16 + 2] << 16;
                 }
-                total_kp += hdr[img * 8];
-                max_rounds = std::max(max_rounds, hdr[img * 8 + 3]);
+                total_kp += hdr[img * 16];
+                max_rounds = std::max(max_rounds, hdr[img * 16 + 3]);
             }
             for (int k = 0; k < 4; ++k) c->sel_last_ticks[k] = hdr[4 + k];  // (image 0's phases)
             c->sel_last_rounds = max_rounds;
             c->sel_last_fallback = fallen;
             if (dev_sel && total_kp > spec_kp) {  // more keypoints than last time: the rest
-                std::vector<uint8_t> keep_r((const uint8_t*)c->pin[0].p, (const uint8_t*)c->pin[0].p + (size_t)spec_kp * sizeof(sel::KpRec));
-                std::vector<uint8_t> keep_o((const uint8_t*)c->pin[9].p, (const uint8_t*)c->pin[9].p + (size_t)spec_kp * sizeof(OrientOut));
-                AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)total_kp * sizeof(sel::KpRec)));
-                AKZ_TRY(ensure_pinned(c, c->pin[9], (size_t)total_kp * sizeof(OrientOut)));
+                std::vector<uint8_t> keep_r((const uint8_t*)c->pin[0].p, (const uint8_t*)c->pin[0].p + (size_t)spec_kp * sizeof(SelKpHost));
+                AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)total_kp * sizeof(SelKpHost)));
                 std::memcpy(c->pin[0].p, keep_r.data(), keep_r.size());
-                std::memcpy(c->pin[9].p, keep_o.data(), keep_o.size());
-                AKZ_HIP_TRY(hipMemcpyAsync((sel::KpRec*)c->pin[0].p + spec_kp, (const sel::KpRec*)c->sel_recs.p + spec_kp,
-                                           (size_t)(total_kp - spec_kp) * sizeof(sel::KpRec), hipMemcpyDeviceToHost, s));
-                AKZ_HIP_TRY(hipMemcpyAsync((OrientOut*)c->pin[9].p + spec_kp, (const OrientOut*)c->kp_out.p + spec_kp,
-                                           (size_t)(total_kp - spec_kp) * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+                AKZ_HIP_TRY(hipMemcpyAsync((SelKpHost*)c->pin[0].p + spec_kp, (const SelKpHost*)c->sel_recs.p + spec_kp,
+                                           (size_t)(total_kp - spec_kp) * sizeof(SelKpHost), hipMemcpyDeviceToHost, s));
                 AKZ_HIP_TRY(hipStreamSynchronize(s));
             }
             if (dev_sel) break;
@@ -2025,14 +2050,14 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     r->desc_off.assign(n + 1, 0);
     if (dev_sel) {  // the device's selection: the records into the host's form (size and octave follow from the level)
         const uint32_t* hdr = (const uint32_t*)c->pin[8].p;
-        const sel::KpRec* recs = (const sel::KpRec*)c->pin[0].p;
+        const SelKpHost* recs = (const SelKpHost*)c->pin[0].p;
         std::vector<uint64_t> first(n + 1, 0);
-        for (uint32_t img = 0; img < n; ++img) first[img + 1] = first[img] + hdr[img * 8];
+        for (uint32_t img = 0; img < n; ++img) first[img + 1] = first[img] + hdr[img * 16];
         c->pool().run(n, [&](size_t img) {
-            r->n_extrema[img] = hdr[img * 8 + 1];
-            hk[img].resize(hdr[img * 8]);
+            r->n_extrema[img] = hdr[img * 16 + 1];
+            hk[img].resize(hdr[img * 16]);
             for (size_t i = 0; i < hk[img].size(); ++i) {
-                const sel::KpRec& q = recs[first[img] + i];
+                const sel::KpRec& q = recs[first[img] + i].rec;
                 HostKeypoint& k = hk[img][i];
                 k.x = q.x; k.y = q.y; k.response = q.response;
                 k.size = lsize[q.level];
@@ -2091,9 +2116,11 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         const double t_or0 = now_ms();
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* oo = nullptr;
+        size_t oo_stride = 1;
         AKZ_TRY(ensure(c, c->cosi, total_kp * 2 * sizeof(float)));
-        if (dev_sel) {  // (parameters and sums are the device selection's: already here)
-            oo = (OrientOut*)c->pin[9].p;
+        if (dev_sel) {  // (parameters and sums are the device selection's: already here, next to the keypoints' records)
+            oo = &((SelKpHost*)c->pin[0].p)->sums;
+            oo_stride = 2;
         } else {
             AKZ_TRY(ensure(c, c->kp_in, total_kp * sizeof(KpParam)));
             AKZ_TRY(ensure(c, c->kp_out, total_kp * sizeof(OrientOut)));
@@ -2116,11 +2143,12 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         AKZ_TRY(ensure_pinned(c, c->pin[4], total_kp * 2 * sizeof(float)));
         float* cosi = (float*)c->pin[4].p;
         std::vector<float> angles(total_kp);
-        const size_t kAngleChunk = 4096;  // keypoints per libm job
+        const size_t kAngleChunk = 4096;  // keypoints per libm job (a lone frame's few thousand in four pieces: no gain)
         c->pool().run((total_kp + kAngleChunk - 1) / kAngleChunk, [&](size_t j) {
             const size_t b = j * kAngleChunk, e = std::min<size_t>(total_kp, b + kAngleChunk);
             for (size_t g = b; g < e; ++g) {
-                const float ang = oo[g].found ? atan2f(oo[g].sum_y, oo[g].sum_x) : 0.0f;  // scale_space_extrema.rs:326
+                const OrientOut& og = oo[g * oo_stride];
+                const float ang = og.found ? atan2f(og.sum_y, og.sum_x) : 0.0f;  // scale_space_extrema.rs:326
                 angles[g] = ang;
                 cosi[2 * g] = cosf(ang);                                                  // descriptors.rs:55-56
                 cosi[2 * g + 1] = sinf(ang);

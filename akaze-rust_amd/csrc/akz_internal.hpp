@@ -246,26 +246,32 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
 // the candidate list into scan order on the device (akz_sort.hip): by image, level, flat pixel index.  false: the
 // batch needs more key bits than the sort takes (the host then sorts)
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images);
+uint32_t sort_small_capacity();  // one image's list up to this capacity is sorted by one launch of one workgroup:
+// false: not this list (too long, too many rows) -- the caller takes sort_candidates_device
+bool sort_candidates_rows(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, const uint32_t* level_w,
+                          const uint32_t* level_h, uint32_t n_levels, Candidate* d_sorted, uint32_t* d_zero);
 bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, uint64_t max_px,
                             uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted, uint32_t* d_zero = nullptr);
 // who can be within `size` of whom (akz_sort.hip, k_relations): per candidate of the SORTED list kRel1 indices of earlier
 // candidates of its own / the previous level and kRel2 of the next level, relative to its image's first candidate
-size_t candidate_relations_bytes(uint32_t cap, uint32_t n_levels, uint32_t n_images);
+size_t candidate_relations_bytes(uint32_t cap, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images);
 void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
-                         const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, void* scratch, uint16_t** d_rel_out,
-                         uint32_t** d_flags_out, void* sel_scratch = nullptr);
+                         const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, void* scratch,
+                         uint16_t** d_rel_out, uint32_t** d_flags_out, void* sel_scratch = nullptr);
 // The selection itself on the device (akz_sort.hip: k_sel_prepare, k_select, k_sel_pack; akz_select.hpp): dependency rounds
 // over the neighbour lists, one workgroup per image.  sel_scratch (select_device_bytes) must have been handed to
 // sort_candidates_device (d_zero = select_device_revcnt(...)) and to candidate_relations of the same list.  Leaves, in image
-// order, the selected keypoints (d_recs: 16-byte records x, y, response, level) and the parameters of the keypoint kernels
-// (d_pars), room for `cap` of each; *d_hdr_out: per image {keypoints, extrema, status, rounds} -- status != 0: the image is
-// for the host's selection (an overflowed list, too many candidates) and the whole job should take that path --;
-// *d_total_out: the keypoint count of the job
+// order, the selected keypoints (d_recs: 32-byte records -- x, y, response, level, then room for the keypoint's OrientOut,
+// which orientation_counted(..., out_stride 2) fills in: one copy brings both to the host) and the parameters of the keypoint
+// kernels (d_pars), room for `cap` of each; *d_hdr_out: per image 16 words {keypoints, extrema, status, looks, four phase
+// times, the list's length, the image's flags, its contrast factor (2 words), 4 unused} -- status != 0: the image is for the
+// host's selection (an overflowed list, too many candidates) and the whole job should take that path --; *d_total_out: the
+// keypoint count of the job
 size_t select_device_bytes(uint32_t cap, uint32_t n_images);
 uint32_t* select_device_revcnt(void* sel_scratch, uint32_t cap, uint32_t n_images);
 void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
-                   const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, const void* rel_scratch, void* sel_scratch, void* d_recs,
-                   KpParam* d_pars, uint32_t** d_hdr_out, uint32_t** d_total_out);
+                   const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, const void* rel_scratch,
+                   void* sel_scratch, const double* d_k, void* d_recs, KpParam* d_pars, uint32_t** d_hdr_out, uint32_t** d_total_out);
 // candidates of all images are appended to ONE list (d_count is a single counter, cap the list capacity)
 void nms(hipStream_t s, const float* ldet, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
@@ -273,7 +279,7 @@ void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint3
                  unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out);
 // the same with the keypoint count still on the device (*d_nkp <= max_kp: the grid is sized for max_kp)
 void orientation_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t max_kp,
-                         unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out);
+                         unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out, uint32_t out_stride);
 // d_cosi: (cosf(angle), sinf(angle)) per keypoint from the host libm (descriptors.rs:55-56)
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64);

@@ -626,7 +626,7 @@ __device__ __forceinline__ unsigned xcd_contiguous_group(unsigned b, unsigned nb
 constexpr int ORI_KPB = 32, ORI_NS = 109, ORI_NT = 256;
 __global__ void __launch_bounds__(ORI_NT)
 k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, const unsigned* __restrict__ d_nkp,
-              unsigned long long window_mask, unsigned n_windows, OrientOut* __restrict__ out) {
+              unsigned long long window_mask, unsigned n_windows, OrientOut* __restrict__ out, unsigned out_stride) {
     __shared__ float s_rx[ORI_KPB * ORI_NS];
     __shared__ float s_ry[ORI_KPB * ORI_NS + 16];
     if (d_nkp) nkp = min(nkp, *d_nkp);  // (the count of a selection that ran on the device; nkp: what the grid was sized for)
@@ -705,7 +705,7 @@ k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, con
     if (!is_y && base + j < nkp) {
         OrientOut o;
         o.sum_x = bx; o.sum_y = by; o.found = found; o._pad = 0;
-        out[base + j] = o;
+        out[(size_t)(base + j) * out_stride] = o;
     }
 }
 
@@ -1242,14 +1242,14 @@ void orientation(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, uint3
     if (nkp == 0) return;
     const uint32_t groups = (nkp + ORI_KPB - 1) / ORI_KPB;
     hipLaunchKernelGGL(k_orientation, dim3((groups + 7u) / 8u * 8u), dim3(ORI_NT), 0, s, lt, d_kp, nkp, (const unsigned*)nullptr,
-                       window_mask, n_windows, d_out);
+                       window_mask, n_windows, d_out, 1u);
 }
 void orientation_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t max_kp,
-                         unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out) {
+                         unsigned long long window_mask, uint32_t n_windows, OrientOut* d_out, uint32_t out_stride) {
     if (max_kp == 0) return;
     const uint32_t groups = (max_kp + ORI_KPB - 1) / ORI_KPB;
     hipLaunchKernelGGL(k_orientation, dim3((groups + 7u) / 8u * 8u), dim3(ORI_NT), 0, s, lt, d_kp, max_kp, d_nkp, window_mask, n_windows,
-                       d_out);
+                       d_out, out_stride);
 }
 
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,

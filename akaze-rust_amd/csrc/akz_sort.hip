@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <vector>
 #include <type_traits>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -64,26 +65,123 @@ __global__ void k_candidate_gather(const Candidate* __restrict__ cand, unsigned 
 // 65 533 candidates is flagged and takes the grid path.
 struct RelLevels {  // per level, as select_keypoints computes them
     float size[kMaxLevels], ratio[kMaxLevels];
-    unsigned w[kMaxLevels];
+    unsigned w[kMaxLevels], h[kMaxLevels];
+    unsigned row_base[kMaxLevels + 1];  // where a level's rows begin in an image's row table (h + 1 entries per level)
     unsigned n_levels, n_images;
 };
-// first list position of every (image, level): offs[img * (L + 1) + level], level == L: the image's end
-__global__ void k_rel_offsets(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap, unsigned n_levels,
-                              unsigned n_images, unsigned* __restrict__ offs, unsigned* __restrict__ img_flags) {
+// first list position of every (image, level): offs[img * (L + 1) + level], level == L: the image's end; and of every
+// (image, level, row): rows[img * R + row_base[level] + y], y == h: the level's end, R = row_base[L] -- k_relations asks for
+// the candidates of a band of rows, and a binary search per question (a dozen dependent loads) was most of its time
+__global__ void k_rel_offsets(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap, RelLevels lv,
+                              unsigned* __restrict__ offs, unsigned* __restrict__ rows, unsigned* __restrict__ img_flags) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_images * (n_levels + 1)) return;
-    if (t < n_images) img_flags[t] = 0u;  // (only k_relations and k_sel_prepare, which come later, set them)
-    const unsigned img = t / (n_levels + 1), level = t - img * (n_levels + 1);
+    const unsigned L = lv.n_levels, R = lv.row_base[L], n_off = lv.n_images * (L + 1);
+    if (t >= n_off + lv.n_images * R) return;
+    if (t < lv.n_images) img_flags[t] = 0u;  // (only k_relations and k_sel_prepare, which come later, set them)
+    unsigned img, level, idx = 0;
+    if (t < n_off) {
+        img = t / (L + 1);
+        level = t - img * (L + 1);
+    } else {
+        const unsigned u = t - n_off;
+        img = u / R;
+        const unsigned r = u - img * R;
+        level = 0;
+        while (level + 1 < L && lv.row_base[level + 1] <= r) ++level;
+        idx = (r - lv.row_base[level]) * lv.w[level];
+    }
     const unsigned n = min(*d_count, cap);
-    unsigned lo = 0, hi = n;  // first entry with (img', level') >= (img, level)
+    unsigned lo = 0, hi = n;  // first entry with (img', level', idx') >= (img, level, idx)
     while (lo < hi) {
         const unsigned mid = (lo + hi) >> 1;
         const Candidate c = sorted[mid];
-        const bool before = c.img < img || (c.img == img && c.level < level);
+        const bool before = c.img < img || (c.img == img && (c.level < level || (c.level == level && c.idx < idx)));
         if (before) lo = mid + 1;
         else hi = mid;
     }
-    offs[t] = lo;
+    if (t < n_off) offs[t] = lo;
+    else rows[t - n_off] = lo;
+}
+// One image's list of up to SORT_SMALL_N candidates into scan order in ONE launch of one workgroup (a lone frame's; ten
+// launches of keys, rocPRIM's passes and the gather before: 45-55 us of a lone 1080p frame's call, each a few microseconds
+// of work): a counting sort over the (level, row) buckets in LDS -- the scan order is level, then row, then column -- and
+// an insertion sort of the handful of candidates inside each row.  Keys are unique: the same permutation as the radix sort.
+constexpr unsigned SORT_SMALL_N = 8192, SORT_SMALL_ROWS = 16384;
+__global__ void __launch_bounds__(1024) k_sort_rows(const Candidate* __restrict__ cand, unsigned cap, const unsigned* __restrict__ d_count,
+                                                    RelLevels lv, Candidate* __restrict__ out, unsigned* __restrict__ zero) {
+    __shared__ unsigned s_start[SORT_SMALL_ROWS + 1];  // per bucket: its count, then where it begins
+    __shared__ unsigned s_idx[SORT_SMALL_N];
+    __shared__ unsigned short s_pos[SORT_SMALL_N];
+    __shared__ unsigned s_part[16];
+    const unsigned n = min(min(*d_count, cap), SORT_SMALL_N), tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const unsigned R = lv.row_base[lv.n_levels];
+    for (unsigned b = tid; b <= R; b += 1024) s_start[b] = 0u;
+    __syncthreads();
+    constexpr int PER = SORT_SMALL_N / 1024;
+    unsigned bucket[PER], slot[PER], idx[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const unsigned i = tid + k * 1024;
+        bucket[k] = 0xffffffffu;
+        if (i < n) {
+            const Candidate c = cand[i];
+            const unsigned l = min(c.level, lv.n_levels - 1);
+            idx[k] = c.idx;
+            bucket[k] = lv.row_base[l] + min(c.idx / lv.w[l], lv.h[l] - 1u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (bucket[k] != 0xffffffffu) slot[k] = atomicAdd(&s_start[bucket[k]], 1u);
+    __syncthreads();
+    // exclusive scan of the counts: a contiguous chunk of buckets per thread
+    const unsigned per = (R + 1023) / 1024, b0 = min(R, tid * per), b1 = min(R, b0 + per);
+    unsigned mine = 0;
+    for (unsigned b = b0; b < b1; ++b) mine += s_start[b];
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - mine;
+    for (unsigned w = 0; w < wv; ++w) run += s_part[w];
+    for (unsigned b = b0; b < b1; ++b) {
+        const unsigned cnt = s_start[b];
+        s_start[b] = run;
+        run += cnt;
+    }
+    if (tid == 1023) s_start[R] = n;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (bucket[k] != 0xffffffffu) {
+            const unsigned at = s_start[bucket[k]] + slot[k];
+            s_pos[at] = (unsigned short)(tid + k * 1024);
+            s_idx[at] = idx[k];
+        }
+    __syncthreads();
+    for (unsigned b = tid; b < R; b += 1024) {  // inside a row: by column (insertion sort of a handful)
+        const unsigned lo = s_start[b], hi = s_start[b + 1];
+        for (unsigned i = lo + 1; i < hi; ++i) {
+            const unsigned v = s_idx[i];
+            const unsigned short pv = s_pos[i];
+            unsigned j = i;
+            for (; j > lo && s_idx[j - 1] > v; --j) {
+                s_idx[j] = s_idx[j - 1];
+                s_pos[j] = s_pos[j - 1];
+            }
+            s_idx[j] = v;
+            s_pos[j] = pv;
+        }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += 1024) {
+        out[i] = cand[s_pos[i]];
+        if (zero) zero[i] = 0u;
+    }
 }
 __device__ __forceinline__ unsigned rel_lower_bound(const Candidate* __restrict__ s, unsigned lo, unsigned hi, unsigned idx) {
     while (lo < hi) {  // first entry of [lo, hi) with .idx >= idx
@@ -94,9 +192,9 @@ __device__ __forceinline__ unsigned rel_lower_bound(const Candidate* __restrict_
     return lo;
 }
 __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
-                                                   RelLevels lv, const unsigned* __restrict__ offs, unsigned short* __restrict__ rel,
-                                                   unsigned* __restrict__ img_flags, unsigned* __restrict__ revcnt,
-                                                   unsigned short* __restrict__ rev) {
+                                                   RelLevels lv, const unsigned* __restrict__ offs, const unsigned* __restrict__ rows,
+                                                   unsigned short* __restrict__ rel, unsigned* __restrict__ img_flags,
+                                                   unsigned* __restrict__ revcnt, unsigned short* __restrict__ rev) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*d_count, cap)) return;
     const Candidate c = sorted[i];
@@ -114,21 +212,28 @@ __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__
     const float qx = (float)lx * ratio, qy = (float)ly * ratio;                  // the query point of the first pass (:52-53 of the host code)
     const float px = qx + 0.5f * (ratio - 1.0f), py = qy + 0.5f * (ratio - 1.0f);  // the candidate's stored position
     // partners of level pl in [b, e): rows whose stored y can lie within `reach` of y0 -- a conservative band, the exact
-    // test decides
+    // test decides.  The band's list positions come from the row table: the loop's bounds do not depend on what it loads.
+    const unsigned* rowI = rows + (size_t)c.img * lv.row_base[L];
     auto scan = [&](unsigned pl, unsigned b, unsigned e, float x0, float y0, int first, int room, int& used, bool& overflow) {
         if (b >= e) return;
         const float pr = lv.ratio[pl], off = 0.5f * (pr - 1.0f);
-        const unsigned pw = lv.w[pl];
+        const unsigned pw = lv.w[pl], ph = lv.h[pl];
         const float reach = size + 1.0f;
         const float ylo = (y0 - reach - off) / pr - 1.0f, yhi = (y0 + reach - off) / pr + 1.0f;
         const unsigned r0 = ylo <= 0.0f ? 0u : (unsigned)ylo;
-        if (yhi < 0.0f) return;
-        const unsigned long long last = (unsigned long long)((unsigned)yhi + 1u) * pw;
-        unsigned j = rel_lower_bound(sorted, b, e, r0 * pw);
-        for (; j < e; ++j) {
-            const Candidate p = sorted[j];
-            if ((unsigned long long)p.idx >= last) break;
-            const unsigned py_i = p.idx / pw, px_i = p.idx - py_i * pw;
+        if (yhi < 0.0f || r0 >= ph) return;
+        const unsigned r1 = min((unsigned)yhi + 1u, ph);  // one past the last row
+        const unsigned* rt = rowI + lv.row_base[pl];
+        const unsigned jb = max(b, rt[r0]), je = min(e, rt[r1]);
+        for (unsigned j0 = jb; j0 < je; j0 += 4) {  // (four loads in flight: a thread's loop is bound by their latency)
+            unsigned pidx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pidx[u] = j0 + u < je ? sorted[j0 + u].idx : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+            const unsigned j = j0 + u;
+            if (j >= je) break;
+            const unsigned py_i = pidx[u] / pw, px_i = pidx[u] - py_i * pw;
             const float sx = (float)px_i * pr + off, sy = (float)py_i * pr + off;  // its stored position
             const float dist = (x0 - sx) * (x0 - sx) + (y0 - sy) * (y0 - sy);
             if (dist <= size2) {
@@ -139,6 +244,7 @@ __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__
                     const unsigned at = atomicAdd(&revcnt[j], 1u);
                     if (at < (unsigned)sel::kRev) rev[(size_t)j * sel::kRev + at] = (unsigned short)(i - img0);
                 }
+            }
             }
         }
     };
@@ -221,13 +327,28 @@ constexpr int SEL_NT = 1024;
 constexpr unsigned SEL_MAX_CANDS = 49152;      // x 3 bytes = 144 KB of the 160 KB; an image with more goes to the host
 constexpr unsigned SEL_MAX_LOOKS = 4u << 20;   // (a turn that never becomes ready cannot happen; if it did, the image goes to the host)
 constexpr unsigned char SEL_SURVIVOR = 8;      // on the byte of a cache position's creator: its occupant is a keypoint
+struct SelKp {  // what the host fetches per keypoint: the selection's record, then the orientation sums (k_orientation fills them in)
+    sel::KpRec rec;
+    OrientOut sums;
+};
+static_assert(sizeof(SelKp) == 32, "akz_api.cpp fetches 32-byte records");
 struct SelOut {
-    unsigned* hdr;        // per image, 8 words: keypoints, extrema (before the refinement), status (0: done here), looks of the
-                          // slowest thread, 10 ns ticks of the four phases (first states, turns, second pass, output)
-    sel::KpRec* recs;     // per image at its first candidate's list position (one image: final)
+    unsigned* hdr;        // per image, 16 words: keypoints, extrema (before the refinement), status (0: done here), looks of the
+                          // slowest thread, 10 ns ticks of the four phases (first states, turns, second pass, output), and what the
+                          // host wants with them in ONE copy: the list's length (all images), the image's flags, its contrast factor
+    SelKp* recs;          // per image at its first candidate's list position (one image: final)
     KpParam* pars;
     unsigned* total;      // one image: the keypoint count again, for the kernels that follow
+    const unsigned* d_count;
+    const double* d_k;
 };
+__device__ __forceinline__ void sel_header_extras(const SelOut& out, unsigned img, unsigned flags) {
+    out.hdr[img * 16 + 8] = *out.d_count;
+    out.hdr[img * 16 + 9] = flags;
+    const double k = out.d_k[img];
+    out.hdr[img * 16 + 10] = (unsigned)((unsigned long long)__double_as_longlong(k) & 0xffffffffull);
+    out.hdr[img * 16 + 11] = (unsigned)((unsigned long long)__double_as_longlong(k) >> 32);
+}
 struct SelPacked {  // a row as its sixteen dwords: 0..5 rel1 (two per dword), 6..11 pred, 12 wins | rel2[0], 13..14 rel2[1..4], 15 rel2[5] | refined
     uint4 v[4];
 };
@@ -254,7 +375,8 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
     if (n > SEL_MAX_CANDS) status |= 1u;
     if (status != 0u || n == 0u) {
         if (tid == 0) {
-            out.hdr[img * 8 + 0] = 0u; out.hdr[img * 8 + 1] = 0u; out.hdr[img * 8 + 2] = status; out.hdr[img * 8 + 3] = 0u;
+            out.hdr[img * 16 + 0] = 0u; out.hdr[img * 16 + 1] = 0u; out.hdr[img * 16 + 2] = status; out.hdr[img * 16 + 3] = 0u;
+            sel_header_extras(out, img, img_flags[img]);
             if (out.total) *out.total = 0u;
         }
         return;
@@ -372,7 +494,8 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
     if (s_abort) status = 4u;
     if (status != 0u) {
         if (tid == 0) {
-            out.hdr[img * 8 + 0] = 0u; out.hdr[img * 8 + 1] = 0u; out.hdr[img * 8 + 2] = status; out.hdr[img * 8 + 3] = s_looks;
+            out.hdr[img * 16 + 0] = 0u; out.hdr[img * 16 + 1] = 0u; out.hdr[img * 16 + 2] = status; out.hdr[img * 16 + 3] = s_looks;
+            sel_header_extras(out, img, img_flags[img]);
             if (out.total) *out.total = 0u;
         }
         return;
@@ -415,7 +538,7 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
                         const unsigned r0 = ylo <= 0.0f ? 0u : (unsigned)ylo;
                         const unsigned long long last = (unsigned long long)((unsigned)yhi + 1u) * pw;
                         const unsigned e = o[l + 2];
-                        for (unsigned j = rel_lower_bound(sorted, o[l + 1], e, r0 * pw); j < e && !repeated; ++j) {
+                        for (unsigned j = rel_lower_bound(sorted, o[l + 1], e, r0 * pw); j < e && !repeated; ++j) {  // (rare: a search will do)
                             const Candidate p = sorted[j];
                             if ((unsigned long long)p.idx >= last) break;
                             const unsigned q = j - img0;
@@ -501,37 +624,38 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
             p.level = l;
             p.img = img;
             p._pad[0] = p._pad[1] = p._pad[2] = 0u;
-            out.recs[img0 + at] = rec;
+            out.recs[img0 + at].rec = rec;
             out.pars[img0 + at] = p;
         }
         (void)nb;
     }
     if (tid == 0) {
-        out.hdr[img * 8 + 0] = total; out.hdr[img * 8 + 1] = s_extrema; out.hdr[img * 8 + 2] = 0u; out.hdr[img * 8 + 3] = s_looks;
-        out.hdr[img * 8 + 4] = (unsigned)(t1 - t0); out.hdr[img * 8 + 5] = (unsigned)(t2 - t1); out.hdr[img * 8 + 6] = (unsigned)(t3 - t2);
-        out.hdr[img * 8 + 7] = (unsigned)(wall_clock64() - t3);
+        out.hdr[img * 16 + 0] = total; out.hdr[img * 16 + 1] = s_extrema; out.hdr[img * 16 + 2] = 0u; out.hdr[img * 16 + 3] = s_looks;
+        out.hdr[img * 16 + 4] = (unsigned)(t1 - t0); out.hdr[img * 16 + 5] = (unsigned)(t2 - t1); out.hdr[img * 16 + 6] = (unsigned)(t3 - t2);
+        out.hdr[img * 16 + 7] = (unsigned)(wall_clock64() - t3);
+        sel_header_extras(out, img, img_flags[img]);
         if (out.total) *out.total = total;
     }
 }
 
 // several images: the per-image runs into one list in image order (the keypoint kernels and the descriptor rows index it)
 __global__ void __launch_bounds__(256) k_sel_pack(const unsigned* __restrict__ offs, unsigned n_levels, unsigned n_images,
-                                                  const unsigned* __restrict__ hdr, const sel::KpRec* __restrict__ recs_in,
-                                                  const KpParam* __restrict__ pars_in, sel::KpRec* __restrict__ recs, KpParam* __restrict__ pars,
+                                                  const unsigned* __restrict__ hdr, const SelKp* __restrict__ recs_in,
+                                                  const KpParam* __restrict__ pars_in, SelKp* __restrict__ recs, KpParam* __restrict__ pars,
                                                   unsigned* __restrict__ total) {
     __shared__ unsigned s_red[256];
     const unsigned img = blockIdx.x, tid = threadIdx.x;
     unsigned part = 0;
-    for (unsigned j = tid; j < img; j += 256) part += hdr[j * 8];
+    for (unsigned j = tid; j < img; j += 256) part += hdr[j * 16];
     s_red[tid] = part;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)tid < off) s_red[tid] += s_red[tid + off];
         __syncthreads();
     }
-    const unsigned base = s_red[0], cnt = hdr[img * 8], img0 = offs[(size_t)img * (n_levels + 1)];
+    const unsigned base = s_red[0], cnt = hdr[img * 16], img0 = offs[(size_t)img * (n_levels + 1)];
     for (unsigned i = blockIdx.y * 256 + tid; i < cnt; i += gridDim.y * 256) {
-        recs[base + i] = recs_in[img0 + i];
+        recs[base + i].rec = recs_in[img0 + i].rec;
         pars[base + i] = pars_in[img0 + i];
     }
     if (img + 1 == n_images && blockIdx.y == 0 && tid == 0) *total = base + cnt;
@@ -542,9 +666,31 @@ __global__ void __launch_bounds__(256) k_sel_pack(const unsigned* __restrict__ o
 namespace launch {
 
 static size_t up256(size_t b) { return (b + 255) / 256 * 256; }
-size_t candidate_relations_bytes(uint32_t cap, uint32_t n_levels, uint32_t n_images) {
-    const size_t offs = ((size_t)n_images * (n_levels + 1) * 4 + 255) / 256 * 256, flags = ((size_t)n_images * 4 + 255) / 256 * 256;
-    return offs + flags + (size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t) + 256;
+// rel scratch: level offsets | image flags | neighbour lists | row table
+static uint32_t rows_per_image(const uint32_t* level_h, uint32_t n_levels) {
+    uint32_t r = 0;
+    for (uint32_t l = 0; l < n_levels; ++l) r += level_h[l] + 1;
+    return r;
+}
+size_t candidate_relations_bytes(uint32_t cap, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images) {
+    return up256((size_t)n_images * (n_levels + 1) * 4) + up256((size_t)n_images * 4) + up256((size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t)) +
+           up256((size_t)n_images * rows_per_image(level_h, n_levels) * 4) + 256;
+}
+static void fill_levels(RelLevels& lv, const float* size, const float* ratio, const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels,
+                        uint32_t n_images) {
+    std::memset(&lv, 0, sizeof(lv));
+    uint32_t base = 0;
+    for (uint32_t l = 0; l < n_levels && l < (uint32_t)kMaxLevels; ++l) {
+        lv.size[l] = size[l];
+        lv.ratio[l] = ratio[l];
+        lv.w[l] = level_w[l];
+        lv.h[l] = level_h[l];
+        lv.row_base[l] = base;
+        base += level_h[l] + 1;
+    }
+    lv.row_base[std::min<uint32_t>(n_levels, kMaxLevels)] = base;
+    lv.n_levels = n_levels;
+    lv.n_images = n_images;
 }
 // scratch of the device selection: reverse-list counters | reverse lists | rows | first states | headers | total |
 // per-image keypoint runs (several images)
@@ -559,9 +705,9 @@ static SelLayout sel_layout(uint32_t cap, uint32_t n_images) {
     l.rev = take((size_t)cap * sel::kRev * 2);
     l.rows = take((size_t)cap * sizeof(SelRow));
     l.state0 = take(cap);
-    l.hdr = take((size_t)n_images * 32);
+    l.hdr = take((size_t)n_images * 64);
     l.total = take(4);
-    l.recs_tmp = take(n_images > 1 ? (size_t)cap * sizeof(sel::KpRec) : 0);
+    l.recs_tmp = take(n_images > 1 ? (size_t)cap * sizeof(SelKp) : 0);
     l.pars_tmp = take(n_images > 1 ? (size_t)cap * sizeof(KpParam) : 0);
     l.end = at;
     return l;
@@ -571,8 +717,8 @@ uint32_t* select_device_revcnt(void* sel_scratch, uint32_t cap, uint32_t n_image
     return (uint32_t*)((char*)sel_scratch + sel_layout(cap, n_images).revcnt);
 }
 void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
-                   const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, const void* rel_scratch, void* sel_scratch, void* d_recs,
-                   KpParam* d_pars, uint32_t** d_hdr_out, uint32_t** d_total_out) {
+                   const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, const void* rel_scratch,
+                   void* sel_scratch, const double* d_k, void* d_recs, KpParam* d_pars, uint32_t** d_hdr_out, uint32_t** d_total_out) {
     const SelLayout l = sel_layout(cap, n_images);
     char* p = (char*)sel_scratch;
     const size_t offs_b = up256((size_t)n_images * (n_levels + 1) * 4), flags_b = up256((size_t)n_images * 4);
@@ -580,14 +726,7 @@ void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const
     unsigned* flags = (unsigned*)((char*)rel_scratch + offs_b);
     const unsigned short* rel = (const unsigned short*)((const char*)rel_scratch + offs_b + flags_b);
     RelLevels lv;
-    std::memset(&lv, 0, sizeof(lv));
-    for (uint32_t k = 0; k < n_levels && k < (uint32_t)kMaxLevels; ++k) {
-        lv.size[k] = size[k];
-        lv.ratio[k] = ratio[k];
-        lv.w[k] = level_w[k];
-    }
-    lv.n_levels = n_levels;
-    lv.n_images = n_images;
+    fill_levels(lv, size, ratio, level_w, level_h, n_levels, n_images);
     hipLaunchKernelGGL(k_sel_prepare, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, n_levels, n_images, offs, rel,
                        (const unsigned*)(p + l.revcnt), (const unsigned short*)(p + l.rev), (SelRow*)(p + l.rows),
                        (unsigned char*)(p + l.state0), flags);
@@ -595,38 +734,35 @@ void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const
     out.hdr = (unsigned*)(p + l.hdr);
     unsigned* total = (unsigned*)(p + l.total);
     const bool one = n_images == 1;
-    out.recs = one ? (sel::KpRec*)d_recs : (sel::KpRec*)(p + l.recs_tmp);
+    out.recs = one ? (SelKp*)d_recs : (SelKp*)(p + l.recs_tmp);
+    out.d_count = d_count;
+    out.d_k = d_k;
     out.pars = one ? d_pars : (KpParam*)(p + l.pars_tmp);
     out.total = one ? total : nullptr;
     hipLaunchKernelGGL(k_select, dim3(n_images), dim3(SEL_NT), 0, s, d_sorted, lv, offs, (const SelRow*)(p + l.rows),
                        (const unsigned char*)(p + l.state0), (const unsigned*)flags, out);
     if (!one)
         hipLaunchKernelGGL(k_sel_pack, dim3(n_images, 4), dim3(256), 0, s, offs, n_levels, n_images, (const unsigned*)out.hdr,
-                           (const sel::KpRec*)out.recs, (const KpParam*)out.pars, (sel::KpRec*)d_recs, d_pars, total);
+                           (const SelKp*)out.recs, (const KpParam*)out.pars, (SelKp*)d_recs, d_pars, total);
     *d_hdr_out = out.hdr;
     *d_total_out = total;
 }
 // d_rel_out / d_flags_out: where the lists and the per-image overflow flags are inside `scratch`
 void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
-                         const uint32_t* level_w, uint32_t n_levels, uint32_t n_images, void* scratch, uint16_t** d_rel_out,
-                         uint32_t** d_flags_out, void* sel_scratch) {
-    const size_t offs_b = ((size_t)n_images * (n_levels + 1) * 4 + 255) / 256 * 256, flags_b = ((size_t)n_images * 4 + 255) / 256 * 256;
+                         const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, void* scratch,
+                         uint16_t** d_rel_out, uint32_t** d_flags_out, void* sel_scratch) {
+    const size_t offs_b = up256((size_t)n_images * (n_levels + 1) * 4), flags_b = up256((size_t)n_images * 4),
+                 rel_b = up256((size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t));
     unsigned* offs = (unsigned*)scratch;
     unsigned* flags = (unsigned*)((char*)scratch + offs_b);
     unsigned short* rel = (unsigned short*)((char*)scratch + offs_b + flags_b);
+    unsigned* rows = (unsigned*)((char*)scratch + offs_b + flags_b + rel_b);
     *d_rel_out = rel;
     *d_flags_out = flags;
     RelLevels lv;
-    std::memset(&lv, 0, sizeof(lv));
-    for (uint32_t l = 0; l < n_levels && l < (uint32_t)kMaxLevels; ++l) {
-        lv.size[l] = size[l];
-        lv.ratio[l] = ratio[l];
-        lv.w[l] = level_w[l];
-    }
-    lv.n_levels = n_levels;
-    lv.n_images = n_images;
-    const unsigned no = n_images * (n_levels + 1);
-    hipLaunchKernelGGL(k_rel_offsets, dim3((no + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, n_levels, n_images, offs, flags);
+    fill_levels(lv, size, ratio, level_w, level_h, n_levels, n_images);
+    const unsigned no = n_images * (n_levels + 1) + n_images * lv.row_base[std::min<uint32_t>(n_levels, kMaxLevels)];
+    hipLaunchKernelGGL(k_rel_offsets, dim3((no + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rows, flags);
     unsigned* revcnt = nullptr;
     unsigned short* rev = nullptr;
     if (sel_scratch) {  // (the counters were zeroed by the sort's gather)
@@ -634,7 +770,7 @@ void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap,
         revcnt = (unsigned*)((char*)sel_scratch + l.revcnt);
         rev = (unsigned short*)((char*)sel_scratch + l.rev);
     }
-    hipLaunchKernelGGL(k_relations, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rel, flags, revcnt, rev);
+    hipLaunchKernelGGL(k_relations, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rows, rel, flags, revcnt, rev);
 }
 
 // scratch layout: keys in | keys out | positions in | positions out | rocPRIM's temporary storage
@@ -650,6 +786,16 @@ static KeyBits key_bits(uint64_t max_px, uint32_t n_levels, uint32_t n_images) {
     kb.level_bits = bits_for(n_levels);
     kb.total = kb.idx_bits + kb.level_bits + bits_for((unsigned long long)n_images + 1);  // + 1: the all-ones padding key
     return kb;
+}
+uint32_t sort_small_capacity() { return SORT_SMALL_N; }
+bool sort_candidates_rows(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, const uint32_t* level_w,
+                          const uint32_t* level_h, uint32_t n_levels, Candidate* d_sorted, uint32_t* d_zero) {
+    if (cap > SORT_SMALL_N || n_levels == 0 || n_levels > (uint32_t)kMaxLevels || rows_per_image(level_h, n_levels) > SORT_SMALL_ROWS) return false;
+    RelLevels lv;
+    std::vector<float> none(n_levels, 0.0f);
+    fill_levels(lv, none.data(), none.data(), level_w, level_h, n_levels, 1);
+    hipLaunchKernelGGL(k_sort_rows, dim3(1), dim3(1024), 0, s, d_cand, cap, d_count, lv, d_sorted, d_zero);
+    return true;
 }
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images) {
     const KeyBits kb = key_bits(max_px, n_levels, n_images);

@@ -491,8 +491,8 @@ def test_selection_on_the_device(amd, ref):
             ("4k", amd.synth_frame(3840, 2160, 2)[None], None, False, 2),
             ("5x5", amd.synth_frame(800, 600, 9)[None], dict(num_sublevels=5, max_octave_evolution=5), True, 2),
             ("flat", np.full((1, 240, 320), 90, np.uint8), None, False, 2),
+            ("dense", noise, dict(detector_threshold=1e-7), True, 2),  # (before "noise": a short list would shorten the next job's)
             ("noise", noise, None, True, 2),
-            ("dense", noise, dict(detector_threshold=1e-7), True, 2),
             ("many", np.random.default_rng(12).integers(0, 256, (1, 1200, 2048), dtype=np.uint8), None, False, None),
             ("batch+many", np.concatenate([amd.synth_frame(2048, 1200, 3)[None],
                                            np.random.default_rng(13).integers(0, 256, (1, 1200, 2048), dtype=np.uint8)]), None, False, None),
@@ -537,6 +537,38 @@ def test_selection_on_the_device(amd, ref):
             r = j.finish()
             assert r.keypoints(0).tobytes() == base.keypoints(0).tobytes() and r.descriptors(0).tobytes() == base.descriptors(0).tobytes()
         assert c.debug_select_info()[0] == 2
+    finally:
+        c.close()
+
+
+def test_short_candidate_lists_take_the_one_launch_sort_and_overflow_back(amd):
+    """A job of the same shape as the one before it whose list was short gets a list no longer than the one-launch sort takes
+    (k_sort_small); a frame of that shape with more candidates than that overflows it and is redone with room: every result
+    identical to a fresh context's."""
+    import torch
+    quiet = [amd.synth_frame(960, 540, 40 + i)[None] for i in range(3)]
+    busy = np.random.default_rng(5).integers(0, 256, (1, 540, 960), dtype=np.uint8)
+    seq = [quiet[0], quiet[1], busy, quiet[2], quiet[0], busy, busy, quiet[1]]
+    expect = []
+    for fr in seq:
+        c0 = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+        try:
+            r = c0.extract_features(torch.from_numpy(fr).cuda(), keep_all_planes=False)
+            expect.append((r.counts(0), r.keypoints(0).tobytes(), r.descriptors(0).tobytes()))
+        finally:
+            c0.close()
+    assert expect[2][0][1] > 3000 > expect[0][0][1] > 50
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        for mode in (None, 2, 1):
+            c.debug_set_select(mode)
+            for k, fr in enumerate(seq):
+                r = c.extract_features(torch.from_numpy(fr).cuda(), keep_all_planes=False)
+                assert (r.counts(0), r.keypoints(0).tobytes(), r.descriptors(0).tobytes()) == expect[k], (mode, k, r.counts(0), expect[k][0])
+            jobs = [c.extract_begin(torch.from_numpy(fr).cuda(), keep_all_planes=False) for fr in (quiet[0], quiet[1], busy)]
+            for k, j in zip((0, 1, 2), jobs):
+                r = j.finish()
+                assert (r.counts(0), r.keypoints(0).tobytes(), r.descriptors(0).tobytes()) == expect[k], (mode, "pipelined", k)
     finally:
         c.close()
 

@@ -27,11 +27,18 @@ print("streamed ms/frame", (time.perf_counter() - t) / 60 * 1e3)
 torch.cuda.synchronize(); time.sleep(0.05)
 ctx.extract_begin(frame, cfg).finish().close()   # one synchronous call last
 PY
-rocprofv3 --kernel-trace --output-format csv -d /tmp/lt_$$ -- python3 /tmp/lt_$$.py > $O/run.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/lt_$$ -- python3 /tmp/lt_$$.py > $O/run.log 2>&1
 f=$(find /tmp/lt_$$ -name "*kernel_trace.csv" | head -1)
-python3 - "$f" > $O/timeline.txt <<'PY'
+m=$(find /tmp/lt_$$ -name "*memory_copy_trace.csv" | head -1)
+python3 - "$f" "$m" > $O/timeline.txt <<'PY'
 import csv, sys
-rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+rows = list(csv.DictReader(open(sys.argv[1])))
+try:  # copies that an SDMA engine carries do not show as kernels
+    rows += [dict(r, Kernel_Name="COPY " + r.get("Direction", "").replace("MEMORY_COPY_", ""), Queue_Id="-", Workgroup_Size_X="1", Grid_Size_X="1")
+             for r in csv.DictReader(open(sys.argv[2]))]
+except Exception:
+    pass
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def nm(r): return r["Kernel_Name"].replace("void ", "").replace("akz::(anonymous namespace)::", "").split("(")[0][:40]
 blur = [i for i, r in enumerate(rows) if "k_blur" in nm(r) and "unsigned char" in nm(r)]
 # the streamed part: frames -8 .. -3 ; the synchronous call: the last blur

@@ -216,6 +216,7 @@ struct akz_ctx {
     // bandwidth unused -- that is where the next job's blur and contrast passes go (sched[1] = 2)
     hipEvent_t pre_ev[kFedRing] = {nullptr, nullptr, nullptr, nullptr};
     std::atomic<uint64_t> begin_seq{0};  // sequence number of the job begun last
+    std::shared_ptr<std::atomic<int>> in_hand = std::make_shared<std::atomic<int>>(0);  // akz_job::in_hand
     std::unique_ptr<WorkerPool> workers;  // host threads of the finish half (started on first use)
     unsigned host_threads = 0;            // akz_ctx_set_host_threads; 0 = sized by host_cpu_share()
     WorkerPool& pool() {
@@ -1026,6 +1027,13 @@ struct akz_job {
     int rc = 0;
     akz_result* out = nullptr;
     std::string err;
+    // jobs of the context that the caller has begun and not collected yet (this one included), counted until the job object
+    // goes: a job begun with none other in the caller's hand is being waited for, one begun with company is part of a stream
+    std::shared_ptr<std::atomic<int>> in_hand;
+    bool alone_at_begin = true;
+    ~akz_job() {
+        if (in_hand) --*in_hand;
+    }
 };
 
 static void result_release_device(akz_result* r) {
@@ -1324,6 +1332,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         return AKZ_ERR_INVALID_ARG;
     }
     std::unique_ptr<akz_job> job(new akz_job);
+    job->in_hand = c->in_hand;
+    job->alone_at_begin = job->in_hand->fetch_add(1) == 0;
     job->r.reset(new akz_result);
     akz_result* r = job->r.get();
     r->ctx = c;
@@ -1805,12 +1815,14 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // the keypoints it leaves -- the host neither fetches the candidate list nor selects, and one of the two round trips of
     // the finish half is gone.  Taken where the neighbour lists are (the host's selection is the longest piece of a lone
     // image's call); an image whose lists overflowed sends the job down the host's path below.
-    // ... and where the call waits for it: a job with another one begun behind it is part of a stream, whose rate the chip
-    // bounds, not the host -- and k_select's workgroup wants nearly all of a compute unit's LDS, which a chip busy with the
+    // ... and where the call waits for it: a job begun while another one was still in the caller's hand is part of a
+    // stream, whose rate the chip bounds, not the host -- and k_select's workgroup wants nearly all of a compute unit's LDS, which a chip busy with the
     // next job's kernels frees only at their ends (pairs of 4K frames streamed: 2.9 ms per pair with the host's selection,
     // 4.4 with the device's; the synchronous pair 4.3 -> 3.7 ms, a lone 4K frame 2.06 -> 1.81 ms, a lone 1080p frame
     // 0.98 -> 0.95 ms)
-    const bool want_dev = c->dbg_select == 2 || (c->dbg_select < 0 && want_rel && (c->pool().size() < 4 || !(c->begin_seq.load() > job->seq)));
+    // (a lane's jobs run next to the other lanes': part of a stream as well)
+    const bool waited_for = !c->is_lane && job->alone_at_begin;
+    const bool want_dev = c->dbg_select == 2 || (c->dbg_select < 0 && want_rel && (c->pool().size() < 4 || waited_for));
     bool sorted = false, dev_sel = false;
     uint16_t* d_rel = nullptr;
     uint32_t* d_rel_flags = nullptr;
@@ -1844,7 +1856,8 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             lh[l] = plan[l].h;
         }
         uint32_t* d_zero = selp ? launch::select_device_revcnt(selp, cap, n) : nullptr;
-        sorted = n == 1 && launch::sort_candidates_rows(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, lw.data(), lh.data(), (uint32_t)L,
+        // (the one-launch sort is one workgroup with 112 KB of LDS: as k_select, for the job that is waited for)
+        sorted = n == 1 && (waited_for || c->dbg_select == 2) && launch::sort_candidates_rows(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, lw.data(), lh.data(), (uint32_t)L,
                                                         (Candidate*)c->cand_sorted.p, d_zero);
         if (!sorted)
             sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
@@ -2289,6 +2302,8 @@ static int extract_from_planes(akz_ctx* c, uint32_t w, uint32_t h, const akz_con
         return AKZ_ERR_INVALID_ARG;
     }
     std::unique_ptr<akz_job> job(new akz_job);
+    job->in_hand = c->in_hand;
+    job->alone_at_begin = job->in_hand->fetch_add(1) == 0;
     job->r.reset(new akz_result);
     akz_result* r = job->r.get();
     r->ctx = c;

@@ -1075,6 +1075,16 @@ def main_rank(args):
         single = {"workload": f"one {W}x{H} frame per extract_features call (BASELINE configs[1])",
                   "latency_ms": round(lat * 1e3, 3), "stream_ms_per_frame": round(thr * 1e3, 3),
                   "stream_Mpix_s": round(W * H / thr / 1e6, 1)}
+        if not stub:
+            try:  # where the order-dependent keypoint selection of a synchronous call ran (akz_debug_select_info)
+                ctx.extract_features(one, cfg, keep_all_planes=not args.lean).close()
+                si = ctx.debug_select_info()
+                single["selection"] = {"where": {0: "host, spatial grids", 1: "host, device neighbour lists", 2: "device (k_select)"}.get(si[0], str(si[0])),
+                                       "candidates": si[3], "looks_of_slowest_thread": si[1],
+                                       "k_select_phase_us": {"first_states": si[4] / 100.0, "turns": si[5] / 100.0, "second_pass": si[6] / 100.0,
+                                                             "output": si[7] / 100.0}}
+            except Exception as e:
+                single["selection"] = {"error": str(e)[:200]}
         # the same stream on ONE context with lanes: frames dealt to 2 .. 4 child contexts, each of which finishes its frames
         # on its own thread; the caller's thread only enqueues the next frames and collects results; lone 4K frames the same way
         def stream_eager(frame, lanes, reps_e):

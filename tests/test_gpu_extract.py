@@ -541,6 +541,47 @@ def test_selection_on_the_device(amd, ref):
         c.close()
 
 
+def test_selection_on_the_device_random_jobs(amd):
+    """Randomised jobs (sizes, batch sizes, synthetic / noise / blended frames, thresholds, pyramid depths) through the device's
+    selection and through the host's grids: identical counts, keypoints and descriptors, image by image."""
+    import torch
+    rng = np.random.default_rng(20261005)
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    on_device = 0
+    try:
+        for case in range(36):
+            w, h = int(rng.integers(96, 720)), int(rng.integers(96, 560))
+            n = int(rng.integers(1, 7))
+            frames = []
+            for i in range(n):
+                kind = int(rng.integers(0, 4))
+                syn = amd.synth_frame(w, h, int(rng.integers(0, 1000)))
+                noi = rng.integers(0, 256, (h, w), dtype=np.uint8)
+                frames.append(syn if kind == 0 else noi if kind == 1 else ((syn.astype(np.uint16) + noi) // 2).astype(np.uint8) if kind == 2
+                              else np.full((h, w), int(rng.integers(0, 256)), np.uint8))
+            frames = np.stack(frames)
+            kw = {}
+            if rng.integers(0, 3) == 0:
+                kw["detector_threshold"] = float(10.0 ** rng.uniform(-6, -2.5))
+            if rng.integers(0, 4) == 0 and min(w, h) >= 200:
+                kw.update(num_sublevels=int(rng.integers(2, 6)), max_octave_evolution=int(rng.integers(2, 5)))
+            cfg = amd.Config(**kw)
+            dev = torch.from_numpy(frames).cuda()
+            c.debug_set_select(2)
+            r2 = c.extract_features(dev, cfg, keep_all_planes=False)
+            on_device += c.debug_select_info()[0] == 2
+            c.debug_set_select(0)
+            r0 = c.extract_features(dev, cfg, keep_all_planes=False)
+            for i in range(n):
+                assert r2.counts(i) == r0.counts(i), (case, w, h, n, kw, i, r2.counts(i), r0.counts(i))
+                assert r2.keypoints(i).tobytes() == r0.keypoints(i).tobytes(), (case, w, h, n, kw, i)
+                assert r2.descriptors(i).tobytes() == r0.descriptors(i).tobytes(), (case, w, h, n, kw, i)
+            r2.close(); r0.close()
+        assert on_device >= 30, on_device
+    finally:
+        c.close()
+
+
 def test_short_candidate_lists_take_the_one_launch_sort_and_overflow_back(amd):
     """A job of the same shape as the one before it whose list was short gets a list no longer than the one-launch sort takes
     (k_sort_small); a frame of that shape with more candidates than that overflows it and is redone with room: every result

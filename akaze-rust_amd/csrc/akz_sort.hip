@@ -434,6 +434,15 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
         wp[0] = r.v[1].z; wp[1] = r.v[1].w; wp[2] = r.v[2].x; wp[3] = r.v[2].y; wp[4] = r.v[2].z; wp[5] = r.v[2].w;
         wins = r.v[3].x & 0xffffu;
         len = (r.v[3].w >> 24) & 15u;
+        // (the row is wanted HERE: without this the compiler lets the lists live in the registers the row was loaded into and
+        // waits for every outstanding load -- the next row's prefetch too -- in each look of the loop below)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            AKZ_SEL_KEEP(wq[i]);
+            AKZ_SEL_KEEP(wp[i]);
+        }
+        AKZ_SEL_KEEP(wins);
+        AKZ_SEL_KEEP(len);
         sel::start(&prog);
     };
     {
@@ -441,6 +450,9 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
         fetch(first, b_cur);
         if (b_cur >= 0) open_row(first);
     }
+    // (the first row has arrived before the loop is entered: the compiler would otherwise wait for "everything outstanding"
+    // at the top of every look, i.e. for the prefetch of the next row as well)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     fetch(nxt, b_nxt);
     unsigned looks = 0, waited = 0;
     while (b_cur >= 0) {
@@ -483,9 +495,12 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
             if (b_cur >= 0) open_row(nxt);
             fetch(nxt, b_nxt);
             waited = 0;
-        } else if (++waited > SEL_MAX_LOOKS || *(volatile unsigned*)&s_abort) {
-            *(volatile unsigned*)&s_abort = 1u;
-            break;
+        } else if ((++waited & 255u) == 0u) {  // (every 256th fruitless look: has the workgroup given up?  A plain LDS read --
+            sel_compiler_fence();              // a volatile one is a FLAT load, which waits for the next row's prefetch too)
+            if (waited > SEL_MAX_LOOKS || s_abort != 0u) {
+                s_abort = 1u;
+                break;
+            }
         }
     }
     atomicMax(&s_looks, looks);

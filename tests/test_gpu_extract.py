@@ -582,6 +582,56 @@ def test_selection_on_the_device_random_jobs(amd):
         c.close()
 
 
+def test_selection_on_the_device_from_four_threads(amd):
+    """Four host threads, a context and a stream each, synchronous calls with the device's selection at the same time (the
+    workgroups of k_select / k_sort_rows of different contexts compete for compute units with most of their LDS free): every
+    result identical to the one a lone context gives."""
+    import threading
+    import torch
+    frames = [amd.synth_frame(960, 540, 300 + i)[None] for i in range(4)] + [amd.synth_frame(1920, 1080, 310)[None]]
+    c0 = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        c0.debug_set_select(0)
+        expect = []
+        for fr in frames:
+            r = c0.extract_features(torch.from_numpy(fr).cuda(), keep_all_planes=False)
+            expect.append((r.counts(0), r.keypoints(0).tobytes(), r.descriptors(0).tobytes()))
+            r.close()
+    finally:
+        c0.close()
+    dev_frames = [torch.from_numpy(fr).cuda() for fr in frames]
+    torch.cuda.synchronize()
+    errors, bar = [], threading.Barrier(4)
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream()
+            c = amd.Context(0, st.cuda_stream)
+            try:
+                c.debug_set_select(2)
+                bar.wait()
+                for it in range(12):
+                    j = (k + it) % len(frames)
+                    r = c.extract_features(dev_frames[j], keep_all_planes=False)
+                    if (r.counts(0), r.keypoints(0).tobytes(), r.descriptors(0).tobytes()) != expect[j]:
+                        errors.append((k, it, j, r.counts(0), expect[j][0]))
+                    if c.debug_select_info()[0] != 2:
+                        errors.append((k, it, j, "not on the device", c.debug_select_info()))
+                    r.close()
+            finally:
+                c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads)
+    assert not errors, errors[:4]
+
+
 def test_short_candidate_lists_take_the_one_launch_sort_and_overflow_back(amd):
     """A job of the same shape as the one before it whose list was short gets a list no longer than the one-launch sort takes
     (k_sort_small); a frame of that shape with more candidates than that overflows it and is redone with room: every result

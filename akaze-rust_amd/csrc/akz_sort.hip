@@ -385,13 +385,11 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
     const SelRow* rowI = rows + img0;
     const unsigned long long t0 = wall_clock64();  // (100 MHz; the phases' durations go into the header: akz_debug_select_info)
     if (tid == 0) { s_extrema = 0u; s_abort = 0u; s_looks = 0u; }
-#ifndef AKZ_SEL_BLOCKED
-#define AKZ_SEL_BLOCKED 0
-#endif
-    // this thread's candidates: a contiguous run of the list (its neighbours of the same level are mostly its own, so that
-    // the lanes of a wave wait for each other less than with candidates dealt out in turn)
+    // this thread's candidates: dealt out in turn -- t, t + 1024, ... (a contiguous run per thread, so that a candidate's
+    // same-level neighbours are mostly its own thread's, was measured: the threads of a level then start a whole run behind the
+    // level before, 1 000 - 1 900 looks on a 4K frame instead of ~100)
     const unsigned per = (n + SEL_NT - 1) / SEL_NT;
-    auto cand_of = [&](unsigned k) -> unsigned { return k >= per ? 0xffffffffu : (AKZ_SEL_BLOCKED ? tid * per + k : tid + k * SEL_NT); };
+    auto cand_of = [&](unsigned k) -> unsigned { return k >= per ? 0xffffffffu : tid + k * SEL_NT; };
     unsigned long long mask = 0ull;  // this thread's undecided candidates: bit k <-> candidate cand_of(k)
     constexpr int U = 8;
     for (unsigned k0 = 0; k0 < per; k0 += U) {

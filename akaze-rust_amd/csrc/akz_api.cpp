@@ -114,6 +114,8 @@ struct akz_ctx {
     int dbg_select = -1;                     // akz_debug_set_select: 2 / 1 / 0 force the device / the neighbour-list / the grid selection, -1 automatic
     std::atomic<uint32_t> last_total_kp{0};  // keypoints of the previous finished job (speculative fetch size of the device selection)
     std::atomic<int> sel_last_mode{-1};      // akz_debug_select_info: how the last finished job was selected (0 grids, 1 lists, 2 device), the
+    std::atomic<int> sel_skip{0};            // jobs of shape sel_skip_shape that leave the device's selection out (the last one fell back)
+    std::atomic<uint64_t> sel_skip_shape{0};
     std::atomic<uint32_t> sel_last_ticks[4];
     std::atomic<uint32_t> sel_last_rounds{0}, sel_last_fallback{0};  // device's longest run of rounds, images that sent it back to the host
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
@@ -1822,7 +1824,19 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // 0.98 -> 0.95 ms)
     // (a lane's jobs run next to the other lanes': part of a stream as well)
     const bool waited_for = !c->is_lane && job->alone_at_begin;
-    const bool want_dev = c->dbg_select == 2 || (c->dbg_select < 0 && want_rel && (c->pool().size() < 4 || waited_for));
+    // (a job whose lists overflowed went back to the host's selection after the device's attempt: the next eight jobs of that
+    // shape do not try -- dense texture stays dense)
+    const uint64_t shape = ((uint64_t)r->w << 40) | ((uint64_t)r->h << 16) | n;
+    bool skip_dev = false;
+    if (c->sel_skip.load() > 0 && c->sel_skip_shape.load() == shape) {
+        skip_dev = true;
+        --c->sel_skip;
+    }
+    const bool want_dev = c->dbg_select == 2 || (c->dbg_select < 0 && want_rel && !skip_dev && (c->pool().size() < 4 || waited_for));
+    if (!want_dev) {  // (akz_debug_select_info: nothing was tried on the device)
+        c->sel_last_rounds = 0;
+        c->sel_last_fallback = 0;
+    }
     bool sorted = false, dev_sel = false;
     uint16_t* d_rel = nullptr;
     uint32_t* d_rel_flags = nullptr;
@@ -1972,6 +1986,10 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             for (int k = 0; k < 4; ++k) c->sel_last_ticks[k] = hdr[4 + k];  // (image 0's phases)
             c->sel_last_rounds = max_rounds;
             c->sel_last_fallback = fallen;
+            if (fallen) {
+                c->sel_skip = 8;
+                c->sel_skip_shape = shape;
+            }
             if (dev_sel && total_kp > spec_kp) {  // more keypoints than last time: the rest
                 std::vector<uint8_t> keep_r((const uint8_t*)c->pin[0].p, (const uint8_t*)c->pin[0].p + (size_t)spec_kp * sizeof(SelKpHost));
                 AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)total_kp * sizeof(SelKpHost)));

@@ -541,6 +541,32 @@ def test_selection_on_the_device(amd, ref):
         c.close()
 
 
+def test_device_selection_is_not_retried_at_once_after_a_fallback(amd):
+    """A job whose image has more candidates than k_select holds goes back to the host after the device's attempt; the next
+    eight jobs of that shape leave the attempt out (jobs of another shape do not), the ninth tries again."""
+    import torch
+    many = torch.from_numpy(np.random.default_rng(12).integers(0, 256, (1, 1200, 2048), dtype=np.uint8)).cuda()
+    other = torch.from_numpy(amd.synth_frame(640, 480, 1)[None]).cuda()
+    c = amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        first = c.extract_features(many, keep_all_planes=False)  # (its list outgrows the first job's capacity: redone with room)
+        want = (first.counts(0), first.keypoints(0).tobytes())
+        assert c.debug_select_info()[3] > 49152
+        attempts = []
+        for k in range(11):
+            c.extract_features(other, keep_all_planes=False).close()
+            assert c.debug_select_info()[0] == 2  # (a synchronous call of another shape: on the device)
+            r = c.extract_features(many, keep_all_planes=False)
+            assert (r.counts(0), r.keypoints(0).tobytes()) == want
+            r.close()
+            info = c.debug_select_info()
+            assert info[0] != 2
+            attempts.append((info[2] & 0xffff) == 1)
+        assert attempts == [True] + [False] * 8 + [True, False], attempts
+    finally:
+        c.close()
+
+
 def test_selection_on_the_device_random_jobs(amd):
     """Randomised jobs (sizes, batch sizes, synthetic / noise / blended frames, thresholds, pyramid depths) through the device's
     selection and through the host's grids: identical counts, keypoints and descriptors, image by image."""

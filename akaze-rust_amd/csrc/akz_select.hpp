@@ -6,8 +6,9 @@
 // or is dropped, otherwise it is appended.  Afterwards entries that have a LATER entry of the next level within `size` are
 // dropped.  Two observations turn the walk into something a GPU can do:
 //   * "first" and "later" compare cache positions, and a cache position is created by exactly one candidate (an in-place
-//     replacement inherits it): positions are ordered like the candidates that created them.  origin[c] = the candidate
-//     that created the position c sits in replaces the running counter: no global state is left.
+//     replacement inherits it): positions are ordered like the candidates that created them.  The creator of the position
+//     a candidate sits in replaces the running counter: no global state is left, and one 16-bit word per candidate holds
+//     its whole state.
 //   * what candidate c sees of a neighbour q (k_relations' lists, rel1(c)) is q's own outcome plus whether an EARLIER
 //     candidate that also has q in its list replaced q before c's turn.  With rev(q) = {c' : q in rel1(c')}, c's view of q
 //     is final as soon as q and every member of rev(q) before c have had their turns -- and the members of rev(q) wait for
@@ -34,10 +35,11 @@ namespace akz {
 namespace sel {
 
 constexpr int kRev = 12;  // members of a reverse list the device keeps (more: the image goes to the host's selection)
-// a candidate's byte; written at its own turn and by the one member of its reverse list that replaces it, never from two
-// sides at once
-constexpr uint8_t kDecided = 1, kAccepted = 2, kKilled = 4;
 constexpr uint16_t kNone = 0xffffu, kListOverflow = 0xfffeu;
+// A candidate's word says it all: kUndecided until its turn; afterwards the creator of the cache position it sits in (a
+// candidate index: below kGone) while it is in the cache, kGone if it was dropped or has been replaced.  Written at the
+// candidate's own turn and by the one member of its reverse list that replaces it, never from two sides at once.
+constexpr uint16_t kUndecided = 0xffffu, kGone = 0xfffeu;
 
 struct KpRec {  // a selected keypoint as the host needs it (size and octave follow from the level)
     float x, y, response;
@@ -56,7 +58,7 @@ struct alignas(16) Row {
     uint16_t refined;  // bit 0: passes the refinement's gradient test (:141-178); bits 8 .. 11: entries of rel1
 };
 
-AKZ_SEL_HD bool alive(uint8_t b) { return (b & (kAccepted | kKilled)) == kAccepted; }
+AKZ_SEL_HD bool alive(uint16_t word) { return word < kGone; }
 
 // A candidate's progress through its list (scale_space_extrema.rs:57-99): how many neighbours are through, and of those the
 // live one with the first cache position (at: its place in the list, -1: none yet)
@@ -66,43 +68,41 @@ struct Progress {
     uint16_t hit;  // the creator of that cache position
 };
 AKZ_SEL_HD void start(Progress* p) { p->through = 0; p->at = -1; p->hit = kNone; }
-// Is neighbour `through` through?  byte_pred MUST have been read before byte_q, and byte_q before origin_q (the writers store
-// in the opposite order).  If so its contribution is folded in and the function returns true.
-AKZ_SEL_HD bool advance(Progress* p, bool has_pred, uint8_t byte_pred, uint8_t byte_q, uint16_t origin_q) {
-    if (!(byte_q & kDecided) || (has_pred && !(byte_pred & kDecided))) return false;
-    if (alive(byte_q) && origin_q < p->hit) {  // (origins of live entries are distinct and below 0xfffe)
-        p->hit = origin_q;
+// Is neighbour `through` through?  word_pred MUST have been read before word_q (the predecessor stores "q is gone" before its
+// own word).  If so the neighbour's contribution is folded in and the function returns true.
+AKZ_SEL_HD bool advance(Progress* p, bool has_pred, uint16_t word_pred, uint16_t word_q) {
+    if (word_q == kUndecided || (has_pred && word_pred == kUndecided)) return false;
+    if (alive(word_q) && word_q < p->hit) {  // (the creators of live entries are distinct)
+        p->hit = word_q;
         p->at = p->through;
     }
     ++p->through;
     return true;
 }
-// the turn, once every neighbour is through: the candidate's byte, the creator of its cache position, and whether the
-// neighbour at p.at dies (the caller stores origin first, then the neighbour's byte | kKilled, then the candidate's byte)
-AKZ_SEL_HD uint8_t turn(const Progress& p, uint16_t c, uint16_t wins, uint16_t* origin_c, bool* kills) {
-    *kills = false;
-    if (p.at < 0) {
-        *origin_c = c;
-        return (uint8_t)(kDecided | kAccepted);
-    }
+// the turn, once every neighbour is through: the candidate's word, and whether the neighbour at p.at is replaced (the
+// caller stores kGone into that neighbour's word first, then the candidate's word)
+AKZ_SEL_HD uint16_t turn(const Progress& p, uint16_t c, uint16_t wins, bool* replaces) {
+    *replaces = false;
+    if (p.at < 0) return c;  // a cache position of its own
     if ((wins >> p.at) & 1u) {
-        *origin_c = p.hit;
-        *kills = true;
-        return (uint8_t)(kDecided | kAccepted);
+        *replaces = true;
+        return p.hit;        // takes the neighbour's position over
     }
-    *origin_c = kNone;
-    return kDecided;  // not an extremum
+    return kGone;            // not an extremum
 }
 
 // second pass (:109-129): a live entry of the next level, at or after this entry's cache position, within `size`
-template <int K2, class SD, class OG>
-AKZ_SEL_HD bool repeated_later(uint16_t mine, const uint16_t* rel2, SD sd, OG og) {
+template <int K2, class W>
+AKZ_SEL_HD bool repeated_later(uint16_t mine, const uint16_t* rel2, W word) {
     bool rep = false, open = true;
     AKZ_SEL_UNROLL
     for (int j = 0; j < K2; ++j) {
         const uint16_t q = rel2[j];
         open = open && q != kNone;
-        if (open && alive(sd(q)) && og(q) >= mine) rep = true;
+        if (open) {
+            const uint16_t w = word(q);
+            if (alive(w) && w >= mine) rep = true;
+        }
     }
     return rep;
 }

@@ -183,14 +183,6 @@ __global__ void __launch_bounds__(1024) k_sort_rows(const Candidate* __restrict_
         if (zero) zero[i] = 0u;
     }
 }
-__device__ __forceinline__ unsigned rel_lower_bound(const Candidate* __restrict__ s, unsigned lo, unsigned hi, unsigned idx) {
-    while (lo < hi) {  // first entry of [lo, hi) with .idx >= idx
-        const unsigned mid = (lo + hi) >> 1;
-        if (s[mid].idx < idx) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
 __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
                                                    RelLevels lv, const unsigned* __restrict__ offs, const unsigned* __restrict__ rows,
                                                    unsigned short* __restrict__ rel, unsigned* __restrict__ img_flags,
@@ -310,23 +302,23 @@ __global__ void __launch_bounds__(256) k_sel_prepare(const Candidate* __restrict
         out.refined = (unsigned short)((fabsf(-d_x) <= 1.0f && fabsf(-d_y) <= 1.0f ? 1u : 0u) | (len << 8));
     }
     rows[i] = out;
-    state0[i] = row[0] == sel::kNone ? (unsigned char)(sel::kDecided | sel::kAccepted) : (unsigned char)0;
+    state0[i] = row[0] == sel::kNone ? (unsigned char)1 : (unsigned char)0;  // 1: opens a cache position of its own, no turn to wait for
     if (over) atomicOr(&img_flags[c.img], (row[0] == sel::kListOverflow ? 2u : 0u) | (revcnt[i] > (unsigned)sel::kRev ? 16u : 0u));
 }
 
-// k_select: one workgroup per image; a byte (state, done) and the creator of its cache position per candidate in LDS.  Thread
-// t owns the candidates t, t + 1024, ... and walks them in index order: when the current one is ready (sel::ready) it takes
-// its turn and moves on; otherwise it looks again.  No barrier separates the turns: whoever sees a neighbour's done counter
-// at its own rank sees everything the earlier members of that reverse list wrote (LDS operations of a wave execute in
-// order), and the lowest undecided candidate of the image is always ready, so every wave keeps moving.  A look fetches the
-// neighbours' bytes at once; the row of the next candidate is fetched while the current one waits.  Then the second pass and
-// the refinement's test (a bit on the byte of the cache position's creator), a count of those bits per chunk of creators,
-// and every survivor writes its keypoint at the rank of its cache position.  One workgroup's loops over tens of candidates
-// per thread are bound by the latency of their loads: they fetch for several candidates before they use the first.
+// k_select: one workgroup per image; ONE 16-bit word per candidate in LDS (undecided / the creator of the cache position it
+// sits in / gone: akz_select.hpp).  Thread t owns the candidates t, t + 1024, ... and walks them in index order: it waits for
+// the current one's neighbours one after the other -- a neighbour is through when its word and its predecessor's (the
+// previous candidate that also looks at it) are decided --, folds each one's contribution in, takes its turn (two stores)
+// and moves on.  No barrier separates the turns: whoever sees a predecessor's word decided sees what it stored before (LDS
+// operations of a wave execute in order), and the lowest undecided candidate of the image can always go, so every wave
+// keeps moving.  The row of the next candidate is fetched while the current one waits.  Then the second pass and the
+// refinement's test (a bit per cache position, by its creator), an exclusive scan over the bit words, and every survivor
+// writes its keypoint at the rank of its cache position.  One workgroup's loops over tens of candidates per thread are
+// bound by the latency of their loads: they fetch for several candidates before they use the first.
 constexpr int SEL_NT = 1024;
-constexpr unsigned SEL_MAX_CANDS = 49152;      // x 3 bytes = 144 KB of the 160 KB; an image with more goes to the host
+constexpr unsigned SEL_MAX_CANDS = 65536;      // x 2 bytes = 128 KB of the 160 KB (the lists' 16-bit indices allow 65 533 per image)
 constexpr unsigned SEL_MAX_LOOKS = 4u << 20;   // (a turn that never becomes ready cannot happen; if it did, the image goes to the host)
-constexpr unsigned char SEL_SURVIVOR = 8;      // on the byte of a cache position's creator: its occupant is a keypoint
 struct SelKp {  // what the host fetches per keypoint: the selection's record, then the orientation sums (k_orientation fills them in)
     sel::KpRec rec;
     OrientOut sums;
@@ -361,18 +353,26 @@ __device__ __forceinline__ SelPacked sel_load_row(const SelRow* __restrict__ p) 
 __device__ __forceinline__ void sel_compiler_fence() { __asm__ volatile("" ::: "memory"); }
 __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__ sorted, RelLevels lv, const unsigned* __restrict__ offs,
                                                    const SelRow* __restrict__ rows, const unsigned char* __restrict__ state0,
-                                                   const unsigned* __restrict__ img_flags, SelOut out) {
-    __shared__ unsigned short s_origin[SEL_MAX_CANDS];
-    __shared__ unsigned char s_sd[SEL_MAX_CANDS + 16];  // (+ the spare byte)
-    __shared__ unsigned s_base[SEL_NT];
+                                                   const unsigned* __restrict__ img_flags, const unsigned* __restrict__ row_table,
+                                                   SelOut out) {
+    __shared__ unsigned short s_word[SEL_MAX_CANDS];      // sel::kUndecided / the creator of the candidate's cache position / sel::kGone
+    __shared__ unsigned s_bits[SEL_MAX_CANDS / 32];        // per cache position (by its creator): its occupant is a keypoint
+    __shared__ unsigned s_pref[SEL_MAX_CANDS / 32];        // keypoints before the word
     __shared__ unsigned s_part[SEL_NT / 64];
     __shared__ unsigned s_extrema, s_abort, s_looks;
+    __shared__ float s_ratio[kMaxLevels], s_size[kMaxLevels];  // the level tables by a lane's own index: from LDS, not by a
+    __shared__ unsigned s_w[kMaxLevels];                        // per-lane load from the kernel arguments
     const unsigned img = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid < (unsigned)kMaxLevels) {
+        s_ratio[tid] = lv.ratio[tid];
+        s_size[tid] = lv.size[tid];
+        s_w[tid] = lv.w[tid];
+    }
     const unsigned L = lv.n_levels;
     const unsigned* o = offs + (size_t)img * (L + 1);
     const unsigned img0 = o[0], n = o[L] - img0;
     unsigned status = img_flags[img];
-    if (n > SEL_MAX_CANDS) status |= 1u;
+    if (n > 65533u) status |= 1u;
     if (status != 0u || n == 0u) {
         if (tid == 0) {
             out.hdr[img * 16 + 0] = 0u; out.hdr[img * 16 + 1] = 0u; out.hdr[img * 16 + 2] = status; out.hdr[img * 16 + 3] = 0u;
@@ -403,15 +403,15 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
         for (int u = 0; u < U; ++u) {
             const unsigned c = cand_of(k0 + u);
             if (c < n) {
-                s_sd[c] = st[u];
-                s_origin[c] = st[u] ? (unsigned short)c : sel::kNone;
+                s_word[c] = st[u] ? (unsigned short)c : sel::kUndecided;
                 if (!st[u]) mask |= 1ull << (k0 + u);
             }
         }
     }
     __syncthreads();
     const unsigned long long t1 = wall_clock64();
-    auto OG = [&](unsigned short q) -> unsigned short { return s_origin[q]; };
+    auto WORD = [&](unsigned short q) -> unsigned short { return s_word[q]; };
+    for (unsigned i = tid; i < SEL_MAX_CANDS / 32; i += SEL_NT) s_bits[i] = 0u;  // (read after the barriers that follow the turns)
     // The loop below runs ~100 times on the slowest thread and a wave pays for its longest path every time: it is kept short.
     // The lists stay packed in their dwords and are shifted down as the neighbours get through; a neighbour's contribution is
     // folded in when it is through (sel::advance), so that the turn itself is three stores.
@@ -458,17 +458,15 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
         while ((unsigned)prog.through < len) {
             const unsigned q = wq[0] & 0xffffu, pr = wp[0] & 0xffffu;
             const bool has_pred = pr != sel::kNone;
-            // the predecessor's byte BEFORE the neighbour's, the neighbour's before its cache position (the writers store in the
-            // opposite order; LDS operations of a wave execute in the order they are issued)
+            // the predecessor's word BEFORE the neighbour's (the predecessor stores "the neighbour is gone" before its own word;
+            // LDS operations of a wave execute in the order they are issued)
             sel_compiler_fence();
-            const unsigned bp = s_sd[has_pred ? pr : SEL_MAX_CANDS];
+            const unsigned wpred = s_word[has_pred ? pr : 0u];
             sel_compiler_fence();
-            const unsigned bq = s_sd[q];
-            sel_compiler_fence();
-            const unsigned oq = s_origin[q];
+            const unsigned wq_now = s_word[q];
             sel_compiler_fence();
             const int before = prog.at;
-            if (!sel::advance(&prog, has_pred, (unsigned char)bp, (unsigned char)bq, (unsigned short)oq)) break;
+            if (!sel::advance(&prog, has_pred, (unsigned short)wpred, (unsigned short)wq_now)) break;
             if (prog.at != before) hit_q = q;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -480,14 +478,11 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
         }
         if ((unsigned)prog.through == len) {
             const unsigned short c = (unsigned short)cand_of((unsigned)b_cur);
-            unsigned short oc;
-            bool kills;
-            const unsigned char mine = sel::turn(prog, c, (unsigned short)wins, &oc, &kills);
-            s_origin[c] = oc;
-            sel_compiler_fence();  // (the position's creator is in place before anyone can see the turn as taken)
-            if (kills) s_sd[hit_q] = (unsigned char)(s_sd[hit_q] | sel::kKilled);
-            sel_compiler_fence();  // (the replaced entry is dead before anyone can see the turn as taken)
-            s_sd[c] = mine;
+            bool replaces;
+            const unsigned short mine = sel::turn(prog, c, (unsigned short)wins, &replaces);
+            if (replaces) s_word[hit_q] = sel::kGone;
+            sel_compiler_fence();  // (the replaced entry is gone before anyone can see the turn as taken)
+            s_word[c] = mine;
             sel_compiler_fence();
             b_cur = b_nxt;
             if (b_cur >= 0) open_row(nxt);
@@ -516,46 +511,45 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
     // second pass (:109-129) and the refinement's test (:141-178) on this thread's candidates
     unsigned long long surv = 0ull;
     unsigned my_extrema = 0;
-    constexpr int U2 = 4;
-    for (unsigned k0 = 0; k0 < per; k0 += U2) {
-        uint4 tail[U2];  // the row's last 16 bytes: wins, the next-level neighbours, the refinement's flag
+    constexpr int U2 = 4, U3 = 4;
+    for (unsigned k0 = 0; k0 < per; k0 += U3) {
+        uint4 tail[U3];  // the row's last 16 bytes: wins, the next-level neighbours, the refinement's flag
 #pragma unroll
-        for (int u = 0; u < U2; ++u) {
+        for (int u = 0; u < U3; ++u) {
             const unsigned c = cand_of(k0 + u);
             tail[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (c < n && sel::alive(s_sd[c] & 7u)) tail[u] = reinterpret_cast<const uint4*>(rowI + c)[3];
+            if (c < n && sel::alive(s_word[c])) tail[u] = reinterpret_cast<const uint4*>(rowI + c)[3];
         }
 #pragma unroll
-        for (int u = 0; u < U2; ++u) {
+        for (int u = 0; u < U3; ++u) {
             const unsigned c = cand_of(k0 + u);
-            if (c >= n || !sel::alive(s_sd[c] & 7u)) continue;
+            if (c >= n || !sel::alive(s_word[c])) continue;
             union { uint4 v; unsigned short h[8]; } t;
             t.v = tail[u];
             const unsigned short* r2 = &t.h[1];  // (bytes 50 .. 61 of the row)
-            const unsigned short mine = s_origin[c];
+            const unsigned short mine = s_word[c];
             bool repeated;
             if (r2[0] == sel::kListOverflow) {
                 // more next-level neighbours than the list holds: that level's candidates in the band of rows that can lie within
                 // `size` of this one's stored position, with the selection's own expressions (as the host does for such a candidate)
                 repeated = false;
                 const Candidate cd = cand[c];
-                const unsigned l = cd.level, w = lv.w[l];
+                const unsigned l = cd.level, w = s_w[l];
                 if (l + 1 < L) {
-                    const float ratio = lv.ratio[l], size = lv.size[l], size2 = size * size;
+                    const float ratio = s_ratio[l], size = s_size[l], size2 = size * size;
                     const unsigned ly = cd.idx / w, lx = cd.idx - ly * w;
                     const float px = (float)lx * ratio + 0.5f * (ratio - 1.0f), py = (float)ly * ratio + 0.5f * (ratio - 1.0f);
-                    const float pr = lv.ratio[l + 1], off = 0.5f * (pr - 1.0f), reach = size + 1.0f;
-                    const unsigned pw = lv.w[l + 1];
+                    const float pr = s_ratio[l + 1], off = 0.5f * (pr - 1.0f), reach = size + 1.0f;
+                    const unsigned pw = s_w[l + 1], ph = lv.h[l + 1];
                     const float ylo = (py - reach - off) / pr - 1.0f, yhi = (py + reach - off) / pr + 1.0f;
-                    if (yhi >= 0.0f) {
-                        const unsigned r0 = ylo <= 0.0f ? 0u : (unsigned)ylo;
-                        const unsigned long long last = (unsigned long long)((unsigned)yhi + 1u) * pw;
-                        const unsigned e = o[l + 2];
-                        for (unsigned j = rel_lower_bound(sorted, o[l + 1], e, r0 * pw); j < e && !repeated; ++j) {  // (rare: a search will do)
+                    const unsigned r0 = ylo <= 0.0f ? 0u : (unsigned)ylo;
+                    if (yhi >= 0.0f && r0 < ph) {
+                        const unsigned* rt = row_table + (size_t)img * lv.row_base[L] + lv.row_base[l + 1];  // (k_rel_offsets' row table)
+                        const unsigned jb = rt[r0], je = rt[min((unsigned)yhi + 1u, ph)];
+                        for (unsigned j = jb; j < je && !repeated; ++j) {
                             const Candidate p = sorted[j];
-                            if ((unsigned long long)p.idx >= last) break;
                             const unsigned q = j - img0;
-                            if (!sel::alive(s_sd[q] & 7u) || s_origin[q] < mine) continue;
+                            if (!sel::alive(s_word[q]) || s_word[q] < mine) continue;
                             const unsigned qy = p.idx / pw, qx = p.idx - qy * pw;
                             const float sx = (float)qx * pr + off, sy = (float)qy * pr + off;
                             const float dist = (px - sx) * (px - sx) + (py - sy) * (py - sy);
@@ -564,7 +558,7 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
                     }
                 }
             } else {
-                repeated = sel::repeated_later<kRel2>(mine, r2, [&](unsigned short q) { return (unsigned char)(s_sd[q] & 7u); }, OG);
+                repeated = sel::repeated_later<kRel2>(mine, r2, WORD);
             }
             if (repeated) continue;
             ++my_extrema;
@@ -574,18 +568,21 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) my_extrema += __shfl_xor(my_extrema, off, 64);
     if (lane == 0 && my_extrema) atomicAdd(&s_extrema, my_extrema);
-    __syncthreads();  // (every alive / origin test of the second pass is through: the survivor bits may go onto the bytes)
+    __syncthreads();
     const unsigned long long t3 = wall_clock64();
     for (unsigned long long m = surv; m; m &= m - 1ull) {
-        const unsigned c = cand_of((unsigned)(__ffsll((long long)m) - 1));
-        const unsigned short org = s_origin[c];
-        s_sd[org] = (unsigned char)(s_sd[org] | SEL_SURVIVOR);  // (one occupant per cache position: one writer per byte)
+        const unsigned org = s_word[cand_of((unsigned)(__ffsll((long long)m) - 1))];
+        atomicOr(&s_bits[org >> 5], 1u << (org & 31u));
     }
     __syncthreads();
-    // keypoints in cache order = in the order of the positions' creators: bits per contiguous chunk, an exclusive scan
-    const unsigned o0 = min(n, tid * per), o1 = min(n, o0 + per);
-    unsigned mine_n = 0;
-    for (unsigned q = o0; q < o1; ++q) mine_n += (s_sd[q] & SEL_SURVIVOR) ? 1u : 0u;
+    // keypoints in cache order = in the order of the positions' creators: an exclusive scan over the bit words
+    constexpr unsigned WPT = SEL_MAX_CANDS / 32 / SEL_NT;  // bit words per thread
+    unsigned cnt[WPT], mine_n = 0;
+#pragma unroll
+    for (unsigned k = 0; k < WPT; ++k) {
+        cnt[k] = __popc(s_bits[tid * WPT + k]);
+        mine_n += cnt[k];
+    }
     unsigned incl = mine_n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -600,7 +597,12 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
         if (w < wv) before += v;
         total += v;
     }
-    s_base[tid] = before + incl - mine_n;
+    unsigned run = before + incl - mine_n;
+#pragma unroll
+    for (unsigned k = 0; k < WPT; ++k) {
+        s_pref[tid * WPT + k] = run;
+        run += cnt[k];
+    }
     __syncthreads();
     // every survivor's keypoint at the rank of its cache position
     for (unsigned long long m = surv; m;) {
@@ -621,19 +623,18 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
         for (int u = 0; u < U2; ++u) {
             if (cs[u] == 0xffffffffu) continue;
             const Candidate cd = cds[u];
-            const unsigned org = s_origin[cs[u]], chunk = org / per;
-            unsigned at = s_base[chunk];
-            for (unsigned q = chunk * per; q < org; ++q) at += (s_sd[q] & SEL_SURVIVOR) ? 1u : 0u;
-            const unsigned l = cd.level, w = lv.w[l];
+            const unsigned org = s_word[cs[u]];
+            const unsigned at = s_pref[org >> 5] + __popc(s_bits[org >> 5] & ((1u << (org & 31u)) - 1u));
+            const unsigned l = cd.level, w = s_w[l];
             const unsigned ly = cd.idx / w, lx = cd.idx - ly * w;
-            const float ratio = lv.ratio[l];
+            const float ratio = s_ratio[l];
             sel::KpRec rec;
             rec.level = l;
             (void)sel::refine(lx, ly, cd.v, cd.xp, cd.xm, cd.yp, cd.ym, ratio, &rec);
             KpParam p;
             p.xf = rec.x / ratio;
             p.yf = rec.y / ratio;
-            p.scale = roundf(0.5f * lv.size[l] / ratio);
+            p.scale = roundf(0.5f * s_size[l] / ratio);
             p.level = l;
             p.img = img;
             p._pad[0] = p._pad[1] = p._pad[2] = 0u;
@@ -738,6 +739,7 @@ void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const
     const unsigned* offs = (const unsigned*)rel_scratch;
     unsigned* flags = (unsigned*)((char*)rel_scratch + offs_b);
     const unsigned short* rel = (const unsigned short*)((const char*)rel_scratch + offs_b + flags_b);
+    const unsigned* row_table = (const unsigned*)((const char*)rel_scratch + offs_b + flags_b + up256((size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t)));
     RelLevels lv;
     fill_levels(lv, size, ratio, level_w, level_h, n_levels, n_images);
     hipLaunchKernelGGL(k_sel_prepare, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, n_levels, n_images, offs, rel,
@@ -753,7 +755,7 @@ void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const
     out.pars = one ? d_pars : (KpParam*)(p + l.pars_tmp);
     out.total = one ? total : nullptr;
     hipLaunchKernelGGL(k_select, dim3(n_images), dim3(SEL_NT), 0, s, d_sorted, lv, offs, (const SelRow*)(p + l.rows),
-                       (const unsigned char*)(p + l.state0), (const unsigned*)flags, out);
+                       (const unsigned char*)(p + l.state0), (const unsigned*)flags, row_table, out);
     if (!one)
         hipLaunchKernelGGL(k_sel_pack, dim3(n_images, 4), dim3(256), 0, s, offs, n_levels, n_images, (const unsigned*)out.hdr,
                            (const SelKp*)out.recs, (const KpParam*)out.pars, (SelKp*)d_recs, d_pars, total);

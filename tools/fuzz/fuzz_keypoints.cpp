@@ -228,8 +228,7 @@ int main(int argc, char** argv) {
                     // candidates (c % threads == owner) in index order, interleaved at random, every write visible at once
                     typedef sel::Row<kRel1, kRel2> Row;
                     std::vector<Row> rows(n);
-                    std::vector<uint8_t> sd(n, 0);
-                    std::vector<uint16_t> origin(n, sel::kNone);
+                    std::vector<uint16_t> word(n, sel::kUndecided);
                     const size_t threads = (size_t)uni(1, 96);
                     std::vector<std::vector<uint16_t>> own(threads);
                     size_t undecided = 0;
@@ -249,11 +248,10 @@ int main(int argc, char** argv) {
                         }
                         for (int j = 0; j < K2; ++j) rw.rel2[j] = r1[K1 + j];
                         rw.refined = (uint16_t)(len << 8);
-                        if (r1[0] == sel::kNone) { sd[i] = sel::kDecided | sel::kAccepted; origin[i] = (uint16_t)i; }
+                        if (r1[0] == sel::kNone) word[i] = (uint16_t)i;
                         else { own[i % threads].push_back((uint16_t)i); ++undecided; }
                     }
-                    auto SD = [&](uint16_t q) { return sd[q]; };
-                    auto OG = [&](uint16_t q) { return origin[q]; };
+                    auto WORD = [&](uint16_t q) { return word[q]; };
                     std::vector<size_t> at_of(threads, 0);
                     std::vector<sel::Progress> prog(threads);
                     for (auto& pr : prog) sel::start(&pr);
@@ -270,35 +268,31 @@ int main(int argc, char** argv) {
                         if (prog[t].through < len) {
                             const int j = prog[t].through;
                             const bool has_pred = rw.pred[j] != sel::kNone;
-                            const uint8_t bp = has_pred ? sd[rw.pred[j]] : (uint8_t)0;
-                            const uint8_t bq = sd[rw.rel1[j]];
-                            moved = sel::advance(&prog[t], has_pred, bp, bq, origin[rw.rel1[j]]);
+                            const uint16_t wp = has_pred ? word[rw.pred[j]] : (uint16_t)0;
+                            moved = sel::advance(&prog[t], has_pred, wp, word[rw.rel1[j]]);
                         }
                         if (prog[t].through < len) {
                             if (!moved && ++idle > 4000000) { fprintf(stderr, "round %d: the turns stalled with %zu candidates\n", it, undecided); return 1; }
                             continue;
                         }
                         idle = 0;
-                        uint16_t oc;
-                        bool kills;
-                        const uint8_t mine = sel::turn(prog[t], c, rw.wins, &oc, &kills);
-                        origin[c] = oc;
-                        if (kills) sd[rw.rel1[prog[t].at]] |= sel::kKilled;
-                        sd[c] = mine;
+                        bool replaces;
+                        const uint16_t mine = sel::turn(prog[t], c, rw.wins, &replaces);
+                        if (replaces) word[rw.rel1[prog[t].at]] = sel::kGone;
+                        word[c] = mine;
                         ++at_of[t];
                         sel::start(&prog[t]);
                         --undecided;
                     }
                     max_rounds = std::max(max_rounds, looks);
-                    const std::vector<uint8_t>& state = sd;
-                    // second pass, refinement, cache order = order of the origins
+                    // second pass, refinement, cache order = order of the positions' creators
                     std::vector<int32_t> at(n, -1);
                     uint64_t ne3 = 0;
                     for (size_t k = 0; k < n; ++k) {
-                        if (!sel::alive(state[k])) continue;
-                        if (sel::repeated_later<kRel2>(origin[k], rows[k].rel2, SD, OG)) continue;
+                        if (!sel::alive(word[k])) continue;
+                        if (sel::repeated_later<kRel2>(word[k], rows[k].rel2, WORD)) continue;
                         ++ne3;
-                        at[origin[k]] = (int32_t)k;
+                        at[word[k]] = (int32_t)k;
                     }
                     std::vector<sel::KpRec> got3;
                     for (size_t o = 0; o < n; ++o) {

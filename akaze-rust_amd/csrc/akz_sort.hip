@@ -1,10 +1,15 @@
-// Extrema candidates into the reference's scan order ON THE DEVICE (scale_space_extrema.rs:32-42 walks the levels in
-// order and each level's pixels in raster order; the detector kernels append their candidates to one list in whatever
-// order their waves finish).  Key = (image, level, flat pixel index), packed into as few bits as the batch needs; a
-// device radix sort of (key, list position) pairs and one gather leave the list sorted by image, level and pixel, so
-// that the host neither buckets nor sorts: with the host cores of a node shared by 8 ranks those two passes were a fifth
-// of the host work of a batch (the other four fifths, the order-dependent selection, cannot move).
-// The sort is rocPRIM's device radix sort (a library primitive); keys are unique, so the result is deterministic.
+// The keypoint half's front end ON THE DEVICE: the extrema candidates into the reference's scan order, who can meet whom in
+// the keypoint selection, and the selection itself.
+//   * Scan order (scale_space_extrema.rs:32-42 walks the levels in order and each level's pixels in raster order; the
+//     detector kernels append their candidates to one list in whatever order their waves finish).  Key = (image, level, flat
+//     pixel index), packed into as few bits as the batch needs; rocPRIM's device radix sort of (key, list position) pairs
+//     and one gather -- or, for one image's short list, k_sort_rows: ONE launch -- leave the list sorted by image, level and
+//     pixel.  Keys are unique, so the result is deterministic.
+//   * k_rel_offsets / k_relations: per candidate the earlier candidates of its own / the previous level and those of the next
+//     level within `size` of it (pure geometry; the selection's order-dependent questions are asked of these short lists).
+//   * k_sel_prepare / k_select / k_sel_pack: the order-dependent selection as a data flow of turns (akz_select.hpp).
+// With the host cores of a node shared by 8 ranks, bucketing + sorting were a fifth of the host work of a batch and the
+// selection the other four; for a lone image's call the host's selection was the longest piece after the scale space.
 #include <hip/hip_runtime.h>
 
 #include <cstring>

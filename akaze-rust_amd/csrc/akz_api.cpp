@@ -1870,17 +1870,20 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             lh[l] = plan[l].h;
         }
         uint32_t* d_zero = selp ? launch::select_device_revcnt(selp, cap, n) : nullptr;
+        const bool want_lists = want_rel || want_dev;
+        if (want_lists) AKZ_TRY(ensure(c, c->rel_scratch, launch::candidate_relations_bytes(cap, lh.data(), (uint32_t)L, n)));
         // (the one-launch sort is one workgroup with 112 KB of LDS: as k_select, for the job that is waited for)
-        sorted = n == 1 && (waited_for || c->dbg_select == 2) && launch::sort_candidates_rows(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, lw.data(), lh.data(), (uint32_t)L,
-                                                        (Candidate*)c->cand_sorted.p, d_zero);
+        const bool rows_sort = n == 1 && (waited_for || c->dbg_select == 2) &&
+                               launch::sort_candidates_rows(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, lw.data(), lh.data(), (uint32_t)L,
+                                                            (Candidate*)c->cand_sorted.p, d_zero, want_lists ? c->rel_scratch.p : nullptr);
+        sorted = rows_sort;
         if (!sorted)
             sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
                                                     n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p, d_zero);
         AKZ_HIP_TRY(hipGetLastError());
         if (sorted && (want_rel || want_dev)) {
-            AKZ_TRY(ensure(c, c->rel_scratch, launch::candidate_relations_bytes(cap, lh.data(), (uint32_t)L, n)));
             launch::candidate_relations(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), lh.data(),
-                                        (uint32_t)L, n, c->rel_scratch.p, &d_rel, &d_rel_flags, selp);
+                                        (uint32_t)L, n, c->rel_scratch.p, &d_rel, &d_rel_flags, selp, rows_sort);
             AKZ_HIP_TRY(hipGetLastError());
             if (want_dev) {
                 AKZ_TRY(ensure(c, c->sel_recs, (size_t)cap * sizeof(SelKpHost)));

@@ -248,8 +248,10 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images);
 uint32_t sort_small_capacity();  // one image's list up to this capacity is sorted by one launch of one workgroup:
 // false: not this list (too long, too many rows) -- the caller takes sort_candidates_device
+// rel_scratch (candidate_relations_bytes for ONE image, or null): the sort leaves candidate_relations' level / row tables there
+// (its bucket starts are those tables) -- pass tables_ready to candidate_relations
 bool sort_candidates_rows(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, const uint32_t* level_w,
-                          const uint32_t* level_h, uint32_t n_levels, Candidate* d_sorted, uint32_t* d_zero);
+                          const uint32_t* level_h, uint32_t n_levels, Candidate* d_sorted, uint32_t* d_zero, void* rel_scratch);
 bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, uint64_t max_px,
                             uint32_t n_levels, uint32_t n_images, void* scratch, Candidate* d_sorted, uint32_t* d_zero = nullptr);
 // who can be within `size` of whom (akz_sort.hip, k_relations): per candidate of the SORTED list kRel1 indices of earlier
@@ -257,7 +259,7 @@ bool sort_candidates_device(hipStream_t s, const Candidate* d_cand, uint32_t cap
 size_t candidate_relations_bytes(uint32_t cap, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images);
 void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
                          const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, void* scratch,
-                         uint16_t** d_rel_out, uint32_t** d_flags_out, void* sel_scratch = nullptr);
+                         uint16_t** d_rel_out, uint32_t** d_flags_out, void* sel_scratch = nullptr, bool tables_ready = false);
 // The selection itself on the device (akz_sort.hip: k_sel_prepare, k_select, k_sel_pack; akz_select.hpp): dependency rounds
 // over the neighbour lists, one workgroup per image.  sel_scratch (select_device_bytes) must have been handed to
 // sort_candidates_device (d_zero = select_device_revcnt(...)) and to candidate_relations of the same list.  Leaves, in image

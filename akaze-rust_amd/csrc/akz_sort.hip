@@ -113,7 +113,8 @@ __global__ void k_rel_offsets(const Candidate* __restrict__ sorted, const unsign
 // an insertion sort of the handful of candidates inside each row.  Keys are unique: the same permutation as the radix sort.
 constexpr unsigned SORT_SMALL_N = 8192, SORT_SMALL_ROWS = 16384;
 __global__ void __launch_bounds__(1024) k_sort_rows(const Candidate* __restrict__ cand, unsigned cap, const unsigned* __restrict__ d_count,
-                                                    RelLevels lv, Candidate* __restrict__ out, unsigned* __restrict__ zero) {
+                                                    RelLevels lv, Candidate* __restrict__ out, unsigned* __restrict__ zero,
+                                                    unsigned* __restrict__ offs, unsigned* __restrict__ rows, unsigned* __restrict__ img_flags) {
     __shared__ unsigned s_start[SORT_SMALL_ROWS + 1];  // per bucket: its count, then where it begins
     __shared__ unsigned s_idx[SORT_SMALL_N];
     __shared__ unsigned short s_pos[SORT_SMALL_N];
@@ -186,6 +187,11 @@ __global__ void __launch_bounds__(1024) k_sort_rows(const Candidate* __restrict_
     for (unsigned i = tid; i < n; i += 1024) {
         out[i] = cand[s_pos[i]];
         if (zero) zero[i] = 0u;
+    }
+    if (offs) {  // the bucket starts ARE k_rel_offsets' tables (one image): that launch is not needed
+        for (unsigned b = tid; b < R; b += 1024) rows[b] = s_start[b];
+        if (tid <= lv.n_levels) offs[tid] = tid < lv.n_levels ? s_start[lv.row_base[tid]] : n;
+        if (tid == 0) img_flags[0] = 0u;
     }
 }
 __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
@@ -770,7 +776,7 @@ void select_device(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const
 // d_rel_out / d_flags_out: where the lists and the per-image overflow flags are inside `scratch`
 void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap, const uint32_t* d_count, const float* size, const float* ratio,
                          const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, void* scratch,
-                         uint16_t** d_rel_out, uint32_t** d_flags_out, void* sel_scratch) {
+                         uint16_t** d_rel_out, uint32_t** d_flags_out, void* sel_scratch, bool tables_ready) {
     const size_t offs_b = up256((size_t)n_images * (n_levels + 1) * 4), flags_b = up256((size_t)n_images * 4),
                  rel_b = up256((size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t));
     unsigned* offs = (unsigned*)scratch;
@@ -782,7 +788,8 @@ void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap,
     RelLevels lv;
     fill_levels(lv, size, ratio, level_w, level_h, n_levels, n_images);
     const unsigned no = n_images * (n_levels + 1) + n_images * lv.row_base[std::min<uint32_t>(n_levels, kMaxLevels)];
-    hipLaunchKernelGGL(k_rel_offsets, dim3((no + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rows, flags);
+    if (!tables_ready)  // (sort_candidates_rows leaves them behind)
+        hipLaunchKernelGGL(k_rel_offsets, dim3((no + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rows, flags);
     unsigned* revcnt = nullptr;
     unsigned short* rev = nullptr;
     if (sel_scratch) {  // (the counters were zeroed by the sort's gather)
@@ -809,12 +816,19 @@ static KeyBits key_bits(uint64_t max_px, uint32_t n_levels, uint32_t n_images) {
 }
 uint32_t sort_small_capacity() { return SORT_SMALL_N; }
 bool sort_candidates_rows(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, const uint32_t* level_w,
-                          const uint32_t* level_h, uint32_t n_levels, Candidate* d_sorted, uint32_t* d_zero) {
+                          const uint32_t* level_h, uint32_t n_levels, Candidate* d_sorted, uint32_t* d_zero, void* rel_scratch) {
     if (cap > SORT_SMALL_N || n_levels == 0 || n_levels > (uint32_t)kMaxLevels || rows_per_image(level_h, n_levels) > SORT_SMALL_ROWS) return false;
     RelLevels lv;
     std::vector<float> none(n_levels, 0.0f);
     fill_levels(lv, none.data(), none.data(), level_w, level_h, n_levels, 1);
-    hipLaunchKernelGGL(k_sort_rows, dim3(1), dim3(1024), 0, s, d_cand, cap, d_count, lv, d_sorted, d_zero);
+    unsigned *offs = nullptr, *rows = nullptr, *flags = nullptr;
+    if (rel_scratch) {  // (candidate_relations' layout for one image)
+        const size_t offs_b = up256((size_t)(n_levels + 1) * 4), flags_b = up256(4), rel_b = up256((size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t));
+        offs = (unsigned*)rel_scratch;
+        flags = (unsigned*)((char*)rel_scratch + offs_b);
+        rows = (unsigned*)((char*)rel_scratch + offs_b + flags_b + rel_b);
+    }
+    hipLaunchKernelGGL(k_sort_rows, dim3(1), dim3(1024), 0, s, d_cand, cap, d_count, lv, d_sorted, d_zero, offs, rows, flags);
     return true;
 }
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images) {

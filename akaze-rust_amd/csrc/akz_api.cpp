@@ -111,6 +111,7 @@ struct akz_ctx {
     DevBuf cand_sorted, sort_scratch;        // the list in scan order (device sort of extract_finish) and the sort's scratch
     DevBuf rel_scratch;                      // the selection's neighbour lists (launch::candidate_relations)
     DevBuf sel_scratch, sel_recs;            // the selection on the device (launch::select_device): its scratch, the selected keypoints
+    DevBuf bucket_scratch;                   // launch::sort_candidates_buckets (its counters are zero between jobs)
     int dbg_select = -1;                     // akz_debug_set_select: 2 / 1 / 0 force the device / the neighbour-list / the grid selection, -1 automatic
     std::atomic<uint32_t> last_total_kp{0};  // keypoints of the previous finished job (speculative fetch size of the device selection)
     std::atomic<int> sel_last_mode{-1};      // akz_debug_select_info: how the last finished job was selected (0 grids, 1 lists, 2 device), the
@@ -439,7 +440,7 @@ int akz_ctx_destroy(akz_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->lazy[0], &c->lazy[1], &c->lazy[2], &c->lazy[3], &c->lazy[4], &c->lazy[5],
                       &c->scratch[0], &c->scratch[1], &c->scratch[2], &c->scratch[3], &c->scratch[4], &c->scratch[5], &c->scratch_coarse,
-                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->sel_scratch, &c->sel_recs, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec, &c->match_state,
+                      &c->small, &c->cand, &c->cand_sorted, &c->sort_scratch, &c->rel_scratch, &c->sel_scratch, &c->sel_recs, &c->bucket_scratch, &c->kp_in, &c->kp_out, &c->match_a, &c->match_b, &c->match_rec, &c->match_state,
                       &c->match_out, &c->cosi, &c->mm_q8, &c->mm_t8, &c->mm_pop, &c->mm_tab, &c->mm_cols,
                       &c->ms1.q8, &c->ms1.t8, &c->ms1.pop, &c->ms1.tab, &c->ms1.cols, &c->ms1.rec, &c->ransac_dev};
     for (DevBuf* b : bufs)
@@ -1858,7 +1859,6 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     orientation_windows(&wmask, &nwin);
     if (c->dbg_host_sort == 0 || (c->dbg_host_sort < 0 && (c->pool().size() < 4 || want_rel)) || want_dev) {
         AKZ_TRY(ensure(c, c->cand_sorted, (size_t)cap * sizeof(Candidate)));
-        AKZ_TRY(ensure(c, c->sort_scratch, launch::sort_candidates_scratch(cap, max_px, (uint32_t)L, n)));
         void* selp = nullptr;
         if (want_dev) {
             AKZ_TRY(ensure(c, c->sel_scratch, launch::select_device_bytes(cap, n)));
@@ -1877,13 +1877,24 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                                launch::sort_candidates_rows(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, lw.data(), lh.data(), (uint32_t)L,
                                                             (Candidate*)c->cand_sorted.p, d_zero, want_lists ? c->rel_scratch.p : nullptr);
         sorted = rows_sort;
-        if (!sorted)
+        bool buckets_sort = false;
+        if (!sorted) {  // several images or a longer list: the same sort in four launches, if the job has few enough rows
+            const size_t before = c->bucket_scratch.bytes;  // (a buffer that has just been (re)allocated: its counters are not zero yet)
+            AKZ_TRY(ensure(c, c->bucket_scratch, launch::sort_candidates_buckets_scratch(cap)));
+            buckets_sort = launch::sort_candidates_buckets(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, lw.data(), lh.data(), (uint32_t)L,
+                                                           n, c->bucket_scratch.p, c->bucket_scratch.bytes != before, (Candidate*)c->cand_sorted.p, d_zero,
+                                                           want_lists ? c->rel_scratch.p : nullptr);
+            sorted = buckets_sort;
+        }
+        if (!sorted) {
+            AKZ_TRY(ensure(c, c->sort_scratch, launch::sort_candidates_scratch(cap, max_px, (uint32_t)L, n)));
             sorted = launch::sort_candidates_device(s, (const Candidate*)c->cand_slot[job->slot].p, cap, d_count, max_px, (uint32_t)L,
                                                     n, c->sort_scratch.p, (Candidate*)c->cand_sorted.p, d_zero);
+        }
         AKZ_HIP_TRY(hipGetLastError());
         if (sorted && (want_rel || want_dev)) {
             launch::candidate_relations(s, (const Candidate*)c->cand_sorted.p, cap, d_count, lsize.data(), lratio.data(), lw.data(), lh.data(),
-                                        (uint32_t)L, n, c->rel_scratch.p, &d_rel, &d_rel_flags, selp, rows_sort);
+                                        (uint32_t)L, n, c->rel_scratch.p, &d_rel, &d_rel_flags, selp, rows_sort || buckets_sort);
             AKZ_HIP_TRY(hipGetLastError());
             if (want_dev) {
                 AKZ_TRY(ensure(c, c->sel_recs, (size_t)cap * sizeof(SelKpHost)));

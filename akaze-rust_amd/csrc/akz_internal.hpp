@@ -248,6 +248,13 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images);
 uint32_t sort_small_capacity();  // one image's list up to this capacity is sorted by one launch of one workgroup:
 // false: not this list (too long, too many rows) -- the caller takes sort_candidates_device
+// Lists of any length, several images, up to 65 536 (image, level, row) buckets: the same counting sort in four launches
+// (scratch: sort_candidates_buckets_scratch(cap) bytes; scratch_is_new: the buffer has just been (re)allocated).  false: too
+// many buckets -- the caller takes sort_candidates_device.  rel_scratch as for sort_candidates_rows.
+size_t sort_candidates_buckets_scratch(uint32_t cap);
+bool sort_candidates_buckets(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, const uint32_t* level_w,
+                             const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, void* scratch, bool scratch_is_new,
+                             Candidate* d_sorted, uint32_t* d_zero, void* rel_scratch);
 // rel_scratch (candidate_relations_bytes for ONE image, or null): the sort leaves candidate_relations' level / row tables there
 // (its bucket starts are those tables) -- pass tables_ready to candidate_relations
 bool sort_candidates_rows(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, const uint32_t* level_w,

@@ -194,6 +194,93 @@ __global__ void __launch_bounds__(1024) k_sort_rows(const Candidate* __restrict_
         if (tid == 0) img_flags[0] = 0u;
     }
 }
+// Longer lists, several images (a lone 4K frame's 26 K candidates, a pair's): the same counting sort over (image, level, row)
+// buckets in four launches -- count (a candidate learns its bucket and its place in it), scan of the bucket counts (one
+// workgroup, up to SORT_BUCKETS_MAX buckets; leaves the counters zero for the next job and writes k_rel_offsets' tables: the
+// bucket starts ARE those tables), place (the columns of a row side by side), rank (a candidate counts the row-mates left of
+// it and moves to its final place) -- against eleven (keys, eight rocPRIM passes, gather, offsets).
+constexpr unsigned SORT_BUCKETS_MAX = 65536;
+__global__ void __launch_bounds__(256) k_bucket_count(const Candidate* __restrict__ cand, unsigned cap, const unsigned* __restrict__ d_count,
+                                                      RelLevels lv, unsigned* __restrict__ cnt, unsigned* __restrict__ bucket_of,
+                                                      unsigned* __restrict__ slot_of) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(*d_count, cap)) return;
+    const Candidate c = cand[i];
+    const unsigned l = min(c.level, lv.n_levels - 1), img = min(c.img, lv.n_images - 1);
+    const unsigned b = img * lv.row_base[lv.n_levels] + lv.row_base[l] + min(c.idx / lv.w[l], lv.h[l] - 1u);
+    bucket_of[i] = b;
+    slot_of[i] = atomicAdd(&cnt[b], 1u);
+}
+// start: nb + 1 entries (the row table of candidate_relations when the job wants its lists, else scratch)
+__global__ void __launch_bounds__(1024) k_bucket_scan(unsigned* __restrict__ cnt, unsigned nb, unsigned* __restrict__ start,
+                                                      const unsigned* __restrict__ d_count, unsigned cap, RelLevels lv,
+                                                      unsigned* __restrict__ offs, unsigned* __restrict__ img_flags) {
+    __shared__ unsigned s_part[16];
+    __shared__ unsigned s_run;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) s_run = 0u;
+    __syncthreads();
+    for (unsigned t0 = 0; t0 < nb; t0 += 4096) {  // tiles of 4 096 buckets: four consecutive ones per thread
+        const unsigned b0 = t0 + tid * 4;
+        unsigned v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = b0 + k < nb ? cnt[b0 + k] : 0u;
+            if (b0 + k < nb) cnt[b0 + k] = 0u;  // (the counters are zero again for the next job)
+        }
+        const unsigned mine = v[0] + v[1] + v[2] + v[3];
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned u = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += u;
+        }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        unsigned run = s_run + incl - mine;
+        for (unsigned w = 0; w < wv; ++w) run += s_part[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (b0 + k < nb) start[b0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_run = run;
+        __syncthreads();
+    }
+    const unsigned n = min(*d_count, cap);
+    if (tid == 0) start[nb] = n;
+    if (offs) {  // candidate_relations' level table and flags (its row table is `start`)
+        __syncthreads();  // (this workgroup's own stores to start are visible to it)
+        const unsigned L = lv.n_levels, R = lv.row_base[L];
+        for (unsigned t = tid; t < lv.n_images * (L + 1); t += 1024) {
+            const unsigned img = t / (L + 1), l = t - img * (L + 1);
+            offs[t] = l < L ? start[img * R + lv.row_base[l]] : (img + 1 < lv.n_images ? start[(img + 1) * R] : n);
+        }
+        for (unsigned t = tid; t < lv.n_images; t += 1024) img_flags[t] = 0u;
+    }
+}
+__global__ void __launch_bounds__(256) k_bucket_place(const Candidate* __restrict__ cand, unsigned cap, const unsigned* __restrict__ d_count,
+                                                      const unsigned* __restrict__ start, const unsigned* __restrict__ bucket_of,
+                                                      const unsigned* __restrict__ slot_of, unsigned* __restrict__ row_keys) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(*d_count, cap)) return;
+    row_keys[start[bucket_of[i]] + slot_of[i]] = cand[i].idx;  // the row's columns side by side, in arrival order
+}
+__global__ void __launch_bounds__(256) k_bucket_rank(const Candidate* __restrict__ cand, unsigned cap, const unsigned* __restrict__ d_count,
+                                                     const unsigned* __restrict__ start, const unsigned* __restrict__ bucket_of,
+                                                     const unsigned* __restrict__ row_keys, Candidate* __restrict__ out,
+                                                     unsigned* __restrict__ zero) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(*d_count, cap)) return;
+    const Candidate c = cand[i];
+    const unsigned b = bucket_of[i], lo = start[b], hi = start[b + 1];
+    unsigned rank = 0;
+    for (unsigned j = lo; j < hi; ++j) rank += row_keys[j] < c.idx ? 1u : 0u;  // (one candidate per pixel: the keys of a row differ)
+    out[lo + rank] = c;
+    if (zero) zero[lo + rank] = 0u;
+}
+
 __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
                                                    RelLevels lv, const unsigned* __restrict__ offs, const unsigned* __restrict__ rows,
                                                    unsigned short* __restrict__ rel, unsigned* __restrict__ img_flags,
@@ -699,7 +786,7 @@ static uint32_t rows_per_image(const uint32_t* level_h, uint32_t n_levels) {
 }
 size_t candidate_relations_bytes(uint32_t cap, const uint32_t* level_h, uint32_t n_levels, uint32_t n_images) {
     return up256((size_t)n_images * (n_levels + 1) * 4) + up256((size_t)n_images * 4) + up256((size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t)) +
-           up256((size_t)n_images * rows_per_image(level_h, n_levels) * 4) + 256;
+           up256(((size_t)n_images * rows_per_image(level_h, n_levels) + 1) * 4) + 256;  // (+ 1: the bucket sort's end entry)
 }
 static void fill_levels(RelLevels& lv, const float* size, const float* ratio, const uint32_t* level_w, const uint32_t* level_h, uint32_t n_levels,
                         uint32_t n_images) {
@@ -829,6 +916,45 @@ bool sort_candidates_rows(hipStream_t s, const Candidate* d_cand, uint32_t cap, 
         rows = (unsigned*)((char*)rel_scratch + offs_b + flags_b + rel_b);
     }
     hipLaunchKernelGGL(k_sort_rows, dim3(1), dim3(1024), 0, s, d_cand, cap, d_count, lv, d_sorted, d_zero, offs, rows, flags);
+    return true;
+}
+// scratch of the bucket sort: counters (zero between jobs) | starts | bucket of a candidate | its place | the rows' keys
+size_t sort_candidates_buckets_scratch(uint32_t cap) {
+    return up256((size_t)(SORT_BUCKETS_MAX + 1) * 4) * 2 + up256((size_t)cap * 4) * 3 + 256;
+}
+bool sort_candidates_buckets(hipStream_t s, const Candidate* d_cand, uint32_t cap, const uint32_t* d_count, const uint32_t* level_w,
+                             const uint32_t* level_h, uint32_t n_levels, uint32_t n_images, void* scratch, bool scratch_is_new,
+                             Candidate* d_sorted, uint32_t* d_zero, void* rel_scratch) {
+    if (n_levels == 0 || n_levels > (uint32_t)kMaxLevels || cap == 0) return false;
+    const uint64_t nb64 = (uint64_t)n_images * rows_per_image(level_h, n_levels);
+    if (nb64 > SORT_BUCKETS_MAX) return false;
+    const unsigned nb = (unsigned)nb64;
+    RelLevels lv;
+    std::vector<float> none(n_levels, 0.0f);
+    fill_levels(lv, none.data(), none.data(), level_w, level_h, n_levels, n_images);
+    char* p = (char*)scratch;
+    const size_t cb = up256((size_t)(SORT_BUCKETS_MAX + 1) * 4), lb = up256((size_t)cap * 4);
+    unsigned* cnt = (unsigned*)p;
+    unsigned* start = (unsigned*)(p + cb);
+    unsigned* bucket_of = (unsigned*)(p + 2 * cb);
+    unsigned* slot_of = (unsigned*)(p + 2 * cb + lb);
+    unsigned* row_keys = (unsigned*)(p + 2 * cb + 2 * lb);
+    if (scratch_is_new) (void)hipMemsetAsync(cnt, 0, cb, s);  // (afterwards k_bucket_scan leaves them zero)
+    unsigned *offs = nullptr, *flags = nullptr;
+    if (rel_scratch) {  // (candidate_relations' layout: its row table holds the bucket starts)
+        const size_t offs_b = up256((size_t)n_images * (n_levels + 1) * 4), flags_b = up256((size_t)n_images * 4),
+                     rel_b = up256((size_t)cap * (kRel1 + kRel2) * sizeof(uint16_t));
+        offs = (unsigned*)rel_scratch;
+        flags = (unsigned*)((char*)rel_scratch + offs_b);
+        start = (unsigned*)((char*)rel_scratch + offs_b + flags_b + rel_b);
+    }
+    const unsigned gb = (cap + 255) / 256;
+    hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), 0, s, d_cand, cap, d_count, lv, cnt, bucket_of, slot_of);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, s, cnt, nb, start, d_count, cap, lv, offs, flags);
+    hipLaunchKernelGGL(k_bucket_place, dim3(gb), dim3(256), 0, s, d_cand, cap, d_count, (const unsigned*)start, (const unsigned*)bucket_of,
+                       (const unsigned*)slot_of, row_keys);
+    hipLaunchKernelGGL(k_bucket_rank, dim3(gb), dim3(256), 0, s, d_cand, cap, d_count, (const unsigned*)start, (const unsigned*)bucket_of,
+                       (const unsigned*)row_keys, d_sorted, d_zero);
     return true;
 }
 size_t sort_candidates_scratch(uint32_t cap, uint64_t max_px, uint32_t n_levels, uint32_t n_images) {

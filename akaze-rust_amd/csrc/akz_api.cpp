@@ -895,16 +895,21 @@ int akz_op_half_size(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, ui
 int akz_op_scharr(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n, int x_order,
                   int y_order, uint32_t sigma) {
     AKZ_TRY(bind(c));
-    if ((x_order != 0) == (y_order != 0)) {
-        set_error("scharr: exactly one of x_order / y_order must be set (the pipeline never uses the others)");
-        return AKZ_ERR_INVALID_ARG;
+    if (x_order == 0 && y_order == 0) {
+        // derivatives.rs:127-128: neither order is a new (zero) image of the input's size; sigma_size is not looked at
+        AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, 0));
+        AKZ_HIP_TRY(hipMemsetAsync(d_out, 0, plane_bytes(w, h, n), c->stream));
+        return AKZ_OK;
     }
     if (sigma == 0 || 2 * sigma + 1 > (uint32_t)kMaxTaps) {
         set_error("scharr: sigma_size must be in 1..6");
         return AKZ_ERR_INVALID_ARG;
     }
     AKZ_TRY(check_plane_args(d_in, d_out, w, h, n, (int)sigma));
+    // derivatives.rs:118-122: with both orders the reference takes the HORIZONTAL derivative twice and adds the two
+    // images (`sqrt_squared` is `image_1 += image_2`, image.rs:218-231)
     AKZ_TRY(scharr_impl(c, d_in, d_out, w, h, n, x_order != 0, sigma));
+    if (x_order != 0 && y_order != 0) launch::accumulate(c->stream, d_out, d_out, (uint64_t)w * h * n);
     AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
 }

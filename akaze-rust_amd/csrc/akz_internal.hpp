@@ -241,6 +241,7 @@ bool detector_nms_fused_supported(uint32_t sigma);
 void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
                         float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
+void accumulate(hipStream_t s, float* a, const float* b, uint64_t count);  // a += b (image.rs:218-231); a may equal b
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat);
 // the candidate list into scan order on the device (akz_sort.hip): by image, level, flat pixel index.  false: the

@@ -493,6 +493,14 @@ __global__ void k_ldet(const float* __restrict__ lxx, const float* __restrict__ 
     out[i] = ((lxx[i] * lyy[i]) - (lxy[i] * lxy[i])) * q;
 }
 
+// image_1[i] += image_2[i]: what the reference's `sqrt_squared` does despite its name (akaze/src/types/image.rs:218-231);
+// the two pointers may be the same plane (scharr with both orders adds the horizontal derivative to itself)
+__global__ void k_accumulate(float* a, const float* b, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    a[i] = a[i] + b[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // NMS candidates (akaze/src/ops/scale_space_extrema.rs:32-42) pre-filtered by the descriptor
 // border test (:80-87), which depends only on (x, y, level); out-of-border candidates never
@@ -1231,6 +1239,9 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
           float sigma_quat) {
     hipLaunchKernelGGL(k_ldet, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, lxx, lyy, lxy, out,
                        (size_t)count, sigma_quat);
+}
+void accumulate(hipStream_t s, float* a, const float* b, uint64_t count) {
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, (size_t)count);
 }
 void nms(hipStream_t s, const float* ldet_p, uint32_t w, uint32_t h, uint32_t n, uint64_t img_stride, uint32_t level,
          float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count) {

@@ -582,32 +582,19 @@ pub mod ops {
     }
     /// akaze/src/ops/derivatives.rs
     pub mod derivatives {
-        use crate::types::image::{sqrt_squared, GrayFloatImage, ImageFunctions};
+        use crate::types::image::{GrayFloatImage, ImageFunctions};
         use crate::{check, ctx, ffi, DevPlane};
-        fn one(image: &GrayFloatImage, x_order: bool, sigma_size: u32) -> GrayFloatImage {
+        /// akaze/src/ops/derivatives.rs:112-130 — `akz_op_scharr`, which covers all four order combinations as the
+        /// reference does: x only / y only; both = the HORIZONTAL derivative added to itself (:118-122, through
+        /// the misnamed `sqrt_squared`, types/image.rs:218-231); neither = a new zero image (:127-128).
+        pub fn scharr(image: &GrayFloatImage, x_order: bool, y_order: bool, sigma_size: u32) -> GrayFloatImage {
             let (w, h) = (image.width(), image.height());
             let src = DevPlane::upload(&image.buffer);
             let dst = DevPlane::zeros(w * h);
             check(unsafe {
-                ffi::akz_op_scharr(ctx(), src.f32(), dst.f32(), w as u32, h as u32, 1, x_order as i32, (!x_order) as i32, sigma_size)
+                ffi::akz_op_scharr(ctx(), src.f32(), dst.f32(), w as u32, h as u32, 1, x_order as i32, y_order as i32, sigma_size)
             });
             GrayFloatImage::from_buffer(dst.download(), w, h)
-        }
-        /// akaze/src/ops/derivatives.rs:112-130 — `akz_op_scharr`.  With both orders set the reference adds the
-        /// horizontal Scharr image to itself (:118-122, through the misnamed `sqrt_squared`); so does this.
-        pub fn scharr(image: &GrayFloatImage, x_order: bool, y_order: bool, sigma_size: u32) -> GrayFloatImage {
-            if x_order && y_order {
-                let horizontal = one(image, true, sigma_size);
-                let mut vertical = one(image, true, sigma_size);
-                sqrt_squared(&mut vertical, &horizontal);
-                vertical
-            } else if x_order {
-                one(image, true, sigma_size)
-            } else if y_order {
-                one(image, false, sigma_size)
-            } else {
-                image.clone()
-            }
         }
     }
     /// akaze/src/ops/descriptors.rs

@@ -178,7 +178,9 @@ int akz_op_gaussian_blur_u8(akz_ctx* ctx, const uint8_t* d_in, float* d_out, uin
                             float sigma);
 /* ImageFunctions::half_size — image.rs:102-118 ; out is (w/2) x (h/2) */
 int akz_op_half_size(akz_ctx* ctx, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n);
-/* ops::derivatives::scharr — derivatives.rs:112-130 (x_order xor y_order; both -> INVALID_ARG) */
+/* ops::derivatives::scharr — derivatives.rs:112-130, all four order combinations as the reference has them:
+ * x only / y only -> scharr_horizontal / scharr_vertical; both -> the horizontal derivative added to itself (:118-122 via
+ * image.rs:218-231); neither -> a zero image (:127-128; sigma_size unused). */
 int akz_op_scharr(akz_ctx* ctx, const float* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n, int x_order,
                   int y_order, uint32_t sigma_size);
 /* pm_g2 — lib.rs:26-41 ; d_k: n contrast factors (double) on the device */

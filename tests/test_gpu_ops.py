@@ -78,9 +78,22 @@ def test_scharr(ctx, ref, shape, sigma):
     same(host(ctx.scharr(dev(img), False, True, sigma)), ref.scharr(img, False, True, sigma))
 
 
-def test_scharr_rejects_unused_orders(ctx, amd):
-    with pytest.raises(amd.AkazeError):
-        ctx.scharr(dev(rand_img(20, 20, 0)), True, True, 1)
+@pytest.mark.parametrize("shape", [(20, 20), (63, 130), (257, 33)])
+@pytest.mark.parametrize("sigma", [1, 2, 4])
+def test_scharr_both_and_neither_order(ctx, ref, shape, sigma):
+    """derivatives.rs:118-122 (both: horizontal + horizontal) and :127-128 (neither: zeros), also on a batch"""
+    img = rand_img(*shape, seed=14, lo=-1.0)
+    both = ref.scharr(img, True, True, sigma)
+    assert np.array_equal(both, ref.scharr(img, True, False, sigma) * np.float32(2))  # what the reference computes
+    same(host(ctx.scharr(dev(img), True, True, sigma)), both)
+    none = host(ctx.scharr(dev(img), False, False, sigma))
+    same(none, ref.scharr(img, False, False, sigma))
+    assert none.shape == img.shape and not none.any()
+    same(host(ctx.scharr(dev(img), False, False, 0)), none)  # sigma_size is not looked at without an order
+    batch = np.stack([img, rand_img(*shape, seed=15, lo=-1.0)])
+    got = host(ctx.scharr(dev(batch), True, True, sigma))
+    for i in range(2):
+        same(got[i], ref.scharr(batch[i], True, True, sigma))
 
 
 @pytest.mark.parametrize("k", [0.0043, 0.03, 0.5])

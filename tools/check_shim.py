@@ -11,6 +11,12 @@ There is no Rust toolchain in the build image, so the shim cannot be compiled; t
   3. every `extern "C"` declaration of the shim must name a function of include/akaze_hip.h with the same number
      of parameters.
 
+  4. the BODIES: every function of the shim (public or not, methods included) is reduced to the ordered list of
+     `ffi::akz_*` functions it names; tests/shim_twin/shim_twin.cpp — a C++ restatement of the same bodies that IS
+     compiled against the header and run against the oracle on a GPU (tests/test_gpu_shim_twin.py) — is reduced the same
+     way, tag by tag (`// shim: <path>`).  Every shim function that names an `akz_*` function must have a twin with the
+     same list, and no twin may exist without its function: a body cannot change without its tested twin changing too.
+
 Exit status 0 = every reference item has a counterpart with an identical signature (type paths are compared by their
 last segment: `types::evolution::Config` == `Config`)."""
 import argparse
@@ -195,11 +201,91 @@ def shim_externs(path):
     return out
 
 
+def _block_end(src, k):
+    """src[k] == '{': index just after the matching '}'"""
+    depth, e = 1, k + 1
+    while depth and e < len(src):
+        depth += src[e] == "{"
+        depth -= src[e] == "}"
+        e += 1
+    return e
+
+
+def shim_bodies(path):
+    """{path of every fn / method / thread_local of the shim: ordered `ffi::akz_*` names in its body}"""
+    src = strip_comments(open(path).read())
+    out = {}
+
+    def walk(block, prefix):
+        i = 0
+        pat = re.compile(r"\b(mod\s+(\w+)\s*\{|impl\b([^{;]*)\{|trait\s+\w+[^{;]*\{|extern\s+\"C\"\s*\{|fn\s+(\w+)\s*(?:<[^>{]*>)?\s*\(|"
+                         r"thread_local!\s*\{)")
+        while True:
+            m = pat.search(block, i)
+            if not m:
+                return
+            text = m.group(0)
+            if text.startswith("fn"):
+                q, depth = m.end(), 1
+                while depth and q < len(block):
+                    depth += block[q] == "("
+                    depth -= block[q] == ")"
+                    q += 1
+                j, semi = block.find("{", q), block.find(";", q)
+                if j < 0 or 0 <= semi < j:
+                    i = (semi if semi >= 0 else q) + 1
+                    continue
+                e = _block_end(block, j)
+                name = "::".join(prefix + [m.group(4)])
+                out[name] = re.findall(r"\bffi::(akz_\w+)", block[j:e])
+                i = e
+                continue
+            k = m.end() - 1
+            e = _block_end(block, k)
+            body = block[k + 1:e - 1]
+            if text.startswith("mod"):
+                walk(body, prefix + [m.group(2)])
+            elif text.startswith("impl"):
+                head = m.group(3).strip()
+                ty = head.split(" for ")[-1].strip()
+                ty = re.sub(r"<.*", "", ty)
+                # `impl Drop for X { fn drop }` -> X::drop ; `impl Default for Config` etc. likewise
+                walk(body, prefix + [ty])
+            elif text.startswith("thread_local"):
+                tm = re.search(r"static\s+(\w+)", body)
+                out["::".join(prefix + [tm.group(1)])] = re.findall(r"\bffi::(akz_\w+)", body)
+            # trait declarations and the extern block hold no bodies
+            i = e
+
+    walk(src, [])
+    return out
+
+
+def twin_bodies(path, known):
+    """{tag: ordered names of C-ABI functions used between `// shim: tag` and the next tag}"""
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"\s*// shim: (\S+)", line)
+        if m:
+            cur = None if m.group(1) == "end" else m.group(1)
+            if cur is not None:
+                if cur in out:
+                    raise SystemExit(f"twin tag {cur} appears twice")
+                out[cur] = []
+            continue
+        if cur is None:
+            continue
+        code = re.sub(r"//.*", "", line)
+        out[cur] += [t for t in re.findall(r"\bakz_\w+\b", code) if t in known]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--shim", default=os.path.join(ROOT, "akaze-rust_amd", "rust", "src", "lib.rs"))
     ap.add_argument("--snapshot", default=os.path.join(ROOT, "tests", "golden", "reference_api.json"))
+    ap.add_argument("--twin", default=os.path.join(ROOT, "tests", "shim_twin", "shim_twin.cpp"))
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
     if os.path.isdir(os.path.join(args.reference, "akaze", "src")):
@@ -233,7 +319,20 @@ def main():
             problems.append(f'extern "C" {fn}: not declared in include/akaze_hip.h')
         elif hdr[fn] != n:
             problems.append(f'extern "C" {fn}: {n} parameters in the shim, {hdr[fn]} in include/akaze_hip.h')
+    bodies = shim_bodies(args.shim)
+    twins = twin_bodies(args.twin, set(hdr))
+    for name, calls in sorted(bodies.items()):
+        if not calls and name not in twins:
+            continue  # host-only helper without a twin: nothing crosses the ABI
+        if name not in twins:
+            problems.append(f"body of {name} calls {calls} but tests/shim_twin has no `// shim: {name}`")
+        elif twins[name] != calls:
+            problems.append(f"body of {name}: shim calls {calls}, its tested twin calls {twins[name]}")
+    for name in sorted(set(twins) - set(bodies)):
+        problems.append(f"twin `// shim: {name}` has no function of that path in the shim")
     if not args.quiet:
+        print(f"bodies: {len(bodies)} shim functions, {sum(1 for c in bodies.values() if c)} of them cross the ABI; "
+              f"{len(twins)} twins ({sum(1 for n in twins if n in bodies and twins[n] == bodies[n])} with identical call lists)")
         print(f"reference public items: {len(ref)} ({sum(1 for v in ref.values() if v['kind'] == 'fn')} functions, "
               f"{sum(1 for v in ref.values() if v['kind'] == 'struct')} structs, "
               f"{sum(1 for v in ref.values() if v['kind'] == 'trait')} traits); shim items: {len(shim)}; "

@@ -22,10 +22,22 @@
 #include "../../include/akaze_hip.h"
 #include "../../include/akaze_hip_debug.h"
 
+// An exchange that timed out (AKZ_ERR_TIMEOUT: a peer is missing or hung) leaves a collective on the communicator's stream
+// that may never complete.  The host reports it, may still release its objects (akz_gather_free / akz_comm_destroy return
+// at once on an abandoned communicator), and ends the process WITHOUT the runtime's exit handlers, which could wait for
+// that stream: _exit, non-zero.
+static akz_comm* g_comm = nullptr;
 #define TRY(expr)                                                                          \
     do {                                                                                   \
-        if ((expr) != AKZ_OK) {                                                            \
+        const int st_ = (expr);                                                            \
+        if (st_ != AKZ_OK) {                                                               \
             fprintf(stderr, "FAILED: %s: %s\n", #expr, akz_last_error());                  \
+            if (st_ == AKZ_ERR_TIMEOUT) {                                                  \
+                akz_comm_destroy(g_comm);                                                  \
+                fprintf(stderr, "communicator abandoned after a timeout: exiting with status 3\n"); \
+                fflush(stderr);                                                            \
+                _exit(3);                                                                  \
+            }                                                                              \
             return 1;                                                                      \
         }                                                                                  \
     } while (0)
@@ -74,6 +86,8 @@ int main(int argc, char** argv) {
     }
     akz_comm* comm = nullptr;
     TRY(akz_comm_create(device, id, rank, nranks, &comm));
+    g_comm = comm;
+    if (const char* t = getenv("AKZ_SELFTEST_TIMEOUT_S")) TRY(akz_comm_set_timeout(comm, atof(t)));
     int r2 = -1, n2 = -1;
     TRY(akz_comm_info(comm, &r2, &n2));
     CHECK(r2 == rank && n2 == nranks);

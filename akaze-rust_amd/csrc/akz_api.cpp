@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
@@ -121,7 +122,8 @@ struct akz_ctx {
     std::atomic<uint32_t> sel_last_rounds{0}, sel_last_fallback{0};  // device's longest run of rounds, images that sent it back to the host
     DevBuf kp_in, kp_out;                    // keypoint params / orientation sums
     DevBuf match_a, match_b, match_rec, match_out;
-    DevBuf match_state;                      // k_match_merge_compact's per-workgroup counts (zeroed when allocated, then told apart by epoch)
+    DevBuf match_state;                      // k_match_merge_compact's per-workgroup counts (zeroed when allocated, then told apart by epoch);
+                                             // single-stream: only ever touched by launches on `stream` (see match_device_impl)
     uint32_t match_epoch = 0;
     DevBuf ransac_dev, ransac_pin;           // match_features: the trials' inputs and outputs on the device / pinned staging of both
     DevBuf mm_q8, mm_t8, mm_pop, mm_tab;     // MFMA matcher: unpacked int8 images of the two sets, bit counts, set tables
@@ -2943,7 +2945,14 @@ static int match_device_impl(akz_ctx* c, const uint8_t* d_d0, uint64_t n0, const
     // folding 11 chunks of 11 K queries there took 35 us against 5 for the 44-workgroup merge)
     // Query sets of a few workgroups and more: merge, ratio test and ordered compaction in ONE launch (k_match_merge_compact:
     // 44 workgroups for a 4K frame's 11 K rows); tiny ones keep the single-workgroup compaction
-    if (n0 >= 2048) {
+    // k_match_merge_compact is a chained look-back: a workgroup publishes its count, then waits for the counts of the
+    // workgroups before it.  Two conditions keep that free of deadlock and of cross-talk, and both are enforced HERE:
+    //   * every workgroup of the grid is resident at once (progress never depends on the order of dispatch): at most 1 024
+    //     workgroups of 256 threads -- four per compute unit -- i.e. query sets of up to 262 144 rows; larger sets take the
+    //     merge + single-workgroup compaction below;
+    //   * match_state (told apart by epoch) belongs to ONE stream: this function, like every user of the context's matcher
+    //     scratch (match_rec, mm_q8, mm_t8, mm_pop), enqueues on c->stream only -- launches of two epochs never overlap.
+    if (n0 >= 2048 && n0 <= 262144) {
         const size_t need = launch::match_merge_compact_state_bytes((uint32_t)n0);
         if (c->match_state.bytes < need) {
             AKZ_TRY(ensure(c, c->match_state, need * 2));
@@ -3238,9 +3247,8 @@ int akz_ctx_warmup(akz_ctx* c) {
     if (!c->placed) AKZ_TRY(place_streams(c));
     return AKZ_OK;
 }
-int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
+static int get_profile_full(akz_ctx* c, akz_profile* out, int reset) {
     AKZ_TRY(bind(c));
-    if (!out) return AKZ_ERR_INVALID_ARG;
     AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
     resolve_spans(c);
     *out = c->prof;
@@ -3253,7 +3261,7 @@ int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
     if (reset) c->prof = akz_profile{};
     for (akz_ctx* l : c->lanes) {  // jobs dealt to the lanes are part of this context's profile
         akz_profile p{};
-        AKZ_TRY(akz_ctx_get_profile(l, &p, reset));
+        AKZ_TRY(get_profile_full(l, &p, reset));
         for (size_t i = 0; i < sizeof(p.ms) / sizeof(p.ms[0]); ++i) out->ms[i] += p.ms[i];
         out->calls += p.calls;
         out->pixels += p.pixels;
@@ -3264,6 +3272,22 @@ int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
         out->fused_px += p.fused_px;
     }
     return AKZ_OK;
+}
+// The struct has grown at its end (ABI 5: placement_*) and may grow again: akz_ctx_get_profile2 writes at most the bytes the
+// caller says its struct has; the original symbol writes the ABI-4 prefix only, so that a host compiled against the
+// smaller struct is never written past its end.
+int akz_ctx_get_profile2(akz_ctx* c, akz_profile* out, uint64_t struct_size, int reset) {
+    if (!out || struct_size < offsetof(akz_profile, placement_probed)) {
+        set_error("akz_ctx_get_profile2: null struct, or one smaller than the ABI-4 akz_profile");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    akz_profile full{};
+    AKZ_TRY(get_profile_full(c, &full, reset));
+    std::memcpy(out, &full, (size_t)std::min<uint64_t>(struct_size, sizeof(full)));
+    return AKZ_OK;
+}
+int akz_ctx_get_profile(akz_ctx* c, akz_profile* out, int reset) {
+    return akz_ctx_get_profile2(c, out, offsetof(akz_profile, placement_probed), reset);
 }
 int akz_remove_outliers(const akz_keypoint*, uint64_t, const akz_keypoint*, uint64_t, const akz_match*, uint64_t, uint64_t,
                         float, float, akz_match*, uint64_t*);
@@ -3463,6 +3487,13 @@ int akz_debug_set_host_sort(akz_ctx* c, int on) {
     if (!c) return AKZ_ERR_INVALID_ARG;
     c->dbg_host_sort = on < 0 ? -1 : (on != 0);
     for (akz_ctx* l : c->lanes) l->dbg_host_sort = c->dbg_host_sort;
+    return AKZ_OK;
+}
+int akz_debug_rcp_f64_to_f32(akz_ctx* c, const double* d_x, float* d_out, uint64_t n) {
+    AKZ_TRY(bind(c));
+    if (!d_x || !d_out) return AKZ_ERR_INVALID_ARG;
+    if (n) launch::rcp_f64_to_f32(c->stream, d_x, d_out, n);
+    AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
 }
 int akz_debug_set_match_chunks(akz_ctx* c, uint32_t pair_chunks, uint32_t set_chunks) {

@@ -117,12 +117,17 @@ struct akz_gather {
 };
 
 static void pairs_destroy(akz_pairs* p);  // (defined with akz_pairs, below)
+static void delete_pairs_host_only(akz_pairs* p);
 static void pairs_orphan_all(akz_comm* c);
 struct akz_comm {
     int device = 0, rank = 0, nranks = 1;
     ncclComm_t nccl = nullptr;
     bool external = false;          // akz_comm_create_external: the CALLER moves the blocks between ranks (no RCCL in the process)
     double timeout_s = 0.0;         // akz_comm_set_timeout: how long akz_gather_finish waits for an exchange (0: without limit)
+    bool abandoned = false;         // an exchange timed out: the collective may never complete.  Nothing waits for the
+                                    // communicator's streams or events any more (akz_gather_free, akz_comm_destroy return at
+                                    // once and LEAK the device objects: hipFree / hipStreamDestroy / ncclCommDestroy would
+                                    // wait for the stuck collective), no new exchange is accepted; the process is expected to end
     hipStream_t xs = nullptr;       // exchange stream: the collectives, in order
     hipStream_t cs = nullptr;       // copy stream: local rows -> send block, headers -> host (never behind a collective)
     hipEvent_t ready = nullptr;     // producer-side event the copy stream waits for
@@ -150,6 +155,10 @@ static void gather_release_buffers(akz_gather* g) {
 }
 
 static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
+    if (c->abandoned) {
+        set_error("gather: an earlier exchange on this communicator timed out (a peer is missing or hung); it accepts no further work");
+        return AKZ_ERR_TIMEOUT;
+    }
     akz_gather* g = nullptr;
     for (akz_gather* p : c->pool)
         if (!p->in_use && p->send && p->cap_rows == cap_rows) {
@@ -351,6 +360,18 @@ int akz_gather_deliver(akz_gather* g, void* stream) {
 
 int akz_comm_destroy(akz_comm* c) {
     if (!c) return AKZ_OK;
+    if (c->abandoned) {
+        // A collective that will never complete sits on c->xs.  Every call that would wait for it -- synchronising or
+        // destroying the streams, hipFree (synchronises the device), ncclCommDestroy -- is left out: the device objects
+        // leak, the host objects go, and the caller can end the process with an error instead of hanging in teardown.
+        for (akz_gather* g : c->pool) delete g;
+        c->pool.clear();
+        for (akz_pairs* p : c->pairs_pool) delete_pairs_host_only(p);
+        c->pairs_pool.clear();
+        pairs_orphan_all(c);
+        delete c;
+        return AKZ_OK;
+    }
     (void)hipSetDevice(c->device);
     if (c->xs) (void)hipStreamSynchronize(c->xs);
     if (c->cs) (void)hipStreamSynchronize(c->cs);
@@ -490,6 +511,7 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
             (void)hipGetLastError();
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
                 set_error("gather: the exchange did not complete within the communicator's timeout (akz_comm_set_timeout): a peer is missing or hung");
+                c->abandoned = true;  // from here on nothing waits for this communicator's streams (akz_gather_free, akz_comm_destroy)
                 return AKZ_ERR_TIMEOUT;
             }
             std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -555,6 +577,9 @@ int akz_gather_image_rows(akz_gather* g, int rank, uint64_t* rows_per_image, uin
 
 int akz_gather_free(akz_gather* g) {
     if (!g) return AKZ_OK;
+    if (g->comm->abandoned) {  // its collective may never complete: do not wait, and never hand the buffers out again
+        return AKZ_OK;         // (in_use stays set; gather_acquire refuses new work on this communicator anyway)
+    }
     if (g->in_use && g->done && (!g->comm->external || g->delivered)) {
         (void)hipSetDevice(g->comm->device);
         (void)hipEventSynchronize(g->done);
@@ -666,6 +691,7 @@ static uint64_t pairs_lead(uint64_t a, uint64_t b) {
     const uint64_t lo = std::min(a, b), hi = std::max(a, b);
     return ((hi - lo) & 1u) ? lo : hi;
 }
+static void delete_pairs_host_only(akz_pairs* p) { delete p; }  // abandoned communicator: device objects leak (see akz_comm_destroy)
 static void pairs_destroy(akz_pairs* p) {
     if (!p) return;
     if (p->d_block) (void)hipFree(p->d_block);

@@ -241,6 +241,7 @@ bool detector_nms_fused_supported(uint32_t sigma);
 void detector_nms_fused(hipStream_t s, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx,
                         float* lyy, float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level,
                         float thr, float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
+void rcp_f64_to_f32(hipStream_t s, const double* x, float* out, uint64_t n);  // test hook (akz_pm_g2.hpp)
 void accumulate(hipStream_t s, float* a, const float* b, uint64_t count);  // a += b (image.rs:218-231); a may equal b
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat);

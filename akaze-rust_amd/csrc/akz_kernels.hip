@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "akz_internal.hpp"
+#include "akz_pm_g2.hpp"
 
 namespace akz {
 namespace {
@@ -89,9 +90,10 @@ __device__ __forceinline__ double octave_contrast(double k, unsigned pow) {
     for (unsigned i = 0; i < pow; ++i) k = k * 0.75;
     return k;
 }
-__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {
-    const double dx = (double)lx, dy = (double)ly;
-    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
+// test hook: the reciprocal of pm_g2 alone, on doubles the test chooses (akz_pm_g2.hpp)
+__global__ void k_rcp_f64_to_f32(const double* __restrict__ x, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rcp_f64_to_f32(x[i]);
 }
 __global__ void k_pm_g2(const float* __restrict__ lx, const float* __restrict__ ly, float* __restrict__ out,
                         size_t plane, const double* __restrict__ d_k, unsigned pow) {
@@ -1239,6 +1241,9 @@ void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, f
           float sigma_quat) {
     hipLaunchKernelGGL(k_ldet, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, lxx, lyy, lxy, out,
                        (size_t)count, sigma_quat);
+}
+void rcp_f64_to_f32(hipStream_t s, const double* x, float* out, uint64_t n) {
+    hipLaunchKernelGGL(k_rcp_f64_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, (size_t)n);
 }
 void accumulate(hipStream_t s, float* a, const float* b, uint64_t count) {
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, (size_t)count);

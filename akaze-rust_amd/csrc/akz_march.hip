@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "akz_internal.hpp"
+#include "akz_pm_g2.hpp"
 
 namespace akz {
 namespace {
@@ -455,10 +456,6 @@ __device__ __forceinline__ f2 tap3(f2 a, f2 b, f2 c, float k0, float k1, float k
 __device__ __forceinline__ double octave_contrast(double k, unsigned pow) {  // lib.rs:84: one octave at a time, in f64
     for (unsigned i = 0; i < pow; ++i) k = k * 0.75;
     return k;
-}
-__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {  // lib.rs:30-37
-    const double dx = (double)lx, dy = (double)ly;
-    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
 }
 
 // HALF: the level opens an octave and `prev` is the previous octave's last Lt (pw x ph = 2w x 2h, pw a multiple of 4): its

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "akz_internal.hpp"
+#include "akz_pm_g2.hpp"
 
 namespace akz {
 namespace {
@@ -64,10 +65,6 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 __device__ __forceinline__ double octave_contrast(double k, unsigned pow) {  // lib.rs:84, one octave at a time
     for (unsigned i = 0; i < pow; ++i) k = k * 0.75;
     return k;
-}
-__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {  // lib.rs:30-37
-    const double dx = (double)lx, dy = (double)ly;
-    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
 }
 
 // Patch grid of one level.  Thread t owns the patch (bx, by) = (t % XG, t / XG): pixels x0 .. x0+7, y0 .. y0+7.

@@ -449,6 +449,18 @@ __device__ __forceinline__ SelPacked sel_load_row(const SelRow* __restrict__ p) 
     return r;
 }
 __device__ __forceinline__ void sel_compiler_fence() { __asm__ volatile("" ::: "memory"); }
+// The words the waves of k_select exchange while they run are read and written as RELAXED ATOMICS of workgroup scope: the same
+// ds_read_u16 / ds_write_b16 as a plain access (no wait is attached to a relaxed operation -- an acquire or release of
+// workgroup scope would wait for the global loads in flight, the next row's prefetch, as well), but an access the compiler may
+// neither tear, merge with a neighbour, repeat nor hoist out of the loop, and one that is not a data race in the language's
+// model.  Order between two of them: sel_compiler_fence() keeps the compiler from moving one across the other, and the LDS
+// operations of a wave execute in the order they are issued.
+__device__ __forceinline__ unsigned short sel_word_load(const unsigned short* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void sel_word_store(unsigned short* p, unsigned short v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__ sorted, RelLevels lv, const unsigned* __restrict__ offs,
                                                    const SelRow* __restrict__ rows, const unsigned char* __restrict__ state0,
                                                    const unsigned* __restrict__ img_flags, const unsigned* __restrict__ row_table,
@@ -559,9 +571,9 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
             // the predecessor's word BEFORE the neighbour's (the predecessor stores "the neighbour is gone" before its own word;
             // LDS operations of a wave execute in the order they are issued)
             sel_compiler_fence();
-            const unsigned wpred = s_word[has_pred ? pr : 0u];
+            const unsigned wpred = sel_word_load(&s_word[has_pred ? pr : 0u]);
             sel_compiler_fence();
-            const unsigned wq_now = s_word[q];
+            const unsigned wq_now = sel_word_load(&s_word[q]);
             sel_compiler_fence();
             const int before = prog.at;
             if (!sel::advance(&prog, has_pred, (unsigned short)wpred, (unsigned short)wq_now)) break;
@@ -578,9 +590,9 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
             const unsigned short c = (unsigned short)cand_of((unsigned)b_cur);
             bool replaces;
             const unsigned short mine = sel::turn(prog, c, (unsigned short)wins, &replaces);
-            if (replaces) s_word[hit_q] = sel::kGone;
+            if (replaces) sel_word_store(&s_word[hit_q], sel::kGone);
             sel_compiler_fence();  // (the replaced entry is gone before anyone can see the turn as taken)
-            s_word[c] = mine;
+            sel_word_store(&s_word[c], mine);
             sel_compiler_fence();
             b_cur = b_nxt;
             if (b_cur >= 0) open_row(nxt);
@@ -588,8 +600,8 @@ __global__ void __launch_bounds__(SEL_NT) k_select(const Candidate* __restrict__
             waited = 0;
         } else if ((++waited & 255u) == 0u) {  // (every 256th fruitless look: has the workgroup given up?  A plain LDS read --
             sel_compiler_fence();              // a volatile one is a FLAT load, which waits for the next row's prefetch too)
-            if (waited > SEL_MAX_LOOKS || s_abort != 0u) {
-                s_abort = 1u;
+            if (waited > SEL_MAX_LOOKS || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+                __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 break;
             }
         }

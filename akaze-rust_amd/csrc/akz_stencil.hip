@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "akz_internal.hpp"
+#include "akz_pm_g2.hpp"
 
 namespace akz {
 namespace {
@@ -74,10 +75,6 @@ __device__ __forceinline__ float unit_px(const uint8_t* p, size_t i) { return ((
 __device__ __forceinline__ double octave_contrast(double k, unsigned pow) {
     for (unsigned i = 0; i < pow; ++i) k = k * 0.75;  // lib.rs:84, one octave at a time in f64
     return k;
-}
-__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {  // lib.rs:30-37
-    const double dx = (double)lx, dy = (double)ly;
-    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
 }
 
 struct DenseTaps {

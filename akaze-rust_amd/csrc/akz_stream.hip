@@ -37,6 +37,7 @@
 #include <cstdlib>
 
 #include "akz_internal.hpp"
+#include "akz_pm_g2.hpp"
 
 namespace akz {
 namespace {
@@ -155,10 +156,6 @@ __device__ __forceinline__ float from_right_lane(float v) {  // lane i receives 
 }
 __device__ __forceinline__ f4 tap3(f4 a, f4 b, f4 c, float k0, float k1, float k2) {
     return ((0.0f + k0 * a) + k1 * b) + k2 * c;
-}
-__device__ __forceinline__ float pm_g2_px(float lx, float ly, double inverse_k) {  // lib.rs:30-37
-    const double dx = (double)lx, dy = (double)ly;
-    return (float)(1.0 / (1.0 + inverse_k * (dx * dx + dy * dy)));
 }
 __device__ __forceinline__ float mean4(float p00, float p01, float p10, float p11) {  // image.rs:108-114
     float v = 0.0f;

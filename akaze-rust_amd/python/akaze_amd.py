@@ -128,6 +128,7 @@ def lib():
         "akz_op_gaussian_blur_u8": ([vp, vp, vp, u32, u32, u32, C.c_float], i32),
         "akz_op_half_size": ([vp, vp, vp, u32, u32, u32], i32),
         "akz_op_scharr": ([vp, vp, vp, u32, u32, u32, i32, i32, u32], i32),
+        "akz_debug_rcp_f64_to_f32": ([vp, vp, vp, u64], i32),
         "akz_op_pm_g2": ([vp, vp, vp, vp, u32, u32, u32, vp], i32),
         "akz_op_contrast_factor": ([vp, vp, u32, u32, u32, f64, f64, u64, vp], i32),
         "akz_op_flow": ([vp, vp, vp, u32, u32, u32, vp, u32], i32),
@@ -204,6 +205,7 @@ def lib():
         "akz_ctx_set_detector_mode": ([vp, i32], i32),
         "akz_ctx_set_prep_mode": ([vp, i32], i32),
         "akz_ctx_get_profile": ([vp, C.POINTER(Profile), i32], i32),
+        "akz_ctx_get_profile2": ([vp, C.POINTER(Profile), u64, i32], i32),
         "akz_ctx_warmup": ([vp], i32),
         "akz_debug_placement_verdict": ([C.c_float, C.c_float, C.c_float, C.c_float], i32),
         "akz_synth_frame_u8": ([vp, u32, u32, u64, C.c_int32, C.c_int32], i32),
@@ -401,7 +403,7 @@ class Context:
 
     def get_profile(self, reset=True):
         p = Profile()
-        _check(lib().akz_ctx_get_profile(self._h, C.byref(p), int(reset)))
+        _check(lib().akz_ctx_get_profile2(self._h, C.byref(p), C.sizeof(Profile), int(reset)))
         return p.as_dict()
 
     def set_host_threads(self, threads):
@@ -651,6 +653,13 @@ class Context:
         out = torch.empty_like(img)
         _check(lib().akz_op_scharr(self._h, img.data_ptr(), out.data_ptr(), w, h, n, int(x_order), int(y_order),
                                    sigma_size))
+        return out
+
+    def debug_rcp_f64_to_f32(self, x):
+        """(1.0 / x) as f32 for a CUDA float64 tensor, the way pm_g2 forms it inside the level kernels"""
+        import torch
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        _check(lib().akz_debug_rcp_f64_to_f32(self._h, x.data_ptr(), out.data_ptr(), x.numel()))
         return out
 
     def pm_g2(self, lx, ly, k):

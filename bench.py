@@ -1401,19 +1401,35 @@ def main_rank(args):
     # frames, 5 octaves x 5 sublevels, frame f on rank f mod N, descriptors stay on the device; per step extraction -> exchange
     # (akz_gather_begin) -> akz_match_all_pairs -> totals of every held list read.  Un-pipelined (one step at a time): the figure
     # of `--workload c5`, which pipelines the steps, is higher.  The driver's `bench.py --gpus N` thereby measures configs[4]
-    # too.  A watchdog guards the headline: if the leg does not finish, rank 0 prints the line without it and every rank exits 0.
+    # too.  A watchdog guards the headline: if the leg does not finish, rank 0 prints the line with the error in the leg's place and
+    # every rank exits NON-zero (a hung collective or matcher is a failed run, whatever the line says).
     leg = None
     if world > 1 and not stub and not c5 and not args.no_c5_leg and xch["comm"] is not None and exchange in ("capi", "external"):
         import threading
+        wd_lock = threading.Lock()
+        wd_state = {"over": False}
 
-        def bail():
-            if rank == 0:
-                out["config"]["all_pairs_c5_leg"] = {"error": f"given up after {args.c5_leg_timeout} s; the figures above were complete before it began"}
-                print(json.dumps(out), file=json_out, flush=True)
-            os._exit(0)
-        wd = threading.Timer(args.c5_leg_timeout, bail)
+        def give_up(why, status=3):
+            # The leg cannot complete on this rank (it hangs, or it failed here while the peers sit in a collective).  The
+            # headline figures were complete before the leg began: rank 0 still prints them, with the error -- and EVERY rank
+            # then leaves with a non-zero status, without the runtime's exit handlers (a stuck collective would hold them).
+            with wd_lock:
+                if wd_state["over"]:
+                    return
+                wd_state["over"] = True
+                if rank == 0:
+                    out["config"]["all_pairs_c5_leg"] = {"error": why}
+                    print(json.dumps(out), file=json_out, flush=True)
+                sys.stderr.write(f"rank {rank}: all-pairs leg: {why}; exiting with status {status}\n")
+                sys.stderr.flush()
+                os._exit(status)
+        wd = threading.Timer(args.c5_leg_timeout, give_up,
+                             (f"given up after {args.c5_leg_timeout} s; the figures above were complete before it began",))
         wd.daemon = True
         wd.start()
+        # local preparation first; whether it worked is agreed on by all ranks BEFORE the first collective of the leg, so that
+        # a rank that cannot take part does not leave the others waiting in one
+        prep_error = None
         try:
             n5, W5, H5, steps5 = max(1, args.c5_leg_frames), 3840, 2160, 3
             cfg55 = A.Config(num_sublevels=5, max_octave_evolution=5)
@@ -1426,41 +1442,51 @@ def main_rank(args):
             r5 = extract5()
             rows5 = sum(r5.counts(i)[1] for i in range(r5.num_images))
             r5.close()
-            most = int(host_max(float(rows5)))
-            cap5 = max(1024, (most + most // 4 + 4095) // 4096 * 4096)
+        except Exception as e:
+            prep_error = str(e)[:300]
+        if host_max(0.0 if prep_error is None else 1.0) > 0.5:
+            leg = {"error": f"skipped on every rank: preparation failed on at least one ({prep_error or 'another rank'})"}
+        else:
+            try:
+                most = int(host_max(float(rows5)))
+                cap5 = max(1024, (most + most // 4 + 4095) // 4096 * 4096)
 
-            def step5():
-                r_ = extract5()
-                g_ = xch["comm"].gather_begin([r_], cap5)
-                if exchange == "external":
-                    g_.exchange_over()
-                r_.close()
-                p_ = g_.match_all_pairs(ctx)
-                tot = p_.totals()  # waits for the launches, reads every held list's count
-                n_img = p_.n_images
-                p_.free()
-                g_.free()
-                return tot, n_img
-            step5()
-            barrier()
-            t5 = time.perf_counter()
-            for _ in range(steps5):
-                tot5, n_img5 = step5()
-            barrier()
-            el5 = host_max(time.perf_counter() - t5)
-            dist5, match5 = host_sum(float(tot5[2])), host_sum(float(tot5[1]))
-            lists5 = host_allgather(float(tot5[0]))
-            leg = {"workload": f"BASELINE configs[4] over {world} ranks: {n5} 3840x2160 frames per rank per step, 5 octaves x 5 sublevels, "
-                               "descriptors on the device; extraction -> exchange -> akz_match_all_pairs -> totals read, one step at a "
-                               "time (un-pipelined; `--workload c5` pipelines)",
-                   "Mpix_s": round(float(W5) * H5 * n5 * world * steps5 / el5 / 1e6, 1), "ms_per_step": round(el5 / steps5 * 1e3, 2),
-                   "images_per_step": int(n_img5), "unordered_image_pairs_per_step": int(n_img5) * (int(n_img5) - 1) // 2,
-                   "Tdistances_per_s": round(dist5 * steps5 / el5 / 1e12, 3), "matches_per_step": int(match5),
-                   "match_lists_held_per_rank": [int(v) for v in lists5], "transport": exchange}
-            del d5
-        except Exception as e:  # (a failure on one rank leaves the others in a collective: the watchdog ends them)
-            leg = {"error": str(e)[:300]}
-        wd.cancel()
+                def step5():
+                    r_ = extract5()
+                    g_ = xch["comm"].gather_begin([r_], cap5)
+                    if exchange == "external":
+                        g_.exchange_over()
+                    r_.close()
+                    p_ = g_.match_all_pairs(ctx)
+                    tot = p_.totals()  # waits for the launches, reads every held list's count
+                    n_img = p_.n_images
+                    p_.free()
+                    g_.free()
+                    return tot, n_img
+                step5()
+                barrier()
+                t5 = time.perf_counter()
+                for _ in range(steps5):
+                    tot5, n_img5 = step5()
+                barrier()
+                el5 = host_max(time.perf_counter() - t5)
+                dist5, match5 = host_sum(float(tot5[2])), host_sum(float(tot5[1]))
+                lists5 = host_allgather(float(tot5[0]))
+                leg = {"workload": f"BASELINE configs[4] over {world} ranks: {n5} 3840x2160 frames per rank per step, 5 octaves x 5 sublevels, "
+                                   "descriptors on the device; extraction -> exchange -> akz_match_all_pairs -> totals read, one step at a "
+                                   "time (un-pipelined; `--workload c5` pipelines)",
+                       "Mpix_s": round(float(W5) * H5 * n5 * world * steps5 / el5 / 1e6, 1), "ms_per_step": round(el5 / steps5 * 1e3, 2),
+                       "images_per_step": int(n_img5), "unordered_image_pairs_per_step": int(n_img5) * (int(n_img5) - 1) // 2,
+                       "Tdistances_per_s": round(dist5 * steps5 / el5 / 1e12, 3), "matches_per_step": int(match5),
+                       "match_lists_held_per_rank": [int(v) for v in lists5], "transport": exchange}
+                del d5
+            except Exception as e:
+                # between collectives there is no way to tell the peers: this rank reports and leaves non-zero; theirs end
+                # through the communicator's timeout or their own watchdog, non-zero as well
+                give_up(f"failed on rank {rank}: {str(e)[:300]}")
+        with wd_lock:  # the timer either has fired (and ended the process) or never will
+            wd_state["over"] = True
+            wd.cancel()
     if rank == 0:
         out["config"]["all_pairs_c5_leg"] = leg
         print(json.dumps(out), file=json_out, flush=True)
@@ -1485,7 +1511,18 @@ def main():
     elif int(env_world) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: start bench.py with --gpus equal to the number of "
                          "ranks (or without WORLD_SIZE in the environment, and it starts the ranks itself)")
-    sys.exit(main_rank(args))
+    try:
+        rc = main_rank(args)
+    except Exception as e:
+        # An exchange that timed out (AKZ_ERR_TIMEOUT: a peer is missing or hung) leaves a collective on the communicator's
+        # stream that may never complete; interpreter shutdown would run the GPU runtime's exit handlers behind it.  Report and
+        # leave without them, non-zero.
+        if getattr(e, "status", None) == -10:
+            sys.stderr.write(f"bench.py: {e}\nbench.py: the exchange timed out; exiting with status 3 without runtime teardown\n")
+            sys.stderr.flush()
+            os._exit(3)
+        raise
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

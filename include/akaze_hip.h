@@ -40,8 +40,11 @@ extern "C" {
    5 (round 5): additions -- akz_comm_create_external / akz_gather_blocks / akz_gather_deliver (the exchange carried by the
    caller), akz_comm_set_timeout, akz_pairs_totals, akz_ctx_warmup; akz_profile grew by the placement_* fields at its END
    (a caller built against version 4 must not pass its smaller struct to akz_ctx_get_profile); an akz_pairs may be freed
-   after its communicator; AKZ_ERR_TIMEOUT.  No signature changed. */
-#define AKZ_ABI_VERSION 5
+   after its communicator; AKZ_ERR_TIMEOUT.  No signature changed.
+   6 (round 6): additions -- akz_ctx_get_profile2 (size-checked; akz_ctx_get_profile writes the ABI-4 prefix of akz_profile
+   only from now on); akz_op_scharr accepts both and neither order as the reference does; a communicator whose exchange
+   timed out is abandoned (akz_comm_set_timeout).  No signature changed. */
+#define AKZ_ABI_VERSION 6
 
 typedef enum akz_status {
     AKZ_OK = 0,
@@ -350,8 +353,12 @@ int akz_comm_create_external(int device, int rank, int nranks, akz_comm** out);
 int akz_comm_destroy(akz_comm* comm);
 /* How long akz_gather_finish (and what calls it: akz_gather_descriptors, akz_match_all_pairs) waits for an exchange before
    it gives up with AKZ_ERR_TIMEOUT -- a peer that crashed or never joined leaves a collective waiting for ever, and a host
-   that can report that is worth more than one that hangs.  0 (default): wait without limit.  After a timeout the gather is
-   still in flight (akz_gather_free waits for it): the job is expected to end. */
+   that can report that is worth more than one that hangs.  0 (default): wait without limit.  After a timeout the
+   communicator is ABANDONED: the stuck collective still sits on its stream, so nothing waits for that stream any more --
+   akz_gather_free and akz_comm_destroy return at once and leak the device buffers, streams and the RCCL communicator (freeing
+   them would wait for the collective), new exchanges are refused with AKZ_ERR_TIMEOUT.  The host is expected to report the
+   error and end the process with a non-zero status WITHOUT running the GPU runtime's exit handlers (`_exit` / `os._exit`:
+   they, too, may wait for the stuck stream). */
 int akz_comm_set_timeout(akz_comm* comm, double seconds);
 /* Optional, once, with idle streams (before the first step): moves the communicator's two streams onto hardware queues and
    command-processor pipes that `ctx`'s busy streams (the caller's, the coarse chain's, the finish half's) do not use -- the
@@ -506,6 +513,11 @@ typedef struct akz_profile {
 /* on: 0 = off, 1 = every stage (two HIP events per stage and level), 2 = light: only the FED and detector spans and
    the host-clock stages (what bench.py uses inside its timed region) */
 int akz_ctx_set_profiling(akz_ctx* ctx, int on);
+/* akz_profile has grown at its end (ABI 5) and may again.  akz_ctx_get_profile2 writes min(struct_size, sizeof(akz_profile))
+   bytes -- pass sizeof(akz_profile) of the header the caller was compiled against; akz_ctx_get_profile, the original symbol,
+   writes the ABI-4 prefix only (everything before placement_probed), so a host built against the smaller struct is never
+   written past its end. */
+int akz_ctx_get_profile2(akz_ctx* ctx, akz_profile* out, uint64_t struct_size, int reset);
 int akz_ctx_get_profile(akz_ctx* ctx, akz_profile* out, int reset);
 /* Optional, once, with the caller's stream idle and NOT being captured: runs the stream-placement probe now (~2 ms: spins
    and tiny kernels on the context's streams, which are synchronised) instead of inside the first large akz_extract_begin_*

@@ -45,6 +45,9 @@ int akz_debug_stream_placement(akz_ctx* ctx, int* info);
    end; tiny_pair_ms: 24 + 24 interleaved tiny kernels on the two streams (negative: not measured); tiny_alone_ms: 24 of
    them on one stream. */
 int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float tiny_alone_ms, float spin_ms);
+/* Test hook: pm_g2's reciprocal on its own -- d_out[i] = (1.0 / d_x[i]) as f32 the way every level kernel forms it
+   (csrc/akz_pm_g2.hpp: refined hardware reciprocal, the full f64 division only where the f32 rounding could depend on it). */
+int akz_debug_rcp_f64_to_f32(akz_ctx* ctx, const double* d_x, float* d_out, uint64_t n);
 /* Test hook: where the extrema candidates are put into scan order: 1 = bucketed and sorted on the HOST (also the fallback
    that a candidate-list overflow and over-wide sort keys take), 0 = device sort, -1 = automatic (the default: device
    sort for contexts with fewer than four host threads).  Results are identical. */

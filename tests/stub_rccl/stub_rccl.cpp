@@ -3,7 +3,10 @@
 // LD_LIBRARY_PATH of a C++ host (gather_selftest: no PyTorch, so no other RCCL is in the process) to exercise what cannot be
 // exercised with the real library on a one-GPU box:
 //   * fault paths: AKZ_STUB_RCCL=init_fail (ncclCommInitRank fails), allgather_fail (ncclAllGather returns an error),
-//     built with -DSTUB_NO_ALLGATHER (a symbol is missing);
+//     built with -DSTUB_NO_ALLGATHER (a symbol is missing); stall_after_N (the (N+1)-th ncclAllGather "loses its peer": it
+//     returns success like the real call does once the collective is enqueued, and the stream then stays busy for
+//     AKZ_STUB_RCCL_STALL_S seconds -- default 25 -- behind a HOST function that sleeps: the stream-side picture of a
+//     collective whose peer died, bounded, and without a single GPU wave spinning);
 //   * the communicator's logic with MORE THAN ONE rank: AKZ_STUB_RCCL=ok (default) all-gathers between PROCESSES through a
 //     POSIX shared-memory segment named by the unique id (host staged, synchronous; a peer that does not arrive within
 //     AKZ_STUB_RCCL_TIMEOUT_S -- default 30 -- is an error, not a hang), so that `gather_selftest RANK NRANKS ID_FILE 0`
@@ -114,9 +117,22 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
 }
 
 #ifndef STUB_NO_ALLGATHER
+namespace {
+std::atomic<int> g_calls{0};
+void stall(void* seconds) {
+    const double s = *(const double*)seconds;
+    std::this_thread::sleep_for(std::chrono::duration<double>(s));
+}
+double g_stall_s = 25.0;
+}  // namespace
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclComm_t comm, hipStream_t stream) {
     Comm* c = (Comm*)comm;
     if (!std::strcmp(mode(), "allgather_fail")) return ncclUnhandledCudaError;
+    if (!std::strncmp(mode(), "stall_after_", 12) && g_calls.fetch_add(1) >= atoi(mode() + 12)) {
+        const char* t = getenv("AKZ_STUB_RCCL_STALL_S");
+        if (t) g_stall_s = atof(t);
+        return hipLaunchHostFunc(stream, stall, &g_stall_s) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+    }
     if (dt != ncclUint8 && dt != ncclInt8) return ncclInvalidArgument;
     if (count * (size_t)c->nranks > kData) return ncclInvalidArgument;
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;

@@ -35,9 +35,9 @@ def test_stub_rccl_builds_and_exports_what_akz_comm_binds(tmp_path):
     assert " T ncclAllGather" not in subprocess.run(["nm", "-D", "--defined-only", lib2], capture_output=True, text=True).stdout
 
 
-def _ranks(stub_dir, world, tmp_path, mode="ok", only=None, timeout_s="30", limit=300):
+def _ranks(stub_dir, world, tmp_path, mode="ok", only=None, timeout_s="30", limit=300, extra_env=None):
     env = dict(os.environ, LD_LIBRARY_PATH=stub_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), AKZ_STUB_RCCL=mode,
-               AKZ_STUB_RCCL_TIMEOUT_S=timeout_s)
+               AKZ_STUB_RCCL_TIMEOUT_S=timeout_s, **(extra_env or {}))
     idf = str(tmp_path / f"id_{mode}_{world}_{time.monotonic_ns()}")
     procs = [subprocess.Popen([BIN, str(r), str(world), idf, "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in (range(world) if only is None else only)]
@@ -79,3 +79,19 @@ def test_comm_fault_paths_end_with_a_message_not_a_hang(tmp_path):
     # a peer that never arrives: rank 0 of 2 alone gives up (the stub's collective init times out), it does not hang
     rcs, outs, dt = _ranks(stub, 2, tmp_path, only=[0], timeout_s="3", limit=120)
     assert rcs[0] != 0 and "ncclCommInitRank failed" in outs[0] and dt < 60, (outs, dt)
+
+
+@pytest.mark.gpu
+def test_a_peer_lost_after_init_ends_the_rank_with_an_error_within_the_timeout(tmp_path):
+    """The collective is enqueued and never completes (the stub keeps the stream busy for 25 s behind a sleeping host
+    function -- what a rank sees when its peer dies mid-job).  With akz_comm_set_timeout(2 s) akz_gather_finish gives up
+    with AKZ_ERR_TIMEOUT, the communicator is abandoned: akz_comm_destroy returns at once (it must not synchronise the
+    stuck stream, free device memory or destroy the RCCL communicator) and the host exits non-zero -- long before the
+    25 s are over.  Both a stall of the very first exchange and one after several good ones (pooled gathers in flight)."""
+    stub = os.path.dirname(_build(str(tmp_path / "stub")))
+    for after in (0, 3):
+        rcs, outs, dt = _ranks(stub, 1, tmp_path, mode=f"stall_after_{after}", limit=120,
+                               extra_env=dict(AKZ_SELFTEST_TIMEOUT_S="2", AKZ_STUB_RCCL_STALL_S="25"))
+        assert rcs[0] == 3, outs
+        assert "did not complete within the communicator's timeout" in outs[0] and "exiting with status 3" in outs[0], outs
+        assert dt < 15, (dt, outs)  # 2 s timeout + start-up; nothing waited for the 25 s stall

@@ -102,6 +102,34 @@ def test_pm_g2(ctx, ref, k):
     same(host(ctx.pm_g2(dev(lx), dev(ly), k)), ref.pm_g2(lx, ly, k))
 
 
+def test_pm_g2_reciprocal_boundaries(ctx):
+    """pm_g2's `(1.0 / x) as f32` (lib.rs:36) takes the refined hardware reciprocal except where the f32 rounding could
+    depend on the last bits of the f64 quotient (akz_pm_g2.hpp).  Doubles whose quotient lies ON an f32 rounding boundary,
+    a few ulp either side of one, and far from any, against numpy's correctly rounded division."""
+    import torch
+    rng = np.random.default_rng(21)
+    f = rng.uniform(2.0 ** -20, 1.0, 200_000).astype(np.float32)
+    mid = (f.astype(np.float64) + np.nextafter(f, np.float32(2)).astype(np.float64)) * 0.5  # boundaries in (0, 1]
+    x0 = 1.0 / mid
+    xs = [x0]
+    for d in (1, 2, 3, 5, 9, 17, 40):  # quotients within a few ulp(f64) of the boundary, both sides
+        for sgn in (1, -1):
+            x = x0.copy()
+            for _ in range(d):
+                x = np.nextafter(x, np.inf if sgn > 0 else -np.inf)
+            xs.append(x)
+    xs.append(1.0 + rng.uniform(0, 1, 2_000_000) * 10.0 ** rng.uniform(-6, 6, 2_000_000))  # what pm_g2 sees
+    xs.append(np.array([1.0, 2.0, 4.0, 3.0, 1e19, 2.0 ** 64, 2.0 ** 100, 1e300, 2.0 ** 127, 2.0 ** 140, 2.0 ** 149,
+                        2.0 ** 150, np.inf, 0.5, 1e-30]))
+    x = np.maximum(np.concatenate(xs), 1e-30)
+    got = host(ctx.debug_rcp_f64_to_f32(torch.from_numpy(x).cuda()))
+    with np.errstate(over="ignore", under="ignore"):
+        want = (1.0 / x).astype(np.float32)
+    assert np.array_equal(got, want), (x[got != want][:5], got[got != want][:5], want[got != want][:5])
+    # the boundary cases must really be there: without the guard a plain (float)r would differ somewhere
+    assert (np.abs((1.0 / x0) - mid) <= np.spacing(mid) * 2).mean() > 0.9
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_flow_is_scharr1_plus_pm_g2(ctx, ref, shape):
     ls = rand_img(*shape, seed=7)

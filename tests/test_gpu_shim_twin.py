@@ -114,7 +114,7 @@ def test_allocate_evolutions_and_fed_tau(twin, amd, ref):
     want = ref.fed_tau(5.9984531212995087)
     assert n.value == len(want) == 8 and out[:8].tobytes() == np.asarray(want).tobytes()
     # where the reference never terminates the shim panics: status -1 with the library's message
-    assert twin.twin_fed_tau(C.c_double(0.2), 1, C.c_double(0.25), 1, fp(out), 64, C.byref(n)) == -1
+    assert twin.twin_fed_tau(C.c_double(0.1), 1, C.c_double(0.25), 1, fp(out), 64, C.byref(n)) == -1
     assert b"akaze_hip status" in twin.twin_last_error()
 
 
@@ -135,10 +135,10 @@ def test_calculate_step_and_eval(twin, ref):
 
 @pytest.fixture(scope="module")
 def features(twin, amd):
-    frame = amd.synth_frame(400, 300, 5)
+    frame = amd.synth_frame(640, 480, 1)
     cfg = amd.Config()
     h = C.c_void_p()
-    ok(twin, twin.twin_extract_features(fp(frame), 400, 300, C.byref(cfg), C.byref(h)))
+    ok(twin, twin.twin_extract_features(fp(frame), 640, 480, C.byref(cfg), C.byref(h)))
     yield frame, cfg, h
     twin.twin_features_free(h)
 
@@ -157,7 +157,7 @@ def test_extract_features_returns_what_the_reference_returns(twin, amd, ref, fea
     frame, cfg, h = features
     rf = ref.extract(frame)
     nl, kp, d = _kp(twin, amd, h)
-    assert nl == rf.num_levels and len(kp) == rf.num_keypoints > 100
+    assert nl == rf.num_levels and len(kp) == rf.num_keypoints > 50
     rk = rf.keypoints()
     for f in ("x", "y", "response", "size", "octave", "class_id", "angle"):
         assert np.array_equal(kp[f], rk[f]), f
@@ -188,7 +188,7 @@ def test_ops_on_the_callers_evolutions(twin, amd, ref, features):
     rf = ref.extract(frame)
     _, kp, d = _kp(twin, amd, h)
     ok(twin, twin.twin_detector_response(h, C.byref(cfg)))  # recomputed from Lsmooth, must reproduce the planes
-    for lvl in (0, 5, 15):
+    for lvl in (0, 5, rf.num_levels - 1):
         for pi in (2, 3, 4, 5, 6, 9):
             want = rf.plane(lvl, PLANES[pi])
             got = np.empty(want.shape, np.float32); n_px = C.c_uint64()

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(amd):
     # and the binding declares a signature for each of them
     assert sorted(set(syms) - set(L._declared)) == []
     hdr = open(os.path.join(ROOT, "include", "akaze_hip.h")).read()
-    assert L.akz_abi_version() == int(re.search(r"#define\s+AKZ_ABI_VERSION\s+(\d+)", hdr).group(1)) == 5
+    assert L.akz_abi_version() == int(re.search(r"#define\s+AKZ_ABI_VERSION\s+(\d+)", hdr).group(1)) == 6
 
 
 def test_no_oracle_in_product_path():
@@ -139,13 +139,17 @@ def test_isa_has_no_contracted_fma():
     rows, bad = isa_audit.audit(os.path.join(pkg, "csrc", "akz_kernels.s"))
     rows2, bad2 = isa_audit.audit(os.path.join(pkg, "csrc", "akz_stencil.s"))
     assert len(rows) >= 14 and len(rows2) >= 18 and not bad and not bad2, (bad, bad2)
-    # k_octave_resident: f64 FMAs only, five per pm_g2 division (its expansion); no f32 FMA at all (the 2x2 mean's
-    # division by 4 is a multiplication by 0.25)
+    # k_octave_resident: f64 FMAs only, and only those of pm_g2 (akz_pm_g2.hpp): per pixel site the four of the refined
+    # reciprocal (one v_rcp_f64) plus the five of the full division's expansion on the rare path (a second v_rcp_f64, one
+    # v_div_fmas_f64); a plain division (1 / k^2) has the expansion alone.  No f32 FMA at all (the 2x2 mean's division by 4
+    # is a multiplication by 0.25)
     import re
     res = open(os.path.join(pkg, "csrc", "akz_resident.s")).read()
     assert not re.findall(r"\bv_(?:pk_fma|fma|fmac|mad|mac|fmaak|fmamk)_(?:f32|legacy_f32)\b", res)
     n_div = len(re.findall(r"\bv_div_fmas_f64\b", res))
-    assert n_div >= 2 and len(re.findall(r"\bv_(?:fma|fmac)_f64", res)) == 5 * n_div
+    n_rcp = len(re.findall(r"\bv_rcp_f64", res))
+    sites, plain = n_rcp - n_div, 2 * n_div - n_rcp
+    assert sites >= 2 and plain >= 0 and len(re.findall(r"\bv_(?:fma|fmac)_f64", res)) == 9 * sites + 5 * plain
     pure = {r[0]: r[1] for r in rows + rows2}
     for k, v in pure.items():
         if k.startswith(("k_fed", "k_filter_v", "k_filter_hIf", "k_ldet", "k_nms", "k_orientation", "k_deriv",

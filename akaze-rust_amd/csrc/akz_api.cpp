@@ -207,8 +207,11 @@ struct akz_ctx {
     hipEvent_t probe_ev[2] = {nullptr, nullptr};
     int profiling = 0;  // 0 off, 1 FED spans + host-clock stages, 2 every stage
     akz_profile prof{};
-    struct Span { int stage; hipEvent_t a, b; };
+    struct Span { int stage; hipEvent_t a, b; int row; };
     std::vector<Span> spans;          // recorded, not yet resolved
+    // akz_debug_kernel_rows: the spans of the two dominant stages by kernel variant and launch shape (what bench.py lists
+    // behind roofline.kernel); a span's `row` indexes this table (-1: not broken down)
+    std::vector<akz_kernel_row> rows;
     std::vector<hipEvent_t> ev_pool;  // recycled events
     std::mutex ev_m;                  // guards spans and ev_pool (begin records on the caller's thread while a finish resolves)
     // Every extract_begin records, behind its last fine-level diffusion launch, the event fed_ev[seq % kFedRing] of its
@@ -251,6 +254,7 @@ struct StageTimer {
     }
     bool on;
     hipStream_t s;
+    int row = -1;
     StageTimer(akz_ctx* ctx, int st, hipStream_t stream = nullptr) : c(ctx), stage(st), s(stream ? stream : ctx->stream) {
         on = c->profiling >= 2 || (c->profiling == 1 && (st == AKZ_ST_FED || st == AKZ_ST_DETECTOR));
         if (!on) return;
@@ -258,11 +262,30 @@ struct StageTimer {
         b = get(c);
         (void)hipEventRecord(a, s);
     }
+    // the span belongs to kernel variant (kind, param) on launches of shape (w, h, n): `launches` launches over `px` level
+    // pixels (x batch) that advance `px_steps` pixel-steps (FED kinds)
+    void kernel(uint32_t kind, uint32_t param, uint32_t w, uint32_t h, uint32_t n, uint64_t launches, uint64_t px, uint64_t px_steps = 0) {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(c->ev_m);
+        for (size_t i = 0; i < c->rows.size() && row < 0; ++i) {
+            const akz_kernel_row& r = c->rows[i];
+            if (r.stage == (uint32_t)stage && r.kind == kind && r.param == param && r.w == w && r.h == h && r.n == n) row = (int)i;
+        }
+        if (row < 0) {
+            akz_kernel_row r{};
+            r.stage = (uint32_t)stage, r.kind = kind, r.param = param, r.w = w, r.h = h, r.n = n;
+            c->rows.push_back(r);
+            row = (int)c->rows.size() - 1;
+        }
+        c->rows[(size_t)row].launches += launches;
+        c->rows[(size_t)row].px += px;
+        c->rows[(size_t)row].px_steps += px_steps;
+    }
     ~StageTimer() {
         if (!on) return;
         (void)hipEventRecord(b, s);
         std::lock_guard<std::mutex> lk(c->ev_m);
-        c->spans.push_back({stage, a, b});
+        c->spans.push_back({stage, a, b, row});
     }
 };
 static void ev_put(akz_ctx* c, hipEvent_t e) {
@@ -279,7 +302,10 @@ static void resolve_spans(akz_ctx* c) {
             continue;
         }
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) c->prof.ms[sp.stage] += (double)ms;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            c->prof.ms[sp.stage] += (double)ms;
+            if (sp.row >= 0 && (size_t)sp.row < c->rows.size()) c->rows[(size_t)sp.row].ms += (double)ms;
+        }
         c->ev_pool.push_back(sp.a);
         c->ev_pool.push_back(sp.b);
     }
@@ -951,6 +977,7 @@ int akz_op_fed_steps(akz_ctx* c, float* d_lt, const float* d_lflow, float* d_lst
     float* in = (float*)c->scratch[3].p;
     AKZ_HIP_TRY(hipMemcpyAsync(in, d_lt, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
     StageTimer st(c, AKZ_ST_FED);  // the launches alone, without the copy above (stand-alone roofline legs of bench.py)
+    st.kernel(AKZ_KR_FED_OWN, n_tau, w, h, n, fed_num_launches(c, n_tau, w, h, n), 0, (uint64_t)w * h * n * n_tau);
     return fed_impl(c, in, d_lt, B, d_lflow, d_lstep, w, h, n, taus, n_tau);
 }
 int akz_op_detector_response(akz_ctx* c, const float* d_lsmooth, uint32_t sigma_size, float* d_lx, float* d_ly,
@@ -1440,6 +1467,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         if (const int fam = detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all)) {
             StageTimer st(c, AKZ_ST_DETECTOR, st_);
+            st.kernel(fam == 5 ? AKZ_KR_DETECTOR_MARCH : AKZ_KR_DETECTOR_TILED, lv.det_sigma, lv.w, lv.h, n, 1, (uint64_t)lv.w * lv.h * n);
             (fam == 5 ? launch::detector_march : launch::detector_tiled_fused)(
                 st_, P(l, AKZ_LSMOOTH), lv.det_sigma, P(l, AKZ_LX), P(l, AKZ_LY), P(l, AKZ_LXX), P(l, AKZ_LYY),
                 P(l, AKZ_LXY), P(l, AKZ_LDET), lv.w, lv.h, n, (uint32_t)l, thr, bm, d_cand, cap, d_count);
@@ -1579,6 +1607,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                 px_steps += (uint64_t)plan[l].w * plan[l].h * n * plan[l].tau.size();
             }
             StageTimer st(c, AKZ_ST_FED);
+            st.kernel(AKZ_KR_OCTAVE_RESIDENT, (uint32_t)rl.size(), plan[i].w, plan[i].h, n, 1, 0, px_steps);
             launch::octave_resident(ls, P(i - 1, AKZ_LT), pv.w, pv.h, n, rl.data(), (uint32_t)rl.size(), g1.data(), r->d_k);
             if (c->profiling) {
                 c->prof.fed_launches += 1;
@@ -1628,6 +1657,8 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             for (uint32_t j = 0; j < n1; ++j) ht[j] = 0.5f * (float)lv.tau[j];
             {
                 StageTimer st(c, AKZ_ST_FED);
+                st.kernel(AKZ_KR_LEVEL_MARCH, n1 | (fold_half ? 16u : 0u) | ((rem == 0 && keep_all) ? 32u : 0u), lv.w, lv.h, n, 1,
+                          (uint64_t)lv.w * lv.h * n, (uint64_t)lv.w * lv.h * n * n1);
                 launch::level_march(ls, level_in, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), d1,
                                     (rem == 0 && keep_all) ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n, g1.data(), r->d_k,
                                     lv.octave, ht, n1, fold_half ? pv.w : 0u, fold_half ? pv.h : 0u);
@@ -1636,9 +1667,12 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                     c->prof.fed_px_steps += (uint64_t)lv.w * lv.h * n * n1;
                     c->prof.fused_px += (uint64_t)lv.w * lv.h * n;
                 }
-                if (rem)
-                    AKZ_TRY(fed_impl(c, d1, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
-                                     lv.tau.data() + n1, rem));
+            }
+            if (rem) {  // (a span of its own: the rows of akz_debug_kernel_rows tell the two kernels apart)
+                StageTimer st(c, AKZ_ST_FED);
+                st.kernel(AKZ_KR_FED_OWN, rem, lv.w, lv.h, n, rest, 0, (uint64_t)lv.w * lv.h * n * rem);
+                AKZ_TRY(fed_impl(c, d1, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
+                                 lv.tau.data() + n1, rem));
             }
             AKZ_HIP_TRY(hipGetLastError());
             continue;
@@ -1664,6 +1698,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         {
             StageTimer st(c, AKZ_ST_FED);
+            st.kernel(AKZ_KR_FED_OWN, n_tau, lv.w, lv.h, n, fed_num_launches(c, n_tau, lv.w, lv.h, n), 0, (uint64_t)lv.w * lv.h * n * n_tau);
             AKZ_TRY(fed_impl(c, fed_in, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
                              lv.tau.data(), n_tau));
         }
@@ -1714,8 +1749,11 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
                 StageTimer st(c, AKZ_ST_DETECTOR, st_);
                 if (c->profiling) {
                     c->prof.det_launches += 1;
-                    for (size_t j = i; j < std::min(kv.second.size(), i + maxn); ++j)
-                        c->prof.det_px += (uint64_t)kv.second[j].w * kv.second[j].h * n;
+                    uint64_t set_px = 0;
+                    for (size_t j = i; j < std::min(kv.second.size(), i + maxn); ++j) set_px += (uint64_t)kv.second[j].w * kv.second[j].h * n;
+                    c->prof.det_px += set_px;
+                    // one launch over several levels of one sigma_size: the row carries the largest level's shape
+                    st.kernel(AKZ_KR_DETECTOR_TILED, kv.first, kv.second[i].w, kv.second[i].h, n, 1, set_px);
                 }
                 launch::detector_tiled_set(st_, kv.first, kv.second.data() + i, (uint32_t)std::min<size_t>(maxn, kv.second.size() - i),
                                            n, (float)cfg.detector_threshold, d_cand, cap, d_count);
@@ -3487,6 +3525,20 @@ int akz_debug_set_host_sort(akz_ctx* c, int on) {
     if (!c) return AKZ_ERR_INVALID_ARG;
     c->dbg_host_sort = on < 0 ? -1 : (on != 0);
     for (akz_ctx* l : c->lanes) l->dbg_host_sort = c->dbg_host_sort;
+    return AKZ_OK;
+}
+int akz_debug_kernel_rows(akz_ctx* c, akz_kernel_row* out, uint32_t cap, uint32_t* n_rows, int reset) {
+    AKZ_TRY(bind(c));
+    if (!n_rows || (cap && !out)) return AKZ_ERR_INVALID_ARG;
+    AKZ_HIP_TRY(hipStreamSynchronize(c->stream));
+    resolve_spans(c);
+    std::lock_guard<std::mutex> lk(c->ev_m);
+    *n_rows = (uint32_t)c->rows.size();
+    for (size_t i = 0; i < c->rows.size() && i < cap; ++i) out[i] = c->rows[i];
+    if (reset) {
+        // spans still in flight keep their row index: the table keeps its rows and only the figures start again
+        for (akz_kernel_row& r : c->rows) r.launches = 0, r.px = 0, r.px_steps = 0, r.ms = 0.0;
+    }
     return AKZ_OK;
 }
 int akz_debug_rcp_f64_to_f32(akz_ctx* c, const double* d_x, float* d_out, uint64_t n) {

@@ -109,6 +109,7 @@ struct akz_gather {
     bool overflow = false;     // this rank's shard did not fit: it sent its header only
     bool finished = false;     // akz_gather_finish has read the headers and the per-image tables
     bool delivered = false;    // external transport: akz_gather_deliver has been called (`done` is recorded)
+    bool timed_out = false;    // akz_gather_finish gave up on it (the communicator is abandoned while any such gather is unresolved)
     std::vector<uint64_t> hdr_rows, hdr_images;      // per rank, from the headers
     std::vector<std::vector<uint64_t>> image_rows;   // per rank: rows of every image of its shard
     std::vector<uint64_t> table;                     // this rank's per-image table, staged for the send block
@@ -123,6 +124,9 @@ struct akz_comm {
     int device = 0, rank = 0, nranks = 1;
     ncclComm_t nccl = nullptr;
     bool external = false;          // akz_comm_create_external: the CALLER moves the blocks between ranks (no RCCL in the process)
+    bool host = false;              // ... with device AKZ_COMM_HOST: the blocks (and the caller's rows) live in HOST memory and no
+                                    // GPU call is made -- the wire format, the overflow protocol and the all-pairs plan under a
+                                    // CPU-only process group (tests/test_distributed.py)
     double timeout_s = 0.0;         // akz_comm_set_timeout: how long akz_gather_finish waits for an exchange (0: without limit)
     bool abandoned = false;         // an exchange timed out: the collective may never complete.  Nothing waits for the
                                     // communicator's streams or events any more (akz_gather_free, akz_comm_destroy return at
@@ -142,6 +146,15 @@ struct akz_comm {
 };
 
 static void gather_release_buffers(akz_gather* g) {
+    if (g->comm && g->comm->host) {
+        std::free(g->send);
+        std::free(g->recv);
+        std::free(g->pinned);
+        g->send = g->recv = nullptr;
+        g->pinned = nullptr;
+        g->cap_rows = ~0ull;
+        return;
+    }
     if (g->send) (void)hipFree(g->send);
     if (g->recv) (void)hipFree(g->recv);
     if (g->pinned) (void)hipHostFree(g->pinned);
@@ -180,10 +193,18 @@ static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
         // the object matches a capacity only once every buffer exists: a failure part-way leaves it free and empty
         g->cap_rows = ~0ull;
         const size_t send_bytes = (size_t)(1 + cap_rows) * kRow, recv_bytes = send_bytes * (size_t)c->nranks;
-        const bool ok = hipMalloc((void**)&g->send, send_bytes) == hipSuccess && hipMalloc((void**)&g->recv, recv_bytes) == hipSuccess &&
-                        hipMemsetAsync(g->send, 0, send_bytes, c->cs) == hipSuccess &&  // no uninitialised bytes on the wire
-                        hipHostMalloc((void**)&g->pinned, (size_t)c->nranks * kRow + kRow, hipHostMallocDefault) == hipSuccess &&
-                        hipEventCreateWithFlags(&g->done, hipEventDisableTiming) == hipSuccess;
+        bool ok;
+        if (c->host) {
+            g->send = (uint8_t*)std::calloc(1, send_bytes);  // no uninitialised bytes on the wire
+            g->recv = (uint8_t*)std::malloc(recv_bytes);
+            g->pinned = (uint64_t*)std::malloc((size_t)c->nranks * kRow + kRow);
+            ok = g->send && g->recv && g->pinned;
+        } else {
+            ok = hipMalloc((void**)&g->send, send_bytes) == hipSuccess && hipMalloc((void**)&g->recv, recv_bytes) == hipSuccess &&
+                 hipMemsetAsync(g->send, 0, send_bytes, c->cs) == hipSuccess &&  // no uninitialised bytes on the wire
+                 hipHostMalloc((void**)&g->pinned, (size_t)c->nranks * kRow + kRow, hipHostMallocDefault) == hipSuccess &&
+                 hipEventCreateWithFlags(&g->done, hipEventDisableTiming) == hipSuccess;
+        }
         if (!ok) {
             (void)hipGetLastError();
             gather_release_buffers(g);
@@ -198,6 +219,7 @@ static int gather_acquire(akz_comm* c, uint64_t cap_rows, akz_gather** out) {
     g->overflow = false;
     g->finished = false;
     g->delivered = false;
+    g->timed_out = false;
     *out = g;
     return AKZ_OK;
 }
@@ -217,6 +239,17 @@ static int gather_enqueue(akz_comm* c, akz_gather* g, const uint8_t* const* d_sr
     // a shard that does not fit still takes part (header only, marked): a rank that skipped the collective would leave
     // every other rank waiting in it, and every later collective of the communicator mismatched
     g->overflow = rows + table_rows > g->cap_rows;
+    if (c->host) {  // the same block, assembled with memcpy: header row, descriptor rows, per-image table
+        uint64_t hdr[8] = {rows, images, g->cap_rows, ++c->sequence, g->overflow ? 1ull : 0ull, g->overflow ? 0ull : table_rows, 0, 0};
+        std::memcpy(g->send, hdr, kRow);
+        uint64_t at = 1;
+        for (uint64_t i = 0; i < n_src && !g->overflow; ++i) {
+            if (src_rows[i]) std::memcpy(g->send + at * kRow, d_src[i], src_rows[i] * kRow);
+            at += src_rows[i];
+        }
+        if (!g->overflow && table_rows) std::memcpy(g->send + at * kRow, g->table.data(), table_rows * kRow);
+        return AKZ_OK;
+    }
     if (g->readers_pending) {  // an all-pairs match of the step before still copies out of these buffers on its own stream
         AKZ_HIP_TRY(hipStreamWaitEvent(c->cs, g->readers, 0));
         g->readers_pending = false;
@@ -314,6 +347,15 @@ int akz_comm_create_external(int device, int rank, int nranks, akz_comm** out) {
         set_error("akz_comm_create_external: bad rank / nranks");
         return AKZ_ERR_INVALID_ARG;
     }
+    if (device == AKZ_COMM_HOST) {  // blocks in host memory: no device, no stream, no event
+        akz_comm* c = new akz_comm;
+        c->device = device;
+        c->rank = rank;
+        c->nranks = nranks;
+        c->external = c->host = true;
+        *out = c;
+        return AKZ_OK;
+    }
     AKZ_HIP_TRY(hipSetDevice(device));
     akz_comm* c = new akz_comm;
     c->device = device;
@@ -352,6 +394,10 @@ int akz_gather_deliver(akz_gather* g, void* stream) {
         return AKZ_ERR_INVALID_ARG;
     }
     akz_comm* c = g->comm;
+    if (c->host) {
+        g->delivered = true;  // (host blocks are complete when the caller says so)
+        return AKZ_OK;
+    }
     AKZ_HIP_TRY(hipSetDevice(c->device));
     AKZ_HIP_TRY(hipEventRecord(g->done, stream ? (hipStream_t)stream : c->xs));  // (NULL: the blocks are complete now)
     g->delivered = true;
@@ -365,6 +411,18 @@ int akz_comm_destroy(akz_comm* c) {
         // destroying the streams, hipFree (synchronises the device), ncclCommDestroy -- is left out: the device objects
         // leak, the host objects go, and the caller can end the process with an error instead of hanging in teardown.
         for (akz_gather* g : c->pool) delete g;
+        c->pool.clear();
+        for (akz_pairs* p : c->pairs_pool) delete_pairs_host_only(p);
+        c->pairs_pool.clear();
+        pairs_orphan_all(c);
+        delete c;
+        return AKZ_OK;
+    }
+    if (c->host) {
+        for (akz_gather* g : c->pool) {
+            gather_release_buffers(g);
+            delete g;
+        }
         c->pool.clear();
         for (akz_pairs* p : c->pairs_pool) delete_pairs_host_only(p);
         c->pairs_pool.clear();
@@ -403,6 +461,7 @@ int akz_comm_place_streams(akz_comm* c, akz_ctx* ctx) {
         set_error("akz_comm_place_streams: null argument");
         return AKZ_ERR_INVALID_ARG;
     }
+    if (c->host) return AKZ_OK;  // (no streams)
     AKZ_HIP_TRY(hipSetDevice(c->device));
     hipStream_t slots[2] = {c->xs, c->cs};
     int shared = 0;
@@ -426,10 +485,36 @@ int akz_gather_begin_rows(akz_comm* c, const uint8_t* d_local, uint64_t n_local,
         return AKZ_ERR_INVALID_ARG;
     }
     *out = nullptr;
-    AKZ_HIP_TRY(hipSetDevice(c->device));
+    if (!c->host) AKZ_HIP_TRY(hipSetDevice(c->device));
     akz_gather* g = nullptr;
     AKZ_TRY(gather_acquire(c, cap_rows, &g));
     const int st = gather_enqueue(c, g, &d_local, &n_local, 1, 1, (hipStream_t)producer_stream, false);
+    if (st != AKZ_OK) {
+        g->in_use = false;
+        return st;
+    }
+    *out = g;
+    return AKZ_OK;
+}
+
+int akz_gather_begin_image_rows(akz_comm* c, const uint8_t* d_local, const uint64_t* rows_per_image, uint64_t n_images,
+                                uint64_t cap_rows, void* producer_stream, akz_gather** out) {
+    if (!c || !out || (n_images && !rows_per_image)) {
+        set_error("akz_gather_begin_image_rows: null argument");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    std::vector<uint64_t> per_image(rows_per_image, rows_per_image + n_images);
+    uint64_t n_local = 0;
+    for (uint64_t v : per_image) n_local += v;
+    if (n_local && !d_local) {
+        set_error("akz_gather_begin_image_rows: rows without a block");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    if (!c->host) AKZ_HIP_TRY(hipSetDevice(c->device));
+    akz_gather* g = nullptr;
+    AKZ_TRY(gather_acquire(c, cap_rows, &g));
+    const int st = gather_enqueue(c, g, &d_local, &n_local, 1, n_images, (hipStream_t)producer_stream, false, &per_image);
     if (st != AKZ_OK) {
         g->in_use = false;
         return st;
@@ -445,6 +530,10 @@ int akz_gather_begin(akz_comm* c, const akz_result* const* results, uint64_t n_r
         return AKZ_ERR_INVALID_ARG;
     }
     *out = nullptr;
+    if (c->host) {
+        set_error("akz_gather_begin: extraction results live on a device; a host-memory communicator takes akz_gather_begin_image_rows");
+        return AKZ_ERR_UNSUPPORTED;
+    }
     AKZ_HIP_TRY(hipSetDevice(c->device));
     std::vector<const uint8_t*> src;
     std::vector<uint64_t> rows, per_image;
@@ -486,6 +575,7 @@ int akz_gather_stream_wait(akz_gather* g, void* stream) {
         set_error("gather: the blocks of this exchange have not been delivered yet (akz_gather_deliver)");
         return AKZ_ERR_INVALID_ARG;
     }
+    if (g->comm->host) return AKZ_OK;  // (delivered host blocks are complete: nothing to wait for)
     AKZ_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, g->done, 0));
     return AKZ_OK;
 }
@@ -496,13 +586,13 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
         return AKZ_ERR_INVALID_ARG;
     }
     akz_comm* c = g->comm;
-    AKZ_HIP_TRY(hipSetDevice(c->device));
+    if (!c->host) AKZ_HIP_TRY(hipSetDevice(c->device));
     if (c->external && !g->delivered) {
         set_error("gather: the blocks of this exchange have not been delivered yet (akz_gather_deliver)");
         return AKZ_ERR_INVALID_ARG;
     }
     // the headers of all blocks -> host (64 bytes per rank): an overflow anywhere is an error everywhere
-    if (c->timeout_s > 0.0 && !g->finished) {  // a peer that never joined leaves the collective waiting for ever: give up with a message
+    if (c->timeout_s > 0.0 && !g->finished && !c->host) {  // a peer that never joined leaves the collective waiting for ever: give up with a message
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             const hipError_t q = hipEventQuery(g->done);
@@ -512,15 +602,28 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
                 set_error("gather: the exchange did not complete within the communicator's timeout (akz_comm_set_timeout): a peer is missing or hung");
                 c->abandoned = true;  // from here on nothing waits for this communicator's streams (akz_gather_free, akz_comm_destroy)
+                g->timed_out = true;
                 return AKZ_ERR_TIMEOUT;
             }
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
-    AKZ_HIP_TRY(hipEventSynchronize(g->done));
+    if (!c->host) AKZ_HIP_TRY(hipEventSynchronize(g->done));
+    if (g->timed_out) {
+        // the caller asked again (a longer limit, or none) and the exchange DID complete -- it was slow, not stuck: the stream
+        // is healthy, the communicator is back in service unless another gather is still overdue
+        g->timed_out = false;
+        bool any = false;
+        for (akz_gather* o : c->pool) any = any || o->timed_out;
+        c->abandoned = any;
+    }
     if (!g->finished) {
-        AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost, c->cs));
-        AKZ_HIP_TRY(hipStreamSynchronize(c->cs));
+        if (c->host) {
+            for (int r = 0; r < c->nranks; ++r) std::memcpy(g->pinned + (size_t)r * 8, g->recv + (size_t)r * g->send_bytes, kRow);
+        } else {
+            AKZ_HIP_TRY(hipMemcpy2DAsync(g->pinned, kRow, g->recv, g->send_bytes, kRow, (size_t)c->nranks, hipMemcpyDeviceToHost, c->cs));
+            AKZ_HIP_TRY(hipStreamSynchronize(c->cs));
+        }
         g->hdr_rows.assign((size_t)c->nranks, 0);
         g->hdr_images.assign((size_t)c->nranks, 0);
         g->image_rows.assign((size_t)c->nranks, {});
@@ -540,7 +643,9 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
                 const uint64_t* h = g->pinned + (size_t)r * 8;
                 std::vector<uint64_t>& t = g->image_rows[(size_t)r];
                 t.assign((size_t)h[5] * 8, 0);
-                if (h[5])
+                if (h[5] && c->host)
+                    std::memcpy(t.data(), g->recv + (size_t)r * g->send_bytes + (1 + h[0]) * kRow, h[5] * kRow);
+                else if (h[5])
                     AKZ_HIP_TRY(hipMemcpy(t.data(), g->recv + (size_t)r * g->send_bytes + (1 + h[0]) * kRow, h[5] * kRow,
                                           hipMemcpyDeviceToHost));
                 t.resize((size_t)std::min<uint64_t>(h[1], t.size()));
@@ -580,7 +685,7 @@ int akz_gather_free(akz_gather* g) {
     if (g->comm->abandoned) {  // its collective may never complete: do not wait, and never hand the buffers out again
         return AKZ_OK;         // (in_use stays set; gather_acquire refuses new work on this communicator anyway)
     }
-    if (g->in_use && g->done && (!g->comm->external || g->delivered)) {
+    if (!g->comm->host && g->in_use && g->done && (!g->comm->external || g->delivered)) {
         (void)hipSetDevice(g->comm->device);
         (void)hipEventSynchronize(g->done);
     }
@@ -675,6 +780,7 @@ struct akz_pairs {
     hipStream_t last_stream = nullptr;   // the matcher's stream of the step that used these buffers last (reuse on another one waits for `done`)
     bool used = false;                   // `done` has been recorded at least once
     bool waited = false;
+    bool plan_only = false;              // akz_pairs_plan: who matches what, nothing matched (no device object behind it)
     std::vector<uint64_t> rows, offset;  // per image: rows, first row in the compacted block
     std::vector<int> owner;
     uint64_t first_owned = 0, n_owned = 0;
@@ -718,6 +824,44 @@ static void pairs_release(akz_pairs* p) {
     if (p->used && p->done) (void)hipEventSynchronize(p->done);  // launches of its last step may still read the block
     pairs_destroy(p);
 }
+// The all-pairs plan of a finished gather, host arithmetic only: the job's images numbered rank-major with their row counts
+// and owners, this rank's images, and for each of those the images it LEADS (pairs_lead) -- the pairs this rank matches.
+static int pairs_plan(akz_comm* c, akz_gather* g, akz_pairs* p, uint64_t* total_rows) {
+    p->rows.clear(); p->offset.clear(); p->owner.clear(); p->lead.clear();
+    p->first_owned = p->n_owned = 0;
+    uint64_t total = 0;
+    for (int r = 0; r < c->nranks; ++r) {
+        if (r == c->rank) p->first_owned = p->rows.size();
+        uint64_t in_rank = 0;
+        for (uint64_t n : g->image_rows[(size_t)r]) {
+            p->offset.push_back(total + in_rank);
+            p->rows.push_back(n);
+            p->owner.push_back(r);
+            in_rank += n;
+        }
+        if (in_rank != g->hdr_rows[(size_t)r]) {
+            set_error("akz_match_all_pairs: a block's per-image table does not add up to its row count");
+            return AKZ_ERR_INVALID_ARG;
+        }
+        if (r == c->rank) p->n_owned = g->image_rows[(size_t)r].size();
+        total += in_rank;
+    }
+    const uint64_t n_images = p->rows.size();
+    p->lead.resize((size_t)p->n_owned);
+    for (uint64_t k = 0; k < p->n_owned; ++k) {
+        akz_pairs::Lead& L = p->lead[(size_t)k];
+        const uint64_t q = p->first_owned + k;
+        uint64_t col_rows = 0;
+        for (uint64_t j = 0; j < n_images; ++j)
+            if (j != q && pairs_lead(q, j) == q) {
+                L.sets.push_back(j);
+                L.col0.push_back(col_rows);
+                col_rows += p->rows[(size_t)j];
+            }
+    }
+    if (total_rows) *total_rows = total;
+    return AKZ_OK;
+}
 static void pairs_orphan_all(akz_comm* c) {
     for (akz_pairs* p : c->live_pairs) p->comm = nullptr;
     c->live_pairs.clear();
@@ -732,6 +876,10 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
         return AKZ_ERR_INVALID_ARG;
     }
     akz_comm* c = g->comm;
+    if (c->host) {
+        set_error("akz_match_all_pairs: the matcher needs the gathered rows on a device; a host-memory communicator offers akz_pairs_plan");
+        return AKZ_ERR_UNSUPPORTED;
+    }
     const uint8_t* blocks = nullptr;
     uint64_t block_rows = 0;
     AKZ_TRY(akz_gather_finish(g, &blocks, &block_rows, nullptr, nullptr));
@@ -754,41 +902,19 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     c->live_pairs.push_back(p);
     p->device = c->device;
     p->waited = false;
-    p->rows.clear(); p->offset.clear(); p->owner.clear(); p->lead.clear();
-    p->first_owned = p->n_owned = 0;
+    p->plan_only = false;
     uint64_t total = 0;
-    for (int r = 0; r < c->nranks; ++r) {
-        if (r == c->rank) p->first_owned = p->rows.size();
-        uint64_t in_rank = 0;
-        for (uint64_t n : g->image_rows[(size_t)r]) {
-            p->offset.push_back(total + in_rank);
-            p->rows.push_back(n);
-            p->owner.push_back(r);
-            in_rank += n;
-        }
-        if (in_rank != g->hdr_rows[(size_t)r]) {
-            set_error("akz_match_all_pairs: a block's per-image table does not add up to its row count");
-            return AKZ_ERR_INVALID_ARG;
-        }
-        if (r == c->rank) p->n_owned = g->image_rows[(size_t)r].size();
-        total += in_rank;
-    }
+    AKZ_TRY(pairs_plan(c, g, p, &total));
     const uint64_t n_images = p->rows.size();
+    (void)n_images;
     // layout of the block: rows | per lead: lists lead -> set, lists set -> lead | counts
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t bytes = up(std::max<uint64_t>(1, total) * kRow), n_cnt = 0;
-    p->lead.resize((size_t)p->n_owned);
     std::vector<size_t> off_rows((size_t)p->n_owned), off_cols((size_t)p->n_owned);
     for (uint64_t k = 0; k < p->n_owned; ++k) {
         akz_pairs::Lead& L = p->lead[(size_t)k];
         const uint64_t q = p->first_owned + k;
-        uint64_t col_rows = 0;
-        for (uint64_t j = 0; j < n_images; ++j)
-            if (j != q && pairs_lead(q, j) == q) {
-                L.sets.push_back(j);
-                L.col0.push_back(col_rows);
-                col_rows += p->rows[(size_t)j];
-            }
+        const uint64_t col_rows = L.sets.empty() ? 0 : L.col0.back() + p->rows[(size_t)L.sets.back()];
         off_rows[(size_t)k] = bytes;
         bytes += up(std::max<uint64_t>(1, L.sets.size() * p->rows[(size_t)q]) * sizeof(akz_match));
         off_cols[(size_t)k] = bytes;
@@ -879,6 +1005,37 @@ int akz_match_all_pairs(akz_ctx* ctx, akz_gather* g, uint64_t distance_threshold
     *out = p;
     return AKZ_OK;
 }
+int akz_pairs_plan(akz_gather* g, akz_pairs** out) {
+    if (!out) return AKZ_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!g || !g->in_use) {
+        set_error("akz_pairs_plan: not a gather in flight");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    akz_comm* c = g->comm;
+    AKZ_TRY(akz_gather_finish(g, nullptr, nullptr, nullptr, nullptr));
+    akz_pairs* p = new akz_pairs;  // (never pooled: it owns nothing on a device)
+    p->comm = nullptr;
+    p->device = c->device;
+    p->plan_only = true;
+    const int st = pairs_plan(c, g, p, nullptr);
+    if (st != AKZ_OK) {
+        delete p;
+        return st;
+    }
+    *out = p;
+    return AKZ_OK;
+}
+int akz_pairs_lead_sets(const akz_pairs* p, uint64_t lead_image, uint64_t* images, uint64_t cap, uint64_t* n) {
+    if (!p || !n || lead_image < p->first_owned || lead_image >= p->first_owned + p->n_owned) {
+        set_error("akz_pairs_lead_sets: an image this rank owns");
+        return AKZ_ERR_INVALID_ARG;
+    }
+    const akz_pairs::Lead& L = p->lead[(size_t)(lead_image - p->first_owned)];
+    *n = L.sets.size();
+    for (size_t i = 0; i < L.sets.size() && i < cap && images; ++i) images[i] = L.sets[i];
+    return AKZ_OK;
+}
 int akz_pairs_info(const akz_pairs* p, uint64_t* n_images, uint64_t* first_owned, uint64_t* n_owned) {
     if (!p) return AKZ_ERR_INVALID_ARG;
     if (n_images) *n_images = p->rows.size();
@@ -913,6 +1070,10 @@ int akz_pairs_matches(const akz_pairs* pc, uint64_t query, uint64_t image, akz_m
         set_error("akz_pairs_matches: this pair was matched by the rank akz_pairs_holder names");
         return AKZ_ERR_INVALID_ARG;
     }
+    if (p->plan_only) {
+        set_error("akz_pairs_matches: a plan (akz_pairs_plan) holds no lists; akz_match_all_pairs does");
+        return AKZ_ERR_INVALID_ARG;
+    }
     const akz_pairs::Lead& L = p->lead[(size_t)(lead - p->first_owned)];
     const uint64_t other = lead == query ? image : query;
     const size_t k = (size_t)(std::lower_bound(L.sets.begin(), L.sets.end(), other) - L.sets.begin());
@@ -934,6 +1095,18 @@ int akz_pairs_matches(const akz_pairs* pc, uint64_t query, uint64_t image, akz_m
 int akz_pairs_totals(const akz_pairs* pc, uint64_t* n_lists, uint64_t* n_matches, uint64_t* n_distances) {
     akz_pairs* p = const_cast<akz_pairs*>(pc);
     if (!p) return AKZ_ERR_INVALID_ARG;
+    if (p->plan_only) {  // what WOULD be matched: lists and distances, no matches yet
+        uint64_t lists = 0, dist = 0;
+        for (uint64_t k = 0; k < p->n_owned; ++k)
+            for (uint64_t j : p->lead[(size_t)k].sets) {
+                lists += 2;
+                dist += p->rows[(size_t)(p->first_owned + k)] * p->rows[(size_t)j];
+            }
+        if (n_lists) *n_lists = lists;
+        if (n_matches) *n_matches = 0;
+        if (n_distances) *n_distances = dist;
+        return AKZ_OK;
+    }
     AKZ_HIP_TRY(hipSetDevice(p->device));
     if (!p->waited) {
         AKZ_HIP_TRY(hipEventSynchronize(p->done));
@@ -956,6 +1129,10 @@ int akz_pairs_totals(const akz_pairs* pc, uint64_t* n_lists, uint64_t* n_matches
 }
 int akz_pairs_free(akz_pairs* p) {
     if (!p) return AKZ_OK;
+    if (p->plan_only) {
+        delete p;
+        return AKZ_OK;
+    }
     (void)hipSetDevice(p->device);
     // the buffers go back to the communicator's pool: the next step's launches are ordered behind this step's on the
     // matcher's stream, and a reader of this object has waited for `done`

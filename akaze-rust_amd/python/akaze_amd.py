@@ -61,6 +61,15 @@ class Config(C.Structure):
 STAGES = ["blur0", "contrast", "prep", "fed", "detector", "nms", "host_kp", "orient", "mldb", "total"]
 
 
+class KernelRow(C.Structure):
+    """akz_kernel_row (akaze_hip_debug.h)"""
+    _fields_ = [("stage", C.c_uint32), ("kind", C.c_uint32), ("param", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32),
+                ("n", C.c_uint32), ("launches", C.c_uint64), ("px", C.c_uint64), ("px_steps", C.c_uint64), ("ms", C.c_double)]
+
+
+KERNEL_ROW_KINDS = {1: "k_level_march", 2: "k_fed_own", 3: "k_octave_resident", 4: "k_detector_tiled", 5: "k_detector_march"}
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 10), ("fed_launches", C.c_uint64), ("fed_px_steps", C.c_uint64),
                 ("calls", C.c_uint64), ("pixels", C.c_uint64), ("det_launches", C.c_uint64), ("det_px", C.c_uint64), ("fused_px", C.c_uint64),
@@ -129,6 +138,7 @@ def lib():
         "akz_op_half_size": ([vp, vp, vp, u32, u32, u32], i32),
         "akz_op_scharr": ([vp, vp, vp, u32, u32, u32, i32, i32, u32], i32),
         "akz_debug_rcp_f64_to_f32": ([vp, vp, vp, u64], i32),
+        "akz_debug_kernel_rows": ([vp, vp, u32, vp, i32], i32),
         "akz_op_pm_g2": ([vp, vp, vp, vp, u32, u32, u32, vp], i32),
         "akz_op_contrast_factor": ([vp, vp, u32, u32, u32, f64, f64, u64, vp], i32),
         "akz_op_flow": ([vp, vp, vp, u32, u32, u32, vp, u32], i32),
@@ -221,6 +231,9 @@ def lib():
         "akz_gather_descriptors": ([vp, vp, u64, C.POINTER(vp), pu64], i32),
         "akz_gather_begin": ([vp, C.POINTER(vp), u64, u64, C.POINTER(vp)], i32),
         "akz_gather_begin_rows": ([vp, vp, u64, u64, vp, C.POINTER(vp)], i32),
+        "akz_gather_begin_image_rows": ([vp, vp, pu64, u64, u64, vp, C.POINTER(vp)], i32),
+        "akz_pairs_plan": ([vp, C.POINTER(vp)], i32),
+        "akz_pairs_lead_sets": ([vp, u64, pu64, u64, pu64], i32),
         "akz_gather_image_rows": ([vp, i32, pu64, u64, pu64], i32),
         "akz_match_all_pairs": ([vp, vp, u64, C.c_double, C.POINTER(vp)], i32),
         "akz_pairs_info": ([vp, pu64, pu64, pu64], i32),
@@ -405,6 +418,24 @@ class Context:
         p = Profile()
         _check(lib().akz_ctx_get_profile2(self._h, C.byref(p), C.sizeof(Profile), int(reset)))
         return p.as_dict()
+
+    def kernel_rows(self, reset=True):
+        """akz_debug_kernel_rows: the FED / detector spans by kernel variant and launch shape (profiling must be on)."""
+        n = C.c_uint32()
+        rows = (KernelRow * 256)()
+        _check(lib().akz_debug_kernel_rows(self._h, C.cast(rows, C.c_void_p), 256, C.cast(C.pointer(n), C.c_void_p), int(reset)))
+        out = []
+        for r in rows[:min(n.value, 256)]:
+            if r.launches == 0:
+                continue
+            name = KERNEL_ROW_KINDS.get(r.kind, str(r.kind))
+            if r.kind == 1:
+                name += f"<{r.param & 15}{', Lstep' if r.param & 32 else ''}{', HALF' if r.param & 16 else ''}>"
+            elif r.kind in (4, 5):
+                name += f"<{r.param}>"
+            out.append(dict(kernel=name, kind=r.kind, param=r.param, w=r.w, h=r.h, n=r.n, launches=int(r.launches), px=int(r.px),
+                            px_steps=int(r.px_steps), ms=float(r.ms)))
+        return out
 
     def set_host_threads(self, threads):
         """akz_ctx_set_host_threads: host threads of the finish half (0 = automatic)."""
@@ -1055,13 +1086,29 @@ class Gather:
         """akz_gather_deliver: every rank's block has been written where blocks() said, in the order of `stream`."""
         _check(lib().akz_gather_deliver(self._h, C.c_void_p(stream) if stream else None))
 
+    def plan_all_pairs(self):
+        """akz_pairs_plan: who matches what (akz_match_all_pairs' holder map and lead sets) without matching -- host arithmetic."""
+        p = C.c_void_p()
+        _check(lib().akz_pairs_plan(self._h, C.byref(p)))
+        return Pairs(None, p)
+
     def exchange_over(self, group=None):
         """External transport over torch.distributed (any backend; gloo in the one-GPU rehearsals): this rank's block D2H,
-        one all-gather of the fixed-size blocks, H2D, deliver.  Synchronous."""
+        one all-gather of the fixed-size blocks, H2D, deliver.  Synchronous.  On a HOST communicator the blocks ARE host
+        memory: the all-gather runs on them in place."""
         import torch
         import torch.distributed as dist
         send, recv, nbytes = self.blocks()
         world = self._comm.nranks
+        if self._comm.host:
+            h_send = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,)))
+            h_recv = torch.from_numpy(np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(world * nbytes,)))
+            if world == 1 and not dist.is_initialized():
+                h_recv.copy_(h_send)
+            else:
+                dist.all_gather_into_tensor(h_recv, h_send, group=group)
+            self.deliver()
+            return
         if world == 1 and not dist.is_initialized():  # a single rank without a process group: its block is the job
             copy_raw(recv, send, nbytes, 3)
             self.deliver()
@@ -1150,6 +1197,14 @@ class Pairs:
         """ordered pairs (query, image) whose lists this rank holds"""
         return [(a, b) for a in range(self.n_images) for b in range(self.n_images) if a != b and self.holder(a, b) == rank]
 
+    def lead_sets(self, lead_image):
+        """akz_pairs_lead_sets: the images this rank matches `lead_image` (one it owns) against"""
+        n = C.c_uint64()
+        _check(lib().akz_pairs_lead_sets(self._h, int(lead_image), None, 0, C.byref(n)))
+        out = (C.c_uint64 * max(1, n.value))()
+        _check(lib().akz_pairs_lead_sets(self._h, int(lead_image), out, n.value, C.byref(n)))
+        return [int(v) for v in out[:n.value]]
+
     def total_matches(self, rank=0):
         return sum(self.count(a, b) for a, b in self.held(rank))
 
@@ -1177,9 +1232,12 @@ class Comm:
     comm_unique_id() from rank 0: RCCL carries the blocks (akz_comm_create); unique_id = None: the caller does
     (akz_comm_create_external; Gather.blocks / Gather.deliver)."""
 
+    HOST = -1  # AKZ_COMM_HOST: an external-transport communicator whose blocks and rows are HOST memory (no GPU call)
+
     def __init__(self, device, unique_id, rank, nranks):
         self._h = C.c_void_p()
         self.external = unique_id is None
+        self.host = self.external and int(device) == Comm.HOST
         if self.external:
             _check(lib().akz_comm_create_external(int(device), int(rank), int(nranks), C.byref(self._h)))
         else:
@@ -1230,6 +1288,20 @@ class Comm:
         n = int(rows.shape[0])
         _check(lib().akz_gather_begin_rows(self._h, C.c_void_p(rows.data_ptr()) if n else None, n, int(cap_rows),
                                            C.c_void_p(producer_stream) if producer_stream else None, C.byref(g)))
+        gg = Gather(self, g)
+        gg._keep = rows
+        return gg
+
+    def gather_begin_image_rows(self, rows, rows_per_image, cap_rows, producer_stream=None):
+        """akz_gather_begin_image_rows: the rows of several images back to back -- a torch CUDA uint8 tensor [n, 64], or, on a
+        HOST communicator, a C-contiguous numpy uint8 array [n, 64]."""
+        g = C.c_void_p()
+        per = (C.c_uint64 * max(1, len(rows_per_image)))(*[int(v) for v in rows_per_image])
+        n = int(rows.shape[0])
+        assert n == sum(int(v) for v in rows_per_image)
+        ptr = (rows.ctypes.data if self.host else rows.data_ptr()) if n else None
+        _check(lib().akz_gather_begin_image_rows(self._h, C.c_void_p(ptr) if n else None, per, len(rows_per_image), int(cap_rows),
+                                                 C.c_void_p(producer_stream) if producer_stream else None, C.byref(g)))
         gg = Gather(self, g)
         gg._keep = rows
         return gg

@@ -670,6 +670,8 @@ def main_rank(args):
     ctx.get_profile(reset=True)
     run_steps(1)
     warm_prof = ctx.get_profile(reset=True)
+    if not stub:
+        ctx.kernel_rows(reset=True)  # (the rows below cover the timed regions only)
     ctx.set_profiling(0 if args.no_profile else 2)
     want_check = not stub and not c5 and ((rank == 0 and not args.no_self_check) or use_dist or F <= 4)
     # The timed region -- exactly args.steps steps between two barriers -- is run args.regions times back to back; the
@@ -687,6 +689,7 @@ def main_rank(args):
         el = time.perf_counter() - t0
         regions.append((host_max(el), el))
     prof = ctx.get_profile(reset=True)  # spans of ALL regions: the rooflines average over args.regions * args.steps steps
+    kernel_rows = [] if stub else ctx.kernel_rows(reset=True)  # the same spans by kernel variant and launch shape
     ctx.set_profiling(False)
     timed_steps = args.steps * args.regions
     host_ms_timed = dict(host_ms)  # the accumulators go on counting in the host-input leg below: the line reports the timed regions
@@ -770,6 +773,55 @@ def main_rank(args):
                     "k_fed_own (<= 8 steps per launch); 12 B per pixel-step ALGORITHMIC plus 12 B per pixel for a "
                     "preparation that runs inside the launch — steps are fused, so frac can exceed 1; traffic_frac is "
                     "the DRAM figure")
+    # ---- the rows behind the two groups: one per kernel NAME (as rocprofv3's kernel stats list them, so that avg_launch_us can
+    # be held against profiles/*_kernel_stats.csv), with the launch shapes it ran on ----
+    def per_kernel_traffic(name):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if d.get("workload") != workload_key:
+                return None
+            e = d.get("per_kernel", {}).get(name)
+            return e.get("hbm_bytes_per_launch") if e else None
+        except Exception:
+            return None
+
+    def kernel_table(kinds):
+        by_name = {}
+        for r in kernel_rows:
+            if r["kind"] not in kinds:
+                continue
+            odd = "true" if (r["w"] & 1) else "false"
+            if r["kind"] == 1:    # k_level_march<N, KEEPSTEP, ODDW, HALF>
+                name = f"k_level_march<{r['param'] & 15}, {'true' if r['param'] & 32 else 'false'}, {odd}, {'true' if r['param'] & 16 else 'false'}>"
+                alg = 12.0 * r["px"] + FED_BYTES_PER_PX_STEP * r["px_steps"]
+            elif r["kind"] == 2:  # the k_fed_own launches of one level (their template arguments depend on the launch size)
+                name, alg = "k_fed_own", FED_BYTES_PER_PX_STEP * r["px_steps"]
+            elif r["kind"] == 3:
+                name, alg = "k_octave_resident<true>", FED_BYTES_PER_PX_STEP * r["px_steps"]
+            elif r["kind"] == 4:  # k_detector_tiled<S, NMS, KEEP>
+                name, alg = f"k_detector_tiled<{r['param']}, true, {'false' if args.lean else 'true'}>", float(det_bpp) * r["px"]
+            else:                 # k_detector_march<S, NMS, KEEP, ODDW>
+                name, alg = f"k_detector_march<{r['param']}, true, {'false' if args.lean else 'true'}, {odd}>", float(det_bpp) * r["px"]
+            e = by_name.setdefault(name, {"kernel": name, "launches": 0, "ms": 0.0, "alg": 0.0, "shapes": []})
+            e["launches"] += r["launches"]
+            e["ms"] += r["ms"]
+            e["alg"] += alg
+            e["shapes"].append({"level": f"{r['n']} x {r['w']}x{r['h']}", "launches": r["launches"],
+                                "avg_launch_us": round(r["ms"] * 1e3 / max(1, r["launches"]), 1)})
+        out_rows = []
+        for e in sorted(by_name.values(), key=lambda e: -e["ms"]):
+            us = e["ms"] * 1e3 / max(1, e["launches"])
+            gbs = e["alg"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] > 0 else 0.0
+            tr = per_kernel_traffic(e["kernel"])
+            out_rows.append({"kernel": e["kernel"], "launches": e["launches"], "launches_per_step": round(e["launches"] / max(1, timed_steps), 2),
+                             "avg_launch_us": round(us, 1), "ms_per_step": round(e["ms"] / max(1, timed_steps), 3),
+                             "algorithmic_bytes_per_launch": round(e["alg"] / max(1, e["launches"])),
+                             "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr,
+                             "traffic_frac": round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if tr and us > 0 else None,
+                             "shapes": e["shapes"]})
+        return out_rows
+    roof_det["kernels"] = kernel_table((4, 5))
+    roof_fed["kernels"] = kernel_table((1, 2, 3))
     # the detector march is the kernel with the largest share of the step when each kernel runs alone (2.2 of 5.7 ms of
     # kernel time); since the fork the two groups' spans overlap in the step, so their sums no longer rank them
     roofline, roofline_2 = roof_det, roof_fed
@@ -814,6 +866,16 @@ def main_rank(args):
                 except Exception:
                     fed_alone[name].update({"traffic": None, "traffic_frac": None})
             del lt, lf
+        # the north star's own point -- the FED inner loop on one 3840x2160 plane -- inside `roofline` (the record the driver
+        # parses): algorithmic_frac counts SURVEY 8(d)'s 12 B per pixel-step, traffic_frac what the launch really moves
+        f4 = fed_alone.get("4k_plane")
+        if f4:
+            roofline["fed_4k"] = {"kernel": "k_fed_own<64, 32, 8, 512>", "plane": "1 x 3840x2160", "steps_per_launch": f4["steps"] // max(1, f4["launches_per_pass"]),
+                                  "avg_launch_us": f4["avg_launch_us"], "us_per_step": round(f4["avg_launch_us"] * f4["launches_per_pass"] / f4["steps"], 2),
+                                  "ideal_unfused_us_per_step": round(FED_BYTES_PER_PX_STEP * 3840 * 2160 / (HBM_PEAK_GBS * 1e9) * 1e6, 2),
+                                  "algorithmic_frac": f4["frac"], "traffic": f4.get("traffic"), "traffic_frac": f4.get("traffic_frac"),
+                                  "bound": "vector issue / LDS latency (8 steps fused per launch on a plane that sits in the Infinity Cache): "
+                                           "algorithmic_frac > 0.40 is the north-star target in SURVEY 8(d)'s terms; traffic_frac is the DRAM figure"}
 
     # ---- the detector kernel alone, on HBM-cold inputs: four plane sets of a 32 x 1080p level in turn (a launch that
     # re-reads the plane it read last time finds most of it in the 256 MB Infinity Cache and looks 25 % faster than any

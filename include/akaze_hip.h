@@ -43,7 +43,8 @@ extern "C" {
    after its communicator; AKZ_ERR_TIMEOUT.  No signature changed.
    6 (round 6): additions -- akz_ctx_get_profile2 (size-checked; akz_ctx_get_profile writes the ABI-4 prefix of akz_profile
    only from now on); akz_op_scharr accepts both and neither order as the reference does; a communicator whose exchange
-   timed out is abandoned (akz_comm_set_timeout).  No signature changed. */
+   timed out is abandoned (akz_comm_set_timeout); AKZ_COMM_HOST communicators, akz_gather_begin_image_rows, akz_pairs_plan,
+   akz_pairs_lead_sets.  No signature changed. */
 #define AKZ_ABI_VERSION 6
 
 typedef enum akz_status {
@@ -350,13 +351,22 @@ int akz_comm_create(int device, const uint8_t* id, int rank, int nranks, akz_com
    and everything behind it (akz_gather_finish, akz_gather_stream_wait, akz_match_all_pairs, ...) as with RCCL.  The wire
    format is the one described below; akz_gather_descriptors (the synchronous two-collective form) is not available. */
 int akz_comm_create_external(int device, int rank, int nranks, akz_comm** out);
+/* device = AKZ_COMM_HOST: the same object with its blocks (and the caller's descriptor rows) in HOST memory -- no GPU call is
+   made by any akz_comm_* / akz_gather_* function on it.  It serves the wire format, the overflow protocol and the all-pairs
+   plan (akz_pairs_plan) to hosts that stage descriptors in host memory and to CPU-only rehearsals of the multi-rank job
+   (tests/test_distributed.py under gloo); rows come in through akz_gather_begin_rows / akz_gather_begin_image_rows as host
+   pointers, akz_gather_blocks returns host pointers, akz_gather_begin and akz_match_all_pairs (device work) are
+   AKZ_ERR_UNSUPPORTED. */
+#define AKZ_COMM_HOST (-1)
 int akz_comm_destroy(akz_comm* comm);
 /* How long akz_gather_finish (and what calls it: akz_gather_descriptors, akz_match_all_pairs) waits for an exchange before
    it gives up with AKZ_ERR_TIMEOUT -- a peer that crashed or never joined leaves a collective waiting for ever, and a host
    that can report that is worth more than one that hangs.  0 (default): wait without limit.  After a timeout the
    communicator is ABANDONED: the stuck collective still sits on its stream, so nothing waits for that stream any more --
    akz_gather_free and akz_comm_destroy return at once and leak the device buffers, streams and the RCCL communicator (freeing
-   them would wait for the collective), new exchanges are refused with AKZ_ERR_TIMEOUT.  The host is expected to report the
+   them would wait for the collective), new exchanges are refused with AKZ_ERR_TIMEOUT.  (An exchange that was only slow: a
+   later akz_gather_finish of the same gather -- after a longer akz_comm_set_timeout, or 0 -- that sees it complete puts the
+   communicator back in service.)  The host is expected to report the
    error and end the process with a non-zero status WITHOUT running the GPU runtime's exit handlers (`_exit` / `os._exit`:
    they, too, may wait for the stuck stream). */
 int akz_comm_set_timeout(akz_comm* comm, double seconds);
@@ -403,6 +413,11 @@ int akz_gather_finish(akz_gather* g, const uint8_t** d_all, uint64_t* block_rows
 int akz_gather_image_rows(akz_gather* g, int rank, uint64_t* rows_per_image, uint64_t cap, uint64_t* n_images);
 /* hand the blocks back to the communicator (waits for the collective if it is still running) */
 int akz_gather_free(akz_gather* g);
+/* akz_gather_begin_rows for the rows of SEVERAL images held by the caller (device memory, or host memory on an
+   AKZ_COMM_HOST communicator): n_images images back to back, rows_per_image[i] rows each; the per-image table travels
+   behind the rows exactly as with akz_gather_begin. */
+int akz_gather_begin_image_rows(akz_comm* comm, const uint8_t* d_local, const uint64_t* rows_per_image, uint64_t n_images,
+                                uint64_t cap_rows, void* producer_stream, akz_gather** out);
 
 /* BASELINE configs[4] — the cross-GPU all-pairs match for hosts that are not Python: after an
    exchange every rank holds the descriptor rows of every image of the job (numbered rank-major).  Every UNORDERED image
@@ -415,6 +430,13 @@ int akz_gather_free(akz_gather* g);
    not; the gather may be freed afterwards (a later exchange that reuses its buffers is ordered behind this call's copies). */
 typedef struct akz_pairs akz_pairs;
 int akz_match_all_pairs(akz_ctx* ctx, akz_gather* gather, uint64_t distance_threshold, double lowes_ratio, akz_pairs** out);
+/* The PLAN of akz_match_all_pairs without the match: finishes the gather and returns an akz_pairs that answers
+   akz_pairs_info / _image_rows / _holder / _lead_sets / _totals (lists and distances this rank would compute; no matches) --
+   host arithmetic only, also on an AKZ_COMM_HOST communicator.  akz_pairs_matches on it is an error. */
+int akz_pairs_plan(akz_gather* gather, akz_pairs** out);
+/* the images that `lead_image` (one this rank owns) is matched against by this rank, ascending: with akz_pairs_holder
+   these say who computes every unordered pair of the job */
+int akz_pairs_lead_sets(const akz_pairs* p, uint64_t lead_image, uint64_t* images, uint64_t cap, uint64_t* n);
 /* *n_images: images of the whole job; this rank's are first_owned .. first_owned + n_owned - 1 */
 int akz_pairs_info(const akz_pairs* p, uint64_t* n_images, uint64_t* first_owned, uint64_t* n_owned);
 int akz_pairs_image_rows(const akz_pairs* p, uint64_t image, uint64_t* rows, int* owner_rank);

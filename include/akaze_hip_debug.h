@@ -45,6 +45,20 @@ int akz_debug_stream_placement(akz_ctx* ctx, int* info);
    end; tiny_pair_ms: 24 + 24 interleaved tiny kernels on the two streams (negative: not measured); tiny_alone_ms: 24 of
    them on one stream. */
 int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float tiny_alone_ms, float spin_ms);
+/* Measurement hook: the HIP-event spans of the diffusion and detector stages (akz_ctx_set_profiling) broken down by kernel
+   variant and launch shape -- the rows behind bench.py's roofline.kernel, which names a group of kernels.  kind: see below;
+   param: fused FED steps of a k_level_march launch (+16: the octave's 2x2 mean folded in, +32: Lstep written), FED steps
+   covered by a group of k_fed_own launches, levels inside a k_octave_resident launch, sigma_size of a detector launch;
+   (w, h, n): the launch's level size and batch (the largest level of a k_detector_tiled launch over several levels);
+   launches, px = level pixels x batch, px_steps = pixel-steps advanced, ms = sum of the spans.  Rows accumulate like
+   akz_profile; reset != 0 zeroes the figures.  *n_rows = rows there are (may exceed cap). */
+enum { AKZ_KR_LEVEL_MARCH = 1, AKZ_KR_FED_OWN = 2, AKZ_KR_OCTAVE_RESIDENT = 3, AKZ_KR_DETECTOR_TILED = 4, AKZ_KR_DETECTOR_MARCH = 5 };
+typedef struct akz_kernel_row {
+    uint32_t stage, kind, param, w, h, n;
+    uint64_t launches, px, px_steps;
+    double ms;
+} akz_kernel_row;
+int akz_debug_kernel_rows(akz_ctx* ctx, akz_kernel_row* out, uint32_t cap, uint32_t* n_rows, int reset);
 /* Test hook: pm_g2's reciprocal on its own -- d_out[i] = (1.0 / d_x[i]) as f32 the way every level kernel forms it
    (csrc/akz_pm_g2.hpp: refined hardware reciprocal, the full f64 division only where the f32 rounding could depend on it). */
 int akz_debug_rcp_f64_to_f32(akz_ctx* ctx, const double* d_x, float* d_out, uint64_t n);

@@ -1,8 +1,9 @@
-"""world_size-2 tests of the multi-GPU logic on CPU (gloo): per-image sharding and the descriptor-row
-all-gather that precedes a cross-image match, as the Python helpers `akaze_amd.gather_descriptor_rows` / `all_pairs_match`
-(torch.distributed) do them.  The PRODUCT's exchange is `akz_comm.cpp` behind the C ABI (its own RCCL communicator, or a
-caller-carried transport): that one needs a device and is driven by tests/test_gpu_gather.py -- two and three real ranks on
-one GPU with the C ABI's blocks over gloo -- and by tests/test_comm_faults.py against a stub librccl."""
+"""world_size-2 tests of the multi-GPU logic on CPU (gloo).  (a) The PRODUCT's exchange -- `akz_comm.cpp` behind the C ABI --
+on a host-memory communicator (AKZ_COMM_HOST): its wire format (header row, descriptor rows, per-image table), the overflow
+protocol, the capacity check and the all-pairs plan (akz_pairs_plan: lead rule, holder map) with the blocks carried by
+gloo, no GPU anywhere.  (b) per-image sharding and the Python helpers `akaze_amd.gather_descriptor_rows` /
+`all_pairs_match` (torch.distributed).  With a device the same C-ABI objects are driven by tests/test_gpu_gather.py -- two and
+three real ranks on one GPU -- and by tests/test_comm_faults.py against a stub librccl."""
 import os
 import socket
 import sys
@@ -55,6 +56,123 @@ def _worker(rank, world, port, counts, out_dir):
         np.save(os.path.join(out_dir, f"owned_{rank}.npy"), np.array(owned))
     finally:
         dist.destroy_process_group()
+
+
+def _capi_worker(rank, world, port, sizes, out_dir):
+    """One rank of the product's exchange on host memory: blocks by akz_gather_blocks, carried by gloo."""
+    sys.path.insert(0, os.path.join(ROOT, "akaze-rust_amd", "python"))
+    import ctypes as C
+    import pickle
+    import torch.distributed as dist
+    import akaze_amd as A
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = None
+    try:
+        rng = np.random.default_rng(50 + rank)
+        per = list(sizes[rank])
+        local = rng.integers(0, 256, (sum(per), 64), dtype=np.uint8)
+        comm = A.Comm(A.Comm.HOST, None, rank, world)
+        most = max(sum(s) for s in sizes)
+        cap = most + 4  # rows + the per-image table's rows
+        log = {}
+        # ---- an exchange that fits: headers, rows, per-image tables of every rank ----
+        g = comm.gather_begin_image_rows(local, per, cap)
+        with pytest.raises(A.AkazeError):  # not delivered yet
+            g.finish()
+        g.exchange_over()
+        blocks, block_rows, counts, images = g.finish()
+        assert block_rows == cap + 1 and counts == [sum(s) for s in sizes] and images == [len(s) for s in sizes]
+        raw = np.ctypeslib.as_array(C.cast(blocks, C.POINTER(C.c_uint8)), shape=(world, block_rows, 64)).copy()
+        log["raw"] = raw
+        for r in range(world):
+            assert g.image_rows(r) == list(sizes[r])
+            hdr = raw[r, 0].view(np.uint64)
+            table_rows = (len(sizes[r]) + 7) // 8
+            assert list(hdr[:6]) == [sum(sizes[r]), len(sizes[r]), cap, 1, 0, table_rows]  # rows, images, capacity, sequence, overflow, table rows
+            tab = raw[r, 1 + sum(sizes[r]):1 + sum(sizes[r]) + table_rows].view(np.uint64).ravel()
+            assert list(tab[:len(sizes[r])]) == list(sizes[r]) and not tab[len(sizes[r]):].any()
+        assert np.array_equal(raw[rank, 1:1 + len(local)], local)
+        # ---- the all-pairs plan over this gather: who matches what ----
+        plan = g.plan_all_pairs()
+        n_img = sum(len(s) for s in sizes)
+        assert plan.n_images == n_img and plan.first_owned == sum(len(s) for s in sizes[:rank]) and plan.n_owned == len(per)
+        flat = [n for s in sizes for n in s]
+        owners = [r for r in range(world) for _ in sizes[r]]
+        assert [plan.image_rows(j) for j in range(n_img)] == list(zip(flat, owners))
+        mine = {}
+        for k in range(plan.n_owned):
+            q = plan.first_owned + k
+            mine[q] = plan.lead_sets(q)
+            assert all(A.pairs_lead(q, j) == q and plan.holder(q, j) == rank for j in mine[q])
+        lists, matches, dists = plan.totals()
+        assert lists == 2 * sum(len(v) for v in mine.values()) and matches == 0
+        assert dists == sum(flat[q] * flat[j] for q, v in mine.items() for j in v)
+        if n_img >= 2:  # a plan holds no lists (and a pair another rank leads is not this rank's to read either way)
+            with pytest.raises(A.AkazeError):
+                plan.matches(0, 1)
+        log["mine"] = mine
+        log["holder"] = {(a, b): plan.holder(a, b) for a in range(n_img) for b in range(n_img) if a != b}
+        plan.free()
+        g.free()
+        # ---- a shard that does not fit the agreed capacity: the rank still takes part (header only), EVERY rank gets
+        # AKZ_ERR_BUFFER with the counts, and the communicator stays usable ----
+        small = most - 1
+        g2 = comm.gather_begin_image_rows(local, per, small)
+        g2.exchange_over()
+        with pytest.raises(A.AkazeError) as e:
+            g2.finish()
+        assert e.value.status == -7
+        g2.free()
+        # ---- raw rows (one image, no table) ----
+        g4 = comm.gather_begin_image_rows(local, [len(local)], cap)
+        g4.exchange_over()
+        _, _, counts4, images4 = g4.finish()
+        assert counts4 == [sum(s) for s in sizes] and images4 == [1] * world
+        g4.free()
+        # device-only calls are refused, not attempted
+        with pytest.raises(A.AkazeError) as e:
+            comm.gather_begin([], cap)
+        assert e.value.status == -6
+        with open(os.path.join(out_dir, f"capi_{rank}.pkl"), "wb") as f:
+            pickle.dump(log, f)
+    finally:
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [((5, 9, 2), (4,)), ((0, 7), (3, 0, 6, 1, 1, 2, 5, 4, 3)), ((), (8, 2))])
+def test_product_wire_format_and_all_pairs_plan_gloo(tmp_path, sizes):
+    """akz_comm.cpp's exchange with two CPU ranks: the blocks every rank ends up with are identical, carry the documented
+    header / rows / table, and the all-pairs plans of the ranks cover every unordered image pair exactly once."""
+    _run_capi(tmp_path, sizes)
+
+
+def _run_capi(tmp_path, sizes):
+    import pickle
+    import torch.multiprocessing as mp
+    world = len(sizes)
+    mp.spawn(_capi_worker, args=(world, _free_port(), sizes, str(tmp_path)), nprocs=world, join=True)
+    logs = [pickle.load(open(tmp_path / f"capi_{r}.pkl", "rb")) for r in range(world)]
+    for lg in logs[1:]:
+        assert np.array_equal(logs[0]["raw"], lg["raw"])       # the same gathered blocks on every rank
+        assert logs[0]["holder"] == lg["holder"]               # every rank names the same holder for every pair
+    n_img = sum(len(s) for s in sizes)
+    covered = [frozenset((q, j)) for lg in logs for q, v in lg["mine"].items() for j in v]
+    assert len(covered) == len(set(covered)) == n_img * (n_img - 1) // 2   # every unordered pair, exactly once
+    return logs
+
+
+def test_product_exchange_with_the_eight_ranks_of_a_node_gloo(tmp_path):
+    """BASELINE configs[4]'s job shape -- eight ranks, two 4K frames each -- through akz_comm.cpp's exchange and all-pairs plan on
+    the CPU: eight processes, one rendezvous, one fixed-size all-gather per exchange; all 120 unordered pairs of the 16
+    images assigned exactly once, 14-16 per rank (the lead rule balances without a further exchange)."""
+    sizes = tuple((11 + r, 7 + 2 * r) for r in range(8))
+    logs = _run_capi(tmp_path, sizes)
+    per_rank = [sum(len(v) for v in lg["mine"].values()) for lg in logs]
+    assert sum(per_rank) == 120 and min(per_rank) >= 14 and max(per_rank) <= 16, per_rank
 
 
 @pytest.mark.parametrize("counts", [(5, 9), (0, 4), (7, 0)])
@@ -182,6 +300,16 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     assert out["n_gpus"] == 2 and out["stub"] is True and out["steps"] == 3
     assert len(out["config"]["per_rank_ms_per_step"]) == 2
     assert out["config"]["exchange_ms_per_step"] > 0
+
+
+def test_bench_launcher_with_the_eight_ranks_of_a_node():
+    """`bench.py --gpus 8` as the driver starts it on an 8-GPU node, rehearsed without GPUs (stub contexts): eight rank
+    processes, an eight-way gloo rendezvous, every rank's figure on the line."""
+    import json
+    p = _bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--frames", "2", "--stub", timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["stub"] is True and len(out["config"]["per_rank_ms_per_step"]) == 8
 
 
 def test_bench_refuses_world_size_mismatch():

@@ -350,6 +350,39 @@ def test_bench_two_real_ranks_share_one_gpu():
     assert one["host_input"]["value"] > 0 and two["config"]["placement"] is not None
 
 
+def test_bench_five_real_ranks_share_one_gpu():
+    """As far towards the 8-rank node as one box goes.  The box allows six processes on its GPU and this test process is one
+    of them, so FIVE rank processes: five placement probes, five finisher threads and RANSAC pools on one host, a five-way
+    rendezvous, the exchange with an odd world size -- for the default workload (with its configs[4] leg) and for
+    `--workload c5`.  Every rank must take part in the exchange, every ordered image pair must be held by exactly one
+    rank, every frame must equal what a single rank computes, and no rank may fall far behind the others."""
+    world = 5
+    run = _bench_json(["--gpus", str(world), "--share-gpu", "--frames", "2", "--c5-leg-frames", "1"], timeout=1500)
+    cfg = run["config"]
+    assert run["n_gpus"] == world and cfg["exchange_ranks_seen"] == world
+    per = cfg["per_rank_Mpix_s"]
+    assert len(per) == world and all(v > 0 for v in per)
+    med = sorted(per)[world // 2]
+    assert min(per) * 1.3 >= med, per   # (per-rank throughput: the slowest rank within 1.3 x of the median)
+    leg = cfg["all_pairs_c5_leg"]
+    assert "error" not in leg, leg
+    assert leg["images_per_step"] == world and leg["unordered_image_pairs_per_step"] == world * (world - 1) // 2
+    assert sum(leg["match_lists_held_per_rank"]) == world * (world - 1) and min(leg["match_lists_held_per_rank"]) > 0
+    assert run["self_check"]["identical_to_single_frame_extraction"] is True
+    one = _bench_json(["--gpus", "1", "--frames", "4"])   # (a single rank lists its first four frames: global frames 0 .. 3)
+    sha, sha1 = cfg["frame_sha256_16"], one["config"]["frame_sha256_16"]
+    assert sorted(sha, key=int) == [str(i) for i in range(2 * world)] and sorted(sha1) == ["0", "1", "2", "3"]
+    assert all(sha[k] == v for k, v in sha1.items()), (sha, sha1)
+    c5 = _bench_json(["--gpus", str(world), "--share-gpu", "--workload", "c5", "--frames", "2", "--width", "1280", "--height", "720"], timeout=1500)
+    ap = c5["config"]["all_pairs"]
+    n_img = 2 * world
+    assert c5["config"]["exchange_ranks_seen"] == world and ap["images_per_step"] == n_img
+    assert ap["unordered_image_pairs_per_step"] == n_img * (n_img - 1) // 2
+    held = ap["match_lists_held_per_rank"]
+    assert sum(held) == n_img * (n_img - 1) and min(held) > 0 and max(held) <= 2 * min(held), held
+    assert ap["pairs_check"]["both_directions_equal_descriptor_match"] is True
+
+
 def test_bench_host_share_of_an_8_rank_node():
     """One rank with 1/8 of the host cores as its thread budget: same results, and the line carries the share it ran with."""
     full = _bench_json(["--frames", "4", "--no-host-input"])

@@ -21,6 +21,25 @@ def twin(amd):
     assert os.path.exists(TWIN_PATH), "tests/shim_twin/libshim_twin.so is built by __graft_entry__.build()"
     L = C.CDLL(TWIN_PATH)
     L.twin_last_error.restype = C.c_char_p
+    vp, u64, u32, i32, f32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_double
+    # (arguments past the sixth travel on the stack, where an undeclared Python int fills only half of a 64-bit slot)
+    for name, args in {
+        "twin_allocate_evolutions": [u32, u32, vp, u64, vp, vp, vp, vp, vp, u64],
+        "twin_contrast_factor": [vp, u32, u32, f64, f64, u64, vp],
+        "twin_fed_tau": [f64, i32, f64, i32, vp, u64, vp],
+        "twin_descriptor_match": [vp, u64, vp, u64, u64, u64, f64, vp, vp],
+        "twin_remove_outliers": [vp, u64, vp, u64, vp, u64, u64, f32, f32, vp, vp],
+        "twin_estimate_fundamental_matrix": [vp, u64, vp, u64, vp, f32, vp, vp],
+        "twin_match_features": [vp, u64, vp, u64, vp, u64, vp, u64, u64, f64, u64, f32, vp, vp],
+        "twin_draw_keypoints": [vp, u32, u32, vp, u64, vp],
+        "twin_draw_matches": [vp, u32, u32, vp, u32, u32, vp, u64, vp, u64, vp, u64, vp, u64, vp, vp],
+        "twin_features_level": [vp, u64, vp, vp, vp, vp, vp],
+        "twin_features_plane": [vp, u64, i32, vp, vp],
+        "twin_detect_keypoints": [vp, vp, vp, u64, vp],
+        "twin_extract_descriptors": [vp, vp, vp, u64, vp],
+        "twin_features_free": [vp],
+    }.items():
+        getattr(L, name).argtypes = args
     return L
 
 
@@ -30,6 +49,11 @@ def ok(L, status):
 
 def fp(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def ref_of(obj):
+    """a ctypes object's address as c_void_p (what declared c_void_p parameters accept)"""
+    return C.cast(C.pointer(obj), C.c_void_p)
 
 
 def rand_img(h, w, seed, lo=0.0, hi=1.0):
@@ -61,7 +85,7 @@ def test_image_functions(twin, ref, shape):
         same(o, ref.scharr(img, bool(xo), bool(yo), s))
     k = C.c_double()
     pos = rand_img(h, w, 3)
-    ok(twin, twin.twin_contrast_factor(fp(pos), w, h, C.c_double(0.7), C.c_double(1.0), 300, C.byref(k)))
+    ok(twin, twin.twin_contrast_factor(fp(pos), w, h, C.c_double(0.7), C.c_double(1.0), 300, ref_of(k)))
     assert k.value == ref.contrast_factor(pos, 0.7, 1.0, 300)
 
 
@@ -100,7 +124,7 @@ def test_allocate_evolutions_and_fed_tau(twin, amd, ref):
         cfg = amd.Config(**kw)
         n = C.c_uint64()
         times = np.zeros((64, 2)); ints = np.zeros((64, 3), np.uint32); n_tau = np.zeros(64, np.uint64); tau = np.zeros(4096)
-        ok(twin, twin.twin_allocate_evolutions(w, h, C.byref(cfg), 64, C.byref(n), fp(times), fp(ints), fp(n_tau), fp(tau), 4096))
+        ok(twin, twin.twin_allocate_evolutions(w, h, ref_of(cfg), 64, ref_of(n), fp(times), fp(ints), fp(n_tau), fp(tau), 4096))
         plan = amd.plan_levels(w, h, cfg)
         assert n.value == len(plan)
         at = 0
@@ -110,11 +134,11 @@ def test_allocate_evolutions_and_fed_tau(twin, amd, ref):
             assert tau[at:at + int(n_tau[i])].tobytes() == np.asarray(lv["tau"], np.float64).tobytes()
             at += int(n_tau[i])
     out = np.zeros(64); n = C.c_uint64()
-    ok(twin, twin.twin_fed_tau(C.c_double(5.9984531212995087), 1, C.c_double(0.25), 1, fp(out), 64, C.byref(n)))
+    ok(twin, twin.twin_fed_tau(C.c_double(5.9984531212995087), 1, C.c_double(0.25), 1, fp(out), 64, ref_of(n)))
     want = ref.fed_tau(5.9984531212995087)
     assert n.value == len(want) == 8 and out[:8].tobytes() == np.asarray(want).tobytes()
     # where the reference never terminates the shim panics: status -1 with the library's message
-    assert twin.twin_fed_tau(C.c_double(0.1), 1, C.c_double(0.25), 1, fp(out), 64, C.byref(n)) == -1
+    assert twin.twin_fed_tau(C.c_double(0.1), 1, C.c_double(0.25), 1, fp(out), 64, ref_of(n)) == -1
     assert b"akaze_hip status" in twin.twin_last_error()
 
 
@@ -129,7 +153,7 @@ def test_calculate_step_and_eval(twin, ref):
     # nonlinear_diffusion.rs:149-173 with the offsets of the interior case (:63-67, xpos)
     px = np.array([0, 1, 1, 0], np.int32); py = np.zeros(4, np.int32)
     v = C.c_float()
-    ok(twin, twin.twin_eval(fp(lflow), fp(lt), w, h, 10, 20, fp(px), fp(py), C.byref(v)))
+    ok(twin, twin.twin_eval(fp(lflow), fp(lt), w, h, 10, 20, fp(px), fp(py), ref_of(v)))
     assert np.float32(v.value) == (lflow[20, 10] + lflow[20, 11]) * (lt[20, 11] - lt[20, 10])
 
 
@@ -138,14 +162,14 @@ def features(twin, amd):
     frame = amd.synth_frame(640, 480, 1)
     cfg = amd.Config()
     h = C.c_void_p()
-    ok(twin, twin.twin_extract_features(fp(frame), 640, 480, C.byref(cfg), C.byref(h)))
+    ok(twin, twin.twin_extract_features(fp(frame), 640, 480, ref_of(cfg), ref_of(h)))
     yield frame, cfg, h
     twin.twin_features_free(h)
 
 
 def _kp(twin, amd, h):
     nl, nk, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
-    twin.twin_features_counts(h, C.byref(nl), C.byref(nk), C.byref(nb))
+    twin.twin_features_counts(h, ref_of(nl), ref_of(nk), ref_of(nb))
     kp = np.zeros(nk.value, amd.KEYPOINT_DTYPE)
     ok(twin, twin.twin_features_keypoints(h, fp(kp)))
     d = np.zeros((nk.value, nb.value), np.uint8)
@@ -164,19 +188,19 @@ def test_extract_features_returns_what_the_reference_returns(twin, amd, ref, fea
     assert np.array_equal(d, rf.descriptors())
     for lvl in range(nl):
         times = np.zeros(2); ints = np.zeros(3, np.uint32); wh = np.zeros(2, np.uint32); nt = C.c_uint64(); tau = np.zeros(8192)
-        twin.twin_features_level(h, lvl, fp(times), fp(ints), fp(wh), C.byref(nt), fp(tau))
+        twin.twin_features_level(h, lvl, fp(times), fp(ints), fp(wh), ref_of(nt), fp(tau))
         info = rf.level_info(lvl)
         assert (times[0], times[1], *ints, *wh) == (info["etime"], info["esigma"], info["octave"], info["sublevel"],
                                                      info["sigma_size"], info["w"], info["h"])
         assert tau[:nt.value].tobytes() == info["tau"].tobytes()
         for pi, name in enumerate(PLANES):
             n_px = C.c_uint64()
-            twin.twin_features_plane(h, lvl, pi, None, C.byref(n_px))
+            twin.twin_features_plane(h, lvl, pi, None, ref_of(n_px))
             want = rf.plane(lvl, name)
             assert n_px.value == want.size, (lvl, name)  # level 0: Lflow, Lstep are 0 x 0
             if want.size:
                 got = np.empty(want.shape, np.float32)
-                twin.twin_features_plane(h, lvl, pi, fp(got), C.byref(n_px))
+                twin.twin_features_plane(h, lvl, pi, fp(got), ref_of(n_px))
                 same(got, want)
 
 
@@ -187,21 +211,21 @@ def test_ops_on_the_callers_evolutions(twin, amd, ref, features):
     frame, cfg, h = features
     rf = ref.extract(frame)
     _, kp, d = _kp(twin, amd, h)
-    ok(twin, twin.twin_detector_response(h, C.byref(cfg)))  # recomputed from Lsmooth, must reproduce the planes
+    ok(twin, twin.twin_detector_response(h, ref_of(cfg)))  # recomputed from Lsmooth, must reproduce the planes
     for lvl in (0, 5, rf.num_levels - 1):
         for pi in (2, 3, 4, 5, 6, 9):
             want = rf.plane(lvl, PLANES[pi])
             got = np.empty(want.shape, np.float32); n_px = C.c_uint64()
-            twin.twin_features_plane(h, lvl, pi, fp(got), C.byref(n_px))
+            twin.twin_features_plane(h, lvl, pi, fp(got), ref_of(n_px))
             same(got, want)
     out = np.zeros(len(kp) + 16, amd.KEYPOINT_DTYPE); n = C.c_uint64()
-    ok(twin, twin.twin_detect_keypoints(h, C.byref(cfg), fp(out), len(out), C.byref(n)))
+    ok(twin, twin.twin_detect_keypoints(h, ref_of(cfg), fp(out), len(out), ref_of(n)))
     assert n.value == len(kp) and out[:len(kp)].tobytes() == kp.tobytes()
     sub = np.ascontiguousarray(kp[::3])
     dd = np.zeros((len(sub), 61), np.uint8)
-    ok(twin, twin.twin_extract_descriptors(h, C.byref(cfg), fp(sub), len(sub), fp(dd)))
+    ok(twin, twin.twin_extract_descriptors(h, ref_of(cfg), fp(sub), len(sub), fp(dd)))
     assert np.array_equal(dd, d[::3])
-    assert twin.twin_extract_descriptors(h, C.byref(cfg), fp(sub), 0, fp(dd)) == 0  # descriptors.rs: no keypoints, no work
+    assert twin.twin_extract_descriptors(h, ref_of(cfg), fp(sub), 0, fp(dd)) == 0  # descriptors.rs: no keypoints, no work
 
 
 def test_matching_functions(twin, amd, ref):
@@ -211,26 +235,26 @@ def test_matching_functions(twin, amd, ref):
     k0, k1 = r0.keypoints().astype(amd.KEYPOINT_DTYPE), r1.keypoints().astype(amd.KEYPOINT_DTYPE)
     want = ref.descriptor_match(d0, d1, 10000, 0.86)
     out = np.zeros(len(d0), amd.MATCH_DTYPE); n = C.c_uint64()
-    ok(twin, twin.twin_descriptor_match(fp(d0), len(d0), fp(d1), len(d1), 61, 10000, C.c_double(0.86), fp(out), C.byref(n)))
+    ok(twin, twin.twin_descriptor_match(fp(d0), len(d0), fp(d1), len(d1), 61, 10000, C.c_double(0.86), fp(out), ref_of(n)))
     assert n.value == len(want) > 50 and out[:n.value].tobytes() == np.ascontiguousarray(want).tobytes()
     # empty sides (the reference returns an empty Vec)
-    ok(twin, twin.twin_descriptor_match(fp(d0), 0, fp(d1), len(d1), 61, 10000, C.c_double(0.86), fp(out), C.byref(n)))
+    ok(twin, twin.twin_descriptor_match(fp(d0), 0, fp(d1), len(d1), 61, 10000, C.c_double(0.86), fp(out), ref_of(n)))
     assert n.value == 0
     # RANSAC from the pinned random stream: the same stream in the oracle
     ref.random_seed(42, 69); amd.random_seed(42, 69)
     want_in = ref.remove_outliers(r0.keypoints(), r1.keypoints(), want, 200, 0.05, 3.0)
     got = np.zeros(len(want), amd.MATCH_DTYPE)
     ok(twin, twin.twin_remove_outliers(fp(k0), len(k0), fp(k1), len(k1), fp(np.ascontiguousarray(want)), len(want), 200,
-                                       C.c_float(0.05), C.c_float(3.0), fp(got), C.byref(n)))
+                                       C.c_float(0.05), C.c_float(3.0), fp(got), ref_of(n)))
     assert n.value == len(want_in) and got[:n.value].tobytes() == np.ascontiguousarray(want_in).tobytes()
     ref.random_seed(42, 69); amd.random_seed(42, 69)
     want_in = ref.remove_outliers(r0.keypoints(), r1.keypoints(), want, 200, 0.05, 3.0)
     ok(twin, twin.twin_match_features(fp(k0), len(k0), fp(d0), len(d0), fp(k1), len(k1), fp(d1), len(d1), 61, C.c_double(0.86), 200,
-                                      C.c_float(3.0), fp(got), C.byref(n)))
+                                      C.c_float(3.0), fp(got), ref_of(n)))
     assert n.value == len(want_in) and got[:n.value].tobytes() == np.ascontiguousarray(want_in).tobytes()
     f9 = np.zeros(9, np.float32); found = C.c_int()
     m8 = np.ascontiguousarray(want[:8])
-    ok(twin, twin.twin_estimate_fundamental_matrix(fp(k0), len(k0), fp(k1), len(k1), fp(m8), C.c_float(0.05), fp(f9), C.byref(found)))
+    ok(twin, twin.twin_estimate_fundamental_matrix(fp(k0), len(k0), fp(k1), len(k1), fp(m8), C.c_float(0.05), fp(f9), ref_of(found)))
     F = amd.estimate_fundamental_matrix(k0, k1, m8, 0.05)
     assert (found.value != 0) == (F is not None) and (F is None or np.array_equal(np.asarray(F, np.float32).ravel(), f9))
 
@@ -255,12 +279,16 @@ def test_drawing_functions(twin, amd):
     got = np.empty(want.size, np.uint8); ow, oh = C.c_uint32(), C.c_uint32()
     second = np.ascontiguousarray(rgb[:, :100])
     ok(twin, twin.twin_draw_matches(fp(rgb), 120, 90, fp(second), 100, 90, fp(kp), len(kp), fp(kp), len(kp), fp(m), len(m), fp(got),
-                                    got.size, C.byref(ow), C.byref(oh)))
+                                    got.size, ref_of(ow), ref_of(oh)))
     assert (oh.value, ow.value) == want.shape[:2] and np.array_equal(got.reshape(want.shape), want)
     c = np.zeros(3, np.uint8)
     amd.random_seed(42, 69)
     ok(twin, twin.twin_random_color(fp(c)))
-    img = np.zeros((40, 40, 3), np.uint8)
+    img, want = np.zeros((40, 40, 3), np.uint8), np.zeros((40, 40, 3), np.uint8)
+    L = amd.lib()
     ok(twin, twin.twin_draw_circle(fp(img), 40, 40, C.c_float(20), C.c_float(20), fp(c), C.c_float(5)))
-    assert img.any() and (img[20, 20] == c).all()
+    assert L.akz_draw_circle(fp(want), 40, 40, C.c_float(20), C.c_float(20), fp(c), C.c_float(5)) == 0
+    assert img.any() and np.array_equal(img, want)
     ok(twin, twin.twin_draw_line(fp(img), 40, 40, C.c_float(2), C.c_float(2), C.c_float(30), C.c_float(35), fp(c), C.c_float(1)))
+    assert L.akz_draw_line(fp(want), 40, 40, C.c_float(2), C.c_float(2), C.c_float(30), C.c_float(35), fp(c), C.c_float(1)) == 0
+    assert np.array_equal(img, want)

@@ -88,6 +88,9 @@ doc = dict(
     source=f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1` ({tag}); "
            "HBM bytes = FETCH_SIZE x fetch_factor + WRITE_SIZE (KiB x 1024)",
     calibration=cal,
+    # every kernel by its own name (bench.py attaches these to the rows of roofline.kernels / roofline_2.kernels)
+    per_kernel={k: dict(launches=f[k][0], hbm_bytes_per_launch=round((kib(f, k) * factor(k) + kib(w, k)) * 1024.0))
+                for k in f if k.startswith("k_")},
     kernels={
         "detector (k_detector_march + k_detector_tiled)": group(["k_detector_march", "k_detector_tiled"]),  # every detector launch, as bench.py counts them
         "k_level_march + k_fed_own": group(["k_level_march", "k_fed_own", "k_octave_resident"]),  # every diffusion launch

@@ -1,0 +1,60 @@
+// Every size / host-thread gate that chooses between kernel families or paths of the C ABI, in ONE table.
+//
+// Results never depend on a gate (each side of each gate is held to the oracle bit for bit; tests/test_gpu_gates.py forces
+// every path on every BASELINE geometry through both entry points): a gate only says which of two equivalent forms is
+// expected to be faster.  The values were measured on MI355X boxes of this pool (profiles/r04_*, r05_job_gate*.txt,
+// r05_lone_select.txt); akz_debug_gates() hands the table out (DESIGN.md section 6 is rendered from it by
+// tools/render_gates.py), akz_debug_set_schedule(ctx, 4, ...) overrides the job gates for measurements, and
+// akz_ctx_calibrate_gates() re-derives the job gates from timings on the machine at hand.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/akaze_hip_debug.h"
+
+namespace akz {
+namespace gates {
+
+// ---- which path a JOB takes (w * h * n input pixels) ----
+// The batch path -- column-march kernels, forked coarse chain, resident tail -- uses the chip better from ~3 Mpx on but ends
+// later when nothing else is in flight: a synchronous call takes it later than a job of the begin / finish interface.
+constexpr uint64_t kBigPxSync = 6000000;    // akz_extract_*           (lone 4K 2.68 -> 2.38 ms, r05_job_gate.txt)
+constexpr uint64_t kBigPxAsync = 3000000;   // akz_extract_begin_*     (2016x1512 streamed 0.77 -> 0.67 ms)
+                                            // (akz_ctx_set_lanes deals the jobs below kBigPxAsync to its lanes)
+// ---- which kernel family a LAUNCH takes (level w * h * n pixels) ----
+constexpr uint64_t kMarchPx = 8u << 20;     // blur / contrast / detector marches instead of the tiled kernels (also every
+                                            // full-resolution launch of a batch-path job, whatever its size)
+constexpr uint64_t kLevelMarchPx = 4000000; // k_level_march (preparation + <= 4 FED steps in one launch) instead of k_prep + k_fed_own
+constexpr uint64_t kStreamPx = 2u << 20;    // the streaming preparation / blur kernels instead of the tiled ones
+constexpr uint64_t kFedDeepWorkgroups = 512;  // launches of at most this many workgroups fuse 16 FED steps instead of 8
+// ---- where the order-dependent keypoint selection and the candidate sort run ----
+constexpr unsigned kFewHostThreads = 4;     // contexts with fewer host threads keep selection and sort on the device
+constexpr uint64_t kSelectDevicePx = 6000000;  // images of this size and more: neighbour lists + device selection when waited for
+constexpr uint32_t kSortBuckets = 65536;    // (image, level, row) buckets the four-launch counting sort takes; rocPRIM beyond
+// ---- the matcher ----
+constexpr uint64_t kMergeCompactMinRows = 2048;     // query sets from here on: merge + ratio test + compaction in one launch
+constexpr uint64_t kMergeCompactMaxRows = 262144;   // ... up to here (every workgroup of its look-back chain resident at once)
+constexpr uint32_t kPremergeChunks = 4;             // more train chunks than this: a parallel merge before the compaction
+
+// the table akz_debug_gates() returns: name, value, unit, what lies on either side
+inline const akz_gate* table(size_t* n) {
+    static const akz_gate rows[] = {
+        {"big_px_sync", (double)kBigPxSync, "input px per job", "synchronous akz_extract_*: tiled / streaming kernels on one stream below, the batch path (marches, forked coarse chain, resident tail) from here on"},
+        {"big_px_async", (double)kBigPxAsync, "input px per job", "akz_extract_begin_*: the same choice for a job of the begin / finish interface; akz_ctx_set_lanes deals the jobs below it to its lanes"},
+        {"march_px", (double)kMarchPx, "level px per launch", "k_blur5_march / k_contrast_march / k_detector_march instead of the tiled kernels (batch-path jobs: their full-resolution launches regardless)"},
+        {"level_march_px", (double)kLevelMarchPx, "level px per launch", "k_level_march instead of k_prep + k_fed_own"},
+        {"stream_px", (double)kStreamPx, "level px per launch", "k_prep_stream / k_blur5_stream instead of the tiled k_prep / k_blur"},
+        {"fed_deep_workgroups", (double)kFedDeepWorkgroups, "workgroups per launch", "k_fed_own fuses 16 steps per launch at or below, 8 above"},
+        {"few_host_threads", (double)kFewHostThreads, "host threads of the context", "fewer: candidate sort and keypoint selection on the device; from here on the host's counting sort and grids serve large batches"},
+        {"select_device_px", (double)kSelectDevicePx, "px per image", "images from here on: device neighbour lists (+ k_select when the job is waited for) even on many-core hosts"},
+        {"sort_buckets", (double)kSortBuckets, "(image, level, row) buckets", "k_sort_rows / k_bucket_* up to here, rocPRIM radix sort beyond"},
+        {"merge_compact_min_rows", (double)kMergeCompactMinRows, "query rows", "single-workgroup compaction below, k_match_merge_compact from here on"},
+        {"merge_compact_max_rows", (double)kMergeCompactMaxRows, "query rows", "k_match_merge_compact up to here (its look-back needs the whole grid resident), merge + compaction beyond"},
+        {"premerge_chunks", (double)kPremergeChunks, "train chunks", "more chunks than this: k_match_merge before the compaction"},
+    };
+    if (n) *n = sizeof(rows) / sizeof(rows[0]);
+    return rows;
+}
+
+}  // namespace gates
+}  // namespace akz

@@ -19,6 +19,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "akz_internal.hpp"
+#include "akz_gates.hpp"
 #include "akz_select.hpp"
 
 namespace akz {
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_sort_rows(const Candidate* __restrict_
 // workgroup, up to SORT_BUCKETS_MAX buckets; leaves the counters zero for the next job and writes k_rel_offsets' tables: the
 // bucket starts ARE those tables), place (the columns of a row side by side), rank (a candidate counts the row-mates left of
 // it and moves to its final place) -- against eleven (keys, eight rocPRIM passes, gather, offsets).
-constexpr unsigned SORT_BUCKETS_MAX = 65536;
+constexpr unsigned SORT_BUCKETS_MAX = gates::kSortBuckets;
 __global__ void __launch_bounds__(256) k_bucket_count(const Candidate* __restrict__ cand, unsigned cap, const unsigned* __restrict__ d_count,
                                                       RelLevels lv, unsigned* __restrict__ cnt, unsigned* __restrict__ bucket_of,
                                                       unsigned* __restrict__ slot_of) {

@@ -70,6 +70,20 @@ class KernelRow(C.Structure):
 KERNEL_ROW_KINDS = {1: "k_level_march", 2: "k_fed_own", 3: "k_octave_resident", 4: "k_detector_tiled", 5: "k_detector_march"}
 
 
+class Gate(C.Structure):
+    """akz_gate (akaze_hip_debug.h)"""
+    _fields_ = [("name", C.c_char_p), ("value", C.c_double), ("unit", C.c_char_p), ("meaning", C.c_char_p)]
+
+
+def gates():
+    """akz_debug_gates: the table of every size / host-thread gate (csrc/akz_gates.hpp) as a list of dicts; needs no GPU."""
+    p, n = C.c_void_p(), C.c_uint64()
+    _check(lib().akz_debug_gates(C.byref(p), C.byref(n)))
+    rows = C.cast(p, C.POINTER(Gate))
+    return [dict(name=rows[i].name.decode(), value=rows[i].value, unit=rows[i].unit.decode(), meaning=rows[i].meaning.decode())
+            for i in range(n.value)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 10), ("fed_launches", C.c_uint64), ("fed_px_steps", C.c_uint64),
                 ("calls", C.c_uint64), ("pixels", C.c_uint64), ("det_launches", C.c_uint64), ("det_px", C.c_uint64), ("fused_px", C.c_uint64),
@@ -139,6 +153,8 @@ def lib():
         "akz_op_scharr": ([vp, vp, vp, u32, u32, u32, i32, i32, u32], i32),
         "akz_debug_rcp_f64_to_f32": ([vp, vp, vp, u64], i32),
         "akz_debug_kernel_rows": ([vp, vp, u32, vp, i32], i32),
+        "akz_debug_gates": ([C.POINTER(vp), pu64], i32),
+        "akz_ctx_calibrate_gates": ([vp, pu64, pu64, C.POINTER(C.c_double)], i32),
         "akz_op_pm_g2": ([vp, vp, vp, vp, u32, u32, u32, vp], i32),
         "akz_op_contrast_factor": ([vp, vp, u32, u32, u32, f64, f64, u64, vp], i32),
         "akz_op_flow": ([vp, vp, vp, u32, u32, u32, vp, u32], i32),
@@ -418,6 +434,13 @@ class Context:
         p = Profile()
         _check(lib().akz_ctx_get_profile2(self._h, C.byref(p), C.sizeof(Profile), int(reset)))
         return p.as_dict()
+
+    def calibrate_gates(self):
+        """akz_ctx_calibrate_gates: the two job gates from timings on this machine -> (sync_px, async_px, ms[5][4])"""
+        a, b = C.c_uint64(), C.c_uint64()
+        ms = (C.c_double * 20)()
+        _check(lib().akz_ctx_calibrate_gates(self._h, C.byref(a), C.byref(b), ms))
+        return a.value, b.value, [[ms[i * 4 + k] for k in range(4)] for i in range(5)]
 
     def kernel_rows(self, reset=True):
         """akz_debug_kernel_rows: the FED / detector spans by kernel variant and launch shape (profiling must be on)."""

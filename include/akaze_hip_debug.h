@@ -45,6 +45,25 @@ int akz_debug_stream_placement(akz_ctx* ctx, int* info);
    end; tiny_pair_ms: 24 + 24 interleaved tiny kernels on the two streams (negative: not measured); tiny_alone_ms: 24 of
    them on one stream. */
 int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float tiny_alone_ms, float spin_ms);
+/* The gate table (csrc/akz_gates.hpp): every size / host-thread threshold that chooses between two equivalent kernel families
+   or paths -- name, value, what it counts, what lies on either side.  Results never depend on a gate.  *rows points at a
+   static table of *n entries.  (big_px_sync / big_px_async are the compiled-in values; akz_ctx_calibrate_gates and
+   akz_debug_set_schedule(ctx, 4, ...) change a context's own copies.) */
+typedef struct akz_gate {
+    const char* name;
+    double value;
+    const char* unit;
+    const char* meaning;
+} akz_gate;
+int akz_debug_gates(const akz_gate** rows, uint64_t* n);
+/* Re-derives the two JOB gates of this context from timings on the machine at hand instead of the compiled-in values (which
+   were tuned on a 16-core host of one pool): lone synthetic frames of 2.1 / 3.0 / 4.1 / 6.2 / 8.3 Mpx are extracted through
+   the synchronous call and through the begin / finish interface (two jobs in flight), each with the batch path forced on
+   and off; a gate becomes the smallest size from which the batch path is the faster one at that size and at every larger
+   one (the largest size + 1 if it never is).  ~0.2 s, allocates what such jobs allocate; the caller's stream must be idle.
+   *sync_px / *async_px (may be NULL): the gates chosen; ms (may be NULL): 5 sizes x {sync lone, sync batch, streamed lone,
+   streamed batch} = 20 medians in milliseconds.  Results of extractions never depend on the outcome. */
+int akz_ctx_calibrate_gates(akz_ctx* ctx, uint64_t* sync_px, uint64_t* async_px, double* ms);
 /* Measurement hook: the HIP-event spans of the diffusion and detector stages (akz_ctx_set_profiling) broken down by kernel
    variant and launch shape -- the rows behind bench.py's roofline.kernel, which names a group of kernels.  kind: see below;
    param: fused FED steps of a k_level_march launch (+16: the octave's 2x2 mean folded in, +32: Lstep written), FED steps

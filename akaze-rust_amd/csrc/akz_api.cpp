@@ -290,6 +290,7 @@ int akz_ctx_set_profiling(akz_ctx* c, int on) {
 int akz_ctx_warmup(akz_ctx* c) {
     AKZ_TRY(bind(c));
     if (!c->placed) AKZ_TRY(place_streams(c));
+    (void)device_libm_mode(c);  // (once per process: the self-test of the device's atan2f / cosf / sinf against this libm)
     return AKZ_OK;
 }
 static int get_profile_full(akz_ctx* c, akz_profile* out, int reset) {
@@ -437,7 +438,7 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
 }
 const char* akz_detector_kernel_name(void) { return "detector (k_detector_march + k_detector_tiled)"; }
 int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
-    if (!c || key < 0 || key > 4) return AKZ_ERR_INVALID_ARG;
+    if (!c || key < 0 || key > 5) return AKZ_ERR_INVALID_ARG;
     AKZ_TRY(bind(c));
     c->sched[key] = value;
     if (key == 4) {
@@ -483,6 +484,28 @@ int akz_debug_set_host_sort(akz_ctx* c, int on) {
     if (!c) return AKZ_ERR_INVALID_ARG;
     c->dbg_host_sort = on < 0 ? -1 : (on != 0);
     for (akz_ctx* l : c->lanes) l->dbg_host_sort = c->dbg_host_sort;
+    return AKZ_OK;
+}
+int akz_debug_set_device_libm(akz_ctx* c, int mode) {
+    if (!c) return AKZ_ERR_INVALID_ARG;
+    c->dbg_device_libm = mode == 0 ? 0 : -1;
+    for (akz_ctx* l : c->lanes) l->dbg_device_libm = c->dbg_device_libm;
+    return AKZ_OK;
+}
+int akz_debug_device_libm(akz_ctx* c, int* available, int* last_job) {
+    AKZ_TRY(bind(c));
+    if (available) *available = device_libm_mode(c);
+    if (last_job) {
+        *last_job = c->libm_last;
+        for (akz_ctx* l : c->lanes) *last_job = std::max(*last_job, l->libm_last);
+    }
+    return AKZ_OK;
+}
+int akz_debug_libm_eval(akz_ctx* c, const float* d_a, const float* d_b, float* d_out3, uint64_t n, int fma) {
+    AKZ_TRY(bind(c));
+    if (!d_a || !d_b || !d_out3) return AKZ_ERR_INVALID_ARG;
+    launch::libm_eval(c->stream, d_a, d_b, d_out3, n, fma != 0, nullptr);
+    AKZ_HIP_TRY(hipGetLastError());
     return AKZ_OK;
 }
 int akz_debug_gates(const akz_gate** rows, uint64_t* n) {

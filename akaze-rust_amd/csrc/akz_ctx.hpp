@@ -129,6 +129,8 @@ struct akz_ctx {
     } ms1;
     int match_mode = 2;                      // 0: popcount kernel, 1: matrix cores on int8 operands, 2 (default) / 3: on FP4 operands (akz_ctx_set_match_mode)
     uint32_t dbg_pair_chunks = 0, dbg_set_chunks = 0;  // akz_debug_set_match_chunks (0: automatic)
+    int dbg_device_libm = -1;   // akz_debug_set_device_libm: 0 = the host's libm always, -1 = automatic (device_libm_mode)
+    int libm_last = 0;          // how the last finished job got its angles: 0 host libm, 1 / 2 the device's FMA / SSE2 forms
     int dbg_host_sort = -1;                            // akz_debug_set_host_sort: 1 / 0 force the host / the device sort, -1 automatic
     DevBuf cosi;                             // (cos, sin) per keypoint
     DevBuf pin[10];                          // pinned host staging: candidates, orientation sums, descriptor
@@ -172,7 +174,7 @@ struct akz_ctx {
     // placement probe found it a queue and a pipe of its own (below), 1 the copy stream regardless, 2 a stream of their own
     // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
     // has finished its fine-level diffusion (default) or not; [2] no placement probe
-    int sched[5] = {0, 1, 0, 0, 0};
+    int sched[6] = {0, 1, 0, 0, 0, 0};
     uint64_t big_px = gates::kBigPxAsync;  // the gate of the job being begun (set by extract_begin from the two below; the begin half's helpers read it)
     uint64_t big_px_sync = gates::kBigPxSync, big_px_async = gates::kBigPxAsync;  // (sched[4] sets both: measurement)
     // pixels per LAUNCH (level w*h*n) from which the blur, the contrast passes and the detectors take their column-march
@@ -405,3 +407,4 @@ AKZ_LOCAL int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, fl
                   float* ldet_out, uint32_t w, uint32_t h, uint32_t n);
 // akz_extract.cpp
 AKZ_LOCAL int place_streams(akz_ctx* c);
+AKZ_LOCAL int device_libm_mode(akz_ctx* c);  // 0: host libm; 1 / 2: the device's FMA / SSE2 forms reproduce it (akz_libm.hpp)

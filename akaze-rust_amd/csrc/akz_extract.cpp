@@ -602,10 +602,19 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     // starts (run_levels stops at the resident launch, which covers every level behind it: a fork behind that point
     // would run those levels a second time as separate launches)
     if (fork_level < L && res_first < fork_level) fork_level = res_first;
+    // sched[5] (measurement, profiles/r06_interleave.txt): the detector of a fine level right behind the kernel that wrote its
+    // Lsmooth instead of after the whole fine chain -- does the detector then find (part of) the plane in the Infinity Cache?
+    std::vector<char> det_done(L, 0);
+    auto interleave_detector = [&](size_t l) {
+        if (c->sched[5] && l < fork_level && !det_done[l] &&
+            detector_family(c, plan[l].det_sigma, plan[l].w, plan[l].h, n, border_margin(plan[l], cfg), keep_all) == 5 && detector_one_pass(l, ls))
+            det_done[l] = 1;
+    };
     auto run_levels = [&](size_t lo, size_t hi) -> int {
     for (size_t i = lo; i < hi; ++i) {
         const LevelPlan& lv = plan[i];
         const LevelPlan& pv = plan[i - 1];
+        if (i >= 2) interleave_detector(i - 1);  // (level i - 1 is complete; its Lsmooth was written one launch group ago)
 
         if (i == res_first) {
             std::vector<launch::ResidentLevel> rl;
@@ -737,6 +746,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     auto detectors = [&](size_t lo, size_t hi, hipStream_t st_) -> int {
         std::map<uint32_t, std::vector<launch::DetLevelDesc>> sets;
         for (size_t l = lo; l < hi; ++l) {
+            if (det_done[l]) continue;  // (sched[5]: enqueued behind its level kernel already)
             const LevelPlan& lv = plan[l];
             const float thr = (float)cfg.detector_threshold, bm = border_margin(lv, cfg);
             if (detector_family(c, lv.det_sigma, lv.w, lv.h, n, bm, keep_all) == 4) {
@@ -827,6 +837,86 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     return AKZ_OK;
 }
 
+// Can the device stand in for this process's libm (akz_libm.hpp)?  Decided once per process: the build of sinf / cosf that
+// glibc's selector takes on this CPU (FMA + AVX2: the FMA build; FMA4: a third build the header does not state; otherwise
+// SSE2), then every bit of atan2f, cosf, sinf on kN arguments each -- orientation-like angles, every binade of small and
+// large ratios, zeros, infinities, NaNs, the reduction's breakpoints -- against the host's functions.
+int device_libm_mode(akz_ctx* c) {
+    if (c->dbg_device_libm == 0) return 0;
+    static std::mutex m;
+    static int mode = -1;
+    std::lock_guard<std::mutex> lk(m);
+    if (mode >= 0) return mode;
+    mode = 0;
+#if defined(__x86_64__) && defined(__GLIBC__)
+    __builtin_cpu_init();
+    const bool fma = __builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2");
+    if (!fma && __builtin_cpu_supports("fma4")) return mode;
+    constexpr size_t kN = 1u << 21;
+    std::vector<float> a(kN), b(kN);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {  // SplitMix64
+        uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    const float special[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 0x1p-126f, -0x1p-126f, 0x1p-149f, 0x1.fffffep127f, 0x1p-12f,
+                             0x1.921fb6p-1f, 0x1.921fb6p0f, 0x1.921fb6p1f, -0x1.921fb6p1f, 0.4375f, 0.6875f, 1.1875f, 2.4375f, 0x1p25f, 0x1p-29f,
+                             119.99f, 120.0f, 1e10f};
+    const size_t n_sp = sizeof(special) / sizeof(special[0]);
+    for (size_t i = 0; i < kN; ++i) {
+        const uint64_t r = next(), q = next();
+        if (i < n_sp * n_sp) {
+            a[i] = special[i / n_sp];
+            b[i] = special[i % n_sp];
+        } else if (i & 1) {  // an orientation-like angle and a ratio near it: |a| <= pi (+ a little), b of any magnitude
+            a[i] = (float)((double)(int64_t)(r >> 11) * (1.0 / 9007199254740992.0) * 6.6 - 3.3);
+            uint32_t u = (uint32_t)q;
+            u = (u & 0x807fffffu) | ((64u + (u >> 23) % 128u) << 23);  // exponents 2^-63 .. 2^64
+            std::memcpy(&b[i], &u, 4);
+        } else {  // both of any magnitude: every reduction branch of atanf, the k > 60 / k < -60 shortcuts
+            uint32_t u = (uint32_t)r, v = (uint32_t)q;
+            u = (u & 0x807fffffu) | ((32u + (u >> 23) % 192u) << 23);
+            v = (v & 0x807fffffu) | ((32u + (v >> 23) % 192u) << 23);
+            if ((i & 6) == 2) v = (v & 0x80000000u) | (u & 0x7f800000u) | (v & 0x007fffffu);  // comparable magnitudes
+            std::memcpy(&a[i], &u, 4);
+            std::memcpy(&b[i], &v, 4);
+        }
+    }
+    float *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    std::vector<float> got(3 * kN);
+    const bool ok_dev = hipMalloc((void**)&d_a, kN * 4) == hipSuccess && hipMalloc((void**)&d_b, kN * 4) == hipSuccess &&
+                        hipMalloc((void**)&d_o, 3 * kN * 4) == hipSuccess &&
+                        hipMemcpy(d_a, a.data(), kN * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(d_b, b.data(), kN * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok_dev) {
+        launch::libm_eval(nullptr, d_a, d_b, d_o, kN, fma, nullptr);
+        const bool ran = hipGetLastError() == hipSuccess && hipMemcpy(got.data(), d_o, 3 * kN * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        std::atomic<uint64_t> bad{ran ? 0u : 1u};
+        if (ran) {
+            const size_t pieces = 64;
+            c->pool().run(pieces, [&](size_t p) {
+                uint64_t mine = 0;
+                auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+                auto same = [&](float x, float y) { return bits(x) == bits(y) || (x != x && y != y); };
+                for (size_t i = kN * p / pieces; i < kN * (p + 1) / pieces; ++i) {
+                    mine += !same(got[3 * i], atan2f(a[i], b[i]));
+                    if (std::fabs(a[i]) < 119.9f) mine += !same(got[3 * i + 1], cosf(a[i])) + !same(got[3 * i + 2], sinf(a[i]));
+                }
+                bad += mine;
+            });
+        }
+        if (bad.load() == 0) mode = fma ? 1 : 2;
+    }
+    (void)hipGetLastError();
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (d_o) (void)hipFree(d_o);
+#endif
+    return mode;
+}
+
 // The finish half proper.  The job shell stays with the caller; on failure everything the job held is released.
 static int extract_finish_body(akz_job* jobp, akz_result** out) {
     *out = nullptr;
@@ -896,6 +986,8 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         c->sel_last_fallback = 0;
     }
     bool sorted = false, dev_sel = false;
+    int libm_dev = 0;        // 1 / 2: angles and descriptors were enqueued on the device behind the selection (device_libm_mode)
+    bool dev_angles_ok = true;  // ... and every angle was one the device forms cover
     uint16_t* d_rel = nullptr;
     uint32_t* d_rel_flags = nullptr;
     uint32_t *d_sel_hdr = nullptr, *d_sel_total = nullptr;
@@ -963,6 +1055,18 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                 launch::orientation_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, cap, wmask, nwin, &((SelKpHost*)c->sel_recs.p)->sums, 2);
                 AKZ_HIP_TRY(hipGetLastError());
                 dev_sel = true;
+                // ... and, where the device reproduces this process's atan2f / cosf / sinf (akz_libm.hpp), the descriptors right
+                // behind the orientation sums: no host round trip between the two.  Speculative like the selection itself: a job
+                // that goes back to the host's selection, or an angle outside what the device forms cover, discards them.
+                libm_dev = device_libm_mode(c);
+                if (libm_dev) {
+                    void* blk = nullptr;
+                    AKZ_TRY(slab_acquire(c, (size_t)cap * 64, &blk, &r->desc_block_bytes));
+                    r->d_desc64 = (uint8_t*)blk;
+                    launch::mldb_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, cap, &((SelKpHost*)c->sel_recs.p)->sums, 2, libm_dev == 1,
+                                         nullptr, (uint32_t)cfg.descriptor_channels, r->d_desc64);
+                    AKZ_HIP_TRY(hipGetLastError());
+                }
             }
         }
     }
@@ -987,6 +1091,10 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             AKZ_HIP_TRY(hipMemcpyAsync(c->pin[8].p, d_sel_hdr, (size_t)n * 64, hipMemcpyDeviceToHost, s));
             AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec_kp * sizeof(SelKpHost)));
             AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->sel_recs.p, (size_t)spec_kp * sizeof(SelKpHost), hipMemcpyDeviceToHost, s));
+            if (libm_dev && !(r->flags & AKZ_NO_HOST_DESCRIPTORS)) {  // the descriptor rows of those keypoints with the same synchronisation
+                AKZ_TRY(ensure_pinned(c, c->pin[2], (size_t)spec_kp * 64));
+                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[2].p, r->d_desc64, (size_t)spec_kp * 64, hipMemcpyDeviceToHost, s));
+            }
             AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
             AKZ_TRY(ensure_pinned(c, c->pin[7], (size_t)n * sizeof(uint32_t)));
         } else if (attempt == 0) {
@@ -1067,6 +1175,13 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                 std::memcpy(c->pin[0].p, keep_r.data(), keep_r.size());
                 AKZ_HIP_TRY(hipMemcpyAsync((SelKpHost*)c->pin[0].p + spec_kp, (const SelKpHost*)c->sel_recs.p + spec_kp,
                                            (size_t)(total_kp - spec_kp) * sizeof(SelKpHost), hipMemcpyDeviceToHost, s));
+                if (libm_dev && !(r->flags & AKZ_NO_HOST_DESCRIPTORS)) {
+                    std::vector<uint8_t> keep_d((const uint8_t*)c->pin[2].p, (const uint8_t*)c->pin[2].p + (size_t)spec_kp * 64);
+                    AKZ_TRY(ensure_pinned(c, c->pin[2], (size_t)total_kp * 64));
+                    std::memcpy(c->pin[2].p, keep_d.data(), keep_d.size());
+                    AKZ_HIP_TRY(hipMemcpyAsync((uint8_t*)c->pin[2].p + (size_t)spec_kp * 64, r->d_desc64 + (size_t)spec_kp * 64,
+                                               (size_t)(total_kp - spec_kp) * 64, hipMemcpyDeviceToHost, s));
+                }
                 AKZ_HIP_TRY(hipStreamSynchronize(s));
             }
             if (dev_sel) break;
@@ -1166,10 +1281,18 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                 k.octave = plan[q.level].octave;
                 k.class_id = q.level;
                 k.angle = 0.0f;
+                if (libm_dev) std::memcpy(&k.angle, &recs[first[img] + i].sums.angle_bits, 4);  // (formed on the device: k_mldb)
                 k.lx = k.ly = 0;
                 k.xp = k.xm = k.yp = k.ym = 0.0f;
             }
         });
+        if (libm_dev)
+            for (uint32_t img = 0; img < n && dev_angles_ok; ++img)
+                for (const HostKeypoint& k : hk[img])
+                    if (!(std::fabs(k.angle) < 119.9f)) {  // NaN, or beyond the device's sinf / cosf: the host's libm takes the job's angles
+                        dev_angles_ok = false;
+                        break;
+                    }
         c->last_total_kp = (uint32_t)total_kp;
     } else {
         c->pool().run(n, [&](size_t img) {  // images are independent
@@ -1214,7 +1337,21 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         }
     });
     r->kps.assign(n, {});
-    if (total_kp) {
+    const bool dev_desc = dev_sel && libm_dev != 0 && dev_angles_ok;  // angles in hk, descriptor rows in r->d_desc64 (and pin[2]) already
+    c->libm_last = dev_desc ? libm_dev : 0;
+    if (total_kp && dev_desc) {
+        const double t_ml0 = now_ms();
+        if (!(r->flags & AKZ_NO_HOST_DESCRIPTORS)) {
+            const uint8_t* rows = (const uint8_t*)c->pin[2].p;
+            r->rows64.resize(total_kp * 64);
+            const size_t kRowChunk = 8192;
+            c->pool().run((total_kp + kRowChunk - 1) / kRowChunk, [&](size_t j) {
+                const size_t b = j * kRowChunk * 64, e = std::min<size_t>(total_kp * 64, b + kRowChunk * 64);
+                std::memcpy(r->rows64.data() + b, rows + b, e - b);
+            });
+        }
+        if (c->profiling) c->prof.ms[AKZ_ST_MLDB] += now_ms() - t_ml0;
+    } else if (total_kp) {
         const double t_or0 = now_ms();
         KpParam* d_kp = (KpParam*)c->kp_in.p;
         OrientOut* oo = nullptr;
@@ -1263,9 +1400,15 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         const double t_ml0 = now_ms();
         if (c->profiling) c->prof.ms[AKZ_ST_ORIENT] += t_ml0 - t_or0;
         // descriptor rows live in a pooled device block owned by the result
-        void* blk = nullptr;
-        AKZ_TRY(slab_acquire(c, total_kp * 64, &blk, &r->desc_block_bytes));
-        r->d_desc64 = (uint8_t*)blk;
+        if (r->d_desc64 && r->desc_block_bytes < total_kp * 64) {  // (a block acquired for the device's own attempt, too small now)
+            slab_release(c, r->d_desc64, r->desc_block_bytes);
+            r->d_desc64 = nullptr;
+        }
+        if (!r->d_desc64) {
+            void* blk = nullptr;
+            AKZ_TRY(slab_acquire(c, total_kp * 64, &blk, &r->desc_block_bytes));
+            r->d_desc64 = (uint8_t*)blk;
+        }
         launch::mldb(s, tab, d_kp, (const float*)c->cosi.p, (uint32_t)total_kp, (uint32_t)cfg.descriptor_channels,
                      r->d_desc64);
         AKZ_HIP_TRY(hipGetLastError());

@@ -119,7 +119,7 @@ struct KpParam {  // per-keypoint input of the orientation / descriptor kernels
 struct OrientOut {
     float sum_x, sum_y;
     uint32_t found;
-    uint32_t _pad;
+    uint32_t angle_bits;  // the angle as f32 bits where the device formed it (k_mldb with DeviceAngles); unused otherwise
 };
 struct MatchRec {  // per query descriptor
     uint32_t min_d, second_d, min_j, _pad;
@@ -294,6 +294,12 @@ void orientation_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_k
 // d_cosi: (cosf(angle), sinf(angle)) per keypoint from the host libm (descriptors.rs:55-56)
 void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float* d_cosi, uint32_t nkp,
           uint32_t channels, uint8_t* d_desc64);
+// the same with the keypoint count still on the device and the angle, cosf, sinf of every keypoint formed ON the device from
+// its orientation sums (akz_libm.hpp; d_sums[i * sums_stride]): the angle is left in d_sums[..].angle_bits, *d_flag is raised
+// if an argument is outside what the device forms cover
+void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t max_kp, OrientOut* d_sums,
+                  uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64);
+void libm_eval(hipStream_t s, const float* a, const float* b, float* out3, uint64_t n, bool fma, uint32_t* d_flag);
 uint32_t match_num_chunks(uint32_t n0, uint32_t n1);
 // Both scans write one record per (chunk of the train set, query): d_rec[chunk * n0 + query]; match_compact merges a
 // query's chunk records (ascending rows: the lowest row wins among equal minima) and applies the ratio test.

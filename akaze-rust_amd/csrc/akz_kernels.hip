@@ -9,6 +9,7 @@
 
 #include "akz_internal.hpp"
 #include "akz_pm_g2.hpp"
+#include "akz_libm.hpp"
 
 namespace akz {
 namespace {
@@ -94,6 +95,16 @@ __device__ __forceinline__ double octave_contrast(double k, unsigned pow) {
 __global__ void k_rcp_f64_to_f32(const double* __restrict__ x, float* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rcp_f64_to_f32(x[i]);
+}
+__global__ void k_libm_eval(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out3, size_t n, unsigned fma,
+                            unsigned* __restrict__ flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool bad = false;
+    out3[3 * i] = libm::atan2f_glibc(a[i], b[i]);
+    out3[3 * i + 1] = fma ? libm::cosf_glibc<true>(a[i], &bad) : libm::cosf_glibc<false>(a[i], &bad);
+    out3[3 * i + 2] = fma ? libm::sinf_glibc<true>(a[i], &bad) : libm::sinf_glibc<false>(a[i], &bad);
+    if (bad && flag) atomicOr(flag, 1u);
 }
 __global__ void k_pm_g2(const float* __restrict__ lx, const float* __restrict__ ly, float* __restrict__ out,
                         size_t plane, const double* __restrict__ d_k, unsigned pow) {
@@ -714,7 +725,7 @@ k_orientation(LevelTable tab, const KpParam* __restrict__ kps, unsigned nkp, con
     }
     if (!is_y && base + j < nkp) {
         OrientOut o;
-        o.sum_x = bx; o.sum_y = by; o.found = found; o._pad = 0;
+        o.sum_x = bx; o.sum_y = by; o.found = found; o.angle_bits = 0;
         out[(size_t)(base + j) * out_stride] = o;
     }
 }
@@ -773,16 +784,47 @@ __constant__ BitTable3 c_bits3 = make_bits3();
 // Workgroup numbering: xcd_contiguous_group, as in k_orientation.
 constexpr int MLDB_KPB = 4;
 constexpr int MLDB_LAT = 21, MLDB_NS = MLDB_LAT * MLDB_LAT;
+// The keypoint's orientation on the device (akz_libm.hpp: this machine's atan2f / cosf / sinf as IEEE arithmetic), for the
+// job whose selection ran on the device: the angle from the orientation sums (scale_space_extrema.rs:326), then its cosine and
+// sine (descriptors.rs:55-56).  Wave-uniform (one keypoint per wave); lane 0 leaves the angle in the keypoint's record for the
+// host.  `fma`: which of glibc's two sinf / cosf builds this machine's libm runs.  An argument the device forms do not cover
+// raises *flag: the host then redoes the job's angles and descriptors with its own libm.
+struct DeviceAngles {
+    OrientOut* sums;     // NULL: (cos, sin) come from the host (cosi)
+    unsigned stride;     // in OrientOut units
+    unsigned fma;
+    unsigned* flag;
+};
+__device__ __forceinline__ float2 device_angle(const DeviceAngles& da, unsigned kpi, bool write) {
+    OrientOut* o = da.sums + (size_t)kpi * da.stride;
+    const float ang = o->found ? libm::atan2f_glibc(o->sum_y, o->sum_x) : 0.0f;
+    bool bad = false;
+    float co, si;
+    if (da.fma) {
+        co = libm::cosf_glibc<true>(ang, &bad);
+        si = libm::sinf_glibc<true>(ang, &bad);
+    } else {
+        co = libm::cosf_glibc<false>(ang, &bad);
+        si = libm::sinf_glibc<false>(ang, &bad);
+    }
+    if (write) {
+        o->angle_bits = __float_as_uint(ang);
+        if (bad && da.flag) atomicOr(da.flag, 1u);  // (the host also sees it in the angle itself: NaN or |angle| >= 120)
+    }
+    return float2{co, si};
+}
 __global__ void __launch_bounds__(64 * MLDB_KPB)
-k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi, unsigned nkp,
-       unsigned channels, uint8_t* __restrict__ desc64) {
+k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi, unsigned nkp, const unsigned* __restrict__ d_nkp,
+       DeviceAngles da, unsigned channels, uint8_t* __restrict__ desc64) {
     __shared__ float s_win[MLDB_KPB][3][MLDB_NS + 7];
     __shared__ float s_val[MLDB_KPB][3][32];
+    if (d_nkp) nkp = min(nkp, *d_nkp);  // (the count of a selection that ran on the device; nkp: what the grid was sized for)
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const unsigned kpi = xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB + wv;
+    if (xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB >= nkp) return;  // whole workgroup
     const bool live = kpi < nkp;
     KpParam kp = kps[live ? kpi : 0];
-    const float2 cs = cosi[live ? kpi : 0];
+    const float2 cs = da.sums ? device_angle(da, live ? kpi : 0, live && lane == 0) : cosi[live ? kpi : 0];
     // one keypoint per wave: its level is wave-uniform, so the level's pointers come from the kernel arguments by
     // scalar loads (a per-lane index would send the whole table through scratch memory)
     const LevelPtrs lv = tab.lv[__builtin_amdgcn_readfirstlane(kp.level)];
@@ -1273,7 +1315,20 @@ void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float*
     if (nkp == 0) return;
     const uint32_t groups = (nkp + MLDB_KPB - 1) / MLDB_KPB;
     hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp,
-                       reinterpret_cast<const float2*>(d_cosi), nkp, channels, d_desc64);
+                       reinterpret_cast<const float2*>(d_cosi), nkp, (const unsigned*)nullptr, DeviceAngles{nullptr, 0u, 0u, nullptr}, channels,
+                       d_desc64);
+}
+void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t max_kp, OrientOut* d_sums,
+                  uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64) {
+    if (max_kp == 0) return;
+    const uint32_t groups = (max_kp + MLDB_KPB - 1) / MLDB_KPB;
+    hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp, (const float2*)nullptr, max_kp, d_nkp,
+                       DeviceAngles{d_sums, sums_stride, libm_fma ? 1u : 0u, d_flag}, channels, d_desc64);
+}
+// test / self-test hook: out[i] = {atan2f(a[i], b[i]), cosf(a[i]), sinf(a[i])} as the device forms them (akz_libm.hpp)
+void libm_eval(hipStream_t s, const float* a, const float* b, float* out3, uint64_t n, bool fma, uint32_t* d_flag) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_libm_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out3, (size_t)n, fma ? 1u : 0u, d_flag);
 }
 uint32_t match_num_chunks(uint32_t n0, uint32_t n1) {
     const uint32_t qblocks = (n0 + MT - 1) / MT, tiles = std::max<uint32_t>(1, (n1 + MT - 1) / MT);

@@ -154,6 +154,9 @@ def lib():
         "akz_debug_rcp_f64_to_f32": ([vp, vp, vp, u64], i32),
         "akz_debug_kernel_rows": ([vp, vp, u32, vp, i32], i32),
         "akz_debug_gates": ([C.POINTER(vp), pu64], i32),
+        "akz_debug_device_libm": ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
+        "akz_debug_set_device_libm": ([vp, i32], i32),
+        "akz_debug_libm_eval": ([vp, vp, vp, vp, u64, i32], i32),
         "akz_ctx_calibrate_gates": ([vp, pu64, pu64, C.POINTER(C.c_double)], i32),
         "akz_op_pm_g2": ([vp, vp, vp, vp, u32, u32, u32, vp], i32),
         "akz_op_contrast_factor": ([vp, vp, u32, u32, u32, f64, f64, u64, vp], i32),
@@ -434,6 +437,24 @@ class Context:
         p = Profile()
         _check(lib().akz_ctx_get_profile2(self._h, C.byref(p), C.sizeof(Profile), int(reset)))
         return p.as_dict()
+
+    def debug_device_libm(self):
+        """akz_debug_device_libm -> (available, last_job): 0 = the host's libm, 1 / 2 = the device's FMA / SSE2 forms of glibc's
+        atan2f / cosf / sinf (csrc/akz_libm.hpp), proven equal to this process's libm by a self-test."""
+        a, b = C.c_int32(), C.c_int32()
+        _check(lib().akz_debug_device_libm(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def debug_set_device_libm(self, on):
+        """False: angles and their cosines / sines always from the host's libm; True / None: automatic."""
+        _check(lib().akz_debug_set_device_libm(self._h, 0 if on is False else -1))
+
+    def debug_libm_eval(self, a, b, fma=True):
+        """(atan2f(a, b), cosf(a), sinf(a)) per element as the device forms them: torch CUDA float32 tensors -> [n, 3]"""
+        import torch
+        out = torch.empty((a.numel(), 3), dtype=torch.float32, device=a.device)
+        _check(lib().akz_debug_libm_eval(self._h, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), int(bool(fma))))
+        return out
 
     def calibrate_gates(self):
         """akz_ctx_calibrate_gates: the two job gates from timings on this machine -> (sync_px, async_px, ms[5][4])"""

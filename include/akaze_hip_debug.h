@@ -45,6 +45,19 @@ int akz_debug_stream_placement(akz_ctx* ctx, int* info);
    end; tiny_pair_ms: 24 + 24 interleaved tiny kernels on the two streams (negative: not measured); tiny_alone_ms: 24 of
    them on one stream. */
 int akz_debug_placement_verdict(float spin_pair_ms, float tiny_pair_ms, float tiny_alone_ms, float spin_ms);
+/* The orientation's libm calls ON the device.  The reference's angle is atan2f of two sums, its descriptor pattern is rotated
+   by cosf / sinf of that angle -- the platform's libm, i.e. glibc's float routines on the machine the reference runs on.
+   csrc/akz_libm.hpp states those routines (glibc 2.35: fdlibm atan2f / atanf, sincosf.h in its FMA and SSE2 builds) as IEEE
+   arithmetic; a job whose keypoint selection ran on the device then needs no host round trip between orientation and
+   descriptors.  Used only where it is PROVEN equal: on x86-64, with the build glibc's own selector picks for this CPU, after
+   a self-test of ~2 million arguments of each function against the process's libm (once per process).
+   akz_debug_device_libm: *available = 0 (the host's libm is used), 1 (device, FMA build), 2 (device, SSE2 build); *last_job =
+   the same for the last finished job (0 also when that job's selection ran on the host).  akz_debug_set_device_libm(ctx, 0)
+   switches it off, (ctx, -1) back to automatic.  akz_debug_libm_eval: d_out3[3 i .. 3 i + 2] = atan2f(d_a[i], d_b[i]),
+   cosf(d_a[i]), sinf(d_a[i]) as the device forms them (fma != 0: the FMA build) -- NaN for |d_a[i]| >= 120. */
+int akz_debug_device_libm(akz_ctx* ctx, int* available, int* last_job);
+int akz_debug_set_device_libm(akz_ctx* ctx, int mode);
+int akz_debug_libm_eval(akz_ctx* ctx, const float* d_a, const float* d_b, float* d_out3, uint64_t n, int fma);
 /* The gate table (csrc/akz_gates.hpp): every size / host-thread threshold that chooses between two equivalent kernel families
    or paths -- name, value, what it counts, what lies on either side.  Results never depend on a gate.  *rows points at a
    static table of *n entries.  (big_px_sync / big_px_async are the compiled-in values; akz_ctx_calibrate_gates and

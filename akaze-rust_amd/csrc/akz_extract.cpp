@@ -986,6 +986,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         c->sel_last_fallback = 0;
     }
     bool sorted = false, dev_sel = false;
+    uint32_t mldb_spec = 0;  // keypoints the device's own descriptor launch covered
     int libm_dev = 0;        // 1 / 2: angles and descriptors were enqueued on the device behind the selection (device_libm_mode)
     bool dev_angles_ok = true;  // ... and every angle was one the device forms cover
     uint16_t* d_rel = nullptr;
@@ -1063,8 +1064,12 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                     void* blk = nullptr;
                     AKZ_TRY(slab_acquire(c, (size_t)cap * 64, &blk, &r->desc_block_bytes));
                     r->d_desc64 = (uint8_t*)blk;
-                    launch::mldb_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, cap, &((SelKpHost*)c->sel_recs.p)->sums, 2, libm_dev == 1,
-                                         nullptr, (uint32_t)cfg.descriptor_channels, r->d_desc64);
+                    // (the grid for as many keypoints as the last job had + 25 %, like the speculative fetch below: a list's capacity
+                    // is 3-15 x its keypoints, and 8 000 workgroups that find nothing to do cost 15 us; the rest, should there be
+                    // one, follows when the count is known)
+                    mldb_spec = std::min<uint32_t>(cap, c->last_total_kp.load() + c->last_total_kp.load() / 4 + 256u);
+                    launch::mldb_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, 0, mldb_spec, &((SelKpHost*)c->sel_recs.p)->sums, 2,
+                                         libm_dev == 1, nullptr, (uint32_t)cfg.descriptor_channels, r->d_desc64);
                     AKZ_HIP_TRY(hipGetLastError());
                 }
             }
@@ -1086,7 +1091,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
         if (dev_fetch) {  // the device's selection: two copies -- the headers (with the list's length, the contrast factors and the
                           // images' flags) and as many keypoints with their orientation sums as the last job had (+25 %)
             const uint32_t last = c->last_total_kp.load();
-            spec_kp = std::min<uint32_t>(cap, last + last / 4 + 256u);
+            spec_kp = libm_dev ? mldb_spec : std::min<uint32_t>(cap, last + last / 4 + 256u);  // (with the device's descriptors: exactly the keypoints their launch covered)
             AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 64));
             AKZ_HIP_TRY(hipMemcpyAsync(c->pin[8].p, d_sel_hdr, (size_t)n * 64, hipMemcpyDeviceToHost, s));
             AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec_kp * sizeof(SelKpHost)));
@@ -1168,6 +1173,11 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
             if (fallen) {
                 c->sel_skip = 8;
                 c->sel_skip_shape = shape;
+            }
+            if (dev_sel && libm_dev && total_kp > mldb_spec) {  // ... than the device's descriptor launch covered: the rest of them
+                launch::mldb_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, mldb_spec, (uint32_t)total_kp, &((SelKpHost*)c->sel_recs.p)->sums, 2,
+                                     libm_dev == 1, nullptr, (uint32_t)cfg.descriptor_channels, r->d_desc64);
+                AKZ_HIP_TRY(hipGetLastError());
             }
             if (dev_sel && total_kp > spec_kp) {  // more keypoints than last time: the rest
                 std::vector<uint8_t> keep_r((const uint8_t*)c->pin[0].p, (const uint8_t*)c->pin[0].p + (size_t)spec_kp * sizeof(SelKpHost));

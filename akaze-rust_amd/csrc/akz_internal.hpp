@@ -297,7 +297,8 @@ void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float*
 // the same with the keypoint count still on the device and the angle, cosf, sinf of every keypoint formed ON the device from
 // its orientation sums (akz_libm.hpp; d_sums[i * sums_stride]): the angle is left in d_sums[..].angle_bits, *d_flag is raised
 // if an argument is outside what the device forms cover
-void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t max_kp, OrientOut* d_sums,
+// (keypoints [first, min(last, *d_nkp)): the grid covers first .. last; first is rounded down to the kernel's group of four)
+void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t first, uint32_t last, OrientOut* d_sums,
                   uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64);
 void libm_eval(hipStream_t s, const float* a, const float* b, float* out3, uint64_t n, bool fma, uint32_t* d_flag);
 uint32_t match_num_chunks(uint32_t n0, uint32_t n1);

@@ -815,13 +815,14 @@ __device__ __forceinline__ float2 device_angle(const DeviceAngles& da, unsigned 
 }
 __global__ void __launch_bounds__(64 * MLDB_KPB)
 k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi, unsigned nkp, const unsigned* __restrict__ d_nkp,
-       DeviceAngles da, unsigned channels, uint8_t* __restrict__ desc64) {
+       DeviceAngles da, unsigned channels, uint8_t* __restrict__ desc64, unsigned first) {
     __shared__ float s_win[MLDB_KPB][3][MLDB_NS + 7];
     __shared__ float s_val[MLDB_KPB][3][32];
-    if (d_nkp) nkp = min(nkp, *d_nkp);  // (the count of a selection that ran on the device; nkp: what the grid was sized for)
+    if (d_nkp) nkp = min(nkp, *d_nkp);  // (the count of a selection that ran on the device; nkp: the last keypoint the grid covers)
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const unsigned kpi = xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB + wv;
-    if (xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB >= nkp) return;  // whole workgroup
+    const unsigned group0 = first + xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB;  // (first: a multiple of MLDB_KPB)
+    const unsigned kpi = group0 + wv;
+    if (group0 >= nkp) return;  // whole workgroup
     const bool live = kpi < nkp;
     KpParam kp = kps[live ? kpi : 0];
     const float2 cs = da.sums ? device_angle(da, live ? kpi : 0, live && lane == 0) : cosi[live ? kpi : 0];
@@ -889,7 +890,7 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
     // Cell sums: lanes 0..28 of wave 0 take the cells of the workgroup's keypoint 0, lanes 32..60 those of keypoint 1;
     // wave 1 keypoints 2 and 3 the same way (a wave that sums for one keypoint issues the same instructions for 29 lanes)
     const unsigned cl = lane & 31u, ckp = 2u * wv + (lane >> 5);  // cell and keypoint (of the workgroup) of this lane
-    if (wv < MLDB_KPB / 2 && cl < 29 && xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB + ckp < nkp) {
+    if (wv < MLDB_KPB / 2 && cl < 29 && group0 + ckp < nkp) {
         // cell ids 0..3: 2x2 grid (step 10), 4..12: 3x3 (step 7), 13..28: 4x4 (step 5)
         const int g = cl < 4 ? 0 : (cl < 13 ? 1 : 2);
         const int step = g == 0 ? 10 : (g == 1 ? 7 : 5), ng = g + 2;
@@ -1316,14 +1317,15 @@ void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float*
     const uint32_t groups = (nkp + MLDB_KPB - 1) / MLDB_KPB;
     hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp,
                        reinterpret_cast<const float2*>(d_cosi), nkp, (const unsigned*)nullptr, DeviceAngles{nullptr, 0u, 0u, nullptr}, channels,
-                       d_desc64);
+                       d_desc64, 0u);
 }
-void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t max_kp, OrientOut* d_sums,
+void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t first, uint32_t last, OrientOut* d_sums,
                   uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64) {
-    if (max_kp == 0) return;
-    const uint32_t groups = (max_kp + MLDB_KPB - 1) / MLDB_KPB;
-    hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp, (const float2*)nullptr, max_kp, d_nkp,
-                       DeviceAngles{d_sums, sums_stride, libm_fma ? 1u : 0u, d_flag}, channels, d_desc64);
+    first = first / MLDB_KPB * MLDB_KPB;
+    if (last <= first) return;
+    const uint32_t groups = (last - first + MLDB_KPB - 1) / MLDB_KPB;
+    hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp, (const float2*)nullptr, last, d_nkp,
+                       DeviceAngles{d_sums, sums_stride, libm_fma ? 1u : 0u, d_flag}, channels, d_desc64, first);
 }
 // test / self-test hook: out[i] = {atan2f(a[i], b[i]), cosf(a[i]), sinf(a[i])} as the device forms them (akz_libm.hpp)
 void libm_eval(hipStream_t s, const float* a, const float* b, float* out3, uint64_t n, bool fma, uint32_t* d_flag) {

@@ -1147,6 +1147,14 @@ def main_rank(args):
                                                              "output": si[7] / 100.0}}
             except Exception as e:
                 single["selection"] = {"error": str(e)[:200]}
+            try:  # where that call's angles (atan2f) and their cosines / sines came from (akz_debug_device_libm)
+                avail, last = ctx.debug_device_libm()
+                names = {0: "host libm (one host round trip between orientation and descriptors)",
+                         1: "device: glibc's atan2f + the FMA build of cosf / sinf as IEEE arithmetic, proven against this process's libm",
+                         2: "device: glibc's atan2f + the SSE2 build of cosf / sinf as IEEE arithmetic, proven against this process's libm"}
+                single["orientation_libm"] = {"available": names.get(avail, str(avail)), "this_call": names.get(last, str(last))}
+            except Exception as e:
+                single["orientation_libm"] = {"error": str(e)[:200]}
         # the same stream on ONE context with lanes: frames dealt to 2 .. 4 child contexts, each of which finishes its frames
         # on its own thread; the caller's thread only enqueues the next frames and collects results; lone 4K frames the same way
         def stream_eager(frame, lanes, reps_e):

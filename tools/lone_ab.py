@@ -2,7 +2,7 @@
 """Lone frames (BASELINE configs[1] taken literally), A/B over schedule keys in ONE process: latency of a synchronous call,
 ms per streamed frame (next frame begun before this one is finished), GPU time of the begin chain.
     python tools/lone_ab.py [W H] -- variants are akz_debug_set_schedule settings ("name:key=value,...";
-key "select": akz_debug_set_select), alternated three times."""
+key "select": akz_debug_set_select, key "libm": akz_debug_set_device_libm), alternated three times."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "akaze-rust_amd", "python"))
 import numpy as np, torch
@@ -19,12 +19,13 @@ ctx.warmup()
 VARIANTS = [("default", {})]
 for extra in sys.argv[3:]:
     name, _, kv = extra.partition(":")
-    VARIANTS.append((name, {(k if k == "select" else int(k)): int(v) for k, v in (x.split("=") for x in kv.split(",") if x)}))
+    VARIANTS.append((name, {(k if k in ("select", "libm") else int(k)): int(v) for k, v in (x.split("=") for x in kv.split(",") if x)}))
 def setv(d):
-    KEYS = sorted({k for _, dd in VARIANTS for k in dd if k != "select"})
+    KEYS = sorted({k for _, dd in VARIANTS for k in dd if k not in ("select", "libm")})
     for k in KEYS:
         ctx.debug_set_schedule(k, d.get(k, 0))
     ctx.debug_set_select(d.get("select"))  # (akz_debug_set_select: 2 device, 1 host from the neighbour lists, 0 grids; absent: automatic)
+    ctx.debug_set_device_libm(d.get("libm", 1) != 0)  # ("libm=0": angles, cosines and sines from the host's libm; default: on the device where proven)
 def measure():
     for _ in range(10):
         ctx.extract_begin(frame, cfg).finish().close()

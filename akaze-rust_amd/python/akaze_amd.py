@@ -854,7 +854,11 @@ class ExtractResult:
         return p.value, n.value
 
     def copy_device_descriptors(self, dst):
-        """D2D copy of every image's 64-byte descriptor rows into the torch CUDA uint8 tensor dst [rows, 64]."""
+        """D2D copy of every image's 64-byte descriptor rows into the torch CUDA uint8 tensor dst [rows, 64].  The copy runs on a
+        stream of the context's own and is complete on return; what torch itself still has queued for `dst` (the fill of a
+        torch.zeros) is waited for first, or it could land after the copy."""
+        import torch
+        torch.cuda.current_stream(dst.device).synchronize()
         n = C.c_uint64()
         _check(lib().akz_result_copy_device_descriptors(self._h, C.c_void_p(dst.data_ptr()), dst.shape[0],
                                                         C.byref(n)))

@@ -72,7 +72,8 @@ def test_angles_and_descriptors_without_the_host_round_trip(ctx, amd, ref, w, h,
             assert np.array_equal(dev.descriptors(img), host.descriptors(img))
             assert dev2.keypoints(img).tobytes() == kh.tobytes()
             total = sum(dev2.counts(i)[1] for i in range(n))
-            allrows = torch.zeros((total, 64), dtype=torch.uint8, device="cuda")
+            allrows = torch.empty((total, 64), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()   # (the copy runs on a stream of the context's own: nothing of torch's may still be writing the buffer)
             dev2.copy_device_descriptors(allrows)
             first = sum(dev2.counts(i)[1] for i in range(img))
             rows = allrows[first:first + len(kh)].cpu().numpy()

@@ -129,6 +129,15 @@ def test_fails_loudly_without_gpu(amd):
     assert e.value.status == -3 and "no CPU fallback" in str(e.value)
 
 
+def test_design_gate_table_is_the_librarys(amd):
+    """DESIGN.md 6.1 is rendered from the library's own gate table (csrc/akz_gates.hpp through akz_debug_gates)"""
+    p = subprocess.run([__import__("sys").executable, os.path.join(ROOT, "tools", "render_gates.py"), "--check"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    names = [g["name"] for g in amd.gates()]
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert all(f"`{n}`" in design for n in names) and len(names) >= 12
+
+
 def test_isa_has_no_contracted_fma():
     """Bit-exact parity needs un-fused mul/add in the image arithmetic (tools/isa_audit.py)."""
     pkg = os.path.join(ROOT, "akaze-rust_amd")

@@ -27,6 +27,7 @@ while time.time() - t0 < budget:
     kw = {}
     if rng.integers(0, 3) == 0: kw["detector_threshold"] = float(10.0 ** rng.uniform(-6.5, -2.5))
     if rng.integers(0, 4) == 0 and min(w, h) >= 200: kw.update(num_sublevels=int(rng.integers(2, 6)), max_octave_evolution=int(rng.integers(2, 5)))
+    if rng.integers(0, 5) == 0: kw["descriptor_channels"] = int(rng.integers(1, 4))
     cfg = A.Config(**kw)
     dev = torch.from_numpy(np.stack(frames)).cuda()
     c.debug_set_select(1)

@@ -438,7 +438,7 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
 }
 const char* akz_detector_kernel_name(void) { return "detector (k_detector_march + k_detector_tiled)"; }
 int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
-    if (!c || key < 0 || key > 5) return AKZ_ERR_INVALID_ARG;
+    if (!c || key < 0 || key > 6) return AKZ_ERR_INVALID_ARG;
     AKZ_TRY(bind(c));
     c->sched[key] = value;
     if (key == 4) {

@@ -64,9 +64,7 @@ struct DevBuf {
 //   2 x 1080p      1.42 / 1.51           0.90 / 0.78
 //   3 x 1080p      1.76 / 1.78           1.09 / 0.92
 //   1 x 4K         2.65 / 2.40           1.50 / 1.37
-// The batch path is the more efficient use of the chip from 3 Mpx on, but its forked chain and resident tail end later when
-// nothing else is in flight: a SYNCHRONOUS call (akz_extract_*: its latency is all the caller sees) takes it from 6 Mpx, a job
-// of the begin / finish interface (a caller that keeps jobs in flight) from 3 Mpx.
+// Which jobs take the batch path (column marches, forked coarse chain, resident tail) is decided by job size per entry point:
 // (the two values: akz_gates.hpp, gates::kBigPxSync / kBigPxAsync)
 // The finish half of a lane's jobs on a thread of the library (akz_ctx_set_eager_finish): started by begin, so that the
 // candidate round trip, the host keypoint logic and the keypoint kernels of frame i run while the caller's thread
@@ -174,7 +172,7 @@ struct akz_ctx {
     // placement probe found it a queue and a pipe of its own (below), 1 the copy stream regardless, 2 a stream of their own
     // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
     // has finished its fine-level diffusion (default) or not; [2] no placement probe
-    int sched[6] = {0, 1, 0, 0, 0, 0};
+    int sched[7] = {0, 1, 0, 0, 0, 0, 0};
     uint64_t big_px = gates::kBigPxAsync;  // the gate of the job being begun (set by extract_begin from the two below; the begin half's helpers read it)
     uint64_t big_px_sync = gates::kBigPxSync, big_px_async = gates::kBigPxAsync;  // (sched[4] sets both: measurement)
     // pixels per LAUNCH (level w*h*n) from which the blur, the contrast passes and the detectors take their column-march
@@ -399,8 +397,9 @@ AKZ_LOCAL int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t 
 AKZ_LOCAL uint32_t fed_max_fuse(const akz_ctx* c, uint32_t w, uint32_t h, uint32_t n);
 AKZ_LOCAL uint32_t fed_num_launches(const akz_ctx* c, uint32_t n_tau, uint32_t w, uint32_t h, uint32_t n);
 AKZ_LOCAL float* fed_dst(uint32_t launches, uint32_t k /*1-based*/, float* A, float* B);
+// next / next_done: the last launch may also prepare the NEXT level (launch::fed_fused's epilogue); *next_done says whether it did
 AKZ_LOCAL int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float* lflow, float* lstep, uint32_t w, uint32_t h, uint32_t n,
-             const double* taus, uint32_t n_tau);
+             const double* taus, uint32_t n_tau, const launch::FedNextPrep* next = nullptr, bool* next_done = nullptr);
 AKZ_LOCAL int detector_family(const akz_ctx* c, uint32_t sigma, uint32_t w, uint32_t h, uint32_t n, float border_m, bool keep_second,
                     bool nms = true);
 AKZ_LOCAL int detector_impl(akz_ctx* c, const float* lsmooth, uint32_t sigma, float* lx, float* ly, float* lxx, float* lyy, float* lxy,

@@ -511,6 +511,17 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         hipStream_t main;
         ~StreamRestore() { c->stream = main; }
     } stream_restore{c, s};
+    // Jobs below gates::kTiledPrepPx take the TILED preparation family whatever their launches' sizes -- k_blur, k_contrast_max /
+    // _hist, k_prep riding on the previous level's last k_fed_own launch, no resident tail: since that epilogue exists the
+    // chain of few-microsecond launches beats the streaming kernels and k_level_march up to ~8 Mpx per job (profiles/
+    // r06_lone_libm.txt: 2-6 x 1080p, 4-8 x 720p, lone 2-5 Mpx frames 3-9 % faster per call, 0-9 % as a stream).  The helpers
+    // read c->prep_mode: it is swapped for the duration of this begin half (only the automatic mode 2 is overridden).
+    struct PrepModeRestore {
+        akz_ctx* c;
+        int mode;
+        ~PrepModeRestore() { c->prep_mode = mode; }
+    } prep_mode_restore{c, c->prep_mode};
+    if (c->prep_mode == 2 && c->sched[6] == 0 && (uint64_t)w * h * n < gates::kTiledPrepPx) c->prep_mode = 0;
     bool early = false;
     const bool big = (uint64_t)w * h * n >= c->big_px;
     c->launch_min_px = big ? std::min<uint64_t>(akz_ctx::kLaunchMarchPx, (uint64_t)w * h * n) : akz_ctx::kLaunchMarchPx;
@@ -610,6 +621,18 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
             detector_family(c, plan[l].det_sigma, plan[l].w, plan[l].h, n, border_margin(plan[l], cfg), keep_all) == 5 && detector_one_pass(l, ls))
             det_done[l] = 1;
     };
+    // prepared[l]: level l's Lsmooth and Lflow have been written by the last diffusion launch of level l - 1 (k_fed_own's epilogue)
+    std::vector<char> prepared(L + 1, 0);
+    const uint64_t level_min_px = gates::kLevelMarchPx;
+    auto takes_level_march = [&](size_t l) {
+        return !plan[l].tau.empty() && c->fed_mode == 2 && launch::level_march_supported(plan[l].w, plan[l].h) &&
+               (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)plan[l].w * plan[l].h * n >= level_min_px));
+    };
+    auto takes_stream_prep = [&](size_t l) {
+        const bool half_l = plan[l].octave > plan[l - 1].octave;
+        return c->prep_mode != 0 && launch::prep_stream_supported(plan[l].w, plan[l].h) &&
+               (c->prep_mode == 1 || (c->prep_mode >= 2 && !half_l && (uint64_t)plan[l].w * plan[l].h * n >= c->stream_min_px));
+    };
     auto run_levels = [&](size_t lo, size_t hi) -> int {
     for (size_t i = lo; i < hi; ++i) {
         const LevelPlan& lv = plan[i];
@@ -657,9 +680,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         // 12 + 12 (+4); a new octave's 2x2 mean is materialised first.  Remaining steps follow in k_fed_own launches.
         // (from 4 Mpx per launch -- the third octave of a 32-frame 1080p batch -- on: one launch less per level in the
         // coarse chain that runs next to the fine detectors, +1.0 % throughput, measured 4 x 80 steps each way)
-        const uint64_t level_min_px = gates::kLevelMarchPx;
-        const bool fuse_level = n_tau >= 1 && c->fed_mode == 2 && launch::level_march_supported(lv.w, lv.h) &&
-                                (c->prep_mode == 3 || (c->prep_mode == 2 && (uint64_t)lv.w * lv.h * n >= level_min_px));
+        const bool fuse_level = takes_level_march(i);
         if (fuse_level) {
             const uint32_t n1 = std::min<uint32_t>(n_tau, 4u), rem = n_tau - n1;
             const uint32_t rest = rem ? fed_num_launches(c, rem, lv.w, lv.h, n) : 0;
@@ -701,27 +722,34 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         // (Preparation + the first eight diffusion steps as ONE tiled launch -- k_prep and k_fed_own fused, tile + halo 8 + 2 --
         // was built and measured in round 3: 20 us per launch at best against 6-8 + 8-10 for the pair (the preparation then runs
         // on the whole diffusion region, 2.3 x the tile); a lone 1080p frame 0.59 -> 0.86 ms, batches -1 ... -4 %.  Removed.)
-        {
+        if (!prepared[i]) {
             StageTimer st(c, AKZ_ST_PREP);
             // measured on MI355X: the streaming kernel is ~2x faster for cloned levels of a batch (a single
             // frame is launch-latency bound and stays on the tiled kernel); for the first
             // level of an octave (2x2 mean of a 4x larger input) the two are equal, the tiled one stays
-            const bool stream_prep = c->prep_mode != 0 && launch::prep_stream_supported(lv.w, lv.h) &&
-                                     (c->prep_mode == 1 || (c->prep_mode >= 2 && !half && (uint64_t)lv.w * lv.h * n >= c->stream_min_px));
+            const bool stream_prep = takes_stream_prep(i);
             if (stream_prep)
                 launch::prep_stream(ls, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
                                     pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
             else
                 launch::prep_fused(ls, P(i - 1, AKZ_LT), half, half_buf, P(i, AKZ_LSMOOTH), P(i, AKZ_LFLOW), lv.w, lv.h,
                                    pv.w, pv.h, n, g1.data(), r->d_k, lv.octave);
-            float* lstep0 = keep_all ? P(i, AKZ_LSTEP) : nullptr;
-            if (lstep0 && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(lstep0, 0, plane_bytes(lv.w, lv.h, n), ls));
         }
+        if (keep_all && n_tau == 0) AKZ_HIP_TRY(hipMemsetAsync(P(i, AKZ_LSTEP), 0, plane_bytes(lv.w, lv.h, n), ls));
         {
+            // The next level of the octave starts from this level's final Lt: where it would take the tiled preparation
+            // (k_prep), the last diffusion launch of this level writes its Lsmooth and Lflow as well -- one dependent launch
+            // less per level of a lone frame's chain (sched[6] = 1: a launch of its own, as before)
+            launch::FedNextPrep np{};
+            const bool ride = c->sched[6] == 0 && c->fed_mode == 2 && i + 1 < L && i + 1 != res_first && plan[i + 1].octave == lv.octave &&
+                              !takes_level_march(i + 1) && !takes_stream_prep(i + 1);
+            if (ride) np = launch::FedNextPrep{P(i + 1, AKZ_LSMOOTH), P(i + 1, AKZ_LFLOW), g1.data(), r->d_k, plan[i + 1].octave};
+            bool rode = false;
             StageTimer st(c, AKZ_ST_FED);
             st.kernel(AKZ_KR_FED_OWN, n_tau, lv.w, lv.h, n, fed_num_launches(c, n_tau, lv.w, lv.h, n), 0, (uint64_t)lv.w * lv.h * n * n_tau);
             AKZ_TRY(fed_impl(c, fed_in, A, B, P(i, AKZ_LFLOW), keep_all ? P(i, AKZ_LSTEP) : nullptr, lv.w, lv.h, n,
-                             lv.tau.data(), n_tau));
+                             lv.tau.data(), n_tau, ride ? &np : nullptr, &rode));
+            prepared[i + 1] = rode ? 1 : 0;
         }
     }
     return AKZ_OK;
@@ -958,8 +986,13 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // cost the kernels of the next batch more than the idle host threads gain.
     // (... and for images of 6 Mpx and more, whose sequential selection -- 1.4 ms per 4K frame on the grids -- is the longest
     // single piece of a synchronous call)
+    // (... and for the job that is WAITED FOR, and for jobs of fewer images than the host's selection needs threads: the host
+    // walks one image per thread, which a stream hides and a call does not -- a lone 3-6 Mpx frame on the batch path spent
+    // 0.5 ms on the grids, 1.93 against 1.29 ms per call either side of 6 Mpx; 4 x 1080p per call 2.07 against 1.75)
+    // (a lane's jobs run next to the other lanes': part of a stream)
+    const bool waited_for = !c->is_lane && job->alone_at_begin;
     const bool want_rel = c->dbg_select == 1 || (c->dbg_select < 0 && (c->pool().size() < gates::kFewHostThreads || (uint64_t)r->w * r->h * n < r->big_px ||
-                                                                        (uint64_t)r->w * r->h >= gates::kSelectDevicePx));
+                                                                        (uint64_t)r->w * r->h >= gates::kSelectDevicePx || n < gates::kFewHostThreads || waited_for));
     // The selection ITSELF on the device (round 5; akz_select.hpp, launch::select_device): the order-dependent walk as
     // dependency rounds over the same neighbour lists, one workgroup per image, and the orientation sums right behind it on
     // the keypoints it leaves -- the host neither fetches the candidate list nor selects, and one of the two round trips of
@@ -970,8 +1003,6 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // next job's kernels frees only at their ends (pairs of 4K frames streamed: 2.9 ms per pair with the host's selection,
     // 4.4 with the device's; the synchronous pair 4.3 -> 3.7 ms, a lone 4K frame 2.06 -> 1.81 ms, a lone 1080p frame
     // 0.98 -> 0.95 ms)
-    // (a lane's jobs run next to the other lanes': part of a stream as well)
-    const bool waited_for = !c->is_lane && job->alone_at_begin;
     // (a job whose lists overflowed went back to the host's selection after the device's attempt: the next eight jobs of that
     // shape do not try -- dense texture stays dense)
     const uint64_t shape = ((uint64_t)r->w << 40) | ((uint64_t)r->h << 16) | n;
@@ -1662,7 +1693,7 @@ int akz_extract_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t
     return extract_impl<float>(c, d_imgs, w, h, n, cfg, flags, out);
 }
 
-// lanes = 1 (default): every job runs on the context's own stream.  lanes = k > 1: jobs below the batch-path gate (3 Mpx) are dealt to k child
+// lanes = 1 (default): every job runs on the context's own stream.  lanes = k > 1: jobs below the batch-path gate (gates::kBigPxAsync) are dealt to k child
 // contexts in turn (larger jobs fill the chip on their own and stay on the context).  A job's result belongs to the
 // lane it ran on; nothing else changes for the caller (same begin / finish / result calls, bit-identical results).
 int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
@@ -1873,7 +1904,7 @@ int akz_ctx_graph_probe(akz_ctx* c, const uint8_t* d_imgs, uint32_t w, uint32_t 
     AKZ_TRY(bind(c));
     if (!d_imgs || !cfg || !ms_graph || !ms_plain || reps == 0) return AKZ_ERR_INVALID_ARG;
     if ((uint64_t)w * h * n >= c->big_px_async) {  // such a batch forks its coarse chain and completes on that stream: not one capture
-        set_error("akz_ctx_graph_probe: jobs of 3 Mpx and more fork onto a second stream and cannot be captured from one");
+        set_error("akz_ctx_graph_probe: jobs that take the batch path fork onto a second stream and cannot be captured from one");
         return AKZ_ERR_INVALID_ARG;
     }
     const int prof = c->profiling;

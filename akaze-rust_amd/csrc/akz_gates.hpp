@@ -16,11 +16,17 @@ namespace akz {
 namespace gates {
 
 // ---- which path a JOB takes (w * h * n input pixels) ----
-// The batch path -- column-march kernels, forked coarse chain, resident tail -- uses the chip better from ~3 Mpx on but ends
-// later when nothing else is in flight: a synchronous call takes it later than a job of the begin / finish interface.
-constexpr uint64_t kBigPxSync = 6000000;    // akz_extract_*           (lone 4K 2.68 -> 2.38 ms, r05_job_gate.txt)
-constexpr uint64_t kBigPxAsync = 3000000;   // akz_extract_begin_*     (2016x1512 streamed 0.77 -> 0.67 ms)
-                                            // (akz_ctx_set_lanes deals the jobs below kBigPxAsync to its lanes)
+// The batch path -- column-march kernels on launches that are large enough, forked coarse chain, resident tail -- against the
+// chain of tiled launches on one stream.  Rounds 4-5 had the gate at 6 Mpx for a synchronous call and 3 Mpx for a job of the
+// begin / finish interface; round 6 found why a call liked the batch path so much later than a stream: its keypoint
+// selection ran on the host's grids (one thread per image), which a stream hides and a call does not.  With the selection of
+// the job that is waited for on the device, the batch path wins from ~2.4 Mpx on through both entry points (at 1 x 1080p and
+// 2 x 720p the two are equal): profiles/r06_job_gates.txt.  Two constants remain because akz_ctx_calibrate_gates measures both.
+constexpr uint64_t kBigPxSync = 2400000;    // akz_extract_*
+constexpr uint64_t kBigPxAsync = 2400000;   // akz_extract_begin_*  (akz_ctx_set_lanes deals the jobs below it to its lanes)
+constexpr uint64_t kTiledPrepPx = 8000000;  // jobs below this: the tiled preparation family for every launch (k_blur, k_contrast_max /
+                                            // _hist, k_prep riding on k_fed_own's last launch, no resident tail) whatever the
+                                            // per-launch gates below say (r06_lone_libm.txt)
 // ---- which kernel family a LAUNCH takes (level w * h * n pixels) ----
 constexpr uint64_t kMarchPx = 8u << 20;     // blur / contrast / detector marches instead of the tiled kernels (also every
                                             // full-resolution launch of a batch-path job, whatever its size)
@@ -39,8 +45,9 @@ constexpr uint32_t kPremergeChunks = 4;             // more train chunks than th
 // the table akz_debug_gates() returns: name, value, unit, what lies on either side
 inline const akz_gate* table(size_t* n) {
     static const akz_gate rows[] = {
-        {"big_px_sync", (double)kBigPxSync, "input px per job", "synchronous akz_extract_*: tiled / streaming kernels on one stream below, the batch path (marches, forked coarse chain, resident tail) from here on"},
+        {"big_px_sync", (double)kBigPxSync, "input px per job", "synchronous akz_extract_*: the chain of tiled launches on one stream below, the batch path (forked coarse chain; marches and resident tail where tiled_prep_px and the per-launch gates allow) from here on"},
         {"big_px_async", (double)kBigPxAsync, "input px per job", "akz_extract_begin_*: the same choice for a job of the begin / finish interface; akz_ctx_set_lanes deals the jobs below it to its lanes"},
+        {"tiled_prep_px", (double)kTiledPrepPx, "input px per job", "below: the tiled preparation family for every launch of the job (level-0 blur, contrast passes, k_prep as an epilogue of the previous level's last k_fed_own launch, no resident tail); from here on the per-launch gates below decide"},
         {"march_px", (double)kMarchPx, "level px per launch", "k_blur5_march / k_contrast_march / k_detector_march instead of the tiled kernels (batch-path jobs: their full-resolution launches regardless)"},
         {"level_march_px", (double)kLevelMarchPx, "level px per launch", "k_level_march instead of k_prep + k_fed_own"},
         {"stream_px", (double)kStreamPx, "level px per launch", "k_prep_stream / k_blur5_stream instead of the tiled k_prep / k_blur"},

@@ -150,8 +150,18 @@ void flow(hipStream_t s, const float* lsmooth, float* lflow, uint32_t w, uint32_
 void fed_step(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
               uint32_t h, uint32_t n, float half_tau);
 // n_steps <= 16 explicit steps in one launch of k_fed_own (LDS tile + register ownership, temporally fused)
-void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
-               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps);
+// next != NULL: the launch also writes the NEXT level's Lsmooth and Lflow from this level's final Lt (k_fed_own's epilogue;
+// only where fed_epilogue_supported says so)
+struct FedNextPrep {
+    float* lsmooth;
+    float* lflow;
+    const float* g3;     // gaussian_kernel(1.0, 3)
+    const double* d_k;
+    uint32_t k_pow;
+};
+bool fed_epilogue_supported(uint32_t w, uint32_t h, uint32_t n_steps);
+void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w, uint32_t h,
+               uint32_t n, const float* half_taus, uint32_t n_steps, const FedNextPrep* next = nullptr);
 // workgroups of a 9..16-step launch (64 x 10 tiles)
 uint64_t fed_deep_workgroups(uint32_t w, uint32_t h, uint32_t n);
 void contrast_max(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n,

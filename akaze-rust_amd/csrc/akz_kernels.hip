@@ -10,6 +10,7 @@
 #include "akz_internal.hpp"
 #include "akz_pm_g2.hpp"
 #include "akz_libm.hpp"
+#include "akz_prep_passes.hpp"
 
 namespace akz {
 namespace {
@@ -213,20 +214,37 @@ __device__ __forceinline__ float from_right_lane(float v) {  // lane i receives 
 #ifndef AKZ_FED_WAVES
 #define AKZ_FED_WAVES 6  // 80 VGPRs: three 512-thread workgroups per CU instead of two (+9 % on the FED launches); 8 would spill
 #endif
-template <int TW, int TH, int HALO, int NT>
+// EPI: the NEXT level's preparation as an epilogue of this level's last diffusion launch (a lone frame's chain is ~45
+// dependent launches of 6-16 us, most of which is what a launch costs at that size, not its work: profiles/r06_lone_libm.txt).
+// The next level of the same octave starts from this level's final Lt (a clone, lib.rs:92) and its Lsmooth / Lflow need that
+// plane two pixels beyond the tile: the region carries n + 2 halo rows (and HALO >= n + 2 columns) for the n steps, so the final
+// values are exact on the tile + 2; they go into an LDS window and akz_prep_passes.hpp -- the same four passes as k_prep's --
+// writes the next level's Lsmooth and Lflow.  The host uses it only where no tile has a single in-image row or column
+// ((w - 1) % TW != 0, (h - 1) % TH != 0: the passes' clamped reads then stay inside the window).
+struct FedEpi {
+    float* lsmooth;      // of the NEXT level
+    float* lflow;
+    PrepTaps taps;
+    const double* d_k;   // contrast factors of octave 0, per image
+    unsigned k_pow;      // octave of the next level (= this one's)
+};
+template <int TW, int TH, int HALO, int NT, bool EPI = false>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(AKZ_FED_WAVES, AKZ_FED_WAVES)))
 k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __restrict__ L_out,
-          float* __restrict__ Lstep, int w, int h, FedTaus ht) {
+          float* __restrict__ Lstep, int w, int h, FedTaus ht, FedEpi ep) {
     constexpr int RW = TW + 2 * HALO;    // region width in pixels (multiple of 4)
     constexpr int XG = RW / 4;           // float4 group columns
     constexpr int RP = RW + 8;           // LDS pitch: 4 pad floats on each side
     constexpr int RHMAX = TH + 2 * HALO;
     constexpr int PLANE = (RHMAX + 2) * RP;  // one pad row above and below
     static_assert(XG * (RHMAX / 2) <= NT, "one thread per pair of region rows and group column");
-    __shared__ __attribute__((aligned(16))) float sA[PLANE];
-    __shared__ __attribute__((aligned(16))) float sB[PLANE];
+    static_assert(PLANE % 4 == 0, "the second plane stays 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) float sAB[2 * PLANE];
+    float* const sA = sAB;
+    float* const sB = sAB + PLANE;
     const int tid = threadIdx.x;
-    const int n = ht.n;
+    const int steps = ht.n;
+    const int n = steps + (EPI ? 2 : 0);  // halo rows: the steps, plus two for the epilogue's window (host: n <= HALO)
     const int RH = TH + 2 * n;  // even
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
@@ -323,7 +341,7 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
     float* src = sA;
     float* dst = sB;
     v2 ST[4] = {v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}, v2{0.f, 0.f}};
-    for (int s = 1; s <= n; ++s) {
+    for (int s = 1; s <= steps; ++s) {
         const float half_tau = ht.half_tau[s - 1];
         // left / right neighbours from the adjacent lanes (same row pair, neighbouring group column);
         // the first / last lane of a wave and region edges fall back to LDS (edge values are never used)
@@ -372,7 +390,7 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
                 L[i] = L[i] + ST[i];
             }
         }
-        if (s < n) {
+        if (s < steps) {
             if (active) {
                 *reinterpret_cast<float4*>(dst + oa) = make_float4(L[0].x, L[1].x, L[2].x, L[3].x);
                 *reinterpret_cast<float4*>(dst + ob) = make_float4(L[0].y, L[1].y, L[2].y, L[3].y);
@@ -387,26 +405,53 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
     const float sta[4] = {ST[0].x, ST[1].x, ST[2].x, ST[3].x}, stb[4] = {ST[0].y, ST[1].y, ST[2].y, ST[3].y};
 
     // ---- centre groups go straight to HBM ----
-    if (!active || gx < x0 || gx >= x0 + TW) return;
+    if (active && gx >= x0 && gx < x0 + TW) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int ly = r == 0 ? lya : lyb, gy = r == 0 ? gya : gyb;
-        if (ly < n || ly >= n + TH || gy >= h || gx >= w) continue;
-        const float* v = r == 0 ? la : lb;
-        const float* st = r == 0 ? sta : stb;
-        float* po = L_out + base + (size_t)gy * w;
-        float* ps = Lstep ? Lstep + base + (size_t)gy * w : nullptr;
-        if (vec_ok && gx + 3 < w) {
-            plane_store4(po + gx, v[0], v[1], v[2], v[3]);
-            if (ps) plane_store4(ps + gx, st[0], st[1], st[2], st[3]);
-        } else {
+        for (int r = 0; r < 2; ++r) {
+            const int ly = r == 0 ? lya : lyb, gy = r == 0 ? gya : gyb;
+            if (ly < n || ly >= n + TH || gy >= h || gx >= w) continue;
+            const float* v = r == 0 ? la : lb;
+            const float* st = r == 0 ? sta : stb;
+            float* po = L_out + base + (size_t)gy * w;
+            float* ps = Lstep ? Lstep + base + (size_t)gy * w : nullptr;
+            if (vec_ok && gx + 3 < w) {
+                plane_store4(po + gx, v[0], v[1], v[2], v[3]);
+                if (ps) plane_store4(ps + gx, st[0], st[1], st[2], st[3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (gx + e < w) {
-                    plane_store(po + gx + e, v[e]);
-                    if (ps) plane_store(ps + gx + e, st[e]);
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (gx + e < w) {
+                        plane_store(po + gx + e, v[e]);
+                        if (ps) plane_store(ps + gx + e, st[e]);
+                    }
+            }
         }
+    }
+    if constexpr (EPI) {
+        // ---- the next level's preparation from the final values on the tile + 2 ----
+        constexpr int IW = TW + 4, IH = TH + 4;
+        static_assert(IH * IW + (TH + 4) * (TW + 2) + (TH + 2) * (TW + 2) <= 2 * PLANE, "the preparation's windows fit the two planes");
+        float* const wI = sAB;                        // input window, origin (x0 - 2, y0 - 2)
+        float* const wA = wI + IH * IW;
+        float* const wB = wA + (TH + 4) * (TW + 2);
+        __syncthreads();  // (the last step's neighbour reads of the planes are done)
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int gy = r == 0 ? gya : gyb;
+                const int wy = gy - (y0 - 2);
+                if (wy < 0 || wy >= IH || gy < 0 || gy >= h) continue;
+                const float* v = r == 0 ? la : lb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int wx = gx + e - (x0 - 2);
+                    if (wx >= 0 && wx < IW && gx + e >= 0 && gx + e < w) wI[wy * IW + wx] = v[e];
+                }
+            }
+        }
+        __syncthreads();
+        const double kc = octave_contrast(ep.d_k[blockIdx.z], ep.k_pow);
+        prep_passes<TW, TH, NT>(wI, wA, wB, x0, y0, w, h, base, ep.lsmooth, ep.lflow, ep.taps, 1.0 / (kc * kc));
     }
 }
 
@@ -1227,13 +1272,37 @@ constexpr int kFedDeepTh = 10;
 uint64_t fed_deep_workgroups(uint32_t w, uint32_t h, uint32_t n) {
     return (uint64_t)((w + 63) / 64) * ((h + kFedDeepTh - 1) / kFedDeepTh) * n;
 }
+// Can the next level's preparation ride on a diffusion launch of n_steps steps over w x h (k_fed_own<.., EPI>)?  The region
+// needs n_steps + 2 halo rows and columns inside the template's HALO, and no tile may have a single in-image row or column.
+bool fed_epilogue_supported(uint32_t w, uint32_t h, uint32_t n_steps) {
+    if (n_steps == 0 || n_steps > 14 || w < 8 || h < 8 || (w - 1) % 64 == 0) return false;
+    const uint32_t th = n_steps <= 6 ? 32u : (uint32_t)kFedDeepTh;
+    return (h - 1) % th != 0;
+}
 void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_out, float* lstep, uint32_t w,
-               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps) {
+               uint32_t h, uint32_t n, const float* half_taus, uint32_t n_steps, const FedNextPrep* next) {
     constexpr int TW = 64, TH = 32, NT = 512;
     FedTaus ht;
     ht.n = (int)n_steps;
     for (uint32_t i = 0; i < 16; ++i) ht.half_tau[i] = i < n_steps ? half_taus[i] : 0.0f;
     const dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
+    FedEpi ep{};
+    if (next) {  // (the caller has asked fed_epilogue_supported)
+        const Taps m = taps_scharr_main(1);
+        ep.lsmooth = next->lsmooth;
+        ep.lflow = next->lflow;
+        ep.taps = PrepTaps{next->g3[0], next->g3[1], next->g3[2], m.wgt[0], m.wgt[1]};
+        ep.d_k = next->d_k;
+        ep.k_pow = next->k_pow;
+        if (n_steps <= 6) {
+            hipLaunchKernelGGL((k_fed_own<TW, TH, 8, NT, true>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w, (int)h, ht, ep);
+        } else {
+            const dim3 g10((w + TW - 1) / TW, (h + kFedDeepTh - 1) / kFedDeepTh, n);
+            hipLaunchKernelGGL((k_fed_own<TW, kFedDeepTh, 16, NT, true>), g10, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w, (int)h, ht,
+                               ep);
+        }
+        return;
+    }
     {
         if (n_steps <= 4) {
             // halo 4: a 64 x 48 tile gives 18 x 27 (n = 3) or 18 x 28 (n = 4) owner threads of 512; 64 x 32 only 342 / 360
@@ -1241,19 +1310,19 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
             if (h >= 48) {
                 const dim3 g48((w + TW - 1) / TW, (h + 47) / 48, n);
                 hipLaunchKernelGGL((k_fed_own<TW, 48, 4, NT>), g48, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
-                                   (int)h, ht);
+                                   (int)h, ht, ep);
             } else
                 hipLaunchKernelGGL((k_fed_own<TW, TH, 4, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
-                                   (int)h, ht);
+                                   (int)h, ht, ep);
         } else if (n_steps <= 8)
             hipLaunchKernelGGL((k_fed_own<TW, TH, 8, NT>), grid, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep, (int)w,
-                               (int)h, ht);
+                               (int)h, ht, ep);
         else {
             // up to 16 steps on 64 x 10 tiles (region 96 x 42: 6.3 x the tile, so only where a launch is a handful of
             // workgroups at the floor of a dependent dispatch and halving the launches is what counts)
             const dim3 g10((w + TW - 1) / TW, (h + kFedDeepTh - 1) / kFedDeepTh, n);
             hipLaunchKernelGGL((k_fed_own<TW, kFedDeepTh, 16, NT>), g10, dim3(NT), 0, s, lt_in, lflow, lt_out, lstep,
-                               (int)w, (int)h, ht);
+                               (int)w, (int)h, ht, ep);
         }
     }
 }

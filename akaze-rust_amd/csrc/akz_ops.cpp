@@ -141,7 +141,8 @@ float* fed_dst(uint32_t launches, uint32_t k /*1-based*/, float* A, float* B) {
     return ((launches - k) % 2 == 0) ? A : B;
 }
 int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float* lflow, float* lstep, uint32_t w,
-                    uint32_t h, uint32_t n, const double* taus, uint32_t n_tau) {
+                    uint32_t h, uint32_t n, const double* taus, uint32_t n_tau, const launch::FedNextPrep* next, bool* next_done) {
+    if (next_done) *next_done = false;
     const uint32_t launches = fed_num_launches(c, n_tau, w, h, n);
     if (launches == 0) {
         if (in != A) AKZ_HIP_TRY(hipMemcpyAsync(A, in, plane_bytes(w, h, n), hipMemcpyDeviceToDevice, c->stream));
@@ -164,7 +165,10 @@ int fed_impl(akz_ctx* c, const float* in, float* A, float* B, const float* lflow
             float ht[2 * kFedMaxFuse];
             for (uint32_t j = 0; j < cnt; ++j) ht[j] = 0.5f * (float)taus[done + j];
             done += cnt;
-            launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt);
+            // the level's last launch may carry the next level's preparation (k_fed_own's epilogue)
+            const launch::FedNextPrep* np = (k == launches && next && launch::fed_epilogue_supported(w, h, cnt)) ? next : nullptr;
+            launch::fed_fused(c->stream, cur, lflow, dst, (done == n_tau) ? lstep : nullptr, w, h, n, ht, cnt, np);
+            if (np && next_done) *next_done = true;
         }
         cur = dst;
     }

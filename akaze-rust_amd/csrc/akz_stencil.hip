@@ -27,6 +27,7 @@
 
 #include "akz_internal.hpp"
 #include "akz_pm_g2.hpp"
+#include "akz_prep_passes.hpp"
 
 namespace akz {
 namespace {
@@ -172,8 +173,6 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
     __shared__ float sI[IH * IW];
     __shared__ float sA[AH * AW];
     __shared__ float sB[BH * BW];
-    float* const sM = sI;
-    float* const sO = sA;
     const int tid = threadIdx.x;
     const int ntiles = tg.tx * tg.ty * tg.n;
     float regs[NLOAD];
@@ -222,53 +221,9 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
-        for (int idx = tid; idx < AH * AW; idx += NT) {  // A = H_g(in)
-            const int ly = idx / AW, lx = idx - ly * AW;
-            const int x = x0 - 1 + lx, y = y0 - 2 + ly;
-            if (x >= 0 && x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-                const float* p = sI + (cy - (y0 - 2)) * IW + (cx - (x0 - 2));
-                sA[idx] = ((0.0f + g0 * p[-1]) + g1 * p[0]) + g2 * p[1];
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < BH * BW; idx += NT) {  // B = Lsmooth = V_g(A)
-            const int ly = idx / BW, lx = idx - ly * BW;
-            const int x = x0 - 1 + lx, y = y0 - 1 + ly;
-            if (x >= 0 && x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-                const float* p = sA + (cy - (y0 - 2)) * AW + (cx - (x0 - 1));
-                const float v = ((0.0f + g0 * p[-AW]) + g1 * p[0]) + g2 * p[AW];
-                sB[idx] = v;
-                if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) lsmooth[base + (size_t)y * w + x] = v;
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < CH * TW; idx += NT) {  // H passes of the Scharr pair (derivatives.rs:41-65)
-            const int ly = idx / TW, lx = idx - ly * TW;
-            const int x = x0 + lx, y = y0 - 1 + ly;
-            if (x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-                const float* p = sB + (cy - (y0 - 1)) * BW + (cx - (x0 - 1));
-                const float a = p[-1], b = p[0], c = p[1];
-                sM[idx] = ((0.0f + kn * a) + kwn * b) + kn * c;
-                sO[idx] = (0.0f - a) + c;
-            }
-        }
-        __syncthreads();
+        // the four passes on the window (akz_prep_passes.hpp: shared with the diffusion kernel's epilogue)
         const double kc = octave_contrast(d_k[tl.bz], k_pow);
-        const double inverse_k = 1.0 / (kc * kc);
-        for (int idx = tid; idx < TH * TW; idx += NT) {  // V passes + pm_g2
-            const int ly = idx / TW, lx = idx - ly * TW;
-            const int x = x0 + lx, y = y0 + ly;
-            if (x < w && y < h) {
-                const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-                const int o = (cy - (y0 - 1)) * TW + (cx - x0);
-                const float lx1 = (0.0f - sM[o - TW]) + sM[o + TW];
-                const float ly1 = ((0.0f + kn * sO[o - TW]) + kwn * sO[o]) + kn * sO[o + TW];
-                lflow[base + (size_t)y * w + x] = pm_g2_px(lx1, ly1, inverse_k);
-            }
-        }
+        prep_passes<TW, TH, NT>(sI, sA, sB, x0, y0, w, h, base, lsmooth, lflow, PrepTaps{g0, g1, g2, kn, kwn}, 1.0 / (kc * kc));
         __syncthreads();
     }
 }

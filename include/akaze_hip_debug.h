@@ -33,7 +33,10 @@ int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_
    stream of their own (a fifth busy stream), 3 = the context's stream (no running ahead); key 1: they are held back until
    the batch before has finished its fine-level diffusion (1, default) or start at once (0); key 2: 1 = no placement probe;
    key 3: octave at which the coarse chain forks (0 = default 2); key 4: the job size in thousands of pixels (w*h*n) from
-   which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (6 000 for a synchronous call, 3 000 for a job of the begin / finish interface). */
+   which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (2 400 for both entry points since round 6; 6 000 / 3 000 before);
+   key 5: 1 = the detector of a fine level right behind its level kernel (profiles/r06_interleave.txt: measured, not the default);
+   key 6: 1 = every level's preparation as a launch of its own (default 0: on the tiled path the last diffusion launch of a level
+   also prepares the next level of the octave -- k_fed_own's epilogue). */
 int akz_debug_set_schedule(akz_ctx* ctx, int key, int value);
 /* What the stream-placement probe of the context's first large batch found: info[0] = it has run, info[1] = early stages on
    the context's stream (0) or the copy stream (2), info[2] = streams it re-created because they shared a hardware queue
@@ -102,7 +105,7 @@ int akz_debug_set_host_sort(akz_ctx* ctx, int on);
    neighbour lists, k_select; a job with an image whose lists overflowed falls back to 1), 1 = on the host from the device's
    neighbour lists (k_relations; needs the device sort, which it switches on), 0 = on the host from its spatial grids,
    -1 = automatic (the default: on the device for contexts with fewer than four host threads, for jobs that do not take the
-   batch path and for images of 6 Mpx and more; the grids otherwise).  Results are identical. */
+   batch path, for jobs of fewer than four images, for the job that is waited for and for images of 6 Mpx and more; the grids otherwise).  Results are identical. */
 int akz_debug_set_select(akz_ctx* ctx, int mode);
 /* The selection of the last finished job: info[0] = where it ran (0 / 1 / 2 as above), info[1] = the most dependency rounds
    an image took on the device, info[2] = images that sent the job back to the host's selection, info[3] = candidates,

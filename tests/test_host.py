@@ -161,9 +161,25 @@ def test_isa_has_no_contracted_fma():
     assert sites >= 2 and plain >= 0 and len(re.findall(r"\bv_(?:fma|fmac)_f64", res)) == 9 * sites + 5 * plain
     pure = {r[0]: r[1] for r in rows + rows2}
     for k, v in pure.items():
+        if k.startswith("k_fed_own") and "Lb1E" in k:
+            continue  # the variants that prepare the next level as their epilogue carry pm_g2: checked below
         if k.startswith(("k_fed", "k_filter_v", "k_filter_hIf", "k_ldet", "k_nms", "k_orientation", "k_deriv",
                          "k_blurILi1EfE", "k_blurILi2EfE")):
             assert v == 0, (k, v)
+    # k_prep and k_fed_own's epilogue (the same akz_prep_passes.hpp): the same account -- f64 FMAs of pm_g2's one pixel site and
+    # of 1 / k^2, no f32 FMA
+    ker = open(os.path.join(pkg, "csrc", "akz_kernels.s")).read() + open(os.path.join(pkg, "csrc", "akz_stencil.s")).read()
+    seen = 0
+    for m in re.finditer(r"^(_ZN3akz\w+):[^\n]*\n(.*?)^\.Lfunc_end", ker, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if not (("k_fed_own" in name and "Lb1E" in name) or "k_prepILb" in name):
+            continue
+        seen += 1
+        assert not re.findall(r"\bv_(?:pk_fma|fma|fmac|mad|mac|fmaak|fmamk)_(?:f32|legacy_f32)\b", body), name
+        n_div = len(re.findall(r"\bv_div_fmas_f64\b", body))
+        n_rcp = len(re.findall(r"\bv_rcp_f64", body))
+        assert n_rcp - n_div == 1 and 2 * n_div - n_rcp == 1 and len(re.findall(r"\bv_(?:fma|fmac)_f64", body)) == 14, name
+    assert seen == 4, seen
 
 
 def _round_half_away(v):

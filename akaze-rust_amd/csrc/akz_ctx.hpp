@@ -172,7 +172,7 @@ struct akz_ctx {
     // placement probe found it a queue and a pipe of its own (below), 1 the copy stream regardless, 2 a stream of their own
     // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
     // has finished its fine-level diffusion (default) or not; [2] no placement probe
-    int sched[7] = {0, 1, 0, 0, 0, 0, 0};
+    int sched[10] = {0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t big_px = gates::kBigPxAsync;  // the gate of the job being begun (set by extract_begin from the two below; the begin half's helpers read it)
     uint64_t big_px_sync = gates::kBigPxSync, big_px_async = gates::kBigPxAsync;  // (sched[4] sets both: measurement)
     // pixels per LAUNCH (level w*h*n) from which the blur, the contrast passes and the detectors take their column-march

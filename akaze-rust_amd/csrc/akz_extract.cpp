@@ -755,20 +755,6 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     return AKZ_OK;
     };
 
-    // the fine levels (all levels when the batch does not fork) on the main stream
-    {
-        size_t oct1 = 1;  // first level past the first octave (fork_level if there is none on the main stream)
-        while (oct1 < fork_level && plan[oct1].octave == plan[0].octave) ++oct1;
-        AKZ_TRY(run_levels(1, oct1));
-        AKZ_HIP_TRY(hipEventRecord(c->pre_ev[seq % akz_ctx::kFedRing], s));
-        AKZ_TRY(run_levels(oct1, fork_level));
-    }
-    // The keypoint kernels of the batch that is finished next (orientation, M-LDB: gather-bound, on the auxiliary
-    // stream) wait for this point: next to the VALU-bound diffusion launches they cost more than next to the
-    // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.
-    AKZ_HIP_TRY(hipEventRecord(c->fed_ev[seq % akz_ctx::kFedRing], s));
-    c->begin_seq.store(seq);
-
     // ---- detectors: levels [lo, hi) on stream st (c->stream is st while this runs) ----
     // levels whose detector is the one-kernel tiled form are grouped by sigma_size: one launch per group
     auto detectors = [&](size_t lo, size_t hi, hipStream_t st_) -> int {
@@ -811,6 +797,23 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         return AKZ_OK;
     };
+    // (A small job's first-octave detectors on the second stream, under the remaining octaves' chain of small launches: built
+    // and measured in round 6 -- lone 1080p call 0.795 / 0.799 ms with / without, 720p 0.634 / 0.620: the small launches each
+    // fill the chip for their few microseconds and then wait for places the detector's workgroups hold.  Not kept.)
+    // the fine levels (all levels when the batch does not fork) on the main stream
+    {
+        size_t oct1 = 1;  // first level past the first octave (fork_level if there is none on the main stream)
+        while (oct1 < fork_level && plan[oct1].octave == plan[0].octave) ++oct1;
+        AKZ_TRY(run_levels(1, oct1));
+        AKZ_HIP_TRY(hipEventRecord(c->pre_ev[seq % akz_ctx::kFedRing], s));
+        AKZ_TRY(run_levels(oct1, fork_level));
+    }
+    // The keypoint kernels of the batch that is finished next (orientation, M-LDB: gather-bound, on the auxiliary
+    // stream) wait for this point: next to the VALU-bound diffusion launches they cost more than next to the
+    // bandwidth-bound detector launches that follow, and the diffusion launches stay individually timeable.
+    AKZ_HIP_TRY(hipEventRecord(c->fed_ev[seq % akz_ctx::kFedRing], s));
+    c->begin_seq.store(seq);
+
     hipStream_t done_on = s;  // the stream behind whose work the batch's candidate list is complete
     if (fork_level < L) {
         // The coarse chain (levels from fork_level on, then their detectors) runs on the second stream; the main stream
@@ -1020,6 +1023,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     uint32_t mldb_spec = 0;  // keypoints the device's own descriptor launch covered
     int libm_dev = 0;        // 1 / 2: angles and descriptors were enqueued on the device behind the selection (device_libm_mode)
     bool dev_angles_ok = true;  // ... and every angle was one the device forms cover
+    bool mirrored = false;      // ... and that launch stored the host's copies itself (headers, records, descriptor rows)
     uint16_t* d_rel = nullptr;
     uint32_t* d_rel_flags = nullptr;
     uint32_t *d_sel_hdr = nullptr, *d_sel_total = nullptr;
@@ -1099,8 +1103,19 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                     // is 3-15 x its keypoints, and 8 000 workgroups that find nothing to do cost 15 us; the rest, should there be
                     // one, follows when the count is known)
                     mldb_spec = std::min<uint32_t>(cap, c->last_total_kp.load() + c->last_total_kp.load() / 4 + 256u);
+                    // ... and what the host wants of them -- headers, keypoint records, descriptor rows -- stored into its pinned
+                    // buffers by the same launch (k_mldb's host mirror; sched[9] = 1: three copies behind the kernel, as before)
+                    launch::MldbMirror mir{};
+                    if (c->sched[9] == 0) {
+                        const bool host_rows = !(r->flags & AKZ_NO_HOST_DESCRIPTORS);
+                        AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 64));
+                        AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)mldb_spec * sizeof(SelKpHost)));
+                        if (host_rows) AKZ_TRY(ensure_pinned(c, c->pin[2], (size_t)mldb_spec * 64));
+                        mir = launch::MldbMirror{c->pin[0].p, d_sel_hdr, c->pin[8].p, n * 64u, host_rows ? (uint8_t*)c->pin[2].p : nullptr};
+                        mirrored = true;
+                    }
                     launch::mldb_counted(s, tab, (const KpParam*)c->kp_in.p, d_sel_total, 0, mldb_spec, &((SelKpHost*)c->sel_recs.p)->sums, 2,
-                                         libm_dev == 1, nullptr, (uint32_t)cfg.descriptor_channels, r->d_desc64);
+                                         libm_dev == 1, nullptr, (uint32_t)cfg.descriptor_channels, r->d_desc64, mirrored ? &mir : nullptr);
                     AKZ_HIP_TRY(hipGetLastError());
                 }
             }
@@ -1123,14 +1138,16 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                           // images' flags) and as many keypoints with their orientation sums as the last job had (+25 %)
             const uint32_t last = c->last_total_kp.load();
             spec_kp = libm_dev ? mldb_spec : std::min<uint32_t>(cap, last + last / 4 + 256u);  // (with the device's descriptors: exactly the keypoints their launch covered)
-            AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 64));
-            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[8].p, d_sel_hdr, (size_t)n * 64, hipMemcpyDeviceToHost, s));
-            AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec_kp * sizeof(SelKpHost)));
-            AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->sel_recs.p, (size_t)spec_kp * sizeof(SelKpHost), hipMemcpyDeviceToHost, s));
-            if (libm_dev && !(r->flags & AKZ_NO_HOST_DESCRIPTORS)) {  // the descriptor rows of those keypoints with the same synchronisation
-                AKZ_TRY(ensure_pinned(c, c->pin[2], (size_t)spec_kp * 64));
-                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[2].p, r->d_desc64, (size_t)spec_kp * 64, hipMemcpyDeviceToHost, s));
-            }
+            if (!mirrored) {
+                AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 64));
+                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[8].p, d_sel_hdr, (size_t)n * 64, hipMemcpyDeviceToHost, s));
+                AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)spec_kp * sizeof(SelKpHost)));
+                AKZ_HIP_TRY(hipMemcpyAsync(c->pin[0].p, c->sel_recs.p, (size_t)spec_kp * sizeof(SelKpHost), hipMemcpyDeviceToHost, s));
+                if (libm_dev && !(r->flags & AKZ_NO_HOST_DESCRIPTORS)) {  // the descriptor rows of those keypoints with the same synchronisation
+                    AKZ_TRY(ensure_pinned(c, c->pin[2], (size_t)spec_kp * 64));
+                    AKZ_HIP_TRY(hipMemcpyAsync(c->pin[2].p, r->d_desc64, (size_t)spec_kp * 64, hipMemcpyDeviceToHost, s));
+                }
+            }  // (else: k_mldb's host mirror has stored all three)
             AKZ_TRY(ensure_pinned(c, c->pin[5], (size_t)n * sizeof(double)));
             AKZ_TRY(ensure_pinned(c, c->pin[7], (size_t)n * sizeof(uint32_t)));
         } else if (attempt == 0) {

@@ -225,6 +225,7 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
                     float* lxy, float* ldet_out, uint32_t w, uint32_t h, uint32_t n, uint32_t level, float thr,
                     float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 // level preparation + the first n_steps <= 4 diffusion steps of a level in one launch (akz_march.hip, k_level_march)
+void march_min_band_rows(int detector, int level);  // measurement hook (process-wide): 0 = the planners' own rules
 bool level_march_supported(uint32_t w, uint32_t h);
 // pw, ph != 0: `prev` is the previous octave's last Lt (pw x ph) and the level starts from its 2x2 mean, formed inside the
 // kernel (level_march_half_supported)
@@ -308,8 +309,17 @@ void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float*
 // its orientation sums (akz_libm.hpp; d_sums[i * sums_stride]): the angle is left in d_sums[..].angle_bits, *d_flag is raised
 // if an argument is outside what the device forms cover
 // (keypoints [first, min(last, *d_nkp)): the grid covers first .. last; first is rounded down to the kernel's group of four)
+// `mirror`: the kernel also stores every keypoint's 32-byte record and descriptor row, and the selection's headers, into the
+// host's (pinned, device-visible) buffers -- the waited-for job's results without copies behind the kernel
+struct MldbMirror {
+    void* host_recs;        // 32 bytes per keypoint
+    const void* d_hdr;      // the selection's headers on the device, hdr_bytes (a multiple of 16) ...
+    void* host_hdr;         // ... and where the host wants them
+    uint32_t hdr_bytes;
+    uint8_t* host_desc;     // 64 bytes per keypoint, or NULL
+};
 void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t first, uint32_t last, OrientOut* d_sums,
-                  uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64);
+                  uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64, const MldbMirror* mirror = nullptr);
 void libm_eval(hipStream_t s, const float* a, const float* b, float* out3, uint64_t n, bool fma, uint32_t* d_flag);
 uint32_t match_num_chunks(uint32_t n0, uint32_t n1);
 // Both scans write one record per (chunk of the train set, query): d_rec[chunk * n0 + query]; match_compact merges a

@@ -840,7 +840,19 @@ struct DeviceAngles {
     unsigned fma;
     unsigned* flag;
 };
-__device__ __forceinline__ float2 device_angle(const DeviceAngles& da, unsigned kpi, bool write) {
+// The job that is waited for: what the host wants of a keypoint -- its 32-byte record (position, response, level, orientation
+// sums, angle) and its descriptor row -- is ALSO stored straight into the host's pinned buffers by the wave that finishes the
+// keypoint, and the selection's headers by the first workgroup, instead of three copies behind the kernel: a lone frame's call
+// ended with 35-60 us of copy-engine work and the gaps between the copies.  (Stores to host memory are posted writes over the
+// link: they drain while the other waves compute; the host reads after the stream's synchronisation, as it did the copies.)
+struct MldbHostMirror {
+    uint4* recs;        // host: 2 x uint4 per keypoint (NULL: no mirror)
+    const uint4* hdr;   // device: hdr_vec x uint4 of selection headers ...
+    uint4* hdr_host;    // ... and their place on the host
+    unsigned hdr_vec;
+    uint8_t* desc;      // host: 64-byte descriptor rows (NULL: the caller keeps them on the device)
+};
+__device__ __forceinline__ float2 device_angle(const DeviceAngles& da, unsigned kpi, bool write, const MldbHostMirror& hm) {
     OrientOut* o = da.sums + (size_t)kpi * da.stride;
     const float ang = o->found ? libm::atan2f_glibc(o->sum_y, o->sum_x) : 0.0f;
     bool bad = false;
@@ -855,14 +867,23 @@ __device__ __forceinline__ float2 device_angle(const DeviceAngles& da, unsigned 
     if (write) {
         o->angle_bits = __float_as_uint(ang);
         if (bad && da.flag) atomicOr(da.flag, 1u);  // (the host also sees it in the angle itself: NaN or |angle| >= 120)
+        if (hm.recs) {  // (stride 2: the sums are the second half of the keypoint's 32-byte record)
+            const uint4* rec = reinterpret_cast<const uint4*>(da.sums) + (size_t)kpi * 2u - 1u;
+            uint4 r0 = rec[0], r1 = rec[1];
+            r1.w = __float_as_uint(ang);
+            hm.recs[(size_t)kpi * 2u] = r0;
+            hm.recs[(size_t)kpi * 2u + 1u] = r1;
+        }
     }
     return float2{co, si};
 }
 __global__ void __launch_bounds__(64 * MLDB_KPB)
 k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict__ cosi, unsigned nkp, const unsigned* __restrict__ d_nkp,
-       DeviceAngles da, unsigned channels, uint8_t* __restrict__ desc64, unsigned first) {
+       DeviceAngles da, unsigned channels, uint8_t* __restrict__ desc64, unsigned first, MldbHostMirror hm) {
     __shared__ float s_win[MLDB_KPB][3][MLDB_NS + 7];
     __shared__ float s_val[MLDB_KPB][3][32];
+    if (hm.recs && blockIdx.x == 0)  // (before anything can return: a job without keypoints still reports its headers)
+        for (unsigned i = threadIdx.x; i < hm.hdr_vec; i += 64 * MLDB_KPB) hm.hdr_host[i] = hm.hdr[i];
     if (d_nkp) nkp = min(nkp, *d_nkp);  // (the count of a selection that ran on the device; nkp: the last keypoint the grid covers)
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const unsigned group0 = first + xcd_contiguous_group(blockIdx.x, gridDim.x) * MLDB_KPB;  // (first: a multiple of MLDB_KPB)
@@ -870,7 +891,7 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
     if (group0 >= nkp) return;  // whole workgroup
     const bool live = kpi < nkp;
     KpParam kp = kps[live ? kpi : 0];
-    const float2 cs = da.sums ? device_angle(da, live ? kpi : 0, live && lane == 0) : cosi[live ? kpi : 0];
+    const float2 cs = da.sums ? device_angle(da, live ? kpi : 0, live && lane == 0, hm) : cosi[live ? kpi : 0];
     // one keypoint per wave: its level is wave-uniform, so the level's pointers come from the kernel arguments by
     // scalar loads (a per-lane index would send the whole table through scratch memory)
     const LevelPtrs lv = tab.lv[__builtin_amdgcn_readfirstlane(kp.level)];
@@ -1001,6 +1022,7 @@ k_mldb(LevelTable tab, const KpParam* __restrict__ kps, const float2* __restrict
         for (int r = 1; r < 8; ++r)
             if (lane == (unsigned)r) wvw = words[r];
         reinterpret_cast<unsigned long long*>(desc64 + (size_t)kpi * 64)[lane] = wvw;
+        if (hm.desc) reinterpret_cast<unsigned long long*>(hm.desc + (size_t)kpi * 64)[lane] = wvw;
     }
 }
 
@@ -1386,15 +1408,18 @@ void mldb(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const float*
     const uint32_t groups = (nkp + MLDB_KPB - 1) / MLDB_KPB;
     hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp,
                        reinterpret_cast<const float2*>(d_cosi), nkp, (const unsigned*)nullptr, DeviceAngles{nullptr, 0u, 0u, nullptr}, channels,
-                       d_desc64, 0u);
+                       d_desc64, 0u, MldbHostMirror{nullptr, nullptr, nullptr, 0u, nullptr});
 }
 void mldb_counted(hipStream_t s, const LevelTable& lt, const KpParam* d_kp, const uint32_t* d_nkp, uint32_t first, uint32_t last, OrientOut* d_sums,
-                  uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64) {
+                  uint32_t sums_stride, bool libm_fma, uint32_t* d_flag, uint32_t channels, uint8_t* d_desc64, const MldbMirror* mirror) {
     first = first / MLDB_KPB * MLDB_KPB;
-    if (last <= first) return;
-    const uint32_t groups = (last - first + MLDB_KPB - 1) / MLDB_KPB;
+    MldbHostMirror hm{nullptr, nullptr, nullptr, 0u, nullptr};
+    if (mirror && sums_stride == 2)
+        hm = MldbHostMirror{(uint4*)mirror->host_recs, (const uint4*)mirror->d_hdr, (uint4*)mirror->host_hdr, mirror->hdr_bytes / 16u, mirror->host_desc};
+    if (last <= first && !hm.recs) return;
+    const uint32_t groups = last > first ? (last - first + MLDB_KPB - 1) / MLDB_KPB : 1u;  // (a mirror's headers travel with workgroup 0 at least)
     hipLaunchKernelGGL(k_mldb, dim3((groups + 7u) / 8u * 8u), dim3(64 * MLDB_KPB), 0, s, lt, d_kp, (const float2*)nullptr, last, d_nkp,
-                       DeviceAngles{d_sums, sums_stride, libm_fma ? 1u : 0u, d_flag}, channels, d_desc64, first);
+                       DeviceAngles{d_sums, sums_stride, libm_fma ? 1u : 0u, d_flag}, channels, d_desc64, first, hm);
 }
 // test / self-test hook: out[i] = {atan2f(a[i], b[i]), cosf(a[i]), sinf(a[i])} as the device forms them (akz_libm.hpp)
 void libm_eval(hipStream_t s, const float* a, const float* b, float* out3, uint64_t n, bool fma, uint32_t* d_flag) {

@@ -1076,6 +1076,12 @@ bool detector_march_supported(uint32_t sigma, uint32_t w, uint32_t h, float bord
     return !nms || border_m >= (float)(sigma + 2);
 }
 
+static int g_det_min_rows = 0, g_lvl_min_rows = 0;  // (akz_debug_set_schedule keys 7, 8: measurement; 0 = the rules below)
+void march_min_band_rows(int detector, int level) {
+    g_det_min_rows = detector;
+    g_lvl_min_rows = level;
+}
+
 template <int S, bool NMS, bool KEEP>
 static void launch_detector_march(hipStream_t s, const float* lsmooth, float* lx, float* ly, float* lxx, float* lyy, float* lxy,
                                   float* ldet_out, uint32_t w, uint32_t h, uint32_t n, float kn, float kwn, float quat,
@@ -1084,10 +1090,14 @@ static void launch_detector_march(hipStream_t s, const float* lsmooth, float* lx
 #ifndef AKZ_DET_FILL
 #define AKZ_DET_FILL 3
 #endif
+    // (bands of at least 40 interior rows: only a small job is cut that fine -- a lone 4K frame into 53 bands x 8 strips instead
+    // of 33 x 8, one workgroup per compute unit and each marching 80 rows one after the other: 100 -> 70 us per launch; with 64
+    // rows, the rule until round 6, a lone 4K call took 1.62 ms, with 40 or 32 1.55, with 24 or 16 1.60.  Batches are cut by the
+    // fill target long before.)
 #ifndef AKZ_DET_MINROWS
-#define AKZ_DET_MINROWS 64
+#define AKZ_DET_MINROWS 40
 #endif
-    const MarchGrid mg = plan_march(w, h, n, S, &gr, AKZ_DET_FILL, AKZ_DET_MINROWS);
+    const MarchGrid mg = plan_march(w, h, n, S, &gr, AKZ_DET_FILL, g_det_min_rows > 0 ? g_det_min_rows : AKZ_DET_MINROWS);
     if (w & 1u)
         hipLaunchKernelGGL((k_detector_march<S, NMS, KEEP, true>), gr, dim3(MT), 0, s, lsmooth, lx, ly, lxx, lyy, lxy, ldet_out,
                            (int)w, (int)h, mg, kn, kwn, quat, na);
@@ -1179,7 +1189,12 @@ void contrast_march(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint
 #ifndef AKZ_LVL_FILL
 #define AKZ_LVL_FILL 3
 #endif
-static int level_min_band_rows(uint32_t w, uint32_t h, uint32_t n) { return (uint64_t)w * h * n < (48u << 20) ? 40 : 64; }
+static int level_min_band_rows(uint32_t w, uint32_t h, uint32_t n) {
+    if (g_lvl_min_rows > 0) return g_lvl_min_rows;
+    // (below 48 Mpx the fill target decides, down to 20-row bands: a lone 4K frame's three full-resolution launches 76 -> ~60 us
+    // each, 96 x 8 workgroups instead of 54 x 8; 20, 16, 12 and 8 rows measure the same)
+    return (uint64_t)w * h * n < (48u << 20) ? 20 : 64;
+}
 // Test hook (CPU): the bands the planners cut an n-image batch of w x h into -- kind 0: detector / blur march with
 // kernel half width S, kind 1: level march.  Writes up to cap [cs, ce) pairs, returns the number of bands.
 uint32_t march_band_rows(int kind, uint32_t w, uint32_t h, uint32_t n, int S, int32_t* cs_ce, uint32_t cap) {

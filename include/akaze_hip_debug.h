@@ -36,7 +36,11 @@ int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_
    which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (2 400 for both entry points since round 6; 6 000 / 3 000 before);
    key 5: 1 = the detector of a fine level right behind its level kernel (profiles/r06_interleave.txt: measured, not the default);
    key 6: 1 = every level's preparation as a launch of its own (default 0: on the tiled path the last diffusion launch of a level
-   also prepares the next level of the octave -- k_fed_own's epilogue). */
+   also prepares the next level of the octave -- k_fed_own's epilogue);
+   keys 7, 8 (process-wide): the least interior rows of a band of the detector march / the level march, 0 = the planners' rules
+   (40; 20 below 48 Mpx per launch) -- how finely a small job's column marches are cut into workgroups;
+   key 9: 1 = the waited-for job's headers, keypoint records and descriptor rows come to the host as three copies behind the
+   descriptor kernel (default 0: that kernel stores them into the host's pinned buffers itself). */
 int akz_debug_set_schedule(akz_ctx* ctx, int key, int value);
 /* What the stream-placement probe of the context's first large batch found: info[0] = it has run, info[1] = early stages on
    the context's stream (0) or the copy stream (2), info[2] = streams it re-created because they shared a hardware queue

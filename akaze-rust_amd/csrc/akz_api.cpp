@@ -438,7 +438,7 @@ int akz_debug_march_bands(int kind, uint32_t w, uint32_t h, uint32_t n, int half
 }
 const char* akz_detector_kernel_name(void) { return "detector (k_detector_march + k_detector_tiled)"; }
 int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
-    if (!c || key < 0 || key > 9) return AKZ_ERR_INVALID_ARG;
+    if (!c || key < 0 || key > 10) return AKZ_ERR_INVALID_ARG;
     AKZ_TRY(bind(c));
     c->sched[key] = value;
     if (key == 7 || key == 8) launch::march_min_band_rows(c->sched[7], c->sched[8]);  // (process-wide: measurement)

@@ -91,6 +91,8 @@ struct akz_ctx {
     DevBuf scratch_coarse;                   // the coarse chain's own diffusion scratch: it outlives the batch's join (see extract_begin)
     DevBuf lazy[6];                          // one-image planes of akz_fetch_plane's recomputation (never shared with scratch users)
     DevBuf small;                            // hmax bits / histogram / counters
+    void* small_zero_p = nullptr;            // ... of which the first small_zero bytes are known to be zero (head_impl: its histogram
+    size_t small_zero = 0;                   //     pass leaves them so; 0: not known)
     DevBuf cand;                             // NMS candidates
     DevBuf cand_sorted, sort_scratch;        // the list in scan order (device sort of extract_finish) and the sort's scratch
     DevBuf rel_scratch;                      // the selection's neighbour lists (launch::candidate_relations)
@@ -172,7 +174,7 @@ struct akz_ctx {
     // placement probe found it a queue and a pipe of its own (below), 1 the copy stream regardless, 2 a stream of their own
     // (a fifth busy stream), 3 the context's stream (no running ahead); [1] early stages held back until the batch before
     // has finished its fine-level diffusion (default) or not; [2] no placement probe
-    int sched[10] = {0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+    int sched[11] = {0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t big_px = gates::kBigPxAsync;  // the gate of the job being begun (set by extract_begin from the two below; the begin half's helpers read it)
     uint64_t big_px_sync = gates::kBigPxSync, big_px_async = gates::kBigPxAsync;  // (sched[4] sets both: measurement)
     // pixels per LAUNCH (level w*h*n) from which the blur, the contrast passes and the detectors take their column-march
@@ -392,6 +394,10 @@ AKZ_LOCAL int level_info_out(const std::vector<LevelPlan>& plan, uint64_t level,
 // akz_ops.cpp: the launch helpers behind the per-op entry points, which the extraction pipeline calls as well
 template <typename T>
 AKZ_LOCAL int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32_t w, uint32_t h, uint32_t n, float sigma);
+// level 0 of a small job in two launches (k_head, k_contrast_hist_final); *fused = false: not this job (the separate stages follow)
+template <typename T>
+AKZ_LOCAL int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, uint32_t w, uint32_t h, uint32_t n, float sigma0, double percentile, double gscale,
+                        uint64_t nbins, double* d_k_out, bool* fused);
 AKZ_LOCAL int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile, double gscale, uint64_t nbins,
                   double* d_k_out);
 AKZ_LOCAL uint32_t fed_max_fuse(const akz_ctx* c, uint32_t w, uint32_t h, uint32_t n);

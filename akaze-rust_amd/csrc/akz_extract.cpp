@@ -549,14 +549,19 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     }
     // the job's candidate counter is cleared on the stream of its first stage (every detector launch comes behind that)
     AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
-    {
-        StageTimer st(c, AKZ_ST_BLUR0);
-        AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));
-    }
-    {
-        StageTimer st(c, AKZ_ST_CONTRAST);
-        AKZ_TRY(contrast_impl(c, P(0, AKZ_LSMOOTH), w, h, n, cfg.contrast_percentile, 1.0,
-                              cfg.contrast_factor_num_bins, r->d_k));
+    bool head_fused = false;  // (a small job: both stages in two launches -- akz_ops.cpp: head_impl)
+    AKZ_TRY(head_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset, cfg.contrast_percentile, 1.0,
+                         cfg.contrast_factor_num_bins, r->d_k, &head_fused));
+    if (!head_fused) {
+        {
+            StageTimer st(c, AKZ_ST_BLUR0);
+            AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));
+        }
+        {
+            StageTimer st(c, AKZ_ST_CONTRAST);
+            AKZ_TRY(contrast_impl(c, P(0, AKZ_LSMOOTH), w, h, n, cfg.contrast_percentile, 1.0,
+                                  cfg.contrast_factor_num_bins, r->d_k));
+        }
     }
     // every job marks the end of its level-0 stages (the last use of the context's contrast scratch): a later job that
     // runs ahead waits for exactly that, whichever stream it was recorded on

@@ -543,6 +543,68 @@ k_contrast_final(const unsigned long long* __restrict__ d_hmax_bits, const unsig
     d_k[img] = num_elements >= threshold ? hmax * (double)k / (double)nbins : 0.03;
 }
 
+// The histogram pass behind k_head (akz_stencil.hip), and the percentile with it: d_smax_bits holds the largest SQUARED
+// gradient magnitude (hmax is its square root); the workgroup that finishes an image last -- a ticket per workgroup, taken
+// after its bins have been added -- replays the percentile scan (k_contrast_final) and leaves the bins, the maximum and the
+// tickets ZERO for the next job: no launch for the scan, none for clearing the scratch.
+__global__ void __launch_bounds__(CT)
+k_contrast_hist_final(const float* __restrict__ blurred, int w, int h, Scharr1 sk, unsigned long long* __restrict__ d_smax_bits,
+                      unsigned nbins, unsigned copies, unsigned* __restrict__ d_hist, unsigned* __restrict__ d_done, double percentile,
+                      double* __restrict__ d_k) {
+    extern __shared__ unsigned s_hist[];  // `copies` private histograms (lanes spread over them); max(nbins * copies, nbins) words
+    __shared__ unsigned s_last;
+    const unsigned tid = threadIdx.x, img = blockIdx.z;
+    for (unsigned b = tid; b < nbins * copies; b += CT) s_hist[b] = 0u;
+    __syncthreads();
+    const float* I = blurred + (size_t)img * (size_t)w * (size_t)h;
+    const double hmax = sqrt(__longlong_as_double((long long)d_smax_bits[img]));
+    unsigned* mine = s_hist + (tid & (copies - 1u)) * nbins;
+    for (int y = 1 + (int)blockIdx.x; y < h - 1; y += (int)gridDim.x)
+        for (int x = 1 + (int)tid; x < w - 1; x += CT) {
+            const double g = grad_mod(I, w, h, x, y, sk);
+            if (g != 0.0) {
+                const double f = floor((double)nbins * (g / hmax));
+                const unsigned b = f >= (double)nbins ? nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
+                atomicAdd(&mine[b], 1u);
+            }
+        }
+    __syncthreads();
+    unsigned* hist = d_hist + (size_t)img * nbins;
+    for (unsigned b = tid; b < nbins; b += CT) {
+        unsigned v = 0;
+        for (unsigned c = 0; c < copies; ++c) v += s_hist[c * nbins + b];
+        if (v) atomicAdd(&hist[b], v);
+    }
+    // This workgroup's bins have been ADDED (device-scope atomics, performed where all XCDs see them) before its ticket is taken:
+    // the wave waits for its outstanding memory operations, the barrier for all waves.  (Not __threadfence(): a device-scope
+    // fence on this chip writes the XCD's L2 back -- 16 MB of k_head's planes, by every one of 512 workgroups: 51 us for this
+    // kernel instead of 23.  Nothing but atomics is exchanged here: the bins, the ticket, and the last workgroup's atomic loads.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&d_done[img], 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    for (unsigned b = tid; b < nbins; b += CT) {
+        s_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    unsigned long long num_points = 0;
+    for (unsigned b = 0; b < nbins; ++b) num_points += s_hist[b];
+    const double tf = (double)num_points * percentile;
+    const unsigned long long threshold = tf > 0.0 ? (unsigned long long)tf : 0ull;
+    unsigned long long k = 0, num_elements = 0;
+    while (num_elements < threshold && k < nbins) {
+        num_elements += s_hist[k];
+        k += 1;
+    }
+    d_k[img] = num_elements >= threshold ? hmax * (double)k / (double)nbins : 0.03;
+    d_smax_bits[img] = 0ull;
+    d_done[img] = 0u;
+}
+
 // Ldet = ((Lxx*Lyy) - (Lxy*Lxy)) * sigma^4   (akaze/src/ops/detector_response.rs:52)
 __global__ void k_ldet(const float* __restrict__ lxx, const float* __restrict__ lyy, const float* __restrict__ lxy,
                        float* __restrict__ out, size_t count, float q) {
@@ -1370,6 +1432,12 @@ void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const 
                     double percentile, uint32_t n, double* d_k) {
     hipLaunchKernelGGL(k_contrast_final, dim3(n), dim3(256), nbins * sizeof(unsigned), s, d_hmax_bits, d_hist, nbins, percentile,
                        n, d_k);
+}
+void contrast_hist_final(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n, unsigned long long* d_smax_bits,
+                         uint32_t nbins, uint32_t* d_hist, uint32_t* d_done, double percentile, double* d_k) {
+    const unsigned copies = nbins <= 512 ? 8u : (nbins <= 2048 ? 2u : 1u);
+    hipLaunchKernelGGL(k_contrast_hist_final, dim3(contrast_blocks(h, n), 1, n), dim3(CT), nbins * copies * sizeof(unsigned), s, blurred,
+                       (int)w, (int)h, scharr1(), d_smax_bits, nbins, copies, d_hist, d_done, percentile, d_k);
 }
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat) {

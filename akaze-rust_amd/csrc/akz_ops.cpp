@@ -77,6 +77,46 @@ static int scharr_impl(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, 
     return AKZ_OK;
 }
 
+// Level 0 of a job of the tiled family (lib.rs:56-69): Lt0 = gaussian_blur(frame, base_scale_offset) and the contrast factor of
+// it in TWO launches -- k_head (both blurs, the Scharr pair, the largest squared gradient magnitude) and k_contrast_hist_final
+// (histogram, percentile; leaves the scratch zero) -- instead of six (blur, fill, blur, maximum, histogram, percentile).
+// sched[10] = 1: the separate stages (measurement).
+template <typename T>
+int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, uint32_t w, uint32_t h, uint32_t n, float sigma0, double percentile, double gscale,
+              uint64_t nbins, double* d_k_out, bool* fused) {
+    *fused = false;
+    if (c->prep_mode != 0 || c->sched[10] != 0 || !(sigma0 > 0.0f) || !(gscale > 0.0) || nbins == 0 || nbins > 4096) return AKZ_OK;
+    const size_t ks0 = gaussian_kernel_size(sigma0), ks1 = gaussian_kernel_size((float)gscale);
+    if (!launch::head_fused_supported(w, h, (uint32_t)ks0, (uint32_t)ks1) || (const void*)d_in == (const void*)d_lt0) return AKZ_OK;
+    const std::vector<float> k5 = gaussian_kernel(sigma0, ks0), g3 = gaussian_kernel((float)gscale, ks1);
+    const size_t small_bytes = ((size_t)n * (8 + 4 + nbins * 4) + 255) / 256 * 256;  // maxima | bins | tickets
+    AKZ_TRY(ensure(c, c->small, small_bytes + (size_t)n * (nbins + 1) * sizeof(double)));
+    unsigned long long* d_smax = (unsigned long long*)c->small.p;
+    uint32_t* d_hist = (uint32_t*)((char*)c->small.p + (size_t)n * 8);
+    uint32_t* d_done = d_hist + (size_t)n * nbins;
+    if (c->small_zero_p != c->small.p || c->small_zero < small_bytes) {  // (first use, a larger job, or another family used it last)
+        AKZ_HIP_TRY(hipMemsetAsync(c->small.p, 0, small_bytes, c->stream));
+        c->small_zero_p = c->small.p;
+        c->small_zero = small_bytes;
+    }
+    AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
+    float* blurred = (float*)c->scratch[1].p;
+    {
+        StageTimer st(c, AKZ_ST_BLUR0);
+        if constexpr (std::is_same<T, uint8_t>::value) launch::head_fused_u8(c->stream, d_in, d_lt0, blurred, w, h, n, k5.data(), g3.data(), d_smax);
+        else launch::head_fused_f32(c->stream, d_in, d_lt0, blurred, w, h, n, k5.data(), g3.data(), d_smax);
+    }
+    {
+        StageTimer st(c, AKZ_ST_CONTRAST);
+        launch::contrast_hist_final(c->stream, blurred, w, h, n, d_smax, (uint32_t)nbins, d_hist, d_done, percentile, d_k_out);
+    }
+    AKZ_HIP_TRY(hipGetLastError());
+    *fused = true;
+    return AKZ_OK;
+}
+template int head_impl<float>(akz_ctx*, const float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
+template int head_impl<uint8_t>(akz_ctx*, const uint8_t*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
+
 int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile,
                          double gscale, uint64_t nbins, double* d_k_out) {
     if (nbins == 0 || nbins > 4096) {
@@ -96,6 +136,7 @@ int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_
     uint32_t* d_hist = (uint32_t*)((char*)c->small.p + (size_t)n * 8);
     double* d_thr = (double*)((char*)c->small.p + small_bytes);
     AKZ_HIP_TRY(hipMemsetAsync(c->small.p, 0, small_bytes, c->stream));
+    c->small_zero = 0;  // (these passes do not clean up after themselves)
     const size_t ks = gaussian_kernel_size((float)gscale);
     const bool stream = c->prep_mode != 0 && gscale > 0.0 && launch::contrast_stream_supported(w, h, (uint32_t)ks, (uint32_t)nbins) &&
                         (c->prep_mode == 1 || (uint64_t)w * h * n >= c->stream_min_px);

@@ -23,10 +23,12 @@ struct PrepTaps {
     float kn, kwn;     // scharr main-axis taps [kn, kwn, kn] at scale 1
 };
 
-template <int TW, int TH, int NT>
-__device__ __forceinline__ void prep_passes(float* __restrict__ sI, float* __restrict__ sA, float* __restrict__ sB, int x0, int y0, int w,
-                                            int h, size_t base, float* __restrict__ lsmooth, float* __restrict__ lflow, PrepTaps t,
-                                            double inverse_k) {
+// `fin(x, y, lx, ly)`: what becomes of the Scharr pair of pixel (x, y) -- evaluated, like every stage, at the coordinates
+// clamped to the interior: the preparation stores pm_g2 of it, the level-0 kernel (k_head) folds it into the contrast
+// factor's maximum.
+template <int TW, int TH, int NT, class Fin>
+__device__ __forceinline__ void prep_passes_fin(float* __restrict__ sI, float* __restrict__ sA, float* __restrict__ sB, int x0, int y0, int w,
+                                                int h, size_t base, float* __restrict__ lsmooth, PrepTaps t, Fin fin) {
     constexpr int IW = TW + 4;
     constexpr int AW = TW + 2, AH = TH + 4;
     constexpr int BW = TW + 2, BH = TH + 2;
@@ -78,9 +80,17 @@ __device__ __forceinline__ void prep_passes(float* __restrict__ sI, float* __res
             const int o = (cy - (y0 - 1)) * TW + (cx - x0);
             const float lx1 = (0.0f - sM[o - TW]) + sM[o + TW];
             const float ly1 = ((0.0f + t.kn * sO[o - TW]) + t.kwn * sO[o]) + t.kn * sO[o + TW];
-            lflow[base + (size_t)y * w + x] = pm_g2_px(lx1, ly1, inverse_k);
+            fin(x, y, lx1, ly1);
         }
     }
+}
+template <int TW, int TH, int NT>
+__device__ __forceinline__ void prep_passes(float* __restrict__ sI, float* __restrict__ sA, float* __restrict__ sB, int x0, int y0, int w,
+                                            int h, size_t base, float* __restrict__ lsmooth, float* __restrict__ lflow, PrepTaps t,
+                                            double inverse_k) {
+    prep_passes_fin<TW, TH, NT>(sI, sA, sB, x0, y0, w, h, base, lsmooth, t, [&](int x, int y, float lx1, float ly1) {
+        lflow[base + (size_t)y * w + x] = pm_g2_px(lx1, ly1, inverse_k);
+    });
 }
 
 }  // namespace akz

@@ -229,6 +229,117 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Level 0 of a small job in ONE launch (lib.rs:56-60, contrast_factor.rs:18-40): the frame -> Lt0 = gaussian_blur(frame,
+// base_scale_offset) (5 taps, stored) -> the contrast factor's own gaussian_blur(Lt0, 1.0) (3 taps, stored for the histogram
+// pass) -> its scale-1 Scharr pair -> the LARGEST squared gradient magnitude of the image (f64, one atomicMax per workgroup
+// and image).  Four launches before -- blur, the clearing of the contrast scratch, blur, k_contrast_max: 44 us of a lone
+// 1080p frame's 760 -- each a few microseconds of work behind its launch's floor.
+// The maximum is taken over dx*dx + dy*dy and its square root once (by the histogram pass): sqrt is monotone and correctly
+// rounded, so sqrt(max s) IS max sqrt(s), the reference's hmax, and no pixel pays for an f64 square root here.  Border pixels
+// enter with their clamped (interior) coordinates, i.e. as duplicates of interior pixels (the reference walks the interior
+// only, :27-38).
+// Windows: frame +-4, H pass of the 5-tap blur rows +-4 cols +-2, Lt0 +-2 -- which is the input window of the preparation's
+// passes (akz_prep_passes.hpp), whose Gaussian and Scharr stages are the contrast factor's (the same kernel sizes).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT)
+k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ blurred, int w, int h, TileGrid tg, DenseTaps t5,
+       PrepTaps t3, unsigned long long* __restrict__ d_smax_bits) {
+    constexpr int IW = TW + 8, IH = TH + 8;  // frame,  origin (x0-4, y0-4)
+    constexpr int HW = TW + 4, HH = TH + 8;  // H pass, origin (x0-2, y0-4)
+    constexpr int LW = TW + 4, LH = TH + 4;  // Lt0,    origin (x0-2, y0-2)
+    constexpr int NLOAD = (IH * IW + NT - 1) / NT;
+    static_assert((TH + 4) * (TW + 2) <= IH * IW && (TH + 2) * (TW + 2) <= HH * HW, "the preparation's scratch windows fit the dead ones");
+    __shared__ float sIn[IH * IW];  // (then the passes' H_g window)
+    __shared__ float sH[HH * HW];   // (then the passes' Lsmooth window)
+    __shared__ float sL[LH * LW];
+    __shared__ unsigned long long s_part[NT / 64];
+    const int tid = threadIdx.x;
+    const int ntiles = tg.tx * tg.ty * tg.n;
+    float regs[NLOAD];
+    auto issue = [&](int tile) {
+        const Tile tl = decode_tile(tile, tg, w, h);
+        const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * NT;
+            const int ly = idx / IW, lx = idx - ly * IW;
+            const int gx = tl.x0 - 4 + lx, gy = tl.y0 - 4 + ly;
+            regs[k] = (idx < IH * IW && gx >= 0 && gx < w && gy >= 0 && gy < h) ? unit_px(in, base + (size_t)gy * w + gx) : 0.0f;
+        }
+    };
+    double m = 0.0;  // this thread's largest dx*dx + dy*dy of image m_img
+    int m_img = -1;
+    auto flush = [&](int img) {  // (all threads; non-negative doubles order like their bit patterns)
+        unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(bits, o, 64);
+            bits = other > bits ? other : bits;
+        }
+        if ((tid & 63) == 0) s_part[tid >> 6] = bits;
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < NT / 64; ++i) bits = s_part[i] > bits ? s_part[i] : bits;
+            if (bits != 0ull) atomicMax(d_smax_bits + img, bits);
+        }
+        __syncthreads();
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const Tile tl = decode_tile(tile, tg, w, h);
+        const int x0 = tl.x0, y0 = tl.y0;
+        const size_t base = (size_t)tl.bz * (size_t)w * (size_t)h;
+        if (tl.bz != m_img) {  // (workgroup-uniform)
+            if (m_img >= 0) flush(m_img);
+            m_img = tl.bz;
+            m = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < IH * IW) sIn[idx] = regs[k];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        for (int idx = tid; idx < HH * HW; idx += NT) {  // H pass of the 5-tap blur (types/image.rs:374-380), filled
+            const int ly = idx / HW, lx = idx - ly * HW;
+            const int x = x0 - 2 + lx, y = y0 - 4 + ly;
+            if (x >= 0 && x < w && y >= 0 && y < h) {
+                const int cx = clampi(x, 2, w - 3), cy = clampi(y, 2, h - 3);
+                const float* p = sIn + (cy - (y0 - 4)) * IW + (cx - 2 - (x0 - 4));
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i];
+                sH[idx] = acc;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < LH * LW; idx += NT) {  // V pass: Lt0 on the tile + 2
+            const int ly = idx / LW, lx = idx - ly * LW;
+            const int x = x0 - 2 + lx, y = y0 - 2 + ly;
+            if (x >= 0 && x < w && y >= 0 && y < h) {
+                const int cx = clampi(x, 2, w - 3), cy = clampi(y, 2, h - 3);
+                const float* p = sH + (cy - 2 - (y0 - 4)) * HW + (cx - (x0 - 2));
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i * HW];
+                sL[idx] = acc;
+                if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) lt0[base + (size_t)y * w + x] = acc;
+            }
+        }
+        __syncthreads();
+        prep_passes_fin<TW, TH, NT>(sL, sIn, sH, x0, y0, w, h, base, blurred, t3, [&](int, int, float lx1, float ly1) {
+            const double dx = (double)lx1, dy = (double)ly1;
+            const double s2 = dx * dx + dy * dy;
+            if (s2 > m) m = s2;
+        });
+        __syncthreads();
+    }
+    if (m_img >= 0) flush(m_img);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Quad helpers: the detector kernels process four consecutive pixels of a row per thread.  Window
 // origins and pitches are multiples of 4 floats, so the centre taps are one aligned float4 and
 // vertical taps are aligned float4s of other rows; horizontal taps at -S / +S are assembled from the
@@ -886,6 +997,28 @@ void prep_fused(hipStream_t s, const float* prev, bool half, float* lt_out, floa
     else
         hipLaunchKernelGGL((k_prep<false>), l.grid, dim3(NT), 0, s, prev, lt_out, lsmooth, lflow, (int)w, (int)h,
                            (int)pw, (int)ph, l.tg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], d_k, k_pow);
+}
+
+bool head_fused_supported(uint32_t w, uint32_t h, uint32_t ntaps0, uint32_t ntaps1) { return ntaps0 == 5 && ntaps1 == 3 && w >= 5 && h >= 5; }
+// Level 0 of a small job: Lt0, the contrast factor's blurred image and the largest squared gradient magnitude per image (k_head);
+// d_smax_bits must be zero before (the histogram pass leaves it so)
+template <typename T>
+static void head_fused_t(hipStream_t s, const T* in, float* lt0, float* blurred, uint32_t w, uint32_t h, uint32_t n, const float* k5,
+                         const float* g3, unsigned long long* d_smax_bits) {
+    DenseTaps t;
+    for (uint32_t i = 0; i < (uint32_t)kMaxTaps; ++i) t.k[i] = i < 5 ? k5[i] : 0.0f;
+    const Taps m = taps_scharr_main(1);
+    const Launch l = plan_tiles(w, h, n);
+    hipLaunchKernelGGL((k_head<T>), l.grid, dim3(NT), 0, s, in, lt0, blurred, (int)w, (int)h, l.tg, t,
+                       PrepTaps{g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1]}, d_smax_bits);
+}
+void head_fused_u8(hipStream_t s, const uint8_t* in, float* lt0, float* blurred, uint32_t w, uint32_t h, uint32_t n, const float* k5,
+                   const float* g3, unsigned long long* d_smax_bits) {
+    head_fused_t<uint8_t>(s, in, lt0, blurred, w, h, n, k5, g3, d_smax_bits);
+}
+void head_fused_f32(hipStream_t s, const float* in, float* lt0, float* blurred, uint32_t w, uint32_t h, uint32_t n, const float* k5,
+                    const float* g3, unsigned long long* d_smax_bits) {
+    head_fused_t<float>(s, in, lt0, blurred, w, h, n, k5, g3, d_smax_bits);
 }
 
 bool detector_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <= 6; }

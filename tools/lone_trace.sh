@@ -40,7 +40,7 @@ except Exception:
     pass
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def nm(r): return r["Kernel_Name"].replace("void ", "").replace("akz::(anonymous namespace)::", "").split("(")[0][:40]
-blur = [i for i, r in enumerate(rows) if "k_blur" in nm(r) and "unsigned char" in nm(r)]
+blur = [i for i, r in enumerate(rows) if ("k_blur" in nm(r) or "k_head" in nm(r)) and "unsigned char" in nm(r)]  # a frame's first kernel
 # the streamed part: frames -8 .. -3 ; the synchronous call: the last blur
 a, b = blur[-7], blur[-3]
 t0 = int(rows[a]["Start_Timestamp"])

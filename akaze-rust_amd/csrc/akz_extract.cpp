@@ -549,9 +549,13 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     }
     // the job's candidate counter is cleared on the stream of its first stage (every detector launch comes behind that)
     AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
-    bool head_fused = false;  // (a small job: both stages in two launches -- akz_ops.cpp: head_impl)
-    AKZ_TRY(head_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset, cfg.contrast_percentile, 1.0,
-                         cfg.contrast_factor_num_bins, r->d_k, &head_fused));
+    // (a small job: both stages in two launches -- akz_ops.cpp: head_impl; level 1, where it continues the octave, finds its Lsmooth
+    // written -- the contrast factor's blur of Lt0 is the same image -- and the Scharr pair of it in level 0's Lx / Ly planes)
+    bool head_fused = false;
+    const bool level1_clone = L > 1 && plan[1].octave == plan[0].octave && plan[1].w == w && plan[1].h == h;
+    AKZ_TRY(head_impl<T>(c, d_imgs, P(0, AKZ_LT), level1_clone ? P(1, AKZ_LSMOOTH) : nullptr, P(0, AKZ_LX), P(0, AKZ_LY), w, h, n,
+                         (float)cfg.base_scale_offset, cfg.contrast_percentile, 1.0, cfg.contrast_factor_num_bins, r->d_k, &head_fused));
+    const bool head_level1 = head_fused && level1_clone;
     if (!head_fused) {
         {
             StageTimer st(c, AKZ_ST_BLUR0);
@@ -727,7 +731,10 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         // (Preparation + the first eight diffusion steps as ONE tiled launch -- k_prep and k_fed_own fused, tile + halo 8 + 2 --
         // was built and measured in round 3: 20 us per launch at best against 6-8 + 8-10 for the pair (the preparation then runs
         // on the whole diffusion region, 2.3 x the tile); a lone 1080p frame 0.59 -> 0.86 ms, batches -1 ... -4 %.  Removed.)
-        if (!prepared[i]) {
+        if (i == 1 && head_level1) {  // Lsmooth is k_head's; Lflow = pm_g2 of the Scharr pair k_head left in level 0's Lx / Ly
+            StageTimer st(c, AKZ_ST_PREP);
+            launch::flow_from_pair(ls, P(0, AKZ_LX), P(0, AKZ_LY), P(1, AKZ_LFLOW), lv.w, lv.h, n, r->d_k, lv.octave);
+        } else if (!prepared[i]) {
             StageTimer st(c, AKZ_ST_PREP);
             // measured on MI355X: the streaming kernel is ~2x faster for cloned levels of a batch (a single
             // frame is launch-latency bound and stays on the tiled kernel); for the first
@@ -802,9 +809,12 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         }
         return AKZ_OK;
     };
-    // (A small job's first-octave detectors on the second stream, under the remaining octaves' chain of small launches: built
-    // and measured in round 6 -- lone 1080p call 0.795 / 0.799 ms with / without, 720p 0.634 / 0.620: the small launches each
-    // fill the chip for their few microseconds and then wait for places the detector's workgroups hold.  Not kept.)
+    // (A small job's first-octave detectors on a second stream, under the remaining octaves' chain of small launches, was built
+    // and measured twice in round 6.  With the persistent detector launches: lone 1080p call 0.795 / 0.799 ms with / without, 720p
+    // 0.634 / 0.620 -- persistent workgroups hold their compute units until the launch ends and the chain's launches wait for
+    // places.  With one tile per workgroup on a lowest-priority stream the two do run side by side -- under rocprofv3 the begin
+    // chain ends 40 us earlier -- but unprofiled, where the chain's launches follow each other without the profiler's gaps, there
+    // is nothing to fill: the call 0.745-0.751 / 0.749-0.750 ms, 720p 0.588 / 0.576.  Not kept.)
     // the fine levels (all levels when the batch does not fork) on the main stream
     {
         size_t oct1 = 1;  // first level past the first octave (fork_level if there is none on the main stream)

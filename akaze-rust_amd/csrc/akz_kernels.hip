@@ -543,34 +543,64 @@ k_contrast_final(const unsigned long long* __restrict__ d_hmax_bits, const unsig
     d_k[img] = num_elements >= threshold ? hmax * (double)k / (double)nbins : 0.03;
 }
 
-// The histogram pass behind k_head (akz_stencil.hip), and the percentile with it: d_smax_bits holds the largest SQUARED
-// gradient magnitude (hmax is its square root); the workgroup that finishes an image last -- a ticket per workgroup, taken
-// after its bins have been added -- replays the percentile scan (k_contrast_final) and leaves the bins, the maximum and the
-// tickets ZERO for the next job: no launch for the scan, none for clearing the scratch.
-__global__ void __launch_bounds__(CT)
-k_contrast_hist_final(const float* __restrict__ blurred, int w, int h, Scharr1 sk, unsigned long long* __restrict__ d_smax_bits,
+// The histogram pass behind k_head (akz_stencil.hip), and the percentile with it.  k_head has stored the Scharr pair of every
+// pixel: this pass is elementwise -- four pixels per thread and trip, no neighbourhood -- over the interior (contrast_factor.rs:
+// 27-38 walks x in 1..w-1, y in 1..h-1; the border pixels of the planes hold copies of interior values and are skipped).
+// d_smax_bits holds the largest SQUARED gradient magnitude (hmax is its square root).  The workgroup that finishes an image
+// last -- a ticket per workgroup, taken after its bins have been added -- replays the percentile scan (k_contrast_final) and
+// leaves the bins, the maximum and the tickets ZERO for the next job: no launch for the scan, none for clearing the scratch.
+template <int NTH>
+__global__ void __launch_bounds__(NTH)
+k_contrast_hist_final(const float* __restrict__ gxp, const float* __restrict__ gyp, int w, int h, unsigned long long* __restrict__ d_smax_bits,
                       unsigned nbins, unsigned copies, unsigned* __restrict__ d_hist, unsigned* __restrict__ d_done, double percentile,
                       double* __restrict__ d_k) {
     extern __shared__ unsigned s_hist[];  // `copies` private histograms (lanes spread over them); max(nbins * copies, nbins) words
     __shared__ unsigned s_last;
     const unsigned tid = threadIdx.x, img = blockIdx.z;
-    for (unsigned b = tid; b < nbins * copies; b += CT) s_hist[b] = 0u;
+    for (unsigned b = tid; b < nbins * copies; b += NTH) s_hist[b] = 0u;
     __syncthreads();
-    const float* I = blurred + (size_t)img * (size_t)w * (size_t)h;
+    const size_t px = (size_t)w * (size_t)h;
+    const float* GX = gxp + (size_t)img * px;
+    const float* GY = gyp + (size_t)img * px;
     const double hmax = sqrt(__longlong_as_double((long long)d_smax_bits[img]));
     unsigned* mine = s_hist + (tid & (copies - 1u)) * nbins;
-    for (int y = 1 + (int)blockIdx.x; y < h - 1; y += (int)gridDim.x)
-        for (int x = 1 + (int)tid; x < w - 1; x += CT) {
-            const double g = grad_mod(I, w, h, x, y, sk);
-            if (g != 0.0) {
-                const double f = floor((double)nbins * (g / hmax));
-                const unsigned b = f >= (double)nbins ? nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
-                atomicAdd(&mine[b], 1u);
+    const bool vec = (px & 3u) == 0;  // every image's plane starts on a 16-byte boundary
+    const size_t nquads = (px + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * NTH + tid; q < nquads; q += (size_t)gridDim.x * NTH) {
+        const size_t i0 = q * 4;
+        float ax[4], ay[4];
+        if (vec) {
+            const float4 a = *reinterpret_cast<const float4*>(GX + i0), b = *reinterpret_cast<const float4*>(GY + i0);
+            ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w;
+            ay[0] = b.x; ay[1] = b.y; ay[2] = b.z; ay[3] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ax[e] = i0 + e < px ? GX[i0 + e] : 0.0f;
+                ay[e] = i0 + e < px ? GY[i0 + e] : 0.0f;
             }
         }
+        int y = (int)(i0 / (size_t)w), x = (int)(i0 - (size_t)y * w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+                const double dx = (double)ax[e], dy = (double)ay[e];
+                const double g = sqrt(dx * dx + dy * dy);
+                if (g != 0.0) {
+                    const double f = floor((double)nbins * (g / hmax));
+                    const unsigned b = f >= (double)nbins ? nbins - 1u : (f > 0.0 ? (unsigned)f : 0u);
+                    atomicAdd(&mine[b], 1u);
+                }
+            }
+            if (++x == w) {
+                x = 0;
+                ++y;
+            }
+        }
+    }
     __syncthreads();
     unsigned* hist = d_hist + (size_t)img * nbins;
-    for (unsigned b = tid; b < nbins; b += CT) {
+    for (unsigned b = tid; b < nbins; b += NTH) {
         unsigned v = 0;
         for (unsigned c = 0; c < copies; ++c) v += s_hist[c * nbins + b];
         if (v) atomicAdd(&hist[b], v);
@@ -585,7 +615,7 @@ k_contrast_hist_final(const float* __restrict__ blurred, int w, int h, Scharr1 s
     if (tid == 0) s_last = atomicAdd(&d_done[img], 1u) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
-    for (unsigned b = tid; b < nbins; b += CT) {
+    for (unsigned b = tid; b < nbins; b += NTH) {
         s_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hist[b] = 0u;
     }
@@ -603,6 +633,31 @@ k_contrast_hist_final(const float* __restrict__ blurred, int w, int h, Scharr1 s
     d_k[img] = num_elements >= threshold ? hmax * (double)k / (double)nbins : 0.03;
     d_smax_bits[img] = 0ull;
     d_done[img] = 0u;
+}
+// Lflow = pm_g2 of a stored Scharr pair (lib.rs:98-105; k_head's pair is level 1's: its Lsmooth is the blur the contrast
+// factor took of Lt0), elementwise
+__global__ void __launch_bounds__(256)
+k_flow_pair(const float* __restrict__ gxp, const float* __restrict__ gyp, float* __restrict__ lflow, size_t px, const double* __restrict__ d_k,
+            unsigned k_pow) {
+    const unsigned img = blockIdx.z;
+    const double kc = octave_contrast(d_k[img], k_pow);
+    const double inverse_k = 1.0 / (kc * kc);
+    const float* GX = gxp + (size_t)img * px;
+    const float* GY = gyp + (size_t)img * px;
+    float* out = lflow + (size_t)img * px;
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= px) return;
+    if ((px & 3u) == 0) {
+        const float4 a = *reinterpret_cast<const float4*>(GX + i0), b = *reinterpret_cast<const float4*>(GY + i0);
+        float4 o;
+        o.x = pm_g2_px(a.x, b.x, inverse_k);
+        o.y = pm_g2_px(a.y, b.y, inverse_k);
+        o.z = pm_g2_px(a.z, b.z, inverse_k);
+        o.w = pm_g2_px(a.w, b.w, inverse_k);
+        *reinterpret_cast<float4*>(out + i0) = o;
+    } else {
+        for (size_t i = i0; i < i0 + 4 && i < px; ++i) out[i] = pm_g2_px(GX[i], GY[i], inverse_k);
+    }
 }
 
 // Ldet = ((Lxx*Lyy) - (Lxy*Lxy)) * sigma^4   (akaze/src/ops/detector_response.rs:52)
@@ -1412,6 +1467,9 @@ void fed_fused(hipStream_t s, const float* lt_in, const float* lflow, float* lt_
 }
 // Workgroups per image of the two contrast passes: 128 fat ones for a batch (one atomicMax / one histogram flush
 // each); a small batch gets more, shorter ones so that the chip is filled (a lone 1080p frame: 38 + 36 us with 128).
+#ifndef AKZ_HIST_BLOCKS
+#define AKZ_HIST_BLOCKS 128u  // workgroups of the elementwise histogram pass (each flushes its bins once)
+#endif
 static unsigned contrast_blocks(uint32_t h, uint32_t n) {
     constexpr uint32_t target = 512u;  // lone 1080p frame: 37 + 34 us with 128, 18 + 24 with 512, 19 + 33 with 1024
     const uint32_t per_image = std::max<uint32_t>(128u, target / std::max<uint32_t>(n, 1u));
@@ -1433,11 +1491,21 @@ void contrast_final(hipStream_t s, const unsigned long long* d_hmax_bits, const 
     hipLaunchKernelGGL(k_contrast_final, dim3(n), dim3(256), nbins * sizeof(unsigned), s, d_hmax_bits, d_hist, nbins, percentile,
                        n, d_k);
 }
-void contrast_hist_final(hipStream_t s, const float* blurred, uint32_t w, uint32_t h, uint32_t n, unsigned long long* d_smax_bits,
+constexpr int HT = 1024;  // threads per workgroup of the elementwise histogram pass
+void contrast_hist_final(hipStream_t s, const float* gx, const float* gy, uint32_t w, uint32_t h, uint32_t n, unsigned long long* d_smax_bits,
                          uint32_t nbins, uint32_t* d_hist, uint32_t* d_done, double percentile, double* d_k) {
     const unsigned copies = nbins <= 512 ? 8u : (nbins <= 2048 ? 2u : 1u);
-    hipLaunchKernelGGL(k_contrast_hist_final, dim3(contrast_blocks(h, n), 1, n), dim3(CT), nbins * copies * sizeof(unsigned), s, blurred,
-                       (int)w, (int)h, scharr1(), d_smax_bits, nbins, copies, d_hist, d_done, percentile, d_k);
+    const uint64_t quads = ((uint64_t)w * h + 3) / 4;
+    // 128 workgroups of 1 024 threads (each adds its bins to the image's once): 19.6 us for a lone 1080p frame; 512 x 256 threads
+    // 25.7 -- the same threads, four times the flushes onto the same 300 counters
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((quads + HT - 1) / HT, std::max<uint32_t>(32u, AKZ_HIST_BLOCKS / std::max<uint32_t>(n, 1u))));
+    hipLaunchKernelGGL(k_contrast_hist_final<HT>, dim3(blocks, 1, n), dim3(HT), nbins * copies * sizeof(unsigned), s, gx, gy, (int)w, (int)h,
+                       d_smax_bits, nbins, copies, d_hist, d_done, percentile, d_k);
+}
+void flow_from_pair(hipStream_t s, const float* gx, const float* gy, float* lflow, uint32_t w, uint32_t h, uint32_t n, const double* d_k,
+                    uint32_t k_pow) {
+    const uint64_t px = (uint64_t)w * h;
+    hipLaunchKernelGGL(k_flow_pair, dim3((unsigned)((px + 1023) / 1024), 1, n), dim3(256), 0, s, gx, gy, lflow, (size_t)px, d_k, k_pow);
 }
 void ldet(hipStream_t s, const float* lxx, const float* lyy, const float* lxy, float* out, uint64_t count,
           float sigma_quat) {

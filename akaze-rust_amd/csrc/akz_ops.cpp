@@ -80,10 +80,12 @@ static int scharr_impl(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, 
 // Level 0 of a job of the tiled family (lib.rs:56-69): Lt0 = gaussian_blur(frame, base_scale_offset) and the contrast factor of
 // it in TWO launches -- k_head (both blurs, the Scharr pair, the largest squared gradient magnitude) and k_contrast_hist_final
 // (histogram, percentile; leaves the scratch zero) -- instead of six (blur, fill, blur, maximum, histogram, percentile).
+// d_gx / d_gy: two planes for the contrast factor's Scharr pair (the caller's level-0 Lx / Ly, which the detector writes much
+// later); d_blurred: where the contrast factor's blur of Lt0 goes (level 1's Lsmooth, or NULL: context scratch).
 // sched[10] = 1: the separate stages (measurement).
 template <typename T>
-int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, uint32_t w, uint32_t h, uint32_t n, float sigma0, double percentile, double gscale,
-              uint64_t nbins, double* d_k_out, bool* fused) {
+int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, float* d_blurred, float* d_gx, float* d_gy, uint32_t w, uint32_t h, uint32_t n, float sigma0,
+              double percentile, double gscale, uint64_t nbins, double* d_k_out, bool* fused) {
     *fused = false;
     if (c->prep_mode != 0 || c->sched[10] != 0 || !(sigma0 > 0.0f) || !(gscale > 0.0) || nbins == 0 || nbins > 4096) return AKZ_OK;
     const size_t ks0 = gaussian_kernel_size(sigma0), ks1 = gaussian_kernel_size((float)gscale);
@@ -99,23 +101,28 @@ int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, uint32_t w, uint32_t h, u
         c->small_zero_p = c->small.p;
         c->small_zero = small_bytes;
     }
-    AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
-    float* blurred = (float*)c->scratch[1].p;
+    float* blurred = d_blurred;  // (level 1's Lsmooth where level 1 continues the octave: the same blur of Lt0, lib.rs:92-95)
+    if (!blurred) {
+        AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
+        blurred = (float*)c->scratch[1].p;
+    }
     {
         StageTimer st(c, AKZ_ST_BLUR0);
-        if constexpr (std::is_same<T, uint8_t>::value) launch::head_fused_u8(c->stream, d_in, d_lt0, blurred, w, h, n, k5.data(), g3.data(), d_smax);
-        else launch::head_fused_f32(c->stream, d_in, d_lt0, blurred, w, h, n, k5.data(), g3.data(), d_smax);
+        if constexpr (std::is_same<T, uint8_t>::value)
+            launch::head_fused_u8(c->stream, d_in, d_lt0, blurred, d_gx, d_gy, w, h, n, k5.data(), g3.data(), d_smax);
+        else
+            launch::head_fused_f32(c->stream, d_in, d_lt0, blurred, d_gx, d_gy, w, h, n, k5.data(), g3.data(), d_smax);
     }
     {
         StageTimer st(c, AKZ_ST_CONTRAST);
-        launch::contrast_hist_final(c->stream, blurred, w, h, n, d_smax, (uint32_t)nbins, d_hist, d_done, percentile, d_k_out);
+        launch::contrast_hist_final(c->stream, d_gx, d_gy, w, h, n, d_smax, (uint32_t)nbins, d_hist, d_done, percentile, d_k_out);
     }
     AKZ_HIP_TRY(hipGetLastError());
     *fused = true;
     return AKZ_OK;
 }
-template int head_impl<float>(akz_ctx*, const float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
-template int head_impl<uint8_t>(akz_ctx*, const uint8_t*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
+template int head_impl<float>(akz_ctx*, const float*, float*, float*, float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
+template int head_impl<uint8_t>(akz_ctx*, const uint8_t*, float*, float*, float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
 
 int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile,
                          double gscale, uint64_t nbins, double* d_k_out) {

@@ -231,8 +231,9 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
 // ---------------------------------------------------------------------------------------------
 // Level 0 of a small job in ONE launch (lib.rs:56-60, contrast_factor.rs:18-40): the frame -> Lt0 = gaussian_blur(frame,
 // base_scale_offset) (5 taps, stored) -> the contrast factor's own gaussian_blur(Lt0, 1.0) (3 taps, stored for the histogram
-// pass) -> its scale-1 Scharr pair -> the LARGEST squared gradient magnitude of the image (f64, one atomicMax per workgroup
-// and image).  Four launches before -- blur, the clearing of the contrast scratch, blur, k_contrast_max: 44 us of a lone
+// pass) -> its scale-1 Scharr pair (stored: the histogram pass bins it, and level 1 -- whose Lsmooth is this very blur of Lt0,
+// lib.rs:92-95 -- forms its Lflow from it) -> the LARGEST squared gradient magnitude of the image (f64, one atomicMax per
+// workgroup and image).  Four launches before -- blur, the clearing of the contrast scratch, blur, k_contrast_max: 44 us of a lone
 // 1080p frame's 760 -- each a few microseconds of work behind its launch's floor.
 // The maximum is taken over dx*dx + dy*dy and its square root once (by the histogram pass): sqrt is monotone and correctly
 // rounded, so sqrt(max s) IS max sqrt(s), the reference's hmax, and no pixel pays for an f64 square root here.  Border pixels
@@ -243,8 +244,8 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(NT)
-k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ blurred, int w, int h, TileGrid tg, DenseTaps t5,
-       PrepTaps t3, unsigned long long* __restrict__ d_smax_bits) {
+k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ blurred, float* __restrict__ gx_out, float* __restrict__ gy_out,
+       int w, int h, TileGrid tg, DenseTaps t5, PrepTaps t3, unsigned long long* __restrict__ d_smax_bits) {
     constexpr int IW = TW + 8, IH = TH + 8;  // frame,  origin (x0-4, y0-4)
     constexpr int HW = TW + 4, HH = TH + 8;  // H pass, origin (x0-2, y0-4)
     constexpr int LW = TW + 4, LH = TH + 4;  // Lt0,    origin (x0-2, y0-2)
@@ -329,7 +330,10 @@ k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ bl
             }
         }
         __syncthreads();
-        prep_passes_fin<TW, TH, NT>(sL, sIn, sH, x0, y0, w, h, base, blurred, t3, [&](int, int, float lx1, float ly1) {
+        prep_passes_fin<TW, TH, NT>(sL, sIn, sH, x0, y0, w, h, base, blurred, t3, [&](int x, int y, float lx1, float ly1) {
+            const size_t gi = base + (size_t)y * w + x;  // the (filled) Scharr pair: the histogram pass and level 1's Lflow read it
+            gx_out[gi] = lx1;
+            gy_out[gi] = ly1;
             const double dx = (double)lx1, dy = (double)ly1;
             const double s2 = dx * dx + dy * dy;
             if (s2 > m) m = s2;
@@ -1003,22 +1007,22 @@ bool head_fused_supported(uint32_t w, uint32_t h, uint32_t ntaps0, uint32_t ntap
 // Level 0 of a small job: Lt0, the contrast factor's blurred image and the largest squared gradient magnitude per image (k_head);
 // d_smax_bits must be zero before (the histogram pass leaves it so)
 template <typename T>
-static void head_fused_t(hipStream_t s, const T* in, float* lt0, float* blurred, uint32_t w, uint32_t h, uint32_t n, const float* k5,
-                         const float* g3, unsigned long long* d_smax_bits) {
+static void head_fused_t(hipStream_t s, const T* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
+                         const float* k5, const float* g3, unsigned long long* d_smax_bits) {
     DenseTaps t;
     for (uint32_t i = 0; i < (uint32_t)kMaxTaps; ++i) t.k[i] = i < 5 ? k5[i] : 0.0f;
     const Taps m = taps_scharr_main(1);
     const Launch l = plan_tiles(w, h, n);
-    hipLaunchKernelGGL((k_head<T>), l.grid, dim3(NT), 0, s, in, lt0, blurred, (int)w, (int)h, l.tg, t,
+    hipLaunchKernelGGL((k_head<T>), l.grid, dim3(NT), 0, s, in, lt0, blurred, gx, gy, (int)w, (int)h, l.tg, t,
                        PrepTaps{g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1]}, d_smax_bits);
 }
-void head_fused_u8(hipStream_t s, const uint8_t* in, float* lt0, float* blurred, uint32_t w, uint32_t h, uint32_t n, const float* k5,
-                   const float* g3, unsigned long long* d_smax_bits) {
-    head_fused_t<uint8_t>(s, in, lt0, blurred, w, h, n, k5, g3, d_smax_bits);
+void head_fused_u8(hipStream_t s, const uint8_t* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
+                   const float* k5, const float* g3, unsigned long long* d_smax_bits) {
+    head_fused_t<uint8_t>(s, in, lt0, blurred, gx, gy, w, h, n, k5, g3, d_smax_bits);
 }
-void head_fused_f32(hipStream_t s, const float* in, float* lt0, float* blurred, uint32_t w, uint32_t h, uint32_t n, const float* k5,
-                    const float* g3, unsigned long long* d_smax_bits) {
-    head_fused_t<float>(s, in, lt0, blurred, w, h, n, k5, g3, d_smax_bits);
+void head_fused_f32(hipStream_t s, const float* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
+                    const float* k5, const float* g3, unsigned long long* d_smax_bits) {
+    head_fused_t<float>(s, in, lt0, blurred, gx, gy, w, h, n, k5, g3, d_smax_bits);
 }
 
 bool detector_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <= 6; }

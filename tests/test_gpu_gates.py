@@ -29,6 +29,12 @@ FORCED = [
     ("stream_px: tiled preparation, tiled detector pair", lambda c: (c.set_prep_mode(0), c.set_detector_mode(0)),
      lambda c: (c.set_prep_mode(2), c.set_detector_mode(2))),
     ("fed: one launch per step", lambda c: c.set_fed_mode(0), lambda c: c.set_fed_mode(2)),
+    ("tiled family, level 0 as separate launches and every preparation a launch of its own",
+     lambda c: (c.set_prep_mode(0), c.debug_set_schedule(10, 1), c.debug_set_schedule(6, 1)),
+     lambda c: (c.set_prep_mode(2), c.debug_set_schedule(10, 0), c.debug_set_schedule(6, 0))),
+    ("results by three copies behind the descriptor kernel", lambda c: c.debug_set_schedule(9, 1), lambda c: c.debug_set_schedule(9, 0)),
+    ("column marches cut into 16-row bands", lambda c: (c.debug_set_schedule(7, 16), c.debug_set_schedule(8, 16)),
+     lambda c: (c.debug_set_schedule(7, 0), c.debug_set_schedule(8, 0))),
     ("few_host_threads: selection and sort on the device", lambda c: (c.debug_set_select(2), c.debug_set_host_sort(False)),
      lambda c: (c.debug_set_select(None), c.debug_set_host_sort(None))),
     ("select_device_px: neighbour lists + host selection", lambda c: c.debug_set_select(1), lambda c: c.debug_set_select(None)),

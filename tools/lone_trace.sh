@@ -15,6 +15,8 @@ cfg = A.Config()
 st = torch.cuda.Stream(dev); torch.cuda.set_stream(st)
 ctx = A.Context(0, st.cuda_stream); ctx.warmup()
 ctx.debug_set_schedule(4, $s4)
+for kv in "$KEYS".split(","):
+    if kv: ctx.debug_set_schedule(int(kv.split("=")[0]), int(kv.split("=")[1]))
 for _ in range(10): ctx.extract_begin(frame, cfg).finish().close()
 torch.cuda.synchronize()
 t = time.perf_counter(); prev = None

@@ -14,6 +14,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "akz_pm_g2.hpp"
 
 namespace akz {
@@ -38,51 +40,58 @@ __device__ __forceinline__ void prep_passes_fin(float* __restrict__ sI, float* _
     float* const sO = sA;
     const int tid = threadIdx.x;
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    for (int idx = tid; idx < AH * AW; idx += NT) {  // A = H_g(in)
-        const int ly = idx / AW, lx = idx - ly * AW;
-        const int x = x0 - 1 + lx, y = y0 - 2 + ly;
-        if (x >= 0 && x < w && y >= 0 && y < h) {
-            const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-            const float* p = sI + (cy - (y0 - 2)) * IW + (cx - (x0 - 2));
-            sA[idx] = ((0.0f + t.g0 * p[-1]) + t.g1 * p[0]) + t.g2 * p[1];
+    // a tile whose windows lie in the image's interior needs neither the in-image tests nor fill_border's clamps (all identities)
+    const bool interior = x0 >= 3 && x0 + TW + 3 <= w && y0 >= 3 && y0 + TH + 3 <= h;
+    auto passes = [&](auto in_tag) {
+        constexpr bool IN = decltype(in_tag)::value;
+        for (int idx = tid; idx < AH * AW; idx += NT) {  // A = H_g(in)
+            const int ly = idx / AW, lx = idx - ly * AW;
+            const int x = x0 - 1 + lx, y = y0 - 2 + ly;
+            if (IN || (x >= 0 && x < w && y >= 0 && y < h)) {
+                const int cx = IN ? x : clampi(x, 1, w - 2), cy = IN ? y : clampi(y, 1, h - 2);
+                const float* p = sI + (cy - (y0 - 2)) * IW + (cx - (x0 - 2));
+                sA[idx] = ((0.0f + t.g0 * p[-1]) + t.g1 * p[0]) + t.g2 * p[1];
+            }
         }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < BH * BW; idx += NT) {  // B = Lsmooth = V_g(A)
-        const int ly = idx / BW, lx = idx - ly * BW;
-        const int x = x0 - 1 + lx, y = y0 - 1 + ly;
-        if (x >= 0 && x < w && y >= 0 && y < h) {
-            const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-            const float* p = sA + (cy - (y0 - 2)) * AW + (cx - (x0 - 1));
-            const float v = ((0.0f + t.g0 * p[-AW]) + t.g1 * p[0]) + t.g2 * p[AW];
-            sB[idx] = v;
-            if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) lsmooth[base + (size_t)y * w + x] = v;
+        __syncthreads();
+        for (int idx = tid; idx < BH * BW; idx += NT) {  // B = Lsmooth = V_g(A)
+            const int ly = idx / BW, lx = idx - ly * BW;
+            const int x = x0 - 1 + lx, y = y0 - 1 + ly;
+            if (IN || (x >= 0 && x < w && y >= 0 && y < h)) {
+                const int cx = IN ? x : clampi(x, 1, w - 2), cy = IN ? y : clampi(y, 1, h - 2);
+                const float* p = sA + (cy - (y0 - 2)) * AW + (cx - (x0 - 1));
+                const float v = ((0.0f + t.g0 * p[-AW]) + t.g1 * p[0]) + t.g2 * p[AW];
+                sB[idx] = v;
+                if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) lsmooth[base + (size_t)y * w + x] = v;
+            }
         }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < CH * TW; idx += NT) {  // H passes of the Scharr pair (derivatives.rs:41-65)
-        const int ly = idx / TW, lx = idx - ly * TW;
-        const int x = x0 + lx, y = y0 - 1 + ly;
-        if (x < w && y >= 0 && y < h) {
-            const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-            const float* p = sB + (cy - (y0 - 1)) * BW + (cx - (x0 - 1));
-            const float a = p[-1], b = p[0], c = p[1];
-            sM[idx] = ((0.0f + t.kn * a) + t.kwn * b) + t.kn * c;
-            sO[idx] = (0.0f - a) + c;
+        __syncthreads();
+        for (int idx = tid; idx < CH * TW; idx += NT) {  // H passes of the Scharr pair (derivatives.rs:41-65)
+            const int ly = idx / TW, lx = idx - ly * TW;
+            const int x = x0 + lx, y = y0 - 1 + ly;
+            if (IN || (x < w && y >= 0 && y < h)) {
+                const int cx = IN ? x : clampi(x, 1, w - 2), cy = IN ? y : clampi(y, 1, h - 2);
+                const float* p = sB + (cy - (y0 - 1)) * BW + (cx - (x0 - 1));
+                const float a = p[-1], b = p[0], c = p[1];
+                sM[idx] = ((0.0f + t.kn * a) + t.kwn * b) + t.kn * c;
+                sO[idx] = (0.0f - a) + c;
+            }
         }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < TH * TW; idx += NT) {  // V passes + pm_g2
-        const int ly = idx / TW, lx = idx - ly * TW;
-        const int x = x0 + lx, y = y0 + ly;
-        if (x < w && y < h) {
-            const int cx = clampi(x, 1, w - 2), cy = clampi(y, 1, h - 2);
-            const int o = (cy - (y0 - 1)) * TW + (cx - x0);
-            const float lx1 = (0.0f - sM[o - TW]) + sM[o + TW];
-            const float ly1 = ((0.0f + t.kn * sO[o - TW]) + t.kwn * sO[o]) + t.kn * sO[o + TW];
-            fin(x, y, lx1, ly1);
+        __syncthreads();
+        for (int idx = tid; idx < TH * TW; idx += NT) {  // V passes + pm_g2
+            const int ly = idx / TW, lx = idx - ly * TW;
+            const int x = x0 + lx, y = y0 + ly;
+            if (IN || (x < w && y < h)) {
+                const int cx = IN ? x : clampi(x, 1, w - 2), cy = IN ? y : clampi(y, 1, h - 2);
+                const int o = (cy - (y0 - 1)) * TW + (cx - x0);
+                const float lx1 = (0.0f - sM[o - TW]) + sM[o + TW];
+                const float ly1 = ((0.0f + t.kn * sO[o - TW]) + t.kwn * sO[o]) + t.kn * sO[o + TW];
+                fin(x, y, lx1, ly1);
+            }
         }
-    }
+    };
+    if (interior) passes(std::true_type{});
+    else passes(std::false_type{});
 }
 template <int TW, int TH, int NT>
 __device__ __forceinline__ void prep_passes(float* __restrict__ sI, float* __restrict__ sA, float* __restrict__ sB, int x0, int y0, int w,

@@ -27,6 +27,8 @@
 
 #include "akz_internal.hpp"
 #include "akz_pm_g2.hpp"
+#include <type_traits>
+
 #include "akz_prep_passes.hpp"
 
 namespace akz {
@@ -303,33 +305,39 @@ k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ bl
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
-        for (int idx = tid; idx < HH * HW; idx += NT) {  // H pass of the 5-tap blur (types/image.rs:374-380), filled
-            const int ly = idx / HW, lx = idx - ly * HW;
-            const int x = x0 - 2 + lx, y = y0 - 4 + ly;
-            if (x >= 0 && x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, 2, w - 3), cy = clampi(y, 2, h - 3);
-                const float* p = sIn + (cy - (y0 - 4)) * IW + (cx - 2 - (x0 - 4));
-                float acc = 0.0f;
+        const bool interior = x0 >= 6 && x0 + TW + 6 <= w && y0 >= 6 && y0 + TH + 6 <= h;  // (no test, no clamp: as in k_detector_tiled)
+        auto blur5 = [&](auto in_tag) {
+            constexpr bool IN = decltype(in_tag)::value;
+            for (int idx = tid; idx < HH * HW; idx += NT) {  // H pass of the 5-tap blur (types/image.rs:374-380), filled
+                const int ly = idx / HW, lx = idx - ly * HW;
+                const int x = x0 - 2 + lx, y = y0 - 4 + ly;
+                if (IN || (x >= 0 && x < w && y >= 0 && y < h)) {
+                    const int cx = IN ? x : clampi(x, 2, w - 3), cy = IN ? y : clampi(y, 2, h - 3);
+                    const float* p = sIn + (cy - (y0 - 4)) * IW + (cx - 2 - (x0 - 4));
+                    float acc = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i];
-                sH[idx] = acc;
+                    for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i];
+                    sH[idx] = acc;
+                }
             }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < LH * LW; idx += NT) {  // V pass: Lt0 on the tile + 2
-            const int ly = idx / LW, lx = idx - ly * LW;
-            const int x = x0 - 2 + lx, y = y0 - 2 + ly;
-            if (x >= 0 && x < w && y >= 0 && y < h) {
-                const int cx = clampi(x, 2, w - 3), cy = clampi(y, 2, h - 3);
-                const float* p = sH + (cy - 2 - (y0 - 4)) * HW + (cx - (x0 - 2));
-                float acc = 0.0f;
+            __syncthreads();
+            for (int idx = tid; idx < LH * LW; idx += NT) {  // V pass: Lt0 on the tile + 2
+                const int ly = idx / LW, lx = idx - ly * LW;
+                const int x = x0 - 2 + lx, y = y0 - 2 + ly;
+                if (IN || (x >= 0 && x < w && y >= 0 && y < h)) {
+                    const int cx = IN ? x : clampi(x, 2, w - 3), cy = IN ? y : clampi(y, 2, h - 3);
+                    const float* p = sH + (cy - 2 - (y0 - 4)) * HW + (cx - (x0 - 2));
+                    float acc = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i * HW];
-                sL[idx] = acc;
-                if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) lt0[base + (size_t)y * w + x] = acc;
+                    for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i * HW];
+                    sL[idx] = acc;
+                    if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) lt0[base + (size_t)y * w + x] = acc;
+                }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+        };
+        if (interior) blur5(std::true_type{});
+        else blur5(std::false_type{});
         prep_passes_fin<TW, TH, NT>(sL, sIn, sH, x0, y0, w, h, base, blurred, t3, [&](int x, int y, float lx1, float ly1) {
             const size_t gi = base + (size_t)y * w + x;  // the (filled) Scharr pair: the histogram pass and level 1's Lflow read it
             gx_out[gi] = lx1;
@@ -874,72 +882,80 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
         float* const lyy_out = dl.lyy;
         float* const lxy_out = dl.lxy;
         float* const ldet_out = dl.ldet;
-        // ---- stage 1, H pass: Hm = H_main(Ls), Ho = H_off(Ls) ----
-        for (int idx = tid; idx < H1W * H1H; idx += NT) {
-            const int wy = idx / H1W, wx = idx - wy * H1W;
-            const int x = x0 - R - S + wx, y = y0 - R - 2 * S + wy;
-            if (x < 0 || x >= w || y < 0 || y >= h) continue;
-            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-            const float* p = s0 + (cy - (y0 - R - 2 * S)) * W0W + (cx - (x0 - R - 2 * S));
-            const float a = p[-S], b = p[0], c = p[S];
-            sHm[idx] = tap_main(a, b, c, kn, kwn);
-            sHo[idx] = tap_off(a, b, c);
-        }
-        __syncthreads();  // the Lsmooth window is dead from here on
-        // ---- stage 1, V pass: Lx = V_off(Hm), Ly = V_main(Ho); the tile's own pixels go to HBM ----
-        for (int idx = tid; idx < W2W * W2H; idx += NT) {
-            const int wy = idx / W2W, wx = idx - wy * W2W;
-            const int x = x0 - R - S + wx, y = y0 - R - S + wy;
-            if (x < 0 || x >= w || y < 0 || y >= h) continue;
-            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-            const int o = (cy - (y0 - R - 2 * S)) * H1W + (cx - (x0 - R - S));
-            const float vx = tap_off(sHm[o - S * H1W], sHm[o], sHm[o + S * H1W]);
-            const float vy = tap_main(sHo[o - S * H1W], sHo[o], sHo[o + S * H1W], kn, kwn);
-            sLx[idx] = vx;
-            sLy[idx] = vy;
-            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
-                const size_t gi = base + (size_t)y * w + x;
-                lx_out[gi] = vx;
-                ly_out[gi] = vy;
+        // A tile whose windows lie in the image's interior -- nine in ten of a 1080p level -- needs neither the in-image tests nor
+        // the clamps of fill_border (every clamp is the identity there): the same arithmetic, two thirds of the instructions.
+        const bool interior = x0 >= R + 3 * S && x0 + TW + R + 3 * S <= w && y0 >= R + 3 * S && y0 + DTH + R + 3 * S <= h;
+        auto passes = [&](auto in_tag) {
+            constexpr bool IN = decltype(in_tag)::value;
+            // ---- stage 1, H pass: Hm = H_main(Ls), Ho = H_off(Ls) ----
+            for (int idx = tid; idx < H1W * H1H; idx += NT) {
+                const int wy = idx / H1W, wx = idx - wy * H1W;
+                const int x = x0 - R - S + wx, y = y0 - R - 2 * S + wy;
+                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
+                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
+                const float* p = s0 + (cy - (y0 - R - 2 * S)) * W0W + (cx - (x0 - R - 2 * S));
+                const float a = p[-S], b = p[0], c = p[S];
+                sHm[idx] = tap_main(a, b, c, kn, kwn);
+                sHo[idx] = tap_off(a, b, c);
             }
-        }
-        __syncthreads();  // Hm / Ho are dead from here on
-        // ---- stage 2, H pass: A = H_main(Lx), B = H_off(Ly), C = H_off(Lx) ----
-        for (int idx = tid; idx < H2W * H2H; idx += NT) {
-            const int wy = idx / H2W, wx = idx - wy * H2W;
-            const int x = x0 - R + wx, y = y0 - R - S + wy;
-            if (x < 0 || x >= w || y < 0 || y >= h) continue;
-            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-            const int o = (cy - (y0 - R - S)) * W2W + (cx - (x0 - R - S));
-            const float xa = sLx[o - S], xb = sLx[o], xc = sLx[o + S];
-            const float ya = sLy[o - S], yb = sLy[o], yc = sLy[o + S];
-            sA[idx] = tap_main(xa, xb, xc, kn, kwn);
-            sB[idx] = tap_off(ya, yb, yc);
-            sC[idx] = tap_off(xa, xb, xc);
-        }
-        __syncthreads();  // Lx / Ly windows are dead from here on (sD aliases them)
-        // ---- stage 2, V pass + determinant ----
-        for (int idx = tid; idx < DW * DH; idx += NT) {
-            const int wy = idx / DW, wx = idx - wy * DW;
-            const int x = x0 - R + wx, y = y0 - R + wy;
-            if (x < 0 || x >= w || y < 0 || y >= h) continue;
-            const int cx = clampi(x, S, w - 1 - S), cy = clampi(y, S, h - 1 - S);
-            const int o = (cy - (y0 - R - S)) * H2W + (cx - (x0 - R));
-            const float lxx = tap_off(sA[o - S * H2W], sA[o], sA[o + S * H2W]);
-            const float lyy = tap_main(sB[o - S * H2W], sB[o], sB[o + S * H2W], kn, kwn);
-            const float lxy = tap_main(sC[o - S * H2W], sC[o], sC[o + S * H2W], kn, kwn);
-            const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
-            if (NMS) sD[idx] = det;
-            if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
-                const size_t gi = base + (size_t)y * w + x;
-                if (KEEP) {
-                    lxx_out[gi] = lxx;
-                    lyy_out[gi] = lyy;
-                    lxy_out[gi] = lxy;
+            __syncthreads();  // the Lsmooth window is dead from here on
+            // ---- stage 1, V pass: Lx = V_off(Hm), Ly = V_main(Ho); the tile's own pixels go to HBM ----
+            for (int idx = tid; idx < W2W * W2H; idx += NT) {
+                const int wy = idx / W2W, wx = idx - wy * W2W;
+                const int x = x0 - R - S + wx, y = y0 - R - S + wy;
+                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
+                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
+                const int o = (cy - (y0 - R - 2 * S)) * H1W + (cx - (x0 - R - S));
+                const float vx = tap_off(sHm[o - S * H1W], sHm[o], sHm[o + S * H1W]);
+                const float vy = tap_main(sHo[o - S * H1W], sHo[o], sHo[o + S * H1W], kn, kwn);
+                sLx[idx] = vx;
+                sLy[idx] = vy;
+                if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
+                    const size_t gi = base + (size_t)y * w + x;
+                    lx_out[gi] = vx;
+                    ly_out[gi] = vy;
                 }
-                ldet_out[gi] = det;
             }
-        }
+            __syncthreads();  // Hm / Ho are dead from here on
+            // ---- stage 2, H pass: A = H_main(Lx), B = H_off(Ly), C = H_off(Lx) ----
+            for (int idx = tid; idx < H2W * H2H; idx += NT) {
+                const int wy = idx / H2W, wx = idx - wy * H2W;
+                const int x = x0 - R + wx, y = y0 - R - S + wy;
+                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
+                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
+                const int o = (cy - (y0 - R - S)) * W2W + (cx - (x0 - R - S));
+                const float xa = sLx[o - S], xb = sLx[o], xc = sLx[o + S];
+                const float ya = sLy[o - S], yb = sLy[o], yc = sLy[o + S];
+                sA[idx] = tap_main(xa, xb, xc, kn, kwn);
+                sB[idx] = tap_off(ya, yb, yc);
+                sC[idx] = tap_off(xa, xb, xc);
+            }
+            __syncthreads();  // Lx / Ly windows are dead from here on (sD aliases them)
+            // ---- stage 2, V pass + determinant ----
+            for (int idx = tid; idx < DW * DH; idx += NT) {
+                const int wy = idx / DW, wx = idx - wy * DW;
+                const int x = x0 - R + wx, y = y0 - R + wy;
+                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
+                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
+                const int o = (cy - (y0 - R - S)) * H2W + (cx - (x0 - R));
+                const float lxx = tap_off(sA[o - S * H2W], sA[o], sA[o + S * H2W]);
+                const float lyy = tap_main(sB[o - S * H2W], sB[o], sB[o + S * H2W], kn, kwn);
+                const float lxy = tap_main(sC[o - S * H2W], sC[o], sC[o + S * H2W], kn, kwn);
+                const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
+                if (NMS) sD[idx] = det;
+                if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
+                    const size_t gi = base + (size_t)y * w + x;
+                    if (KEEP) {
+                        lxx_out[gi] = lxx;
+                        lyy_out[gi] = lyy;
+                        lxy_out[gi] = lxy;
+                    }
+                    ldet_out[gi] = det;
+                }
+            }
+        };
+        if (interior) passes(std::true_type{});
+        else passes(std::false_type{});
         __syncthreads();
         if (NMS) {
             tile_extrema<DW, DTH>(sD, sCnt, tid, tl, w, h, ds.thr, dl.border_m, dl.level, ds.cand, ds.cap, ds.count);

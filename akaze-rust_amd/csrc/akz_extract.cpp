@@ -80,6 +80,7 @@ struct akz_job {
     // goes: a job begun with none other in the caller's hand is being waited for, one begun with company is part of a stream
     std::shared_ptr<std::atomic<int>> in_hand;
     bool alone_at_begin = true;
+    hipStream_t done_stream = nullptr;  // the stream the begin chain ended on (the main stream, or the forked coarse chain's)
     ~akz_job() {
         if (in_hand) --*in_hand;
     }
@@ -874,6 +875,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     AKZ_HIP_TRY(hipGetLastError());
     job->nms_done = StageTimer::get(c);
     AKZ_HIP_TRY(hipEventRecord(job->nms_done, done_on));
+    job->done_stream = done_on;
     job->slot = slot;
     job->cap = cap;
     job->seq = seq;
@@ -975,7 +977,12 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
     // half): the streams of a process share a few hardware queues, each of which runs its packets in order, so every
     // further stream of a lane queues its keypoint kernels behind the launch chain of some other lane
     hipStream_t s = c->main;  // (never c->stream: extract_begin may be swapping it on the caller's thread right now)
-    if (!(c->is_lane && job->fin)) {
+    // ... and the job that is alone in the context's hands takes the stream its chain ended on: its keypoint kernels follow the
+    // last detector in order, without a dependency between two hardware queues (lone 1080p call 0.721 -> 0.694 ms)
+    const bool in_order = !c->is_lane && job->done_stream && job->alone_at_begin && job->in_hand && job->in_hand->load() == 1 && (c->sched[9] & 2) == 0;
+    if (in_order) {
+        s = job->done_stream;
+    } else if (!(c->is_lane && job->fin)) {
         AKZ_TRY(ensure_aux(c));
         s = c->aux;
     }
@@ -1121,7 +1128,7 @@ static int extract_finish_body(akz_job* jobp, akz_result** out) {
                     // ... and what the host wants of them -- headers, keypoint records, descriptor rows -- stored into its pinned
                     // buffers by the same launch (k_mldb's host mirror; sched[9] = 1: three copies behind the kernel, as before)
                     launch::MldbMirror mir{};
-                    if (c->sched[9] == 0) {
+                    if ((c->sched[9] & 1) == 0) {
                         const bool host_rows = !(r->flags & AKZ_NO_HOST_DESCRIPTORS);
                         AKZ_TRY(ensure_pinned(c, c->pin[8], (size_t)n * 64));
                         AKZ_TRY(ensure_pinned(c, c->pin[0], (size_t)mldb_spec * sizeof(SelKpHost)));

@@ -39,8 +39,10 @@ int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_
    also prepares the next level of the octave -- k_fed_own's epilogue);
    keys 7, 8 (process-wide): the least interior rows of a band of the detector march / the level march, 0 = the planners' rules
    (40; 20 below 48 Mpx per launch) -- how finely a small job's column marches are cut into workgroups;
-   key 9: 1 = the waited-for job's headers, keypoint records and descriptor rows come to the host as three copies behind the
-   descriptor kernel (default 0: that kernel stores them into the host's pinned buffers itself);
+   key 9: bit 0 = the waited-for job's headers, keypoint records and descriptor rows come to the host as three copies behind the
+   descriptor kernel (default: that kernel stores them into the host's pinned buffers itself); bit 1 = the keypoint kernels of
+   a job that is alone in the context's hands on the auxiliary stream, as every other job's (default: on the main stream,
+   in order behind its detectors, when its chain ended there);
    key 10: 1 = level 0 of a tiled-family job as separate launches -- blur, clearing of the contrast scratch, blur, maximum,
    histogram, percentile, and level 1's preparation as a k_prep launch (default 0: k_head + k_contrast_hist_final, and
    level 1's Lflow from k_head's Scharr pair). */

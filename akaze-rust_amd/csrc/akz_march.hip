@@ -988,6 +988,20 @@ k_blur5_march(const T* __restrict__ in, float* __restrict__ out, int w, int h, M
     }
 }
 
+}  // namespace
+namespace launch {
+static int g_det_min_rows = 0, g_lvl_min_rows = 0, g_head_min_rows = 0;  // (akz_debug_set_schedule keys 7, 8: measurement; 0 = the planners' rules)
+void march_min_band_rows(int detector, int level) {
+    g_det_min_rows = detector;
+    g_lvl_min_rows = level % 1000;
+    g_head_min_rows = level / 1000;  // (key 8 = 1000 * rows of the level-0 marches + rows of the level marches)
+}
+}  // namespace launch
+namespace {
+using launch::g_det_min_rows;
+using launch::g_lvl_min_rows;
+using launch::g_head_min_rows;
+
 inline MarchGrid plan_level_march(uint32_t w, uint32_t h, uint32_t n, dim3* grid, int fill_wg = 3, int min_band_rows = 64) {
     static int cus = 0;
     if (!cus) {
@@ -1076,11 +1090,6 @@ bool detector_march_supported(uint32_t sigma, uint32_t w, uint32_t h, float bord
     return !nms || border_m >= (float)(sigma + 2);
 }
 
-static int g_det_min_rows = 0, g_lvl_min_rows = 0;  // (akz_debug_set_schedule keys 7, 8: measurement; 0 = the rules below)
-void march_min_band_rows(int detector, int level) {
-    g_det_min_rows = detector;
-    g_lvl_min_rows = level;
-}
 
 template <int S, bool NMS, bool KEEP>
 static void launch_detector_march(hipStream_t s, const float* lsmooth, float* lx, float* ly, float* lxx, float* lyy, float* lxy,
@@ -1148,7 +1157,7 @@ static void blur5_march_t(hipStream_t s, const T* in, float* out, uint32_t w, ui
     for (int i = 0; i < 5; ++i) tp.k[i] = k[i];
     dim3 gr;
     // a light kernel (36-40 registers): six workgroups per compute unit instead of three, 86 -> 66 us per 32 x 1080p
-    const MarchGrid mg = plan_march(w, h, n, 2, &gr, 6, 32);
+    const MarchGrid mg = plan_march(w, h, n, 2, &gr, 6, g_head_min_rows > 0 ? g_head_min_rows : 32);
     if (w & 1u) hipLaunchKernelGGL((k_blur5_march<T, true>), gr, dim3(MT), 0, s, in, out, (int)w, (int)h, mg, tp);
     else hipLaunchKernelGGL((k_blur5_march<T, false>), gr, dim3(MT), 0, s, in, out, (int)w, (int)h, mg, tp);
 }
@@ -1171,7 +1180,7 @@ void contrast_march(hipStream_t s, const float* in, uint32_t w, uint32_t h, uint
     dim3 gr;
     // light kernels (52-59 registers, 8 to 20 KB of LDS): eight workgroups per compute unit hide the row latency that
     // three leave exposed (maximum pass 103 -> 82 us per 32 x 1080p); a band warms up over six rows only
-    const MarchGrid mg = plan_level_march(w, h, n, &gr, 8, 32);
+    const MarchGrid mg = plan_level_march(w, h, n, &gr, 8, g_head_min_rows > 0 ? g_head_min_rows : 32);
     if (w & 1u)
         hipLaunchKernelGGL((k_contrast_march<1, true>), gr, dim3(MT), 0, s, in, (int)w, (int)h, mg, g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1], ca);
     else

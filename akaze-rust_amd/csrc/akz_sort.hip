@@ -282,20 +282,27 @@ __global__ void __launch_bounds__(256) k_bucket_rank(const Candidate* __restrict
     if (zero) zero[lo + rank] = 0u;
 }
 
-__global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
-                                                   RelLevels lv, const unsigned* __restrict__ offs, const unsigned* __restrict__ rows,
-                                                   unsigned short* __restrict__ rel, unsigned* __restrict__ img_flags,
-                                                   unsigned* __restrict__ revcnt, unsigned short* __restrict__ rev) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= min(*d_count, cap)) return;
+// One WAVE per candidate (round 6; one thread per candidate before: 20 workgroups for a lone 1080p frame's list, every thread a
+// chain of ~15 dependent loads -- 32 us of the call, 55 for a 4K frame's): the lanes test a row band's entries side by side, so a
+// scan is one round of loads; matches take their places in list order by a ballot's prefix count, the lists are put together
+// in LDS (a wave's LDS operations execute in order) and leave in one store per place.
+constexpr int REL_WAVES = 4;  // candidates per workgroup
+__global__ void __launch_bounds__(64 * REL_WAVES) k_relations(const Candidate* __restrict__ sorted, const unsigned* __restrict__ d_count, unsigned cap,
+                                                              RelLevels lv, const unsigned* __restrict__ offs, const unsigned* __restrict__ rows,
+                                                              unsigned short* __restrict__ rel, unsigned* __restrict__ img_flags,
+                                                              unsigned* __restrict__ revcnt, unsigned short* __restrict__ rev) {
+    __shared__ unsigned short s_out[REL_WAVES][kRel1 + kRel2 + 2];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned i = blockIdx.x * REL_WAVES + wv;
+    if (i >= min(*d_count, cap)) return;  // (wave-uniform; no workgroup barrier below)
     const Candidate c = sorted[i];
     if (c.img >= lv.n_images || c.level >= lv.n_levels) return;
     const unsigned L = lv.n_levels, l = c.level;
     const unsigned* o = offs + (size_t)c.img * (L + 1);
     const unsigned img0 = o[0];
-    unsigned short* out = rel + (size_t)i * (kRel1 + kRel2);
-#pragma unroll
-    for (int k = 0; k < kRel1 + kRel2; ++k) out[k] = 0xffffu;
+    unsigned short* const mine = s_out[wv];
+    if (lane < (unsigned)(kRel1 + kRel2)) mine[lane] = 0xffffu;
     const bool too_many = o[L] - img0 > 65533u;
     bool over1 = false, over2 = false;
     const float size = lv.size[l], size2 = size * size, ratio = lv.ratio[l];
@@ -316,36 +323,40 @@ __global__ void __launch_bounds__(256) k_relations(const Candidate* __restrict__
         const unsigned r1 = min((unsigned)yhi + 1u, ph);  // one past the last row
         const unsigned* rt = rowI + lv.row_base[pl];
         const unsigned jb = max(b, rt[r0]), je = min(e, rt[r1]);
-        for (unsigned j0 = jb; j0 < je; j0 += 4) {  // (four loads in flight: a thread's loop is bound by their latency)
-            unsigned pidx[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) pidx[u] = j0 + u < je ? sorted[j0 + u].idx : 0u;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-            const unsigned j = j0 + u;
-            if (j >= je) break;
-            const unsigned py_i = pidx[u] / pw, px_i = pidx[u] - py_i * pw;
-            const float sx = (float)px_i * pr + off, sy = (float)py_i * pr + off;  // its stored position
-            const float dist = (x0 - sx) * (x0 - sx) + (y0 - sy) * (y0 - sy);
-            if (dist <= size2) {
-                if (used < room) out[first + used] = (unsigned short)(j - img0);
-                else overflow = true;
-                ++used;
+        for (unsigned j0 = jb; j0 < je; j0 += 64u) {  // (all of them wave-uniform)
+            const unsigned j = j0 + lane;
+            bool hit = false;
+            if (j < je) {
+                const unsigned pidx = sorted[j].idx;
+                const unsigned py_i = pidx / pw, px_i = pidx - py_i * pw;
+                const float sx = (float)px_i * pr + off, sy = (float)py_i * pr + off;  // its stored position
+                const float dist = (x0 - sx) * (x0 - sx) + (y0 - sy) * (y0 - sy);
+                hit = dist <= size2;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int at_list = used + (int)__popcll(m & ((1ull << lane) - 1ull));  // its place: list order is position order
+                if (at_list < room) mine[first + at_list] = (unsigned short)(j - img0);
                 if (first == 0 && revcnt) {  // the device selection: j learns that this candidate looks at it (akz_select.hpp)
                     const unsigned at = atomicAdd(&revcnt[j], 1u);
                     if (at < (unsigned)sel::kRev) rev[(size_t)j * sel::kRev + at] = (unsigned short)(i - img0);
                 }
             }
-            }
+            used += (int)__popcll(m);
+            if (used > room) overflow = true;
         }
     };
     int used1 = 0, used2 = 0;
     if (l > 0) scan(l - 1, o[l - 1], o[l], qx, qy, 0, kRel1, used1, over1);   // every entry of the previous level comes before this one
     scan(l, o[l], i, qx, qy, 0, kRel1, used1, over1);                          // its own level: the ones before it
     if (l + 1 < L) scan(l + 1, o[l + 1], o[l + 2], px, py, kRel1, kRel2, used2, over2);
-    if (over1) out[0] = 0xfffeu;
-    if (over2) out[kRel1] = 0xfffeu;
-    if (too_many) img_flags[c.img] = 1u;
+    if (lane == 0) {
+        if (over1) mine[0] = 0xfffeu;
+        if (over2) mine[kRel1] = 0xfffeu;
+        if (too_many) img_flags[c.img] = 1u;
+    }
+    unsigned short* out = rel + (size_t)i * (kRel1 + kRel2);
+    if (lane < (unsigned)(kRel1 + kRel2)) out[lane] = mine[lane];
 }
 
 
@@ -897,7 +908,8 @@ void candidate_relations(hipStream_t s, const Candidate* d_sorted, uint32_t cap,
         revcnt = (unsigned*)((char*)sel_scratch + l.revcnt);
         rev = (unsigned short*)((char*)sel_scratch + l.rev);
     }
-    hipLaunchKernelGGL(k_relations, dim3((cap + 255) / 256), dim3(256), 0, s, d_sorted, d_count, cap, lv, offs, rows, rel, flags, revcnt, rev);
+    hipLaunchKernelGGL(k_relations, dim3((cap + REL_WAVES - 1) / REL_WAVES), dim3(64 * REL_WAVES), 0, s, d_sorted, d_count, cap, lv, offs, rows, rel, flags,
+                       revcnt, rev);
 }
 
 // scratch layout: keys in | keys out | positions in | positions out | rocPRIM's temporary storage

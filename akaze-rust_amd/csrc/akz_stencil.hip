@@ -887,70 +887,103 @@ k_detector_tiled(DetSet ds, float kn, float kwn, float quat) {
         const bool interior = x0 >= R + 3 * S && x0 + TW + R + 3 * S <= w && y0 >= R + 3 * S && y0 + DTH + R + 3 * S <= h;
         auto passes = [&](auto in_tag) {
             constexpr bool IN = decltype(in_tag)::value;
+            // Every pass: a thread owns one window COLUMN and walks down it in strides of NT / width rows -- the column's
+            // in-image test and clamp are formed once per pass, the row's cost an add and (off the interior) a clamp, where
+            // an element index per trip cost a division by the window width and both clamps.
             // ---- stage 1, H pass: Hm = H_main(Ls), Ho = H_off(Ls) ----
-            for (int idx = tid; idx < H1W * H1H; idx += NT) {
-                const int wy = idx / H1W, wx = idx - wy * H1W;
-                const int x = x0 - R - S + wx, y = y0 - R - 2 * S + wy;
-                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
-                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
-                const float* p = s0 + (cy - (y0 - R - 2 * S)) * W0W + (cx - (x0 - R - 2 * S));
-                const float a = p[-S], b = p[0], c = p[S];
-                sHm[idx] = tap_main(a, b, c, kn, kwn);
-                sHo[idx] = tap_off(a, b, c);
+            {
+                constexpr int RS = NT / H1W;
+                const int r0 = tid / H1W, wx = tid - r0 * H1W;
+                const int x = x0 - R - S + wx;
+                if (r0 < RS && (IN || (x >= 0 && x < w))) {
+                    const int cx = IN ? x : clampi(x, S, w - 1 - S);
+                    for (int wy = r0; wy < H1H; wy += RS) {
+                        const int y = y0 - R - 2 * S + wy;
+                        if (!IN && (y < 0 || y >= h)) continue;
+                        const int cy = IN ? y : clampi(y, S, h - 1 - S);
+                        const float* p = s0 + (cy - (y0 - R - 2 * S)) * W0W + (cx - (x0 - R - 2 * S));
+                        const float a = p[-S], b = p[0], c = p[S];
+                        sHm[wy * H1W + wx] = tap_main(a, b, c, kn, kwn);
+                        sHo[wy * H1W + wx] = tap_off(a, b, c);
+                    }
+                }
             }
             __syncthreads();  // the Lsmooth window is dead from here on
             // ---- stage 1, V pass: Lx = V_off(Hm), Ly = V_main(Ho); the tile's own pixels go to HBM ----
-            for (int idx = tid; idx < W2W * W2H; idx += NT) {
-                const int wy = idx / W2W, wx = idx - wy * W2W;
-                const int x = x0 - R - S + wx, y = y0 - R - S + wy;
-                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
-                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
-                const int o = (cy - (y0 - R - 2 * S)) * H1W + (cx - (x0 - R - S));
-                const float vx = tap_off(sHm[o - S * H1W], sHm[o], sHm[o + S * H1W]);
-                const float vy = tap_main(sHo[o - S * H1W], sHo[o], sHo[o + S * H1W], kn, kwn);
-                sLx[idx] = vx;
-                sLy[idx] = vy;
-                if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
-                    const size_t gi = base + (size_t)y * w + x;
-                    lx_out[gi] = vx;
-                    ly_out[gi] = vy;
+            {
+                constexpr int RS = NT / W2W;
+                const int r0 = tid / W2W, wx = tid - r0 * W2W;
+                const int x = x0 - R - S + wx;
+                if (r0 < RS && (IN || (x >= 0 && x < w))) {
+                    const int cx = IN ? x : clampi(x, S, w - 1 - S);
+                    const bool own_x = x >= x0 && x < x0 + TW;
+                    for (int wy = r0; wy < W2H; wy += RS) {
+                        const int y = y0 - R - S + wy;
+                        if (!IN && (y < 0 || y >= h)) continue;
+                        const int cy = IN ? y : clampi(y, S, h - 1 - S);
+                        const int o = (cy - (y0 - R - 2 * S)) * H1W + (cx - (x0 - R - S));
+                        const float vx = tap_off(sHm[o - S * H1W], sHm[o], sHm[o + S * H1W]);
+                        const float vy = tap_main(sHo[o - S * H1W], sHo[o], sHo[o + S * H1W], kn, kwn);
+                        sLx[wy * W2W + wx] = vx;
+                        sLy[wy * W2W + wx] = vy;
+                        if (own_x && y >= y0 && y < y0 + DTH) {
+                            const size_t gi = base + (size_t)y * w + x;
+                            lx_out[gi] = vx;
+                            ly_out[gi] = vy;
+                        }
+                    }
                 }
             }
             __syncthreads();  // Hm / Ho are dead from here on
             // ---- stage 2, H pass: A = H_main(Lx), B = H_off(Ly), C = H_off(Lx) ----
-            for (int idx = tid; idx < H2W * H2H; idx += NT) {
-                const int wy = idx / H2W, wx = idx - wy * H2W;
-                const int x = x0 - R + wx, y = y0 - R - S + wy;
-                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
-                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
-                const int o = (cy - (y0 - R - S)) * W2W + (cx - (x0 - R - S));
-                const float xa = sLx[o - S], xb = sLx[o], xc = sLx[o + S];
-                const float ya = sLy[o - S], yb = sLy[o], yc = sLy[o + S];
-                sA[idx] = tap_main(xa, xb, xc, kn, kwn);
-                sB[idx] = tap_off(ya, yb, yc);
-                sC[idx] = tap_off(xa, xb, xc);
+            {
+                constexpr int RS = NT / H2W;
+                const int r0 = tid / H2W, wx = tid - r0 * H2W;
+                const int x = x0 - R + wx;
+                if (r0 < RS && (IN || (x >= 0 && x < w))) {
+                    const int cx = IN ? x : clampi(x, S, w - 1 - S);
+                    for (int wy = r0; wy < H2H; wy += RS) {
+                        const int y = y0 - R - S + wy;
+                        if (!IN && (y < 0 || y >= h)) continue;
+                        const int cy = IN ? y : clampi(y, S, h - 1 - S);
+                        const int o = (cy - (y0 - R - S)) * W2W + (cx - (x0 - R - S));
+                        const float xa = sLx[o - S], xb = sLx[o], xc = sLx[o + S];
+                        const float ya = sLy[o - S], yb = sLy[o], yc = sLy[o + S];
+                        sA[wy * H2W + wx] = tap_main(xa, xb, xc, kn, kwn);
+                        sB[wy * H2W + wx] = tap_off(ya, yb, yc);
+                        sC[wy * H2W + wx] = tap_off(xa, xb, xc);
+                    }
+                }
             }
             __syncthreads();  // Lx / Ly windows are dead from here on (sD aliases them)
             // ---- stage 2, V pass + determinant ----
-            for (int idx = tid; idx < DW * DH; idx += NT) {
-                const int wy = idx / DW, wx = idx - wy * DW;
-                const int x = x0 - R + wx, y = y0 - R + wy;
-                if (!IN && (x < 0 || x >= w || y < 0 || y >= h)) continue;
-                const int cx = IN ? x : clampi(x, S, w - 1 - S), cy = IN ? y : clampi(y, S, h - 1 - S);
-                const int o = (cy - (y0 - R - S)) * H2W + (cx - (x0 - R));
-                const float lxx = tap_off(sA[o - S * H2W], sA[o], sA[o + S * H2W]);
-                const float lyy = tap_main(sB[o - S * H2W], sB[o], sB[o + S * H2W], kn, kwn);
-                const float lxy = tap_main(sC[o - S * H2W], sC[o], sC[o + S * H2W], kn, kwn);
-                const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
-                if (NMS) sD[idx] = det;
-                if (x >= x0 && x < x0 + TW && y >= y0 && y < y0 + DTH) {
-                    const size_t gi = base + (size_t)y * w + x;
-                    if (KEEP) {
-                        lxx_out[gi] = lxx;
-                        lyy_out[gi] = lyy;
-                        lxy_out[gi] = lxy;
+            {
+                constexpr int RS = NT / DW;
+                const int r0 = tid / DW, wx = tid - r0 * DW;
+                const int x = x0 - R + wx;
+                if (r0 < RS && (IN || (x >= 0 && x < w))) {
+                    const int cx = IN ? x : clampi(x, S, w - 1 - S);
+                    const bool own_x = x >= x0 && x < x0 + TW;
+                    for (int wy = r0; wy < DH; wy += RS) {
+                        const int y = y0 - R + wy;
+                        if (!IN && (y < 0 || y >= h)) continue;
+                        const int cy = IN ? y : clampi(y, S, h - 1 - S);
+                        const int o = (cy - (y0 - R - S)) * H2W + (cx - (x0 - R));
+                        const float lxx = tap_off(sA[o - S * H2W], sA[o], sA[o + S * H2W]);
+                        const float lyy = tap_main(sB[o - S * H2W], sB[o], sB[o + S * H2W], kn, kwn);
+                        const float lxy = tap_main(sC[o - S * H2W], sC[o], sC[o + S * H2W], kn, kwn);
+                        const float det = ((lxx * lyy) - (lxy * lxy)) * quat;
+                        if (NMS) sD[wy * DW + wx] = det;
+                        if (own_x && y >= y0 && y < y0 + DTH) {
+                            const size_t gi = base + (size_t)y * w + x;
+                            if (KEEP) {
+                                lxx_out[gi] = lxx;
+                                lyy_out[gi] = lyy;
+                                lxy_out[gi] = lxy;
+                            }
+                            ldet_out[gi] = det;
+                        }
                     }
-                    ldet_out[gi] = det;
                 }
             }
         };

@@ -811,11 +811,13 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         return AKZ_OK;
     };
     // (A small job's first-octave detectors on a second stream, under the remaining octaves' chain of small launches, was built
-    // and measured twice in round 6.  With the persistent detector launches: lone 1080p call 0.795 / 0.799 ms with / without, 720p
-    // 0.634 / 0.620 -- persistent workgroups hold their compute units until the launch ends and the chain's launches wait for
-    // places.  With one tile per workgroup on a lowest-priority stream the two do run side by side -- under rocprofv3 the begin
-    // chain ends 40 us earlier -- but unprofiled, where the chain's launches follow each other without the profiler's gaps, there
-    // is nothing to fill: the call 0.745-0.751 / 0.749-0.750 ms, 720p 0.588 / 0.576.  Not kept.)
+    // and measured three times in round 6.  With the persistent detector launches: lone 1080p call 0.795 / 0.799 ms with /
+    // without, 720p 0.634 / 0.620 -- persistent workgroups hold their compute units until the launch ends and the chain's
+    // launches wait for places.  With one tile per workgroup on a lowest-priority stream the two do run side by side -- under
+    // rocprofv3 the begin chain ends 40 us earlier -- but unprofiled, where the chain's launches follow each other without the
+    // profiler's gaps, there is nothing to fill: 0.745-0.751 / 0.749-0.750 ms, 720p 0.588 / 0.576.  On a stream with a CU mask
+    // (hipExtStreamCreateWithCUMask: 64 / 128 / 192 of the 256 compute units): 0.730 / 0.690 / 0.670 against 0.682 without, a
+    // stream of frames 0.57 / 0.54 / 0.514 against 0.519, 720p 0.54 against 0.53.  Not kept.)
     // the fine levels (all levels when the batch does not fork) on the main stream
     {
         size_t oct1 = 1;  // first level past the first octave (fork_level if there is none on the main stream)

@@ -334,9 +334,31 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
     }
     __syncthreads();  // sB is free from here on: it becomes the second Lt buffer
 
-    // image-border presence flags of the two owned rows (constant over the steps)
-    const bool inner = gya >= 1 && gyb + 1 < h && gx >= 1 && gx + 4 < w;
-    const bool a_hyn = gya > 0, a_hyp = gya + 1 < h, b_hyn = gyb > 0, b_hyp = gyb + 1 < h;
+    // The image's border WITHOUT the case-by-case expressions of :84-137 (column 0 is a group's first; column w-1 may be any of a
+    // group's four).  Every case is the full
+    // expression  ((x_pos - x_neg) + y_pos) - y_neg  with the missing term replaced by a signed zero that makes the sum
+    // bit-identical to the reference's shorter one:
+    //   no left neighbour   t = x_pos            == x_pos - (+0)          x - (+0) == x for every x, -0 included
+    //   no right neighbour  t = -x_neg           == (-0) - x_neg          (-0) - x == -x for every x, both zeros included
+    //   first row           t = .. + y_pos       == (.. + y_pos) - (+0)
+    //   last row            t = .. + c' (L(y-1) - L)  [:104-119: y_pos taken towards y-1, nothing subtracted]
+    //                                            == (.. + y_pos') - (+0)  with y_pos' that very product: the pair sum and the
+    //                                               neighbour of y_neg in y_pos's place
+    // so a border thread runs the same packed instructions as every other plus a few selects, behind branches that are
+    // uniform over the wave.  (Before, a thread with any border or outside pixel ran all eight of its pixels through the cases:
+    // in the tiles on the image's left and right edges that is every wave, and a fused step of a small level -- whose launch
+    // lasts as long as its slowest workgroup -- cost 0.85 us instead of 0.47: a third of a lone frame's coarse octaves.)
+    const bool left = gx == 0;
+    const int kr = w - gx;  // the flux to the right of the image's last column is XF[kr], if this group holds that column
+    const bool right = kr >= 1 && kr <= 4;
+    const bool zu_a = gya == 0 || gya == h - 1, zu_b = gyb == 0 || gyb == h - 1;  // no y_neg term: first row, last row
+    const bool bot_a = gya == h - 1, bot_b = gyb == h - 1;
+    const bool colcase = __ballot(left || right) != 0ull, rowcase = __ballot(zu_a || zu_b) != 0ull;  // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // last row: y_pos' uses y_neg's pair sum
+        if (bot_a) SV[i].x = SU[i].x;
+        if (bot_b) SV[i].y = SU[i].y;
+    }
 
     float* src = sA;
     float* dst = sB;
@@ -362,33 +384,26 @@ k_fed_own(const float* __restrict__ L_in, const float* __restrict__ C, float* __
             U[i] = SU[i] * (L[i] - v2{ln[i], L[i].x});
             V[i] = SV[i] * (v2{L[i].y, ls[i]} - L[i]);
         }
-        if (inner) {
+        if (colcase) {
+            if (left) XF[0] = v2{0.0f, 0.0f};
+#pragma unroll
+            for (int k = 1; k <= 4; ++k)
+                if (kr == k) XF[k] = v2{-0.0f, -0.0f};
+        }
+        if (rowcase) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ST[i] = half_tau * (((XF[i + 1] - XF[i]) + V[i]) - U[i]);
-                L[i] = L[i] + ST[i];
+                // (last row: the product c' (L(y-1) - L) in y_pos's place; row b's y-1 is row a)
+                if (bot_a) V[i].x = SV[i].x * (ln[i] - L[i].x);
+                if (bot_b) V[i].y = SV[i].y * (L[i].x - L[i].y);
+                if (zu_a) U[i].x = 0.0f;
+                if (zu_b) U[i].y = 0.0f;
             }
-        } else {
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool hxp = gx + i + 1 < w, hxn = gx + i > 0;
-                float ta = hxp ? (hxn ? XF[i + 1].x - XF[i].x : XF[i + 1].x) : -XF[i].x;
-                float tb = hxp ? (hxn ? XF[i + 1].y - XF[i].y : XF[i + 1].y) : -XF[i].y;
-                if (a_hyp) {
-                    ta = ta + V[i].x;
-                    if (a_hyn) ta = ta - U[i].x;
-                } else {
-                    ta = ta + SU[i].x * (ln[i] - L[i].x);  // last image row: y_pos towards y-1 (:104-119)
-                }
-                if (b_hyp) {
-                    tb = tb + V[i].y;
-                    if (b_hyn) tb = tb - U[i].y;
-                } else {
-                    tb = tb + SU[i].y * (L[i].x - L[i].y);
-                }
-                ST[i] = v2{half_tau * ta, half_tau * tb};
-                L[i] = L[i] + ST[i];
-            }
+        for (int i = 0; i < 4; ++i) {
+            ST[i] = half_tau * (((XF[i + 1] - XF[i]) + V[i]) - U[i]);
+            L[i] = L[i] + ST[i];
         }
         if (s < steps) {
             if (active) {

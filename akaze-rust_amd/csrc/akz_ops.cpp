@@ -96,11 +96,10 @@ int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, float* d_blurred, float* 
     unsigned long long* d_smax = (unsigned long long*)c->small.p;
     uint32_t* d_hist = (uint32_t*)((char*)c->small.p + (size_t)n * 8);
     uint32_t* d_done = d_hist + (size_t)n * nbins;
-    if (c->small_zero_p != c->small.p || c->small_zero < small_bytes) {  // (first use, a larger job, or another family used it last)
+    const size_t known_zero = c->small_zero_p == c->small.p ? c->small_zero : 0;
+    c->small_zero = 0;  // (until both launches are enqueued: an error in between leaves the scratch in an unknown state)
+    if (known_zero < small_bytes)  // (first use, a larger job, or another family used it last)
         AKZ_HIP_TRY(hipMemsetAsync(c->small.p, 0, small_bytes, c->stream));
-        c->small_zero_p = c->small.p;
-        c->small_zero = small_bytes;
-    }
     float* blurred = d_blurred;  // (level 1's Lsmooth where level 1 continues the octave: the same blur of Lt0, lib.rs:92-95)
     if (!blurred) {
         AKZ_TRY(ensure(c, c->scratch[1], plane_bytes(w, h, n)));
@@ -118,6 +117,8 @@ int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, float* d_blurred, float* 
         launch::contrast_hist_final(c->stream, d_gx, d_gy, w, h, n, d_smax, (uint32_t)nbins, d_hist, d_done, percentile, d_k_out);
     }
     AKZ_HIP_TRY(hipGetLastError());
+    c->small_zero_p = c->small.p;
+    c->small_zero = std::max(known_zero, small_bytes);  // (the histogram pass leaves what it used zero again)
     *fused = true;
     return AKZ_OK;
 }

@@ -178,7 +178,9 @@ def test_isa_has_no_contracted_fma():
         assert not re.findall(r"\bv_(?:pk_fma|fma|fmac|mad|mac|fmaak|fmamk)_(?:f32|legacy_f32)\b", body), name
         n_div = len(re.findall(r"\bv_div_fmas_f64\b", body))
         n_rcp = len(re.findall(r"\bv_rcp_f64", body))
-        assert n_rcp - n_div == 1 and 2 * n_div - n_rcp == 1 and len(re.findall(r"\bv_(?:fma|fmac)_f64", body)) == 14, name
+        # (the passes are compiled twice -- tiles in the image's interior without tests and clamps, the others with: two pixel sites)
+        sites, plain = n_rcp - n_div, 2 * n_div - n_rcp
+        assert sites in (1, 2) and plain == 1 and len(re.findall(r"\bv_(?:fma|fmac)_f64", body)) == 9 * sites + 5 * plain, name
     assert seen == 4, seen
 
 

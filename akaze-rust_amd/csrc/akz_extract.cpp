@@ -1734,7 +1734,7 @@ int akz_extract_device_f32(akz_ctx* c, const float* d_imgs, uint32_t w, uint32_t
     return extract_impl<float>(c, d_imgs, w, h, n, cfg, flags, out);
 }
 
-// lanes = 1 (default): every job runs on the context's own stream.  lanes = k > 1: jobs below the batch-path gate (gates::kBigPxAsync) are dealt to k child
+// lanes = 1 (default): every job runs on the context's own stream.  lanes = k > 1: jobs below gates::kLanePx are dealt to k child
 // contexts in turn (larger jobs fill the chip on their own and stay on the context).  A job's result belongs to the
 // lane it ran on; nothing else changes for the caller (same begin / finish / result calls, bit-identical results).
 int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
@@ -1767,8 +1767,8 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->det_mode = c->det_mode; l->prep_mode = c->prep_mode; l->match_mode = c->match_mode; l->fed_mode = c->fed_mode;
         l->cand_cap_hint = c->cand_cap_hint.load();
         l->stream_min_px = c->stream_min_px;
-        l->big_px_sync = c->big_px_sync;
-        l->big_px_async = c->big_px_async;
+        l->big_px_sync = std::max(c->big_px_sync, c->lane_px);  // (a job that is dealt to a lane runs there as a one-stream chain)
+        l->big_px_async = std::max(c->big_px_async, c->lane_px);
         l->host_threads = c->host_threads;
         l->profiling = c->profiling;
         l->dbg_pair_chunks = c->dbg_pair_chunks;
@@ -1791,7 +1791,7 @@ int akz_ctx_set_eager_finish(akz_ctx* c, int on) {
 static int extract_begin_dispatch(akz_ctx* c, const void* imgs, bool is_u8, uint32_t w, uint32_t h, uint32_t n,
                                   const akz_config* cfg, uint32_t flags, akz_job** out, bool on_host = false) {
     akz_ctx* on = c;
-    if (c && !c->lanes.empty() && (uint64_t)w * h * n < c->big_px_async) {
+    if (c && !c->lanes.empty() && (uint64_t)w * h * n < c->lane_px) {
         AKZ_TRY(bind(c, false));
         on = c->lanes[c->next_lane++ % c->lanes.size()];
         // the lane starts when the caller's stream has reached this point (its inputs are complete)

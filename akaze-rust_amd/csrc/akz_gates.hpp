@@ -20,10 +20,16 @@ namespace gates {
 // chain of tiled launches on one stream.  Rounds 4-5 had the gate at 6 Mpx for a synchronous call and 3 Mpx for a job of the
 // begin / finish interface; round 6 found why a call liked the batch path so much later than a stream: its keypoint
 // selection ran on the host's grids (one thread per image), which a stream hides and a call does not.  With the selection of
-// the job that is waited for on the device, the batch path wins from ~2.4 Mpx on through both entry points (at 1 x 1080p and
-// 2 x 720p the two are equal): profiles/r06_job_gates.txt.  Two constants remain because akz_ctx_calibrate_gates measures both.
-constexpr uint64_t kBigPxSync = 2400000;    // akz_extract_*
-constexpr uint64_t kBigPxAsync = 2400000;   // akz_extract_begin_*  (akz_ctx_set_lanes deals the jobs below it to its lanes)
+// the job that is waited for on the device, the batch path won from ~2.4 Mpx on through both entry points (at 1 x 1080p and
+// 2 x 720p the two were equal): profiles/r06_job_gates.txt.  Later in round 6 the diffusion kernel stopped paying for the
+// image's border (akz_kernels.hip: k_fed_own) and the fork of the coarse chain began to pay for a lone 1080p frame as well:
+// 0.633 -> 0.617 ms per call, 0.470 -> 0.443 per streamed frame; 1760 x 990: 0.628 -> 0.597 / 0.455 -> 0.426; at 1600 x 900 the two
+// are equal, at 2 x 960 x 540 and 1280 x 720 the one-stream chain is 5-8 % ahead (profiles/r06_lone_chain.txt): 1.5 Mpx.  Two
+// constants remain because akz_ctx_calibrate_gates measures both.
+constexpr uint64_t kBigPxSync = 1500000;    // akz_extract_*
+constexpr uint64_t kBigPxAsync = 1500000;   // akz_extract_begin_*
+constexpr uint64_t kLanePx = 2400000;       // akz_ctx_set_lanes deals the jobs below this to its lanes (where they run as one-stream chains:
+                                            // four lanes carry 1080p frames at 0.34-0.37 ms each, the batch path on one context at 0.44)
 constexpr uint64_t kTiledPrepPx = 8000000;  // jobs below this: the tiled preparation family for every launch (k_blur, k_contrast_max /
                                             // _hist, k_prep riding on k_fed_own's last launch, no resident tail) whatever the
                                             // per-launch gates below say (r06_lone_libm.txt)
@@ -46,7 +52,8 @@ constexpr uint32_t kPremergeChunks = 4;             // more train chunks than th
 inline const akz_gate* table(size_t* n) {
     static const akz_gate rows[] = {
         {"big_px_sync", (double)kBigPxSync, "input px per job", "synchronous akz_extract_*: the chain of tiled launches on one stream below, the batch path (forked coarse chain; marches and resident tail where tiled_prep_px and the per-launch gates allow) from here on"},
-        {"big_px_async", (double)kBigPxAsync, "input px per job", "akz_extract_begin_*: the same choice for a job of the begin / finish interface; akz_ctx_set_lanes deals the jobs below it to its lanes"},
+        {"big_px_async", (double)kBigPxAsync, "input px per job", "akz_extract_begin_*: the same choice for a job of the begin / finish interface"},
+        {"lane_px", (double)kLanePx, "input px per job", "a context with lanes (akz_ctx_set_lanes) deals the jobs below this to them, as one-stream chains; larger jobs stay on the context"},
         {"tiled_prep_px", (double)kTiledPrepPx, "input px per job", "below: the tiled preparation family for every launch of the job (level-0 blur, contrast passes, k_prep as an epilogue of the previous level's last k_fed_own launch, no resident tail); from here on the per-launch gates below decide"},
         {"march_px", (double)kMarchPx, "level px per launch", "k_blur5_march / k_contrast_march / k_detector_march instead of the tiled kernels (batch-path jobs: their full-resolution launches regardless)"},
         {"level_march_px", (double)kLevelMarchPx, "level px per launch", "k_level_march instead of k_prep + k_fed_own"},

@@ -1157,14 +1157,18 @@ def main_rank(args):
                 single["orientation_libm"] = {"error": str(e)[:200]}
         # the same stream on ONE context with lanes: frames dealt to 2 .. 4 child contexts, each of which finishes its frames
         # on its own thread; the caller's thread only enqueues the next frames and collects results; lone 4K frames the same way
-        def stream_eager(frame, lanes, reps_e):
-            ctx.set_lanes(lanes)
-            for _ in range(2 * lanes):
-                ctx.extract_begin(frame, cfg, keep_all_planes=not args.lean).finish().close()
+        # (on a context of its own, as tools/lanes_ab.py: the bench's context has been through every other leg -- its four
+        # streams, host-thread settings and probes -- and its lanes then measure 0.5-0.7 ms per frame where a fresh context's
+        # measure 0.33-0.40)
+        def stream_eager(lctx, frame, lanes, reps_e):
+            lctx.set_lanes(lanes)
+            for _ in range(2 * lanes + 4):
+                lctx.extract_begin(frame, cfg, keep_all_planes=not args.lean).finish().close()
+            torch.cuda.synchronize()
             t_e = time.perf_counter()
             pend = []
             for _ in range(reps_e):
-                pend.append(ctx.extract_begin(frame, cfg, keep_all_planes=not args.lean))
+                pend.append(lctx.extract_begin(frame, cfg, keep_all_planes=not args.lean))
                 if len(pend) >= lanes:
                     pend.pop(0).finish().close()
             while pend:
@@ -1172,9 +1176,21 @@ def main_rank(args):
             dt = (time.perf_counter() - t_e) / reps_e
             return dt
         single["lanes"] = {}
-        for lanes in (2, 3, 4):
-            thr_e = stream_eager(one, lanes, reps)
-            single["lanes"][str(lanes)] = {"stream_ms_per_frame": round(thr_e * 1e3, 3), "stream_Mpix_s": round(W * H / thr_e / 1e6, 1)}
+        try:
+            if stub:
+                raise RuntimeError("no lanes on the stub context")
+            st_l = torch.cuda.Stream(dev)
+            with torch.cuda.stream(st_l):
+                ctx_l = A.Context(dev_index, st_l.cuda_stream)
+                if hasattr(ctx_l, "warmup"):
+                    ctx_l.warmup()
+                for lanes in (2, 3, 4):
+                    thr_e = stream_eager(ctx_l, one, lanes, 2 * reps)
+                    single["lanes"][str(lanes)] = {"stream_ms_per_frame": round(thr_e * 1e3, 3), "stream_Mpix_s": round(W * H / thr_e / 1e6, 1)}
+                ctx_l.set_lanes(1)
+                ctx_l.close()
+        except Exception as e:
+            single["lanes"]["error"] = str(e)[:300]
         if not stub:
             try:
                 one4k = torch.from_numpy(A.synth_frame(3840, 2160, 3)[None]).to(dev)

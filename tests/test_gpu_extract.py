@@ -46,7 +46,7 @@ def test_extract_matches_oracle_all_planes(ctx, amd, ref, w, h, idx):
 
 
 @pytest.mark.parametrize("w,h", [(11, 11), (12, 40), (33, 17), (81, 41), (159, 79), (160, 80), (161, 81), (2000, 24),
-                                 (24, 1500)])
+                                 (24, 1500), (70, 50), (162, 83), (166, 82), (67, 133)])
 def test_extract_edge_sizes(ctx, amd, ref, w, h):
     """The smallest accepted frame (11 x 11: the detector Scharr of sigma 4 needs 2*4+3), frames smaller than one
     tile, strips, and the sizes either side of the second octave's admission rule (evolution.rs:138-149: 160 x 80)."""
@@ -55,6 +55,47 @@ def test_extract_edge_sizes(ctx, amd, ref, w, h):
     rf = ref.extract(frame)
     assert res.counts(0)[0] == rf.num_levels == (8 if w >= 160 and h >= 80 else 4)
     assert_same_result(res, rf)
+
+
+@pytest.mark.parametrize("w,h,n", [(163, 81, 3), (130, 66, 4), (321, 243, 2)])
+def test_extract_small_batches_of_odd_frames(ctx, amd, ref, w, h, n):
+    """Several frames per job whose planes do not start on 16-byte boundaries (w * h odd or 2 mod 4: the elementwise
+    histogram and flow kernels of the level-0 launches take their scalar form) and whose last column is not the last of a
+    group of four (k_fed_own's border substitution at every place of a group): every image equals the oracle's, planes included."""
+    import torch
+    frames = np.stack([amd.synth_frame(w, h, 60 + i) for i in range(n)])
+    res = ctx.extract_features(torch.from_numpy(frames).cuda())
+    for i in range(n):
+        rf = ref.extract(frames[i])
+        assert_same_result(res, rf, img=i)
+        rf.close()
+
+
+@pytest.mark.parametrize("w,h,block", [(200, 120, 8), (163, 81, 5), (640, 360, 16), (322, 200, 7)])
+def test_diffusion_planes_bit_for_bit_on_blocky_frames(ctx, amd, ref, w, h, block):
+    """Frames of constant blocks: most fluxes of the diffusion are exact zeros, at the image's border too -- where k_fed_own
+    replaces the missing term of the reference's shorter expressions by a signed zero (nonlinear_diffusion.rs:84-137).  Lt and
+    Lstep of every level must equal the oracle's BIT FOR BIT (np.array_equal takes -0.0 for +0.0: compared as words here)."""
+    rng = np.random.default_rng(w * 31 + h)
+    coarse = rng.integers(0, 256, ((h + block - 1) // block, (w + block - 1) // block), dtype=np.uint8)
+    coarse[rng.random(coarse.shape) < 0.5] = 0  # (half of the blocks black: exact zeros in the planes themselves)
+    frame = np.ascontiguousarray(np.kron(coarse, np.ones((block, block), np.uint8))[:h, :w])
+    res, rf = ctx.extract_features(frame), ref.extract(frame)
+    nl = res.counts(0)[0]
+    assert nl == rf.num_levels
+    for lvl in range(nl):
+        for pl in ("Lt", "Lstep", "Lflow", "Lsmooth"):
+            a, b = np.ascontiguousarray(res.plane(lvl, pl, 0)), np.ascontiguousarray(rf.plane(lvl, pl))
+            if a.size == 0:
+                continue
+            nan = np.isnan(a)
+            assert np.array_equal(nan, np.isnan(b)), (lvl, pl)
+            wa, wb = a.view(np.uint32)[~nan], b.view(np.uint32)[~nan]
+            if not np.array_equal(wa, wb):
+                bad = np.flatnonzero(wa != wb)
+                raise AssertionError(f"level {lvl} plane {pl}: {len(bad)} words differ, first {hex(wa[bad[0]])} vs {hex(wb[bad[0]])}")
+    assert_same_result(res, rf)
+    rf.close()
 
 
 def test_extract_flat_and_noise_frames(ctx, amd, ref):

@@ -553,7 +553,7 @@ int akz_ctx_warmup(akz_ctx* ctx);
    exists so that this path can be tested and so that callers with very dense frames can skip the retry. */
 int akz_ctx_set_candidate_hint(akz_ctx* ctx, uint32_t per_image);
 /* Lanes for small jobs.  A lone 1080p frame is a chain of ~45 launches of a few hundred workgroups each: the chip is busy
-   but only a fraction of it at a time.  With lanes = k (2..8) the extract_begin calls of jobs below 2.4 Mpx (akz_debug_gates: lane_px) are dealt in
+   but only a fraction of it at a time.  With lanes = k (2..8) the extract_begin calls of jobs below 2.4 Mpx (the lane gate of DESIGN.md 6.1) are dealt in
    turn to k child contexts with their own streams, scratch planes, candidate buffers and HOST THREAD: the finish half of
    a lane's job (candidate round trip, keypoint selection, orientation / descriptor kernels and their copies) starts on
    the lane's thread as soon as the job has been begun, so that the chains of consecutive frames overlap on the chip and

@@ -308,30 +308,44 @@ k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ bl
         const bool interior = x0 >= 6 && x0 + TW + 6 <= w && y0 >= 6 && y0 + TH + 6 <= h;  // (no test, no clamp: as in k_detector_tiled)
         auto blur5 = [&](auto in_tag) {
             constexpr bool IN = decltype(in_tag)::value;
-            for (int idx = tid; idx < HH * HW; idx += NT) {  // H pass of the 5-tap blur (types/image.rs:374-380), filled
-                const int ly = idx / HW, lx = idx - ly * HW;
-                const int x = x0 - 2 + lx, y = y0 - 4 + ly;
-                if (IN || (x >= 0 && x < w && y >= 0 && y < h)) {
-                    const int cx = IN ? x : clampi(x, 2, w - 3), cy = IN ? y : clampi(y, 2, h - 3);
-                    const float* p = sIn + (cy - (y0 - 4)) * IW + (cx - 2 - (x0 - 4));
-                    float acc = 0.0f;
+            // (a thread owns a window column and walks down it, as in k_detector_tiled)
+            {  // H pass of the 5-tap blur (types/image.rs:374-380), filled
+                constexpr int RS = NT / HW;
+                const int r0 = tid / HW, lx = tid - r0 * HW;
+                const int x = x0 - 2 + lx;
+                if (r0 < RS && (IN || (x >= 0 && x < w))) {
+                    const int cx = IN ? x : clampi(x, 2, w - 3);
+                    for (int ly = r0; ly < HH; ly += RS) {
+                        const int y = y0 - 4 + ly;
+                        if (!IN && (y < 0 || y >= h)) continue;
+                        const int cy = IN ? y : clampi(y, 2, h - 3);
+                        const float* p = sIn + (cy - (y0 - 4)) * IW + (cx - 2 - (x0 - 4));
+                        float acc = 0.0f;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i];
-                    sH[idx] = acc;
+                        for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i];
+                        sH[ly * HW + lx] = acc;
+                    }
                 }
             }
             __syncthreads();
-            for (int idx = tid; idx < LH * LW; idx += NT) {  // V pass: Lt0 on the tile + 2
-                const int ly = idx / LW, lx = idx - ly * LW;
-                const int x = x0 - 2 + lx, y = y0 - 2 + ly;
-                if (IN || (x >= 0 && x < w && y >= 0 && y < h)) {
-                    const int cx = IN ? x : clampi(x, 2, w - 3), cy = IN ? y : clampi(y, 2, h - 3);
-                    const float* p = sH + (cy - 2 - (y0 - 4)) * HW + (cx - (x0 - 2));
-                    float acc = 0.0f;
+            {  // V pass: Lt0 on the tile + 2
+                constexpr int RS = NT / LW;
+                const int r0 = tid / LW, lx = tid - r0 * LW;
+                const int x = x0 - 2 + lx;
+                if (r0 < RS && (IN || (x >= 0 && x < w))) {
+                    const int cx = IN ? x : clampi(x, 2, w - 3);
+                    const bool own_x = lx >= 2 && lx < TW + 2;
+                    for (int ly = r0; ly < LH; ly += RS) {
+                        const int y = y0 - 2 + ly;
+                        if (!IN && (y < 0 || y >= h)) continue;
+                        const int cy = IN ? y : clampi(y, 2, h - 3);
+                        const float* p = sH + (cy - 2 - (y0 - 4)) * HW + (cx - (x0 - 2));
+                        float acc = 0.0f;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i * HW];
-                    sL[idx] = acc;
-                    if (lx >= 2 && lx < TW + 2 && ly >= 2 && ly < TH + 2) lt0[base + (size_t)y * w + x] = acc;
+                        for (int i = 0; i < 5; ++i) acc = acc + t5.k[i] * p[i * HW];
+                        sL[ly * LW + lx] = acc;
+                        if (own_x && ly >= 2 && ly < TH + 2) lt0[base + (size_t)y * w + x] = acc;
+                    }
                 }
             }
             __syncthreads();

@@ -514,7 +514,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     } stream_restore{c, s};
     // Jobs below gates::kTiledPrepPx take the TILED preparation family whatever their launches' sizes -- k_blur, k_contrast_max /
     // _hist, k_prep riding on the previous level's last k_fed_own launch, no resident tail: since that epilogue exists the
-    // chain of few-microsecond launches beats the streaming kernels and k_level_march up to ~8 Mpx per job (profiles/
+    // chain of few-microsecond launches beats the streaming kernels and k_level_march up to ~11 Mpx per job (akz_gates.hpp: kTiledPrepPx; profiles/
     // r06_lone_libm.txt: 2-6 x 1080p, 4-8 x 720p, lone 2-5 Mpx frames 3-9 % faster per call, 0-9 % as a stream).  The helpers
     // read c->prep_mode: it is swapped for the duration of this begin half (only the automatic mode 2 is overridden).
     struct PrepModeRestore {

@@ -30,9 +30,12 @@ constexpr uint64_t kBigPxSync = 1500000;    // akz_extract_*
 constexpr uint64_t kBigPxAsync = 1500000;   // akz_extract_begin_*
 constexpr uint64_t kLanePx = 2400000;       // akz_ctx_set_lanes deals the jobs below this to its lanes (where they run as one-stream chains:
                                             // four lanes carry 1080p frames at 0.34-0.37 ms each, the batch path on one context at 0.44)
-constexpr uint64_t kTiledPrepPx = 8000000;  // jobs below this: the tiled preparation family for every launch (k_blur, k_contrast_max /
-                                            // _hist, k_prep riding on k_fed_own's last launch, no resident tail) whatever the
-                                            // per-launch gates below say (r06_lone_libm.txt)
+constexpr uint64_t kTiledPrepPx = 11000000; // jobs below this: the tiled preparation family for every launch (k_head, k_contrast_hist_final,
+                                            // k_prep riding on k_fed_own's last launch, no resident tail) whatever the per-launch gates
+                                            // below say.  8 Mpx when the family was introduced (r06_lone_libm.txt); after the rest of
+                                            // round 6 (level 0 in two launches, k_fed_own's borders) it is ahead up to 10.4 Mpx --
+                                            // 4 x 1080p 1.51 -> 1.36 ms per call, 5 x 1080p 1.72 -> 1.58, a lone 4K frame 1.38 -> 1.37 --,
+                                            // mixed at 12-17 Mpx and behind from 25 (r06_lone_chain.txt section 19)
 // ---- which kernel family a LAUNCH takes (level w * h * n pixels) ----
 constexpr uint64_t kMarchPx = 8u << 20;     // blur / contrast / detector marches instead of the tiled kernels (also every
                                             // full-resolution launch of a batch-path job, whatever its size)

@@ -386,7 +386,7 @@ class Context:
         _check(lib().akz_ctx_set_candidate_hint(self._h, int(per_image)))
 
     def set_lanes(self, lanes):
-        """Deal jobs below 8 Mpx to `lanes` child contexts in turn (1 = off): the launch chains of consecutive single
+        """Deal jobs below 2.4 Mpx to `lanes` child contexts in turn (1 = off): the launch chains of consecutive single
         frames then overlap on the chip."""
         _check(lib().akz_ctx_set_lanes(self._h, int(lanes)))
 

@@ -3,7 +3,7 @@ Every EvolutionStep plane, keypoint and descriptor byte against the CPU oracle, 
 grid: widths / heights that are not multiples of the 8 x 8 patches or of 4 (scalar global accesses), a single border
 column or row in the last patch, images that are resident from level 1 on (no 2x2 mean in front), several octaves
 inside one launch, batches, the lean plane set, non-default pyramids, and -- in the default mode, where only batches
-of 8 Mpx and more take it -- a 1080p batch at the size the bench runs."""
+of 11 Mpx and more take it -- a 1080p batch at the size the bench runs."""
 import numpy as np
 import pytest
 
@@ -68,40 +68,40 @@ def test_resident_flat_and_noise(rctx, amd, ref):
 
 
 def test_default_mode_1080p_batch_all_planes(ctx, amd, ref):
-    """The bench's shape in the default mode: a 5-frame 1080p batch (10.4 Mpx, above the 8 388 608 px gate: the blur,
+    """The bench's shape in the default mode: a 6-frame 1080p batch (12.4 Mpx, above tiled_prep_px = 11 Mpx: the blur,
     contrast, level and detector marches of the fine octaves, the forked coarse chain and the resident last octave all
-    engage -- four frames are 8 294 400 px and only take the level march); EVERY plane of one frame against the oracle."""
+    engage -- five frames take the tiled preparation family); EVERY plane of one frame against the oracle."""
     import torch
-    frames = np.stack([amd.synth_frame(1920, 1080, 60 + i) for i in range(5)])
+    frames = np.stack([amd.synth_frame(1920, 1080, 60 + i) for i in range(6)])
     ctx.set_profiling(2)  # light: counts launches without moving the batch onto one stream
     ctx.get_profile(reset=True)
     res = ctx.extract_features(torch.from_numpy(frames).cuda())
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(0)
     # octave 0's three diffusing levels went through k_level_march (preparation inside the diffusion launch)
-    assert prof["fused_px"] >= 3 * 5 * 1920 * 1080, prof
+    assert prof["fused_px"] >= 3 * 6 * 1920 * 1080, prof
     assert_same_result(res, ref.extract(frames[2], threads=16), img=2)
     assert_same_result(res, ref.extract(frames[0], threads=16), planes=False, img=0)
 
 
 def test_default_mode_odd_batch_all_planes(ctx, amd, ref):
-    """The default mode on a batch of odd-sized frames above the 8 Mpx threshold (6 x 1501 x 999: dword accesses in
+    """The default mode on a batch of odd-sized frames above the 11 Mpx threshold (8 x 1501 x 999: dword accesses in
     every march kernel, four strips with a narrow last one, octave sizes 750 x 499, 375 x 249, 187 x 124): every plane of
     one frame, keypoints and descriptors of all."""
     import torch
-    frames = np.stack([amd.synth_frame(1501, 999, 80 + i) for i in range(6)])
+    frames = np.stack([amd.synth_frame(1501, 999, 80 + i) for i in range(8)])
     res = ctx.extract_features(torch.from_numpy(frames).cuda())
-    for i in range(6):
+    for i in range(8):
         assert_same_result(res, ref.extract(frames[i], threads=16), planes=(i == 3), img=i)
 
 
 def test_input_ready_batches_run_ahead(ctx, amd, ref):
     """AKZ_INPUT_READY: the level-0 blur and the contrast factor of a large batch run on their own stream, under the
-    kernels of the batch begun before (three different 5-frame 1080p batches, two in flight; the contrast scratch of the
+    kernels of the batch begun before (three different 6-frame 1080p batches, two in flight; the contrast scratch of the
     context is shared by them).  Identical to the same batches without the flag; every plane of one frame and the
     keypoints / descriptors of others against the oracle.  Host frames (the library's own upload) take the same path."""
     import torch
-    batches = [np.stack([amd.synth_frame(1920, 1080, 200 + 5 * b + i) for i in range(5)]) for b in range(3)]
+    batches = [np.stack([amd.synth_frame(1920, 1080, 200 + 6 * b + i) for i in range(6)]) for b in range(3)]
     dev = [torch.from_numpy(b).cuda() for b in batches]
     torch.cuda.synchronize()
     jobs = [ctx.extract_begin(dev[0], input_ready=True), ctx.extract_begin(dev[1], input_ready=True)]
@@ -112,7 +112,7 @@ def test_input_ready_batches_run_ahead(ctx, amd, ref):
     host = [ctx.extract_begin_host(torch.from_numpy(b).pin_memory()) for b in batches[:2]]
     host = [j.finish() for j in host]
     for b in range(3):
-        for i in range(5):
+        for i in range(6):
             assert res[b].keypoints(i).tobytes() == plain[b].keypoints(i).tobytes(), (b, i)
             assert res[b].descriptors(i).tobytes() == plain[b].descriptors(i).tobytes(), (b, i)
             if b < 2:
@@ -125,12 +125,12 @@ def test_input_ready_batches_run_ahead(ctx, amd, ref):
 
 
 def test_small_frames_large_batch_resident_tail_runs_once(ctx, amd, ref):
-    """Small frames in a batch above the 8 Mpx gate (72 x 480x270 = 9.3 Mpx): the resident tail starts at octave 1 (240 x
+    """Small frames in a batch above the 11 Mpx gate (90 x 480x270 = 11.7 Mpx): the resident tail starts at octave 1 (240 x
     135 fits one compute unit), BEFORE the octave the coarse chain would fork at -- the chain then forks where the tail
     starts and the levels behind it are not run a second time as separate launches (round-3 advice): three fused level
     launches + one resident launch, every plane of one frame against the oracle."""
     import torch
-    frames = np.stack([amd.synth_frame(480, 270, 500 + i) for i in range(72)])
+    frames = np.stack([amd.synth_frame(480, 270, 500 + i) for i in range(90)])
     ctx.set_profiling(2)
     ctx.get_profile(reset=True)
     res = ctx.extract_features(torch.from_numpy(frames).cuda())
@@ -143,12 +143,12 @@ def test_small_frames_large_batch_resident_tail_runs_once(ctx, amd, ref):
 
 def test_eager_finish_batches_three_in_flight(amd, ref):
     """akz_ctx_set_eager_finish on a context without lanes: the finish half of every batch runs on the context's own
-    thread while the caller begins the next ones (three 5-frame 1080p batches begun back to back, device and host input,
+    thread while the caller begins the next ones (three 6-frame 1080p batches begun back to back, device and host input,
     every schedule variant); finish() only collects.  Identical to the plain pipelined calls; one frame's planes and
     others' keypoints against the oracle; an abandoned job and a context destroyed with a job in flight do no harm."""
     import torch
     ctx = amd.Context(0, torch.cuda.current_stream().cuda_stream)
-    batches = [np.stack([amd.synth_frame(1920, 1080, 300 + 5 * b + i) for i in range(5)]) for b in range(3)]
+    batches = [np.stack([amd.synth_frame(1920, 1080, 300 + 6 * b + i) for i in range(6)]) for b in range(3)]
     dev = [torch.from_numpy(b).cuda() for b in batches]
     torch.cuda.synchronize()
     ctx.set_eager_finish(False)  # (the default is on)
@@ -161,7 +161,7 @@ def test_eager_finish_batches_three_in_flight(amd, ref):
                 ctx.extract_begin_host(torch.from_numpy(batches[2]).pin_memory())]
         res = [j.finish() for j in jobs]
         for b in range(3):
-            for i in range(5):
+            for i in range(6):
                 assert res[b].keypoints(i).tobytes() == plain[b].keypoints(i).tobytes(), (sched, b, i)
                 assert res[b].descriptors(i).tobytes() == plain[b].descriptors(i).tobytes(), (sched, b, i)
     assert_same_result(res[0], ref.extract(batches[0][1], threads=16), img=1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the pipelined batch path: batches of 1-7 1080p frames (2-14 Mpx: both sides of the 8 Mpx threshold of the march
+"""Soak of the pipelined batch path: batches of 1-7 1080p frames (2-14 Mpx: both sides of the 11 Mpx threshold of the march
 kernels, the fork and the run-ahead stages) from device or pinned host memory, with and without AKZ_INPUT_READY, up to
 three batches in flight, the finish half on the caller's thread or on the context's own (akz_ctx_set_eager_finish), every
 schedule variant of akz_debug_set_schedule; keypoints and descriptors of every frame against the synchronous extraction of that frame alone.

@@ -618,12 +618,16 @@ k_contrast_hist_final(const float* __restrict__ gxp, const float* __restrict__ g
     for (unsigned b = tid; b < nbins; b += NTH) {
         unsigned v = 0;
         for (unsigned c = 0; c < copies; ++c) v += s_hist[c * nbins + b];
-        if (v) atomicAdd(&hist[b], v);
+        if (v) {  // (the RETURNING form: the wave's wait below then covers the add's completion by construction)
+            const unsigned before = atomicAdd(&hist[b], v);
+            asm volatile("" ::"v"(before));
+        }
     }
     // This workgroup's bins have been ADDED (device-scope atomics, performed where all XCDs see them) before its ticket is taken:
     // the wave waits for its outstanding memory operations, the barrier for all waves.  (Not __threadfence(): a device-scope
     // fence on this chip writes the XCD's L2 back -- 16 MB of k_head's planes, by every one of 512 workgroups: 51 us for this
-    // kernel instead of 23.  Nothing but atomics is exchanged here: the bins, the ticket, and the last workgroup's atomic loads.)
+    // kernel instead of 23.  Nothing but atomics is exchanged here: the bins -- added in the returning form, so that the wait
+    // covers them by construction --, the ticket, and the last workgroup's atomic loads.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();

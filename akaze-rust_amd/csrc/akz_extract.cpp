@@ -1857,7 +1857,7 @@ int akz_extract_finish(akz_job* job, akz_result** out) { return extract_finish(j
 // on (gate 0); medians of kReps.  A gate = the smallest size from which the batch path wins at that size and every larger one.
 int akz_ctx_calibrate_gates(akz_ctx* c, uint64_t* sync_px, uint64_t* async_px, double* ms_out) {
     AKZ_TRY(bind(c));
-    static const uint32_t kShapes[5][2] = {{1920, 1080}, {2016, 1512}, {2688, 1512}, {3328, 1872}, {3840, 2160}};
+    static const uint32_t kShapes[5][2] = {{1280, 720}, {1600, 900}, {1920, 1080}, {2688, 1512}, {3840, 2160}};  // (0.9 .. 8.3 Mpx: both sides of the gates)
     constexpr int kReps = 5;
     akz_config cfg;
     akz_config_default(&cfg);
@@ -1925,9 +1925,9 @@ int akz_ctx_calibrate_gates(akz_ctx* c, uint64_t* sync_px, uint64_t* async_px, d
     restore.armed = false;
     c->big_px_sync = gate(0, 1);
     c->big_px_async = gate(2, 3);
-    for (akz_ctx* l : c->lanes) {
-        l->big_px_sync = c->big_px_sync;
-        l->big_px_async = c->big_px_async;
+    for (akz_ctx* l : c->lanes) {  // (a job that is dealt to a lane runs there as a one-stream chain)
+        l->big_px_sync = std::max(c->big_px_sync, c->lane_px);
+        l->big_px_async = std::max(c->big_px_async, c->lane_px);
     }
     if (sync_px) *sync_px = c->big_px_sync;
     if (async_px) *async_px = c->big_px_async;

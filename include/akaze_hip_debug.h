@@ -83,7 +83,7 @@ typedef struct akz_gate {
 } akz_gate;
 int akz_debug_gates(const akz_gate** rows, uint64_t* n);
 /* Re-derives the two JOB gates of this context from timings on the machine at hand instead of the compiled-in values (which
-   were tuned on a 16-core host of one pool): lone synthetic frames of 2.1 / 3.0 / 4.1 / 6.2 / 8.3 Mpx are extracted through
+   were tuned on a 16-core host of one pool): lone synthetic frames of 0.9 / 1.4 / 2.1 / 4.1 / 8.3 Mpx are extracted through
    the synchronous call and through the begin / finish interface (two jobs in flight), each with the batch path forced on
    and off; a gate becomes the smallest size from which the batch path is the faster one at that size and at every larger
    one (the largest size + 1 if it never is).  ~0.2 s, allocates what such jobs allocate; the caller's stream must be idle.

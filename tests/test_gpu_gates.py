@@ -134,7 +134,7 @@ def test_calibrated_job_gates_change_nothing_but_the_gates(ctx, amd):
     before.close()
     try:
         sync_px, async_px, ms = ctx.calibrate_gates()
-        sizes = [1920 * 1080, 2016 * 1512, 2688 * 1512, 3328 * 1872, 3840 * 2160, 3840 * 2160 + 1]
+        sizes = [1280 * 720, 1600 * 900, 1920 * 1080, 2688 * 1512, 3840 * 2160, 3840 * 2160 + 1]
         assert sync_px in sizes and async_px in sizes
         assert all(0.05 < v < 50 for row in ms for v in row), ms
         after = ctx.extract_features(d)

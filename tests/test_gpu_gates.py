@@ -124,6 +124,34 @@ def test_matcher_gates_both_sides(ctx, amd, ref):
         ctx.debug_set_match_chunks(0, 0)
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (1280, 720), (500, 400)])
+def test_lean_jobs_of_the_begin_finish_interface(ctx, amd, ref, w, h):
+    """big_px_async_lean: without AKZ_KEEP_ALL_PLANES a begun job takes the batch path from 0.3 Mpx on (a synchronous call and a
+    job that keeps all planes from 1.5 Mpx): both sides of it, pipelined two deep, against the oracle and against the other paths."""
+    import torch
+    frames = [amd.synth_frame(w, h, 90 + i) for i in range(3)]
+    dev = [torch.from_numpy(f[None]).cuda() for f in frames]
+    torch.cuda.synchronize()
+    jobs = [ctx.extract_begin(dev[0], keep_all_planes=False), ctx.extract_begin(dev[1], keep_all_planes=False)]
+    res = [jobs[0].finish()]
+    jobs.append(ctx.extract_begin(dev[2], keep_all_planes=False))
+    res += [jobs[1].finish(), jobs[2].finish()]
+    for i in range(3):
+        rf = ref.extract(frames[i])
+        kp, rk = res[i].keypoints(0), rf.keypoints()
+        assert len(kp) == len(rk) > 50
+        assert all(np.array_equal(kp[f], rk[f]) for f in ("x", "y", "response", "size", "octave", "class_id", "angle"))
+        assert np.array_equal(res[i].descriptors(0), rf.descriptors())
+        assert float(res[i].contrast(0)) == rf.contrast
+        sync = ctx.extract_features(dev[i], keep_all_planes=False)
+        full = ctx.extract_begin(dev[i]).finish()
+        for other in (sync, full):
+            assert other.keypoints(0).tobytes() == kp.tobytes() and other.descriptors(0).tobytes() == res[i].descriptors(0).tobytes()
+            other.close()
+        rf.close()
+        res[i].close()
+
+
 def test_calibrated_job_gates_change_nothing_but_the_gates(ctx, amd):
     """akz_ctx_calibrate_gates: the two job gates re-derived from timings on this machine -- values among the measured sizes,
     and results before / after identical."""

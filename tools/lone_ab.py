@@ -10,6 +10,7 @@ import akaze_amd as A
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 dev = torch.device("cuda", 0)
 NF = int(os.environ.get("LONE_FRAMES", "1"))  # frames per call (1: a lone frame)
+KEEP = os.environ.get("LEAN", "0") != "1"      # LEAN=1: without Lxx, Lyy, Lxy, Lstep (AKZ_KEEP_ALL_PLANES not set)
 frame = torch.from_numpy(np.stack([A.synth_frame(W, H, i) for i in range(NF)])).to(dev)
 cfg = A.Config()
 st = torch.cuda.Stream(dev)
@@ -28,25 +29,25 @@ def setv(d):
     ctx.debug_set_device_libm(d.get("libm", 1) != 0)  # ("libm=0": angles, cosines and sines from the host's libm; default: on the device where proven)
 def measure():
     for _ in range(10):
-        ctx.extract_begin(frame, cfg).finish().close()
+        ctx.extract_begin(frame, cfg, keep_all_planes=KEEP).finish().close()
     torch.cuda.synchronize()
     reps = 100
     for _ in range(5):
-        ctx.extract_features(frame, cfg).close()
+        ctx.extract_features(frame, cfg, keep_all_planes=KEEP).close()
     t = time.perf_counter()
     for _ in range(reps):
-        ctx.extract_features(frame, cfg).close()          # the synchronous entry point (akz_extract_device_*)
+        ctx.extract_features(frame, cfg, keep_all_planes=KEEP).close()          # the synchronous entry point (akz_extract_device_*)
     lat = (time.perf_counter() - t) / reps
     t = time.perf_counter(); prev = None
     for _ in range(reps):
-        j = ctx.extract_begin(frame, cfg)
+        j = ctx.extract_begin(frame, cfg, keep_all_planes=KEEP)
         if prev is not None: prev.finish().close()
         prev = j
     prev.finish().close()
     thr = (time.perf_counter() - t) / reps
     ts = []
     for _ in range(30):
-        torch.cuda.synchronize(); a = time.perf_counter(); j = ctx.extract_begin(frame, cfg); b = time.perf_counter(); ctx.synchronize(); c = time.perf_counter()
+        torch.cuda.synchronize(); a = time.perf_counter(); j = ctx.extract_begin(frame, cfg, keep_all_planes=KEEP); b = time.perf_counter(); ctx.synchronize(); c = time.perf_counter()
         ts.append((b - a, c - a)); j.finish().close()
     return lat, thr, float(np.median([x for x, _ in ts])), float(np.median([y for _, y in ts]))
 ref = None
@@ -54,7 +55,7 @@ for rnd in range(3):
     for name, d in VARIANTS:
         setv(d)
         lat, thr, hb, gb = measure()
-        r = ctx.extract_begin(frame, cfg).finish()
+        r = ctx.extract_begin(frame, cfg, keep_all_planes=KEEP).finish()
         sig = (r.keypoints(0).tobytes(), r.descriptors(0).tobytes()); r.close()
         ref = ref or sig
         print(f"{NF}x{W}x{H} {name:22s} sync call {lat*1e3:.3f} ms  streamed {thr*1e3:.3f} ms/frame  begin: host {hb*1e3:.3f} ms, GPU idle after {gb*1e3:.3f} ms  same={sig == ref}", flush=True)

@@ -24,10 +24,11 @@ namespace gates {
 // 2 x 720p the two were equal): profiles/r06_job_gates.txt.  Later in round 6 the diffusion kernel stopped paying for the
 // image's border (akz_kernels.hip: k_fed_own) and the fork of the coarse chain began to pay for a lone 1080p frame as well:
 // 0.633 -> 0.617 ms per call, 0.470 -> 0.443 per streamed frame; 1760 x 990: 0.628 -> 0.597 / 0.455 -> 0.426; at 1600 x 900 the two
-// are equal, at 2 x 960 x 540 and 1280 x 720 the one-stream chain is 5-8 % ahead (profiles/r06_lone_chain.txt): 1.5 Mpx.  Two
-// constants remain because akz_ctx_calibrate_gates measures both.
-constexpr uint64_t kBigPxSync = 1500000;    // akz_extract_*
-constexpr uint64_t kBigPxAsync = 1500000;   // akz_extract_begin_*
+// are equal with all planes kept and the batch path 3-5 % ahead without, at 2 x 960 x 540 and 1280 x 720 the one-stream chain is
+// 5-8 % ahead (profiles/r06_lone_chain.txt sections 12, 22): 1.4 Mpx.  Two constants remain because akz_ctx_calibrate_gates
+// measures both.
+constexpr uint64_t kBigPxSync = 1400000;    // akz_extract_*
+constexpr uint64_t kBigPxAsync = 1400000;   // akz_extract_begin_*
 constexpr uint64_t kBigPxAsyncLean = 300000; // ... without AKZ_KEEP_ALL_PLANES: a stream of lean jobs is ahead on the batch path at every size
                                             // measured (640 x 480: 0.321 -> 0.301 ms per frame, 1280 x 720: 0.360 -> 0.325, 1600 x 900: 0.398 ->
                                             // 0.364; with all planes kept the one-stream chain is ahead below 1.5 Mpx; r06_lone_chain.txt 22)

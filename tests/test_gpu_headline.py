@@ -89,13 +89,13 @@ def test_pair_4k_host_batch_then_match_features(ctx, amd, ref):
     rp.close()
 
 
-@pytest.mark.parametrize("w,h,n", [(2016, 1512, 1), (1920, 1080, 2), (1920, 1080, 3), (3840, 2160, 1), (1600, 1200, 1), (1440, 1000, 1),
+@pytest.mark.parametrize("w,h,n", [(2016, 1512, 1), (1920, 1080, 2), (1920, 1080, 3), (3840, 2160, 1), (1600, 1200, 1), (1366, 768, 1),
                                    (1920, 1080, 6)])
 def test_job_size_gates_both_entry_points(ctx, amd, ref, w, h, n):
-    """Jobs either side of the job gates (csrc/akz_gates.hpp: big_px_sync / big_px_async, 1.5 Mpx since the end of round 6;
+    """Jobs either side of the job gates (csrc/akz_gates.hpp: big_px_sync / big_px_async, 1.4 Mpx since the end of round 6;
     tiled_prep_px 11 Mpx) through BOTH entry points: the batch path -- forked coarse chain, marches and resident tail where the
-    size allows -- from 1.5 Mpx, the tiled preparation family below 11 Mpx (a lone 4K frame), the march family above (6 x 1080p);
-    1440 x 1000 (1.44 Mpx) stays on the one-stream chain either way.  Both must equal the oracle, planes included (lib.rs:167-194)."""
+    size allows -- from 1.4 Mpx, the tiled preparation family below 11 Mpx (a lone 4K frame), the march family above (6 x 1080p);
+    1366 x 768 (1.05 Mpx) stays on the one-stream chain either way.  Both must equal the oracle, planes included (lib.rs:167-194)."""
     import torch
     frames = np.stack([amd.synth_frame(w, h, 40 + i) for i in range(n)])
     d = torch.from_numpy(frames).cuda()

@@ -445,12 +445,10 @@ int akz_debug_set_schedule(akz_ctx* c, int key, int value) {
     if (key == 4) {
         c->big_px_sync = value > 0 ? (uint64_t)value * 1000u : gates::kBigPxSync;
         c->big_px_async = value > 0 ? (uint64_t)value * 1000u : gates::kBigPxAsync;
-        c->big_px_async_lean = value > 0 ? (uint64_t)value * 1000u : gates::kBigPxAsyncLean;
         c->lane_px = value > 0 ? (uint64_t)value * 1000u : gates::kLanePx;
         for (akz_ctx* l : c->lanes) {  // (a job that is dealt to a lane runs there as a one-stream chain)
             l->big_px_sync = std::max(c->big_px_sync, c->lane_px);
             l->big_px_async = std::max(c->big_px_async, c->lane_px);
-            l->big_px_async_lean = std::max(c->big_px_async_lean, c->lane_px);
         }
     }
     return AKZ_OK;

@@ -177,7 +177,6 @@ struct akz_ctx {
     int sched[11] = {0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t big_px = gates::kBigPxAsync;  // the gate of the job being begun (set by extract_begin from the two below; the begin half's helpers read it)
     uint64_t big_px_sync = gates::kBigPxSync, big_px_async = gates::kBigPxAsync;  // (sched[4] sets both: measurement)
-    uint64_t big_px_async_lean = gates::kBigPxAsyncLean;  // (jobs of the begin / finish interface that do not keep all planes)
     uint64_t lane_px = gates::kLanePx;  // jobs below it go to the lanes, if the context has any (sched[4] sets it too)
     // pixels per LAUNCH (level w*h*n) from which the blur, the contrast passes and the detectors take their column-march
     // form: 8 Mpx (a 32 x 480x270 level: 41 us tiled against 66 for the march, which would run one strip per image row);

@@ -362,7 +362,7 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
     if (!out) return AKZ_ERR_INVALID_ARG;
     *out = nullptr;
     AKZ_TRY(bind(c, true, c && c->is_lane));  // (a lane's finish half shares the lane's one stream: begin waits for it)
-    c->big_px = sync_call ? c->big_px_sync : ((flags & AKZ_KEEP_ALL_PLANES) ? c->big_px_async : c->big_px_async_lean);  // (akz_gates.hpp)
+    c->big_px = sync_call ? c->big_px_sync : c->big_px_async;  // (akz_gates.hpp)
     struct GateRestore {  // the per-op entry points (akz_op_*) use the same helpers: they see the begin / finish interface's gate
         akz_ctx* c;
         ~GateRestore() {
@@ -1769,7 +1769,6 @@ int akz_ctx_set_lanes(akz_ctx* c, uint32_t lanes) {
         l->stream_min_px = c->stream_min_px;
         l->big_px_sync = std::max(c->big_px_sync, c->lane_px);  // (a job that is dealt to a lane runs there as a one-stream chain)
         l->big_px_async = std::max(c->big_px_async, c->lane_px);
-        l->big_px_async_lean = std::max(c->big_px_async_lean, c->lane_px);
         l->host_threads = c->host_threads;
         l->profiling = c->profiling;
         l->dbg_pair_chunks = c->dbg_pair_chunks;
@@ -1862,13 +1861,13 @@ int akz_ctx_calibrate_gates(akz_ctx* c, uint64_t* sync_px, uint64_t* async_px, d
     constexpr int kReps = 5;
     akz_config cfg;
     akz_config_default(&cfg);
-    const uint64_t keep_sync = c->big_px_sync, keep_async = c->big_px_async, keep_lean = c->big_px_async_lean;
+    const uint64_t keep_sync = c->big_px_sync, keep_async = c->big_px_async;
     struct Restore {
         akz_ctx* c;
-        uint64_t s, a, l;
+        uint64_t s, a;
         bool armed = true;
-        ~Restore() { if (armed) { c->big_px_sync = s; c->big_px_async = a; c->big_px_async_lean = l; } }
-    } restore{c, keep_sync, keep_async, keep_lean};
+        ~Restore() { if (armed) { c->big_px_sync = s; c->big_px_async = a; } }
+    } restore{c, keep_sync, keep_async};
     double ms[5][4];
     auto median = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     for (int si = 0; si < 5; ++si) {
@@ -1880,7 +1879,7 @@ int akz_ctx_calibrate_gates(akz_ctx* c, uint64_t* sync_px, uint64_t* async_px, d
         struct Free { akz_ctx* c; void* d; ~Free() { (void)akz_device_free(c, d); } } fr{c, d};
         AKZ_TRY(akz_memcpy_h2d(c, d, frame.data(), frame.size()));
         for (int path = 0; path < 2; ++path) {
-            c->big_px_sync = c->big_px_async = c->big_px_async_lean = path ? 0 : ~0ull;
+            c->big_px_sync = c->big_px_async = path ? 0 : ~0ull;
             // synchronous call
             std::vector<double> t;
             for (int r = 0; r < kReps + 1; ++r) {
@@ -1926,11 +1925,9 @@ int akz_ctx_calibrate_gates(akz_ctx* c, uint64_t* sync_px, uint64_t* async_px, d
     restore.armed = false;
     c->big_px_sync = gate(0, 1);
     c->big_px_async = gate(2, 3);
-    c->big_px_async_lean = std::min(keep_lean, c->big_px_async);  // (measured without AKZ_KEEP_ALL_PLANES: it bounds the lean gate too)
     for (akz_ctx* l : c->lanes) {  // (a job that is dealt to a lane runs there as a one-stream chain)
         l->big_px_sync = std::max(c->big_px_sync, c->lane_px);
         l->big_px_async = std::max(c->big_px_async, c->lane_px);
-        l->big_px_async_lean = std::max(c->big_px_async_lean, c->lane_px);
     }
     if (sync_px) *sync_px = c->big_px_sync;
     if (async_px) *async_px = c->big_px_async;

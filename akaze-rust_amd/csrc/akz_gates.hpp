@@ -28,10 +28,10 @@ namespace gates {
 // 5-8 % ahead (profiles/r06_lone_chain.txt sections 12, 22): 1.4 Mpx.  Two constants remain because akz_ctx_calibrate_gates
 // measures both.
 constexpr uint64_t kBigPxSync = 1400000;    // akz_extract_*
-constexpr uint64_t kBigPxAsync = 1400000;   // akz_extract_begin_*
-constexpr uint64_t kBigPxAsyncLean = 300000; // ... without AKZ_KEEP_ALL_PLANES: a stream of lean jobs is ahead on the batch path at every size
-                                            // measured (640 x 480: 0.321 -> 0.301 ms per frame, 1280 x 720: 0.360 -> 0.325, 1600 x 900: 0.398 ->
-                                            // 0.364; with all planes kept the one-stream chain is ahead below 1.5 Mpx; r06_lone_chain.txt 22)
+constexpr uint64_t kBigPxAsync = 300000;    // akz_extract_begin_*: a STREAM of jobs is ahead on the batch path from VGA frames on, with all planes
+                                            // kept or without (640 x 480: 0.324 -> 0.305 ms per frame, 1280 x 720: 0.365 -> 0.332, 1600 x 900:
+                                            // 0.41 -> 0.37; 480 x 360: 0.216 against 0.299 the other way) -- since the detector march of a job of few
+                                            // strip columns is cut into 24-row bands (akz_march.hip); r06_lone_chain.txt sections 22-24
 constexpr uint64_t kLanePx = 2400000;       // akz_ctx_set_lanes deals the jobs below this to its lanes (where they run as one-stream chains:
                                             // four lanes carry 1080p frames at 0.34-0.37 ms each, the batch path on one context at 0.44)
 constexpr uint64_t kTiledPrepPx = 11000000; // jobs below this: the tiled preparation family for every launch (k_head, k_contrast_hist_final,
@@ -59,8 +59,7 @@ constexpr uint32_t kPremergeChunks = 4;             // more train chunks than th
 inline const akz_gate* table(size_t* n) {
     static const akz_gate rows[] = {
         {"big_px_sync", (double)kBigPxSync, "input px per job", "synchronous akz_extract_*: the chain of tiled launches on one stream below, the batch path (forked coarse chain; marches and resident tail where tiled_prep_px and the per-launch gates allow) from here on"},
-        {"big_px_async", (double)kBigPxAsync, "input px per job", "akz_extract_begin_*: the same choice for a job of the begin / finish interface that keeps all planes"},
-        {"big_px_async_lean", (double)kBigPxAsyncLean, "input px per job", "akz_extract_begin_* without AKZ_KEEP_ALL_PLANES: the batch path from here on"},
+        {"big_px_async", (double)kBigPxAsync, "input px per job", "akz_extract_begin_*: the same choice for a job of the begin / finish interface (a stream of jobs overlaps the two chains of consecutive jobs: the batch path pays from much smaller jobs on than for a call that is waited for)"},
         {"lane_px", (double)kLanePx, "input px per job", "a context with lanes (akz_ctx_set_lanes) deals the jobs below this to them, as one-stream chains; larger jobs stay on the context"},
         {"tiled_prep_px", (double)kTiledPrepPx, "input px per job", "below: the tiled preparation family for every launch of the job (level-0 blur, contrast passes, k_prep as an epilogue of the previous level's last k_fed_own launch, no resident tail); from here on the per-launch gates below decide"},
         {"march_px", (double)kMarchPx, "level px per launch", "k_blur5_march / k_contrast_march / k_detector_march instead of the tiled kernels (batch-path jobs: their full-resolution launches regardless)"},

@@ -33,8 +33,8 @@ int akz_debug_set_match_chunks(akz_ctx* ctx, uint32_t pair_chunks, uint32_t set_
    stream of their own (a fifth busy stream), 3 = the context's stream (no running ahead); key 1: they are held back until
    the batch before has finished its fine-level diffusion (1, default) or start at once (0); key 2: 1 = no placement probe;
    key 3: octave at which the coarse chain forks (0 = default 2); key 4: the job size in thousands of pixels (w*h*n) from
-   which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (1 400 for both entry points since the end of round 6, 6 000 / 3 000 in round 5; 300 for begun jobs that
-   do not keep all planes; the same value also replaces lane_px, the size below which a context with lanes deals its jobs to them);
+   which a job takes the batch path -- column-march kernels, forked coarse chain, resident tail -- 0 = default (1 400 for the synchronous entry points, 300 for the begin / finish interface since the end of round 6;
+   6 000 / 3 000 in round 5; the same value also replaces lane_px, the size below which a context with lanes deals its jobs to them);
    key 5: 1 = the detector of a fine level right behind its level kernel (profiles/r06_interleave.txt: measured, not the default);
    key 6: 1 = every level's preparation as a launch of its own (default 0: on the tiled path the last diffusion launch of a level
    also prepares the next level of the octave -- k_fed_own's epilogue);

@@ -126,8 +126,8 @@ def test_matcher_gates_both_sides(ctx, amd, ref):
 
 @pytest.mark.parametrize("w,h", [(640, 480), (1280, 720), (500, 400)])
 def test_lean_jobs_of_the_begin_finish_interface(ctx, amd, ref, w, h):
-    """big_px_async_lean: without AKZ_KEEP_ALL_PLANES a begun job takes the batch path from 0.3 Mpx on (a synchronous call and a
-    job that keeps all planes from 1.4 Mpx): both sides of it, pipelined two deep, against the oracle and against the other paths."""
+    """big_px_async: a begun job takes the batch path from 0.3 Mpx on (a synchronous call from 1.4 Mpx): both sides of it, lean
+    planes, pipelined two deep, against the oracle and against the other entry point / plane set."""
     import torch
     frames = [amd.synth_frame(w, h, 90 + i) for i in range(3)]
     dev = [torch.from_numpy(f[None]).cuda() for f in frames]

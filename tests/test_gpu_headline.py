@@ -95,7 +95,7 @@ def test_job_size_gates_both_entry_points(ctx, amd, ref, w, h, n):
     """Jobs either side of the job gates (csrc/akz_gates.hpp: big_px_sync / big_px_async, 1.4 Mpx since the end of round 6;
     tiled_prep_px 11 Mpx) through BOTH entry points: the batch path -- forked coarse chain, marches and resident tail where the
     size allows -- from 1.4 Mpx, the tiled preparation family below 11 Mpx (a lone 4K frame), the march family above (6 x 1080p);
-    1366 x 768 (1.05 Mpx) stays on the one-stream chain either way.  Both must equal the oracle, planes included (lib.rs:167-194)."""
+    1366 x 768 (1.05 Mpx) is a one-stream chain as a call and a batch-path job when begun (big_px_async: 0.3 Mpx).  Both must equal the oracle, planes included (lib.rs:167-194)."""
     import torch
     frames = np.stack([amd.synth_frame(w, h, 40 + i) for i in range(n)])
     d = torch.from_numpy(frames).cuda()

@@ -398,7 +398,7 @@ AKZ_LOCAL int gaussian_blur_impl(akz_ctx* c, const T* d_in, float* d_out, uint32
 // level 0 of a small job in two launches (k_head, k_contrast_hist_final); *fused = false: not this job (the separate stages follow)
 template <typename T>
 AKZ_LOCAL int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, float* d_blurred, float* d_gx, float* d_gy, uint32_t w, uint32_t h, uint32_t n,
-                        float sigma0, double percentile, double gscale, uint64_t nbins, double* d_k_out, bool* fused);
+                        float sigma0, double percentile, double gscale, uint64_t nbins, double* d_k_out, bool* fused, uint32_t* d_zero_word = nullptr);
 AKZ_LOCAL int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile, double gscale, uint64_t nbins,
                   double* d_k_out);
 AKZ_LOCAL uint32_t fed_max_fuse(const akz_ctx* c, uint32_t w, uint32_t h, uint32_t n);

@@ -548,16 +548,17 @@ static int extract_begin(akz_ctx* c, const T* d_imgs, uint32_t w, uint32_t h, ui
         c->stream = ps;
         early = true;
     }
-    // the job's candidate counter is cleared on the stream of its first stage (every detector launch comes behind that)
-    AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
+    // the job's candidate counter is cleared on the stream of its first stage (every detector launch comes behind that):
+    // by that stage's kernel itself where it is k_head, by a fill otherwise
     // (a small job: both stages in two launches -- akz_ops.cpp: head_impl; level 1, where it continues the octave, finds its Lsmooth
     // written -- the contrast factor's blur of Lt0 is the same image -- and the Scharr pair of it in level 0's Lx / Ly planes)
     bool head_fused = false;
     const bool level1_clone = L > 1 && plan[1].octave == plan[0].octave && plan[1].w == w && plan[1].h == h;
     AKZ_TRY(head_impl<T>(c, d_imgs, P(0, AKZ_LT), level1_clone ? P(1, AKZ_LSMOOTH) : nullptr, P(0, AKZ_LX), P(0, AKZ_LY), w, h, n,
-                         (float)cfg.base_scale_offset, cfg.contrast_percentile, 1.0, cfg.contrast_factor_num_bins, r->d_k, &head_fused));
+                         (float)cfg.base_scale_offset, cfg.contrast_percentile, 1.0, cfg.contrast_factor_num_bins, r->d_k, &head_fused, d_count));
     const bool head_level1 = head_fused && level1_clone;
     if (!head_fused) {
+        AKZ_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
         {
             StageTimer st(c, AKZ_ST_BLUR0);
             AKZ_TRY(gaussian_blur_impl<T>(c, d_imgs, P(0, AKZ_LT), w, h, n, (float)cfg.base_scale_offset));

@@ -226,10 +226,11 @@ void detector_march(hipStream_t s, const float* lsmooth, uint32_t sigma, float* 
                     float border_m, Candidate* d_cand, uint32_t cap, uint32_t* d_count);
 // level preparation + the first n_steps <= 4 diffusion steps of a level in one launch (akz_march.hip, k_level_march)
 bool head_fused_supported(uint32_t w, uint32_t h, uint32_t ntaps0, uint32_t ntaps1);
+// (d_zero_word: a 32-bit word the kernel clears -- the job's candidate counter -- or NULL)
 void head_fused_u8(hipStream_t s, const uint8_t* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
-                   const float* k5, const float* g3, unsigned long long* d_smax_bits);
+                   const float* k5, const float* g3, unsigned long long* d_smax_bits, uint32_t* d_zero_word = nullptr);
 void head_fused_f32(hipStream_t s, const float* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
-                    const float* k5, const float* g3, unsigned long long* d_smax_bits);
+                    const float* k5, const float* g3, unsigned long long* d_smax_bits, uint32_t* d_zero_word = nullptr);
 // the histogram + percentile pass over the stored Scharr pair (gx, gy: k_head's), and Lflow = pm_g2 of the same pair
 void contrast_hist_final(hipStream_t s, const float* gx, const float* gy, uint32_t w, uint32_t h, uint32_t n, unsigned long long* d_smax_bits,
                          uint32_t nbins, uint32_t* d_hist, uint32_t* d_done, double percentile, double* d_k);

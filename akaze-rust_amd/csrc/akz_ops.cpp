@@ -85,7 +85,7 @@ static int scharr_impl(akz_ctx* c, const float* d_in, float* d_out, uint32_t w, 
 // sched[10] = 1: the separate stages (measurement).
 template <typename T>
 int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, float* d_blurred, float* d_gx, float* d_gy, uint32_t w, uint32_t h, uint32_t n, float sigma0,
-              double percentile, double gscale, uint64_t nbins, double* d_k_out, bool* fused) {
+              double percentile, double gscale, uint64_t nbins, double* d_k_out, bool* fused, uint32_t* d_zero_word) {
     *fused = false;
     if (c->prep_mode != 0 || c->sched[10] != 0 || !(sigma0 > 0.0f) || !(gscale > 0.0) || nbins == 0 || nbins > 4096) return AKZ_OK;
     const size_t ks0 = gaussian_kernel_size(sigma0), ks1 = gaussian_kernel_size((float)gscale);
@@ -108,9 +108,9 @@ int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, float* d_blurred, float* 
     {
         StageTimer st(c, AKZ_ST_BLUR0);
         if constexpr (std::is_same<T, uint8_t>::value)
-            launch::head_fused_u8(c->stream, d_in, d_lt0, blurred, d_gx, d_gy, w, h, n, k5.data(), g3.data(), d_smax);
+            launch::head_fused_u8(c->stream, d_in, d_lt0, blurred, d_gx, d_gy, w, h, n, k5.data(), g3.data(), d_smax, d_zero_word);
         else
-            launch::head_fused_f32(c->stream, d_in, d_lt0, blurred, d_gx, d_gy, w, h, n, k5.data(), g3.data(), d_smax);
+            launch::head_fused_f32(c->stream, d_in, d_lt0, blurred, d_gx, d_gy, w, h, n, k5.data(), g3.data(), d_smax, d_zero_word);
     }
     {
         StageTimer st(c, AKZ_ST_CONTRAST);
@@ -122,8 +122,8 @@ int head_impl(akz_ctx* c, const T* d_in, float* d_lt0, float* d_blurred, float* 
     *fused = true;
     return AKZ_OK;
 }
-template int head_impl<float>(akz_ctx*, const float*, float*, float*, float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
-template int head_impl<uint8_t>(akz_ctx*, const uint8_t*, float*, float*, float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*);
+template int head_impl<float>(akz_ctx*, const float*, float*, float*, float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*, uint32_t*);
+template int head_impl<uint8_t>(akz_ctx*, const uint8_t*, float*, float*, float*, float*, uint32_t, uint32_t, uint32_t, float, double, double, uint64_t, double*, bool*, uint32_t*);
 
 int contrast_impl(akz_ctx* c, const float* d_in, uint32_t w, uint32_t h, uint32_t n, double percentile,
                          double gscale, uint64_t nbins, double* d_k_out) {

@@ -247,7 +247,7 @@ k_prep(const float* __restrict__ prev, float* __restrict__ lt_out, float* __rest
 template <typename T>
 __global__ void __launch_bounds__(NT)
 k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ blurred, float* __restrict__ gx_out, float* __restrict__ gy_out,
-       int w, int h, TileGrid tg, DenseTaps t5, PrepTaps t3, unsigned long long* __restrict__ d_smax_bits) {
+       int w, int h, TileGrid tg, DenseTaps t5, PrepTaps t3, unsigned long long* __restrict__ d_smax_bits, unsigned* __restrict__ zero_word) {
     constexpr int IW = TW + 8, IH = TH + 8;  // frame,  origin (x0-4, y0-4)
     constexpr int HW = TW + 4, HH = TH + 8;  // H pass, origin (x0-2, y0-4)
     constexpr int LW = TW + 4, LH = TH + 4;  // Lt0,    origin (x0-2, y0-2)
@@ -259,6 +259,7 @@ k_head(const T* __restrict__ in, float* __restrict__ lt0, float* __restrict__ bl
     __shared__ unsigned long long s_part[NT / 64];
     const int tid = threadIdx.x;
     const int ntiles = tg.tx * tg.ty * tg.n;
+    if (zero_word && blockIdx.x == 0 && tid == 0) *zero_word = 0u;  // (the job's candidate counter: its first user is a later launch)
     float regs[NLOAD];
     auto issue = [&](int tile) {
         const Tile tl = decode_tile(tile, tg, w, h);
@@ -1071,21 +1072,21 @@ bool head_fused_supported(uint32_t w, uint32_t h, uint32_t ntaps0, uint32_t ntap
 // d_smax_bits must be zero before (the histogram pass leaves it so)
 template <typename T>
 static void head_fused_t(hipStream_t s, const T* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
-                         const float* k5, const float* g3, unsigned long long* d_smax_bits) {
+                         const float* k5, const float* g3, unsigned long long* d_smax_bits, uint32_t* d_zero_word) {
     DenseTaps t;
     for (uint32_t i = 0; i < (uint32_t)kMaxTaps; ++i) t.k[i] = i < 5 ? k5[i] : 0.0f;
     const Taps m = taps_scharr_main(1);
     const Launch l = plan_tiles(w, h, n);
     hipLaunchKernelGGL((k_head<T>), l.grid, dim3(NT), 0, s, in, lt0, blurred, gx, gy, (int)w, (int)h, l.tg, t,
-                       PrepTaps{g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1]}, d_smax_bits);
+                       PrepTaps{g3[0], g3[1], g3[2], m.wgt[0], m.wgt[1]}, d_smax_bits, d_zero_word);
 }
 void head_fused_u8(hipStream_t s, const uint8_t* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
-                   const float* k5, const float* g3, unsigned long long* d_smax_bits) {
-    head_fused_t<uint8_t>(s, in, lt0, blurred, gx, gy, w, h, n, k5, g3, d_smax_bits);
+                   const float* k5, const float* g3, unsigned long long* d_smax_bits, uint32_t* d_zero_word) {
+    head_fused_t<uint8_t>(s, in, lt0, blurred, gx, gy, w, h, n, k5, g3, d_smax_bits, d_zero_word);
 }
 void head_fused_f32(hipStream_t s, const float* in, float* lt0, float* blurred, float* gx, float* gy, uint32_t w, uint32_t h, uint32_t n,
-                    const float* k5, const float* g3, unsigned long long* d_smax_bits) {
-    head_fused_t<float>(s, in, lt0, blurred, gx, gy, w, h, n, k5, g3, d_smax_bits);
+                    const float* k5, const float* g3, unsigned long long* d_smax_bits, uint32_t* d_zero_word) {
+    head_fused_t<float>(s, in, lt0, blurred, gx, gy, w, h, n, k5, g3, d_smax_bits, d_zero_word);
 }
 
 bool detector_fused_supported(uint32_t sigma) { return sigma >= 1 && sigma <= 6; }
